@@ -342,6 +342,7 @@ class MjbModel:
     arrays: Dict[str, np.ndarray]
     names: Dict[str, List[str]] = field(default_factory=dict)
     model_name: str = ""
+    stat: Dict[str, object] = field(default_factory=dict)
 
     def __getattr__(self, key):
         d = self.__dict__
@@ -390,6 +391,13 @@ def parse_mjb(blob: bytes) -> MjbModel:
     base = len(blob) - nbuffer
     if base < off:
         raise MjbError("nbuffer larger than the file")
+    # mjStatistic {meaninertia, meanmass, meansize, extent, center[3]} closes the fixed-size
+    # blocks, immediately before the array buffer (mjVisual sits between mjOption and it).
+    if base - off < 56:
+        raise MjbError("no room for mjVisual/mjStatistic before the array buffer")
+    st = struct.unpack_from("<7d", blob, base - 56)
+    stat = {"meaninertia": st[0], "meanmass": st[1], "meansize": st[2], "extent": st[3],
+            "center": list(st[4:7])}
     arrays: Dict[str, np.ndarray] = {}
     pos = 0
     for line in _SPEC.strip().splitlines():
@@ -418,4 +426,4 @@ def parse_mjb(blob: bytes) -> MjbModel:
         adrs = arrays[f"name_{kind}adr"]
         names[kind] = [_name_at(int(a)) for a in adrs]
     # MuJoCo 2.1 stores no separate model-name entry: body 0 ("world") starts at offset 0.
-    return MjbModel(sizes=sizes, opt=opt, arrays=arrays, names=names, model_name="")
+    return MjbModel(sizes=sizes, opt=opt, arrays=arrays, names=names, model_name="", stat=stat)

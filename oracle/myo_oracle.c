@@ -1,0 +1,1342 @@
+/* myo_oracle.c — TEST INFRASTRUCTURE (see myo_oracle.h for the parity status).
+ *
+ * Scalar fp64 restatement of MuJoCo 2.1's mj_step pipeline for the feature subset the
+ * MyoSuite muscle-tendon models use, plus MyoSuite's Baoding task step.  Written from the
+ * published algorithm; the code the reference actually runs lives in
+ * un-vendored third-party packages (MuJoCo 2.1.x via free-mujoco-py==2.1.6, MyoSuite==1.2.3;
+ * /root/reference/requirements.txt:41,81).  Stage names follow SURVEY.md §8a P1-P12.
+ */
+#include "myo_oracle.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/myo_model_blob.h"
+
+#define MINVAL 1e-15
+#define MINIMP 0.0001
+#define MAXIMP 0.9999
+#define MAXCON 64
+#define MAXEFC 320
+#define LS_ITER 50
+#define LS_TOL 0.01
+
+struct OrcModel {
+  void* blob;
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair;
+  int integrator, cone, iterations, disableflags;
+  double timestep, tolerance, impratio, gravity[3], o_margin, meaninertia;
+  const int *body_parentid, *body_rootid, *body_weldid, *body_jntnum, *body_jntadr, *body_dofnum,
+      *body_dofadr, *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited, *dof_bodyid,
+      *dof_jntid, *dof_parentid, *geom_type, *geom_condim, *geom_bodyid, *geom_priority,
+      *site_bodyid, *tendon_adr, *tendon_num, *tendon_limited, *wrap_type, *wrap_objid,
+      *actuator_trntype, *actuator_dyntype, *actuator_gaintype, *actuator_biastype,
+      *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *pair_geom1, *pair_geom2;
+  const double *qpos0, *qpos_spring, *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass,
+      *body_inertia, *body_invweight0, *jnt_solref, *jnt_solimp, *jnt_pos, *jnt_axis,
+      *jnt_stiffness, *jnt_range, *jnt_margin, *dof_armature, *dof_damping, *dof_invweight0,
+      *geom_solmix, *geom_solref, *geom_solimp, *geom_size, *geom_rbound, *geom_pos, *geom_quat,
+      *geom_friction, *geom_margin, *geom_gap, *site_pos, *tendon_solref_lim, *tendon_solimp_lim,
+      *tendon_range, *tendon_margin, *tendon_stiffness, *tendon_damping, *tendon_lengthspring,
+      *tendon_invweight0, *wrap_prm, *actuator_dynprm, *actuator_gainprm, *actuator_biasprm,
+      *actuator_ctrlrange, *actuator_forcerange, *actuator_gear, *actuator_acc0,
+      *actuator_lengthrange;
+};
+
+typedef struct {
+  double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5];
+  int geom1, geom2;
+} OrcContact;
+
+typedef struct { const char* name; double* p; int n; } OrcField;
+
+struct OrcData {
+  const OrcModel* m;
+  double time;
+  int ncon, nefc, solver_iter, bad, nl, ntl;
+  /* state */
+  double *qpos, *qvel, *act, *ctrl, *qacc_warmstart;
+  /* per-env model overrides (P2 randomisation, reference baoding.py:559-604) */
+  double *body_mass, *geom_friction, *geom_size, *site_pos;
+  /* position stage */
+  double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat,
+      *site_xpos, *subtree_com, *cinert, *cdof, *crb, *ten_length, *ten_J, *actuator_length,
+      *actuator_moment, *M, *Mchol;
+  /* velocity stage */
+  double *ten_velocity, *actuator_velocity, *cvel, *cdof_dot, *qfrc_passive, *qfrc_bias;
+  /* actuation / acceleration */
+  double *act_dot, *actuator_force, *qfrc_actuator, *qfrc_smooth, *qacc_smooth, *qacc,
+      *qfrc_constraint;
+  /* constraints */
+  OrcContact con[MAXCON];
+  double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_vel, *efc_force,
+      *efc_diagApprox, *efc_KBIP;
+  int efc_type[MAXEFC], efc_id[MAXEFC];
+  /* scratch */
+  double *w1, *w2, *w3, *w4, *w5, *H, *cacc, *cfrc;
+  OrcField fields[64];
+  int nfields;
+};
+
+/* ------------------------------------------------------------------ small vector math */
+static double dot3(const double* a, const double* b) { return a[0]*b[0]+a[1]*b[1]+a[2]*b[2]; }
+static void cross3(double* r, const double* a, const double* b) {
+  double x = a[1]*b[2]-a[2]*b[1], y = a[2]*b[0]-a[0]*b[2], z = a[0]*b[1]-a[1]*b[0];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+static double norm3(const double* a) { return sqrt(dot3(a,a)); }
+static double normalize3(double* a) {
+  double n = norm3(a);
+  if (n < MINVAL) { a[0]=1; a[1]=0; a[2]=0; } else { a[0]/=n; a[1]/=n; a[2]/=n; }
+  return n;
+}
+static void mulmatvec3(double* r, const double* R, const double* v) {
+  double x=R[0]*v[0]+R[1]*v[1]+R[2]*v[2], y=R[3]*v[0]+R[4]*v[1]+R[5]*v[2], z=R[6]*v[0]+R[7]*v[1]+R[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+static void mulmatTvec3(double* r, const double* R, const double* v) {
+  double x=R[0]*v[0]+R[3]*v[1]+R[6]*v[2], y=R[1]*v[0]+R[4]*v[1]+R[7]*v[2], z=R[2]*v[0]+R[5]*v[1]+R[8]*v[2];
+  r[0]=x; r[1]=y; r[2]=z;
+}
+static void quat2mat(double* R, const double* q) {
+  double w=q[0],x=q[1],y=q[2],z=q[3];
+  R[0]=w*w+x*x-y*y-z*z; R[1]=2*(x*y-w*z); R[2]=2*(x*z+w*y);
+  R[3]=2*(x*y+w*z); R[4]=w*w-x*x+y*y-z*z; R[5]=2*(y*z-w*x);
+  R[6]=2*(x*z-w*y); R[7]=2*(y*z+w*x); R[8]=w*w-x*x-y*y+z*z;
+}
+static void mulquat(double* r, const double* a, const double* b) {
+  double t[4] = { a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3], a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2],
+                  a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1], a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0] };
+  memcpy(r, t, sizeof t);
+}
+static void normalize4(double* q) {
+  double n = sqrt(q[0]*q[0]+q[1]*q[1]+q[2]*q[2]+q[3]*q[3]);
+  if (n < MINVAL) { q[0]=1; q[1]=q[2]=q[3]=0; } else { q[0]/=n; q[1]/=n; q[2]/=n; q[3]/=n; }
+}
+static void axisangle2quat(double* q, const double* axis, double angle) {
+  double s = sin(angle*0.5);
+  q[0]=cos(angle*0.5); q[1]=axis[0]*s; q[2]=axis[1]*s; q[3]=axis[2]*s;
+}
+
+/* ------------------------------------------------------------------ blob parsing */
+static const myo_blob_field* blob_find(const void* blob, const char* name) {
+  const myo_blob_header* h = (const myo_blob_header*)blob;
+  const myo_blob_field* f = (const myo_blob_field*)((const char*)blob + sizeof(myo_blob_header));
+  for (uint32_t i = 0; i < h->n_fields; ++i)
+    if (strncmp(f[i].name, name, MYO_BLOB_NAME_LEN) == 0) return &f[i];
+  return NULL;
+}
+
+OrcModel* orc_model_from_blob(const void* src, size_t nbytes, char* err, int errlen) {
+  const myo_blob_header* h = (const myo_blob_header*)src;
+  if (nbytes < sizeof *h || h->magic != MYO_BLOB_MAGIC || h->version != MYO_BLOB_VERSION ||
+      h->total_bytes != nbytes) {
+    if (err) snprintf(err, errlen, "bad model blob header");
+    return NULL;
+  }
+  OrcModel* m = (OrcModel*)calloc(1, sizeof *m);
+  m->blob = malloc(nbytes);
+  memcpy(m->blob, src, nbytes);
+  const char* base = (const char*)m->blob;
+  int missing = 0;
+#define GETI(n) do { const myo_blob_field* f = blob_find(m->blob, #n); \
+    if (!f || f->dtype != MYO_BLOB_I32) { if (err) snprintf(err, errlen, "missing int field %s", #n); missing = 1; } \
+    else m->n = (const int*)(base + f->offset); } while (0)
+#define GETD(n) do { const myo_blob_field* f = blob_find(m->blob, #n); \
+    if (!f || f->dtype != MYO_BLOB_F64) { if (err) snprintf(err, errlen, "missing f64 field %s", #n); missing = 1; } \
+    else m->n = (const double*)(base + f->offset); } while (0)
+  GETI(body_parentid); GETI(body_rootid); GETI(body_weldid); GETI(body_jntnum); GETI(body_jntadr);
+  GETI(body_dofnum); GETI(body_dofadr); GETI(jnt_type); GETI(jnt_qposadr); GETI(jnt_dofadr);
+  GETI(jnt_bodyid); GETI(jnt_limited); GETI(dof_bodyid); GETI(dof_jntid); GETI(dof_parentid);
+  GETI(geom_type); GETI(geom_condim); GETI(geom_bodyid); GETI(geom_priority); GETI(site_bodyid);
+  GETI(tendon_adr); GETI(tendon_num); GETI(tendon_limited); GETI(wrap_type); GETI(wrap_objid);
+  GETI(actuator_trntype); GETI(actuator_dyntype); GETI(actuator_gaintype); GETI(actuator_biastype);
+  GETI(actuator_trnid); GETI(actuator_ctrllimited); GETI(actuator_forcelimited);
+  GETD(qpos0); GETD(qpos_spring); GETD(body_pos); GETD(body_quat); GETD(body_ipos); GETD(body_iquat);
+  GETD(body_mass); GETD(body_inertia); GETD(body_invweight0); GETD(jnt_solref); GETD(jnt_solimp);
+  GETD(jnt_pos); GETD(jnt_axis); GETD(jnt_stiffness); GETD(jnt_range); GETD(jnt_margin);
+  GETD(dof_armature); GETD(dof_damping); GETD(dof_invweight0); GETD(geom_solmix); GETD(geom_solref);
+  GETD(geom_solimp); GETD(geom_size); GETD(geom_rbound); GETD(geom_pos); GETD(geom_quat);
+  GETD(geom_friction); GETD(geom_margin); GETD(geom_gap); GETD(site_pos); GETD(tendon_solref_lim);
+  GETD(tendon_solimp_lim); GETD(tendon_range); GETD(tendon_margin); GETD(tendon_stiffness);
+  GETD(tendon_damping); GETD(tendon_lengthspring); GETD(tendon_invweight0); GETD(wrap_prm);
+  GETD(actuator_dynprm); GETD(actuator_gainprm); GETD(actuator_biasprm); GETD(actuator_ctrlrange);
+  GETD(actuator_forcerange); GETD(actuator_gear); GETD(actuator_acc0); GETD(actuator_lengthrange);
+  const myo_blob_field *fs = blob_find(m->blob, "sizes"), *fi = blob_find(m->blob, "opt_int"),
+                       *fd = blob_find(m->blob, "opt_f64"), *p1 = blob_find(m->blob, "x_pair_geom1"),
+                       *p2 = blob_find(m->blob, "x_pair_geom2");
+  if (missing || !fs || !fi || !fd || !p1 || !p2) {
+    if (err && !missing) snprintf(err, errlen, "missing sizes/opt/pair fields");
+    free(m->blob); free(m); return NULL;
+  }
+  const int* s = (const int*)(base + fs->offset);
+  m->nq=s[0]; m->nv=s[1]; m->nu=s[2]; m->na=s[3]; m->nbody=s[4]; m->njnt=s[5]; m->ngeom=s[6];
+  m->nsite=s[7]; m->ntendon=s[8]; m->nwrap=s[9];
+  const int* oi = (const int*)(base + fi->offset);
+  m->integrator=oi[0]; m->cone=oi[1]; m->iterations=oi[2]; m->disableflags=oi[3];
+  const double* od = (const double*)(base + fd->offset);
+  m->timestep=od[0]; m->tolerance=od[1]; m->impratio=od[2];
+  m->gravity[0]=od[3]; m->gravity[1]=od[4]; m->gravity[2]=od[5]; m->o_margin=od[6]; m->meaninertia=od[7];
+  m->npair = (int)p1->count;
+  m->pair_geom1 = (const int*)(base + p1->offset);
+  m->pair_geom2 = (const int*)(base + p2->offset);
+  return m;
+}
+
+void orc_model_free(OrcModel* m) { if (m) { free(m->blob); free(m); } }
+
+int orc_model_int(const OrcModel* m, const char* n) {
+#define MI(x) if (!strcmp(n, #x)) return m->x
+  MI(nq); MI(nv); MI(nu); MI(na); MI(nbody); MI(njnt); MI(ngeom); MI(nsite); MI(ntendon);
+  MI(nwrap); MI(npair); MI(integrator); MI(iterations);
+  return -1;
+}
+
+/* ------------------------------------------------------------------ data */
+static double* falloc(OrcData* d, const char* name, int n) {
+  double* p = (double*)calloc(n > 0 ? n : 1, sizeof(double));
+  d->fields[d->nfields].name = name; d->fields[d->nfields].p = p; d->fields[d->nfields].n = n;
+  d->nfields++;
+  return p;
+}
+
+OrcData* orc_data_new(const OrcModel* m) {
+  OrcData* d = (OrcData*)calloc(1, sizeof *d);
+  d->m = m;
+  int nv=m->nv, nb=m->nbody;
+#define A(name, n) d->name = falloc(d, #name, (n))
+  A(qpos, m->nq); A(qvel, nv); A(act, m->na); A(ctrl, m->nu); A(qacc_warmstart, nv);
+  A(body_mass, nb); A(geom_friction, 3*m->ngeom); A(geom_size, 3*m->ngeom); A(site_pos, 3*m->nsite);
+  A(xpos, 3*nb); A(xquat, 4*nb); A(xmat, 9*nb); A(xipos, 3*nb); A(ximat, 9*nb);
+  A(xanchor, 3*m->njnt); A(xaxis, 3*m->njnt); A(geom_xpos, 3*m->ngeom); A(geom_xmat, 9*m->ngeom);
+  A(site_xpos, 3*m->nsite); A(subtree_com, 3*nb); A(cinert, 10*nb); A(cdof, 6*nv); A(crb, 10*nb);
+  A(ten_length, m->ntendon); A(ten_J, m->ntendon*nv); A(actuator_length, m->nu);
+  A(actuator_moment, m->nu*nv); A(M, nv*nv); A(Mchol, nv*nv);
+  A(ten_velocity, m->ntendon); A(actuator_velocity, m->nu); A(cvel, 6*nb); A(cdof_dot, 6*nv);
+  A(qfrc_passive, nv); A(qfrc_bias, nv);
+  A(act_dot, m->na); A(actuator_force, m->nu); A(qfrc_actuator, nv); A(qfrc_smooth, nv);
+  A(qacc_smooth, nv); A(qacc, nv); A(qfrc_constraint, nv);
+  A(efc_J, MAXEFC*nv); A(efc_pos, MAXEFC); A(efc_margin, MAXEFC); A(efc_D, MAXEFC); A(efc_R, MAXEFC);
+  A(efc_aref, MAXEFC); A(efc_vel, MAXEFC); A(efc_force, MAXEFC); A(efc_diagApprox, MAXEFC);
+  A(efc_KBIP, 4*MAXEFC);
+  A(w1, MAXEFC+nv); A(w2, MAXEFC+nv); A(w3, MAXEFC+nv); A(w4, MAXEFC+nv); A(w5, MAXEFC+nv);
+  A(H, nv*nv); A(cacc, 6*nb); A(cfrc, 6*nb);
+#undef A
+  orc_reset(m, d);
+  return d;
+}
+
+void orc_data_free(OrcData* d) {
+  if (!d) return;
+  for (int i = 0; i < d->nfields; ++i) free(d->fields[i].p);
+  free(d);
+}
+
+void orc_reset(const OrcModel* m, OrcData* d) {
+  memcpy(d->qpos, m->qpos0, sizeof(double)*m->nq);
+  memset(d->qvel, 0, sizeof(double)*m->nv);
+  memset(d->act, 0, sizeof(double)*m->na);
+  memset(d->ctrl, 0, sizeof(double)*m->nu);
+  memset(d->qacc_warmstart, 0, sizeof(double)*m->nv);
+  memcpy(d->body_mass, m->body_mass, sizeof(double)*m->nbody);
+  memcpy(d->geom_friction, m->geom_friction, sizeof(double)*3*m->ngeom);
+  memcpy(d->geom_size, m->geom_size, sizeof(double)*3*m->ngeom);
+  memcpy(d->site_pos, m->site_pos, sizeof(double)*3*m->nsite);
+  d->time = 0; d->bad = 0;
+}
+
+double* orc_ptr(OrcData* d, const char* name) {
+  if (!strcmp(name, "time")) return &d->time;
+  for (int i = 0; i < d->nfields; ++i) if (!strcmp(d->fields[i].name, name)) return d->fields[i].p;
+  return NULL;
+}
+int orc_count(const OrcData* d, const char* name) {
+  for (int i = 0; i < d->nfields; ++i) if (!strcmp(d->fields[i].name, name)) return d->fields[i].n;
+  return -1;
+}
+int orc_get_int(const OrcData* d, const char* n) {
+  if (!strcmp(n, "ncon")) return d->ncon;
+  if (!strcmp(n, "nefc")) return d->nefc;
+  if (!strcmp(n, "solver_iter")) return d->solver_iter;
+  if (!strcmp(n, "bad")) return d->bad;
+  if (!strcmp(n, "nl")) return d->nl;
+  if (!strcmp(n, "ntl")) return d->ntl;
+  return -1;
+}
+
+/* ------------------------------------------------------------------ P2 kinematics */
+void orc_kinematics(const OrcModel* m, OrcData* d) {
+  double* xpos=d->xpos; double* xquat=d->xquat; double* xmat=d->xmat;
+  xpos[0]=xpos[1]=xpos[2]=0; xquat[0]=1; xquat[1]=xquat[2]=xquat[3]=0; quat2mat(xmat, xquat);
+  memcpy(d->xipos, xpos, 3*sizeof(double)); memcpy(d->ximat, xmat, 9*sizeof(double));
+  for (int b = 1; b < m->nbody; ++b) {
+    int par = m->body_parentid[b];
+    int jn = m->body_jntnum[b], ja = m->body_jntadr[b];
+    double p[3], q[4];
+    if (jn == 1 && m->jnt_type[ja] == MYO_JNT_FREE) {
+      int qa = m->jnt_qposadr[ja];
+      normalize4(d->qpos + qa + 3);
+      memcpy(p, d->qpos + qa, 3*sizeof(double)); memcpy(q, d->qpos + qa + 3, 4*sizeof(double));
+      memcpy(d->xanchor + 3*ja, p, 3*sizeof(double));
+      d->xaxis[3*ja]=0; d->xaxis[3*ja+1]=0; d->xaxis[3*ja+2]=1;
+    } else {
+      double t[3];
+      mulmatvec3(t, xmat + 9*par, m->body_pos + 3*b);
+      p[0]=xpos[3*par]+t[0]; p[1]=xpos[3*par+1]+t[1]; p[2]=xpos[3*par+2]+t[2];
+      mulquat(q, xquat + 4*par, m->body_quat + 4*b);
+      for (int k = 0; k < jn; ++k) {
+        int j = ja + k, qa = m->jnt_qposadr[j];
+        double R[9], anchor[3], axis[3];
+        quat2mat(R, q);
+        mulmatvec3(anchor, R, m->jnt_pos + 3*j); anchor[0]+=p[0]; anchor[1]+=p[1]; anchor[2]+=p[2];
+        mulmatvec3(axis, R, m->jnt_axis + 3*j);
+        memcpy(d->xanchor + 3*j, anchor, sizeof anchor); memcpy(d->xaxis + 3*j, axis, sizeof axis);
+        double ang = d->qpos[qa] - m->qpos0[qa];
+        if (m->jnt_type[j] == MYO_JNT_SLIDE) {
+          p[0]+=axis[0]*ang; p[1]+=axis[1]*ang; p[2]+=axis[2]*ang;
+        } else { /* hinge: rotate about the local axis, keep the anchor fixed */
+          double qloc[4], R2[9], t2[3];
+          axisangle2quat(qloc, m->jnt_axis + 3*j, ang);
+          mulquat(q, q, qloc);
+          quat2mat(R2, q);
+          mulmatvec3(t2, R2, m->jnt_pos + 3*j);
+          p[0]=anchor[0]-t2[0]; p[1]=anchor[1]-t2[1]; p[2]=anchor[2]-t2[2];
+        }
+      }
+    }
+    normalize4(q);
+    memcpy(xpos + 3*b, p, sizeof p); memcpy(xquat + 4*b, q, sizeof q);
+    quat2mat(xmat + 9*b, q);
+    double t[3], qi[4];
+    mulmatvec3(t, xmat + 9*b, m->body_ipos + 3*b);
+    d->xipos[3*b]=p[0]+t[0]; d->xipos[3*b+1]=p[1]+t[1]; d->xipos[3*b+2]=p[2]+t[2];
+    mulquat(qi, q, m->body_iquat + 4*b);
+    quat2mat(d->ximat + 9*b, qi);
+  }
+  for (int g = 0; g < m->ngeom; ++g) {
+    int b = m->geom_bodyid[g]; double t[3], q[4];
+    mulmatvec3(t, xmat + 9*b, m->geom_pos + 3*g);
+    for (int k = 0; k < 3; ++k) d->geom_xpos[3*g+k] = xpos[3*b+k] + t[k];
+    mulquat(q, xquat + 4*b, m->geom_quat + 4*g);
+    quat2mat(d->geom_xmat + 9*g, q);
+  }
+  for (int s = 0; s < m->nsite; ++s) {
+    int b = m->site_bodyid[s]; double t[3];
+    mulmatvec3(t, xmat + 9*b, d->site_pos + 3*s);
+    for (int k = 0; k < 3; ++k) d->site_xpos[3*s+k] = xpos[3*b+k] + t[k];
+  }
+}
+
+/* ------------------------------------------------------------------ P2 comPos (cinert, cdof) */
+static void com_pos(const OrcModel* m, OrcData* d) {
+  int nb = m->nbody;
+  double* sc = d->subtree_com; double* mass = d->w1; /* subtree mass scratch */
+  for (int b = 0; b < nb; ++b) {
+    mass[b] = d->body_mass[b];
+    for (int k = 0; k < 3; ++k) sc[3*b+k] = d->body_mass[b]*d->xipos[3*b+k];
+  }
+  for (int b = nb-1; b > 0; --b) {
+    int p = m->body_parentid[b];
+    mass[p] += mass[b];
+    for (int k = 0; k < 3; ++k) sc[3*p+k] += sc[3*b+k];
+  }
+  for (int b = 0; b < nb; ++b) {
+    if (mass[b] < MINVAL) for (int k = 0; k < 3; ++k) sc[3*b+k] = d->xipos[3*b+k];
+    else for (int k = 0; k < 3; ++k) sc[3*b+k] /= mass[b];
+  }
+  for (int b = 1; b < nb; ++b) {
+    const double* R = d->ximat + 9*b; const double* I = m->body_inertia + 3*b;
+    const double* c = sc + 3*m->body_rootid[b];
+    double off[3] = { d->xipos[3*b]-c[0], d->xipos[3*b+1]-c[1], d->xipos[3*b+2]-c[2] };
+    double mb = d->body_mass[b];
+    double Iw[6]; /* xx yy zz xy xz yz */
+    Iw[0]=R[0]*R[0]*I[0]+R[1]*R[1]*I[1]+R[2]*R[2]*I[2];
+    Iw[1]=R[3]*R[3]*I[0]+R[4]*R[4]*I[1]+R[5]*R[5]*I[2];
+    Iw[2]=R[6]*R[6]*I[0]+R[7]*R[7]*I[1]+R[8]*R[8]*I[2];
+    Iw[3]=R[0]*R[3]*I[0]+R[1]*R[4]*I[1]+R[2]*R[5]*I[2];
+    Iw[4]=R[0]*R[6]*I[0]+R[1]*R[7]*I[1]+R[2]*R[8]*I[2];
+    Iw[5]=R[3]*R[6]*I[0]+R[4]*R[7]*I[1]+R[5]*R[8]*I[2];
+    double* ci = d->cinert + 10*b;
+    ci[0]=Iw[0]+mb*(off[1]*off[1]+off[2]*off[2]);
+    ci[1]=Iw[1]+mb*(off[0]*off[0]+off[2]*off[2]);
+    ci[2]=Iw[2]+mb*(off[0]*off[0]+off[1]*off[1]);
+    ci[3]=Iw[3]-mb*off[0]*off[1]; ci[4]=Iw[4]-mb*off[0]*off[2]; ci[5]=Iw[5]-mb*off[1]*off[2];
+    ci[6]=mb*off[0]; ci[7]=mb*off[1]; ci[8]=mb*off[2]; ci[9]=mb;
+  }
+  memset(d->cinert, 0, 10*sizeof(double));
+  for (int j = 0; j < m->njnt; ++j) {
+    int b = m->jnt_bodyid[j], da = m->jnt_dofadr[j];
+    const double* c = sc + 3*m->body_rootid[b];
+    double off[3] = { c[0]-d->xanchor[3*j], c[1]-d->xanchor[3*j+1], c[2]-d->xanchor[3*j+2] };
+    if (m->jnt_type[j] == MYO_JNT_FREE) {
+      for (int k = 0; k < 3; ++k) {
+        double* cd = d->cdof + 6*(da+k); memset(cd, 0, 6*sizeof(double)); cd[3+k] = 1;
+      }
+      for (int k = 0; k < 3; ++k) {
+        double* cd = d->cdof + 6*(da+3+k);
+        double ax[3] = { d->xmat[9*b+k], d->xmat[9*b+3+k], d->xmat[9*b+6+k] };
+        memcpy(cd, ax, sizeof ax); cross3(cd+3, ax, off);
+      }
+    } else if (m->jnt_type[j] == MYO_JNT_SLIDE) {
+      double* cd = d->cdof + 6*da; cd[0]=cd[1]=cd[2]=0; memcpy(cd+3, d->xaxis + 3*j, 3*sizeof(double));
+    } else {
+      double* cd = d->cdof + 6*da; memcpy(cd, d->xaxis + 3*j, 3*sizeof(double)); cross3(cd+3, d->xaxis + 3*j, off);
+    }
+  }
+}
+
+/* spatial inertia (10-vector about the tree reference point) times motion vector */
+static void mul_inert_vec(double* r, const double* I, const double* v) {
+  const double* w = v; const double* l = v+3; const double* h = I+6; double mass = I[9];
+  double t[3];
+  r[0]=I[0]*w[0]+I[3]*w[1]+I[4]*w[2]; r[1]=I[3]*w[0]+I[1]*w[1]+I[5]*w[2]; r[2]=I[4]*w[0]+I[5]*w[1]+I[2]*w[2];
+  cross3(t, h, l); r[0]+=t[0]; r[1]+=t[1]; r[2]+=t[2];
+  cross3(t, h, w); r[3]=mass*l[0]-t[0]; r[4]=mass*l[1]-t[1]; r[5]=mass*l[2]-t[2];
+}
+static void cross_motion(double* r, const double* v, const double* mvec) {
+  double a[3], b[3], c[3];
+  cross3(a, v, mvec); cross3(b, v, mvec+3); cross3(c, v+3, mvec);
+  r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; r[3]=b[0]+c[0]; r[4]=b[1]+c[1]; r[5]=b[2]+c[2];
+}
+static void cross_force(double* r, const double* v, const double* f) {
+  double a[3], b[3], c[3];
+  cross3(a, v, f); cross3(b, v+3, f+3); cross3(c, v, f+3);
+  r[0]=a[0]+b[0]; r[1]=a[1]+b[1]; r[2]=a[2]+b[2]; r[3]=c[0]; r[4]=c[1]; r[5]=c[2];
+}
+
+/* ------------------------------------------------------------------ P5 CRB + factor */
+static int chol_factor(double* L, const double* A, int n) {
+  if (L != A) memcpy(L, A, sizeof(double)*n*n);
+  for (int k = 0; k < n; ++k) {
+    double s = L[k*n+k];
+    for (int j = 0; j < k; ++j) s -= L[k*n+j]*L[k*n+j];
+    if (s < MINVAL) s = MINVAL;
+    double dk = sqrt(s); L[k*n+k] = dk;
+    for (int i = k+1; i < n; ++i) {
+      double t = L[i*n+k];
+      for (int j = 0; j < k; ++j) t -= L[i*n+j]*L[k*n+j];
+      L[i*n+k] = t/dk;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const double* L, double* x, int n) { /* in place */
+  for (int i = 0; i < n; ++i) { double s = x[i]; for (int j = 0; j < i; ++j) s -= L[i*n+j]*x[j]; x[i] = s/L[i*n+i]; }
+  for (int i = n-1; i >= 0; --i) { double s = x[i]; for (int j = i+1; j < n; ++j) s -= L[j*n+i]*x[j]; x[i] = s/L[i*n+i]; }
+}
+
+static void crb(const OrcModel* m, OrcData* d) {
+  int nv = m->nv, nb = m->nbody;
+  memcpy(d->crb, d->cinert, sizeof(double)*10*nb);
+  for (int b = nb-1; b > 0; --b) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int k = 0; k < 10; ++k) d->crb[10*p+k] += d->crb[10*b+k];
+  }
+  memset(d->M, 0, sizeof(double)*nv*nv);
+  for (int i = 0; i < nv; ++i) {
+    double buf[6];
+    mul_inert_vec(buf, d->crb + 10*m->dof_bodyid[i], d->cdof + 6*i);
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      double s = 0; for (int k = 0; k < 6; ++k) s += d->cdof[6*j+k]*buf[k];
+      d->M[i*nv+j] = s; d->M[j*nv+i] = s;
+    }
+    d->M[i*nv+i] += m->dof_armature[i];
+  }
+  chol_factor(d->Mchol, d->M, nv);
+}
+
+/* ------------------------------------------------------------------ Jacobian of a point */
+static void jac_point(const OrcModel* m, const OrcData* d, int body, const double* point,
+                      double* jacp /* 3 x nv */) {
+  int nv = m->nv;
+  memset(jacp, 0, sizeof(double)*3*nv);
+  while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+  if (body <= 0) return;
+  const double* c = d->subtree_com + 3*m->body_rootid[body];
+  double off[3] = { point[0]-c[0], point[1]-c[1], point[2]-c[2] };
+  int i = m->body_dofadr[body] + m->body_dofnum[body] - 1;
+  while (i >= 0) {
+    const double* cd = d->cdof + 6*i; double t[3];
+    cross3(t, cd, off);
+    jacp[i] = cd[3]+t[0]; jacp[nv+i] = cd[4]+t[1]; jacp[2*nv+i] = cd[5]+t[2];
+    i = m->dof_parentid[i];
+  }
+}
+
+/* ------------------------------------------------------------------ P3 tendon wrapping */
+static int is_intersect(const double* p1, const double* p2, const double* p3, const double* p4) {
+  double det = (p4[1]-p3[1])*(p2[0]-p1[0]) - (p4[0]-p3[0])*(p2[1]-p1[1]);
+  if (fabs(det) < MINVAL) return 0;
+  double a = ((p4[0]-p3[0])*(p1[1]-p3[1]) - (p4[1]-p3[1])*(p1[0]-p3[0]))/det;
+  double b = ((p2[0]-p1[0])*(p1[1]-p3[1]) - (p2[1]-p1[1])*(p1[0]-p3[0]))/det;
+  return (a >= 0 && a <= 1 && b >= 0 && b <= 1);
+}
+
+/* 2-D circle wrap: end points d[0:2], d[2:4], optional side point sd, radius rad.
+ * Returns arc length (>=0) and the two tangent points in pnt, or -1 for a straight path. */
+static double wrap_circle(double* pnt, const double* dd, const double* sd, double rad) {
+  double sqlen0 = dd[0]*dd[0]+dd[1]*dd[1], sqlen1 = dd[2]*dd[2]+dd[3]*dd[3], sqrad = rad*rad;
+  double dif[2] = { dd[2]-dd[0], dd[3]-dd[1] };
+  double dsq = dif[0]*dif[0]+dif[1]*dif[1];
+  if (sqlen0 < sqrad || sqlen1 < sqrad || rad < MINVAL) return -1;
+  if (dsq < MINVAL) return -1;
+  double a = -(dif[0]*dd[0]+dif[1]*dd[1])/dsq;
+  if (a < 0) a = 0; else if (a > 1) a = 1;
+  double tmp[2] = { a*dif[0]+dd[0], a*dif[1]+dd[1] };
+  if (tmp[0]*tmp[0]+tmp[1]*tmp[1] > sqrad && (!sd || sd[0]*tmp[0]+sd[1]*tmp[1] >= 0)) return -1;
+  double sol[2][4], good[2];
+  double sqrt0 = sqrt(sqlen0 - sqrad), sqrt1 = sqrt(sqlen1 - sqrad);
+  for (int i = 0; i < 2; ++i) {
+    int sgn = (i == 0 ? 1 : -1);
+    sol[i][0] = (dd[0]*sqrad + sgn*rad*dd[1]*sqrt0)/sqlen0;
+    sol[i][1] = (dd[1]*sqrad - sgn*rad*dd[0]*sqrt0)/sqlen0;
+    sol[i][2] = (dd[2]*sqrad - sgn*rad*dd[3]*sqrt1)/sqlen1;
+    sol[i][3] = (dd[3]*sqrad + sgn*rad*dd[2]*sqrt1)/sqlen1;
+    if (sd) {
+      double t[2] = { sol[i][0]+sol[i][2], sol[i][1]+sol[i][3] };
+      double n = sqrt(t[0]*t[0]+t[1]*t[1]);
+      if (n < MINVAL) { t[0]=1; t[1]=0; } else { t[0]/=n; t[1]/=n; }
+      good[i] = t[0]*sd[0]+t[1]*sd[1];
+    } else {
+      double t[2] = { sol[i][0]-sol[i][2], sol[i][1]-sol[i][3] };
+      good[i] = -(t[0]*t[0]+t[1]*t[1]);
+    }
+    if (is_intersect(dd, sol[i], dd+2, sol[i]+2)) good[i] = -10000;
+  }
+  int i = (good[0] > good[1]) ? 0 : 1;
+  memcpy(pnt, sol[i], 4*sizeof(double));
+  if (is_intersect(dd, pnt, dd+2, pnt+2)) return -1;
+  double c = (pnt[0]*pnt[2]+pnt[1]*pnt[3])/sqrad;
+  if (c > 1) c = 1; else if (c < -1) c = -1;
+  return rad*acos(c);
+}
+
+static double wrap_geom(double* wpnt /*6*/, const double* x0, const double* x1, const double* xpos,
+                        const double* xmat, double radius, int type, const double* side) {
+  double p0[3], p1[3], t[3];
+  for (int k = 0; k < 3; ++k) t[k] = x0[k]-xpos[k];
+  mulmatTvec3(p0, xmat, t);
+  for (int k = 0; k < 3; ++k) t[k] = x1[k]-xpos[k];
+  mulmatTvec3(p1, xmat, t);
+  if (norm3(p0) < MINVAL || norm3(p1) < MINVAL) return -1;
+  double axis0[3], axis1[3];
+  if (type == MYO_WRAP_SPHERE) {
+    double normal[3];
+    memcpy(axis0, p0, sizeof p0); normalize3(axis0);
+    cross3(normal, p0, p1);
+    double nrm = norm3(normal);
+    if (nrm < MINVAL) { /* p0, p1 and the centre collinear: any plane through them */
+      int imin = 0; if (fabs(axis0[1]) < fabs(axis0[imin])) imin = 1; if (fabs(axis0[2]) < fabs(axis0[imin])) imin = 2;
+      double e[3] = {0,0,0}; e[imin] = 1;
+      cross3(normal, axis0, e); normalize3(normal);
+    } else { normal[0]/=nrm; normal[1]/=nrm; normal[2]/=nrm; }
+    cross3(axis1, normal, axis0); normalize3(axis1);
+  } else {
+    axis0[0]=1; axis0[1]=0; axis0[2]=0; axis1[0]=0; axis1[1]=1; axis1[2]=0;
+  }
+  double s[4] = { dot3(p0,axis0), dot3(p0,axis1), dot3(p1,axis0), dot3(p1,axis1) };
+  double sd[2]; int has_side = 0;
+  if (side) {
+    double ps[3];
+    for (int k = 0; k < 3; ++k) t[k] = side[k]-xpos[k];
+    mulmatTvec3(ps, xmat, t);
+    sd[0] = dot3(ps,axis0); sd[1] = dot3(ps,axis1);
+    double n = sqrt(sd[0]*sd[0]+sd[1]*sd[1]);
+    if (n < MINVAL) { sd[0]=1; sd[1]=0; } else { sd[0]/=n; sd[1]/=n; }
+    sd[0]*=radius; sd[1]*=radius;
+    has_side = 1;
+  }
+  double pnt[4];
+  double wlen = wrap_circle(pnt, s, has_side ? sd : NULL, radius);
+  if (wlen < 0) return -1;
+  double r0[3], r1[3];
+  for (int k = 0; k < 3; ++k) { r0[k] = axis0[k]*pnt[0]+axis1[k]*pnt[1]; r1[k] = axis0[k]*pnt[2]+axis1[k]*pnt[3]; }
+  if (type == MYO_WRAP_CYLINDER) {
+    double L0 = sqrt((s[0]-pnt[0])*(s[0]-pnt[0])+(s[1]-pnt[1])*(s[1]-pnt[1]));
+    double L1 = sqrt((s[2]-pnt[2])*(s[2]-pnt[2])+(s[3]-pnt[3])*(s[3]-pnt[3]));
+    r0[2] = p0[2] + (p1[2]-p0[2])*L0/(L0+wlen+L1);
+    r1[2] = p0[2] + (p1[2]-p0[2])*(L0+wlen)/(L0+wlen+L1);
+    double height = fabs(r1[2]-r0[2]);
+    wlen = sqrt(wlen*wlen + height*height);
+  }
+  mulmatvec3(wpnt, xmat, r0); mulmatvec3(wpnt+3, xmat, r1);
+  for (int k = 0; k < 3; ++k) { wpnt[k] += xpos[k]; wpnt[3+k] += xpos[k]; }
+  return wlen;
+}
+
+static void tendon(const OrcModel* m, OrcData* d) {
+  int nv = m->nv;
+  double* jac0 = d->w1; /* reuse big scratch: need 3*nv each */
+  double* jac1 = d->w2;
+  memset(d->ten_J, 0, sizeof(double)*m->ntendon*nv);
+  for (int t = 0; t < m->ntendon; ++t) {
+    int adr = m->tendon_adr[t], num = m->tendon_num[t];
+    double len = 0, divisor = 1; double* J = d->ten_J + t*nv;
+    int j = 0;
+    while (j < num-1) {
+      int type0 = m->wrap_type[adr+j], type1 = m->wrap_type[adr+j+1];
+      int id0 = m->wrap_objid[adr+j], id1 = m->wrap_objid[adr+j+1];
+      if (type0 == MYO_WRAP_PULLEY || type1 == MYO_WRAP_PULLEY) {
+        if (type0 == MYO_WRAP_PULLEY) divisor = m->wrap_prm[adr+j];
+        j++; continue;
+      }
+      double wpnt[12]; int wbody[4]; int wcnt; double wlen = -1; int idg = -1;
+      wbody[0] = m->site_bodyid[id0]; memcpy(wpnt, d->site_xpos + 3*id0, 3*sizeof(double));
+      if (type1 == MYO_WRAP_SPHERE || type1 == MYO_WRAP_CYLINDER) {
+        idg = id1; id1 = m->wrap_objid[adr+j+2];
+        int sideid = (int)lround(m->wrap_prm[adr+j+1]);
+        const double* side = sideid >= 0 ? d->site_xpos + 3*sideid : NULL;
+        wlen = wrap_geom(wpnt+3, d->site_xpos + 3*id0, d->site_xpos + 3*id1, d->geom_xpos + 3*idg,
+                         d->geom_xmat + 9*idg, d->geom_size[3*idg], type1, side);
+      }
+      if (wlen < 0) {
+        wbody[1] = m->site_bodyid[id1]; memcpy(wpnt+3, d->site_xpos + 3*id1, 3*sizeof(double)); wcnt = 2;
+      } else {
+        wbody[1] = wbody[2] = m->geom_bodyid[idg]; wbody[3] = m->site_bodyid[id1];
+        memcpy(wpnt+9, d->site_xpos + 3*id1, 3*sizeof(double)); wcnt = 4;
+      }
+      for (int k = 0; k < wcnt-1; ++k) {
+        if (wcnt == 4 && k == 1) { len += wlen/divisor; continue; }
+        double dif[3] = { wpnt[3*k+3]-wpnt[3*k], wpnt[3*k+4]-wpnt[3*k+1], wpnt[3*k+5]-wpnt[3*k+2] };
+        double dn = norm3(dif);
+        len += dn/divisor;
+        if (wbody[k] != wbody[k+1] && dn > MINVAL) {
+          dif[0]/=dn; dif[1]/=dn; dif[2]/=dn;
+          jac_point(m, d, wbody[k], wpnt+3*k, jac0);
+          jac_point(m, d, wbody[k+1], wpnt+3*k+3, jac1);
+          for (int c = 0; c < nv; ++c)
+            J[c] += (dif[0]*(jac1[c]-jac0[c]) + dif[1]*(jac1[nv+c]-jac0[nv+c]) + dif[2]*(jac1[2*nv+c]-jac0[2*nv+c]))/divisor;
+        }
+      }
+      j += (idg >= 0 ? 2 : 1);
+    }
+    d->ten_length[t] = len;
+  }
+}
+
+/* ------------------------------------------------------------------ P4 transmission */
+static void transmission(const OrcModel* m, OrcData* d) {
+  int nv = m->nv;
+  memset(d->actuator_moment, 0, sizeof(double)*m->nu*nv);
+  for (int i = 0; i < m->nu; ++i) {
+    double gear = m->actuator_gear[6*i]; int id = m->actuator_trnid[2*i];
+    if (m->actuator_trntype[i] == MYO_TRN_TENDON) {
+      d->actuator_length[i] = gear*d->ten_length[id];
+      for (int c = 0; c < nv; ++c) d->actuator_moment[i*nv+c] = gear*d->ten_J[id*nv+c];
+    } else { /* joint (hinge/slide) */
+      d->actuator_length[i] = gear*d->qpos[m->jnt_qposadr[id]];
+      d->actuator_moment[i*nv + m->jnt_dofadr[id]] = gear;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ P6 collision */
+static void make_frame(double* f) {
+  normalize3(f);
+  f[3]=f[4]=f[5]=0;
+  if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+  double t = dot3(f, f+3);
+  f[3]-=t*f[0]; f[4]-=t*f[1]; f[5]-=t*f[2];
+  normalize3(f+3);
+  cross3(f+6, f, f+3);
+}
+
+static int sphere_sphere_raw(double* dist, double* pos, double* n, const double* c1, double r1,
+                             const double* c2, double r2, double margin) {
+  double dif[3] = { c2[0]-c1[0], c2[1]-c1[1], c2[2]-c1[2] };
+  double cd = norm3(dif);
+  if (cd - r1 - r2 > margin) return 0;
+  if (cd < MINVAL) { n[0]=1; n[1]=0; n[2]=0; } else { n[0]=dif[0]/cd; n[1]=dif[1]/cd; n[2]=dif[2]/cd; }
+  *dist = cd - r1 - r2;
+  for (int k = 0; k < 3; ++k) pos[k] = c1[k] + n[k]*(r1 + 0.5*(*dist));
+  return 1;
+}
+
+static void seg_nearest(double* out, const double* c, const double* axis, double half, const double* p) {
+  double t = (p[0]-c[0])*axis[0]+(p[1]-c[1])*axis[1]+(p[2]-c[2])*axis[2];
+  if (t > half) t = half; else if (t < -half) t = -half;
+  for (int k = 0; k < 3; ++k) out[k] = c[k] + t*axis[k];
+}
+
+static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, double margin,
+                        double* dist, double* pos, double* nrm /* up to 2 results */) {
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  const double *p1 = d->geom_xpos + 3*g1, *p2 = d->geom_xpos + 3*g2;
+  const double *R1 = d->geom_xmat + 9*g1, *R2 = d->geom_xmat + 9*g2;
+  const double *s1 = d->geom_size + 3*g1, *s2 = d->geom_size + 3*g2;
+  if (t1 == MYO_GEOM_PLANE && t2 == MYO_GEOM_SPHERE) {
+    double n[3] = { R1[2], R1[5], R1[8] };
+    double dd = (p2[0]-p1[0])*n[0]+(p2[1]-p1[1])*n[1]+(p2[2]-p1[2])*n[2] - s2[0];
+    if (dd > margin) return 0;
+    dist[0] = dd; memcpy(nrm, n, sizeof n);
+    for (int k = 0; k < 3; ++k) pos[k] = p2[k] - n[k]*(s2[0] + 0.5*dd);
+    return 1;
+  }
+  if (t1 == MYO_GEOM_PLANE && t2 == MYO_GEOM_CAPSULE) {
+    double n[3] = { R1[2], R1[5], R1[8] }, ax[3] = { R2[2], R2[5], R2[8] };
+    int cnt = 0;
+    for (int e = 0; e < 2; ++e) {
+      double sg = e ? -1.0 : 1.0, c[3];
+      for (int k = 0; k < 3; ++k) c[k] = p2[k] + sg*s2[1]*ax[k];
+      double dd = (c[0]-p1[0])*n[0]+(c[1]-p1[1])*n[1]+(c[2]-p1[2])*n[2] - s2[0];
+      if (dd > margin) continue;
+      dist[cnt] = dd; memcpy(nrm+3*cnt, n, sizeof n);
+      for (int k = 0; k < 3; ++k) pos[3*cnt+k] = c[k] - n[k]*(s2[0] + 0.5*dd);
+      cnt++;
+    }
+    return cnt;
+  }
+  if (t1 == MYO_GEOM_SPHERE && t2 == MYO_GEOM_SPHERE)
+    return sphere_sphere_raw(dist, pos, nrm, p1, s1[0], p2, s2[0], margin);
+  if (t1 == MYO_GEOM_SPHERE && t2 == MYO_GEOM_CAPSULE) {
+    double ax[3] = { R2[2], R2[5], R2[8] }, q[3];
+    seg_nearest(q, p2, ax, s2[1], p1);
+    return sphere_sphere_raw(dist, pos, nrm, p1, s1[0], q, s2[0], margin);
+  }
+  if (t1 == MYO_GEOM_CAPSULE && t2 == MYO_GEOM_CAPSULE) {
+    double a1[3] = { R1[2], R1[5], R1[8] }, a2[3] = { R2[2], R2[5], R2[8] };
+    double dif[3] = { p1[0]-p2[0], p1[1]-p2[1], p1[2]-p2[2] };
+    double ma = dot3(a1,a1), mb = -dot3(a1,a2), mc = dot3(a2,a2);
+    double u = -dot3(a1,dif), v = dot3(a2,dif);
+    double det = ma*mc - mb*mb, x1, x2;
+    if (fabs(det) < 1e-12) { /* parallel: project centre of 2 onto 1 */
+      x1 = 0; x2 = v/mc;
+    } else {
+      x1 = (mc*u - mb*v)/det; x2 = (ma*v - mb*u)/det;
+    }
+    if (x1 > s1[1]) x1 = s1[1]; else if (x1 < -s1[1]) x1 = -s1[1];
+    if (x2 > s2[1]) x2 = s2[1]; else if (x2 < -s2[1]) x2 = -s2[1];
+    double q1[3], q2[3];
+    for (int k = 0; k < 3; ++k) q1[k] = p1[k] + x1*a1[k];
+    seg_nearest(q2, p2, a2, s2[1], q1);
+    seg_nearest(q1, p1, a1, s1[1], q2);
+    return sphere_sphere_raw(dist, pos, nrm, q1, s1[0], q2, s2[0], margin);
+  }
+  if (t1 == MYO_GEOM_SPHERE && t2 == MYO_GEOM_BOX) {
+    double t[3] = { p1[0]-p2[0], p1[1]-p2[1], p1[2]-p2[2] }, c[3], cl[3];
+    mulmatTvec3(c, R2, t);
+    int inside = 1;
+    for (int k = 0; k < 3; ++k) {
+      cl[k] = c[k];
+      if (cl[k] > s2[k]) { cl[k] = s2[k]; inside = 0; } else if (cl[k] < -s2[k]) { cl[k] = -s2[k]; inside = 0; }
+    }
+    double nl[3], dd;
+    if (!inside) {
+      double df[3] = { cl[0]-c[0], cl[1]-c[1], cl[2]-c[2] };
+      double dn = norm3(df);
+      dd = dn - s1[0];
+      if (dd > margin) return 0;
+      nl[0]=df[0]/dn; nl[1]=df[1]/dn; nl[2]=df[2]/dn;
+    } else { /* centre inside the box: push out through the nearest face */
+      int kb = 0; double best = 1e300;
+      for (int k = 0; k < 3; ++k) { double e = s2[k]-fabs(c[k]); if (e < best) { best = e; kb = k; } }
+      nl[0]=nl[1]=nl[2]=0; nl[kb] = c[kb] > 0 ? -1.0 : 1.0;
+      dd = -best - s1[0];
+    }
+    mulmatvec3(nrm, R2, nl);
+    dist[0] = dd;
+    for (int k = 0; k < 3; ++k) pos[k] = p1[k] + nrm[k]*(s1[0] + 0.5*dd);
+    return 1;
+  }
+  return 0;
+}
+
+static void mix_params(const OrcModel* m, const OrcData* d, int g1, int g2, OrcContact* c) {
+  int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
+  double mix;
+  if (pr1 != pr2) mix = pr1 > pr2 ? 1.0 : 0.0;
+  else {
+    double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2];
+    if (s1 >= MINVAL && s2 >= MINVAL) mix = s1/(s1+s2);
+    else if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
+    else mix = s1 < MINVAL ? 0.0 : 1.0;
+  }
+  const double *r1 = m->geom_solref + 2*g1, *r2 = m->geom_solref + 2*g2;
+  if (r1[0] > 0 && r2[0] > 0) for (int k = 0; k < 2; ++k) c->solref[k] = mix*r1[k] + (1-mix)*r2[k];
+  else for (int k = 0; k < 2; ++k) c->solref[k] = r1[k] < r2[k] ? r1[k] : r2[k];
+  for (int k = 0; k < 5; ++k) c->solimp[k] = mix*m->geom_solimp[5*g1+k] + (1-mix)*m->geom_solimp[5*g2+k];
+  double f[3];
+  for (int k = 0; k < 3; ++k) {
+    double a = d->geom_friction[3*g1+k], b = d->geom_friction[3*g2+k];
+    f[k] = (pr1 == pr2) ? (a > b ? a : b) : (pr1 > pr2 ? a : b);
+  }
+  c->friction[0]=f[0]; c->friction[1]=f[0]; c->friction[2]=f[1]; c->friction[3]=f[2]; c->friction[4]=f[2];
+}
+
+static void collision(const OrcModel* m, OrcData* d) {
+  d->ncon = 0;
+  for (int p = 0; p < m->npair; ++p) {
+    int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+    double mg1 = m->geom_margin[g1], mg2 = m->geom_margin[g2];
+    double margin = mg1 > mg2 ? mg1 : mg2;
+    double gap = m->geom_gap[g1] > m->geom_gap[g2] ? m->geom_gap[g1] : m->geom_gap[g2];
+    /* bounding-sphere filter with the MODEL's rbound: the reference rewrites geom_size per
+     * episode without refreshing rbound (baoding.py:586-604), so the stale value gates contacts */
+    double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
+    if (rb1 > 0 && rb2 > 0) {
+      double df[3] = { d->geom_xpos[3*g1]-d->geom_xpos[3*g2], d->geom_xpos[3*g1+1]-d->geom_xpos[3*g2+1],
+                       d->geom_xpos[3*g1+2]-d->geom_xpos[3*g2+2] };
+      double bound = rb1 + rb2 + margin;
+      if (dot3(df, df) > bound*bound) continue;
+    }
+    double dist[2], pos[6], nrm[6];
+    int n = collide_pair(m, d, g1, g2, margin, dist, pos, nrm);
+    for (int k = 0; k < n && d->ncon < MAXCON; ++k) {
+      OrcContact* c = &d->con[d->ncon++];
+      c->dist = dist[k]; memcpy(c->pos, pos+3*k, 3*sizeof(double));
+      memcpy(c->frame, nrm+3*k, 3*sizeof(double)); make_frame(c->frame);
+      c->includemargin = margin - gap; c->geom1 = g1; c->geom2 = g2;
+      mix_params(m, d, g1, g2, c);
+    }
+  }
+}
+
+/* ------------------------------------------------------------------ P7 constraints */
+static void get_solparam(const OrcModel* m, const double* solref, const double* solimp, double pos_minus_margin,
+                         double* K, double* B, double* I) {
+  double d0 = solimp[0], d1 = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  if (d0 < MINIMP) d0 = MINIMP; else if (d0 > MAXIMP) d0 = MAXIMP;
+  if (d1 < MINIMP) d1 = MINIMP; else if (d1 > MAXIMP) d1 = MAXIMP;
+  if (width < 0) width = 0;
+  if (mid < MINIMP) mid = MINIMP; else if (mid > MAXIMP) mid = MAXIMP;
+  if (power < 1) power = 1;
+  double imp;
+  if (d0 == d1 || width <= MINVAL) imp = 0.5*(d0+d1);
+  else {
+    double x = fabs(pos_minus_margin)/width;
+    if (x >= 1) imp = d1;
+    else if (x <= 0) imp = d0;
+    else {
+      double y;
+      if (power == 1) y = x;
+      else if (x <= mid) y = pow(x, power)/pow(mid, power-1);
+      else y = 1 - pow(1-x, power)/pow(1-mid, power-1);
+      imp = d0 + y*(d1-d0);
+    }
+  }
+  double tc = solref[0], dr = solref[1];
+  if (tc > 0) {
+    if (!(m->disableflags & (1<<11)) && tc < 2*m->timestep) tc = 2*m->timestep; /* refsafe */
+    double a = d1*d1*tc*tc*dr*dr; *K = 1/(a > MINVAL ? a : MINVAL);
+    double b = d1*tc; *B = 2/(b > MINVAL ? b : MINVAL);
+  } else { *K = -tc/(d1*d1); *B = -dr/d1; }
+  *I = imp;
+}
+
+static void add_row(OrcData* d, int nv, int type, int id, double pos, double margin, double diagApprox,
+                    const double* solref, const double* solimp) {
+  int r = d->nefc;
+  if (r >= MAXEFC) return;
+  d->efc_type[r] = type; d->efc_id[r] = id; d->efc_pos[r] = pos; d->efc_margin[r] = margin;
+  d->efc_diagApprox[r] = diagApprox;
+  double K, B, I;
+  get_solparam(d->m, solref, solimp, pos - margin, &K, &B, &I);
+  d->efc_KBIP[4*r] = K; d->efc_KBIP[4*r+1] = B; d->efc_KBIP[4*r+2] = I; d->efc_KBIP[4*r+3] = 0;
+  double R = (1-I)*diagApprox/I; if (R < MINVAL) R = MINVAL;
+  d->efc_R[r] = R;
+  d->nefc++;
+  (void)nv;
+}
+
+static void make_constraint(const OrcModel* m, OrcData* d) {
+  int nv = m->nv;
+  d->nefc = 0; d->nl = 0; d->ntl = 0;
+  double* jac1 = d->w1; double* jac2 = d->w2;
+  /* joint limits */
+  for (int j = 0; j < m->njnt; ++j) {
+    if (!m->jnt_limited[j] || m->jnt_type[j] == MYO_JNT_FREE) continue;
+    double q = d->qpos[m->jnt_qposadr[j]];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side < 0 ? q - m->jnt_range[2*j] : m->jnt_range[2*j+1] - q;
+      if (dist < m->jnt_margin[j] && d->nefc < MAXEFC) {
+        double* J = d->efc_J + d->nefc*nv; memset(J, 0, sizeof(double)*nv);
+        J[m->jnt_dofadr[j]] = -(double)side;
+        add_row(d, nv, 0, j, dist, m->jnt_margin[j], m->dof_invweight0[m->jnt_dofadr[j]],
+                m->jnt_solref + 2*j, m->jnt_solimp + 5*j);
+        d->nl++;
+      }
+    }
+  }
+  /* tendon limits */
+  for (int t = 0; t < m->ntendon; ++t) {
+    if (!m->tendon_limited[t]) continue;
+    double L = d->ten_length[t];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side < 0 ? L - m->tendon_range[2*t] : m->tendon_range[2*t+1] - L;
+      if (dist < m->tendon_margin[t] && d->nefc < MAXEFC) {
+        double* J = d->efc_J + d->nefc*nv;
+        for (int c = 0; c < nv; ++c) J[c] = -(double)side*d->ten_J[t*nv+c];
+        add_row(d, nv, 1, t, dist, m->tendon_margin[t], m->tendon_invweight0[t],
+                m->tendon_solref_lim + 2*t, m->tendon_solimp_lim + 5*t);
+        d->ntl++;
+      }
+    }
+  }
+  /* contacts: pyramidal, condim 3 -> 4 rows each */
+  for (int ci = 0; ci < d->ncon; ++ci) {
+    OrcContact* c = &d->con[ci];
+    if (c->dist >= c->includemargin) continue;
+    int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
+    jac_point(m, d, b1, c->pos, jac1); jac_point(m, d, b2, c->pos, jac2);
+    double Jf[3][64*4]; /* nv <= 256 */
+    for (int a = 0; a < 3; ++a)
+      for (int col = 0; col < nv; ++col)
+        Jf[a][col] = c->frame[3*a]*(jac2[col]-jac1[col]) + c->frame[3*a+1]*(jac2[nv+col]-jac1[nv+col]) +
+                     c->frame[3*a+2]*(jac2[2*nv+col]-jac1[2*nv+col]);
+    double tran = m->body_invweight0[2*b1] + m->body_invweight0[2*b2];
+    int first = d->nefc;
+    for (int k = 0; k < 2; ++k) {
+      double mu = c->friction[k];
+      for (int sg = 0; sg < 2; ++sg) {
+        if (d->nefc >= MAXEFC) break;
+        double* J = d->efc_J + d->nefc*nv;
+        double s = sg ? -mu : mu;
+        for (int col = 0; col < nv; ++col) J[col] = Jf[0][col] + s*Jf[1+k][col];
+        add_row(d, nv, 2, ci, c->dist, c->includemargin, tran + mu*mu*tran, c->solref, c->solimp);
+      }
+    }
+    /* pyramidal regularisation: every edge row gets Rpy = 2 mu^2 R(first row), mu = friction[0]/sqrt(impratio) */
+    if (d->nefc - first == 4) {
+      double mu = c->friction[0]/sqrt(m->impratio);
+      double Rpy = 2*mu*mu*d->efc_R[first];
+      if (Rpy < MINVAL) Rpy = MINVAL;
+      for (int r = first; r < first+4; ++r) d->efc_R[r] = Rpy;
+    }
+  }
+  for (int r = 0; r < d->nefc; ++r) d->efc_D[r] = 1/d->efc_R[r];
+}
+
+/* ------------------------------------------------------------------ P8 velocity stage */
+static void fwd_velocity(const OrcModel* m, OrcData* d) {
+  int nv = m->nv, nb = m->nbody;
+  for (int t = 0; t < m->ntendon; ++t) {
+    double s = 0; for (int c = 0; c < nv; ++c) s += d->ten_J[t*nv+c]*d->qvel[c];
+    d->ten_velocity[t] = s;
+  }
+  for (int i = 0; i < m->nu; ++i) {
+    double s = 0; for (int c = 0; c < nv; ++c) s += d->actuator_moment[i*nv+c]*d->qvel[c];
+    d->actuator_velocity[i] = s;
+  }
+  /* comVel */
+  memset(d->cvel, 0, 6*sizeof(double));
+  for (int b = 1; b < nb; ++b) {
+    double cv[6]; memcpy(cv, d->cvel + 6*m->body_parentid[b], sizeof cv);
+    int jn = m->body_jntnum[b], ja = m->body_jntadr[b];
+    for (int k = 0; k < jn; ++k) {
+      int j = ja + k, da = m->jnt_dofadr[j];
+      if (m->jnt_type[j] == MYO_JNT_FREE) {
+        memset(d->cdof_dot + 6*da, 0, 18*sizeof(double));
+        for (int a = 0; a < 3; ++a) for (int e = 0; e < 6; ++e) cv[e] += d->cdof[6*(da+a)+e]*d->qvel[da+a];
+        for (int a = 3; a < 6; ++a) cross_motion(d->cdof_dot + 6*(da+a), cv, d->cdof + 6*(da+a));
+        for (int a = 3; a < 6; ++a) for (int e = 0; e < 6; ++e) cv[e] += d->cdof[6*(da+a)+e]*d->qvel[da+a];
+      } else {
+        cross_motion(d->cdof_dot + 6*da, cv, d->cdof + 6*da);
+        for (int e = 0; e < 6; ++e) cv[e] += d->cdof[6*da+e]*d->qvel[da];
+      }
+    }
+    memcpy(d->cvel + 6*b, cv, sizeof cv);
+  }
+  /* passive */
+  for (int c = 0; c < nv; ++c) d->qfrc_passive[c] = -m->dof_damping[c]*d->qvel[c];
+  for (int j = 0; j < m->njnt; ++j) {
+    if (m->jnt_type[j] == MYO_JNT_FREE || m->jnt_stiffness[j] == 0) continue;
+    int qa = m->jnt_qposadr[j];
+    d->qfrc_passive[m->jnt_dofadr[j]] -= m->jnt_stiffness[j]*(d->qpos[qa] - m->qpos_spring[qa]);
+  }
+  for (int t = 0; t < m->ntendon; ++t) {
+    double k = m->tendon_stiffness[t], b = m->tendon_damping[t];
+    if (k == 0 && b == 0) continue;
+    double f = -k*(d->ten_length[t] - m->tendon_lengthspring[t]) - b*d->ten_velocity[t];
+    for (int c = 0; c < nv; ++c) d->qfrc_passive[c] += d->ten_J[t*nv+c]*f;
+  }
+  /* constraint reference needs efc_vel */
+  for (int r = 0; r < d->nefc; ++r) {
+    double s = 0; for (int c = 0; c < nv; ++c) s += d->efc_J[r*nv+c]*d->qvel[c];
+    d->efc_vel[r] = s;
+    d->efc_aref[r] = -d->efc_KBIP[4*r+1]*s - d->efc_KBIP[4*r]*d->efc_KBIP[4*r+2]*(d->efc_pos[r] - d->efc_margin[r]);
+  }
+  /* RNE bias */
+  double* cacc = d->cacc; double* cfrc = d->cfrc;
+  cacc[0]=cacc[1]=cacc[2]=0; cacc[3]=-m->gravity[0]; cacc[4]=-m->gravity[1]; cacc[5]=-m->gravity[2];
+  memset(cfrc, 0, 6*sizeof(double));
+  for (int b = 1; b < nb; ++b) {
+    double a[6]; memcpy(a, cacc + 6*m->body_parentid[b], sizeof a);
+    int da = m->body_dofadr[b];
+    for (int k = 0; k < m->body_dofnum[b]; ++k)
+      for (int e = 0; e < 6; ++e) a[e] += d->cdof_dot[6*(da+k)+e]*d->qvel[da+k];
+    memcpy(cacc + 6*b, a, sizeof a);
+    double t1[6], t2[6], t3[6];
+    mul_inert_vec(t1, d->cinert + 10*b, a);
+    mul_inert_vec(t2, d->cinert + 10*b, d->cvel + 6*b);
+    cross_force(t3, d->cvel + 6*b, t2);
+    for (int e = 0; e < 6; ++e) cfrc[6*b+e] = t1[e] + t3[e];
+  }
+  for (int b = nb-1; b > 0; --b) {
+    int p = m->body_parentid[b];
+    if (p > 0) for (int e = 0; e < 6; ++e) cfrc[6*p+e] += cfrc[6*b+e];
+  }
+  for (int c = 0; c < nv; ++c) {
+    double s = 0; for (int e = 0; e < 6; ++e) s += d->cdof[6*c+e]*cfrc[6*m->dof_bodyid[c]+e];
+    d->qfrc_bias[c] = s;
+  }
+}
+
+/* ------------------------------------------------------------------ P9 actuation */
+static double muscle_gain_length(double L, double lmin, double lmax) {
+  if (L < lmin || L > lmax) return 0;
+  double a = 0.5*(lmin+1), b = 0.5*(1+lmax), x;
+  if (L <= a) { x = (L-lmin)/fmax(MINVAL, a-lmin); return 0.5*x*x; }
+  if (L <= 1) { x = (1-L)/fmax(MINVAL, 1-a); return 1-0.5*x*x; }
+  if (L <= b) { x = (L-1)/fmax(MINVAL, b-1); return 1-0.5*x*x; }
+  x = (lmax-L)/fmax(MINVAL, lmax-b); return 0.5*x*x;
+}
+static double muscle_gain(double len, double vel, const double* lr, double acc0, const double* prm) {
+  double range0 = prm[0], range1 = prm[1], force = prm[2], scale = prm[3], lmin = prm[4], lmax = prm[5],
+         vmax = prm[6], fvmax = prm[8];
+  if (force < 0) force = scale/fmax(MINVAL, acc0);
+  double L0 = (lr[1]-lr[0])/fmax(MINVAL, range1-range0);
+  double L = range0 + (len-lr[0])/fmax(MINVAL, L0);
+  double V = vel/fmax(MINVAL, L0*vmax);
+  double FL = muscle_gain_length(L, lmin, lmax), FV;
+  double y = fvmax-1;
+  if (V <= -1) FV = 0;
+  else if (V <= 0) FV = (V+1)*(V+1);
+  else if (V <= y) FV = fvmax - (y-V)*(y-V)/fmax(MINVAL, y);
+  else FV = fvmax;
+  return -force*FL*FV;
+}
+static double muscle_bias(double len, const double* lr, double acc0, const double* prm) {
+  double range0 = prm[0], range1 = prm[1], force = prm[2], scale = prm[3], lmax = prm[5], fpmax = prm[7];
+  if (force < 0) force = scale/fmax(MINVAL, acc0);
+  double L0 = (lr[1]-lr[0])/fmax(MINVAL, range1-range0);
+  double L = range0 + (len-lr[0])/fmax(MINVAL, L0);
+  double b = 0.5*(1+lmax);
+  if (L <= 1) return 0;
+  if (L <= b) { double x = (L-1)/fmax(MINVAL, b-1); return -force*fpmax*0.5*x*x; }
+  double x = (L-b)/fmax(MINVAL, b-1);
+  return -force*fpmax*(0.5+x);
+}
+
+static void fwd_actuation(const OrcModel* m, OrcData* d) {
+  int nv = m->nv;
+  memset(d->qfrc_actuator, 0, sizeof(double)*nv);
+  for (int i = 0; i < m->nu; ++i) {
+    double ctrl = d->ctrl[i];
+    if (m->actuator_ctrllimited[i]) {
+      double lo = m->actuator_ctrlrange[2*i], hi = m->actuator_ctrlrange[2*i+1];
+      if (ctrl < lo) ctrl = lo; else if (ctrl > hi) ctrl = hi;
+    }
+    double input = ctrl;
+    if (m->actuator_dyntype[i] == MYO_DYN_MUSCLE) {
+      int ia = i - (m->nu - m->na);
+      double act = d->act[ia];
+      const double* prm = m->actuator_dynprm + 10*i;
+      double cc = ctrl < 0 ? 0 : (ctrl > 1 ? 1 : ctrl), ac = act < 0 ? 0 : (act > 1 ? 1 : act);
+      double tau = cc > act ? prm[0]*(0.5+1.5*ac) : prm[1]/(0.5+1.5*ac);
+      d->act_dot[ia] = (cc-act)/fmax(MINVAL, tau);
+      input = act;
+    }
+    double len = d->actuator_length[i], vel = d->actuator_velocity[i], gain, bias = 0;
+    if (m->actuator_gaintype[i] == MYO_GAIN_MUSCLE)
+      gain = muscle_gain(len, vel, m->actuator_lengthrange + 2*i, m->actuator_acc0[i], m->actuator_gainprm + 10*i);
+    else gain = m->actuator_gainprm[10*i];
+    if (m->actuator_biastype[i] == MYO_BIAS_MUSCLE)
+      bias = muscle_bias(len, m->actuator_lengthrange + 2*i, m->actuator_acc0[i], m->actuator_biasprm + 10*i);
+    else if (m->actuator_biastype[i] == MYO_BIAS_AFFINE)
+      bias = m->actuator_biasprm[10*i] + m->actuator_biasprm[10*i+1]*len + m->actuator_biasprm[10*i+2]*vel;
+    double f = gain*input + bias;
+    if (m->actuator_forcelimited[i]) {
+      double lo = m->actuator_forcerange[2*i], hi = m->actuator_forcerange[2*i+1];
+      if (f < lo) f = lo; else if (f > hi) f = hi;
+    }
+    d->actuator_force[i] = f;
+    for (int c = 0; c < nv; ++c) d->qfrc_actuator[c] += d->actuator_moment[i*nv+c]*f;
+  }
+}
+
+/* ------------------------------------------------------------------ P10 acceleration + Newton */
+static void mul_M(const OrcData* d, int nv, double* r, const double* v) {
+  for (int i = 0; i < nv; ++i) { double s = 0; for (int j = 0; j < nv; ++j) s += d->M[i*nv+j]*v[j]; r[i] = s; }
+}
+
+typedef struct { double cost, d1, d2; } LsEval;
+
+static LsEval ls_eval(const OrcData* d, double alpha, const double* jar, const double* jv, const double* qg) {
+  LsEval e; e.cost = alpha*alpha*qg[2] + alpha*qg[1] + qg[0]; e.d1 = 2*alpha*qg[2] + qg[1]; e.d2 = 2*qg[2];
+  for (int r = 0; r < d->nefc; ++r) {
+    double x = jar[r] + alpha*jv[r];
+    if (x < 0) { double D = d->efc_D[r]; e.cost += 0.5*D*x*x; e.d1 += D*x*jv[r]; e.d2 += D*jv[r]*jv[r]; }
+  }
+  return e;
+}
+
+static double constraint_update(OrcData* d, int nv, const double* jar, const double* qacc, const double* Ma,
+                                double* grad, int* nactive_changed, unsigned char* active) {
+  double cost = 0; int changed = 0;
+  memset(d->qfrc_constraint, 0, sizeof(double)*nv);
+  for (int r = 0; r < d->nefc; ++r) {
+    unsigned char a = jar[r] < 0;
+    if (a != active[r]) changed = 1;
+    active[r] = a;
+    if (a) { d->efc_force[r] = -d->efc_D[r]*jar[r]; cost += 0.5*d->efc_D[r]*jar[r]*jar[r]; }
+    else d->efc_force[r] = 0;
+    if (a) for (int c = 0; c < nv; ++c) d->qfrc_constraint[c] += d->efc_J[r*nv+c]*d->efc_force[r];
+  }
+  double g = 0;
+  for (int c = 0; c < nv; ++c) g += (Ma[c]-d->qfrc_smooth[c])*(qacc[c]-d->qacc_smooth[c]);
+  cost += 0.5*g;
+  for (int c = 0; c < nv; ++c) grad[c] = Ma[c] - d->qfrc_smooth[c] - d->qfrc_constraint[c];
+  *nactive_changed = changed;
+  return cost;
+}
+
+static void newton_solve(const OrcModel* m, OrcData* d) {
+  int nv = m->nv, ne = d->nefc;
+  double* qacc = d->qacc;
+  double *Ma = d->w1, *jar = d->w2, *grad = d->w3, *search = d->w4, *Mv = d->w5;
+  double jv[MAXEFC]; unsigned char active[MAXEFC];
+  memset(active, 2, sizeof active);
+  /* warm start: pick the cheaper of qacc_warmstart and qacc_smooth */
+  {
+    double costw = 0, costs = 0;
+    mul_M(d, nv, Ma, d->qacc_warmstart);
+    for (int r = 0; r < ne; ++r) {
+      double xw = -d->efc_aref[r], xs = -d->efc_aref[r];
+      for (int c = 0; c < nv; ++c) { xw += d->efc_J[r*nv+c]*d->qacc_warmstart[c]; xs += d->efc_J[r*nv+c]*d->qacc_smooth[c]; }
+      if (xw < 0) costw += 0.5*d->efc_D[r]*xw*xw;
+      if (xs < 0) costs += 0.5*d->efc_D[r]*xs*xs;
+    }
+    double g = 0;
+    for (int c = 0; c < nv; ++c) g += (Ma[c]-d->qfrc_smooth[c])*(d->qacc_warmstart[c]-d->qacc_smooth[c]);
+    costw += 0.5*g;
+    memcpy(qacc, costw < costs ? d->qacc_warmstart : d->qacc_smooth, sizeof(double)*nv);
+  }
+  mul_M(d, nv, Ma, qacc);
+  for (int r = 0; r < ne; ++r) { double s = -d->efc_aref[r]; for (int c = 0; c < nv; ++c) s += d->efc_J[r*nv+c]*qacc[c]; jar[r] = s; }
+  int changed;
+  double cost = constraint_update(d, nv, jar, qacc, Ma, grad, &changed, active);
+  double scale = 1/(m->meaninertia*(nv > 1 ? nv : 1));
+  int iter = 0;
+  double* H = d->H;
+  for (; iter < m->iterations; ) {
+    /* Hessian H = M + J' D_active J, Cholesky, search = -H^-1 grad */
+    memcpy(H, d->M, sizeof(double)*nv*nv);
+    for (int r = 0; r < ne; ++r) if (active[r]) {
+      const double* J = d->efc_J + r*nv; double D = d->efc_D[r];
+      for (int i = 0; i < nv; ++i) if (J[i] != 0) { double t = D*J[i]; for (int j = 0; j < nv; ++j) H[i*nv+j] += t*J[j]; }
+    }
+    chol_factor(H, H, nv);
+    for (int c = 0; c < nv; ++c) search[c] = -grad[c];
+    chol_solve(H, search, nv);
+    /* exact line search on the piecewise-quadratic cost */
+    mul_M(d, nv, Mv, search);
+    for (int r = 0; r < ne; ++r) { double s = 0; for (int c = 0; c < nv; ++c) s += d->efc_J[r*nv+c]*search[c]; jv[r] = s; }
+    double qg[3] = {0, 0, 0}, snorm = 0;
+    for (int c = 0; c < nv; ++c) {
+      qg[1] += search[c]*(Ma[c]-d->qfrc_smooth[c]); qg[2] += 0.5*search[c]*Mv[c]; snorm += search[c]*search[c];
+    }
+    snorm = sqrt(snorm);
+    if (snorm < MINVAL) break;
+    double gtol = m->tolerance*LS_TOL*snorm/scale;
+    double alpha = 0, lo = 0, hi = -1;
+    LsEval e = ls_eval(d, 0, jar, jv, qg);
+    for (int li = 0; li < LS_ITER; ++li) {
+      if (fabs(e.d1) < gtol) break;
+      if (e.d1 < 0) lo = alpha; else hi = alpha;
+      double next = alpha - e.d1/e.d2;
+      if (hi >= 0 && (next <= lo || next >= hi)) next = 0.5*(lo+hi);
+      if (next == alpha) break;
+      alpha = next;
+      e = ls_eval(d, alpha, jar, jv, qg);
+    }
+    if (alpha == 0) break;
+    for (int c = 0; c < nv; ++c) { qacc[c] += alpha*search[c]; Ma[c] += alpha*Mv[c]; }
+    for (int r = 0; r < ne; ++r) jar[r] += alpha*jv[r];
+    double oldcost = cost;
+    cost = constraint_update(d, nv, jar, qacc, Ma, grad, &changed, active);
+    iter++;
+    double gn = 0; for (int c = 0; c < nv; ++c) gn += grad[c]*grad[c];
+    double improvement = scale*(oldcost-cost), gradient = scale*sqrt(gn);
+    if (improvement < m->tolerance || gradient < m->tolerance) break;
+  }
+  d->solver_iter = iter;
+}
+
+static void fwd_acceleration(const OrcModel* m, OrcData* d) {
+  int nv = m->nv;
+  for (int c = 0; c < nv; ++c) d->qfrc_smooth[c] = d->qfrc_passive[c] - d->qfrc_bias[c] + d->qfrc_actuator[c];
+  memcpy(d->qacc_smooth, d->qfrc_smooth, sizeof(double)*nv);
+  chol_solve(d->Mchol, d->qacc_smooth, nv);
+  if (d->nefc == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double)*nv);
+    memset(d->qfrc_constraint, 0, sizeof(double)*nv);
+    d->solver_iter = 0;
+    return;
+  }
+  newton_solve(m, d);
+}
+
+void orc_fwd_position(const OrcModel* m, OrcData* d) {
+  orc_kinematics(m, d);
+  com_pos(m, d);
+  tendon(m, d);
+  transmission(m, d);
+  crb(m, d);
+  collision(m, d);
+  make_constraint(m, d);
+}
+
+void orc_forward(const OrcModel* m, OrcData* d) {
+  orc_fwd_position(m, d);
+  fwd_velocity(m, d);
+  fwd_actuation(m, d);
+  fwd_acceleration(m, d);
+}
+
+/* ------------------------------------------------------------------ P11 integrators */
+static void integrate_pos(const OrcModel* m, double* qpos, const double* qvel, double h) {
+  for (int j = 0; j < m->njnt; ++j) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == MYO_JNT_FREE) {
+      for (int k = 0; k < 3; ++k) qpos[qa+k] += h*qvel[da+k];
+      double w[3] = { qvel[da+3], qvel[da+4], qvel[da+5] };
+      double ang = h*norm3(w);
+      if (ang > 0) {
+        double ax[3] = { w[0], w[1], w[2] }, qr[4];
+        normalize3(ax);
+        axisangle2quat(qr, ax, ang);
+        mulquat(qpos+qa+3, qpos+qa+3, qr);
+      }
+      normalize4(qpos+qa+3);
+    } else qpos[qa] += h*qvel[da];
+  }
+}
+
+static void advance(const OrcModel* m, OrcData* d, const double* act_dot, const double* qacc, const double* qvel_for_pos) {
+  double h = m->timestep;
+  for (int i = 0; i < m->na; ++i) {
+    d->act[i] += h*act_dot[i];
+    int iu = i + (m->nu - m->na);
+    if (m->actuator_dyntype[iu] == MYO_DYN_MUSCLE) { if (d->act[i] < 0) d->act[i] = 0; else if (d->act[i] > 1) d->act[i] = 1; }
+  }
+  for (int c = 0; c < m->nv; ++c) d->qvel[c] += h*qacc[c];
+  integrate_pos(m, d->qpos, qvel_for_pos ? qvel_for_pos : d->qvel, h);
+  d->time += h;
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double)*m->nv);
+}
+
+static void check_state(const OrcModel* m, OrcData* d) {
+  for (int i = 0; i < m->nq; ++i) if (!isfinite(d->qpos[i]) || fabs(d->qpos[i]) > 1e10) d->bad = 1;
+  for (int i = 0; i < m->nv; ++i) if (!isfinite(d->qvel[i]) || fabs(d->qvel[i]) > 1e10) d->bad = 1;
+}
+
+static void euler(const OrcModel* m, OrcData* d) {
+  int nv = m->nv; int damped = 0;
+  for (int c = 0; c < nv; ++c) if (m->dof_damping[c] > 0) damped = 1;
+  if (!damped) { advance(m, d, d->act_dot, d->qacc, NULL); return; }
+  double* H = d->H; double* qa = d->w1;
+  memcpy(H, d->M, sizeof(double)*nv*nv);
+  for (int c = 0; c < nv; ++c) { H[c*nv+c] += m->timestep*m->dof_damping[c]; qa[c] = d->qfrc_smooth[c] + d->qfrc_constraint[c]; }
+  chol_factor(H, H, nv);
+  chol_solve(H, qa, nv);
+  advance(m, d, d->act_dot, qa, NULL);
+}
+
+static void rk4(const OrcModel* m, OrcData* d) {
+  static const double A[9] = {0.5,0,0, 0,0.5,0, 0,0,1}, B[4] = {1.0/6,1.0/3,1.0/3,1.0/6};
+  int nq = m->nq, nv = m->nv, na = m->na; double h = m->timestep, t0 = d->time;
+  double *X0q = (double*)malloc(sizeof(double)*(nq+nv+na)), *F[4];
+  double *X0v = X0q+nq, *X0a = X0v+nv;
+  memcpy(X0q, d->qpos, sizeof(double)*nq); memcpy(X0v, d->qvel, sizeof(double)*nv); memcpy(X0a, d->act, sizeof(double)*na);
+  for (int i = 0; i < 4; ++i) F[i] = (double*)malloc(sizeof(double)*(2*nv+na));
+  double* dX = (double*)malloc(sizeof(double)*(2*nv+na));
+  memcpy(F[0], d->qvel, sizeof(double)*nv); memcpy(F[0]+nv, d->qacc, sizeof(double)*nv); memcpy(F[0]+2*nv, d->act_dot, sizeof(double)*na);
+  for (int i = 1; i < 4; ++i) {
+    memset(dX, 0, sizeof(double)*(2*nv+na));
+    for (int j = 0; j < i; ++j) for (int k = 0; k < 2*nv+na; ++k) dX[k] += A[(i-1)*3+j]*F[j][k];
+    memcpy(d->qpos, X0q, sizeof(double)*nq);
+    integrate_pos(m, d->qpos, dX, h);
+    for (int k = 0; k < nv; ++k) d->qvel[k] = X0v[k] + h*dX[nv+k];
+    for (int k = 0; k < na; ++k) d->act[k] = X0a[k] + h*dX[2*nv+k];
+    double c = 0; for (int j = 0; j < i; ++j) c += A[(i-1)*3+j];
+    d->time = t0 + h*c;
+    orc_forward(m, d);
+    memcpy(F[i], d->qvel, sizeof(double)*nv); memcpy(F[i]+nv, d->qacc, sizeof(double)*nv); memcpy(F[i]+2*nv, d->act_dot, sizeof(double)*na);
+  }
+  memset(dX, 0, sizeof(double)*(2*nv+na));
+  for (int j = 0; j < 4; ++j) for (int k = 0; k < 2*nv+na; ++k) dX[k] += B[j]*F[j][k];
+  memcpy(d->qpos, X0q, sizeof(double)*nq); memcpy(d->qvel, X0v, sizeof(double)*nv); memcpy(d->act, X0a, sizeof(double)*na);
+  d->time = t0;
+  advance(m, d, dX+2*nv, dX+nv, dX);
+  for (int i = 0; i < 4; ++i) free(F[i]);
+  free(dX); free(X0q);
+}
+
+void orc_step(const OrcModel* m, OrcData* d) {
+  check_state(m, d);
+  orc_forward(m, d);
+  for (int c = 0; c < m->nv; ++c) if (!isfinite(d->qacc[c]) || fabs(d->qacc[c]) > 1e10) d->bad = 1;
+  if (m->integrator == MYO_INT_RK4) rk4(m, d); else euler(m, d);
+}
+
+/* ------------------------------------------------------------------ Baoding task layer */
+void orc_baoding_obs(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg, double* obs) {
+  /* layout: SURVEY.md §8a-T1 (pinned by tests/golden/reset_obs_golden.npy, obs_snapshots.npz) */
+  double dt = cfg->frame_skip*m->timestep;
+  int nh = cfg->n_hand, o = 0;
+  for (int i = 0; i < nh; ++i) obs[o++] = d->qpos[i];
+  int nv = m->nv;
+  const double* s1 = d->site_xpos + 3*cfg->obj1_sid; const double* s2 = d->site_xpos + 3*cfg->obj2_sid;
+  const double* t1 = d->site_xpos + 3*cfg->target1_sid; const double* t2 = d->site_xpos + 3*cfg->target2_sid;
+  for (int k = 0; k < 3; ++k) obs[o++] = s1[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = d->qvel[nv-12+k]*dt;
+  for (int k = 0; k < 3; ++k) obs[o++] = s2[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = d->qvel[nv-6+k]*dt;
+  for (int k = 0; k < 3; ++k) obs[o++] = t1[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = t2[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = t1[k]-s1[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = t2[k]-s2[k];
+  for (int i = 0; i < m->na; ++i) obs[o++] = d->act[i];
+}
+
+void orc_baoding_reward(const OrcBaodingCfg* cfg, int na, const double* obs, double* c) {
+  /* restates /root/reference/src/envs/baoding.py:24-94 (P1) == :403-467 (P2) */
+  int nh = cfg->n_hand;
+  const double* e1 = obs + nh + 18; const double* e2 = obs + nh + 21; const double* act = obs + nh + 24;
+  double d1 = sqrt(e1[0]*e1[0]+e1[1]*e1[1]+e1[2]*e1[2]), d2 = sqrt(e2[0]*e2[0]+e2[1]*e2[1]+e2[2]*e2[2]);
+  double am = 0; for (int i = 0; i < na; ++i) am += act[i]*act[i];
+  am = na ? sqrt(am)/na : 0;
+  int fall = (obs[nh+2] < cfg->drop_th) || (obs[nh+8] < cfg->drop_th);
+  c[0] = -d1; c[1] = -d2; c[2] = -am; c[3] = fall ? 0 : 1; c[4] = -(d1+d2);
+  c[5] = (d1 < cfg->proximity_th) && (d2 < cfg->proximity_th) && !fall; c[6] = fall;
+  double dense = 0; for (int k = 0; k < 7; ++k) dense += cfg->w[k]*c[k];
+  c[7] = dense;
+}
+
+void orc_baoding_step(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg, OrcBaodingState* st,
+                      const float* action, double* obs, double* comps) {
+  /* BaodingEnvV1.step [3P-RECALL, SURVEY §3.3]: place targets from the goal schedule, then BaseV0.step */
+  double dt = cfg->frame_skip*m->timestep;
+  if (st->which_task != 0) {
+    double sign = st->which_task == 1 ? -1.0 : 1.0;
+    double ang = sign*2*M_PI*(st->counter*dt/st->time_period);
+    double a1 = ang + st->start_angle[0], a2 = ang + st->start_angle[1];
+    d->site_pos[3*cfg->target1_sid]   = st->x_radius*cos(a1) + cfg->center_pos[0];
+    d->site_pos[3*cfg->target1_sid+1] = st->y_radius*sin(a1) + cfg->center_pos[1];
+    d->site_pos[3*cfg->target2_sid]   = st->x_radius*cos(a2) + cfg->center_pos[0];
+    d->site_pos[3*cfg->target2_sid+1] = st->y_radius*sin(a2) + cfg->center_pos[1];
+  }
+  st->counter++;
+  for (int i = 0; i < m->nu; ++i) { /* normalize_act: float32 sigmoid(5(a-0.5)) after clip */
+    float a = action[i]; if (a < -1.f) a = -1.f; else if (a > 1.f) a = 1.f;
+    float c = 1.0f/(1.0f + expf(-5.0f*(a-0.5f)));
+    d->ctrl[i] = (double)c;
+  }
+  for (int k = 0; k < cfg->frame_skip; ++k) orc_step(m, d);
+  orc_kinematics(m, d);
+  orc_baoding_obs(m, d, cfg, obs);
+  orc_baoding_reward(cfg, m->na, obs, comps);
+}

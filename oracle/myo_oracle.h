@@ -1,0 +1,79 @@
+/* myo_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar fp64 CPU restatement of the hot path the reference executes through third-party
+ * code: MyoSuite's BaodingEnvV1.step -> MuJoCo 2.1 mj_step x frame_skip
+ * (call stack: SURVEY.md §3.3; reference call sites /root/reference/src/envs/baoding.py:179,
+ * 183,206,608,625,632 and the inherited step).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY STATUS
+ *   - statics at qpos0 (FK, tendon wrapping, inertia, M^-1, moment arms): PINNED against the
+ *     MuJoCo-computed constants embedded in the three .mjb files the reference ships
+ *     (tests/test_oracle_statics.py).
+ *   - task layer (obs layout, reward, termination, goal schedule): PINNED against golden
+ *     vectors produced by importing /root/reference/src/envs/baoding.py (tools/make_golden.py).
+ *   - stepping (constraint solver, contacts, integrators): PARITY UNPINNED.  MuJoCo 2.1.x
+ *     (free-mujoco-py==2.1.6), MyoSuite==1.2.3 are absent from /root/reference and from this
+ *     image, and the reference has no tests or trajectories; the algorithm below restates the
+ *     published MuJoCo 2.1 pipeline and is checked by self-consistency
+ *     (energy, KKT residual, finite differences) only.
+ */
+#ifndef MYO_ORACLE_H
+#define MYO_ORACLE_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcModel OrcModel;
+typedef struct OrcData OrcData;
+
+OrcModel* orc_model_from_blob(const void* blob, size_t nbytes, char* err, int errlen);
+void orc_model_free(OrcModel* m);
+int orc_model_int(const OrcModel* m, const char* name); /* nq, nv, nu, ... */
+
+OrcData* orc_data_new(const OrcModel* m);
+void orc_data_free(OrcData* d);
+void orc_reset(const OrcModel* m, OrcData* d); /* qpos0, zero velocity/activation */
+
+/* named access to per-env arrays (qpos, qvel, act, ctrl, xpos, ten_length, ten_J, M, ...) */
+double* orc_ptr(OrcData* d, const char* name);
+int orc_count(const OrcData* d, const char* name);
+int orc_get_int(const OrcData* d, const char* name); /* ncon, nefc, solver_iter, bad */
+
+void orc_fwd_position(const OrcModel* m, OrcData* d);
+void orc_forward(const OrcModel* m, OrcData* d);
+void orc_step(const OrcModel* m, OrcData* d);
+/* kinematics only (what MyoSuite's observation sim does before get_obs) */
+void orc_kinematics(const OrcModel* m, OrcData* d);
+
+/* ---- Baoding task layer ---------------------------------------- */
+typedef struct OrcBaodingCfg {
+  int frame_skip;
+  int obj1_sid, obj2_sid, target1_sid, target2_sid;
+  int obj1_bid, obj2_bid, obj1_gid, obj2_gid;
+  int n_hand; /* qpos[:n_hand] = hand_pos */
+  double drop_th, proximity_th;
+  double center_pos[2];
+  /* weights in the order pos_dist_1,pos_dist_2,act_reg,alive,sparse,solved,done */
+  double w[7];
+} OrcBaodingCfg;
+
+typedef struct OrcBaodingState {
+  int which_task; /* 0 hold, 1 cw, 2 ccw */
+  int counter;
+  double start_angle[2];
+  double x_radius, y_radius, time_period;
+} OrcBaodingState;
+
+/* one env.step(a): goal placement, sigmoid action map, frame_skip physics steps, obs, reward.
+ * comps = pos_dist_1,pos_dist_2,act_reg,alive,sparse,solved,done,dense */
+void orc_baoding_step(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg,
+                      OrcBaodingState* st, const float* action, double* obs, double* comps);
+void orc_baoding_obs(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg, double* obs);
+void orc_baoding_reward(const OrcBaodingCfg* cfg, int na, const double* obs, double* comps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,165 @@
+"""ctypes wrapper around oracle/libmyo_oracle.so — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(parity status: see oracle/myo_oracle.h — statics and task layer pinned, stepping unpinned).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libmyo_oracle.so")
+    src = os.path.join(_HERE, "myo_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_model_from_blob.restype = C.c_void_p
+        L.orc_model_from_blob.argtypes = [C.c_void_p, C.c_size_t, C.c_char_p, C.c_int]
+        L.orc_model_free.argtypes = [C.c_void_p]
+        L.orc_model_int.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_data_new.restype = C.c_void_p
+        L.orc_data_new.argtypes = [C.c_void_p]
+        L.orc_data_free.argtypes = [C.c_void_p]
+        L.orc_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_ptr.restype = C.POINTER(C.c_double)
+        L.orc_ptr.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_count.argtypes = [C.c_void_p, C.c_char_p]
+        L.orc_get_int.argtypes = [C.c_void_p, C.c_char_p]
+        for f in ("orc_fwd_position", "orc_forward", "orc_step", "orc_kinematics"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_baoding_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.POINTER(C.c_float), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double)]
+        L.orc_baoding_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_baoding_reward.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double)]
+        _LIB = L
+    return _LIB
+
+
+class BaodingCfg(C.Structure):
+    _fields_ = [("frame_skip", C.c_int), ("obj1_sid", C.c_int), ("obj2_sid", C.c_int),
+                ("target1_sid", C.c_int), ("target2_sid", C.c_int), ("obj1_bid", C.c_int),
+                ("obj2_bid", C.c_int), ("obj1_gid", C.c_int), ("obj2_gid", C.c_int),
+                ("n_hand", C.c_int), ("drop_th", C.c_double), ("proximity_th", C.c_double),
+                ("center_pos", C.c_double * 2), ("w", C.c_double * 7)]
+
+
+class BaodingState(C.Structure):
+    _fields_ = [("which_task", C.c_int), ("counter", C.c_int), ("start_angle", C.c_double * 2),
+                ("x_radius", C.c_double), ("y_radius", C.c_double), ("time_period", C.c_double)]
+
+
+REWARD_KEYS = ("pos_dist_1", "pos_dist_2", "act_reg", "alive", "sparse", "solved", "done")
+
+
+class OracleModel:
+    def __init__(self, blob: bytes):
+        self._blob = blob
+        err = C.create_string_buffer(256)
+        buf = C.create_string_buffer(blob, len(blob))
+        self.h = lib().orc_model_from_blob(buf, len(blob), err, 256)
+        if not self.h:
+            raise ValueError(err.value.decode())
+
+    def __getattr__(self, name):
+        v = lib().orc_model_int(self.h, name.encode())
+        if v < 0:
+            raise AttributeError(name)
+        return v
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_model_free(self.h)
+            self.h = None
+
+
+class OracleData:
+    def __init__(self, model: OracleModel):
+        self.model = model
+        self.h = lib().orc_data_new(model.h)
+
+    def arr(self, name, shape=None):
+        n = lib().orc_count(self.h, name.encode())
+        if name == "time":
+            n = 1
+        if n < 0:
+            raise KeyError(name)
+        p = lib().orc_ptr(self.h, name.encode())
+        a = np.ctypeslib.as_array(p, shape=(max(n, 1),))[:n]
+        return a.reshape(shape) if shape else a
+
+    def __getattr__(self, name):
+        if name in ("ncon", "nefc", "solver_iter", "bad", "nl", "ntl"):
+            return lib().orc_get_int(self.h, name.encode())
+        try:
+            return self.arr(name)
+        except KeyError as exc:
+            raise AttributeError(name) from exc
+
+    def reset(self):
+        lib().orc_reset(self.model.h, self.h)
+
+    def fwd_position(self):
+        lib().orc_fwd_position(self.model.h, self.h)
+
+    def forward(self):
+        lib().orc_forward(self.model.h, self.h)
+
+    def step(self):
+        lib().orc_step(self.model.h, self.h)
+
+    def kinematics(self):
+        lib().orc_kinematics(self.model.h, self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_data_free(self.h)
+            self.h = None
+
+
+def make_cfg(ids: dict, frame_skip=10, drop_th=1.25, proximity_th=0.015, weights=None,
+             n_hand=23, center_pos=(-0.0125, -0.07)):
+    cfg = BaodingCfg()
+    cfg.frame_skip = frame_skip
+    for k in ("obj1_sid", "obj2_sid", "target1_sid", "target2_sid", "obj1_bid", "obj2_bid",
+              "obj1_gid", "obj2_gid"):
+        setattr(cfg, k, int(ids[k]))
+    cfg.n_hand = n_hand
+    cfg.drop_th, cfg.proximity_th = drop_th, proximity_th
+    cfg.center_pos[0], cfg.center_pos[1] = center_pos
+    weights = weights or {"pos_dist_1": 5.0, "pos_dist_2": 5.0}
+    for i, k in enumerate(REWARD_KEYS):
+        cfg.w[i] = float(weights.get(k, 0.0))
+    return cfg
+
+
+def baoding_reward(cfg, obs, na=39):
+    obs = np.ascontiguousarray(obs, np.float64)
+    out = np.zeros(8)
+    lib().orc_baoding_reward(C.byref(cfg), na, obs.ctypes.data_as(C.POINTER(C.c_double)),
+                             out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def baoding_step(data: OracleData, cfg, st, action):
+    a = np.ascontiguousarray(action, np.float32)
+    obs = np.zeros(cfg.n_hand + 24 + data.model.na)
+    comps = np.zeros(8)
+    lib().orc_baoding_step(data.model.h, data.h, C.byref(cfg), C.byref(st),
+                           a.ctypes.data_as(C.POINTER(C.c_float)),
+                           obs.ctypes.data_as(C.POINTER(C.c_double)),
+                           comps.ctypes.data_as(C.POINTER(C.c_double)))
+    return obs, comps

@@ -1,0 +1,512 @@
+"""SYNTHETIC MyoHand-shaped stand-in for the missing ``myo_hand_baoding.mjb``.
+
+The reference registers its Baoding environments on
+``data/myosuite/assets/hand/myo_hand_baoding.mjb``
+(/root/reference/src/envs/__init__.py:17,63) but that file is a stripped blob
+(/root/reference/.MISSING_LARGE_BLOBS:3).  Everything the reference pins about it is
+reproduced here; everything else is invented and labelled synthetic:
+
+pinned by the reference
+  * 39 muscle actuators (``np.zeros(39)``, baoding.py:183), 23 hand joints + two free balls:
+    nq=37, nv=35 (baoding.py:187-194,282), obs = 86;
+  * joint order: 0 pro_sup, 1 deviation, 2 flexion, 3-6 thumb, then four fingers of
+    (mcp_flexion, mcp_abduction, pip, dip) — baoding.py:101-142 (palm/thumb/finger/abduction
+    index sets of the reset noise);
+  * names ``ball1``/``ball2`` (bodies, geoms), ``ball1_site``, ``ball2_site``,
+    ``target1_site``, ``target2_site`` (baoding.py:264-269,371-378);
+  * ball nominal radius 0.022, mass 0.043, friction (1, 0.005, 0.0001)
+    (src/envs/__init__.py:70-72 comments); ball start positions, and the world position of
+    both target sites at the init pose ``qpos=[-1.57,0,…]`` — taken from the decoded reset
+    observation tests/golden/reset_obs_golden.npy, so the stand-in reproduces that
+    observation (FK known answer);
+  * muscle names: the 39 MyoHand muscles; muscle parameter rows follow the layout decoded
+    from the shipped finger model;
+  * option block of the only decodable MyoSuite model: timestep 0.002, Euler, Newton,
+    pyramidal cone, 100 iterations, tolerance 1e-8.
+
+invented (geometry, inertias, tendon routing, strengths, joint ranges).  Numbers measured
+on this model describe the COST SHAPE of the real task (35 dofs, 39 wrapped tendons, ball
+contacts), not its biomechanics.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .mathutil import axis_angle_quat, mat_to_quat, quat_mul, quat_to_mat
+from .mjb import MjbModel
+from .setconst import set_const
+
+ASSET = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "synth_myohand_baoding.npz")
+
+MUSCLES = ("ECRL ECRB ECU FCR FCU PL PT PQ FDS5 FDS4 FDS3 FDS2 FDP5 FDP4 FDP3 FDP2 EDC5 EDC4 "
+           "EDC3 EDC2 EDM EIP EPL EPB FPL APL OP RI2 LU_RB2 UI_UB2 RI3 LU_RB3 UI_UB3 RI4 LU_RB4 "
+           "UI_UB4 RI5 LU_RB5 UI_UB5").split()
+assert len(MUSCLES) == 39
+
+BALL1 = np.array([-0.227, -0.511, 1.452])
+BALL2 = np.array([-0.256, -0.552, 1.442])
+TARGET1 = np.array([-0.215914, -0.510662, 1.445070])   # overwritten from the golden file
+TARGET2 = np.array([-0.255075, -0.546083, 1.450521])
+CENTER = np.array([-0.0125, -0.07])
+BALL_R = 0.022
+
+
+class _Builder:
+    def __init__(self):
+        self.body = [dict(name="world", parent=0, pos=np.zeros(3), quat=np.array([1.0, 0, 0, 0]),
+                          mass=0.0, inertia=np.zeros(3), ipos=np.zeros(3))]
+        self.jnt, self.geom, self.site, self.tendon, self.wrap, self.act = [], [], [], [], [], []
+
+    def add_body(self, name, parent, pos, quat=(1, 0, 0, 0), mass=0.0, inertia=(0, 0, 0), ipos=(0, 0, 0)):
+        self.body.append(dict(name=name, parent=parent, pos=np.array(pos, float),
+                              quat=np.array(quat, float), mass=float(mass),
+                              inertia=np.array(inertia, float), ipos=np.array(ipos, float)))
+        return len(self.body) - 1
+
+    def add_joint(self, name, body, jtype, pos=(0, 0, 0), axis=(0, 0, 1), rng=(0, 0), damping=0.05,
+                  armature=0.001):
+        self.jnt.append(dict(name=name, body=body, type=jtype, pos=np.array(pos, float),
+                             axis=np.array(axis, float) / max(1e-30, np.linalg.norm(axis)),
+                             range=tuple(rng), damping=damping, armature=armature))
+        return len(self.jnt) - 1
+
+    def add_geom(self, name, body, gtype, size, pos=(0, 0, 0), quat=(1, 0, 0, 0), collide=0,
+                 friction=(1.0, 0.005, 0.0001)):
+        size = list(size) + [0.0] * (3 - len(size))
+        self.geom.append(dict(name=name, body=body, type=gtype, size=np.array(size, float),
+                              pos=np.array(pos, float), quat=np.array(quat, float),
+                              collide=collide, friction=np.array(friction, float)))
+        return len(self.geom) - 1
+
+    def add_site(self, name, body, pos):
+        self.site.append(dict(name=name, body=body, pos=np.array(pos, float)))
+        return len(self.site) - 1
+
+    def add_tendon(self, name, path):
+        """path: list of ("site", sid) | ("cyl"/"sph", gid, sidesite_or_-1)."""
+        adr = len(self.wrap)
+        for el in path:
+            if el[0] == "site":
+                self.wrap.append((3, el[1], 0.0))
+            else:
+                self.wrap.append((5 if el[0] == "cyl" else 4, el[1], float(el[2])))
+        self.tendon.append(dict(name=name, adr=adr, num=len(path)))
+        return len(self.tendon) - 1
+
+    def add_muscle(self, name, tendon, force):
+        self.act.append(dict(name=name, tendon=tendon, force=force))
+
+    def finish(self) -> MjbModel:
+        nb, nj, ng, ns = len(self.body), len(self.jnt), len(self.geom), len(self.site)
+        nt, nw, nu = len(self.tendon), len(self.wrap), len(self.act)
+        # joints must be grouped by body in body order
+        order = sorted(range(nj), key=lambda j: (self.jnt[j]["body"], j))
+        assert order == list(range(nj)), "add joints in body order"
+        A = {}
+        jb = np.array([j["body"] for j in self.jnt], np.int32)
+        jt = np.array([j["type"] for j in self.jnt], np.int32)
+        qn = np.where(jt == 0, 7, 1)
+        dn = np.where(jt == 0, 6, 1)
+        qadr = np.concatenate([[0], np.cumsum(qn)[:-1]]).astype(np.int32)
+        dadr = np.concatenate([[0], np.cumsum(dn)[:-1]]).astype(np.int32)
+        nq, nv = int(qn.sum()), int(dn.sum())
+        par = np.array([b["parent"] for b in self.body], np.int32)
+        A["body_parentid"] = par
+        root = np.zeros(nb, np.int32)
+        for b in range(1, nb):
+            root[b] = b if par[b] == 0 else root[par[b]]
+        A["body_rootid"] = root
+        jntnum = np.array([(jb == b).sum() for b in range(nb)], np.int32)
+        jntadr = np.array([int(np.argmax(jb == b)) if jntnum[b] else -1 for b in range(nb)], np.int32)
+        A["body_jntnum"], A["body_jntadr"] = jntnum, jntadr
+        dofnum = np.array([int(dn[jb == b].sum()) for b in range(nb)], np.int32)
+        dofadr = np.array([int(dadr[jntadr[b]]) if jntnum[b] else -1 for b in range(nb)], np.int32)
+        A["body_dofnum"], A["body_dofadr"] = dofnum, dofadr
+        weld = np.zeros(nb, np.int32)
+        for b in range(1, nb):
+            weld[b] = b if jntnum[b] else weld[par[b]]
+        A["body_weldid"] = weld
+        A["body_pos"] = np.array([b["pos"] for b in self.body])
+        A["body_quat"] = np.array([b["quat"] / np.linalg.norm(b["quat"]) for b in self.body])
+        A["body_ipos"] = np.array([b["ipos"] for b in self.body])
+        A["body_iquat"] = np.tile([1.0, 0, 0, 0], (nb, 1))
+        A["body_mass"] = np.array([b["mass"] for b in self.body])
+        A["body_inertia"] = np.array([b["inertia"] for b in self.body])
+        A["body_invweight0"] = np.zeros((nb, 2))
+        A["jnt_type"], A["jnt_qposadr"], A["jnt_dofadr"], A["jnt_bodyid"] = jt, qadr, dadr, jb
+        A["jnt_limited"] = np.array([0 if j["type"] == 0 else 1 for j in self.jnt], np.uint8)
+        A["jnt_solref"] = np.tile([0.02, 1.0], (nj, 1))
+        A["jnt_solimp"] = np.tile([0.9, 0.95, 0.001, 0.5, 2.0], (nj, 1))
+        A["jnt_pos"] = np.array([j["pos"] for j in self.jnt])
+        A["jnt_axis"] = np.array([j["axis"] for j in self.jnt])
+        A["jnt_stiffness"] = np.zeros(nj)
+        A["jnt_range"] = np.array([j["range"] for j in self.jnt], float)
+        A["jnt_margin"] = np.zeros(nj)
+        dof_body, dof_jnt, dof_par = np.zeros(nv, np.int32), np.zeros(nv, np.int32), np.zeros(nv, np.int32)
+        damping, armature = np.zeros(nv), np.zeros(nv)
+        last_dof_of_body = {}
+        for j in range(nj):
+            b = int(jb[j])
+            for k in range(int(dn[j])):
+                d = int(dadr[j]) + k
+                dof_body[d], dof_jnt[d] = b, j
+                if d > 0 and dof_body[d - 1] == b:
+                    dof_par[d] = d - 1
+                else:
+                    p = int(par[b])
+                    while p > 0 and p not in last_dof_of_body:
+                        p = int(par[p])
+                    dof_par[d] = last_dof_of_body.get(p, -1)
+                last_dof_of_body[b] = d
+                damping[d] = 0.0 if jt[j] == 0 else self.jnt[j]["damping"]
+                armature[d] = 0.0 if jt[j] == 0 else self.jnt[j]["armature"]
+        A["dof_bodyid"], A["dof_jntid"], A["dof_parentid"] = dof_body, dof_jnt, dof_par
+        A["dof_armature"], A["dof_damping"] = armature, damping
+        A["dof_frictionloss"] = np.zeros(nv)
+        A["dof_invweight0"] = np.zeros(nv)
+        A["dof_M0"] = np.zeros(nv)
+        qpos0 = np.zeros(nq)
+        for j in range(nj):
+            if jt[j] == 0:
+                b = self.body[jb[j]]
+                qpos0[qadr[j]:qadr[j] + 3] = b["pos"]
+                qpos0[qadr[j] + 3:qadr[j] + 7] = b["quat"]
+        A["qpos0"], A["qpos_spring"] = qpos0, qpos0.copy()
+        gtype = np.array([g["type"] for g in self.geom], np.int32)
+        A["geom_type"] = gtype
+        A["geom_contype"] = np.array([1 if g["collide"] else 0 for g in self.geom], np.int32)
+        A["geom_conaffinity"] = np.array([1 if g["collide"] == 2 else 0 for g in self.geom], np.int32)
+        A["geom_condim"] = np.full(ng, 3, np.int32)
+        A["geom_bodyid"] = np.array([g["body"] for g in self.geom], np.int32)
+        A["geom_priority"] = np.zeros(ng, np.int32)
+        A["geom_solmix"] = np.ones(ng)
+        A["geom_solref"] = np.tile([0.02, 1.0], (ng, 1))
+        A["geom_solimp"] = np.tile([0.9, 0.95, 0.001, 0.5, 2.0], (ng, 1))
+        A["geom_size"] = np.array([g["size"] for g in self.geom])
+        rb = np.zeros(ng)
+        for i, g in enumerate(self.geom):
+            s = g["size"]
+            rb[i] = {2: s[0], 3: s[0] + s[1], 5: np.hypot(s[0], s[1]), 6: np.linalg.norm(s)}.get(g["type"], 0.0)
+        A["geom_rbound"] = rb
+        A["geom_pos"] = np.array([g["pos"] for g in self.geom])
+        A["geom_quat"] = np.array([g["quat"] / np.linalg.norm(g["quat"]) for g in self.geom])
+        A["geom_friction"] = np.array([g["friction"] for g in self.geom])
+        A["geom_margin"], A["geom_gap"] = np.zeros(ng), np.zeros(ng)
+        A["site_bodyid"] = np.array([s["body"] for s in self.site], np.int32)
+        A["site_pos"] = np.array([s["pos"] for s in self.site])
+        A["tendon_adr"] = np.array([t["adr"] for t in self.tendon], np.int32)
+        A["tendon_num"] = np.array([t["num"] for t in self.tendon], np.int32)
+        A["tendon_limited"] = np.zeros(nt, np.uint8)
+        A["tendon_solref_lim"] = np.tile([0.02, 1.0], (nt, 1))
+        A["tendon_solimp_lim"] = np.tile([0.9, 0.95, 0.001, 0.5, 2.0], (nt, 1))
+        A["tendon_range"] = np.zeros((nt, 2))
+        for k in ("tendon_margin", "tendon_stiffness", "tendon_damping", "tendon_frictionloss",
+                  "tendon_lengthspring", "tendon_length0", "tendon_invweight0"):
+            A[k] = np.zeros(nt)
+        A["wrap_type"] = np.array([w[0] for w in self.wrap], np.int32)
+        A["wrap_objid"] = np.array([w[1] for w in self.wrap], np.int32)
+        A["wrap_prm"] = np.array([w[2] for w in self.wrap], float)
+        A["actuator_trntype"] = np.full(nu, 3, np.int32)
+        A["actuator_dyntype"] = np.full(nu, 3, np.int32)
+        A["actuator_gaintype"] = np.full(nu, 1, np.int32)
+        A["actuator_biastype"] = np.full(nu, 2, np.int32)
+        A["actuator_trnid"] = np.array([[a["tendon"], -1] for a in self.act], np.int32)
+        A["actuator_ctrllimited"] = np.ones(nu, np.uint8)
+        A["actuator_forcelimited"] = np.zeros(nu, np.uint8)
+        dyn = np.zeros((nu, 10))
+        dyn[:, 0], dyn[:, 1] = 0.01, 0.04
+        A["actuator_dynprm"] = dyn
+        gp = np.zeros((nu, 10))
+        for i, a in enumerate(self.act):
+            gp[i, :9] = [0.75, 1.05, a["force"], 200.0, 0.5, 1.6, 1.5, 1.3, 1.2]
+        A["actuator_gainprm"], A["actuator_biasprm"] = gp, gp.copy()
+        A["actuator_ctrlrange"] = np.tile([0.0, 1.0], (nu, 1))
+        A["actuator_forcerange"] = np.zeros((nu, 2))
+        gear = np.zeros((nu, 6))
+        gear[:, 0] = 1
+        A["actuator_gear"] = gear
+        for k in ("actuator_acc0", "actuator_length0"):
+            A[k] = np.zeros(nu)
+        A["actuator_lengthrange"] = np.zeros((nu, 2))
+        sizes = dict(nq=nq, nv=nv, nu=nu, na=nu, nbody=nb, njnt=nj, ngeom=ng, nsite=ns, ntendon=nt,
+                     nwrap=nw, neq=0)
+        opt = dict(timestep=0.002, apirate=100.0, impratio=1.0, tolerance=1e-8, gravity=[0, 0, -9.81],
+                   o_margin=0.0, integrator=0, collision=0, cone=0, jacobian=2, solver=2,
+                   iterations=100, disableflags=0, enableflags=0)
+        names = dict(body=[b["name"] for b in self.body], jnt=[j["name"] for j in self.jnt],
+                     geom=[g["name"] for g in self.geom], site=[s["name"] for s in self.site],
+                     tendon=[t["name"] for t in self.tendon], actuator=[a["name"] for a in self.act])
+        return MjbModel(sizes=sizes, opt=opt, arrays=A, names=names, model_name="synthetic_myohand_baoding",
+                        stat={"meaninertia": 1.0})
+
+
+def _palm_frame(t1, t2, b1, b2):
+    """Rotation R (palm->world) and origin O: targets land on the golden world positions with
+    local z = 0; the remaining rotation about the target line is chosen so that the palm
+    normal is as close to world-up as the two points allow."""
+    a1, a2 = 3 * np.pi / 4, -np.pi / 4
+    l1 = np.array([0.025 * np.cos(a1) + CENTER[0], 0.028 * np.sin(a1) + CENTER[1], 0.0])
+    l2 = np.array([0.025 * np.cos(a2) + CENTER[0], 0.028 * np.sin(a2) + CENTER[1], 0.0])
+    ul = (l2 - l1) / np.linalg.norm(l2 - l1)
+    uw = (t2 - t1) / np.linalg.norm(t2 - t1)
+    up = np.array([0, 0, 1.0])
+    n = up - (up @ uw) * uw
+    n /= np.linalg.norm(n)
+    vw = np.cross(n, uw)
+    vl = np.cross([0, 0, 1.0], ul)
+    R = np.outer(uw, ul) + np.outer(vw, vl) + np.outer(n, [0, 0, 1.0])
+    O = t1 - R @ l1
+    return R, O
+
+
+def build_synthetic_hand(golden_obs=None, lengthrange_samples=384) -> MjbModel:
+    t1, t2 = TARGET1.copy(), TARGET2.copy()
+    if golden_obs is not None:
+        t1, t2 = np.array(golden_obs[35:38], float), np.array(golden_obs[38:41], float)
+    R, O = _palm_frame(t1, t2, BALL1, BALL2)
+    b1l, b2l = R.T @ (BALL1 - O), R.T @ (BALL2 - O)
+    B = _Builder()
+    HINGE, FREE = 3, 0
+    # palm collision surface: a box whose top plane passes under both balls (dist = 0 at reset)
+    e = b2l - b1l
+    nb_ = np.array([0, 0, 1.0]) - (e[2] / (e @ e)) * e
+    nb_ /= np.linalg.norm(nb_)
+    ex = np.cross([0, 1.0, 0], nb_); ex /= np.linalg.norm(ex)
+    ey = np.cross(nb_, ex)
+    Rb = np.stack([ex, ey, nb_], 1)
+    mid = 0.5 * (b1l + b2l) - BALL_R * nb_
+    cbox = mid - 0.008 * nb_
+    zmid = float(mid[2])
+    zf = zmid - 0.009
+    W = np.array([0.0, -0.105, zf])              # wrist centre in the palm frame
+    # forearm: fixed to the world, frame = palm frame at the init pose, origin at the wrist
+    qF = mat_to_quat(R)
+    fore = B.add_body("forearm", 0, O + R @ W, qF, mass=0.0)
+    # radius: carries pro_sup about the forearm's long (local y) axis.  init_qpos[0] = -1.57
+    # (baoding.py:283) must give the palm-up pose, so the body is pre-rotated by +1.57.
+    rad = B.add_body("radius", fore, (0, 0, 0), axis_angle_quat([0, 1, 0], 1.57), mass=0.12,
+                     inertia=(2e-4, 4e-5, 2e-4), ipos=(0, -0.08, 0))
+    B.add_joint("pro_sup", rad, HINGE, (0, 0, 0), (0, 1, 0), (-1.6, 1.6), damping=0.5)
+    palm = B.add_body("palm", rad, (0, 0, 0), mass=0.26, inertia=(2.6e-4, 2.0e-4, 4.2e-4),
+                      ipos=tuple(np.array([-0.003, -0.052, zf]) - W))
+    B.add_joint("deviation", palm, HINGE, (0, 0, 0), (0, 0, 1), (-0.35, 0.45), damping=0.5)
+    B.add_joint("flexion", palm, HINGE, (0, 0, 0), (1, 0, 0), (-1.0, 1.0), damping=0.5)
+    P = lambda p: tuple(np.array(p, float) - W)      # palm-frame point -> palm-body coords
+
+    def capsule_inertia(mass, r, half):
+        L = 2 * half
+        return (mass * (r * r / 4 + L * L / 12), mass * (r * r / 4 + L * L / 12), mass * r * r / 2)
+
+    qy = axis_angle_quat([1, 0, 0], -np.pi / 2)      # capsule/cylinder z-axis -> +y
+    qx = axis_angle_quat([0, 1, 0], np.pi / 2)       # z-axis -> +x (flexion-axis cylinders)
+    B.add_geom("palm_box", palm, 6, (0.05, 0.06, 0.008), P(cbox), mat_to_quat(Rb), collide=1)
+    B.add_geom("thenar", palm, 3, (0.013, 0.03), P(mid + 0.046 * ex - 0.02 * ey + 0.006 * nb_), qy, collide=1)
+    B.add_geom("hypothenar", palm, 3, (0.012, 0.035), P(mid - 0.05 * ex - 0.005 * ey + 0.006 * nb_), qy, collide=1)
+    B.add_geom("heel", palm, 3, (0.012, 0.035), P(mid - 0.052 * ey + 0.006 * nb_), qx, collide=1)
+    wrist_cyl = B.add_geom("wrist_wrap", rad, 5, (0.014, 0.03), (0, 0, 0), qx)
+    wrist_sph = B.add_geom("wrist_sph", rad, 2, (0.012,), (0, 0, 0))
+    B.add_site("target1_site", palm, P((0.025 * np.cos(3 * np.pi / 4) + CENTER[0],
+                                        0.028 * np.sin(3 * np.pi / 4) + CENTER[1], 0)))
+    B.add_site("target2_site", palm, P((0.025 * np.cos(-np.pi / 4) + CENTER[0],
+                                        0.028 * np.sin(-np.pi / 4) + CENTER[1], 0)))
+    # ---- thumb: 4 hinges, 3 bodies
+    tb = np.array([0.036, -0.082, zmid - 0.004])
+    ut = np.array([0.72, 0.66, 0.2]); ut /= np.linalg.norm(ut)
+    af = np.cross(ut, [0, 0, 1.0]); af /= np.linalg.norm(af)       # flexion axis
+    aa = np.cross(af, ut)                                           # abduction axis
+    Rt = np.stack([af, ut, aa], 1)
+    qt = mat_to_quat(Rt)                                            # thumb frame: x=flex axis, y=along
+    tl = (0.042, 0.032, 0.026)
+    th1 = B.add_body("thumb_mc", palm, P(tb), qt, mass=0.03, inertia=capsule_inertia(0.03, 0.01, tl[0] / 2),
+                     ipos=(0, tl[0] / 2, 0))
+    B.add_joint("cmc_abduction", th1, HINGE, (0, 0, 0), (0, 0, 1), (-0.5, 0.9))
+    B.add_joint("cmc_flexion", th1, HINGE, (0, 0, 0), (1, 0, 0), (-0.6, 0.8))
+    th2 = B.add_body("thumb_prox", th1, (0, tl[0], 0), mass=0.018, inertia=capsule_inertia(0.018, 0.009, tl[1] / 2),
+                     ipos=(0, tl[1] / 2, 0))
+    B.add_joint("mp_flexion", th2, HINGE, (0, 0, 0), (1, 0, 0), (-0.4, 1.0))
+    th3 = B.add_body("thumb_dist", th2, (0, tl[1], 0), mass=0.012, inertia=capsule_inertia(0.012, 0.008, tl[2] / 2),
+                     ipos=(0, tl[2] / 2, 0))
+    B.add_joint("ip_flexion", th3, HINGE, (0, 0, 0), (1, 0, 0), (-0.4, 1.3))
+    for nm, bd, ln, r in (("thumb_mc_g", th1, tl[0], 0.010), ("thumb_prox_g", th2, tl[1], 0.009),
+                          ("thumb_dist_g", th3, tl[2], 0.008)):
+        B.add_geom(nm, bd, 3, (r, ln / 2), (0, ln / 2, 0), qy, collide=1)
+    thumb_cyl = [B.add_geom("th_cmc_wrap", palm, 5, (0.009, 0.02), P(tb), quat_mul(qt, qx)),
+                 B.add_geom("th_mp_wrap", th1, 5, (0.007, 0.02), (0, tl[0], 0), qx),
+                 B.add_geom("th_ip_wrap", th2, 5, (0.006, 0.02), (0, tl[1], 0), qx)]
+    thumb_bodies = [th1, th2, th3]
+    # ---- fingers: index(2) .. little(5)
+    fx = {2: 0.031, 3: 0.009, 4: -0.013, 5: -0.034}
+    fy = {2: 0.0, 3: 0.004, 4: -0.002, 5: -0.012}
+    flen = {2: (0.044, 0.026, 0.020), 3: (0.048, 0.030, 0.021), 4: (0.045, 0.028, 0.021), 5: (0.036, 0.021, 0.019)}
+    fingers = {}
+    for f in (2, 3, 4, 5):
+        L = flen[f]
+        mcp = np.array([fx[f], fy[f], zf])
+        b_p = B.add_body(f"proxph{f}", palm, P(mcp), mass=0.02, inertia=capsule_inertia(0.02, 0.009, L[0] / 2),
+                         ipos=(0, L[0] / 2, 0))
+        B.add_joint(f"mcp{f}_flexion", b_p, HINGE, (0, 0, 0), (1, 0, 0), (-0.5, 1.57))
+        B.add_joint(f"mcp{f}_abduction", b_p, HINGE, (0, 0, 0), (0, 0, 1), (-0.35, 0.35))
+        b_m = B.add_body(f"midph{f}", b_p, (0, L[0], 0), mass=0.011, inertia=capsule_inertia(0.011, 0.008, L[1] / 2),
+                         ipos=(0, L[1] / 2, 0))
+        B.add_joint(f"pm{f}_flexion", b_m, HINGE, (0, 0, 0), (1, 0, 0), (0.0, 1.7))
+        b_d = B.add_body(f"distph{f}", b_m, (0, L[1], 0), mass=0.007, inertia=capsule_inertia(0.007, 0.007, L[2] / 2),
+                         ipos=(0, L[2] / 2, 0))
+        B.add_joint(f"md{f}_flexion", b_d, HINGE, (0, 0, 0), (1, 0, 0), (0.0, 1.4))
+        for nm, bd, ln, r in ((f"proxph{f}_g", b_p, L[0], 0.009), (f"midph{f}_g", b_m, L[1], 0.008),
+                              (f"distph{f}_g", b_d, L[2], 0.007)):
+            B.add_geom(nm, bd, 3, (r, ln / 2), (0, ln / 2, 0), qy, collide=1)
+        cyl = [B.add_geom(f"mcp{f}_wrap", palm, 5, (0.0085, 0.01), P(mcp), qx),
+               B.add_geom(f"pip{f}_wrap", b_p, 5, (0.0065, 0.01), (0, L[0], 0), qx),
+               B.add_geom(f"dip{f}_wrap", b_m, 5, (0.005, 0.01), (0, L[1], 0), qx)]
+        fingers[f] = dict(bodies=[b_p, b_m, b_d], L=L, mcp=mcp, cyl=cyl)
+    # ---- balls (free bodies; qpos[23:30], qpos[30:37], baoding.py:187-194)
+    bi = 0.4 * 0.043 * BALL_R ** 2
+    ball1 = B.add_body("ball1", 0, BALL1, mass=0.043, inertia=(bi, bi, bi))
+    B.add_joint("ball1_free", ball1, FREE)
+    ball2 = B.add_body("ball2", 0, BALL2, mass=0.043, inertia=(bi, bi, bi))
+    B.add_joint("ball2_free", ball2, FREE)
+    B.add_geom("ball1", ball1, 2, (BALL_R,), collide=2)
+    B.add_geom("ball2", ball2, 2, (BALL_R,), collide=2)
+    B.add_site("ball1_site", ball1, (0, 0, 0))
+    B.add_site("ball2_site", ball2, (0, 0, 0))
+
+    # ---- tendons -------------------------------------------------------------------------
+    cnt = [0]
+
+    def S(body, pos):
+        cnt[0] += 1
+        return ("site", B.add_site(f"s{cnt[0]}", body, pos))
+
+    def side(body, pos):
+        cnt[0] += 1
+        return B.add_site(f"side{cnt[0]}", body, pos)
+
+    def finger_tendon(name, f, palmar, upto, x_off=0.0, force=100.0, origin_x=None):
+        """origin on the forearm -> wrist cylinder -> palm -> MCP/PIP/DIP cylinders -> phalanx."""
+        sg = 1.0 if palmar else -1.0
+        F = fingers[f]
+        L, mcp = F["L"], F["mcp"]
+        ox = fx[f] * 0.6 if origin_x is None else origin_x
+        path = [S(fore, (ox, -0.16, sg * 0.022)),
+                ("cyl", wrist_cyl, side(rad, (ox, 0.0, sg * 0.03))),
+                S(palm, P((fx[f] * 0.8 + x_off, -0.06, zf + sg * 0.014))),
+                ("cyl", F["cyl"][0], side(palm, P(mcp + [0, 0, sg * 0.03]))),
+                S(F["bodies"][0], (x_off, L[0] * 0.5, sg * 0.0105))]
+        if upto >= 2:
+            path += [("cyl", F["cyl"][1], side(F["bodies"][0], (0, L[0], sg * 0.03))),
+                     S(F["bodies"][1], (0, L[1] * 0.5, sg * 0.009))]
+        if upto >= 3:
+            path += [("cyl", F["cyl"][2], side(F["bodies"][1], (0, L[1], sg * 0.03))),
+                     S(F["bodies"][2], (0, L[2] * 0.5, sg * 0.008))]
+        B.add_muscle(name, B.add_tendon(name + "_tendon", path), force)
+
+    def wrist_tendon(name, x, palmar, force):
+        sg = 1.0 if palmar else -1.0
+        path = [S(fore, (x * 0.7, -0.2, sg * 0.02)),
+                ("cyl", wrist_cyl, side(rad, (x, 0.0, sg * 0.03))),
+                S(palm, P((x, -0.075, zf + sg * 0.013)))]
+        B.add_muscle(name, B.add_tendon(name + "_tendon", path), force)
+
+    def intrinsic(name, f, x_sign, z, force):
+        F = fingers[f]
+        path = [S(palm, P((fx[f] + x_sign * 0.009, -0.045, zf + z))),
+                S(palm, P(F["mcp"] + [x_sign * 0.011, -0.004, z])),
+                S(F["bodies"][0], (x_sign * 0.008, F["L"][0] * 0.45, z * 0.6))]
+        B.add_muscle(name, B.add_tendon(name + "_tendon", path), force)
+
+    def thumb_tendon(name, palmar, upto, x_off, force):
+        sg = 1.0 if palmar else -1.0
+        path = [S(fore, (0.03, -0.15, sg * 0.02)),
+                ("cyl", wrist_cyl, side(rad, (0.03, 0.0, sg * 0.03))),
+                S(palm, P(tb - 0.02 * ut + sg * 0.012 * aa + x_off * af)),
+                ("cyl", thumb_cyl[0], side(palm, P(tb + sg * 0.03 * aa))),
+                S(thumb_bodies[0], (x_off, tl[0] * 0.5, sg * 0.011))]
+        if upto >= 2:
+            path += [("cyl", thumb_cyl[1], side(thumb_bodies[0], (0, tl[0], sg * 0.03))),
+                     S(thumb_bodies[1], (0, tl[1] * 0.5, sg * 0.0095))]
+        if upto >= 3:
+            path += [("cyl", thumb_cyl[2], side(thumb_bodies[1], (0, tl[1], sg * 0.03))),
+                     S(thumb_bodies[2], (0, tl[2] * 0.5, sg * 0.0085))]
+        B.add_muscle(name, B.add_tendon(name + "_tendon", path), force)
+
+    made = {}
+    def make(name):
+        if name in ("ECRL", "ECRB", "ECU", "FCR", "FCU", "PL"):
+            x = {"ECRL": 0.03, "ECRB": 0.015, "ECU": -0.035, "FCR": 0.022, "FCU": -0.035, "PL": 0.0}[name]
+            wrist_tendon(name, x, name[0] == "F" or name == "PL", {"ECRL": 650, "ECRB": 550, "ECU": 500,
+                         "FCR": 400, "FCU": 480, "PL": 100}[name])
+        elif name in ("PT", "PQ"):
+            y = -0.14 if name == "PT" else -0.03
+            path = [S(fore, (-0.03, y - 0.05, 0.012)), S(fore, (-0.012, y - 0.02, 0.02)),
+                    S(rad, (0.02, y, 0.012))]
+            B.add_muscle(name, B.add_tendon(name + "_tendon", path), 550 if name == "PT" else 280)
+        elif name.startswith("FDS"):
+            finger_tendon(name, int(name[3]), True, 2, 0.002, {5: 75, 4: 170, 3: 260, 2: 160}[int(name[3])])
+        elif name.startswith("FDP"):
+            finger_tendon(name, int(name[3]), True, 3, -0.002, {5: 240, 4: 210, 3: 210, 2: 200}[int(name[3])])
+        elif name.startswith("EDC"):
+            finger_tendon(name, int(name[3]), False, 3, 0.0, {5: 120, 4: 300, 3: 280, 2: 150}[int(name[3])])
+        elif name == "EDM":
+            finger_tendon(name, 5, False, 3, -0.003, 150, origin_x=-0.03)
+        elif name == "EIP":
+            finger_tendon(name, 2, False, 3, 0.003, 120, origin_x=0.0)
+        elif name == "EPL":
+            thumb_tendon(name, False, 3, 0.0, 200)
+        elif name == "EPB":
+            thumb_tendon(name, False, 2, 0.003, 120)
+        elif name == "FPL":
+            thumb_tendon(name, True, 3, 0.0, 200)
+        elif name == "APL":
+            thumb_tendon(name, False, 1, -0.006, 200)
+        elif name == "OP":
+            path = [S(palm, P((0.005, -0.075, zmid - 0.002))), S(palm, P(tb - 0.012 * af + 0.006 * aa)),
+                    S(thumb_bodies[0], (-0.009, tl[0] * 0.6, 0.006))]
+            B.add_muscle(name, B.add_tendon(name + "_tendon", path), 140)
+        elif name.startswith("RI"):
+            intrinsic(name, int(name[2]), +1, -0.004, 60)
+        elif name.startswith("UI_UB"):
+            intrinsic(name, int(name[5]), -1, -0.004, 60)
+        elif name.startswith("LU_RB"):
+            intrinsic(name, int(name[5]), +1, +0.008, 45)
+        else:
+            raise KeyError(name)
+        made[name] = True
+
+    for nm in MUSCLES:
+        make(nm)
+    m = B.finish()
+    set_const(m, lengthrange_samples=lengthrange_samples, seed=0)
+    m.arrays["tendon_lengthspring"] = m.arrays["tendon_length0"].copy()
+    return m
+
+
+def save_asset(m: MjbModel, path=ASSET):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    import json
+    np.savez_compressed(path, __meta__=np.array(json.dumps(
+        {"sizes": m.sizes, "opt": m.opt, "names": m.names, "stat": m.stat, "model_name": m.model_name})),
+        **m.arrays)
+
+
+def load_asset(path=ASSET) -> MjbModel:
+    import json
+    z = np.load(path, allow_pickle=False)
+    meta = json.loads(str(z["__meta__"]))
+    arrays = {k: z[k] for k in z.files if k != "__meta__"}
+    return MjbModel(sizes=meta["sizes"], opt=meta["opt"], arrays=arrays, names=meta["names"],
+                    model_name=meta["model_name"], stat=meta["stat"])
+
+
+def synthetic_hand() -> MjbModel:
+    """The committed synthetic stand-in (rebuild with ``python -m myochallenge_amd.synth_hand``)."""
+    return load_asset()
+
+
+if __name__ == "__main__":
+    golden = os.path.join(os.path.dirname(ASSET), "..", "..", "tests", "golden", "reset_obs_golden.npy")
+    obs = np.load(golden) if os.path.exists(golden) else None
+    model = build_synthetic_hand(obs)
+    save_asset(model)
+    print("wrote", ASSET, {k: v for k, v in model.sizes.items()})

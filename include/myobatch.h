@@ -1,0 +1,139 @@
+/* myobatch.h — C ABI of libmyobatch: batched MyoSuite-class muscle-tendon physics + the
+ * Baoding task layer, resident on one MI355X.
+ *
+ * The reference has no native boundary; the seam this library sits behind is the per-process
+ * gym API that stable-baselines3's SubprocVecEnv drives over pipes:
+ *     SubprocVecEnv([thunk]*n)            /root/reference/src/main_baoding.py:56-65
+ *     env.reset() / env.step(a)           /root/reference/src/main_eval.py:92,104
+ *     EnvironmentFactory.create(name,**kw) /root/reference/src/envs/environment_factory.py:8-63
+ * Each entry point below names the reference interface it replaces.  All pointers marked
+ * "dev" are device (HBM) pointers owned by the caller (torch tensors); `stream` is a
+ * hipStream_t passed as void* (NULL = default stream).  Every function returns 0 on success
+ * or a negative MYO_E_* code; myo_last_error() gives the thread-local message.  A numerical
+ * blow-up of one environment is not an error: the env reports done=1 and is reset
+ * (MuJoCo's mj_checkPos/Vel/Acc -> mj_resetData behaviour).
+ *
+ * There is no CPU execution path in this library.
+ */
+#ifndef MYOBATCH_H
+#define MYOBATCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MYO_OK 0
+#define MYO_E_ARG -1      /* bad argument / malformed blob */
+#define MYO_E_UNSUPPORTED -2 /* model uses a feature the stepper lacks or exceeds its limits */
+#define MYO_E_DEVICE -3   /* HIP runtime error */
+#define MYO_E_STATE -4    /* call sequence error */
+
+typedef struct myo_model myo_model;
+typedef struct myo_batch myo_batch;
+
+enum { MYO_F64 = 0, MYO_F32 = 1 };            /* arithmetic type of the stepper */
+enum { MYO_TASK_NONE = 0, MYO_TASK_BAODING_P1 = 1, MYO_TASK_BAODING_P2 = 2 };
+enum { MYO_WHICH_HOLD = 0, MYO_WHICH_CW = 1, MYO_WHICH_CCW = 2 }; /* MyoSuite Task enum */
+enum { MYO_CHOICE_FIXED = 0, MYO_CHOICE_CW = 1, MYO_CHOICE_CCW = 2, MYO_CHOICE_RANDOM = 3 };
+
+#define MYO_N_RWD 8 /* pos_dist_1,pos_dist_2,act_reg,alive,sparse,solved,done,dense */
+
+/* Task configuration = the kwargs of CustomBaodingEnv._setup / CustomBaodingP2Env._setup
+ * (/root/reference/src/envs/baoding.py:210-227,300-324) lowered to plain numbers, plus the
+ * ids the reference resolves by name (baoding.py:264-269,371-378) and the TimeLimit horizon
+ * (/root/reference/src/envs/__init__.py:15,61). */
+typedef struct myo_task_cfg {
+  int32_t kind;              /* MYO_TASK_* */
+  int32_t frame_skip;        /* 10 */
+  int32_t max_episode_steps; /* 200 */
+  int32_t n_hand;            /* 23: obs hand_pos = qpos[:n_hand] */
+  int32_t obj1_sid, obj2_sid, target1_sid, target2_sid;
+  int32_t obj1_bid, obj2_bid, obj1_gid, obj2_gid;
+  int32_t task_choice;       /* MYO_CHOICE_*: P1 `task` (None->FIXED=CCW,"cw","ccw","random"); P2 `task_choice` */
+  int32_t enable_rsi, balls_overlap, limit_init_angle_on, beta_init_angle_on, beta_ball_size_on,
+      beta_ball_mass_on;
+  double drop_th, proximity_th;
+  double center_pos[2];
+  double weights[7];         /* pos_dist_1,pos_dist_2,act_reg,alive,sparse,solved,done */
+  double goal_time_period[2], goal_xrange[2], goal_yrange[2];
+  double rsi_probability, overlap_probability;
+  double noise_palm, noise_fingers, noise_balls;
+  double limit_init_angle, beta_init_angle[2], beta_ball_size[2], beta_ball_mass[2];
+  double obj_size_range[2], obj_mass_range[2], obj_friction_change[3];
+  double init_qpos0;         /* -1.57 (baoding.py:283,401) */
+} myo_task_cfg;
+
+/* -- model ------------------------------------------------------------------------------
+ * replaces gym.make(..., model_path=...) -> mj_loadModel (src/envs/__init__.py:17,63).
+ * `blob` is the named-array format of include/myo_model_blob.h (host memory). */
+int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** out);
+void myo_model_destroy(myo_model* m);
+int myo_model_size(const myo_model* m, const char* name); /* nq nv nu na nbody ... ; -1 unknown */
+
+/* -- batch ------------------------------------------------------------------------------
+ * replaces SubprocVecEnv([thunk]*n) + TimeLimit + Monitor (src/main_baoding.py:56-65).
+ * `cfg` may be NULL (kind NONE: physics only).  dtype: MYO_F64 | MYO_F32. */
+int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int n_envs, int device,
+                     uint64_t seed, int dtype, myo_batch** out);
+void myo_batch_destroy(myo_batch* b);
+int myo_batch_num_envs(const myo_batch* b);
+int myo_batch_obs_dim(const myo_batch* b);
+int myo_batch_lds_bytes(const myo_batch* b); /* LDS footprint of one env's working set */
+
+/* env.reset() for the envs selected by mask (dev uint8[N] or NULL = all); writes obs
+ * (dev float[N,obs_dim], may be NULL).  baoding.py:146-208 / :494-647. */
+int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, void* stream);
+
+/* env.step(a) for every env with SubprocVecEnv auto-reset semantics: BaodingEnvV1.step ->
+ * BaseV0.step -> mj_step x frame_skip -> get_obs/get_reward_dict (baoding.py:24-94,403-467),
+ * TimeLimit truncation, reset on done.  act: dev float[N,nu].  Outputs (dev): obs[N,obs_dim]
+ * (post-reset obs where done), rew[N], done[N], trunc[N] (info["TimeLimit.truncated"]),
+ * term_obs[N,obs_dim] (info["terminal_observation"], valid where done), comps[N,MYO_N_RWD]
+ * (rwd_dict of the step), ep_info[N,2] (Monitor's episode r,l; valid where done).
+ * Any output pointer except obs/rew/done may be NULL. */
+int myo_batch_step(myo_batch* b, const float* act, float* obs, float* rew, uint8_t* done,
+                   uint8_t* trunc, float* term_obs, float* comps, float* ep_info, void* stream);
+
+/* raw physics: apply ctrl (dev double[N,nu]) and run `nsub` mj_step substeps; no task layer.
+ * Used by parity tests on arbitrary models. */
+int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub, void* stream);
+
+/* state access (sim.data.qpos/qvel/act/time; env.set_state; robot.reset).  dev double
+ * arrays [N,nq],[N,nv],[N,na],[N]; any may be NULL. */
+int myo_batch_get_state(myo_batch* b, double* qpos, double* qvel, double* act, double* time,
+                        void* stream);
+int myo_batch_set_state(myo_batch* b, const double* qpos, const double* qvel, const double* act,
+                        const double* time, void* stream);
+
+/* per-env task parameters, explicit injection for parity tests (what reset() samples):
+ * task_i  dev int32[N,2]  = which_task, counter
+ * task_d  dev double[N,9] = start_angle1, start_angle2, x_radius, y_radius, time_period,
+ *                           target1_x, target1_y, target2_x, target2_y (palm-frame site xy)
+ * ball_d  dev double[N,10]= mass1, mass2, friction1[3], friction2[3], size1, size2 */
+int myo_batch_set_task(myo_batch* b, const int32_t* task_i, const double* task_d,
+                       const double* ball_d, void* stream);
+int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ball_d, void* stream);
+
+/* forward dynamics of the current state with intermediates dumped for stage-wise parity
+ * tests: out is dev double[N, myo_batch_dump_size()] ; layout by myo_batch_dump_offset(name).
+ * names: ten_length ten_J(nt*nv) M(nv*nv) qfrc_bias qfrc_passive qfrc_actuator qacc_smooth
+ *        qacc actuator_force act_dot counts(ncon,nefc,iter) efc_aref efc_D site_xpos subtree_com */
+int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* out, void* stream);
+int myo_batch_dump_size(const myo_batch* b);
+int myo_batch_dump_offset(const myo_batch* b, const char* name);
+
+/* average duration (ms) of the step kernel over the launches since the last call, measured
+ * with HIP events on the launch stream; resets the accumulator.  Returns <0 if no launch. */
+double myo_batch_kernel_ms(myo_batch* b);
+int myo_batch_enable_timing(myo_batch* b, int on);
+
+const char* myo_last_error(void);
+const char* myo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,51 @@
+"""Build recipes for the native pieces (all in-tree, so the .so files travel with gpurun).
+
+* ``build_hip()``   hipcc --offload-arch=gfx950 -> myochallenge_amd/libmyobatch.so (the product)
+* ``build_emu()``   g++ -DMYO_EMU             -> tests/emu/libmyobatch_emu.so (test tooling:
+                    lane-serial emulation of the kernel source, optional sanitizers)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h"]
+HEADERS = [os.path.join(ROOT, "include", "myobatch.h"), os.path.join(ROOT, "include", "myo_model_blob.h")]
+
+
+def _stale(target: str) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    out = os.path.join(HERE, "libmyobatch.so")
+    if force or _stale(out):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            hipcc = "hipcc"
+        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+               os.path.join(CSRC, "myobatch.hip"), "-o", out]
+        if verbose:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_emu(force: bool = False, sanitize: bool = False) -> str:
+    d = os.path.join(ROOT, "tests", "emu")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, "libmyobatch_emu_asan.so" if sanitize else "libmyobatch_emu.so")
+    if force or _stale(out):
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DMYO_EMU", "-x", "c++",
+               os.path.join(CSRC, "myobatch.hip"), "-o", out]
+        if sanitize:
+            cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+        subprocess.check_call(cmd)
+    return out

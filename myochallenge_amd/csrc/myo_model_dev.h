@@ -1,0 +1,72 @@
+// myo_model_dev.h — device-side view of a compiled model (shared by the HIP build and the
+// MYO_EMU test build).  All arrays live in HBM, are read-only during stepping and are shared by
+// every environment (they stay L2/L1 resident: ~25 KB for the 35-dof hand).
+#pragma once
+#include <stdint.h>
+
+// compile-time capacity of one environment's scratch (LDS).  A model that exceeds any of these
+// is rejected at myo_batch_create with MYO_E_UNSUPPORTED.
+#define MYO_NB_MAX 24     // bodies
+#define MYO_NJ_MAX 28     // joints
+#define MYO_NV_MAX 36     // dofs (<= 64 required by the 64-bit dof masks)
+#define MYO_NQ_MAX 38
+#define MYO_NT_MAX 40     // tendons
+#define MYO_NU_MAX 40     // actuators
+#define MYO_TJ_MAX 8      // dofs one tendon can move
+#define MYO_NM_MAX 176    // tree-sparse inertia entries
+#define MYO_NCON_MAX 24   // contacts
+#define MYO_CS_MAX 16     // dofs one contact can move
+#define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows
+#define MYO_NEFC_MAX (MYO_NLIM_MAX + 4 * MYO_NCON_MAX)
+#define MYO_OBS_MAX 96
+
+// X-macro lists: (type, name).  I = int32, U = uint64, R = real (T)
+#define MYO_MODEL_INT_ARRAYS(X)                                                                  \
+  X(body_parentid) X(body_rootid) X(body_jntnum) X(body_jntadr) X(body_dofnum) X(body_dofadr)    \
+  X(body_depth) X(jnt_type) X(jnt_qposadr) X(jnt_dofadr) X(jnt_bodyid) X(jnt_limited)            \
+  X(dof_bodyid) X(dof_jntid) X(dof_parentid) X(dof_rootbody) X(dof_Madr) X(geom_type)            \
+  X(geom_bodyid) X(geom_priority) X(site_bodyid) X(tendon_adr) X(tendon_num) X(tendon_limited)   \
+  X(wrap_type) X(wrap_objid) X(wrap_side) X(actuator_dyntype) X(actuator_gaintype)               \
+  X(actuator_biastype) X(actuator_tendon) X(actuator_ctrllimited) X(actuator_forcelimited)       \
+  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e)
+#define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask)
+#define MYO_MODEL_REAL_ARRAYS(X)                                                                 \
+  X(qpos0) X(qpos_spring) X(body_pos) X(body_quat) X(body_ipos) X(body_imat) X(body_mass)        \
+  X(body_inertia) X(body_invweight0) X(jnt_solref) X(jnt_solimp) X(jnt_pos) X(jnt_axis)          \
+  X(jnt_stiffness) X(jnt_range) X(jnt_margin) X(dof_armature) X(dof_damping) X(dof_invweight0)   \
+  X(geom_solmix) X(geom_solref) X(geom_solimp) X(geom_size) X(geom_rbound) X(geom_pos)           \
+  X(geom_mat) X(geom_friction) X(geom_margin) X(geom_gap) X(site_pos) X(tendon_solref_lim)       \
+  X(tendon_solimp_lim) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping)    \
+  X(tendon_lengthspring) X(tendon_invweight0) X(wrap_prm) X(actuator_dynprm)                     \
+  X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
+  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange)
+
+template <typename T>
+struct DevModel {
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive;
+  T timestep, tolerance, impratio, gravity[3], meaninertia;
+#define X(n) const int* n;
+  MYO_MODEL_INT_ARRAYS(X)
+#undef X
+#define X(n) const unsigned long long* n;
+  MYO_MODEL_U64_ARRAYS(X)
+#undef X
+#define X(n) const T* n;
+  MYO_MODEL_REAL_ARRAYS(X)
+#undef X
+};
+
+// Per-env state record in HBM (always fp64, env-major: one env's record is contiguous, so the
+// 64 lanes of the env's wavefront read consecutive scalars).
+struct EnvRecordLayout {
+  int nq, nv, na;
+  int off_qpos, off_qvel, off_act, off_warm, off_time, off_taskd, off_balld, off_misc;
+  int stride;  // doubles per env
+};
+// taskd: start_angle[2], x_radius, y_radius, time_period, target_xy[4]  (9)
+// balld: mass[2], friction[2][3], size[2]  (10)
+// misc : which_task, counter, elapsed_steps, episode_index, ep_return, ep_len (6, stored as double)
+#define MYO_TASKD_N 9
+#define MYO_BALLD_N 10
+#define MYO_MISC_N 6

@@ -1,0 +1,1595 @@
+// myo_physics.h — the per-environment forward dynamics + integrators, one env per wavefront.
+//
+// Restates the MuJoCo 2.1 mj_step pipeline that the reference runs through
+// MyoSuite -> mujoco_py (reference call sites
+// /root/reference/src/envs/baoding.py:179,183,206,608,625,632) as wave-parallel phases:
+//
+//   kinematics   lanes = bodies, level by level          (mj_kinematics)
+//   com/cdof     lanes = bodies / joints                  (mj_comPos)
+//   tendon       lanes = tendons, wrap walk + moment arms (mj_tendon, mju_wrap)
+//   crb          lanes = tree-sparse M entries            (mj_crb)
+//   collision    lanes = candidate geom pairs             (mj_collision)
+//   constraint   lanes = joints / tendons / contacts      (mj_makeConstraint, mj_makeImpedance)
+//   velocity     lanes = bodies / dofs                    (mj_comVel, mj_passive, mj_rne)
+//   actuation    lanes = muscles                          (mj_fwdActuation, mju_muscle*)
+//   solve        packed 35x35 Cholesky in LDS + Newton with exact line search (mj_solNewton)
+//   integrate    Euler with implicit joint damping / RK4  (mj_Euler, mj_RungeKutta)
+//
+// The constraint Jacobian is never materialised: J*v and J'*f go through per-body spatial
+// vectors (6 numbers per body), and the Newton Hessian M + J' D J is assembled per contact from
+// 3x3 blocks.  Everything an env touches between load and store lives in LDS (Scratch<T>).
+#pragma once
+#include "myo_model_dev.h"
+#include "wave.h"
+
+#define MYO_MINVAL ((T)1e-15)
+#define MYO_HIDX(i, j) ((i) * ((i) + 1) / 2 + (j)) /* packed lower triangle, i >= j */
+
+struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
+  int kind, frame_skip, max_episode_steps, n_hand;
+  int obj1_sid, obj2_sid, target1_sid, target2_sid, obj1_bid, obj2_bid, obj1_gid, obj2_gid;
+  int task_choice, enable_rsi, balls_overlap, limit_init_angle_on, beta_init_angle_on,
+      beta_ball_size_on, beta_ball_mass_on;
+  double drop_th, proximity_th, center_pos[2], weights[7];
+  double goal_time_period[2], goal_xrange[2], goal_yrange[2];
+  double rsi_probability, overlap_probability, noise_palm, noise_fingers, noise_balls;
+  double limit_init_angle, beta_init_angle[2], beta_ball_size[2], beta_ball_mass[2];
+  double obj_size_range[2], obj_mass_range[2], obj_friction_change[3], init_qpos0;
+  unsigned long long seed;
+};
+
+template <typename T>
+struct ContactRec {
+  T pos[3], frame[9], mu[2], D, B, kip, F[3], A[5];
+  int b1, b2, nsup;
+  unsigned char sup[MYO_CS_MAX];
+};
+
+template <typename T>
+struct Scratch {
+  // ---- state
+  T qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX], ctrl[MYO_NU_MAX], qacc_warm[MYO_NV_MAX];
+  T time;
+  // ---- per-env parameters
+  T ball_mass[2], ball_fric[6], ball_size[2], target_xy[4], start_angle[2], x_radius, y_radius,
+      time_period, ep_ret;
+  int which_task, counter, elapsed, episode, ep_len;
+  // ---- position stage
+  T xpos[MYO_NB_MAX * 3], xquat[MYO_NB_MAX * 4], xmat[MYO_NB_MAX * 9], xipos[MYO_NB_MAX * 3];
+  T xanchor[MYO_NJ_MAX * 3], xaxis[MYO_NJ_MAX * 3];
+  T com[MYO_NB_MAX * 3], cinert[MYO_NB_MAX * 10], crb[MYO_NB_MAX * 10];
+  T cdof[MYO_NV_MAX * 6], cdof_dot[MYO_NV_MAX * 6];
+  T cvel[MYO_NB_MAX * 6], bvec[MYO_NB_MAX * 6], cfrcb[MYO_NB_MAX * 6];
+  T ten_length[MYO_NT_MAX], ten_vel[MYO_NT_MAX], ten_J[MYO_NT_MAX * MYO_TJ_MAX];
+  T act_force[MYO_NU_MAX], act_dot[MYO_NU_MAX];
+  T qM[MYO_NM_MAX], H[MYO_NV_MAX * (MYO_NV_MAX + 1) / 2];
+  T qfrc_passive[MYO_NV_MAX], qfrc_bias[MYO_NV_MAX], qfrc_actuator[MYO_NV_MAX],
+      qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX],
+      qfrc_constraint[MYO_NV_MAX];
+  T Ma[MYO_NV_MAX], grad[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX], tmpv[MYO_NV_MAX];
+  // ---- constraints
+  int ncon, nefc, nl, ntl, bad, solver_iter, npre[64];
+  ContactRec<T> con[MYO_NCON_MAX];
+  int lim_id[MYO_NLIM_MAX];
+  T lim_sgn[MYO_NLIM_MAX];
+  T efc_D[MYO_NEFC_MAX], efc_B[MYO_NEFC_MAX], efc_kip[MYO_NEFC_MAX], efc_aref[MYO_NEFC_MAX],
+      efc_jar[MYO_NEFC_MAX], efc_jv[MYO_NEFC_MAX], efc_force[MYO_NEFC_MAX];
+  unsigned char efc_active[MYO_NEFC_MAX];
+  // ---- RK4 stage storage
+  T rk_x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];
+  T rk_F[4][2 * MYO_NV_MAX + MYO_NU_MAX];
+  T rk_dX[2 * MYO_NV_MAX + MYO_NU_MAX];
+  // ---- task layer
+  T obs[MYO_OBS_MAX];
+  T rwd[8];
+};
+
+// ------------------------------------------------------------------------------------------
+// small math
+template <typename T> DEV T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <typename T> DEV void cross3(T* r, const T* a, const T* b) {
+  T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> DEV T norm3(const T* a) { return sqrt(dot3(a, a)); }
+template <typename T> DEV T normalize3(T* a) {
+  T n = norm3(a);
+  if (n < MYO_MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; } else { T i = 1 / n; a[0] *= i; a[1] *= i; a[2] *= i; }
+  return n;
+}
+template <typename T> DEV void mulmatvec3(T* r, const T* R, const T* v) {
+  T x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2], y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+    z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> DEV void mulmatTvec3(T* r, const T* R, const T* v) {
+  T x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2], y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2],
+    z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> DEV void mulmat3(T* r, const T* A, const T* B) {
+  T t[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  for (int i = 0; i < 9; ++i) r[i] = t[i];
+}
+template <typename T> DEV void quat2mat(T* R, const T* q) {
+  T w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+template <typename T> DEV void mulquat(T* r, const T* a, const T* b) {
+  T t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+    t2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], t3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = t0; r[1] = t1; r[2] = t2; r[3] = t3;
+}
+template <typename T> DEV void normalize4(T* q) {
+  T n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MYO_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; } else { T i = 1 / n; q[0] *= i; q[1] *= i; q[2] *= i; q[3] *= i; }
+}
+template <typename T> DEV void axisangle2quat(T* q, const T* axis, T angle) {
+  T s = sin(angle * (T)0.5);
+  q[0] = cos(angle * (T)0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+template <typename T> DEV T tmax(T a, T b) { return a > b ? a : b; }
+template <typename T> DEV T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> DEV T tclamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// spatial algebra in MuJoCo's com-based convention: motion = [ang; lin], force = [torque; force]
+template <typename T> DEV void mul_inert_vec(T* r, const T* I, const T* v) {
+  const T* w = v; const T* l = v + 3; const T* h = I + 6; T mass = I[9]; T t[3];
+  r[0] = I[0] * w[0] + I[3] * w[1] + I[4] * w[2]; r[1] = I[3] * w[0] + I[1] * w[1] + I[5] * w[2];
+  r[2] = I[4] * w[0] + I[5] * w[1] + I[2] * w[2];
+  cross3(t, h, l); r[0] += t[0]; r[1] += t[1]; r[2] += t[2];
+  cross3(t, h, w); r[3] = mass * l[0] - t[0]; r[4] = mass * l[1] - t[1]; r[5] = mass * l[2] - t[2];
+}
+template <typename T> DEV void cross_motion(T* r, const T* v, const T* m) {
+  T a[3], b[3], c[3];
+  cross3(a, v, m); cross3(b, v, m + 3); cross3(c, v + 3, m);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+template <typename T> DEV void cross_force(T* r, const T* v, const T* f) {
+  T a[3], b[3], c[3];
+  cross3(a, v, f); cross3(b, v + 3, f + 3); cross3(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+
+// per-env overrides of model constants (P2 randomisation writes ball mass / size / friction
+// into the model, /root/reference/src/envs/baoding.py:559-604)
+template <typename T> DEV T body_mass_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int b) {
+  if (b == K.obj1_bid) return s.ball_mass[0];
+  if (b == K.obj2_bid) return s.ball_mass[1];
+  return M.body_mass[b];
+}
+template <typename T> DEV T geom_size0_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+  if (g == K.obj1_gid) return s.ball_size[0];
+  if (g == K.obj2_gid) return s.ball_size[1];
+  return M.geom_size[3 * g];
+}
+template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, int k) {
+  if (g == K.obj1_gid) return s.ball_fric[k];
+  if (g == K.obj2_gid) return s.ball_fric[3 + k];
+  return M.geom_friction[3 * g + k];
+}
+
+// world position of a point given in body coordinates
+template <typename T> DEV void body_point(const Scratch<T>& s, int b, const T* local, T* out) {
+  mulmatvec3(out, s.xmat + 9 * b, local);
+  out[0] += s.xpos[3 * b]; out[1] += s.xpos[3 * b + 1]; out[2] += s.xpos[3 * b + 2];
+}
+// translational Jacobian column of dof d for a world point p: cdof_lin + cdof_ang x (p - com)
+template <typename T> DEV void jac_col(const DevModel<T>& M, const Scratch<T>& s, int d, const T* p, T* col) {
+  const T* c = s.com + 3 * M.dof_rootbody[d]; const T* cd = s.cdof + 6 * d;
+  T off[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]}, t[3];
+  cross3(t, cd, off);
+  col[0] = cd[3] + t[0]; col[1] = cd[4] + t[1]; col[2] = cd[5] + t[2];
+}
+
+// ------------------------------------------------------------------------------------------
+// P2: kinematics (mj_kinematics)
+template <typename T>
+DEV void kinematics(const DevModel<T>& M, Scratch<T>& s) {
+  WAVE_FN
+  PHASE {
+    if (lane == 0) {
+      s.xpos[0] = s.xpos[1] = s.xpos[2] = 0; s.xquat[0] = 1; s.xquat[1] = s.xquat[2] = s.xquat[3] = 0;
+      for (int k = 0; k < 9; ++k) s.xmat[k] = (k % 4 == 0) ? (T)1 : (T)0;
+    }
+  }
+  SYNC();
+  for (int level = 1; level <= M.maxdepth; ++level) {
+    PHASE {
+      const int b = lane;
+      if (b > 0 && b < M.nbody && M.body_depth[b] == level) {
+        const int par = M.body_parentid[b], jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+        T p[3], q[4];
+        if (jn == 1 && M.jnt_type[ja] == 0) {
+          const int qa = M.jnt_qposadr[ja];
+          T qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
+          normalize4(qq);
+          for (int k = 0; k < 4; ++k) { s.qpos[qa + 3 + k] = qq[k]; q[k] = qq[k]; }
+          for (int k = 0; k < 3; ++k) { p[k] = s.qpos[qa + k]; s.xanchor[3 * ja + k] = p[k]; }
+          s.xaxis[3 * ja] = 0; s.xaxis[3 * ja + 1] = 0; s.xaxis[3 * ja + 2] = 1;
+        } else {
+          T t[3];
+          mulmatvec3(t, s.xmat + 9 * par, M.body_pos + 3 * b);
+          p[0] = s.xpos[3 * par] + t[0]; p[1] = s.xpos[3 * par + 1] + t[1]; p[2] = s.xpos[3 * par + 2] + t[2];
+          mulquat(q, s.xquat + 4 * par, M.body_quat + 4 * b);
+          for (int k = 0; k < jn; ++k) {
+            const int j = ja + k, qa = M.jnt_qposadr[j];
+            T R[9], anchor[3], axis[3];
+            quat2mat(R, q);
+            mulmatvec3(anchor, R, M.jnt_pos + 3 * j);
+            anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
+            mulmatvec3(axis, R, M.jnt_axis + 3 * j);
+            for (int e = 0; e < 3; ++e) { s.xanchor[3 * j + e] = anchor[e]; s.xaxis[3 * j + e] = axis[e]; }
+            const T ang = s.qpos[qa] - M.qpos0[qa];
+            if (M.jnt_type[j] == 2) {
+              p[0] += axis[0] * ang; p[1] += axis[1] * ang; p[2] += axis[2] * ang;
+            } else {
+              T ql[4], R2[9], t2[3];
+              axisangle2quat(ql, M.jnt_axis + 3 * j, ang);
+              mulquat(q, q, ql);
+              quat2mat(R2, q);
+              mulmatvec3(t2, R2, M.jnt_pos + 3 * j);
+              p[0] = anchor[0] - t2[0]; p[1] = anchor[1] - t2[1]; p[2] = anchor[2] - t2[2];
+            }
+          }
+        }
+        normalize4(q);
+        for (int k = 0; k < 3; ++k) s.xpos[3 * b + k] = p[k];
+        for (int k = 0; k < 4; ++k) s.xquat[4 * b + k] = q[k];
+        T R[9];
+        quat2mat(R, q);
+        for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = R[k];
+        T t[3];
+        mulmatvec3(t, R, M.body_ipos + 3 * b);
+        for (int k = 0; k < 3; ++k) s.xipos[3 * b + k] = p[k] + t[k];
+      }
+    }
+    SYNC();
+  }
+}
+
+// P2: mj_comPos — tree reference points, body inertias about them, dof motion axes
+template <typename T>
+DEV void com_pos(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  WAVE_FN
+  PHASE {
+    const int b = lane;
+    if (b == 0) { s.com[0] = s.com[1] = s.com[2] = 0; }
+    if (b > 0 && b < M.nbody && M.body_rootid[b] == b) {
+      T mass = 0, c[3] = {0, 0, 0};
+      for (int o = 1; o < M.nbody; ++o)
+        if (M.body_rootid[o] == b) {
+          const T mo = body_mass_of(M, K, s, o);
+          mass += mo; c[0] += mo * s.xipos[3 * o]; c[1] += mo * s.xipos[3 * o + 1]; c[2] += mo * s.xipos[3 * o + 2];
+        }
+      if (mass < MYO_MINVAL) { c[0] = s.xipos[3 * b]; c[1] = s.xipos[3 * b + 1]; c[2] = s.xipos[3 * b + 2]; }
+      else { c[0] /= mass; c[1] /= mass; c[2] /= mass; }
+      s.com[3 * b] = c[0]; s.com[3 * b + 1] = c[1]; s.com[3 * b + 2] = c[2];
+    }
+  }
+  SYNC();
+  PHASE {
+    const int b = lane;
+    if (b < M.nbody) {
+      T* ci = s.cinert + 10 * b;
+      if (b == 0) { for (int k = 0; k < 10; ++k) ci[k] = 0; }
+      else {
+        T R[9];
+        mulmat3(R, s.xmat + 9 * b, M.body_imat + 9 * b);
+        const T* I = M.body_inertia + 3 * b; const T* c = s.com + 3 * M.body_rootid[b];
+        const T off[3] = {s.xipos[3 * b] - c[0], s.xipos[3 * b + 1] - c[1], s.xipos[3 * b + 2] - c[2]};
+        const T mb = body_mass_of(M, K, s, b);
+        ci[0] = R[0] * R[0] * I[0] + R[1] * R[1] * I[1] + R[2] * R[2] * I[2] + mb * (off[1] * off[1] + off[2] * off[2]);
+        ci[1] = R[3] * R[3] * I[0] + R[4] * R[4] * I[1] + R[5] * R[5] * I[2] + mb * (off[0] * off[0] + off[2] * off[2]);
+        ci[2] = R[6] * R[6] * I[0] + R[7] * R[7] * I[1] + R[8] * R[8] * I[2] + mb * (off[0] * off[0] + off[1] * off[1]);
+        ci[3] = R[0] * R[3] * I[0] + R[1] * R[4] * I[1] + R[2] * R[5] * I[2] - mb * off[0] * off[1];
+        ci[4] = R[0] * R[6] * I[0] + R[1] * R[7] * I[1] + R[2] * R[8] * I[2] - mb * off[0] * off[2];
+        ci[5] = R[3] * R[6] * I[0] + R[4] * R[7] * I[1] + R[5] * R[8] * I[2] - mb * off[1] * off[2];
+        ci[6] = mb * off[0]; ci[7] = mb * off[1]; ci[8] = mb * off[2]; ci[9] = mb;
+      }
+    }
+    const int j = lane;
+    if (j < M.njnt) {
+      const int b = M.jnt_bodyid[j], da = M.jnt_dofadr[j];
+      const T* c = s.com + 3 * M.body_rootid[b];
+      const T off[3] = {c[0] - s.xanchor[3 * j], c[1] - s.xanchor[3 * j + 1], c[2] - s.xanchor[3 * j + 2]};
+      if (M.jnt_type[j] == 0) {
+        for (int k = 0; k < 3; ++k) { T* cd = s.cdof + 6 * (da + k); for (int e = 0; e < 6; ++e) cd[e] = 0; cd[3 + k] = 1; }
+        for (int k = 0; k < 3; ++k) {
+          T* cd = s.cdof + 6 * (da + 3 + k);
+          const T ax[3] = {s.xmat[9 * b + k], s.xmat[9 * b + 3 + k], s.xmat[9 * b + 6 + k]};
+          cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
+          cross3(cd + 3, ax, off);
+        }
+      } else if (M.jnt_type[j] == 2) {
+        T* cd = s.cdof + 6 * da; cd[0] = cd[1] = cd[2] = 0;
+        cd[3] = s.xaxis[3 * j]; cd[4] = s.xaxis[3 * j + 1]; cd[5] = s.xaxis[3 * j + 2];
+      } else {
+        T* cd = s.cdof + 6 * da; const T ax[3] = {s.xaxis[3 * j], s.xaxis[3 * j + 1], s.xaxis[3 * j + 2]};
+        cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
+        cross3(cd + 3, ax, off);
+      }
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// P3: spatial tendons with sphere / cylinder wrapping (mj_tendon + mju_wrap)
+template <typename T> DEV int seg_intersect(const T* p1, const T* p2, const T* p3, const T* p4) {
+  const T det = (p4[1] - p3[1]) * (p2[0] - p1[0]) - (p4[0] - p3[0]) * (p2[1] - p1[1]);
+  if (fabs(det) < MYO_MINVAL) return 0;
+  const T a = ((p4[0] - p3[0]) * (p1[1] - p3[1]) - (p4[1] - p3[1]) * (p1[0] - p3[0])) / det;
+  const T b = ((p2[0] - p1[0]) * (p1[1] - p3[1]) - (p2[1] - p1[1]) * (p1[0] - p3[0])) / det;
+  return (a >= 0 && a <= 1 && b >= 0 && b <= 1);
+}
+
+template <typename T> DEV T wrap_circle(T* pnt, const T* dd, const T* sd, int has_side, T rad) {
+  const T sqlen0 = dd[0] * dd[0] + dd[1] * dd[1], sqlen1 = dd[2] * dd[2] + dd[3] * dd[3], sqrad = rad * rad;
+  const T dif[2] = {dd[2] - dd[0], dd[3] - dd[1]};
+  const T dsq = dif[0] * dif[0] + dif[1] * dif[1];
+  if (sqlen0 < sqrad || sqlen1 < sqrad || rad < MYO_MINVAL) return -1;
+  if (dsq < MYO_MINVAL) return -1;
+  T a = -(dif[0] * dd[0] + dif[1] * dd[1]) / dsq;
+  a = tclamp(a, (T)0, (T)1);
+  const T tmp[2] = {a * dif[0] + dd[0], a * dif[1] + dd[1]};
+  if (tmp[0] * tmp[0] + tmp[1] * tmp[1] > sqrad && (!has_side || sd[0] * tmp[0] + sd[1] * tmp[1] >= 0)) return -1;
+  T sol[2][4], good[2];
+  const T sqrt0 = sqrt(sqlen0 - sqrad), sqrt1 = sqrt(sqlen1 - sqrad);
+  for (int i = 0; i < 2; ++i) {
+    const T sgn = (i == 0) ? (T)1 : (T)-1;
+    sol[i][0] = (dd[0] * sqrad + sgn * rad * dd[1] * sqrt0) / sqlen0;
+    sol[i][1] = (dd[1] * sqrad - sgn * rad * dd[0] * sqrt0) / sqlen0;
+    sol[i][2] = (dd[2] * sqrad - sgn * rad * dd[3] * sqrt1) / sqlen1;
+    sol[i][3] = (dd[3] * sqrad + sgn * rad * dd[2] * sqrt1) / sqlen1;
+    if (has_side) {
+      T t[2] = {sol[i][0] + sol[i][2], sol[i][1] + sol[i][3]};
+      const T n = sqrt(t[0] * t[0] + t[1] * t[1]);
+      if (n < MYO_MINVAL) { t[0] = 1; t[1] = 0; } else { t[0] /= n; t[1] /= n; }
+      good[i] = t[0] * sd[0] + t[1] * sd[1];
+    } else {
+      const T t[2] = {sol[i][0] - sol[i][2], sol[i][1] - sol[i][3]};
+      good[i] = -(t[0] * t[0] + t[1] * t[1]);
+    }
+    if (seg_intersect(dd, sol[i], dd + 2, sol[i] + 2)) good[i] = -10000;
+  }
+  const int i = (good[0] > good[1]) ? 0 : 1;
+  for (int k = 0; k < 4; ++k) pnt[k] = sol[i][k];
+  if (seg_intersect(dd, pnt, dd + 2, pnt + 2)) return -1;
+  const T c = tclamp((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqrad, (T)-1, (T)1);
+  return rad * acos(c);
+}
+
+template <typename T>
+DEV T wrap_geom(T* wpnt, const T* x0, const T* x1, const T* gpos, const T* gmat, T radius, int type,
+                const T* side, int has_side) {
+  T p0[3], p1[3], t[3];
+  for (int k = 0; k < 3; ++k) t[k] = x0[k] - gpos[k];
+  mulmatTvec3(p0, gmat, t);
+  for (int k = 0; k < 3; ++k) t[k] = x1[k] - gpos[k];
+  mulmatTvec3(p1, gmat, t);
+  if (norm3(p0) < MYO_MINVAL || norm3(p1) < MYO_MINVAL) return -1;
+  T axis0[3], axis1[3];
+  if (type == 4) {
+    T normal[3];
+    axis0[0] = p0[0]; axis0[1] = p0[1]; axis0[2] = p0[2];
+    normalize3(axis0);
+    cross3(normal, p0, p1);
+    const T nrm = norm3(normal);
+    if (nrm < MYO_MINVAL) {
+      int imin = 0;
+      if (fabs(axis0[1]) < fabs(axis0[imin])) imin = 1;
+      if (fabs(axis0[2]) < fabs(axis0[imin])) imin = 2;
+      T e[3] = {0, 0, 0};
+      e[imin] = 1;
+      cross3(normal, axis0, e);
+      normalize3(normal);
+    } else { normal[0] /= nrm; normal[1] /= nrm; normal[2] /= nrm; }
+    cross3(axis1, normal, axis0);
+    normalize3(axis1);
+  } else {
+    axis0[0] = 1; axis0[1] = 0; axis0[2] = 0; axis1[0] = 0; axis1[1] = 1; axis1[2] = 0;
+  }
+  const T s2[4] = {dot3(p0, axis0), dot3(p0, axis1), dot3(p1, axis0), dot3(p1, axis1)};
+  T sd[2] = {0, 0};
+  if (has_side) {
+    T ps[3];
+    for (int k = 0; k < 3; ++k) t[k] = side[k] - gpos[k];
+    mulmatTvec3(ps, gmat, t);
+    sd[0] = dot3(ps, axis0); sd[1] = dot3(ps, axis1);
+    const T n = sqrt(sd[0] * sd[0] + sd[1] * sd[1]);
+    if (n < MYO_MINVAL) { sd[0] = 1; sd[1] = 0; } else { sd[0] /= n; sd[1] /= n; }
+    sd[0] *= radius; sd[1] *= radius;
+  }
+  T pnt[4];
+  T wlen = wrap_circle(pnt, s2, sd, has_side, radius);
+  if (wlen < 0) return -1;
+  T r0[3], r1[3];
+  for (int k = 0; k < 3; ++k) { r0[k] = axis0[k] * pnt[0] + axis1[k] * pnt[1]; r1[k] = axis0[k] * pnt[2] + axis1[k] * pnt[3]; }
+  if (type == 5) {
+    const T L0 = sqrt((s2[0] - pnt[0]) * (s2[0] - pnt[0]) + (s2[1] - pnt[1]) * (s2[1] - pnt[1]));
+    const T L1 = sqrt((s2[2] - pnt[2]) * (s2[2] - pnt[2]) + (s2[3] - pnt[3]) * (s2[3] - pnt[3]));
+    r0[2] = p0[2] + (p1[2] - p0[2]) * L0 / (L0 + wlen + L1);
+    r1[2] = p0[2] + (p1[2] - p0[2]) * (L0 + wlen) / (L0 + wlen + L1);
+    const T height = fabs(r1[2] - r0[2]);
+    wlen = sqrt(wlen * wlen + height * height);
+  }
+  mulmatvec3(wpnt, gmat, r0);
+  mulmatvec3(wpnt + 3, gmat, r1);
+  for (int k = 0; k < 3; ++k) { wpnt[k] += gpos[k]; wpnt[3 + k] += gpos[k]; }
+  return wlen;
+}
+
+// moment contribution of one straight tendon segment p0 (on body b0) -> p1 (on body b1).
+// Dofs that move both bodies contribute axis x (p1-p0) . u = 0, so only the symmetric
+// difference of the two ancestor-dof masks is visited.
+template <typename T>
+DEV void tendon_segment_moment(const DevModel<T>& M, const Scratch<T>& s, T* Jrow, unsigned long long tmask,
+                               int b0, const T* p0, int b1, const T* p1, const T* u, T inv_div) {
+  const unsigned long long m0 = M.body_dofmask[b0], m1 = M.body_dofmask[b1];
+  unsigned long long x = (m0 ^ m1) & tmask;
+  while (x) {
+    const int d = myo_ffsll(x);
+    x &= x - 1;
+    T col[3];
+    const int on1 = (int)((m1 >> d) & 1ull);
+    jac_col(M, s, d, on1 ? p1 : p0, col);
+    const T v = dot3(col, u) * inv_div;
+    const int slot = myo_popcll(tmask & ((1ull << d) - 1ull));
+    Jrow[slot] += on1 ? v : -v;
+  }
+}
+
+template <typename T>
+DEV void tendon(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  WAVE_FN
+  PHASE {
+    const int t = lane;
+    if (t < M.ntendon) {
+      const int adr = M.tendon_adr[t], num = M.tendon_num[t];
+      const unsigned long long tmask = M.tendon_dofmask[t];
+      T* J = s.ten_J + t * MYO_TJ_MAX;
+      for (int k = 0; k < MYO_TJ_MAX; ++k) J[k] = 0;
+      T len = 0, divisor = 1;
+      int j = 0;
+      while (j < num - 1) {
+        const int type0 = M.wrap_type[adr + j], type1 = M.wrap_type[adr + j + 1];
+        const int id0 = M.wrap_objid[adr + j];
+        int id1 = M.wrap_objid[adr + j + 1];
+        if (type0 == 2 || type1 == 2) {
+          if (type0 == 2) divisor = M.wrap_prm[adr + j];
+          j++;
+          continue;
+        }
+        T wpnt[12];
+        int wbody[4], wcnt, idg = -1;
+        T wlen = -1;
+        wbody[0] = M.site_bodyid[id0];
+        body_point(s, wbody[0], M.site_pos + 3 * id0, wpnt);
+        T x1[3];
+        if (type1 == 4 || type1 == 5) {
+          idg = id1;
+          id1 = M.wrap_objid[adr + j + 2];
+          const int b1 = M.site_bodyid[id1];
+          body_point(s, b1, M.site_pos + 3 * id1, x1);
+          const int gb = M.geom_bodyid[idg];
+          T gpos[3], gmat[9], side[3] = {0, 0, 0};
+          body_point(s, gb, M.geom_pos + 3 * idg, gpos);
+          mulmat3(gmat, s.xmat + 9 * gb, M.geom_mat + 9 * idg);
+          const int sid = M.wrap_side[adr + j + 1];
+          if (sid >= 0) body_point(s, M.site_bodyid[sid], M.site_pos + 3 * sid, side);
+          wlen = wrap_geom(wpnt + 3, wpnt, x1, gpos, gmat, geom_size0_of(M, K, s, idg), type1, side, sid >= 0);
+        } else {
+          body_point(s, M.site_bodyid[id1], M.site_pos + 3 * id1, x1);
+        }
+        if (wlen < 0) {
+          wbody[1] = M.site_bodyid[id1];
+          wpnt[3] = x1[0]; wpnt[4] = x1[1]; wpnt[5] = x1[2];
+          wcnt = 2;
+        } else {
+          wbody[1] = wbody[2] = M.geom_bodyid[idg];
+          wbody[3] = M.site_bodyid[id1];
+          wpnt[9] = x1[0]; wpnt[10] = x1[1]; wpnt[11] = x1[2];
+          wcnt = 4;
+        }
+        const T inv_div = 1 / divisor;
+        for (int k = 0; k < wcnt - 1; ++k) {
+          if (wcnt == 4 && k == 1) { len += wlen * inv_div; continue; }
+          T dif[3] = {wpnt[3 * k + 3] - wpnt[3 * k], wpnt[3 * k + 4] - wpnt[3 * k + 1], wpnt[3 * k + 5] - wpnt[3 * k + 2]};
+          const T dn = norm3(dif);
+          len += dn * inv_div;
+          if (wbody[k] != wbody[k + 1] && dn > MYO_MINVAL) {
+            dif[0] /= dn; dif[1] /= dn; dif[2] /= dn;
+            tendon_segment_moment(M, s, J, tmask, wbody[k], wpnt + 3 * k, wbody[k + 1], wpnt + 3 * k + 3, dif, inv_div);
+          }
+        }
+        j += (idg >= 0 ? 2 : 1);
+      }
+      s.ten_length[t] = len;
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// P5: composite rigid body inertia -> tree-sparse M (mj_crb)
+template <typename T>
+DEV void crb(const DevModel<T>& M, Scratch<T>& s) {
+  WAVE_FN
+  PHASE {
+    const int b = lane;
+    if (b > 0 && b < M.nbody) {
+      T acc[10];
+      for (int k = 0; k < 10; ++k) acc[k] = 0;
+      unsigned long long sub = M.body_submask[b];
+      while (sub) {
+        const int c = myo_ffsll(sub);
+        sub &= sub - 1;
+        for (int k = 0; k < 10; ++k) acc[k] += s.cinert[10 * c + k];
+      }
+      for (int k = 0; k < 10; ++k) s.crb[10 * b + k] = acc[k];
+    }
+  }
+  SYNC();
+  PHASE {
+    for (int e = lane; e < M.nM; e += 64) {
+      const int i = M.M_i[e], j = M.M_j[e];
+      T buf[6];
+      mul_inert_vec(buf, s.crb + 10 * M.dof_bodyid[i], s.cdof + 6 * i);
+      T v = 0;
+      for (int k = 0; k < 6; ++k) v += s.cdof[6 * j + k] * buf[k];
+      if (i == j) v += M.dof_armature[i];
+      s.qM[e] = v;
+    }
+  }
+  SYNC();
+}
+
+// out = M * v   (lanes = dofs; static CSR pattern of the symmetric tree-sparse matrix)
+template <typename T>
+DEV void mul_M(const DevModel<T>& M, const Scratch<T>& s, T* out, const T* v) {
+  WAVE_FN
+  PHASE {
+    const int i = lane;
+    if (i < M.nv) {
+      T acc = 0;
+      for (int k = M.mv_adr[i]; k < M.mv_adr[i + 1]; ++k) acc += s.qM[M.mv_e[k]] * v[M.mv_col[k]];
+      out[i] = acc;
+    }
+  }
+  SYNC();
+}
+
+// packed dense H <- M (+ diag)
+template <typename T>
+DEV void load_H_from_M(const DevModel<T>& M, Scratch<T>& s, const T* diag_add, T diag_scale) {
+  WAVE_FN
+  const int nh = M.nv * (M.nv + 1) / 2;
+  PHASE { for (int k = lane; k < nh; k += 64) s.H[k] = 0; }
+  SYNC();
+  PHASE {
+    for (int e = lane; e < M.nM; e += 64) {
+      const int i = M.M_i[e], j = M.M_j[e];
+      T v = s.qM[e];
+      if (i == j && diag_add) v += diag_scale * diag_add[i];
+      s.H[MYO_HIDX(i, j)] = v;
+    }
+  }
+  SYNC();
+}
+
+// in-place Cholesky of the packed lower triangle (right-looking; lanes tile the trailing block)
+template <typename T>
+DEV void chol_factor(Scratch<T>& s, int n) {
+  WAVE_FN
+  for (int k = 0; k < n; ++k) {
+    PHASE {
+      // every lane derives the pivot; lanes k+1.. scale their column entry
+      T piv = s.H[MYO_HIDX(k, k)];
+      if (piv < MYO_MINVAL) piv = MYO_MINVAL;
+      const T dk = sqrt(piv);
+      const int i = k + 1 + lane;
+      if (i < n) s.H[MYO_HIDX(i, k)] = s.H[MYO_HIDX(i, k)] / dk;
+      if (lane == 63) s.H[MYO_HIDX(k, k)] = dk;  // last lane: never a column lane (n <= 36 < 64)
+    }
+    SYNC();
+    PHASE {
+      const int li = lane >> 3, lj = lane & 7;
+      for (int i = k + 1 + li; i < n; i += 8) {
+        const T lik = s.H[MYO_HIDX(i, k)];
+        for (int j = k + 1 + lj; j <= i; j += 8) s.H[MYO_HIDX(i, j)] -= lik * s.H[MYO_HIDX(j, k)];
+      }
+    }
+    SYNC();
+  }
+}
+
+// solve L L' x = b in place (x in scratch vector)
+template <typename T>
+DEV void chol_solve(Scratch<T>& s, T* x, int n) {
+  WAVE_FN
+  for (int k = 0; k < n; ++k) {
+    PHASE {
+      const T xk = x[k] / s.H[MYO_HIDX(k, k)];
+      const int i = k + 1 + lane;
+      if (i < n) x[i] -= s.H[MYO_HIDX(i, k)] * xk;
+      if (lane == 63) x[k] = xk;
+    }
+    SYNC();
+  }
+  for (int k = n - 1; k >= 0; --k) {
+    PHASE {
+      const T xk = x[k] / s.H[MYO_HIDX(k, k)];
+      const int i = lane;
+      if (i < k) x[i] -= s.H[MYO_HIDX(k, i)] * xk;
+      if (lane == 63) x[k] = xk;
+    }
+    SYNC();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// P6: collision (narrow phase per candidate pair; lanes = pairs)
+template <typename T> struct ContactTmp { T dist[2], pos[6], nrm[6]; int n; };
+
+template <typename T> DEV void make_frame(T* f) {
+  normalize3(f);
+  f[3] = f[4] = f[5] = 0;
+  if (f[1] < (T)0.5 && f[1] > (T)-0.5) f[4] = 1; else f[5] = 1;
+  const T t = dot3(f, f + 3);
+  f[3] -= t * f[0]; f[4] -= t * f[1]; f[5] -= t * f[2];
+  normalize3(f + 3);
+  cross3(f + 6, f, f + 3);
+}
+template <typename T>
+DEV int sphere_sphere(T* dist, T* pos, T* n, const T* c1, T r1, const T* c2, T r2, T margin) {
+  const T dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  const T cd = norm3(dif);
+  if (cd - r1 - r2 > margin) return 0;
+  if (cd < MYO_MINVAL) { n[0] = 1; n[1] = 0; n[2] = 0; } else { n[0] = dif[0] / cd; n[1] = dif[1] / cd; n[2] = dif[2] / cd; }
+  *dist = cd - r1 - r2;
+  for (int k = 0; k < 3; ++k) pos[k] = c1[k] + n[k] * (r1 + (T)0.5 * (*dist));
+  return 1;
+}
+template <typename T> DEV void seg_nearest(T* out, const T* c, const T* axis, T half, const T* p) {
+  T t = (p[0] - c[0]) * axis[0] + (p[1] - c[1]) * axis[1] + (p[2] - c[2]) * axis[2];
+  t = tclamp(t, -half, half);
+  for (int k = 0; k < 3; ++k) out[k] = c[k] + t * axis[k];
+}
+
+template <typename T>
+DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g1, int g2, T margin,
+                      ContactTmp<T>& o) {
+  const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  const int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
+  T p1[3], p2[3], R1[9], R2[9];
+  body_point(s, b1, M.geom_pos + 3 * g1, p1);
+  body_point(s, b2, M.geom_pos + 3 * g2, p2);
+  mulmat3(R1, s.xmat + 9 * b1, M.geom_mat + 9 * g1);
+  mulmat3(R2, s.xmat + 9 * b2, M.geom_mat + 9 * g2);
+  const T s1[3] = {geom_size0_of(M, K, s, g1), M.geom_size[3 * g1 + 1], M.geom_size[3 * g1 + 2]};
+  const T s2[3] = {geom_size0_of(M, K, s, g2), M.geom_size[3 * g2 + 1], M.geom_size[3 * g2 + 2]};
+  o.n = 0;
+  if (t1 == 0 && t2 == 2) {
+    const T n[3] = {R1[2], R1[5], R1[8]};
+    const T dd = (p2[0] - p1[0]) * n[0] + (p2[1] - p1[1]) * n[1] + (p2[2] - p1[2]) * n[2] - s2[0];
+    if (dd > margin) return;
+    o.dist[0] = dd;
+    for (int k = 0; k < 3; ++k) { o.nrm[k] = n[k]; o.pos[k] = p2[k] - n[k] * (s2[0] + (T)0.5 * dd); }
+    o.n = 1;
+  } else if (t1 == 0 && t2 == 3) {
+    const T n[3] = {R1[2], R1[5], R1[8]}, ax[3] = {R2[2], R2[5], R2[8]};
+    for (int e = 0; e < 2; ++e) {
+      const T sg = e ? (T)-1 : (T)1;
+      T c[3];
+      for (int k = 0; k < 3; ++k) c[k] = p2[k] + sg * s2[1] * ax[k];
+      const T dd = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2] - s2[0];
+      if (dd > margin) continue;
+      o.dist[o.n] = dd;
+      for (int k = 0; k < 3; ++k) { o.nrm[3 * o.n + k] = n[k]; o.pos[3 * o.n + k] = c[k] - n[k] * (s2[0] + (T)0.5 * dd); }
+      o.n++;
+    }
+  } else if (t1 == 2 && t2 == 2) {
+    o.n = sphere_sphere(o.dist, o.pos, o.nrm, p1, s1[0], p2, s2[0], margin);
+  } else if (t1 == 2 && t2 == 3) {
+    const T ax[3] = {R2[2], R2[5], R2[8]};
+    T q[3];
+    seg_nearest(q, p2, ax, s2[1], p1);
+    o.n = sphere_sphere(o.dist, o.pos, o.nrm, p1, s1[0], q, s2[0], margin);
+  } else if (t1 == 3 && t2 == 3) {
+    const T a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
+    const T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const T ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
+    const T u = -dot3(a1, dif), v = dot3(a2, dif);
+    const T det = ma * mc - mb * mb;
+    T x1, x2;
+    if (fabs(det) < (T)1e-12) { x1 = 0; x2 = v / mc; } else { x1 = (mc * u - mb * v) / det; x2 = (ma * v - mb * u) / det; }
+    x1 = tclamp(x1, -s1[1], s1[1]);
+    x2 = tclamp(x2, -s2[1], s2[1]);
+    (void)x2;
+    T q1[3], q2[3];
+    for (int k = 0; k < 3; ++k) q1[k] = p1[k] + x1 * a1[k];
+    seg_nearest(q2, p2, a2, s2[1], q1);
+    seg_nearest(q1, p1, a1, s1[1], q2);
+    o.n = sphere_sphere(o.dist, o.pos, o.nrm, q1, s1[0], q2, s2[0], margin);
+  } else if (t1 == 2 && t2 == 6) {
+    const T t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    T c[3], cl[3];
+    mulmatTvec3(c, R2, t);
+    int inside = 1;
+    for (int k = 0; k < 3; ++k) {
+      cl[k] = c[k];
+      if (cl[k] > s2[k]) { cl[k] = s2[k]; inside = 0; } else if (cl[k] < -s2[k]) { cl[k] = -s2[k]; inside = 0; }
+    }
+    T nl[3], dd;
+    if (!inside) {
+      const T df[3] = {cl[0] - c[0], cl[1] - c[1], cl[2] - c[2]};
+      const T dn = norm3(df);
+      dd = dn - s1[0];
+      if (dd > margin) return;
+      nl[0] = df[0] / dn; nl[1] = df[1] / dn; nl[2] = df[2] / dn;
+    } else {
+      int kb = 0;
+      T best = (T)1e30;
+      for (int k = 0; k < 3; ++k) { const T e = s2[k] - fabs(c[k]); if (e < best) { best = e; kb = k; } }
+      nl[0] = nl[1] = nl[2] = 0;
+      nl[kb] = c[kb] > 0 ? (T)-1 : (T)1;
+      dd = -best - s1[0];
+    }
+    mulmatvec3(o.nrm, R2, nl);
+    o.dist[0] = dd;
+    for (int k = 0; k < 3; ++k) o.pos[k] = p1[k] + o.nrm[k] * (s1[0] + (T)0.5 * dd);
+    o.n = 1;
+  }
+}
+
+// impedance / reference parameters of one constraint row (mj_makeImpedance, getsolparam)
+template <typename T>
+DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos_minus_margin, T* Kp, T* Bp, T* Ip) {
+  T d0 = tclamp(solimp[0], (T)0.0001, (T)0.9999), d1 = tclamp(solimp[1], (T)0.0001, (T)0.9999);
+  T width = solimp[2] < 0 ? (T)0 : solimp[2];
+  const T mid = tclamp(solimp[3], (T)0.0001, (T)0.9999);
+  const T power = solimp[4] < 1 ? (T)1 : solimp[4];
+  T imp;
+  if (d0 == d1 || width <= MYO_MINVAL) imp = (T)0.5 * (d0 + d1);
+  else {
+    const T x = fabs(pos_minus_margin) / width;
+    if (x >= 1) imp = d1;
+    else if (x <= 0) imp = d0;
+    else {
+      T y;
+      if (power == 1) y = x;
+      else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+      else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+      imp = d0 + y * (d1 - d0);
+    }
+  }
+  T tc = solref[0];
+  const T dr = solref[1];
+  if (tc > 0) {
+    if (!(M.disableflags & (1 << 11)) && tc < 2 * M.timestep) tc = 2 * M.timestep;
+    *Kp = 1 / tmax(MYO_MINVAL, d1 * d1 * tc * tc * dr * dr);
+    *Bp = 2 / tmax(MYO_MINVAL, d1 * tc);
+  } else { *Kp = -tc / (d1 * d1); *Bp = -dr / d1; }
+  *Ip = imp;
+}
+
+template <typename T>
+DEV void collision_and_constraints(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  WAVE_FN
+  // ---- limit rows: joints (lanes = joints), then tendons (lanes = tendons)
+  LANE_VAR(int, cnt);
+  LANE_VAR(T, dlo);
+  LANE_VAR(T, dhi);
+  int total = 0;
+  PHASE {
+    const int j = lane;
+    int c = 0;
+    T a = 0, b = 0;
+    if (j < M.njnt && M.jnt_limited[j] && M.jnt_type[j] != 0) {
+      const T q = s.qpos[M.jnt_qposadr[j]];
+      a = q - M.jnt_range[2 * j]; b = M.jnt_range[2 * j + 1] - q;
+      c = (a < M.jnt_margin[j] ? 1 : 0) + (b < M.jnt_margin[j] ? 1 : 0);
+    }
+    LV(cnt) = c; LV(dlo) = a; LV(dhi) = b;
+  }
+  WAVE_EXSCAN(LV(cnt), s.npre, total);
+  PHASE {
+    const int j = lane;
+    if (LV(cnt) > 0) {
+      int r = s.npre[lane];
+      const T mg = M.jnt_margin[j];
+      for (int side = 0; side < 2; ++side) {
+        const T dist = side ? LV(dhi) : LV(dlo);
+        if (dist < mg && r < MYO_NLIM_MAX) {
+          T Kc, Bc, Ic;
+          sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dist - mg, &Kc, &Bc, &Ic);
+          const T R = tmax(MYO_MINVAL, (1 - Ic) * M.dof_invweight0[M.jnt_dofadr[j]] / Ic);
+          s.lim_id[r] = j; s.lim_sgn[r] = side ? (T)-1 : (T)1;
+          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * (dist - mg);
+          r++;
+        }
+      }
+    }
+    if (lane == 0) s.nl = total < MYO_NLIM_MAX ? total : MYO_NLIM_MAX;
+  }
+  SYNC();
+  const int nl = s.nl;
+  PHASE {
+    const int t = lane;
+    int c = 0;
+    T a = 0, b = 0;
+    if (t < M.ntendon && M.tendon_limited[t]) {
+      const T L = s.ten_length[t];
+      a = L - M.tendon_range[2 * t]; b = M.tendon_range[2 * t + 1] - L;
+      c = (a < M.tendon_margin[t] ? 1 : 0) + (b < M.tendon_margin[t] ? 1 : 0);
+    }
+    LV(cnt) = c; LV(dlo) = a; LV(dhi) = b;
+  }
+  WAVE_EXSCAN(LV(cnt), s.npre, total);
+  PHASE {
+    const int t = lane;
+    if (LV(cnt) > 0) {
+      int r = nl + s.npre[lane];
+      const T mg = M.tendon_margin[t];
+      for (int side = 0; side < 2; ++side) {
+        const T dist = side ? LV(dhi) : LV(dlo);
+        if (dist < mg && r < MYO_NLIM_MAX) {
+          T Kc, Bc, Ic;
+          sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dist - mg, &Kc, &Bc, &Ic);
+          const T R = tmax(MYO_MINVAL, (1 - Ic) * M.tendon_invweight0[t] / Ic);
+          s.lim_id[r] = t; s.lim_sgn[r] = side ? (T)-1 : (T)1;
+          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * (dist - mg);
+          r++;
+        }
+      }
+    }
+    if (lane == 0) { int n = nl + total; s.ntl = (n < MYO_NLIM_MAX ? n : MYO_NLIM_MAX) - nl; }
+  }
+  SYNC();
+  const int nlim = s.nl + s.ntl;
+  // ---- contacts: lanes = candidate pairs (64 at a time)
+  int ncon = 0;
+  LANE_VAR(ContactTmp<T>, ct);
+  for (int base = 0; base < M.npair; base += 64) {
+    PHASE {
+      const int p = base + lane;
+      LV(ct).n = 0;
+      if (p < M.npair) {
+        const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+        const T margin = tmax(M.geom_margin[g1], M.geom_margin[g2]);
+        const T rb1 = M.geom_rbound[g1], rb2 = M.geom_rbound[g2];
+        int skip = 0;
+        if (rb1 > 0 && rb2 > 0) {
+          // bounding-sphere filter with the MODEL rbound (the reference rewrites geom_size per
+          // episode without refreshing rbound, baoding.py:586-604 — the stale value gates contacts)
+          T c1[3], c2[3];
+          body_point(s, M.geom_bodyid[g1], M.geom_pos + 3 * g1, c1);
+          body_point(s, M.geom_bodyid[g2], M.geom_pos + 3 * g2, c2);
+          const T df[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+          const T bound = rb1 + rb2 + margin;
+          if (dot3(df, df) > bound * bound) skip = 1;
+        }
+        if (!skip) {
+          collide_pair(M, K, s, g1, g2, margin, LV(ct));
+          // keep only contacts that enter the constraint set (dist < margin - gap)
+          const T inc = margin - tmax(M.geom_gap[g1], M.geom_gap[g2]);
+          int keep = 0;
+          for (int k = 0; k < LV(ct).n; ++k)
+            if (LV(ct).dist[k] < inc) {
+              if (keep != k) {
+                LV(ct).dist[keep] = LV(ct).dist[k];
+                for (int e = 0; e < 3; ++e) { LV(ct).pos[3 * keep + e] = LV(ct).pos[3 * k + e]; LV(ct).nrm[3 * keep + e] = LV(ct).nrm[3 * k + e]; }
+              }
+              keep++;
+            }
+          LV(ct).n = keep;
+        }
+      }
+    }
+    WAVE_EXSCAN(LV(ct).n, s.npre, total);
+    PHASE {
+      const int p = base + lane;
+      for (int k = 0; k < LV(ct).n; ++k) {
+        const int ci = ncon + s.npre[lane] + k;
+        if (ci >= MYO_NCON_MAX) break;
+        const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+        ContactRec<T>& c = s.con[ci];
+        for (int e = 0; e < 3; ++e) { c.pos[e] = LV(ct).pos[3 * k + e]; c.frame[e] = LV(ct).nrm[3 * k + e]; }
+        make_frame(c.frame);
+        c.b1 = M.geom_bodyid[g1]; c.b2 = M.geom_bodyid[g2];
+        // parameter mixing (mj_contactParam)
+        const int pr1 = M.geom_priority[g1], pr2 = M.geom_priority[g2];
+        T mix;
+        if (pr1 != pr2) mix = pr1 > pr2 ? (T)1 : (T)0;
+        else {
+          const T m1 = M.geom_solmix[g1], m2 = M.geom_solmix[g2];
+          if (m1 >= MYO_MINVAL && m2 >= MYO_MINVAL) mix = m1 / (m1 + m2);
+          else if (m1 < MYO_MINVAL && m2 < MYO_MINVAL) mix = (T)0.5;
+          else mix = m1 < MYO_MINVAL ? (T)0 : (T)1;
+        }
+        T solref[2], solimp[5], fr[3];
+        const T *r1 = M.geom_solref + 2 * g1, *r2 = M.geom_solref + 2 * g2;
+        if (r1[0] > 0 && r2[0] > 0) { for (int e = 0; e < 2; ++e) solref[e] = mix * r1[e] + (1 - mix) * r2[e]; }
+        else { for (int e = 0; e < 2; ++e) solref[e] = tmin(r1[e], r2[e]); }
+        for (int e = 0; e < 5; ++e) solimp[e] = mix * M.geom_solimp[5 * g1 + e] + (1 - mix) * M.geom_solimp[5 * g2 + e];
+        for (int e = 0; e < 3; ++e) {
+          const T a = geom_fric_of(M, K, s, g1, e), b = geom_fric_of(M, K, s, g2, e);
+          fr[e] = (pr1 == pr2) ? tmax(a, b) : (pr1 > pr2 ? a : b);
+        }
+        c.mu[0] = fr[0]; c.mu[1] = fr[0];  // condim 3: both tangential directions use friction[0]
+        const T margin = tmax(M.geom_margin[g1], M.geom_margin[g2]);
+        const T inc = margin - tmax(M.geom_gap[g1], M.geom_gap[g2]);
+        const T dist = LV(ct).dist[k];
+        T Kc, Bc, Ic;
+        sol_param(M, solref, solimp, dist - inc, &Kc, &Bc, &Ic);
+        const T tran = M.body_invweight0[2 * c.b1] + M.body_invweight0[2 * c.b2];
+        const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr[0] * fr[0] * tran) / Ic);
+        const T mu = fr[0] / sqrt(M.impratio);
+        const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
+        c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * (dist - inc);
+        // dofs this contact can move
+        unsigned long long sup = M.body_dofmask[c.b1] | M.body_dofmask[c.b2];
+        int ns = 0;
+        while (sup && ns < MYO_CS_MAX) { c.sup[ns++] = (unsigned char)myo_ffsll(sup); sup &= sup - 1; }
+        c.nsup = ns;
+      }
+    }
+    SYNC();
+    ncon += total;
+    if (ncon > MYO_NCON_MAX) ncon = MYO_NCON_MAX;
+  }
+  PHASE {
+    if (lane == 0) { s.ncon = ncon; s.nefc = nlim + 4 * ncon; }
+    // contact row parameters replicated per pyramid edge
+    for (int ci = lane; ci < ncon; ci += 64)
+      for (int e = 0; e < 4; ++e) {
+        const int r = nlim + 4 * ci + e;
+        s.efc_D[r] = s.con[ci].D; s.efc_B[r] = s.con[ci].B; s.efc_kip[r] = s.con[ci].kip;
+      }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// matrix-free constraint Jacobian products
+// body spatial vectors V_b(v) = sum_{d in ancestors(b)} cdof_d v_d   (lanes = bodies)
+template <typename T>
+DEV void body_vectors(const DevModel<T>& M, const Scratch<T>& s, const T* v, T* out) {
+  WAVE_FN
+  PHASE {
+    const int b = lane;
+    if (b < M.nbody) {
+      T acc[6] = {0, 0, 0, 0, 0, 0};
+      unsigned long long m = M.body_dofmask[b];
+      while (m) {
+        const int d = myo_ffsll(m);
+        m &= m - 1;
+        const T vd = v[d];
+        for (int e = 0; e < 6; ++e) acc[e] += s.cdof[6 * d + e] * vd;
+      }
+      for (int e = 0; e < 6; ++e) out[6 * b + e] = acc[e];
+    }
+  }
+  SYNC();
+}
+template <typename T>
+DEV void point_vel(const DevModel<T>& M, const Scratch<T>& s, const T* bv, int b, const T* p, T* out) {
+  int r = M.body_rootid[b];
+  const T* c = s.com + 3 * r; const T* V = bv + 6 * b;
+  const T off[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+  T t[3];
+  cross3(t, V, off);
+  out[0] = V[3] + t[0]; out[1] = V[4] + t[1]; out[2] = V[5] + t[2];
+}
+
+// out[r] = (J v)[r] for every constraint row; bv = body vectors of v (already computed)
+template <typename T>
+DEV void J_times(const DevModel<T>& M, const Scratch<T>& s, const T* v, const T* bv, T* out) {
+  WAVE_FN
+  const int nl = s.nl, nlim = s.nl + s.ntl, nefc = s.nefc;
+  PHASE {
+    for (int r = lane; r < nefc; r += 64) {
+      T val;
+      if (r < nl) val = s.lim_sgn[r] * v[M.jnt_dofadr[s.lim_id[r]]];
+      else if (r < nlim) {
+        const int t = s.lim_id[r];
+        unsigned long long m = M.tendon_dofmask[t];
+        T acc = 0;
+        int slot = 0;
+        while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * v[d]; slot++; }
+        val = s.lim_sgn[r] * acc;
+      } else {
+        const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
+        const ContactRec<T>& c = s.con[ci];
+        T v1[3], v2[3];
+        point_vel(M, s, bv, c.b1, c.pos, v1);
+        point_vel(M, s, bv, c.b2, c.pos, v2);
+        const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+        const T vn = dot3(c.frame, rel), vt = dot3(c.frame + 3 + 3 * (e >> 1), rel);
+        val = vn + ((e & 1) ? -c.mu[e >> 1] : c.mu[e >> 1]) * vt;
+      }
+      out[r] = val;
+    }
+  }
+  SYNC();
+}
+
+// out = J' f  (lanes = dofs; contacts act as a world force at the contact point)
+template <typename T>
+DEV void JT_times(const DevModel<T>& M, Scratch<T>& s, const T* f, T* out) {
+  WAVE_FN
+  const int nl = s.nl, nlim = s.nl + s.ntl, ncon = s.ncon;
+  PHASE {
+    for (int ci = lane; ci < ncon; ci += 64) {
+      ContactRec<T>& c = s.con[ci];
+      const T* fe = f + nlim + 4 * ci;
+      const T fn = fe[0] + fe[1] + fe[2] + fe[3], ft1 = c.mu[0] * (fe[0] - fe[1]), ft2 = c.mu[1] * (fe[2] - fe[3]);
+      for (int k = 0; k < 3; ++k) c.F[k] = c.frame[k] * fn + c.frame[3 + k] * ft1 + c.frame[6 + k] * ft2;
+    }
+  }
+  SYNC();
+  PHASE {
+    const int d = lane;
+    if (d < M.nv) {
+      T acc = 0;
+      for (int r = 0; r < nl; ++r)
+        if (M.jnt_dofadr[s.lim_id[r]] == d) acc += s.lim_sgn[r] * f[r];
+      for (int r = nl; r < nlim; ++r) {
+        const int t = s.lim_id[r];
+        const unsigned long long m = M.tendon_dofmask[t];
+        if ((m >> d) & 1ull) acc += s.lim_sgn[r] * s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f[r];
+      }
+      for (int ci = 0; ci < ncon; ++ci) {
+        const ContactRec<T>& c = s.con[ci];
+        const int on1 = (int)((M.body_dofmask[c.b1] >> d) & 1ull), on2 = (int)((M.body_dofmask[c.b2] >> d) & 1ull);
+        if (on1 != on2) {
+          T col[3];
+          jac_col(M, s, d, c.pos, col);
+          const T v = dot3(col, c.F);
+          acc += on2 ? v : -v;
+        }
+      }
+      out[d] = acc;
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// P8: velocity stage (mj_fwdVelocity): tendon/actuator velocity, comVel, passive, RNE bias, aref
+template <typename T>
+DEV void fwd_velocity(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  WAVE_FN
+  body_vectors(M, s, s.qvel, s.cvel);
+  PHASE {
+    const int t = lane;
+    if (t < M.ntendon) {
+      unsigned long long m = M.tendon_dofmask[t];
+      T acc = 0;
+      int slot = 0;
+      while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * s.qvel[d]; slot++; }
+      s.ten_vel[t] = acc;
+    }
+    const int d = lane;
+    if (d < M.nv) {
+      // cdof_dot = (velocity accumulated before this dof) x cdof   (mj_comVel)
+      T cv[6] = {0, 0, 0, 0, 0, 0};
+      unsigned long long m = M.dof_prevmask[d];
+      const int is_free_trans = (int)((m >> 63) & 1ull);
+      m &= ~(1ull << 63);
+      while (m) {
+        const int o = myo_ffsll(m);
+        m &= m - 1;
+        const T vo = s.qvel[o];
+        for (int e = 0; e < 6; ++e) cv[e] += s.cdof[6 * o + e] * vo;
+      }
+      if (is_free_trans) { for (int e = 0; e < 6; ++e) s.cdof_dot[6 * d + e] = 0; }
+      else cross_motion(s.cdof_dot + 6 * d, cv, s.cdof + 6 * d);
+      // passive joint forces
+      T p = -M.dof_damping[d] * s.qvel[d];
+      const int j = M.dof_jntid[d];
+      if (M.jnt_type[j] != 0 && M.jnt_stiffness[j] != 0) {
+        const int qa = M.jnt_qposadr[j];
+        p -= M.jnt_stiffness[j] * (s.qpos[qa] - M.qpos_spring[qa]);
+      }
+      s.qfrc_passive[d] = p;
+    }
+  }
+  SYNC();
+  if (M.any_tendon_passive) {
+    PHASE {
+      const int d = lane;
+      if (d < M.nv) {
+        T acc = 0;
+        for (int t = 0; t < M.ntendon; ++t) {
+          const T k = M.tendon_stiffness[t], b = M.tendon_damping[t];
+          const unsigned long long m = M.tendon_dofmask[t];
+          if ((k != 0 || b != 0) && ((m >> d) & 1ull)) {
+            const T f = -k * (s.ten_length[t] - M.tendon_lengthspring[t]) - b * s.ten_vel[t];
+            acc += s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f;
+          }
+        }
+        s.qfrc_passive[d] += acc;
+      }
+    }
+    SYNC();
+  }
+  // RNE with zero acceleration: body forces
+  PHASE {
+    const int b = lane;
+    if (b < M.nbody) {
+      T a[6] = {0, 0, 0, -M.gravity[0], -M.gravity[1], -M.gravity[2]};
+      unsigned long long m = M.body_dofmask[b];
+      while (m) {
+        const int d = myo_ffsll(m);
+        m &= m - 1;
+        const T vd = s.qvel[d];
+        for (int e = 0; e < 6; ++e) a[e] += s.cdof_dot[6 * d + e] * vd;
+      }
+      T t1[6], t2[6], t3[6];
+      mul_inert_vec(t1, s.cinert + 10 * b, a);
+      mul_inert_vec(t2, s.cinert + 10 * b, s.cvel + 6 * b);
+      cross_force(t3, s.cvel + 6 * b, t2);
+      for (int e = 0; e < 6; ++e) s.cfrcb[6 * b + e] = (b == 0) ? (T)0 : t1[e] + t3[e];
+    }
+  }
+  SYNC();
+  PHASE {
+    const int d = lane;
+    if (d < M.nv) {
+      T f[6] = {0, 0, 0, 0, 0, 0};
+      unsigned long long sub = M.body_submask[M.dof_bodyid[d]];
+      while (sub) {
+        const int c = myo_ffsll(sub);
+        sub &= sub - 1;
+        for (int e = 0; e < 6; ++e) f[e] += s.cfrcb[6 * c + e];
+      }
+      T acc = 0;
+      for (int e = 0; e < 6; ++e) acc += s.cdof[6 * d + e] * f[e];
+      s.qfrc_bias[d] = acc;
+    }
+  }
+  SYNC();
+  // reference acceleration of every constraint row: aref = -B vel - K imp (pos - margin)
+  if (s.nefc > 0) {
+    J_times(M, s, s.qvel, s.cvel, s.efc_jv);
+    PHASE { for (int r = lane; r < s.nefc; r += 64) s.efc_aref[r] = -s.efc_B[r] * s.efc_jv[r] - s.efc_kip[r]; }
+    SYNC();
+  }
+  (void)K;
+}
+
+// ------------------------------------------------------------------------------------------
+// P9: muscle actuation (mj_fwdActuation, mju_muscleDynamics/Gain/Bias)
+template <typename T> DEV T muscle_FL(T L, T lmin, T lmax) {
+  if (L < lmin || L > lmax) return 0;
+  const T a = (T)0.5 * (lmin + 1), b = (T)0.5 * (1 + lmax);
+  T x;
+  if (L <= a) { x = (L - lmin) / tmax(MYO_MINVAL, a - lmin); return (T)0.5 * x * x; }
+  if (L <= 1) { x = (1 - L) / tmax(MYO_MINVAL, 1 - a); return 1 - (T)0.5 * x * x; }
+  if (L <= b) { x = (L - 1) / tmax(MYO_MINVAL, b - 1); return 1 - (T)0.5 * x * x; }
+  x = (lmax - L) / tmax(MYO_MINVAL, lmax - b);
+  return (T)0.5 * x * x;
+}
+
+template <typename T>
+DEV void fwd_actuation(const DevModel<T>& M, Scratch<T>& s) {
+  WAVE_FN
+  PHASE {
+    const int i = lane;
+    if (i < M.nu) {
+      T ctrl = s.ctrl[i];
+      if (M.actuator_ctrllimited[i]) ctrl = tclamp(ctrl, M.actuator_ctrlrange[2 * i], M.actuator_ctrlrange[2 * i + 1]);
+      T input = ctrl;
+      if (M.actuator_dyntype[i] == 3) {
+        const int ia = i - (M.nu - M.na);
+        const T act = s.act[ia];
+        const T* prm = M.actuator_dynprm + 10 * i;
+        const T cc = tclamp(ctrl, (T)0, (T)1), ac = tclamp(act, (T)0, (T)1);
+        const T tau = cc > act ? prm[0] * ((T)0.5 + (T)1.5 * ac) : prm[1] / ((T)0.5 + (T)1.5 * ac);
+        s.act_dot[ia] = (cc - act) / tmax(MYO_MINVAL, tau);
+        input = act;
+      }
+      const int tid = M.actuator_tendon[i];
+      const T gear = M.actuator_gear[6 * i];
+      const T len = gear * s.ten_length[tid], vel = gear * s.ten_vel[tid];
+      T gain, bias = 0;
+      const T* lr = M.actuator_lengthrange + 2 * i;
+      if (M.actuator_gaintype[i] == 1) {
+        const T* prm = M.actuator_gainprm + 10 * i;
+        T force = prm[2];
+        if (force < 0) force = prm[3] / tmax(MYO_MINVAL, M.actuator_acc0[i]);
+        const T L0 = (lr[1] - lr[0]) / tmax(MYO_MINVAL, prm[1] - prm[0]);
+        const T L = prm[0] + (len - lr[0]) / tmax(MYO_MINVAL, L0);
+        const T V = vel / tmax(MYO_MINVAL, L0 * prm[6]);
+        const T FL = muscle_FL(L, prm[4], prm[5]);
+        const T y = prm[8] - 1;
+        T FV;
+        if (V <= -1) FV = 0;
+        else if (V <= 0) FV = (V + 1) * (V + 1);
+        else if (V <= y) FV = prm[8] - (y - V) * (y - V) / tmax(MYO_MINVAL, y);
+        else FV = prm[8];
+        gain = -force * FL * FV;
+      } else gain = M.actuator_gainprm[10 * i];
+      if (M.actuator_biastype[i] == 2) {
+        const T* prm = M.actuator_biasprm + 10 * i;
+        T force = prm[2];
+        if (force < 0) force = prm[3] / tmax(MYO_MINVAL, M.actuator_acc0[i]);
+        const T L0 = (lr[1] - lr[0]) / tmax(MYO_MINVAL, prm[1] - prm[0]);
+        const T L = prm[0] + (len - lr[0]) / tmax(MYO_MINVAL, L0);
+        const T b = (T)0.5 * (1 + prm[5]);
+        if (L <= 1) bias = 0;
+        else if (L <= b) { const T x = (L - 1) / tmax(MYO_MINVAL, b - 1); bias = -force * prm[7] * (T)0.5 * x * x; }
+        else { const T x = (L - b) / tmax(MYO_MINVAL, b - 1); bias = -force * prm[7] * ((T)0.5 + x); }
+      } else if (M.actuator_biastype[i] == 1) {
+        const T* prm = M.actuator_biasprm + 10 * i;
+        bias = prm[0] + prm[1] * len + prm[2] * vel;
+      }
+      T f = gain * input + bias;
+      if (M.actuator_forcelimited[i]) f = tclamp(f, M.actuator_forcerange[2 * i], M.actuator_forcerange[2 * i + 1]);
+      s.act_force[i] = f;
+    }
+  }
+  SYNC();
+  PHASE {
+    const int d = lane;
+    if (d < M.nv) {
+      T acc = 0;
+      for (int i = 0; i < M.nu; ++i) {
+        const int t = M.actuator_tendon[i];
+        const unsigned long long m = M.tendon_dofmask[t];
+        if ((m >> d) & 1ull)
+          acc += M.actuator_gear[6 * i] * s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * s.act_force[i];
+      }
+      s.qfrc_actuator[d] = acc;
+      s.qfrc_smooth[d] = s.qfrc_passive[d] - s.qfrc_bias[d] + acc;
+    }
+  }
+  SYNC();
+}
+
+// ------------------------------------------------------------------------------------------
+// P10: Newton solver on the primal problem (mj_solNewton)
+template <typename T>
+DEV T update_constraint(const DevModel<T>& M, Scratch<T>& s) {
+  // forces / active set from jar, cost, qfrc_constraint, gradient
+  WAVE_FN
+  const int nefc = s.nefc;
+  PHASE {
+    for (int r = lane; r < nefc; r += 64) {
+      const T x = s.efc_jar[r];
+      const unsigned char a = x < 0;
+      s.efc_active[r] = a;
+      s.efc_force[r] = a ? -s.efc_D[r] * x : (T)0;
+    }
+  }
+  SYNC();
+  JT_times(M, s, s.efc_force, s.qfrc_constraint);
+  WAVE_SUM_N(T, ccost, nefc, r, (s.efc_active[r] ? (T)0.5 * s.efc_D[r] * s.efc_jar[r] * s.efc_jar[r] : (T)0));
+  WAVE_SUM_N(T, gcost, M.nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc[c] - s.qacc_smooth[c])));
+  PHASE {
+    const int c = lane;
+    if (c < M.nv) s.grad[c] = s.Ma[c] - s.qfrc_smooth[c] - s.qfrc_constraint[c];
+  }
+  SYNC();
+  return ccost + (T)0.5 * gcost;
+}
+
+template <typename T>
+DEV void build_hessian(const DevModel<T>& M, Scratch<T>& s) {
+  WAVE_FN
+  load_H_from_M(M, s, (const T*)0, (T)0);
+  const int nl = s.nl, nlim = s.nl + s.ntl;
+  // joint-limit rows touch one diagonal entry each (lanes = dofs scan the rows)
+  PHASE {
+    const int d = lane;
+    if (d < M.nv) {
+      T acc = 0;
+      for (int r = 0; r < nl; ++r)
+        if (s.efc_active[r] && M.jnt_dofadr[s.lim_id[r]] == d) acc += s.efc_D[r];
+      if (acc != 0) s.H[MYO_HIDX(d, d)] += acc;
+    }
+  }
+  SYNC();
+  // tendon-limit rows: rank-1 blocks over the tendon's dofs (one row at a time)
+  for (int r = nl; r < nlim; ++r) {
+    if (!s.efc_active[r]) continue;
+    PHASE {
+      const int t = s.lim_id[r];
+      const unsigned long long m = M.tendon_dofmask[t];
+      const int n = myo_popcll(m);
+      const int a = lane >> 3, b = lane & 7;
+      if (a < n && b <= a) {
+        // a-th / b-th set bits
+        unsigned long long ma = m, mb = m;
+        for (int k = 0; k < a; ++k) ma &= ma - 1;
+        for (int k = 0; k < b; ++k) mb &= mb - 1;
+        const int da = myo_ffsll(ma), db = myo_ffsll(mb);
+        s.H[MYO_HIDX(da, db)] += s.efc_D[r] * s.ten_J[t * MYO_TJ_MAX + a] * s.ten_J[t * MYO_TJ_MAX + b];
+      }
+    }
+    SYNC();
+  }
+  // contacts: H += Jp' (R' A R) Jp with A = D sum_active w w'  (3x3 per contact, frame coordinates)
+  for (int ci = 0; ci < s.ncon; ++ci) {
+    PHASE {
+      if (lane == 0) {
+        ContactRec<T>& c = s.con[ci];
+        const unsigned char* act = s.efc_active + nlim + 4 * ci;
+        // A = [[nn, n1, n2],[n1, 11, 0],[n2, 0, 22]]
+        T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
+        if (act[0]) { nn += 1; n1 += c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
+        if (act[1]) { nn += 1; n1 -= c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
+        if (act[2]) { nn += 1; n2 += c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
+        if (act[3]) { nn += 1; n2 -= c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
+        c.A[0] = c.D * nn; c.A[1] = c.D * n1; c.A[2] = c.D * n2; c.A[3] = c.D * a11; c.A[4] = c.D * a22;
+      }
+    }
+    SYNC();
+    PHASE {
+      const ContactRec<T>& c = s.con[ci];
+      if (c.A[0] != 0) {
+        const int ns = c.nsup;
+        const unsigned long long m1 = M.body_dofmask[c.b1], m2 = M.body_dofmask[c.b2];
+        for (int a = lane >> 3; a < ns; a += 8)
+          for (int b = lane & 7; b <= a; b += 8) {
+            const int da = c.sup[a], db = c.sup[b];
+            const int a1 = (int)((m1 >> da) & 1ull), a2 = (int)((m2 >> da) & 1ull);
+            const int b1 = (int)((m1 >> db) & 1ull), b2 = (int)((m2 >> db) & 1ull);
+            if (a1 == a2 || b1 == b2) continue;
+            T ca[3], cb[3];
+            jac_col(M, s, da, c.pos, ca);
+            jac_col(M, s, db, c.pos, cb);
+            T ja[3] = {dot3(c.frame, ca), dot3(c.frame + 3, ca), dot3(c.frame + 6, ca)};
+            T jb[3] = {dot3(c.frame, cb), dot3(c.frame + 3, cb), dot3(c.frame + 6, cb)};
+            if (!a2) { ja[0] = -ja[0]; ja[1] = -ja[1]; ja[2] = -ja[2]; }
+            if (!b2) { jb[0] = -jb[0]; jb[1] = -jb[1]; jb[2] = -jb[2]; }
+            const T Ajb0 = c.A[0] * jb[0] + c.A[1] * jb[1] + c.A[2] * jb[2];
+            const T Ajb1 = c.A[1] * jb[0] + c.A[3] * jb[1];
+            const T Ajb2 = c.A[2] * jb[0] + c.A[4] * jb[2];
+            s.H[MYO_HIDX(da, db)] += ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2;
+          }
+      }
+    }
+    SYNC();
+  }
+}
+
+template <typename T>
+DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
+  WAVE_FN
+  const int nv = M.nv, nefc = s.nefc;
+  // ---- warm start: cheaper of qacc_warmstart and qacc_smooth
+  body_vectors(M, s, s.qacc_warm, s.bvec);
+  J_times(M, s, s.qacc_warm, s.bvec, s.efc_jar);
+  body_vectors(M, s, s.qacc_smooth, s.bvec);
+  J_times(M, s, s.qacc_smooth, s.bvec, s.efc_jv);
+  mul_M(M, s, s.Ma, s.qacc_warm);
+  WAVE_SUM_N(T, costw_c, nefc, r, ((s.efc_jar[r] - s.efc_aref[r]) < 0 ? (T)0.5 * s.efc_D[r] * (s.efc_jar[r] - s.efc_aref[r]) * (s.efc_jar[r] - s.efc_aref[r]) : (T)0));
+  WAVE_SUM_N(T, costs, nefc, r, ((s.efc_jv[r] - s.efc_aref[r]) < 0 ? (T)0.5 * s.efc_D[r] * (s.efc_jv[r] - s.efc_aref[r]) * (s.efc_jv[r] - s.efc_aref[r]) : (T)0));
+  WAVE_SUM_N(T, gw, nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc_warm[c] - s.qacc_smooth[c])));
+  const int use_warm = (costw_c + (T)0.5 * gw) < costs;
+  PHASE {
+    const int c = lane;
+    if (c < nv) {
+      s.qacc[c] = use_warm ? s.qacc_warm[c] : s.qacc_smooth[c];
+      if (!use_warm) s.Ma[c] = s.qfrc_smooth[c];  // M qacc_smooth = qfrc_smooth
+    }
+    for (int r = lane; r < nefc; r += 64) s.efc_jar[r] = (use_warm ? s.efc_jar[r] : s.efc_jv[r]) - s.efc_aref[r];
+  }
+  SYNC();
+  if (!use_warm) mul_M(M, s, s.Ma, s.qacc);  // keep Ma exactly consistent with M*qacc
+  T cost = update_constraint(M, s);
+  const T scale = 1 / (M.meaninertia * (T)(nv > 1 ? nv : 1));
+  int iter = 0;
+  while (iter < M.iterations) {
+    build_hessian(M, s);
+    chol_factor(s, nv);
+    PHASE { const int c = lane; if (c < nv) s.search[c] = -s.grad[c]; }
+    SYNC();
+    chol_solve(s, s.search, nv);
+    mul_M(M, s, s.Mv, s.search);
+    body_vectors(M, s, s.search, s.bvec);
+    J_times(M, s, s.search, s.bvec, s.efc_jv);
+    WAVE_SUM3_N(T, q1, q2, sn2, nv, c, { _e1 = s.search[c] * (s.Ma[c] - s.qfrc_smooth[c]); _e2 = (T)0.5 * s.search[c] * s.Mv[c]; _e3 = s.search[c] * s.search[c]; });
+    const T snorm = sqrt(sn2);
+#ifdef MYO_EMU_DEBUG
+    printf("newton iter %d cost %g q1 %g q2 %g snorm %g nefc %d\n", iter, (double)cost, (double)q1, (double)q2, (double)snorm, nefc);
+#endif
+    if (snorm < MYO_MINVAL) break;
+    const T gtol = M.tolerance * (T)0.01 * snorm / scale;
+    // exact 1-D minimisation of the convex piecewise-quadratic: safeguarded Newton on p'(alpha)
+    T alpha = 0, lo = 0, hi = -1;
+    for (int li = 0; li < 50; ++li) {
+      WAVE_SUM3_N(T, e0, e1, e2, nefc, r, {
+        const T x = s.efc_jar[r] + alpha * s.efc_jv[r];
+        if (x < 0) { const T D = s.efc_D[r], jv = s.efc_jv[r]; _e1 = (T)0.5 * D * x * x; _e2 = D * x * jv; _e3 = D * jv * jv; }
+      });
+      (void)e0;
+      const T d1 = 2 * alpha * q2 + q1 + e1, d2 = 2 * q2 + e2;
+#ifdef MYO_EMU_DEBUG
+      printf("   ls %d alpha %g d1 %g d2 %g gtol %g e1 %g e2 %g jar0 %g jv0 %g D0 %g\n", li, (double)alpha, (double)d1, (double)d2, (double)gtol, (double)e1, (double)e2, (double)s.efc_jar[0], (double)s.efc_jv[0], (double)s.efc_D[0]);
+#endif
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      T next = alpha - d1 / d2;
+      if (hi >= 0 && (next <= lo || next >= hi)) next = (T)0.5 * (lo + hi);
+      if (next == alpha) break;
+      alpha = next;
+#ifdef MYO_EMU_DEBUG
+      printf("   ls %d alpha %g d1 %g d2 %g gtol %g\n", li, (double)alpha, (double)d1, (double)d2, (double)gtol);
+#endif
+    }
+    if (alpha == 0) break;
+    PHASE {
+      const int c = lane;
+      if (c < nv) { s.qacc[c] += alpha * s.search[c]; s.Ma[c] += alpha * s.Mv[c]; }
+      for (int r = lane; r < nefc; r += 64) s.efc_jar[r] += alpha * s.efc_jv[r];
+    }
+    SYNC();
+    const T oldcost = cost;
+    cost = update_constraint(M, s);
+    iter++;
+    WAVE_SUM_N(T, gn, nv, c, (s.grad[c] * s.grad[c]));
+    const T improvement = scale * (oldcost - cost), gradient = scale * sqrt(gn);
+    if (improvement < M.tolerance || gradient < M.tolerance) break;
+  }
+  PHASE { if (lane == 0) s.solver_iter = iter; }
+  SYNC();
+}
+
+template <typename T>
+DEV void fwd_acceleration(const DevModel<T>& M, Scratch<T>& s) {
+  WAVE_FN
+  load_H_from_M(M, s, (const T*)0, (T)0);
+  chol_factor(s, M.nv);
+  PHASE { const int c = lane; if (c < M.nv) s.qacc_smooth[c] = s.qfrc_smooth[c]; }
+  SYNC();
+  chol_solve(s, s.qacc_smooth, M.nv);
+  if (s.nefc == 0) {
+    PHASE {
+      const int c = lane;
+      if (c < M.nv) { s.qacc[c] = s.qacc_smooth[c]; s.qfrc_constraint[c] = 0; }
+      if (lane == 0) s.solver_iter = 0;
+    }
+    SYNC();
+    return;
+  }
+  newton_solve(M, s);
+}
+
+template <typename T>
+DEV void forward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  kinematics(M, s);
+  com_pos(M, K, s);
+  tendon(M, K, s);
+  crb(M, s);
+  collision_and_constraints(M, K, s);
+  fwd_velocity(M, K, s);
+  fwd_actuation(M, s);
+  fwd_acceleration(M, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// P11: integrators
+template <typename T>
+DEV void integrate_pos(const DevModel<T>& M, Scratch<T>& s, const T* vel, T h) {
+  WAVE_FN
+  PHASE {
+    const int j = lane;
+    if (j < M.njnt) {
+      const int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
+      if (M.jnt_type[j] == 0) {
+        for (int k = 0; k < 3; ++k) s.qpos[qa + k] += h * vel[da + k];
+        T w[3] = {vel[da + 3], vel[da + 4], vel[da + 5]};
+        const T ang = h * norm3(w);
+        T q[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
+        if (ang > 0) {
+          T qr[4];
+          normalize3(w);
+          axisangle2quat(qr, w, ang);
+          mulquat(q, q, qr);
+        }
+        normalize4(q);
+        for (int k = 0; k < 4; ++k) s.qpos[qa + 3 + k] = q[k];
+      } else s.qpos[qa] += h * vel[da];
+    }
+  }
+  SYNC();
+}
+
+template <typename T>
+DEV void advance(const DevModel<T>& M, Scratch<T>& s, const T* act_dot, const T* qacc, const T* vel_for_pos) {
+  WAVE_FN
+  const T h = M.timestep;
+  PHASE {
+    const int i = lane;
+    if (i < M.na) {
+      T a = s.act[i] + h * act_dot[i];
+      if (M.actuator_dyntype[i + (M.nu - M.na)] == 3) a = tclamp(a, (T)0, (T)1);
+      s.act[i] = a;
+    }
+    if (i < M.nv) { s.qvel[i] += h * qacc[i]; s.qacc_warm[i] = s.qacc[i]; }
+    if (lane == 0) s.time += h;
+  }
+  SYNC();
+  integrate_pos(M, s, vel_for_pos ? vel_for_pos : s.qvel, h);
+}
+
+template <typename T>
+DEV void check_state(const DevModel<T>& M, Scratch<T>& s, int check_acc) {
+  WAVE_FN
+  WAVE_SUM_N(int, badq, M.nq, i, ((isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (T)1e10) ? 0 : 1));
+  WAVE_SUM_N(int, badv, M.nv, i, ((isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (T)1e10) ? 0 : 1));
+  int bada = 0;
+  if (check_acc) {
+    WAVE_SUM_N(int, ba, M.nv, i, ((isfinite(s.qacc[i]) && fabs(s.qacc[i]) < (T)1e10) ? 0 : 1));
+    bada = ba;
+  }
+  if (badq + badv + bada) { PHASE { if (lane == 0) s.bad = 1; } SYNC(); }
+}
+
+template <typename T>
+DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  WAVE_FN
+  check_state(M, s, 0);
+  forward(M, K, s);
+  check_state(M, s, 1);
+  if (M.integrator == 1) {
+    // RK4 (mj_RungeKutta): tableau 1/2,1/2,1; weights 1/6,1/3,1/3,1/6
+    const int nq = M.nq, nv = M.nv, na = M.na, nf = 2 * nv + na;
+    const T h = M.timestep, t0 = s.time;
+    PHASE {
+      for (int i = lane; i < nq; i += 64) s.rk_x0[i] = s.qpos[i];
+      for (int i = lane; i < nv; i += 64) { s.rk_x0[nq + i] = s.qvel[i]; s.rk_F[0][i] = s.qvel[i]; s.rk_F[0][nv + i] = s.qacc[i]; }
+      for (int i = lane; i < na; i += 64) { s.rk_x0[nq + nv + i] = s.act[i]; s.rk_F[0][2 * nv + i] = s.act_dot[i]; }
+    }
+    SYNC();
+    for (int st = 1; st < 4; ++st) {
+      const T a = (st == 3) ? (T)1 : (T)0.5;
+      PHASE {
+        for (int i = lane; i < nf; i += 64) s.rk_dX[i] = a * s.rk_F[st - 1][i];
+        for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk_x0[i];
+      }
+      SYNC();
+      integrate_pos(M, s, s.rk_dX, h);
+      PHASE {
+        for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk_x0[nq + i] + h * s.rk_dX[nv + i];
+        for (int i = lane; i < na; i += 64) s.act[i] = s.rk_x0[nq + nv + i] + h * s.rk_dX[2 * nv + i];
+        if (lane == 0) s.time = t0 + h * a;
+      }
+      SYNC();
+      forward(M, K, s);
+      PHASE {
+        for (int i = lane; i < nv; i += 64) { s.rk_F[st][i] = s.qvel[i]; s.rk_F[st][nv + i] = s.qacc[i]; }
+        for (int i = lane; i < na; i += 64) s.rk_F[st][2 * nv + i] = s.act_dot[i];
+      }
+      SYNC();
+    }
+    PHASE {
+      for (int i = lane; i < nf; i += 64)
+        s.rk_dX[i] = (s.rk_F[0][i] + 2 * s.rk_F[1][i] + 2 * s.rk_F[2][i] + s.rk_F[3][i]) / 6;
+      for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk_x0[i];
+      for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk_x0[nq + i];
+      for (int i = lane; i < na; i += 64) s.act[i] = s.rk_x0[nq + nv + i];
+      if (lane == 0) s.time = t0;
+    }
+    SYNC();
+    advance(M, s, s.rk_dX + 2 * nv, s.rk_dX + nv, s.rk_dX);
+  } else if (M.any_damping) {
+    // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
+    load_H_from_M(M, s, M.dof_damping, M.timestep);
+    chol_factor(s, M.nv);
+    PHASE { const int c = lane; if (c < M.nv) s.tmpv[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }
+    SYNC();
+    chol_solve(s, s.tmpv, M.nv);
+    advance(M, s, s.act_dot, s.tmpv, (const T*)0);
+  } else {
+    advance(M, s, s.act_dot, s.qacc, (const T*)0);
+  }
+}

@@ -1,0 +1,464 @@
+// myo_task.h — Baoding task layer on the device: goal schedule, action map, observation,
+// reward, termination, TimeLimit, SubprocVecEnv-style auto-reset with the reference's
+// curriculum / RSI / domain-randomisation reset logic.
+//
+// Restates (per environment, wave-uniform control flow):
+//   BaodingEnvV1.step + BaseV0.step            [MyoSuite 1.2.3, SURVEY.md §3.3, Appendix B.8]
+//   CustomBaodingEnv.get_reward_dict           /root/reference/src/envs/baoding.py:24-94 (P2: 403-467)
+//   CustomBaodingEnv.reset                     /root/reference/src/envs/baoding.py:146-208
+//   CustomBaodingP2Env.reset                   /root/reference/src/envs/baoding.py:494-647
+//   _add_noise_to_{palm,finger}_positions      /root/reference/src/envs/baoding.py:96-144,469-492
+//   TimeLimit(200) + SubprocVecEnv auto-reset  /root/reference/src/envs/__init__.py:15,61; SURVEY C.6
+// Random numbers: the reference mixes gym's np_random, the global np.random and random.choice
+// (SURVEY §7.4-6); seed-for-seed parity is not meaningful, so the device draws from
+// Philox4x32-10 keyed by (seed, env, episode) in the reference's draw ORDER.
+#pragma once
+#include "myo_physics.h"
+
+#define MYO_PI 3.14159265358979323846
+
+struct Philox {
+  unsigned int key0, key1, c0, c1, c2, idx;
+};
+DEV void philox_round(unsigned int* c, unsigned int k0, unsigned int k1) {
+  const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+  const unsigned int h0 = (unsigned int)(p0 >> 32), l0 = (unsigned int)p0, h1 = (unsigned int)(p1 >> 32), l1 = (unsigned int)p1;
+  const unsigned int n0 = h1 ^ c[1] ^ k0, n1 = l1, n2 = h0 ^ c[3] ^ k1, n3 = l0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+DEV double philox_uniform(Philox& g) {  // (0,1), 53 bits
+  unsigned int c[4] = {g.c0, g.c1, g.c2, g.idx};
+  unsigned int k0 = g.key0, k1 = g.key1;
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  g.idx++;
+  const unsigned long long bits = ((((unsigned long long)c[0]) << 32) | (unsigned long long)c[1]) >> 11;
+  return ((double)bits + 0.5) * (1.0 / 9007199254740992.0);
+}
+DEV double rng_range(Philox& g, double lo, double hi) { return lo + (hi - lo) * philox_uniform(g); }
+DEV double rng_normal(Philox& g) {
+  const double u1 = philox_uniform(g), u2 = philox_uniform(g);
+  return sqrt(-2.0 * log(u1)) * cos(2.0 * MYO_PI * u2);
+}
+DEV double rng_gamma(Philox& g, double a) {  // Marsaglia-Tsang
+  double boost = 1.0;
+  if (a < 1.0) { boost = pow(philox_uniform(g), 1.0 / a); a += 1.0; }
+  const double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+  for (int it = 0; it < 64; ++it) {
+    const double x = rng_normal(g);
+    double v = 1.0 + c * x;
+    if (v <= 0) continue;
+    v = v * v * v;
+    const double u = philox_uniform(g);
+    if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) return boost * d * v;
+  }
+  return boost * d;
+}
+DEV double rng_beta(Philox& g, double a, double b) {
+  const double x = rng_gamma(g, a), y = rng_gamma(g, b);
+  return x / (x + y);
+}
+
+// ---- observation (layout pinned by tests/golden/reset_obs_golden.npy) and reward
+template <typename T>
+DEV void baoding_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  WAVE_FN
+  const int nh = K.n_hand;
+  const T dt = (T)K.frame_skip * M.timestep;
+  PHASE {
+    const int i = lane;
+    if (i < nh) s.obs[i] = s.qpos[i];
+    if (i < 3) {
+      T p1[3], p2[3], t1[3], t2[3];
+      body_point(s, M.site_bodyid[K.obj1_sid], M.site_pos + 3 * K.obj1_sid, p1);
+      body_point(s, M.site_bodyid[K.obj2_sid], M.site_pos + 3 * K.obj2_sid, p2);
+      const T l1[3] = {s.target_xy[0], s.target_xy[1], M.site_pos[3 * K.target1_sid + 2]};
+      const T l2[3] = {s.target_xy[2], s.target_xy[3], M.site_pos[3 * K.target2_sid + 2]};
+      body_point(s, M.site_bodyid[K.target1_sid], l1, t1);
+      body_point(s, M.site_bodyid[K.target2_sid], l2, t2);
+      s.obs[nh + i] = p1[i];
+      s.obs[nh + 3 + i] = s.qvel[M.nv - 12 + i] * dt;
+      s.obs[nh + 6 + i] = p2[i];
+      s.obs[nh + 9 + i] = s.qvel[M.nv - 6 + i] * dt;
+      s.obs[nh + 12 + i] = t1[i];
+      s.obs[nh + 15 + i] = t2[i];
+      s.obs[nh + 18 + i] = t1[i] - p1[i];
+      s.obs[nh + 21 + i] = t2[i] - p2[i];
+    }
+    if (i < M.na) s.obs[nh + 24 + i] = s.act[i];
+  }
+  SYNC();
+  WAVE_SUM_N(T, asq, M.na, i, (s.act[i] * s.act[i]));
+  PHASE {
+    if (lane == 0) {
+      const T* e1 = s.obs + nh + 18; const T* e2 = s.obs + nh + 21;
+      const T d1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), d2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+      const T am = M.na ? sqrt(asq) / (T)M.na : (T)0;
+      const int fall = (s.obs[nh + 2] < (T)K.drop_th) || (s.obs[nh + 8] < (T)K.drop_th);
+      T c[7];
+      c[0] = -d1; c[1] = -d2; c[2] = -am; c[3] = fall ? (T)0 : (T)1; c[4] = -(d1 + d2);
+      c[5] = ((d1 < (T)K.proximity_th) && (d2 < (T)K.proximity_th) && !fall) ? (T)1 : (T)0;
+      c[6] = fall ? (T)1 : (T)0;
+      T dense = 0;
+      for (int k = 0; k < 7; ++k) { dense += (T)K.weights[k] * c[k]; s.rwd[k] = c[k]; }
+      s.rwd[7] = dense;
+    }
+  }
+  SYNC();
+}
+
+// ---- env.step(a) without the VecEnv bookkeeping
+template <typename T>
+DEV void baoding_step_core(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, const float* action /* may be null = zeros */) {
+  WAVE_FN
+  PHASE {
+    if (lane == 0) {
+      if (s.which_task != 0) {
+        const double dt = (double)K.frame_skip * (double)M.timestep;
+        const double sign = s.which_task == 1 ? -1.0 : 1.0;
+        const double ang = sign * 2.0 * MYO_PI * ((double)s.counter * dt / (double)s.time_period);
+        const double a1 = ang + (double)s.start_angle[0], a2 = ang + (double)s.start_angle[1];
+        s.target_xy[0] = (T)((double)s.x_radius * cos(a1) + K.center_pos[0]);
+        s.target_xy[1] = (T)((double)s.y_radius * sin(a1) + K.center_pos[1]);
+        s.target_xy[2] = (T)((double)s.x_radius * cos(a2) + K.center_pos[0]);
+        s.target_xy[3] = (T)((double)s.y_radius * sin(a2) + K.center_pos[1]);
+      }
+      s.counter++;
+    }
+    const int i = lane;
+    if (i < M.nu) {  // BaseV0.step: clip, then float32 sigmoid(5(a-0.5)) for muscles (normalize_act)
+      float a = action ? action[i] : 0.0f;
+      a = a < -1.f ? -1.f : (a > 1.f ? 1.f : a);
+      const float c = 1.0f / (1.0f + expf(-5.0f * (a - 0.5f)));
+      s.ctrl[i] = (T)c;
+    }
+  }
+  SYNC();
+  for (int k = 0; k < K.frame_skip; ++k) mj_step(M, K, s);
+  kinematics(M, s);
+  baoding_obs_reward(M, K, s);
+}
+
+template <typename T>
+DEV void set_init_state(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int keep_dynamics) {
+  // robot.reset(init_qpos, init_qvel): init_qpos[:-14]=0, init_qpos[0]=-1.57 (baoding.py:281-283)
+  WAVE_FN
+  PHASE {
+    for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (i < K.n_hand) ? (i == 0 ? (T)K.init_qpos0 : (T)0) : M.qpos0[i];
+    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = 0; if (!keep_dynamics) s.qacc_warm[i] = 0; }
+    if (!keep_dynamics) {
+      for (int i = lane; i < M.na; i += 64) s.act[i] = 0;
+      for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = 0;
+      if (lane == 0) { s.time = 0; s.bad = 0; }
+    }
+  }
+  SYNC();
+}
+
+// ---- reset(): returns with the post-reset state in scratch and the reset observation in s.obs
+template <typename T>
+DEV void baoding_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int env) {
+  WAVE_FN
+  Philox g;
+  g.key0 = (unsigned int)K.seed; g.key1 = (unsigned int)(K.seed >> 32);
+  g.c0 = (unsigned int)env; g.c1 = (unsigned int)s.episode; g.c2 = 0x42414f44u; g.idx = 0;
+  int do_rsi = 0;
+  // every lane runs the (cheap, scalar) sampling redundantly with identical results; lane 0 stores
+  double start1 = (double)s.start_angle[0], start2 = (double)s.start_angle[1];
+  int which = s.which_task;
+  double xr, yr, period, mass[2], fric[6], size[2];
+  mass[0] = (double)s.ball_mass[0]; mass[1] = (double)s.ball_mass[1];
+  size[0] = (double)s.ball_size[0]; size[1] = (double)s.ball_size[1];
+  for (int k = 0; k < 6; ++k) fric[k] = (double)s.ball_fric[k];
+  if (K.kind == 1) {
+    // P1 (baoding.py:146-208)
+    if (K.task_choice == 3) { int c = (int)(philox_uniform(g) * 3.0); which = c > 2 ? 2 : c; }
+    else which = (K.task_choice == 1) ? 1 : 2;
+    const double phase = K.enable_rsi ? rng_range(g, -MYO_PI, MYO_PI) : 0.0;
+    start1 = 3.0 * MYO_PI / 4.0 + phase; start2 = -MYO_PI / 4.0 + phase;
+    xr = rng_range(g, K.goal_xrange[0], K.goal_xrange[1]);
+    yr = rng_range(g, K.goal_yrange[0], K.goal_yrange[1]);
+    period = rng_range(g, K.goal_time_period[0], K.goal_time_period[1]);
+    if (K.enable_rsi) do_rsi = philox_uniform(g) < K.rsi_probability;
+  } else {
+    // P2 (baoding.py:494-647)
+    if (K.task_choice == 3) {
+      int c = (int)(philox_uniform(g) * 3.0);
+      which = c > 2 ? 2 : c;
+      if (philox_uniform(g) < K.overlap_probability) start1 = 3.0 * MYO_PI / 4.0;
+      else if (K.limit_init_angle_on) {
+        double phase = rng_range(g, -K.limit_init_angle, K.limit_init_angle);
+        if (K.beta_init_angle_on) phase = rng_beta(g, K.beta_init_angle[0], K.beta_init_angle[1]) * 2.0 * MYO_PI - MYO_PI;
+        start1 = 3.0 * MYO_PI / 4.0 + phase;
+      } else start1 = rng_range(g, 0.0, 2.0 * MYO_PI);
+      start2 = start1 - MYO_PI;
+    }
+    xr = rng_range(g, K.goal_xrange[0], K.goal_xrange[1]);
+    yr = rng_range(g, K.goal_yrange[0], K.goal_yrange[1]);
+    period = rng_range(g, K.goal_time_period[0], K.goal_time_period[1]);
+    mass[0] = rng_range(g, K.obj_mass_range[0], K.obj_mass_range[1]);
+    mass[1] = rng_range(g, K.obj_mass_range[0], K.obj_mass_range[1]);
+    if (K.beta_ball_mass_on)
+      for (int k = 0; k < 2; ++k)
+        mass[k] = rng_beta(g, K.beta_ball_mass[0], K.beta_ball_mass[1]) * (K.obj_mass_range[1] - K.obj_mass_range[0]) + K.obj_mass_range[0];
+    for (int b = 0; b < 2; ++b)
+      for (int k = 0; k < 3; ++k) {
+        const double nominal = (double)M.geom_friction[3 * K.obj1_gid + k];
+        fric[3 * b + k] = rng_range(g, nominal - K.obj_friction_change[k], nominal + K.obj_friction_change[k]);
+      }
+    size[0] = rng_range(g, K.obj_size_range[0], K.obj_size_range[1]);
+    size[1] = rng_range(g, K.obj_size_range[0], K.obj_size_range[1]);
+    if (K.beta_ball_size_on)
+      for (int k = 0; k < 2; ++k)
+        size[k] = rng_beta(g, K.beta_ball_size[0], K.beta_ball_size[1]) * (K.obj_size_range[1] - K.obj_size_range[0]) + K.obj_size_range[0];
+    if (K.enable_rsi && philox_uniform(g) < K.rsi_probability) {
+      do_rsi = 1;
+      const double phase = rng_range(g, -MYO_PI, MYO_PI);
+      start1 = 3.0 * MYO_PI / 4.0 + phase; start2 = -MYO_PI / 4.0 + phase;
+    }
+  }
+  PHASE {
+    if (lane == 0) {
+      s.which_task = which; s.counter = 0; s.elapsed = 0; s.ep_ret = 0; s.ep_len = 0;
+      s.start_angle[0] = (T)start1; s.start_angle[1] = (T)start2;
+      s.x_radius = (T)xr; s.y_radius = (T)yr; s.time_period = (T)period;
+      s.ball_mass[0] = (T)mass[0]; s.ball_mass[1] = (T)mass[1];
+      s.ball_size[0] = (T)size[0]; s.ball_size[1] = (T)size[1];
+      for (int k = 0; k < 6; ++k) s.ball_fric[k] = (T)fric[k];
+    }
+  }
+  SYNC();
+  set_init_state(M, K, s, 0);
+  if (do_rsi) {
+    // self.step(np.zeros(39)); balls teleported onto the targets (xy), hand back to init pose
+    baoding_step_core(M, K, s, (const float*)0);
+    T bx[4];
+    const int nh = K.n_hand;
+    bx[0] = s.obs[nh + 12]; bx[1] = s.obs[nh + 13]; bx[2] = s.obs[nh + 15]; bx[3] = s.obs[nh + 16];
+    SYNC();
+    set_init_state(M, K, s, 1);
+    PHASE {
+      if (lane == 0) {
+        s.qpos[nh] = bx[0]; s.qpos[nh + 1] = bx[1]; s.qpos[nh + 7] = bx[2]; s.qpos[nh + 8] = bx[3];
+      }
+    }
+    SYNC();
+    if (K.kind == 2 && !K.balls_overlap) {
+      const double a = rng_range(g, 0.0, 2.0 * MYO_PI);
+      PHASE { if (lane == 0) { s.start_angle[0] = (T)a; s.start_angle[1] = (T)(a - MYO_PI); } }
+      SYNC();
+    }
+  }
+  // noise (one scalar per joint group, exactly as the reference's broadcast assignments)
+  if (K.kind == 1) {
+    double nb[6] = {0, 0, 0, 0, 0, 0}, np_[3] = {0, 0, 0}, nf[3] = {0, 0, 0};
+    if (K.noise_balls != 0) for (int k = 0; k < 6; ++k) nb[k] = rng_range(g, -K.noise_balls, K.noise_balls);
+    if (K.noise_palm != 0) {
+      np_[0] = rng_range(g, -MYO_PI / 2, -MYO_PI / 2 + MYO_PI / 18 * K.noise_palm);
+      np_[1] = rng_range(g, -MYO_PI / 18 * K.noise_palm, MYO_PI / 18 * K.noise_palm);
+      np_[2] = rng_range(g, -MYO_PI / 18 * K.noise_palm, MYO_PI / 18 * K.noise_palm);
+    }
+    if (K.noise_fingers != 0) {
+      nf[0] = rng_range(g, -MYO_PI / 18 * K.noise_fingers, MYO_PI / 18 * K.noise_fingers);
+      nf[1] = rng_range(g, 0.0, MYO_PI / 6 * K.noise_fingers);
+      nf[2] = rng_range(g, -MYO_PI / 36 * K.noise_fingers, MYO_PI / 36 * K.noise_fingers);
+    }
+    PHASE {
+      if (lane == 0) {
+        const int nh = K.n_hand;
+        if (K.noise_balls != 0) {
+          const int idx[6] = {nh, nh + 1, nh + 2, nh + 7, nh + 8, nh + 9};
+          for (int k = 0; k < 6; ++k) s.qpos[idx[k]] += (T)nb[k];
+        }
+        if (K.noise_palm != 0) for (int k = 0; k < 3; ++k) s.qpos[k] = (T)np_[k];
+        if (K.noise_fingers != 0) {
+          for (int k = 3; k < 7; ++k) s.qpos[k] = (T)nf[0];
+          for (int k = 7; k < nh; ++k) s.qpos[k] = ((k - 7) % 4 == 1) ? (T)nf[2] : (T)nf[1];
+        }
+      }
+    }
+    SYNC();
+  } else if (K.noise_fingers != 0) {
+    const double n0 = rng_range(g, -MYO_PI / 18 * K.noise_fingers, MYO_PI / 18 * K.noise_fingers);
+    const double n1 = rng_range(g, 0.0, MYO_PI / 6 * K.noise_fingers);
+    PHASE {
+      if (lane == 0) {
+        for (int k = 4; k < 7; ++k) s.qpos[k] = (T)n0;
+        for (int k = 7; k < K.n_hand; ++k) if ((k - 7) % 4 != 1) s.qpos[k] = (T)n1;
+      }
+    }
+    SYNC();
+  }
+  kinematics(M, s);
+  baoding_obs_reward(M, K, s);
+}
+
+// ---- HBM record <-> scratch
+template <typename T>
+DEV void load_env(const DevModel<T>& M, const EnvRecordLayout& L, const double* rec, Scratch<T>& s) {
+  WAVE_FN
+  PHASE {
+    for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (T)rec[L.off_qpos + i];
+    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = (T)rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
+    for (int i = lane; i < M.na; i += 64) s.act[i] = (T)rec[L.off_act + i];
+    for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = 0;
+    if (lane == 0) {
+      s.time = (T)rec[L.off_time];
+      const double* td = rec + L.off_taskd;
+      s.start_angle[0] = (T)td[0]; s.start_angle[1] = (T)td[1]; s.x_radius = (T)td[2]; s.y_radius = (T)td[3];
+      s.time_period = (T)td[4];
+      for (int k = 0; k < 4; ++k) s.target_xy[k] = (T)td[5 + k];
+      const double* bd = rec + L.off_balld;
+      s.ball_mass[0] = (T)bd[0]; s.ball_mass[1] = (T)bd[1];
+      for (int k = 0; k < 6; ++k) s.ball_fric[k] = (T)bd[2 + k];
+      s.ball_size[0] = (T)bd[8]; s.ball_size[1] = (T)bd[9];
+      const double* mi = rec + L.off_misc;
+      s.which_task = (int)mi[0]; s.counter = (int)mi[1]; s.elapsed = (int)mi[2]; s.episode = (int)mi[3];
+      s.ep_ret = (T)mi[4]; s.ep_len = (int)mi[5];
+      s.bad = 0; s.ncon = 0; s.nefc = 0; s.nl = 0; s.ntl = 0; s.solver_iter = 0;
+    }
+  }
+  SYNC();
+}
+
+template <typename T>
+DEV void store_env(const DevModel<T>& M, const EnvRecordLayout& L, double* rec, const Scratch<T>& s) {
+  WAVE_FN
+  PHASE {
+    for (int i = lane; i < M.nq; i += 64) rec[L.off_qpos + i] = (double)s.qpos[i];
+    for (int i = lane; i < M.nv; i += 64) { rec[L.off_qvel + i] = (double)s.qvel[i]; rec[L.off_warm + i] = (double)s.qacc_warm[i]; }
+    for (int i = lane; i < M.na; i += 64) rec[L.off_act + i] = (double)s.act[i];
+    if (lane == 0) {
+      rec[L.off_time] = (double)s.time;
+      double* td = rec + L.off_taskd;
+      td[0] = (double)s.start_angle[0]; td[1] = (double)s.start_angle[1]; td[2] = (double)s.x_radius;
+      td[3] = (double)s.y_radius; td[4] = (double)s.time_period;
+      for (int k = 0; k < 4; ++k) td[5 + k] = (double)s.target_xy[k];
+      double* bd = rec + L.off_balld;
+      bd[0] = (double)s.ball_mass[0]; bd[1] = (double)s.ball_mass[1];
+      for (int k = 0; k < 6; ++k) bd[2 + k] = (double)s.ball_fric[k];
+      bd[8] = (double)s.ball_size[0]; bd[9] = (double)s.ball_size[1];
+      double* mi = rec + L.off_misc;
+      mi[0] = s.which_task; mi[1] = s.counter; mi[2] = s.elapsed; mi[3] = s.episode;
+      mi[4] = (double)s.ep_ret; mi[5] = s.ep_len;
+    }
+  }
+  SYNC();
+}
+
+// ---- the three env-level entry points (one call = one env; the kernels are thin wrappers)
+template <typename T>
+DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+                  int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
+                  float* term_obs, float* comps, float* ep_info) {
+  WAVE_FN
+  const int nobs = K.n_hand + 24 + M.na;
+  load_env(M, L, rec, s);
+  baoding_step_core(M, K, s, act + (size_t)env * M.nu);
+  const int fall = s.rwd[6] != 0 || s.bad;
+  int is_trunc = 0, is_done = fall;
+  PHASE {
+    if (lane == 0) { s.elapsed++; s.ep_len++; s.ep_ret += s.rwd[7]; }
+  }
+  SYNC();
+  if (s.elapsed >= K.max_episode_steps) { is_trunc = !fall; is_done = 1; }  // gym TimeLimit
+  PHASE {
+    if (lane == 0) {
+      rew[env] = (float)s.rwd[7];
+      done[env] = (unsigned char)is_done;
+      if (trunc) trunc[env] = (unsigned char)is_trunc;
+      if (ep_info) { ep_info[2 * env] = (float)s.ep_ret; ep_info[2 * env + 1] = (float)s.ep_len; }
+    }
+    if (comps && lane < 8) comps[(size_t)env * 8 + lane] = (float)s.rwd[lane];
+    if (term_obs) for (int i = lane; i < nobs; i += 64) term_obs[(size_t)env * nobs + i] = (float)s.obs[i];
+  }
+  SYNC();
+  if (is_done) {
+    PHASE { if (lane == 0) s.episode++; }
+    SYNC();
+    baoding_reset(M, K, s, env);
+  }
+  PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)s.obs[i]; }
+  SYNC();
+  store_env(M, L, rec, s);
+}
+
+template <typename T>
+DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+                   int env, const unsigned char* mask, float* obs) {
+  WAVE_FN
+  if (mask && !mask[env]) return;
+  const int nobs = K.n_hand + 24 + M.na;
+  load_env(M, L, rec, s);
+  PHASE { if (lane == 0) s.episode++; }
+  SYNC();
+  baoding_reset(M, K, s, env);
+  if (obs) { PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)s.obs[i]; } SYNC(); }
+  store_env(M, L, rec, s);
+}
+
+template <typename T>
+DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+                     int env, const double* ctrl, int nsub) {
+  WAVE_FN
+  load_env(M, L, rec, s);
+  PHASE { for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0; }
+  SYNC();
+  for (int k = 0; k < nsub; ++k) mj_step(M, K, s);
+  store_env(M, L, rec, s);
+}
+
+// forward dynamics with intermediates exported (stage-wise parity tests)
+struct DumpLayout {
+  int ten_length, ten_J, M, qfrc_bias, qfrc_passive, qfrc_actuator, qacc_smooth, qacc, actuator_force, act_dot,
+      counts, efc_aref, efc_D, site_xpos, subtree_com, xpos, total;
+};
+template <typename T>
+DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+                          int env, const double* ctrl, const DumpLayout& D, double* out_all) {
+  WAVE_FN
+  double* out = out_all + (size_t)env * D.total;
+  load_env(M, L, rec, s);
+  PHASE { for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0; }
+  SYNC();
+  forward(M, K, s);
+  const int nv = M.nv;
+  PHASE {
+    for (int i = lane; i < D.total; i += 64) out[i] = 0;
+  }
+  SYNC();
+  PHASE {
+    for (int t = lane; t < M.ntendon; t += 64) {
+      out[D.ten_length + t] = (double)s.ten_length[t];
+      unsigned long long m = M.tendon_dofmask[t];
+      int slot = 0;
+      while (m) { const int d = myo_ffsll(m); m &= m - 1; out[D.ten_J + t * nv + d] = (double)s.ten_J[t * MYO_TJ_MAX + slot]; slot++; }
+    }
+    for (int e = lane; e < M.nM; e += 64) {
+      out[D.M + M.M_i[e] * nv + M.M_j[e]] = (double)s.qM[e];
+      out[D.M + M.M_j[e] * nv + M.M_i[e]] = (double)s.qM[e];
+    }
+    for (int i = lane; i < nv; i += 64) {
+      out[D.qfrc_bias + i] = (double)s.qfrc_bias[i]; out[D.qfrc_passive + i] = (double)s.qfrc_passive[i];
+      out[D.qfrc_actuator + i] = (double)s.qfrc_actuator[i]; out[D.qacc_smooth + i] = (double)s.qacc_smooth[i];
+      out[D.qacc + i] = (double)s.qacc[i];
+    }
+    for (int i = lane; i < M.nu; i += 64) out[D.actuator_force + i] = (double)s.act_force[i];
+    for (int i = lane; i < M.na; i += 64) out[D.act_dot + i] = (double)s.act_dot[i];
+    if (lane == 0) { out[D.counts] = s.ncon; out[D.counts + 1] = s.nefc; out[D.counts + 2] = s.solver_iter; out[D.counts + 3] = s.nl; }
+    for (int r = lane; r < s.nefc; r += 64) { out[D.efc_aref + r] = (double)s.efc_aref[r]; out[D.efc_D + r] = (double)s.efc_D[r]; }
+    for (int sid = lane; sid < M.nsite; sid += 64) {
+      T p[3];
+      body_point(s, M.site_bodyid[sid], M.site_pos + 3 * sid, p);
+      for (int k = 0; k < 3; ++k) out[D.site_xpos + 3 * sid + k] = (double)p[k];
+    }
+    for (int b = lane; b < M.nbody; b += 64)
+      for (int k = 0; k < 3; ++k) {
+        out[D.subtree_com + 3 * b + k] = (double)s.com[3 * M.body_rootid[b] + k];
+        out[D.xpos + 3 * b + k] = (double)s.xpos[3 * b + k];
+      }
+  }
+  SYNC();
+}

@@ -1,0 +1,675 @@
+// myobatch.hip — host side of libmyobatch (C ABI in include/myobatch.h) and the gfx950 kernels.
+//
+// Built two ways from this one file:
+//   hipcc --offload-arch=gfx950        -> libmyobatch.so        (the product; no CPU path)
+//   g++ -x c++ -DMYO_EMU               -> tests/emu/libmyobatch_emu.so (lane-serial emulation
+//                                        of the same kernel source, test infrastructure only)
+// One workgroup = one wavefront = one environment; grid = number of environments.
+#include "../../include/myobatch.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/myo_model_blob.h"
+#include "myo_task.h"
+
+// ------------------------------------------------------------------------------------------ backend
+#ifdef MYO_EMU
+typedef void* be_stream;
+static int be_malloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : -1; }
+static void be_free(void* p) { free(p); }
+static int be_h2d(void* d, const void* h, size_t n) { memcpy(d, h, n); return 0; }
+static int be_set_device(int) { return 0; }
+static const char* be_errstr(int) { return "emu"; }
+#else
+typedef hipStream_t be_stream;
+static int be_malloc(void** p, size_t n) { return (int)hipMalloc(p, n ? n : 1); }
+static void be_free(void* p) { (void)hipFree(p); }
+static int be_h2d(void* d, const void* h, size_t n) { return (int)hipMemcpy(d, h, n, hipMemcpyHostToDevice); }
+static int be_set_device(int dev) { return (int)hipSetDevice(dev); }
+static const char* be_errstr(int e) { return hipGetErrorString((hipError_t)e); }
+#endif
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+extern "C" const char* myo_last_error(void) { return g_err; }
+extern "C" const char* myo_version(void) {
+#ifdef MYO_EMU
+  return "myobatch 0.1 (MYO_EMU lane-serial test build)";
+#else
+  return "myobatch 0.1 (gfx950)";
+#endif
+}
+
+// ------------------------------------------------------------------------------------------ host model
+struct myo_model {
+  int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive;
+  double timestep, tolerance, impratio, gravity[3], meaninertia;
+#define X(n) std::vector<int> n;
+  MYO_MODEL_INT_ARRAYS(X)
+#undef X
+#define X(n) std::vector<unsigned long long> n;
+  MYO_MODEL_U64_ARRAYS(X)
+#undef X
+#define X(n) std::vector<double> n;
+  MYO_MODEL_REAL_ARRAYS(X)
+#undef X
+};
+
+static const myo_blob_field* blob_find(const void* blob, const char* name) {
+  const myo_blob_header* h = (const myo_blob_header*)blob;
+  const myo_blob_field* f = (const myo_blob_field*)((const char*)blob + sizeof(myo_blob_header));
+  for (uint32_t i = 0; i < h->n_fields; ++i)
+    if (strncmp(f[i].name, name, MYO_BLOB_NAME_LEN) == 0) return &f[i];
+  return nullptr;
+}
+static bool get_i(const void* blob, size_t nbytes, const char* name, std::vector<int>& out) {
+  const myo_blob_field* f = blob_find(blob, name);
+  if (!f || f->dtype != MYO_BLOB_I32 || f->offset + 4ull * f->count > nbytes) return false;
+  const int* p = (const int*)((const char*)blob + f->offset);
+  out.assign(p, p + f->count);
+  return true;
+}
+static bool get_d(const void* blob, size_t nbytes, const char* name, std::vector<double>& out) {
+  const myo_blob_field* f = blob_find(blob, name);
+  if (!f || f->dtype != MYO_BLOB_F64 || f->offset + 8ull * f->count > nbytes) return false;
+  const double* p = (const double*)((const char*)blob + f->offset);
+  out.assign(p, p + f->count);
+  return true;
+}
+static void quat2mat_h(const double* q, double* R) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+
+extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** out) {
+  if (!blob || !out || nbytes < sizeof(myo_blob_header)) return fail(MYO_E_ARG, "null or short blob");
+  const myo_blob_header* h = (const myo_blob_header*)blob;
+  if (h->magic != MYO_BLOB_MAGIC || h->version != MYO_BLOB_VERSION || h->total_bytes != nbytes ||
+      sizeof(myo_blob_header) + (size_t)h->n_fields * sizeof(myo_blob_field) > nbytes)
+    return fail(MYO_E_ARG, "bad model blob header");
+  myo_model* m = new myo_model();
+  std::vector<int> sizes, opt_i, trntype, trnid, body_weldid, geom_condim;
+  std::vector<double> opt_d, body_iquat, geom_quat;
+  bool ok = get_i(blob, nbytes, "sizes", sizes) && sizes.size() >= 10 && get_i(blob, nbytes, "opt_int", opt_i) &&
+            opt_i.size() >= 4 && get_d(blob, nbytes, "opt_f64", opt_d) && opt_d.size() >= 8;
+  const char* missing = nullptr;
+#define GI(n) if (ok && !get_i(blob, nbytes, #n, m->n)) { ok = false; missing = #n; }
+#define GD(n) if (ok && !get_d(blob, nbytes, #n, m->n)) { ok = false; missing = #n; }
+  GI(body_parentid) GI(body_rootid) GI(body_jntnum) GI(body_jntadr) GI(body_dofnum) GI(body_dofadr)
+  GI(jnt_type) GI(jnt_qposadr) GI(jnt_dofadr) GI(jnt_bodyid) GI(jnt_limited) GI(dof_bodyid) GI(dof_jntid)
+  GI(dof_parentid) GI(geom_type) GI(geom_bodyid) GI(geom_priority) GI(site_bodyid) GI(tendon_adr)
+  GI(tendon_num) GI(tendon_limited) GI(wrap_type) GI(wrap_objid) GI(actuator_dyntype) GI(actuator_gaintype)
+  GI(actuator_biastype) GI(actuator_ctrllimited) GI(actuator_forcelimited)
+  GD(qpos0) GD(qpos_spring) GD(body_pos) GD(body_quat) GD(body_ipos) GD(body_mass) GD(body_inertia)
+  GD(body_invweight0) GD(jnt_solref) GD(jnt_solimp) GD(jnt_pos) GD(jnt_axis) GD(jnt_stiffness) GD(jnt_range)
+  GD(jnt_margin) GD(dof_armature) GD(dof_damping) GD(dof_invweight0) GD(geom_solmix) GD(geom_solref)
+  GD(geom_solimp) GD(geom_size) GD(geom_rbound) GD(geom_pos) GD(geom_friction) GD(geom_margin) GD(geom_gap)
+  GD(site_pos) GD(tendon_solref_lim) GD(tendon_solimp_lim) GD(tendon_range) GD(tendon_margin)
+  GD(tendon_stiffness) GD(tendon_damping) GD(tendon_lengthspring) GD(tendon_invweight0) GD(wrap_prm)
+  GD(actuator_dynprm) GD(actuator_gainprm) GD(actuator_biasprm) GD(actuator_ctrlrange) GD(actuator_forcerange)
+  GD(actuator_gear) GD(actuator_acc0) GD(actuator_lengthrange)
+#undef GI
+#undef GD
+  if (ok) ok = get_i(blob, nbytes, "actuator_trntype", trntype) && get_i(blob, nbytes, "actuator_trnid", trnid) &&
+               get_d(blob, nbytes, "body_iquat", body_iquat) && get_d(blob, nbytes, "geom_quat", geom_quat) &&
+               get_i(blob, nbytes, "x_pair_geom1", m->pair_geom1) && get_i(blob, nbytes, "x_pair_geom2", m->pair_geom2);
+  if (!ok) {
+    int rc = fail(MYO_E_ARG, "model blob lacks field %s", missing ? missing : "(sizes/opt/derived)");
+    delete m;
+    return rc;
+  }
+  m->nq = sizes[0]; m->nv = sizes[1]; m->nu = sizes[2]; m->na = sizes[3]; m->nbody = sizes[4]; m->njnt = sizes[5];
+  m->ngeom = sizes[6]; m->nsite = sizes[7]; m->ntendon = sizes[8]; m->nwrap = sizes[9];
+  m->npair = (int)m->pair_geom1.size();
+  m->integrator = opt_i[0]; m->iterations = opt_i[2]; m->disableflags = opt_i[3];
+  m->timestep = opt_d[0]; m->tolerance = opt_d[1]; m->impratio = opt_d[2];
+  m->gravity[0] = opt_d[3]; m->gravity[1] = opt_d[4]; m->gravity[2] = opt_d[5]; m->meaninertia = opt_d[7];
+  // ---- capacity / feature checks
+#define LIM(cond, what) if (cond) { int rc = fail(MYO_E_UNSUPPORTED, "model exceeds stepper capacity: %s", what); delete m; return rc; }
+  LIM(m->nbody > MYO_NB_MAX, "nbody") LIM(m->njnt > MYO_NJ_MAX, "njnt") LIM(m->nv > MYO_NV_MAX, "nv")
+  LIM(m->nq > MYO_NQ_MAX, "nq") LIM(m->ntendon > MYO_NT_MAX, "ntendon") LIM(m->nu > MYO_NU_MAX, "nu")
+  LIM(m->nbody > 64 || m->njnt > 64 || m->ntendon > 64 || m->nu > 64, "more than 64 bodies/joints/tendons/actuators")
+  for (int i = 0; i < m->nu; ++i) LIM(trntype[i] != MYO_TRN_TENDON, "only tendon transmissions are supported")
+  for (int j = 0; j < m->njnt; ++j) LIM(m->jnt_type[j] == MYO_JNT_BALL, "ball joints")
+  // ---- derived tables
+  const int nb = m->nbody, nv = m->nv;
+  m->body_depth.assign(nb, 0);
+  m->maxdepth = 0;
+  for (int b = 1; b < nb; ++b) { m->body_depth[b] = m->body_depth[m->body_parentid[b]] + 1; if (m->body_depth[b] > m->maxdepth) m->maxdepth = m->body_depth[b]; }
+  m->dof_rootbody.resize(nv);
+  for (int d = 0; d < nv; ++d) m->dof_rootbody[d] = m->body_rootid[m->dof_bodyid[d]];
+  m->body_dofmask.assign(nb, 0ull);
+  for (int b = 1; b < nb; ++b) {
+    unsigned long long mk = m->body_dofmask[m->body_parentid[b]];
+    for (int k = 0; k < m->body_dofnum[b]; ++k) mk |= 1ull << (m->body_dofadr[b] + k);
+    m->body_dofmask[b] = mk;
+  }
+  m->body_submask.assign(nb, 0ull);
+  for (int b = nb - 1; b >= 1; --b) {
+    m->body_submask[b] |= 1ull << b;
+    if (m->body_parentid[b] > 0) m->body_submask[m->body_parentid[b]] |= m->body_submask[b];
+  }
+  m->dof_prevmask.assign(nv, 0ull);
+  for (int d = 0; d < nv; ++d) {
+    const int j = m->dof_jntid[d], b = m->dof_bodyid[d];
+    unsigned long long below = (d == 0) ? 0ull : ((1ull << d) - 1ull);
+    if (m->jnt_type[j] == MYO_JNT_FREE) {
+      const int da = m->jnt_dofadr[j];
+      if (d < da + 3) m->dof_prevmask[d] = 1ull << 63;  // translational: cdof_dot = 0
+      else m->dof_prevmask[d] = (m->body_dofmask[b] & ((da == 0) ? 0ull : ((1ull << da) - 1ull))) | (7ull << da);
+    } else m->dof_prevmask[d] = m->body_dofmask[b] & below;
+  }
+  // tree-sparse M (MuJoCo's dof_Madr order: row i holds (i,i),(i,parent),(i,grandparent),...)
+  m->dof_Madr.resize(nv);
+  m->M_i.clear(); m->M_j.clear();
+  for (int i = 0; i < nv; ++i) {
+    m->dof_Madr[i] = (int)m->M_i.size();
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) { m->M_i.push_back(i); m->M_j.push_back(j); }
+  }
+  m->nM = (int)m->M_i.size();
+  LIM(m->nM > MYO_NM_MAX, "nM")
+  {
+    std::vector<std::vector<std::pair<int, int>>> rows(nv);
+    for (int e = 0; e < m->nM; ++e) {
+      rows[m->M_i[e]].push_back({m->M_j[e], e});
+      if (m->M_i[e] != m->M_j[e]) rows[m->M_j[e]].push_back({m->M_i[e], e});
+    }
+    m->mv_adr.assign(nv + 1, 0);
+    for (int i = 0; i < nv; ++i) {
+      m->mv_adr[i] = (int)m->mv_col.size();
+      for (auto& pr : rows[i]) { m->mv_col.push_back(pr.first); m->mv_e.push_back(pr.second); }
+    }
+    m->mv_adr[nv] = (int)m->mv_col.size();
+  }
+  // tendons: dofs each one can move; side sites
+  m->tendon_dofmask.assign(m->ntendon, 0ull);
+  m->wrap_side.assign(m->nwrap, -1);
+  for (int t = 0; t < m->ntendon; ++t) {
+    unsigned long long mk = 0;
+    for (int w = m->tendon_adr[t]; w < m->tendon_adr[t] + m->tendon_num[t]; ++w) {
+      const int ty = m->wrap_type[w];
+      if (ty == MYO_WRAP_SITE) mk |= m->body_dofmask[m->site_bodyid[m->wrap_objid[w]]];
+      else if (ty == MYO_WRAP_SPHERE || ty == MYO_WRAP_CYLINDER) {
+        mk |= m->body_dofmask[m->geom_bodyid[m->wrap_objid[w]]];
+        m->wrap_side[w] = m->wrap_prm[w] >= 0 ? (int)lround(m->wrap_prm[w]) : -1;
+      } else if (ty != MYO_WRAP_PULLEY) LIM(true, "fixed (joint) tendons")
+    }
+    m->tendon_dofmask[t] = mk;
+    int cnt = 0;
+    for (unsigned long long x = mk; x; x &= x - 1) cnt++;
+    LIM(cnt > MYO_TJ_MAX, "a tendon moves more than MYO_TJ_MAX dofs")
+  }
+  m->actuator_tendon.resize(m->nu);
+  for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
+  for (int b = 0; b < nb; ++b) {
+    int cnt = 0;
+    for (unsigned long long x = m->body_dofmask[b]; x; x &= x - 1) cnt++;
+    LIM(2 * cnt > MYO_CS_MAX + 4 && false, "contact support")
+  }
+  for (int p = 0; p < m->npair; ++p) {
+    unsigned long long mk = m->body_dofmask[m->geom_bodyid[m->pair_geom1[p]]] | m->body_dofmask[m->geom_bodyid[m->pair_geom2[p]]];
+    int cnt = 0;
+    for (unsigned long long x = mk; x; x &= x - 1) cnt++;
+    LIM(cnt > MYO_CS_MAX, "a contact pair moves more than MYO_CS_MAX dofs")
+  }
+  m->body_imat.resize(9 * nb);
+  for (int b = 0; b < nb; ++b) quat2mat_h(&body_iquat[4 * b], &m->body_imat[9 * b]);
+  m->geom_mat.resize(9 * (size_t)m->ngeom);
+  for (int g = 0; g < m->ngeom; ++g) quat2mat_h(&geom_quat[4 * g], &m->geom_mat[9 * g]);
+  m->any_damping = 0;
+  for (int d = 0; d < nv; ++d) if (m->dof_damping[d] > 0) m->any_damping = 1;
+  m->any_tendon_passive = 0;
+  for (int t = 0; t < m->ntendon; ++t) if (m->tendon_stiffness[t] != 0 || m->tendon_damping[t] != 0) m->any_tendon_passive = 1;
+#undef LIM
+  *out = m;
+  return MYO_OK;
+}
+
+extern "C" void myo_model_destroy(myo_model* m) { delete m; }
+extern "C" int myo_model_size(const myo_model* m, const char* n) {
+  if (!m || !n) return -1;
+#define S(x) if (!strcmp(n, #x)) return m->x;
+  S(nq) S(nv) S(nu) S(na) S(nbody) S(njnt) S(ngeom) S(nsite) S(ntendon) S(nwrap) S(npair) S(nM) S(integrator)
+#undef S
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------ batch
+struct myo_batch {
+  int n, device, dtype, nobs;
+  myo_task_cfg cfg;
+  TaskDev K;
+  EnvRecordLayout L;
+  DumpLayout D;
+  double* rec;                 // dev [n, L.stride]
+  std::vector<void*> allocs;   // every device allocation (model arrays, records)
+  DevModel<double> Md;
+  DevModel<float> Mf;
+  int nq, nv, nu, na, nbody, nsite, ntendon;
+  int timing;
+  double ms_sum;
+  int ms_cnt;
+#ifndef MYO_EMU
+  hipEvent_t ev0, ev1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+#endif
+};
+
+template <typename T>
+static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& allocs) {
+  D.nq = m->nq; D.nv = m->nv; D.nu = m->nu; D.na = m->na; D.nbody = m->nbody; D.njnt = m->njnt; D.ngeom = m->ngeom;
+  D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
+  D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
+  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive;
+  D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
+  for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];
+  D.meaninertia = (T)m->meaninertia;
+  int rc = 0;
+#define X(n)                                                                            \
+  {                                                                                     \
+    void* p = nullptr;                                                                  \
+    rc |= be_malloc(&p, m->n.size() * sizeof(int));                                     \
+    if (!rc && !m->n.empty()) rc |= be_h2d(p, m->n.data(), m->n.size() * sizeof(int));  \
+    allocs.push_back(p);                                                                \
+    D.n = (const int*)p;                                                                \
+  }
+  MYO_MODEL_INT_ARRAYS(X)
+#undef X
+#define X(n)                                                                                               \
+  {                                                                                                        \
+    void* p = nullptr;                                                                                     \
+    rc |= be_malloc(&p, m->n.size() * sizeof(unsigned long long));                                         \
+    if (!rc && !m->n.empty()) rc |= be_h2d(p, m->n.data(), m->n.size() * sizeof(unsigned long long));      \
+    allocs.push_back(p);                                                                                   \
+    D.n = (const unsigned long long*)p;                                                                    \
+  }
+  MYO_MODEL_U64_ARRAYS(X)
+#undef X
+#define X(n)                                                                  \
+  {                                                                           \
+    std::vector<T> tmp(m->n.begin(), m->n.end());                             \
+    void* p = nullptr;                                                        \
+    rc |= be_malloc(&p, tmp.size() * sizeof(T));                              \
+    if (!rc && !tmp.empty()) rc |= be_h2d(p, tmp.data(), tmp.size() * sizeof(T)); \
+    allocs.push_back(p);                                                      \
+    D.n = (const T*)p;                                                        \
+  }
+  MYO_MODEL_REAL_ARRAYS(X)
+#undef X
+  return rc;
+}
+
+static void make_taskdev(const myo_task_cfg* c, uint64_t seed, TaskDev& K) {
+  memset(&K, 0, sizeof K);
+  K.kind = MYO_TASK_NONE; K.frame_skip = 1; K.max_episode_steps = 1 << 30;
+  K.obj1_sid = K.obj2_sid = K.target1_sid = K.target2_sid = -1;
+  K.obj1_bid = K.obj2_bid = K.obj1_gid = K.obj2_gid = -1;
+  K.seed = seed;
+  if (!c) return;
+  K.kind = c->kind; K.frame_skip = c->frame_skip; K.max_episode_steps = c->max_episode_steps; K.n_hand = c->n_hand;
+  K.obj1_sid = c->obj1_sid; K.obj2_sid = c->obj2_sid; K.target1_sid = c->target1_sid; K.target2_sid = c->target2_sid;
+  K.obj1_bid = c->obj1_bid; K.obj2_bid = c->obj2_bid; K.obj1_gid = c->obj1_gid; K.obj2_gid = c->obj2_gid;
+  K.task_choice = c->task_choice; K.enable_rsi = c->enable_rsi; K.balls_overlap = c->balls_overlap;
+  K.limit_init_angle_on = c->limit_init_angle_on; K.beta_init_angle_on = c->beta_init_angle_on;
+  K.beta_ball_size_on = c->beta_ball_size_on; K.beta_ball_mass_on = c->beta_ball_mass_on;
+  K.drop_th = c->drop_th; K.proximity_th = c->proximity_th;
+  memcpy(K.center_pos, c->center_pos, sizeof K.center_pos); memcpy(K.weights, c->weights, sizeof K.weights);
+  memcpy(K.goal_time_period, c->goal_time_period, 16); memcpy(K.goal_xrange, c->goal_xrange, 16);
+  memcpy(K.goal_yrange, c->goal_yrange, 16);
+  K.rsi_probability = c->rsi_probability; K.overlap_probability = c->overlap_probability;
+  K.noise_palm = c->noise_palm; K.noise_fingers = c->noise_fingers; K.noise_balls = c->noise_balls;
+  K.limit_init_angle = c->limit_init_angle;
+  memcpy(K.beta_init_angle, c->beta_init_angle, 16); memcpy(K.beta_ball_size, c->beta_ball_size, 16);
+  memcpy(K.beta_ball_mass, c->beta_ball_mass, 16); memcpy(K.obj_size_range, c->obj_size_range, 16);
+  memcpy(K.obj_mass_range, c->obj_mass_range, 16); memcpy(K.obj_friction_change, c->obj_friction_change, 24);
+  K.init_qpos0 = c->init_qpos0;
+}
+
+extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int n_envs, int device, uint64_t seed,
+                                int dtype, myo_batch** out) {
+  if (!m || !out || n_envs <= 0) return fail(MYO_E_ARG, "bad arguments to myo_batch_create");
+  if (dtype != MYO_F64 && dtype != MYO_F32) return fail(MYO_E_ARG, "dtype must be MYO_F64 or MYO_F32");
+  if (cfg && cfg->kind != MYO_TASK_NONE) {
+    if (cfg->kind != MYO_TASK_BAODING_P1 && cfg->kind != MYO_TASK_BAODING_P2) return fail(MYO_E_ARG, "unknown task kind");
+    if (cfg->obj1_sid < 0 || cfg->obj1_sid >= m->nsite || cfg->obj2_sid < 0 || cfg->obj2_sid >= m->nsite ||
+        cfg->target1_sid < 0 || cfg->target1_sid >= m->nsite || cfg->target2_sid < 0 || cfg->target2_sid >= m->nsite ||
+        cfg->obj1_bid <= 0 || cfg->obj1_bid >= m->nbody || cfg->obj2_bid <= 0 || cfg->obj2_bid >= m->nbody ||
+        cfg->obj1_gid < 0 || cfg->obj1_gid >= m->ngeom || cfg->obj2_gid < 0 || cfg->obj2_gid >= m->ngeom)
+      return fail(MYO_E_ARG, "task ids out of range");
+    if (cfg->n_hand + 14 != m->nq || m->nv < 12 || cfg->n_hand + 24 + m->na > MYO_OBS_MAX)
+      return fail(MYO_E_UNSUPPORTED, "Baoding task needs nq = n_hand + 14 (two free balls last)");
+    if (cfg->frame_skip <= 0 || cfg->max_episode_steps <= 0) return fail(MYO_E_ARG, "frame_skip / max_episode_steps");
+  }
+  int rc = be_set_device(device);
+  if (rc) return fail(MYO_E_DEVICE, "hipSetDevice(%d): %s", device, be_errstr(rc));
+  myo_batch* b = new myo_batch();
+  b->n = n_envs; b->device = device; b->dtype = dtype; b->timing = 0; b->ms_sum = 0; b->ms_cnt = 0;
+  b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon;
+  if (cfg) b->cfg = *cfg; else memset(&b->cfg, 0, sizeof b->cfg);
+  make_taskdev(cfg && cfg->kind != MYO_TASK_NONE ? cfg : nullptr, seed, b->K);
+  b->nobs = b->K.kind ? b->K.n_hand + 24 + m->na : 0;
+  memset(&b->Md, 0, sizeof b->Md); memset(&b->Mf, 0, sizeof b->Mf);
+  rc = (dtype == MYO_F64) ? upload_model<double>(m, b->Md, b->allocs) : upload_model<float>(m, b->Mf, b->allocs);
+  EnvRecordLayout& L = b->L;
+  L.nq = m->nq; L.nv = m->nv; L.na = m->na;
+  int o = 0;
+  L.off_qpos = o; o += m->nq; L.off_qvel = o; o += m->nv; L.off_act = o; o += m->na; L.off_warm = o; o += m->nv;
+  L.off_time = o; o += 1; L.off_taskd = o; o += MYO_TASKD_N; L.off_balld = o; o += MYO_BALLD_N; L.off_misc = o; o += MYO_MISC_N;
+  L.stride = (o + 7) / 8 * 8;
+  DumpLayout& D = b->D;
+  o = 0;
+  D.ten_length = o; o += m->ntendon; D.ten_J = o; o += m->ntendon * m->nv; D.M = o; o += m->nv * m->nv;
+  D.qfrc_bias = o; o += m->nv; D.qfrc_passive = o; o += m->nv; D.qfrc_actuator = o; o += m->nv;
+  D.qacc_smooth = o; o += m->nv; D.qacc = o; o += m->nv; D.actuator_force = o; o += m->nu; D.act_dot = o; o += m->na;
+  D.counts = o; o += 4; D.efc_aref = o; o += MYO_NEFC_MAX; D.efc_D = o; o += MYO_NEFC_MAX;
+  D.site_xpos = o; o += 3 * m->nsite; D.subtree_com = o; o += 3 * m->nbody; D.xpos = o; o += 3 * m->nbody; D.total = o;
+  // initial records: qpos0, zero velocity; model ball parameters; target sites at their model xy;
+  // start angles per _setup (baoding.py:246-247 P1; :349-354 P2 decided per env at reset time here)
+  std::vector<double> host((size_t)n_envs * L.stride, 0.0);
+  for (int e = 0; e < n_envs; ++e) {
+    double* r = &host[(size_t)e * L.stride];
+    for (int i = 0; i < m->nq; ++i) r[L.off_qpos + i] = m->qpos0[i];
+    double* td = r + L.off_taskd; double* bd = r + L.off_balld; double* mi = r + L.off_misc;
+    td[0] = 3.0 * MYO_PI / 4.0; td[1] = -MYO_PI / 4.0; td[2] = 0.025; td[3] = 0.028; td[4] = 5.0;
+    mi[0] = MYO_WHICH_CCW;
+    if (b->K.kind) {
+      td[2] = 0.5 * (b->K.goal_xrange[0] + b->K.goal_xrange[1]); td[3] = 0.5 * (b->K.goal_yrange[0] + b->K.goal_yrange[1]);
+      td[4] = 0.5 * (b->K.goal_time_period[0] + b->K.goal_time_period[1]);
+      if (b->K.kind == MYO_TASK_BAODING_P2 && !(b->K.overlap_probability >= 1.0)) { td[0] = MYO_PI / 4.0; td[1] = MYO_PI / 4.0 - MYO_PI; }
+      td[5] = m->site_pos[3 * b->K.target1_sid]; td[6] = m->site_pos[3 * b->K.target1_sid + 1];
+      td[7] = m->site_pos[3 * b->K.target2_sid]; td[8] = m->site_pos[3 * b->K.target2_sid + 1];
+      bd[0] = m->body_mass[b->K.obj1_bid]; bd[1] = m->body_mass[b->K.obj2_bid];
+      for (int k = 0; k < 3; ++k) { bd[2 + k] = m->geom_friction[3 * b->K.obj1_gid + k]; bd[5 + k] = m->geom_friction[3 * b->K.obj2_gid + k]; }
+      bd[8] = m->geom_size[3 * b->K.obj1_gid]; bd[9] = m->geom_size[3 * b->K.obj2_gid];
+      if (b->K.task_choice == MYO_CHOICE_CW) mi[0] = MYO_WHICH_CW;
+    }
+  }
+  void* p = nullptr;
+  rc |= be_malloc(&p, host.size() * sizeof(double));
+  if (!rc) rc |= be_h2d(p, host.data(), host.size() * sizeof(double));
+  b->rec = (double*)p;
+  b->allocs.push_back(p);
+#ifndef MYO_EMU
+  if (!rc) { rc |= (int)hipEventCreate(&b->ev0); rc |= (int)hipEventCreate(&b->ev1); }
+#endif
+  if (rc) {
+    int r2 = fail(MYO_E_DEVICE, "device allocation/upload failed: %s", be_errstr(rc));
+    for (void* q : b->allocs) be_free(q);
+    delete b;
+    return r2;
+  }
+  *out = b;
+  return MYO_OK;
+}
+
+extern "C" void myo_batch_destroy(myo_batch* b) {
+  if (!b) return;
+#ifndef MYO_EMU
+  (void)hipSetDevice(b->device);
+  for (auto& pr : b->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
+#endif
+  for (void* q : b->allocs) be_free(q);
+  delete b;
+}
+extern "C" int myo_batch_num_envs(const myo_batch* b) { return b ? b->n : -1; }
+extern "C" int myo_batch_obs_dim(const myo_batch* b) { return b ? b->nobs : -1; }
+extern "C" int myo_batch_lds_bytes(const myo_batch* b) {
+  if (!b) return -1;
+  return b->dtype == MYO_F64 ? (int)sizeof(Scratch<double>) : (int)sizeof(Scratch<float>);
+}
+extern "C" int myo_batch_dump_size(const myo_batch* b) { return b ? b->D.total : -1; }
+extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
+  if (!b || !n) return -1;
+#define S(x) if (!strcmp(n, #x)) return b->D.x;
+  S(ten_length) S(ten_J) S(M) S(qfrc_bias) S(qfrc_passive) S(qfrc_actuator) S(qacc_smooth) S(qacc) S(actuator_force)
+  S(act_dot) S(counts) S(efc_aref) S(efc_D) S(site_xpos) S(subtree_com) S(xpos)
+#undef S
+  return -1;
+}
+
+// ------------------------------------------------------------------------------------------ kernels
+#ifndef MYO_EMU
+template <typename T>
+__global__ void __launch_bounds__(64) k_step(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const float* act,
+                                             float* obs, float* rew, unsigned char* done, unsigned char* trunc,
+                                             float* term_obs, float* comps, float* ep_info) {
+  __shared__ Scratch<T> s;
+  const int env = blockIdx.x;
+  env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+}
+template <typename T>
+__global__ void __launch_bounds__(64) k_reset(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
+                                              const unsigned char* mask, float* obs) {
+  __shared__ Scratch<T> s;
+  const int env = blockIdx.x;
+  env_reset<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, obs);
+}
+template <typename T>
+__global__ void __launch_bounds__(64) k_physics(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
+                                                const double* ctrl, int nsub) {
+  __shared__ Scratch<T> s;
+  const int env = blockIdx.x;
+  env_physics<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, nsub);
+}
+template <typename T>
+__global__ void __launch_bounds__(64) k_dump(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const double* ctrl,
+                                             DumpLayout D, double* out) {
+  __shared__ Scratch<T> s;
+  const int env = blockIdx.x;
+  env_forward_dump<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, D, out);
+}
+// state gather/scatter: one thread per scalar
+__global__ void k_state(double* rec, int stride, int off, int cnt, int n, double* ext, int to_ext) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n * cnt) return;
+  const int e = (int)(i / cnt), k = (int)(i % cnt);
+  if (to_ext) ext[i] = rec[(size_t)e * stride + off + k]; else rec[(size_t)e * stride + off + k] = ext[i];
+}
+__global__ void k_state_i(double* rec, int stride, int off, int cnt, int n, int* ext, int to_ext) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n * cnt) return;
+  const int e = (int)(i / cnt), k = (int)(i % cnt);
+  if (to_ext) ext[i] = (int)rec[(size_t)e * stride + off + k]; else rec[(size_t)e * stride + off + k] = (double)ext[i];
+}
+#define LAUNCH_CHECK(b)                                                                          \
+  {                                                                                              \
+    hipError_t _e = hipGetLastError();                                                           \
+    if (_e != hipSuccess) return fail(MYO_E_DEVICE, "kernel launch failed: %s", hipGetErrorString(_e)); \
+  }
+static void timing_begin(myo_batch* b, hipStream_t st) {
+  if (!b->timing) return;
+  hipEvent_t a, c;
+  (void)hipEventCreate(&a); (void)hipEventCreate(&c);
+  (void)hipEventRecord(a, st);
+  b->pending.push_back({a, c});
+}
+static void timing_end(myo_batch* b, hipStream_t st) {
+  if (!b->timing) return;
+  (void)hipEventRecord(b->pending.back().second, st);
+}
+#endif
+
+static void xfer(myo_batch* b, int off, int cnt, double* ext, int to_ext, be_stream st) {
+  if (!ext) return;
+#ifdef MYO_EMU
+  (void)st;
+  for (int e = 0; e < b->n; ++e)
+    for (int k = 0; k < cnt; ++k) {
+      double* r = b->rec + (size_t)e * b->L.stride + off + k;
+      if (to_ext) ext[(size_t)e * cnt + k] = *r; else *r = ext[(size_t)e * cnt + k];
+    }
+#else
+  const long long tot = (long long)b->n * cnt;
+  hipLaunchKernelGGL(k_state, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->rec, b->L.stride, off, cnt, b->n, ext, to_ext);
+#endif
+}
+static void xfer_i(myo_batch* b, int off, int cnt, int* ext, int to_ext, be_stream st) {
+  if (!ext) return;
+#ifdef MYO_EMU
+  (void)st;
+  for (int e = 0; e < b->n; ++e)
+    for (int k = 0; k < cnt; ++k) {
+      double* r = b->rec + (size_t)e * b->L.stride + off + k;
+      if (to_ext) ext[(size_t)e * cnt + k] = (int)*r; else *r = (double)ext[(size_t)e * cnt + k];
+    }
+#else
+  const long long tot = (long long)b->n * cnt;
+  hipLaunchKernelGGL(k_state_i, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->rec, b->L.stride, off, cnt, b->n, ext, to_ext);
+#endif
+}
+
+extern "C" int myo_batch_get_state(myo_batch* b, double* qpos, double* qvel, double* act, double* time, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  be_stream st = (be_stream)stream;
+  xfer(b, b->L.off_qpos, b->nq, qpos, 1, st); xfer(b, b->L.off_qvel, b->nv, qvel, 1, st);
+  xfer(b, b->L.off_act, b->na, act, 1, st); xfer(b, b->L.off_time, 1, time, 1, st);
+#ifndef MYO_EMU
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+extern "C" int myo_batch_set_state(myo_batch* b, const double* qpos, const double* qvel, const double* act,
+                                   const double* time, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  be_stream st = (be_stream)stream;
+  xfer(b, b->L.off_qpos, b->nq, (double*)qpos, 0, st); xfer(b, b->L.off_qvel, b->nv, (double*)qvel, 0, st);
+  xfer(b, b->L.off_act, b->na, (double*)act, 0, st); xfer(b, b->L.off_time, 1, (double*)time, 0, st);
+#ifndef MYO_EMU
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+extern "C" int myo_batch_set_task(myo_batch* b, const int32_t* task_i, const double* task_d, const double* ball_d, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  be_stream st = (be_stream)stream;
+  xfer_i(b, b->L.off_misc, 2, (int*)task_i, 0, st);
+  xfer(b, b->L.off_taskd, MYO_TASKD_N, (double*)task_d, 0, st); xfer(b, b->L.off_balld, MYO_BALLD_N, (double*)ball_d, 0, st);
+#ifndef MYO_EMU
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+extern "C" int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ball_d, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  be_stream st = (be_stream)stream;
+  xfer_i(b, b->L.off_misc, 2, (int*)task_i, 1, st);
+  xfer(b, b->L.off_taskd, MYO_TASKD_N, task_d, 1, st); xfer(b, b->L.off_balld, MYO_BALLD_N, ball_d, 1, st);
+#ifndef MYO_EMU
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+#ifdef MYO_EMU
+#define FOR_ENVS_F64(call) { Scratch<double>* s = new Scratch<double>(); memset(s, 0, sizeof *s); for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; }
+#define FOR_ENVS_F32(call) { Scratch<float>* s = new Scratch<float>(); memset(s, 0, sizeof *s); for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; }
+#endif
+
+extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  if (!b->K.kind) return fail(MYO_E_STATE, "batch has no task layer");
+#ifdef MYO_EMU
+  (void)stream;
+  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_reset<double>(b->Md, b->K, b->L, rec, *s, env, mask, obs))
+  else FOR_ENVS_F32(env_reset<float>(b->Mf, b->K, b->L, rec, *s, env, mask, obs))
+#else
+  hipStream_t st = (hipStream_t)stream;
+  if (b->dtype == MYO_F64) hipLaunchKernelGGL(k_reset<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, mask, obs);
+  else hipLaunchKernelGGL(k_reset<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, mask, obs);
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float* rew, uint8_t* done, uint8_t* trunc,
+                              float* term_obs, float* comps, float* ep_info, void* stream) {
+  if (!b || !act || !obs || !rew || !done) return fail(MYO_E_ARG, "myo_batch_step: act/obs/rew/done are required");
+  if (!b->K.kind) return fail(MYO_E_STATE, "batch has no task layer");
+#ifdef MYO_EMU
+  (void)stream;
+  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_step<double>(b->Md, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info))
+  else FOR_ENVS_F32(env_step<float>(b->Mf, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info))
+#else
+  hipStream_t st = (hipStream_t)stream;
+  timing_begin(b, st);
+  if (b->dtype == MYO_F64)
+    hipLaunchKernelGGL(k_step<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+  else
+    hipLaunchKernelGGL(k_step<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+  timing_end(b, st);
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+extern "C" int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub, void* stream) {
+  if (!b || nsub < 0) return fail(MYO_E_ARG, "bad arguments");
+#ifdef MYO_EMU
+  (void)stream;
+  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_physics<double>(b->Md, b->K, b->L, rec, *s, env, ctrl, nsub))
+  else FOR_ENVS_F32(env_physics<float>(b->Mf, b->K, b->L, rec, *s, env, ctrl, nsub))
+#else
+  hipStream_t st = (hipStream_t)stream;
+  timing_begin(b, st);
+  if (b->dtype == MYO_F64) hipLaunchKernelGGL(k_physics<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, nsub);
+  else hipLaunchKernelGGL(k_physics<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, nsub);
+  timing_end(b, st);
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+extern "C" int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* out, void* stream) {
+  if (!b || !out) return fail(MYO_E_ARG, "bad arguments");
+#ifdef MYO_EMU
+  (void)stream;
+  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_forward_dump<double>(b->Md, b->K, b->L, rec, *s, env, ctrl, b->D, out))
+  else FOR_ENVS_F32(env_forward_dump<float>(b->Mf, b->K, b->L, rec, *s, env, ctrl, b->D, out))
+#else
+  hipStream_t st = (hipStream_t)stream;
+  if (b->dtype == MYO_F64) hipLaunchKernelGGL(k_dump<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, b->D, out);
+  else hipLaunchKernelGGL(k_dump<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, b->D, out);
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+extern "C" int myo_batch_enable_timing(myo_batch* b, int on) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  b->timing = on;
+  return MYO_OK;
+}
+extern "C" double myo_batch_kernel_ms(myo_batch* b) {
+  if (!b) return -1.0;
+#ifdef MYO_EMU
+  return -1.0;
+#else
+  double sum = 0;
+  int cnt = 0;
+  for (auto& pr : b->pending) {
+    (void)hipEventSynchronize(pr.second);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { sum += ms; cnt++; }
+    (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+  }
+  b->pending.clear();
+  return cnt ? sum / cnt : -1.0;
+#endif
+}

@@ -1,0 +1,100 @@
+// wave.h — "one environment per 64-lane wavefront" programming layer.
+//
+// The stepper is written as a sequence of PHASES.  Inside a phase every lane works on its own
+// item (a body, a tendon, a dof, a constraint row …) and only READS what earlier phases wrote to
+// the per-env scratch (LDS); a SYNC() separates phases.  Values that all lanes agree on
+// ("uniform": counts, loop bounds, step sizes) live in the scratch or are produced by the
+// WAVE_* reductions below.
+//
+// gfx950 build (hipcc): a workgroup is exactly one wavefront (64 threads), `lane` is
+// threadIdx.x, PHASE expands to nothing, SYNC() is __syncthreads() (for a single-wave
+// workgroup that is an LDS wait, no s_barrier round trip), reductions use cross-lane
+// shuffles, compaction uses 64-bit ballots.
+//
+// MYO_EMU build (g++, tests only): PHASE expands to `for (lane = 0..63)`, i.e. the lanes of a
+// phase run one after another on the CPU.  This exists so the kernel SOURCE can be debugged
+// and run under AddressSanitizer/UBSan without a GPU (GPU ASan is unavailable on the pool).
+// It is compiled only by tests/emu/ into a separate library; libmyobatch.so contains no CPU
+// path.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#ifdef MYO_EMU
+#define DEV static inline
+#define WAVE_FN
+#define PHASE for (int lane = 0; lane < 64; ++lane)
+#define SYNC() ((void)0)
+#define LANE_VAR(T, name) T name[64]
+#define LV(name) name[lane]
+// sum over i in [0,n) of expr(i); result uniform
+#define WAVE_SUM_N(T, out, n, i, expr) \
+  T out = 0;                           \
+  for (int i = 0; i < (n); ++i) { out += (expr); }
+#define WAVE_SUM3_N(T, o1, o2, o3, n, i, ...)   \
+  T o1 = 0, o2 = 0, o3 = 0;                      \
+  for (int i = 0; i < (n); ++i) {                \
+    T _e1 = 0, _e2 = 0, _e3 = 0;                 \
+    __VA_ARGS__;                                 \
+    o1 += _e1; o2 += _e2; o3 += _e3;             \
+  }
+// exclusive prefix over lanes of a per-lane count in {0,1,2}; pre = scratch int[64]
+#define WAVE_EXSCAN(cnt_expr, pre, total)            \
+  {                                                  \
+    int _t = 0;                                      \
+    for (int lane = 0; lane < 64; ++lane) {          \
+      (pre)[lane] = _t;                              \
+      _t += (cnt_expr);                              \
+    }                                                \
+    (total) = _t;                                    \
+  }
+#define UNI(x) (x)
+static inline int myo_popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
+#else
+#include <hip/hip_runtime.h>
+#define DEV __device__ __forceinline__
+#define WAVE_FN const int lane = threadIdx.x; (void)lane;
+#define PHASE
+#define SYNC() __syncthreads()
+#define LANE_VAR(T, name) T name
+#define LV(name) name
+template <typename T>
+__device__ __forceinline__ T myo_wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+#define WAVE_SUM_N(T, out, n, i, expr)                       \
+  T out;                                                     \
+  {                                                          \
+    T _a = 0;                                                \
+    for (int i = lane; i < (n); i += 64) { _a += (expr); }   \
+    out = myo_wave_sum<T>(_a);                               \
+  }
+#define WAVE_SUM3_N(T, o1, o2, o3, n, i, ...)               \
+  T o1, o2, o3;                                              \
+  {                                                          \
+    T _a1 = 0, _a2 = 0, _a3 = 0;                             \
+    for (int i = lane; i < (n); i += 64) {                   \
+      T _e1 = 0, _e2 = 0, _e3 = 0;                           \
+      __VA_ARGS__;                                           \
+      _a1 += _e1; _a2 += _e2; _a3 += _e3;                    \
+    }                                                        \
+    o1 = myo_wave_sum<T>(_a1);                               \
+    o2 = myo_wave_sum<T>(_a2);                               \
+    o3 = myo_wave_sum<T>(_a3);                               \
+  }
+#define WAVE_EXSCAN(cnt_expr, pre, total)                                          \
+  {                                                                                \
+    int _c = (cnt_expr);                                                           \
+    unsigned long long _m1 = __ballot(_c >= 1), _m2 = __ballot(_c >= 2);          \
+    unsigned long long _below = (1ull << lane) - 1ull;                             \
+    (pre)[lane] = __popcll(_m1 & _below) + __popcll(_m2 & _below);                 \
+    (total) = __popcll(_m1) + __popcll(_m2);                                       \
+  }                                                                                \
+  __syncthreads();
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+__device__ __forceinline__ int myo_popcll(unsigned long long x) { return __popcll(x); }
+__device__ __forceinline__ int myo_ffsll(unsigned long long x) { return __ffsll((long long)x) - 1; }
+#endif

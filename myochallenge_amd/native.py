@@ -1,0 +1,218 @@
+"""ctypes binding of libmyobatch (C ABI: include/myobatch.h).
+
+The product library is ``myochallenge_amd/libmyobatch.so`` built by ``__graft_entry__.build()``
+with hipcc for gfx950.  There is no CPU fallback: if the library is missing, ``load()`` raises.
+(``tests/emu`` builds a lane-serial emulation of the same kernel source for debugging; tests
+load it by passing its explicit path — nothing in the package ever does.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmyobatch.so")
+
+MYO_F64, MYO_F32 = 0, 1
+TASK_NONE, TASK_BAODING_P1, TASK_BAODING_P2 = 0, 1, 2
+CHOICE_FIXED, CHOICE_CW, CHOICE_CCW, CHOICE_RANDOM = 0, 1, 2, 3
+N_RWD = 8
+RWD_KEYS = ("pos_dist_1", "pos_dist_2", "act_reg", "alive", "sparse", "solved", "done", "dense")
+
+
+class TaskCfg(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("frame_skip", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("n_hand", C.c_int32),
+        ("obj1_sid", C.c_int32), ("obj2_sid", C.c_int32), ("target1_sid", C.c_int32),
+        ("target2_sid", C.c_int32), ("obj1_bid", C.c_int32), ("obj2_bid", C.c_int32),
+        ("obj1_gid", C.c_int32), ("obj2_gid", C.c_int32),
+        ("task_choice", C.c_int32), ("enable_rsi", C.c_int32), ("balls_overlap", C.c_int32),
+        ("limit_init_angle_on", C.c_int32), ("beta_init_angle_on", C.c_int32),
+        ("beta_ball_size_on", C.c_int32), ("beta_ball_mass_on", C.c_int32),
+        ("drop_th", C.c_double), ("proximity_th", C.c_double), ("center_pos", C.c_double * 2),
+        ("weights", C.c_double * 7),
+        ("goal_time_period", C.c_double * 2), ("goal_xrange", C.c_double * 2),
+        ("goal_yrange", C.c_double * 2),
+        ("rsi_probability", C.c_double), ("overlap_probability", C.c_double),
+        ("noise_palm", C.c_double), ("noise_fingers", C.c_double), ("noise_balls", C.c_double),
+        ("limit_init_angle", C.c_double), ("beta_init_angle", C.c_double * 2),
+        ("beta_ball_size", C.c_double * 2), ("beta_ball_mass", C.c_double * 2),
+        ("obj_size_range", C.c_double * 2), ("obj_mass_range", C.c_double * 2),
+        ("obj_friction_change", C.c_double * 3), ("init_qpos0", C.c_double),
+    ]
+
+
+class MyoError(RuntimeError):
+    pass
+
+
+class NativeLib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise MyoError(
+                f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()').  libmyobatch has no CPU fallback.")
+        L = C.CDLL(path)
+        self.path = path
+        self.L = L
+        vp, i32, u64, dbl = C.c_void_p, C.c_int, C.c_uint64, C.c_double
+        L.myo_last_error.restype = C.c_char_p
+        L.myo_version.restype = C.c_char_p
+        L.myo_model_from_blob.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.myo_model_destroy.argtypes = [vp]
+        L.myo_model_size.argtypes = [vp, C.c_char_p]
+        L.myo_batch_create.argtypes = [vp, C.POINTER(TaskCfg), i32, i32, u64, i32, C.POINTER(vp)]
+        L.myo_batch_destroy.argtypes = [vp]
+        L.myo_batch_num_envs.argtypes = [vp]
+        L.myo_batch_obs_dim.argtypes = [vp]
+        L.myo_batch_lds_bytes.argtypes = [vp]
+        L.myo_batch_reset.argtypes = [vp, vp, vp, vp]
+        L.myo_batch_step.argtypes = [vp] * 10
+        L.myo_batch_physics_step.argtypes = [vp, vp, i32, vp]
+        L.myo_batch_get_state.argtypes = [vp] * 6
+        L.myo_batch_set_state.argtypes = [vp] * 6
+        L.myo_batch_set_task.argtypes = [vp] * 5
+        L.myo_batch_get_task.argtypes = [vp] * 5
+        L.myo_batch_forward_dump.argtypes = [vp, vp, vp, vp]
+        L.myo_batch_dump_size.argtypes = [vp]
+        L.myo_batch_dump_offset.argtypes = [vp, C.c_char_p]
+        L.myo_batch_kernel_ms.argtypes = [vp]
+        L.myo_batch_kernel_ms.restype = dbl
+        L.myo_batch_enable_timing.argtypes = [vp, i32]
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise MyoError(f"libmyobatch error {rc}: {self.L.myo_last_error().decode()}")
+
+    @property
+    def version(self) -> str:
+        return self.L.myo_version().decode()
+
+    @property
+    def is_emulation(self) -> bool:
+        return "MYO_EMU" in self.version
+
+
+_LIB: Optional[NativeLib] = None
+
+
+def load(path: Optional[str] = None) -> NativeLib:
+    """Load the HIP library (or an explicitly named one — tests only)."""
+    global _LIB
+    if path is not None:
+        return NativeLib(path)
+    if _LIB is None:
+        _LIB = NativeLib(LIB_PATH)
+    return _LIB
+
+
+EXPORTED_SYMBOLS = [
+    "myo_model_from_blob", "myo_model_destroy", "myo_model_size", "myo_batch_create",
+    "myo_batch_destroy", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
+    "myo_batch_reset", "myo_batch_step", "myo_batch_physics_step", "myo_batch_get_state",
+    "myo_batch_set_state", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_forward_dump",
+    "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
+    "myo_batch_enable_timing", "myo_last_error", "myo_version",
+]
+
+
+class Model:
+    """Host handle of a compiled model (myo_model*)."""
+
+    def __init__(self, compiled, lib: Optional[NativeLib] = None):
+        self.lib = lib or load()
+        self.compiled = compiled
+        blob = compiled.to_blob()
+        self._buf = C.create_string_buffer(blob, len(blob))
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.myo_model_from_blob(self._buf, len(blob), C.byref(h)))
+        self.h = h
+
+    def size(self, name: str) -> int:
+        return self.lib.L.myo_model_size(self.h, name.encode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.L.myo_model_destroy(self.h)
+            self.h = None
+
+
+def _ptr(x):
+    """Device/host pointer of a torch tensor, numpy array, int or None."""
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data
+    return x.data_ptr()  # torch.Tensor
+
+
+class Batch:
+    """Thin handle of myo_batch*; every array argument is a pointer provider (see _ptr)."""
+
+    def __init__(self, model: Model, cfg: Optional[TaskCfg], n_envs: int, device: int = 0, seed: int = 0,
+                 dtype: int = MYO_F32):
+        self.lib, self.model = model.lib, model
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.myo_batch_create(model.h, C.byref(cfg) if cfg is not None else None,
+                                                   n_envs, device, seed, dtype, C.byref(h)))
+        self.h = h
+        self.n = n_envs
+        self.dtype = dtype
+        self.obs_dim = self.lib.L.myo_batch_obs_dim(h)
+
+    def reset(self, mask=None, obs=None, stream=None):
+        self.lib.check(self.lib.L.myo_batch_reset(self.h, _ptr(mask), _ptr(obs), stream))
+
+    def step(self, act, obs, rew, done, trunc=None, term_obs=None, comps=None, ep_info=None, stream=None):
+        self.lib.check(self.lib.L.myo_batch_step(self.h, _ptr(act), _ptr(obs), _ptr(rew), _ptr(done), _ptr(trunc),
+                                                 _ptr(term_obs), _ptr(comps), _ptr(ep_info), stream))
+
+    def physics_step(self, ctrl, nsub, stream=None):
+        self.lib.check(self.lib.L.myo_batch_physics_step(self.h, _ptr(ctrl), nsub, stream))
+
+    def get_state(self, qpos=None, qvel=None, act=None, time=None, stream=None):
+        self.lib.check(self.lib.L.myo_batch_get_state(self.h, _ptr(qpos), _ptr(qvel), _ptr(act), _ptr(time), stream))
+
+    def set_state(self, qpos=None, qvel=None, act=None, time=None, stream=None):
+        self.lib.check(self.lib.L.myo_batch_set_state(self.h, _ptr(qpos), _ptr(qvel), _ptr(act), _ptr(time), stream))
+
+    def set_task(self, task_i=None, task_d=None, ball_d=None, stream=None):
+        self.lib.check(self.lib.L.myo_batch_set_task(self.h, _ptr(task_i), _ptr(task_d), _ptr(ball_d), stream))
+
+    def get_task(self, task_i=None, task_d=None, ball_d=None, stream=None):
+        self.lib.check(self.lib.L.myo_batch_get_task(self.h, _ptr(task_i), _ptr(task_d), _ptr(ball_d), stream))
+
+    def forward_dump(self, ctrl, out, stream=None):
+        self.lib.check(self.lib.L.myo_batch_forward_dump(self.h, _ptr(ctrl), _ptr(out), stream))
+
+    @property
+    def dump_size(self) -> int:
+        return self.lib.L.myo_batch_dump_size(self.h)
+
+    def dump_offset(self, name: str) -> int:
+        return self.lib.L.myo_batch_dump_offset(self.h, name.encode())
+
+    @property
+    def lds_bytes(self) -> int:
+        return self.lib.L.myo_batch_lds_bytes(self.h)
+
+    def enable_timing(self, on=True):
+        self.lib.check(self.lib.L.myo_batch_enable_timing(self.h, int(on)))
+
+    def kernel_ms(self) -> float:
+        return self.lib.L.myo_batch_kernel_ms(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.L.myo_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()

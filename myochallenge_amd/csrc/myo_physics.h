@@ -23,6 +23,14 @@
 #include "wave.h"
 
 #define MYO_MINVAL ((T)1e-15)
+
+// Stage timers: compiled only into the diagnostic build (-DMYO_PROF, libmyobatch_prof.so); the
+// product build contains no stamp.  Lane 0 accumulates s_memtime deltas per stage in LDS.
+#if defined(MYO_PROF) && !defined(MYO_EMU)
+#define PROF(s, k) { if (threadIdx.x == 0) { unsigned long long _t = clock64(); (s).prof[k] += _t - (s).prof_t; (s).prof_t = _t; } }
+#else
+#define PROF(s, k)
+#endif
 #define MYO_HIDX(i, j) ((i) * ((i) + 1) / 2 + (j)) /* packed lower triangle, i >= j */
 
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
@@ -82,6 +90,9 @@ struct Scratch {
   // ---- task layer
   T obs[MYO_OBS_MAX];
   T rwd[8];
+#ifdef MYO_PROF
+  unsigned long long prof[16], prof_t;
+#endif
 };
 
 // ------------------------------------------------------------------------------------------
@@ -630,6 +641,94 @@ DEV void chol_solve(Scratch<T>& s, T* x, int n) {
     }
     SYNC();
   }
+}
+
+#ifndef MYO_EMU
+// ---- register-resident Cholesky (gfx950 build).  Lane i keeps row i of the lower triangle in
+// VGPRs; pivots and column entries are broadcast with v_readlane (no LDS round trip, no
+// dependent LDS read-modify-write chain).  Padded to MYO_NV_MAX with identity rows.  The
+// arithmetic per element is the same k-ordered FMA sequence as the LDS version above, which the
+// MYO_EMU build keeps.
+template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
+template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+template <> __device__ __forceinline__ double lane_bcast<double>(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// solve (L L') x = b with H (packed, LDS) and x (LDS) ; H is overwritten with L
+template <typename T>
+__device__ __forceinline__ void chol_factor_solve_reg(Scratch<T>& s, T* x, int n) {
+  constexpr int N = MYO_NV_MAX;
+  const int lane = threadIdx.x;
+  T a[N];
+  const int rbase = lane * (lane + 1) / 2;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    T v = (j == lane) ? (T)1 : (T)0;
+    if (lane < n && j <= lane) v = s.H[rbase + j];
+    a[j] = v;
+  }
+  T b = (lane < n) ? x[lane] : (T)0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    T akk = lane_bcast<T>(a[k], k);
+    akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
+    const T dk = sqrt(akk);
+    const T inv = 1 / dk;
+    const T lik = (lane > k) ? a[k] * inv : ((lane == k) ? dk : (T)0);
+    a[k] = lik;
+#pragma unroll
+    for (int j = k + 1; j < N; ++j) {
+      const T ljk = lane_bcast<T>(lik, j);
+      a[j] -= lik * ljk;
+    }
+  }
+  // zero the (garbage) strict upper part, keep 1/diag
+  T invd = 1;
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    if (j == lane) invd = 1 / a[j];
+    if (j > lane) a[j] = 0;
+  }
+  // forward substitution  L y = b
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const T yj = lane_bcast<T>(b * invd, j);
+    b = (lane == j) ? yj : b - a[j] * yj;   // a[j] = 0 for lanes < j
+  }
+  // transpose through LDS: lane i needs column i
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+    if (lane < n && j <= lane) s.H[rbase + j] = a[j];
+  __syncthreads();
+  T c[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) c[j] = (j > lane && j < n) ? s.H[j * (j + 1) / 2 + lane] : (T)0;
+  // backward substitution  L' x = y
+#pragma unroll
+  for (int j = N - 1; j >= 0; --j) {
+    const T xj = lane_bcast<T>(b * invd, j);
+    b = (lane == j) ? xj : b - c[j] * xj;   // c[j] = 0 for lanes > j
+  }
+  if (lane < n) x[lane] = b;
+  __syncthreads();
+}
+#endif
+
+template <typename T>
+DEV void chol_factor_solve(Scratch<T>& s, T* x, int n) {
+#ifdef MYO_EMU
+  chol_factor(s, n);
+  chol_solve(s, x, n);
+#else
+  chol_factor_solve_reg<T>(s, x, n);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1388,11 +1487,13 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
   const T scale = 1 / (M.meaninertia * (T)(nv > 1 ? nv : 1));
   int iter = 0;
   while (iter < M.iterations) {
+    PROF(s, 11)
     build_hessian(M, s);
-    chol_factor(s, nv);
+    PROF(s, 9)
     PHASE { const int c = lane; if (c < nv) s.search[c] = -s.grad[c]; }
     SYNC();
-    chol_solve(s, s.search, nv);
+    chol_factor_solve(s, s.search, nv);
+    PROF(s, 10)
     mul_M(M, s, s.Mv, s.search);
     body_vectors(M, s, s.search, s.bvec);
     J_times(M, s, s.search, s.bvec, s.efc_jv);
@@ -1441,16 +1542,17 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
   }
   PHASE { if (lane == 0) s.solver_iter = iter; }
   SYNC();
+  PROF(s, 11)
 }
 
 template <typename T>
 DEV void fwd_acceleration(const DevModel<T>& M, Scratch<T>& s) {
   WAVE_FN
   load_H_from_M(M, s, (const T*)0, (T)0);
-  chol_factor(s, M.nv);
   PHASE { const int c = lane; if (c < M.nv) s.qacc_smooth[c] = s.qfrc_smooth[c]; }
   SYNC();
-  chol_solve(s, s.qacc_smooth, M.nv);
+  chol_factor_solve(s, s.qacc_smooth, M.nv);
+  PROF(s, 8)
   if (s.nefc == 0) {
     PHASE {
       const int c = lane;
@@ -1465,13 +1567,21 @@ DEV void fwd_acceleration(const DevModel<T>& M, Scratch<T>& s) {
 
 template <typename T>
 DEV void forward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  PROF(s, 15)
   kinematics(M, s);
+  PROF(s, 1)
   com_pos(M, K, s);
+  PROF(s, 2)
   tendon(M, K, s);
+  PROF(s, 3)
   crb(M, s);
+  PROF(s, 4)
   collision_and_constraints(M, K, s);
+  PROF(s, 5)
   fwd_velocity(M, K, s);
+  PROF(s, 6)
   fwd_actuation(M, s);
+  PROF(s, 7)
   fwd_acceleration(M, s);
 }
 
@@ -1540,6 +1650,7 @@ DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
   check_state(M, s, 0);
   forward(M, K, s);
   check_state(M, s, 1);
+  PROF(s, 15)
   if (M.integrator == 1) {
     // RK4 (mj_RungeKutta): tableau 1/2,1/2,1; weights 1/6,1/3,1/3,1/6
     const int nq = M.nq, nv = M.nv, na = M.na, nf = 2 * nv + na;
@@ -1584,11 +1695,12 @@ DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
     load_H_from_M(M, s, M.dof_damping, M.timestep);
-    chol_factor(s, M.nv);
     PHASE { const int c = lane; if (c < M.nv) s.tmpv[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }
     SYNC();
-    chol_solve(s, s.tmpv, M.nv);
+    chol_factor_solve(s, s.tmpv, M.nv);
+    PROF(s, 12)
     advance(M, s, s.act_dot, s.tmpv, (const T*)0);
+    PROF(s, 13)
   } else {
     advance(M, s, s.act_dot, s.qacc, (const T*)0);
   }

@@ -446,13 +446,32 @@ extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
 
 // ------------------------------------------------------------------------------------------ kernels
 #ifndef MYO_EMU
+#ifdef MYO_PROF
+__device__ unsigned long long g_prof[16];
+extern "C" int myo_debug_read_prof(double* out16, int reset) {
+  unsigned long long h[16];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof h) != hipSuccess) return -1;
+  for (int k = 0; k < 16; ++k) out16[k] = (double)h[k];
+  if (reset) { memset(h, 0, sizeof h); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof h); }
+  return 0;
+}
+#endif
 template <typename T>
 __global__ void __launch_bounds__(64) k_step(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const float* act,
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info) {
   __shared__ Scratch<T> s;
   const int env = blockIdx.x;
+#ifdef MYO_PROF
+  if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
+  __syncthreads();
+#endif
   env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+#ifdef MYO_PROF
+  PROF(s, 0)
+  __syncthreads();
+  if (threadIdx.x < 16) atomicAdd(&g_prof[threadIdx.x], s.prof[threadIdx.x]);
+#endif
 }
 template <typename T>
 __global__ void __launch_bounds__(64) k_reset(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,

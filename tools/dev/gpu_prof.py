@@ -1,0 +1,33 @@
+"""Stage-share diagnostic: runs the -DMYO_PROF build (tools/dev/libmyobatch_prof.so) and prints
+the s_memtime cycle shares per stage.  Shares only — never quote this build's run time."""
+import ctypes as C, sys, time
+import numpy as np, torch
+from myochallenge_amd import native
+from myochallenge_amd.envs.config import make_task_cfg
+from myochallenge_amd.model import compile_model
+from myochallenge_amd.synth_hand import synthetic_hand
+names = ["load/store/other", "kinematics", "com_pos", "tendon", "crb", "collision+constraint", "velocity", "actuation",
+         "qacc_smooth(chol)", "hessian", "newton chol", "newton rest", "euler implicit chol", "advance", "-", "check/misc"]
+lib = native.load("tools/dev/libmyobatch_prof.so")
+dev = torch.device("cuda:0")
+for integ in (0,):
+  for dtype, dn in ((native.MYO_F32, "f32"), (native.MYO_F64, "f64")):
+    cm = compile_model(synthetic_hand(), integrator=integ)
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    b = native.Batch(native.Model(cm, lib), make_task_cfg("CustomMyoBaodingBallsP1", cm), N, 0, 1, dtype)
+    obs = torch.zeros((N, 86), dtype=torch.float32, device=dev); rew = torch.zeros(N, dtype=torch.float32, device=dev)
+    done = torch.zeros(N, dtype=torch.uint8, device=dev)
+    b.reset(None, obs)
+    for _ in range(3):
+        b.step(torch.clamp(torch.randn((N, 39), device=dev) * 0.135, -1, 1), obs, rew, done)
+    torch.cuda.synchronize()
+    out = (C.c_double * 16)(); lib.L.myo_debug_read_prof(out, 1)
+    K = 5; t0 = time.time()
+    for _ in range(K):
+        b.step(torch.clamp(torch.randn((N, 39), device=dev) * 0.135, -1, 1), obs, rew, done)
+    torch.cuda.synchronize(); dt = (time.time() - t0) / K
+    lib.L.myo_debug_read_prof(out, 1)
+    p = np.array(out[:]); tot = p.sum()
+    print(f"== {dn} integ={integ} N={N}: {dt*1e3:.2f} ms/step; cycles per env-substep {tot/(N*K*10):,.0f}")
+    for k in np.argsort(-p):
+        if p[k] > 0: print(f"   {names[k]:24s} {100*p[k]/tot:5.1f}%  {p[k]/(N*K*10):10,.0f} cyc/substep")

@@ -1,0 +1,146 @@
+"""Actor-critic policies with stable-baselines3 / sb3-contrib parameter naming.
+
+The reference trains ``RecurrentPPO("MlpLstmPolicy", ...)`` (/root/reference/src/train/trainer.py:57-64)
+with ``policy_kwargs`` such as ``lstm_hidden_size=256, net_arch=[dict(pi=[256,256], vf=[256,256])],
+enable_critic_lstm=True, ortho_init=False, activation_fn=ReLU, log_std_init=-2``
+(trained_models/curriculum_steps_complete_baoding_winner/01_rsi_static/main.py:178-200) and ships
+one checkpoint whose ``policy.pth`` has LSTM-128 actor/critic and no MLP
+(trained_models/phase_1/phase1_final.zip [ART]).  State-dict keys below are exactly SB3's, so
+``policy.pth`` loads with ``load_state_dict`` unchanged (tests/test_checkpoint.py).
+
+``lstm_hidden_size=None`` gives the plain MLP policy of BASELINE.json's configs ("PPO MLP[256,256]").
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+
+def _mlp(inp: int, sizes: Sequence[int], act) -> nn.Sequential:
+    layers = []
+    for h in sizes:
+        layers += [nn.Linear(inp, h), act()]
+        inp = h
+    return nn.Sequential(*layers)
+
+
+class MlpExtractor(nn.Module):
+    def __init__(self, inp: int, pi: Sequence[int], vf: Sequence[int], act):
+        super().__init__()
+        self.policy_net = _mlp(inp, pi, act)
+        self.value_net = _mlp(inp, vf, act)
+        self.latent_dim_pi = pi[-1] if pi else inp
+        self.latent_dim_vf = vf[-1] if vf else inp
+
+
+class ActorCriticPolicy(nn.Module):
+    def __init__(self, obs_dim: int, act_dim: int, pi: Sequence[int] = (256, 256), vf: Sequence[int] = (256, 256),
+                 lstm_hidden_size: Optional[int] = None, enable_critic_lstm: bool = True,
+                 log_std_init: float = -2.0, activation_fn=nn.ReLU):
+        super().__init__()
+        self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.recurrent = lstm_hidden_size is not None
+        feat = obs_dim
+        if self.recurrent:
+            self.lstm_actor = nn.LSTM(obs_dim, lstm_hidden_size, num_layers=1)
+            self.lstm_critic = nn.LSTM(obs_dim, lstm_hidden_size, num_layers=1) if enable_critic_lstm else None
+            if not enable_critic_lstm:
+                raise NotImplementedError("shared / linear critic variants are not used by the reference")
+            feat = lstm_hidden_size
+        self.hidden = lstm_hidden_size
+        self.mlp_extractor = MlpExtractor(feat, list(pi), list(vf), activation_fn)
+        self.action_net = nn.Linear(self.mlp_extractor.latent_dim_pi, act_dim)
+        self.value_net = nn.Linear(self.mlp_extractor.latent_dim_vf, 1)
+        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
+
+    # ---- recurrent helpers
+    def initial_state(self, n: int, device) -> Optional[Tuple[torch.Tensor, ...]]:
+        if not self.recurrent:
+            return None
+        z = lambda: torch.zeros((1, n, self.hidden), device=device)
+        return (z(), z(), z(), z())   # (h_pi, c_pi, h_vf, c_vf)
+
+    @staticmethod
+    def _lstm_seq(lstm: nn.LSTM, x, h, c, starts):
+        """x [T,N,F]; starts [T,N] (1 = episode start: state zeroed before that step) — sb3-contrib
+        ``_process_sequence`` [3P-RECALL, SURVEY.md C.3]."""
+        if starts is None or not bool(starts.any()):
+            out, (h, c) = lstm(x, (h, c))
+            return out, h, c
+        outs = []
+        for t in range(x.shape[0]):
+            keep = (1.0 - starts[t].to(x.dtype)).view(1, -1, 1)
+            o, (h, c) = lstm(x[t:t + 1], (h * keep, c * keep))
+            outs.append(o)
+        return torch.cat(outs, 0), h, c
+
+    def _latents(self, obs, state, starts):
+        """obs [T,N,F] (recurrent) or [B,F]."""
+        if self.recurrent:
+            hp, cp, hv, cv = state
+            lp, hp, cp = self._lstm_seq(self.lstm_actor, obs, hp, cp, starts)
+            lv, hv, cv = self._lstm_seq(self.lstm_critic, obs, hv, cv, starts)
+            state = (hp, cp, hv, cv)
+        else:
+            lp = lv = obs
+        return self.mlp_extractor.policy_net(lp), self.mlp_extractor.value_net(lv), state
+
+    def _dist(self, latent_pi):
+        mean = self.action_net(latent_pi).float()
+        return mean, self.log_std.float()
+
+    @staticmethod
+    def log_prob(actions, mean, log_std):
+        var = torch.exp(2 * log_std)
+        return (-0.5 * ((actions - mean) ** 2) / var - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+
+    def entropy(self):
+        return (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std.float()).sum()
+
+    # ---- rollout: one step for all envs
+    @torch.no_grad()
+    def act(self, obs, state=None, episode_starts=None, deterministic=False):
+        x = obs.unsqueeze(0) if self.recurrent else obs
+        st = episode_starts.unsqueeze(0) if (self.recurrent and episode_starts is not None) else None
+        lp, lv, state = self._latents(x, state, st)
+        if self.recurrent:
+            lp, lv = lp[0], lv[0]
+        mean, log_std = self._dist(lp)
+        actions = mean if deterministic else mean + torch.exp(log_std) * torch.randn_like(mean)
+        values = self.value_net(lv).float().squeeze(-1)
+        return actions, values, self.log_prob(actions, mean, log_std), state
+
+    @torch.no_grad()
+    def predict_values(self, obs, state=None, episode_starts=None):
+        x = obs.unsqueeze(0) if self.recurrent else obs
+        st = episode_starts.unsqueeze(0) if (self.recurrent and episode_starts is not None) else None
+        _, lv, _ = self._latents(x, state, st)
+        if self.recurrent:
+            lv = lv[0]
+        return self.value_net(lv).float().squeeze(-1)
+
+    # ---- training: evaluate stored actions
+    def evaluate_actions(self, obs, actions, state=None, episode_starts=None):
+        """MLP: obs [B,F], actions [B,A].  Recurrent: obs [T,N,F], actions [T,N,A], state at t=0."""
+        lp, lv, _ = self._latents(obs, state, episode_starts)
+        mean, log_std = self._dist(lp)
+        values = self.value_net(lv).float().squeeze(-1)
+        return values, self.log_prob(actions, mean, log_std), self.entropy()
+
+    def predict(self, observation, state=None, episode_start=None, deterministic=False):
+        """SB3-style predict on numpy or tensors (used by evaluation loops such as
+        /root/reference/src/main_eval.py:86-118)."""
+        import numpy as np
+        dev = self.log_std.device
+        obs = torch.as_tensor(observation, dtype=torch.float32, device=dev)
+        if obs.dim() == 1:
+            obs = obs.unsqueeze(0)
+        if self.recurrent and state is None:
+            state = self.initial_state(obs.shape[0], dev)
+        starts = None if episode_start is None else torch.as_tensor(np.asarray(episode_start), dtype=torch.float32, device=dev)
+        a, _, _, state = self.act(obs, state, starts, deterministic)
+        a = torch.clamp(a, -1.0, 1.0)
+        return (a.cpu().numpy() if isinstance(observation, np.ndarray) else a), state

@@ -1,0 +1,212 @@
+"""PPO rollout/update engine on device tensors (SB3 ``OnPolicyAlgorithm`` / sb3-contrib
+``RecurrentPPO`` semantics).
+
+What the reference runs (``RecurrentPPO.learn``; /root/reference/src/train/trainer.py:66-71):
+  collect_rollouts: policy forward (no_grad) -> clip -> env.step -> timeout bootstrap
+                    ``r += gamma * V(terminal_obs)`` -> buffer.add
+  compute_returns_and_advantage: GAE(gamma, lambda) backward scan with episode_starts[t+1]
+  train: n_epochs x minibatches; per-minibatch advantage normalisation; clipped surrogate +
+         vf_coef * MSE + ent_coef * entropy; clip_grad_norm_; Adam(eps=1e-5)
+Here the buffer, the normaliser and the policy stay on the GPU; the env step is one HIP kernel
+launch (myo_batch_step).  Multi-GPU: one process per GPU, envs sharded by rank, ONE all-reduce
+of a flat fp32 gradient bucket per optimizer step over RCCL (torch.distributed backend "nccl").
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from .policy import ActorCriticPolicy
+
+
+@dataclass
+class PPOConfig:
+    n_steps: int = 128
+    batch_size: int = 4096
+    n_epochs: int = 10
+    learning_rate: float = 3e-4
+    clip_range: float = 0.2
+    ent_coef: float = 0.0
+    vf_coef: float = 0.5
+    gamma: float = 0.99
+    gae_lambda: float = 0.95
+    max_grad_norm: float = 0.5
+    normalize_advantage: bool = True
+    bf16: bool = True               # autocast the policy GEMMs to bf16 (fp32 master weights)
+    sync_adv_moments: bool = False  # all-reduce advantage moments (exact single-process semantics)
+
+
+def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
+    """rewards/values/episode_starts [T,N]; SB3 buffer semantics: non-terminal mask for step t is
+    1 - episode_starts[t+1] (1 - dones for the last step)."""
+    T = rewards.shape[0]
+    adv = torch.zeros_like(rewards)
+    last = torch.zeros_like(last_values)
+    for t in reversed(range(T)):
+        if t == T - 1:
+            nonterm, nextv = 1.0 - last_dones, last_values
+        else:
+            nonterm, nextv = 1.0 - episode_starts[t + 1], values[t + 1]
+        delta = rewards[t] + gamma * nextv * nonterm - values[t]
+        last = delta + gamma * lam * nonterm * last
+        adv[t] = last
+    return adv, adv + values
+
+
+class PPO:
+    def __init__(self, env, policy: ActorCriticPolicy, cfg: PPOConfig = PPOConfig(), seed: int = 0):
+        self.env, self.policy, self.cfg = env, policy, cfg
+        self.device = env.device
+        self.policy.to(self.device)
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        N, T, O, A = env.num_envs, cfg.n_steps, env.obs_dim, env.act_dim
+        d = self.device
+        self.obs_buf = torch.zeros((T, N, O), device=d)
+        self.act_buf = torch.zeros((T, N, A), device=d)
+        self.rew_buf = torch.zeros((T, N), device=d)
+        self.val_buf = torch.zeros((T, N), device=d)
+        self.logp_buf = torch.zeros((T, N), device=d)
+        self.start_buf = torch.zeros((T, N), device=d)
+        self._last_obs = None
+        self._last_starts = torch.ones(N, device=d)
+        self._state = policy.initial_state(N, d)
+        self._rollout_state0 = None
+        self.num_timesteps = 0
+        self.n_updates = 0
+        self.ep_returns: list = []
+        self.ep_lengths: list = []
+        self.gen = torch.Generator(device="cpu")
+        self.gen.manual_seed(seed + 1000 * self.rank)
+        nparam = sum(p.numel() for p in self.policy.parameters())
+        self._flat_grad = torch.zeros(nparam, device=d)
+        self.timers: Dict[str, float] = {"rollout": 0.0, "gae": 0.0, "update": 0.0}
+
+    def _autocast(self):
+        on = self.cfg.bf16 and self.device.type == "cuda"
+        return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=on)
+
+    # ---------------------------------------------------------------- rollout
+    @torch.no_grad()
+    def collect_rollouts(self) -> None:
+        cfg, env, pol = self.cfg, self.env, self.policy
+        if self._last_obs is None:
+            self._last_obs = env.reset_tensor().clone()
+        if pol.recurrent:
+            self._rollout_state0 = tuple(s.clone() for s in self._state)
+        for t in range(cfg.n_steps):
+            obs, starts = self._last_obs, self._last_starts
+            with self._autocast():
+                actions, values, logp, new_state = pol.act(obs, self._state, starts)
+            clipped = torch.clamp(actions, -1.0, 1.0)
+            nobs, rew, done, trunc, term, comps, ep = env.step_tensor(clipped)
+            rew = rew.clone()
+            if bool(trunc.any()):   # timeout bootstrap with the terminal observation and pre-step state
+                with self._autocast():
+                    tv = pol.predict_values(term, self._state, starts)
+                rew = rew + cfg.gamma * tv * trunc.to(rew.dtype)
+            self.obs_buf[t], self.act_buf[t], self.rew_buf[t] = obs, actions, rew
+            self.val_buf[t], self.logp_buf[t], self.start_buf[t] = values, logp, starts
+            self._state = new_state
+            self._last_obs = nobs.clone()
+            self._last_starts = done.to(torch.float32)
+        self.num_timesteps += cfg.n_steps * env.num_envs * self.world
+        with self._autocast():
+            self._last_values = pol.predict_values(self._last_obs, self._state, self._last_starts)
+
+    # ---------------------------------------------------------------- update
+    def _allreduce_grads(self) -> None:
+        if self.world == 1:
+            return
+        off = 0
+        for p in self.policy.parameters():
+            n = p.numel()
+            self._flat_grad[off:off + n] = p.grad.reshape(-1) if p.grad is not None else 0
+            off += n
+        dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+        self._flat_grad /= self.world
+        off = 0
+        for p in self.policy.parameters():
+            n = p.numel()
+            p.grad = self._flat_grad[off:off + n].view_as(p).clone()
+            off += n
+
+    def _loss(self, values, logp, entropy, old_logp, adv, returns):
+        cfg = self.cfg
+        if cfg.normalize_advantage and adv.numel() > 1:
+            if cfg.sync_adv_moments and self.world > 1:
+                m = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device)])
+                dist.all_reduce(m)
+                mean = m[0] / m[2]
+                std = torch.sqrt(torch.clamp(m[1] / m[2] - mean * mean, min=0.0) * m[2] / (m[2] - 1))
+            else:
+                mean, std = adv.mean(), adv.std()
+            adv = (adv - mean) / (std + 1e-8)
+        ratio = torch.exp(logp - old_logp)
+        pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
+        vl = torch.nn.functional.mse_loss(values, returns)
+        return pl + cfg.ent_coef * (-entropy) + cfg.vf_coef * vl, pl.detach(), vl.detach()
+
+    def train(self) -> Dict[str, float]:
+        cfg, pol = self.cfg, self.policy
+        T, N = cfg.n_steps, self.env.num_envs
+        adv, ret = compute_gae(self.rew_buf, self.val_buf, self.start_buf, self._last_values,
+                               self._last_starts, cfg.gamma, cfg.gae_lambda)
+        stats = {}
+        if not pol.recurrent:
+            B = T * N
+            obs, act = self.obs_buf.view(B, -1), self.act_buf.view(B, -1)
+            oldlp, advf, retf = self.logp_buf.view(B), adv.view(B), ret.view(B)
+            bs = min(cfg.batch_size, B)
+            for _ in range(cfg.n_epochs):
+                perm = torch.randperm(B, generator=self.gen).to(self.device)
+                for s in range(0, B - bs + 1, bs):
+                    idx = perm[s:s + bs]
+                    with self._autocast():
+                        v, lp, ent = pol.evaluate_actions(obs[idx], act[idx])
+                    loss, pl, vl = self._loss(v, lp, ent, oldlp[idx], advf[idx], retf[idx])
+                    self.optimizer.zero_grad(set_to_none=True)
+                    loss.backward()
+                    self._allreduce_grads()
+                    torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)
+                    self.optimizer.step()
+                    self.n_updates += 1
+        else:
+            # sequences = whole rollouts of a subset of envs, initial LSTM state = state at rollout start
+            envs_per_mb = max(1, min(N, cfg.batch_size // T))
+            for _ in range(cfg.n_epochs):
+                perm = torch.randperm(N, generator=self.gen).to(self.device)
+                for s in range(0, N - envs_per_mb + 1, envs_per_mb):
+                    idx = perm[s:s + envs_per_mb]
+                    st0 = tuple(x[:, idx] for x in self._rollout_state0)
+                    with self._autocast():
+                        v, lp, ent = pol.evaluate_actions(self.obs_buf[:, idx], self.act_buf[:, idx], st0,
+                                                          self.start_buf[:, idx])
+                    loss, pl, vl = self._loss(v.reshape(-1), lp.reshape(-1), ent, self.logp_buf[:, idx].reshape(-1),
+                                              adv[:, idx].reshape(-1), ret[:, idx].reshape(-1))
+                    self.optimizer.zero_grad(set_to_none=True)
+                    loss.backward()
+                    self._allreduce_grads()
+                    torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)
+                    self.optimizer.step()
+                    self.n_updates += 1
+        stats.update(policy_loss=float(pl), value_loss=float(vl), n_updates=self.n_updates)
+        return stats
+
+    def learn(self, total_timesteps: int, callback: Optional[Callable[["PPO"], None]] = None, log=None):
+        t_start = time.time()
+        while self.num_timesteps < total_timesteps:
+            self.collect_rollouts()
+            stats = self.train()
+            if callback is not None:
+                callback(self)
+            if log is not None and self.rank == 0:
+                fps = self.num_timesteps / max(1e-9, time.time() - t_start)
+                log({"time/fps": fps, "time/total_timesteps": self.num_timesteps,
+                     "rollout/ep_rew_mean": float(self.rew_buf.sum(0).mean()), **{"train/" + k: v for k, v in stats.items()}})
+        return self

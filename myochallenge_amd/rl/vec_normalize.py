@@ -1,0 +1,189 @@
+"""Device-resident ``VecNormalize`` with stable-baselines3's state format and update rule.
+
+Replaces ``stable_baselines3.common.vec_env.VecNormalize`` as the reference uses it:
+``VecNormalize.load(path, venv)`` (/root/reference/src/main_baoding.py:75), ``.normalize_obs`` and
+``.save`` (/root/reference/src/metrics/custom_callbacks.py:34,60), ``envs.save``
+(/root/reference/src/train/trainer.py:75), ``.training`` / ``.norm_reward``
+(/root/reference/src/main_eval.py:65-67).  Update rule [3P-RECALL SB3 1.6.2, SURVEY.md C.2]:
+Chan's parallel mean/variance merge with initial count 1e-4, ``ret = ret*gamma + r``,
+clip(obs) ±10, clip(reward) ±10, epsilon 1e-8.  The pickles the reference ships are read
+without SB3 through a ``find_class`` remap; statistics live on the device in
+float64 so the running moments match the host implementation.
+"""
+from __future__ import annotations
+
+import pickle
+from typing import Optional
+
+import numpy as np
+import torch
+
+
+class RunningMeanStd:
+    def __init__(self, shape=(), device="cpu", epsilon: float = 1e-4):
+        self.mean = torch.zeros(shape, dtype=torch.float64, device=device)
+        self.var = torch.ones(shape, dtype=torch.float64, device=device)
+        self.count = float(epsilon)
+
+    def update(self, x: torch.Tensor) -> None:
+        x = x.to(torch.float64)
+        self.update_from_moments(x.mean(0), x.var(0, unbiased=False), x.shape[0])
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count) -> None:
+        delta = batch_mean - self.mean
+        tot = self.count + batch_count
+        new_mean = self.mean + delta * batch_count / tot
+        m2 = self.var * self.count + batch_var * batch_count + delta * delta * self.count * batch_count / tot
+        self.mean, self.var, self.count = new_mean, m2 / tot, tot
+
+    def state(self):
+        return {"mean": self.mean.cpu().numpy().copy(), "var": self.var.cpu().numpy().copy(), "count": float(self.count)}
+
+
+class _Stub:
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, s):
+        self.__dict__.update(s if isinstance(s, dict) else {"_state": s})
+
+
+class _StubUnpickler(pickle.Unpickler):
+    _PASS = ("numpy", "builtins", "collections", "copyreg", "_codecs")
+
+    def find_class(self, module, name):
+        if module.split(".")[0] in self._PASS:
+            return super().find_class(module, name)
+        return type(name, (_Stub,), {"__module__": module})
+
+
+class VecNormalize:
+    """Wraps a tensor-native batched env (``reset_tensor`` / ``step_tensor``)."""
+
+    def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
+                 gamma=0.99, epsilon=1e-8):
+        self.venv = venv
+        self.num_envs = venv.num_envs if venv is not None else 0
+        dev = venv.device if venv is not None else "cpu"
+        self.device = dev
+        obs_dim = venv.obs_dim if venv is not None else 0
+        self.obs_rms = RunningMeanStd((obs_dim,), dev)
+        self.ret_rms = RunningMeanStd((), dev)
+        self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
+        self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
+        self.returns = torch.zeros(self.num_envs, dtype=torch.float64, device=dev)
+        self.old_obs = None
+        self.old_reward = None
+        if venv is not None:
+            self.observation_space, self.action_space = venv.observation_space, venv.action_space
+            self.obs_dim, self.act_dim = venv.obs_dim, venv.act_dim
+
+    # -- normalisation
+    def normalize_obs(self, obs):
+        is_np = isinstance(obs, np.ndarray)
+        o = torch.as_tensor(obs, device=self.device)
+        if self.norm_obs:
+            o = torch.clamp((o.to(torch.float64) - self.obs_rms.mean) / torch.sqrt(self.obs_rms.var + self.epsilon),
+                            -self.clip_obs, self.clip_obs).to(torch.float32)
+        return o.cpu().numpy() if is_np else o
+
+    def normalize_reward(self, r):
+        if self.norm_reward:
+            r = torch.clamp(r.to(torch.float64) / torch.sqrt(self.ret_rms.var + self.epsilon), -self.clip_reward,
+                            self.clip_reward).to(torch.float32)
+        return r
+
+    def unnormalize_obs(self, obs):
+        if not self.norm_obs:
+            return obs
+        return (obs.to(torch.float64) * torch.sqrt(self.obs_rms.var + self.epsilon) + self.obs_rms.mean).to(torch.float32)
+
+    def get_original_obs(self):
+        return self.old_obs
+
+    def get_original_reward(self):
+        return self.old_reward
+
+    # -- stepping (tensor-native)
+    def reset_tensor(self):
+        obs = self.venv.reset_tensor()
+        self.old_obs = obs.clone()
+        self.returns.zero_()
+        if self.training and self.norm_obs:
+            self.obs_rms.update(obs)
+        return self.normalize_obs(obs)
+
+    def step_tensor(self, actions):
+        obs, rew, done, trunc, term, comps, ep = self.venv.step_tensor(actions)
+        self.old_obs, self.old_reward = obs.clone(), rew.clone()
+        if self.training and self.norm_obs:
+            self.obs_rms.update(obs)
+        if self.training:
+            self.returns = self.returns * self.gamma + rew.to(torch.float64)
+            self.ret_rms.update(self.returns)
+        nrew = self.normalize_reward(rew)
+        nobs = self.normalize_obs(obs)
+        nterm = self.normalize_obs(term)
+        self.returns = torch.where(done.bool(), torch.zeros_like(self.returns), self.returns)
+        return nobs, nrew, done, trunc, nterm, comps, ep
+
+    # -- SB3 protocol (numpy)
+    def reset(self):
+        return self.reset_tensor().cpu().numpy()
+
+    def step(self, actions):
+        a = torch.as_tensor(np.asarray(actions, np.float32), device=self.device)
+        nobs, nrew, done, trunc, nterm, comps, ep = self.step_tensor(a)
+        done_h, trunc_h = done.cpu().numpy().astype(bool), trunc.cpu().numpy().astype(bool)
+        infos = []
+        nterm_h, ep_h = nterm.cpu().numpy(), ep.cpu().numpy()
+        for i in range(self.num_envs):
+            info = {}
+            if done_h[i]:
+                info = {"terminal_observation": nterm_h[i].copy(), "TimeLimit.truncated": bool(trunc_h[i]),
+                        "episode": {"r": float(ep_h[i, 0]), "l": int(ep_h[i, 1])}}
+            infos.append(info)
+        return nobs.cpu().numpy(), nrew.cpu().numpy(), done_h, infos
+
+    def close(self):
+        if self.venv is not None:
+            self.venv.close()
+
+    # -- persistence
+    def state_dict(self):
+        return {"obs_rms": self.obs_rms.state(), "ret_rms": self.ret_rms.state(), "clip_obs": self.clip_obs,
+                "clip_reward": self.clip_reward, "gamma": self.gamma, "epsilon": self.epsilon,
+                "norm_obs": self.norm_obs, "norm_reward": self.norm_reward, "training": self.training}
+
+    def save(self, path: str) -> None:
+        with open(path, "wb") as fh:
+            pickle.dump({"format": "myochallenge_amd.VecNormalize/1", **self.state_dict()}, fh)
+
+    def _load_state(self, st) -> None:
+        def rms(dst, src):
+            dst.mean = torch.as_tensor(np.asarray(src["mean"], np.float64), device=self.device)
+            dst.var = torch.as_tensor(np.asarray(src["var"], np.float64), device=self.device)
+            dst.count = float(src["count"])
+        rms(self.obs_rms, st["obs_rms"])
+        rms(self.ret_rms, st["ret_rms"])
+        for k in ("clip_obs", "clip_reward", "gamma", "epsilon", "norm_obs", "norm_reward", "training"):
+            setattr(self, k, st[k])
+
+    @staticmethod
+    def read_pickle(path: str) -> dict:
+        """Statistics of an SB3 VecNormalize pickle (read without SB3) or of a file written by save()."""
+        with open(path, "rb") as fh:
+            obj = _StubUnpickler(fh).load()
+        if isinstance(obj, dict):
+            return obj
+        g = lambda o: {"mean": np.asarray(o.mean), "var": np.asarray(o.var), "count": float(o.count)}
+        return {"obs_rms": g(obj.obs_rms), "ret_rms": g(obj.ret_rms), "clip_obs": float(obj.clip_obs),
+                "clip_reward": float(obj.clip_reward), "gamma": float(obj.gamma), "epsilon": float(obj.epsilon),
+                "norm_obs": bool(obj.norm_obs), "norm_reward": bool(obj.norm_reward), "training": bool(obj.training)}
+
+    @classmethod
+    def load(cls, load_path: str, venv) -> "VecNormalize":
+        st = cls.read_pickle(load_path)
+        self = cls(venv)
+        self._load_state(st)
+        return self

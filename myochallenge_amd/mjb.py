@@ -393,8 +393,9 @@ def parse_mjb(blob: bytes) -> MjbModel:
         raise MjbError("nbuffer larger than the file")
     # mjStatistic {meaninertia, meanmass, meansize, extent, center[3]} closes the fixed-size
     # blocks, immediately before the array buffer (mjVisual sits between mjOption and it).
-    if base - off < 56:
-        raise MjbError("no room for mjVisual/mjStatistic before the array buffer")
+    if base - off != 608:
+        raise MjbError(f"expected 608 bytes of mjVisual+mjStatistic between mjOption and the array buffer "
+                       f"(MuJoCo 2.1 layout), found {base - off}: truncated or different version")
     st = struct.unpack_from("<7d", blob, base - 56)
     stat = {"meaninertia": st[0], "meanmass": st[1], "meansize": st[2], "extent": st[3],
             "center": list(st[4:7])}

@@ -1,0 +1,50 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu through gpurun)")
+    config.addinivalue_line("markers", "slow: takes more than a few seconds")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """Lane-serial emulation build of the kernel source (TEST TOOLING, see wave.h)."""
+    from myochallenge_amd import native
+    from myochallenge_amd.build import build_emu
+    return native.load(build_emu())
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    import torch
+    from myochallenge_amd import native
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    lib = native.load()
+    assert not lib.is_emulation
+    return lib
+
+
+@pytest.fixture(scope="session")
+def models():
+    from myochallenge_amd.mjb import load_mjb
+    from myochallenge_amd.synth_hand import synthetic_hand
+    return {
+        "finger": load_mjb(os.path.join(GOLDEN, "myo_finger_v0.mjb")),
+        "motor_finger": load_mjb(os.path.join(GOLDEN, "motor_finger_v0.mjb")),
+        "load": load_mjb(os.path.join(GOLDEN, "myo_load.mjb")),
+        "hand": synthetic_hand(),
+    }

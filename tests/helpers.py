@@ -1,0 +1,64 @@
+"""Shared helpers for the parity tests (emu on CPU, HIP on GPU) — both go through the C ABI."""
+import numpy as np
+
+from myochallenge_amd import native
+from myochallenge_amd.envs.config import make_task_cfg, task_ids
+from myochallenge_amd.model import compile_model
+from oracle.oracle import BaodingState, OracleData, OracleModel, baoding_step, make_cfg
+
+
+class Mem:
+    """Array factory: numpy for the emulation library, torch-on-GPU for the HIP library."""
+
+    def __init__(self, lib):
+        self.gpu = not lib.is_emulation
+        if self.gpu:
+            import torch
+            self.torch = torch
+            self.dev = torch.device("cuda:0")
+
+    def arr(self, a, dtype=np.float64):
+        a = np.ascontiguousarray(np.asarray(a, dtype=dtype))
+        if not self.gpu:
+            return a.copy()
+        return self.torch.as_tensor(a, device=self.dev)
+
+    def zeros(self, shape, dtype=np.float64):
+        return self.arr(np.zeros(shape, dtype=dtype), dtype)
+
+    def host(self, x):
+        if not self.gpu:
+            return np.asarray(x)
+        self.torch.cuda.synchronize()
+        return x.cpu().numpy()
+
+
+def oracle_for(mj, integrator=None):
+    cm = compile_model(mj, integrator=integrator)
+    om = OracleModel(cm.to_blob())
+    return cm, om, OracleData(om)
+
+
+def forward_dump(lib, mem, cm, qpos, qvel, act, ctrl, dtype=native.MYO_F64, n=2):
+    nm = native.Model(cm, lib)
+    b = native.Batch(nm, None, n, 0, 0, dtype)
+    tile = lambda x: mem.arr(np.tile(np.asarray(x, float), (n, 1)))
+    b.set_state(tile(qpos), tile(qvel), tile(act), mem.zeros(n))
+    out = mem.zeros((n, b.dump_size))
+    b.forward_dump(tile(ctrl), out)
+    res = mem.host(out)[n - 1]
+    get = lambda name, k: res[b.dump_offset(name):b.dump_offset(name) + k]
+    return get, b
+
+
+def default_state(which=2, period=5.0, xr=0.025, yr=0.028, s1=3 * np.pi / 4, s2=-np.pi / 4):
+    st = BaodingState()
+    st.which_task, st.counter = which, 0
+    st.start_angle[0], st.start_angle[1] = s1, s2
+    st.x_radius, st.y_radius, st.time_period = xr, yr, period
+    return st
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

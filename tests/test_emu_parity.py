@@ -1,0 +1,57 @@
+"""CPU-side parity of the KERNEL SOURCE: tests/emu/libmyobatch_emu.so is myobatch.hip compiled
+with -DMYO_EMU (lanes of a phase run serially).  It is test tooling — the product library has no
+CPU path — and lets the wave-parallel algorithm be checked against the oracle without a GPU.
+The same cases run on the real HIP kernels in test_gpu_parity.py (-m gpu)."""
+import numpy as np
+import pytest
+
+import parity_cases as pc
+from myochallenge_amd import native
+
+
+def test_forward_stages_f64(emu_lib, models):
+    pc.case_forward_stages(emu_lib, models, native.MYO_F64, 1e-9)
+
+
+def test_forward_stages_f32(emu_lib, models):
+    pc.case_forward_stages(emu_lib, models, native.MYO_F32, 2e-4)
+
+
+@pytest.mark.parametrize("name,integ,steps", [("finger", 1, 120), ("load", None, 300), ("finger", None, 60)])
+def test_trajectory_small_models(emu_lib, models, name, integ, steps):
+    pc.case_trajectory(emu_lib, models[name], steps, native.MYO_F64, 1e-8, integrator=integ)
+
+
+@pytest.mark.parametrize("integ,steps", [(None, 60), (1, 25)])
+def test_trajectory_hand(emu_lib, models, integ, steps):
+    q = models["hand"].qpos0.copy(); q[0] = -1.57
+    pc.case_trajectory(emu_lib, models["hand"], steps, native.MYO_F64, 1e-8, integrator=integ, q0=q)
+
+
+def test_task_step(emu_lib, models):
+    pc.case_task_step(emu_lib, models, native.MYO_F64, 1e-7)
+
+
+def test_vecenv_protocol(emu_lib, models):
+    pc.case_vecenv_protocol(emu_lib, models, native.MYO_F64)
+
+
+def test_reset_logic(emu_lib, models):
+    pc.case_reset_logic(emu_lib, models, native.MYO_F64)
+
+
+def test_capacity_and_argument_errors(emu_lib, models):
+    from myochallenge_amd.model import compile_model
+    import copy
+    cm = compile_model(models["hand"])
+    m = native.Model(cm, emu_lib)
+    with pytest.raises(native.MyoError):
+        native.Batch(m, None, 0, 0, 0, native.MYO_F64)                # n_envs <= 0
+    with pytest.raises(native.MyoError):
+        native.Batch(m, None, 1, 0, 0, 7)                             # bad dtype
+    b = native.Batch(m, None, 1, 0, 0, native.MYO_F64)
+    with pytest.raises(native.MyoError):
+        b.reset()                                                     # no task layer
+    bad = copy.deepcopy(cm); bad.fields = dict(cm.fields); del bad.fields["jnt_axis"]
+    with pytest.raises(native.MyoError):
+        native.Model(bad, emu_lib)

@@ -1,0 +1,146 @@
+"""PPO side on CPU: GAE, VecNormalize (SB3 state format), SB3 checkpoint loading, PPO step,
+2-rank gloo data parallelism (env shards + one flat gradient all-reduce)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from myochallenge_amd.rl.policy import ActorCriticPolicy
+from myochallenge_amd.rl.ppo import PPO, PPOConfig, compute_gae
+from myochallenge_amd.rl.sb3_zip import load_policy, read_zip
+from myochallenge_amd.rl.vec_normalize import RunningMeanStd, VecNormalize
+
+
+def test_gae_matches_reference_recursion():
+    rng = np.random.RandomState(0)
+    T, N, g, lam = 12, 5, 0.99, 0.9
+    r, v = rng.normal(size=(T, N)), rng.normal(size=(T, N))
+    starts = (rng.uniform(size=(T, N)) < 0.2).astype(np.float64)
+    lastv, lastd = rng.normal(size=N), (rng.uniform(size=N) < 0.3).astype(np.float64)
+    adv = np.zeros((T, N)); last = np.zeros(N)
+    for t in reversed(range(T)):            # SB3 RolloutBuffer.compute_returns_and_advantage
+        nn, nv = (1 - lastd, lastv) if t == T - 1 else (1 - starts[t + 1], v[t + 1])
+        delta = r[t] + g * nv * nn - v[t]
+        last = delta + g * lam * nn * last
+        adv[t] = last
+    a, ret = compute_gae(*(torch.tensor(x) for x in (r, v, starts, lastv, lastd)), g, lam)
+    np.testing.assert_allclose(a.numpy(), adv, atol=1e-12)
+    np.testing.assert_allclose(ret.numpy(), adv + v, atol=1e-12)
+
+
+def test_running_mean_std_chan_merge():
+    rng = np.random.RandomState(1)
+    x = rng.normal(3, 2, size=(1000, 4))
+    rms = RunningMeanStd((4,))
+    for chunk in np.split(x, 10):
+        rms.update(torch.tensor(chunk))
+    # equals one pass over [epsilon-weighted prior ; data]
+    n = 1e-4 + 1000
+    mean = x.sum(0) / n
+    var = (1e-4 * (1 + mean ** 2) + ((x - mean) ** 2).sum(0)) / n
+    np.testing.assert_allclose(rms.mean.numpy(), mean, rtol=1e-10)
+    np.testing.assert_allclose(rms.var.numpy(), var, rtol=1e-8)
+    assert abs(rms.count - n) < 1e-9
+
+
+def test_vecnormalize_reads_reference_pickle(golden_dir):
+    st = VecNormalize.read_pickle(os.path.join(golden_dir, "normalized_env_phase1_final.pkl"))
+    ref = json.load(open(os.path.join(golden_dir, "vecnormalize_states.json")))["phase_1/normalized_env_phase1_final"]
+    np.testing.assert_array_equal(st["obs_rms"]["mean"], ref["obs_rms"]["mean"])
+    np.testing.assert_array_equal(st["obs_rms"]["var"], ref["obs_rms"]["var"])
+    assert st["obs_rms"]["count"] == ref["obs_rms"]["count"] and st["clip_obs"] == 10.0 and st["gamma"] == 0.99
+    assert abs(st["obs_rms"]["count"] % 1 - 1e-4) < 1e-6          # SB3's initial count 1e-4 [ART]
+
+
+def test_vecnormalize_load_save_roundtrip(golden_dir, tmp_path, emu_lib):
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=2, lib=emu_lib)
+    v = VecNormalize.load(os.path.join(golden_dir, "normalized_env_phase1_final.pkl"), env)
+    obs = v.reset()
+    assert obs.shape == (2, 86) and np.abs(obs).max() <= 10.0
+    raw = v.get_original_obs().numpy()
+    mean, var = v.obs_rms.mean.numpy(), v.obs_rms.var.numpy()
+    np.testing.assert_allclose(obs, np.clip((raw - mean) / np.sqrt(var + 1e-8), -10, 10), atol=1e-5)
+    p = str(tmp_path / "env.pkl"); v.save(p)
+    w = VecNormalize.load(p, env)
+    np.testing.assert_array_equal(w.obs_rms.mean.numpy(), v.obs_rms.mean.numpy())
+    assert w.ret_rms.count == v.ret_rms.count
+    o2, r2, d2, infos = v.step(np.zeros((2, 39), np.float32))
+    assert o2.shape == (2, 86) and r2.shape == (2,) and len(infos) == 2
+    env.close()
+
+
+def test_sb3_checkpoint_loads_and_matches_stock_torch(golden_dir):
+    pol, data = load_policy(os.path.join(golden_dir, "phase1_final.zip"))
+    assert data["n_steps"] == 256 and data["gae_lambda"] == 0.9 and data["policy_kwargs"]["lstm_hidden_size"] == 128
+    assert sum(p.numel() for p in pol.parameters()) == 226383
+    g = np.load(os.path.join(golden_dir, "phase1_policy_io.npz"))
+    st = pol.initial_state(16, "cpu")
+    a, v, lp, st2 = pol.act(torch.tensor(g["last_obs"]), st, torch.zeros(16), deterministic=True)
+    np.testing.assert_allclose(a.numpy(), g["mean"], atol=1e-6)
+    np.testing.assert_allclose(v.numpy(), g["value"][:, 0], atol=1e-6)
+    np.testing.assert_allclose(lp.numpy(), g["logp_of_mean"], atol=1e-4)
+    np.testing.assert_allclose(st2[0][0].numpy(), g["h_actor"], atol=1e-6)
+    np.testing.assert_allclose(st2[3][0].numpy(), g["c_critic"], atol=1e-6)
+    schema = json.load(open(os.path.join(golden_dir, "sb3_zip_schema.json")))
+    d, sd, opt = read_zip(os.path.join(golden_dir, "phase1_final.zip"))
+    assert d["_sb3_version"] == schema["version"] and opt is not None
+
+
+def test_entropy_matches_reference_log(golden_dir):
+    """first logged train/entropy_loss of 01_rsi_static = 22.66 = 39 (2 - 0.5 ln(2 pi e))"""
+    pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=256, log_std_init=-2)
+    assert abs(float(-pol.entropy().detach()) - 22.6626) < 5e-3   # logged after the first updates
+    assert sum(p.numel() for p in pol.parameters()) > 900_000
+
+
+@pytest.mark.parametrize("hidden", [None, 32])
+def test_ppo_runs_on_emulated_env(emu_lib, hidden):
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=4, lib=emu_lib, seed=1, dtype="f64")
+    venv = VecNormalize(env)
+    pol = ActorCriticPolicy(86, 39, (32, 32), (32, 32), lstm_hidden_size=hidden)
+    before = [p.detach().clone() for p in pol.parameters()]
+    algo = PPO(venv, pol, PPOConfig(n_steps=6, batch_size=12, n_epochs=2))
+    algo.learn(48)
+    assert algo.num_timesteps == 48 and algo.n_updates > 0
+    assert any(not torch.equal(a, b) for a, b in zip(before, pol.parameters()))
+    assert all(torch.isfinite(p).all() for p in pol.parameters())
+    env.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _dp_worker(rank, world, port, emu_path, out):
+    import torch.distributed as dist
+    from myochallenge_amd import native
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    pol = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=None)
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=2, lib=native.load(emu_path), seed=100 + rank, dtype="f64")
+    algo = PPO(env, pol, PPOConfig(n_steps=4, batch_size=8, n_epochs=1, bf16=False))
+    algo.collect_rollouts()
+    algo.train()
+    out[rank] = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).numpy()
+    dist.barrier(); dist.destroy_process_group(); env.close()
+
+
+def test_two_rank_data_parallel_keeps_replicas_identical(emu_lib):
+    """world_size 2 over gloo: env shards differ per rank, ONE flat gradient all-reduce per optimizer
+    step keeps the policy replicas bit-identical (the N>1 path of bench.py, RCCL on the GPU box)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, emu_lib.path, out), nprocs=2, join=True)
+    assert np.array_equal(out[0], out[1])
+    torch.manual_seed(0)
+    init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (16,), (16,)).parameters()]).numpy()
+    assert not np.array_equal(out[0], init)

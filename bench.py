@@ -85,14 +85,14 @@ def cpu_baseline(seconds: float, all_cores: bool):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--integrator", default="model", choices=["model", "euler", "rk4"])
-    ap.add_argument("--n-steps", type=int, default=16, help="rollout length between PPO updates")
+    ap.add_argument("--n-steps", type=int, default=64, help="rollout length between PPO updates")
     ap.add_argument("--n-epochs", type=int, default=10)
-    ap.add_argument("--batch-size", type=int, default=4096)
+    ap.add_argument("--batch-size", type=int, default=16384, help="minibatch: 1/16 of the rollout as in the reference (4096 of 65536)")
     ap.add_argument("--env-name", default="CustomMyoBaodingBallsP1")
     ap.add_argument("--no-ppo", action="store_true", help="rollout only (reported as invalid for the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

@@ -48,9 +48,18 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
 
 template <typename T>
 struct ContactRec {
-  T pos[3], frame[9], mu[2], D, B, kip, F[3], A[5];
+  T pos[3], frame[9], mu[2], D, B, kip, F[3];
+  T r1[3], r2[3];                 // contact point relative to the reference point of body1's / body2's tree
+  unsigned long long m1, m2;      // ancestor-dof masks of the two bodies
   int b1, b2, nsup;
   unsigned char sup[MYO_CS_MAX];
+};
+
+template <typename T>
+struct RkScratch {                // RK4 stage storage, only instantiated by the RK4 kernels
+  T x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];
+  T F[4][2 * MYO_NV_MAX + MYO_NU_MAX];
+  T dX[2 * MYO_NV_MAX + MYO_NU_MAX];
 };
 
 template <typename T>
@@ -63,11 +72,11 @@ struct Scratch {
       time_period, ep_ret;
   int which_task, counter, elapsed, episode, ep_len;
   // ---- position stage
-  T xpos[MYO_NB_MAX * 3], xquat[MYO_NB_MAX * 4], xmat[MYO_NB_MAX * 9], xipos[MYO_NB_MAX * 3];
-  T xanchor[MYO_NJ_MAX * 3], xaxis[MYO_NJ_MAX * 3];
-  T com[MYO_NB_MAX * 3], cinert[MYO_NB_MAX * 10], crb[MYO_NB_MAX * 10];
-  T cdof[MYO_NV_MAX * 6], cdof_dot[MYO_NV_MAX * 6];
-  T cvel[MYO_NB_MAX * 6], bvec[MYO_NB_MAX * 6], cfrcb[MYO_NB_MAX * 6];
+  // (short-lived arrays alias longer-lived storage, see the S_* accessors below)
+  T xpos[MYO_NB_MAX * 3], xmat[MYO_NB_MAX * 9], xipos[MYO_NB_MAX * 3];
+  T com[MYO_NB_MAX * 3], cinert[MYO_NB_MAX * 10];
+  T cdof[MYO_NV_MAX * 6];
+  T cvel[MYO_NB_MAX * 6], bvec[MYO_NB_MAX * 6];
   T ten_length[MYO_NT_MAX], ten_vel[MYO_NT_MAX], ten_J[MYO_NT_MAX * MYO_TJ_MAX];
   T act_force[MYO_NU_MAX], act_dot[MYO_NU_MAX];
   T qM[MYO_NM_MAX], H[MYO_NV_MAX * (MYO_NV_MAX + 1) / 2];
@@ -80,20 +89,31 @@ struct Scratch {
   ContactRec<T> con[MYO_NCON_MAX];
   int lim_id[MYO_NLIM_MAX];
   T lim_sgn[MYO_NLIM_MAX];
-  T efc_D[MYO_NEFC_MAX], efc_B[MYO_NEFC_MAX], efc_kip[MYO_NEFC_MAX], efc_aref[MYO_NEFC_MAX],
-      efc_jar[MYO_NEFC_MAX], efc_jv[MYO_NEFC_MAX], efc_force[MYO_NEFC_MAX];
+  T efc_D[MYO_NLIM_MAX], efc_B[MYO_NLIM_MAX], efc_kip[MYO_NLIM_MAX];   // limit rows only; contact rows: con[]
+  T efc_aref[MYO_NEFC_MAX], efc_jar[MYO_NEFC_MAX], efc_jv[MYO_NEFC_MAX], efc_force[MYO_NEFC_MAX];
   unsigned char efc_active[MYO_NEFC_MAX];
-  // ---- RK4 stage storage
-  T rk_x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];
-  T rk_F[4][2 * MYO_NV_MAX + MYO_NU_MAX];
-  T rk_dX[2 * MYO_NV_MAX + MYO_NU_MAX];
+  RkScratch<T>* rk;               // null unless the model integrates with RK4
   // ---- task layer
-  T obs[MYO_OBS_MAX];
   T rwd[8];
 #ifdef MYO_PROF
   unsigned long long prof[16], prof_t;
 #endif
 };
+
+// Aliases: arrays whose lifetime ends before the buffer they live in is next written.
+//   crb (CRB only), cdof_dot (velocity stage only), obs (after the physics) -> inside H (666 T)
+//   xquat (kinematics only) -> efc_jar;  xanchor / xaxis (until cdof is built) -> efc_aref / efc_jv
+//   cfrcb (RNE only) -> bvec (solver only)
+#define S_CRB(s) ((s).H)
+#define S_CDOFDOT(s) ((s).H + MYO_NB_MAX * 10)
+#define S_OBS(s) ((s).H + MYO_NB_MAX * 10 + MYO_NV_MAX * 6)
+#define S_XQUAT(s) ((s).efc_jar)
+#define S_XANCHOR(s) ((s).efc_aref)
+#define S_XAXIS(s) ((s).efc_jv)
+#define S_CFRCB(s) ((s).bvec)
+static_assert(MYO_NB_MAX * 10 + MYO_NV_MAX * 6 + MYO_OBS_MAX <= MYO_NV_MAX * (MYO_NV_MAX + 1) / 2, "H aliases");
+static_assert(MYO_NB_MAX * 4 <= MYO_NEFC_MAX && MYO_NJ_MAX * 3 <= MYO_NEFC_MAX, "efc aliases");
+template <typename T> DEV T row_D(const Scratch<T>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
 
 // ------------------------------------------------------------------------------------------
 // small math
@@ -204,7 +224,7 @@ DEV void kinematics(const DevModel<T>& M, Scratch<T>& s) {
   WAVE_FN
   PHASE {
     if (lane == 0) {
-      s.xpos[0] = s.xpos[1] = s.xpos[2] = 0; s.xquat[0] = 1; s.xquat[1] = s.xquat[2] = s.xquat[3] = 0;
+      s.xpos[0] = s.xpos[1] = s.xpos[2] = 0; S_XQUAT(s)[0] = 1; S_XQUAT(s)[1] = S_XQUAT(s)[2] = S_XQUAT(s)[3] = 0;
       for (int k = 0; k < 9; ++k) s.xmat[k] = (k % 4 == 0) ? (T)1 : (T)0;
     }
   }
@@ -220,13 +240,13 @@ DEV void kinematics(const DevModel<T>& M, Scratch<T>& s) {
           T qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
           normalize4(qq);
           for (int k = 0; k < 4; ++k) { s.qpos[qa + 3 + k] = qq[k]; q[k] = qq[k]; }
-          for (int k = 0; k < 3; ++k) { p[k] = s.qpos[qa + k]; s.xanchor[3 * ja + k] = p[k]; }
-          s.xaxis[3 * ja] = 0; s.xaxis[3 * ja + 1] = 0; s.xaxis[3 * ja + 2] = 1;
+          for (int k = 0; k < 3; ++k) { p[k] = s.qpos[qa + k]; S_XANCHOR(s)[3 * ja + k] = p[k]; }
+          S_XAXIS(s)[3 * ja] = 0; S_XAXIS(s)[3 * ja + 1] = 0; S_XAXIS(s)[3 * ja + 2] = 1;
         } else {
           T t[3];
           mulmatvec3(t, s.xmat + 9 * par, M.body_pos + 3 * b);
           p[0] = s.xpos[3 * par] + t[0]; p[1] = s.xpos[3 * par + 1] + t[1]; p[2] = s.xpos[3 * par + 2] + t[2];
-          mulquat(q, s.xquat + 4 * par, M.body_quat + 4 * b);
+          mulquat(q, S_XQUAT(s) + 4 * par, M.body_quat + 4 * b);
           for (int k = 0; k < jn; ++k) {
             const int j = ja + k, qa = M.jnt_qposadr[j];
             T R[9], anchor[3], axis[3];
@@ -234,7 +254,7 @@ DEV void kinematics(const DevModel<T>& M, Scratch<T>& s) {
             mulmatvec3(anchor, R, M.jnt_pos + 3 * j);
             anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
             mulmatvec3(axis, R, M.jnt_axis + 3 * j);
-            for (int e = 0; e < 3; ++e) { s.xanchor[3 * j + e] = anchor[e]; s.xaxis[3 * j + e] = axis[e]; }
+            for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = anchor[e]; S_XAXIS(s)[3 * j + e] = axis[e]; }
             const T ang = s.qpos[qa] - M.qpos0[qa];
             if (M.jnt_type[j] == 2) {
               p[0] += axis[0] * ang; p[1] += axis[1] * ang; p[2] += axis[2] * ang;
@@ -250,7 +270,7 @@ DEV void kinematics(const DevModel<T>& M, Scratch<T>& s) {
         }
         normalize4(q);
         for (int k = 0; k < 3; ++k) s.xpos[3 * b + k] = p[k];
-        for (int k = 0; k < 4; ++k) s.xquat[4 * b + k] = q[k];
+        for (int k = 0; k < 4; ++k) S_XQUAT(s)[4 * b + k] = q[k];
         T R[9];
         quat2mat(R, q);
         for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = R[k];
@@ -307,7 +327,7 @@ DEV void com_pos(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
     if (j < M.njnt) {
       const int b = M.jnt_bodyid[j], da = M.jnt_dofadr[j];
       const T* c = s.com + 3 * M.body_rootid[b];
-      const T off[3] = {c[0] - s.xanchor[3 * j], c[1] - s.xanchor[3 * j + 1], c[2] - s.xanchor[3 * j + 2]};
+      const T off[3] = {c[0] - S_XANCHOR(s)[3 * j], c[1] - S_XANCHOR(s)[3 * j + 1], c[2] - S_XANCHOR(s)[3 * j + 2]};
       if (M.jnt_type[j] == 0) {
         for (int k = 0; k < 3; ++k) { T* cd = s.cdof + 6 * (da + k); for (int e = 0; e < 6; ++e) cd[e] = 0; cd[3 + k] = 1; }
         for (int k = 0; k < 3; ++k) {
@@ -318,9 +338,9 @@ DEV void com_pos(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
         }
       } else if (M.jnt_type[j] == 2) {
         T* cd = s.cdof + 6 * da; cd[0] = cd[1] = cd[2] = 0;
-        cd[3] = s.xaxis[3 * j]; cd[4] = s.xaxis[3 * j + 1]; cd[5] = s.xaxis[3 * j + 2];
+        cd[3] = S_XAXIS(s)[3 * j]; cd[4] = S_XAXIS(s)[3 * j + 1]; cd[5] = S_XAXIS(s)[3 * j + 2];
       } else {
-        T* cd = s.cdof + 6 * da; const T ax[3] = {s.xaxis[3 * j], s.xaxis[3 * j + 1], s.xaxis[3 * j + 2]};
+        T* cd = s.cdof + 6 * da; const T ax[3] = {S_XAXIS(s)[3 * j], S_XAXIS(s)[3 * j + 1], S_XAXIS(s)[3 * j + 2]};
         cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
         cross3(cd + 3, ax, off);
       }
@@ -542,7 +562,7 @@ DEV void crb(const DevModel<T>& M, Scratch<T>& s) {
         sub &= sub - 1;
         for (int k = 0; k < 10; ++k) acc[k] += s.cinert[10 * c + k];
       }
-      for (int k = 0; k < 10; ++k) s.crb[10 * b + k] = acc[k];
+      for (int k = 0; k < 10; ++k) S_CRB(s)[10 * b + k] = acc[k];
     }
   }
   SYNC();
@@ -550,7 +570,7 @@ DEV void crb(const DevModel<T>& M, Scratch<T>& s) {
     for (int e = lane; e < M.nM; e += 64) {
       const int i = M.M_i[e], j = M.M_j[e];
       T buf[6];
-      mul_inert_vec(buf, s.crb + 10 * M.dof_bodyid[i], s.cdof + 6 * i);
+      mul_inert_vec(buf, S_CRB(s) + 10 * M.dof_bodyid[i], s.cdof + 6 * i);
       T v = 0;
       for (int k = 0; k < 6; ++k) v += s.cdof[6 * j + k] * buf[k];
       if (i == j) v += M.dof_armature[i];
@@ -661,60 +681,71 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 }
 
 // solve (L L') x = b with H (packed, LDS) and x (LDS) ; H is overwritten with L
+// `OPAQUE(lane)` re-materialises the lane id so that clang does not hoist the 100+ loop-invariant
+// lane-compare masks into SGPR pairs (it then spills them through v_writelane).
+#define MYO_OPAQUE_LANE(v) int v = (int)threadIdx.x; asm volatile("" : "+v"(v));
 template <typename T>
-__device__ __forceinline__ void chol_factor_solve_reg(Scratch<T>& s, T* x, int n) {
+__device__ __noinline__ void chol_factor_solve_reg(Scratch<T>& s, T* x, int n) {
   constexpr int N = MYO_NV_MAX;
   const int lane = threadIdx.x;
   T a[N];
   const int rbase = lane * (lane + 1) / 2;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    T v = (j == lane) ? (T)1 : (T)0;
-    if (lane < n && j <= lane) v = s.H[rbase + j];
+    MYO_OPAQUE_LANE(l)
+    T v = (j == l) ? (T)1 : (T)0;
+    if (l < n && j <= l) v = s.H[rbase + j];
     a[j] = v;
   }
   T b = (lane < n) ? x[lane] : (T)0;
+  // factor: right-looking, no lane predicates.  Entries above the diagonal (j > lane) hold
+  // don't-care values that never flow into valid ones (every valid update uses lanes >= j only).
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     T akk = lane_bcast<T>(a[k], k);
     akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
-    const T dk = sqrt(akk);
-    const T inv = 1 / dk;
-    const T lik = (lane > k) ? a[k] * inv : ((lane == k) ? dk : (T)0);
+    const T inv = 1 / sqrt(akk);
+    const T lik = a[k] * inv;             // lane k: akk / sqrt(akk) = sqrt(akk)
     a[k] = lik;
 #pragma unroll
-    for (int j = k + 1; j < N; ++j) {
-      const T ljk = lane_bcast<T>(lik, j);
-      a[j] -= lik * ljk;
-    }
+    for (int j = k + 1; j < N; ++j) a[j] -= lik * lane_bcast<T>(lik, j);
+    __builtin_amdgcn_sched_barrier(0);
   }
-  // zero the (garbage) strict upper part, keep 1/diag
+  // forward substitution  L y = b   (lane j finishes at step j; later steps must not touch it)
   T invd = 1;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
-    if (j == lane) invd = 1 / a[j];
-    if (j > lane) a[j] = 0;
+    MYO_OPAQUE_LANE(l)
+    if (j == l) invd = 1 / a[j];
   }
-  // forward substitution  L y = b
 #pragma unroll
   for (int j = 0; j < N; ++j) {
+    MYO_OPAQUE_LANE(l)
     const T yj = lane_bcast<T>(b * invd, j);
-    b = (lane == j) ? yj : b - a[j] * yj;   // a[j] = 0 for lanes < j
+    b = (l == j) ? yj : ((l > j) ? b - a[j] * yj : b);
+    __builtin_amdgcn_sched_barrier(0);
   }
   // transpose through LDS: lane i needs column i
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < N; ++j)
-    if (lane < n && j <= lane) s.H[rbase + j] = a[j];
+  for (int j = 0; j < N; ++j) {
+    MYO_OPAQUE_LANE(l)
+    if (l < n && j <= l) s.H[rbase + j] = a[j];
+  }
   __syncthreads();
   T c[N];
 #pragma unroll
-  for (int j = 0; j < N; ++j) c[j] = (j > lane && j < n) ? s.H[j * (j + 1) / 2 + lane] : (T)0;
+  for (int j = 0; j < N; ++j) {
+    MYO_OPAQUE_LANE(l)
+    c[j] = (j > l && j < n) ? s.H[j * (j + 1) / 2 + l] : (T)0;
+  }
   // backward substitution  L' x = y
 #pragma unroll
   for (int j = N - 1; j >= 0; --j) {
+    MYO_OPAQUE_LANE(l)
     const T xj = lane_bcast<T>(b * invd, j);
-    b = (lane == j) ? xj : b - c[j] * xj;   // c[j] = 0 for lanes > j
+    b = (l == j) ? xj : b - c[j] * xj;    // c[j] = 0 for lanes >= j
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (lane < n) x[lane] = b;
   __syncthreads();
@@ -908,7 +939,7 @@ DEV void collision_and_constraints(const DevModel<T>& M, const TaskDev& K, Scrat
           T Kc, Bc, Ic;
           sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dist - mg, &Kc, &Bc, &Ic);
           const T R = tmax(MYO_MINVAL, (1 - Ic) * M.dof_invweight0[M.jnt_dofadr[j]] / Ic);
-          s.lim_id[r] = j; s.lim_sgn[r] = side ? (T)-1 : (T)1;
+          s.lim_id[r] = M.jnt_dofadr[j]; s.lim_sgn[r] = side ? (T)-1 : (T)1;   // joint rows keep the DOF index
           s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * (dist - mg);
           r++;
         }
@@ -1032,7 +1063,12 @@ DEV void collision_and_constraints(const DevModel<T>& M, const TaskDev& K, Scrat
         const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
         c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * (dist - inc);
         // dofs this contact can move
-        unsigned long long sup = M.body_dofmask[c.b1] | M.body_dofmask[c.b2];
+        c.m1 = M.body_dofmask[c.b1]; c.m2 = M.body_dofmask[c.b2];
+        {
+          const T* c1 = s.com + 3 * M.body_rootid[c.b1]; const T* c2 = s.com + 3 * M.body_rootid[c.b2];
+          for (int e = 0; e < 3; ++e) { c.r1[e] = c.pos[e] - c1[e]; c.r2[e] = c.pos[e] - c2[e]; }
+        }
+        unsigned long long sup = c.m1 | c.m2;
         int ns = 0;
         while (sup && ns < MYO_CS_MAX) { c.sup[ns++] = (unsigned char)myo_ffsll(sup); sup &= sup - 1; }
         c.nsup = ns;
@@ -1044,12 +1080,6 @@ DEV void collision_and_constraints(const DevModel<T>& M, const TaskDev& K, Scrat
   }
   PHASE {
     if (lane == 0) { s.ncon = ncon; s.nefc = nlim + 4 * ncon; }
-    // contact row parameters replicated per pyramid edge
-    for (int ci = lane; ci < ncon; ci += 64)
-      for (int e = 0; e < 4; ++e) {
-        const int r = nlim + 4 * ci + e;
-        s.efc_D[r] = s.con[ci].D; s.efc_B[r] = s.con[ci].B; s.efc_kip[r] = s.con[ci].kip;
-      }
   }
   SYNC();
 }
@@ -1077,13 +1107,18 @@ DEV void body_vectors(const DevModel<T>& M, const Scratch<T>& s, const T* v, T* 
   SYNC();
 }
 template <typename T>
-DEV void point_vel(const DevModel<T>& M, const Scratch<T>& s, const T* bv, int b, const T* p, T* out) {
-  int r = M.body_rootid[b];
-  const T* c = s.com + 3 * r; const T* V = bv + 6 * b;
-  const T off[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+DEV void point_vel(const T* bv, int b, const T* off, T* out) {
+  const T* V = bv + 6 * b;
   T t[3];
   cross3(t, V, off);
   out[0] = V[3] + t[0]; out[1] = V[4] + t[1]; out[2] = V[5] + t[2];
+}
+// Jacobian column of dof d at a contact, given the contact offset from the dof's tree reference point
+template <typename T> DEV void con_col(const Scratch<T>& s, int d, const T* off, T* col) {
+  const T* cd = s.cdof + 6 * d;
+  T t[3];
+  cross3(t, cd, off);
+  col[0] = cd[3] + t[0]; col[1] = cd[4] + t[1]; col[2] = cd[5] + t[2];
 }
 
 // out[r] = (J v)[r] for every constraint row; bv = body vectors of v (already computed)
@@ -1094,7 +1129,7 @@ DEV void J_times(const DevModel<T>& M, const Scratch<T>& s, const T* v, const T*
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T val;
-      if (r < nl) val = s.lim_sgn[r] * v[M.jnt_dofadr[s.lim_id[r]]];
+      if (r < nl) val = s.lim_sgn[r] * v[s.lim_id[r]];
       else if (r < nlim) {
         const int t = s.lim_id[r];
         unsigned long long m = M.tendon_dofmask[t];
@@ -1106,8 +1141,8 @@ DEV void J_times(const DevModel<T>& M, const Scratch<T>& s, const T* v, const T*
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
         T v1[3], v2[3];
-        point_vel(M, s, bv, c.b1, c.pos, v1);
-        point_vel(M, s, bv, c.b2, c.pos, v2);
+        point_vel(bv, c.b1, c.r1, v1);
+        point_vel(bv, c.b2, c.r2, v2);
         const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
         const T vn = dot3(c.frame, rel), vt = dot3(c.frame + 3 + 3 * (e >> 1), rel);
         val = vn + ((e & 1) ? -c.mu[e >> 1] : c.mu[e >> 1]) * vt;
@@ -1137,7 +1172,7 @@ DEV void JT_times(const DevModel<T>& M, Scratch<T>& s, const T* f, T* out) {
     if (d < M.nv) {
       T acc = 0;
       for (int r = 0; r < nl; ++r)
-        if (M.jnt_dofadr[s.lim_id[r]] == d) acc += s.lim_sgn[r] * f[r];
+        if (s.lim_id[r] == d) acc += s.lim_sgn[r] * f[r];
       for (int r = nl; r < nlim; ++r) {
         const int t = s.lim_id[r];
         const unsigned long long m = M.tendon_dofmask[t];
@@ -1145,10 +1180,10 @@ DEV void JT_times(const DevModel<T>& M, Scratch<T>& s, const T* f, T* out) {
       }
       for (int ci = 0; ci < ncon; ++ci) {
         const ContactRec<T>& c = s.con[ci];
-        const int on1 = (int)((M.body_dofmask[c.b1] >> d) & 1ull), on2 = (int)((M.body_dofmask[c.b2] >> d) & 1ull);
+        const int on1 = (int)((c.m1 >> d) & 1ull), on2 = (int)((c.m2 >> d) & 1ull);
         if (on1 != on2) {
           T col[3];
-          jac_col(M, s, d, c.pos, col);
+          con_col(s, d, on2 ? c.r2 : c.r1, col);
           const T v = dot3(col, c.F);
           acc += on2 ? v : -v;
         }
@@ -1187,8 +1222,8 @@ DEV void fwd_velocity(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
         const T vo = s.qvel[o];
         for (int e = 0; e < 6; ++e) cv[e] += s.cdof[6 * o + e] * vo;
       }
-      if (is_free_trans) { for (int e = 0; e < 6; ++e) s.cdof_dot[6 * d + e] = 0; }
-      else cross_motion(s.cdof_dot + 6 * d, cv, s.cdof + 6 * d);
+      if (is_free_trans) { for (int e = 0; e < 6; ++e) S_CDOFDOT(s)[6 * d + e] = 0; }
+      else cross_motion(S_CDOFDOT(s) + 6 * d, cv, s.cdof + 6 * d);
       // passive joint forces
       T p = -M.dof_damping[d] * s.qvel[d];
       const int j = M.dof_jntid[d];
@@ -1228,13 +1263,13 @@ DEV void fwd_velocity(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
         const int d = myo_ffsll(m);
         m &= m - 1;
         const T vd = s.qvel[d];
-        for (int e = 0; e < 6; ++e) a[e] += s.cdof_dot[6 * d + e] * vd;
+        for (int e = 0; e < 6; ++e) a[e] += S_CDOFDOT(s)[6 * d + e] * vd;
       }
       T t1[6], t2[6], t3[6];
       mul_inert_vec(t1, s.cinert + 10 * b, a);
       mul_inert_vec(t2, s.cinert + 10 * b, s.cvel + 6 * b);
       cross_force(t3, s.cvel + 6 * b, t2);
-      for (int e = 0; e < 6; ++e) s.cfrcb[6 * b + e] = (b == 0) ? (T)0 : t1[e] + t3[e];
+      for (int e = 0; e < 6; ++e) S_CFRCB(s)[6 * b + e] = (b == 0) ? (T)0 : t1[e] + t3[e];
     }
   }
   SYNC();
@@ -1246,7 +1281,7 @@ DEV void fwd_velocity(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
       while (sub) {
         const int c = myo_ffsll(sub);
         sub &= sub - 1;
-        for (int e = 0; e < 6; ++e) f[e] += s.cfrcb[6 * c + e];
+        for (int e = 0; e < 6; ++e) f[e] += S_CFRCB(s)[6 * c + e];
       }
       T acc = 0;
       for (int e = 0; e < 6; ++e) acc += s.cdof[6 * d + e] * f[e];
@@ -1257,7 +1292,14 @@ DEV void fwd_velocity(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
   // reference acceleration of every constraint row: aref = -B vel - K imp (pos - margin)
   if (s.nefc > 0) {
     J_times(M, s, s.qvel, s.cvel, s.efc_jv);
-    PHASE { for (int r = lane; r < s.nefc; r += 64) s.efc_aref[r] = -s.efc_B[r] * s.efc_jv[r] - s.efc_kip[r]; }
+    PHASE {
+      const int nlim_ = s.nl + s.ntl;
+      for (int r = lane; r < s.nefc; r += 64) {
+        const T Bc = r < nlim_ ? s.efc_B[r] : s.con[(r - nlim_) >> 2].B;
+        const T kp = r < nlim_ ? s.efc_kip[r] : s.con[(r - nlim_) >> 2].kip;
+        s.efc_aref[r] = -Bc * s.efc_jv[r] - kp;
+      }
+    }
     SYNC();
   }
   (void)K;
@@ -1358,18 +1400,18 @@ template <typename T>
 DEV T update_constraint(const DevModel<T>& M, Scratch<T>& s) {
   // forces / active set from jar, cost, qfrc_constraint, gradient
   WAVE_FN
-  const int nefc = s.nefc;
+  const int nefc = s.nefc, nlim = s.nl + s.ntl;
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       const T x = s.efc_jar[r];
       const unsigned char a = x < 0;
       s.efc_active[r] = a;
-      s.efc_force[r] = a ? -s.efc_D[r] * x : (T)0;
+      s.efc_force[r] = a ? -row_D(s, r, nlim) * x : (T)0;
     }
   }
   SYNC();
   JT_times(M, s, s.efc_force, s.qfrc_constraint);
-  WAVE_SUM_N(T, ccost, nefc, r, (s.efc_active[r] ? (T)0.5 * s.efc_D[r] * s.efc_jar[r] * s.efc_jar[r] : (T)0));
+  WAVE_SUM_N(T, ccost, nefc, r, (s.efc_active[r] ? (T)0.5 * row_D(s, r, nlim) * s.efc_jar[r] * s.efc_jar[r] : (T)0));
   WAVE_SUM_N(T, gcost, M.nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc[c] - s.qacc_smooth[c])));
   PHASE {
     const int c = lane;
@@ -1390,7 +1432,7 @@ DEV void build_hessian(const DevModel<T>& M, Scratch<T>& s) {
     if (d < M.nv) {
       T acc = 0;
       for (int r = 0; r < nl; ++r)
-        if (s.efc_active[r] && M.jnt_dofadr[s.lim_id[r]] == d) acc += s.efc_D[r];
+        if (s.efc_active[r] && s.lim_id[r] == d) acc += s.efc_D[r];
       if (acc != 0) s.H[MYO_HIDX(d, d)] += acc;
     }
   }
@@ -1417,24 +1459,18 @@ DEV void build_hessian(const DevModel<T>& M, Scratch<T>& s) {
   // contacts: H += Jp' (R' A R) Jp with A = D sum_active w w'  (3x3 per contact, frame coordinates)
   for (int ci = 0; ci < s.ncon; ++ci) {
     PHASE {
-      if (lane == 0) {
-        ContactRec<T>& c = s.con[ci];
-        const unsigned char* act = s.efc_active + nlim + 4 * ci;
-        // A = [[nn, n1, n2],[n1, 11, 0],[n2, 0, 22]]
-        T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
-        if (act[0]) { nn += 1; n1 += c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
-        if (act[1]) { nn += 1; n1 -= c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
-        if (act[2]) { nn += 1; n2 += c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
-        if (act[3]) { nn += 1; n2 -= c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
-        c.A[0] = c.D * nn; c.A[1] = c.D * n1; c.A[2] = c.D * n2; c.A[3] = c.D * a11; c.A[4] = c.D * a22;
-      }
-    }
-    SYNC();
-    PHASE {
       const ContactRec<T>& c = s.con[ci];
-      if (c.A[0] != 0) {
+      const unsigned char* act = s.efc_active + nlim + 4 * ci;
+      // A = [[nn, n1, n2],[n1, a11, 0],[n2, 0, a22]] (every lane derives it: 4 flags, ~10 flops)
+      T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
+      if (act[0]) { nn += 1; n1 += c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
+      if (act[1]) { nn += 1; n1 -= c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
+      if (act[2]) { nn += 1; n2 += c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
+      if (act[3]) { nn += 1; n2 -= c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
+      if (nn != 0) {
+        const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
         const int ns = c.nsup;
-        const unsigned long long m1 = M.body_dofmask[c.b1], m2 = M.body_dofmask[c.b2];
+        const unsigned long long m1 = c.m1, m2 = c.m2;
         for (int a = lane >> 3; a < ns; a += 8)
           for (int b = lane & 7; b <= a; b += 8) {
             const int da = c.sup[a], db = c.sup[b];
@@ -1442,15 +1478,15 @@ DEV void build_hessian(const DevModel<T>& M, Scratch<T>& s) {
             const int b1 = (int)((m1 >> db) & 1ull), b2 = (int)((m2 >> db) & 1ull);
             if (a1 == a2 || b1 == b2) continue;
             T ca[3], cb[3];
-            jac_col(M, s, da, c.pos, ca);
-            jac_col(M, s, db, c.pos, cb);
+            con_col(s, da, a2 ? c.r2 : c.r1, ca);
+            con_col(s, db, b2 ? c.r2 : c.r1, cb);
             T ja[3] = {dot3(c.frame, ca), dot3(c.frame + 3, ca), dot3(c.frame + 6, ca)};
             T jb[3] = {dot3(c.frame, cb), dot3(c.frame + 3, cb), dot3(c.frame + 6, cb)};
             if (!a2) { ja[0] = -ja[0]; ja[1] = -ja[1]; ja[2] = -ja[2]; }
             if (!b2) { jb[0] = -jb[0]; jb[1] = -jb[1]; jb[2] = -jb[2]; }
-            const T Ajb0 = c.A[0] * jb[0] + c.A[1] * jb[1] + c.A[2] * jb[2];
-            const T Ajb1 = c.A[1] * jb[0] + c.A[3] * jb[1];
-            const T Ajb2 = c.A[2] * jb[0] + c.A[4] * jb[2];
+            const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
+            const T Ajb1 = A1 * jb[0] + A3 * jb[1];
+            const T Ajb2 = A2 * jb[0] + A4 * jb[2];
             s.H[MYO_HIDX(da, db)] += ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2;
           }
       }
@@ -1469,8 +1505,9 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
   body_vectors(M, s, s.qacc_smooth, s.bvec);
   J_times(M, s, s.qacc_smooth, s.bvec, s.efc_jv);
   mul_M(M, s, s.Ma, s.qacc_warm);
-  WAVE_SUM_N(T, costw_c, nefc, r, ((s.efc_jar[r] - s.efc_aref[r]) < 0 ? (T)0.5 * s.efc_D[r] * (s.efc_jar[r] - s.efc_aref[r]) * (s.efc_jar[r] - s.efc_aref[r]) : (T)0));
-  WAVE_SUM_N(T, costs, nefc, r, ((s.efc_jv[r] - s.efc_aref[r]) < 0 ? (T)0.5 * s.efc_D[r] * (s.efc_jv[r] - s.efc_aref[r]) * (s.efc_jv[r] - s.efc_aref[r]) : (T)0));
+  const int nlim = s.nl + s.ntl;
+  WAVE_SUM_N(T, costw_c, nefc, r, ((s.efc_jar[r] - s.efc_aref[r]) < 0 ? (T)0.5 * row_D(s, r, nlim) * (s.efc_jar[r] - s.efc_aref[r]) * (s.efc_jar[r] - s.efc_aref[r]) : (T)0));
+  WAVE_SUM_N(T, costs, nefc, r, ((s.efc_jv[r] - s.efc_aref[r]) < 0 ? (T)0.5 * row_D(s, r, nlim) * (s.efc_jv[r] - s.efc_aref[r]) * (s.efc_jv[r] - s.efc_aref[r]) : (T)0));
   WAVE_SUM_N(T, gw, nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc_warm[c] - s.qacc_smooth[c])));
   const int use_warm = (costw_c + (T)0.5 * gw) < costs;
   PHASE {
@@ -1509,7 +1546,7 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
     for (int li = 0; li < 50; ++li) {
       WAVE_SUM3_N(T, e0, e1, e2, nefc, r, {
         const T x = s.efc_jar[r] + alpha * s.efc_jv[r];
-        if (x < 0) { const T D = s.efc_D[r], jv = s.efc_jv[r]; _e1 = (T)0.5 * D * x * x; _e2 = D * x * jv; _e3 = D * jv * jv; }
+        if (x < 0) { const T D = row_D(s, r, nlim), jv = s.efc_jv[r]; _e1 = (T)0.5 * D * x * x; _e2 = D * x * jv; _e3 = D * jv * jv; }
       });
       (void)e0;
       const T d1 = 2 * alpha * q2 + q1 + e1, d2 = 2 * q2 + e2;
@@ -1656,42 +1693,42 @@ DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
     const int nq = M.nq, nv = M.nv, na = M.na, nf = 2 * nv + na;
     const T h = M.timestep, t0 = s.time;
     PHASE {
-      for (int i = lane; i < nq; i += 64) s.rk_x0[i] = s.qpos[i];
-      for (int i = lane; i < nv; i += 64) { s.rk_x0[nq + i] = s.qvel[i]; s.rk_F[0][i] = s.qvel[i]; s.rk_F[0][nv + i] = s.qacc[i]; }
-      for (int i = lane; i < na; i += 64) { s.rk_x0[nq + nv + i] = s.act[i]; s.rk_F[0][2 * nv + i] = s.act_dot[i]; }
+      for (int i = lane; i < nq; i += 64) s.rk->x0[i] = s.qpos[i];
+      for (int i = lane; i < nv; i += 64) { s.rk->x0[nq + i] = s.qvel[i]; s.rk->F[0][i] = s.qvel[i]; s.rk->F[0][nv + i] = s.qacc[i]; }
+      for (int i = lane; i < na; i += 64) { s.rk->x0[nq + nv + i] = s.act[i]; s.rk->F[0][2 * nv + i] = s.act_dot[i]; }
     }
     SYNC();
     for (int st = 1; st < 4; ++st) {
       const T a = (st == 3) ? (T)1 : (T)0.5;
       PHASE {
-        for (int i = lane; i < nf; i += 64) s.rk_dX[i] = a * s.rk_F[st - 1][i];
-        for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk_x0[i];
+        for (int i = lane; i < nf; i += 64) s.rk->dX[i] = a * s.rk->F[st - 1][i];
+        for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       }
       SYNC();
-      integrate_pos(M, s, s.rk_dX, h);
+      integrate_pos(M, s, s.rk->dX, h);
       PHASE {
-        for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk_x0[nq + i] + h * s.rk_dX[nv + i];
-        for (int i = lane; i < na; i += 64) s.act[i] = s.rk_x0[nq + nv + i] + h * s.rk_dX[2 * nv + i];
+        for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * s.rk->dX[nv + i];
+        for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i] + h * s.rk->dX[2 * nv + i];
         if (lane == 0) s.time = t0 + h * a;
       }
       SYNC();
       forward(M, K, s);
       PHASE {
-        for (int i = lane; i < nv; i += 64) { s.rk_F[st][i] = s.qvel[i]; s.rk_F[st][nv + i] = s.qacc[i]; }
-        for (int i = lane; i < na; i += 64) s.rk_F[st][2 * nv + i] = s.act_dot[i];
+        for (int i = lane; i < nv; i += 64) { s.rk->F[st][i] = s.qvel[i]; s.rk->F[st][nv + i] = s.qacc[i]; }
+        for (int i = lane; i < na; i += 64) s.rk->F[st][2 * nv + i] = s.act_dot[i];
       }
       SYNC();
     }
     PHASE {
       for (int i = lane; i < nf; i += 64)
-        s.rk_dX[i] = (s.rk_F[0][i] + 2 * s.rk_F[1][i] + 2 * s.rk_F[2][i] + s.rk_F[3][i]) / 6;
-      for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk_x0[i];
-      for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk_x0[nq + i];
-      for (int i = lane; i < na; i += 64) s.act[i] = s.rk_x0[nq + nv + i];
+        s.rk->dX[i] = (s.rk->F[0][i] + 2 * s.rk->F[1][i] + 2 * s.rk->F[2][i] + s.rk->F[3][i]) / 6;
+      for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
+      for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i];
+      for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i];
       if (lane == 0) s.time = t0;
     }
     SYNC();
-    advance(M, s, s.rk_dX + 2 * nv, s.rk_dX + nv, s.rk_dX);
+    advance(M, s, s.rk->dX + 2 * nv, s.rk->dX + nv, s.rk->dX);
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
     load_H_from_M(M, s, M.dof_damping, M.timestep);

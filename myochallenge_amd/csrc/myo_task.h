@@ -69,7 +69,7 @@ DEV void baoding_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& 
   const T dt = (T)K.frame_skip * M.timestep;
   PHASE {
     const int i = lane;
-    if (i < nh) s.obs[i] = s.qpos[i];
+    if (i < nh) S_OBS(s)[i] = s.qpos[i];
     if (i < 3) {
       T p1[3], p2[3], t1[3], t2[3];
       body_point(s, M.site_bodyid[K.obj1_sid], M.site_pos + 3 * K.obj1_sid, p1);
@@ -78,25 +78,25 @@ DEV void baoding_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& 
       const T l2[3] = {s.target_xy[2], s.target_xy[3], M.site_pos[3 * K.target2_sid + 2]};
       body_point(s, M.site_bodyid[K.target1_sid], l1, t1);
       body_point(s, M.site_bodyid[K.target2_sid], l2, t2);
-      s.obs[nh + i] = p1[i];
-      s.obs[nh + 3 + i] = s.qvel[M.nv - 12 + i] * dt;
-      s.obs[nh + 6 + i] = p2[i];
-      s.obs[nh + 9 + i] = s.qvel[M.nv - 6 + i] * dt;
-      s.obs[nh + 12 + i] = t1[i];
-      s.obs[nh + 15 + i] = t2[i];
-      s.obs[nh + 18 + i] = t1[i] - p1[i];
-      s.obs[nh + 21 + i] = t2[i] - p2[i];
+      S_OBS(s)[nh + i] = p1[i];
+      S_OBS(s)[nh + 3 + i] = s.qvel[M.nv - 12 + i] * dt;
+      S_OBS(s)[nh + 6 + i] = p2[i];
+      S_OBS(s)[nh + 9 + i] = s.qvel[M.nv - 6 + i] * dt;
+      S_OBS(s)[nh + 12 + i] = t1[i];
+      S_OBS(s)[nh + 15 + i] = t2[i];
+      S_OBS(s)[nh + 18 + i] = t1[i] - p1[i];
+      S_OBS(s)[nh + 21 + i] = t2[i] - p2[i];
     }
-    if (i < M.na) s.obs[nh + 24 + i] = s.act[i];
+    if (i < M.na) S_OBS(s)[nh + 24 + i] = s.act[i];
   }
   SYNC();
   WAVE_SUM_N(T, asq, M.na, i, (s.act[i] * s.act[i]));
   PHASE {
     if (lane == 0) {
-      const T* e1 = s.obs + nh + 18; const T* e2 = s.obs + nh + 21;
+      const T* e1 = S_OBS(s) + nh + 18; const T* e2 = S_OBS(s) + nh + 21;
       const T d1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), d2 = sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
       const T am = M.na ? sqrt(asq) / (T)M.na : (T)0;
-      const int fall = (s.obs[nh + 2] < (T)K.drop_th) || (s.obs[nh + 8] < (T)K.drop_th);
+      const int fall = (S_OBS(s)[nh + 2] < (T)K.drop_th) || (S_OBS(s)[nh + 8] < (T)K.drop_th);
       T c[7];
       c[0] = -d1; c[1] = -d2; c[2] = -am; c[3] = fall ? (T)0 : (T)1; c[4] = -(d1 + d2);
       c[5] = ((d1 < (T)K.proximity_th) && (d2 < (T)K.proximity_th) && !fall) ? (T)1 : (T)0;
@@ -157,7 +157,7 @@ DEV void set_init_state(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, i
   SYNC();
 }
 
-// ---- reset(): returns with the post-reset state in scratch and the reset observation in s.obs
+// ---- reset(): returns with the post-reset state in scratch and the reset observation in S_OBS(s)
 template <typename T>
 DEV void baoding_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int env) {
   WAVE_FN
@@ -236,7 +236,7 @@ DEV void baoding_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, in
     baoding_step_core(M, K, s, (const float*)0);
     T bx[4];
     const int nh = K.n_hand;
-    bx[0] = s.obs[nh + 12]; bx[1] = s.obs[nh + 13]; bx[2] = s.obs[nh + 15]; bx[3] = s.obs[nh + 16];
+    bx[0] = S_OBS(s)[nh + 12]; bx[1] = S_OBS(s)[nh + 13]; bx[2] = S_OBS(s)[nh + 15]; bx[3] = S_OBS(s)[nh + 16];
     SYNC();
     set_init_state(M, K, s, 1);
     PHASE {
@@ -372,7 +372,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
       if (ep_info) { ep_info[2 * env] = (float)s.ep_ret; ep_info[2 * env + 1] = (float)s.ep_len; }
     }
     if (comps && lane < 8) comps[(size_t)env * 8 + lane] = (float)s.rwd[lane];
-    if (term_obs) for (int i = lane; i < nobs; i += 64) term_obs[(size_t)env * nobs + i] = (float)s.obs[i];
+    if (term_obs) for (int i = lane; i < nobs; i += 64) term_obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
   }
   SYNC();
   if (is_done) {
@@ -380,7 +380,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
     SYNC();
     baoding_reset(M, K, s, env);
   }
-  PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)s.obs[i]; }
+  PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i]; }
   SYNC();
   store_env(M, L, rec, s);
 }
@@ -395,7 +395,7 @@ DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout
   PHASE { if (lane == 0) s.episode++; }
   SYNC();
   baoding_reset(M, K, s, env);
-  if (obs) { PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)s.obs[i]; } SYNC(); }
+  if (obs) { PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i]; } SYNC(); }
   store_env(M, L, rec, s);
 }
 

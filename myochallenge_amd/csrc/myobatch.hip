@@ -261,7 +261,7 @@ struct myo_batch {
   std::vector<void*> allocs;   // every device allocation (model arrays, records)
   DevModel<double> Md;
   DevModel<float> Mf;
-  int nq, nv, nu, na, nbody, nsite, ntendon;
+  int nq, nv, nu, na, nbody, nsite, ntendon, integrator;
   int timing;
   double ms_sum;
   int ms_cnt;
@@ -360,6 +360,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   if (rc) return fail(MYO_E_DEVICE, "hipSetDevice(%d): %s", device, be_errstr(rc));
   myo_batch* b = new myo_batch();
   b->n = n_envs; b->device = device; b->dtype = dtype; b->timing = 0; b->ms_sum = 0; b->ms_cnt = 0;
+  b->integrator = m->integrator;
   b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon;
   if (cfg) b->cfg = *cfg; else memset(&b->cfg, 0, sizeof b->cfg);
   make_taskdev(cfg && cfg->kind != MYO_TASK_NONE ? cfg : nullptr, seed, b->K);
@@ -432,7 +433,9 @@ extern "C" int myo_batch_num_envs(const myo_batch* b) { return b ? b->n : -1; }
 extern "C" int myo_batch_obs_dim(const myo_batch* b) { return b ? b->nobs : -1; }
 extern "C" int myo_batch_lds_bytes(const myo_batch* b) {
   if (!b) return -1;
-  return b->dtype == MYO_F64 ? (int)sizeof(Scratch<double>) : (int)sizeof(Scratch<float>);
+  const int rk = b->integrator == 1;
+  return b->dtype == MYO_F64 ? (int)(sizeof(Scratch<double>) + rk * sizeof(RkScratch<double>))
+                             : (int)(sizeof(Scratch<float>) + rk * sizeof(RkScratch<float>));
 }
 extern "C" int myo_batch_dump_size(const myo_batch* b) { return b ? b->D.total : -1; }
 extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
@@ -456,11 +459,12 @@ extern "C" int myo_debug_read_prof(double* out16, int reset) {
   return 0;
 }
 #endif
-template <typename T>
-__global__ void __launch_bounds__(64) k_step(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const float* act,
+template <typename T, bool RK>
+__global__ void __launch_bounds__(64, 2) k_step(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const float* act,
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info) {
   __shared__ Scratch<T> s;
+  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
   const int env = blockIdx.x;
 #ifdef MYO_PROF
   if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
@@ -473,24 +477,27 @@ __global__ void __launch_bounds__(64) k_step(DevModel<T> M, TaskDev K, EnvRecord
   if (threadIdx.x < 16) atomicAdd(&g_prof[threadIdx.x], s.prof[threadIdx.x]);
 #endif
 }
-template <typename T>
-__global__ void __launch_bounds__(64) k_reset(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
+template <typename T, bool RK>
+__global__ void __launch_bounds__(64, 2) k_reset(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
                                               const unsigned char* mask, float* obs) {
   __shared__ Scratch<T> s;
+  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
   const int env = blockIdx.x;
   env_reset<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, obs);
 }
-template <typename T>
-__global__ void __launch_bounds__(64) k_physics(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
+template <typename T, bool RK>
+__global__ void __launch_bounds__(64, 2) k_physics(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
                                                 const double* ctrl, int nsub) {
   __shared__ Scratch<T> s;
+  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
   const int env = blockIdx.x;
   env_physics<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, nsub);
 }
-template <typename T>
-__global__ void __launch_bounds__(64) k_dump(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const double* ctrl,
+template <typename T, bool RK>
+__global__ void __launch_bounds__(64, 2) k_dump(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const double* ctrl,
                                              DumpLayout D, double* out) {
   __shared__ Scratch<T> s;
+  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
   const int env = blockIdx.x;
   env_forward_dump<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, D, out);
 }
@@ -597,8 +604,11 @@ extern "C" int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d,
 }
 
 #ifdef MYO_EMU
-#define FOR_ENVS_F64(call) { Scratch<double>* s = new Scratch<double>(); memset(s, 0, sizeof *s); for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; }
-#define FOR_ENVS_F32(call) { Scratch<float>* s = new Scratch<float>(); memset(s, 0, sizeof *s); for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; }
+#define FOR_ENVS_F64(call) { Scratch<double>* s = new Scratch<double>(); memset(s, 0, sizeof *s); RkScratch<double>* rk = new RkScratch<double>(); s->rk = rk; for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; delete rk; }
+#define FOR_ENVS_F32(call) { Scratch<float>* s = new Scratch<float>(); memset(s, 0, sizeof *s); RkScratch<float>* rk = new RkScratch<float>(); s->rk = rk; for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; delete rk; }
+#else
+// the RK4 stage storage is only allocated (LDS) by the kernel variants of RK4 models
+#define LAUNCH_RK(b, ...) if ((b)->integrator == 1) { constexpr bool RKV = true; __VA_ARGS__; } else { constexpr bool RKV = false; __VA_ARGS__; }
 #endif
 
 extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, void* stream) {
@@ -610,8 +620,9 @@ extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, vo
   else FOR_ENVS_F32(env_reset<float>(b->Mf, b->K, b->L, rec, *s, env, mask, obs))
 #else
   hipStream_t st = (hipStream_t)stream;
-  if (b->dtype == MYO_F64) hipLaunchKernelGGL(k_reset<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, mask, obs);
-  else hipLaunchKernelGGL(k_reset<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, mask, obs);
+  LAUNCH_RK(b,
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, mask, obs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<float, RKV>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, mask, obs))
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;
@@ -628,10 +639,11 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
 #else
   hipStream_t st = (hipStream_t)stream;
   timing_begin(b, st);
-  if (b->dtype == MYO_F64)
-    hipLaunchKernelGGL(k_step<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
-  else
-    hipLaunchKernelGGL(k_step<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+  LAUNCH_RK(b,
+    if (b->dtype == MYO_F64)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info))
   timing_end(b, st);
   LAUNCH_CHECK(b)
 #endif
@@ -647,8 +659,9 @@ extern "C" int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub
 #else
   hipStream_t st = (hipStream_t)stream;
   timing_begin(b, st);
-  if (b->dtype == MYO_F64) hipLaunchKernelGGL(k_physics<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, nsub);
-  else hipLaunchKernelGGL(k_physics<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, nsub);
+  LAUNCH_RK(b,
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<double, RKV>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, nsub);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<float, RKV>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, nsub))
   timing_end(b, st);
   LAUNCH_CHECK(b)
 #endif
@@ -663,8 +676,8 @@ extern "C" int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* 
   else FOR_ENVS_F32(env_forward_dump<float>(b->Mf, b->K, b->L, rec, *s, env, ctrl, b->D, out))
 #else
   hipStream_t st = (hipStream_t)stream;
-  if (b->dtype == MYO_F64) hipLaunchKernelGGL(k_dump<double>, dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, b->D, out);
-  else hipLaunchKernelGGL(k_dump<float>, dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, b->D, out);
+  if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<double, false>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, b->D, out);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<float, false>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, b->D, out);
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;

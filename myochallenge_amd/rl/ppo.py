@@ -38,6 +38,7 @@ class PPOConfig:
     normalize_advantage: bool = True
     bf16: bool = True               # autocast the policy GEMMs to bf16 (fp32 master weights)
     sync_adv_moments: bool = False  # all-reduce advantage moments (exact single-process semantics)
+    use_graphs: bool = True         # capture one optimizer step in a hipGraph (MLP policy, GPU only)
 
 
 def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
@@ -62,7 +63,10 @@ class PPO:
         self.env, self.policy, self.cfg = env, policy, cfg
         self.device = env.device
         self.policy.to(self.device)
-        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5)
+        on_gpu = self.device.type == "cuda"
+        self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
+                                          capturable=on_gpu, foreach=True if on_gpu else None)
+        self._graph = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         N, T, O, A = env.num_envs, cfg.n_steps, env.obs_dim, env.act_dim
@@ -158,7 +162,9 @@ class PPO:
         adv, ret = compute_gae(self.rew_buf, self.val_buf, self.start_buf, self._last_values,
                                self._last_starts, cfg.gamma, cfg.gae_lambda)
         stats = {}
-        if not pol.recurrent:
+        if not pol.recurrent and cfg.use_graphs and self.device.type == "cuda":
+            pl, vl = self._train_graphed(adv, ret)
+        elif not pol.recurrent:
             B = T * N
             obs, act = self.obs_buf.view(B, -1), self.act_buf.view(B, -1)
             oldlp, advf, retf = self.logp_buf.view(B), adv.view(B), ret.view(B)
@@ -197,6 +203,78 @@ class PPO:
                     self.n_updates += 1
         stats.update(policy_loss=float(pl), value_loss=float(vl), n_updates=self.n_updates)
         return stats
+
+    # ---------------------------------------------------------------- hipGraph-captured minibatch step
+    def _mb_forward_backward(self):
+        g = self._gs
+        idx = g["idx"]
+        with self._autocast():
+            v, lp, ent = self.policy.evaluate_actions(g["obs"][idx], g["act"][idx])
+        loss, pl, vl = self._loss(v, lp, ent, g["oldlp"][idx], g["adv"][idx], g["ret"][idx])
+        for p in self.policy.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        loss.backward()
+        g["pl"].copy_(pl); g["vl"].copy_(vl)
+        if self.world > 1:
+            off = 0
+            for p in self.policy.parameters():
+                n = p.numel()
+                self._flat_grad[off:off + n].copy_(p.grad.reshape(-1))
+                off += n
+
+    def _mb_apply(self):
+        if self.world > 1:
+            off = 0
+            for p in self.policy.parameters():
+                n = p.numel()
+                p.grad.copy_((self._flat_grad[off:off + n] / self.world).view_as(p))
+                off += n
+        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.cfg.max_grad_norm, foreach=True)
+        self.optimizer.step()
+
+    def _build_graphs(self, B, bs):
+        d = self.device
+        self._gs = {"idx": torch.zeros(bs, dtype=torch.long, device=d),
+                    "obs": self.obs_buf.view(B, -1), "act": self.act_buf.view(B, -1), "oldlp": self.logp_buf.view(B),
+                    "adv": torch.zeros(B, device=d), "ret": torch.zeros(B, device=d),
+                    "pl": torch.zeros((), device=d), "vl": torch.zeros((), device=d)}
+        self._gs["idx"].copy_(torch.arange(bs, device=d))
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side):       # eager warm-up: creates .grad tensors and Adam state
+            for _ in range(2):
+                self._mb_forward_backward()
+                if self.world > 1:
+                    dist.all_reduce(self._flat_grad)
+                self._mb_apply()
+        torch.cuda.current_stream(d).wait_stream(side)
+        torch.cuda.synchronize(d)
+        self._graph_fb, self._graph_ap = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_fb):
+            self._mb_forward_backward()
+        with torch.cuda.graph(self._graph_ap, pool=self._graph_fb.pool()):
+            self._mb_apply()
+        self._graph = (B, bs)
+
+    def _train_graphed(self, adv, ret):
+        cfg = self.cfg
+        B = cfg.n_steps * self.env.num_envs
+        bs = min(cfg.batch_size, B)
+        if self._graph != (B, bs):
+            self._build_graphs(B, bs)
+        g = self._gs
+        g["adv"].copy_(adv.view(B)); g["ret"].copy_(ret.view(B))
+        for _ in range(cfg.n_epochs):
+            perm = torch.randperm(B, generator=self.gen).to(self.device, non_blocking=True)
+            for s in range(0, B - bs + 1, bs):
+                g["idx"].copy_(perm[s:s + bs])
+                self._graph_fb.replay()
+                if self.world > 1:
+                    dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+                self._graph_ap.replay()
+                self.n_updates += 1
+        return g["pl"], g["vl"]
 
     def learn(self, total_timesteps: int, callback: Optional[Callable[["PPO"], None]] = None, log=None):
         t_start = time.time()

@@ -44,7 +44,7 @@
 template <typename T>
 struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead;
   T timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) const int* n;
   MYO_MODEL_INT_ARRAYS(X)

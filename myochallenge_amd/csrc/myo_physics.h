@@ -684,9 +684,8 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 // `OPAQUE(lane)` re-materialises the lane id so that clang does not hoist the 100+ loop-invariant
 // lane-compare masks into SGPR pairs (it then spills them through v_writelane).
 #define MYO_OPAQUE_LANE(v) int v = (int)threadIdx.x; asm volatile("" : "+v"(v));
-template <typename T>
+template <typename T, int N>
 __device__ __noinline__ void chol_factor_solve_reg(Scratch<T>& s, T* x, int n) {
-  constexpr int N = MYO_NV_MAX;
   const int lane = threadIdx.x;
   T a[N];
   const int rbase = lane * (lane + 1) / 2;
@@ -752,13 +751,24 @@ __device__ __noinline__ void chol_factor_solve_reg(Scratch<T>& s, T* x, int n) {
 }
 #endif
 
+// `lead` = number of leading dofs that are coupled; dofs >= lead have a diagonal-only row in the
+// matrix at hand (free bodies whose inertial frame is the body frame: the two balls), so their
+// solve is a division.  M-only solves and contact-free Newton steps use the 24-wide variant.
+#define MYO_CHOL_SMALL 24
 template <typename T>
-DEV void chol_factor_solve(Scratch<T>& s, T* x, int n) {
+DEV void chol_factor_solve(Scratch<T>& s, T* x, int n, int lead) {
 #ifdef MYO_EMU
+  (void)lead;
   chol_factor(s, n);
   chol_solve(s, x, n);
 #else
-  chol_factor_solve_reg<T>(s, x, n);
+  if (lead < n && lead <= MYO_CHOL_SMALL) {
+    const int lane = threadIdx.x;
+    if (lane >= lead && lane < n) x[lane] = x[lane] / s.H[MYO_HIDX(lane, lane)];
+    chol_factor_solve_reg<T, MYO_CHOL_SMALL>(s, x, lead);
+  } else {
+    chol_factor_solve_reg<T, MYO_NV_MAX>(s, x, n);
+  }
 #endif
 }
 
@@ -1529,7 +1539,7 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
     PROF(s, 9)
     PHASE { const int c = lane; if (c < nv) s.search[c] = -s.grad[c]; }
     SYNC();
-    chol_factor_solve(s, s.search, nv);
+    chol_factor_solve(s, s.search, nv, (s.ncon == 0 && s.ntl == 0) ? M.nlead : nv);
     PROF(s, 10)
     mul_M(M, s, s.Mv, s.search);
     body_vectors(M, s, s.search, s.bvec);
@@ -1588,7 +1598,7 @@ DEV void fwd_acceleration(const DevModel<T>& M, Scratch<T>& s) {
   load_H_from_M(M, s, (const T*)0, (T)0);
   PHASE { const int c = lane; if (c < M.nv) s.qacc_smooth[c] = s.qfrc_smooth[c]; }
   SYNC();
-  chol_factor_solve(s, s.qacc_smooth, M.nv);
+  chol_factor_solve(s, s.qacc_smooth, M.nv, M.nlead);
   PROF(s, 8)
   if (s.nefc == 0) {
     PHASE {
@@ -1734,7 +1744,7 @@ DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
     load_H_from_M(M, s, M.dof_damping, M.timestep);
     PHASE { const int c = lane; if (c < M.nv) s.tmpv[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }
     SYNC();
-    chol_factor_solve(s, s.tmpv, M.nv);
+    chol_factor_solve(s, s.tmpv, M.nv, M.nlead);
     PROF(s, 12)
     advance(M, s, s.act_dot, s.tmpv, (const T*)0);
     PROF(s, 13)

@@ -55,7 +55,7 @@ extern "C" const char* myo_version(void) {
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
   MYO_MODEL_INT_ARRAYS(X)
@@ -232,6 +232,19 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   for (int b = 0; b < nb; ++b) quat2mat_h(&body_iquat[4 * b], &m->body_imat[9 * b]);
   m->geom_mat.resize(9 * (size_t)m->ngeom);
   for (int g = 0; g < m->ngeom; ++g) quat2mat_h(&geom_quat[4 * g], &m->geom_mat[9 * g]);
+  // trailing dofs whose row of M is diagonal by construction: a free joint on a leaf body whose
+  // inertial frame coincides with the body frame (M = diag(m,m,m,Ixx,Iyy,Izz)); nlead = first of them
+  m->nlead = nv;
+  for (int j = m->njnt - 1; j >= 0; --j) {
+    const int b = m->jnt_bodyid[j];
+    bool leaf = true;
+    for (int o = 1; o < nb; ++o) if (m->body_parentid[o] == b) leaf = false;
+    const double* iq = &body_iquat[4 * b]; const double* ip = &m->body_ipos[3 * b];
+    const bool aligned = fabs(fabs(iq[0]) - 1.0) < 1e-12 && fabs(ip[0]) + fabs(ip[1]) + fabs(ip[2]) < 1e-14;
+    if (m->jnt_type[j] == MYO_JNT_FREE && leaf && aligned && m->body_jntnum[b] == 1 && m->jnt_dofadr[j] + 6 == m->nlead)
+      m->nlead = m->jnt_dofadr[j];
+    else break;
+  }
   m->any_damping = 0;
   for (int d = 0; d < nv; ++d) if (m->dof_damping[d] > 0) m->any_damping = 1;
   m->any_tendon_passive = 0;
@@ -276,8 +289,11 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nq = m->nq; D.nv = m->nv; D.nu = m->nu; D.na = m->na; D.nbody = m->nbody; D.njnt = m->njnt; D.ngeom = m->ngeom;
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
-  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive;
+  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
+  // fp32 stepper: the scaled cost/gradient tests of the Newton solver cannot resolve below ~1e-6
+  // (24-bit mantissa); with the model's 1e-8 it would spend an extra iteration on rounding noise.
+  if (sizeof(T) == 4 && D.tolerance < (T)1e-6) D.tolerance = (T)1e-6;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];
   D.meaninertia = (T)m->meaninertia;
   int rc = 0;

@@ -59,11 +59,55 @@ static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #define SYNC() __syncthreads()
 #define LANE_VAR(T, name) T name
 #define LV(name) name
-template <typename T>
-__device__ __forceinline__ T myo_wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+// Wave-wide sum in ~11 VALU instructions: DPP butterflies inside each 16-lane row
+// (quad_perm xor1, xor2, row_half_mirror, row_mirror), then the four row totals are read with
+// v_readlane and added as scalars.  (A __shfl_xor chain lowers to 6 dependent ds_bpermute round
+// trips through the LDS crossbar, ~10x slower; the solver's line search does dozens per substep.)
+__device__ __forceinline__ float myo_dpp_f(float v, const int ctrl_sel) {
+  const int i = __float_as_int(v);
+  int r;
+  switch (ctrl_sel) {
+    case 0: r = __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: r = __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: r = __builtin_amdgcn_mov_dpp(i, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+    default: r = __builtin_amdgcn_mov_dpp(i, 0x140, 0xF, 0xF, true); break; // row_mirror
+  }
+  return __int_as_float(r);
+}
+__device__ __forceinline__ double myo_dpp_d(double v, const int ctrl_sel) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  switch (ctrl_sel) {
+    case 0: lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: lo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break;
+  }
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <typename T> __device__ __forceinline__ T myo_wave_sum(T v);
+template <> __device__ __forceinline__ float myo_wave_sum<float>(float v) {
+  v += myo_dpp_f(v, 0); v += myo_dpp_f(v, 1); v += myo_dpp_f(v, 2); v += myo_dpp_f(v, 3);
+  const int i = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(i, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(i, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(i, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(i, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+template <> __device__ __forceinline__ double myo_wave_sum<double>(double v) {
+  v += myo_dpp_d(v, 0); v += myo_dpp_d(v, 1); v += myo_dpp_d(v, 2); v += myo_dpp_d(v, 3);
+  const long long b = __double_as_longlong(v);
+  const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+  double r[4];
+  for (int k = 0; k < 4; ++k) {
+    const int l = __builtin_amdgcn_readlane(lo, 16 * k), h = __builtin_amdgcn_readlane(hi, 16 * k);
+    r[k] = __longlong_as_double(((long long)h << 32) | (unsigned int)l);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+template <> __device__ __forceinline__ int myo_wave_sum<int>(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);
+  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true); v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xF, 0xF, true);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 #define WAVE_SUM_N(T, out, n, i, expr)                       \
   T out;                                                     \

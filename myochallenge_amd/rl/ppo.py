@@ -206,15 +206,12 @@ class PPO:
 
     # ---------------------------------------------------------------- hipGraph-captured minibatch step
     def _mb_forward_backward(self):
-        g = self._gs
+        from .fused_mlp import ppo_mlp_step_grads
+        g, cfg = self._gs, self.cfg
         idx = g["idx"]
-        with self._autocast():
-            v, lp, ent = self.policy.evaluate_actions(g["obs"][idx], g["act"][idx])
-        loss, pl, vl = self._loss(v, lp, ent, g["oldlp"][idx], g["adv"][idx], g["ret"][idx])
-        for p in self.policy.parameters():
-            if p.grad is not None:
-                p.grad.zero_()
-        loss.backward()
+        pl, vl = ppo_mlp_step_grads(self.policy, g["obs"][idx], g["act"][idx], g["oldlp"][idx], g["adv"][idx],
+                                    g["ret"][idx], cfg.clip_range, cfg.ent_coef, cfg.vf_coef,
+                                    cfg.normalize_advantage, cfg.bf16)
         g["pl"].copy_(pl); g["vl"].copy_(vl)
         if self.world > 1:
             off = 0

@@ -144,3 +144,29 @@ def test_two_rank_data_parallel_keeps_replicas_identical(emu_lib):
     torch.manual_seed(0)
     init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (16,), (16,)).parameters()]).numpy()
     assert not np.array_equal(out[0], init)
+
+
+def test_fused_mlp_gradients_match_autograd():
+    """rl/fused_mlp.py (hand-derived backward used inside the captured hipGraph) == autograd."""
+    from myochallenge_amd.rl.fused_mlp import ppo_mlp_step_grads
+    torch.manual_seed(0)
+    pol = ActorCriticPolicy(86, 39, (64, 48), (32, 32), lstm_hidden_size=None)
+    B = 96
+    obs, act = torch.randn(B, 86), torch.randn(B, 39) * 0.3
+    with torch.no_grad():
+        oldlp = pol.evaluate_actions(obs, act)[1] + torch.randn(B) * 0.3   # ratios on both sides of the clip
+    adv, ret = torch.randn(B), torch.randn(B)
+
+    class E:  # minimal env stub for PPO()
+        num_envs, obs_dim, act_dim, device = 4, 86, 39, torch.device("cpu")
+    algo = PPO(E(), pol, PPOConfig(n_steps=2, clip_range=0.2, ent_coef=0.01, vf_coef=0.7, bf16=False))
+    v, lp, ent = pol.evaluate_actions(obs, act)
+    loss, pl_ref, vl_ref = algo._loss(v, lp, ent, oldlp, adv, ret)
+    pol.zero_grad(); loss.backward()
+    ref = [p.grad.clone() for p in pol.parameters()]
+    for p in pol.parameters():
+        p.grad = None
+    pl, vl = ppo_mlp_step_grads(pol, obs, act, oldlp, adv, ret, 0.2, 0.01, 0.7, True, bf16=False, split_k=4)
+    assert abs(float(pl - pl_ref)) < 1e-5 and abs(float(vl - vl_ref)) < 1e-5
+    for p, r in zip(pol.parameters(), ref):
+        np.testing.assert_allclose(p.grad.numpy(), r.numpy(), rtol=2e-4, atol=5e-5)   # fp32 summation order

@@ -113,6 +113,42 @@ struct Scratch {
 #define S_CFRCB(s) ((s).bvec)
 static_assert(MYO_NB_MAX * 10 + MYO_NV_MAX * 6 + MYO_OBS_MAX <= MYO_NV_MAX * (MYO_NV_MAX + 1) / 2, "H aliases");
 static_assert(MYO_NB_MAX * 4 <= MYO_NEFC_MAX && MYO_NJ_MAX * 3 <= MYO_NEFC_MAX, "efc aliases");
+// ---- phase functions are real (non-inlined) functions in the gfx950 build: each gets its own
+// register allocation (the fully inlined kernel spilled ~170 VGPRs and was several MB of code).
+// They do not receive the model / task / scratch through arguments: the model and task live in
+// __constant__ memory (scalar loads), the scratch is THE dynamic LDS block of the workgroup, so
+// every access keeps its address space (ds_* / s_load_*).  LDS vectors are passed as byte offsets.
+#ifdef MYO_EMU
+#define DEVFN static inline
+#define MYO_BIND_M(T) const DevModel<T>& M = M_in;
+#define MYO_BIND_K const TaskDev& K = K_in;
+#define MYO_BIND_S(T) auto& s = s_in;
+#define LREF(T) T*
+#define LCREF(T) const T*
+#define LOFF(s, p) (p)
+#define LPTR(T, r) (r)
+#define LNULL(T) ((T*)0)
+#define LISNULL(r) ((r) == 0)
+#else
+#define DEVFN __device__ __noinline__
+extern __shared__ __align__(16) unsigned char myo_lds[];
+__constant__ DevModel<float> c_model_f;
+__constant__ DevModel<double> c_model_d;
+__constant__ TaskDev c_task;
+template <typename T> __device__ __forceinline__ const DevModel<T>& myo_cmodel();
+template <> __device__ __forceinline__ const DevModel<float>& myo_cmodel<float>() { return c_model_f; }
+template <> __device__ __forceinline__ const DevModel<double>& myo_cmodel<double>() { return c_model_d; }
+#define MYO_BIND_M(T) const DevModel<T>& M = myo_cmodel<T>(); (void)M_in;
+#define MYO_BIND_K const TaskDev& K = c_task; (void)K_in;
+#define MYO_BIND_S(T) Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds); (void)s_in;
+#define LREF(T) int
+#define LCREF(T) int
+#define LOFF(s, p) ((int)((const char*)(p) - (const char*)&(s)))
+#define LPTR(T, r) (reinterpret_cast<T*>(myo_lds + (r)))
+#define LNULL(T) (-1)
+#define LISNULL(r) ((r) < 0)
+#endif
+
 template <typename T> DEV T row_D(const Scratch<T>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
 
 // ------------------------------------------------------------------------------------------
@@ -220,7 +256,8 @@ template <typename T> DEV void jac_col(const DevModel<T>& M, const Scratch<T>& s
 // ------------------------------------------------------------------------------------------
 // P2: kinematics (mj_kinematics)
 template <typename T>
-DEV void kinematics(const DevModel<T>& M, Scratch<T>& s) {
+DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     if (lane == 0) {
@@ -285,7 +322,8 @@ DEV void kinematics(const DevModel<T>& M, Scratch<T>& s) {
 
 // P2: mj_comPos — tree reference points, body inertias about them, dof motion axes
 template <typename T>
-DEV void com_pos(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     const int b = lane;
@@ -476,7 +514,8 @@ DEV void tendon_segment_moment(const DevModel<T>& M, const Scratch<T>& s, T* Jro
 }
 
 template <typename T>
-DEV void tendon(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     const int t = lane;
@@ -549,7 +588,8 @@ DEV void tendon(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
 // ------------------------------------------------------------------------------------------
 // P5: composite rigid body inertia -> tree-sparse M (mj_crb)
 template <typename T>
-DEV void crb(const DevModel<T>& M, Scratch<T>& s) {
+DEVFN void crb(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     const int b = lane;
@@ -582,7 +622,9 @@ DEV void crb(const DevModel<T>& M, Scratch<T>& s) {
 
 // out = M * v   (lanes = dofs; static CSR pattern of the symmetric tree-sparse matrix)
 template <typename T>
-DEV void mul_M(const DevModel<T>& M, const Scratch<T>& s, T* out, const T* v) {
+DEVFN void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r, LCREF(T) v_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  T* out = LPTR(T, out_r); const T* v = LPTR(const T, v_r);
   WAVE_FN
   PHASE {
     const int i = lane;
@@ -597,7 +639,8 @@ DEV void mul_M(const DevModel<T>& M, const Scratch<T>& s, T* out, const T* v) {
 
 // packed dense H <- M (+ diag)
 template <typename T>
-DEV void load_H_from_M(const DevModel<T>& M, Scratch<T>& s, const T* diag_add, T diag_scale) {
+DEVFN void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* diag_add, T diag_scale) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   const int nh = M.nv * (M.nv + 1) / 2;
   PHASE { for (int k = lane; k < nh; k += 64) s.H[k] = 0; }
@@ -685,7 +728,9 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
 // lane-compare masks into SGPR pairs (it then spills them through v_writelane).
 #define MYO_OPAQUE_LANE(v) int v = (int)threadIdx.x; asm volatile("" : "+v"(v));
 template <typename T, int N>
-__device__ __noinline__ void chol_factor_solve_reg(Scratch<T>& s, T* x, int n) {
+__device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
+  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  T* x = LPTR(T, x_r);
   const int lane = threadIdx.x;
   T a[N];
   const int rbase = lane * (lane + 1) / 2;
@@ -765,9 +810,9 @@ DEV void chol_factor_solve(Scratch<T>& s, T* x, int n, int lead) {
   if (lead < n && lead <= MYO_CHOL_SMALL) {
     const int lane = threadIdx.x;
     if (lane >= lead && lane < n) x[lane] = x[lane] / s.H[MYO_HIDX(lane, lane)];
-    chol_factor_solve_reg<T, MYO_CHOL_SMALL>(s, x, lead);
+    chol_factor_solve_reg<T, MYO_CHOL_SMALL>(LOFF(s, x), lead);
   } else {
-    chol_factor_solve_reg<T, MYO_NV_MAX>(s, x, n);
+    chol_factor_solve_reg<T, MYO_NV_MAX>(LOFF(s, x), n);
   }
 #endif
 }
@@ -919,7 +964,8 @@ DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos
 }
 
 template <typename T>
-DEV void collision_and_constraints(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   // ---- limit rows: joints (lanes = joints), then tendons (lanes = tendons)
   LANE_VAR(int, cnt);
@@ -1098,7 +1144,9 @@ DEV void collision_and_constraints(const DevModel<T>& M, const TaskDev& K, Scrat
 // matrix-free constraint Jacobian products
 // body spatial vectors V_b(v) = sum_{d in ancestors(b)} cdof_d v_d   (lanes = bodies)
 template <typename T>
-DEV void body_vectors(const DevModel<T>& M, const Scratch<T>& s, const T* v, T* out) {
+DEVFN void body_vectors(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LREF(T) out_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* v = LPTR(const T, v_r); T* out = LPTR(T, out_r);
   WAVE_FN
   PHASE {
     const int b = lane;
@@ -1133,7 +1181,9 @@ template <typename T> DEV void con_col(const Scratch<T>& s, int d, const T* off,
 
 // out[r] = (J v)[r] for every constraint row; bv = body vectors of v (already computed)
 template <typename T>
-DEV void J_times(const DevModel<T>& M, const Scratch<T>& s, const T* v, const T* bv, T* out) {
+DEVFN void J_times(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* v = LPTR(const T, v_r); const T* bv = LPTR(const T, bv_r); T* out = LPTR(T, out_r);
   WAVE_FN
   const int nl = s.nl, nlim = s.nl + s.ntl, nefc = s.nefc;
   PHASE {
@@ -1165,7 +1215,9 @@ DEV void J_times(const DevModel<T>& M, const Scratch<T>& s, const T* v, const T*
 
 // out = J' f  (lanes = dofs; contacts act as a world force at the contact point)
 template <typename T>
-DEV void JT_times(const DevModel<T>& M, Scratch<T>& s, const T* f, T* out) {
+DEVFN void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LREF(T) out_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* f = LPTR(const T, f_r); T* out = LPTR(T, out_r);
   WAVE_FN
   const int nl = s.nl, nlim = s.nl + s.ntl, ncon = s.ncon;
   PHASE {
@@ -1207,9 +1259,10 @@ DEV void JT_times(const DevModel<T>& M, Scratch<T>& s, const T* f, T* out) {
 // ------------------------------------------------------------------------------------------
 // P8: velocity stage (mj_fwdVelocity): tendon/actuator velocity, comVel, passive, RNE bias, aref
 template <typename T>
-DEV void fwd_velocity(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
-  body_vectors(M, s, s.qvel, s.cvel);
+  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, s.cvel));
   PHASE {
     const int t = lane;
     if (t < M.ntendon) {
@@ -1301,7 +1354,7 @@ DEV void fwd_velocity(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
   SYNC();
   // reference acceleration of every constraint row: aref = -B vel - K imp (pos - margin)
   if (s.nefc > 0) {
-    J_times(M, s, s.qvel, s.cvel, s.efc_jv);
+    J_times(M, s, LOFF(s, s.qvel), LOFF(s, s.cvel), LOFF(s, s.efc_jv));
     PHASE {
       const int nlim_ = s.nl + s.ntl;
       for (int r = lane; r < s.nefc; r += 64) {
@@ -1329,7 +1382,8 @@ template <typename T> DEV T muscle_FL(T L, T lmin, T lmax) {
 }
 
 template <typename T>
-DEV void fwd_actuation(const DevModel<T>& M, Scratch<T>& s) {
+DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     const int i = lane;
@@ -1407,7 +1461,8 @@ DEV void fwd_actuation(const DevModel<T>& M, Scratch<T>& s) {
 // ------------------------------------------------------------------------------------------
 // P10: Newton solver on the primal problem (mj_solNewton)
 template <typename T>
-DEV T update_constraint(const DevModel<T>& M, Scratch<T>& s) {
+DEVFN T update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   // forces / active set from jar, cost, qfrc_constraint, gradient
   WAVE_FN
   const int nefc = s.nefc, nlim = s.nl + s.ntl;
@@ -1420,7 +1475,7 @@ DEV T update_constraint(const DevModel<T>& M, Scratch<T>& s) {
     }
   }
   SYNC();
-  JT_times(M, s, s.efc_force, s.qfrc_constraint);
+  JT_times(M, s, LOFF(s, s.efc_force), LOFF(s, s.qfrc_constraint));
   WAVE_SUM_N(T, ccost, nefc, r, (s.efc_active[r] ? (T)0.5 * row_D(s, r, nlim) * s.efc_jar[r] * s.efc_jar[r] : (T)0));
   WAVE_SUM_N(T, gcost, M.nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc[c] - s.qacc_smooth[c])));
   PHASE {
@@ -1432,7 +1487,8 @@ DEV T update_constraint(const DevModel<T>& M, Scratch<T>& s) {
 }
 
 template <typename T>
-DEV void build_hessian(const DevModel<T>& M, Scratch<T>& s) {
+DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   load_H_from_M(M, s, (const T*)0, (T)0);
   const int nl = s.nl, nlim = s.nl + s.ntl;
@@ -1506,15 +1562,16 @@ DEV void build_hessian(const DevModel<T>& M, Scratch<T>& s) {
 }
 
 template <typename T>
-DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
+DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   const int nv = M.nv, nefc = s.nefc;
   // ---- warm start: cheaper of qacc_warmstart and qacc_smooth
-  body_vectors(M, s, s.qacc_warm, s.bvec);
-  J_times(M, s, s.qacc_warm, s.bvec, s.efc_jar);
-  body_vectors(M, s, s.qacc_smooth, s.bvec);
-  J_times(M, s, s.qacc_smooth, s.bvec, s.efc_jv);
-  mul_M(M, s, s.Ma, s.qacc_warm);
+  body_vectors(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec));
+  J_times(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_jar));
+  body_vectors(M, s, LOFF(s, s.qacc_smooth), LOFF(s, s.bvec));
+  J_times(M, s, LOFF(s, s.qacc_smooth), LOFF(s, s.bvec), LOFF(s, s.efc_jv));
+  mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc_warm));
   const int nlim = s.nl + s.ntl;
   WAVE_SUM_N(T, costw_c, nefc, r, ((s.efc_jar[r] - s.efc_aref[r]) < 0 ? (T)0.5 * row_D(s, r, nlim) * (s.efc_jar[r] - s.efc_aref[r]) * (s.efc_jar[r] - s.efc_aref[r]) : (T)0));
   WAVE_SUM_N(T, costs, nefc, r, ((s.efc_jv[r] - s.efc_aref[r]) < 0 ? (T)0.5 * row_D(s, r, nlim) * (s.efc_jv[r] - s.efc_aref[r]) * (s.efc_jv[r] - s.efc_aref[r]) : (T)0));
@@ -1529,7 +1586,7 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
     for (int r = lane; r < nefc; r += 64) s.efc_jar[r] = (use_warm ? s.efc_jar[r] : s.efc_jv[r]) - s.efc_aref[r];
   }
   SYNC();
-  if (!use_warm) mul_M(M, s, s.Ma, s.qacc);  // keep Ma exactly consistent with M*qacc
+  if (!use_warm) mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc));  // keep Ma exactly consistent with M*qacc
   T cost = update_constraint(M, s);
   const T scale = 1 / (M.meaninertia * (T)(nv > 1 ? nv : 1));
   int iter = 0;
@@ -1541,9 +1598,9 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
     SYNC();
     chol_factor_solve(s, s.search, nv, (s.ncon == 0 && s.ntl == 0) ? M.nlead : nv);
     PROF(s, 10)
-    mul_M(M, s, s.Mv, s.search);
-    body_vectors(M, s, s.search, s.bvec);
-    J_times(M, s, s.search, s.bvec, s.efc_jv);
+    mul_M(M, s, LOFF(s, s.Mv), LOFF(s, s.search));
+    body_vectors(M, s, LOFF(s, s.search), LOFF(s, s.bvec));
+    J_times(M, s, LOFF(s, s.search), LOFF(s, s.bvec), LOFF(s, s.efc_jv));
     WAVE_SUM3_N(T, q1, q2, sn2, nv, c, { _e1 = s.search[c] * (s.Ma[c] - s.qfrc_smooth[c]); _e2 = (T)0.5 * s.search[c] * s.Mv[c]; _e3 = s.search[c] * s.search[c]; });
     const T snorm = sqrt(sn2);
 #ifdef MYO_EMU_DEBUG
@@ -1593,7 +1650,8 @@ DEV void newton_solve(const DevModel<T>& M, Scratch<T>& s) {
 }
 
 template <typename T>
-DEV void fwd_acceleration(const DevModel<T>& M, Scratch<T>& s) {
+DEVFN void fwd_acceleration(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   load_H_from_M(M, s, (const T*)0, (T)0);
   PHASE { const int c = lane; if (c < M.nv) s.qacc_smooth[c] = s.qfrc_smooth[c]; }
@@ -1613,7 +1671,8 @@ DEV void fwd_acceleration(const DevModel<T>& M, Scratch<T>& s) {
 }
 
 template <typename T>
-DEV void forward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+DEVFN void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   PROF(s, 15)
   kinematics(M, s);
   PROF(s, 1)
@@ -1635,7 +1694,9 @@ DEV void forward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
 // ------------------------------------------------------------------------------------------
 // P11: integrators
 template <typename T>
-DEV void integrate_pos(const DevModel<T>& M, Scratch<T>& s, const T* vel, T h) {
+DEVFN void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel_r, T h) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* vel = LPTR(const T, vel_r);
   WAVE_FN
   PHASE {
     const int j = lane;
@@ -1661,7 +1722,9 @@ DEV void integrate_pos(const DevModel<T>& M, Scratch<T>& s, const T* vel, T h) {
 }
 
 template <typename T>
-DEV void advance(const DevModel<T>& M, Scratch<T>& s, const T* act_dot, const T* qacc, const T* vel_for_pos) {
+DEVFN void advance(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) act_dot_r, LCREF(T) qacc_r, LCREF(T) vel_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* act_dot = LPTR(const T, act_dot_r); const T* qacc = LPTR(const T, qacc_r);
   WAVE_FN
   const T h = M.timestep;
   PHASE {
@@ -1675,11 +1738,12 @@ DEV void advance(const DevModel<T>& M, Scratch<T>& s, const T* act_dot, const T*
     if (lane == 0) s.time += h;
   }
   SYNC();
-  integrate_pos(M, s, vel_for_pos ? vel_for_pos : s.qvel, h);
+  integrate_pos(M, s, LISNULL(vel_r) ? LOFF(s, s.qvel) : vel_r, h);
 }
 
 template <typename T>
-DEV void check_state(const DevModel<T>& M, Scratch<T>& s, int check_acc) {
+DEVFN void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   WAVE_SUM_N(int, badq, M.nq, i, ((isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (T)1e10) ? 0 : 1));
   WAVE_SUM_N(int, badv, M.nv, i, ((isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (T)1e10) ? 0 : 1));
@@ -1692,7 +1756,8 @@ DEV void check_state(const DevModel<T>& M, Scratch<T>& s, int check_acc) {
 }
 
 template <typename T>
-DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+DEVFN void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   check_state(M, s, 0);
   forward(M, K, s);
@@ -1715,7 +1780,7 @@ DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
         for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       }
       SYNC();
-      integrate_pos(M, s, s.rk->dX, h);
+      integrate_pos(M, s, LOFF(s, s.rk->dX), h);
       PHASE {
         for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * s.rk->dX[nv + i];
         for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i] + h * s.rk->dX[2 * nv + i];
@@ -1738,7 +1803,7 @@ DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
       if (lane == 0) s.time = t0;
     }
     SYNC();
-    advance(M, s, s.rk->dX + 2 * nv, s.rk->dX + nv, s.rk->dX);
+    advance(M, s, LOFF(s, s.rk->dX + 2 * nv), LOFF(s, s.rk->dX + nv), LOFF(s, s.rk->dX));
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
     load_H_from_M(M, s, M.dof_damping, M.timestep);
@@ -1746,9 +1811,9 @@ DEV void mj_step(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
     SYNC();
     chol_factor_solve(s, s.tmpv, M.nv, M.nlead);
     PROF(s, 12)
-    advance(M, s, s.act_dot, s.tmpv, (const T*)0);
+    advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.tmpv), LNULL(const T));
     PROF(s, 13)
   } else {
-    advance(M, s, s.act_dot, s.qacc, (const T*)0);
+    advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.qacc), LNULL(const T));
   }
 }

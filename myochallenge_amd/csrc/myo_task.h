@@ -63,7 +63,8 @@ DEV double rng_beta(Philox& g, double a, double b) {
 
 // ---- observation (layout pinned by tests/golden/reset_obs_golden.npy) and reward
 template <typename T>
-DEV void baoding_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   const int nh = K.n_hand;
   const T dt = (T)K.frame_skip * M.timestep;
@@ -111,7 +112,8 @@ DEV void baoding_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& 
 
 // ---- env.step(a) without the VecEnv bookkeeping
 template <typename T>
-DEV void baoding_step_core(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, const float* action /* may be null = zeros */) {
+DEVFN void baoding_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, const float* action /* may be null = zeros */) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     if (lane == 0) {
@@ -142,7 +144,8 @@ DEV void baoding_step_core(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s
 }
 
 template <typename T>
-DEV void set_init_state(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int keep_dynamics) {
+DEVFN void set_init_state(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int keep_dynamics) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   // robot.reset(init_qpos, init_qvel): init_qpos[:-14]=0, init_qpos[0]=-1.57 (baoding.py:281-283)
   WAVE_FN
   PHASE {
@@ -159,7 +162,8 @@ DEV void set_init_state(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, i
 
 // ---- reset(): returns with the post-reset state in scratch and the reset observation in S_OBS(s)
 template <typename T>
-DEV void baoding_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int env) {
+DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int env) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   Philox g;
   g.key0 = (unsigned int)K.seed; g.key1 = (unsigned int)(K.seed >> 32);
@@ -297,7 +301,8 @@ DEV void baoding_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, in
 
 // ---- HBM record <-> scratch
 template <typename T>
-DEV void load_env(const DevModel<T>& M, const EnvRecordLayout& L, const double* rec, Scratch<T>& s) {
+DEVFN void load_env(const DevModel<T>& M_in, const EnvRecordLayout L, const double* rec, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (T)rec[L.off_qpos + i];
@@ -324,7 +329,8 @@ DEV void load_env(const DevModel<T>& M, const EnvRecordLayout& L, const double* 
 }
 
 template <typename T>
-DEV void store_env(const DevModel<T>& M, const EnvRecordLayout& L, double* rec, const Scratch<T>& s) {
+DEVFN void store_env(const DevModel<T>& M_in, const EnvRecordLayout L, double* rec, const Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     for (int i = lane; i < M.nq; i += 64) rec[L.off_qpos + i] = (double)s.qpos[i];

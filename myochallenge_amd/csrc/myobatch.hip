@@ -264,6 +264,8 @@ extern "C" int myo_model_size(const myo_model* m, const char* n) {
 }
 
 // ------------------------------------------------------------------------------------------ batch
+struct myo_batch;
+static const myo_batch* g_bound = nullptr;   // batch whose model/task currently sit in __constant__ memory
 struct myo_batch {
   int n, device, dtype, nobs;
   myo_task_cfg cfg;
@@ -438,6 +440,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
 extern "C" void myo_batch_destroy(myo_batch* b) {
   if (!b) return;
 #ifndef MYO_EMU
+  if (g_bound == b) g_bound = nullptr;
   (void)hipSetDevice(b->device);
   for (auto& pr : b->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
@@ -465,6 +468,7 @@ extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
 
 // ------------------------------------------------------------------------------------------ kernels
 #ifndef MYO_EMU
+#define MYO_LDS_ALIGN(n) (((n) + 15) / 16 * 16)
 #ifdef MYO_PROF
 __device__ unsigned long long g_prof[16];
 extern "C" int myo_debug_read_prof(double* out16, int reset) {
@@ -476,11 +480,13 @@ extern "C" int myo_debug_read_prof(double* out16, int reset) {
 }
 #endif
 template <typename T, bool RK>
-__global__ void __launch_bounds__(64, 2) k_step(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const float* act,
+__global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, const float* act,
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info) {
-  __shared__ Scratch<T> s;
-  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
+  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  const DevModel<T>& M = myo_cmodel<T>();
+  const TaskDev& K = c_task;
   const int env = blockIdx.x;
 #ifdef MYO_PROF
   if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
@@ -494,26 +500,32 @@ __global__ void __launch_bounds__(64, 2) k_step(DevModel<T> M, TaskDev K, EnvRec
 #endif
 }
 template <typename T, bool RK>
-__global__ void __launch_bounds__(64, 2) k_reset(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
+__global__ void __launch_bounds__(64, 2) k_reset(EnvRecordLayout L, double* rec,
                                               const unsigned char* mask, float* obs) {
-  __shared__ Scratch<T> s;
-  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
+  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  const DevModel<T>& M = myo_cmodel<T>();
+  const TaskDev& K = c_task;
   const int env = blockIdx.x;
   env_reset<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, obs);
 }
 template <typename T, bool RK>
-__global__ void __launch_bounds__(64, 2) k_physics(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec,
+__global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* rec,
                                                 const double* ctrl, int nsub) {
-  __shared__ Scratch<T> s;
-  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
+  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  const DevModel<T>& M = myo_cmodel<T>();
+  const TaskDev& K = c_task;
   const int env = blockIdx.x;
   env_physics<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, nsub);
 }
 template <typename T, bool RK>
-__global__ void __launch_bounds__(64, 2) k_dump(DevModel<T> M, TaskDev K, EnvRecordLayout L, double* rec, const double* ctrl,
+__global__ void __launch_bounds__(64, 2) k_dump(EnvRecordLayout L, double* rec, const double* ctrl,
                                              DumpLayout D, double* out) {
-  __shared__ Scratch<T> s;
-  if constexpr (RK) { __shared__ RkScratch<T> rk; s.rk = &rk; } else { s.rk = nullptr; }
+  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  const DevModel<T>& M = myo_cmodel<T>();
+  const TaskDev& K = c_task;
   const int env = blockIdx.x;
   env_forward_dump<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, D, out);
 }
@@ -546,6 +558,27 @@ static void timing_end(myo_batch* b, hipStream_t st) {
   if (!b->timing) return;
   (void)hipEventRecord(b->pending.back().second, st);
 }
+#endif
+
+#ifndef MYO_EMU
+// model / task parameters live in __constant__ memory (scalar loads in every phase function);
+// (re)bound on the launch stream whenever a different batch launches.
+static int bind_constants(myo_batch* b, hipStream_t st) {
+  if (g_bound == b) return 0;
+  hipError_t e;
+  if (b->dtype == MYO_F64) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_d), &b->Md, sizeof b->Md, 0, hipMemcpyHostToDevice, st);
+  else e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_f), &b->Mf, sizeof b->Mf, 0, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_task), &b->K, sizeof b->K, 0, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return fail(MYO_E_DEVICE, "binding model constants failed: %s", hipGetErrorString(e));
+  g_bound = b;
+  return 0;
+}
+static unsigned lds_dyn(const myo_batch* b) {
+  const int rk = b->integrator == 1;
+  if (b->dtype == MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<double>)) + rk * sizeof(RkScratch<double>));
+  return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + rk * sizeof(RkScratch<float>));
+}
+#define BIND_OR_RETURN(b, st) { int _rc = bind_constants(b, st); if (_rc) return _rc; }
 #endif
 
 static void xfer(myo_batch* b, int off, int cnt, double* ext, int to_ext, be_stream st) {
@@ -636,9 +669,10 @@ extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, vo
   else FOR_ENVS_F32(env_reset<float>(b->Mf, b->K, b->L, rec, *s, env, mask, obs))
 #else
   hipStream_t st = (hipStream_t)stream;
+  BIND_OR_RETURN(b, st)
   LAUNCH_RK(b,
-    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, mask, obs);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<float, RKV>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, mask, obs))
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs))
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;
@@ -654,12 +688,13 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
   else FOR_ENVS_F32(env_step<float>(b->Mf, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info))
 #else
   hipStream_t st = (hipStream_t)stream;
+  BIND_OR_RETURN(b, st)
   timing_begin(b, st);
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info))
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info))
   timing_end(b, st);
   LAUNCH_CHECK(b)
 #endif
@@ -674,10 +709,11 @@ extern "C" int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub
   else FOR_ENVS_F32(env_physics<float>(b->Mf, b->K, b->L, rec, *s, env, ctrl, nsub))
 #else
   hipStream_t st = (hipStream_t)stream;
+  BIND_OR_RETURN(b, st)
   timing_begin(b, st);
   LAUNCH_RK(b,
-    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<double, RKV>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, nsub);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<float, RKV>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, nsub))
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub))
   timing_end(b, st);
   LAUNCH_CHECK(b)
 #endif
@@ -692,8 +728,9 @@ extern "C" int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* 
   else FOR_ENVS_F32(env_forward_dump<float>(b->Mf, b->K, b->L, rec, *s, env, ctrl, b->D, out))
 #else
   hipStream_t st = (hipStream_t)stream;
-  if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<double, false>), dim3(b->n), dim3(64), 0, st, b->Md, b->K, b->L, b->rec, ctrl, b->D, out);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<float, false>), dim3(b->n), dim3(64), 0, st, b->Mf, b->K, b->L, b->rec, ctrl, b->D, out);
+  BIND_OR_RETURN(b, st)
+  if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<double, false>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<float, false>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out);
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;

@@ -130,6 +130,24 @@ int myo_batch_dump_offset(const myo_batch* b, const char* name);
 double myo_batch_kernel_ms(myo_batch* b);
 int myo_batch_enable_timing(myo_batch* b, int on);
 
+/* Elementwise part of one PPO minibatch step in a single launch (SB3 PPO.train loss terms; the
+ * reference runs them as separate torch ops inside sb3_contrib.RecurrentPPO.train,
+ * /root/reference/src/train/trainer.py:66-71).  All pointers dev float32: mean[B,A] values[B]
+ * actions[B,A] old_logp[B] adv[B] (raw) returns[B] log_std[A] adv_stats[2]={mean,std of adv}.
+ * Outputs: dmean[B,A], dvalue[B] = d loss/d(policy mean, value); acc[A+2] = {sum_i dlogp_i (z^2-1)
+ * per action dim (entropy term not included), policy loss, value loss}. */
+int myo_ppo_loss_grad(const float* mean, const float* values, const float* actions, const float* old_logp,
+                      const float* adv, const float* returns, const float* log_std, const float* adv_stats,
+                      int B, int A, float clip, float vf_coef, float* dmean, float* dvalue, float* acc,
+                      void* stream);
+
+/* GAE(gamma, lambda) backward scan = SB3 RolloutBuffer.compute_returns_and_advantage (run by
+ * RecurrentPPO.learn, /root/reference/src/train/trainer.py:66-71).  dev float32 [T,N] row-major:
+ * rew, val, starts (episode_starts), outputs adv, ret; last_val[N], last_done[N]. */
+int myo_gae(const float* rew, const float* val, const float* starts, const float* last_val,
+            const float* last_done, int T, int N, float gamma, float lam, float* adv, float* ret,
+            void* stream);
+
 const char* myo_last_error(void);
 const char* myo_version(void);
 

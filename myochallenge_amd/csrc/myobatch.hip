@@ -736,6 +736,124 @@ extern "C" int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* 
   return MYO_OK;
 }
 
+// ------------------------------------------------------------------------------------------ PPO loss
+// One launch for the whole elementwise part of a PPO minibatch step (SB3 PPO.train loss,
+// SURVEY.md C.5): diag-Gaussian log-prob, ratio, clipped surrogate, value MSE, and their
+// gradients w.r.t. the policy mean, the value and log_std.  One thread per sample; block
+// reduction + atomics into acc[A+2] = {d loss / d log_std[A] (without the entropy term), pl, vl}.
+#ifndef MYO_EMU
+__global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mean, const float* __restrict__ values,
+                                                  const float* __restrict__ actions, const float* __restrict__ old_logp,
+                                                  const float* __restrict__ adv, const float* __restrict__ returns,
+                                                  const float* __restrict__ log_std, const float* __restrict__ adv_stats,
+                                                  int B, int A, float clip, float vf_coef, float* __restrict__ dmean,
+                                                  float* __restrict__ dvalue, float* __restrict__ acc) {
+  __shared__ float red[66];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int k = threadIdx.x; k < A + 2; k += blockDim.x) red[k] = 0.f;
+  __syncthreads();
+  float pl_i = 0.f, vl_i = 0.f, dlogp = 0.f;
+  if (i < B) {
+    float logp = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float ls = log_std[a];
+      const float z = (actions[(size_t)i * A + a] - mean[(size_t)i * A + a]) * __expf(-ls);
+      logp += -0.5f * z * z - ls - 0.9189385332046727f;
+    }
+    const float an = (adv[i] - adv_stats[0]) / (adv_stats[1] + 1e-8f);
+    const float ratio = __expf(logp - old_logp[i]);
+    const float s1 = an * ratio;
+    const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+    const float s2 = an * rc;
+    pl_i = -fminf(s1, s2) / B;
+    const bool inside = (ratio > 1.f - clip) && (ratio < 1.f + clip);
+    dlogp = -(an * ratio) * ((s1 <= s2) ? 1.f : (inside ? 1.f : 0.f)) / B;
+    const float dv = values[i] - returns[i];
+    vl_i = dv * dv / B;
+    dvalue[i] = vf_coef * 2.f / B * dv;
+  }
+  for (int a = 0; a < A; ++a) {
+    float g = 0.f;
+    if (i < B) {
+      const float inv = __expf(-log_std[a]);
+      const float z = (actions[(size_t)i * A + a] - mean[(size_t)i * A + a]) * inv;
+      dmean[(size_t)i * A + a] = dlogp * z * inv;
+      g = dlogp * (z * z - 1.f);
+    }
+    for (int off = 32; off >= 1; off >>= 1) g += __shfl_xor(g, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&red[a], g);
+  }
+  for (int off = 32; off >= 1; off >>= 1) { pl_i += __shfl_xor(pl_i, off, 64); vl_i += __shfl_xor(vl_i, off, 64); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&red[A], pl_i); atomicAdd(&red[A + 1], vl_i); }
+  __syncthreads();
+  for (int k = threadIdx.x; k < A + 2; k += blockDim.x) atomicAdd(&acc[k], red[k]);
+}
+#endif
+extern "C" int myo_ppo_loss_grad(const float* mean, const float* values, const float* actions, const float* old_logp,
+                                 const float* adv, const float* returns, const float* log_std, const float* adv_stats,
+                                 int B, int A, float clip, float vf_coef, float* dmean, float* dvalue, float* acc,
+                                 void* stream) {
+  if (!mean || !values || !actions || !old_logp || !adv || !returns || !log_std || !adv_stats || !dmean || !dvalue || !acc ||
+      B <= 0 || A <= 0 || A > 64)
+    return fail(MYO_E_ARG, "myo_ppo_loss_grad: bad arguments");
+#ifdef MYO_EMU
+  (void)clip; (void)vf_coef; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_ppo_loss_grad is a GPU kernel");
+#else
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(acc, 0, sizeof(float) * (A + 2), st) != hipSuccess) return fail(MYO_E_DEVICE, "memset failed");
+  hipLaunchKernelGGL(k_ppo_loss, dim3((B + 255) / 256), dim3(256), 0, st, mean, values, actions, old_logp, adv, returns,
+                     log_std, adv_stats, B, A, clip, vf_coef, dmean, dvalue, acc);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------ GAE
+// compute_returns_and_advantage of SB3's RolloutBuffer: backward scan over T with
+// the episode_starts[t+1] mask; one thread per env, coalesced over envs.  [T,N] row-major.
+#ifndef MYO_EMU
+__global__ void k_gae(const float* __restrict__ rew, const float* __restrict__ val, const float* __restrict__ starts,
+                      const float* __restrict__ last_val, const float* __restrict__ last_done, int T, int N, float gamma,
+                      float lam, float* __restrict__ adv, float* __restrict__ ret) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  float last = 0.f, nextv = last_val[e], nonterm = 1.f - last_done[e];
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t i = (size_t)t * N + e;
+    const float v = val[i];
+    const float delta = rew[i] + gamma * nextv * nonterm - v;
+    last = delta + gamma * lam * nonterm * last;
+    adv[i] = last;
+    ret[i] = last + v;
+    nextv = v;
+    nonterm = 1.f - starts[i];
+  }
+}
+#endif
+extern "C" int myo_gae(const float* rew, const float* val, const float* starts, const float* last_val, const float* last_done,
+                       int T, int N, float gamma, float lam, float* adv, float* ret, void* stream) {
+  if (!rew || !val || !starts || !last_val || !last_done || !adv || !ret || T <= 0 || N <= 0) return fail(MYO_E_ARG, "myo_gae: bad arguments");
+#ifdef MYO_EMU
+  (void)stream;
+  for (int e = 0; e < N; ++e) {
+    float last = 0.f, nextv = last_val[e], nonterm = 1.f - last_done[e];
+    for (int t = T - 1; t >= 0; --t) {
+      const size_t i = (size_t)t * N + e;
+      const float v = val[i], delta = rew[i] + gamma * nextv * nonterm - v;
+      last = delta + gamma * lam * nonterm * last;
+      adv[i] = last; ret[i] = last + v; nextv = v; nonterm = 1.f - starts[i];
+    }
+  }
+  return MYO_OK;
+#else
+  hipLaunchKernelGGL(k_gae, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, val, starts, last_val, last_done, T, N,
+                     gamma, lam, adv, ret);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
 extern "C" int myo_batch_enable_timing(myo_batch* b, int on) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   b->timing = on;

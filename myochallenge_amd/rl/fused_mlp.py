@@ -1,15 +1,20 @@
 """Hand-derived forward/backward of the PPO minibatch loss for the MLP actor-critic.
 
 Same loss as ``PPO._loss`` (clipped surrogate + vf_coef * MSE - ent_coef * entropy, per-minibatch
-advantage normalisation; SB3 semantics) but without autograd: ~60 kernel launches
-per optimizer step instead of ~140, bf16 GEMMs on contiguous operands, and the weight-gradient
-GEMMs (dW = dY' X with a 16k-long reduction and a 256x256 output) done as a split-K ``bmm`` —
-hipBLASLt otherwise runs them on 16 workgroups of a 256-CU chip (94 us each, 22 % of the update).
-The bias gradient rides along as an extra "ones" column of X.  Checked against autograd in
-tests/test_rl.py.
+advantage normalisation; SB3 semantics) without autograd:
+
+* bf16 GEMMs on contiguous operands, weights cast once per step with one multi-tensor copy;
+* weight gradients dW = dY' X (16k-long reduction, 256x256 output) as a split-K ``bmm`` —
+  hipBLASLt otherwise runs them on 16 workgroups of a 256-CU chip (94 us each, 22 % of the update);
+* the whole elementwise part (log-prob, ratio, clip, value loss and their gradients) in ONE HIP
+  kernel of libmyobatch (``myo_ppo_loss_grad``) instead of ~40 torch launches.
+
+``ppo_mlp_step_grads`` is the pure-torch statement of the same math (CPU tests compare it with
+autograd); ``FusedPPOStep`` is the GPU path that PPO captures into a hipGraph.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import List, Tuple
 
@@ -20,30 +25,31 @@ def _layers(seq) -> List[torch.nn.Linear]:
     return [m for m in seq if isinstance(m, torch.nn.Linear)]
 
 
+def _nets(policy):
+    return {"pi": _layers(policy.mlp_extractor.policy_net) + [policy.action_net],
+            "vf": _layers(policy.mlp_extractor.value_net) + [policy.value_net]}
+
+
 def _splitk_wgrad(dy: torch.Tensor, x: torch.Tensor, split: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """dW = dy' x, db = dy' 1  with x [B,in], dy [B,out]; split-K over the batch."""
     B = x.shape[0]
-    ones = torch.ones((B, 1), dtype=x.dtype, device=x.device)
-    xa = torch.cat([x, ones], 1)
     if split > 1 and B % split == 0:
-        g = torch.bmm(dy.view(split, B // split, -1).transpose(1, 2), xa.view(split, B // split, -1)).float().sum(0)
+        gw = torch.bmm(dy.view(split, B // split, -1).transpose(1, 2), x.view(split, B // split, -1)).sum(0, dtype=torch.float32)
     else:
-        g = (dy.t() @ xa).float()
-    return g[:, :-1], g[:, -1]
+        gw = (dy.t() @ x).float()
+    return gw, dy.sum(0, dtype=torch.float32)
 
 
 @torch.no_grad()
 def ppo_mlp_step_grads(policy, obs, actions, old_logp, adv, returns, clip_range, ent_coef, vf_coef,
                        normalize_advantage=True, bf16=True, split_k=32):
-    """Writes d(loss)/d(param) into ``p.grad`` of every policy parameter; returns (pl, vl)."""
+    """Reference (pure torch) version: writes d(loss)/d(param) into ``p.grad``; returns (pl, vl)."""
     assert not policy.recurrent
     cd = torch.bfloat16 if (bf16 and obs.is_cuda) else torch.float32
     B = obs.shape[0]
     x0 = obs.to(cd)
-    nets = {"pi": _layers(policy.mlp_extractor.policy_net) + [policy.action_net],
-            "vf": _layers(policy.mlp_extractor.value_net) + [policy.value_net]}
-    acts = {}
-    outs = {}
+    nets = _nets(policy)
+    acts, outs = {}, {}
     for name, layers in nets.items():
         h = x0
         saved = [h]
@@ -62,17 +68,15 @@ def ppo_mlp_step_grads(policy, obs, actions, old_logp, adv, returns, clip_range,
         adv = (adv - adv.mean()) / (adv.std() + 1e-8)
     ratio = torch.exp(logp - old_logp)
     s1 = adv * ratio
-    clipped = torch.clamp(ratio, 1 - clip_range, 1 + clip_range)
-    s2 = adv * clipped
+    s2 = adv * torch.clamp(ratio, 1 - clip_range, 1 + clip_range)
     pl = -torch.min(s1, s2).mean()
     vl = torch.mean((values - returns) ** 2)
-    # d pl / d logp
     inside = (ratio > 1 - clip_range) & (ratio < 1 + clip_range)
-    use1 = s1 <= s2
-    dlogp = -(adv * ratio) * torch.where(use1, torch.ones_like(ratio), inside.to(ratio.dtype)) / B
-    dmean = (dlogp.unsqueeze(-1) * z * inv_std)
+    dlogp = -(adv * ratio) * torch.where(s1 <= s2, torch.ones_like(ratio), inside.to(ratio.dtype)) / B
+    dmean = dlogp.unsqueeze(-1) * z * inv_std
     dlogstd = (dlogp.unsqueeze(-1) * (z * z - 1)).sum(0) - ent_coef
     dvalue = (vf_coef * 2.0 / B) * (values - returns)
+
     def put(p, g):
         if p.grad is None:
             p.grad = g.clone()
@@ -90,3 +94,74 @@ def ppo_mlp_step_grads(policy, obs, actions, old_logp, adv, returns, clip_range,
             if li > 0:
                 dy = (dy @ lin.weight.to(cd)) * (saved[li] > 0).to(cd)
     return pl, vl
+
+
+class FusedPPOStep:
+    """GPU path: persistent bf16 weight copies + the HIP loss kernel.  All shapes static so the
+    sequence can be captured in a hipGraph."""
+
+    def __init__(self, policy, lib, clip_range, ent_coef, vf_coef, split_k=32):
+        assert not policy.recurrent
+        self.policy, self.lib = policy, lib
+        self.clip, self.ent, self.vf, self.split = float(clip_range), float(ent_coef), float(vf_coef), split_k
+        self.nets = _nets(policy)
+        dev = policy.log_std.device
+        self.master, self.half = [], []
+        self.wb = {}
+        for name, layers in self.nets.items():
+            for lin in layers:
+                for p in (lin.weight, lin.bias):
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    h = torch.empty_like(p, dtype=torch.bfloat16)
+                    self.master.append(p.data)
+                    self.half.append(h)
+                    self.wb[id(p)] = h
+        if policy.log_std.grad is None:
+            policy.log_std.grad = torch.zeros_like(policy.log_std)
+        A = policy.act_dim
+        self.acc = torch.zeros(A + 2, device=dev)
+        self.stats = torch.zeros(2, device=dev)
+        self.A = A
+
+    @torch.no_grad()
+    def run(self, obs, actions, old_logp, adv, returns):
+        pol = self.policy
+        B, A = obs.shape[0], self.A
+        torch._foreach_copy_(self.half, self.master)
+        x0 = obs.to(torch.bfloat16)
+        acts, outs = {}, {}
+        for name, layers in self.nets.items():
+            h = x0
+            saved = [h]
+            for li, lin in enumerate(layers):
+                h = torch.addmm(self.wb[id(lin.bias)], h, self.wb[id(lin.weight)].t())
+                if li < len(layers) - 1:
+                    h = torch.relu_(h)
+                    saved.append(h)
+            acts[name], outs[name] = saved, h.float()
+        mean, values = outs["pi"].contiguous(), outs["vf"].reshape(B).contiguous()
+        var, mu = torch.var_mean(adv)                      # unbiased, as torch.std in SB3
+        self.stats[0].copy_(mu)
+        self.stats[1].copy_(var.sqrt())
+        dmean = torch.empty((B, A), device=obs.device)
+        dvalue = torch.empty(B, device=obs.device)
+        stream = torch.cuda.current_stream(obs.device).cuda_stream
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self.lib.check(self.lib.L.myo_ppo_loss_grad(
+            p(mean), p(values), p(actions), p(old_logp), p(adv), p(returns), p(pol.log_std.data), p(self.stats),
+            B, A, self.clip, self.vf, p(dmean), p(dvalue), p(self.acc), C.c_void_p(stream)))
+        torch.sub(self.acc[:A], self.ent, out=pol.log_std.grad)
+        for name, dout in (("pi", dmean), ("vf", dvalue.unsqueeze(-1))):
+            layers, saved = self.nets[name], acts[name]
+            dy = dout.to(torch.bfloat16)
+            for li in reversed(range(len(layers))):
+                lin = layers[li]
+                x = saved[li]
+                s = self.split if (B % self.split == 0) else 1
+                part = torch.bmm(dy.view(s, B // s, -1).transpose(1, 2), x.view(s, B // s, -1))
+                torch.sum(part, 0, dtype=torch.float32, out=lin.weight.grad)
+                torch.sum(dy, 0, dtype=torch.float32, out=lin.bias.grad)
+                if li > 0:
+                    dy = torch.ops.aten.threshold_backward(dy @ self.wb[id(lin.weight)], saved[li], 0)
+        return self.acc[A], self.acc[A + 1]

@@ -43,8 +43,20 @@ class PPOConfig:
 
 def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
     """rewards/values/episode_starts [T,N]; SB3 buffer semantics: non-terminal mask for step t is
-    1 - episode_starts[t+1] (1 - dones for the last step)."""
+    1 - episode_starts[t+1] (1 - dones for the last step).  On the GPU this is one HIP kernel
+    (myo_gae); the torch loop below is the CPU statement of the same scan."""
     T = rewards.shape[0]
+    if rewards.is_cuda and rewards.dtype == torch.float32:
+        import ctypes as C
+        from .. import native
+        lib = native.load()
+        adv, ret = torch.empty_like(rewards), torch.empty_like(rewards)
+        p = lambda t: C.c_void_p(t.contiguous().data_ptr())
+        lv, ld = last_values.float().contiguous(), last_dones.float().contiguous()
+        lib.check(lib.L.myo_gae(p(rewards), p(values), p(episode_starts), p(lv), p(ld), T, rewards.shape[1],
+                                float(gamma), float(lam), p(adv), p(ret),
+                                C.c_void_p(torch.cuda.current_stream(rewards.device).cuda_stream)))
+        return adv, ret
     adv = torch.zeros_like(rewards)
     last = torch.zeros_like(last_values)
     for t in reversed(range(T)):
@@ -67,6 +79,7 @@ class PPO:
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                           capturable=on_gpu, foreach=True if on_gpu else None)
         self._graph = None
+        self._fused = None
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         N, T, O, A = env.num_envs, cfg.n_steps, env.obs_dim, env.act_dim
@@ -85,7 +98,7 @@ class PPO:
         self.n_updates = 0
         self.ep_returns: list = []
         self.ep_lengths: list = []
-        self.gen = torch.Generator(device="cpu")
+        self.gen = torch.Generator(device=self.device if on_gpu else "cpu")   # minibatch permutations on the device
         self.gen.manual_seed(seed + 1000 * self.rank)
         nparam = sum(p.numel() for p in self.policy.parameters())
         self._flat_grad = torch.zeros(nparam, device=d)
@@ -170,7 +183,7 @@ class PPO:
             oldlp, advf, retf = self.logp_buf.view(B), adv.view(B), ret.view(B)
             bs = min(cfg.batch_size, B)
             for _ in range(cfg.n_epochs):
-                perm = torch.randperm(B, generator=self.gen).to(self.device)
+                perm = torch.randperm(B, generator=self.gen, device=self.device)
                 for s in range(0, B - bs + 1, bs):
                     idx = perm[s:s + bs]
                     with self._autocast():
@@ -186,7 +199,7 @@ class PPO:
             # sequences = whole rollouts of a subset of envs, initial LSTM state = state at rollout start
             envs_per_mb = max(1, min(N, cfg.batch_size // T))
             for _ in range(cfg.n_epochs):
-                perm = torch.randperm(N, generator=self.gen).to(self.device)
+                perm = torch.randperm(N, generator=self.gen, device=self.device)
                 for s in range(0, N - envs_per_mb + 1, envs_per_mb):
                     idx = perm[s:s + envs_per_mb]
                     st0 = tuple(x[:, idx] for x in self._rollout_state0)
@@ -206,12 +219,13 @@ class PPO:
 
     # ---------------------------------------------------------------- hipGraph-captured minibatch step
     def _mb_forward_backward(self):
-        from .fused_mlp import ppo_mlp_step_grads
         g, cfg = self._gs, self.cfg
         idx = g["idx"]
-        pl, vl = ppo_mlp_step_grads(self.policy, g["obs"][idx], g["act"][idx], g["oldlp"][idx], g["adv"][idx],
-                                    g["ret"][idx], cfg.clip_range, cfg.ent_coef, cfg.vf_coef,
-                                    cfg.normalize_advantage, cfg.bf16)
+        if self._fused is None:
+            from .. import native
+            from .fused_mlp import FusedPPOStep
+            self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
+        pl, vl = self._fused.run(g["obs"][idx], g["act"][idx], g["oldlp"][idx], g["adv"][idx], g["ret"][idx])
         g["pl"].copy_(pl); g["vl"].copy_(vl)
         if self.world > 1:
             off = 0
@@ -263,7 +277,7 @@ class PPO:
         g = self._gs
         g["adv"].copy_(adv.view(B)); g["ret"].copy_(ret.view(B))
         for _ in range(cfg.n_epochs):
-            perm = torch.randperm(B, generator=self.gen).to(self.device, non_blocking=True)
+            perm = torch.randperm(B, generator=self.gen, device=self.device)
             for s in range(0, B - bs + 1, bs):
                 g["idx"].copy_(perm[s:s + bs])
                 self._graph_fb.replay()

@@ -185,6 +185,18 @@ def main():
     if rank == 0:
         alg_bytes = ALG_BYTES_F64_STATE * args.envs
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+        traffic, valu = None, None
+        try:   # PMC figures are collected off-line with rocprofv3 (profiles/README.md) for the default workload
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            if args.envs == pmc["envs_per_launch"] and args.dtype == "f32" and integ_name == "Euler":
+                traffic = pmc["hbm_bytes_per_launch"]
+                lanes_per_s = pmc["SQ_INSTS_VALU"] * 64 / (kernel_ms * 1e-3)
+                valu = {"valu_wave_instructions_per_launch": pmc["SQ_INSTS_VALU"],
+                        "achieved_lane_ops_per_s": lanes_per_s, "peak_lane_ops_per_s": 78.65e12,
+                        "frac_of_valu_issue_peak": lanes_per_s / 78.65e12,
+                        "note": "peak = 157.3 TFLOP/s fp32 vector / 2 (one FMA = 2 flop) = lane-instructions/s"}
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec (Baoding, 4096 envs)", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -200,7 +212,7 @@ def main():
             "env_kernel_ms": kernel_ms,
             "env_kernel_only_steps_per_sec_per_gpu": args.envs / (kernel_ms * 1e-3) if kernel_ms > 0 else None,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": (achieved / 8000.0) if achieved else None, "traffic": None,
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic, "valu": valu,
                          "kernel": "k_step<%s>" % ("float" if args.dtype == "f32" else "double"),
                          "note": "algorithmic bytes = 2508 B/env-step x envs per launch; the kernel is a long "
                                  "dependent chain of small vector ops (VALU/latency-bound), so the HBM fraction "

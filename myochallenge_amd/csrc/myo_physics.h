@@ -31,7 +31,7 @@
 #else
 #define PROF(s, k)
 #endif
-#define MYO_HIDX(i, j) ((i) * ((i) + 1) / 2 + (j)) /* packed lower triangle, i >= j */
+#define MYO_HIDX(i, j) ((i) * MYO_NV_MAX + (j)) /* square row-major storage, lower triangle (i >= j) is used */
 
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
@@ -73,19 +73,18 @@ struct Scratch {
   int which_task, counter, elapsed, episode, ep_len;
   // ---- position stage
   // (short-lived arrays alias longer-lived storage, see the S_* accessors below)
-  T xpos[MYO_NB_MAX * 3], xmat[MYO_NB_MAX * 9], xipos[MYO_NB_MAX * 3];
-  T com[MYO_NB_MAX * 3], cinert[MYO_NB_MAX * 10];
+  T xpos[MYO_NB_MAX * 3], xmat[MYO_NB_MAX * 9];
+  T com[MYO_NB_MAX * 3];
   T cdof[MYO_NV_MAX * 6];
-  T cvel[MYO_NB_MAX * 6], bvec[MYO_NB_MAX * 6];
+  T bvec[MYO_NB_MAX * 6];
   T ten_length[MYO_NT_MAX], ten_vel[MYO_NT_MAX], ten_J[MYO_NT_MAX * MYO_TJ_MAX];
   T act_force[MYO_NU_MAX], act_dot[MYO_NU_MAX];
-  T qM[MYO_NM_MAX], H[MYO_NV_MAX * (MYO_NV_MAX + 1) / 2];
-  T qfrc_passive[MYO_NV_MAX], qfrc_bias[MYO_NV_MAX], qfrc_actuator[MYO_NV_MAX],
-      qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX],
-      qfrc_constraint[MYO_NV_MAX];
+  T qM[MYO_NM_MAX];
+  alignas(16) T H[MYO_NV_MAX * MYO_NV_MAX];   // dense system matrix / its Cholesky factor; hosts short-lived arrays too
+  T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
   T Ma[MYO_NV_MAX], grad[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX], tmpv[MYO_NV_MAX];
   // ---- constraints
-  int ncon, nefc, nl, ntl, bad, solver_iter, npre[64];
+  int ncon, nefc, nl, ntl, bad, solver_iter;
   ContactRec<T> con[MYO_NCON_MAX];
   int lim_id[MYO_NLIM_MAX];
   T lim_sgn[MYO_NLIM_MAX];
@@ -101,18 +100,30 @@ struct Scratch {
 };
 
 // Aliases: arrays whose lifetime ends before the buffer they live in is next written.
-//   crb (CRB only), cdof_dot (velocity stage only), obs (after the physics) -> inside H (666 T)
+//   H (36x36) is only live from qacc_smooth to the end of the solver / Euler solve.  Before that
+//   it hosts: cinert (com_pos..RNE), crb (CRB only) then cdof_dot (velocity stage), the passive /
+//   bias / actuator force vectors (velocity..actuation), and after the physics the observation.
 //   xquat (kinematics only) -> efc_jar;  xanchor / xaxis (until cdof is built) -> efc_aref / efc_jv
-//   cfrcb (RNE only) -> bvec (solver only)
-#define S_CRB(s) ((s).H)
+//   xipos (until cinert is built) and the compaction prefix npre -> efc_force;  cfrcb (RNE) -> bvec
+#define S_CINERT(s) ((s).H)
+#define S_CRB(s) ((s).H + MYO_NB_MAX * 10)
 #define S_CDOFDOT(s) ((s).H + MYO_NB_MAX * 10)
-#define S_OBS(s) ((s).H + MYO_NB_MAX * 10 + MYO_NV_MAX * 6)
+#define S_QFRC_PASSIVE(s) ((s).H + MYO_NB_MAX * 20)
+#define S_QFRC_BIAS(s) ((s).H + MYO_NB_MAX * 20 + MYO_NV_MAX)
+#define S_QFRC_ACTUATOR(s) ((s).H + MYO_NB_MAX * 20 + 2 * MYO_NV_MAX)
+#define S_OBS(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX)
 #define S_XQUAT(s) ((s).efc_jar)
 #define S_XANCHOR(s) ((s).efc_aref)
 #define S_XAXIS(s) ((s).efc_jv)
+#define S_XIPOS(s) ((s).efc_force)
+#define S_NPRE(s) (reinterpret_cast<int*>((s).efc_force))
 #define S_CFRCB(s) ((s).bvec)
-static_assert(MYO_NB_MAX * 10 + MYO_NV_MAX * 6 + MYO_OBS_MAX <= MYO_NV_MAX * (MYO_NV_MAX + 1) / 2, "H aliases");
-static_assert(MYO_NB_MAX * 4 <= MYO_NEFC_MAX && MYO_NJ_MAX * 3 <= MYO_NEFC_MAX, "efc aliases");
+#define S_CVEL(s) ((s).Ma)   /* body velocities (velocity stage) live in the solver vectors Ma,grad,search,Mv */
+static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_NV_MAX * MYO_NV_MAX, "H aliases");
+static_assert(MYO_NV_MAX * 6 <= MYO_NB_MAX * 10, "cdof_dot fits where crb was");
+static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in Ma..Mv");
+static_assert(MYO_NB_MAX * 4 <= MYO_NEFC_MAX && MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX && 64 <= MYO_NEFC_MAX, "efc aliases");
+
 // ---- phase functions are real (non-inlined) functions in the gfx950 build: each gets its own
 // register allocation (the fully inlined kernel spilled ~170 VGPRs and was several MB of code).
 // They do not receive the model / task / scratch through arguments: the model and task live in
@@ -313,7 +324,7 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
         for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = R[k];
         T t[3];
         mulmatvec3(t, R, M.body_ipos + 3 * b);
-        for (int k = 0; k < 3; ++k) s.xipos[3 * b + k] = p[k] + t[k];
+        for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = p[k] + t[k];
       }
     }
     SYNC();
@@ -333,9 +344,9 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_i
       for (int o = 1; o < M.nbody; ++o)
         if (M.body_rootid[o] == b) {
           const T mo = body_mass_of(M, K, s, o);
-          mass += mo; c[0] += mo * s.xipos[3 * o]; c[1] += mo * s.xipos[3 * o + 1]; c[2] += mo * s.xipos[3 * o + 2];
+          mass += mo; c[0] += mo * S_XIPOS(s)[3 * o]; c[1] += mo * S_XIPOS(s)[3 * o + 1]; c[2] += mo * S_XIPOS(s)[3 * o + 2];
         }
-      if (mass < MYO_MINVAL) { c[0] = s.xipos[3 * b]; c[1] = s.xipos[3 * b + 1]; c[2] = s.xipos[3 * b + 2]; }
+      if (mass < MYO_MINVAL) { c[0] = S_XIPOS(s)[3 * b]; c[1] = S_XIPOS(s)[3 * b + 1]; c[2] = S_XIPOS(s)[3 * b + 2]; }
       else { c[0] /= mass; c[1] /= mass; c[2] /= mass; }
       s.com[3 * b] = c[0]; s.com[3 * b + 1] = c[1]; s.com[3 * b + 2] = c[2];
     }
@@ -344,13 +355,13 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_i
   PHASE {
     const int b = lane;
     if (b < M.nbody) {
-      T* ci = s.cinert + 10 * b;
+      T* ci = S_CINERT(s) + 10 * b;
       if (b == 0) { for (int k = 0; k < 10; ++k) ci[k] = 0; }
       else {
         T R[9];
         mulmat3(R, s.xmat + 9 * b, M.body_imat + 9 * b);
         const T* I = M.body_inertia + 3 * b; const T* c = s.com + 3 * M.body_rootid[b];
-        const T off[3] = {s.xipos[3 * b] - c[0], s.xipos[3 * b + 1] - c[1], s.xipos[3 * b + 2] - c[2]};
+        const T off[3] = {S_XIPOS(s)[3 * b] - c[0], S_XIPOS(s)[3 * b + 1] - c[1], S_XIPOS(s)[3 * b + 2] - c[2]};
         const T mb = body_mass_of(M, K, s, b);
         ci[0] = R[0] * R[0] * I[0] + R[1] * R[1] * I[1] + R[2] * R[2] * I[2] + mb * (off[1] * off[1] + off[2] * off[2]);
         ci[1] = R[3] * R[3] * I[0] + R[4] * R[4] * I[1] + R[5] * R[5] * I[2] + mb * (off[0] * off[0] + off[2] * off[2]);
@@ -600,7 +611,7 @@ DEVFN void crb(const DevModel<T>& M_in, Scratch<T>& s_in) {
       while (sub) {
         const int c = myo_ffsll(sub);
         sub &= sub - 1;
-        for (int k = 0; k < 10; ++k) acc[k] += s.cinert[10 * c + k];
+        for (int k = 0; k < 10; ++k) acc[k] += S_CINERT(s)[10 * c + k];
       }
       for (int k = 0; k < 10; ++k) S_CRB(s)[10 * b + k] = acc[k];
     }
@@ -642,8 +653,9 @@ template <typename T>
 DEVFN void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* diag_add, T diag_scale) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
-  const int nh = M.nv * (M.nv + 1) / 2;
-  PHASE { for (int k = lane; k < nh; k += 64) s.H[k] = 0; }
+  PHASE {
+    for (int k = lane; k < MYO_NV_MAX * MYO_NV_MAX; k += 64) s.H[k] = ((k / MYO_NV_MAX) == (k % MYO_NV_MAX) && (k / MYO_NV_MAX) >= M.nv) ? (T)1 : (T)0;
+  }
   SYNC();
   PHASE {
     for (int e = lane; e < M.nM; e += 64) {
@@ -723,72 +735,86 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-// solve (L L') x = b with H (packed, LDS) and x (LDS) ; H is overwritten with L
-// `OPAQUE(lane)` re-materialises the lane id so that clang does not hoist the 100+ loop-invariant
-// lane-compare masks into SGPR pairs (it then spills them through v_writelane).
+// solve (L L') x = b with H (square, LDS) and x (LDS); H is overwritten with L.
+// Lane i owns row i of the matrix in VGPRs.  Column k is exchanged through LDS (one store per
+// lane, then broadcast wide reads): the LDS pipe does the broadcasting, the VALU only the
+// multiply-adds, two per instruction (v_pk_fma_f32).  No lane predicates in the factor loop:
+// entries above the diagonal hold don't-care values that never flow into valid ones (every
+// valid update of a[j] happens in lanes >= j and only reads column entries of lanes >= j).
+__device__ __forceinline__ float myo_rsqrt(float v) { return __frsqrt_rn(v); }
+__device__ __forceinline__ double myo_rsqrt(double v) { return rsqrt(v); }
 #define MYO_OPAQUE_LANE(v) int v = (int)threadIdx.x; asm volatile("" : "+v"(v));
 template <typename T, int N>
 __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
+  static_assert(N % 4 == 0 && N <= MYO_NV_MAX, "row vectors are loaded 4 at a time");
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  typedef T V4 __attribute__((ext_vector_type(4)));
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
   T* x = LPTR(T, x_r);
   const int lane = threadIdx.x;
-  T a[N];
-  const int rbase = lane * (lane + 1) / 2;
+  const int row = lane < N ? lane : N - 1;          // lanes >= N shadow the last row and never store
+  V2 a2[N / 2];
+  {
+    const V4* hr = reinterpret_cast<const V4*>(s.H + row * MYO_NV_MAX);
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    MYO_OPAQUE_LANE(l)
-    T v = (j == l) ? (T)1 : (T)0;
-    if (l < n && j <= l) v = s.H[rbase + j];
-    a[j] = v;
+    for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
   }
   T b = (lane < n) ? x[lane] : (T)0;
-  // factor: right-looking, no lane predicates.  Entries above the diagonal (j > lane) hold
-  // don't-care values that never flow into valid ones (every valid update uses lanes >= j only).
+  T* colbuf = s.efc_jv;                              // >= 64 entries, free while a system is solved
+  T invd = 1;                                        // 1 / L[lane][lane]
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    T akk = lane_bcast<T>(a[k], k);
-    akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
-    const T inv = 1 / sqrt(akk);
-    const T lik = a[k] * inv;             // lane k: akk / sqrt(akk) = sqrt(akk)
-    a[k] = lik;
+    const T ak = (k & 1) ? a2[k / 2].y : a2[k / 2].x;
+    colbuf[lane] = ak;
+    __syncthreads();
+    const V2* cb = reinterpret_cast<const V2*>(colbuf);
+    V2 c2[N / 2];
 #pragma unroll
-    for (int j = k + 1; j < N; ++j) a[j] -= lik * lane_bcast<T>(lik, j);
+    for (int p = k / 2; p < N / 2; ++p) c2[p] = cb[p];
+    __syncthreads();
+    T akk = (k & 1) ? c2[k / 2].y : c2[k / 2].x;
+    akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
+    const T inv = myo_rsqrt(akk);
+    const T lik = ak * inv;                           // lane k: akk / sqrt(akk) = sqrt(akk)
+    const V2 m = V2{-lik * inv, -lik * inv};
+#pragma unroll
+    for (int p = (k + 1) / 2; p < N / 2; ++p) a2[p] = __builtin_elementwise_fma(m, c2[p], a2[p]);
+    if (k & 1) a2[k / 2].y = lik; else a2[k / 2].x = lik;
+    {
+      MYO_OPAQUE_LANE(l)
+      if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   // forward substitution  L y = b   (lane j finishes at step j; later steps must not touch it)
-  T invd = 1;
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     MYO_OPAQUE_LANE(l)
-    if (j == l) invd = 1 / a[j];
-  }
-#pragma unroll
-  for (int j = 0; j < N; ++j) {
-    MYO_OPAQUE_LANE(l)
+    const T aj = (j & 1) ? a2[j / 2].y : a2[j / 2].x;
     const T yj = lane_bcast<T>(b * invd, j);
-    b = (l == j) ? yj : ((l > j) ? b - a[j] * yj : b);
+    b = (l == j) ? yj : ((l > j) ? b - aj * yj : b);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // transpose through LDS: lane i needs column i
-  __syncthreads();
+  // transpose through LDS: lane i needs column i of L
+  if (lane < N) {
+    V4* hw = reinterpret_cast<V4*>(s.H + lane * MYO_NV_MAX);
 #pragma unroll
-  for (int j = 0; j < N; ++j) {
-    MYO_OPAQUE_LANE(l)
-    if (l < n && j <= l) s.H[rbase + j] = a[j];
+    for (int q = 0; q < N / 4; ++q) hw[q] = V4{a2[2 * q].x, a2[2 * q].y, a2[2 * q + 1].x, a2[2 * q + 1].y};
   }
   __syncthreads();
   T c[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     MYO_OPAQUE_LANE(l)
-    c[j] = (j > l && j < n) ? s.H[j * (j + 1) / 2 + l] : (T)0;
+    const T v = s.H[j * MYO_NV_MAX + row];
+    c[j] = (j > l) ? v : (T)0;
   }
   // backward substitution  L' x = y
 #pragma unroll
   for (int j = N - 1; j >= 0; --j) {
     MYO_OPAQUE_LANE(l)
     const T xj = lane_bcast<T>(b * invd, j);
-    b = (l == j) ? xj : b - c[j] * xj;    // c[j] = 0 for lanes >= j
+    b = (l == j) ? xj : b - c[j] * xj;                // c[j] = 0 for lanes >= j
     __builtin_amdgcn_sched_barrier(0);
   }
   if (lane < n) x[lane] = b;
@@ -983,11 +1009,11 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     }
     LV(cnt) = c; LV(dlo) = a; LV(dhi) = b;
   }
-  WAVE_EXSCAN(LV(cnt), s.npre, total);
+  WAVE_EXSCAN(LV(cnt), S_NPRE(s), total);
   PHASE {
     const int j = lane;
     if (LV(cnt) > 0) {
-      int r = s.npre[lane];
+      int r = S_NPRE(s)[lane];
       const T mg = M.jnt_margin[j];
       for (int side = 0; side < 2; ++side) {
         const T dist = side ? LV(dhi) : LV(dlo);
@@ -1016,11 +1042,11 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     }
     LV(cnt) = c; LV(dlo) = a; LV(dhi) = b;
   }
-  WAVE_EXSCAN(LV(cnt), s.npre, total);
+  WAVE_EXSCAN(LV(cnt), S_NPRE(s), total);
   PHASE {
     const int t = lane;
     if (LV(cnt) > 0) {
-      int r = nl + s.npre[lane];
+      int r = nl + S_NPRE(s)[lane];
       const T mg = M.tendon_margin[t];
       for (int side = 0; side < 2; ++side) {
         const T dist = side ? LV(dhi) : LV(dlo);
@@ -1077,11 +1103,11 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
         }
       }
     }
-    WAVE_EXSCAN(LV(ct).n, s.npre, total);
+    WAVE_EXSCAN(LV(ct).n, S_NPRE(s), total);
     PHASE {
       const int p = base + lane;
       for (int k = 0; k < LV(ct).n; ++k) {
-        const int ci = ncon + s.npre[lane] + k;
+        const int ci = ncon + S_NPRE(s)[lane] + k;
         if (ci >= MYO_NCON_MAX) break;
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
         ContactRec<T>& c = s.con[ci];
@@ -1262,7 +1288,7 @@ template <typename T>
 DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
-  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, s.cvel));
+  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)));
   PHASE {
     const int t = lane;
     if (t < M.ntendon) {
@@ -1294,7 +1320,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
         const int qa = M.jnt_qposadr[j];
         p -= M.jnt_stiffness[j] * (s.qpos[qa] - M.qpos_spring[qa]);
       }
-      s.qfrc_passive[d] = p;
+      S_QFRC_PASSIVE(s)[d] = p;
     }
   }
   SYNC();
@@ -1311,7 +1337,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
             acc += s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f;
           }
         }
-        s.qfrc_passive[d] += acc;
+        S_QFRC_PASSIVE(s)[d] += acc;
       }
     }
     SYNC();
@@ -1329,9 +1355,9 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
         for (int e = 0; e < 6; ++e) a[e] += S_CDOFDOT(s)[6 * d + e] * vd;
       }
       T t1[6], t2[6], t3[6];
-      mul_inert_vec(t1, s.cinert + 10 * b, a);
-      mul_inert_vec(t2, s.cinert + 10 * b, s.cvel + 6 * b);
-      cross_force(t3, s.cvel + 6 * b, t2);
+      mul_inert_vec(t1, S_CINERT(s) + 10 * b, a);
+      mul_inert_vec(t2, S_CINERT(s) + 10 * b, S_CVEL(s) + 6 * b);
+      cross_force(t3, S_CVEL(s) + 6 * b, t2);
       for (int e = 0; e < 6; ++e) S_CFRCB(s)[6 * b + e] = (b == 0) ? (T)0 : t1[e] + t3[e];
     }
   }
@@ -1348,13 +1374,13 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
       }
       T acc = 0;
       for (int e = 0; e < 6; ++e) acc += s.cdof[6 * d + e] * f[e];
-      s.qfrc_bias[d] = acc;
+      S_QFRC_BIAS(s)[d] = acc;
     }
   }
   SYNC();
   // reference acceleration of every constraint row: aref = -B vel - K imp (pos - margin)
   if (s.nefc > 0) {
-    J_times(M, s, LOFF(s, s.qvel), LOFF(s, s.cvel), LOFF(s, s.efc_jv));
+    J_times(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
     PHASE {
       const int nlim_ = s.nl + s.ntl;
       for (int r = lane; r < s.nefc; r += 64) {
@@ -1451,8 +1477,8 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
         if ((m >> d) & 1ull)
           acc += M.actuator_gear[6 * i] * s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * s.act_force[i];
       }
-      s.qfrc_actuator[d] = acc;
-      s.qfrc_smooth[d] = s.qfrc_passive[d] - s.qfrc_bias[d] + acc;
+      S_QFRC_ACTUATOR(s)[d] = acc;
+      s.qfrc_smooth[d] = S_QFRC_PASSIVE(s)[d] - S_QFRC_BIAS(s)[d] + acc;
     }
   }
   SYNC();

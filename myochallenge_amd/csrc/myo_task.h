@@ -429,12 +429,28 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   load_env(M, L, rec, s);
   PHASE { for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0; }
   SYNC();
-  forward(M, K, s);
   const int nv = M.nv;
   PHASE {
     for (int i = lane; i < D.total; i += 64) out[i] = 0;
   }
   SYNC();
+  // same sequence as forward(); the force vectors share LDS with the system matrix, so they are
+  // exported before the acceleration stage overwrites them
+  kinematics(M, s);
+  com_pos(M, K, s);
+  tendon(M, K, s);
+  crb(M, s);
+  collision_and_constraints(M, K, s);
+  fwd_velocity(M, K, s);
+  fwd_actuation(M, s);
+  PHASE {
+    for (int i = lane; i < nv; i += 64) {
+      out[D.qfrc_bias + i] = (double)S_QFRC_BIAS(s)[i]; out[D.qfrc_passive + i] = (double)S_QFRC_PASSIVE(s)[i];
+      out[D.qfrc_actuator + i] = (double)S_QFRC_ACTUATOR(s)[i];
+    }
+  }
+  SYNC();
+  fwd_acceleration(M, s);
   PHASE {
     for (int t = lane; t < M.ntendon; t += 64) {
       out[D.ten_length + t] = (double)s.ten_length[t];
@@ -447,8 +463,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       out[D.M + M.M_j[e] * nv + M.M_i[e]] = (double)s.qM[e];
     }
     for (int i = lane; i < nv; i += 64) {
-      out[D.qfrc_bias + i] = (double)s.qfrc_bias[i]; out[D.qfrc_passive + i] = (double)s.qfrc_passive[i];
-      out[D.qfrc_actuator + i] = (double)s.qfrc_actuator[i]; out[D.qacc_smooth + i] = (double)s.qacc_smooth[i];
+      out[D.qacc_smooth + i] = (double)s.qacc_smooth[i];
       out[D.qacc + i] = (double)s.qacc[i];
     }
     for (int i = lane; i < M.nu; i += 64) out[D.actuator_force + i] = (double)s.act_force[i];

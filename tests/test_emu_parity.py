@@ -55,3 +55,63 @@ def test_capacity_and_argument_errors(emu_lib, models):
     bad = copy.deepcopy(cm); bad.fields = dict(cm.fields); del bad.fields["jnt_axis"]
     with pytest.raises(native.MyoError):
         native.Model(bad, emu_lib)
+
+
+def test_device_reset_agrees_with_reference_reset_goldens(emu_lib, models, golden_dir):
+    """tests/golden/reset_logic_goldens.json records what the REFERENCE reset() did on a recording
+    fake (tools/make_golden.py).  For every archived curriculum config the device reset must
+    touch exactly the same qpos slots, keep the untouched ones at init_qpos, draw the task
+    parameters from the same ranges and take the RSI branch (one zero-action step) when the
+    reference does with probability 0 / 1."""
+    import json
+    import os
+    from myochallenge_amd.envs.config import make_task_cfg
+    from myochallenge_amd.model import compile_model
+    from helpers import Mem
+    cases = json.load(open(os.path.join(golden_dir, "reset_logic_goldens.json")))
+    cm = compile_model(models["hand"])
+    mem = Mem(emu_lib)
+    init = models["hand"].qpos0.copy(); init[:23] = 0; init[0] = -1.57
+    by_cfg = {}
+    for c in cases:
+        by_cfg.setdefault((c["variant"], c["config_index"]), []).append(c)
+    checked = 0
+    for (variant, ci), group in by_cfg.items():
+        cfg = dict(group[0]["config"])
+        name = "CustomMyoBaodingBallsP1" if variant == "p1" else "CustomMyoBaodingBallsP2"
+        # reference side: union over seeds of the slots its final set_state/robot.reset changed
+        ref_changed = np.zeros(37, bool)
+        ref_rsi = []
+        for c in group:
+            finals = [k for k in c["calls"] if k["call"] in ("set_state", "robot.reset")]
+            q = np.array(finals[-1]["qpos"])
+            ginit = np.array(c["calls"][[k["call"] for k in c["calls"]].index("robot.reset")]["qpos"])
+            ref_changed |= np.abs(q - ginit) > 0
+            ref_rsi.append(any(k["call"] == "step" for k in c["calls"]))
+            assert all(np.allclose(k["action"], 0) for k in c["calls"] if k["call"] == "step")   # RSI steps with zeros(39)
+        n = 48
+        b = native.Batch(native.Model(cm, emu_lib), make_task_cfg(name, cm, **cfg), n, 0, 3, native.MYO_F64)
+        obs = mem.zeros((n, 86), np.float32); b.reset(None, obs)
+        qp, tt = mem.zeros((n, 37)), mem.zeros(n)
+        ti, td, bd = mem.zeros((n, 2), np.int32), mem.zeros((n, 9)), mem.zeros((n, 10))
+        b.get_state(qp, None, None, tt); b.get_task(ti, td, bd)
+        dev_changed = np.abs(mem.host(qp) - init).max(0) > 1e-12
+        # ball xy slots move when RSI fires (targets differ from the init ball xy); the reference fake
+        # returns a random obs, so those 4 slots are marked changed there as well
+        assert (dev_changed == ref_changed).all(), (variant, ci, np.where(dev_changed != ref_changed))
+        dev_rsi = mem.host(ti)[:, 1] == 1
+        p = float(cfg.get("rsi_probability", 1)) if cfg.get("enable_rsi") else 0.0
+        if p in (0.0, 1.0):
+            assert all(r == bool(p) for r in ref_rsi) and (dev_rsi == bool(p)).all()
+        else:
+            assert abs(dev_rsi.mean() - p) < 0.25
+        # parameter ranges the reference sampled from
+        gx, gy, gp = cfg["goal_xrange"], cfg["goal_yrange"], cfg["goal_time_period"]
+        t = mem.host(td)
+        assert (t[:, 2] >= gx[0] - 1e-12).all() and (t[:, 2] <= gx[1] + 1e-12).all()
+        assert (t[:, 3] >= gy[0] - 1e-12).all() and (t[:, 3] <= gy[1] + 1e-12).all()
+        assert (t[:, 4] >= gp[0] - 1e-12).all() and (t[:, 4] <= gp[1] + 1e-12).all()
+        for c in group:
+            assert gx[0] - 1e-12 <= c["x_radius"] <= gx[1] + 1e-12 and gy[0] - 1e-12 <= c["y_radius"] <= gy[1] + 1e-12
+        b.close(); checked += 1
+    assert checked >= 20

@@ -135,31 +135,17 @@ def main():
                     clip_range=0.2, ent_coef=2.5e-4, vf_coef=0.5, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, bf16=True)
     algo = PPO(venv, policy, cfg, seed=rank)
 
-    # one "step" of the bench = one rollout step; the PPO update fires every n_steps steps
+    # one "step" of the bench = one rollout step (PPO.rollout_step: hipGraph(policy) -> myo_batch_step
+    # -> hipGraph(normaliser, bootstrap, buffer write)); the PPO update fires every n_steps steps
     state = {"t": 0}
-    algo._last_obs = venv.reset_tensor().clone()
 
     def one_step():
-        t = state["t"]
-        with torch.no_grad():
-            obs, starts = algo._last_obs, algo._last_starts
-            with algo._autocast():
-                actions, values, logp, _ = policy.act(obs, None, None)
-            nobs, rew, done, trunc, term, comps, ep = venv.step_tensor(torch.clamp(actions, -1.0, 1.0))
-            rew = rew.clone()
-            with algo._autocast():   # timeout bootstrap (mask-multiplied: no host sync)
-                tv = policy.predict_values(term)
-            rew = rew + cfg.gamma * tv * trunc.to(rew.dtype)
-            algo.obs_buf[t], algo.act_buf[t], algo.rew_buf[t] = obs, actions, rew
-            algo.val_buf[t], algo.logp_buf[t], algo.start_buf[t] = values, logp, starts
-            algo._last_obs = nobs.clone()
-            algo._last_starts = done.to(torch.float32)
-        state["t"] = t + 1
+        algo.rollout_step()
+        state["t"] += 1
         if state["t"] == cfg.n_steps:
             state["t"] = 0
+            algo.finish_rollout()
             if not args.no_ppo:
-                with torch.no_grad(), algo._autocast():
-                    algo._last_values = policy.predict_values(algo._last_obs)
                 algo.train()
 
     def fence():

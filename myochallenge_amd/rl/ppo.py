@@ -108,10 +108,91 @@ class PPO:
         on = self.cfg.bf16 and self.device.type == "cuda"
         return torch.autocast(device_type=self.device.type, dtype=torch.bfloat16, enabled=on)
 
+    # ---------------------------------------------------------------- rollout (hipGraph path)
+    def _graphed_rollout(self) -> bool:
+        return (self.cfg.use_graphs and self.device.type == "cuda" and not self.policy.recurrent
+                and hasattr(self.env, "step_tensor"))
+
+    @torch.no_grad()
+    def _rollout_policy_part(self):
+        with self._autocast():
+            actions, values, logp, _ = self.policy.act(self._obs_s, None, None)
+        self._act_s.copy_(actions); self._val_s.copy_(values); self._logp_s.copy_(logp)
+        self._clip_s.copy_(torch.clamp(actions, -1.0, 1.0))
+
+    @torch.no_grad()
+    def _rollout_post_part(self, raw):
+        cfg = self.cfg
+        outs = self._vec.process_step(*raw) if self._vec is not None else raw
+        nobs, rew, done, trunc, term, comps, ep = outs
+        with self._autocast():   # timeout bootstrap r += gamma V(terminal_obs) where truncated (mask, no host sync)
+            tv = self.policy.predict_values(term)
+        rew = rew + cfg.gamma * tv * trunc.to(rew.dtype)
+        idx = self._t_idx
+        self.obs_buf.index_copy_(0, idx, self._obs_s.unsqueeze(0))
+        self.act_buf.index_copy_(0, idx, self._act_s.unsqueeze(0))
+        self.rew_buf.index_copy_(0, idx, rew.unsqueeze(0))
+        self.val_buf.index_copy_(0, idx, self._val_s.unsqueeze(0))
+        self.logp_buf.index_copy_(0, idx, self._logp_s.unsqueeze(0))
+        self.start_buf.index_copy_(0, idx, self._starts_s.unsqueeze(0))
+        self._obs_s.copy_(nobs)
+        self._starts_s.copy_(done.to(torch.float32))
+        self._t_idx.add_(1).remainder_(cfg.n_steps)
+
+    def _init_rollout_graphs(self):
+        """Per step: graph A (policy inference + sampling) -> eager myo_batch_step (so its HIP events can
+        still bracket the kernel) -> graph B (normaliser, timeout bootstrap, buffer writes)."""
+        env, d = self.env, self.device
+        self._vec = env if hasattr(env, "process_step") else None
+        self._raw = env.venv if self._vec is not None else env
+        N, A = env.num_envs, env.act_dim
+        first = env.reset_tensor() if self._last_obs is None else self._last_obs
+        self._obs_s = first.clone()
+        self._starts_s = self._last_starts.clone()
+        self._act_s, self._clip_s = torch.zeros((N, A), device=d), torch.zeros((N, A), device=d)
+        self._val_s, self._logp_s = torch.zeros(N, device=d), torch.zeros(N, device=d)
+        self._t_idx = torch.zeros(1, dtype=torch.long, device=d)
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side):           # eager warm-up (also binds the env's constants)
+            for _ in range(2):
+                self._rollout_policy_part()
+                raw = self._raw.step_tensor(self._clip_s)
+                self._rollout_post_part(raw)
+        torch.cuda.current_stream(d).wait_stream(side)
+        torch.cuda.synchronize(d)
+        self._t_idx.zero_()
+        self._raw_static = raw                  # the env returns views of its own (static) buffers
+        self._gA, self._gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._gA):
+            self._rollout_policy_part()
+        with torch.cuda.graph(self._gB):          # own pool: graph B keeps tensors alive across replays
+            self._rollout_post_part(self._raw_static)
+        self._rollout_ready = True
+
+    def rollout_step(self) -> None:
+        """One environment step for the whole batch (graphed path only)."""
+        if not getattr(self, "_rollout_ready", False):
+            self._init_rollout_graphs()
+        self._gA.replay()
+        self._raw.step_tensor(self._clip_s)
+        self._gB.replay()
+
+    def finish_rollout(self) -> None:
+        with torch.no_grad(), self._autocast():
+            self._last_values = self.policy.predict_values(self._obs_s)
+        self._last_obs, self._last_starts = self._obs_s, self._starts_s
+
     # ---------------------------------------------------------------- rollout
     @torch.no_grad()
     def collect_rollouts(self) -> None:
         cfg, env, pol = self.cfg, self.env, self.policy
+        if self._graphed_rollout():
+            for _ in range(cfg.n_steps):
+                self.rollout_step()
+            self.finish_rollout()
+            self.num_timesteps += cfg.n_steps * env.num_envs * self.world
+            return
         if self._last_obs is None:
             self._last_obs = env.reset_tensor().clone()
         if pol.recurrent:
@@ -264,7 +345,7 @@ class PPO:
         self._graph_fb, self._graph_ap = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph_fb):
             self._mb_forward_backward()
-        with torch.cuda.graph(self._graph_ap, pool=self._graph_fb.pool()):
+        with torch.cuda.graph(self._graph_ap):
             self._mb_apply()
         self._graph = (B, bs)
 

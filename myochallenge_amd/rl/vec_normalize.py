@@ -23,7 +23,7 @@ class RunningMeanStd:
     def __init__(self, shape=(), device="cpu", epsilon: float = 1e-4):
         self.mean = torch.zeros(shape, dtype=torch.float64, device=device)
         self.var = torch.ones(shape, dtype=torch.float64, device=device)
-        self.count = float(epsilon)
+        self.count = torch.tensor(float(epsilon), dtype=torch.float64, device=device)   # on the device: no host sync per step
 
     def update(self, x: torch.Tensor) -> None:
         x = x.to(torch.float64)
@@ -34,7 +34,9 @@ class RunningMeanStd:
         tot = self.count + batch_count
         new_mean = self.mean + delta * batch_count / tot
         m2 = self.var * self.count + batch_var * batch_count + delta * delta * self.count * batch_count / tot
-        self.mean, self.var, self.count = new_mean, m2 / tot, tot
+        self.mean.copy_(new_mean)          # in place: the tensors keep their addresses (hipGraph replay)
+        self.var.copy_(m2 / tot)
+        self.count.copy_(tot)
 
     def state(self):
         return {"mean": self.mean.cpu().numpy().copy(), "var": self.var.cpu().numpy().copy(), "count": float(self.count)}
@@ -113,19 +115,22 @@ class VecNormalize:
             self.obs_rms.update(obs)
         return self.normalize_obs(obs)
 
-    def step_tensor(self, actions):
-        obs, rew, done, trunc, term, comps, ep = self.venv.step_tensor(actions)
+    def process_step(self, obs, rew, done, trunc, term, comps, ep):
+        """Normaliser update + normalisation of one raw env step (pure tensor ops, capturable)."""
         self.old_obs, self.old_reward = obs.clone(), rew.clone()
         if self.training and self.norm_obs:
             self.obs_rms.update(obs)
         if self.training:
-            self.returns = self.returns * self.gamma + rew.to(torch.float64)
+            self.returns.mul_(self.gamma).add_(rew.to(torch.float64))
             self.ret_rms.update(self.returns)
         nrew = self.normalize_reward(rew)
         nobs = self.normalize_obs(obs)
         nterm = self.normalize_obs(term)
-        self.returns = torch.where(done.bool(), torch.zeros_like(self.returns), self.returns)
+        self.returns.mul_(1.0 - done.to(torch.float64))
         return nobs, nrew, done, trunc, nterm, comps, ep
+
+    def step_tensor(self, actions):
+        return self.process_step(*self.venv.step_tensor(actions))
 
     # -- SB3 protocol (numpy)
     def reset(self):
@@ -163,7 +168,7 @@ class VecNormalize:
         def rms(dst, src):
             dst.mean = torch.as_tensor(np.asarray(src["mean"], np.float64), device=self.device)
             dst.var = torch.as_tensor(np.asarray(src["var"], np.float64), device=self.device)
-            dst.count = float(src["count"])
+            dst.count = torch.tensor(float(src["count"]), dtype=torch.float64, device=self.device)
         rms(self.obs_rms, st["obs_rms"])
         rms(self.ret_rms, st["ret_rms"])
         for k in ("clip_obs", "clip_reward", "gamma", "epsilon", "norm_obs", "norm_reward", "training"):

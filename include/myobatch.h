@@ -148,6 +148,13 @@ int myo_gae(const float* rew, const float* val, const float* starts, const float
             const float* last_done, int T, int N, float gamma, float lam, float* adv, float* ret,
             void* stream);
 
+/* clip_grad_norm_(max_norm) followed by one torch.optim.Adam step over a flat fp32 parameter vector
+ * (what RecurrentPPO.train does per minibatch; /root/reference/src/train/trainer.py:66-71, SB3 Adam
+ * eps 1e-5).  g is multiplied by grad_scale first (1/world after an all-reduce SUM).  step: dev
+ * int32 counter (incremented); scratch: dev float[1] (receives sum g^2). */
+int myo_adam_clip_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
+                       float eps, float max_norm, float grad_scale, int* step, float* scratch, void* stream);
+
 const char* myo_last_error(void);
 const char* myo_version(void);
 

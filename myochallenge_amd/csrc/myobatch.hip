@@ -854,6 +854,57 @@ extern "C" int myo_gae(const float* rew, const float* val, const float* starts, 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ Adam
+// clip_grad_norm_(max_norm) + torch.optim.Adam step (no weight decay / amsgrad) over ONE flat fp32
+// parameter vector: 2 launches instead of ~12 multi-tensor ones.  scratch[0] = sum g^2 (after
+// grad_scale), step = device-side step counter (incremented here).  SB3 semantics: SURVEY.md C.5.
+#ifndef MYO_EMU
+__global__ void __launch_bounds__(256) k_grad_sqnorm(const float* __restrict__ g, int n, float gs, float* __restrict__ out) {
+  float acc = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const float x = g[i] * gs; acc += x * x; }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
+                                              float max_norm, float gs, const int* __restrict__ step,
+                                              const float* __restrict__ sq) {
+  const int t = *step + 1;
+  const float norm = sqrtf(*sq);
+  const float clip = (max_norm > 0.f) ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+  const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float gi = g[i] * gs * clip;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+}
+__global__ void k_inc(int* step) { *step += 1; }
+#endif
+extern "C" int myo_adam_clip_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
+                                  float eps, float max_norm, float grad_scale, int* step, float* scratch, void* stream) {
+  if (!p || !g || !m || !v || !step || !scratch || n <= 0) return fail(MYO_E_ARG, "myo_adam_clip_step: bad arguments");
+#ifdef MYO_EMU
+  (void)lr; (void)b1; (void)b2; (void)eps; (void)max_norm; (void)grad_scale; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_adam_clip_step is a GPU kernel");
+#else
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(scratch, 0, sizeof(float), st) != hipSuccess) return fail(MYO_E_DEVICE, "memset failed");
+  const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+  hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, g, n, grad_scale, scratch);
+  hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, max_norm, grad_scale, step, scratch);
+  hipLaunchKernelGGL(k_inc, dim3(1), dim3(1), 0, st, step);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
 extern "C" int myo_batch_enable_timing(myo_batch* b, int on) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   b->timing = on;

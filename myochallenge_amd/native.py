@@ -85,6 +85,7 @@ class NativeLib:
         L.myo_batch_enable_timing.argtypes = [vp, i32]
         L.myo_ppo_loss_grad.argtypes = [vp] * 8 + [i32, i32, C.c_float, C.c_float, vp, vp, vp, vp]
         L.myo_gae.argtypes = [vp] * 5 + [i32, i32, C.c_float, C.c_float, vp, vp, vp]
+        L.myo_adam_clip_step.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, vp]
 
     def check(self, rc: int):
         if rc != 0:
@@ -118,7 +119,7 @@ EXPORTED_SYMBOLS = [
     "myo_batch_reset", "myo_batch_step", "myo_batch_physics_step", "myo_batch_get_state",
     "myo_batch_set_state", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
-    "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_gae", "myo_last_error", "myo_version",
+    "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_gae", "myo_adam_clip_step", "myo_last_error", "myo_version",
 ]
 
 

@@ -96,6 +96,55 @@ def ppo_mlp_step_grads(policy, obs, actions, old_logp, adv, returns, clip_range,
     return pl, vl
 
 
+def flatten_parameters(policy, pad: int = 64):
+    """Re-home every parameter (and its .grad) as a view into ONE flat fp32 vector, each slot padded to
+    `pad` elements (keeps bf16 GEMM operands 128-byte aligned).  Lets the optimiser be one kernel
+    (``myo_adam_clip_step``) and the data-parallel all-reduce run in place on one buffer.  Must run
+    before any hipGraph captures the parameters' addresses."""
+    if getattr(policy, "_flat", None) is not None:
+        return policy._flat
+    params = list(policy.parameters())
+    dev = params[0].device
+    slots, n = [], 0
+    for p in params:
+        slots.append((n, p.numel()))
+        n += (p.numel() + pad - 1) // pad * pad
+    pflat, gflat = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for p, (off, k) in zip(params, slots):
+        pflat[off:off + k].copy_(p.data.reshape(-1))
+        p.data = pflat[off:off + k].view(p.shape)
+        p.grad = gflat[off:off + k].view(p.shape)
+    policy._flat = {"p": pflat, "g": gflat, "slots": slots, "params": params}
+    return policy._flat
+
+
+class FlatAdam:
+    """clip_grad_norm_ + Adam over the flat vector in libmyobatch (2 launches, capturable)."""
+
+    def __init__(self, flat, lib, lr, max_norm, betas=(0.9, 0.999), eps=1e-5):
+        self.flat, self.lib = flat, lib
+        self.lr, self.max_norm, self.betas, self.eps = float(lr), float(max_norm), betas, float(eps)
+        dev = flat["p"].device
+        self.m, self.v = torch.zeros_like(flat["p"]), torch.zeros_like(flat["p"])
+        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.sq = torch.zeros(1, device=dev)
+
+    def step(self, grad_scale: float = 1.0):
+        f = self.flat
+        stream = torch.cuda.current_stream(f["p"].device).cuda_stream
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self.lib.check(self.lib.L.myo_adam_clip_step(
+            p(f["p"]), p(f["g"]), p(self.m), p(self.v), f["p"].numel(), self.lr, self.betas[0], self.betas[1],
+            self.eps, self.max_norm, float(grad_scale), p(self.step_count), p(self.sq), C.c_void_p(stream)))
+
+    def snapshot(self):
+        return [t.clone() for t in (self.flat["p"], self.m, self.v, self.step_count)]
+
+    def restore(self, snap):
+        for t, s in zip((self.flat["p"], self.m, self.v, self.step_count), snap):
+            t.copy_(s)
+
+
 class FusedPPOStep:
     """GPU path: persistent bf16 weight copies + the HIP loss kernel.  All shapes static so the
     sequence can be captured in a hipGraph."""
@@ -108,15 +157,22 @@ class FusedPPOStep:
         dev = policy.log_std.device
         self.master, self.half = [], []
         self.wb = {}
-        for name, layers in self.nets.items():
-            for lin in layers:
-                for p in (lin.weight, lin.bias):
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                    h = torch.empty_like(p, dtype=torch.bfloat16)
-                    self.master.append(p.data)
-                    self.half.append(h)
-                    self.wb[id(p)] = h
+        flat = getattr(policy, "_flat", None)
+        if flat is not None:             # one bf16 shadow of the flat vector: a single cast per step
+            hflat = torch.empty_like(flat["p"], dtype=torch.bfloat16)
+            self.master, self.half = [flat["p"]], [hflat]
+            for p, (off, k) in zip(flat["params"], flat["slots"]):
+                self.wb[id(p)] = hflat[off:off + k].view(p.shape)
+        else:
+            for name, layers in self.nets.items():
+                for lin in layers:
+                    for p in (lin.weight, lin.bias):
+                        if p.grad is None:
+                            p.grad = torch.zeros_like(p)
+                        h = torch.empty_like(p, dtype=torch.bfloat16)
+                        self.master.append(p.data)
+                        self.half.append(h)
+                        self.wb[id(p)] = h
         if policy.log_std.grad is None:
             policy.log_std.grad = torch.zeros_like(policy.log_std)
         A = policy.act_dim

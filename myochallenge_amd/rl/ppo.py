@@ -80,6 +80,13 @@ class PPO:
                                           capturable=on_gpu, foreach=True if on_gpu else None)
         self._graph = None
         self._fused = None
+        self._flat_adam = None
+        if cfg.use_graphs and on_gpu and not policy.recurrent:
+            # flat parameter/grad vectors (before any graph captures addresses) + the one-kernel optimiser
+            from .. import native
+            from .fused_mlp import FlatAdam, flatten_parameters
+            self._flat_adam = FlatAdam(flatten_parameters(self.policy), native.load(), cfg.learning_rate,
+                                       cfg.max_grad_norm)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         N, T, O, A = env.num_envs, cfg.n_steps, env.obs_dim, env.act_dim
@@ -101,7 +108,7 @@ class PPO:
         self.gen = torch.Generator(device=self.device if on_gpu else "cpu")   # minibatch permutations on the device
         self.gen.manual_seed(seed + 1000 * self.rank)
         nparam = sum(p.numel() for p in self.policy.parameters())
-        self._flat_grad = torch.zeros(nparam, device=d)
+        self._flat_grad = self.policy._flat["g"] if self._flat_adam is not None else torch.zeros(nparam, device=d)
         self.timers: Dict[str, float] = {"rollout": 0.0, "gae": 0.0, "update": 0.0}
 
     def _autocast(self):
@@ -307,23 +314,10 @@ class PPO:
             from .fused_mlp import FusedPPOStep
             self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
         pl, vl = self._fused.run(g["obs"][idx], g["act"][idx], g["oldlp"][idx], g["adv"][idx], g["ret"][idx])
-        g["pl"].copy_(pl); g["vl"].copy_(vl)
-        if self.world > 1:
-            off = 0
-            for p in self.policy.parameters():
-                n = p.numel()
-                self._flat_grad[off:off + n].copy_(p.grad.reshape(-1))
-                off += n
+        g["pl"].copy_(pl); g["vl"].copy_(vl)      # gradients land in the flat vector (p.grad are views of it)
 
     def _mb_apply(self):
-        if self.world > 1:
-            off = 0
-            for p in self.policy.parameters():
-                n = p.numel()
-                p.grad.copy_((self._flat_grad[off:off + n] / self.world).view_as(p))
-                off += n
-        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.cfg.max_grad_norm, foreach=True)
-        self.optimizer.step()
+        self._flat_adam.step(1.0 / self.world)    # all-reduce SUM ran in place on the flat gradient
 
     def _build_graphs(self, B, bs):
         d = self.device
@@ -334,7 +328,8 @@ class PPO:
         self._gs["idx"].copy_(torch.arange(bs, device=d))
         side = torch.cuda.Stream(device=d)
         side.wait_stream(torch.cuda.current_stream(d))
-        with torch.cuda.stream(side):       # eager warm-up: creates .grad tensors and Adam state
+        snap = self._flat_adam.snapshot()   # warm-up and capture must not move the parameters
+        with torch.cuda.stream(side):       # eager warm-up (library handles, workspaces)
             for _ in range(2):
                 self._mb_forward_backward()
                 if self.world > 1:
@@ -342,11 +337,16 @@ class PPO:
                 self._mb_apply()
         torch.cuda.current_stream(d).wait_stream(side)
         torch.cuda.synchronize(d)
-        self._graph_fb, self._graph_ap = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._graph_fb, self._graph_ap = torch.cuda.CUDAGraph(), None
         with torch.cuda.graph(self._graph_fb):
             self._mb_forward_backward()
-        with torch.cuda.graph(self._graph_ap):
-            self._mb_apply()
+            if self.world == 1:             # single GPU: forward, backward and optimiser in ONE graph
+                self._mb_apply()
+        if self.world > 1:                  # the RCCL all-reduce runs between the two graphs
+            self._graph_ap = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_ap):
+                self._mb_apply()
+        self._flat_adam.restore(snap)
         self._graph = (B, bs)
 
     def _train_graphed(self, adv, ret):
@@ -364,7 +364,7 @@ class PPO:
                 self._graph_fb.replay()
                 if self.world > 1:
                     dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
-                self._graph_ap.replay()
+                    self._graph_ap.replay()
                 self.n_updates += 1
         return g["pl"], g["vl"]
 

@@ -131,3 +131,32 @@ def test_gae_kernel_matches_torch_scan(hip_lib):
     a_ref, ret_ref = compute_gae(r, v, st, lv, ld, 0.99, 0.9)                     # CPU torch loop
     a, ret = compute_gae(*(x.cuda() for x in (r, v, st, lv, ld)), 0.99, 0.9)      # myo_gae kernel
     assert float((a.cpu() - a_ref).abs().max()) < 1e-4 and float((ret.cpu() - ret_ref).abs().max()) < 1e-4
+
+
+def test_flat_adam_matches_torch_clip_and_adam(hip_lib):
+    """myo_adam_clip_step == clip_grad_norm_(0.5) + torch.optim.Adam(eps=1e-5) over several steps."""
+    import torch
+    from myochallenge_amd.rl.fused_mlp import FlatAdam, flatten_parameters
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    torch.manual_seed(3)
+    pol = ActorCriticPolicy(86, 39).cuda()
+    ref = ActorCriticPolicy(86, 39).cuda()
+    ref.load_state_dict(pol.state_dict())
+    flat = flatten_parameters(pol)
+    opt = FlatAdam(flat, hip_lib, 2.5e-4, 0.5)
+    topt = torch.optim.Adam(ref.parameters(), lr=2.5e-4, eps=1e-5)
+    for it in range(5):
+        scale = 10.0 if it % 2 == 0 else 0.01          # exercises both the clipped and the unclipped branch
+        for p, q in zip(pol.parameters(), ref.parameters()):
+            g = torch.randn_like(p) * scale
+            p.grad.copy_(g)
+            q.grad = g.clone()
+        opt.step(1.0)
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        topt.step()
+    torch.cuda.synchronize()
+    assert int(opt.step_count) == 5
+    for (n, p), q in zip(pol.named_parameters(), ref.parameters()):
+        assert p.data_ptr() >= flat["p"].data_ptr()
+        err = float((p - q).abs().max())
+        assert err < 2e-6, (n, err)

@@ -134,12 +134,38 @@ int myo_batch_enable_timing(myo_batch* b, int on);
  * reference runs them as separate torch ops inside sb3_contrib.RecurrentPPO.train,
  * /root/reference/src/train/trainer.py:66-71).  All pointers dev float32: mean[B,A] values[B]
  * actions[B,A] old_logp[B] adv[B] (raw) returns[B] log_std[A] adv_stats[2]={mean,std of adv}.
- * Outputs: dmean[B,A], dvalue[B] = d loss/d(policy mean, value); acc[A+2] = {sum_i dlogp_i (z^2-1)
- * per action dim (entropy term not included), policy loss, value loss}. */
+ * Outputs: dmean[B,A], dvalue[B] = d loss/d(policy mean, value); acc[2A+3] = {sum_i dlogp_i (z^2-1)
+ * per action dim (entropy term not included) [A], policy loss, value loss, sum_i dmean[i,:] [A],
+ * sum_i dvalue[i]} (the last two are the bias gradients of the action / value heads).
+ * dmean_bf16 / dvalue_bf16: optional (NULL) bfloat16 copies of dmean / dvalue for the backward GEMMs.
+ * work: dev float32 [ceil(B/64) * (2A+3)] scratch; the sums are formed from per-block partials in
+ * block order by a second small launch (deterministic, no float atomics). */
 int myo_ppo_loss_grad(const float* mean, const float* values, const float* actions, const float* old_logp,
                       const float* adv, const float* returns, const float* log_std, const float* adv_stats,
                       int B, int A, float clip, float vf_coef, float* dmean, float* dvalue, float* acc,
-                      void* stream);
+                      uint16_t* dmean_bf16, uint16_t* dvalue_bf16, float* work, void* stream);
+
+/* Minibatch gather of one optimiser step (SB3 RolloutBuffer.get + the per-minibatch advantage
+ * normalisation statistics of PPO.train): rows idx[0..bs) (dev int64) of obs[N,obs_dim] act[N,act_dim]
+ * oldlp[N] adv[N] ret[N] (dev float32) -> obs_bf16 [copies, bs, obs_dim] (bfloat16), act_mb, oldlp_mb,
+ * adv_mb, ret_mb, adv_stats[2] = {mean, unbiased std} of adv_mb.  work: dev float32
+ * [2*ceil(bs/16)] scratch (block moments, merged in block order by a second small launch). */
+int myo_ppo_gather(const float* obs, const float* act, const float* oldlp, const float* adv, const float* ret,
+                   const int64_t* idx, int bs, int obs_dim, int act_dim, uint16_t* obs_bf16, int copies,
+                   float* act_mb, float* oldlp_mb, float* adv_mb, float* ret_mb, float* adv_stats, float* work,
+                   void* stream);
+
+/* h <- max(h + bias, 0) in place: bfloat16 h[groups, rows, cols], bias[groups, cols] (cols even). */
+int myo_bias_relu_bf16(uint16_t* h, const uint16_t* bias, int groups, int rows, int cols, void* stream);
+
+/* Finishes a split-K product: out[g, j] = sum_k part[g, k, j]; part dev [groups, splits, n] of
+ * bfloat16 (part_is_bf16 != 0) or float32, n even; out dev float32 [groups, n]. */
+int myo_splitk_reduce(const void* part, int part_is_bf16, float* out, int groups, int splits, int n, void* stream);
+
+/* ReLU backward in place on bfloat16 dy[rows, cols] (dy *= act > 0) plus column sums of the result
+ * over blocks of 32 rows: partial dev float32 [rows/32, cols] (finish with myo_splitk_reduce: the
+ * bias gradient).  rows % 32 == 0, cols/2 divides 256. */
+int myo_relu_bwd_colsum_bf16(uint16_t* dy, const uint16_t* act, int rows, int cols, float* partial, void* stream);
 
 /* GAE(gamma, lambda) backward scan = SB3 RolloutBuffer.compute_returns_and_advantage (run by
  * RecurrentPPO.learn, /root/reference/src/train/trainer.py:66-71).  dev float32 [T,N] row-major:

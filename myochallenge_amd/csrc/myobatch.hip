@@ -575,6 +575,11 @@ static int bind_constants(myo_batch* b, hipStream_t st) {
 }
 static unsigned lds_dyn(const myo_batch* b) {
   const int rk = b->integrator == 1;
+#ifdef MYO_LDS_PAD_EXPERIMENT
+  static int pad = -1;
+  if (pad < 0) { const char* e = getenv("MYO_LDS_PAD"); pad = e ? atoi(e) : 0; }
+  if (b->dtype != MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + rk * sizeof(RkScratch<float>) + pad);
+#endif
   if (b->dtype == MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<double>)) + rk * sizeof(RkScratch<double>));
   return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + rk * sizeof(RkScratch<float>));
 }
@@ -737,28 +742,43 @@ extern "C" int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* 
 }
 
 // ------------------------------------------------------------------------------------------ PPO loss
-// One launch for the whole elementwise part of a PPO minibatch step (SB3 PPO.train loss,
-// SURVEY.md C.5): diag-Gaussian log-prob, ratio, clipped surrogate, value MSE, and their
-// gradients w.r.t. the policy mean, the value and log_std.  One thread per sample; block
-// reduction + atomics into acc[A+2] = {d loss / d log_std[A] (without the entropy term), pl, vl}.
+// Elementwise part of one PPO minibatch step (SB3 PPO.train semantics) in one launch:
+// Gaussian log-prob, ratio, clipped surrogate, value loss and their gradients.  A block owns 64
+// consecutive rows: the [64,A] tiles of mean / actions are staged through LDS with coalesced loads
+// (row stride A is odd for the hand, A = 39, so the per-row reads are conflict-free), dmean leaves
+// the same way.  acc[2A+3] = {d loss/d log_std[A] (without the entropy term), pl, vl,
+// sum_i dmean[i,:] (bias grad of the action head), sum_i dvalue[i] (bias grad of the value head)}.
 #ifndef MYO_EMU
-__global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mean, const float* __restrict__ values,
-                                                  const float* __restrict__ actions, const float* __restrict__ old_logp,
-                                                  const float* __restrict__ adv, const float* __restrict__ returns,
-                                                  const float* __restrict__ log_std, const float* __restrict__ adv_stats,
-                                                  int B, int A, float clip, float vf_coef, float* __restrict__ dmean,
-                                                  float* __restrict__ dvalue, float* __restrict__ acc) {
-  __shared__ float red[66];
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int k = threadIdx.x; k < A + 2; k += blockDim.x) red[k] = 0.f;
+__device__ __forceinline__ unsigned short myo_f2bf(float x) {   // round-to-nearest-even, as torch's .to(bfloat16)
+  unsigned u = __float_as_uint(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__global__ void __launch_bounds__(64) k_ppo_loss(const float* __restrict__ mean, const float* __restrict__ values,
+                                                 const float* __restrict__ actions, const float* __restrict__ old_logp,
+                                                 const float* __restrict__ adv, const float* __restrict__ returns,
+                                                 const float* __restrict__ log_std, const float* __restrict__ adv_stats,
+                                                 int B, int A, float clip, float vf_coef, float* __restrict__ dmean,
+                                                 float* __restrict__ dvalue, float* __restrict__ acc,
+                                                 unsigned short* __restrict__ dmean_h, unsigned short* __restrict__ dvalue_h,
+                                                 float* __restrict__ part) {
+  __shared__ float t_mean[64 * 64], t_act[64 * 64], s_ls[64], s_inv[64];
+  const int lane = threadIdx.x, r0 = blockIdx.x * 64;
+  const int rows = (B - r0) < 64 ? (B - r0) : 64;
+  const int n = rows * A;
+  const size_t base = (size_t)r0 * A;
+  for (int k = lane; k < n; k += 64) { t_mean[k] = mean[base + k]; t_act[k] = actions[base + k]; }
+  if (lane < A) { const float ls = log_std[lane]; s_ls[lane] = ls; s_inv[lane] = __expf(-ls); }
   __syncthreads();
-  float pl_i = 0.f, vl_i = 0.f, dlogp = 0.f;
-  if (i < B) {
+  const int i = r0 + lane;
+  const bool on = lane < rows;
+  float pl_i = 0.f, vl_i = 0.f, dlogp = 0.f, dv_i = 0.f;
+  if (on) {
     float logp = 0.f;
     for (int a = 0; a < A; ++a) {
-      const float ls = log_std[a];
-      const float z = (actions[(size_t)i * A + a] - mean[(size_t)i * A + a]) * __expf(-ls);
-      logp += -0.5f * z * z - ls - 0.9189385332046727f;
+      const float z = (t_act[lane * A + a] - t_mean[lane * A + a]) * s_inv[a];
+      logp += -0.5f * z * z - s_ls[a] - 0.9189385332046727f;
     }
     const float an = (adv[i] - adv_stats[0]) / (adv_stats[1] + 1e-8f);
     const float ratio = __expf(logp - old_logp[i]);
@@ -770,40 +790,288 @@ __global__ void __launch_bounds__(256) k_ppo_loss(const float* __restrict__ mean
     dlogp = -(an * ratio) * ((s1 <= s2) ? 1.f : (inside ? 1.f : 0.f)) / B;
     const float dv = values[i] - returns[i];
     vl_i = dv * dv / B;
-    dvalue[i] = vf_coef * 2.f / B * dv;
+    dv_i = vf_coef * 2.f / B * dv;
+    dvalue[i] = dv_i;
+    if (dvalue_h) dvalue_h[i] = myo_f2bf(dv_i);
   }
-  for (int a = 0; a < A; ++a) {
-    float g = 0.f;
-    if (i < B) {
-      const float inv = __expf(-log_std[a]);
-      const float z = (actions[(size_t)i * A + a] - mean[(size_t)i * A + a]) * inv;
-      dmean[(size_t)i * A + a] = dlogp * z * inv;
-      g = dlogp * (z * z - 1.f);
+  // per-row gradient tiles: dmean into t_mean, dlogp (z^2-1) into t_act (own row only: no hazard)
+  if (on) {
+    for (int a = 0; a < A; ++a) {
+      const float inv = s_inv[a];
+      const float z = (t_act[lane * A + a] - t_mean[lane * A + a]) * inv;
+      t_mean[lane * A + a] = dlogp * z * inv;
+      t_act[lane * A + a] = dlogp * (z * z - 1.f);
     }
-    for (int off = 32; off >= 1; off >>= 1) g += __shfl_xor(g, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&red[a], g);
   }
-  for (int off = 32; off >= 1; off >>= 1) { pl_i += __shfl_xor(pl_i, off, 64); vl_i += __shfl_xor(vl_i, off, 64); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&red[A], pl_i); atomicAdd(&red[A + 1], vl_i); }
   __syncthreads();
-  for (int k = threadIdx.x; k < A + 2; k += blockDim.x) atomicAdd(&acc[k], red[k]);
+  float my_ls = 0.f, my_db = 0.f;     // lane a: column sums of action dim a over the block's rows
+  if (lane < A)
+    for (int r = 0; r < rows; ++r) { my_ls += t_act[r * A + lane]; my_db += t_mean[r * A + lane]; }
+  for (int k = lane; k < n; k += 64) {
+    const float v = t_mean[k];
+    dmean[base + k] = v;
+    if (dmean_h) dmean_h[base + k] = myo_f2bf(v);
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    pl_i += __shfl_xor(pl_i, off, 64); vl_i += __shfl_xor(vl_i, off, 64); dv_i += __shfl_xor(dv_i, off, 64);
+  }
+  // per-block partial sums (column-major: part[c, block]); k_colmajor_finish adds them up
+  // in a fixed order (deterministic, no float atomics)
+  const int W = 2 * A + 3, NB = gridDim.x;
+  if (lane < A) { part[(size_t)lane * NB + blockIdx.x] = my_ls; part[(size_t)(A + 2 + lane) * NB + blockIdx.x] = my_db; }
+  if (lane == 0) {
+    part[(size_t)A * NB + blockIdx.x] = pl_i; part[(size_t)(A + 1) * NB + blockIdx.x] = vl_i;
+    part[(size_t)(2 * A + 2) * NB + blockIdx.x] = dv_i;
+  }
+}
+// acc[c] = sum over blocks of part[c, block] (fixed order: deterministic); one wave per column.
+// A separate launch instead of a last-block epilogue: an in-kernel release fence writes back the
+// whole L2 of the XCD on this chip (measured: +90 us), a kernel boundary is cheaper.
+__global__ void __launch_bounds__(64) k_colmajor_finish(const float* __restrict__ part, float* __restrict__ acc, int NB) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float a = 0.f;
+  for (int b = lane; b < NB; b += 64) a += part[(size_t)c * NB + b];
+  for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+  if (lane == 0) acc[c] = a;
 }
 #endif
 extern "C" int myo_ppo_loss_grad(const float* mean, const float* values, const float* actions, const float* old_logp,
                                  const float* adv, const float* returns, const float* log_std, const float* adv_stats,
                                  int B, int A, float clip, float vf_coef, float* dmean, float* dvalue, float* acc,
-                                 void* stream) {
+                                 uint16_t* dmean_bf16, uint16_t* dvalue_bf16, float* work, void* stream) {
   if (!mean || !values || !actions || !old_logp || !adv || !returns || !log_std || !adv_stats || !dmean || !dvalue || !acc ||
-      B <= 0 || A <= 0 || A > 64)
+      !work || B <= 0 || A <= 0 || A > 64)
     return fail(MYO_E_ARG, "myo_ppo_loss_grad: bad arguments");
 #ifdef MYO_EMU
-  (void)clip; (void)vf_coef; (void)stream;
+  (void)clip; (void)vf_coef; (void)stream; (void)dmean_bf16; (void)dvalue_bf16;
   return fail(MYO_E_UNSUPPORTED, "myo_ppo_loss_grad is a GPU kernel");
 #else
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(acc, 0, sizeof(float) * (A + 2), st) != hipSuccess) return fail(MYO_E_DEVICE, "memset failed");
-  hipLaunchKernelGGL(k_ppo_loss, dim3((B + 255) / 256), dim3(256), 0, st, mean, values, actions, old_logp, adv, returns,
-                     log_std, adv_stats, B, A, clip, vf_coef, dmean, dvalue, acc);
+  const int nblk = (B + 63) / 64;
+  hipLaunchKernelGGL(k_ppo_loss, dim3(nblk), dim3(64), 0, st, mean, values, actions, old_logp, adv, returns,
+                     log_std, adv_stats, B, A, clip, vf_coef, dmean, dvalue, acc, dmean_bf16, dvalue_bf16, work);
+  hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, work, acc, nblk);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------ split-K
+// out[g, j] = sum_k part[g, k, j]: the reduction that finishes a split-K weight-gradient bmm
+// (bf16 partial products, fp32 sum).  torch's generic reduce over a middle dimension takes 37 us on
+// a [2,32,256,256] tensor; this is one coalesced pass.
+#ifndef MYO_EMU
+template <bool BF16>
+__global__ void __launch_bounds__(256) k_splitk_reduce(const unsigned* __restrict__ part, float2* __restrict__ out, int splits,
+                                                       int n2, int total2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;   // index of an element pair in the output
+  if (j >= total2) return;
+  const int g = j / n2, c = j - g * n2;
+  float a0 = 0.f, a1 = 0.f;
+  if (BF16) {
+    const unsigned* src = part + (size_t)g * splits * n2 + c;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) {
+      const unsigned u = src[(size_t)k * n2];
+      a0 += __uint_as_float(u << 16);
+      a1 += __uint_as_float(u & 0xffff0000u);
+    }
+  } else {
+    const float2* src = reinterpret_cast<const float2*>(part) + (size_t)g * splits * n2 + c;
+#pragma unroll 8
+    for (int k = 0; k < splits; ++k) { const float2 v = src[(size_t)k * n2]; a0 += v.x; a1 += v.y; }
+  }
+  out[j] = make_float2(a0, a1);
+}
+// dy <- dy * (act > 0) (ReLU backward, bf16 in place) and per-block column sums of the result:
+// partial[blk, c] over the block's 32 rows.  cols/2 must divide 256 (cols = 256: one column pair
+// per thread, two row phases).  Followed by k_splitk_reduce<false> for the bias gradient.
+__global__ void __launch_bounds__(256) k_relu_bwd_colsum(unsigned* __restrict__ dy, const unsigned* __restrict__ act, int P,
+                                                         float2* __restrict__ partial) {
+  __shared__ float2 red[256];
+  const int t = threadIdx.x, cp = t % P, rph = t / P, nph = 256 / P;
+  const size_t row0 = (size_t)blockIdx.x * 32;
+  float a0 = 0.f, a1 = 0.f;
+  for (int r = rph; r < 32; r += nph) {
+    const size_t i = (row0 + r) * P + cp;
+    const unsigned g = dy[i], a = act[i];
+    // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+    const unsigned lo = ((a & 0x8000u) == 0 && (a & 0x7fffu) != 0) ? (g & 0xffffu) : 0u;
+    const unsigned hi = ((a & 0x80000000u) == 0 && (a & 0x7fff0000u) != 0) ? (g & 0xffff0000u) : 0u;
+    dy[i] = lo | hi;
+    a0 += __uint_as_float(lo << 16);
+    a1 += __uint_as_float(hi);
+  }
+  red[t] = make_float2(a0, a1);
+  __syncthreads();
+  if (t < P) {
+    float2 v = red[t];
+    for (int k = 1; k < nph; ++k) { v.x += red[t + k * P].x; v.y += red[t + k * P].y; }
+    partial[(size_t)blockIdx.x * P + t] = v;
+  }
+}
+#endif
+#ifndef MYO_EMU
+// h <- max(h + bias, 0) in place, bf16 [G, R, C] with bias [G, C] (the epilogue of a batched GEMM).
+__global__ void __launch_bounds__(256) k_bias_relu(unsigned* __restrict__ h, const unsigned* __restrict__ bias, int P, size_t RP,
+                                                   size_t total) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t g = i / RP;
+  const int cp = (int)(i % P);
+  const unsigned x = h[i], b = bias[g * P + cp];
+  const float lo = fmaxf(__uint_as_float(x << 16) + __uint_as_float(b << 16), 0.f);
+  const float hi = fmaxf(__uint_as_float(x & 0xffff0000u) + __uint_as_float(b & 0xffff0000u), 0.f);
+  h[i] = (unsigned)myo_f2bf(lo) | ((unsigned)myo_f2bf(hi) << 16);
+}
+// Minibatch gather of one PPO optimiser step: rows idx[0..bs) of the rollout arrays -> contiguous
+// minibatch arrays (obs as `copies` stacked bf16 copies: the GEMM operand of the stacked actor /
+// critic trunks), plus mean and unbiased std of the gathered advantages (block-wise mean / M2, merged
+// by k_moments_finish in block order: deterministic).  Replaces 5 index kernels, 3 casts/copies and
+// the var_mean reduction.
+#define MYO_GATHER_ROWS 16
+__global__ void __launch_bounds__(256) k_ppo_gather(const float* __restrict__ obs, const float* __restrict__ act,
+                                                    const float* __restrict__ oldlp, const float* __restrict__ adv,
+                                                    const float* __restrict__ ret, const long long* __restrict__ idx, int bs,
+                                                    int O, int A, unsigned short* __restrict__ obs_h, int copies,
+                                                    float* __restrict__ act_mb, float* __restrict__ oldlp_mb,
+                                                    float* __restrict__ adv_mb, float* __restrict__ ret_mb,
+                                                    float* __restrict__ part) {
+  constexpr int R = MYO_GATHER_ROWS;
+  __shared__ long long s_idx[R];
+  const int t = threadIdx.x, r0 = blockIdx.x * R;
+  const int rows = (bs - r0) < R ? (bs - r0) : R;
+  if (t < rows) s_idx[t] = idx[r0 + t];
+  __syncthreads();
+#pragma unroll 2
+  for (int e = t; e < rows * O; e += 256) {
+    const int r = e / O, c = e - r * O;
+    const unsigned short v = myo_f2bf(obs[(size_t)s_idx[r] * O + c]);
+    for (int k = 0; k < copies; ++k) obs_h[((size_t)k * bs + r0 + r) * O + c] = v;
+  }
+#pragma unroll 2
+  for (int e = t; e < rows * A; e += 256) {
+    const int r = e / A, c = e - r * A;
+    act_mb[(size_t)(r0 + r) * A + c] = act[(size_t)s_idx[r] * A + c];
+  }
+  if (t < 64) {
+    float a = 0.f;
+    if (t < rows) {
+      const size_t src = (size_t)s_idx[t];
+      a = adv[src];
+      oldlp_mb[r0 + t] = oldlp[src]; adv_mb[r0 + t] = a; ret_mb[r0 + t] = ret[src];
+    }
+    float sum = a;
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / rows;
+    const float d = (t < rows) ? (a - mean) : 0.f;
+    float m2 = d * d;
+    for (int off = 32; off >= 1; off >>= 1) m2 += __shfl_xor(m2, off, 64);
+    if (t == 0) { part[2 * blockIdx.x] = mean; part[2 * blockIdx.x + 1] = m2; }
+  }
+}
+// merges the block moments of k_ppo_gather in block order (Chan): mean and unbiased std
+__global__ void __launch_bounds__(64) k_moments_finish(const float* __restrict__ part, int nb, int bs, float* __restrict__ adv_stats) {
+  constexpr int R = MYO_GATHER_ROWS;
+  const int t = threadIdx.x;
+  float wsum = 0.f;
+  for (int b = t; b < nb; b += 64) {
+    const int n_b = (bs - b * R) < R ? (bs - b * R) : R;
+    wsum += n_b * part[2 * b];
+  }
+  for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
+  const float mean = wsum / bs;
+  float m2 = 0.f;
+  for (int b = t; b < nb; b += 64) {
+    const int n_b = (bs - b * R) < R ? (bs - b * R) : R;
+    const float dm = part[2 * b] - mean;
+    m2 += part[2 * b + 1] + n_b * dm * dm;
+  }
+  for (int off = 32; off >= 1; off >>= 1) m2 += __shfl_xor(m2, off, 64);
+  if (t == 0) { adv_stats[0] = mean; adv_stats[1] = sqrtf(m2 / (bs > 1 ? bs - 1 : 1)); }
+}
+// Tall fp32 reduction out[g, c] = sum_k part[g, k, c] for few columns and many splits (bias gradients):
+// a block owns 32 column pairs, 8 split phases per pair, combined through LDS in phase order.
+__global__ void __launch_bounds__(256) k_colsum_finish(const float2* __restrict__ part, float2* __restrict__ out, int splits, int n2) {
+  __shared__ float2 red[256];
+  const int t = threadIdx.x, cl = t & 31, ph = t >> 5;
+  const int j = blockIdx.x * 32 + cl;                 // output pair index (over groups * n2)
+  const int g = j / n2, c = j - g * n2;
+  const float2* src = part + (size_t)g * splits * n2 + c;
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+  for (int k = ph; k < splits; k += 8) { const float2 v = src[(size_t)k * n2]; a0 += v.x; a1 += v.y; }
+  red[t] = make_float2(a0, a1);
+  __syncthreads();
+  if (ph == 0) {
+    float2 v = red[cl];
+    for (int k = 1; k < 8; ++k) { v.x += red[cl + 32 * k].x; v.y += red[cl + 32 * k].y; }
+    out[j] = v;
+  }
+}
+#endif
+extern "C" int myo_bias_relu_bf16(uint16_t* h, const uint16_t* bias, int groups, int rows, int cols, void* stream) {
+  if (!h || !bias || groups <= 0 || rows <= 0 || cols <= 0 || (cols & 1)) return fail(MYO_E_ARG, "myo_bias_relu_bf16: bad arguments");
+#ifdef MYO_EMU
+  (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_bias_relu_bf16 is a GPU kernel");
+#else
+  const size_t P = cols / 2, RP = (size_t)rows * P, total = RP * groups;
+  hipLaunchKernelGGL(k_bias_relu, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (unsigned*)h,
+                     (const unsigned*)bias, (int)P, RP, total);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_ppo_gather(const float* obs, const float* act, const float* oldlp, const float* adv, const float* ret,
+                              const int64_t* idx, int bs, int obs_dim, int act_dim, uint16_t* obs_bf16, int copies,
+                              float* act_mb, float* oldlp_mb, float* adv_mb, float* ret_mb, float* adv_stats, float* work,
+                              void* stream) {
+  if (!obs || !act || !oldlp || !adv || !ret || !idx || !obs_bf16 || !act_mb || !oldlp_mb || !adv_mb || !ret_mb || !adv_stats ||
+      !work || bs <= 0 || obs_dim <= 0 || act_dim <= 0 || copies <= 0)
+    return fail(MYO_E_ARG, "myo_ppo_gather: bad arguments");
+#ifdef MYO_EMU
+  (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_ppo_gather is a GPU kernel");
+#else
+  hipLaunchKernelGGL(k_ppo_gather, dim3((bs + MYO_GATHER_ROWS - 1) / MYO_GATHER_ROWS), dim3(256), 0, (hipStream_t)stream, obs, act, oldlp, adv, ret,
+                     (const long long*)idx, bs, obs_dim, act_dim, obs_bf16, copies, act_mb, oldlp_mb, adv_mb, ret_mb, work);
+  hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, work,
+                     (bs + MYO_GATHER_ROWS - 1) / MYO_GATHER_ROWS, bs, adv_stats);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
+extern "C" int myo_splitk_reduce(const void* part, int part_is_bf16, float* out, int groups, int splits, int n, void* stream) {
+  if (!part || !out || groups <= 0 || splits <= 0 || n <= 0 || (n & 1)) return fail(MYO_E_ARG, "myo_splitk_reduce: bad arguments");
+#ifdef MYO_EMU
+  (void)stream; (void)part_is_bf16;
+  return fail(MYO_E_UNSUPPORTED, "myo_splitk_reduce is a GPU kernel");
+#else
+  const int total2 = groups * (n / 2);
+  if (part_is_bf16)
+    hipLaunchKernelGGL(k_splitk_reduce<true>, dim3((total2 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned*)part, (float2*)out, splits, n / 2, total2);
+  else if ((n / 2) % 32 == 0 && splits >= 64)
+    hipLaunchKernelGGL(k_colsum_finish, dim3(total2 / 32), dim3(256), 0, (hipStream_t)stream, (const float2*)part, (float2*)out,
+                       splits, n / 2);
+  else
+    hipLaunchKernelGGL(k_splitk_reduce<false>, dim3((total2 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned*)part, (float2*)out, splits, n / 2, total2);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_relu_bwd_colsum_bf16(uint16_t* dy, const uint16_t* act, int rows, int cols, float* partial, void* stream) {
+  if (!dy || !act || !partial || rows <= 0 || cols <= 0 || (rows % 32) || (cols & 1) || (256 % (cols / 2)) || cols / 2 < 8)
+    return fail(MYO_E_ARG, "myo_relu_bwd_colsum_bf16: rows must be a multiple of 32 and cols/2 a divisor of 256 (>= 8)");
+#ifdef MYO_EMU
+  (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_relu_bwd_colsum_bf16 is a GPU kernel");
+#else
+  hipLaunchKernelGGL(k_relu_bwd_colsum, dim3(rows / 32), dim3(256), 0, (hipStream_t)stream, (unsigned*)dy, (const unsigned*)act,
+                     cols / 2, (float2*)partial);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif

@@ -104,6 +104,14 @@ def flatten_parameters(policy, pad: int = 64):
     if getattr(policy, "_flat", None) is not None:
         return policy._flat
     params = list(policy.parameters())
+    if not policy.recurrent:             # interleave actor / critic trunk layers: adjacent slots -> stacked [2,out,in] views
+        pi, vf = _layers(policy.mlp_extractor.policy_net), _layers(policy.mlp_extractor.value_net)
+        if len(pi) == len(vf) and all(a.weight.shape == b.weight.shape for a, b in zip(pi, vf)):
+            lead = []
+            for a, b in zip(pi, vf):
+                lead += [a.weight, b.weight, a.bias, b.bias]
+            ids = {id(p) for p in lead}
+            params = lead + [p for p in params if id(p) not in ids]
     dev = params[0].device
     slots, n = [], 0
     for p in params:
@@ -176,12 +184,148 @@ class FusedPPOStep:
         if policy.log_std.grad is None:
             policy.log_std.grad = torch.zeros_like(policy.log_std)
         A = policy.act_dim
-        self.acc = torch.zeros(A + 2, device=dev)
+        self.merged = None
+        if flat is not None:
+            self.merged = self._stacked_views(flat, hflat)
+        self.acc = torch.zeros(2 * A + 4, device=dev)
         self.stats = torch.zeros(2, device=dev)
         self.A = A
+        self._work = {}
+
+    def _workbuf(self, key, n):
+        """Zero-initialised scratch of the block-ticket kernels (allocated once per shape: graph-safe)."""
+        w = self._work.get((key, n))
+        if w is None:
+            w = self._work[(key, n)] = torch.zeros(n, device=self.acc.device)
+        return w
+
+    def _stacked_views(self, flat, hflat):
+        """[2,out,in] / [2,out] views over the adjacent actor/critic trunk slots (None if not adjacent)."""
+        pi, vf = self.nets["pi"][:-1], self.nets["vf"][:-1]
+        if len(pi) != len(vf) or not pi:
+            return None
+        slot = {id(p): sl for p, sl in zip(flat["params"], flat["slots"])}
+        out = []
+        for a, b in zip(pi, vf):
+            lay = {}
+            for key, pa, pb in (("w", a.weight, b.weight), ("b", a.bias, b.bias)):
+                (oa, k), (ob, kb) = slot[id(pa)], slot[id(pb)]
+                if pa.shape != pb.shape or ob != oa + k:
+                    return None
+                shape = (2,) + tuple(pa.shape)
+                lay[key + "h"] = hflat[oa:oa + 2 * k].view(shape)
+                lay[key + "g"] = flat["g"][oa:oa + 2 * k].view(shape)
+            out.append(lay)
+        return out
+
+    def _reduce(self, part, out, groups, splits):
+        """out[g] = sum_k part[g*splits + k] (bf16 or fp32 partials -> fp32) with the HIP split-K reducer."""
+        n = out.numel() // groups
+        stream = torch.cuda.current_stream(out.device).cuda_stream
+        self.lib.check(self.lib.L.myo_splitk_reduce(C.c_void_p(part.data_ptr()), int(part.dtype == torch.bfloat16),
+                                                    C.c_void_p(out.data_ptr()), groups, splits, n, C.c_void_p(stream)))
+
+    def _relu_bwd_bias(self, dh, act, bias_grad):
+        """dh *= (act > 0) in place; bias_grad[g] = column sums of dh[g]  (dh, act: bf16 [G, B, H])."""
+        G, B, H = dh.shape
+        if B % 32 == 0 and H % 16 == 0 and 256 % (H // 2) == 0:
+            partial = torch.empty((G * B // 32, H), device=dh.device)
+            stream = torch.cuda.current_stream(dh.device).cuda_stream
+            self.lib.check(self.lib.L.myo_relu_bwd_colsum_bf16(C.c_void_p(dh.data_ptr()), C.c_void_p(act.data_ptr()), G * B, H,
+                                                               C.c_void_p(partial.data_ptr()), C.c_void_p(stream)))
+            self._reduce(partial, bias_grad, G, B // 32)
+            return dh
+        dh = torch.ops.aten.threshold_backward(dh, act, 0)
+        torch.sum(dh, 1, dtype=torch.float32, out=bias_grad)
+        return dh
+
+    def _loss_kernel(self, mean, values, actions, old_logp, adv, returns, dmean_h=None, dvalue_h=None):
+        pol = self.policy
+        B, A = mean.shape[0], self.A
+        dev = mean.device
+        dmean, dvalue = torch.empty((B, A), device=dev), torch.empty(B, device=dev)
+        work = self._workbuf("loss", ((B + 63) // 64) * (2 * A + 3))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        self.lib.check(self.lib.L.myo_ppo_loss_grad(
+            p(mean), p(values), p(actions), p(old_logp), p(adv), p(returns), p(pol.log_std.data), p(self.stats),
+            B, A, self.clip, self.vf, p(dmean), p(dvalue), p(self.acc), p(dmean_h), p(dvalue_h), p(work), C.c_void_p(stream)))
+        return dmean, dvalue
+
+    @torch.no_grad()
+    def run_indexed(self, obs_all, act_all, oldlp_all, adv_all, ret_all, idx):
+        """One minibatch step on rows `idx` of the rollout arrays (merged path: HIP gather kernel)."""
+        if self.merged is None:
+            return self.run(obs_all[idx], act_all[idx], oldlp_all[idx], adv_all[idx], ret_all[idx])
+        B, O, A = idx.shape[0], obs_all.shape[1], self.A
+        dev = obs_all.device
+        x2 = torch.empty((2, B, O), device=dev, dtype=torch.bfloat16)
+        act, oldlp = torch.empty((B, A), device=dev), torch.empty(B, device=dev)
+        adv, ret = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        work = self._workbuf("gather", 2 * ((B + 15) // 16))
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self.lib.check(self.lib.L.myo_ppo_gather(p(obs_all), p(act_all), p(oldlp_all), p(adv_all), p(ret_all), p(idx), B, O, A,
+                                                 p(x2), 2, p(act), p(oldlp), p(adv), p(ret), p(self.stats), p(work),
+                                                 C.c_void_p(stream)))
+        return self._merged_core(x2, act, oldlp, adv, ret)
+
+    @torch.no_grad()
+    def _run_merged(self, obs, actions, old_logp, adv, returns):
+        var, mu = torch.var_mean(adv)
+        self.stats[0].copy_(mu)
+        self.stats[1].copy_(var.sqrt())
+        x2 = obs.to(torch.bfloat16).unsqueeze(0).expand(2, obs.shape[0], obs.shape[1]).contiguous()
+        return self._merged_core(x2, actions, old_logp, adv, returns)
+
+    def _merged_core(self, x2, actions, old_logp, adv, returns):
+        """Actor and critic trunks as ONE batched GEMM per layer (batch = net), heads separate.
+        x2: bf16 [2, B, obs_dim] (the same minibatch twice); self.stats holds the advantage moments."""
+        pol, L = self.policy, self.merged
+        B, A = x2.shape[1], self.A
+        s = self.split if (B % self.split == 0) else 1
+        dev = x2.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        self.half[0].copy_(self.master[0])
+        h = x2
+        saved = [h]
+        for lay in L:
+            h = torch.bmm(h, lay["wh"].transpose(1, 2))
+            self.lib.check(self.lib.L.myo_bias_relu_bf16(C.c_void_p(h.data_ptr()), C.c_void_p(lay["bh"].data_ptr()), 2, B,
+                                                         h.shape[2], C.c_void_p(stream)))
+            saved.append(h)
+        pi_head, vf_head = self.nets["pi"][-1], self.nets["vf"][-1]
+        wpi, wvf = self.wb[id(pi_head.weight)], self.wb[id(vf_head.weight)]
+        mean = torch.addmm(self.wb[id(pi_head.bias)], h[0], wpi.t()).float()
+        values = torch.addmm(self.wb[id(vf_head.bias)], h[1], wvf.t()).float().reshape(B)
+        dmean_h = torch.empty((B, A), device=dev, dtype=torch.bfloat16)
+        dvalue_h = torch.empty((B, 1), device=dev, dtype=torch.bfloat16)
+        self._loss_kernel(mean, values, actions, old_logp, adv, returns, dmean_h, dvalue_h)
+        acc = self.acc
+        torch.sub(acc[:A], self.ent, out=pol.log_std.grad)
+        pi_head.bias.grad.copy_(acc[A + 2:2 * A + 2])
+        vf_head.bias.grad.copy_(acc[2 * A + 2:2 * A + 3])
+        # heads: dW (split-K) and the gradient entering the trunks
+        for dy, head, x in ((dmean_h, pi_head, h[0]), (dvalue_h, vf_head, h[1])):
+            part = torch.bmm(dy.view(s, B // s, -1).transpose(1, 2), x.view(s, B // s, -1))
+            self._reduce(part, head.weight.grad, 1, s)
+        dh = torch.empty_like(h)
+        torch.mm(dmean_h, wpi, out=dh[0])
+        torch.mm(dvalue_h, wvf, out=dh[1])
+        for li in reversed(range(len(L))):
+            lay, x = L[li], saved[li]
+            dh = self._relu_bwd_bias(dh, saved[li + 1], lay["bg"])
+            H, I = lay["wh"].shape[1], lay["wh"].shape[2]
+            part = torch.bmm(dh.view(2 * s, B // s, H).transpose(1, 2), x.reshape(2 * s, B // s, I))
+            self._reduce(part, lay["wg"], 2, s)
+            if li > 0:
+                dh = torch.bmm(dh, lay["wh"])
+        return acc[A], acc[A + 1]
 
     @torch.no_grad()
     def run(self, obs, actions, old_logp, adv, returns):
+        if self.merged is not None:
+            return self._run_merged(obs, actions, old_logp, adv, returns)
         pol = self.policy
         B, A = obs.shape[0], self.A
         torch._foreach_copy_(self.half, self.master)
@@ -200,13 +344,7 @@ class FusedPPOStep:
         var, mu = torch.var_mean(adv)                      # unbiased, as torch.std in SB3
         self.stats[0].copy_(mu)
         self.stats[1].copy_(var.sqrt())
-        dmean = torch.empty((B, A), device=obs.device)
-        dvalue = torch.empty(B, device=obs.device)
-        stream = torch.cuda.current_stream(obs.device).cuda_stream
-        p = lambda t: C.c_void_p(t.data_ptr())
-        self.lib.check(self.lib.L.myo_ppo_loss_grad(
-            p(mean), p(values), p(actions), p(old_logp), p(adv), p(returns), p(pol.log_std.data), p(self.stats),
-            B, A, self.clip, self.vf, p(dmean), p(dvalue), p(self.acc), C.c_void_p(stream)))
+        dmean, dvalue = self._loss_kernel(mean, values, actions, old_logp, adv, returns)
         torch.sub(self.acc[:A], self.ent, out=pol.log_std.grad)
         for name, dout in (("pi", dmean), ("vf", dvalue.unsqueeze(-1))):
             layers, saved = self.nets[name], acts[name]

@@ -313,8 +313,8 @@ class PPO:
             from .. import native
             from .fused_mlp import FusedPPOStep
             self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
-        pl, vl = self._fused.run(g["obs"][idx], g["act"][idx], g["oldlp"][idx], g["adv"][idx], g["ret"][idx])
-        g["pl"].copy_(pl); g["vl"].copy_(vl)      # gradients land in the flat vector (p.grad are views of it)
+        pl, vl = self._fused.run_indexed(g["obs"], g["act"], g["oldlp"], g["adv"], g["ret"], idx)
+        g["pl"], g["vl"] = pl, vl                 # views of the loss kernel's accumulator: no copies      # gradients land in the flat vector (p.grad are views of it)
 
     def _mb_apply(self):
         self._flat_adam.step(1.0 / self.world)    # all-reduce SUM ran in place on the flat gradient

@@ -86,38 +86,132 @@ def test_full_size_properties(hip_lib, dtype):
     assert n1 > 0 and n1 == n2 and torch.equal(h1, h2)
 
 
-def test_fused_ppo_step_matches_autograd(hip_lib):
-    """FusedPPOStep (bf16 GEMMs + myo_ppo_loss_grad HIP kernel) vs autograd of PPO._loss in fp32."""
+@pytest.mark.parametrize("merged", [False, True])
+def test_fused_ppo_step_matches_fp32_reference(hip_lib, merged):
+    """FusedPPOStep (bf16 GEMMs + HIP loss / gather / reduction kernels) vs the fp32 statement of the same
+    step (ppo_mlp_step_grads, itself checked against autograd on CPU).  `merged`: flat parameter vector,
+    actor/critic trunks as one batched GEMM per layer.  Tolerance: the policy-gradient terms
+    sum_i adv_i * dlogp_i cancel heavily, so bf16 rounding of the activations shows up as 6-7 % relative
+    gradient noise on the actor (measured, identical for both paths; the critic side is < 2 %); the HIP
+    kernels themselves are checked exactly in test_ppo_elementwise_kernels_exact."""
+    import copy
     import torch
-    from myochallenge_amd.rl.fused_mlp import FusedPPOStep
+    from myochallenge_amd.rl.fused_mlp import FusedPPOStep, flatten_parameters, ppo_mlp_step_grads
     from myochallenge_amd.rl.policy import ActorCriticPolicy
-    from myochallenge_amd.rl.ppo import PPO, PPOConfig
     torch.manual_seed(0)
     dev = torch.device("cuda:0")
     pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None).to(dev)
+    ref_pol = copy.deepcopy(pol)
     B = 4096
-    obs, act = torch.randn(B, 86, device=dev), torch.randn(B, 39, device=dev) * 0.3
-    with torch.no_grad():
-        oldlp = pol.evaluate_actions(obs, act)[1] + torch.randn(B, device=dev) * 0.3
+    obs = torch.randn(B, 86, device=dev)
+    with torch.no_grad():       # on-policy data as in a real update: actions from the policy, ratios near 1
+        act = pol.act(obs, None, None)[0]
+        oldlp = pol.evaluate_actions(obs, act)[1] + torch.randn(B, device=dev) * 0.05
     adv, ret = torch.randn(B, device=dev), torch.randn(B, device=dev)
-
-    class E:
-        num_envs, obs_dim, act_dim, device = 4, 86, 39, dev
-    algo = PPO(E(), pol, PPOConfig(n_steps=2, clip_range=0.2, ent_coef=0.01, vf_coef=0.7, bf16=True, use_graphs=False))
-    with algo._autocast():                      # same bf16 GEMM precision as the fused path
-        v, lp, ent = pol.evaluate_actions(obs, act)
-    loss, pl_ref, vl_ref = algo._loss(v, lp, ent, oldlp, adv, ret)
-    pol.zero_grad(); loss.backward()
-    ref = [p.grad.clone() for p in pol.parameters()]
-    for p in pol.parameters():
-        p.grad = None
+    pl_ref, vl_ref = ppo_mlp_step_grads(ref_pol, obs, act, oldlp, adv, ret, 0.2, 0.01, 0.7, bf16=False)
+    ref = [p.grad.clone() for p in ref_pol.parameters()]
+    if merged:
+        flatten_parameters(pol)
     step = FusedPPOStep(pol, hip_lib, 0.2, 0.01, 0.7)
+    assert (step.merged is not None) == merged
     pl, vl = step.run(obs, act, oldlp, adv, ret)
     torch.cuda.synchronize()
-    assert abs(float(pl - pl_ref)) < 2e-2 * max(1.0, abs(float(pl_ref))) and abs(float(vl - vl_ref)) < 2e-2 * float(vl_ref)
+    assert abs(float(pl - pl_ref)) < 2e-3 and abs(float(vl - vl_ref)) < 2e-2 * float(vl_ref)
     for (name, p), r in zip(pol.named_parameters(), ref):
         err = float((p.grad - r).norm() / (r.norm() + 1e-12))
-        assert err < 4e-2, (name, err)          # both sides bf16 GEMMs; different rounding points
+        critic = "value_net" in name
+        assert err < (6e-2 if critic else 0.10), (name, err)
+    if merged:      # the indexed entry (HIP gather + advantage moments) == run() on the gathered rows
+        g_run = [p.grad.clone() for p in pol.parameters()]
+        perm = torch.randperm(B, device=dev)
+        inv = torch.argsort(perm)
+        pl2, vl2 = step.run_indexed(obs[perm], act[perm], oldlp[perm], adv[perm], ret[perm], inv)
+        torch.cuda.synchronize()
+        assert abs(float(pl2 - pl)) < 1e-5 and abs(float(vl2 - vl)) < 1e-5
+        for (name, p), r in zip(pol.named_parameters(), g_run):
+            assert float((p.grad - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-9, name
+
+
+def test_ppo_elementwise_kernels_exact(hip_lib):
+    """myo_ppo_loss_grad, myo_ppo_gather, myo_bias_relu_bf16, myo_relu_bwd_colsum_bf16 and
+    myo_splitk_reduce against plain torch on the same inputs (fp32 formulas: tight tolerances)."""
+    import ctypes as C
+    import math
+    import torch
+    L = hip_lib.L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    B, A, O = 1000, 39, 86                        # ragged: not a multiple of the 64-row blocks
+    mean, act = torch.randn(B, A, device=dev) * 0.2, torch.randn(B, A, device=dev) * 0.3
+    values, ret, adv = torch.randn(B, device=dev), torch.randn(B, device=dev), torch.randn(B, device=dev)
+    log_std = torch.full((A,), -1.0, device=dev) + 0.1 * torch.randn(A, device=dev)
+    z = (act - mean) * torch.exp(-log_std)
+    logp = (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+    oldlp = logp + 0.3 * torch.randn(B, device=dev)
+    stats = torch.stack([adv.mean(), adv.std()])
+    clip, vf = 0.2, 0.7
+    an = (adv - stats[0]) / (stats[1] + 1e-8)
+    ratio = torch.exp(logp - oldlp)
+    s1, s2 = an * ratio, an * torch.clamp(ratio, 1 - clip, 1 + clip)
+    inside = (ratio > 1 - clip) & (ratio < 1 + clip)
+    dlogp = -(an * ratio) * torch.where(s1 <= s2, torch.ones_like(ratio), inside.float()) / B
+    dmean_ref = dlogp[:, None] * z * torch.exp(-log_std)
+    dval_ref = vf * 2.0 / B * (values - ret)
+    acc_ref = torch.cat([(dlogp[:, None] * (z * z - 1)).sum(0), (-torch.min(s1, s2).mean()).view(1),
+                         ((values - ret) ** 2).mean().view(1), dmean_ref.sum(0), dval_ref.sum().view(1)])
+    dmean, dval = torch.empty(B, A, device=dev), torch.empty(B, device=dev)
+    dmean_h = torch.empty(B, A, device=dev, dtype=torch.bfloat16)
+    dval_h = torch.empty(B, device=dev, dtype=torch.bfloat16)
+    acc = torch.full((2 * A + 3,), 7.0, device=dev)
+    work = torch.empty(((B + 63) // 64) * (2 * A + 3), device=dev)
+    hip_lib.check(L.myo_ppo_loss_grad(p(mean), p(values), p(act), p(oldlp), p(adv), p(ret), p(log_std), p(stats), B, A, clip, vf,
+                                      p(dmean), p(dval), p(acc), p(dmean_h), p(dval_h), p(work), None))
+    torch.cuda.synchronize()
+    tol = lambda a, b, r: float((a - b).abs().max()) <= r * float(b.abs().max()) + 1e-12
+    assert tol(dmean, dmean_ref, 2e-5) and tol(dval, dval_ref, 1e-6) and tol(acc, acc_ref, 2e-5)
+    assert torch.equal(dmean_h, dmean.bfloat16()) and torch.equal(dval_h, dval.bfloat16())
+
+    N = 5000
+    obs_all, act_all = torch.randn(N, O, device=dev), torch.randn(N, A, device=dev)
+    lp_all, adv_all, ret_all = torch.randn(N, device=dev), torch.randn(N, device=dev) + 3.0, torch.randn(N, device=dev)
+    idx = torch.randperm(N, device=dev)[:B]
+    x2 = torch.empty(2, B, O, device=dev, dtype=torch.bfloat16)
+    a_mb, lp_mb, adv_mb, ret_mb = (torch.empty(B, A, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev),
+                                   torch.empty(B, device=dev))
+    st = torch.empty(2, device=dev)
+    work = torch.empty(2 * ((B + 15) // 16), device=dev)
+    hip_lib.check(L.myo_ppo_gather(p(obs_all), p(act_all), p(lp_all), p(adv_all), p(ret_all), p(idx), B, O, A, p(x2), 2, p(a_mb),
+                                   p(lp_mb), p(adv_mb), p(ret_mb), p(st), p(work), None))
+    torch.cuda.synchronize()
+    assert torch.equal(x2[0], obs_all[idx].bfloat16()) and torch.equal(x2[1], x2[0])
+    assert torch.equal(a_mb, act_all[idx]) and torch.equal(lp_mb, lp_all[idx]) and torch.equal(adv_mb, adv_all[idx])
+    assert torch.equal(ret_mb, ret_all[idx])
+    assert abs(float(st[0] - adv_all[idx].mean())) < 1e-5 and abs(float(st[1] - adv_all[idx].std())) < 1e-5
+
+    G, R, Cn = 2, 4096, 256
+    h = torch.randn(G, R, Cn, device=dev).bfloat16()
+    bias = torch.randn(G, Cn, device=dev).bfloat16()
+    want = torch.relu(h.float() + bias.float()[:, None, :]).bfloat16()
+    hip_lib.check(L.myo_bias_relu_bf16(p(h), p(bias), G, R, Cn, None))
+    torch.cuda.synchronize()
+    assert torch.equal(h, want)
+
+    dy = torch.randn(G, R, Cn, device=dev).bfloat16()
+    want_dy = torch.where(h > 0, dy, torch.zeros_like(dy))
+    partial = torch.empty(G * R // 32, Cn, device=dev)
+    hip_lib.check(L.myo_relu_bwd_colsum_bf16(p(dy), p(h), G * R, Cn, p(partial), None))
+    colsum = torch.empty(G, Cn, device=dev)
+    hip_lib.check(L.myo_splitk_reduce(p(partial), 0, p(colsum), G, R // 32, Cn, None))
+    torch.cuda.synchronize()
+    assert torch.equal(dy, want_dy)
+    assert tol(colsum, want_dy.float().sum(1), 1e-5)
+
+    part = torch.randn(2 * 32, 256, 86, device=dev).bfloat16()
+    out = torch.empty(2, 256, 86, device=dev)
+    hip_lib.check(L.myo_splitk_reduce(p(part), 1, p(out), 2, 32, 256 * 86, None))
+    torch.cuda.synchronize()
+    assert tol(out, part.view(2, 32, 256, 86).float().sum(1), 1e-6)
 
 
 def test_gae_kernel_matches_torch_scan(hip_lib):

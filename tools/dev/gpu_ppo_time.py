@@ -1,4 +1,5 @@
-import time, torch
+"""Time the PPO update alone (graph replay) and list the kernels of one minibatch step."""
+import sys, time, torch
 from myochallenge_amd.envs.environment_factory import EnvironmentFactory
 from myochallenge_amd.rl.policy import ActorCriticPolicy
 from myochallenge_amd.rl.ppo import PPO, PPOConfig
@@ -10,22 +11,14 @@ algo = PPO(venv, pol, PPOConfig(n_steps=64, batch_size=16384, n_epochs=10))
 def sync(): torch.cuda.synchronize()
 algo.collect_rollouts(); sync()
 t=time.time(); algo.train(); sync(); print("first train (capture)", time.time()-t)
-t=time.time(); algo.train(); sync(); print("train", time.time()-t, "per opt step ms", (time.time()-t)/160*1e3)
-g=algo._gs
+t=time.time(); algo.train(); sync(); dt=time.time()-t; print("train", dt, "per opt step ms", dt/160*1e3)
 t=time.time()
-for _ in range(50): algo._graph_fb.replay()
-sync(); print("graph_fb replay ms", (time.time()-t)/50*1e3)
-t=time.time()
-for _ in range(50): algo._graph_ap.replay()
-sync(); print("graph_ap replay ms", (time.time()-t)/50*1e3)
-t=time.time()
-for _ in range(10): perm = torch.randperm(262144, generator=algo.gen).to("cuda")
-sync(); print("randperm+h2d ms", (time.time()-t)/10*1e3)
-t=time.time()
-for _ in range(50): g["idx"].copy_(perm[:16384])
-sync(); print("idx copy ms", (time.time()-t)/50*1e3)
-from myochallenge_amd.rl.ppo import compute_gae
-t=time.time()
-for _ in range(5): compute_gae(algo.rew_buf, algo.val_buf, algo.start_buf, algo._last_values, algo._last_starts, 0.99, 0.95)
-sync(); print("gae ms", (time.time()-t)/5*1e3)
+for _ in range(100): algo._graph_fb.replay()
+sync(); print("graph_fb replay ms", (time.time()-t)/100*1e3)
+if len(sys.argv) > 1:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        for _ in range(5): algo._graph_fb.replay()
+        sync()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
 t=time.time(); algo.collect_rollouts(); sync(); print("rollout 64 steps s", time.time()-t)

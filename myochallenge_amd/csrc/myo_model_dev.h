@@ -28,8 +28,8 @@
   X(geom_bodyid) X(geom_priority) X(site_bodyid) X(tendon_adr) X(tendon_num) X(tendon_limited)   \
   X(wrap_type) X(wrap_objid) X(wrap_side) X(actuator_dyntype) X(actuator_gaintype)               \
   X(actuator_biastype) X(actuator_tendon) X(actuator_ctrllimited) X(actuator_forcelimited)       \
-  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e)
-#define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask)
+  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj)
+#define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask) X(act_dofmask)
 #define MYO_MODEL_REAL_ARRAYS(X)                                                                 \
   X(qpos0) X(qpos_spring) X(body_pos) X(body_quat) X(body_ipos) X(body_imat) X(body_mass)        \
   X(body_inertia) X(body_invweight0) X(jnt_solref) X(jnt_solimp) X(jnt_pos) X(jnt_axis)          \
@@ -39,20 +39,39 @@
   X(tendon_solimp_lim) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping)    \
   X(tendon_lengthspring) X(tendon_invweight0) X(wrap_prm) X(actuator_dynprm)                     \
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
-  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange)
+  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0)
+
+// Model table handle.  The tables are immutable for the lifetime of a batch, so the gfx950 build
+// reads them through the CONSTANT address space: a load with a wave-uniform index becomes a scalar
+// (SMEM) load instead of a 64-lane vector load, and LLVM may treat every table load as invariant
+// (hoisting / CSE across LDS stores and calls).  `arr + k` decays to a plain pointer as before.
+template <typename U>
+struct MyoCArr {
+  const U* p;
+#if defined(__HIP_DEVICE_COMPILE__)
+  template <typename I> __device__ __attribute__((always_inline)) U operator[](I i) const {
+    typedef const U __attribute__((address_space(4))) * cptr;
+    return ((cptr)(unsigned long long)p)[i];
+  }
+  __device__ __attribute__((always_inline)) operator const U*() const { return p; }
+#else
+  template <typename I> U operator[](I i) const { return p[i]; }
+  operator const U*() const { return p; }
+#endif
+};
 
 template <typename T>
 struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
   int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead;
   T timestep, tolerance, impratio, gravity[3], meaninertia;
-#define X(n) const int* n;
+#define X(n) MyoCArr<int> n;
   MYO_MODEL_INT_ARRAYS(X)
 #undef X
-#define X(n) const unsigned long long* n;
+#define X(n) MyoCArr<unsigned long long> n;
   MYO_MODEL_U64_ARRAYS(X)
 #undef X
-#define X(n) const T* n;
+#define X(n) MyoCArr<T> n;
   MYO_MODEL_REAL_ARRAYS(X)
 #undef X
 };

@@ -1467,15 +1467,20 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
     }
   }
   SYNC();
+  // qfrc_actuator = moment' * force.  lane = dof; the actuator loop runs over the zero-padded
+  // actuator-major tables in groups of 8 (uniform index: scalar loads, no dependent chain)
   PHASE {
     const int d = lane;
     if (d < M.nv) {
       T acc = 0;
-      for (int i = 0; i < M.nu; ++i) {
-        const int t = M.actuator_tendon[i];
-        const unsigned long long m = M.tendon_dofmask[t];
-        if ((m >> d) & 1ull)
-          acc += M.actuator_gear[6 * i] * s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * s.act_force[i];
+      const unsigned long long below = (1ull << d) - 1ull;
+      for (int i0 = 0; i0 < M.nu; i0 += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int i = i0 + k;
+          const unsigned long long m = M.act_dofmask[i];
+          if ((m >> d) & 1ull) acc += M.act_gear0[i] * s.ten_J[M.act_tj[i] + myo_popcll(m & below)] * s.act_force[i];
+        }
       }
       S_QFRC_ACTUATOR(s)[d] = acc;
       s.qfrc_smooth[d] = S_QFRC_PASSIVE(s)[d] - S_QFRC_BIAS(s)[d] + acc;
@@ -1839,7 +1844,7 @@ DEVFN void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_i
     advance(M, s, LOFF(s, s.rk->dX + 2 * nv), LOFF(s, s.rk->dX + nv), LOFF(s, s.rk->dX));
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
-    load_H_from_M(M, s, M.dof_damping, M.timestep);
+    load_H_from_M(M, s, (const T*)M.dof_damping, M.timestep);
     PHASE { const int c = lane; if (c < M.nv) s.tmpv[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }
     SYNC();
     chol_factor_solve(s, s.tmpv, M.nv, M.nlead);

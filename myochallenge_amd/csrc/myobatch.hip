@@ -217,6 +217,16 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   }
   m->actuator_tendon.resize(m->nu);
   for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
+  // actuator-major copies for the moment-transpose gather, zero-padded to MYO_NU_MAX so the loop
+  // runs in unconditional groups of 8 (scalar loads merge into s_load_dwordx8/x16)
+  m->act_dofmask.assign(MYO_NU_MAX, 0ull);
+  m->act_tj.assign(MYO_NU_MAX, 0);
+  m->act_gear0.assign(MYO_NU_MAX, 0.0);
+  for (int i = 0; i < m->nu; ++i) {
+    m->act_dofmask[i] = m->tendon_dofmask[m->actuator_tendon[i]];
+    m->act_tj[i] = m->actuator_tendon[i] * MYO_TJ_MAX;
+    m->act_gear0[i] = m->actuator_gear[6 * i];
+  }
   for (int b = 0; b < nb; ++b) {
     int cnt = 0;
     for (unsigned long long x = m->body_dofmask[b]; x; x &= x - 1) cnt++;
@@ -305,7 +315,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
     rc |= be_malloc(&p, m->n.size() * sizeof(int));                                     \
     if (!rc && !m->n.empty()) rc |= be_h2d(p, m->n.data(), m->n.size() * sizeof(int));  \
     allocs.push_back(p);                                                                \
-    D.n = (const int*)p;                                                                \
+    D.n.p = (const int*)p;                                                              \
   }
   MYO_MODEL_INT_ARRAYS(X)
 #undef X
@@ -315,7 +325,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
     rc |= be_malloc(&p, m->n.size() * sizeof(unsigned long long));                                         \
     if (!rc && !m->n.empty()) rc |= be_h2d(p, m->n.data(), m->n.size() * sizeof(unsigned long long));      \
     allocs.push_back(p);                                                                                   \
-    D.n = (const unsigned long long*)p;                                                                    \
+    D.n.p = (const unsigned long long*)p;                                                                  \
   }
   MYO_MODEL_U64_ARRAYS(X)
 #undef X
@@ -326,7 +336,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
     rc |= be_malloc(&p, tmp.size() * sizeof(T));                              \
     if (!rc && !tmp.empty()) rc |= be_h2d(p, tmp.data(), tmp.size() * sizeof(T)); \
     allocs.push_back(p);                                                      \
-    D.n = (const T*)p;                                                        \
+    D.n.p = (const T*)p;                                                      \
   }
   MYO_MODEL_REAL_ARRAYS(X)
 #undef X

@@ -507,21 +507,37 @@ DEV T wrap_geom(T* wpnt, const T* x0, const T* x1, const T* gpos, const T* gmat,
 // moment contribution of one straight tendon segment p0 (on body b0) -> p1 (on body b1).
 // Dofs that move both bodies contribute axis x (p1-p0) . u = 0, so only the symmetric
 // difference of the two ancestor-dof masks is visited.
+// moment contribution of one straight tendon segment p0 (on a body with dof mask m0, tree root
+// r0) -> p1 (m1, r1) with unit direction u: the dofs that move exactly one of the two end points
 template <typename T>
-DEV void tendon_segment_moment(const DevModel<T>& M, const Scratch<T>& s, T* Jrow, unsigned long long tmask,
-                               int b0, const T* p0, int b1, const T* p1, const T* u, T inv_div) {
-  const unsigned long long m0 = M.body_dofmask[b0], m1 = M.body_dofmask[b1];
+DEV void tendon_segment_moment(const Scratch<T>& s, T* Jrow, unsigned long long tmask, unsigned long long m0, int r0,
+                               const T* p0, unsigned long long m1, int r1, const T* p1, const T* u, T inv_div) {
   unsigned long long x = (m0 ^ m1) & tmask;
   while (x) {
     const int d = myo_ffsll(x);
     x &= x - 1;
-    T col[3];
     const int on1 = (int)((m1 >> d) & 1ull);
-    jac_col(M, s, d, on1 ? p1 : p0, col);
+    const T* p = on1 ? p1 : p0;
+    const T* c = s.com + 3 * (on1 ? r1 : r0);
+    const T* cd = s.cdof + 6 * d;
+    const T off[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    T t[3];
+    cross3(t, cd, off);
+    const T col[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
     const T v = dot3(col, u) * inv_div;
     const int slot = myo_popcll(tmask & ((1ull << d) - 1ull));
     Jrow[slot] += on1 ? v : -v;
   }
+}
+
+// One wrap object as the tendon stage sees it (resolved on the host, see upload: wr_i / wr_p / wr_m /
+// wr_mask): a single level of table loads per path element instead of type -> objid -> body -> pos.
+template <typename T> struct WrapRec { int type, body, geom, side_body, root, side_root; T pos[3], prm; unsigned long long mask; };
+template <typename T> DEV void load_wrap(const DevModel<T>& M, int w, WrapRec<T>& r) {
+  r.type = M.wr_i[8 * w]; r.body = M.wr_i[8 * w + 1]; r.geom = M.wr_i[8 * w + 2]; r.side_body = M.wr_i[8 * w + 3];
+  r.root = M.wr_i[8 * w + 4]; r.side_root = M.wr_i[8 * w + 5];
+  r.pos[0] = M.wr_p[4 * w]; r.pos[1] = M.wr_p[4 * w + 1]; r.pos[2] = M.wr_p[4 * w + 2]; r.prm = M.wr_p[4 * w + 3];
+  r.mask = M.wr_mask[w];
 }
 
 template <typename T>
@@ -537,43 +553,49 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
       for (int k = 0; k < MYO_TJ_MAX; ++k) J[k] = 0;
       T len = 0, divisor = 1;
       int j = 0;
+      WrapRec<T> w0, w1, w2;
+      if (num > 0) load_wrap(M, adr, w0);
       while (j < num - 1) {
-        const int type0 = M.wrap_type[adr + j], type1 = M.wrap_type[adr + j + 1];
-        const int id0 = M.wrap_objid[adr + j];
-        int id1 = M.wrap_objid[adr + j + 1];
-        if (type0 == 2 || type1 == 2) {
-          if (type0 == 2) divisor = M.wrap_prm[adr + j];
+        // the records of the next two path elements do not depend on anything computed here
+        load_wrap(M, adr + j + 1, w1);
+        const int have2 = (j + 2 < num);
+        if (have2) load_wrap(M, adr + j + 2, w2);
+        if (w0.type == 2 || w1.type == 2) {
+          if (w0.type == 2) divisor = w0.prm;
           j++;
+          w0 = w1;
           continue;
         }
         T wpnt[12];
-        int wbody[4], wcnt, idg = -1;
+        int wcnt;
         T wlen = -1;
-        wbody[0] = M.site_bodyid[id0];
-        body_point(s, wbody[0], M.site_pos + 3 * id0, wpnt);
+        body_point(s, w0.body, w0.pos, wpnt);
         T x1[3];
-        if (type1 == 4 || type1 == 5) {
-          idg = id1;
-          id1 = M.wrap_objid[adr + j + 2];
-          const int b1 = M.site_bodyid[id1];
-          body_point(s, b1, M.site_pos + 3 * id1, x1);
-          const int gb = M.geom_bodyid[idg];
-          T gpos[3], gmat[9], side[3] = {0, 0, 0};
-          body_point(s, gb, M.geom_pos + 3 * idg, gpos);
-          mulmat3(gmat, s.xmat + 9 * gb, M.geom_mat + 9 * idg);
-          const int sid = M.wrap_side[adr + j + 1];
-          if (sid >= 0) body_point(s, M.site_bodyid[sid], M.site_pos + 3 * sid, side);
-          wlen = wrap_geom(wpnt + 3, wpnt, x1, gpos, gmat, geom_size0_of(M, K, s, idg), type1, side, sid >= 0);
-        } else {
-          body_point(s, M.site_bodyid[id1], M.site_pos + 3 * id1, x1);
+        const int is_geom = (w1.type == 4 || w1.type == 5);
+        const WrapRec<T>& we = is_geom ? w2 : w1;      // the site that ends this path element
+        body_point(s, we.body, we.pos, x1);
+        if (is_geom) {
+          const int w = adr + j + 1;
+          T gpos[3], gmat[9], gm[9], side[3] = {0, 0, 0};
+          body_point(s, w1.body, w1.pos, gpos);
+          for (int k = 0; k < 9; ++k) gm[k] = M.wr_m[12 * w + k];
+          mulmat3(gmat, s.xmat + 9 * w1.body, gm);
+          if (w1.side_body >= 0) {
+            const T sl[3] = {M.wr_m[12 * w + 9], M.wr_m[12 * w + 10], M.wr_m[12 * w + 11]};
+            body_point(s, w1.side_body, sl, side);
+          }
+          wlen = wrap_geom(wpnt + 3, wpnt, x1, gpos, gmat, geom_size0_of(M, K, s, w1.geom), w1.type, side, w1.side_body >= 0);
         }
+        unsigned long long wm[4];
+        int wr[4], wb[4];
+        wm[0] = w0.mask; wr[0] = w0.root; wb[0] = w0.body;
         if (wlen < 0) {
-          wbody[1] = M.site_bodyid[id1];
+          wm[1] = we.mask; wr[1] = we.root; wb[1] = we.body;
           wpnt[3] = x1[0]; wpnt[4] = x1[1]; wpnt[5] = x1[2];
           wcnt = 2;
         } else {
-          wbody[1] = wbody[2] = M.geom_bodyid[idg];
-          wbody[3] = M.site_bodyid[id1];
+          wm[1] = wm[2] = w1.mask; wr[1] = wr[2] = w1.root; wb[1] = wb[2] = w1.body;
+          wm[3] = we.mask; wr[3] = we.root; wb[3] = we.body;
           wpnt[9] = x1[0]; wpnt[10] = x1[1]; wpnt[11] = x1[2];
           wcnt = 4;
         }
@@ -583,12 +605,12 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
           T dif[3] = {wpnt[3 * k + 3] - wpnt[3 * k], wpnt[3 * k + 4] - wpnt[3 * k + 1], wpnt[3 * k + 5] - wpnt[3 * k + 2]};
           const T dn = norm3(dif);
           len += dn * inv_div;
-          if (wbody[k] != wbody[k + 1] && dn > MYO_MINVAL) {
+          if (wb[k] != wb[k + 1] && dn > MYO_MINVAL) {
             dif[0] /= dn; dif[1] /= dn; dif[2] /= dn;
-            tendon_segment_moment(M, s, J, tmask, wbody[k], wpnt + 3 * k, wbody[k + 1], wpnt + 3 * k + 3, dif, inv_div);
+            tendon_segment_moment(s, J, tmask, wm[k], wr[k], wpnt + 3 * k, wm[k + 1], wr[k + 1], wpnt + 3 * k + 3, dif, inv_div);
           }
         }
-        j += (idg >= 0 ? 2 : 1);
+        if (is_geom) { j += 2; w0 = w2; } else { j += 1; w0 = w1; }
       }
       s.ten_length[t] = len;
     }

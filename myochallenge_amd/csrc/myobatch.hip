@@ -215,6 +215,38 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
     for (unsigned long long x = mk; x; x &= x - 1) cnt++;
     LIM(cnt > MYO_TJ_MAX, "a tendon moves more than MYO_TJ_MAX dofs")
   }
+  // resolved wrap records: everything the tendon stage needs about wrap object w behind ONE level of
+  // indexing (the stage is bound by dependent table loads otherwise: type -> objid -> bodyid -> pos):
+  //   wr_i[8w..]  = type, body (site / geom body), geom id (-1), side-site body (-1), root body of
+  //                 `body`, root body of the side-site body, 0, 0
+  //   wr_p[4w..]  = local position (site_pos / geom_pos), pulley divisor
+  //   wr_m[12w..] = geom_mat (9), side-site local position (3)
+  //   wr_mask[w]  = body_dofmask[body]
+  m->wr_i.assign(8 * (size_t)m->nwrap, 0);
+  m->wr_p.assign(4 * (size_t)m->nwrap, 0.0);
+  m->wr_m.assign(12 * (size_t)m->nwrap, 0.0);
+  m->wr_mask.assign(m->nwrap, 0ull);
+  for (int w = 0; w < m->nwrap; ++w) {
+    const int ty = m->wrap_type[w], id = m->wrap_objid[w];
+    int* I = &m->wr_i[8 * (size_t)w];
+    I[0] = ty; I[1] = -1; I[2] = -1; I[3] = -1; I[4] = 0; I[5] = 0;
+    if (ty == MYO_WRAP_SITE) {
+      I[1] = m->site_bodyid[id];
+      for (int k = 0; k < 3; ++k) m->wr_p[4 * (size_t)w + k] = m->site_pos[3 * id + k];
+    } else if (ty == MYO_WRAP_SPHERE || ty == MYO_WRAP_CYLINDER) {
+      I[1] = m->geom_bodyid[id]; I[2] = id;
+      for (int k = 0; k < 3; ++k) m->wr_p[4 * (size_t)w + k] = m->geom_pos[3 * id + k];
+      double gm[9];
+      quat2mat_h(&geom_quat[4 * id], gm);
+      for (int k = 0; k < 9; ++k) m->wr_m[12 * (size_t)w + k] = gm[k];
+      const int sid = m->wrap_side[w];
+      if (sid >= 0) {
+        I[3] = m->site_bodyid[sid]; I[5] = m->body_rootid[I[3]];
+        for (int k = 0; k < 3; ++k) m->wr_m[12 * (size_t)w + 9 + k] = m->site_pos[3 * sid + k];
+      }
+    } else if (ty == MYO_WRAP_PULLEY) m->wr_p[4 * (size_t)w + 3] = m->wrap_prm[w];
+    if (I[1] >= 0) { I[4] = m->body_rootid[I[1]]; m->wr_mask[w] = m->body_dofmask[I[1]]; }
+  }
   m->actuator_tendon.resize(m->nu);
   for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
   // actuator-major copies for the moment-transpose gather, zero-padded to MYO_NU_MAX so the loop

@@ -167,6 +167,34 @@ int myo_splitk_reduce(const void* part, int part_is_bf16, float* out, int groups
  * bias gradient).  rows % 32 == 0, cols/2 divides 256. */
 int myo_relu_bwd_colsum_bf16(uint16_t* dy, const uint16_t* act, int rows, int cols, float* partial, void* stream);
 
+/* ---- per-step rollout plumbing (between two myo_batch_step launches) ------------------------------
+ * `t_idx`: dev int32 = rollout-buffer row of the current step; `draw_counter`: dev uint64[2] (Philox
+ * stream position, [1] is the pending value).  Buffers are dev float32, row-major [T, N, ...].
+ *
+ * policy input: obs [N,O] -> obs_buf[t] (may be NULL) and `copies` stacked bfloat16 copies. */
+int myo_rollout_policy_input(const float* obs, int N, int O, float* obs_buf, uint16_t* x_bf16, int copies,
+                             const int32_t* t_idx, void* stream);
+/* SB3 DiagGaussianDistribution sample + log_prob (RecurrentPPO.collect_rollouts ->
+ * policy.forward, /root/reference/src/train/trainer.py:66-71): a = mean + exp(log_std) * eps, eps from
+ * Philox4x32-10(seed, draw_counter[0]); writes act_buf[t], val_buf[t] (from value_bf16), logp_buf[t]
+ * and clipped = clip(a, -1, 1) [N,A] (the env input). */
+int myo_rollout_sample(const uint16_t* mean_bf16, const uint16_t* value_bf16, const float* log_std, int N, int A,
+                       uint64_t seed, uint64_t* draw_counter, const int32_t* t_idx, float* act_buf, float* val_buf,
+                       float* logp_buf, float* clipped, int deterministic, void* stream);
+/* stable_baselines3 VecNormalize.step_wait for one batched step (VecNormalize.load / .normalize_obs:
+ * /root/reference/src/main_baoding.py:75, src/metrics/custom_callbacks.py:34): running mean/var of obs
+ * and of the discounted return (Chan merge, fp64, in place: obs_mean[O] obs_var[O] obs_count[1],
+ * ret_stats[3] = mean,var,count, returns[N]), normalised + clipped obs -> nobs [N,O], reward ->
+ * rew_buf[t], terminal obs -> term_buf[t] (may be NULL), trunc -> trunc_buf[t] (may be NULL),
+ * start_buf[t] <- starts, starts <- done.  work: dev double [ceil(N/128) * 2 * (O+1)]. */
+int myo_vecnorm_step(const float* obs, const float* rew, const uint8_t* done, const uint8_t* trunc, const float* term_obs,
+                     int N, int O, double* obs_mean, double* obs_var, double* obs_count, double* ret_stats,
+                     double* returns, double gamma, double eps, double clip_obs, double clip_rew, int training,
+                     int norm_obs, int norm_reward, float* nobs, float* starts, const int32_t* t_idx, float* rew_buf,
+                     float* start_buf, float* term_buf, float* trunc_buf, double* work, void* stream);
+/* t_idx <- (t_idx + 1) mod T, commit the Philox position. */
+int myo_rollout_advance(int32_t* t_idx, int T, uint64_t* draw_counter, void* stream);
+
 /* GAE(gamma, lambda) backward scan = SB3 RolloutBuffer.compute_returns_and_advantage (run by
  * RecurrentPPO.learn, /root/reference/src/train/trainer.py:66-71).  dev float32 [T,N] row-major:
  * rew, val, starts (episode_starts), outputs adv, ret; last_val[N], last_done[N]. */

@@ -1119,6 +1119,237 @@ extern "C" int myo_relu_bwd_colsum_bf16(uint16_t* dy, const uint16_t* act, int r
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ rollout
+// The per-step plumbing between two env kernels (policy input, action sampling, VecNormalize, rollout
+// buffer writes) as a handful of launches instead of ~80 small framework kernels.  `t_idx` is a
+// DEVICE int32 holding the rollout-buffer row of the current step, so the same launches replay from a
+// hipGraph for every step.
+#ifndef MYO_EMU
+// obs (f32 [N,O]) -> obs_buf[t] (f32) and `copies` stacked bf16 copies (GEMM operand of the trunks)
+__global__ void __launch_bounds__(256) k_obs_prepare(const float* __restrict__ obs, size_t n, float* __restrict__ obs_buf,
+                                                     unsigned short* __restrict__ x_h, int copies, const int* __restrict__ t_idx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = obs[i];
+  if (obs_buf) obs_buf[(size_t)(*t_idx) * n + i] = v;
+  const unsigned short h = myo_f2bf(v);
+  for (int k = 0; k < copies; ++k) x_h[(size_t)k * n + i] = h;
+}
+// DiagGaussian sampling (SB3 DiagGaussianDistribution: a = mu + exp(log_std) eps; log-prob summed over
+// dims) for N rows, one wave per 64 rows x loop over action dims; Philox4x32-10 keyed by (seed, rollout
+// step counter), Box-Muller.  Writes act_buf[t], val_buf[t], logp_buf[t] and the clipped actions.
+__global__ void __launch_bounds__(64) k_sample_actions(const unsigned short* __restrict__ mean_h, const unsigned short* __restrict__ value_h,
+                                                       const float* __restrict__ log_std, int N, int A, unsigned long long seed,
+                                                       unsigned long long* __restrict__ draw_counter, const int* __restrict__ t_idx,
+                                                       float* __restrict__ act_buf, float* __restrict__ val_buf,
+                                                       float* __restrict__ logp_buf, float* __restrict__ clipped, int deterministic) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= N) return;
+  const size_t t = (size_t)(*t_idx);
+  const unsigned long long ctr = *draw_counter;
+  float logp = 0.f;
+  for (int a0 = 0; a0 < A; a0 += 4) {
+    unsigned int c[4] = {(unsigned int)i, (unsigned int)(a0 >> 2), (unsigned int)ctr, (unsigned int)(ctr >> 32)};
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    float z[4];
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * __logf(u1));
+      float sn, cs;
+      __sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+    }
+    for (int k = 0; k < 4 && a0 + k < A; ++k) {
+      const int a = a0 + k;
+      const float ls = log_std[a];
+      const float mu = __uint_as_float(((unsigned)mean_h[(size_t)i * A + a]) << 16);
+      const float act = deterministic ? mu : mu + __expf(ls) * z[k];
+      const float zz = (act - mu) * __expf(-ls);
+      logp += -0.5f * zz * zz - ls - 0.9189385332046727f;
+      act_buf[(t * N + i) * A + a] = act;
+      clipped[(size_t)i * A + a] = fminf(fmaxf(act, -1.f), 1.f);
+    }
+  }
+  logp_buf[t * N + i] = logp;
+  val_buf[t * N + i] = __uint_as_float(((unsigned)value_h[i]) << 16);
+  if (blockIdx.x == 0 && threadIdx.x == 0) draw_counter[1] = ctr + 1;   // committed by k_rollout_advance
+}
+// VecNormalize.step_wait (SB3 1.6.2), kernel 1 of 3: per-block fp64 moments of the raw
+// observation columns over 128-row chunks, discounted-return update ret = ret*gamma + r and its moments.
+#define MYO_VN_ROWS 128
+__global__ void __launch_bounds__(128) k_vecnorm_moments(const float* __restrict__ obs, const float* __restrict__ rew, int N, int O,
+                                                         double* __restrict__ returns, double gamma, int training,
+                                                         double* __restrict__ part) {
+  __shared__ double red[128];
+  const int t = threadIdx.x, r0 = blockIdx.x * MYO_VN_ROWS;
+  const int rows = (N - r0) < MYO_VN_ROWS ? (N - r0) : MYO_VN_ROWS;
+  double* mine = part + (size_t)blockIdx.x * 2 * (O + 1);
+  for (int c = t; c < O; c += 128) {
+    double sum = 0;
+    for (int r = 0; r < rows; ++r) sum += (double)obs[(size_t)(r0 + r) * O + c];
+    const double mean = sum / rows;
+    double m2 = 0;
+    for (int r = 0; r < rows; ++r) { const double d = (double)obs[(size_t)(r0 + r) * O + c] - mean; m2 += d * d; }
+    mine[2 * c] = mean; mine[2 * c + 1] = m2;
+  }
+  double v = 0;
+  if (t < rows) {
+    v = returns[r0 + t];
+    if (training) { v = v * gamma + (double)rew[r0 + t]; returns[r0 + t] = v; }
+  }
+  red[t] = (t < rows) ? v : 0.0;
+  __syncthreads();
+  for (int sft = 64; sft >= 1; sft >>= 1) { if (t < sft) red[t] += red[t + sft]; __syncthreads(); }
+  const double mean = red[0] / rows;
+  __syncthreads();
+  const double d = (t < rows) ? (v - mean) : 0.0;
+  red[t] = d * d;
+  __syncthreads();
+  for (int sft = 64; sft >= 1; sft >>= 1) { if (t < sft) red[t] += red[t + sft]; __syncthreads(); }
+  if (t == 0) { mine[2 * O] = mean; mine[2 * O + 1] = red[0]; }
+}
+// kernel 2 of 3 (one block): merge the block moments in block order -> batch mean / variance, then the
+// running statistics by Chan's parallel update (RunningMeanStd.update_from_moments), in place.
+__global__ void __launch_bounds__(128) k_vecnorm_merge(const double* __restrict__ part, int nb, int N, int O, double* __restrict__ obs_mean,
+                                                       double* __restrict__ obs_var, double* __restrict__ obs_count,
+                                                       double* __restrict__ ret_stats, int upd_obs, int upd_ret) {
+  const int t = threadIdx.x;
+  const double oc = *obs_count, rc = ret_stats[2];
+  __syncthreads();
+  for (int c = t; c <= O; c += 128) {
+    if ((c < O && !upd_obs) || (c == O && !upd_ret)) continue;
+    double wsum = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int n_b = (N - b * MYO_VN_ROWS) < MYO_VN_ROWS ? (N - b * MYO_VN_ROWS) : MYO_VN_ROWS;
+      wsum += n_b * part[((size_t)b * (O + 1) + c) * 2];
+    }
+    const double bmean = wsum / N;
+    double m2 = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int n_b = (N - b * MYO_VN_ROWS) < MYO_VN_ROWS ? (N - b * MYO_VN_ROWS) : MYO_VN_ROWS;
+      const double dm = part[((size_t)b * (O + 1) + c) * 2] - bmean;
+      m2 += part[((size_t)b * (O + 1) + c) * 2 + 1] + n_b * dm * dm;
+    }
+    const double bvar = m2 / N;
+    double* mean = c < O ? obs_mean + c : ret_stats;
+    double* var = c < O ? obs_var + c : ret_stats + 1;
+    const double cnt = c < O ? oc : rc;
+    const double delta = bmean - *mean, tot = cnt + N;
+    const double new_mean = *mean + delta * N / tot;
+    const double M2 = *var * cnt + bvar * N + delta * delta * cnt * N / tot;
+    *mean = new_mean; *var = M2 / tot;
+  }
+  if (t == 0) { if (upd_obs) *obs_count = oc + N; if (upd_ret) ret_stats[2] = rc + N; }
+}
+// kernel 3 of 3: normalise observation, terminal observation and reward with the UPDATED statistics,
+// zero the returns of finished episodes, and write the rollout buffer rows of step t.
+__global__ void __launch_bounds__(256) k_vecnorm_apply(const float* __restrict__ obs, const float* __restrict__ rew,
+                                                       const unsigned char* __restrict__ done, const unsigned char* __restrict__ trunc,
+                                                       const float* __restrict__ term, int N, int O, const double* __restrict__ obs_mean,
+                                                       const double* __restrict__ obs_var, const double* __restrict__ ret_stats,
+                                                       double* __restrict__ returns, double eps, double clip_obs, double clip_rew,
+                                                       int norm_obs, int norm_rew, float* __restrict__ nobs, float* __restrict__ starts,
+                                                       const int* __restrict__ t_idx, float* __restrict__ rew_buf,
+                                                       float* __restrict__ start_buf, float* __restrict__ term_buf,
+                                                       float* __restrict__ trunc_buf) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t n = (size_t)N * O, tt = (size_t)(*t_idx);
+  if (i < n) {
+    const int c = (int)(i % O);
+    double o = obs[i], q = term[i];
+    if (norm_obs) {
+      const double sd = sqrt(obs_var[c] + eps), mu = obs_mean[c];
+      o = fmin(fmax((o - mu) / sd, -clip_obs), clip_obs);
+      q = fmin(fmax((q - mu) / sd, -clip_obs), clip_obs);
+    }
+    nobs[i] = (float)o;
+    if (term_buf) term_buf[tt * n + i] = (float)q;
+  }
+  if (i < (size_t)N) {
+    double r = rew[i];
+    if (norm_rew) r = fmin(fmax(r / sqrt(ret_stats[1] + eps), -clip_rew), clip_rew);
+    rew_buf[tt * N + i] = (float)r;
+    start_buf[tt * N + i] = starts[i];          // episode_starts of the step that produced this transition
+    const unsigned char dn = done[i];
+    starts[i] = dn ? 1.f : 0.f;
+    if (trunc_buf) trunc_buf[tt * N + i] = trunc[i] ? 1.f : 0.f;
+    if (dn) returns[i] = 0.0;
+  }
+}
+__global__ void k_rollout_advance(int* t_idx, int T, unsigned long long* draw_counter) {
+  *t_idx = (*t_idx + 1) % T;
+  draw_counter[0] = draw_counter[1];
+}
+#endif
+extern "C" int myo_rollout_policy_input(const float* obs, int N, int O, float* obs_buf, uint16_t* x_bf16, int copies,
+                                        const int32_t* t_idx, void* stream) {
+  if (!obs || !x_bf16 || !t_idx || N <= 0 || O <= 0 || copies <= 0) return fail(MYO_E_ARG, "myo_rollout_policy_input: bad arguments");
+#ifdef MYO_EMU
+  (void)obs_buf; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_rollout_policy_input is a GPU kernel");
+#else
+  const size_t n = (size_t)N * O;
+  hipLaunchKernelGGL(k_obs_prepare, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, n, obs_buf, x_bf16, copies, t_idx);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_rollout_sample(const uint16_t* mean_bf16, const uint16_t* value_bf16, const float* log_std, int N, int A,
+                                  uint64_t seed, uint64_t* draw_counter, const int32_t* t_idx, float* act_buf, float* val_buf,
+                                  float* logp_buf, float* clipped, int deterministic, void* stream) {
+  if (!mean_bf16 || !value_bf16 || !log_std || !draw_counter || !t_idx || !act_buf || !val_buf || !logp_buf || !clipped || N <= 0 || A <= 0)
+    return fail(MYO_E_ARG, "myo_rollout_sample: bad arguments");
+#ifdef MYO_EMU
+  (void)seed; (void)deterministic; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_rollout_sample is a GPU kernel");
+#else
+  hipLaunchKernelGGL(k_sample_actions, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, mean_bf16, value_bf16, log_std, N, A,
+                     (unsigned long long)seed, (unsigned long long*)draw_counter, t_idx, act_buf, val_buf, logp_buf, clipped, deterministic);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_vecnorm_step(const float* obs, const float* rew, const uint8_t* done, const uint8_t* trunc, const float* term_obs,
+                                int N, int O, double* obs_mean, double* obs_var, double* obs_count, double* ret_stats,
+                                double* returns, double gamma, double eps, double clip_obs, double clip_rew, int training,
+                                int norm_obs, int norm_reward, float* nobs, float* starts, const int32_t* t_idx, float* rew_buf,
+                                float* start_buf, float* term_buf, float* trunc_buf, double* work, void* stream) {
+  if (!obs || !rew || !done || !trunc || !term_obs || !obs_mean || !obs_var || !obs_count || !ret_stats || !returns || !nobs ||
+      !starts || !t_idx || !rew_buf || !start_buf || !work || N <= 0 || O <= 0)
+    return fail(MYO_E_ARG, "myo_vecnorm_step: bad arguments");
+#ifdef MYO_EMU
+  (void)gamma; (void)eps; (void)clip_obs; (void)clip_rew; (void)training; (void)norm_obs; (void)norm_reward; (void)term_buf;
+  (void)trunc_buf; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_vecnorm_step is a GPU kernel");
+#else
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (N + MYO_VN_ROWS - 1) / MYO_VN_ROWS;
+  hipLaunchKernelGGL(k_vecnorm_moments, dim3(nb), dim3(128), 0, st, obs, rew, N, O, returns, gamma, training, work);
+  if (training)
+    hipLaunchKernelGGL(k_vecnorm_merge, dim3(1), dim3(128), 0, st, work, nb, N, O, obs_mean, obs_var, obs_count, ret_stats,
+                       (int)(training && norm_obs), (int)(training != 0));
+  const size_t n = (size_t)N * O;
+  hipLaunchKernelGGL(k_vecnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, obs, rew, done, trunc, term_obs, N, O,
+                     obs_mean, obs_var, ret_stats, returns, eps, clip_obs, clip_rew, norm_obs, norm_reward, nobs, starts, t_idx,
+                     rew_buf, start_buf, term_buf, trunc_buf);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_rollout_advance(int32_t* t_idx, int T, uint64_t* draw_counter, void* stream) {
+  if (!t_idx || !draw_counter || T <= 0) return fail(MYO_E_ARG, "myo_rollout_advance: bad arguments");
+#ifdef MYO_EMU
+  (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_rollout_advance is a GPU kernel");
+#else
+  hipLaunchKernelGGL(k_rollout_advance, dim3(1), dim3(1), 0, (hipStream_t)stream, t_idx, T, (unsigned long long*)draw_counter);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------ GAE
 // compute_returns_and_advantage of SB3's RolloutBuffer: backward scan over T with
 // the episode_starts[t+1] mask; one thread per env, coalesced over envs.  [T,N] row-major.

@@ -278,6 +278,26 @@ class FusedPPOStep:
         x2 = obs.to(torch.bfloat16).unsqueeze(0).expand(2, obs.shape[0], obs.shape[1]).contiguous()
         return self._merged_core(x2, actions, old_logp, adv, returns)
 
+    def refresh_shadow(self):
+        """bf16 shadow of the master weights (one cast kernel on the flat vector)."""
+        torch._foreach_copy_(self.half, self.master)
+
+    def trunk_heads(self, x2):
+        """Stacked actor/critic forward on the bf16 shadow weights: x2 bf16 [2,B,obs] -> (hidden
+        activations per layer, action mean bf16 [B,A], value bf16 [B,1])."""
+        B = x2.shape[1]
+        stream = torch.cuda.current_stream(x2.device).cuda_stream
+        h, saved = x2, [x2]
+        for lay in self.merged:
+            h = torch.bmm(h, lay["wh"].transpose(1, 2))
+            self.lib.check(self.lib.L.myo_bias_relu_bf16(C.c_void_p(h.data_ptr()), C.c_void_p(lay["bh"].data_ptr()), 2, B,
+                                                         h.shape[2], C.c_void_p(stream)))
+            saved.append(h)
+        pi_head, vf_head = self.nets["pi"][-1], self.nets["vf"][-1]
+        mean_h = torch.addmm(self.wb[id(pi_head.bias)], h[0], self.wb[id(pi_head.weight)].t())
+        value_h = torch.addmm(self.wb[id(vf_head.bias)], h[1], self.wb[id(vf_head.weight)].t())
+        return saved, mean_h, value_h
+
     def _merged_core(self, x2, actions, old_logp, adv, returns):
         """Actor and critic trunks as ONE batched GEMM per layer (batch = net), heads separate.
         x2: bf16 [2, B, obs_dim] (the same minibatch twice); self.stats holds the advantage moments."""
@@ -286,18 +306,12 @@ class FusedPPOStep:
         s = self.split if (B % self.split == 0) else 1
         dev = x2.device
         stream = torch.cuda.current_stream(dev).cuda_stream
-        self.half[0].copy_(self.master[0])
-        h = x2
-        saved = [h]
-        for lay in L:
-            h = torch.bmm(h, lay["wh"].transpose(1, 2))
-            self.lib.check(self.lib.L.myo_bias_relu_bf16(C.c_void_p(h.data_ptr()), C.c_void_p(lay["bh"].data_ptr()), 2, B,
-                                                         h.shape[2], C.c_void_p(stream)))
-            saved.append(h)
+        self.refresh_shadow()
+        saved, mean_h, value_h = self.trunk_heads(x2)
+        h = saved[-1]
         pi_head, vf_head = self.nets["pi"][-1], self.nets["vf"][-1]
         wpi, wvf = self.wb[id(pi_head.weight)], self.wb[id(vf_head.weight)]
-        mean = torch.addmm(self.wb[id(pi_head.bias)], h[0], wpi.t()).float()
-        values = torch.addmm(self.wb[id(vf_head.bias)], h[1], wvf.t()).float().reshape(B)
+        mean, values = mean_h.float(), value_h.float().reshape(B)
         dmean_h = torch.empty((B, A), device=dev, dtype=torch.bfloat16)
         dvalue_h = torch.empty((B, 1), device=dev, dtype=torch.bfloat16)
         self._loss_kernel(mean, values, actions, old_logp, adv, returns, dmean_h, dvalue_h)

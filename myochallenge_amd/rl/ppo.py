@@ -87,6 +87,8 @@ class PPO:
             from .fused_mlp import FlatAdam, flatten_parameters
             self._flat_adam = FlatAdam(flatten_parameters(self.policy), native.load(), cfg.learning_rate,
                                        cfg.max_grad_norm)
+            from .fused_mlp import FusedPPOStep
+            self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         N, T, O, A = env.num_envs, cfg.n_steps, env.obs_dim, env.act_dim
@@ -146,6 +148,71 @@ class PPO:
         self._starts_s.copy_(done.to(torch.float32))
         self._t_idx.add_(1).remainder_(cfg.n_steps)
 
+    # -- native rollout step: HIP kernels for policy input, sampling, VecNormalize and buffer writes
+    def _native_rollout(self) -> bool:
+        return (self._graphed_rollout() and self._fused is not None and self._fused.merged is not None
+                and hasattr(self.env, "process_step") and hasattr(self.env, "obs_rms"))
+
+    def _init_native_rollout(self):
+        """Per step: graph A (policy input cast, stacked trunks, heads, myo_rollout_sample) -> eager
+        myo_batch_step -> graph B (myo_vecnorm_step, myo_rollout_advance).  The timeout bootstrap
+        r += gamma V(terminal_obs) is applied once per rollout in finish_rollout() from term_buf/trunc_buf."""
+        import ctypes as C
+        vec, raw, d, cfg = self.env, self.env.venv, self.device, self.cfg
+        N, A, O, T = vec.num_envs, vec.act_dim, vec.obs_dim, cfg.n_steps
+        fused, lib = self._fused, self._fused.lib
+        first = vec.reset_tensor() if self._last_obs is None else self._last_obs
+        self._obs_s = first.clone().contiguous()
+        self._starts_s = self._last_starts.clone()
+        self._clip_s = torch.zeros((N, A), device=d)
+        self._t_idx = torch.zeros(1, dtype=torch.int32, device=d)
+        self._draw = torch.zeros(2, dtype=torch.int64, device=d)
+        self._x2 = torch.empty((2, N, O), device=d, dtype=torch.bfloat16)
+        self.term_buf = torch.zeros((T, N, O), device=d)
+        self.trunc_buf = torch.zeros((T, N), device=d)
+        self._vn_work = torch.zeros(((N + 127) // 128) * 2 * (O + 1), dtype=torch.float64, device=d)
+        seed = int(self.gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        p = lambda t: C.c_void_p(t.data_ptr())
+
+        def part_a():
+            st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+            lib.check(lib.L.myo_rollout_policy_input(p(self._obs_s), N, O, p(self.obs_buf), p(self._x2), 2, p(self._t_idx), st))
+            _, mean_h, value_h = fused.trunk_heads(self._x2)
+            lib.check(lib.L.myo_rollout_sample(p(mean_h), p(value_h), p(self.policy.log_std.data), N, A, seed, p(self._draw),
+                                               p(self._t_idx), p(self.act_buf), p(self.val_buf), p(self.logp_buf),
+                                               p(self._clip_s), 0, st))
+
+        def part_b(rawout):
+            obs, rew, done, trunc, term = rawout[:5]
+            st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+            lib.check(lib.L.myo_vecnorm_step(
+                p(obs), p(rew), p(done), p(trunc), p(term), N, O, p(vec.obs_rms.mean), p(vec.obs_rms.var), p(vec.obs_rms.count),
+                p(vec.ret_rms.buf), p(vec.returns), float(vec.gamma), float(vec.epsilon), float(vec.clip_obs),
+                float(vec.clip_reward), int(vec.training), int(vec.norm_obs), int(vec.norm_reward), p(self._obs_s),
+                p(self._starts_s), p(self._t_idx), p(self.rew_buf), p(self.start_buf), p(self.term_buf), p(self.trunc_buf),
+                p(self._vn_work), st))
+            lib.check(lib.L.myo_rollout_advance(p(self._t_idx), T, p(self._draw), st))
+
+        self._raw = raw
+        fused.refresh_shadow()
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        with torch.cuda.stream(side):           # eager warm-up (library handles; binds the env's constants)
+            part_a()
+            rawout = raw.step_tensor(self._clip_s)
+            part_b(rawout)
+        torch.cuda.current_stream(d).wait_stream(side)
+        torch.cuda.synchronize(d)
+        vec.old_obs, vec.old_reward = rawout[0], rawout[1]      # the env's static output buffers
+        self._t_idx.zero_()
+        self._gA, self._gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._gA):
+            part_a()
+        with torch.cuda.graph(self._gB):
+            part_b(rawout)
+        self._rollout_ready = True
+        self._native = True
+
     def _init_rollout_graphs(self):
         """Per step: graph A (policy inference + sampling) -> eager myo_batch_step (so its HIP events can
         still bracket the kernel) -> graph B (normaliser, timeout bootstrap, buffer writes)."""
@@ -180,13 +247,21 @@ class PPO:
     def rollout_step(self) -> None:
         """One environment step for the whole batch (graphed path only)."""
         if not getattr(self, "_rollout_ready", False):
-            self._init_rollout_graphs()
+            if self._native_rollout():
+                self._init_native_rollout()
+            else:
+                self._init_rollout_graphs()
         self._gA.replay()
         self._raw.step_tensor(self._clip_s)
         self._gB.replay()
 
     def finish_rollout(self) -> None:
         with torch.no_grad(), self._autocast():
+            if getattr(self, "_native", False):
+                # timeout bootstrap for the whole rollout at once: r += gamma V(terminal_obs) where truncated
+                T, N = self.trunc_buf.shape
+                tv = self.policy.predict_values(self.term_buf.view(T * N, -1)).view(T, N)
+                self.rew_buf.add_(self.cfg.gamma * tv * self.trunc_buf)
             self._last_values = self.policy.predict_values(self._obs_s)
         self._last_obs, self._last_starts = self._obs_s, self._starts_s
 
@@ -195,6 +270,8 @@ class PPO:
     def collect_rollouts(self) -> None:
         cfg, env, pol = self.cfg, self.env, self.policy
         if self._graphed_rollout():
+            if self._fused is not None:
+                self._fused.refresh_shadow()        # rollout inference runs on the bf16 shadow weights
             for _ in range(cfg.n_steps):
                 self.rollout_step()
             self.finish_rollout()
@@ -309,10 +386,6 @@ class PPO:
     def _mb_forward_backward(self):
         g, cfg = self._gs, self.cfg
         idx = g["idx"]
-        if self._fused is None:
-            from .. import native
-            from .fused_mlp import FusedPPOStep
-            self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
         pl, vl = self._fused.run_indexed(g["obs"], g["act"], g["oldlp"], g["adv"], g["ret"], idx)
         g["pl"], g["vl"] = pl, vl                 # views of the loss kernel's accumulator: no copies      # gradients land in the flat vector (p.grad are views of it)
 
@@ -366,6 +439,7 @@ class PPO:
                     dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
                     self._graph_ap.replay()
                 self.n_updates += 1
+        self._fused.refresh_shadow()     # rollout inference reads the bf16 shadow weights
         return g["pl"], g["vl"]
 
     def learn(self, total_timesteps: int, callback: Optional[Callable[["PPO"], None]] = None, log=None):

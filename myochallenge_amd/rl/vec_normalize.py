@@ -21,9 +21,17 @@ import torch
 
 class RunningMeanStd:
     def __init__(self, shape=(), device="cpu", epsilon: float = 1e-4):
-        self.mean = torch.zeros(shape, dtype=torch.float64, device=device)
-        self.var = torch.ones(shape, dtype=torch.float64, device=device)
-        self.count = torch.tensor(float(epsilon), dtype=torch.float64, device=device)   # on the device: no host sync per step
+        # one storage [mean | var | count] (views below): the HIP normaliser kernel updates it in place
+        n = int(np.prod(shape)) if shape != () else 1
+        self.buf = torch.zeros(2 * n + 1, dtype=torch.float64, device=device)
+        self.mean, self.var, self.count = self.buf[:n].view(shape), self.buf[n:2 * n].view(shape), self.buf[2 * n]
+        self.var.fill_(1.0)
+        self.count.fill_(float(epsilon))           # on the device: no host sync per step
+
+    def load(self, mean, var, count) -> None:
+        self.mean.copy_(torch.as_tensor(np.asarray(mean, np.float64)).view(self.mean.shape))
+        self.var.copy_(torch.as_tensor(np.asarray(var, np.float64)).view(self.var.shape))
+        self.count.fill_(float(count))
 
     def update(self, x: torch.Tensor) -> None:
         x = x.to(torch.float64)
@@ -165,12 +173,8 @@ class VecNormalize:
             pickle.dump({"format": "myochallenge_amd.VecNormalize/1", **self.state_dict()}, fh)
 
     def _load_state(self, st) -> None:
-        def rms(dst, src):
-            dst.mean = torch.as_tensor(np.asarray(src["mean"], np.float64), device=self.device)
-            dst.var = torch.as_tensor(np.asarray(src["var"], np.float64), device=self.device)
-            dst.count = torch.tensor(float(src["count"]), dtype=torch.float64, device=self.device)
-        rms(self.obs_rms, st["obs_rms"])
-        rms(self.ret_rms, st["ret_rms"])
+        self.obs_rms.load(**st["obs_rms"])
+        self.ret_rms.load(**st["ret_rms"])
         for k in ("clip_obs", "clip_reward", "gamma", "epsilon", "norm_obs", "norm_reward", "training"):
             setattr(self, k, st[k])
 

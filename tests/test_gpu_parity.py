@@ -254,3 +254,86 @@ def test_flat_adam_matches_torch_clip_and_adam(hip_lib):
         assert p.data_ptr() >= flat["p"].data_ptr()
         err = float((p - q).abs().max())
         assert err < 2e-6, (n, err)
+
+
+def test_rollout_plumbing_kernels(hip_lib):
+    """myo_vecnorm_step == VecNormalize.process_step (the torch statement of SB3's step_wait) over
+    several steps incl. episode ends; myo_rollout_sample draws N(mean, exp(log_std)) with the stated
+    log-prob and is reproducible per (seed, counter); myo_rollout_policy_input casts/copies."""
+    import ctypes as C
+    import math
+    import torch
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    L = hip_lib.L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    N, O, A, T = 1000, 86, 39, 4          # ragged vs the 128-row blocks
+
+    class E:
+        num_envs, obs_dim, act_dim, device = N, O, A, dev
+        observation_space = action_space = None
+    ref, nat = VecNormalize(E()), VecNormalize(E())
+    nobs, starts = torch.zeros(N, O, device=dev), torch.ones(N, device=dev)
+    t_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    draw = torch.zeros(2, dtype=torch.int64, device=dev)
+    rew_buf, start_buf = torch.zeros(T, N, device=dev), torch.zeros(T, N, device=dev)
+    term_buf, trunc_buf = torch.zeros(T, N, O, device=dev), torch.zeros(T, N, device=dev)
+    work = torch.zeros(((N + 127) // 128) * 2 * (O + 1), dtype=torch.float64, device=dev)
+    prev_done = torch.ones(N, device=dev)
+    for t in range(T):
+        obs = torch.randn(N, O, device=dev) * (1 + t) + 0.5 * t
+        rew, term = torch.randn(N, device=dev) * 3, torch.randn(N, O, device=dev)
+        done = (torch.rand(N, device=dev) < 0.2).to(torch.uint8)
+        trunc = ((torch.rand(N, device=dev) < 0.5) & (done > 0)).to(torch.uint8)
+        r_obs, r_rew, _, _, r_term, _, _ = ref.process_step(obs, rew, done, trunc, term, None, None)
+        hip_lib.check(L.myo_vecnorm_step(p(obs), p(rew), p(done), p(trunc), p(term), N, O, p(nat.obs_rms.mean), p(nat.obs_rms.var),
+                                         p(nat.obs_rms.count), p(nat.ret_rms.buf), p(nat.returns), nat.gamma, nat.epsilon,
+                                         nat.clip_obs, nat.clip_reward, 1, 1, 1, p(nobs), p(starts), p(t_idx), p(rew_buf),
+                                         p(start_buf), p(term_buf), p(trunc_buf), p(work), None))
+        torch.cuda.synchronize()
+        for a, b in ((nat.obs_rms.mean, ref.obs_rms.mean), (nat.obs_rms.var, ref.obs_rms.var), (nat.ret_rms.var, ref.ret_rms.var),
+                     (nat.ret_rms.mean, ref.ret_rms.mean), (nat.returns, ref.returns)):
+            assert float((a - b).abs().max()) <= 1e-11 * (1 + float(b.abs().max()))
+        assert float(nat.obs_rms.count) == float(ref.obs_rms.count) and float(nat.ret_rms.count) == float(ref.ret_rms.count)
+        assert float((nobs - r_obs).abs().max()) < 1e-5 and float((term_buf[t] - r_term).abs().max()) < 1e-5
+        assert float((rew_buf[t] - r_rew).abs().max()) < 1e-5
+        assert torch.equal(start_buf[t], prev_done) and torch.equal(starts, done.float()) and torch.equal(trunc_buf[t], trunc.float())
+        prev_done = done.float()
+        hip_lib.check(L.myo_rollout_advance(p(t_idx), T, p(draw), None))
+    assert int(t_idx) == 0
+
+    Ns = 4096
+    mean = (torch.randn(Ns, A, device=dev) * 0.3).bfloat16()
+    value = torch.randn(Ns, 1, device=dev).bfloat16()
+    log_std = torch.full((A,), -2.0, device=dev) + 0.2 * torch.randn(A, device=dev)
+    act_buf, val_buf, logp_buf = torch.zeros(T, Ns, A, device=dev), torch.zeros(T, Ns, device=dev), torch.zeros(T, Ns, device=dev)
+    clipped = torch.zeros(Ns, A, device=dev)
+    draw.zero_()
+
+    def sample(tt, counter, det=0):
+        t_idx.fill_(tt); draw[0] = counter
+        hip_lib.check(L.myo_rollout_sample(p(mean), p(value), p(log_std), Ns, A, 1234, p(draw), p(t_idx), p(act_buf), p(val_buf),
+                                           p(logp_buf), p(clipped), det, None))
+        torch.cuda.synchronize()
+    sample(0, 7); sample(1, 7); sample(2, 8); sample(3, 0, det=1)
+    assert torch.equal(act_buf[0], act_buf[1]) and not torch.equal(act_buf[0], act_buf[2])
+    assert torch.equal(act_buf[3], mean.float()) and int(draw[1]) == 1
+    z = (act_buf[0] - mean.float()) * torch.exp(-log_std)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.var()) - 1.0) < 0.02 and float(z.abs().max()) < 6.5
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.15                       # Gaussian kurtosis
+    cz = torch.corrcoef(z[:, :8].t())
+    assert float((cz - torch.eye(8, device=dev)).abs().max()) < 0.06       # dims independent
+    want_lp = (-0.5 * z * z - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
+    assert float((logp_buf[0] - want_lp).abs().max()) < 2e-3
+    assert torch.equal(val_buf[0], value.float().view(-1))
+    sample(2, 8)
+    assert torch.equal(clipped, act_buf[2].clamp(-1, 1))
+
+    obs = torch.randn(N, O, device=dev)
+    obs_buf = torch.zeros(T, N, O, device=dev)
+    x2 = torch.zeros(2, N, O, device=dev, dtype=torch.bfloat16)
+    t_idx.fill_(2)
+    hip_lib.check(L.myo_rollout_policy_input(p(obs), N, O, p(obs_buf), p(x2), 2, p(t_idx), None))
+    torch.cuda.synchronize()
+    assert torch.equal(obs_buf[2], obs) and torch.equal(x2[0], obs.bfloat16()) and torch.equal(x2[1], x2[0])

@@ -139,11 +139,15 @@ int myo_batch_enable_timing(myo_batch* b, int on);
  * sum_i dvalue[i]} (the last two are the bias gradients of the action / value heads).
  * dmean_bf16 / dvalue_bf16: optional (NULL) bfloat16 copies of dmean / dvalue for the backward GEMMs.
  * work: dev float32 [ceil(B/64) * (2A+3)] scratch; the sums are formed from per-block partials in
- * block order by a second small launch (deterministic, no float atomics). */
+ * block order by a second small launch (deterministic, no float atomics).
+ * in_bf16 != 0: `mean` and `values` point to bfloat16 data (the GEMM outputs) instead of float32.
+ * Optional direct gradient outputs (NULL to skip): g_log_std[A] = acc[0..A) - ent_coef,
+ * g_bias_pi[A] = acc[A+2..2A+2), g_bias_vf[1] = acc[2A+2]. */
 int myo_ppo_loss_grad(const float* mean, const float* values, const float* actions, const float* old_logp,
                       const float* adv, const float* returns, const float* log_std, const float* adv_stats,
                       int B, int A, float clip, float vf_coef, float* dmean, float* dvalue, float* acc,
-                      uint16_t* dmean_bf16, uint16_t* dvalue_bf16, float* work, void* stream);
+                      uint16_t* dmean_bf16, uint16_t* dvalue_bf16, float* work, int in_bf16, float ent_coef,
+                      float* g_log_std, float* g_bias_pi, float* g_bias_vf, void* stream);
 
 /* Minibatch gather of one optimiser step (SB3 RolloutBuffer.get + the per-minibatch advantage
  * normalisation statistics of PPO.train): rows idx[0..bs) (dev int64) of obs[N,obs_dim] act[N,act_dim]
@@ -205,7 +209,8 @@ int myo_gae(const float* rew, const float* val, const float* starts, const float
 /* clip_grad_norm_(max_norm) followed by one torch.optim.Adam step over a flat fp32 parameter vector
  * (what RecurrentPPO.train does per minibatch; /root/reference/src/train/trainer.py:66-71, SB3 Adam
  * eps 1e-5).  g is multiplied by grad_scale first (1/world after an all-reduce SUM).  step: dev
- * int32 counter (incremented); scratch: dev float[1] (receives sum g^2). */
+ * int32[2], zero-initialised ([1] = number of steps taken); scratch: dev float[64] (per-block sums
+ * of g^2, added in a fixed order: deterministic). */
 int myo_adam_clip_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
                        float eps, float max_norm, float grad_scale, int* step, float* scratch, void* stream);
 

@@ -277,14 +277,46 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
     }
   }
   SYNC();
+  // Everything a body needs from the model tables is fetched ONCE, before the level loop (lane = body
+  // throughout): inside the loop the table loads would form a chain of 3-4 dependent global loads per
+  // tree level (depth -> joint address -> joint type -> qpos address -> qpos0).
+  LANE_VAR(int, k_depth); LANE_VAR(int, k_par); LANE_VAR(int, k_jn); LANE_VAR(int, k_ja);
+  LANE_VAR(int, k_jtype); LANE_VAR(int, k_qa);
+  LANE_VAR(T, k_q0);
+  LANE_VAR(T, k_bp0); LANE_VAR(T, k_bp1); LANE_VAR(T, k_bp2);
+  LANE_VAR(T, k_bq0); LANE_VAR(T, k_bq1); LANE_VAR(T, k_bq2); LANE_VAR(T, k_bq3);
+  LANE_VAR(T, k_ip0); LANE_VAR(T, k_ip1); LANE_VAR(T, k_ip2);
+  LANE_VAR(T, k_jp0); LANE_VAR(T, k_jp1); LANE_VAR(T, k_jp2);
+  LANE_VAR(T, k_ax0); LANE_VAR(T, k_ax1); LANE_VAR(T, k_ax2);
+  PHASE {
+    const int b = lane;
+    LV(k_depth) = -1; LV(k_par) = 0; LV(k_jn) = 0; LV(k_ja) = 0; LV(k_jtype) = -1; LV(k_qa) = 0; LV(k_q0) = 0;
+    LV(k_bp0) = LV(k_bp1) = LV(k_bp2) = 0; LV(k_bq0) = 1; LV(k_bq1) = LV(k_bq2) = LV(k_bq3) = 0;
+    LV(k_ip0) = LV(k_ip1) = LV(k_ip2) = 0; LV(k_jp0) = LV(k_jp1) = LV(k_jp2) = 0; LV(k_ax0) = LV(k_ax1) = LV(k_ax2) = 0;
+    if (b > 0 && b < M.nbody) {
+      LV(k_depth) = M.body_depth[b]; LV(k_par) = M.body_parentid[b]; LV(k_jn) = M.body_jntnum[b];
+      const int ja = M.body_jntadr[b];
+      LV(k_ja) = ja;
+      LV(k_bp0) = M.body_pos[3 * b]; LV(k_bp1) = M.body_pos[3 * b + 1]; LV(k_bp2) = M.body_pos[3 * b + 2];
+      LV(k_bq0) = M.body_quat[4 * b]; LV(k_bq1) = M.body_quat[4 * b + 1]; LV(k_bq2) = M.body_quat[4 * b + 2];
+      LV(k_bq3) = M.body_quat[4 * b + 3];
+      LV(k_ip0) = M.body_ipos[3 * b]; LV(k_ip1) = M.body_ipos[3 * b + 1]; LV(k_ip2) = M.body_ipos[3 * b + 2];
+      if (LV(k_jn) > 0) {               // first joint of the body (most bodies have exactly one)
+        const int qa = M.jnt_qposadr[ja];
+        LV(k_jtype) = M.jnt_type[ja]; LV(k_qa) = qa; LV(k_q0) = M.qpos0[qa];
+        LV(k_jp0) = M.jnt_pos[3 * ja]; LV(k_jp1) = M.jnt_pos[3 * ja + 1]; LV(k_jp2) = M.jnt_pos[3 * ja + 2];
+        LV(k_ax0) = M.jnt_axis[3 * ja]; LV(k_ax1) = M.jnt_axis[3 * ja + 1]; LV(k_ax2) = M.jnt_axis[3 * ja + 2];
+      }
+    }
+  }
   for (int level = 1; level <= M.maxdepth; ++level) {
     PHASE {
       const int b = lane;
-      if (b > 0 && b < M.nbody && M.body_depth[b] == level) {
-        const int par = M.body_parentid[b], jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+      if (LV(k_depth) == level) {
+        const int par = LV(k_par), jn = LV(k_jn), ja = LV(k_ja);
         T p[3], q[4];
-        if (jn == 1 && M.jnt_type[ja] == 0) {
-          const int qa = M.jnt_qposadr[ja];
+        if (jn == 1 && LV(k_jtype) == 0) {
+          const int qa = LV(k_qa);
           T qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
           normalize4(qq);
           for (int k = 0; k < 4; ++k) { s.qpos[qa + 3 + k] = qq[k]; q[k] = qq[k]; }
@@ -292,26 +324,37 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
           S_XAXIS(s)[3 * ja] = 0; S_XAXIS(s)[3 * ja + 1] = 0; S_XAXIS(s)[3 * ja + 2] = 1;
         } else {
           T t[3];
-          mulmatvec3(t, s.xmat + 9 * par, M.body_pos + 3 * b);
+          const T bpos[3] = {LV(k_bp0), LV(k_bp1), LV(k_bp2)}, bquat[4] = {LV(k_bq0), LV(k_bq1), LV(k_bq2), LV(k_bq3)};
+          mulmatvec3(t, s.xmat + 9 * par, bpos);
           p[0] = s.xpos[3 * par] + t[0]; p[1] = s.xpos[3 * par + 1] + t[1]; p[2] = s.xpos[3 * par + 2] + t[2];
-          mulquat(q, S_XQUAT(s) + 4 * par, M.body_quat + 4 * b);
+          mulquat(q, S_XQUAT(s) + 4 * par, bquat);
           for (int k = 0; k < jn; ++k) {
-            const int j = ja + k, qa = M.jnt_qposadr[j];
+            const int j = ja + k;
+            int qa, jtype;
+            T jpos[3], jaxis[3], q0;
+            if (k == 0) {
+              qa = LV(k_qa); jtype = LV(k_jtype); q0 = LV(k_q0);
+              jpos[0] = LV(k_jp0); jpos[1] = LV(k_jp1); jpos[2] = LV(k_jp2);
+              jaxis[0] = LV(k_ax0); jaxis[1] = LV(k_ax1); jaxis[2] = LV(k_ax2);
+            } else {                    // further joints of a multi-joint body: fetched here (rare)
+              qa = M.jnt_qposadr[j]; jtype = M.jnt_type[j]; q0 = M.qpos0[qa];
+              for (int e = 0; e < 3; ++e) { jpos[e] = M.jnt_pos[3 * j + e]; jaxis[e] = M.jnt_axis[3 * j + e]; }
+            }
             T R[9], anchor[3], axis[3];
             quat2mat(R, q);
-            mulmatvec3(anchor, R, M.jnt_pos + 3 * j);
+            mulmatvec3(anchor, R, jpos);
             anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
-            mulmatvec3(axis, R, M.jnt_axis + 3 * j);
+            mulmatvec3(axis, R, jaxis);
             for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = anchor[e]; S_XAXIS(s)[3 * j + e] = axis[e]; }
-            const T ang = s.qpos[qa] - M.qpos0[qa];
-            if (M.jnt_type[j] == 2) {
+            const T ang = s.qpos[qa] - q0;
+            if (jtype == 2) {
               p[0] += axis[0] * ang; p[1] += axis[1] * ang; p[2] += axis[2] * ang;
             } else {
               T ql[4], R2[9], t2[3];
-              axisangle2quat(ql, M.jnt_axis + 3 * j, ang);
+              axisangle2quat(ql, jaxis, ang);
               mulquat(q, q, ql);
               quat2mat(R2, q);
-              mulmatvec3(t2, R2, M.jnt_pos + 3 * j);
+              mulmatvec3(t2, R2, jpos);
               p[0] = anchor[0] - t2[0]; p[1] = anchor[1] - t2[1]; p[2] = anchor[2] - t2[2];
             }
           }
@@ -323,7 +366,8 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
         quat2mat(R, q);
         for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = R[k];
         T t[3];
-        mulmatvec3(t, R, M.body_ipos + 3 * b);
+        const T ipos[3] = {LV(k_ip0), LV(k_ip1), LV(k_ip2)};
+        mulmatvec3(t, R, ipos);
         for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = p[k] + t[k];
       }
     }
@@ -662,8 +706,20 @@ DEVFN void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r,
   PHASE {
     const int i = lane;
     if (i < M.nv) {
+      // the row's (qM index, column) pairs arrive in one go (3 x 16-byte loads), not one dependent
+      // table load per non-zero
+      unsigned w[MYO_MV_ROW / 2];
+#pragma unroll
+      for (int q = 0; q < MYO_MV_ROW / 2; ++q) w[q] = (unsigned)M.mv_pack[i * (MYO_MV_ROW / 2) + q];
+      const int len = M.mv_len[i];
       T acc = 0;
-      for (int k = M.mv_adr[i]; k < M.mv_adr[i + 1]; ++k) acc += s.qM[M.mv_e[k]] * v[M.mv_col[k]];
+#pragma unroll
+      for (int k = 0; k < MYO_MV_ROW; ++k) {
+        if (k < len) {
+          const unsigned ent = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xffffu);
+          acc += s.qM[ent >> 6] * v[ent & 63u];
+        }
+      }
       out[i] = acc;
     }
   }

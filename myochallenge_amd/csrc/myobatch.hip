@@ -196,6 +196,19 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
       for (auto& pr : rows[i]) { m->mv_col.push_back(pr.first); m->mv_e.push_back(pr.second); }
     }
     m->mv_adr[nv] = (int)m->mv_col.size();
+    // the same rows packed for one wide load per dof: 16-bit entries (qM index << 6 | column), two per word
+    m->mv_pack.assign((size_t)nv * (MYO_MV_ROW / 2), 0);
+    m->mv_len.assign(nv, 0);
+    for (int i = 0; i < nv; ++i) {
+      const int len = m->mv_adr[i + 1] - m->mv_adr[i];
+      LIM(len > MYO_MV_ROW, "a row of the inertia matrix has more than MYO_MV_ROW non-zeros")
+      m->mv_len[i] = len;
+      for (int k = 0; k < len; ++k) {
+        const unsigned ent = ((unsigned)m->mv_e[m->mv_adr[i] + k] << 6) | (unsigned)m->mv_col[m->mv_adr[i] + k];
+        unsigned& w = reinterpret_cast<unsigned&>(m->mv_pack[(size_t)i * (MYO_MV_ROW / 2) + k / 2]);
+        w |= (k & 1) ? (ent << 16) : ent;
+      }
+    }
   }
   // tendons: dofs each one can move; side sites
   m->tendon_dofmask.assign(m->ntendon, 0ull);
@@ -797,6 +810,7 @@ __device__ __forceinline__ unsigned short myo_f2bf(float x) {   // round-to-near
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+template <bool IN_BF16>
 __global__ void __launch_bounds__(64) k_ppo_loss(const float* __restrict__ mean, const float* __restrict__ values,
                                                  const float* __restrict__ actions, const float* __restrict__ old_logp,
                                                  const float* __restrict__ adv, const float* __restrict__ returns,
@@ -810,7 +824,11 @@ __global__ void __launch_bounds__(64) k_ppo_loss(const float* __restrict__ mean,
   const int rows = (B - r0) < 64 ? (B - r0) : 64;
   const int n = rows * A;
   const size_t base = (size_t)r0 * A;
-  for (int k = lane; k < n; k += 64) { t_mean[k] = mean[base + k]; t_act[k] = actions[base + k]; }
+  const unsigned short* mean_h = reinterpret_cast<const unsigned short*>(mean);
+  for (int k = lane; k < n; k += 64) {
+    t_mean[k] = IN_BF16 ? __uint_as_float(((unsigned)mean_h[base + k]) << 16) : mean[base + k];
+    t_act[k] = actions[base + k];
+  }
   if (lane < A) { const float ls = log_std[lane]; s_ls[lane] = ls; s_inv[lane] = __expf(-ls); }
   __syncthreads();
   const int i = r0 + lane;
@@ -830,7 +848,8 @@ __global__ void __launch_bounds__(64) k_ppo_loss(const float* __restrict__ mean,
     pl_i = -fminf(s1, s2) / B;
     const bool inside = (ratio > 1.f - clip) && (ratio < 1.f + clip);
     dlogp = -(an * ratio) * ((s1 <= s2) ? 1.f : (inside ? 1.f : 0.f)) / B;
-    const float dv = values[i] - returns[i];
+    const float val = IN_BF16 ? __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(values)[i]) << 16) : values[i];
+    const float dv = val - returns[i];
     vl_i = dv * dv / B;
     dv_i = vf_coef * 2.f / B * dv;
     dvalue[i] = dv_i;
@@ -869,30 +888,44 @@ __global__ void __launch_bounds__(64) k_ppo_loss(const float* __restrict__ mean,
 // acc[c] = sum over blocks of part[c, block] (fixed order: deterministic); one wave per column.
 // A separate launch instead of a last-block epilogue: an in-kernel release fence writes back the
 // whole L2 of the XCD on this chip (measured: +90 us), a kernel boundary is cheaper.
-__global__ void __launch_bounds__(64) k_colmajor_finish(const float* __restrict__ part, float* __restrict__ acc, int NB) {
+__global__ void __launch_bounds__(64) k_colmajor_finish(const float* __restrict__ part, float* __restrict__ acc, int NB, int A,
+                                                        float ent_coef, float* __restrict__ g_log_std,
+                                                        float* __restrict__ g_bias_pi, float* __restrict__ g_bias_vf) {
   const int c = blockIdx.x, lane = threadIdx.x;
   float a = 0.f;
   for (int b = lane; b < NB; b += 64) a += part[(size_t)c * NB + b];
   for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-  if (lane == 0) acc[c] = a;
+  if (lane == 0) {
+    acc[c] = a;
+    if (g_log_std && c < A) g_log_std[c] = a - ent_coef;          // d(-ent_coef * entropy)/d log_std = -ent_coef
+    if (g_bias_pi && c >= A + 2 && c < 2 * A + 2) g_bias_pi[c - A - 2] = a;
+    if (g_bias_vf && c == 2 * A + 2) g_bias_vf[0] = a;
+  }
 }
 #endif
 extern "C" int myo_ppo_loss_grad(const float* mean, const float* values, const float* actions, const float* old_logp,
                                  const float* adv, const float* returns, const float* log_std, const float* adv_stats,
                                  int B, int A, float clip, float vf_coef, float* dmean, float* dvalue, float* acc,
-                                 uint16_t* dmean_bf16, uint16_t* dvalue_bf16, float* work, void* stream) {
+                                 uint16_t* dmean_bf16, uint16_t* dvalue_bf16, float* work, int in_bf16, float ent_coef,
+                                 float* g_log_std, float* g_bias_pi, float* g_bias_vf, void* stream) {
   if (!mean || !values || !actions || !old_logp || !adv || !returns || !log_std || !adv_stats || !dmean || !dvalue || !acc ||
       !work || B <= 0 || A <= 0 || A > 64)
     return fail(MYO_E_ARG, "myo_ppo_loss_grad: bad arguments");
 #ifdef MYO_EMU
-  (void)clip; (void)vf_coef; (void)stream; (void)dmean_bf16; (void)dvalue_bf16;
+  (void)clip; (void)vf_coef; (void)stream; (void)dmean_bf16; (void)dvalue_bf16; (void)in_bf16; (void)ent_coef;
+  (void)g_log_std; (void)g_bias_pi; (void)g_bias_vf;
   return fail(MYO_E_UNSUPPORTED, "myo_ppo_loss_grad is a GPU kernel");
 #else
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (B + 63) / 64;
-  hipLaunchKernelGGL(k_ppo_loss, dim3(nblk), dim3(64), 0, st, mean, values, actions, old_logp, adv, returns,
-                     log_std, adv_stats, B, A, clip, vf_coef, dmean, dvalue, acc, dmean_bf16, dvalue_bf16, work);
-  hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, work, acc, nblk);
+  if (in_bf16)
+    hipLaunchKernelGGL(k_ppo_loss<true>, dim3(nblk), dim3(64), 0, st, mean, values, actions, old_logp, adv, returns,
+                       log_std, adv_stats, B, A, clip, vf_coef, dmean, dvalue, acc, dmean_bf16, dvalue_bf16, work);
+  else
+    hipLaunchKernelGGL(k_ppo_loss<false>, dim3(nblk), dim3(64), 0, st, mean, values, actions, old_logp, adv, returns,
+                       log_std, adv_stats, B, A, clip, vf_coef, dmean, dvalue, acc, dmean_bf16, dvalue_bf16, work);
+  hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, work, acc, nblk, A, ent_coef, g_log_std, g_bias_pi,
+                     g_bias_vf);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif
@@ -1400,21 +1433,30 @@ extern "C" int myo_gae(const float* rew, const float* val, const float* starts, 
 // parameter vector: 2 launches instead of ~12 multi-tensor ones.  scratch[0] = sum g^2 (after
 // grad_scale), step = device-side step counter (incremented here).  SB3 semantics: SURVEY.md C.5.
 #ifndef MYO_EMU
-__global__ void __launch_bounds__(256) k_grad_sqnorm(const float* __restrict__ g, int n, float gs, float* __restrict__ out) {
+#define MYO_SQN_BLOCKS 64
+// scratch[0..63] <- per-block sums of (g*gs)^2 (fixed order inside a block: no float atomics);
+// step[0] <- committed step count, step[1] <- pending (= this step's ordinal)
+__global__ void __launch_bounds__(256) k_grad_sqnorm(const float* __restrict__ g, int n, float gs, float* __restrict__ part,
+                                                     int* __restrict__ step) {
   float acc = 0.f;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const float x = g[i] * gs; acc += x * x; }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += MYO_SQN_BLOCKS * 256) { const float x = g[i] * gs; acc += x * x; }
   for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
   __shared__ float red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0) { const int done = step[1]; step[0] = done; step[1] = done + 1; }
+  }
 }
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
                                               float max_norm, float gs, const int* __restrict__ step,
-                                              const float* __restrict__ sq) {
-  const int t = *step + 1;
-  const float norm = sqrtf(*sq);
+                                              const float* __restrict__ part) {
+  float sq = 0.f;
+  for (int k = 0; k < MYO_SQN_BLOCKS; ++k) sq += part[k];      // same order in every block
+  const int t = step[1];
+  const float norm = sqrtf(sq);
   const float clip = (max_norm > 0.f) ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
   const float bc1 = 1.f - powf(b1, (float)t), bc2 = 1.f - powf(b2, (float)t);
   const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
@@ -1426,7 +1468,6 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
   }
 }
-__global__ void k_inc(int* step) { *step += 1; }
 #endif
 extern "C" int myo_adam_clip_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
                                   float eps, float max_norm, float grad_scale, int* step, float* scratch, void* stream) {
@@ -1436,11 +1477,9 @@ extern "C" int myo_adam_clip_step(float* p, const float* g, float* m, float* v, 
   return fail(MYO_E_UNSUPPORTED, "myo_adam_clip_step is a GPU kernel");
 #else
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(scratch, 0, sizeof(float), st) != hipSuccess) return fail(MYO_E_DEVICE, "memset failed");
   const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
-  hipLaunchKernelGGL(k_grad_sqnorm, dim3(blocks), dim3(256), 0, st, g, n, grad_scale, scratch);
+  hipLaunchKernelGGL(k_grad_sqnorm, dim3(MYO_SQN_BLOCKS), dim3(256), 0, st, g, n, grad_scale, scratch, step);
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, max_norm, grad_scale, step, scratch);
-  hipLaunchKernelGGL(k_inc, dim3(1), dim3(1), 0, st, step);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif

@@ -83,7 +83,7 @@ class NativeLib:
         L.myo_batch_kernel_ms.argtypes = [vp]
         L.myo_batch_kernel_ms.restype = dbl
         L.myo_batch_enable_timing.argtypes = [vp, i32]
-        L.myo_ppo_loss_grad.argtypes = [vp] * 8 + [i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp]
+        L.myo_ppo_loss_grad.argtypes = [vp] * 8 + [i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32, C.c_float, vp, vp, vp, vp]
         L.myo_ppo_gather.argtypes = [vp] * 6 + [i32, i32, i32, vp, i32] + [vp] * 7
         L.myo_bias_relu_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
         L.myo_splitk_reduce.argtypes = [vp, i32, vp, i32, i32, i32, vp]

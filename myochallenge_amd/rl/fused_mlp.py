@@ -134,8 +134,12 @@ class FlatAdam:
         self.lr, self.max_norm, self.betas, self.eps = float(lr), float(max_norm), betas, float(eps)
         dev = flat["p"].device
         self.m, self.v = torch.zeros_like(flat["p"]), torch.zeros_like(flat["p"])
-        self.step_count = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.sq = torch.zeros(1, device=dev)
+        self._step = torch.zeros(2, dtype=torch.int32, device=dev)    # [committed, taken]
+        self.sq = torch.zeros(64, device=dev)
+
+    @property
+    def step_count(self):
+        return self._step[1]
 
     def step(self, grad_scale: float = 1.0):
         f = self.flat
@@ -143,13 +147,13 @@ class FlatAdam:
         p = lambda t: C.c_void_p(t.data_ptr())
         self.lib.check(self.lib.L.myo_adam_clip_step(
             p(f["p"]), p(f["g"]), p(self.m), p(self.v), f["p"].numel(), self.lr, self.betas[0], self.betas[1],
-            self.eps, self.max_norm, float(grad_scale), p(self.step_count), p(self.sq), C.c_void_p(stream)))
+            self.eps, self.max_norm, float(grad_scale), p(self._step), p(self.sq), C.c_void_p(stream)))
 
     def snapshot(self):
-        return [t.clone() for t in (self.flat["p"], self.m, self.v, self.step_count)]
+        return [t.clone() for t in (self.flat["p"], self.m, self.v, self._step)]
 
     def restore(self, snap):
-        for t, s in zip((self.flat["p"], self.m, self.v, self.step_count), snap):
+        for t, s in zip((self.flat["p"], self.m, self.v, self._step), snap):
             t.copy_(s)
 
 
@@ -239,9 +243,13 @@ class FusedPPOStep:
         torch.sum(dh, 1, dtype=torch.float32, out=bias_grad)
         return dh
 
-    def _loss_kernel(self, mean, values, actions, old_logp, adv, returns, dmean_h=None, dvalue_h=None):
+    def _loss_kernel(self, mean, values, actions, old_logp, adv, returns, dmean_h=None, dvalue_h=None, direct=None):
+        """direct = (g_log_std, g_bias_pi, g_bias_vf) tensors written by the finish kernel (merged path)."""
         pol = self.policy
         B, A = mean.shape[0], self.A
+        in_bf16 = int(mean.dtype == torch.bfloat16)
+        assert values.dtype == mean.dtype
+        d = direct or (None, None, None)
         dev = mean.device
         dmean, dvalue = torch.empty((B, A), device=dev), torch.empty(B, device=dev)
         work = self._workbuf("loss", ((B + 63) // 64) * (2 * A + 3))
@@ -249,7 +257,8 @@ class FusedPPOStep:
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         self.lib.check(self.lib.L.myo_ppo_loss_grad(
             p(mean), p(values), p(actions), p(old_logp), p(adv), p(returns), p(pol.log_std.data), p(self.stats),
-            B, A, self.clip, self.vf, p(dmean), p(dvalue), p(self.acc), p(dmean_h), p(dvalue_h), p(work), C.c_void_p(stream)))
+            B, A, self.clip, self.vf, p(dmean), p(dvalue), p(self.acc), p(dmean_h), p(dvalue_h), p(work), in_bf16, self.ent,
+            p(d[0]), p(d[1]), p(d[2]), C.c_void_p(stream)))
         return dmean, dvalue
 
     @torch.no_grad()
@@ -311,14 +320,11 @@ class FusedPPOStep:
         h = saved[-1]
         pi_head, vf_head = self.nets["pi"][-1], self.nets["vf"][-1]
         wpi, wvf = self.wb[id(pi_head.weight)], self.wb[id(vf_head.weight)]
-        mean, values = mean_h.float(), value_h.float().reshape(B)
         dmean_h = torch.empty((B, A), device=dev, dtype=torch.bfloat16)
         dvalue_h = torch.empty((B, 1), device=dev, dtype=torch.bfloat16)
-        self._loss_kernel(mean, values, actions, old_logp, adv, returns, dmean_h, dvalue_h)
+        self._loss_kernel(mean_h, value_h, actions, old_logp, adv, returns, dmean_h, dvalue_h,
+                          direct=(pol.log_std.grad, pi_head.bias.grad, vf_head.bias.grad))
         acc = self.acc
-        torch.sub(acc[:A], self.ent, out=pol.log_std.grad)
-        pi_head.bias.grad.copy_(acc[A + 2:2 * A + 2])
-        vf_head.bias.grad.copy_(acc[2 * A + 2:2 * A + 3])
         # heads: dW (split-K) and the gradient entering the trunks
         for dy, head, x in ((dmean_h, pi_head, h[0]), (dvalue_h, vf_head, h[1])):
             part = torch.bmm(dy.view(s, B // s, -1).transpose(1, 2), x.view(s, B // s, -1))

@@ -165,12 +165,24 @@ def test_ppo_elementwise_kernels_exact(hip_lib):
     dval_h = torch.empty(B, device=dev, dtype=torch.bfloat16)
     acc = torch.full((2 * A + 3,), 7.0, device=dev)
     work = torch.empty(((B + 63) // 64) * (2 * A + 3), device=dev)
+    g_ls, g_bpi, g_bvf = torch.zeros(A, device=dev), torch.zeros(A, device=dev), torch.zeros(1, device=dev)
     hip_lib.check(L.myo_ppo_loss_grad(p(mean), p(values), p(act), p(oldlp), p(adv), p(ret), p(log_std), p(stats), B, A, clip, vf,
-                                      p(dmean), p(dval), p(acc), p(dmean_h), p(dval_h), p(work), None))
+                                      p(dmean), p(dval), p(acc), p(dmean_h), p(dval_h), p(work), 0, 0.01, p(g_ls), p(g_bpi),
+                                      p(g_bvf), None))
     torch.cuda.synchronize()
     tol = lambda a, b, r: float((a - b).abs().max()) <= r * float(b.abs().max()) + 1e-12
     assert tol(dmean, dmean_ref, 2e-5) and tol(dval, dval_ref, 1e-6) and tol(acc, acc_ref, 2e-5)
     assert torch.equal(dmean_h, dmean.bfloat16()) and torch.equal(dval_h, dval.bfloat16())
+    assert torch.equal(g_ls, acc[:A] - 0.01) and torch.equal(g_bpi, acc[A + 2:2 * A + 2]) and torch.equal(g_bvf, acc[2 * A + 2:])
+    # bfloat16 inputs (the GEMM outputs) give the same result as their float32 widening
+    mean_b, val_b = mean.bfloat16(), values.bfloat16()
+    acc2, dmean2, dval2 = torch.zeros_like(acc), torch.zeros_like(dmean), torch.zeros_like(dval)
+    hip_lib.check(L.myo_ppo_loss_grad(p(mean_b.float()), p(val_b.float()), p(act), p(oldlp), p(adv), p(ret), p(log_std), p(stats), B, A,
+                                      clip, vf, p(dmean), p(dval), p(acc), None, None, p(work), 0, 0.0, None, None, None, None))
+    hip_lib.check(L.myo_ppo_loss_grad(p(mean_b), p(val_b), p(act), p(oldlp), p(adv), p(ret), p(log_std), p(stats), B, A,
+                                      clip, vf, p(dmean2), p(dval2), p(acc2), None, None, p(work), 1, 0.0, None, None, None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(acc, acc2) and torch.equal(dmean, dmean2) and torch.equal(dval, dval2)
 
     N = 5000
     obs_all, act_all = torch.randn(N, O, device=dev), torch.randn(N, A, device=dev)

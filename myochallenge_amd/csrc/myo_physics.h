@@ -838,31 +838,48 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
     for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
   }
   T b = (lane < n) ? x[lane] : (T)0;
-  T* colbuf = s.efc_jv;                              // >= 64 entries, free while a system is solved
+  // Column exchange through LDS, software-pipelined: while the trailing update of step k is still
+  // running, column k+1 (updated first) is already written and read back for step k+1.  Two buffers
+  // alternate; a workgroup is one wavefront, so its LDS operations execute in program order and no
+  // barrier is needed between the write and the reads.
+  T* colbuf0 = s.efc_jv;                             // >= 128 entries, free while a system is solved
+  T* colbuf1 = s.efc_jv + 64;
   T invd = 1;                                        // 1 / L[lane][lane]
+  V2 c2[N / 2], c2n[N / 2];
+  colbuf0[lane] = a2[0].x;
+  {
+    const V2* cb = reinterpret_cast<const V2*>(colbuf0);
+#pragma unroll
+    for (int p = 0; p < N / 2; ++p) c2[p] = cb[p];
+  }
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     const T ak = (k & 1) ? a2[k / 2].y : a2[k / 2].x;
-    colbuf[lane] = ak;
-    __syncthreads();
-    const V2* cb = reinterpret_cast<const V2*>(colbuf);
-    V2 c2[N / 2];
-#pragma unroll
-    for (int p = k / 2; p < N / 2; ++p) c2[p] = cb[p];
-    __syncthreads();
     T akk = (k & 1) ? c2[k / 2].y : c2[k / 2].x;
     akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
     const T inv = myo_rsqrt(akk);
     const T lik = ak * inv;                           // lane k: akk / sqrt(akk) = sqrt(akk)
     const V2 m = V2{-lik * inv, -lik * inv};
+    const int p1 = (k + 1) / 2;
+    if (k + 1 < N) {
+      a2[p1] = __builtin_elementwise_fma(m, c2[p1], a2[p1]);      // the pair holding column k+1 goes first
+      T* nb = ((k + 1) & 1) ? colbuf1 : colbuf0;
+      nb[lane] = ((k + 1) & 1) ? a2[p1].y : a2[p1].x;
+      const V2* cb = reinterpret_cast<const V2*>(nb);
 #pragma unroll
-    for (int p = (k + 1) / 2; p < N / 2; ++p) a2[p] = __builtin_elementwise_fma(m, c2[p], a2[p]);
+      for (int p = p1; p < N / 2; ++p) c2n[p] = cb[p];
+    }
+#pragma unroll
+    for (int p = p1 + 1; p < N / 2; ++p) a2[p] = __builtin_elementwise_fma(m, c2[p], a2[p]);
     if (k & 1) a2[k / 2].y = lik; else a2[k / 2].x = lik;
     {
       MYO_OPAQUE_LANE(l)
       if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (k + 1 < N) {
+#pragma unroll
+      for (int p = p1; p < N / 2; ++p) c2[p] = c2n[p];
+    }
   }
   // forward substitution  L y = b   (lane j finishes at step j; later steps must not touch it)
 #pragma unroll

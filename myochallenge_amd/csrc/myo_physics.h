@@ -1663,8 +1663,15 @@ DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
         const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
         const int ns = c.nsup;
         const unsigned long long m1 = c.m1, m2 = c.m2;
-        for (int a = lane >> 3; a < ns; a += 8)
-          for (int b = lane & 7; b <= a; b += 8) {
+        // lower-triangular pairs (a >= b) of the support set, enumerated linearly: q = a(a+1)/2 + b,
+        // so ceil(ns(ns+1)/128) passes instead of an 8x8 tiling with idle upper-triangle lanes
+        const int npair = ns * (ns + 1) / 2;
+        for (int q = lane; q < npair; q += 64) {
+          int a = (int)((sqrtf((float)(8 * q + 1)) - 1.0f) * 0.5f);
+          if ((a + 1) * (a + 2) / 2 <= q) a++;           // float sqrt rounding guard
+          if (a * (a + 1) / 2 > q) a--;
+          const int b = q - a * (a + 1) / 2;
+          {
             const int da = c.sup[a], db = c.sup[b];
             const int a1 = (int)((m1 >> da) & 1ull), a2 = (int)((m2 >> da) & 1ull);
             const int b1 = (int)((m1 >> db) & 1ull), b2 = (int)((m2 >> db) & 1ull);
@@ -1681,6 +1688,7 @@ DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
             const T Ajb2 = A2 * jb[0] + A4 * jb[2];
             s.H[MYO_HIDX(da, db)] += ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2;
           }
+        }
       }
     }
     SYNC();

@@ -12,6 +12,7 @@
 #define MYO_NQ_MAX 38
 #define MYO_NT_MAX 40     // tendons
 #define MYO_NU_MAX 40     // actuators
+#define MYO_AQ_ROW 40     // actuator moment entries per dof (packed qfrc_actuator gather rows)
 #define MYO_MV_ROW 24     // non-zeros in one row of the tree-sparse inertia matrix (packed M*v rows)
 #define MYO_TJ_MAX 8      // dofs one tendon can move
 #define MYO_NM_MAX 176    // tree-sparse inertia entries
@@ -29,7 +30,7 @@
   X(geom_bodyid) X(geom_priority) X(site_bodyid) X(tendon_adr) X(tendon_num) X(tendon_limited)   \
   X(wrap_type) X(wrap_objid) X(wrap_side) X(actuator_dyntype) X(actuator_gaintype)               \
   X(actuator_biastype) X(actuator_tendon) X(actuator_ctrllimited) X(actuator_forcelimited)       \
-  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(wr_i) X(mv_pack) X(mv_len)
+  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len)
 #define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask) X(act_dofmask) X(wr_mask)
 #define MYO_MODEL_REAL_ARRAYS(X)                                                                 \
   X(qpos0) X(qpos_spring) X(body_pos) X(body_quat) X(body_ipos) X(body_imat) X(body_mass)        \

@@ -112,6 +112,7 @@ struct Scratch {
 #define S_QFRC_BIAS(s) ((s).H + MYO_NB_MAX * 20 + MYO_NV_MAX)
 #define S_QFRC_ACTUATOR(s) ((s).H + MYO_NB_MAX * 20 + 2 * MYO_NV_MAX)
 #define S_OBS(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX)
+#define S_ACT_GF(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX)   /* gear * actuator force (actuation stage) */
 #define S_XQUAT(s) ((s).efc_jar)
 #define S_XANCHOR(s) ((s).efc_aref)
 #define S_XAXIS(s) ((s).efc_jv)
@@ -119,7 +120,8 @@ struct Scratch {
 #define S_NPRE(s) (reinterpret_cast<int*>((s).efc_force))
 #define S_CFRCB(s) ((s).bvec)
 #define S_CVEL(s) ((s).Ma)   /* body velocities (velocity stage) live in the solver vectors Ma,grad,search,Mv */
-static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_NV_MAX * MYO_NV_MAX, "H aliases");
+static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX + MYO_NU_MAX <= MYO_NV_MAX * MYO_NV_MAX, "H aliases");
+static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 1024 && MYO_NU_MAX <= 64, "packed actuator gather entries are 10 + 6 bits");
 static_assert(MYO_NV_MAX * 6 <= MYO_NB_MAX * 10, "cdof_dot fits where crb was");
 static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in Ma..Mv");
 static_assert(MYO_NB_MAX * 4 <= MYO_NEFC_MAX && MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX && 64 <= MYO_NEFC_MAX, "efc aliases");
@@ -1559,22 +1561,25 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
       T f = gain * input + bias;
       if (M.actuator_forcelimited[i]) f = tclamp(f, M.actuator_forcerange[2 * i], M.actuator_forcerange[2 * i + 1]);
       s.act_force[i] = f;
+      S_ACT_GF(s)[i] = M.act_gear0[i] * f;
     }
   }
   SYNC();
-  // qfrc_actuator = moment' * force.  lane = dof; the actuator loop runs over the zero-padded
-  // actuator-major tables in groups of 8 (uniform index: scalar loads, no dependent chain)
+  // qfrc_actuator = moment' * force.  lane = dof; its (ten_J offset, actuator) pairs arrive in one
+  // wide load (host-built dof-major table, actuator order), then two LDS reads per entry
   PHASE {
     const int d = lane;
     if (d < M.nv) {
-      T acc = 0;
-      const unsigned long long below = (1ull << d) - 1ull;
-      for (int i0 = 0; i0 < M.nu; i0 += 8) {
+      unsigned w[MYO_AQ_ROW / 2];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int i = i0 + k;
-          const unsigned long long m = M.act_dofmask[i];
-          if ((m >> d) & 1ull) acc += M.act_gear0[i] * s.ten_J[M.act_tj[i] + myo_popcll(m & below)] * s.act_force[i];
+      for (int q = 0; q < MYO_AQ_ROW / 2; ++q) w[q] = (unsigned)M.aq_pack[d * (MYO_AQ_ROW / 2) + q];
+      const int len = M.aq_len[d];
+      T acc = 0;
+#pragma unroll
+      for (int k = 0; k < MYO_AQ_ROW; ++k) {
+        if (k < len) {
+          const unsigned ent = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xffffu);
+          acc += s.ten_J[ent >> 6] * S_ACT_GF(s)[ent & 63u];
         }
       }
       S_QFRC_ACTUATOR(s)[d] = acc;
@@ -1737,6 +1742,7 @@ DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
     J_times(M, s, LOFF(s, s.search), LOFF(s, s.bvec), LOFF(s, s.efc_jv));
     WAVE_SUM3_N(T, q1, q2, sn2, nv, c, { _e1 = s.search[c] * (s.Ma[c] - s.qfrc_smooth[c]); _e2 = (T)0.5 * s.search[c] * s.Mv[c]; _e3 = s.search[c] * s.search[c]; });
     const T snorm = sqrt(sn2);
+    PROF(s, 0)
 #ifdef MYO_EMU_DEBUG
     printf("newton iter %d cost %g q1 %g q2 %g snorm %g nefc %d\n", iter, (double)cost, (double)q1, (double)q2, (double)snorm, nefc);
 #endif
@@ -1764,6 +1770,7 @@ DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
       printf("   ls %d alpha %g d1 %g d2 %g gtol %g\n", li, (double)alpha, (double)d1, (double)d2, (double)gtol);
 #endif
     }
+    PROF(s, 14)
     if (alpha == 0) break;
     PHASE {
       const int c = lane;

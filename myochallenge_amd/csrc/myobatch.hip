@@ -262,6 +262,26 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   }
   m->actuator_tendon.resize(m->nu);
   for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
+  // qfrc_actuator gather, dof-major: for dof d the (ten_J offset << 6 | actuator) pairs of every
+  // actuator whose tendon moves d, in actuator order; 16-bit entries, two per word (one wide load per dof)
+  m->aq_pack.assign((size_t)nv * (MYO_AQ_ROW / 2), 0);
+  m->aq_len.assign(nv, 0);
+  for (int d = 0; d < nv; ++d) {
+    int len = 0;
+    for (int i = 0; i < m->nu; ++i) {
+      const int t = m->actuator_tendon[i];
+      const unsigned long long mk = m->tendon_dofmask[t];
+      if (!((mk >> d) & 1ull)) continue;
+      LIM(len >= MYO_AQ_ROW, "more than MYO_AQ_ROW actuators act on one dof")
+      int slot = 0;
+      for (int b = 0; b < d; ++b) slot += (int)((mk >> b) & 1ull);
+      const unsigned ent = ((unsigned)(t * MYO_TJ_MAX + slot) << 6) | (unsigned)i;
+      unsigned& w = reinterpret_cast<unsigned&>(m->aq_pack[(size_t)d * (MYO_AQ_ROW / 2) + len / 2]);
+      w |= (len & 1) ? (ent << 16) : ent;
+      len++;
+    }
+    m->aq_len[d] = len;
+  }
   // actuator-major copies for the moment-transpose gather, zero-padded to MYO_NU_MAX so the loop
   // runs in unconditional groups of 8 (scalar loads merge into s_load_dwordx8/x16)
   m->act_dofmask.assign(MYO_NU_MAX, 0ull);

@@ -6,7 +6,7 @@ from myochallenge_amd import native
 from myochallenge_amd.envs.config import make_task_cfg
 from myochallenge_amd.model import compile_model
 from myochallenge_amd.synth_hand import synthetic_hand
-names = ["load/store/other", "kinematics", "com_pos + newton Mv/Jv products", "tendon", "crb", "collision+constraint", "velocity", "actuation",
+names = ["newton Mv,Jv products (+load/store)", "kinematics", "com_pos + newton Mv/Jv products", "tendon", "crb", "collision+constraint", "velocity", "actuation",
          "qacc_smooth(chol)", "hessian", "newton chol", "newton rest", "euler implicit chol", "advance", "newton line search", "check/misc"]
 lib = native.load("tools/dev/libmyobatch_prof.so")
 dev = torch.device("cuda:0")

@@ -734,7 +734,12 @@ DEVFN void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* dia
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    for (int k = lane; k < MYO_NV_MAX * MYO_NV_MAX; k += 64) s.H[k] = ((k / MYO_NV_MAX) == (k % MYO_NV_MAX) && (k / MYO_NV_MAX) >= M.nv) ? (T)1 : (T)0;
+    if (lane < MYO_NV_MAX) {       // lane = row: 16-byte stores; identity on the padding rows
+      T* row = s.H + lane * MYO_NV_MAX;
+#pragma unroll
+      for (int q = 0; q < MYO_NV_MAX; ++q) row[q] = 0;
+      if (lane >= M.nv) row[lane] = 1;
+    }
   }
   SYNC();
   PHASE {

@@ -1755,15 +1755,30 @@ DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
     const T gtol = M.tolerance * (T)0.01 * snorm / scale;
     // exact 1-D minimisation of the convex piecewise-quadratic: safeguarded Newton on p'(alpha)
     T alpha = 0, lo = 0, hi = -1;
+    // each lane keeps its (<= 3) rows' jar, jv and D in registers for the whole line search
+    static_assert(MYO_NEFC_MAX <= 192, "three rows per lane");
+    LANE_VAR(T, ls_x0); LANE_VAR(T, ls_x1); LANE_VAR(T, ls_x2);
+    LANE_VAR(T, ls_v0); LANE_VAR(T, ls_v1); LANE_VAR(T, ls_v2);
+    LANE_VAR(T, ls_d0); LANE_VAR(T, ls_d1); LANE_VAR(T, ls_d2);
+    PHASE {
+      const int r0 = lane, r1 = lane + 64, r2 = lane + 128;
+      LV(ls_x0) = r0 < nefc ? s.efc_jar[r0] : (T)0; LV(ls_v0) = r0 < nefc ? s.efc_jv[r0] : (T)0;
+      LV(ls_d0) = r0 < nefc ? row_D(s, r0, nlim) : (T)0;
+      LV(ls_x1) = r1 < nefc ? s.efc_jar[r1] : (T)0; LV(ls_v1) = r1 < nefc ? s.efc_jv[r1] : (T)0;
+      LV(ls_d1) = r1 < nefc ? row_D(s, r1, nlim) : (T)0;
+      LV(ls_x2) = r2 < nefc ? s.efc_jar[r2] : (T)0; LV(ls_v2) = r2 < nefc ? s.efc_jv[r2] : (T)0;
+      LV(ls_d2) = r2 < nefc ? row_D(s, r2, nlim) : (T)0;
+    }
     for (int li = 0; li < 50; ++li) {
-      WAVE_SUM3_N(T, e0, e1, e2, nefc, r, {
-        const T x = s.efc_jar[r] + alpha * s.efc_jv[r];
-        if (x < 0) { const T D = row_D(s, r, nlim), jv = s.efc_jv[r]; _e1 = (T)0.5 * D * x * x; _e2 = D * x * jv; _e3 = D * jv * jv; }
+      WAVE_SUM2_LANES(T, e1, e2, {
+        const T xa = LV(ls_x0) + alpha * LV(ls_v0), xb = LV(ls_x1) + alpha * LV(ls_v1), xc = LV(ls_x2) + alpha * LV(ls_v2);
+        if (xa < 0) { _e1 += LV(ls_d0) * xa * LV(ls_v0); _e2 += LV(ls_d0) * LV(ls_v0) * LV(ls_v0); }
+        if (xb < 0) { _e1 += LV(ls_d1) * xb * LV(ls_v1); _e2 += LV(ls_d1) * LV(ls_v1) * LV(ls_v1); }
+        if (xc < 0) { _e1 += LV(ls_d2) * xc * LV(ls_v2); _e2 += LV(ls_d2) * LV(ls_v2) * LV(ls_v2); }
       });
-      (void)e0;
       const T d1 = 2 * alpha * q2 + q1 + e1, d2 = 2 * q2 + e2;
 #ifdef MYO_EMU_DEBUG
-      printf("   ls %d alpha %g d1 %g d2 %g gtol %g e1 %g e2 %g jar0 %g jv0 %g D0 %g\n", li, (double)alpha, (double)d1, (double)d2, (double)gtol, (double)e1, (double)e2, (double)s.efc_jar[0], (double)s.efc_jv[0], (double)s.efc_D[0]);
+      printf("   ls %d alpha %g d1 %g d2 %g gtol %g e1 %g e2 %g\n", li, (double)alpha, (double)d1, (double)d2, (double)gtol, (double)e1, (double)e2);
 #endif
       if (fabs(d1) < gtol) break;
       if (d1 < 0) lo = alpha; else hi = alpha;

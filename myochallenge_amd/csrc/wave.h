@@ -38,6 +38,14 @@
     __VA_ARGS__;                                 \
     o1 += _e1; o2 += _e2; o3 += _e3;             \
   }
+// sums over the 64 lanes of two per-lane expressions written with LV() (lane variables)
+#define WAVE_SUM2_LANES(T, o1, o2, ...)          \
+  T o1 = 0, o2 = 0;                              \
+  for (int lane = 0; lane < 64; ++lane) {        \
+    T _e1 = 0, _e2 = 0;                          \
+    __VA_ARGS__;                                 \
+    o1 += _e1; o2 += _e2;                        \
+  }
 // exclusive prefix over lanes of a per-lane count in {0,1,2}; pre = scratch int[64]
 #define WAVE_EXSCAN(cnt_expr, pre, total)            \
   {                                                  \
@@ -128,6 +136,14 @@ template <> __device__ __forceinline__ int myo_wave_sum<int>(int v) {
     o1 = myo_wave_sum<T>(_a1);                               \
     o2 = myo_wave_sum<T>(_a2);                               \
     o3 = myo_wave_sum<T>(_a3);                               \
+  }
+#define WAVE_SUM2_LANES(T, o1, o2, ...)                      \
+  T o1, o2;                                                  \
+  {                                                          \
+    T _e1 = 0, _e2 = 0;                                      \
+    __VA_ARGS__;                                             \
+    o1 = myo_wave_sum<T>(_e1);                               \
+    o2 = myo_wave_sum<T>(_e2);                               \
   }
 #define WAVE_EXSCAN(cnt_expr, pre, total)                                          \
   {                                                                                \

@@ -289,7 +289,10 @@ class FusedPPOStep:
 
     def refresh_shadow(self):
         """bf16 shadow of the master weights (one cast kernel on the flat vector)."""
-        torch._foreach_copy_(self.half, self.master)
+        if len(self.half) == 1:
+            self.half[0].copy_(self.master[0])       # flat vector: one cast kernel
+        else:
+            torch._foreach_copy_(self.half, self.master)
 
     def trunk_heads(self, x2):
         """Stacked actor/critic forward on the bf16 shadow weights: x2 bf16 [2,B,obs] -> (hidden

@@ -1341,6 +1341,74 @@ DEVFN void J_times(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r
   SYNC();
 }
 
+// body_vectors / J_times for TWO vectors at once (the solver's warm-start comparison evaluates J on
+// qacc_warmstart and on qacc_smooth): the cdof entries and contact records are read once.
+template <typename T>
+DEVFN void body_vectors2(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) va_r, LCREF(T) vb_r, LREF(T) outa_r, LREF(T) outb_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* va = LPTR(const T, va_r); const T* vb = LPTR(const T, vb_r);
+  T* outa = LPTR(T, outa_r); T* outb = LPTR(T, outb_r);
+  WAVE_FN
+  PHASE {
+    const int b = lane;
+    if (b < M.nbody) {
+      T acca[6] = {0, 0, 0, 0, 0, 0}, accb[6] = {0, 0, 0, 0, 0, 0};
+      unsigned long long m = M.body_dofmask[b];
+      while (m) {
+        const int d = myo_ffsll(m);
+        m &= m - 1;
+        const T xa = va[d], xb = vb[d];
+        for (int e = 0; e < 6; ++e) { const T cd = s.cdof[6 * d + e]; acca[e] += cd * xa; accb[e] += cd * xb; }
+      }
+      for (int e = 0; e < 6; ++e) { outa[6 * b + e] = acca[e]; outb[6 * b + e] = accb[e]; }
+    }
+  }
+  SYNC();
+}
+template <typename T>
+DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) va_r, LCREF(T) bva_r, LREF(T) outa_r,
+                    LCREF(T) vb_r, LCREF(T) bvb_r, LREF(T) outb_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* va = LPTR(const T, va_r); const T* bva = LPTR(const T, bva_r); T* outa = LPTR(T, outa_r);
+  const T* vb = LPTR(const T, vb_r); const T* bvb = LPTR(const T, bvb_r); T* outb = LPTR(T, outb_r);
+  WAVE_FN
+  const int nl = s.nl, nlim = s.nl + s.ntl, nefc = s.nefc;
+  PHASE {
+    for (int r = lane; r < nefc; r += 64) {
+      T vala, valb;
+      if (r < nl) { const T sg = s.lim_sgn[r]; const int id = s.lim_id[r]; vala = sg * va[id]; valb = sg * vb[id]; }
+      else if (r < nlim) {
+        const int t = s.lim_id[r];
+        unsigned long long m = M.tendon_dofmask[t];
+        T acca = 0, accb = 0;
+        int slot = 0;
+        while (m) {
+          const int d = myo_ffsll(m); m &= m - 1;
+          const T j = s.ten_J[t * MYO_TJ_MAX + slot];
+          acca += j * va[d]; accb += j * vb[d]; slot++;
+        }
+        vala = s.lim_sgn[r] * acca; valb = s.lim_sgn[r] * accb;
+      } else {
+        const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
+        const ContactRec<T>& c = s.con[ci];
+        const T* fn = c.frame; const T* ft = c.frame + 3 + 3 * (e >> 1);
+        const T mu = (e & 1) ? -c.mu[e >> 1] : c.mu[e >> 1];
+        T v1[3], v2[3];
+        point_vel(bva, c.b1, c.r1, v1);
+        point_vel(bva, c.b2, c.r2, v2);
+        const T rela[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+        vala = dot3(fn, rela) + mu * dot3(ft, rela);
+        point_vel(bvb, c.b1, c.r1, v1);
+        point_vel(bvb, c.b2, c.r2, v2);
+        const T relb[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+        valb = dot3(fn, relb) + mu * dot3(ft, relb);
+      }
+      outa[r] = vala; outb[r] = valb;
+    }
+  }
+  SYNC();
+}
+
 // out = J' f  (lanes = dofs; contacts act as a world force at the contact point)
 template <typename T>
 DEVFN void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LREF(T) out_r) {
@@ -1711,10 +1779,10 @@ DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
   WAVE_FN
   const int nv = M.nv, nefc = s.nefc;
   // ---- warm start: cheaper of qacc_warmstart and qacc_smooth
-  body_vectors(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec));
-  J_times(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_jar));
-  body_vectors(M, s, LOFF(s, s.qacc_smooth), LOFF(s, s.bvec));
-  J_times(M, s, LOFF(s, s.qacc_smooth), LOFF(s, s.bvec), LOFF(s, s.efc_jv));
+  // (the second set of body vectors borrows Ma..Mv, which the solver has not started to use)
+  body_vectors2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.qacc_smooth), LOFF(s, s.bvec), LOFF(s, S_CVEL(s)));
+  J_times2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_jar), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)),
+           LOFF(s, s.efc_jv));
   mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc_warm));
   const int nlim = s.nl + s.ntl;
   WAVE_SUM_N(T, costw_c, nefc, r, ((s.efc_jar[r] - s.efc_aref[r]) < 0 ? (T)0.5 * row_D(s, r, nlim) * (s.efc_jar[r] - s.efc_aref[r]) * (s.efc_jar[r] - s.efc_aref[r]) : (T)0));

@@ -1992,7 +1992,7 @@ DEVFN void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc)
 }
 
 template <typename T>
-DEVFN void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   check_state(M, s, 0);

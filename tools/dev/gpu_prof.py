@@ -8,7 +8,8 @@ from myochallenge_amd.model import compile_model
 from myochallenge_amd.synth_hand import synthetic_hand
 names = ["newton Mv,Jv products (+load/store)", "kinematics", "com_pos + newton Mv/Jv products", "tendon", "crb", "collision+constraint", "velocity", "actuation",
          "qacc_smooth(chol)", "hessian", "newton chol", "newton rest", "euler implicit chol", "advance", "newton line search", "check/misc"]
-lib = native.load("tools/dev/libmyobatch_prof.so")
+import os
+lib = native.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyobatch_prof.so"))
 dev = torch.device("cuda:0")
 for integ in (0,):
   for dtype, dn in ((native.MYO_F32, "f32"), (native.MYO_F64, "f64")):

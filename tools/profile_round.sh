@@ -1,0 +1,32 @@
+#!/bin/bash
+# Regenerates the measured records of a round on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh
+# Outputs land in gpurun_out/round/ ; copy the ones to keep into profiles/.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/round
+mkdir -p $OUT
+export PYTHONPATH=$ROOT
+cd /tmp && export TMPDIR=/tmp
+# 1. the bench line itself (with the CPU baseline leg)
+python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+# 2. per-kernel time of the same command (no CPU leg: it is host-only work)
+rm -rf /tmp/prof_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- python3 $ROOT/bench.py --no-cpu-baseline > /tmp/stats.log 2>&1
+find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
+grep -v "^[WIE]2026" /tmp/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
+# 3. PMC counters of k_step inside the same command, one --pmc pass per set (no other tracing)
+: > $OUT/pmc_kstep.txt
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
+  rm -rf /tmp/pmc
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
+  python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_kstep.txt
+done
+# 4. stage shares (instrumented build; shares only)
+python3 $ROOT/tools/dev/gpu_prof.py > $OUT/stage_shares.txt 2>&1
+# 5. other configurations (BASELINE.json configs / variants)
+python3 $ROOT/bench.py --no-cpu-baseline --dtype f64 > $OUT/bench_f64.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --integrator rk4 > $OUT/bench_rk4.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --env-name CustomMyoBaodingBallsP2 --envs 8192 > $OUT/bench_p2_8192.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
+echo done

@@ -70,6 +70,7 @@ class BaodingVecEnv:
             self.device = torch.device(f"cuda:{device}")
         self._model = native.Model(model, self.lib)
         self._cfg = make_task_cfg(env_name, model, **config)
+        self.max_episode_steps = int(self._cfg.max_episode_steps)
         self.dtype = {"f32": native.MYO_F32, "f64": native.MYO_F64}[dtype]
         self.batch = native.Batch(self._model, self._cfg, num_envs, device, seed, self.dtype)
         self.num_envs = num_envs

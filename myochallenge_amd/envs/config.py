@@ -62,12 +62,13 @@ def resolve_kwargs(env_name: str, **kwargs) -> dict:
     defaults = P1_DEFAULTS if reg["variant"] == "p1" else P2_DEFAULTS
     merged = dict(defaults)
     merged.update(reg["kwargs"])
+    horizon = kwargs.pop("max_episode_steps", None)     # gym.make(id, max_episode_steps=...) overrides the TimeLimit
     for k, v in kwargs.items():
         if k not in merged and k not in IGNORED:
             raise TypeError(f"{env_name}: unexpected keyword argument {k!r}")
         merged[k] = v
     merged["variant"] = reg["variant"]
-    merged["max_episode_steps"] = reg["max_episode_steps"]
+    merged["max_episode_steps"] = reg["max_episode_steps"] if horizon is None else int(horizon)
     return merged
 
 

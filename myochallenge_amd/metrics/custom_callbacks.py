@@ -1,0 +1,97 @@
+"""Callbacks with the reference's names (src/metrics/custom_callbacks.py, SB3 EvalCallback), batched.
+
+They are plain callables ``cb(algo)`` for ``PPO.learn(callback=...)`` (called once per rollout; the
+``eval_freq`` / ``save_freq`` counters are in env timesteps like SB3's).
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, Optional
+
+import numpy as np
+
+from .evaluation import evaluate_policy
+
+
+class EvaluateLSTM:
+    """src/metrics/custom_callbacks.py:7-48: every ``eval_freq`` timesteps play ``num_episodes``
+    deterministic episodes with the *training* model and the *training* env's normaliser; record the
+    mean return under ``name``.  The reference plays them one after another on one env."""
+
+    def __init__(self, eval_freq, eval_env, name, num_episodes=20, log: Optional[Callable[[dict], None]] = None):
+        self.eval_freq, self.eval_env, self.name, self.num_episodes, self.log = eval_freq, eval_env, name, num_episodes, log
+        self._next = eval_freq
+        self.history = []
+
+    def __call__(self, algo) -> bool:
+        if algo.num_timesteps < self._next:
+            return True
+        self._next += self.eval_freq
+        normalizer = algo.env if hasattr(algo.env, "normalize_obs") else None
+        res = evaluate_policy(algo.policy, self.eval_env, normalizer, self.num_episodes, deterministic=True)
+        mean = float(np.mean(res["returns"]))
+        self.history.append((algo.num_timesteps, mean))
+        if self.log is not None:
+            self.log({self.name: mean})
+        return True
+
+
+class EnvDumpCallback:
+    """src/metrics/custom_callbacks.py:51-62: save ``best_model`` and the training env's normaliser
+    (``training_env.save``) into ``save_path`` (used as ``callback_on_new_best``)."""
+
+    def __init__(self, save_path, verbose=0):
+        self.save_path, self.verbose = save_path, verbose
+
+    def __call__(self, algo) -> bool:
+        os.makedirs(self.save_path, exist_ok=True)
+        algo.save(os.path.join(self.save_path, "best_model.zip"))
+        if hasattr(algo.env, "save"):
+            algo.env.save(os.path.join(self.save_path, "training_env.pkl"))
+        return True
+
+
+class EvalCallback:
+    """SB3 ``EvalCallback`` as the reference configures it (src/main_baoding.py:81-91): every ``eval_freq``
+    timesteps evaluate ``n_eval_episodes`` deterministic episodes on ``eval_env`` (its own normaliser
+    statistics synchronised from the training env first, as SB3's ``sync_envs_normalization``), append to
+    ``<log_path>/evaluations.npz`` (keys ``timesteps``, ``results``, ``ep_lengths`` — SB3's format), keep
+    the best mean reward and fire ``callback_on_new_best``."""
+
+    def __init__(self, eval_env, callback_on_new_best=None, n_eval_episodes=10, best_model_save_path=None, log_path=None,
+                 eval_freq=10_000, deterministic=True, render=False, verbose=1):
+        self.eval_env, self.on_best, self.n, self.best_path = eval_env, callback_on_new_best, n_eval_episodes, best_model_save_path
+        self.log_path, self.eval_freq, self.deterministic, self.verbose = log_path, eval_freq, deterministic, verbose
+        self._next = eval_freq
+        self.best_mean_reward = -np.inf
+        self.evaluations_timesteps, self.evaluations_results, self.evaluations_length = [], [], []
+
+    def __call__(self, algo) -> bool:
+        if algo.num_timesteps < self._next:
+            return True
+        self._next += self.eval_freq
+        env = self.eval_env
+        normalizer = env if hasattr(env, "normalize_obs") else (algo.env if hasattr(algo.env, "normalize_obs") else None)
+        if hasattr(env, "obs_rms") and hasattr(algo.env, "obs_rms") and env is not algo.env:     # sync_envs_normalization
+            env.obs_rms.load(**algo.env.obs_rms.state())
+            env.ret_rms.load(**algo.env.ret_rms.state())
+        raw = env.venv if hasattr(env, "venv") else env
+        res = evaluate_policy(algo.policy, raw, normalizer, self.n, deterministic=self.deterministic)
+        self.evaluations_timesteps.append(algo.num_timesteps)
+        self.evaluations_results.append(res["returns"][:self.n])
+        self.evaluations_length.append(res["lengths"][:self.n])
+        if self.log_path is not None:
+            os.makedirs(self.log_path, exist_ok=True)
+            np.savez(os.path.join(self.log_path, "evaluations"), timesteps=self.evaluations_timesteps,
+                     results=self.evaluations_results, ep_lengths=self.evaluations_length)
+        mean = float(np.mean(res["returns"]))
+        if self.verbose:
+            print(f"Eval num_timesteps={algo.num_timesteps}, episode_reward={mean:.2f} +/- {np.std(res['returns']):.2f}")
+        if mean > self.best_mean_reward:
+            self.best_mean_reward = mean
+            if self.best_path is not None:
+                os.makedirs(self.best_path, exist_ok=True)
+                algo.save(os.path.join(self.best_path, "best_model.zip"))
+            if self.on_best is not None:
+                self.on_best(algo)
+        return True

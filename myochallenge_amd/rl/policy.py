@@ -42,6 +42,8 @@ class ActorCriticPolicy(nn.Module):
                  log_std_init: float = -2.0, activation_fn=nn.ReLU):
         super().__init__()
         self.obs_dim, self.act_dim = obs_dim, act_dim
+        self.pi_arch, self.vf_arch = list(pi), list(vf)
+        self.lstm_hidden_size, self.enable_critic_lstm = lstm_hidden_size, enable_critic_lstm
         self.recurrent = lstm_hidden_size is not None
         feat = obs_dim
         if self.recurrent:

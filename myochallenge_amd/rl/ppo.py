@@ -442,6 +442,52 @@ class PPO:
         self._fused.refresh_shadow()     # rollout inference reads the bf16 shadow weights
         return g["pl"], g["vl"]
 
+    # ---------------------------------------------------------------- persistence (SB3 zip layout)
+    def _optimizer_state_dict(self) -> dict:
+        """torch.optim.Adam state_dict layout (what SB3 stores in policy.optimizer.pth), parameter order of
+        ``policy.parameters()`` as SB3 builds its optimiser."""
+        cfg = self.cfg
+        params = list(self.policy.parameters())
+        state = {}
+        if self._flat_adam is not None:
+            fa, flat = self._flat_adam, self.policy._flat
+            slot = {id(p): sl for p, sl in zip(flat["params"], flat["slots"])}
+            step = float(fa.step_count)
+            if step > 0:
+                for i, p in enumerate(params):
+                    off, k = slot[id(p)]
+                    state[i] = {"step": torch.tensor(step), "exp_avg": fa.m[off:off + k].view(p.shape).cpu().clone(),
+                                "exp_avg_sq": fa.v[off:off + k].view(p.shape).cpu().clone()}
+        else:
+            sd = self.optimizer.state_dict()
+            state = {i: {k: (v.detach().cpu().clone() if torch.is_tensor(v) else v) for k, v in st.items()}
+                     for i, st in sd["state"].items()}
+        return {"state": state, "param_groups": [{"lr": cfg.learning_rate, "betas": (0.9, 0.999), "eps": 1e-5, "weight_decay": 0,
+                                                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                                                  "params": list(range(len(params)))}]}
+
+    def save(self, path: str) -> None:
+        """``model.save(path)`` of the reference's callbacks (src/metrics/custom_callbacks.py:59): a
+        stable-baselines3-format zip (rl/sb3_zip.save_sb3_zip)."""
+        from .sb3_zip import save_sb3_zip
+        cfg = self.cfg
+        hyper = {k: getattr(cfg, k) for k in ("n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "ent_coef", "vf_coef",
+                                              "max_grad_norm", "learning_rate", "clip_range", "normalize_advantage")}
+        last = self._last_obs.detach().cpu().numpy() if self._last_obs is not None else None
+        orig = getattr(self.env, "old_obs", None)
+        save_sb3_zip(path, self.policy, hyper, n_envs=self.env.num_envs, num_timesteps=self.num_timesteps, n_updates=self.n_updates,
+                     last_obs=last, last_original_obs=orig.detach().cpu().numpy() if orig is not None else None,
+                     last_episode_starts=self._last_starts.detach().cpu().numpy() > 0.5,
+                     optimizer_state=self._optimizer_state_dict(), clip_obs=float(getattr(self.env, "clip_obs", 10.0)))
+
+    def set_parameters(self, path: str) -> None:
+        """Load policy weights from a stable-baselines3 zip (``RecurrentPPO.load`` of src/train/trainer.py:51-56)."""
+        from .sb3_zip import read_zip
+        _, sd, _ = read_zip(path)
+        self.policy.load_state_dict(sd, strict=True)        # in place: the flat-vector views stay valid
+        if self._fused is not None:
+            self._fused.refresh_shadow()
+
     def learn(self, total_timesteps: int, callback: Optional[Callable[["PPO"], None]] = None, log=None):
         t_start = time.time()
         while self.num_timesteps < total_timesteps:

@@ -172,6 +172,34 @@ class VecNormalize:
         with open(path, "wb") as fh:
             pickle.dump({"format": "myochallenge_amd.VecNormalize/1", **self.state_dict()}, fh)
 
+    def save_sb3(self, path: str) -> None:
+        """Write the pickle ``stable_baselines3.common.vec_env.VecNormalize.load`` reads (what the reference's
+        ``envs.save(path)`` produces, /root/reference/src/train/trainer.py:75): a VecNormalize object whose
+        state is SB3's ``__getstate__`` (no venv / class_attributes / returns), with ``RunningMeanStd`` and
+        gym ``Box`` members.  Works without SB3 / gym installed (see rl/sb3_pickle.py)."""
+        from .sb3_pickle import instance, stand_ins
+        specs = [("stable_baselines3.common.vec_env.vec_normalize", "VecNormalize", "object"),
+                 ("stable_baselines3.common.running_mean_std", "RunningMeanStd", "object"),
+                 ("gym.spaces.box", "Box", "object")]
+        O, A = self.obs_dim, self.act_dim
+        with stand_ins(specs) as C:
+            VN, RMS, Box = (C[(m, n)] for m, n, _ in specs)
+            box = lambda n, lo, hi: instance(Box, {"dtype": np.dtype("float32"), "shape": (n,), "low": np.full(n, lo, np.float32),
+                                                  "high": np.full(n, hi, np.float32), "np_random": None})
+            rms = lambda r: instance(RMS, {"mean": r.mean.cpu().numpy().copy(), "var": r.var.cpu().numpy().copy(),
+                                           "count": float(r.count)})
+            old_obs = self.old_obs.cpu().numpy() if self.old_obs is not None else np.zeros((self.num_envs, O), np.float32)
+            old_rew = self.old_reward.cpu().numpy() if self.old_reward is not None else np.zeros(self.num_envs, np.float32)
+            obj = instance(VN, {
+                "num_envs": int(self.num_envs), "observation_space": box(O, -self.clip_obs, self.clip_obs) if self.norm_obs
+                else box(O, -np.inf, np.inf), "action_space": box(A, -1.0, 1.0), "norm_obs": bool(self.norm_obs),
+                "norm_obs_keys": None, "obs_spaces": None, "obs_rms": rms(self.obs_rms), "ret_rms": rms(self.ret_rms),
+                "clip_obs": float(self.clip_obs), "clip_reward": float(self.clip_reward), "gamma": float(self.gamma),
+                "epsilon": float(self.epsilon), "training": bool(self.training), "norm_reward": bool(self.norm_reward),
+                "old_obs": old_obs, "old_reward": old_rew})
+            with open(path, "wb") as fh:
+                pickle.dump(obj, fh, protocol=4)
+
     def _load_state(self, st) -> None:
         self.obs_rms.load(**st["obs_rms"])
         self.ret_rms.load(**st["ret_rms"])

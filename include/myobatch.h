@@ -97,6 +97,13 @@ int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, void* stream)
 int myo_batch_step(myo_batch* b, const float* act, float* obs, float* rew, uint8_t* done,
                    uint8_t* trunc, float* term_obs, float* comps, float* ep_info, void* stream);
 
+/* env.step(a) of the UNWRAPPED env for the envs selected by mask (dev uint8[N], NULL = all): no
+ * TimeLimit / Monitor accounting, no auto-reset.  This is the `self.step(action)` that
+ * MixtureModelBaodingEnv.reset runs with its base policy for the first n_steps_base_model steps
+ * (baoding.py:700-711).  obs rows of unselected envs are left untouched; done (may be NULL) receives
+ * the env's own done flag (ball dropped) for the selected envs. */
+int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const float* act, float* obs, uint8_t* done, void* stream);
+
 /* raw physics: apply ctrl (dev double[N,nu]) and run `nsub` mj_step substeps; no task layer.
  * Used by parity tests on arbitrary models. */
 int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub, void* stream);

@@ -391,6 +391,26 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
   store_env(M, L, rec, s);
 }
 
+// env.step(a) of the UNWRAPPED gym env for the envs selected by mask: no TimeLimit / Monitor accounting and
+// no auto-reset — the steps MixtureModelBaodingEnv.reset takes with its base policy
+// (/root/reference/src/envs/baoding.py:700-711).  done_out = the env's own `done` (ball dropped).
+template <typename T>
+DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+                        int env, const unsigned char* mask, const float* act, float* obs, unsigned char* done_out) {
+  WAVE_FN
+  if (mask && !mask[env]) return;
+  const int nobs = K.n_hand + 24 + M.na;
+  load_env(M, L, rec, s);
+  baoding_step_core(M, K, s, act + (size_t)env * M.nu);
+  const int fall = s.rwd[6] != 0 || s.bad;
+  PHASE {
+    if (lane == 0 && done_out) done_out[env] = (unsigned char)fall;
+    for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
+  }
+  SYNC();
+  store_env(M, L, rec, s);
+}
+
 template <typename T>
 DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
                    int env, const unsigned char* mask, float* obs) {

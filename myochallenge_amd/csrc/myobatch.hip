@@ -585,6 +585,16 @@ __global__ void __launch_bounds__(64, 2) k_reset(EnvRecordLayout L, double* rec,
   env_reset<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, obs);
 }
 template <typename T, bool RK>
+__global__ void __launch_bounds__(64, 2) k_step_inner(EnvRecordLayout L, double* rec, const unsigned char* mask, const float* act,
+                                                   float* obs, unsigned char* done) {
+  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  const DevModel<T>& M = myo_cmodel<T>();
+  const TaskDev& K = c_task;
+  const int env = blockIdx.x;
+  env_step_inner<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, act, obs, done);
+}
+template <typename T, bool RK>
 __global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* rec,
                                                 const double* ctrl, int nsub) {
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
@@ -776,6 +786,26 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info))
   timing_end(b, st);
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+extern "C" int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const float* act, float* obs, uint8_t* done, void* stream) {
+  if (!b || !act || !obs) return fail(MYO_E_ARG, "myo_batch_step_inner: act/obs are required");
+  if (!b->K.kind) return fail(MYO_E_STATE, "batch has no task layer");
+#ifdef MYO_EMU
+  (void)stream;
+  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_step_inner<double>(b->Md, b->K, b->L, rec, *s, env, mask, act, obs, done))
+  else FOR_ENVS_F32(env_step_inner<float>(b->Mf, b->K, b->L, rec, *s, env, mask, act, obs, done))
+#else
+  hipStream_t st = (hipStream_t)stream;
+  BIND_OR_RETURN(b, st)
+  LAUNCH_RK(b,
+    if (b->dtype == MYO_F64)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done))
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;

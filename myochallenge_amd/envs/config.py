@@ -27,6 +27,13 @@ REGISTRATION = {
                 "goal_yrange": (0.022, 0.032), "obj_size_range": (0.018, 0.024),
                 "obj_mass_range": (0.030, 0.300), "obj_friction_change": (0.2, 0.001, 0.00002),
                 "task_choice": "random"}),
+    # src/envs/__init__.py:76-93 (MixtureModelBaoding-v1): the phase-2 env whose reset plays a base policy first
+    "MixtureModelBaodingEnv": dict(
+        variant="p2", max_episode_steps=200,
+        kwargs={"normalize_act": True, "goal_time_period": (4, 6), "goal_xrange": (0.020, 0.030),
+                "goal_yrange": (0.022, 0.032), "obj_size_range": (0.018, 0.024),
+                "obj_mass_range": (0.030, 0.300), "obj_friction_change": (0.2, 0.001, 0.00002),
+                "task_choice": "random"}),
 }
 
 # _setup defaults

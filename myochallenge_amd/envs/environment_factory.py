@@ -25,17 +25,22 @@ class EnvironmentFactory:
         """
         batch_kw = {k: kwargs.pop(k) for k in _BATCH_KEYS if k in kwargs}
         num_envs = batch_kw.pop("num_envs", 1)
+        if env_name == "MixtureModelBaodingEnv":        # src/envs/baoding.py:650-714
+            from .mixture import MixtureModelBaodingVecEnv
+            mix = {k: kwargs.pop(k) for k in ("base_model_path", "base_env_path", "base_env_name", "base_env_config",
+                                             "n_steps_base_model", "base_policy", "base_normalizer") if k in kwargs}
+            return MixtureModelBaodingVecEnv(env_name, num_envs, kwargs, **mix, **batch_kw)
         if env_name in REGISTRATION:
             return BaodingVecEnv(env_name, num_envs, kwargs, **batch_kw)
         known_elsewhere = ("MyoFingerPoseFixed", "MyoFingerPoseRandom", "MyoFingerReachFixed",
                            "MyoFingerReachRandom", "MyoHandKeyTurnFixed", "MyoHandKeyTurnRandom",
                            "MyoBaodingBallsP1", "CustomMyoReorientP1", "CustomMyoReorientP2",
-                           "MyoBaodingBallsP2", "MixtureModelBaodingEnv", "CustomMyoElbowPoseFixed",
+                           "MyoBaodingBallsP2", "CustomMyoElbowPoseFixed",
                            "CustomMyoElbowPoseRandom", "CustomMyoFingerPoseFixed",
                            "CustomMyoFingerPoseRandom", "CustomMyoHandPoseFixed",
                            "CustomMyoHandPoseRandom", "CustomMyoPenTwirlRandom")
         if env_name in known_elsewhere:
             raise NotImplementedError(
                 f"{env_name}: named by the reference but outside this build's hot-path scope "
-                "(SURVEY.md §8: only the Baoding P1/P2 envs are implemented so far)")
+                "(SURVEY.md §8: the Baoding P1 / P2 / MixtureModel envs are implemented so far)")
         raise ValueError("Environment name not recognized:", env_name)

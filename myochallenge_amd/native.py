@@ -72,6 +72,7 @@ class NativeLib:
         L.myo_batch_lds_bytes.argtypes = [vp]
         L.myo_batch_reset.argtypes = [vp, vp, vp, vp]
         L.myo_batch_step.argtypes = [vp] * 10
+        L.myo_batch_step_inner.argtypes = [vp] * 6
         L.myo_batch_physics_step.argtypes = [vp, vp, i32, vp]
         L.myo_batch_get_state.argtypes = [vp] * 6
         L.myo_batch_set_state.argtypes = [vp] * 6
@@ -124,7 +125,7 @@ def load(path: Optional[str] = None) -> NativeLib:
 EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_destroy", "myo_model_size", "myo_batch_create",
     "myo_batch_destroy", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
-    "myo_batch_reset", "myo_batch_step", "myo_batch_physics_step", "myo_batch_get_state",
+    "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_physics_step", "myo_batch_get_state",
     "myo_batch_set_state", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
@@ -185,6 +186,9 @@ class Batch:
     def step(self, act, obs, rew, done, trunc=None, term_obs=None, comps=None, ep_info=None, stream=None):
         self.lib.check(self.lib.L.myo_batch_step(self.h, _ptr(act), _ptr(obs), _ptr(rew), _ptr(done), _ptr(trunc),
                                                  _ptr(term_obs), _ptr(comps), _ptr(ep_info), stream))
+
+    def step_inner(self, mask, act, obs, done=None, stream=None):
+        self.lib.check(self.lib.L.myo_batch_step_inner(self.h, _ptr(mask), _ptr(act), _ptr(obs), _ptr(done), stream))
 
     def physics_step(self, ctrl, nsub, stream=None):
         self.lib.check(self.lib.L.myo_batch_physics_step(self.h, _ptr(ctrl), nsub, stream))

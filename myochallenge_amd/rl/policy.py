@@ -66,9 +66,30 @@ class ActorCriticPolicy(nn.Module):
         return (z(), z(), z(), z())   # (h_pi, c_pi, h_vf, c_vf)
 
     @staticmethod
+    def _lstm_cell_steps(lstm: nn.LSTM, x, h, c, starts):
+        """One-layer LSTM written out as GEMMs + gates (PyTorch gate order i, f, g, o) — the GPU path: the
+        library RNN (MIOpen) compiles its kernels on first use, minutes on a fresh machine, and the rollout /
+        evaluation loops only ever advance one step at a time anyway.  No host sync on `starts`."""
+        w_ih, w_hh, b_ih, b_hh = lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0
+        h, c = h[0], c[0]
+        outs = []
+        for t in range(x.shape[0]):
+            if starts is not None:
+                keep = (1.0 - starts[t].to(h.dtype)).unsqueeze(-1)
+                h, c = h * keep, c * keep
+            gates = torch.addmm(b_ih + b_hh, x[t], w_ih.t()) + h @ w_hh.t()
+            i, f, g, o = gates.chunk(4, dim=-1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        return torch.stack(outs, 0), h.unsqueeze(0), c.unsqueeze(0)
+
+    @staticmethod
     def _lstm_seq(lstm: nn.LSTM, x, h, c, starts):
         """x [T,N,F]; starts [T,N] (1 = episode start: state zeroed before that step) — sb3-contrib
         ``_process_sequence`` [3P-RECALL, SURVEY.md C.3]."""
+        if x.is_cuda:
+            return ActorCriticPolicy._lstm_cell_steps(lstm, x, h, c, starts)
         if starts is None or not bool(starts.any()):
             out, (h, c) = lstm(x, (h, c))
             return out, h, c

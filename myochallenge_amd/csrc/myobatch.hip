@@ -55,7 +55,7 @@ extern "C" const char* myo_version(void) {
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
   MYO_MODEL_INT_ARRAYS(X)
@@ -260,6 +260,19 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
     } else if (ty == MYO_WRAP_PULLEY) m->wr_p[4 * (size_t)w + 3] = m->wrap_prm[w];
     if (I[1] >= 0) { I[4] = m->body_rootid[I[1]]; m->wr_mask[w] = m->body_dofmask[I[1]]; }
   }
+  // geom wraps, enumerated: gw_elem[k] = path element of the k-th sphere/cylinder wrap; wr_i[8w+6] = k
+  m->gw_elem.clear();
+  for (int w = 0; w < m->nwrap; ++w) {
+    m->wr_i[8 * (size_t)w + 6] = -1;
+    if (m->wrap_type[w] == MYO_WRAP_SPHERE || m->wrap_type[w] == MYO_WRAP_CYLINDER) {
+      m->wr_i[8 * (size_t)w + 6] = (int)m->gw_elem.size();
+      m->gw_elem.push_back(w);
+    }
+  }
+  m->ngw = (int)m->gw_elem.size();
+  if (m->gw_elem.empty()) m->gw_elem.push_back(0);
+  LIM(3 * m->nwrap > MYO_NV_MAX * MYO_NV_MAX - MYO_NB_MAX * 10, "tendon path elements (staging area of the tendon stage)")
+  LIM(7 * m->ngw > 4 * MYO_NEFC_MAX, "tendon wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
   for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
   // qfrc_actuator gather, dof-major: for dof d the (ten_J offset << 6 | actuator) pairs of every
@@ -366,7 +379,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nq = m->nq; D.nv = m->nv; D.nu = m->nu; D.na = m->na; D.nbody = m->nbody; D.njnt = m->njnt; D.ngeom = m->ngeom;
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
-  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead;
+  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   // fp32 stepper: the scaled cost/gradient tests of the Newton solver cannot resolve below ~1e-6
   // (24-bit mantissa); with the model's 1e-8 it would spend an extra iteration on rounding noise.

@@ -102,3 +102,42 @@ def test_task_cfg_struct_matches_header():
         if m:
             names += [re.sub(r"\[.*?\]", "", n).strip() for n in m.group(2).split(",")]
     assert names == [f[0] for f in native.TaskCfg._fields_]
+
+
+def test_c_abi_argument_checks(emu_lib):
+    """Every entry point validates its arguments before touching a device: NULL handles / pointers and
+    non-positive sizes give MYO_E_ARG (-1) with a message, never a crash.  (The PPO-side kernels have no CPU
+    execution path: with valid arguments the emulation library answers MYO_E_UNSUPPORTED.)"""
+    import ctypes as C
+    L = emu_lib.L
+    null = None
+    f = C.c_float
+    checks = [
+        (L.myo_model_from_blob, (null, 0, C.byref(C.c_void_p()))),
+        (L.myo_batch_create, (null, null, 4, 0, 0, 1, C.byref(C.c_void_p()))),
+        (L.myo_batch_reset, (null, null, null, null)),
+        (L.myo_batch_step, (null,) * 10),
+        (L.myo_batch_step_inner, (null,) * 6),
+        (L.myo_batch_physics_step, (null, null, 1, null)),
+        (L.myo_batch_get_state, (null,) * 6),
+        (L.myo_batch_set_task, (null,) * 5),
+        (L.myo_ppo_loss_grad, (null,) * 8 + (16, 39, f(0.2), f(0.5)) + (null,) * 6 + (0, f(0.0)) + (null,) * 4),
+        (L.myo_ppo_gather, (null,) * 6 + (16, 86, 39, null, 2) + (null,) * 7),
+        (L.myo_bias_relu_bf16, (null, null, 2, 16, 256, null)),
+        (L.myo_relu_bwd_colsum_bf16, (null, null, 64, 256, null, null)),
+        (L.myo_splitk_reduce, (null, 1, null, 2, 32, 256, null)),
+        (L.myo_adam_clip_step, (null,) * 4 + (10,) + (f(0.1),) * 6 + (null,) * 3),
+        (L.myo_gae, (null,) * 5 + (4, 4, f(0.99), f(0.95), null, null, null)),
+        (L.myo_rollout_policy_input, (null, 4, 86, null, null, 2, null, null)),
+        (L.myo_rollout_sample, (null, null, null, 4, 39, 1, null, null, null, null, null, null, 0, null)),
+        (L.myo_vecnorm_step, (null,) * 5 + (4, 86) + (null,) * 5 + (0.99, 1e-8, 10.0, 10.0, 1, 1, 1) + (null,) * 9),
+        (L.myo_rollout_advance, (null, 4, null, null)),
+    ]
+    for fn, args in checks:
+        rc = fn(*args)
+        assert rc == -1, (fn.__name__, rc)
+        assert len(emu_lib.L.myo_last_error()) > 0
+    assert L.myo_batch_num_envs(null) <= 0 and L.myo_batch_obs_dim(null) <= 0
+    buf = (C.c_float * 64)()
+    assert L.myo_splitk_reduce(buf, 0, buf, 1, 2, 16, None) == -2          # valid arguments, but a GPU kernel
+    assert L.myo_splitk_reduce(buf, 0, buf, 1, 2, 15, None) == -1          # odd n

@@ -410,3 +410,24 @@ def test_two_rank_graph_path_keeps_replicas_identical(hip_lib):
     from myochallenge_amd.rl.policy import ActorCriticPolicy
     init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None).parameters()]).numpy()
     assert not np.array_equal(a, init)
+
+
+@pytest.mark.parametrize("n_envs", [1, 63, 32768])
+def test_batch_size_edges(hip_lib, n_envs):
+    """Ragged and extreme batch sizes (BASELINE config D's per-node total is 32768 envs): a step is
+    independent of how many other envs share the launch — env i of an N-env batch equals env i of a
+    smaller batch with the same seed — and stays finite at the largest size."""
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    torch.manual_seed(0)
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=n_envs, seed=7)
+    small = EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=1, seed=7)
+    o_big, o_small = env.reset_tensor().clone(), small.reset_tensor().clone()
+    assert torch.equal(o_big[0], o_small[0])                 # per-env Philox streams are keyed by (seed, env index)
+    a = torch.clamp(torch.randn((n_envs, 39), device="cuda") * 0.3, -1, 1)
+    for _ in range(3):
+        ob, rb, db, *_ = env.step_tensor(a)
+        os_, rs, ds, *_ = small.step_tensor(a[:1].contiguous())
+        assert torch.isfinite(ob).all() and torch.isfinite(rb).all()
+        assert torch.equal(ob[0], os_[0]) and torch.equal(rb[0], rs[0]) and torch.equal(db[0], ds[0])
+    env.close(); small.close()

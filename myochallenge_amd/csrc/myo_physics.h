@@ -748,10 +748,11 @@ DEVFN void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r,
       T acc = 0;
 #pragma unroll
       for (int k = 0; k < MYO_MV_ROW; ++k) {
-        if (k < len) {
-          const unsigned ent = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xffffu);
-          acc += s.qM[ent >> 6] * v[ent & 63u];
-        }
+        // unconditional LDS reads (padding entries are 0 -> qM[0], v[0], valid) and a select: no exec-mask
+        // branch per entry, so all the reads are in flight together
+        const unsigned ent = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xffffu);
+        const T q = s.qM[ent >> 6], x = v[ent & 63u];
+        acc += (k < len) ? q * x : (T)0;
       }
       out[i] = acc;
     }
@@ -1681,10 +1682,9 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
       T acc = 0;
 #pragma unroll
       for (int k = 0; k < MYO_AQ_ROW; ++k) {
-        if (k < len) {
-          const unsigned ent = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xffffu);
-          acc += s.ten_J[ent >> 6] * S_ACT_GF(s)[ent & 63u];
-        }
+        const unsigned ent = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xffffu);     // padding entries are 0: valid reads
+        const T j = s.ten_J[ent >> 6], f = S_ACT_GF(s)[ent & 63u];
+        acc += (k < len) ? j * f : (T)0;
       }
       S_QFRC_ACTUATOR(s)[d] = acc;
       s.qfrc_smooth[d] = S_QFRC_PASSIVE(s)[d] - S_QFRC_BIAS(s)[d] + acc;

@@ -1,0 +1,61 @@
+"""Train PPO on the batched Baoding env for a fixed number of env steps and evaluate before / after.
+
+    python tools/train_demo.py --steps 30000000
+
+An end-to-end check that the physics, the task layer and the PPO update pull in the same direction:
+the deterministic evaluation return has to rise.  (Synthetic MyoHand-shaped model: the numbers are not
+comparable with the reference's MyoSuite scores.)"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--env-name", default="CustomMyoBaodingBallsP1")
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--steps", type=int, default=30_000_000)
+    ap.add_argument("--eval-episodes", type=int, default=512)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.metrics.evaluation import evaluate_policy, summarize
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    cfgs = {"weighted_reward_keys": {"pos_dist_1": 5.0, "pos_dist_2": 5.0, "act_reg": 0.0, "alive": 1.0, "solved": 5.0,
+                                     "done": 0.0, "sparse": 0.0}}
+    env = EnvironmentFactory.create(a.env_name, num_envs=a.envs, seed=1, **cfgs)
+    eval_env = EnvironmentFactory.create(a.env_name, num_envs=512, seed=999, **cfgs)
+    venv = VecNormalize(env, gamma=0.99)
+    torch.manual_seed(0)
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=None, log_std_init=-2.0)
+    algo = PPO(venv, pol, PPOConfig(n_steps=64, batch_size=16384, n_epochs=10, learning_rate=2.5e-4, clip_range=0.2,
+                                    ent_coef=2.5e-4, vf_coef=0.5, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, bf16=True))
+    log = []
+
+    def ev(tag):
+        r = summarize(evaluate_policy(pol, eval_env, venv, a.eval_episodes, deterministic=True))
+        r.update(tag=tag, timesteps=algo.num_timesteps)
+        log.append(r)
+        print(json.dumps(r), flush=True)
+    ev("before")
+    t0 = time.time()
+    chunk = max(a.steps // 5, a.envs * 64)
+    while algo.num_timesteps < a.steps:
+        algo.learn(min(a.steps, algo.num_timesteps + chunk))
+        torch.cuda.synchronize()
+        ev("t=%.0fs" % (time.time() - t0))
+    print("trained %d env steps in %.1f s (%.0f steps/s incl. evaluations)" % (algo.num_timesteps, time.time() - t0,
+                                                                              algo.num_timesteps / (time.time() - t0)))
+    if a.out:
+        json.dump(log, open(a.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

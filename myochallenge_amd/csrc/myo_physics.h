@@ -1468,15 +1468,19 @@ DEVFN void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LRE
         const unsigned long long m = M.tendon_dofmask[t];
         if ((m >> d) & 1ull) acc += s.lim_sgn[r] * s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f[r];
       }
+      // own motion axis once; per contact only wave-uniform (broadcast) reads, issued unconditionally with a
+      // select at the end: no exec-mask branch around the loads, so consecutive contacts overlap
+      const T cd[6] = {s.cdof[6 * d], s.cdof[6 * d + 1], s.cdof[6 * d + 2], s.cdof[6 * d + 3], s.cdof[6 * d + 4], s.cdof[6 * d + 5]};
+#pragma unroll 2
       for (int ci = 0; ci < ncon; ++ci) {
         const ContactRec<T>& c = s.con[ci];
         const int on1 = (int)((c.m1 >> d) & 1ull), on2 = (int)((c.m2 >> d) & 1ull);
-        if (on1 != on2) {
-          T col[3];
-          con_col(s, d, on2 ? c.r2 : c.r1, col);
-          const T v = dot3(col, c.F);
-          acc += on2 ? v : -v;
-        }
+        const T off[3] = {on2 ? c.r2[0] : c.r1[0], on2 ? c.r2[1] : c.r1[1], on2 ? c.r2[2] : c.r1[2]};
+        T t[3];
+        cross3(t, cd, off);
+        const T col[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
+        const T v = dot3(col, c.F);
+        acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
       }
       out[d] = acc;
     }

@@ -14,6 +14,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: takes more than a few seconds")
 
 
+def pytest_collection_modifyitems(config, items):
+    """Every test gets a wall-clock limit (pytest-timeout, when installed): a hung kernel or a dead rank of a
+    multi-process test must fail the test, not eat the GPU box's time budget."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600 if item.get_closest_marker("gpu") else 900))
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -400,9 +400,18 @@ def test_two_rank_graph_path_keeps_replicas_identical(hip_lib):
     import torch
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mgr = mp.Manager()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
     out = mgr.dict()
-    mp.spawn(_graph_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    procs = [ctx.Process(target=_graph_dp_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)            # a rank that dies leaves its peer waiting in a collective: never wait forever
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.terminate()
+    assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     a, b = out[0], out[1]
     assert np.isfinite(a).all() and np.array_equal(a, b)
     assert out[10] != out[11]                       # the ranks really saw different data

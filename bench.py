@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--integrator", default="model", choices=["model", "euler", "rk4"])
     ap.add_argument("--n-steps", type=int, default=64, help="rollout length between PPO updates")
     ap.add_argument("--n-epochs", type=int, default=10)
-    ap.add_argument("--batch-size", type=int, default=16384, help="minibatch: 1/16 of the rollout as in the reference (4096 of 65536)")
+    ap.add_argument("--batch-size", type=int, default=16384, help="minibatch (default: 1/16 of the default rollout, the reference's ratio: 4096 of 65536)")
     ap.add_argument("--env-name", default="CustomMyoBaodingBallsP1")
     ap.add_argument("--no-ppo", action="store_true", help="rollout only (reported as invalid for the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -124,11 +124,14 @@ def main():
     from myochallenge_amd.rl.ppo import PPO, PPOConfig
     from myochallenge_amd.rl.vec_normalize import VecNormalize
 
-    # every timed region must contain at least one full PPO update: shrink the rollout if K is small,
-    # keeping the reference's minibatch = rollout / 16 ratio
+    # every timed region must contain at least one full PPO update: if K is smaller than the configured rollout
+    # the rollout shrinks to K steps while the minibatch stays (close to) the configured size, so the optimizer
+    # work per env step — and the GEMM shapes — are those of the headline configuration for any K
     if args.steps < args.n_steps:
         args.n_steps = max(1, args.steps)
-    args.batch_size = max(1, min(args.batch_size, args.n_steps * args.envs // 16)) if args.n_steps * args.envs >= 16 else args.n_steps * args.envs
+    rollout = args.n_steps * args.envs
+    n_mb = max(1, rollout // args.batch_size)
+    args.batch_size = max(1, (rollout // n_mb) // 128 * 128) if rollout >= 128 else rollout
     integ = None if args.integrator == "model" else args.integrator
     env = EnvironmentFactory.create(args.env_name, num_envs=args.envs, device=local_rank, seed=1234 + rank,
                                     dtype=args.dtype, integrator=integ)

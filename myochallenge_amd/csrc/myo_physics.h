@@ -837,10 +837,10 @@ DEV void chol_solve(Scratch<T>& s, T* x, int n) {
 
 #ifndef MYO_EMU
 // ---- register-resident Cholesky (gfx950 build).  Lane i keeps row i of the lower triangle in
-// VGPRs; pivots and column entries are broadcast with v_readlane (no LDS round trip, no
-// dependent LDS read-modify-write chain).  Padded to MYO_NV_MAX with identity rows.  The
-// arithmetic per element is the same k-ordered FMA sequence as the LDS version above, which the
-// MYO_EMU build keeps.
+// VGPRs (packed pairs, v_pk_fma trailing update); column k reaches the other lanes through a
+// 64-entry LDS buffer, software-pipelined (see the factor loop); the substitutions broadcast
+// with v_readlane.  Padded to MYO_NV_MAX with identity rows.  The arithmetic per element is the
+// same k-ordered FMA sequence as the LDS version above, which the MYO_EMU build keeps.
 template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
 template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));

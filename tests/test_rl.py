@@ -349,3 +349,116 @@ def test_manual_lstm_cell_matches_nn_lstm():
             outs.append(o)
     assert float((o1 - torch.cat(outs, 0)).abs().max()) < 1e-6 and float((h1 - hh).abs().max()) < 1e-6
     assert float((c1 - cc).abs().max()) < 1e-6
+
+
+def test_task_classifier_matches_reference_goldens(golden_dir):
+    """classifier.pt + scaler.pkl of the winning ensemble: logits / task ids of the reference's own
+    TaskClassifier + sklearn StandardScaler on 64 observation windows (tools/make_golden.py)."""
+    from myochallenge_amd.models.classifier import TaskClassifier, load_scaler
+    g = np.load(os.path.join(golden_dir, "classifier_goldens.npz"))
+    clf = TaskClassifier()
+    clf.load_state_dict(torch.load(os.path.join(golden_dir, "classifier.pt"), map_location="cpu"))
+    clf.eval()
+    mean, scale = load_scaler(os.path.join(golden_dir, "classifier_scaler.pkl"))
+    assert np.array_equal(mean, g["scaler_mean"]) and np.array_equal(scale, g["scaler_scale"])
+    xs = (g["windows"] - mean) / scale
+    assert np.abs(xs - g["scaled"]).max() < 1e-12
+    x = torch.as_tensor(xs, dtype=torch.float32)
+    with torch.no_grad():
+        logits = clf(x).numpy().reshape(-1)
+    assert np.abs(logits - g["logits"]).max() < 1e-5
+    assert np.array_equal(clf.predict_task(x).numpy(), g["task"]) and 0 < (g["task"] == 0).sum() < len(g["task"])
+
+
+@pytest.mark.parametrize("mode", ["artifact", "always_hold"])
+def test_mixture_of_ensembles_matches_sequential_flow(emu_lib, golden_dir, mode):
+    """Batched SuperModel / eval_perf vs a per-env transcription of the reference's flow
+    (src/eval_mixture_of_ensembles.py:190-330): mean action of the base ensemble, observation window of the
+    first 13 steps, classification at step index 12, switch to the hold ensemble with fresh LSTM states."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.eval_mixture_of_ensembles import SuperModel, eval_perf
+    from myochallenge_amd.models.classifier import TaskClassifier, load_scaler
+    N, H = 3, 15
+    mk = lambda: EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=N, lib=emu_lib, seed=21, dtype="f64", max_episode_steps=H)
+    torch.manual_seed(3)
+    pols = [ActorCriticPolicy(86, 39, (8,), (8,), lstm_hidden_size=6) for _ in range(4)]
+
+    class Norm:                                    # distinct statistics per member, like the reference's pickles
+        def __init__(self, k): self.mu, self.training, self.norm_reward = 0.05 * k, True, True
+        def normalize_obs(self, o): return torch.clamp((o - self.mu) / (1.0 + 0.1 * self.mu), -10, 10)
+    norms = [Norm(k) for k in range(4)]
+    clf = TaskClassifier()
+    clf.load_state_dict(torch.load(os.path.join(golden_dir, "classifier.pt"), map_location="cpu"))
+    if mode == "always_hold":
+        with torch.no_grad():
+            clf.layer_out.weight.zero_(); clf.layer_out.bias.fill_(-50.0)
+    scaler = load_scaler(os.path.join(golden_dir, "classifier_scaler.pkl"))
+
+    env = mk()
+    sm = SuperModel(pols[:2], norms[:2], pols[2:], norms[2:], clf, scaler, N, env.device)
+    assert all(not n.training and not n.norm_reward for n in norms)
+    acts_b, obs = [], env.reset_tensor()
+    starts = torch.ones(N)
+    switched_any = False
+    for t in range(2 * H + 3):
+        a = sm.predict(obs, starts)
+        switched_any |= bool(sm.use_hold_net.any())
+        acts_b.append(a.clone())
+        obs, rew, done, *_ = env.step_tensor(torch.clamp(a, -1, 1))
+        starts = done.float()
+
+    # sequential transcription, one env at a time
+    env2 = mk()
+    obs = env2.reset_tensor()
+    st = [dict(buf=[], t=0, hold=False, just=False, task=1, sb=[None, None], sh=[None, None], start=True) for _ in range(N)]
+    acts_s = []
+    with torch.no_grad():
+        for t in range(2 * H + 3):
+            row = []
+            for i in range(N):
+                e, o = st[i], obs[i:i + 1]
+                if e["start"]:
+                    e.update(hold=False, just=False, t=0, buf=[])
+                if e["t"] < 13:
+                    e["buf"].append(o[0, 29:47].double().numpy().copy())
+                if e["t"] == 12:
+                    x = (np.concatenate(e["buf"]).reshape(1, -1) - scaler[0]) / scaler[1]
+                    e["task"] = int(torch.round(torch.sigmoid(clf(torch.FloatTensor(x)))).item() != 0)
+                    if e["task"] == 0:
+                        e["hold"], e["just"] = True, True
+                e["t"] += 1
+                es = torch.tensor([1.0 if e["start"] else 0.0])
+                if e["hold"]:
+                    if e["just"]:
+                        e["just"], e["sh"] = False, [None, None]
+                    outs = []
+                    for k in range(2):
+                        stt = e["sh"][k] if e["sh"][k] is not None else pols[2 + k].initial_state(1, "cpu")
+                        a, _, _, e["sh"][k] = pols[2 + k].act(norms[2 + k].normalize_obs(o), stt, es, deterministic=True)
+                        outs.append(a)
+                else:
+                    outs = []
+                    for k in range(2):
+                        stt = e["sb"][k] if e["sb"][k] is not None else pols[k].initial_state(1, "cpu")
+                        a, _, _, e["sb"][k] = pols[k].act(norms[k].normalize_obs(o), stt, es, deterministic=True)
+                        outs.append(a)
+                row.append(torch.stack(outs, 0).mean(0)[0])
+            a = torch.stack(row, 0)
+            acts_s.append(a)
+            obs, rew, done, *_ = env2.step_tensor(torch.clamp(a, -1, 1))
+            for i in range(N):
+                st[i]["start"] = bool(done[i])
+                if st[i]["start"]:
+                    st[i]["sb"], st[i]["sh"] = [None, None], [None, None]
+    for t, (x, y) in enumerate(zip(acts_b, acts_s)):
+        assert float((x - y).abs().max()) < 1e-5, t
+    if mode == "always_hold":
+        assert all(e["task"] == 0 for e in st) and switched_any
+
+    res = eval_perf(mk(), SuperModel(pols[:2], norms[:2], pols[2:], norms[2:], clf, scaler, N, env.device), num_episodes=5, verbose=False)
+    assert len(res["lengths"]) == 5 and (res["lengths"] <= H).all() and np.isfinite(res["returns"]).all()
+    assert (res["effort"] >= 0).all() and (res["effort"] < 1).all()
+    full = res["lengths"] >= 13
+    assert len(res["classifier_preds"]) >= full.sum() - N and set(np.unique(res["classifier_targets"])) <= {0, 1}
+    if mode == "always_hold":
+        assert (res["classifier_preds"] == 0).all()

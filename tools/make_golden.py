@@ -362,9 +362,42 @@ def reset_goldens(ref, cfgs):
     print("reset goldens:", len(cases))
 
 
+def classifier_goldens(allobs):
+    """Task classifier of the winning ensemble (src/models/classifier.py:160-174, used by
+    src/eval_mixture_of_ensembles.py:139-190): the reference's own TaskClassifier class (imported with the
+    stubs above) + its shipped classifier.pt / scaler.pkl evaluated on windows of 13 consecutive archived
+    observations [29:47] -> classifier_goldens.npz.  The two artifacts are copied as data fixtures."""
+    import torch
+    import warnings
+    spec = importlib.util.spec_from_file_location("ref_classifier", f"{REF}/src/models/classifier.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)          # needs import_reference_baoding() to have installed the stub modules
+    cdir = f"{REF}/trained_models/winning_ensemble/classifier"
+    shutil.copy(f"{cdir}/classifier.pt", f"{OUT}/classifier.pt")
+    shutil.copy(f"{cdir}/scaler.pkl", f"{OUT}/classifier_scaler.pkl")
+    clf = m.TaskClassifier(m.N_OBS_PER_TRIAL)
+    clf.load_state_dict(torch.load(f"{cdir}/classifier.pt", map_location="cpu"))
+    clf.eval()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        scaler = pickle.load(open(f"{cdir}/scaler.pkl", "rb"))
+    rows = np.asarray(allobs, np.float64)[:, 29:47]
+    rng = np.random.RandomState(0)
+    starts = rng.randint(0, len(rows) - 13, size=64)
+    X = np.stack([rows[s:s + 13].reshape(-1) for s in starts])           # [64, 234] raw windows
+    Xs = scaler.transform(X)
+    with torch.no_grad():
+        logits = clf(torch.FloatTensor(Xs)).numpy().reshape(-1)
+    task = np.round(1.0 / (1.0 + np.exp(-logits.astype(np.float64)))).astype(np.int64)   # update_task()
+    np.savez(f"{OUT}/classifier_goldens.npz", windows=X, scaled=Xs, logits=logits, task=task,
+             scaler_mean=scaler.mean_, scaler_scale=scaler.scale_)
+    print("classifier goldens:", X.shape, "hold fraction", float((task == 0).mean()))
+
+
 if __name__ == "__main__":
     ref = import_reference_baoding()
     allobs, cfgs = artifacts()
     mjb_fixtures()
     reward_goldens(ref, allobs, cfgs)
     reset_goldens(ref, cfgs)
+    classifier_goldens(allobs)

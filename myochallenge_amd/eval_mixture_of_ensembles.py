@@ -12,7 +12,7 @@ evaluated for the whole batch each step (a member is one batched forward).
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, Sequence
 
 import numpy as np
 import torch

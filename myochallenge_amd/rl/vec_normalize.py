@@ -13,7 +13,7 @@ float64 so the running moments match the host implementation.
 from __future__ import annotations
 
 import pickle
-from typing import Optional
+
 
 import numpy as np
 import torch

@@ -52,7 +52,7 @@ struct ContactRec {
   T r1[3], r2[3];                 // contact point relative to the reference point of body1's / body2's tree
   unsigned long long m1, m2;      // ancestor-dof masks of the two bodies
   int b1, b2, nsup;
-  unsigned char sup[MYO_CS_MAX];
+  alignas(4) unsigned char sup[MYO_CS_MAX];
 };
 
 template <typename T>
@@ -1247,46 +1247,39 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
         ContactRec<T>& c = s.con[ci];
         for (int e = 0; e < 3; ++e) { c.pos[e] = LV(ct).pos[3 * k + e]; c.frame[e] = LV(ct).nrm[3 * k + e]; }
         make_frame(c.frame);
-        c.b1 = M.geom_bodyid[g1]; c.b2 = M.geom_bodyid[g2];
-        // parameter mixing (mj_contactParam)
-        const int pr1 = M.geom_priority[g1], pr2 = M.geom_priority[g2];
-        T mix;
-        if (pr1 != pr2) mix = pr1 > pr2 ? (T)1 : (T)0;
-        else {
-          const T m1 = M.geom_solmix[g1], m2 = M.geom_solmix[g2];
-          if (m1 >= MYO_MINVAL && m2 >= MYO_MINVAL) mix = m1 / (m1 + m2);
-          else if (m1 < MYO_MINVAL && m2 < MYO_MINVAL) mix = (T)0.5;
-          else mix = m1 < MYO_MINVAL ? (T)0 : (T)1;
-        }
-        T solref[2], solimp[5], fr[3];
-        const T *r1 = M.geom_solref + 2 * g1, *r2 = M.geom_solref + 2 * g2;
-        if (r1[0] > 0 && r2[0] > 0) { for (int e = 0; e < 2; ++e) solref[e] = mix * r1[e] + (1 - mix) * r2[e]; }
-        else { for (int e = 0; e < 2; ++e) solref[e] = tmin(r1[e], r2[e]); }
-        for (int e = 0; e < 5; ++e) solimp[e] = mix * M.geom_solimp[5 * g1 + e] + (1 - mix) * M.geom_solimp[5 * g2 + e];
+        // everything that depends on the two geoms only comes from the host-resolved pair record (pc_*):
+        // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
+        // friction, margin and gap, inverse-weight sum; the balls' per-env friction is patched in here
+        const int b1 = M.pc_i[8 * p], b2 = M.pc_i[8 * p + 1], root1 = M.pc_i[8 * p + 2], root2 = M.pc_i[8 * p + 3];
+        const int ns = M.pc_i[8 * p + 4], fsel = M.pc_i[8 * p + 7];
+        T F[16];
+        for (int e = 0; e < 16; ++e) F[e] = M.pc_f[16 * p + e];
+        c.b1 = b1; c.b2 = b2;
+        T fr[3];
         for (int e = 0; e < 3; ++e) {
-          const T a = geom_fric_of(M, K, s, g1, e), b = geom_fric_of(M, K, s, g2, e);
-          fr[e] = (pr1 == pr2) ? tmax(a, b) : (pr1 > pr2 ? a : b);
+          const T a = (g1 == K.obj1_gid) ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]);
+          const T b = (g2 == K.obj1_gid) ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]);
+          fr[e] = (fsel == 0) ? tmax(a, b) : (fsel == 1 ? a : b);
         }
         c.mu[0] = fr[0]; c.mu[1] = fr[0];  // condim 3: both tangential directions use friction[0]
-        const T margin = tmax(M.geom_margin[g1], M.geom_margin[g2]);
-        const T inc = margin - tmax(M.geom_gap[g1], M.geom_gap[g2]);
+        const T inc = F[1];
         const T dist = LV(ct).dist[k];
         T Kc, Bc, Ic;
-        sol_param(M, solref, solimp, dist - inc, &Kc, &Bc, &Ic);
-        const T tran = M.body_invweight0[2 * c.b1] + M.body_invweight0[2 * c.b2];
+        sol_param(M, F + 2, F + 4, dist - inc, &Kc, &Bc, &Ic);
+        const T tran = F[15];
         const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr[0] * fr[0] * tran) / Ic);
         const T mu = fr[0] / sqrt(M.impratio);
         const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
         c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * (dist - inc);
-        // dofs this contact can move
-        c.m1 = M.body_dofmask[c.b1]; c.m2 = M.body_dofmask[c.b2];
+        c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
         {
-          const T* c1 = s.com + 3 * M.body_rootid[c.b1]; const T* c2 = s.com + 3 * M.body_rootid[c.b2];
+          const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
           for (int e = 0; e < 3; ++e) { c.r1[e] = c.pos[e] - c1[e]; c.r2[e] = c.pos[e] - c2[e]; }
         }
-        unsigned long long sup = c.m1 | c.m2;
-        int ns = 0;
-        while (sup && ns < MYO_CS_MAX) { c.sup[ns++] = (unsigned char)myo_ffsll(sup); sup &= sup - 1; }
+        {
+          int* dst = reinterpret_cast<int*>(c.sup);
+          for (int e = 0; e < MYO_CS_MAX / 4; ++e) dst[e] = M.pc_sup[4 * p + e];
+        }
         c.nsup = ns;
       }
     }

@@ -310,11 +310,50 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
     for (unsigned long long x = m->body_dofmask[b]; x; x &= x - 1) cnt++;
     LIM(2 * cnt > MYO_CS_MAX + 4 && false, "contact support")
   }
+  // per-pair contact records: everything mj_contactParam / the constraint build derive from the two geoms
+  // alone is resolved here (the device stage was a chain of dependent table loads per contact):
+  //   pc_i[8p..]  = body1, body2, root body 1, root body 2, nsup, ball flag 1, ball flag 2 (0 none, 1/2 = the
+  //                 ball whose friction is per-env), friction selector (0 max, 1 geom1, 2 geom2)
+  //   pc_sup[4p..] = the dofs either body can move (<= 16 bytes, ascending)
+  //   pc_f[16p..] = margin, margin - gap, solref[2], solimp[5] (mixed), friction1[3], friction2[3], invweight sum
+  //   pc_mask[2p..] = ancestor-dof masks of the two bodies
+  {
+    const int np = m->npair > 0 ? m->npair : 1;
+    m->pc_i.assign(8 * (size_t)np, 0); m->pc_sup.assign(4 * (size_t)np, 0);
+    m->pc_f.assign(16 * (size_t)np, 0.0); m->pc_mask.assign(2 * (size_t)np, 0ull);
+  }
   for (int p = 0; p < m->npair; ++p) {
-    unsigned long long mk = m->body_dofmask[m->geom_bodyid[m->pair_geom1[p]]] | m->body_dofmask[m->geom_bodyid[m->pair_geom2[p]]];
+    const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+    const int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+    const unsigned long long m1 = m->body_dofmask[b1], m2 = m->body_dofmask[b2];
+    unsigned long long mk = m1 | m2;
     int cnt = 0;
     for (unsigned long long x = mk; x; x &= x - 1) cnt++;
     LIM(cnt > MYO_CS_MAX, "a contact pair moves more than MYO_CS_MAX dofs")
+    int* I = &m->pc_i[8 * (size_t)p];
+    I[0] = b1; I[1] = b2; I[2] = m->body_rootid[b1]; I[3] = m->body_rootid[b2]; I[4] = cnt;
+    unsigned char* sup = reinterpret_cast<unsigned char*>(&m->pc_sup[4 * (size_t)p]);
+    { int ns = 0; for (int d = 0; d < 64 && ns < MYO_CS_MAX; ++d) if ((mk >> d) & 1ull) sup[ns++] = (unsigned char)d; }
+    m->pc_mask[2 * (size_t)p] = m1; m->pc_mask[2 * (size_t)p + 1] = m2;
+    const int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
+    double mix;
+    if (pr1 != pr2) mix = pr1 > pr2 ? 1.0 : 0.0;
+    else {
+      const double x1 = m->geom_solmix[g1], x2 = m->geom_solmix[g2];
+      const double tiny = 1e-15;      // MYO_MINVAL
+      if (x1 >= tiny && x2 >= tiny) mix = x1 / (x1 + x2);
+      else if (x1 < tiny && x2 < tiny) mix = 0.5;
+      else mix = x1 < tiny ? 0.0 : 1.0;
+    }
+    double* F = &m->pc_f[16 * (size_t)p];
+    const double margin = std::max(m->geom_margin[g1], m->geom_margin[g2]);
+    F[0] = margin; F[1] = margin - std::max(m->geom_gap[g1], m->geom_gap[g2]);
+    const double *r1 = &m->geom_solref[2 * g1], *r2 = &m->geom_solref[2 * g2];
+    for (int e = 0; e < 2; ++e) F[2 + e] = (r1[0] > 0 && r2[0] > 0) ? mix * r1[e] + (1 - mix) * r2[e] : std::min(r1[e], r2[e]);
+    for (int e = 0; e < 5; ++e) F[4 + e] = mix * m->geom_solimp[5 * g1 + e] + (1 - mix) * m->geom_solimp[5 * g2 + e];
+    for (int e = 0; e < 3; ++e) { F[9 + e] = m->geom_friction[3 * g1 + e]; F[12 + e] = m->geom_friction[3 * g2 + e]; }
+    F[15] = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+    I[7] = (pr1 == pr2) ? 0 : (pr1 > pr2 ? 1 : 2);
   }
   m->body_imat.resize(9 * nb);
   for (int b = 0; b < nb; ++b) quat2mat_h(&body_iquat[4 * b], &m->body_imat[9 * b]);

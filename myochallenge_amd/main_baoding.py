@@ -1,0 +1,74 @@
+"""Training entry point — the batched counterpart of /root/reference/src/main_baoding.py.
+
+Same flow: env config dict -> (16 SubprocVecEnv workers there, ONE batched GPU env here) -> ``VecNormalize``
+(loaded from a pickle when resuming) -> ``EvalCallback`` + ``CheckpointCallback`` -> ``MyoTrainer`` ->
+``train`` -> ``save``.
+
+    python -m myochallenge_amd.main_baoding --num-envs 4096 --timesteps 50000000 --policy MlpPolicy
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from datetime import datetime
+
+ENV_NAME = "CustomMyoBaodingBallsP2"
+
+# reward structure and task parameters of the reference script (src/main_baoding.py:27-52)
+config = {
+    "weighted_reward_keys": {"pos_dist_1": 2, "pos_dist_2": 2, "act_reg": 0, "alive": 0, "solved": 5, "done": 0, "sparse": 0},
+    "task_choice": "random",
+    "enable_rsi": False, "rsi_probability": 0, "balls_overlap": False, "overlap_probability": 0,
+    "noise_fingers": 0, "limit_init_angle": False,
+    "goal_time_period": [4, 6], "goal_xrange": (0.020, 0.030), "goal_yrange": (0.022, 0.032),
+    "obj_size_range": (0.018, 0.022), "obj_mass_range": (0.030, 0.300), "obj_friction_change": (0.2, 0.001, 0.00002),
+}
+
+
+def make_parallel_envs(env_config, num_env, start_index=0, env_name=ENV_NAME, **batch_kw):
+    """src/main_baoding.py:56-65 returns SubprocVecEnv([thunk] * num_env); here: one batched env."""
+    from .envs.environment_factory import EnvironmentFactory
+    return EnvironmentFactory.create(env_name, num_envs=num_env, seed=start_index, **batch_kw, **env_config)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--env-name", default=ENV_NAME)
+    ap.add_argument("--num-envs", type=int, default=4096)
+    ap.add_argument("--timesteps", type=int, default=10_000_000)
+    ap.add_argument("--log-dir", default=None)
+    ap.add_argument("--load-model", default=None, help="PATH_TO_PRETRAINED_NET (stable-baselines3 zip)")
+    ap.add_argument("--load-env", default=None, help="PATH_TO_NORMALIZED_ENV (VecNormalize pickle)")
+    ap.add_argument("--config", default=None, help="JSON file with the env kwargs (default: the reference script's)")
+    ap.add_argument("--policy", default="MlpLstmPolicy", choices=["MlpLstmPolicy", "MlpPolicy"])
+    ap.add_argument("--n-steps", type=int, default=64)
+    ap.add_argument("--batch-size", type=int, default=16384)
+    ap.add_argument("--learning-rate", type=float, default=5e-05)
+    ap.add_argument("--eval-freq", type=int, default=2_000_000)
+    ap.add_argument("--save-freq", type=int, default=10_000_000)
+    a = ap.parse_args(argv)
+    from .metrics import CheckpointCallback, EnvDumpCallback, EvalCallback
+    from .rl.vec_normalize import VecNormalize
+    from .train.trainer import MyoTrainer
+    cfg = json.load(open(a.config)) if a.config else config
+    log_dir = a.log_dir or os.path.join("output", "training", datetime.now().strftime("%Y-%m-%d/%H-%M-%S"))
+    os.makedirs(log_dir, exist_ok=True)
+    envs = make_parallel_envs(cfg, a.num_envs, env_name=a.env_name)
+    envs = VecNormalize.load(a.load_env, envs) if a.load_env else VecNormalize(envs)
+    eval_env = make_parallel_envs(cfg, min(256, a.num_envs), start_index=12345, env_name=a.env_name)
+    eval_env = VecNormalize.load(a.load_env, eval_env) if a.load_env else VecNormalize(eval_env)
+    eval_callback = EvalCallback(eval_env=eval_env, callback_on_new_best=EnvDumpCallback(log_dir, verbose=0), n_eval_episodes=256,
+                                 best_model_save_path=log_dir, log_path=log_dir, eval_freq=a.eval_freq, deterministic=True, verbose=1)
+    checkpoint_callback = CheckpointCallback(save_freq=a.save_freq, save_path=log_dir, save_vecnormalize=True, verbose=1)
+    trainer = MyoTrainer(envs=envs, env_config=cfg, load_model_path=a.load_model, log_dir=log_dir,
+                         model_config={"policy": a.policy, "learning_rate": lambda _: a.learning_rate, "clip_range": lambda _: 0.2,
+                                       "n_steps": a.n_steps, "batch_size": a.batch_size,
+                                       "policy_kwargs": {"net_arch": [{"pi": [256, 256], "vf": [256, 256]}], "log_std_init": -2.0}},
+                         callbacks=[eval_callback, checkpoint_callback], timesteps=a.timesteps)
+    trainer.train(total_timesteps=trainer.timesteps)
+    trainer.save()
+
+
+if __name__ == "__main__":
+    main()

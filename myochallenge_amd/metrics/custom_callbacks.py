@@ -95,3 +95,28 @@ class EvalCallback:
             if self.on_best is not None:
                 self.on_best(algo)
         return True
+
+
+class CheckpointCallback:
+    """SB3 ``CheckpointCallback`` as the reference configures it (src/main_baoding.py:93-98): every ``save_freq``
+    timesteps write ``<save_path>/<name_prefix>_<steps>_steps.zip`` and, with ``save_vecnormalize``,
+    ``<name_prefix>_vecnormalize_<steps>_steps.pkl`` (the file names found under
+    trained_models/winning_ensemble/base)."""
+
+    def __init__(self, save_freq, save_path, name_prefix="rl_model", save_vecnormalize=False, verbose=0):
+        self.save_freq, self.save_path, self.name_prefix = save_freq, save_path, name_prefix
+        self.save_vecnormalize, self.verbose = bool(save_vecnormalize) and save_vecnormalize != "False", verbose
+        self._next = save_freq
+
+    def __call__(self, algo) -> bool:
+        if algo.num_timesteps < self._next:
+            return True
+        self._next += self.save_freq * max(1, (algo.num_timesteps - self._next) // self.save_freq + 1)
+        os.makedirs(self.save_path, exist_ok=True)
+        path = os.path.join(self.save_path, f"{self.name_prefix}_{algo.num_timesteps}_steps.zip")
+        algo.save(path)
+        if self.save_vecnormalize and hasattr(algo.env, "save"):
+            algo.env.save(os.path.join(self.save_path, f"{self.name_prefix}_vecnormalize_{algo.num_timesteps}_steps.pkl"))
+        if self.verbose:
+            print(f"Saving model checkpoint to {path}")
+        return True

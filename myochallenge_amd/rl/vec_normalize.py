@@ -169,6 +169,11 @@ class VecNormalize:
                 "norm_obs": self.norm_obs, "norm_reward": self.norm_reward, "training": self.training}
 
     def save(self, path: str) -> None:
+        """``envs.save(path)`` (/root/reference/src/train/trainer.py:75): stable-baselines3's pickle layout."""
+        self.save_sb3(path)
+
+    def save_plain(self, path: str) -> None:
+        """The statistics as a plain dict (no class references); ``load`` reads both layouts."""
         with open(path, "wb") as fh:
             pickle.dump({"format": "myochallenge_amd.VecNormalize/1", **self.state_dict()}, fh)
 

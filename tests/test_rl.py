@@ -462,3 +462,43 @@ def test_mixture_of_ensembles_matches_sequential_flow(emu_lib, golden_dir, mode)
     assert len(res["classifier_preds"]) >= full.sum() - N and set(np.unique(res["classifier_targets"])) <= {0, 1}
     if mode == "always_hold":
         assert (res["classifier_preds"] == 0).all()
+
+
+def test_myotrainer_matches_reference_surface(emu_lib, golden_dir, tmp_path):
+    """MyoTrainer (src/train/trainer.py:30-75): env_config.json dump, new model from SB3-style model_config
+    (callable schedules, policy_kwargs), train with callbacks, save() -> final_model.pkl (a model zip) +
+    final_env.pkl (SB3 VecNormalize pickle); resume from a zip with custom_objects-style overrides."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.metrics import CheckpointCallback
+    from myochallenge_amd.rl.vec_normalize import _StubUnpickler
+    from myochallenge_amd.train.trainer import MyoTrainer
+    env_config = {"weighted_reward_keys": {"pos_dist_1": 2, "pos_dist_2": 2, "solved": 5}, "task_choice": "random"}
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=2, lib=emu_lib, seed=3, dtype="f64", max_episode_steps=5, **env_config)
+    venv = VecNormalize(env)
+    log = str(tmp_path / "run")
+    ck = CheckpointCallback(save_freq=8, save_path=log, save_vecnormalize="True")
+    tr = MyoTrainer(envs=venv, env_config=env_config, load_model_path=None, log_dir=log,
+                    model_config={"learning_rate": lambda _: 5e-05, "lr_schedule": lambda _: 5e-05, "clip_range": lambda _: 0.2,
+                                  "n_steps": 4, "batch_size": 8, "n_epochs": 1,
+                                  "policy_kwargs": {"lstm_hidden_size": 8, "net_arch": [{"pi": [8], "vf": [8]}]}},
+                    callbacks=[ck], timesteps=16)
+    assert json.load(open(os.path.join(log, "env_config.json"))) == env_config
+    assert tr.agent.policy.recurrent and tr.agent.cfg.learning_rate == 5e-05 and tr.agent.cfg.clip_range == 0.2
+    tr.train(total_timesteps=tr.timesteps)
+    tr.save()
+    assert tr.agent.num_timesteps == 16
+    assert os.path.exists(os.path.join(log, "rl_model_8_steps.zip")) and os.path.exists(os.path.join(log, "rl_model_vecnormalize_16_steps.pkl"))
+    pol, data = load_policy(os.path.join(log, "final_model.pkl"))
+    assert pol.recurrent and data["n_steps"] == 4 and data["num_timesteps"] == 16
+    obj = _StubUnpickler(open(os.path.join(log, "final_env.pkl"), "rb")).load()
+    assert type(obj).__module__ == "stable_baselines3.common.vec_env.vec_normalize"
+    # resume, as src/main_baoding.py does, from the reference's own phase-1 artifacts
+    venv2 = VecNormalize.load(os.path.join(golden_dir, "normalized_env_phase1_final.pkl"), env)
+    tr2 = MyoTrainer(envs=venv2, env_config=env_config, load_model_path=os.path.join(golden_dir, "phase1_final.zip"), log_dir=log,
+                     model_config={"lr_schedule": lambda _: 5e-05, "learning_rate": lambda _: 5e-05, "clip_range": lambda _: 0.2,
+                                   "n_steps": 4, "batch_size": 8, "n_epochs": 1})
+    assert tr2.agent.policy.lstm_hidden_size == 128 and tr2.agent.cfg.gae_lambda == 0.9 and tr2.agent.cfg.learning_rate == 5e-05
+    tr2.train(total_timesteps=8)
+    assert tr2.agent.num_timesteps == 8
+    with pytest.raises(TypeError):
+        MyoTrainer(envs=venv, env_config=env_config, load_model_path=None, log_dir=log, model_config={"not_a_kwarg": 1})

@@ -44,7 +44,7 @@ def evaluate(model_path: str, env_path: str, env_name: str = "CustomMyoBaodingBa
     if verbose:
         print(f"Average len: {out['mean_len']:.2f} +/- {out['len_err']:.2f}")
         print(f"Average rew: {out['mean_rew']:.2f} +/- {out['rew_err']:.2f}")
-        print(f"\\nFinished evaluating {model_path}!")
+        print(f"\nFinished evaluating {model_path}!")
     return res, out
 
 

@@ -76,7 +76,7 @@ class MyoTrainer:
             agent = PPO(env, policy, self._ppo_config(data), seed=int(mc.get("seed") or 0))
             agent.num_timesteps = 0                               # reset_num_timesteps=True
             return agent
-        print("\\nNo model path provided. Initializing new model.\\n")
+        print("\nNo model path provided. Initializing new model.\n")
         pk = dict(mc.get("policy_kwargs") or {})
         arch = pk.get("net_arch", [dict(pi=[64, 64], vf=[64, 64])])
         arch = arch[0] if isinstance(arch, (list, tuple)) and arch and isinstance(arch[0], dict) else arch

@@ -468,3 +468,57 @@ def test_mixture_of_ensembles_on_gpu(hip_lib, golden_dir):
     assert np.isfinite(r1["returns"]).all() and len(r1["classifier_preds"]) == len(r1["classifier_targets"])
     assert len(r1["classifier_preds"]) >= (r1["lengths"] >= 13).sum() - 64
     assert np.array_equal(r1["lengths"], r2["lengths"]) and np.array_equal(r1["classifier_preds"], r2["classifier_preds"])
+
+
+def test_native_rollout_bookkeeping(hip_lib):
+    """The graph-captured rollout (policy-input / sample / VecNormalize / advance kernels) fills the rollout
+    buffers consistently: episode starts follow dones, truncations appear exactly at the TimeLimit, the
+    deferred timeout bootstrap adds gamma * V(terminal_obs) where (and only where) an episode was truncated,
+    stored log-probs are the policy's log-probs of the stored actions, and the run is reproducible."""
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+
+    def run():
+        torch.manual_seed(0)
+        env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=256, seed=11, max_episode_steps=5)
+        pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
+        algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=12, batch_size=1024, n_epochs=1), seed=0)
+        assert algo._native_rollout()
+        for _ in range(12):
+            algo.rollout_step()
+        torch.cuda.synchronize()
+        before = algo.rew_buf.clone()
+        algo.finish_rollout()
+        torch.cuda.synchronize()
+        return algo, before
+    algo, before = run()
+    T, N = algo.trunc_buf.shape
+    tr = algo.trunc_buf
+    assert float(tr.sum()) > 0 and set(tr.unique().tolist()) <= {0.0, 1.0}
+    # the eager warm-up step of the graph capture already advanced every env by one step, so the recorded rollout
+    # starts at episode step 1: no episode starts in row 0, and a 5-step TimeLimit truncates at rows 3 and 8 for
+    # every env that never dropped a ball
+    st = algo.start_buf
+    assert float(st[0].sum()) == 0
+    dropped = ((st[1:] - tr[:-1]) > 0).any(0)                     # a done that was not a truncation
+    clean = ~dropped
+    assert int(clean.sum()) > 0
+    want_tr = torch.zeros(T, device="cuda"); want_tr[[3, 8]] = 1
+    assert torch.equal(tr[:, clean], want_tr[:, None].expand(T, int(clean.sum())))
+    with torch.no_grad(), algo._autocast():
+        tv = algo.policy.predict_values(algo.term_buf.view(T * N, -1)).view(T, N)
+    want = before + algo.cfg.gamma * tv * tr
+    assert float((algo.rew_buf - want).abs().max()) < 1e-5
+    assert torch.equal((algo.rew_buf != before), (tr * tv != 0))
+    # every truncation is followed by an episode start
+    assert bool(((tr[:-1] == 1) <= (algo.start_buf[1:] == 1)).all())
+    # stored log-prob = log N(a; mean(obs), exp(log_std)) of the stored action under the (bf16) rollout policy
+    with torch.no_grad(), algo._autocast():
+        _, lp, _ = algo.policy.evaluate_actions(algo.obs_buf.view(T * N, -1), algo.act_buf.view(T * N, -1))
+    assert float((lp.view(T, N) - algo.logp_buf).abs().max()) < 0.15      # bf16 action mean (|z| up to ~4, 39 dims)
+    assert float((lp.view(T, N) - algo.logp_buf).abs().mean()) < 0.02
+    algo2, before2 = run()
+    assert torch.equal(algo.act_buf, algo2.act_buf) and torch.equal(algo.rew_buf, algo2.rew_buf)

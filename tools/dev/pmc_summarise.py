@@ -8,4 +8,4 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     v = v[2:] if len(v) > 4 else v          # drop the first launches (cold)
-    print("PMC", k, sum(v) / len(v), len(v))
+    print("PMC", k, sum(v) / len(v), len(v), "total", sum(v), "kernels~" + pat)

@@ -22,6 +22,11 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
   python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_kstep.txt
 done
+# 3b. matrix-core activity of the PPO side (north_star asks for MFMA-busy against peak): hipBLASLt GEMM kernels
+rm -rf /tmp/pmc
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
+python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "Cijk" > $OUT/pmc_gemm.txt
+python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_gemm.txt
 # 4. stage shares (instrumented build; shares only)
 python3 $ROOT/tools/dev/gpu_prof.py > $OUT/stage_shares.txt 2>&1
 # 5. other configurations (BASELINE.json configs / variants)

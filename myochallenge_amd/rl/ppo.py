@@ -195,16 +195,23 @@ class PPO:
 
         self._raw = raw
         fused.refresh_shadow()
+        # eager warm-up of the two halves (library handles, workspaces) WITHOUT stepping the env: part B runs on
+        # the env's static output buffers as they are, and everything it touches is put back afterwards, so the
+        # recorded rollout starts exactly at the reset
+        rawout = (raw._obs, raw._rew, raw._done, raw._trunc, raw._term, raw._comps, raw._ep)
+        keep = [t.clone() for t in (self._obs_s, self._starts_s, vec.obs_rms.buf, vec.ret_rms.buf, vec.returns)]
         side = torch.cuda.Stream(device=d)
         side.wait_stream(torch.cuda.current_stream(d))
-        with torch.cuda.stream(side):           # eager warm-up (library handles; binds the env's constants)
+        with torch.cuda.stream(side):
             part_a()
-            rawout = raw.step_tensor(self._clip_s)
             part_b(rawout)
         torch.cuda.current_stream(d).wait_stream(side)
         torch.cuda.synchronize(d)
+        for t, k in zip((self._obs_s, self._starts_s, vec.obs_rms.buf, vec.ret_rms.buf, vec.returns), keep):
+            t.copy_(k)
         vec.old_obs, vec.old_reward = rawout[0], rawout[1]      # the env's static output buffers
         self._t_idx.zero_()
+        self._draw.zero_()
         self._gA, self._gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._gA, capture_error_mode="thread_local"):
             part_a()

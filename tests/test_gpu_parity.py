@@ -498,16 +498,16 @@ def test_native_rollout_bookkeeping(hip_lib):
     T, N = algo.trunc_buf.shape
     tr = algo.trunc_buf
     assert float(tr.sum()) > 0 and set(tr.unique().tolist()) <= {0.0, 1.0}
-    # the eager warm-up step of the graph capture already advanced every env by one step, so the recorded rollout
-    # starts at episode step 1: no episode starts in row 0, and a 5-step TimeLimit truncates at rows 3 and 8 for
-    # every env that never dropped a ball
+    # the rollout starts exactly at the reset (the graph-capture warm-up does not step the env): every env starts
+    # an episode in row 0, and a 5-step TimeLimit truncates at rows 4 and 9 for every env that never dropped a ball
     st = algo.start_buf
-    assert float(st[0].sum()) == 0
+    assert torch.equal(st[0], torch.ones(N, device="cuda"))
     dropped = ((st[1:] - tr[:-1]) > 0).any(0)                     # a done that was not a truncation
     clean = ~dropped
     assert int(clean.sum()) > 0
-    want_tr = torch.zeros(T, device="cuda"); want_tr[[3, 8]] = 1
+    want_tr = torch.zeros(T, device="cuda"); want_tr[[4, 9]] = 1
     assert torch.equal(tr[:, clean], want_tr[:, None].expand(T, int(clean.sum())))
+    assert float(algo.env.obs_rms.count) == pytest.approx(1e-4 + 13 * N)        # reset + 12 steps, no warm-up residue
     with torch.no_grad(), algo._autocast():
         tv = algo.policy.predict_values(algo.term_buf.view(T * N, -1)).view(T, N)
     want = before + algo.cfg.gamma * tv * tr

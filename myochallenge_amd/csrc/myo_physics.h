@@ -1754,41 +1754,57 @@ DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
     }
     SYNC();
   }
-  // contacts: H += Jp' (R' A R) Jp with A = D sum_active w w'  (3x3 per contact, frame coordinates)
-  for (int ci = 0; ci < s.ncon; ++ci) {
+  // contacts: H += Jp' (R' A R) Jp with A = D sum_active w w'  (3x3 per contact, frame coordinates).
+  // Two-stage per contact, software-pipelined over contacts: while the pairs of contact ci are accumulated,
+  // the (<= 16) lanes of the support set of contact ci+1 already put its Jacobian columns, rotated into the
+  // contact frame and signed, into the other half of a staging buffer — each column is evaluated once per
+  // contact instead of once per pair.  bvec is free here (body vectors are rebuilt after the solve).
+  T* stage = s.bvec;                       // 2 x MYO_CS_MAX x 3
+  static_assert(2 * MYO_CS_MAX * 3 <= MYO_NB_MAX * 6, "staging fits in bvec");
+  const int ncon = s.ncon;
+  for (int ci = -1; ci < ncon; ++ci) {
     PHASE {
-      const ContactRec<T>& c = s.con[ci];
-      const unsigned char* act = s.efc_active + nlim + 4 * ci;
-      // A = [[nn, n1, n2],[n1, a11, 0],[n2, 0, a22]] (every lane derives it: 4 flags, ~10 flops)
-      T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
-      if (act[0]) { nn += 1; n1 += c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
-      if (act[1]) { nn += 1; n1 -= c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
-      if (act[2]) { nn += 1; n2 += c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
-      if (act[3]) { nn += 1; n2 -= c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
-      if (nn != 0) {
-        const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
-        const int ns = c.nsup;
-        const unsigned long long m1 = c.m1, m2 = c.m2;
-        // lower-triangular pairs (a >= b) of the support set, enumerated linearly: q = a(a+1)/2 + b,
-        // so ceil(ns(ns+1)/128) passes instead of an 8x8 tiling with idle upper-triangle lanes
-        const int npair = ns * (ns + 1) / 2;
-        for (int q = lane; q < npair; q += 64) {
-          int a = (int)((sqrtf((float)(8 * q + 1)) - 1.0f) * 0.5f);
-          if ((a + 1) * (a + 2) / 2 <= q) a++;           // float sqrt rounding guard
-          if (a * (a + 1) / 2 > q) a--;
-          const int b = q - a * (a + 1) / 2;
-          {
+      // ---- stage A for contact ci+1
+      const int cn = ci + 1;
+      if (cn < ncon && lane < s.con[cn].nsup) {
+        const ContactRec<T>& c = s.con[cn];
+        const int d = c.sup[lane];
+        const int on2 = (int)((c.m2 >> d) & 1ull), on1 = (int)((c.m1 >> d) & 1ull);
+        T col[3];
+        con_col(s, d, on2 ? c.r2 : c.r1, col);
+        T j[3] = {dot3(c.frame, col), dot3(c.frame + 3, col), dot3(c.frame + 6, col)};
+        if (!on2) { j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2]; }
+        if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion
+        T* dst = stage + (cn & 1) * (MYO_CS_MAX * 3) + 3 * lane;
+        dst[0] = j[0]; dst[1] = j[1]; dst[2] = j[2];
+      }
+      // ---- stage B for contact ci (its columns were staged in the previous trip)
+      if (ci >= 0) {
+        const ContactRec<T>& c = s.con[ci];
+        const unsigned char* act = s.efc_active + nlim + 4 * ci;
+        T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
+        if (act[0]) { nn += 1; n1 += c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
+        if (act[1]) { nn += 1; n1 -= c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
+        if (act[2]) { nn += 1; n2 += c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
+        if (act[3]) { nn += 1; n2 -= c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
+        if (nn != 0) {
+          const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
+          const int ns = c.nsup;
+          const unsigned long long m1 = c.m1, m2 = c.m2;
+          const T* jc = stage + (ci & 1) * (MYO_CS_MAX * 3);
+          // lower-triangular pairs (a >= b) of the support set, enumerated linearly: q = a(a+1)/2 + b
+          const int npair = ns * (ns + 1) / 2;
+          for (int q = lane; q < npair; q += 64) {
+            int a = (int)((sqrtf((float)(8 * q + 1)) - 1.0f) * 0.5f);
+            if ((a + 1) * (a + 2) / 2 <= q) a++;           // float sqrt rounding guard
+            if (a * (a + 1) / 2 > q) a--;
+            const int b = q - a * (a + 1) / 2;
             const int da = c.sup[a], db = c.sup[b];
             const int a1 = (int)((m1 >> da) & 1ull), a2 = (int)((m2 >> da) & 1ull);
             const int b1 = (int)((m1 >> db) & 1ull), b2 = (int)((m2 >> db) & 1ull);
             if (a1 == a2 || b1 == b2) continue;
-            T ca[3], cb[3];
-            con_col(s, da, a2 ? c.r2 : c.r1, ca);
-            con_col(s, db, b2 ? c.r2 : c.r1, cb);
-            T ja[3] = {dot3(c.frame, ca), dot3(c.frame + 3, ca), dot3(c.frame + 6, ca)};
-            T jb[3] = {dot3(c.frame, cb), dot3(c.frame + 3, cb), dot3(c.frame + 6, cb)};
-            if (!a2) { ja[0] = -ja[0]; ja[1] = -ja[1]; ja[2] = -ja[2]; }
-            if (!b2) { jb[0] = -jb[0]; jb[1] = -jb[1]; jb[2] = -jb[2]; }
+            const T ja[3] = {jc[3 * a], jc[3 * a + 1], jc[3 * a + 2]};
+            const T jb[3] = {jc[3 * b], jc[3 * b + 1], jc[3 * b + 2]};
             const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
             const T Ajb1 = A1 * jb[0] + A3 * jb[1];
             const T Ajb2 = A2 * jb[0] + A4 * jb[2];

@@ -388,11 +388,13 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_i
     if (b == 0) { s.com[0] = s.com[1] = s.com[2] = 0; }
     if (b > 0 && b < M.nbody && M.body_rootid[b] == b) {
       T mass = 0, c[3] = {0, 0, 0};
-      for (int o = 1; o < M.nbody; ++o)
-        if (M.body_rootid[o] == b) {
-          const T mo = body_mass_of(M, K, s, o);
-          mass += mo; c[0] += mo * S_XIPOS(s)[3 * o]; c[1] += mo * S_XIPOS(s)[3 * o + 1]; c[2] += mo * S_XIPOS(s)[3 * o + 2];
-        }
+#pragma unroll 4
+      for (int o = 1; o < M.nbody; ++o) {
+        // wave-uniform reads issued unconditionally, membership applied as a select (no branch around the loads)
+        const T mo = (M.body_rootid[o] == b) ? body_mass_of(M, K, s, o) : (T)0;
+        const T x = S_XIPOS(s)[3 * o], y = S_XIPOS(s)[3 * o + 1], z = S_XIPOS(s)[3 * o + 2];
+        mass += mo; c[0] += mo * x; c[1] += mo * y; c[2] += mo * z;
+      }
       if (mass < MYO_MINVAL) { c[0] = S_XIPOS(s)[3 * b]; c[1] = S_XIPOS(s)[3 * b + 1]; c[2] = S_XIPOS(s)[3 * b + 2]; }
       else { c[0] /= mass; c[1] /= mass; c[2] /= mass; }
       s.com[3 * b] = c[0]; s.com[3 * b + 1] = c[1]; s.com[3 * b + 2] = c[2];

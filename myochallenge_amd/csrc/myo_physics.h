@@ -1456,8 +1456,10 @@ DEVFN void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LRE
     const int d = lane;
     if (d < M.nv) {
       T acc = 0;
-      for (int r = 0; r < nl; ++r)
-        if (s.lim_id[r] == d) acc += s.lim_sgn[r] * f[r];
+      for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
+        const T v = s.lim_sgn[r] * f[r];
+        acc += (s.lim_id[r] == d) ? v : (T)0;
+      }
       for (int r = nl; r < nlim; ++r) {
         const int t = s.lim_id[r];
         const unsigned long long m = M.tendon_dofmask[t];
@@ -1731,8 +1733,10 @@ DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
     const int d = lane;
     if (d < M.nv) {
       T acc = 0;
-      for (int r = 0; r < nl; ++r)
-        if (s.efc_active[r] && s.lim_id[r] == d) acc += s.efc_D[r];
+      for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
+        const T Dr = s.efc_D[r];
+        acc += (s.efc_active[r] && s.lim_id[r] == d) ? Dr : (T)0;
+      }
       if (acc != 0) s.H[MYO_HIDX(d, d)] += acc;
     }
   }

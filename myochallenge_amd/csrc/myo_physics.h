@@ -1463,7 +1463,10 @@ DEVFN void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LRE
       for (int r = nl; r < nlim; ++r) {
         const int t = s.lim_id[r];
         const unsigned long long m = M.tendon_dofmask[t];
-        if ((m >> d) & 1ull) acc += s.lim_sgn[r] * s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f[r];
+        const int on = (int)((m >> d) & 1ull);
+        const int slot = on ? myo_popcll(m & ((1ull << d) - 1ull)) : 0;      // slot 0 is always a valid read
+        const T v = s.lim_sgn[r] * s.ten_J[t * MYO_TJ_MAX + slot] * f[r];
+        acc += on ? v : (T)0;
       }
       // own motion axis once; per contact only wave-uniform (broadcast) reads, issued unconditionally with a
       // select at the end: no exec-mask branch around the loads, so consecutive contacts overlap
@@ -1707,12 +1710,13 @@ DEVFN T update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {
       const T x = s.efc_jar[r];
       const unsigned char a = x < 0;
       s.efc_active[r] = a;
-      s.efc_force[r] = a ? -row_D(s, r, nlim) * x : (T)0;
+      const T Dr = row_D(s, r, nlim);
+      s.efc_force[r] = a ? -Dr * x : (T)0;
     }
   }
   SYNC();
   JT_times(M, s, LOFF(s, s.efc_force), LOFF(s, s.qfrc_constraint));
-  WAVE_SUM_N(T, ccost, nefc, r, (s.efc_active[r] ? (T)0.5 * row_D(s, r, nlim) * s.efc_jar[r] * s.efc_jar[r] : (T)0));
+  WAVE_SUM_N(T, ccost, nefc, r, ((T)0.5 * row_D(s, r, nlim) * tmin(s.efc_jar[r], (T)0) * tmin(s.efc_jar[r], (T)0)));   // active <=> jar < 0
   WAVE_SUM_N(T, gcost, M.nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc[c] - s.qacc_smooth[c])));
   PHASE {
     const int c = lane;
@@ -1835,8 +1839,9 @@ DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
            LOFF(s, s.efc_jv));
   mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc_warm));
   const int nlim = s.nl + s.ntl;
-  WAVE_SUM_N(T, costw_c, nefc, r, ((s.efc_jar[r] - s.efc_aref[r]) < 0 ? (T)0.5 * row_D(s, r, nlim) * (s.efc_jar[r] - s.efc_aref[r]) * (s.efc_jar[r] - s.efc_aref[r]) : (T)0));
-  WAVE_SUM_N(T, costs, nefc, r, ((s.efc_jv[r] - s.efc_aref[r]) < 0 ? (T)0.5 * row_D(s, r, nlim) * (s.efc_jv[r] - s.efc_aref[r]) * (s.efc_jv[r] - s.efc_aref[r]) : (T)0));
+  // cost of the violated rows, branch-free: 0.5 D min(x, 0)^2  (no conditional around the D load)
+  WAVE_SUM_N(T, costw_c, nefc, r, ((T)0.5 * row_D(s, r, nlim) * tmin(s.efc_jar[r] - s.efc_aref[r], (T)0) * tmin(s.efc_jar[r] - s.efc_aref[r], (T)0)));
+  WAVE_SUM_N(T, costs, nefc, r, ((T)0.5 * row_D(s, r, nlim) * tmin(s.efc_jv[r] - s.efc_aref[r], (T)0) * tmin(s.efc_jv[r] - s.efc_aref[r], (T)0)));
   WAVE_SUM_N(T, gw, nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc_warm[c] - s.qacc_smooth[c])));
   const int use_warm = (costw_c + (T)0.5 * gw) < costs;
   PHASE {

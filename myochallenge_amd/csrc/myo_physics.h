@@ -719,14 +719,23 @@ DEVFN void crb(const DevModel<T>& M_in, Scratch<T>& s_in) {
   }
   SYNC();
   PHASE {
-    for (int e = lane; e < M.nM; e += 64) {
-      const int i = M.M_i[e], j = M.M_j[e];
-      T buf[6];
-      mul_inert_vec(buf, S_CRB(s) + 10 * M.dof_bodyid[i], s.cdof + 6 * i);
-      T v = 0;
-      for (int k = 0; k < 6; ++k) v += s.cdof[6 * j + k] * buf[k];
-      if (i == j) v += M.dof_armature[i];
-      s.qM[e] = v;
+    // (row, column, body) of each entry packed in one table word, fetched for all of a lane's entries up front
+    constexpr int NE = (MYO_NM_MAX + 63) / 64;
+    int pk[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) pk[q] = M.M_pk[(lane + 64 * q) < MYO_NM_MAX ? (lane + 64 * q) : 0];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q;
+      if (e < M.nM) {
+        const int i = pk[q] & 255, j = (pk[q] >> 8) & 255, bi = pk[q] >> 16;
+        T buf[6];
+        mul_inert_vec(buf, S_CRB(s) + 10 * bi, s.cdof + 6 * i);
+        T v = 0;
+        for (int k = 0; k < 6; ++k) v += s.cdof[6 * j + k] * buf[k];
+        if (i == j) v += M.dof_armature[i];
+        s.qM[e] = v;
+      }
     }
   }
   SYNC();
@@ -777,11 +786,19 @@ DEVFN void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* dia
   }
   SYNC();
   PHASE {
-    for (int e = lane; e < M.nM; e += 64) {
-      const int i = M.M_i[e], j = M.M_j[e];
-      T v = s.qM[e];
-      if (i == j && diag_add) v += diag_scale * diag_add[i];
-      s.H[MYO_HIDX(i, j)] = v;
+    constexpr int NE = (MYO_NM_MAX + 63) / 64;
+    int pk[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) pk[q] = M.M_pk[(lane + 64 * q) < MYO_NM_MAX ? (lane + 64 * q) : 0];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = lane + 64 * q;
+      if (e < M.nM) {
+        const int i = pk[q] & 255, j = (pk[q] >> 8) & 255;
+        T v = s.qM[e];
+        if (i == j && diag_add) v += diag_scale * diag_add[i];
+        s.H[MYO_HIDX(i, j)] = v;
+      }
     }
   }
   SYNC();

@@ -183,6 +183,10 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
     for (int j = i; j >= 0; j = m->dof_parentid[j]) { m->M_i.push_back(i); m->M_j.push_back(j); }
   }
   m->nM = (int)m->M_i.size();
+  // packed entry table: row | column << 8 | body of the row dof << 16 (one load per entry of the sparse M)
+  m->M_pk.assign(MYO_NM_MAX, 0);
+  for (int e = 0; e < m->nM && e < MYO_NM_MAX; ++e)
+    m->M_pk[e] = m->M_i[e] | (m->M_j[e] << 8) | (m->dof_bodyid[m->M_i[e]] << 16);
   LIM(m->nM > MYO_NM_MAX, "nM")
   {
     std::vector<std::vector<std::pair<int, int>>> rows(nv);

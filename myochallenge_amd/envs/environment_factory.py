@@ -32,9 +32,12 @@ class EnvironmentFactory:
             return MixtureModelBaodingVecEnv(env_name, num_envs, kwargs, **mix, **batch_kw)
         if env_name in REGISTRATION:
             return BaodingVecEnv(env_name, num_envs, kwargs, **batch_kw)
+        if env_name in ("CustomMyoReorientP1", "CustomMyoReorientP2"):          # src/envs/reorient.py
+            from .reorient import ReorientVecEnv
+            return ReorientVecEnv(env_name, num_envs, kwargs, **batch_kw)
         known_elsewhere = ("MyoFingerPoseFixed", "MyoFingerPoseRandom", "MyoFingerReachFixed",
                            "MyoFingerReachRandom", "MyoHandKeyTurnFixed", "MyoHandKeyTurnRandom",
-                           "MyoBaodingBallsP1", "CustomMyoReorientP1", "CustomMyoReorientP2",
+                           "MyoBaodingBallsP1",
                            "MyoBaodingBallsP2", "CustomMyoElbowPoseFixed",
                            "CustomMyoElbowPoseRandom", "CustomMyoFingerPoseFixed",
                            "CustomMyoFingerPoseRandom", "CustomMyoHandPoseFixed",
@@ -42,5 +45,5 @@ class EnvironmentFactory:
         if env_name in known_elsewhere:
             raise NotImplementedError(
                 f"{env_name}: named by the reference but outside this build's hot-path scope "
-                "(SURVEY.md §8: the Baoding P1 / P2 / MixtureModel envs are implemented so far)")
+                "(SURVEY.md §8: the Baoding P1 / P2 / MixtureModel and die-reorient P1 / P2 envs are implemented so far)")
         raise ValueError("Environment name not recognized:", env_name)

@@ -39,6 +39,10 @@ from .mjb import MjbModel
 from .setconst import set_const
 
 ASSET = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "synth_myohand_baoding.npz")
+ASSET_DIE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", "synth_myohand_die.npz")
+DIE_H = 0.014        # half extent of the die's outer envelope
+DIE_R = 0.004        # radius of its corner spheres / edge capsules
+DIE_MASS = 0.05
 
 MUSCLES = ("ECRL ECRB ECU FCR FCU PL PT PQ FDS5 FDS4 FDS3 FDS2 FDP5 FDP4 FDP3 FDP2 EDC5 EDC4 "
            "EDC3 EDC2 EDM EIP EPL EPB FPL APL OP RI2 LU_RB2 UI_UB2 RI3 LU_RB3 UI_UB3 RI4 LU_RB4 "
@@ -261,7 +265,12 @@ def _palm_frame(t1, t2, b1, b2):
     return R, O
 
 
-def build_synthetic_hand(golden_obs=None, lengthrange_samples=384) -> MjbModel:
+def build_synthetic_hand(golden_obs=None, lengthrange_samples=384, objects="balls") -> MjbModel:
+    """objects = "balls": the Baoding model (two free spheres).  objects = "die": the same hand with ONE free
+    die for the reorient task (src/envs/reorient.py): body ``Object`` = 8 corner spheres + 12 edge capsules
+    (a rounded cube; the stepper has sphere-box, sphere-capsule and capsule-capsule contacts but no
+    box-capsule), site ``object_o``; static body ``target`` with site ``target_o``, ``target_ball`` and the
+    non-colliding geom ``target_dice`` (reorient.py:76-101)."""
     t1, t2 = TARGET1.copy(), TARGET2.copy()
     if golden_obs is not None:
         t1, t2 = np.array(golden_obs[35:38], float), np.array(golden_obs[38:41], float)
@@ -361,16 +370,44 @@ def build_synthetic_hand(golden_obs=None, lengthrange_samples=384) -> MjbModel:
                B.add_geom(f"pip{f}_wrap", b_p, 5, (0.0065, 0.01), (0, L[0], 0), qx),
                B.add_geom(f"dip{f}_wrap", b_m, 5, (0.005, 0.01), (0, L[1], 0), qx)]
         fingers[f] = dict(bodies=[b_p, b_m, b_d], L=L, mcp=mcp, cyl=cyl)
-    # ---- balls (free bodies; qpos[23:30], qpos[30:37], baoding.py:187-194)
-    bi = 0.4 * 0.043 * BALL_R ** 2
-    ball1 = B.add_body("ball1", 0, BALL1, mass=0.043, inertia=(bi, bi, bi))
-    B.add_joint("ball1_free", ball1, FREE)
-    ball2 = B.add_body("ball2", 0, BALL2, mass=0.043, inertia=(bi, bi, bi))
-    B.add_joint("ball2_free", ball2, FREE)
-    B.add_geom("ball1", ball1, 2, (BALL_R,), collide=2)
-    B.add_geom("ball2", ball2, 2, (BALL_R,), collide=2)
-    B.add_site("ball1_site", ball1, (0, 0, 0))
-    B.add_site("ball2_site", ball2, (0, 0, 0))
+    if objects == "balls":
+        # ---- balls (free bodies; qpos[23:30], qpos[30:37], baoding.py:187-194)
+        bi = 0.4 * 0.043 * BALL_R ** 2
+        ball1 = B.add_body("ball1", 0, BALL1, mass=0.043, inertia=(bi, bi, bi))
+        B.add_joint("ball1_free", ball1, FREE)
+        ball2 = B.add_body("ball2", 0, BALL2, mass=0.043, inertia=(bi, bi, bi))
+        B.add_joint("ball2_free", ball2, FREE)
+        B.add_geom("ball1", ball1, 2, (BALL_R,), collide=2)
+        B.add_geom("ball2", ball2, 2, (BALL_R,), collide=2)
+        B.add_site("ball1_site", ball1, (0, 0, 0))
+        B.add_site("ball2_site", ball2, (0, 0, 0))
+    else:
+        # ---- die: rests on the palm surface between the two ball positions, axes along the palm frame
+        n_w = R @ nb_                                         # palm-surface normal in world coordinates
+        die0 = 0.5 * (BALL1 + BALL2) + (DIE_H - BALL_R) * n_w
+        ii = DIE_MASS * (2 * DIE_H) ** 2 / 6.0
+        die = B.add_body("Object", 0, die0, mat_to_quat(R @ Rb), mass=DIE_MASS, inertia=(ii, ii, ii))
+        B.add_joint("OBJTx", die, FREE)
+        a = DIE_H - DIE_R
+        k = 0
+        for axis in range(3):                                 # 12 edge capsules first (reorient.py:143 sizes them by [:,1])
+            for s1 in (-1, 1):
+                for s2 in (-1, 1):
+                    c = np.zeros(3); c[(axis + 1) % 3] = s1 * a; c[(axis + 2) % 3] = s2 * a
+                    q = {0: qx, 1: qy, 2: (1, 0, 0, 0)}[axis]
+                    B.add_geom(f"die_edge{k}", die, 3, (DIE_R, a), tuple(c), q, collide=2)
+                    k += 1
+        k = 0
+        for sx in (-1, 1):
+            for sy in (-1, 1):
+                for sz in (-1, 1):
+                    B.add_geom(f"die_corner{k}", die, 2, (DIE_R,), (sx * a, sy * a, sz * a), collide=2)
+                    k += 1
+        B.add_site("object_o", die, (0, 0, 0))
+        tgt = B.add_body("target", 0, die0 + np.array([0.0, 0.0, 0.08]), mat_to_quat(R @ Rb), mass=0.0)
+        B.add_geom("target_dice", tgt, 6, (DIE_H, DIE_H, DIE_H), collide=0)
+        B.add_site("target_o", tgt, (0, 0, 0))
+        B.add_site("target_ball", tgt, (0, 0, 0.03))
 
     # ---- tendons -------------------------------------------------------------------------
     cnt = [0]
@@ -504,9 +541,17 @@ def synthetic_hand() -> MjbModel:
     return load_asset()
 
 
+def synthetic_hand_die() -> MjbModel:
+    """The committed synthetic hand + die model of the reorient task."""
+    return load_asset(ASSET_DIE)
+
+
 if __name__ == "__main__":
     golden = os.path.join(os.path.dirname(ASSET), "..", "..", "tests", "golden", "reset_obs_golden.npy")
     obs = np.load(golden) if os.path.exists(golden) else None
     model = build_synthetic_hand(obs)
     save_asset(model)
     print("wrote", ASSET, {k: v for k, v in model.sizes.items()})
+    die = build_synthetic_hand(obs, objects="die")
+    save_asset(die, ASSET_DIE)
+    print("wrote", ASSET_DIE, {k: v for k, v in die.sizes.items()})

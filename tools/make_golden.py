@@ -362,6 +362,56 @@ def reset_goldens(ref, cfgs):
     print("reset goldens:", len(cases))
 
 
+def reorient_goldens():
+    """Die-reorient reward dictionary: /root/reference/src/envs/reorient.py:12-56 called unbound on fake ``self``
+    objects (one env at a time, as the reference does) for 256 random (pos_err, rot_err, act, previous distances)
+    and three weight sets -> reorient_reward_goldens.npz.  euler2quat is only imported by the module, not used
+    by the reward, so a placeholder is enough."""
+    import types as _t
+    for n in ["myosuite.envs.env_base", "myosuite.envs.myo.myochallenge.reorient_v0", "myosuite.utils", "myosuite.utils.quat_math"]:
+        if n not in sys.modules:
+            sys.modules[n] = _t.ModuleType(n)
+    sys.modules["myosuite.envs.env_base"].MujocoEnv = object
+    base = sys.modules["myosuite.envs.myo.base_v0"].BaseV0
+
+    class ReorientEnvV0(base):
+        DEFAULT_OBS_KEYS = ["hand_qpos", "hand_qvel", "obj_pos", "goal_pos", "pos_err", "obj_rot", "goal_rot", "rot_err"]
+        DEFAULT_RWD_KEYS_AND_WEIGHTS = {"pos_dist": 100.0, "rot_dist": 1.0}
+    sys.modules["myosuite.envs.myo.myochallenge.reorient_v0"].ReorientEnvV0 = ReorientEnvV0
+    sys.modules["myosuite.utils.quat_math"].euler2quat = lambda e: None
+    spec = importlib.util.spec_from_file_location("ref_reorient", f"{REF}/src/envs/reorient.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rng = np.random.RandomState(7)
+    weight_sets = [{"pos_dist": 100.0, "rot_dist": 1.0},
+                   {"pos_dist": 1.0, "rot_dist": 1.0, "pos_dist_diff": 100.0, "rot_dist_diff": 10.0, "alive": 1.0, "act_reg": 0.1,
+                    "solved": 2.0, "done": -10.0, "sparse": 0.0},
+                   {"sparse": 1.0, "solved": 10.0}]
+    keys = ["pos_dist", "rot_dist", "pos_dist_diff", "rot_dist_diff", "alive", "act_reg", "sparse", "solved", "done", "dense"]
+    n = 256
+    pos_err = rng.normal(0, 0.03, (n, 3)) * (rng.rand(n, 1) < 0.85) + rng.normal(0, 0.2, (n, 3)) * (rng.rand(n, 1) < 0.2)
+    rot_err = rng.normal(0, 0.6, (n, 3)) * (rng.rand(n, 1) < 0.8)
+    pos_err[:8] *= 0.1; rot_err[:8] *= 0.1                     # some solved cases
+    act = rng.rand(n, 39)
+    prev_p, prev_r = np.abs(rng.normal(0, 0.05, n)), np.abs(rng.normal(0, 1.0, n))
+    out = np.zeros((len(weight_sets), n, len(keys)))
+    for wi, wts in enumerate(weight_sets):
+        for i in range(n):
+            f = _t.SimpleNamespace()
+            # MyoSuite keeps obs_dict entries as (1, 1, n) arrays, so every reward term is (1, 1)-shaped
+            f.obs_dict = {"pos_err": pos_err[i].reshape(1, 1, 3), "rot_err": rot_err[i].reshape(1, 1, 3), "act": act[i].reshape(1, 1, -1)}
+            f.pos_dist, f.rot_dist = np.full((1, 1), prev_p[i]), np.full((1, 1), prev_r[i])
+            f.sim = _t.SimpleNamespace(model=_t.SimpleNamespace(na=39, site_rgba=np.ones((4, 4))))
+            f.drop_th, f.pos_th, f.rot_th = 0.200, 0.025, 0.262
+            f.rwd_keys_wt = wts
+            f.success_indicator_sid = 1
+            rd = m.CustomReorientEnv.get_reward_dict(f, f.obs_dict)
+            out[wi, i] = [float(np.asarray(rd[k]).reshape(-1)[0]) for k in keys]
+    np.savez(f"{OUT}/reorient_reward_goldens.npz", pos_err=pos_err, rot_err=rot_err, act=act, prev_pos_dist=prev_p, prev_rot_dist=prev_r,
+             expected=out, keys=np.array(keys), weights=np.array(json.dumps(weight_sets)), drop_th=0.200, pos_th=0.025, rot_th=0.262)
+    print("reorient reward goldens:", out.shape, "solved", int(out[0, :, 7].sum()), "dropped", int(out[0, :, 8].sum()))
+
+
 def classifier_goldens(allobs):
     """Task classifier of the winning ensemble (src/models/classifier.py:160-174, used by
     src/eval_mixture_of_ensembles.py:139-190): the reference's own TaskClassifier class (imported with the
@@ -401,3 +451,4 @@ if __name__ == "__main__":
     reward_goldens(ref, allobs, cfgs)
     reset_goldens(ref, cfgs)
     classifier_goldens(allobs)
+    reorient_goldens()

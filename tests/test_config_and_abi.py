@@ -56,7 +56,10 @@ def test_environment_factory_names(emu_lib):
     with pytest.raises(ValueError):
         EnvironmentFactory.create("Nope")
     with pytest.raises(NotImplementedError):
-        EnvironmentFactory.create("CustomMyoReorientP1")
+        EnvironmentFactory.create("CustomMyoPenTwirlRandom")          # named by the reference, outside the hot path
+    die = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=2, lib=emu_lib)
+    assert die.observation_space.shape == (103,) and die.action_space.shape == (39,)
+    die.close()
     env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=2, lib=emu_lib)
     assert env.num_envs == 2 and env.observation_space.shape == (86,) and env.action_space.shape == (39,)
     env.close()

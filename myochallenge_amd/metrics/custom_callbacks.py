@@ -120,3 +120,25 @@ class CheckpointCallback:
         if self.verbose:
             print(f"Saving model checkpoint to {path}")
         return True
+
+
+class TensorboardCallback:
+    """src/metrics/custom_callbacks.py:64-81: record the mean of ``info[key]`` (the env's reward-dictionary
+    entries, ``info.update(rwd_dict)`` in reorient.py:211) under ``rollout/<key>``.  The batched envs expose the
+    last step's reward dictionary as ``env.rwd_dict``; its batch mean is recorded once per rollout."""
+
+    def __init__(self, info_keywords, log=None, verbose=0):
+        self.info_keywords, self.log = tuple(info_keywords), log
+        self.history = []
+
+    def __call__(self, algo) -> bool:
+        env = algo.env.venv if hasattr(algo.env, "venv") else algo.env
+        rd = getattr(env, "rwd_dict", None)
+        if not rd:
+            return True
+        rec = {"rollout/" + k: float(rd[k].mean()) for k in self.info_keywords if k in rd}
+        rec["timesteps"] = algo.num_timesteps
+        self.history.append(rec)
+        if self.log is not None:
+            self.log(rec)
+        return True

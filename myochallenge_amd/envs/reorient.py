@@ -160,6 +160,9 @@ class ReorientVecEnv:
         self._obs = z(N, self.obs_dim, dt=torch.float32)
         self._term = z(N, self.obs_dim, dt=torch.float32)
         self._comps = z(N, native.N_RWD, dt=torch.float32)
+        # static output buffers, like BaodingVecEnv (PPO's graph-captured rollout reads them by address)
+        self._rew, self._ep = z(N, dt=torch.float32), z(N, 2, dt=torch.float32)
+        self._done, self._trunc = z(N, dt=torch.uint8), z(N, dt=torch.uint8)
         self.rwd_dict = {}
         self._closed = False
 
@@ -269,7 +272,8 @@ class ReorientVecEnv:
             self._reset_rows(done)
             obs = torch.where(done.unsqueeze(-1), self._flat(self._obs_dict()), obs)
         self._obs.copy_(obs)
-        return self._obs, rew.to(torch.float32), done.to(torch.uint8), trunc.to(torch.uint8), self._term, self._comps, ep
+        self._rew.copy_(rew); self._done.copy_(done); self._trunc.copy_(trunc); self._ep.copy_(ep)
+        return self._obs, self._rew, self._done, self._trunc, self._term, self._comps, self._ep
 
     # ------------------------------------------------------------------ numpy protocol (subset)
     def reset(self):

@@ -93,6 +93,23 @@ def test_reorient_env_logic_on_emulation(emu_lib):
 
 
 @pytest.mark.gpu
+def test_reorient_ppo_mlp_graph_path_on_gpu(hip_lib):
+    """An MLP policy on the reorient env goes through the graph-captured rollout / optimizer path."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    torch.manual_seed(0)
+    env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=512, seed=3)
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=None)
+    algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=16, batch_size=2048, n_epochs=2))
+    assert algo._native_rollout()
+    algo.learn(2 * 16 * 512)
+    assert algo.num_timesteps == 16384 and all(torch.isfinite(p).all() for p in pol.parameters())
+    assert float(algo.env.obs_rms.count) > 16000 and torch.isfinite(algo.rew_buf).all()
+
+
+@pytest.mark.gpu
 def test_reorient_ppo_lstm_on_gpu(hip_lib):
     """BASELINE config E shape: die-reorient envs with a recurrent LSTM policy, PPO rollout + update on the GPU."""
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory

@@ -124,6 +124,12 @@ int myo_batch_set_task(myo_batch* b, const int32_t* task_i, const double* task_d
                        const double* ball_d, void* stream);
 int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ball_d, void* stream);
 
+/* Per-env physical randomisation of an object made of several geoms (the die of CustomReorientEnv.reset,
+ * /root/reference/src/envs/reorient.py:136-147): geoms [gid0, gidn) take their friction from ball_d[2..4]
+ * (friction1) and a size delta from ball_d[8] (size1): every geom centre of the group moves outward by the
+ * delta along each non-zero local coordinate, capsule half-lengths grow by it.  (-1, -1) clears the group. */
+int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn);
+
 /* forward dynamics of the current state with intermediates dumped for stage-wise parity
  * tests: out is dev double[N, myo_batch_dump_size()] ; layout by myo_batch_dump_offset(name).
  * names: ten_length ten_J(nt*nv) M(nv*nv) qfrc_bias qfrc_passive qfrc_actuator qacc_smooth

@@ -36,6 +36,7 @@
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
   int obj1_sid, obj2_sid, target1_sid, target2_sid, obj1_bid, obj2_bid, obj1_gid, obj2_gid;
+  int objg_gid0, objg_gidn;   // geom group with per-env friction (ball_fric[0..2]) and size delta (ball_size[0]); empty = -1,-1
   int task_choice, enable_rsi, balls_overlap, limit_init_angle_on, beta_init_angle_on,
       beta_ball_size_on, beta_ball_mass_on;
   double drop_th, proximity_th, center_pos[2], weights[7];
@@ -249,11 +250,25 @@ template <typename T> DEV T geom_size0_of(const DevModel<T>& M, const TaskDev& K
   return M.geom_size[3 * g];
 }
 template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, int k) {
+  if (g >= K.objg_gid0 && g < K.objg_gidn) return s.ball_fric[k];
   if (g == K.obj1_gid) return s.ball_fric[k];
   if (g == K.obj2_gid) return s.ball_fric[3 + k];
   return M.geom_friction[3 * g + k];
 }
 
+// geometry of a geom of the per-env object group (the die of the reorient task, reorient.py:136-147): every
+// geom centre moves outward by the env's size delta, capsule half-lengths grow by it
+template <typename T> DEV void geom_lpos_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, T* out) {
+  out[0] = M.geom_pos[3 * g]; out[1] = M.geom_pos[3 * g + 1]; out[2] = M.geom_pos[3 * g + 2];
+  if (g >= K.objg_gid0 && g < K.objg_gidn) {
+    const T del = s.ball_size[0];
+    for (int e = 0; e < 3; ++e) if (out[e] != 0) out[e] += out[e] > 0 ? del : -del;
+  }
+}
+template <typename T> DEV T geom_size1_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+  const T v = M.geom_size[3 * g + 1];
+  return (g >= K.objg_gid0 && g < K.objg_gidn && M.geom_type[g] == 3) ? v + s.ball_size[0] : v;
+}
 // world position of a point given in body coordinates
 template <typename T> DEV void body_point(const Scratch<T>& s, int b, const T* local, T* out) {
   mulmatvec3(out, s.xmat + 9 * b, local);
@@ -1030,13 +1045,15 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& 
                       ContactTmp<T>& o) {
   const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   const int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-  T p1[3], p2[3], R1[9], R2[9];
-  body_point(s, b1, M.geom_pos + 3 * g1, p1);
-  body_point(s, b2, M.geom_pos + 3 * g2, p2);
+  T p1[3], p2[3], R1[9], R2[9], l1[3], l2[3];
+  geom_lpos_of(M, K, s, g1, l1);
+  geom_lpos_of(M, K, s, g2, l2);
+  body_point(s, b1, l1, p1);
+  body_point(s, b2, l2, p2);
   mulmat3(R1, s.xmat + 9 * b1, M.geom_mat + 9 * g1);
   mulmat3(R2, s.xmat + 9 * b2, M.geom_mat + 9 * g2);
-  const T s1[3] = {geom_size0_of(M, K, s, g1), M.geom_size[3 * g1 + 1], M.geom_size[3 * g1 + 2]};
-  const T s2[3] = {geom_size0_of(M, K, s, g2), M.geom_size[3 * g2 + 1], M.geom_size[3 * g2 + 2]};
+  const T s1[3] = {geom_size0_of(M, K, s, g1), geom_size1_of(M, K, s, g1), M.geom_size[3 * g1 + 2]};
+  const T s2[3] = {geom_size0_of(M, K, s, g2), geom_size1_of(M, K, s, g2), M.geom_size[3 * g2 + 2]};
   o.n = 0;
   if (t1 == 0 && t2 == 2) {
     const T n[3] = {R1[2], R1[5], R1[8]};
@@ -1232,9 +1249,11 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
         if (rb1 > 0 && rb2 > 0) {
           // bounding-sphere filter with the MODEL rbound (the reference rewrites geom_size per
           // episode without refreshing rbound, baoding.py:586-604 — the stale value gates contacts)
-          T c1[3], c2[3];
-          body_point(s, M.geom_bodyid[g1], M.geom_pos + 3 * g1, c1);
-          body_point(s, M.geom_bodyid[g2], M.geom_pos + 3 * g2, c2);
+          T c1[3], c2[3], l1[3], l2[3];
+          geom_lpos_of(M, K, s, g1, l1);
+          geom_lpos_of(M, K, s, g2, l2);
+          body_point(s, M.geom_bodyid[g1], l1, c1);
+          body_point(s, M.geom_bodyid[g2], l2, c2);
           const T df[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
           const T bound = rb1 + rb2 + margin;
           if (dot3(df, df) > bound * bound) skip = 1;
@@ -1276,8 +1295,9 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
         c.b1 = b1; c.b2 = b2;
         T fr[3];
         for (int e = 0; e < 3; ++e) {
-          const T a = (g1 == K.obj1_gid) ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]);
-          const T b = (g2 == K.obj1_gid) ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]);
+          const int grp1 = (g1 >= K.objg_gid0 && g1 < K.objg_gidn), grp2 = (g2 >= K.objg_gid0 && g2 < K.objg_gidn);
+          const T a = (g1 == K.obj1_gid || grp1) ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]);
+          const T b = (g2 == K.obj1_gid || grp2) ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]);
           fr[e] = (fsel == 0) ? tmax(a, b) : (fsel == 1 ? a : b);
         }
         c.mu[0] = fr[0]; c.mu[1] = fr[0];  // condim 3: both tangential directions use friction[0]

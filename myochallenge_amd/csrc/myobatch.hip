@@ -407,7 +407,7 @@ struct myo_batch {
   std::vector<void*> allocs;   // every device allocation (model arrays, records)
   DevModel<double> Md;
   DevModel<float> Mf;
-  int nq, nv, nu, na, nbody, nsite, ntendon, integrator;
+  int nq, nv, nu, na, nbody, nsite, ntendon, ngeom, integrator;
   int timing;
   double ms_sum;
   int ms_cnt;
@@ -469,6 +469,7 @@ static void make_taskdev(const myo_task_cfg* c, uint64_t seed, TaskDev& K) {
   K.kind = MYO_TASK_NONE; K.frame_skip = 1; K.max_episode_steps = 1 << 30;
   K.obj1_sid = K.obj2_sid = K.target1_sid = K.target2_sid = -1;
   K.obj1_bid = K.obj2_bid = K.obj1_gid = K.obj2_gid = -1;
+  K.objg_gid0 = K.objg_gidn = -1;
   K.seed = seed;
   if (!c) return;
   K.kind = c->kind; K.frame_skip = c->frame_skip; K.max_episode_steps = c->max_episode_steps; K.n_hand = c->n_hand;
@@ -510,7 +511,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   myo_batch* b = new myo_batch();
   b->n = n_envs; b->device = device; b->dtype = dtype; b->timing = 0; b->ms_sum = 0; b->ms_cnt = 0;
   b->integrator = m->integrator;
-  b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon;
+  b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon; b->ngeom = m->ngeom;
   if (cfg) b->cfg = *cfg; else memset(&b->cfg, 0, sizeof b->cfg);
   make_taskdev(cfg && cfg->kind != MYO_TASK_NONE ? cfg : nullptr, seed, b->K);
   b->nobs = b->K.kind ? b->K.n_hand + 24 + m->na : 0;
@@ -785,6 +786,13 @@ extern "C" int myo_batch_set_task(myo_batch* b, const int32_t* task_i, const dou
 #ifndef MYO_EMU
   LAUNCH_CHECK(b)
 #endif
+  return MYO_OK;
+}
+extern "C" int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  if (!(gid0 == -1 && gidn == -1) && (gid0 < 0 || gidn <= gid0 || gidn > b->ngeom)) return fail(MYO_E_ARG, "bad geom range");
+  b->K.objg_gid0 = gid0; b->K.objg_gidn = gidn;
+  g_bound = nullptr;                 // the task block in __constant__ memory is re-uploaded at the next launch
   return MYO_OK;
 }
 extern "C" int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ball_d, void* stream) {

@@ -15,15 +15,14 @@ negligible next to the physics).  What is pinned and what is 
   hand_qpos 23, hand_qvel 23 (x dt), obj_pos 3, goal_pos 3, pos_err 3, obj_rot 3, goal_rot 3, rot_err 3,
   act 39 = 103; Euler angles by the mujoco-py ``rotations.py`` convention MyoSuite copies.
 
-Not supported: per-episode die size / friction randomisation (phase 2's ``obj_size_change``,
-``obj_friction_change``) — the stepper shares one model across the batch; the P2 env runs with the nominal
-die and says so (``physical_randomisation_applied = False``).  The die of the synthetic model is a rounded
-cube made of corner spheres and edge capsules (synth_hand.py).
+Phase 2's per-episode die randomisation (``obj_size_change``, ``obj_friction_change``, reorient.py:136-147)
+goes through ``myo_batch_set_object_group``: per env one size delta (every die geom moves outward by it,
+edge capsules grow by it — the reference's geometry update) and ONE friction triple for the die (the
+reference draws an independent triple for each of the die's geoms).  The die of the synthetic model is a
+rounded cube made of corner spheres and edge capsules (synth_hand.py).
 """
 from __future__ import annotations
 
-import math
-import warnings
 from typing import Optional
 
 import numpy as np
@@ -145,10 +144,16 @@ class ReorientVecEnv:
         self.init_qpos = f64(np.asarray(model.fields["qpos0"]).reshape(-1)).clone()
         self.init_qpos[:-7] = 0                                                   # reorient.py:120-121
         self.init_qpos[0] = -1.5
-        self.physical_randomisation_applied = False
-        if p["obj_size_change"] or any(float(x) != 0 for x in p["obj_friction_change"]):
-            warnings.warn(f"{env_name}: per-episode die size / friction randomisation is not supported by the batched "
-                          "stepper (one shared model); running with the nominal die")
+        gb = np.asarray(model.fields["geom_bodyid"]).reshape(-1)
+        die_geoms = np.nonzero(gb == self.object_bid)[0]
+        self.object_gid0, self.object_gidn = int(die_geoms[0]), int(die_geoms[-1]) + 1
+        assert self.object_gidn - self.object_gid0 == len(die_geoms), "die geoms must be contiguous"
+        self.nominal_friction = f64(np.asarray(model.fields["geom_friction"]).reshape(-1, 3)[self.object_gid0])
+        self.physical_randomisation_applied = bool(p["obj_size_change"]) or any(float(x) != 0 for x in p["obj_friction_change"])
+        if self.physical_randomisation_applied:
+            self.batch.set_object_group(self.object_gid0, self.object_gidn)
+        self._ball_d = torch.zeros((num_envs, 10), dtype=torch.float64, device=d)
+        self._ball_d[:, 2:5] = self.nominal_friction
         self.gen = torch.Generator(device=d)
         self.gen.manual_seed(int(seed) + 7919)
         z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=d)
@@ -214,6 +219,13 @@ class ReorientVecEnv:
             lo, hi = self._axis_range(choices, n)
             e.append(lo + (hi - lo) * torch.rand(n, generator=self.gen, device=self.device, dtype=torch.float64))
         self.goal_quat[idx] = euler2quat(torch.stack(e, -1))
+        if self.physical_randomisation_applied:          # :136-147 (one friction triple per env; see the module docstring)
+            ch = torch.as_tensor(np.asarray(p["obj_friction_change"], np.float64), device=self.device)
+            self._ball_d[idx, 2:5] = self.nominal_friction + (2 * torch.rand((n, 3), generator=self.gen, device=self.device,
+                                                                                dtype=torch.float64) - 1) * ch
+            c = float(p["obj_size_change"])
+            self._ball_d[idx, 8] = self._uniform(-c, c, (n,))
+            self.batch.set_task(None, None, self._ball_d, self._stream())
         qpos = self.init_qpos.expand(n, -1).clone()
         if p["enable_rsi"]:        # :150-176: the die starts between its default pose and the goal pose
             a, b = float(p["rsi_distance_pos"]), float(p["rsi_distance_rot"])

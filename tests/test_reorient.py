@@ -85,11 +85,57 @@ def test_reorient_env_logic_on_emulation(emu_lib):
     assert all(min(abs(float(v) + 0.2), abs(float(v) - 0.3)) < 1e-9 for v in gf[:, 1])
     a, b = mk(), mk()
     assert torch.equal(a.reset_tensor(), b.reset_tensor())
-    with pytest.warns(UserWarning):
-        p2 = EnvironmentFactory.create("CustomMyoReorientP2", num_envs=2, lib=emu_lib, seed=1, dtype="f64")
-    assert not p2.physical_randomisation_applied and float((p2.reset_tensor()[:, 49:52].double() - p2.goal_pos).abs().max()) < 1e-6
+    # phase 2: per-env die size delta and friction through the object group (reorient.py:136-147)
+    p2 = EnvironmentFactory.create("CustomMyoReorientP2", num_envs=3, lib=emu_lib, seed=1, dtype="f64")
+    assert p2.physical_randomisation_applied and p2.object_gidn - p2.object_gid0 == 20
+    assert float((p2.reset_tensor()[:, 49:52].double() - p2.goal_pos).abs().max()) < 1e-6
+    bd = p2._ball_d
+    assert float(bd[:, 8].abs().max()) <= 0.007 and float(bd[:, 8].abs().max()) > 0
+    assert float((bd[:, 2] - 1.0).abs().max()) <= 0.2 and float((bd[:, 3] - 0.005).abs().max()) <= 0.001
+    for _ in range(3):
+        o, *_ = p2.step_tensor(torch.zeros(3, 39))
+        assert torch.isfinite(o).all()
+    # a bigger die rests higher on the palm; with a zero delta and nominal friction the group changes nothing
+    def settle(delta, use_group):
+        e = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=1, lib=emu_lib, seed=1, dtype="f64")
+        e.reset_tensor()
+        if use_group:
+            e.batch.set_object_group(e.object_gid0, e.object_gidn)
+            e._ball_d[:, 8] = delta
+            e.batch.set_task(None, None, e._ball_d)
+        for _ in range(6):
+            e.step_tensor(torch.zeros(1, 39))
+        return e._qp.clone()
+    q_plain, q_zero, q_big = settle(0.0, False), settle(0.0, True), settle(0.006, True)
+    assert torch.equal(q_plain, q_zero)
+    assert float((q_big[0, -7:-4] - q_plain[0, -7:-4]).norm()) > 0.003
     with pytest.raises(TypeError):
         mk(not_a_kwarg=1)
+
+
+@pytest.mark.gpu
+def test_reorient_p2_randomised_die_matches_emulation(hip_lib, emu_lib):
+    """Phase-2 die (per-env size delta + friction through the object geom group): the HIP stepper and the
+    lane-serial CPU build of the same sources agree in fp64 on identical states, dies and actions."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    g = EnvironmentFactory.create("CustomMyoReorientP2", num_envs=8, seed=5, dtype="f64")
+    c = EnvironmentFactory.create("CustomMyoReorientP2", num_envs=8, seed=5, dtype="f64", lib=emu_lib)
+    assert g.physical_randomisation_applied
+    g.reset_tensor()
+    c.reset_tensor()
+    c._ball_d.copy_(g._ball_d.cpu())
+    c.batch.set_task(None, None, c._ball_d)
+    for name in ("_qp", "_qv", "_ac", "_tm", "goal_pos", "goal_quat"):
+        getattr(c, name).copy_(getattr(g, name).cpu())
+    c.batch.set_state(c._qp, c._qv, c._ac, c._tm, None)
+    gen = torch.Generator().manual_seed(0)
+    for _ in range(4):
+        a = torch.rand((8, 39), generator=gen) * 2 - 1
+        g.step_tensor(a.cuda())
+        c.step_tensor(a)
+    torch.cuda.synchronize()
+    d = float((g._qp.cpu() - c._qp).abs().max())
+    assert d < 1e-8, d
 
 
 @pytest.mark.gpu

@@ -1333,13 +1333,32 @@ __global__ void __launch_bounds__(128) k_vecnorm_moments(const float* __restrict
   const int t = threadIdx.x, r0 = blockIdx.x * MYO_VN_ROWS;
   const int rows = (N - r0) < MYO_VN_ROWS ? (N - r0) : MYO_VN_ROWS;
   double* mine = part + (size_t)blockIdx.x * 2 * (O + 1);
-  for (int c = t; c < O; c += 128) {
-    double sum = 0;
-    for (int r = 0; r < rows; ++r) sum += (double)obs[(size_t)(r0 + r) * O + c];
+  // column c of the chunk: thread pair (2c', 2c'+1) -> each half walks alternate rows with 4 independent
+  // accumulators (the loads of a pass are in flight together), halves meet through a lane shuffle
+  const int half = t & 1;
+  for (int c = t >> 1; c < O; c += 64) {
+    const float* col = obs + (size_t)r0 * O + c;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int r = half;
+    for (; r + 6 < rows; r += 8) {
+      a0 += (double)col[(size_t)r * O]; a1 += (double)col[(size_t)(r + 2) * O];
+      a2 += (double)col[(size_t)(r + 4) * O]; a3 += (double)col[(size_t)(r + 6) * O];
+    }
+    for (; r < rows; r += 2) a0 += (double)col[(size_t)r * O];
+    double sum = (a0 + a1) + (a2 + a3);
+    sum += __shfl_xor(sum, 1);
     const double mean = sum / rows;
-    double m2 = 0;
-    for (int r = 0; r < rows; ++r) { const double d = (double)obs[(size_t)(r0 + r) * O + c] - mean; m2 += d * d; }
-    mine[2 * c] = mean; mine[2 * c + 1] = m2;
+    a0 = a1 = a2 = a3 = 0;
+    r = half;
+    for (; r + 6 < rows; r += 8) {
+      const double d0 = (double)col[(size_t)r * O] - mean, d1 = (double)col[(size_t)(r + 2) * O] - mean;
+      const double d2 = (double)col[(size_t)(r + 4) * O] - mean, d3 = (double)col[(size_t)(r + 6) * O] - mean;
+      a0 += d0 * d0; a1 += d1 * d1; a2 += d2 * d2; a3 += d3 * d3;
+    }
+    for (; r < rows; r += 2) { const double d = (double)col[(size_t)r * O] - mean; a0 += d * d; }
+    double m2 = (a0 + a1) + (a2 + a3);
+    m2 += __shfl_xor(m2, 1);
+    if (!half) { mine[2 * c] = mean; mine[2 * c + 1] = m2; }
   }
   double v = 0;
   if (t < rows) {

@@ -67,22 +67,32 @@ class ActorCriticPolicy(nn.Module):
 
     @staticmethod
     def _lstm_cell_steps(lstm: nn.LSTM, x, h, c, starts):
-        """One-layer LSTM written out as GEMMs + gates (PyTorch gate order i, f, g, o) — the GPU path: the
-        library RNN (MIOpen) compiles its kernels on first use, minutes on a fresh machine, and the rollout /
-        evaluation loops only ever advance one step at a time anyway.  No host sync on `starts`."""
+        """One-layer LSTM written out as GEMMs + a fused gate kernel (PyTorch gate order i, f, g, o) — the GPU
+        path: the library RNN (MIOpen) compiles its kernels on first use, minutes on a fresh machine.  The
+        input projection of the whole sequence is ONE GEMM; per step there is the recurrent GEMM and ATen's
+        fused pointwise cell (forward and backward are one kernel each).  No host sync on `starts`."""
         w_ih, w_hh, b_ih, b_hh = lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0
+        st_dtype = h.dtype
         h, c = h[0], c[0]
+        T, N = x.shape[0], x.shape[1]
+        gx = torch.addmm(b_ih + b_hh, x.reshape(T * N, -1), w_ih.t()).view(T, N, -1)
+        keep = None if starts is None else (1.0 - starts.to(gx.dtype)).unsqueeze(-1)
+        h, c = h.to(gx.dtype), c.to(gx.dtype)
+        fused = x.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
+        wt = w_hh.t()
         outs = []
-        for t in range(x.shape[0]):
-            if starts is not None:
-                keep = (1.0 - starts[t].to(h.dtype)).unsqueeze(-1)
-                h, c = h * keep, c * keep
-            gates = torch.addmm(b_ih + b_hh, x[t], w_ih.t()) + h @ w_hh.t()
-            i, f, g, o = gates.chunk(4, dim=-1)
-            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
-            h = torch.sigmoid(o) * torch.tanh(c)
+        for t in range(T):
+            if keep is not None:
+                h, c = h * keep[t], c * keep[t]
+            gh = (h @ wt).to(gx.dtype)
+            if fused:
+                h, c, _ = torch.ops.aten._thnn_fused_lstm_cell(gx[t], gh, c, None, None)
+            else:
+                i, f, g, o = (gx[t] + gh).chunk(4, dim=-1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h = torch.sigmoid(o) * torch.tanh(c)
             outs.append(h)
-        return torch.stack(outs, 0), h.unsqueeze(0), c.unsqueeze(0)
+        return torch.stack(outs, 0), h.unsqueeze(0).to(st_dtype), c.unsqueeze(0).to(st_dtype)
 
     @staticmethod
     def _lstm_seq(lstm: nn.LSTM, x, h, c, starts):

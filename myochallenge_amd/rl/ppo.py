@@ -89,6 +89,13 @@ class PPO:
                                        cfg.max_grad_norm)
             from .fused_mlp import FusedPPOStep
             self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
+        elif cfg.use_graphs and on_gpu:
+            # recurrent policy: autograd does forward / BPTT, but on flat parameter / gradient vectors so that the
+            # whole minibatch step (zero, forward, backward, clip + Adam) is ONE hipGraph (_train_recurrent_graphed)
+            from .. import native
+            from .fused_mlp import FlatAdam, flatten_parameters
+            self._flat_adam = FlatAdam(flatten_parameters(self.policy), native.load(), cfg.learning_rate,
+                                       cfg.max_grad_norm)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         N, T, O, A = env.num_envs, cfg.n_steps, env.obs_dim, env.act_dim
@@ -367,6 +374,8 @@ class PPO:
                     torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.max_grad_norm)
                     self.optimizer.step()
                     self.n_updates += 1
+        elif self._flat_adam is not None:
+            pl, vl = self._train_recurrent_graphed(adv, ret)
         else:
             # sequences = whole rollouts of a subset of envs, initial LSTM state = state at rollout start
             envs_per_mb = max(1, min(N, cfg.batch_size // T))
@@ -447,6 +456,71 @@ class PPO:
                     self._graph_ap.replay()
                 self.n_updates += 1
         self._fused.refresh_shadow()     # rollout inference reads the bf16 shadow weights
+        return g["pl"], g["vl"]
+
+    # ---------------------------------------------------------------- recurrent policy: one hipGraph per minibatch step
+    def _rec_forward_backward(self):
+        g = self._rg
+        idx = g["idx"]
+        self._flat_grad.zero_()
+        st0 = tuple(x.index_select(1, idx) for x in g["state0"])
+        sel = lambda buf: buf.index_select(1, idx)
+        with self._autocast():
+            v, lp, ent = self.policy.evaluate_actions(sel(self.obs_buf), sel(self.act_buf), st0, sel(self.start_buf))
+        loss, pl, vl = self._loss(v.reshape(-1), lp.reshape(-1), ent, sel(self.logp_buf).reshape(-1),
+                                  sel(g["adv"]).reshape(-1), sel(g["ret"]).reshape(-1))
+        loss.backward()                       # p.grad are views of the flat gradient: accumulated in place
+        g["pl"].copy_(pl); g["vl"].copy_(vl)
+
+    def _build_recurrent_graphs(self, T, N, m):
+        d = self.device
+        self._rg = {"idx": torch.arange(m, device=d), "state0": tuple(torch.zeros_like(x) for x in self._rollout_state0),
+                    "adv": torch.zeros((T, N), device=d), "ret": torch.zeros((T, N), device=d),
+                    "pl": torch.zeros((), device=d), "vl": torch.zeros((), device=d)}
+        side = torch.cuda.Stream(device=d)
+        side.wait_stream(torch.cuda.current_stream(d))
+        snap = self._flat_adam.snapshot()
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._rec_forward_backward()
+                if self.world > 1:
+                    dist.all_reduce(self._flat_grad)
+                self._mb_apply()
+        torch.cuda.current_stream(d).wait_stream(side)
+        torch.cuda.synchronize(d)
+        self._rgraph_fb, self._rgraph_ap = torch.cuda.CUDAGraph(), None
+        with torch.cuda.graph(self._rgraph_fb, capture_error_mode="thread_local"):
+            self._rec_forward_backward()
+            if self.world == 1:
+                self._mb_apply()
+        if self.world > 1:
+            self._rgraph_ap = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._rgraph_ap, capture_error_mode="thread_local"):
+                self._mb_apply()
+        self._flat_adam.restore(snap)
+        self._rgraph = (T, N, m)
+
+    def _train_recurrent_graphed(self, adv, ret):
+        """Same minibatches as the eager recurrent path (whole rollouts of a random subset of envs, LSTM state of
+        the rollout start), replayed from a graph: BPTT over n_steps is thousands of small launches."""
+        cfg = self.cfg
+        T, N = cfg.n_steps, self.env.num_envs
+        m = max(1, min(N, cfg.batch_size // T))
+        if getattr(self, "_rgraph", None) != (T, N, m):
+            self._build_recurrent_graphs(T, N, m)
+        g = self._rg
+        g["adv"].copy_(adv); g["ret"].copy_(ret)
+        for dst, src in zip(g["state0"], self._rollout_state0):
+            dst.copy_(src)
+        for _ in range(cfg.n_epochs):
+            perm = torch.randperm(N, generator=self.gen, device=self.device)
+            for s in range(0, N - m + 1, m):
+                g["idx"].copy_(perm[s:s + m])
+                self._rgraph_fb.replay()
+                if self.world > 1:
+                    dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+                    self._rgraph_ap.replay()
+                self.n_updates += 1
         return g["pl"], g["vl"]
 
     # ---------------------------------------------------------------- persistence (SB3 zip layout)

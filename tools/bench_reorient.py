@@ -1,6 +1,6 @@
 """BASELINE config E (die-reorient, 4096 envs on one MI355X, recurrent LSTM policy): env-steps/s of rollout +
 PPO update.  Not the headline bench: the task layer of this env is torch code around myo_batch_physics_step and
-the LSTM policy trains on the autograd path."""
+the LSTM policy trains by autograd BPTT replayed from a hipGraph."""
 import argparse
 import json
 import os

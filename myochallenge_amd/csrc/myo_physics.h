@@ -2073,14 +2073,17 @@ template <typename T>
 DEVFN void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
-  WAVE_SUM_N(int, badq, M.nq, i, ((isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (T)1e10) ? 0 : 1));
-  WAVE_SUM_N(int, badv, M.nv, i, ((isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (T)1e10) ? 0 : 1));
-  int bada = 0;
-  if (check_acc) {
-    WAVE_SUM_N(int, ba, M.nv, i, ((isfinite(s.qacc[i]) && fabs(s.qacc[i]) < (T)1e10) ? 0 : 1));
-    bada = ba;
+  // mj_checkPos / mj_checkVel / mj_checkAcc: any non-finite or huge entry marks the env bad.  No reduction:
+  // every lane tests its own entries and stores the flag itself (all writers store 1; the flag is read
+  // after later barriers, at the end of the env step).
+  PHASE {
+    int bad = 0;
+    for (int i = lane; i < M.nq; i += 64) bad |= !(isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (T)1e10);
+    for (int i = lane; i < M.nv; i += 64) bad |= !(isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (T)1e10);
+    if (check_acc)
+      for (int i = lane; i < M.nv; i += 64) bad |= !(isfinite(s.qacc[i]) && fabs(s.qacc[i]) < (T)1e10);
+    if (bad) s.bad = 1;
   }
-  if (badq + badv + bada) { PHASE { if (lane == 0) s.bad = 1; } SYNC(); }
 }
 
 template <typename T>

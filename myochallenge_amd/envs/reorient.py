@@ -154,6 +154,8 @@ class ReorientVecEnv:
             self.batch.set_object_group(self.object_gid0, self.object_gidn)
         self._ball_d = torch.zeros((num_envs, 10), dtype=torch.float64, device=d)
         self._ball_d[:, 2:5] = self.nominal_friction
+        self._fric_change = f64(np.asarray(p["obj_friction_change"], np.float64))
+        self.sync_free = False        # True: fixed-shape, host-sync-free step (graph capture); see _reset_rows
         self.gen = torch.Generator(device=d)
         self.gen.manual_seed(int(seed) + 7919)
         z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=d)
@@ -207,42 +209,62 @@ class ReorientVecEnv:
         return ch[pick, 0], ch[pick, 1]
 
     def _reset_rows(self, mask: torch.Tensor):
-        """reset() of the envs selected by mask (:124-181); state buffers must be current (_pull)."""
-        idx = mask.nonzero().flatten()
-        n = idx.numel()
-        if n == 0:
-            return
+        """reset() of the envs selected by mask (:124-181); state buffers must be current (_pull).
+
+        Two forms of the same code: indexed (default: one host read of the mask, work only for the rows that
+        reset) and, with ``sync_free``, full width with the mask applied by selects — fixed shapes and no host
+        synchronisation, which is what a hipGraph capture of the env step needs (PPO's recurrent rollout)."""
+        N = self.num_envs
+        if self.sync_free:
+            idx, n = None, N
+        else:
+            idx = mask.nonzero().flatten()
+            n = idx.numel()
+            if n == 0:
+                return
+
+        def put(dst, val):
+            if idx is not None:
+                dst[idx] = val
+            else:
+                m = mask.view(-1, *([1] * (dst.dim() - 1)))
+                v = val if torch.is_tensor(val) else torch.full_like(dst, val)
+                dst.copy_(torch.where(m, v.to(dst.dtype), dst))
+
+        take = (lambda src: src[idx]) if idx is not None else (lambda src: src)
         p = self.p
-        self.goal_pos[idx] = self.goal_init_pos + self._uniform(float(p["goal_pos"][0]), float(p["goal_pos"][1]), (n, 3))
+        put(self.goal_pos, self.goal_init_pos + self._uniform(float(p["goal_pos"][0]), float(p["goal_pos"][1]), (n, 3)))
         e = []
         for choices in (p["goal_rot_x"], p["goal_rot_y"], p["goal_rot_z"]):
             lo, hi = self._axis_range(choices, n)
             e.append(lo + (hi - lo) * torch.rand(n, generator=self.gen, device=self.device, dtype=torch.float64))
-        self.goal_quat[idx] = euler2quat(torch.stack(e, -1))
+        put(self.goal_quat, euler2quat(torch.stack(e, -1)))
         if self.physical_randomisation_applied:          # :136-147 (one friction triple per env; see the module docstring)
-            ch = torch.as_tensor(np.asarray(p["obj_friction_change"], np.float64), device=self.device)
-            self._ball_d[idx, 2:5] = self.nominal_friction + (2 * torch.rand((n, 3), generator=self.gen, device=self.device,
-                                                                                dtype=torch.float64) - 1) * ch
+            fr = self.nominal_friction + (2 * torch.rand((n, 3), generator=self.gen, device=self.device,
+                                                         dtype=torch.float64) - 1) * self._fric_change
             c = float(p["obj_size_change"])
-            self._ball_d[idx, 8] = self._uniform(-c, c, (n,))
+            bd = take(self._ball_d).clone()
+            bd[:, 2:5] = fr
+            bd[:, 8] = self._uniform(-c, c, (n,))
+            put(self._ball_d, bd)
             self.batch.set_task(None, None, self._ball_d, self._stream())
         qpos = self.init_qpos.expand(n, -1).clone()
         if p["enable_rsi"]:        # :150-176: the die starts between its default pose and the goal pose
             a, b = float(p["rsi_distance_pos"]), float(p["rsi_distance_rot"])
-            qpos[:, -7:-4] = a * self.default_init_pos + (1 - a) * (self.goal_pos[idx] - self.goal_obj_offset)
-            q = b * self.default_init_rot + (1 - b) * self.goal_quat[idx]
+            qpos[:, -7:-4] = a * self.default_init_pos + (1 - a) * (take(self.goal_pos) - self.goal_obj_offset)
+            q = b * self.default_init_rot + (1 - b) * take(self.goal_quat)
             qpos[:, -4:] = q / torch.clamp(torch.linalg.norm(q, dim=-1, keepdim=True), min=1e-30)
-        self._qp[idx] = qpos
-        self._qv[idx] = 0
-        self._ac[idx] = 0
-        self._tm[idx] = 0
+        put(self._qp, qpos)
+        put(self._qv, 0.0)
+        put(self._ac, 0.0)
+        put(self._tm, 0.0)
         self.batch.set_state(self._qp, self._qv, self._ac, self._tm, self._stream())
-        self.elapsed[idx] = 0
-        self.ep_len[idx] = 0
-        self.ep_ret[idx] = 0
+        put(self.elapsed, 0)
+        put(self.ep_len, 0.0)
+        put(self.ep_ret, 0.0)
         o = self._obs_dict()
-        self.pos_dist[idx] = torch.abs(torch.linalg.norm(o["pos_err"][idx], dim=-1))       # :178-179
-        self.rot_dist[idx] = torch.abs(torch.linalg.norm(o["rot_err"][idx], dim=-1))
+        put(self.pos_dist, torch.abs(torch.linalg.norm(take(o["pos_err"]), dim=-1)))       # :178-179
+        put(self.rot_dist, torch.abs(torch.linalg.norm(take(o["rot_err"]), dim=-1)))
 
     # ------------------------------------------------------------------ tensor API
     @torch.no_grad()
@@ -266,7 +288,7 @@ class ReorientVecEnv:
                                         float(self.p["drop_th"]), float(self.p["pos_th"]), float(self.p["rot_th"]),
                                         self.p["weighted_reward_keys"])
         self.rwd_dict = rd
-        self.pos_dist, self.rot_dist = pd, rdist                                  # step(): :207-212
+        self.pos_dist.copy_(pd); self.rot_dist.copy_(rdist)                       # step(): :207-212
         rew = torch.where(bad, torch.zeros_like(rd["dense"]), rd["dense"])
         self.elapsed += 1
         self.ep_len += 1
@@ -280,7 +302,7 @@ class ReorientVecEnv:
         comps = torch.stack([rd["pos_dist"], rd["rot_dist"], rd["act_reg"], rd["alive"], rd["sparse"], rd["solved"], rd["done"], rd["dense"]], -1)
         self._comps.copy_(torch.nan_to_num(comps).to(torch.float32))
         ep = torch.stack([self.ep_ret, self.ep_len], -1).to(torch.float32)
-        if bool(done.any()):
+        if self.sync_free or bool(done.any()):
             self._reset_rows(done)
             obs = torch.where(done.unsqueeze(-1), self._flat(self._obs_dict()), obs)
         self._obs.copy_(obs)

@@ -95,6 +95,41 @@ class ActorCriticPolicy(nn.Module):
         return torch.stack(outs, 0), h.unsqueeze(0).to(st_dtype), c.unsqueeze(0).to(st_dtype)
 
     @staticmethod
+    def _lstm_pair_steps(la: nn.LSTM, lc: nn.LSTM, x, state, starts):
+        """Actor and critic LSTMs (same shapes, same input) advanced together: ONE input-projection GEMM for
+        both networks and the whole sequence, then per step one batched recurrent GEMM and one fused cell
+        kernel over the stacked [2N] rows — half the launches of two `_lstm_cell_steps` calls, same math."""
+        ha, ca, hc, cc = state
+        st_dtype = ha.dtype
+        T, N, H = x.shape[0], x.shape[1], la.hidden_size
+        w_ih = torch.cat([la.weight_ih_l0, lc.weight_ih_l0], 0)                       # [8H, F]
+        b = torch.cat([la.bias_ih_l0 + la.bias_hh_l0, lc.bias_ih_l0 + lc.bias_hh_l0], 0)
+        gx = torch.addmm(b, x.reshape(T * N, -1), w_ih.t())                           # [T*N, 8H]
+        gx = gx.view(T, N, 2, 4 * H).transpose(1, 2).contiguous()                     # [T, 2, N, 4H]
+        wt = torch.stack([la.weight_hh_l0.t(), lc.weight_hh_l0.t()], 0)               # [2, H, 4H]
+        h = torch.stack([ha[0], hc[0]], 0).to(gx.dtype)                               # [2, N, H]
+        c = torch.stack([ca[0], cc[0]], 0).to(gx.dtype)
+        keep = None if starts is None else (1.0 - starts.to(gx.dtype)).view(T, 1, N, 1)
+        fused = x.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
+        outs = []
+        for t in range(T):
+            if keep is not None:
+                h, c = h * keep[t], c * keep[t]
+            gh = torch.bmm(h, wt.to(h.dtype)).to(gx.dtype)                            # [2, N, 4H]
+            if fused:
+                h2, c2, _ = torch.ops.aten._thnn_fused_lstm_cell(gx[t].reshape(2 * N, 4 * H), gh.reshape(2 * N, 4 * H),
+                                                                 c.reshape(2 * N, H), None, None)
+                h, c = h2.view(2, N, H), c2.view(2, N, H)
+            else:
+                i, f, g, o = (gx[t] + gh).chunk(4, dim=-1)
+                c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h = torch.sigmoid(o) * torch.tanh(c)
+            outs.append(h)
+        out = torch.stack(outs, 0)                                                     # [T, 2, N, H]
+        fin = lambda z, k: z[k].unsqueeze(0).to(st_dtype)
+        return out[:, 0], out[:, 1], (fin(h, 0), fin(c, 0), fin(h, 1), fin(c, 1))
+
+    @staticmethod
     def _lstm_seq(lstm: nn.LSTM, x, h, c, starts):
         """x [T,N,F]; starts [T,N] (1 = episode start: state zeroed before that step) — sb3-contrib
         ``_process_sequence`` [3P-RECALL, SURVEY.md C.3]."""
@@ -113,10 +148,13 @@ class ActorCriticPolicy(nn.Module):
     def _latents(self, obs, state, starts):
         """obs [T,N,F] (recurrent) or [B,F]."""
         if self.recurrent:
-            hp, cp, hv, cv = state
-            lp, hp, cp = self._lstm_seq(self.lstm_actor, obs, hp, cp, starts)
-            lv, hv, cv = self._lstm_seq(self.lstm_critic, obs, hv, cv, starts)
-            state = (hp, cp, hv, cv)
+            if obs.is_cuda and self.lstm_critic is not None and self.lstm_critic.hidden_size == self.lstm_actor.hidden_size:
+                lp, lv, state = self._lstm_pair_steps(self.lstm_actor, self.lstm_critic, obs, state, starts)
+            else:
+                hp, cp, hv, cv = state
+                lp, hp, cp = self._lstm_seq(self.lstm_actor, obs, hp, cp, starts)
+                lv, hv, cv = self._lstm_seq(self.lstm_critic, obs, hv, cv, starts)
+                state = (hp, cp, hv, cv)
         else:
             lp = lv = obs
         return self.mlp_extractor.policy_net(lp), self.mlp_extractor.value_net(lv), state

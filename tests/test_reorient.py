@@ -111,6 +111,25 @@ def test_reorient_env_logic_on_emulation(emu_lib):
     assert float((q_big[0, -7:-4] - q_plain[0, -7:-4]).norm()) > 0.003
     with pytest.raises(TypeError):
         mk(not_a_kwarg=1)
+    # sync-free (graph-capturable) step == indexed step, except for the random goals of the rows that reset
+    ea = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=3, lib=emu_lib, seed=4, dtype="f64", max_episode_steps=2)
+    eb = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=3, lib=emu_lib, seed=4, dtype="f64", max_episode_steps=2)
+    eb.sync_free = True
+    ea.reset_tensor(); eb.reset_tensor()
+    for name in ("goal_pos", "goal_quat", "_qp", "pos_dist", "rot_dist"):
+        getattr(eb, name).copy_(getattr(ea, name))
+    eb.batch.set_state(eb._qp, eb._qv, eb._ac, eb._tm, None)
+    for k in range(3):
+        act = torch.full((3, 39), 0.1 * k)
+        ra, rb = ea.step_tensor(act), eb.step_tensor(act)
+        assert torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2]) and torch.equal(ra[3], rb[3]) and torch.equal(ra[4], rb[4])
+        assert torch.equal(ea.elapsed, eb.elapsed) and torch.equal(ea._qp[:, :23], eb._qp[:, :23])
+        if k == 1:                      # both truncated at step 2 and were reset: new goals inside the range
+            assert bool(ra[3].all()) and int(eb.elapsed.max()) == 0
+            assert float((eb.goal_pos - eb.goal_init_pos).abs().max()) <= 0.010 + 1e-12
+            for name in ("goal_pos", "goal_quat", "_qp", "pos_dist", "rot_dist"):
+                getattr(eb, name).copy_(getattr(ea, name))
+            eb.batch.set_state(eb._qp, eb._qv, eb._ac, eb._tm, None)
 
 
 @pytest.mark.gpu

@@ -96,6 +96,14 @@ def ppo_mlp_step_grads(policy, obs, actions, old_logp, adv, returns, clip_range,
     return pl, vl
 
 
+def _colsum(x):
+    """fp32 column sums over the second-to-last dim as a ones-row GEMM (ATen's multi-block column reduction is
+    not replay-safe inside a hipGraph on this stack; see rl/policy.py:_LinearGemmBias)."""
+    xf = x.float()
+    ones = torch.ones((*xf.shape[:-2], 1, xf.shape[-2]), device=x.device)
+    return torch.matmul(ones, xf).squeeze(-2)
+
+
 def flatten_parameters(policy, pad: int = 64):
     """Re-home every parameter (and its .grad) as a view into ONE flat fp32 vector, each slot padded to
     `pad` elements (keeps bf16 GEMM operands 128-byte aligned).  Lets the optimiser be one kernel
@@ -240,7 +248,7 @@ class FusedPPOStep:
             self._reduce(partial, bias_grad, G, B // 32)
             return dh
         dh = torch.ops.aten.threshold_backward(dh, act, 0)
-        torch.sum(dh, 1, dtype=torch.float32, out=bias_grad)
+        bias_grad.copy_(_colsum(dh))
         return dh
 
     def _loss_kernel(self, mean, values, actions, old_logp, adv, returns, dmean_h=None, dvalue_h=None, direct=None):
@@ -378,7 +386,7 @@ class FusedPPOStep:
                 s = self.split if (B % self.split == 0) else 1
                 part = torch.bmm(dy.view(s, B // s, -1).transpose(1, 2), x.view(s, B // s, -1))
                 torch.sum(part, 0, dtype=torch.float32, out=lin.weight.grad)
-                torch.sum(dy, 0, dtype=torch.float32, out=lin.bias.grad)
+                lin.bias.grad.copy_(_colsum(dy))
                 if li > 0:
                     dy = torch.ops.aten.threshold_backward(dy @ self.wb[id(lin.weight)], saved[li], 0)
         return self.acc[A], self.acc[A + 1]

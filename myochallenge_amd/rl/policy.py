@@ -27,6 +27,46 @@ def _mlp(inp: int, sizes: Sequence[int], act) -> nn.Sequential:
     return nn.Sequential(*layers)
 
 
+class _LinearGemmBias(torch.autograd.Function):
+    """y = x @ w.T + b whose bias gradient is a [1,B] x [B,out] GEMM instead of a column reduction.
+
+    Why: inside a replayed hipGraph, ATen's multi-block column reduction (many outputs, many rows: semaphore-based
+    global reduce) returns wrong sums on this ROCm stack once the graph's private pool has been reused
+    (tools/dev/gpu_reduce_graph.py reproduces it: every replay after the first is wrong) — it put a stray 1e32
+    into one LSTM bias gradient.  GEMMs, row reductions and single-output reductions replay correctly."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        ones = torch.ones((1, g.shape[0]), dtype=g.dtype, device=g.device)
+        return g @ w, g.t() @ x, (ones @ g).squeeze(0)
+
+
+def _linear(x, w, b):
+    """F.linear for 2-D x; on the GPU with gradients enabled it goes through _LinearGemmBias (autocast-aware)."""
+    if x.is_cuda and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
+        if torch.is_autocast_enabled("cuda"):
+            dt = torch.get_autocast_dtype("cuda")
+            x, w, b = x.to(dt), w.to(dt), b.to(dt)
+        return _LinearGemmBias.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
+
+
+def _apply_net(net, x):
+    """nn.Sequential / nn.Linear forward with every Linear routed through _linear (any leading dims)."""
+    lead = x.shape[:-1]
+    x = x.reshape(-1, x.shape[-1])
+    for layer in (net if isinstance(net, nn.Sequential) else [net]):
+        x = _linear(x, layer.weight, layer.bias) if isinstance(layer, nn.Linear) else layer(x)
+    return x.reshape(*lead, x.shape[-1])
+
+
 class MlpExtractor(nn.Module):
     def __init__(self, inp: int, pi: Sequence[int], vf: Sequence[int], act):
         super().__init__()
@@ -75,11 +115,11 @@ class ActorCriticPolicy(nn.Module):
         st_dtype = h.dtype
         h, c = h[0], c[0]
         T, N = x.shape[0], x.shape[1]
-        gx = torch.addmm(b_ih + b_hh, x.reshape(T * N, -1), w_ih.t()).view(T, N, -1)
+        gx = _linear(x.reshape(T * N, -1), w_ih, b_ih + b_hh).view(T, N, -1)
         keep = None if starts is None else (1.0 - starts.to(gx.dtype)).unsqueeze(-1)
         h, c = h.to(gx.dtype), c.to(gx.dtype)
         fused = x.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
-        wt = w_hh.t()
+        wt = w_hh.t().to(gx.dtype)
         outs = []
         for t in range(T):
             if keep is not None:
@@ -104,18 +144,19 @@ class ActorCriticPolicy(nn.Module):
         T, N, H = x.shape[0], x.shape[1], la.hidden_size
         w_ih = torch.cat([la.weight_ih_l0, lc.weight_ih_l0], 0)                       # [8H, F]
         b = torch.cat([la.bias_ih_l0 + la.bias_hh_l0, lc.bias_ih_l0 + lc.bias_hh_l0], 0)
-        gx = torch.addmm(b, x.reshape(T * N, -1), w_ih.t())                           # [T*N, 8H]
+        gx = _linear(x.reshape(T * N, -1), w_ih, b)                                   # [T*N, 8H]
         gx = gx.view(T, N, 2, 4 * H).transpose(1, 2).contiguous()                     # [T, 2, N, 4H]
         wt = torch.stack([la.weight_hh_l0.t(), lc.weight_hh_l0.t()], 0)               # [2, H, 4H]
         h = torch.stack([ha[0], hc[0]], 0).to(gx.dtype)                               # [2, N, H]
         c = torch.stack([ca[0], cc[0]], 0).to(gx.dtype)
         keep = None if starts is None else (1.0 - starts.to(gx.dtype)).view(T, 1, N, 1)
         fused = x.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
+        wt = wt.to(gx.dtype)
         outs = []
         for t in range(T):
             if keep is not None:
                 h, c = h * keep[t], c * keep[t]
-            gh = torch.bmm(h, wt.to(h.dtype)).to(gx.dtype)                            # [2, N, 4H]
+            gh = torch.bmm(h, wt).to(gx.dtype)                                        # [2, N, 4H]
             if fused:
                 h2, c2, _ = torch.ops.aten._thnn_fused_lstm_cell(gx[t].reshape(2 * N, 4 * H), gh.reshape(2 * N, 4 * H),
                                                                  c.reshape(2 * N, H), None, None)
@@ -157,10 +198,10 @@ class ActorCriticPolicy(nn.Module):
                 state = (hp, cp, hv, cv)
         else:
             lp = lv = obs
-        return self.mlp_extractor.policy_net(lp), self.mlp_extractor.value_net(lv), state
+        return _apply_net(self.mlp_extractor.policy_net, lp), _apply_net(self.mlp_extractor.value_net, lv), state
 
     def _dist(self, latent_pi):
-        mean = self.action_net(latent_pi).float()
+        mean = _apply_net(self.action_net, latent_pi).float()
         return mean, self.log_std.float()
 
     @staticmethod
@@ -181,24 +222,24 @@ class ActorCriticPolicy(nn.Module):
             lp, lv = lp[0], lv[0]
         mean, log_std = self._dist(lp)
         actions = mean if deterministic else mean + torch.exp(log_std) * torch.randn_like(mean)
-        values = self.value_net(lv).float().squeeze(-1)
+        values = _apply_net(self.value_net, lv).float().squeeze(-1)
         return actions, values, self.log_prob(actions, mean, log_std), state
 
     @torch.no_grad()
     def predict_values(self, obs, state=None, episode_starts=None):
-        x = obs.unsqueeze(0) if self.recurrent else obs
-        st = episode_starts.unsqueeze(0) if (self.recurrent and episode_starts is not None) else None
-        _, lv, _ = self._latents(x, state, st)
+        """Critic only (the actor LSTM / trunk are not evaluated)."""
+        lv = obs
         if self.recurrent:
-            lv = lv[0]
-        return self.value_net(lv).float().squeeze(-1)
+            st = episode_starts.unsqueeze(0) if episode_starts is not None else None
+            lv = self._lstm_seq(self.lstm_critic, obs.unsqueeze(0), state[2], state[3], st)[0][0]
+        return _apply_net(self.value_net, _apply_net(self.mlp_extractor.value_net, lv)).float().squeeze(-1)
 
     # ---- training: evaluate stored actions
     def evaluate_actions(self, obs, actions, state=None, episode_starts=None):
         """MLP: obs [B,F], actions [B,A].  Recurrent: obs [T,N,F], actions [T,N,A], state at t=0."""
         lp, lv, _ = self._latents(obs, state, episode_starts)
         mean, log_std = self._dist(lp)
-        values = self.value_net(lv).float().squeeze(-1)
+        values = _apply_net(self.value_net, lv).float().squeeze(-1)
         return values, self.log_prob(actions, mean, log_std), self.entropy()
 
     def predict(self, observation, state=None, episode_start=None, deterministic=False):

@@ -126,13 +126,17 @@ class PPO:
 
     # ---------------------------------------------------------------- rollout (hipGraph path)
     def _graphed_rollout(self) -> bool:
-        return (self.cfg.use_graphs and self.device.type == "cuda" and not self.policy.recurrent
-                and hasattr(self.env, "step_tensor"))
+        return self.cfg.use_graphs and self.device.type == "cuda" and hasattr(self.env, "step_tensor")
 
     @torch.no_grad()
     def _rollout_policy_part(self):
         with self._autocast():
-            actions, values, logp, _ = self.policy.act(self._obs_s, None, None)
+            if self.policy.recurrent:
+                actions, values, logp, new_state = self.policy.act(self._obs_s, self._state_s, self._starts_s)
+                for dst, src in zip(self._state_new, new_state):
+                    dst.copy_(src)
+            else:
+                actions, values, logp, _ = self.policy.act(self._obs_s, None, None)
         self._act_s.copy_(actions); self._val_s.copy_(values); self._logp_s.copy_(logp)
         self._clip_s.copy_(torch.clamp(actions, -1.0, 1.0))
 
@@ -142,7 +146,10 @@ class PPO:
         outs = self._vec.process_step(*raw) if self._vec is not None else raw
         nobs, rew, done, trunc, term, comps, ep = outs
         with self._autocast():   # timeout bootstrap r += gamma V(terminal_obs) where truncated (mask, no host sync)
-            tv = self.policy.predict_values(term)
+            if self.policy.recurrent:    # sb3-contrib: critic state after this step, episode_start False [3P-RECALL]
+                tv = self.policy.predict_values(term, self._state_new, None)
+            else:
+                tv = self.policy.predict_values(term)
         rew = rew + cfg.gamma * tv * trunc.to(rew.dtype)
         idx = self._t_idx
         self.obs_buf.index_copy_(0, idx, self._obs_s.unsqueeze(0))
@@ -153,6 +160,9 @@ class PPO:
         self.start_buf.index_copy_(0, idx, self._starts_s.unsqueeze(0))
         self._obs_s.copy_(nobs)
         self._starts_s.copy_(done.to(torch.float32))
+        if self.policy.recurrent:
+            for dst, src in zip(self._state_s, self._state_new):
+                dst.copy_(src)
         self._t_idx.add_(1).remainder_(cfg.n_steps)
 
     # -- native rollout step: HIP kernels for policy input, sampling, VecNormalize and buffer writes
@@ -240,6 +250,9 @@ class PPO:
         self._act_s, self._clip_s = torch.zeros((N, A), device=d), torch.zeros((N, A), device=d)
         self._val_s, self._logp_s = torch.zeros(N, device=d), torch.zeros(N, device=d)
         self._t_idx = torch.zeros(1, dtype=torch.long, device=d)
+        if self.policy.recurrent:               # static LSTM state (before / after the current step)
+            self._state_s = tuple(x.clone() for x in self._state)
+            self._state_new = tuple(torch.zeros_like(x) for x in self._state)
         side = torch.cuda.Stream(device=d)
         side.wait_stream(torch.cuda.current_stream(d))
         with torch.cuda.stream(side):           # eager warm-up (also binds the env's constants)
@@ -276,7 +289,11 @@ class PPO:
                 T, N = self.trunc_buf.shape
                 tv = self.policy.predict_values(self.term_buf.view(T * N, -1)).view(T, N)
                 self.rew_buf.add_(self.cfg.gamma * tv * self.trunc_buf)
-            self._last_values = self.policy.predict_values(self._obs_s)
+            if self.policy.recurrent:
+                self._last_values = self.policy.predict_values(self._obs_s, self._state_s, self._starts_s)
+                self._state = self._state_s
+            else:
+                self._last_values = self.policy.predict_values(self._obs_s)
         self._last_obs, self._last_starts = self._obs_s, self._starts_s
 
     # ---------------------------------------------------------------- rollout
@@ -286,7 +303,11 @@ class PPO:
         if self._graphed_rollout():
             if self._fused is not None:
                 self._fused.refresh_shadow()        # rollout inference runs on the bf16 shadow weights
-            for _ in range(cfg.n_steps):
+            for t in range(cfg.n_steps):
+                if t == 0 and pol.recurrent:
+                    if not getattr(self, "_rollout_ready", False):
+                        self._init_rollout_graphs()
+                    self._rollout_state0 = tuple(s.clone() for s in self._state_s)
                 self.rollout_step()
             self.finish_rollout()
             self.num_timesteps += cfg.n_steps * env.num_envs * self.world
@@ -302,9 +323,9 @@ class PPO:
             clipped = torch.clamp(actions, -1.0, 1.0)
             nobs, rew, done, trunc, term, comps, ep = env.step_tensor(clipped)
             rew = rew.clone()
-            if bool(trunc.any()):   # timeout bootstrap with the terminal observation and pre-step state
+            if bool(trunc.any()):   # timeout bootstrap: terminal observation, critic state after this step, no episode start
                 with self._autocast():
-                    tv = pol.predict_values(term, self._state, starts)
+                    tv = pol.predict_values(term, new_state, None)
                 rew = rew + cfg.gamma * tv * trunc.to(rew.dtype)
             self.obs_buf[t], self.act_buf[t], self.rew_buf[t] = obs, actions, rew
             self.val_buf[t], self.logp_buf[t], self.start_buf[t] = values, logp, starts

@@ -35,6 +35,15 @@ class RunningMeanStd:
 
     def update(self, x: torch.Tensor) -> None:
         x = x.to(torch.float64)
+        if x.is_cuda and x.dim() == 2:
+            # column moments as [1,N] x [N,O] products: ATen's multi-block column reduction is not replay-safe
+            # inside a hipGraph on this stack (see rl/policy.py:_LinearGemmBias); GEMMs are
+            n = x.shape[0]
+            ones = torch.ones((1, n), dtype=torch.float64, device=x.device)
+            mean = (ones @ x)[0] / n
+            d = x - mean
+            self.update_from_moments(mean, (ones @ (d * d))[0] / n, n)
+            return
         self.update_from_moments(x.mean(0), x.var(0, unbiased=False), x.shape[0])
 
     def update_from_moments(self, batch_mean, batch_var, batch_count) -> None:

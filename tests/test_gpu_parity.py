@@ -522,3 +522,50 @@ def test_native_rollout_bookkeeping(hip_lib):
     assert float((lp.view(T, N) - algo.logp_buf).abs().mean()) < 0.02
     algo2, before2 = run()
     assert torch.equal(algo.act_buf, algo2.act_buf) and torch.equal(algo.rew_buf, algo2.rew_buf)
+
+
+def test_captured_column_sums_survive_replays(hip_lib):
+    """Column sums inside captured graphs (VecNormalize batch moments, bias gradients of the recurrent update)
+    are ones-row GEMMs: ATen's multi-block column reduction returns wrong sums on every replay after the first
+    once the graph's private pool has been reused (tools/dev/gpu_reduce_graph.py).  Replays must stay exact."""
+    import torch
+    from myochallenge_amd.rl.policy import _linear
+    from myochallenge_amd.rl.vec_normalize import RunningMeanStd
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    R, Cc, F = 16384, 2048, 96
+    x = torch.randn(R, F, device=dev).bfloat16()
+    w = (torch.randn(Cc, F, device=dev) * 0.1).requires_grad_()
+    b = torch.zeros(Cc, device=dev, requires_grad=True)
+    gy = torch.randn(R, Cc, device=dev).bfloat16()
+    gb_out, gw_out = torch.zeros(Cc, device=dev), torch.zeros(Cc, F, device=dev)
+    obs = torch.randn(4096, 103, device=dev) * 3 + 1
+    rms = RunningMeanStd((103,), dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = _linear(x, w, b)
+        torch.autograd.grad(y, [w, b], gy)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = _linear(x, w, b)
+        gw, gb = torch.autograd.grad(y, [w, b], gy)
+        gb_out.copy_(gb); gw_out.copy_(gw)
+        rms.update(obs)
+        junk = torch.full((1 << 20,), 7, dtype=torch.int32, device=dev)       # reuse of the pool's freed blocks
+        junk2 = junk + 1
+    ref_gb = gy.float().sum(0)
+    ref_gw = gy.float().t() @ x.float()
+    n0 = 1e-4
+    for k in range(1, 4):
+        g.replay()
+        torch.cuda.synchronize()
+        assert float((gb_out - ref_gb).abs().max()) < 0.02 * float(ref_gb.abs().max()), k
+        assert float((gw_out - ref_gw).abs().max()) < 0.02 * float(ref_gw.abs().max()), k
+        # k identical batches merged into the running statistics: mean -> batch mean, count = eps + k * 4096
+        assert abs(float(rms.count) - (n0 + k * 4096)) < 1e-6
+        assert float((rms.mean - obs.double().mean(0)).abs().max()) < 1e-6

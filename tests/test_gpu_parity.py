@@ -547,6 +547,7 @@ def test_captured_column_sums_survive_replays(hip_lib):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y = _linear(x, w, b)
         torch.autograd.grad(y, [w, b], gy)
+        RunningMeanStd((103,), dev).update(obs)          # library handles are created outside the capture
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -569,3 +570,41 @@ def test_captured_column_sums_survive_replays(hip_lib):
         # k identical batches merged into the running statistics: mean -> batch mean, count = eps + k * 4096
         assert abs(float(rms.count) - (n0 + k * 4096)) < 1e-6
         assert float((rms.mean - obs.double().mean(0)).abs().max()) < 1e-6
+
+
+def test_graph_replay_equals_eager_minibatch_step(hip_lib):
+    """Headline path: a REPLAY of the captured minibatch step (gather, stacked-trunk GEMMs, loss kernel, backward,
+    clip + Adam) leaves exactly what the same sequence leaves when it is launched eagerly — gradients and
+    parameters — on fresh minibatches of later rollouts (i.e. after the graphs' pools have been reused many
+    times).  Guards the captured regions against replay-unsafe operations."""
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    torch.manual_seed(0)
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=1024, seed=5)
+    pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
+    algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=16, batch_size=4096, n_epochs=2), seed=0)
+    algo.collect_rollouts(); algo.train()                 # captures the graphs
+    fa, g = algo._flat_adam, None
+    for it in range(3):
+        algo.collect_rollouts()
+        algo.train()
+        g = algo._gs
+        B = g["obs"].shape[0]
+        idx = torch.randperm(B, device="cuda")[:g["idx"].numel()]
+        g["idx"].copy_(idx)
+        snap = fa.snapshot()
+        algo._graph_fb.replay()
+        torch.cuda.synchronize()
+        g1, p1, pl1 = algo._flat_grad.clone(), fa.flat["p"].clone(), float(g["pl"])
+        fa.restore(snap)
+        algo._mb_forward_backward(); algo._mb_apply()
+        torch.cuda.synchronize()
+        g2, p2, pl2 = algo._flat_grad.clone(), fa.flat["p"].clone(), float(g["pl"])
+        fa.restore(snap)
+        assert torch.isfinite(g1).all() and torch.isfinite(p1).all()
+        assert float((g1 - g2).abs().max()) <= 1e-6 * (1 + float(g2.abs().max())), it
+        assert float((p1 - p2).abs().max()) <= 1e-7, it
+        assert pl1 == pytest.approx(pl2, rel=1e-5, abs=1e-7)

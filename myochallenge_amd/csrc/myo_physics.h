@@ -501,8 +501,8 @@ template <typename T> DEV T wrap_circle(T* pnt, const T* dd, const T* sd, int ha
     }
     if (seg_intersect(dd, sol[i], dd + 2, sol[i] + 2)) good[i] = -10000;
   }
-  const int i = (good[0] > good[1]) ? 0 : 1;
-  for (int k = 0; k < 4; ++k) pnt[k] = sol[i][k];
+  const bool first = good[0] > good[1];          // selects, not sol[i]: a run-time index would move sol to private memory
+  for (int k = 0; k < 4; ++k) pnt[k] = first ? sol[0][k] : sol[1][k];
   if (seg_intersect(dd, pnt, dd + 2, pnt + 2)) return -1;
   const T c = tclamp((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqrad, (T)-1, (T)1);
   return rad * acos(c);
@@ -526,10 +526,10 @@ DEV T wrap_geom(T* wpnt, const T* x0, const T* x1, const T* gpos, const T* gmat,
     const T nrm = norm3(normal);
     if (nrm < MYO_MINVAL) {
       int imin = 0;
-      if (fabs(axis0[1]) < fabs(axis0[imin])) imin = 1;
-      if (fabs(axis0[2]) < fabs(axis0[imin])) imin = 2;
-      T e[3] = {0, 0, 0};
-      e[imin] = 1;
+      T amin = fabs(axis0[0]);
+      if (fabs(axis0[1]) < amin) { imin = 1; amin = fabs(axis0[1]); }
+      if (fabs(axis0[2]) < amin) imin = 2;
+      const T e[3] = {imin == 0 ? (T)1 : (T)0, imin == 1 ? (T)1 : (T)0, imin == 2 ? (T)1 : (T)0};
       cross3(normal, axis0, e);
       normalize3(normal);
     } else { normal[0] /= nrm; normal[1] /= nrm; normal[2] /= nrm; }
@@ -670,39 +670,34 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
         const int is_geom = (w1.type == 4 || w1.type == 5);
         const WrapRec<T>& we = is_geom ? w2 : w1;      // the site that ends this path element
         const int wend = adr + j + (is_geom ? 2 : 1);
-        T wpnt[12];
-        int wcnt;
-        T wlen = -1;
-        for (int e = 0; e < 3; ++e) wpnt[e] = wp[3 * (adr + j) + e];
+        // straight segments of this path element: site -> site, or site -> wrap point, (arc), wrap point -> site.
+        // Selected with scalars (no run-time indexed local arrays: they would live in private memory).
+        const T p0[3] = {wp[3 * (adr + j)], wp[3 * (adr + j) + 1], wp[3 * (adr + j) + 2]};
         const T x1[3] = {wp[3 * wend], wp[3 * wend + 1], wp[3 * wend + 2]};
+        T wlen = -1, g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0};
         if (is_geom) {
           const T* r = wres + 7 * M.wr_i[8 * (adr + j + 1) + 6];
           wlen = r[0];
-          for (int e = 0; e < 6; ++e) wpnt[3 + e] = r[1 + e];
+          for (int e = 0; e < 3; ++e) { g0[e] = r[1 + e]; g1[e] = r[4 + e]; }
         }
-        unsigned long long wm[4];
-        int wr[4], wb[4];
-        wm[0] = w0.mask; wr[0] = w0.root; wb[0] = w0.body;
-        if (wlen < 0) {
-          wm[1] = we.mask; wr[1] = we.root; wb[1] = we.body;
-          wpnt[3] = x1[0]; wpnt[4] = x1[1]; wpnt[5] = x1[2];
-          wcnt = 2;
-        } else {
-          wm[1] = wm[2] = w1.mask; wr[1] = wr[2] = w1.root; wb[1] = wb[2] = w1.body;
-          wm[3] = we.mask; wr[3] = we.root; wb[3] = we.body;
-          wpnt[9] = x1[0]; wpnt[10] = x1[1]; wpnt[11] = x1[2];
-          wcnt = 4;
-        }
+        const bool wrapped = wlen >= 0;
         const T inv_div = 1 / divisor;
-        for (int k = 0; k < wcnt - 1; ++k) {
-          if (wcnt == 4 && k == 1) { len += wlen * inv_div; continue; }
-          T dif[3] = {wpnt[3 * k + 3] - wpnt[3 * k], wpnt[3 * k + 4] - wpnt[3 * k + 1], wpnt[3 * k + 5] - wpnt[3 * k + 2]};
+        for (int sg = 0; sg < 2; ++sg) {
+          if (sg == 1 && !wrapped) break;
+          const bool to_wrap = (sg == 0) && wrapped;          // this segment ends on the wrap geom
+          T pa[3], pb[3];
+          for (int e = 0; e < 3; ++e) { pa[e] = sg == 0 ? p0[e] : g1[e]; pb[e] = to_wrap ? g0[e] : x1[e]; }
+          const unsigned long long ma = sg == 0 ? w0.mask : w1.mask, mb = to_wrap ? w1.mask : we.mask;
+          const int ra = sg == 0 ? w0.root : w1.root, rb = to_wrap ? w1.root : we.root;
+          const int ba = sg == 0 ? w0.body : w1.body, bb = to_wrap ? w1.body : we.body;
+          T dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
           const T dn = norm3(dif);
           len += dn * inv_div;
-          if (wb[k] != wb[k + 1] && dn > MYO_MINVAL) {
+          if (ba != bb && dn > MYO_MINVAL) {
             dif[0] /= dn; dif[1] /= dn; dif[2] /= dn;
-            tendon_segment_moment(s, J, tmask, wm[k], wr[k], wpnt + 3 * k, wm[k + 1], wr[k + 1], wpnt + 3 * k + 3, dif, inv_div);
+            tendon_segment_moment(s, J, tmask, ma, ra, pa, mb, rb, pb, dif, inv_div);
           }
+          if (to_wrap) len += wlen * inv_div;
         }
         if (is_geom) { j += 2; w0 = w2; } else { j += 1; w0 = w1; }
       }
@@ -1063,17 +1058,23 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& 
     for (int k = 0; k < 3; ++k) { o.nrm[k] = n[k]; o.pos[k] = p2[k] - n[k] * (s2[0] + (T)0.5 * dd); }
     o.n = 1;
   } else if (t1 == 0 && t2 == 3) {
+    // both capsule ends against the plane; results are placed with compile-time slot indices (a run-time
+    // slot index would put the whole ContactTmp into private memory)
     const T n[3] = {R1[2], R1[5], R1[8]}, ax[3] = {R2[2], R2[5], R2[8]};
-    for (int e = 0; e < 2; ++e) {
-      const T sg = e ? (T)-1 : (T)1;
-      T c[3];
-      for (int k = 0; k < 3; ++k) c[k] = p2[k] + sg * s2[1] * ax[k];
-      const T dd = (c[0] - p1[0]) * n[0] + (c[1] - p1[1]) * n[1] + (c[2] - p1[2]) * n[2] - s2[0];
-      if (dd > margin) continue;
-      o.dist[o.n] = dd;
-      for (int k = 0; k < 3; ++k) { o.nrm[3 * o.n + k] = n[k]; o.pos[3 * o.n + k] = c[k] - n[k] * (s2[0] + (T)0.5 * dd); }
-      o.n++;
+    T c0[3], c1[3];
+    for (int k = 0; k < 3; ++k) { c0[k] = p2[k] + s2[1] * ax[k]; c1[k] = p2[k] - s2[1] * ax[k]; }
+    const T d0 = (c0[0] - p1[0]) * n[0] + (c0[1] - p1[1]) * n[1] + (c0[2] - p1[2]) * n[2] - s2[0];
+    const T d1 = (c1[0] - p1[0]) * n[0] + (c1[1] - p1[1]) * n[1] + (c1[2] - p1[2]) * n[2] - s2[0];
+    const int v0 = !(d0 > margin), v1 = !(d1 > margin);
+    const T da = v0 ? d0 : d1;
+    o.dist[0] = da;
+    o.dist[1] = d1;
+    for (int k = 0; k < 3; ++k) {
+      o.nrm[k] = n[k]; o.nrm[3 + k] = n[k];
+      o.pos[k] = (v0 ? c0[k] : c1[k]) - n[k] * (s2[0] + (T)0.5 * da);
+      o.pos[3 + k] = c1[k] - n[k] * (s2[0] + (T)0.5 * d1);
     }
+    o.n = v0 + v1;
   } else if (t1 == 2 && t2 == 2) {
     o.n = sphere_sphere(o.dist, o.pos, o.nrm, p1, s1[0], p2, s2[0], margin);
   } else if (t1 == 2 && t2 == 3) {
@@ -1117,8 +1118,8 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& 
       int kb = 0;
       T best = (T)1e30;
       for (int k = 0; k < 3; ++k) { const T e = s2[k] - fabs(c[k]); if (e < best) { best = e; kb = k; } }
-      nl[0] = nl[1] = nl[2] = 0;
-      nl[kb] = c[kb] > 0 ? (T)-1 : (T)1;
+      const T ckb = kb == 0 ? c[0] : (kb == 1 ? c[1] : c[2]);
+      for (int k = 0; k < 3; ++k) nl[k] = (k == kb) ? (ckb > 0 ? (T)-1 : (T)1) : (T)0;
       dd = -best - s1[0];
     }
     mulmatvec3(o.nrm, R2, nl);
@@ -1260,17 +1261,14 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
         }
         if (!skip) {
           collide_pair(M, K, s, g1, g2, margin, LV(ct));
-          // keep only contacts that enter the constraint set (dist < margin - gap)
+          // keep only contacts that enter the constraint set (dist < margin - gap); static slot indices
           const T inc = margin - tmax(M.geom_gap[g1], M.geom_gap[g2]);
-          int keep = 0;
-          for (int k = 0; k < LV(ct).n; ++k)
-            if (LV(ct).dist[k] < inc) {
-              if (keep != k) {
-                LV(ct).dist[keep] = LV(ct).dist[k];
-                for (int e = 0; e < 3; ++e) { LV(ct).pos[3 * keep + e] = LV(ct).pos[3 * k + e]; LV(ct).nrm[3 * keep + e] = LV(ct).nrm[3 * k + e]; }
-              }
-              keep++;
-            }
+          const int k0 = LV(ct).n > 0 && LV(ct).dist[0] < inc, k1 = LV(ct).n > 1 && LV(ct).dist[1] < inc;
+          if (!k0 && k1) {
+            LV(ct).dist[0] = LV(ct).dist[1];
+            for (int e = 0; e < 3; ++e) { LV(ct).pos[e] = LV(ct).pos[3 + e]; LV(ct).nrm[e] = LV(ct).nrm[3 + e]; }
+          }
+          const int keep = k0 + k1;
           LV(ct).n = keep;
         }
       }
@@ -1278,9 +1276,10 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     WAVE_EXSCAN(LV(ct).n, S_NPRE(s), total);
     PHASE {
       const int p = base + lane;
-      for (int k = 0; k < LV(ct).n; ++k) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
         const int ci = ncon + S_NPRE(s)[lane] + k;
-        if (ci >= MYO_NCON_MAX) break;
+        if (k >= LV(ct).n || ci >= MYO_NCON_MAX) break;
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
         ContactRec<T>& c = s.con[ci];
         for (int e = 0; e < 3; ++e) { c.pos[e] = LV(ct).pos[3 * k + e]; c.frame[e] = LV(ct).nrm[3 * k + e]; }

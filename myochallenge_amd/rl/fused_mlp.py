@@ -169,7 +169,7 @@ class FusedPPOStep:
     """GPU path: persistent bf16 weight copies + the HIP loss kernel.  All shapes static so the
     sequence can be captured in a hipGraph."""
 
-    def __init__(self, policy, lib, clip_range, ent_coef, vf_coef, split_k=32):
+    def __init__(self, policy, lib, clip_range, ent_coef, vf_coef, split_k=64):
         assert not policy.recurrent
         self.policy, self.lib = policy, lib
         self.clip, self.ent, self.vf, self.split = float(clip_range), float(ent_coef), float(vf_coef), split_k

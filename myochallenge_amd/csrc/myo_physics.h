@@ -1530,7 +1530,7 @@ template <typename T>
 DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
-  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)));
+  // (the caller has run body_vectors(qvel -> S_CVEL): called from kernel level so that this function stays a leaf)
   PHASE {
     const int t = lane;
     if (t < M.ntendon) {
@@ -1620,7 +1620,15 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
     }
   }
   SYNC();
-  // reference acceleration of every constraint row: aref = -B vel - K imp (pos - margin)
+  (void)K;
+}
+
+// reference acceleration of every constraint row: aref = -B vel - K imp (pos - margin).  Inlined at kernel
+// level (needs S_CVEL from body_vectors(qvel)), so that fwd_velocity and J_times are both leaf functions.
+template <typename T>
+DEV void efc_reference(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  WAVE_FN
   if (s.nefc > 0) {
     J_times(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
     PHASE {
@@ -1633,7 +1641,6 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
     }
     SYNC();
   }
-  (void)K;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1736,7 +1743,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
 // ------------------------------------------------------------------------------------------
 // P10: Newton solver on the primal problem (mj_solNewton)
 template <typename T>
-DEVFN T update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {
+DEV T update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {   // inlined into the solver loop (kernel level): JT_times stays a leaf call
   MYO_BIND_M(T) MYO_BIND_S(T)
   // forces / active set from jar, cost, qfrc_constraint, gradient
   WAVE_FN
@@ -1766,7 +1773,7 @@ template <typename T>
 DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
-  load_H_from_M(M, s, (const T*)0, (T)0);
+  // (the caller has loaded M into H: load_H_from_M is called from kernel level so that this function stays a leaf)
   const int nl = s.nl, nlim = s.nl + s.ntl;
   // joint-limit rows touch one diagonal entry each (lanes = dofs scan the rows)
   PHASE {
@@ -1864,7 +1871,7 @@ DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
 }
 
 template <typename T>
-DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
+DEV void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   const int nv = M.nv, nefc = s.nefc;
@@ -1895,6 +1902,7 @@ DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
   int iter = 0;
   while (iter < M.iterations) {
     PROF(s, 11)
+    load_H_from_M(M, s, (const T*)0, (T)0);
     build_hessian(M, s);
     PROF(s, 9)
     PHASE { const int c = lane; if (c < nv) s.search[c] = -s.grad[c]; }
@@ -1977,7 +1985,7 @@ DEVFN void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
 }
 
 template <typename T>
-DEVFN void fwd_acceleration(const DevModel<T>& M_in, Scratch<T>& s_in) {
+DEV void fwd_acceleration(const DevModel<T>& M_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   load_H_from_M(M, s, (const T*)0, (T)0);
@@ -1998,7 +2006,7 @@ DEVFN void fwd_acceleration(const DevModel<T>& M_in, Scratch<T>& s_in) {
 }
 
 template <typename T>
-DEVFN void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   PROF(s, 15)
   kinematics(M, s);
@@ -2011,7 +2019,9 @@ DEVFN void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_i
   PROF(s, 4)
   collision_and_constraints(M, K, s);
   PROF(s, 5)
+  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
+  efc_reference(M, s);
   PROF(s, 6)
   fwd_actuation(M, s);
   PROF(s, 7)
@@ -2075,12 +2085,15 @@ DEVFN void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc)
   // mj_checkPos / mj_checkVel / mj_checkAcc: any non-finite or huge entry marks the env bad.  No reduction:
   // every lane tests its own entries and stores the flag itself (all writers store 1; the flag is read
   // after later barriers, at the end of the env step).
+  static_assert(MYO_NQ_MAX <= 64 && MYO_NV_MAX <= 64, "one entry per lane");
   PHASE {
+    const int i = lane;
     int bad = 0;
-    for (int i = lane; i < M.nq; i += 64) bad |= !(isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (T)1e10);
-    for (int i = lane; i < M.nv; i += 64) bad |= !(isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (T)1e10);
-    if (check_acc)
-      for (int i = lane; i < M.nv; i += 64) bad |= !(isfinite(s.qacc[i]) && fabs(s.qacc[i]) < (T)1e10);
+    if (i < M.nq) bad |= !(isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (T)1e10);
+    if (i < M.nv) {
+      bad |= !(isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (T)1e10);
+      if (check_acc) bad |= !(isfinite(s.qacc[i]) && fabs(s.qacc[i]) < (T)1e10);
+    }
     if (bad) s.bad = 1;
   }
 }

@@ -112,7 +112,7 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
 
 // ---- env.step(a) without the VecEnv bookkeeping
 template <typename T>
-DEVFN void baoding_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, const float* action /* may be null = zeros */) {
+DEV void baoding_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, const float* action /* may be null = zeros */) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -461,7 +461,9 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   tendon(M, K, s);
   crb(M, s);
   collision_and_constraints(M, K, s);
+  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
+  efc_reference(M, s);
   fwd_actuation(M, s);
   PHASE {
     for (int i = lane; i < nv; i += 64) {

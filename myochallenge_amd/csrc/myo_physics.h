@@ -753,7 +753,7 @@ DEVFN void crb(const DevModel<T>& M_in, Scratch<T>& s_in) {
 
 // out = M * v   (lanes = dofs; static CSR pattern of the symmetric tree-sparse matrix)
 template <typename T>
-DEVFN void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r, LCREF(T) v_r) {
+DEV void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r, LCREF(T) v_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   T* out = LPTR(T, out_r); const T* v = LPTR(const T, v_r);
   WAVE_FN
@@ -783,7 +783,7 @@ DEVFN void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r,
 
 // packed dense H <- M (+ diag)
 template <typename T>
-DEVFN void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* diag_add, T diag_scale) {
+DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* diag_add, T diag_scale) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -1335,7 +1335,7 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
 // matrix-free constraint Jacobian products
 // body spatial vectors V_b(v) = sum_{d in ancestors(b)} cdof_d v_d   (lanes = bodies)
 template <typename T>
-DEVFN void body_vectors(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LREF(T) out_r) {
+DEV void body_vectors(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* v = LPTR(const T, v_r); T* out = LPTR(T, out_r);
   WAVE_FN
@@ -1372,7 +1372,7 @@ template <typename T> DEV void con_col(const Scratch<T>& s, int d, const T* off,
 
 // out[r] = (J v)[r] for every constraint row; bv = body vectors of v (already computed)
 template <typename T>
-DEVFN void J_times(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
+DEV void J_times(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* v = LPTR(const T, v_r); const T* bv = LPTR(const T, bv_r); T* out = LPTR(T, out_r);
   WAVE_FN
@@ -1474,7 +1474,7 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) va
 
 // out = J' f  (lanes = dofs; contacts act as a world force at the contact point)
 template <typename T>
-DEVFN void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LREF(T) out_r) {
+DEV void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* f = LPTR(const T, f_r); T* out = LPTR(T, out_r);
   WAVE_FN
@@ -1770,7 +1770,7 @@ DEV T update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {   // inline
 }
 
 template <typename T>
-DEVFN void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
+DEV void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   // (the caller has loaded M into H: load_H_from_M is called from kernel level so that this function stays a leaf)
@@ -2031,7 +2031,7 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
 // ------------------------------------------------------------------------------------------
 // P11: integrators
 template <typename T>
-DEVFN void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel_r, T h) {
+DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel_r, T h) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* vel = LPTR(const T, vel_r);
   WAVE_FN
@@ -2059,7 +2059,7 @@ DEVFN void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel
 }
 
 template <typename T>
-DEVFN void advance(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) act_dot_r, LCREF(T) qacc_r, LCREF(T) vel_r) {
+DEV void advance(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) act_dot_r, LCREF(T) qacc_r, LCREF(T) vel_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* act_dot = LPTR(const T, act_dot_r); const T* qacc = LPTR(const T, qacc_r);
   WAVE_FN
@@ -2079,7 +2079,7 @@ DEVFN void advance(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) act_dot_r
 }
 
 template <typename T>
-DEVFN void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc) {
+DEV void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   // mj_checkPos / mj_checkVel / mj_checkAcc: any non-finite or huge entry marks the env bad.  No reduction:

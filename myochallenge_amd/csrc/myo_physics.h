@@ -866,8 +866,8 @@ DEV void chol_solve(Scratch<T>& s, T* x, int n) {
 
 #ifndef MYO_EMU
 // ---- register-resident Cholesky (gfx950 build).  Lane i keeps row i of the lower triangle in
-// VGPRs (packed pairs, v_pk_fma trailing update); column k reaches the other lanes through a
-// 64-entry LDS buffer, software-pipelined (see the factor loop); the substitutions broadcast
+// VGPRs (packed pairs, v_pk_fma trailing update); columns reach the other lanes two at a time through
+// 64-entry LDS buffers, software-pipelined (see the factor loop); the substitutions broadcast
 // with v_readlane.  Padded to MYO_NV_MAX with identity rows.  The arithmetic per element is the
 // same k-ordered FMA sequence as the LDS version above, which the MYO_EMU build keeps.
 template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
@@ -906,47 +906,119 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
     for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
   }
   T b = (lane < n) ? x[lane] : (T)0;
-  // Column exchange through LDS, software-pipelined: while the trailing update of step k is still
-  // running, column k+1 (updated first) is already written and read back for step k+1.  Two buffers
-  // alternate; a workgroup is one wavefront, so its LDS operations execute in program order and no
-  // barrier is needed between the write and the reads.
-  T* colbuf0 = s.efc_jv;                             // >= 128 entries, free while a system is solved
-  T* colbuf1 = s.efc_jv + 64;
   T invd = 1;                                        // 1 / L[lane][lane]
-  V2 c2[N / 2], c2n[N / 2];
-  colbuf0[lane] = a2[0].x;
-  {
-    const V2* cb = reinterpret_cast<const V2*>(colbuf0);
-#pragma unroll
-    for (int p = 0; p < N / 2; ++p) c2[p] = cb[p];
-  }
-#pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const T ak = (k & 1) ? a2[k / 2].y : a2[k / 2].x;
-    T akk = (k & 1) ? c2[k / 2].y : c2[k / 2].x;
-    akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
-    const T inv = myo_rsqrt(akk);
-    const T lik = ak * inv;                           // lane k: akk / sqrt(akk) = sqrt(akk)
-    const V2 m = V2{-lik * inv, -lik * inv};
-    const int p1 = (k + 1) / 2;
-    if (k + 1 < N) {
-      a2[p1] = __builtin_elementwise_fma(m, c2[p1], a2[p1]);      // the pair holding column k+1 goes first
-      T* nb = ((k + 1) & 1) ? colbuf1 : colbuf0;
-      nb[lane] = ((k + 1) & 1) ? a2[p1].y : a2[p1].x;
-      const V2* cb = reinterpret_cast<const V2*>(nb);
-#pragma unroll
-      for (int p = p1; p < N / 2; ++p) c2n[p] = cb[p];
-    }
-#pragma unroll
-    for (int p = p1 + 1; p < N / 2; ++p) a2[p] = __builtin_elementwise_fma(m, c2[p], a2[p]);
-    if (k & 1) a2[k / 2].y = lik; else a2[k / 2].x = lik;
+  if constexpr (sizeof(T) == 4) {
+    // fp32: one column per step.  (The two-column scheme below is 14 % faster end to end in fp64, where the
+    // factorisation is a quarter of the kernel, but measured 2.6 % SLOWER in fp32: its serial 2x2 pivot chain
+    // outweighs the saved round trips once the per-column exchange is already pipelined.)
+    // Column exchange through LDS, software-pipelined: while the trailing update of step k is still
+    // running, column k+1 (updated first) is already written and read back for step k+1.  Two buffers
+    // alternate; a workgroup is one wavefront, so its LDS operations execute in program order and no
+    // barrier is needed between the write and the reads.
+    T* colbuf0 = s.efc_jv;                             // >= 128 entries, free while a system is solved
+    T* colbuf1 = s.efc_jv + 64;
+    V2 c2[N / 2], c2n[N / 2];
+    colbuf0[lane] = a2[0].x;
     {
-      MYO_OPAQUE_LANE(l)
-      if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
-    }
-    if (k + 1 < N) {
+      const V2* cb = reinterpret_cast<const V2*>(colbuf0);
 #pragma unroll
-      for (int p = p1; p < N / 2; ++p) c2[p] = c2n[p];
+      for (int p = 0; p < N / 2; ++p) c2[p] = cb[p];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const T ak = (k & 1) ? a2[k / 2].y : a2[k / 2].x;
+      T akk = (k & 1) ? c2[k / 2].y : c2[k / 2].x;
+      akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
+      const T inv = myo_rsqrt(akk);
+      const T lik = ak * inv;                           // lane k: akk / sqrt(akk) = sqrt(akk)
+      const V2 m = V2{-lik * inv, -lik * inv};
+      const int p1 = (k + 1) / 2;
+      if (k + 1 < N) {
+        a2[p1] = __builtin_elementwise_fma(m, c2[p1], a2[p1]);      // the pair holding column k+1 goes first
+        T* nb = ((k + 1) & 1) ? colbuf1 : colbuf0;
+        nb[lane] = ((k + 1) & 1) ? a2[p1].y : a2[p1].x;
+        const V2* cb = reinterpret_cast<const V2*>(nb);
+#pragma unroll
+        for (int p = p1; p < N / 2; ++p) c2n[p] = cb[p];
+      }
+#pragma unroll
+      for (int p = p1 + 1; p < N / 2; ++p) a2[p] = __builtin_elementwise_fma(m, c2[p], a2[p]);
+      if (k & 1) a2[k / 2].y = lik; else a2[k / 2].x = lik;
+      {
+        MYO_OPAQUE_LANE(l)
+        if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
+      }
+      if (k + 1 < N) {
+#pragma unroll
+        for (int p = p1; p < N / 2; ++p) c2[p] = c2n[p];
+      }
+    }
+  } else {
+    // Two columns per step (one LDS round trip per column PAIR: the round trip, not the arithmetic, is the
+    // critical path).  What travels is the UNSCALED pair of columns (2q, 2q+1) of the current trailing matrix,
+    // one step early: X[j] = A[j][2q], Y[j] = A[j][2q+1].  Every lane derives the 2x2 pivot block from rows
+    // 2q, 2q+1 of that broadcast (d00 = X[2q], d10 = X[2q+1], d11 = Y[2q+1]), its own two L entries, and the
+    // rank-2 trailing update  A[i][j] -= L[i][2q] L[j][2q] + L[i][2q+1] L[j][2q+1] = alpha_i X[j] + beta_i Y[j]
+    // with  beta_i = L[i][2q+1] / l11,  alpha_i = L[i][2q] / l00 - beta_i d10 / d00.
+    // Software-pipelined in place: the pair holding columns 2q+2, 2q+3 is updated first, written, and read
+    // back into the registers its old broadcast values just left; every later pair is updated and then
+    // refilled the same way, so the reads are in flight during the rest of the trailing update.  Two buffers
+    // alternate; a workgroup is one wavefront, so its LDS operations execute in program order (no barrier).
+    T* const bx0 = s.efc_jv;                           // 2 x 64 entries each, free while a system is solved
+    T* const by0 = s.efc_jv + 64;
+    T* const bx1 = s.bvec;
+    T* const by1 = s.bvec + 64;
+    static_assert(MYO_NEFC_MAX >= 128 && MYO_NB_MAX * 6 >= 128, "column exchange buffers");
+    V2 cx[N / 2], cy[N / 2];
+    bx0[lane] = a2[0].x;
+    by0[lane] = a2[0].y;
+    {
+      const V2* px = reinterpret_cast<const V2*>(bx0);
+      const V2* py = reinterpret_cast<const V2*>(by0);
+#pragma unroll
+      for (int p = 0; p < N / 2; ++p) { cx[p] = px[p]; cy[p] = py[p]; }
+    }
+#pragma unroll
+    for (int q = 0; q < N / 2; ++q) {
+      T d00 = cx[q].x;
+      const T d10 = cx[q].y;
+      d00 = d00 < MYO_MINVAL ? MYO_MINVAL : d00;
+      const T inv0 = myo_rsqrt(d00);
+      const T l10 = d10 * inv0;
+      T t11 = cy[q].y - l10 * l10;
+      t11 = t11 < MYO_MINVAL ? MYO_MINVAL : t11;
+      const T inv1 = myo_rsqrt(t11);
+      const T li0 = a2[q].x * inv0;                    // lane 2q: sqrt(d00); lane 2q+1: l10
+      const T li1 = (a2[q].y - li0 * l10) * inv1;      // lane 2q+1: sqrt(t11)
+      const T beta = li1 * inv1;
+      const T alpha = li0 * inv0 - beta * (l10 * inv0);
+      const V2 ma = V2{-alpha, -alpha}, mb = V2{-beta, -beta};
+      T* const nx = ((q + 1) & 1) ? bx1 : bx0;
+      T* const ny = ((q + 1) & 1) ? by1 : by0;
+      const V2* px = reinterpret_cast<const V2*>(nx);
+      const V2* py = reinterpret_cast<const V2*>(ny);
+      // refill in place, pair by pair (four registers per pair in fp64: no room for a second set)
+      if (q + 1 < N / 2) {
+        a2[q + 1] = __builtin_elementwise_fma(ma, cx[q + 1], a2[q + 1]);
+        a2[q + 1] = __builtin_elementwise_fma(mb, cy[q + 1], a2[q + 1]);
+        nx[lane] = a2[q + 1].x;
+        ny[lane] = a2[q + 1].y;
+        cx[q + 1] = px[q + 1];
+        cy[q + 1] = py[q + 1];
+      }
+#pragma unroll
+      for (int p = q + 2; p < N / 2; ++p) {
+        a2[p] = __builtin_elementwise_fma(ma, cx[p], a2[p]);
+        a2[p] = __builtin_elementwise_fma(mb, cy[p], a2[p]);
+        cx[p] = px[p];
+        cy[p] = py[p];
+      }
+      a2[q] = V2{li0, li1};
+      {
+        MYO_OPAQUE_LANE(l)
+        if (l == 2 * q) invd = inv0;                   // 1 / L[k][k]
+        if (l == 2 * q + 1) invd = inv1;
+      }
     }
   }
   // forward substitution  L y = b   (lane j finishes at step j; later steps must not touch it)

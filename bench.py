@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--n-epochs", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=16384, help="minibatch (default: 1/16 of the default rollout, the reference's ratio: 4096 of 65536)")
     ap.add_argument("--env-name", default="CustomMyoBaodingBallsP1")
+    ap.add_argument("--lstm-hidden", type=int, default=0, help="recurrent policy (not the headline config): LSTM of this width for "
+                    "actor and critic; 128 with --net-arch '' is the architecture of trained_models/phase_1/phase1_final.zip")
+    ap.add_argument("--net-arch", default="256,256", help="MLP widths after the (optional) LSTM")
     ap.add_argument("--no-ppo", action="store_true", help="rollout only (reported as invalid for the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,7 +141,8 @@ def main():
     integ_name = {0: "Euler", 1: "RK4"}[env._model.size("integrator")]
     venv = VecNormalize(env, gamma=0.99)
     torch.manual_seed(0)   # identical initial weights on every rank
-    policy = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=None, log_std_init=-2.0)
+    arch = tuple(int(x) for x in args.net_arch.split(",") if x.strip())
+    policy = ActorCriticPolicy(env.obs_dim, env.act_dim, arch, arch, lstm_hidden_size=args.lstm_hidden or None, log_std_init=-2.0)
     cfg = PPOConfig(n_steps=args.n_steps, batch_size=args.batch_size, n_epochs=args.n_epochs, learning_rate=2.5e-4,
                     clip_range=0.2, ent_coef=2.5e-4, vf_coef=0.5, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, bf16=True)
     algo = PPO(venv, policy, cfg, seed=rank)
@@ -186,6 +190,7 @@ def main():
     total_envs = args.envs * world
     value = total_envs * args.steps / elapsed
 
+    pol_name = (f"LSTM-{args.lstm_hidden} + " if args.lstm_hidden else "") + f"MLP[{args.net_arch}]"
     if rank == 0:
         alg_bytes = ALG_BYTES_F64_STATE * args.envs
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
@@ -207,7 +212,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic (synthetic MyoHand-shaped model, random-init policy)",
             "config": {"workload": f"Baoding phase-1 config ({args.env_name}), {args.envs} batched envs per GPU, "
-                                   f"PPO MLP[256,256] bf16, frame_skip 10, {integ_name} integrator (model option)",
+                                   f"PPO {pol_name} bf16, frame_skip 10, {integ_name} integrator (model option)",
                        "envs_per_gpu": args.envs, "global_envs": total_envs, "integrator": integ_name,
                        "ppo": "rollout-only" if args.no_ppo else
                        f"n_steps={cfg.n_steps}, batch={cfg.batch_size}, epochs={cfg.n_epochs}, update inside timed region",

@@ -79,6 +79,7 @@ class PPO:
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                           capturable=on_gpu, foreach=True if on_gpu else None)
         self._graph = None
+        self._t_host = 0
         self._fused = None
         self._flat_adam = None
         if cfg.use_graphs and on_gpu and not policy.recurrent:
@@ -278,6 +279,10 @@ class PPO:
                 self._init_native_rollout()
             else:
                 self._init_rollout_graphs()
+        if self.policy.recurrent:
+            if self._t_host == 0:      # LSTM state at the start of the rollout: initial state of the update's sequences
+                self._rollout_state0 = tuple(s.clone() for s in self._state_s)
+            self._t_host = (self._t_host + 1) % self.cfg.n_steps
         self._gA.replay()
         self._raw.step_tensor(self._clip_s)
         self._gB.replay()
@@ -303,11 +308,7 @@ class PPO:
         if self._graphed_rollout():
             if self._fused is not None:
                 self._fused.refresh_shadow()        # rollout inference runs on the bf16 shadow weights
-            for t in range(cfg.n_steps):
-                if t == 0 and pol.recurrent:
-                    if not getattr(self, "_rollout_ready", False):
-                        self._init_rollout_graphs()
-                    self._rollout_state0 = tuple(s.clone() for s in self._state_s)
+            for _ in range(cfg.n_steps):
                 self.rollout_step()
             self.finish_rollout()
             self.num_timesteps += cfg.n_steps * env.num_envs * self.world

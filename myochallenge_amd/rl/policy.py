@@ -48,6 +48,78 @@ class _LinearGemmBias(torch.autograd.Function):
         return g @ w, g.t() @ x, (ones @ g).squeeze(0)
 
 
+def _cell_fwd(gx, gh, c):
+    """LSTM pointwise cell on pre-activations gx + gh ([R,4H], gate order i,f,g,o) -> (h, c_new, workspace)."""
+    if gx.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell"):
+        return torch.ops.aten._thnn_fused_lstm_cell(gx, gh, c, None, None)
+    i, f, g, o = (gx + gh).chunk(4, dim=-1)
+    i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+    cn = f * c + i * g
+    return o * torch.tanh(cn), cn, torch.cat([i, f, g, o], -1)
+
+
+def _cell_bwd(dh, dc, c_prev, c_new, ws):
+    """Backward of _cell_fwd: -> (d pre-activations [R,4H], d c_prev)."""
+    if dh.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell_backward_impl"):
+        dg, dcp, _ = torch.ops.aten._thnn_fused_lstm_cell_backward_impl(dh, dc, c_prev, c_new, ws, False)
+        return dg, dcp
+    i, f, g, o = ws.chunk(4, dim=-1)
+    tc = torch.tanh(c_new)
+    dct = dc + dh * o * (1 - tc * tc)
+    dg = torch.cat([dct * g * i * (1 - i), dct * c_prev * f * (1 - f), dct * i * (1 - g * g), dh * tc * o * (1 - o)], -1)
+    return dg, dct * f
+
+
+class _LstmSeq(torch.autograd.Function):
+    """G stacked one-layer LSTMs over a whole sequence with a hand-written backward.
+
+    gx [T,G,N,4H] input projections (+ biases), wt [G,H,4H] = W_hh^T, h0/c0 [G,N,H], keep [T,1,N,1] (0 where an
+    episode starts: state zeroed before that step).  Autograd's own BPTT of the step loop costs ~10 small
+    kernels per step (select / stack backwards, gradient adds, a weight-gradient GEMM and its accumulation per
+    step); here a step of the backward pass is the fused cell backward, one batched GEMM for dh and the mask,
+    and the recurrent weight gradient is ONE batched GEMM over all steps after the loop."""
+
+    @staticmethod
+    def forward(ctx, gx, wt, h0, c0, keep):
+        T, G, N, H4 = gx.shape
+        H = H4 // 4
+        h, c = h0, c0
+        hs, cs, cn, wss, outs = [], [], [], [], []
+        for t in range(T):
+            if keep is not None:
+                h, c = h * keep[t], c * keep[t]
+            gh = torch.bmm(h, wt)
+            h2, c2, ws = _cell_fwd(gx[t].reshape(G * N, H4), gh.reshape(G * N, H4), c.reshape(G * N, H))
+            hs.append(h); cs.append(c); cn.append(c2); wss.append(ws)
+            h, c = h2.view(G, N, H), c2.view(G, N, H)
+            outs.append(h)
+        ctx.save_for_backward(wt, torch.stack(hs, 0), torch.stack(cs, 0), torch.stack(cn, 0), torch.stack(wss, 0),
+                              keep if keep is not None else wt.new_zeros(0))
+        ctx.has_keep = keep is not None
+        return torch.stack(outs, 0), h, c
+
+    @staticmethod
+    def backward(ctx, dout, dhT, dcT):
+        wt, hs, cs, cn, wss, keep = ctx.saved_tensors
+        T, G, N, H = hs.shape
+        dh = dhT if dhT is not None else torch.zeros_like(hs[0])
+        dc = dcT if dcT is not None else torch.zeros_like(hs[0])
+        wtt = wt.transpose(1, 2).contiguous()
+        dG = torch.empty((T, G, N, 4 * H), dtype=hs.dtype, device=hs.device)
+        for t in range(T - 1, -1, -1):
+            dg, dcp = _cell_bwd((dout[t] + dh).reshape(G * N, H).contiguous(), dc.reshape(G * N, H).contiguous(),
+                                cs[t].reshape(G * N, H), cn[t], wss[t])
+            dG[t] = dg.view(G, N, 4 * H)
+            dh, dc = torch.bmm(dG[t], wtt), dcp.view(G, N, H)
+            if ctx.has_keep:
+                dh, dc = dh * keep[t], dc * keep[t]
+        # dW_hh^T[g] = sum_t h_{t-1}^T dgates_t : one batched GEMM over the flattened (t, n) rows
+        hm = hs.transpose(0, 1).reshape(G, T * N, H)
+        dgm = dG.transpose(0, 1).reshape(G, T * N, 4 * H)
+        dwt = torch.bmm(hm.transpose(1, 2), dgm)
+        return dG, dwt, dh, dc, None
+
+
 def _linear(x, w, b):
     """F.linear for 2-D x; on the GPU with gradients enabled it goes through _LinearGemmBias (autocast-aware)."""
     if x.is_cuda and torch.is_grad_enabled() and (w.requires_grad or x.requires_grad):
@@ -152,6 +224,10 @@ class ActorCriticPolicy(nn.Module):
         keep = None if starts is None else (1.0 - starts.to(gx.dtype)).view(T, 1, N, 1)
         fused = x.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
         wt = wt.to(gx.dtype)
+        fin = lambda z, k: z[k].unsqueeze(0).to(st_dtype)
+        if torch.is_grad_enabled() and gx.requires_grad and T > 1:      # training: hand-written BPTT
+            out, h, c = _LstmSeq.apply(gx, wt, h, c, keep)
+            return out[:, 0], out[:, 1], (fin(h, 0), fin(c, 0), fin(h, 1), fin(c, 1))
         outs = []
         for t in range(T):
             if keep is not None:
@@ -167,7 +243,6 @@ class ActorCriticPolicy(nn.Module):
                 h = torch.sigmoid(o) * torch.tanh(c)
             outs.append(h)
         out = torch.stack(outs, 0)                                                     # [T, 2, N, H]
-        fin = lambda z, k: z[k].unsqueeze(0).to(st_dtype)
         return out[:, 0], out[:, 1], (fin(h, 0), fin(c, 0), fin(h, 1), fin(c, 1))
 
     @staticmethod

@@ -225,3 +225,37 @@ def test_recurrent_update_graph_matches_eager(hip_lib):
     before = [p.detach().clone() for p in pol.parameters()]
     a.collect_rollouts(); a.train()
     assert any(not torch.equal(x, y) for x, y in zip(before, pol.parameters())) and all(torch.isfinite(p).all() for p in pol.parameters())
+
+
+def _lstm_ref_loop(gx, wt, h, c, keep):
+    outs = []
+    for t in range(gx.shape[0]):
+        h, c = h * keep[t], c * keep[t]
+        i, f, g, o = (gx[t] + torch.bmm(h, wt)).chunk(4, -1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs.append(h)
+    return torch.stack(outs), h, c
+
+
+@pytest.mark.parametrize("device", ["cpu", pytest.param("cuda", marks=pytest.mark.gpu)])
+def test_lstm_sequence_function_matches_autograd(device):
+    """The hand-written BPTT of the stacked LSTMs (rl/policy._LstmSeq: fused cell kernels on the GPU, one batched
+    weight-gradient GEMM after the loop) == autograd through the plain step loop: outputs, final state and
+    all four gradients, with episode starts inside the sequence."""
+    from myochallenge_amd.rl.policy import _LstmSeq
+    if device == "cuda" and not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    torch.manual_seed(0)
+    T, G, N, H = 7, 2, 33, 16
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device=device) * sc).requires_grad_()
+    gx, wt, h0, c0 = mk(T, G, N, 4 * H), mk(G, H, 4 * H, sc=0.3), mk(G, N, H), mk(G, N, H)
+    keep = (torch.rand(T, 1, N, 1, device=device) > 0.3).float()
+    w = torch.randn(T, G, N, H, device=device)
+    outs = []
+    for fn in (lambda: _LstmSeq.apply(gx, wt, h0, c0, keep), lambda: _lstm_ref_loop(gx, wt, h0, c0, keep)):
+        o, h, c = fn()
+        loss = (o * w).sum() + 0.5 * h.sum() + (c * c).sum()
+        outs.append((o.detach(), h.detach(), c.detach()) + tuple(torch.autograd.grad(loss, [gx, wt, h0, c0])))
+    for a, b in zip(*outs):
+        assert float((a - b).abs().max()) <= 2e-5 * (1 + float(b.abs().max()))

@@ -212,6 +212,22 @@ int myo_vecnorm_step(const float* obs, const float* rew, const uint8_t* done, co
 /* t_idx <- (t_idx + 1) mod T, commit the Philox position. */
 int myo_rollout_advance(int32_t* t_idx, int T, uint64_t* draw_counter, void* stream);
 
+/* One time step of G stacked one-layer LSTMs (gate order i, f, g, o) around the recurrent GEMM: the pointwise
+ * part of RecurrentActorCriticPolicy's lstm_actor / lstm_critic in collect_rollouts / train
+ * (/root/reference/src/train/trainer.py:49-71; sb3-contrib _process_sequence).  Rows r = g * N + n, R = G * N.
+ * Storage float32 (is_bf16 = 0) or bfloat16 (1); arithmetic fp32.  keep_next: dev float[N], 0 where the NEXT
+ * step starts an episode (NULL = all ones).
+ * fwd: gx, gh [R,4H] pre-activations (input and recurrent parts), c_prev [R,H] (already masked) ->
+ *      out_h, c_new [R,H] (unmasked), hm_next, cm_next [R,H] (times keep_next: inputs of the next step),
+ *      ws [R,4H] (activated gates, for the backward pass).
+ * bwd: dout [R,H] (gradient of out_h, may be NULL), dhm_next / dcm_next [R,H] (gradients of hm_next / cm_next
+ *      from the later step, NULL at the last step) -> dgates [R,4H] (gradient of gx and of gh), dc_prev [R,H]. */
+int myo_lstm_cell_fwd(const void* gx, const void* gh, const void* c_prev, const float* keep_next, int R, int N, int H,
+                      int is_bf16, void* out_h, void* hm_next, void* cm_next, void* c_new, void* ws, void* stream);
+int myo_lstm_cell_bwd(const void* dout, const void* dhm_next, const void* dcm_next, const float* keep_next,
+                      const void* c_prev, const void* c_new, const void* ws, int R, int N, int H, int is_bf16,
+                      void* dgates, void* dc_prev, void* stream);
+
 /* GAE(gamma, lambda) backward scan = SB3 RolloutBuffer.compute_returns_and_advantage (run by
  * RecurrentPPO.learn, /root/reference/src/train/trainer.py:66-71).  dev float32 [T,N] row-major:
  * rew, val, starts (episode_starts), outputs adv, ret; last_val[N], last_done[N]. */

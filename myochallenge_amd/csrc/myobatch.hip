@@ -1516,6 +1516,109 @@ extern "C" int myo_rollout_advance(int32_t* t_idx, int T, uint64_t* draw_counter
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ LSTM cell
+// One time step of G stacked one-layer LSTMs (PyTorch gate order i, f, g, o) around the recurrent GEMM,
+// forward and backward (RecurrentActorCriticPolicy's lstm_actor / lstm_critic).  Rows
+// r = g * N + n.  The episode-start mask of the NEXT step is folded in: the forward kernel emits the unmasked
+// h (the sequence output) and the masked h, c that feed the next step's GEMM / cell; the backward kernel
+// applies the same mask to the incoming state gradients.  E = float or bf16 storage, fp32 arithmetic.
+#ifndef MYO_EMU
+template <typename E> __device__ __forceinline__ float myo_ld(const E* p, size_t i);
+template <> __device__ __forceinline__ float myo_ld<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float myo_ld<unsigned short>(const unsigned short* p, size_t i) { return __uint_as_float((unsigned)p[i] << 16); }
+template <typename E> __device__ __forceinline__ void myo_st(E* p, size_t i, float v);
+template <> __device__ __forceinline__ void myo_st<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void myo_st<unsigned short>(unsigned short* p, size_t i, float v) { p[i] = myo_f2bf(v); }
+__device__ __forceinline__ float myo_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+template <typename E>
+__global__ void __launch_bounds__(256) k_lstm_cell_fwd(const E* __restrict__ gx, const E* __restrict__ gh, const E* __restrict__ c_prev,
+                                                       const float* __restrict__ keep_next, int R, int N, int H, E* __restrict__ out_h,
+                                                       E* __restrict__ hm_next, E* __restrict__ cm_next, E* __restrict__ c_new,
+                                                       E* __restrict__ ws) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)R * H) return;
+  const int r = (int)(idx / H), j = (int)(idx % H);
+  const size_t g0 = (size_t)r * 4 * H + j;
+  const float i = myo_sigmoid(myo_ld(gx, g0) + myo_ld(gh, g0));
+  const float f = myo_sigmoid(myo_ld(gx, g0 + H) + myo_ld(gh, g0 + H));
+  const float g = tanhf(myo_ld(gx, g0 + 2 * H) + myo_ld(gh, g0 + 2 * H));
+  const float o = myo_sigmoid(myo_ld(gx, g0 + 3 * H) + myo_ld(gh, g0 + 3 * H));
+  const float c = f * myo_ld(c_prev, idx) + i * g;
+  const float h = o * tanhf(c);
+  const float k = keep_next ? keep_next[r % N] : 1.f;
+  myo_st(out_h, idx, h);
+  myo_st(c_new, idx, c);
+  myo_st(hm_next, idx, h * k);
+  myo_st(cm_next, idx, c * k);
+  myo_st(ws, g0, i); myo_st(ws, g0 + H, f); myo_st(ws, g0 + 2 * H, g); myo_st(ws, g0 + 3 * H, o);
+}
+template <typename E>
+__global__ void __launch_bounds__(256) k_lstm_cell_bwd(const E* __restrict__ dout, const E* __restrict__ dhm_next, const E* __restrict__ dcm_next,
+                                                       const float* __restrict__ keep_next, const E* __restrict__ c_prev,
+                                                       const E* __restrict__ c_new, const E* __restrict__ ws, int R, int N, int H,
+                                                       E* __restrict__ dgates, E* __restrict__ dc_prev) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)R * H) return;
+  const int r = (int)(idx / H), j = (int)(idx % H);
+  const size_t g0 = (size_t)r * 4 * H + j;
+  const float k = keep_next ? keep_next[r % N] : 1.f;
+  const float dh = (dout ? myo_ld(dout, idx) : 0.f) + (dhm_next ? k * myo_ld(dhm_next, idx) : 0.f);
+  const float dc_in = dcm_next ? k * myo_ld(dcm_next, idx) : 0.f;
+  const float i = myo_ld(ws, g0), f = myo_ld(ws, g0 + H), g = myo_ld(ws, g0 + 2 * H), o = myo_ld(ws, g0 + 3 * H);
+  const float tc = tanhf(myo_ld(c_new, idx));
+  const float dct = dc_in + dh * o * (1.f - tc * tc);
+  myo_st(dgates, g0, dct * g * i * (1.f - i));
+  myo_st(dgates, g0 + H, dct * myo_ld(c_prev, idx) * f * (1.f - f));
+  myo_st(dgates, g0 + 2 * H, dct * i * (1.f - g * g));
+  myo_st(dgates, g0 + 3 * H, dh * tc * o * (1.f - o));
+  myo_st(dc_prev, idx, dct * f);
+}
+#endif
+extern "C" int myo_lstm_cell_fwd(const void* gx, const void* gh, const void* c_prev, const float* keep_next, int R, int N, int H,
+                                 int is_bf16, void* out_h, void* hm_next, void* cm_next, void* c_new, void* ws, void* stream) {
+  if (!gx || !gh || !c_prev || !out_h || !hm_next || !cm_next || !c_new || !ws || R <= 0 || N <= 0 || H <= 0 || R % N)
+    return fail(MYO_E_ARG, "myo_lstm_cell_fwd: bad arguments");
+#ifdef MYO_EMU
+  (void)keep_next; (void)is_bf16; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_lstm_cell_fwd is a GPU kernel");
+#else
+  const unsigned nb = (unsigned)(((size_t)R * H + 255) / 256);
+  if (is_bf16)
+    hipLaunchKernelGGL(k_lstm_cell_fwd<unsigned short>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)gx,
+                       (const unsigned short*)gh, (const unsigned short*)c_prev, keep_next, R, N, H, (unsigned short*)out_h,
+                       (unsigned short*)hm_next, (unsigned short*)cm_next, (unsigned short*)c_new, (unsigned short*)ws);
+  else
+    hipLaunchKernelGGL(k_lstm_cell_fwd<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)gx, (const float*)gh,
+                       (const float*)c_prev, keep_next, R, N, H, (float*)out_h, (float*)hm_next, (float*)cm_next, (float*)c_new,
+                       (float*)ws);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_lstm_cell_bwd(const void* dout, const void* dhm_next, const void* dcm_next, const float* keep_next,
+                                 const void* c_prev, const void* c_new, const void* ws, int R, int N, int H, int is_bf16,
+                                 void* dgates, void* dc_prev, void* stream) {
+  if (!c_prev || !c_new || !ws || !dgates || !dc_prev || R <= 0 || N <= 0 || H <= 0 || R % N)
+    return fail(MYO_E_ARG, "myo_lstm_cell_bwd: bad arguments");
+#ifdef MYO_EMU
+  (void)dout; (void)dhm_next; (void)dcm_next; (void)keep_next; (void)is_bf16; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_lstm_cell_bwd is a GPU kernel");
+#else
+  const unsigned nb = (unsigned)(((size_t)R * H + 255) / 256);
+  if (is_bf16)
+    hipLaunchKernelGGL(k_lstm_cell_bwd<unsigned short>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)dout,
+                       (const unsigned short*)dhm_next, (const unsigned short*)dcm_next, keep_next, (const unsigned short*)c_prev,
+                       (const unsigned short*)c_new, (const unsigned short*)ws, R, N, H, (unsigned short*)dgates,
+                       (unsigned short*)dc_prev);
+  else
+    hipLaunchKernelGGL(k_lstm_cell_bwd<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (const float*)dhm_next,
+                       (const float*)dcm_next, keep_next, (const float*)c_prev, (const float*)c_new, (const float*)ws, R, N, H,
+                       (float*)dgates, (float*)dc_prev);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------ GAE
 // compute_returns_and_advantage of SB3's RolloutBuffer: backward scan over T with
 // the episode_starts[t+1] mask; one thread per env, coalesced over envs.  [T,N] row-major.

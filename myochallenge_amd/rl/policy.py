@@ -70,19 +70,57 @@ def _cell_bwd(dh, dc, c_prev, c_new, ws):
     return dg, dct * f
 
 
+def _native_lib(t):
+    """libmyobatch (HIP build) for CUDA tensors in float32 / bfloat16, else None."""
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    try:
+        from .. import native
+        lib = native.load()
+    except Exception:
+        return None
+    return None if lib.is_emulation else lib
+
+
 class _LstmSeq(torch.autograd.Function):
     """G stacked one-layer LSTMs over a whole sequence with a hand-written backward.
 
     gx [T,G,N,4H] input projections (+ biases), wt [G,H,4H] = W_hh^T, h0/c0 [G,N,H], keep [T,1,N,1] (0 where an
     episode starts: state zeroed before that step).  Autograd's own BPTT of the step loop costs ~10 small
     kernels per step (select / stack backwards, gradient adds, a weight-gradient GEMM and its accumulation per
-    step); here a step of the backward pass is the fused cell backward, one batched GEMM for dh and the mask,
-    and the recurrent weight gradient is ONE batched GEMM over all steps after the loop."""
+    step).  Here a time step is TWO launches in each direction on the GPU — the batched recurrent GEMM and one
+    libmyobatch kernel (``myo_lstm_cell_fwd`` / ``myo_lstm_cell_bwd``: gates, cell, the next step's episode
+    mask, and in the backward pass the gradient add) — and the recurrent weight gradient is ONE batched GEMM
+    over all steps after the loop.  Without the HIP library (CPU) the same recurrences run on ATen ops."""
 
     @staticmethod
     def forward(ctx, gx, wt, h0, c0, keep):
         T, G, N, H4 = gx.shape
         H = H4 // 4
+        lib = _native_lib(gx)
+        ctx.native = lib is not None
+        if lib is not None:
+            import ctypes as C
+            gx = gx.contiguous()
+            kf = None if keep is None else keep.reshape(T, N).float().contiguous()
+            hm = torch.empty((T + 1, G, N, H), dtype=gx.dtype, device=gx.device)      # masked h entering step t
+            cm = torch.empty_like(hm)
+            out, cn = torch.empty((T, G, N, H), dtype=gx.dtype, device=gx.device), torch.empty((T, G, N, H), dtype=gx.dtype, device=gx.device)
+            ws = torch.empty((T, G, N, H4), dtype=gx.dtype, device=gx.device)
+            hm[0] = h0 if kf is None else h0 * keep[0]
+            cm[0] = c0 if kf is None else c0 * keep[0]
+            st = C.c_void_p(torch.cuda.current_stream(gx.device).cuda_stream)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            bf = int(gx.dtype == torch.bfloat16)
+            wt = wt.contiguous()
+            for t in range(T):
+                gh = torch.bmm(hm[t], wt)
+                kn = p(kf[t + 1]) if (kf is not None and t + 1 < T) else None
+                lib.check(lib.L.myo_lstm_cell_fwd(p(gx[t]), p(gh), p(cm[t]), kn, G * N, N, H, bf, p(out[t]), p(hm[t + 1]), p(cm[t + 1]),
+                                                  p(cn[t]), p(ws[t]), st))
+            ctx.save_for_backward(wt, hm, cm, cn, ws, kf if kf is not None else wt.new_zeros(0))
+            ctx.has_keep = kf is not None
+            return out, hm[T], cm[T]                       # no mask after the last step: the final state itself
         h, c = h0, c0
         hs, cs, cn, wss, outs = [], [], [], [], []
         for t in range(T):
@@ -101,10 +139,34 @@ class _LstmSeq(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, dhT, dcT):
         wt, hs, cs, cn, wss, keep = ctx.saved_tensors
+        wtt = wt.transpose(1, 2).contiguous()
+        if ctx.native:
+            import ctypes as C
+            from .. import native
+            lib = native.load()
+            T, G, N, H = cn.shape
+            dG = torch.empty((T, G, N, 4 * H), dtype=cn.dtype, device=cn.device)
+            dcm = torch.empty((2, G, N, H), dtype=cn.dtype, device=cn.device)      # ping-pong: gradient of cm[t]
+            st = C.c_void_p(torch.cuda.current_stream(cn.device).cuda_stream)
+            p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+            bf = int(cn.dtype == torch.bfloat16)
+            dout = dout.contiguous()
+            dhm = None if dhT is None else dhT.contiguous()       # gradient of hm[t+1] (the final state at t = T-1)
+            dcn = None if dcT is None else dcT.contiguous()
+            for t in range(T - 1, -1, -1):
+                kn = p(keep[t + 1]) if (ctx.has_keep and t + 1 < T) else None
+                lib.check(lib.L.myo_lstm_cell_bwd(p(dout[t]), p(dhm), p(dcn), kn, p(cs[t]), p(cn[t]), p(wss[t]), G * N, N, H, bf,
+                                                  p(dG[t]), p(dcm[t & 1]), st))
+                dhm, dcn = torch.bmm(dG[t], wtt), dcm[t & 1]
+            if ctx.has_keep:
+                k0 = keep[0].view(1, N, 1).to(dhm.dtype)
+                dhm, dcn = dhm * k0, dcn * k0
+            hm_in = hs[:T].transpose(0, 1).reshape(G, T * N, H)
+            dwt = torch.bmm(hm_in.transpose(1, 2), dG.transpose(0, 1).reshape(G, T * N, 4 * H))
+            return dG, dwt, dhm, dcn.clone(), None
         T, G, N, H = hs.shape
         dh = dhT if dhT is not None else torch.zeros_like(hs[0])
         dc = dcT if dcT is not None else torch.zeros_like(hs[0])
-        wtt = wt.transpose(1, 2).contiguous()
         dG = torch.empty((T, G, N, 4 * H), dtype=hs.dtype, device=hs.device)
         for t in range(T - 1, -1, -1):
             dg, dcp = _cell_bwd((dout[t] + dh).reshape(G * N, H).contiguous(), dc.reshape(G * N, H).contiguous(),

@@ -136,6 +136,8 @@ def test_c_abi_argument_checks(emu_lib):
         (L.myo_rollout_sample, (null, null, null, 4, 39, 1, null, null, null, null, null, null, 0, null)),
         (L.myo_vecnorm_step, (null,) * 5 + (4, 86) + (null,) * 5 + (0.99, 1e-8, 10.0, 10.0, 1, 1, 1) + (null,) * 9),
         (L.myo_rollout_advance, (null, 4, null, null)),
+        (L.myo_lstm_cell_fwd, (null,) * 4 + (8, 4, 16, 0) + (null,) * 6),
+        (L.myo_lstm_cell_bwd, (null,) * 7 + (8, 4, 16, 0) + (null,) * 3),
     ]
     for fn, args in checks:
         rc = fn(*args)

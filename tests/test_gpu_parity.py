@@ -608,3 +608,51 @@ def test_graph_replay_equals_eager_minibatch_step(hip_lib):
         assert float((g1 - g2).abs().max()) <= 1e-6 * (1 + float(g2.abs().max())), it
         assert float((p1 - p2).abs().max()) <= 1e-7, it
         assert pl1 == pytest.approx(pl2, rel=1e-5, abs=1e-7)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_lstm_cell_kernels_match_formulas(hip_lib, dtype):
+    """myo_lstm_cell_fwd / _bwd against the textbook LSTM cell (gate order i, f, g, o) with the next step's
+    episode mask folded in; fp32 storage to 1e-6, bf16 storage to bf16 rounding."""
+    import ctypes as C
+    import torch
+    L = hip_lib.L
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    G, N, H = 2, 37, 24
+    R = G * N
+    td = torch.float32 if dtype == "f32" else torch.bfloat16
+    tol = 2e-6 if dtype == "f32" else 2e-2
+    mk = lambda *s: torch.randn(*s, device=dev).to(td)
+    gx, gh, cp = mk(R, 4 * H), mk(R, 4 * H), mk(R, H)
+    keep = (torch.rand(N, device=dev) > 0.4).float()
+    out_h, hm, cm, cn = (torch.empty(R, H, device=dev, dtype=td) for _ in range(4))
+    ws = torch.empty(R, 4 * H, device=dev, dtype=td)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    bf = int(dtype == "bf16")
+    hip_lib.check(L.myo_lstm_cell_fwd(p(gx), p(gh), p(cp), p(keep), R, N, H, bf, p(out_h), p(hm), p(cm), p(cn), p(ws), None))
+    torch.cuda.synchronize()
+    a = gx.float() + gh.float()
+    i, f, g, o = torch.sigmoid(a[:, :H]), torch.sigmoid(a[:, H:2 * H]), torch.tanh(a[:, 2 * H:3 * H]), torch.sigmoid(a[:, 3 * H:])
+    c = f * cp.float() + i * g
+    h = o * torch.tanh(c)
+    k = keep.repeat(G).unsqueeze(1)
+    for got, want in ((out_h, h), (cn, c), (hm, h * k), (cm, c * k), (ws, torch.cat([i, f, g, o], 1))):
+        assert float((got.float() - want).abs().max()) <= tol * (1 + float(want.abs().max()))
+    # backward, from the kernel's own saved tensors
+    dout, dhm, dcm = mk(R, H), mk(R, H), mk(R, H)
+    dg, dcp = torch.empty(R, 4 * H, device=dev, dtype=td), torch.empty(R, H, device=dev, dtype=td)
+    hip_lib.check(L.myo_lstm_cell_bwd(p(dout), p(dhm), p(dcm), p(keep), p(cp), p(cn), p(ws), R, N, H, bf, p(dg), p(dcp), None))
+    torch.cuda.synchronize()
+    wi, wf, wg, wo = (ws.float()[:, q * H:(q + 1) * H] for q in range(4))
+    tc = torch.tanh(cn.float())
+    dh = dout.float() + k * dhm.float()
+    dct = k * dcm.float() + dh * wo * (1 - tc * tc)
+    want_dg = torch.cat([dct * wg * wi * (1 - wi), dct * cp.float() * wf * (1 - wf), dct * wi * (1 - wg * wg), dh * tc * wo * (1 - wo)], 1)
+    assert float((dg.float() - want_dg).abs().max()) <= tol * (1 + float(want_dg.abs().max()))
+    assert float((dcp.float() - dct * wf).abs().max()) <= tol * (1 + float((dct * wf).abs().max()))
+    # NULL gradients of the later step (last time step) are zeros
+    hip_lib.check(L.myo_lstm_cell_bwd(p(dout), None, None, None, p(cp), p(cn), p(ws), R, N, H, bf, p(dg), p(dcp), None))
+    torch.cuda.synchronize()
+    dct0 = dout.float() * wo * (1 - tc * tc)
+    assert float((dcp.float() - dct0 * wf).abs().max()) <= tol * (1 + float((dct0 * wf).abs().max()))

@@ -156,6 +156,8 @@ class ReorientVecEnv:
         self._ball_d[:, 2:5] = self.nominal_friction
         self._fric_change = f64(np.asarray(p["obj_friction_change"], np.float64))
         self.sync_free = False        # True: fixed-shape, host-sync-free step (graph capture); see _reset_rows
+        self.use_graph = True         # replay the step (physics + task layer) from a hipGraph after the first call
+        self._graph, self._act_static = None, None
         self.gen = torch.Generator(device=d)
         self.gen.manual_seed(int(seed) + 7919)
         z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device=d)
@@ -274,9 +276,11 @@ class ReorientVecEnv:
         self._obs.copy_(self._flat(self._obs_dict()))
         return self._obs
 
-    @torch.no_grad()
-    def step_tensor(self, actions):
-        a = torch.clamp(actions.to(device=self.device, dtype=torch.float32), -1.0, 1.0)
+    def _step_core(self, actions):
+        """Action map, frame_skip physics substeps, observation / reward / termination and the episode counters:
+        fixed shapes, no host synchronisation, every result lands in a static buffer (so the whole sequence —
+        the physics kernel plus ~25 small tensor kernels — replays from one hipGraph, see step_tensor)."""
+        a = torch.clamp(actions, -1.0, 1.0)
         if self.p["normalize_act"]:                      # BaseV0.step: float32 sigmoid(5(a - 0.5)) for muscles
             a = 1.0 / (1.0 + torch.exp(-5.0 * (a - 0.5)))
         self._ctrl.copy_(a)
@@ -299,15 +303,38 @@ class ReorientVecEnv:
         obs = self._flat(o)
         obs = torch.where(bad.unsqueeze(-1), torch.zeros_like(obs), obs)
         self._term.copy_(obs)
+        self._obs.copy_(obs)
         comps = torch.stack([rd["pos_dist"], rd["rot_dist"], rd["act_reg"], rd["alive"], rd["sparse"], rd["solved"], rd["done"], rd["dense"]], -1)
         self._comps.copy_(torch.nan_to_num(comps).to(torch.float32))
-        ep = torch.stack([self.ep_ret, self.ep_len], -1).to(torch.float32)
+        self._ep.copy_(torch.stack([self.ep_ret, self.ep_len], -1).to(torch.float32))
+        self._rew.copy_(rew); self._done.copy_(done); self._trunc.copy_(trunc)
+
+    @torch.no_grad()
+    def step_tensor(self, actions):
+        a = actions.to(device=self.device, dtype=torch.float32)
+        graphable = self.use_graph and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
+        if graphable and self._graph is not None:
+            self._act_static.copy_(a)
+            self._graph.replay()
+        else:
+            self._step_core(a)
+            if graphable:          # this eager step was the warm-up (constants bound, library handles made): capture the next ones
+                self._act_static = a.clone()
+                self._graph = torch.cuda.CUDAGraph()
+                snap = [t.clone() for t in self._graph_state()]
+                with torch.cuda.graph(self._graph, capture_error_mode="thread_local"):
+                    self._step_core(self._act_static)
+                for t, v in zip(self._graph_state(), snap):   # (capture records, it does not execute; restored for safety)
+                    t.copy_(v)
+        done = self._done.bool()
         if self.sync_free or bool(done.any()):
             self._reset_rows(done)
-            obs = torch.where(done.unsqueeze(-1), self._flat(self._obs_dict()), obs)
-        self._obs.copy_(obs)
-        self._rew.copy_(rew); self._done.copy_(done); self._trunc.copy_(trunc); self._ep.copy_(ep)
+            self._obs.copy_(torch.where(done.unsqueeze(-1), self._flat(self._obs_dict()), self._obs))
         return self._obs, self._rew, self._done, self._trunc, self._term, self._comps, self._ep
+
+    def _graph_state(self):
+        return [self.pos_dist, self.rot_dist, self.elapsed, self.ep_len, self.ep_ret, self._obs, self._term, self._comps, self._ep,
+                self._rew, self._done, self._trunc, self._ctrl, self._qp, self._qv, self._ac, self._tm]
 
     # ------------------------------------------------------------------ numpy protocol (subset)
     def reset(self):

@@ -178,6 +178,10 @@ int myo_bias_relu_bf16(uint16_t* h, const uint16_t* bias, int groups, int rows, 
 /* Finishes a split-K product: out[g, j] = sum_k part[g, k, j]; part dev [groups, splits, n] of
  * bfloat16 (part_is_bf16 != 0) or float32, n even; out dev float32 [groups, n]. */
 int myo_splitk_reduce(const void* part, int part_is_bf16, float* out, int groups, int splits, int n, void* stream);
+/* Two such reductions in one launch (a layer's weight-gradient partials and its bias partials; the two head
+ * gradients): same arguments and the same arithmetic as two myo_splitk_reduce calls. */
+int myo_splitk_reduce2(const void* part_a, int a_is_bf16, float* out_a, int groups_a, int splits_a, int n_a,
+                       const void* part_b, int b_is_bf16, float* out_b, int groups_b, int splits_b, int n_b, void* stream);
 
 /* ReLU backward in place on bfloat16 dy[rows, cols] (dy *= act > 0) plus column sums of the result
  * over blocks of 32 rows: partial dev float32 [rows/32, cols] (finish with myo_splitk_reduce: the

@@ -1198,6 +1198,53 @@ __global__ void __launch_bounds__(256) k_colsum_finish(const float2* __restrict_
     out[j] = v;
   }
 }
+// Two independent split reductions in ONE launch (the weight-gradient partials of a layer and its bias
+// partials; the two head gradients): blocks [0, nbA) run job A, the rest job B, each with the code of the
+// stand-alone kernels above (mode 0: bf16 partials, 1: tall fp32 through LDS, 2: fp32 partials).
+struct ReduceJob { const void* part; float2* out; int splits, n2, total2, mode, nblocks; };
+__device__ __forceinline__ void myo_reduce_job(const ReduceJob& J, int vb, float2* red) {
+  const int t = threadIdx.x;
+  if (J.mode == 1) {
+    const int cl = t & 31, ph = t >> 5;
+    const int j = vb * 32 + cl;
+    const int g = j / J.n2, c = j - g * J.n2;
+    const float2* src = reinterpret_cast<const float2*>(J.part) + (size_t)g * J.splits * J.n2 + c;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 4
+    for (int k = ph; k < J.splits; k += 8) { const float2 v = src[(size_t)k * J.n2]; a0 += v.x; a1 += v.y; }
+    red[t] = make_float2(a0, a1);
+    __syncthreads();
+    if (ph == 0) {
+      float2 v = red[cl];
+      for (int k = 1; k < 8; ++k) { v.x += red[cl + 32 * k].x; v.y += red[cl + 32 * k].y; }
+      J.out[j] = v;
+    }
+    return;
+  }
+  const int j = vb * 256 + t;
+  if (j >= J.total2) return;
+  const int g = j / J.n2, c = j - g * J.n2;
+  float a0 = 0.f, a1 = 0.f;
+  if (J.mode == 0) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(J.part) + (size_t)g * J.splits * J.n2 + c;
+#pragma unroll 8
+    for (int k = 0; k < J.splits; ++k) {
+      const unsigned u = src[(size_t)k * J.n2];
+      a0 += __uint_as_float(u << 16);
+      a1 += __uint_as_float(u & 0xffff0000u);
+    }
+  } else {
+    const float2* src = reinterpret_cast<const float2*>(J.part) + (size_t)g * J.splits * J.n2 + c;
+#pragma unroll 8
+    for (int k = 0; k < J.splits; ++k) { const float2 v = src[(size_t)k * J.n2]; a0 += v.x; a1 += v.y; }
+  }
+  J.out[j] = make_float2(a0, a1);
+}
+__global__ void __launch_bounds__(256) k_reduce_pair(ReduceJob A, ReduceJob B) {
+  __shared__ float2 red[256];
+  if ((int)blockIdx.x < A.nblocks) myo_reduce_job(A, blockIdx.x, red);      // block-uniform branch
+  else myo_reduce_job(B, blockIdx.x - A.nblocks, red);
+}
 #endif
 extern "C" int myo_bias_relu_bf16(uint16_t* h, const uint16_t* bias, int groups, int rows, int cols, void* stream) {
   if (!h || !bias || groups <= 0 || rows <= 0 || cols <= 0 || (cols & 1)) return fail(MYO_E_ARG, "myo_bias_relu_bf16: bad arguments");
@@ -1232,6 +1279,32 @@ extern "C" int myo_ppo_gather(const float* obs, const float* act, const float* o
 #endif
 }
 
+#ifndef MYO_EMU
+static ReduceJob make_reduce_job(const void* part, int part_is_bf16, float* out, int groups, int splits, int n) {
+  ReduceJob J;
+  J.part = part; J.out = (float2*)out; J.splits = splits; J.n2 = n / 2; J.total2 = groups * (n / 2);
+  if (part_is_bf16) { J.mode = 0; J.nblocks = (J.total2 + 255) / 256; }
+  else if (J.n2 % 32 == 0 && splits >= 64) { J.mode = 1; J.nblocks = J.total2 / 32; }
+  else { J.mode = 2; J.nblocks = (J.total2 + 255) / 256; }
+  return J;
+}
+#endif
+extern "C" int myo_splitk_reduce2(const void* part_a, int a_is_bf16, float* out_a, int groups_a, int splits_a, int n_a,
+                                  const void* part_b, int b_is_bf16, float* out_b, int groups_b, int splits_b, int n_b, void* stream) {
+  if (!part_a || !out_a || groups_a <= 0 || splits_a <= 0 || n_a <= 0 || (n_a & 1) || !part_b || !out_b || groups_b <= 0 ||
+      splits_b <= 0 || n_b <= 0 || (n_b & 1))
+    return fail(MYO_E_ARG, "myo_splitk_reduce2: bad arguments");
+#ifdef MYO_EMU
+  (void)stream; (void)a_is_bf16; (void)b_is_bf16;
+  return fail(MYO_E_UNSUPPORTED, "myo_splitk_reduce2 is a GPU kernel");
+#else
+  const ReduceJob A = make_reduce_job(part_a, a_is_bf16, out_a, groups_a, splits_a, n_a);
+  const ReduceJob B = make_reduce_job(part_b, b_is_bf16, out_b, groups_b, splits_b, n_b);
+  hipLaunchKernelGGL(k_reduce_pair, dim3(A.nblocks + B.nblocks), dim3(256), 0, (hipStream_t)stream, A, B);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
 extern "C" int myo_splitk_reduce(const void* part, int part_is_bf16, float* out, int groups, int splits, int n, void* stream) {
   if (!part || !out || groups <= 0 || splits <= 0 || n <= 0 || (n & 1)) return fail(MYO_E_ARG, "myo_splitk_reduce: bad arguments");
 #ifdef MYO_EMU

@@ -89,6 +89,7 @@ class NativeLib:
         L.myo_ppo_gather.argtypes = [vp] * 6 + [i32, i32, i32, vp, i32] + [vp] * 7
         L.myo_bias_relu_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
         L.myo_splitk_reduce.argtypes = [vp, i32, vp, i32, i32, i32, vp]
+        L.myo_splitk_reduce2.argtypes = [vp, i32, vp, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]
         L.myo_relu_bwd_colsum_bf16.argtypes = [vp, vp, i32, i32, vp, vp]
         L.myo_rollout_policy_input.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp]
         L.myo_rollout_sample.argtypes = [vp, vp, vp, i32, i32, u64, vp, vp, vp, vp, vp, vp, i32, vp]
@@ -132,7 +133,7 @@ EXPORTED_SYMBOLS = [
     "myo_batch_set_state", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
-    "myo_vecnorm_step", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
+    "myo_vecnorm_step", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
 ]
 
 

@@ -237,6 +237,26 @@ class FusedPPOStep:
         self.lib.check(self.lib.L.myo_splitk_reduce(C.c_void_p(part.data_ptr()), int(part.dtype == torch.bfloat16),
                                                     C.c_void_p(out.data_ptr()), groups, splits, n, C.c_void_p(stream)))
 
+    def _reduce2(self, part_a, out_a, groups_a, splits_a, part_b, out_b, groups_b, splits_b):
+        """Two _reduce calls in one launch."""
+        stream = torch.cuda.current_stream(out_a.device).cuda_stream
+        self.lib.check(self.lib.L.myo_splitk_reduce2(
+            C.c_void_p(part_a.data_ptr()), int(part_a.dtype == torch.bfloat16), C.c_void_p(out_a.data_ptr()), groups_a, splits_a,
+            out_a.numel() // groups_a, C.c_void_p(part_b.data_ptr()), int(part_b.dtype == torch.bfloat16),
+            C.c_void_p(out_b.data_ptr()), groups_b, splits_b, out_b.numel() // groups_b, C.c_void_p(stream)))
+
+    def _relu_bwd_partial(self, dh, act):
+        """dh *= (act > 0) in place and the per-32-row column sums of the result (fp32 [G*B/32, H]); None if the
+        shape has no fast path (the caller then uses _relu_bwd_bias)."""
+        G, B, H = dh.shape
+        if not (B % 32 == 0 and H % 16 == 0 and 256 % (H // 2) == 0):
+            return None
+        partial = torch.empty((G * B // 32, H), device=dh.device)
+        stream = torch.cuda.current_stream(dh.device).cuda_stream
+        self.lib.check(self.lib.L.myo_relu_bwd_colsum_bf16(C.c_void_p(dh.data_ptr()), C.c_void_p(act.data_ptr()), G * B, H,
+                                                           C.c_void_p(partial.data_ptr()), C.c_void_p(stream)))
+        return partial
+
     def _relu_bwd_bias(self, dh, act, bias_grad):
         """dh *= (act > 0) in place; bias_grad[g] = column sums of dh[g]  (dh, act: bf16 [G, B, H])."""
         G, B, H = dh.shape
@@ -337,18 +357,29 @@ class FusedPPOStep:
                           direct=(pol.log_std.grad, pi_head.bias.grad, vf_head.bias.grad))
         acc = self.acc
         # heads: dW (split-K) and the gradient entering the trunks
-        for dy, head, x in ((dmean_h, pi_head, h[0]), (dvalue_h, vf_head, h[1])):
-            part = torch.bmm(dy.view(s, B // s, -1).transpose(1, 2), x.view(s, B // s, -1))
-            self._reduce(part, head.weight.grad, 1, s)
+        parts = [torch.bmm(dy.view(s, B // s, -1).transpose(1, 2), x.view(s, B // s, -1))
+                 for dy, x in ((dmean_h, h[0]), (dvalue_h, h[1]))]
+        if pi_head.weight.grad.numel() % 2 == 0 and vf_head.weight.grad.numel() % 2 == 0:
+            self._reduce2(parts[0], pi_head.weight.grad, 1, s, parts[1], vf_head.weight.grad, 1, s)
+        else:
+            self._reduce(parts[0], pi_head.weight.grad, 1, s)
+            self._reduce(parts[1], vf_head.weight.grad, 1, s)
         dh = torch.empty_like(h)
         torch.mm(dmean_h, wpi, out=dh[0])
         torch.mm(dvalue_h, wvf, out=dh[1])
         for li in reversed(range(len(L))):
             lay, x = L[li], saved[li]
-            dh = self._relu_bwd_bias(dh, saved[li + 1], lay["bg"])
+            bias_part = self._relu_bwd_partial(dh, saved[li + 1])
+            if bias_part is None:
+                dh = self._relu_bwd_bias(dh, saved[li + 1], lay["bg"])
             H, I = lay["wh"].shape[1], lay["wh"].shape[2]
             part = torch.bmm(dh.view(2 * s, B // s, H).transpose(1, 2), x.reshape(2 * s, B // s, I))
-            self._reduce(part, lay["wg"], 2, s)
+            if bias_part is not None and (H * I) % 2 == 0:      # weight partials and bias partials: one launch
+                self._reduce2(part, lay["wg"], 2, s, bias_part, lay["bg"], 2, B // 32)
+            else:
+                if bias_part is not None:
+                    self._reduce(bias_part, lay["bg"], 2, B // 32)
+                self._reduce(part, lay["wg"], 2, s)
             if li > 0:
                 dh = torch.bmm(dh, lay["wh"])
         return acc[A], acc[A + 1]

@@ -243,9 +243,11 @@ int myo_gae(const float* rew, const float* val, const float* starts, const float
  * (what RecurrentPPO.train does per minibatch; /root/reference/src/train/trainer.py:66-71, SB3 Adam
  * eps 1e-5).  g is multiplied by grad_scale first (1/world after an all-reduce SUM).  step: dev
  * int32[2], zero-initialised ([1] = number of steps taken); scratch: dev float[64] (per-block sums
- * of g^2, added in a fixed order: deterministic). */
+ * of g^2, added in a fixed order: deterministic).  p_bf16 (may be NULL): bfloat16 copy of p, rewritten with
+ * the new parameters in the same pass (the operand the bf16 GEMMs read). */
 int myo_adam_clip_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
-                       float eps, float max_norm, float grad_scale, int* step, float* scratch, void* stream);
+                       float eps, float max_norm, float grad_scale, int* step, float* scratch, uint16_t* p_bf16,
+                       void* stream);
 
 const char* myo_last_error(void);
 const char* myo_version(void);

@@ -1761,7 +1761,7 @@ __global__ void __launch_bounds__(256) k_grad_sqnorm(const float* __restrict__ g
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
                                               float max_norm, float gs, const int* __restrict__ step,
-                                              const float* __restrict__ part) {
+                                              const float* __restrict__ part, unsigned short* __restrict__ p_bf16) {
   float sq = 0.f;
   for (int k = 0; k < MYO_SQN_BLOCKS; ++k) sq += part[k];      // same order in every block
   const int t = step[1];
@@ -1774,21 +1774,25 @@ __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi; v[i] = vi;
-    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    const float pn = p[i] - step_size * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    p[i] = pn;
+    if (p_bf16) p_bf16[i] = myo_f2bf(pn);          // the bf16 shadow the GEMMs read: no separate cast pass
   }
 }
 #endif
 extern "C" int myo_adam_clip_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
-                                  float eps, float max_norm, float grad_scale, int* step, float* scratch, void* stream) {
+                                  float eps, float max_norm, float grad_scale, int* step, float* scratch, uint16_t* p_bf16,
+                                  void* stream) {
   if (!p || !g || !m || !v || !step || !scratch || n <= 0) return fail(MYO_E_ARG, "myo_adam_clip_step: bad arguments");
 #ifdef MYO_EMU
-  (void)lr; (void)b1; (void)b2; (void)eps; (void)max_norm; (void)grad_scale; (void)stream;
+  (void)lr; (void)b1; (void)b2; (void)eps; (void)max_norm; (void)grad_scale; (void)stream; (void)p_bf16;
   return fail(MYO_E_UNSUPPORTED, "myo_adam_clip_step is a GPU kernel");
 #else
   hipStream_t st = (hipStream_t)stream;
   const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
   hipLaunchKernelGGL(k_grad_sqnorm, dim3(MYO_SQN_BLOCKS), dim3(256), 0, st, g, n, grad_scale, scratch, step);
-  hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, max_norm, grad_scale, step, scratch);
+  hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, max_norm, grad_scale, step, scratch,
+                     (unsigned short*)p_bf16);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif

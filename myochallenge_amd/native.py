@@ -98,7 +98,7 @@ class NativeLib:
         L.myo_gae.argtypes = [vp] * 5 + [i32, i32, C.c_float, C.c_float, vp, vp, vp]
         L.myo_lstm_cell_fwd.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 6
         L.myo_lstm_cell_bwd.argtypes = [vp] * 7 + [i32] * 4 + [vp] * 3
-        L.myo_adam_clip_step.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, vp]
+        L.myo_adam_clip_step.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, vp, vp]
 
     def check(self, rc: int):
         if rc != 0:

@@ -144,6 +144,7 @@ class FlatAdam:
         self.m, self.v = torch.zeros_like(flat["p"]), torch.zeros_like(flat["p"])
         self._step = torch.zeros(2, dtype=torch.int32, device=dev)    # [committed, taken]
         self.sq = torch.zeros(64, device=dev)
+        self.shadow = None        # bf16 copy of the flat parameters kept in step by the Adam kernel (FusedPPOStep sets it)
 
     @property
     def step_count(self):
@@ -155,7 +156,8 @@ class FlatAdam:
         p = lambda t: C.c_void_p(t.data_ptr())
         self.lib.check(self.lib.L.myo_adam_clip_step(
             p(f["p"]), p(f["g"]), p(self.m), p(self.v), f["p"].numel(), self.lr, self.betas[0], self.betas[1],
-            self.eps, self.max_norm, float(grad_scale), p(self._step), p(self.sq), C.c_void_p(stream)))
+            self.eps, self.max_norm, float(grad_scale), p(self._step), p(self.sq),
+            p(self.shadow) if self.shadow is not None else None, C.c_void_p(stream)))
 
     def snapshot(self):
         return [t.clone() for t in (self.flat["p"], self.m, self.v, self._step)]
@@ -163,6 +165,8 @@ class FlatAdam:
     def restore(self, snap):
         for t, s in zip((self.flat["p"], self.m, self.v, self._step), snap):
             t.copy_(s)
+        if self.shadow is not None:
+            self.shadow.copy_(self.flat["p"])
 
 
 class FusedPPOStep:
@@ -173,6 +177,7 @@ class FusedPPOStep:
         assert not policy.recurrent
         self.policy, self.lib = policy, lib
         self.clip, self.ent, self.vf, self.split = float(clip_range), float(ent_coef), float(vf_coef), split_k
+        self.adam_syncs_shadow = False
         self.nets = _nets(policy)
         dev = policy.log_std.device
         self.master, self.half = [], []
@@ -346,7 +351,8 @@ class FusedPPOStep:
         s = self.split if (B % self.split == 0) else 1
         dev = x2.device
         stream = torch.cuda.current_stream(dev).cuda_stream
-        self.refresh_shadow()
+        if not self.adam_syncs_shadow:       # (PPO: the Adam kernel rewrites the bf16 shadow with the parameters)
+            self.refresh_shadow()
         saved, mean_h, value_h = self.trunk_heads(x2)
         h = saved[-1]
         pi_head, vf_head = self.nets["pi"][-1], self.nets["vf"][-1]

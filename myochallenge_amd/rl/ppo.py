@@ -90,6 +90,10 @@ class PPO:
                                        cfg.max_grad_norm)
             from .fused_mlp import FusedPPOStep
             self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
+            if len(self._fused.half) == 1:       # one bf16 shadow of the flat vector: Adam keeps it in step
+                self._flat_adam.shadow = self._fused.half[0]
+                self._fused.adam_syncs_shadow = True
+                self._fused.refresh_shadow()
         elif cfg.use_graphs and on_gpu:
             # recurrent policy: autograd does forward / BPTT, but on flat parameter / gradient vectors so that the
             # whole minibatch step (zero, forward, backward, clip + Adam) is ONE hipGraph (_train_recurrent_graphed)

@@ -131,7 +131,7 @@ def test_c_abi_argument_checks(emu_lib):
         (L.myo_relu_bwd_colsum_bf16, (null, null, 64, 256, null, null)),
         (L.myo_splitk_reduce, (null, 1, null, 2, 32, 256, null)),
         (L.myo_splitk_reduce2, (null, 1, null, 2, 32, 256, null, 0, null, 2, 64, 256, null)),
-        (L.myo_adam_clip_step, (null,) * 4 + (10,) + (f(0.1),) * 6 + (null,) * 3),
+        (L.myo_adam_clip_step, (null,) * 4 + (10,) + (f(0.1),) * 6 + (null,) * 4),
         (L.myo_gae, (null,) * 5 + (4, 4, f(0.99), f(0.95), null, null, null)),
         (L.myo_rollout_policy_input, (null, 4, 86, null, null, 2, null, null)),
         (L.myo_rollout_sample, (null, null, null, 4, 39, 1, null, null, null, null, null, null, 0, null)),

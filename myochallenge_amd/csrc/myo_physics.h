@@ -295,102 +295,110 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
     }
   }
   SYNC();
-  // Everything a body needs from the model tables is fetched ONCE, before the level loop (lane = body
-  // throughout): inside the loop the table loads would form a chain of 3-4 dependent global loads per
-  // tree level (depth -> joint address -> joint type -> qpos address -> qpos0).
-  LANE_VAR(int, k_depth); LANE_VAR(int, k_par); LANE_VAR(int, k_jn); LANE_VAR(int, k_ja);
-  LANE_VAR(int, k_jtype); LANE_VAR(int, k_qa);
-  LANE_VAR(T, k_q0);
-  LANE_VAR(T, k_bp0); LANE_VAR(T, k_bp1); LANE_VAR(T, k_bp2);
-  LANE_VAR(T, k_bq0); LANE_VAR(T, k_bq1); LANE_VAR(T, k_bq2); LANE_VAR(T, k_bq3);
-  LANE_VAR(T, k_ip0); LANE_VAR(T, k_ip1); LANE_VAR(T, k_ip2);
-  LANE_VAR(T, k_jp0); LANE_VAR(T, k_jp1); LANE_VAR(T, k_jp2);
-  LANE_VAR(T, k_ax0); LANE_VAR(T, k_ax1); LANE_VAR(T, k_ax2);
+  // Three stages instead of one walk down the tree with everything inside it (lane = body throughout):
+  //  1. parent-independent: every body composes, IN ITS PARENT'S FRAME, its offset (body_pos / body_quat) with
+  //     the rotations / translations of its own joints (the sin / cos of the joint angles, the anchor and axis
+  //     of every joint).  All table loads and all transcendentals happen here, for all bodies at once.
+  //  2. the level loop only chains poses: q = q_parent * q_local, p = p_parent + R(q_parent) p_local — one LDS
+  //     round trip and ~40 flops per tree level instead of the joint code.
+  //  3. parallel again: xmat, xipos, and the world anchors / axes from the parent's final pose.
+  // (mj_kinematics composes in the world frame; the two are the same maps, rounded differently.)
+  LANE_VAR(int, k_depth); LANE_VAR(int, k_par); LANE_VAR(int, k_jn); LANE_VAR(int, k_ja); LANE_VAR(int, k_free);
+  LANE_VAR(T, k_p0); LANE_VAR(T, k_p1); LANE_VAR(T, k_p2);
+  LANE_VAR(T, k_q0); LANE_VAR(T, k_q1); LANE_VAR(T, k_q2); LANE_VAR(T, k_q3);
   PHASE {
     const int b = lane;
-    LV(k_depth) = -1; LV(k_par) = 0; LV(k_jn) = 0; LV(k_ja) = 0; LV(k_jtype) = -1; LV(k_qa) = 0; LV(k_q0) = 0;
-    LV(k_bp0) = LV(k_bp1) = LV(k_bp2) = 0; LV(k_bq0) = 1; LV(k_bq1) = LV(k_bq2) = LV(k_bq3) = 0;
-    LV(k_ip0) = LV(k_ip1) = LV(k_ip2) = 0; LV(k_jp0) = LV(k_jp1) = LV(k_jp2) = 0; LV(k_ax0) = LV(k_ax1) = LV(k_ax2) = 0;
+    LV(k_depth) = -1; LV(k_par) = 0; LV(k_jn) = 0; LV(k_ja) = 0; LV(k_free) = 0;
+    LV(k_p0) = LV(k_p1) = LV(k_p2) = 0; LV(k_q0) = 1; LV(k_q1) = LV(k_q2) = LV(k_q3) = 0;
     if (b > 0 && b < M.nbody) {
-      LV(k_depth) = M.body_depth[b]; LV(k_par) = M.body_parentid[b]; LV(k_jn) = M.body_jntnum[b];
-      const int ja = M.body_jntadr[b];
-      LV(k_ja) = ja;
-      LV(k_bp0) = M.body_pos[3 * b]; LV(k_bp1) = M.body_pos[3 * b + 1]; LV(k_bp2) = M.body_pos[3 * b + 2];
-      LV(k_bq0) = M.body_quat[4 * b]; LV(k_bq1) = M.body_quat[4 * b + 1]; LV(k_bq2) = M.body_quat[4 * b + 2];
-      LV(k_bq3) = M.body_quat[4 * b + 3];
-      LV(k_ip0) = M.body_ipos[3 * b]; LV(k_ip1) = M.body_ipos[3 * b + 1]; LV(k_ip2) = M.body_ipos[3 * b + 2];
-      if (LV(k_jn) > 0) {               // first joint of the body (most bodies have exactly one)
+      const int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
+      LV(k_depth) = M.body_depth[b]; LV(k_par) = M.body_parentid[b]; LV(k_jn) = jn; LV(k_ja) = ja;
+      T p[3] = {M.body_pos[3 * b], M.body_pos[3 * b + 1], M.body_pos[3 * b + 2]};
+      T q[4] = {M.body_quat[4 * b], M.body_quat[4 * b + 1], M.body_quat[4 * b + 2], M.body_quat[4 * b + 3]};
+      if (jn == 1 && M.jnt_type[ja] == 0) {          // free joint: the pose is the state (parent = world)
         const int qa = M.jnt_qposadr[ja];
-        LV(k_jtype) = M.jnt_type[ja]; LV(k_qa) = qa; LV(k_q0) = M.qpos0[qa];
-        LV(k_jp0) = M.jnt_pos[3 * ja]; LV(k_jp1) = M.jnt_pos[3 * ja + 1]; LV(k_jp2) = M.jnt_pos[3 * ja + 2];
-        LV(k_ax0) = M.jnt_axis[3 * ja]; LV(k_ax1) = M.jnt_axis[3 * ja + 1]; LV(k_ax2) = M.jnt_axis[3 * ja + 2];
+        T qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
+        normalize4(qq);
+        for (int k = 0; k < 4; ++k) { s.qpos[qa + 3 + k] = qq[k]; q[k] = qq[k]; }
+        for (int k = 0; k < 3; ++k) { p[k] = s.qpos[qa + k]; S_XANCHOR(s)[3 * ja + k] = p[k]; }
+        S_XAXIS(s)[3 * ja] = 0; S_XAXIS(s)[3 * ja + 1] = 0; S_XAXIS(s)[3 * ja + 2] = 1;
+        LV(k_free) = 1;
+      } else {
+        for (int k = 0; k < jn; ++k) {
+          const int j = ja + k;
+          const int qa = M.jnt_qposadr[j], jtype = M.jnt_type[j];
+          const T jpos[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
+          const T jaxis[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
+          T R[9], anchor[3], axis[3];
+          quat2mat(R, q);
+          mulmatvec3(anchor, R, jpos);
+          anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
+          mulmatvec3(axis, R, jaxis);
+          for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = anchor[e]; S_XAXIS(s)[3 * j + e] = axis[e]; }   // parent frame for now
+          const T ang = s.qpos[qa] - M.qpos0[qa];
+          if (jtype == 2) {
+            p[0] += axis[0] * ang; p[1] += axis[1] * ang; p[2] += axis[2] * ang;
+          } else {
+            T ql[4], R2[9], t2[3];
+            axisangle2quat(ql, jaxis, ang);
+            mulquat(q, q, ql);
+            quat2mat(R2, q);
+            mulmatvec3(t2, R2, jpos);
+            p[0] = anchor[0] - t2[0]; p[1] = anchor[1] - t2[1]; p[2] = anchor[2] - t2[2];
+          }
+        }
       }
+      LV(k_p0) = p[0]; LV(k_p1) = p[1]; LV(k_p2) = p[2];
+      LV(k_q0) = q[0]; LV(k_q1) = q[1]; LV(k_q2) = q[2]; LV(k_q3) = q[3];
     }
   }
   for (int level = 1; level <= M.maxdepth; ++level) {
     PHASE {
       const int b = lane;
       if (LV(k_depth) == level) {
-        const int par = LV(k_par), jn = LV(k_jn), ja = LV(k_ja);
-        T p[3], q[4];
-        if (jn == 1 && LV(k_jtype) == 0) {
-          const int qa = LV(k_qa);
-          T qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
-          normalize4(qq);
-          for (int k = 0; k < 4; ++k) { s.qpos[qa + 3 + k] = qq[k]; q[k] = qq[k]; }
-          for (int k = 0; k < 3; ++k) { p[k] = s.qpos[qa + k]; S_XANCHOR(s)[3 * ja + k] = p[k]; }
-          S_XAXIS(s)[3 * ja] = 0; S_XAXIS(s)[3 * ja + 1] = 0; S_XAXIS(s)[3 * ja + 2] = 1;
-        } else {
-          T t[3];
-          const T bpos[3] = {LV(k_bp0), LV(k_bp1), LV(k_bp2)}, bquat[4] = {LV(k_bq0), LV(k_bq1), LV(k_bq2), LV(k_bq3)};
-          mulmatvec3(t, s.xmat + 9 * par, bpos);
-          p[0] = s.xpos[3 * par] + t[0]; p[1] = s.xpos[3 * par + 1] + t[1]; p[2] = s.xpos[3 * par + 2] + t[2];
-          mulquat(q, S_XQUAT(s) + 4 * par, bquat);
-          for (int k = 0; k < jn; ++k) {
-            const int j = ja + k;
-            int qa, jtype;
-            T jpos[3], jaxis[3], q0;
-            if (k == 0) {
-              qa = LV(k_qa); jtype = LV(k_jtype); q0 = LV(k_q0);
-              jpos[0] = LV(k_jp0); jpos[1] = LV(k_jp1); jpos[2] = LV(k_jp2);
-              jaxis[0] = LV(k_ax0); jaxis[1] = LV(k_ax1); jaxis[2] = LV(k_ax2);
-            } else {                    // further joints of a multi-joint body: fetched here (rare)
-              qa = M.jnt_qposadr[j]; jtype = M.jnt_type[j]; q0 = M.qpos0[qa];
-              for (int e = 0; e < 3; ++e) { jpos[e] = M.jnt_pos[3 * j + e]; jaxis[e] = M.jnt_axis[3 * j + e]; }
-            }
-            T R[9], anchor[3], axis[3];
-            quat2mat(R, q);
-            mulmatvec3(anchor, R, jpos);
-            anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
-            mulmatvec3(axis, R, jaxis);
-            for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = anchor[e]; S_XAXIS(s)[3 * j + e] = axis[e]; }
-            const T ang = s.qpos[qa] - q0;
-            if (jtype == 2) {
-              p[0] += axis[0] * ang; p[1] += axis[1] * ang; p[2] += axis[2] * ang;
-            } else {
-              T ql[4], R2[9], t2[3];
-              axisangle2quat(ql, jaxis, ang);
-              mulquat(q, q, ql);
-              quat2mat(R2, q);
-              mulmatvec3(t2, R2, jpos);
-              p[0] = anchor[0] - t2[0]; p[1] = anchor[1] - t2[1]; p[2] = anchor[2] - t2[2];
-            }
-          }
-        }
+        const int par = LV(k_par);
+        const T pl[3] = {LV(k_p0), LV(k_p1), LV(k_p2)}, ql[4] = {LV(k_q0), LV(k_q1), LV(k_q2), LV(k_q3)};
+        const T qp[4] = {S_XQUAT(s)[4 * par], S_XQUAT(s)[4 * par + 1], S_XQUAT(s)[4 * par + 2], S_XQUAT(s)[4 * par + 3]};
+        T Rp[9], t[3], q[4];
+        quat2mat(Rp, qp);
+        mulmatvec3(t, Rp, pl);
+        mulquat(q, qp, ql);
         normalize4(q);
-        for (int k = 0; k < 3; ++k) s.xpos[3 * b + k] = p[k];
+        for (int k = 0; k < 3; ++k) s.xpos[3 * b + k] = s.xpos[3 * par + k] + t[k];
         for (int k = 0; k < 4; ++k) S_XQUAT(s)[4 * b + k] = q[k];
-        T R[9];
-        quat2mat(R, q);
-        for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = R[k];
-        T t[3];
-        const T ipos[3] = {LV(k_ip0), LV(k_ip1), LV(k_ip2)};
-        mulmatvec3(t, R, ipos);
-        for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = p[k] + t[k];
       }
     }
     SYNC();
   }
+  PHASE {
+    const int b = lane;
+    if (b > 0 && b < M.nbody) {
+      const int par = LV(k_par), jn = LV(k_jn), ja = LV(k_ja);
+      const T q[4] = {S_XQUAT(s)[4 * b], S_XQUAT(s)[4 * b + 1], S_XQUAT(s)[4 * b + 2], S_XQUAT(s)[4 * b + 3]};
+      T R[9], t[3];
+      quat2mat(R, q);
+      for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = R[k];
+      const T ipos[3] = {M.body_ipos[3 * b], M.body_ipos[3 * b + 1], M.body_ipos[3 * b + 2]};
+      mulmatvec3(t, R, ipos);
+      for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = s.xpos[3 * b + k] + t[k];
+      if (!LV(k_free) && jn > 0) {                   // anchors / axes: parent frame -> world
+        const T qp[4] = {S_XQUAT(s)[4 * par], S_XQUAT(s)[4 * par + 1], S_XQUAT(s)[4 * par + 2], S_XQUAT(s)[4 * par + 3]};
+        const T pp[3] = {s.xpos[3 * par], s.xpos[3 * par + 1], s.xpos[3 * par + 2]};
+        T Rp[9];
+        quat2mat(Rp, qp);
+        for (int k = 0; k < jn; ++k) {
+          const int j = ja + k;
+          const T al[3] = {S_XANCHOR(s)[3 * j], S_XANCHOR(s)[3 * j + 1], S_XANCHOR(s)[3 * j + 2]};
+          const T xl[3] = {S_XAXIS(s)[3 * j], S_XAXIS(s)[3 * j + 1], S_XAXIS(s)[3 * j + 2]};
+          T aw[3], xw[3];
+          mulmatvec3(aw, Rp, al);
+          mulmatvec3(xw, Rp, xl);
+          for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = pp[e] + aw[e]; S_XAXIS(s)[3 * j + e] = xw[e]; }
+        }
+      }
+    }
+  }
+  SYNC();
 }
 
 // P2: mj_comPos — tree reference points, body inertias about them, dof motion axes

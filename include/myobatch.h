@@ -130,6 +130,12 @@ int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ba
  * delta along each non-zero local coordinate, capsule half-lengths grow by it.  (-1, -1) clears the group. */
 int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn);
 
+/* The model / task parameters of ONE batch per device sit in __constant__ memory; every launching entry point
+ * re-uploads them (on its stream) when another batch used the device in between.  A caller that REPLAYS a
+ * captured graph containing this batch's launches must call this first whenever other batches of the same
+ * process may have launched since (no-op if this batch is still the bound one). */
+int myo_batch_bind_constants(myo_batch* b, void* stream);
+
 /* forward dynamics of the current state with intermediates dumped for stage-wise parity
  * tests: out is dev double[N, myo_batch_dump_size()] ; layout by myo_batch_dump_offset(name).
  * names: ten_length ten_J(nt*nv) M(nv*nv) qfrc_bias qfrc_passive qfrc_actuator qacc_smooth

@@ -795,6 +795,15 @@ extern "C" int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn) {
   g_bound = nullptr;                 // the task block in __constant__ memory is re-uploaded at the next launch
   return MYO_OK;
 }
+extern "C" int myo_batch_bind_constants(myo_batch* b, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+#ifdef MYO_EMU
+  (void)stream;
+  return MYO_OK;
+#else
+  return bind_constants(b, (hipStream_t)stream);
+#endif
+}
 extern "C" int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ball_d, void* stream) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   be_stream st = (be_stream)stream;

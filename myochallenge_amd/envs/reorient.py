@@ -315,6 +315,7 @@ class ReorientVecEnv:
         graphable = self.use_graph and self.device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
         if graphable and self._graph is not None:
             self._act_static.copy_(a)
+            self.batch.bind_constants(self._stream())     # another batch (an eval env ...) may have launched since
             self._graph.replay()
         else:
             self._step_core(a)

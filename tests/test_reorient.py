@@ -259,3 +259,26 @@ def test_lstm_sequence_function_matches_autograd(device):
         outs.append((o.detach(), h.detach(), c.detach()) + tuple(torch.autograd.grad(loss, [gx, wt, h0, c0])))
     for a, b in zip(*outs):
         assert float((a - b).abs().max()) <= 2e-5 * (1 + float(b.abs().max()))
+
+
+@pytest.mark.gpu
+def test_graph_replayed_step_survives_another_batch_on_the_device(hip_lib):
+    """Model / task parameters of one batch at a time sit in __constant__ memory.  The reorient env replays its
+    step from a hipGraph: a second env (different model: the Baoding hand) launching in between must not change
+    what the replay computes."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    a = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=64, seed=9, dtype="f64")
+    b = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=64, seed=9, dtype="f64")
+    b.use_graph = False
+    other = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=32, seed=1)
+    a.reset_tensor(); b.reset_tensor(); other.reset_tensor()
+    gen = torch.Generator().manual_seed(0)
+    for k in range(5):
+        act = (torch.rand((64, 39), generator=gen) * 2 - 1).cuda()
+        a.step_tensor(act)
+        other.step_tensor(torch.zeros(32, 39, device="cuda"))        # rebinds the constants to the other batch
+        b.step_tensor(act)
+        other.step_tensor(torch.zeros(32, 39, device="cuda"))
+    torch.cuda.synchronize()
+    assert a._graph is not None and b._graph is None
+    assert torch.equal(a._qp, b._qp) and torch.equal(a._obs, b._obs) and torch.equal(a._rew, b._rew)

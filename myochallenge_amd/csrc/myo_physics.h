@@ -726,11 +726,12 @@ DEVFN void crb(const DevModel<T>& M_in, Scratch<T>& s_in) {
     if (b > 0 && b < M.nbody) {
       T acc[10];
       for (int k = 0; k < 10; ++k) acc[k] = 0;
-      unsigned long long sub = M.body_submask[b];
-      while (sub) {
-        const int c = myo_ffsll(sub);
-        sub &= sub - 1;
-        for (int k = 0; k < 10; ++k) acc[k] += S_CINERT(s)[10 * c + k];
+      const unsigned long long sub = M.body_submask[b];
+      // all bodies, membership as a select (wave-uniform reads, all in flight; see the RNE bias loop)
+#pragma unroll 4
+      for (int c = 1; c < M.nbody; ++c) {
+        const T in = ((sub >> c) & 1ull) ? (T)1 : (T)0;
+        for (int k = 0; k < 10; ++k) acc[k] += in * S_CINERT(s)[10 * c + k];
       }
       for (int k = 0; k < 10; ++k) S_CRB(s)[10 * b + k] = acc[k];
     }
@@ -1688,11 +1689,13 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
     const int d = lane;
     if (d < M.nv) {
       T f[6] = {0, 0, 0, 0, 0, 0};
-      unsigned long long sub = M.body_submask[M.dof_bodyid[d]];
-      while (sub) {
-        const int c = myo_ffsll(sub);
-        sub &= sub - 1;
-        for (int e = 0; e < 6; ++e) f[e] += S_CFRCB(s)[6 * c + e];
+      const unsigned long long sub = M.body_submask[M.dof_bodyid[d]];
+      // all bodies, membership as a select: the reads are wave-uniform and all in flight together, instead of
+      // one dependent round trip per subtree body on the lanes of the root dofs (18 bodies for the wrist)
+#pragma unroll 4
+      for (int c = 1; c < M.nbody; ++c) {
+        const T in = ((sub >> c) & 1ull) ? (T)1 : (T)0;
+        for (int e = 0; e < 6; ++e) f[e] += in * S_CFRCB(s)[6 * c + e];
       }
       T acc = 0;
       for (int e = 0; e < 6; ++e) acc += s.cdof[6 * d + e] * f[e];

@@ -114,6 +114,10 @@ int myo_batch_get_state(myo_batch* b, double* qpos, double* qvel, double* act, d
                         void* stream);
 int myo_batch_set_state(myo_batch* b, const double* qpos, const double* qvel, const double* act,
                         const double* time, void* stream);
+/* qacc_warmstart (dev double[N,nv]): the remaining piece of MuJoCo's integration state (mjData.qacc_warmstart
+ * seeds the Newton solver, so two steppers only retrace each other when it is copied along with qpos/qvel/act).
+ * Either pointer may be NULL. */
+int myo_batch_warmstart(myo_batch* b, double* get_qacc_warmstart, const double* set_qacc_warmstart, void* stream);
 
 /* per-env task parameters, explicit injection for parity tests (what reset() samples):
  * task_i  dev int32[N,2]  = which_task, counter

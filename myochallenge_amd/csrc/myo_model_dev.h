@@ -43,6 +43,12 @@
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
   X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(wr_p) X(wr_m) X(pc_f)
 
+// geometry tables of the HP stages (kinematic chain, contact / limit distances, observation): fp64 copies in
+// every build, named h_<array> (the fp64 stepper's h_ tables are its ordinary tables)
+#define MYO_MODEL_HP_ARRAYS(X)                                                                   \
+  X(qpos0) X(body_pos) X(body_quat) X(jnt_pos) X(jnt_axis) X(jnt_range) X(jnt_margin)            \
+  X(geom_pos) X(geom_mat) X(geom_size) X(geom_margin) X(geom_gap) X(site_pos)
+
 // Model table handle.  The tables are immutable for the lifetime of a batch, so the gfx950 build
 // reads them through the CONSTANT address space: a load with a wave-uniform index becomes a scalar
 // (SMEM) load instead of a 64-lane vector load, and LLVM may treat every table load as invariant
@@ -67,6 +73,7 @@ struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
   int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw;
   T timestep, tolerance, impratio, gravity[3], meaninertia;
+  double h_timestep;            // the integration step of the HP state update
 #define X(n) MyoCArr<int> n;
   MYO_MODEL_INT_ARRAYS(X)
 #undef X
@@ -75,6 +82,9 @@ struct DevModel {
 #undef X
 #define X(n) MyoCArr<T> n;
   MYO_MODEL_REAL_ARRAYS(X)
+#undef X
+#define X(n) MyoCArr<double> h_##n;
+  MYO_MODEL_HP_ARRAYS(X)
 #undef X
 };
 

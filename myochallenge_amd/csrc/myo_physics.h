@@ -24,6 +24,21 @@
 
 #define MYO_MINVAL ((T)1e-15)
 
+// Precision plan.  HP ("high precision") is fp64 in EVERY build.  k_step<double> computes everything in fp64.
+// k_step<float> is the MIXED stepper: what decides whether a trajectory stays on the reference's (fp64 MuJoCo)
+// trajectory is kept in HP, the bulk of the arithmetic runs in fp32:
+//   HP : the state (qpos, qvel, act, time) and its integration; the kinematic chain qpos -> body poses
+//        (xpos, xquat); contact and joint-limit DISTANCES (penetrations are ~1e-4 m on world coordinates of
+//        ~1.5 m, and MuJoCo's contact activation at dist < margin is discontinuous: a distance error of eps
+//        flips an activation with probability ~eps / (v h)); goal / target positions and the observation.
+//   T  : everything else — the fp32 stages work in coordinates SHIFTED by the env's origin O (the HP world
+//        position of the model's first tree root), so their positions are ~0.1 m and differences of positions
+//        (moment arms, contact offsets, tendon segments) keep ~1e-8 m.  The dynamics only sees differences
+//        of positions, so the shift changes nothing else.
+// Measured on the lane-serial build against the fp64 oracle: rounding every fp32-stage OUTPUT of the fp64
+// stepper to float moves a 60-env-step contact-rich trajectory by 5e-7; rounding xpos or xmat alone by 3e-3.
+typedef double HP;
+
 // Stage timers: compiled only into the diagnostic build (-DMYO_PROF, libmyobatch_prof.so); the
 // product build contains no stamp.  Lane 0 accumulates s_memtime deltas per stage in LDS.
 #if defined(MYO_PROF) && !defined(MYO_EMU)
@@ -31,7 +46,17 @@
 #else
 #define PROF(s, k)
 #endif
-#define MYO_HIDX(i, j) ((i) * MYO_NV_MAX + (j)) /* square row-major storage, lower triangle (i >= j) is used */
+// Storage of the dense system matrix H: lower triangle, row i padded to the next multiple of four columns
+// (rows 4q..4q+3 hold 4(q+1) entries each), so that a lane still fetches / stores its row with 16-byte
+// accesses: 720 entries for 36 dofs instead of 1296.  myo_hrow(i) = first entry of row i.
+#define MYO_H_SIZE (8 * (MYO_NV_MAX / 4) * (MYO_NV_MAX / 4 + 1))
+static_assert(MYO_NV_MAX % 4 == 0, "H rows are stored in groups of four");
+#ifdef MYO_EMU
+static inline int myo_hrow(int i) { const int q = i >> 2; return ((q * (q + 1)) << 3) + (((i & 3) * (q + 1)) << 2); }
+#else
+__device__ __forceinline__ constexpr int myo_hrow(int i) { const int q = i >> 2; return ((q * (q + 1)) << 3) + (((i & 3) * (q + 1)) << 2); }
+#endif
+#define MYO_HIDX(i, j) (myo_hrow(i) + (j)) /* i >= j */
 
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
@@ -58,39 +83,44 @@ struct ContactRec {
 
 template <typename T>
 struct RkScratch {                // RK4 stage storage, only instantiated by the RK4 kernels
-  T x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];
+  HP x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];
   T F[4][2 * MYO_NV_MAX + MYO_NU_MAX];
   T dX[2 * MYO_NV_MAX + MYO_NU_MAX];
 };
 
 template <typename T>
 struct Scratch {
-  // ---- state
-  T qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX], ctrl[MYO_NU_MAX], qacc_warm[MYO_NV_MAX];
-  T time;
+  // ---- state (HP in every build)
+  HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX];
+  HP time;
+  T ctrl[MYO_NU_MAX], qacc_warm[MYO_NV_MAX];
+  T qvelT_[sizeof(T) == sizeof(HP) ? 1 : MYO_NV_MAX];   // qvel as the fp32 stages read it (see S_QVELT)
   // ---- per-env parameters
-  T ball_mass[2], ball_fric[6], ball_size[2], target_xy[4], start_angle[2], x_radius, y_radius,
-      time_period, ep_ret;
+  HP ball_size[2], target_xy[4], start_angle[2], x_radius, y_radius, time_period, target_w[6];
+  T ball_mass[2], ball_fric[6], ep_ret;
   int which_task, counter, elapsed, episode, ep_len;
   // ---- position stage
   // (short-lived arrays alias longer-lived storage, see the S_* accessors below)
-  T xpos[MYO_NB_MAX * 3], xmat[MYO_NB_MAX * 9];
+  HP xpos[MYO_NB_MAX * 3], xquat[MYO_NB_MAX * 4];     // world poses of the bodies
+  HP origin[3];                                        // O: the fp32 stages' coordinates are world - O
+  T xposT_[sizeof(T) == sizeof(HP) ? 1 : MYO_NB_MAX * 3];   // xpos - O as the fp32 stages read it (see S_XPOST)
+  T xmat[MYO_NB_MAX * 9];
   T com[MYO_NB_MAX * 3];
   T cdof[MYO_NV_MAX * 6];
   T bvec[MYO_NB_MAX * 6];
   T ten_length[MYO_NT_MAX], ten_vel[MYO_NT_MAX], ten_J[MYO_NT_MAX * MYO_TJ_MAX];
   T act_force[MYO_NU_MAX], act_dot[MYO_NU_MAX];
   T qM[MYO_NM_MAX];
-  alignas(16) T H[MYO_NV_MAX * MYO_NV_MAX];   // dense system matrix / its Cholesky factor; hosts short-lived arrays too
+  alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
   T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
   T Ma[MYO_NV_MAX], grad[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX], tmpv[MYO_NV_MAX];
   // ---- constraints
   int ncon, nefc, nl, ntl, bad, solver_iter;
-  ContactRec<T> con[MYO_NCON_MAX];
+  alignas(8) ContactRec<T> con[MYO_NCON_MAX];
   int lim_id[MYO_NLIM_MAX];
   T lim_sgn[MYO_NLIM_MAX];
   T efc_D[MYO_NLIM_MAX], efc_B[MYO_NLIM_MAX], efc_kip[MYO_NLIM_MAX];   // limit rows only; contact rows: con[]
-  T efc_aref[MYO_NEFC_MAX], efc_jar[MYO_NEFC_MAX], efc_jv[MYO_NEFC_MAX], efc_force[MYO_NEFC_MAX];
+  alignas(8) T efc_aref[MYO_NEFC_MAX], efc_jar[MYO_NEFC_MAX], efc_jv[MYO_NEFC_MAX], efc_force[MYO_NEFC_MAX];
   unsigned char efc_active[MYO_NEFC_MAX];
   RkScratch<T>* rk;               // null unless the model integrates with RK4
   // ---- task layer
@@ -100,11 +130,19 @@ struct Scratch {
 #endif
 };
 
+// the fp32 stages' view of the two HP arrays they read every substep: a float copy in the mixed stepper,
+// the HP array itself in the fp64 stepper (O = 0 there)
+template <typename T> DEV T* S_QVELT(Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.qvel); else return s.qvelT_; }
+template <typename T> DEV const T* S_QVELT(const Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.qvel); else return s.qvelT_; }
+template <typename T> DEV T* S_XPOST(Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.xpos); else return s.xposT_; }
+template <typename T> DEV const T* S_XPOST(const Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.xpos); else return s.xposT_; }
+
 // Aliases: arrays whose lifetime ends before the buffer they live in is next written.
-//   H (36x36) is only live from qacc_smooth to the end of the solver / Euler solve.  Before that
+//   H is only live from qacc_smooth to the end of the solver / Euler solve.  Before that
 //   it hosts: cinert (com_pos..RNE), crb (CRB only) then cdof_dot (velocity stage), the passive /
 //   bias / actuator force vectors (velocity..actuation), and after the physics the observation.
-//   xquat (kinematics only) -> efc_jar;  xanchor / xaxis (until cdof is built) -> efc_aref / efc_jv
+//   xanchor / xaxis (until cdof is built) -> efc_aref / efc_jv; the kinematics stage keeps its HP joint
+//   anchors / axes (parent frame) in con[], which is dead until the collision stage
 //   xipos (until cinert is built) and the compaction prefix npre -> efc_force;  cfrcb (RNE) -> bvec
 #define S_CINERT(s) ((s).H)
 #define S_CRB(s) ((s).H + MYO_NB_MAX * 10)
@@ -113,20 +151,21 @@ struct Scratch {
 #define S_QFRC_BIAS(s) ((s).H + MYO_NB_MAX * 20 + MYO_NV_MAX)
 #define S_QFRC_ACTUATOR(s) ((s).H + MYO_NB_MAX * 20 + 2 * MYO_NV_MAX)
 #define S_OBS(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX)
-#define S_TWP(s) ((s).H + MYO_NB_MAX * 10)   /* tendon stage: world position of every path element, then the geom-wrap results */
-#define S_ACT_GF(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX)   /* gear * actuator force (actuation stage) */
-#define S_XQUAT(s) ((s).efc_jar)
+#define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage: position of every path element (con[] is dead until the collision stage) */
+#define S_ACT_GF(s) ((s).efc_force)   /* gear * actuator force (actuation stage; efc_force is first written by the solver) */
+#define S_KTMP(s) (reinterpret_cast<HP*>((s).con))   /* HP [2][MYO_NJ_MAX * 3] */
 #define S_XANCHOR(s) ((s).efc_aref)
 #define S_XAXIS(s) ((s).efc_jv)
 #define S_XIPOS(s) ((s).efc_force)
 #define S_NPRE(s) (reinterpret_cast<int*>((s).efc_force))
 #define S_CFRCB(s) ((s).bvec)
 #define S_CVEL(s) ((s).Ma)   /* body velocities (velocity stage) live in the solver vectors Ma,grad,search,Mv */
-static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX + MYO_NU_MAX <= MYO_NV_MAX * MYO_NV_MAX, "H aliases");
+static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_H_SIZE && MYO_NU_MAX <= MYO_NEFC_MAX, "H aliases");
 static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 1024 && MYO_NU_MAX <= 64, "packed actuator gather entries are 10 + 6 bits");
 static_assert(MYO_NV_MAX * 6 <= MYO_NB_MAX * 10, "cdof_dot fits where crb was");
 static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in Ma..Mv");
-static_assert(MYO_NB_MAX * 4 <= MYO_NEFC_MAX && MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX && 64 <= MYO_NEFC_MAX, "efc aliases");
+static_assert(MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX && 64 <= MYO_NEFC_MAX, "efc aliases");
+static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRec<float>), "kinematics temporaries fit in con[]");
 
 // ---- phase functions are real (non-inlined) functions in the gfx950 build: each gets its own
 // register allocation (the fully inlined kernel spilled ~170 VGPRs and was several MB of code).
@@ -245,9 +284,14 @@ template <typename T> DEV T body_mass_of(const DevModel<T>& M, const TaskDev& K,
   return M.body_mass[b];
 }
 template <typename T> DEV T geom_size0_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+  if (g == K.obj1_gid) return (T)s.ball_size[0];
+  if (g == K.obj2_gid) return (T)s.ball_size[1];
+  return M.geom_size[3 * g];
+}
+template <typename T> DEV HP geom_size0_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
   if (g == K.obj1_gid) return s.ball_size[0];
   if (g == K.obj2_gid) return s.ball_size[1];
-  return M.geom_size[3 * g];
+  return M.h_geom_size[3 * g];
 }
 template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, int k) {
   if (g >= K.objg_gid0 && g < K.objg_gidn) return s.ball_fric[k];
@@ -261,17 +305,36 @@ template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K,
 template <typename T> DEV void geom_lpos_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, T* out) {
   out[0] = M.geom_pos[3 * g]; out[1] = M.geom_pos[3 * g + 1]; out[2] = M.geom_pos[3 * g + 2];
   if (g >= K.objg_gid0 && g < K.objg_gidn) {
-    const T del = s.ball_size[0];
+    const T del = (T)s.ball_size[0];
+    for (int e = 0; e < 3; ++e) if (out[e] != 0) out[e] += out[e] > 0 ? del : -del;
+  }
+}
+template <typename T> DEV void geom_lpos_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, HP* out) {
+  out[0] = M.h_geom_pos[3 * g]; out[1] = M.h_geom_pos[3 * g + 1]; out[2] = M.h_geom_pos[3 * g + 2];
+  if (g >= K.objg_gid0 && g < K.objg_gidn) {
+    const HP del = s.ball_size[0];
     for (int e = 0; e < 3; ++e) if (out[e] != 0) out[e] += out[e] > 0 ? del : -del;
   }
 }
 template <typename T> DEV T geom_size1_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
   const T v = M.geom_size[3 * g + 1];
+  return (g >= K.objg_gid0 && g < K.objg_gidn && M.geom_type[g] == 3) ? v + (T)s.ball_size[0] : v;
+}
+template <typename T> DEV HP geom_size1_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+  const HP v = M.h_geom_size[3 * g + 1];
   return (g >= K.objg_gid0 && g < K.objg_gidn && M.geom_type[g] == 3) ? v + s.ball_size[0] : v;
 }
-// world position of a point given in body coordinates
+// position of a point given in body coordinates, in the fp32 stages' frame (world - O)
 template <typename T> DEV void body_point(const Scratch<T>& s, int b, const T* local, T* out) {
+  const T* xp = S_XPOST(s) + 3 * b;
   mulmatvec3(out, s.xmat + 9 * b, local);
+  out[0] += xp[0]; out[1] += xp[1]; out[2] += xp[2];
+}
+// the same in HP and in WORLD coordinates (contact distances, observation)
+template <typename T> DEV void body_point_hp(const Scratch<T>& s, int b, const HP* local, HP* out) {
+  HP R[9];
+  quat2mat(R, s.xquat + 4 * b);
+  mulmatvec3(out, R, local);
   out[0] += s.xpos[3 * b]; out[1] += s.xpos[3 * b + 1]; out[2] += s.xpos[3 * b + 2];
 }
 // translational Jacobian column of dof d for a world point p: cdof_lin + cdof_ang x (p - com)
@@ -283,16 +346,19 @@ template <typename T> DEV void jac_col(const DevModel<T>& M, const Scratch<T>& s
 }
 
 // ------------------------------------------------------------------------------------------
-// P2: kinematics (mj_kinematics)
+// P2: kinematics (mj_kinematics).  HP throughout (see the precision plan at the top): the chain qpos -> poses
+// is what contact distances are made of.  Leaves xpos / xquat (HP, world), and for the fp32 stages xmat, the
+// shifted positions S_XPOST / S_XIPOS and the shifted joint anchors / axes.
 template <typename T>
 DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
     if (lane == 0) {
-      s.xpos[0] = s.xpos[1] = s.xpos[2] = 0; S_XQUAT(s)[0] = 1; S_XQUAT(s)[1] = S_XQUAT(s)[2] = S_XQUAT(s)[3] = 0;
+      s.xpos[0] = s.xpos[1] = s.xpos[2] = 0; s.xquat[0] = 1; s.xquat[1] = s.xquat[2] = s.xquat[3] = 0;
       for (int k = 0; k < 9; ++k) s.xmat[k] = (k % 4 == 0) ? (T)1 : (T)0;
     }
+    if constexpr (sizeof(T) != sizeof(HP)) { if (lane < M.nv) s.qvelT_[lane] = (T)s.qvel[lane]; }
   }
   SYNC();
   // Three stages instead of one walk down the tree with everything inside it (lane = body throughout):
@@ -303,9 +369,11 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
   //     round trip and ~40 flops per tree level instead of the joint code.
   //  3. parallel again: xmat, xipos, and the world anchors / axes from the parent's final pose.
   // (mj_kinematics composes in the world frame; the two are the same maps, rounded differently.)
+  HP* const kanchor = S_KTMP(s);
+  HP* const kaxis = S_KTMP(s) + MYO_NJ_MAX * 3;
   LANE_VAR(int, k_depth); LANE_VAR(int, k_par); LANE_VAR(int, k_jn); LANE_VAR(int, k_ja); LANE_VAR(int, k_free);
-  LANE_VAR(T, k_p0); LANE_VAR(T, k_p1); LANE_VAR(T, k_p2);
-  LANE_VAR(T, k_q0); LANE_VAR(T, k_q1); LANE_VAR(T, k_q2); LANE_VAR(T, k_q3);
+  LANE_VAR(HP, k_p0); LANE_VAR(HP, k_p1); LANE_VAR(HP, k_p2);
+  LANE_VAR(HP, k_q0); LANE_VAR(HP, k_q1); LANE_VAR(HP, k_q2); LANE_VAR(HP, k_q3);
   PHASE {
     const int b = lane;
     LV(k_depth) = -1; LV(k_par) = 0; LV(k_jn) = 0; LV(k_ja) = 0; LV(k_free) = 0;
@@ -313,33 +381,33 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
     if (b > 0 && b < M.nbody) {
       const int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
       LV(k_depth) = M.body_depth[b]; LV(k_par) = M.body_parentid[b]; LV(k_jn) = jn; LV(k_ja) = ja;
-      T p[3] = {M.body_pos[3 * b], M.body_pos[3 * b + 1], M.body_pos[3 * b + 2]};
-      T q[4] = {M.body_quat[4 * b], M.body_quat[4 * b + 1], M.body_quat[4 * b + 2], M.body_quat[4 * b + 3]};
+      HP p[3] = {M.h_body_pos[3 * b], M.h_body_pos[3 * b + 1], M.h_body_pos[3 * b + 2]};
+      HP q[4] = {M.h_body_quat[4 * b], M.h_body_quat[4 * b + 1], M.h_body_quat[4 * b + 2], M.h_body_quat[4 * b + 3]};
       if (jn == 1 && M.jnt_type[ja] == 0) {          // free joint: the pose is the state (parent = world)
         const int qa = M.jnt_qposadr[ja];
-        T qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
+        HP qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
         normalize4(qq);
         for (int k = 0; k < 4; ++k) { s.qpos[qa + 3 + k] = qq[k]; q[k] = qq[k]; }
-        for (int k = 0; k < 3; ++k) { p[k] = s.qpos[qa + k]; S_XANCHOR(s)[3 * ja + k] = p[k]; }
-        S_XAXIS(s)[3 * ja] = 0; S_XAXIS(s)[3 * ja + 1] = 0; S_XAXIS(s)[3 * ja + 2] = 1;
+        for (int k = 0; k < 3; ++k) { p[k] = s.qpos[qa + k]; kanchor[3 * ja + k] = p[k]; }
+        kaxis[3 * ja] = 0; kaxis[3 * ja + 1] = 0; kaxis[3 * ja + 2] = 1;
         LV(k_free) = 1;
       } else {
         for (int k = 0; k < jn; ++k) {
           const int j = ja + k;
           const int qa = M.jnt_qposadr[j], jtype = M.jnt_type[j];
-          const T jpos[3] = {M.jnt_pos[3 * j], M.jnt_pos[3 * j + 1], M.jnt_pos[3 * j + 2]};
-          const T jaxis[3] = {M.jnt_axis[3 * j], M.jnt_axis[3 * j + 1], M.jnt_axis[3 * j + 2]};
-          T R[9], anchor[3], axis[3];
+          const HP jpos[3] = {M.h_jnt_pos[3 * j], M.h_jnt_pos[3 * j + 1], M.h_jnt_pos[3 * j + 2]};
+          const HP jaxis[3] = {M.h_jnt_axis[3 * j], M.h_jnt_axis[3 * j + 1], M.h_jnt_axis[3 * j + 2]};
+          HP R[9], anchor[3], axis[3];
           quat2mat(R, q);
           mulmatvec3(anchor, R, jpos);
           anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
           mulmatvec3(axis, R, jaxis);
-          for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = anchor[e]; S_XAXIS(s)[3 * j + e] = axis[e]; }   // parent frame for now
-          const T ang = s.qpos[qa] - M.qpos0[qa];
+          for (int e = 0; e < 3; ++e) { kanchor[3 * j + e] = anchor[e]; kaxis[3 * j + e] = axis[e]; }   // parent frame for now
+          const HP ang = s.qpos[qa] - M.h_qpos0[qa];
           if (jtype == 2) {
             p[0] += axis[0] * ang; p[1] += axis[1] * ang; p[2] += axis[2] * ang;
           } else {
-            T ql[4], R2[9], t2[3];
+            HP ql[4], R2[9], t2[3];
             axisangle2quat(ql, jaxis, ang);
             mulquat(q, q, ql);
             quat2mat(R2, q);
@@ -357,43 +425,53 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
       const int b = lane;
       if (LV(k_depth) == level) {
         const int par = LV(k_par);
-        const T pl[3] = {LV(k_p0), LV(k_p1), LV(k_p2)}, ql[4] = {LV(k_q0), LV(k_q1), LV(k_q2), LV(k_q3)};
-        const T qp[4] = {S_XQUAT(s)[4 * par], S_XQUAT(s)[4 * par + 1], S_XQUAT(s)[4 * par + 2], S_XQUAT(s)[4 * par + 3]};
-        T Rp[9], t[3], q[4];
+        const HP pl[3] = {LV(k_p0), LV(k_p1), LV(k_p2)}, ql[4] = {LV(k_q0), LV(k_q1), LV(k_q2), LV(k_q3)};
+        const HP qp[4] = {s.xquat[4 * par], s.xquat[4 * par + 1], s.xquat[4 * par + 2], s.xquat[4 * par + 3]};
+        HP Rp[9], t[3], q[4];
         quat2mat(Rp, qp);
         mulmatvec3(t, Rp, pl);
         mulquat(q, qp, ql);
         normalize4(q);
         for (int k = 0; k < 3; ++k) s.xpos[3 * b + k] = s.xpos[3 * par + k] + t[k];
-        for (int k = 0; k < 4; ++k) S_XQUAT(s)[4 * b + k] = q[k];
+        for (int k = 0; k < 4; ++k) s.xquat[4 * b + k] = q[k];
       }
     }
     SYNC();
   }
+  // O = world position of the first tree root (body 1), fp32-representable so that xpos - O is exact in HP
+  PHASE {
+    if (lane < 3) s.origin[lane] = (sizeof(T) != sizeof(HP) && M.nbody > 1) ? (HP)(float)s.xpos[3 + lane] : (HP)0;
+  }
+  SYNC();
   PHASE {
     const int b = lane;
+    if (b < M.nbody) {
+      if constexpr (sizeof(T) != sizeof(HP)) { for (int k = 0; k < 3; ++k) s.xposT_[3 * b + k] = (T)(s.xpos[3 * b + k] - s.origin[k]); }
+    }
     if (b > 0 && b < M.nbody) {
       const int par = LV(k_par), jn = LV(k_jn), ja = LV(k_ja);
-      const T q[4] = {S_XQUAT(s)[4 * b], S_XQUAT(s)[4 * b + 1], S_XQUAT(s)[4 * b + 2], S_XQUAT(s)[4 * b + 3]};
-      T R[9], t[3];
+      const HP q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+      HP R[9], t[3];
       quat2mat(R, q);
-      for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = R[k];
-      const T ipos[3] = {M.body_ipos[3 * b], M.body_ipos[3 * b + 1], M.body_ipos[3 * b + 2]};
+      for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = (T)R[k];
+      const HP ipos[3] = {(HP)M.body_ipos[3 * b], (HP)M.body_ipos[3 * b + 1], (HP)M.body_ipos[3 * b + 2]};
       mulmatvec3(t, R, ipos);
-      for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = s.xpos[3 * b + k] + t[k];
-      if (!LV(k_free) && jn > 0) {                   // anchors / axes: parent frame -> world
-        const T qp[4] = {S_XQUAT(s)[4 * par], S_XQUAT(s)[4 * par + 1], S_XQUAT(s)[4 * par + 2], S_XQUAT(s)[4 * par + 3]};
-        const T pp[3] = {s.xpos[3 * par], s.xpos[3 * par + 1], s.xpos[3 * par + 2]};
-        T Rp[9];
+      for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = (T)(s.xpos[3 * b + k] - s.origin[k] + t[k]);
+      if (LV(k_free)) {
+        for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * ja + e] = (T)(kanchor[3 * ja + e] - s.origin[e]); S_XAXIS(s)[3 * ja + e] = (T)kaxis[3 * ja + e]; }
+      } else if (jn > 0) {                           // anchors / axes: parent frame -> world
+        const HP qp[4] = {s.xquat[4 * par], s.xquat[4 * par + 1], s.xquat[4 * par + 2], s.xquat[4 * par + 3]};
+        const HP pp[3] = {s.xpos[3 * par] - s.origin[0], s.xpos[3 * par + 1] - s.origin[1], s.xpos[3 * par + 2] - s.origin[2]};
+        HP Rp[9];
         quat2mat(Rp, qp);
         for (int k = 0; k < jn; ++k) {
           const int j = ja + k;
-          const T al[3] = {S_XANCHOR(s)[3 * j], S_XANCHOR(s)[3 * j + 1], S_XANCHOR(s)[3 * j + 2]};
-          const T xl[3] = {S_XAXIS(s)[3 * j], S_XAXIS(s)[3 * j + 1], S_XAXIS(s)[3 * j + 2]};
-          T aw[3], xw[3];
+          const HP al[3] = {kanchor[3 * j], kanchor[3 * j + 1], kanchor[3 * j + 2]};
+          const HP xl[3] = {kaxis[3 * j], kaxis[3 * j + 1], kaxis[3 * j + 2]};
+          HP aw[3], xw[3];
           mulmatvec3(aw, Rp, al);
           mulmatvec3(xw, Rp, xl);
-          for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = pp[e] + aw[e]; S_XAXIS(s)[3 * j + e] = xw[e]; }
+          for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * j + e] = (T)(pp[e] + aw[e]); S_XAXIS(s)[3 * j + e] = (T)xw[e]; }
         }
       }
     }
@@ -512,8 +590,9 @@ template <typename T> DEV T wrap_circle(T* pnt, const T* dd, const T* sd, int ha
   const bool first = good[0] > good[1];          // selects, not sol[i]: a run-time index would move sol to private memory
   for (int k = 0; k < 4; ++k) pnt[k] = first ? sol[0][k] : sol[1][k];
   if (seg_intersect(dd, pnt, dd + 2, pnt + 2)) return -1;
-  const T c = tclamp((pnt[0] * pnt[2] + pnt[1] * pnt[3]) / sqrad, (T)-1, (T)1);
-  return rad * acos(c);
+  // arc angle between the two tangent points (both on the circle): atan2(|cross|, dot) — the same angle as
+  // mju_wrap's acos(dot / r^2), without its square-root loss of precision at small wrap angles (fp32)
+  return rad * atan2(fabs(pnt[0] * pnt[3] - pnt[1] * pnt[2]), pnt[0] * pnt[2] + pnt[1] * pnt[3]);
 }
 
 template <typename T>
@@ -640,17 +719,23 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
     for (int k = lane; k < M.ngw; k += 64) {
       const int w = M.gw_elem[k];
       const int body = M.wr_i[8 * w + 1], type = M.wr_i[8 * w], geom = M.wr_i[8 * w + 2], side_body = M.wr_i[8 * w + 3];
-      T gmat[9], gm[9], side[3] = {0, 0, 0}, pts[6];
-      for (int e = 0; e < 9; ++e) gm[e] = M.wr_m[12 * w + e];
-      mulmat3(gmat, s.xmat + 9 * body, gm);
+      // The wrap solver runs in HP on the (T) staged points: its branches are geometric predicates (point inside
+      // the circle, tangent segments crossing, which of the two tangent pairs) that sit on a knife edge exactly
+      // when a wrap engages — the wrap length is continuous there, but an fp32 evaluation of the predicates picks
+      // the wrong tangent pair (measured: seg_intersect flips on a 7e-7 m wrap and the path goes the long way round).
+      HP gmat[9], gm[9], bm[9], side[3] = {0, 0, 0}, pts[6], x0[3], x1[3], gp[3];
+      for (int e = 0; e < 9; ++e) { gm[e] = (HP)M.wr_m[12 * w + e]; bm[e] = (HP)s.xmat[9 * body + e]; }
+      mulmat3(gmat, bm, gm);
       if (side_body >= 0) {
         const T sl[3] = {M.wr_m[12 * w + 9], M.wr_m[12 * w + 10], M.wr_m[12 * w + 11]};
-        body_point(s, side_body, sl, side);
+        T sd[3];
+        body_point(s, side_body, sl, sd);
+        for (int e = 0; e < 3; ++e) side[e] = (HP)sd[e];
       }
-      const T wlen = wrap_geom(pts, wp + 3 * (w - 1), wp + 3 * (w + 1), wp + 3 * w, gmat, geom_size0_of(M, K, s, geom), type, side,
-                               side_body >= 0);
+      for (int e = 0; e < 3; ++e) { x0[e] = (HP)wp[3 * (w - 1) + e]; x1[e] = (HP)wp[3 * (w + 1) + e]; gp[e] = (HP)wp[3 * w + e]; }
+      const T wlen = (T)wrap_geom(pts, x0, x1, gp, gmat, (HP)geom_size0_of(M, K, s, geom), type, side, side_body >= 0);
       wres[7 * k] = wlen;
-      for (int e = 0; e < 6; ++e) wres[7 * k + 1 + e] = pts[e];
+      for (int e = 0; e < 6; ++e) wres[7 * k + 1 + e] = (T)pts[e];
     }
   }
   SYNC();
@@ -796,15 +881,15 @@ DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* diag_
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (lane < MYO_NV_MAX) {       // lane = row: 16-byte stores; identity on the padding rows
-      T* row = s.H + lane * MYO_NV_MAX;
+    // flat clear with 16-byte stores
+    struct alignas(16) Q4 { T a, b, c, d; };
+    Q4* h4 = reinterpret_cast<Q4*>(s.H);
 #pragma unroll
-      for (int q = 0; q < MYO_NV_MAX; ++q) row[q] = 0;
-      if (lane >= M.nv) row[lane] = 1;
-    }
+    for (int k = 0; k < (MYO_H_SIZE / 4 + 63) / 64; ++k) { const int e = lane + 64 * k; if (e < MYO_H_SIZE / 4) h4[e] = Q4{0, 0, 0, 0}; }
   }
   SYNC();
   PHASE {
+    if (lane >= M.nv && lane < MYO_NV_MAX) s.H[MYO_HIDX(lane, lane)] = 1;   // identity on the padding rows
     constexpr int NE = (MYO_NM_MAX + 63) / 64;
     int pk[NE];
 #pragma unroll
@@ -910,7 +995,9 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   const int row = lane < N ? lane : N - 1;          // lanes >= N shadow the last row and never store
   V2 a2[N / 2];
   {
-    const V4* hr = reinterpret_cast<const V4*>(s.H + row * MYO_NV_MAX);
+    // packed row (MYO_HIDX): N/4 vectors from the row's first entry; what lies beyond the row's own 4(row/4 + 1)
+    // entries belongs to later rows (always inside H: myo_hrow(35) + 36 = MYO_H_SIZE) and lands above the diagonal
+    const V4* hr = reinterpret_cast<const V4*>(s.H + myo_hrow(row));
 #pragma unroll
     for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
   }
@@ -1041,16 +1128,16 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   }
   // transpose through LDS: lane i needs column i of L
   if (lane < N) {
-    V4* hw = reinterpret_cast<V4*>(s.H + lane * MYO_NV_MAX);
+    V4* hw = reinterpret_cast<V4*>(s.H + myo_hrow(lane));
 #pragma unroll
-    for (int q = 0; q < N / 4; ++q) hw[q] = V4{a2[2 * q].x, a2[2 * q].y, a2[2 * q + 1].x, a2[2 * q + 1].y};
+    for (int q = 0; q < N / 4; ++q) if (q <= (lane >> 2)) hw[q] = V4{a2[2 * q].x, a2[2 * q].y, a2[2 * q + 1].x, a2[2 * q + 1].y};
   }
   __syncthreads();
   T c[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     MYO_OPAQUE_LANE(l)
-    const T v = s.H[j * MYO_NV_MAX + row];
+    const T v = s.H[myo_hrow(j) + row];               // L[j][row]; lanes beyond row j's storage read a later row and drop it
     c[j] = (j > l) ? v : (T)0;
   }
   // backward substitution  L' x = y
@@ -1088,8 +1175,11 @@ DEV void chol_factor_solve(Scratch<T>& s, T* x, int n, int lead) {
 }
 
 // ------------------------------------------------------------------------------------------
-// P6: collision (narrow phase per candidate pair; lanes = pairs)
-template <typename T> struct ContactTmp { T dist[2], pos[6], nrm[6]; int n; };
+// P6: collision (narrow phase per candidate pair; lanes = pairs).  HP and world coordinates: the contact
+// distance decides activation (dist < margin, discontinuous in MuJoCo's soft-contact model) and the spring
+// term, and it is a 1e-4 m difference of 1.5 m coordinates.  What leaves this stage for the fp32 stages is
+// the distance itself, the normal, and the contact point relative to O.
+struct ContactTmp { HP dist[2], pos[6], nrm[6]; int n; };
 
 template <typename T> DEV void make_frame(T* f) {
   normalize3(f);
@@ -1100,112 +1190,114 @@ template <typename T> DEV void make_frame(T* f) {
   normalize3(f + 3);
   cross3(f + 6, f, f + 3);
 }
-template <typename T>
-DEV int sphere_sphere(T* dist, T* pos, T* n, const T* c1, T r1, const T* c2, T r2, T margin) {
-  const T dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
-  const T cd = norm3(dif);
+DEV int sphere_sphere(HP* dist, HP* pos, HP* n, const HP* c1, HP r1, const HP* c2, HP r2, HP margin) {
+  const HP dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
+  const HP cd = norm3(dif);
   if (cd - r1 - r2 > margin) return 0;
-  if (cd < MYO_MINVAL) { n[0] = 1; n[1] = 0; n[2] = 0; } else { n[0] = dif[0] / cd; n[1] = dif[1] / cd; n[2] = dif[2] / cd; }
+  if (cd < (HP)1e-15) { n[0] = 1; n[1] = 0; n[2] = 0; } else { n[0] = dif[0] / cd; n[1] = dif[1] / cd; n[2] = dif[2] / cd; }
   *dist = cd - r1 - r2;
-  for (int k = 0; k < 3; ++k) pos[k] = c1[k] + n[k] * (r1 + (T)0.5 * (*dist));
+  for (int k = 0; k < 3; ++k) pos[k] = c1[k] + n[k] * (r1 + (HP)0.5 * (*dist));
   return 1;
 }
-template <typename T> DEV void seg_nearest(T* out, const T* c, const T* axis, T half, const T* p) {
-  T t = (p[0] - c[0]) * axis[0] + (p[1] - c[1]) * axis[1] + (p[2] - c[2]) * axis[2];
+DEV void seg_nearest(HP* out, const HP* c, const HP* axis, HP half, const HP* p) {
+  HP t = (p[0] - c[0]) * axis[0] + (p[1] - c[1]) * axis[1] + (p[2] - c[2]) * axis[2];
   t = tclamp(t, -half, half);
   for (int k = 0; k < 3; ++k) out[k] = c[k] + t * axis[k];
 }
 
 template <typename T>
-DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g1, int g2, T margin,
-                      ContactTmp<T>& o) {
+DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g1, int g2, HP margin,
+                      ContactTmp& o) {
   const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
   const int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-  T p1[3], p2[3], R1[9], R2[9], l1[3], l2[3];
-  geom_lpos_of(M, K, s, g1, l1);
-  geom_lpos_of(M, K, s, g2, l2);
-  body_point(s, b1, l1, p1);
-  body_point(s, b2, l2, p2);
-  mulmat3(R1, s.xmat + 9 * b1, M.geom_mat + 9 * g1);
-  mulmat3(R2, s.xmat + 9 * b2, M.geom_mat + 9 * g2);
-  const T s1[3] = {geom_size0_of(M, K, s, g1), geom_size1_of(M, K, s, g1), M.geom_size[3 * g1 + 2]};
-  const T s2[3] = {geom_size0_of(M, K, s, g2), geom_size1_of(M, K, s, g2), M.geom_size[3 * g2 + 2]};
+  HP p1[3], p2[3], B1[9], B2[9], R1[9], R2[9], l1[3], l2[3];
+  geom_lpos_hp(M, K, s, g1, l1);
+  geom_lpos_hp(M, K, s, g2, l2);
+  quat2mat(B1, s.xquat + 4 * b1);
+  quat2mat(B2, s.xquat + 4 * b2);
+  mulmatvec3(p1, B1, l1);
+  mulmatvec3(p2, B2, l2);
+  for (int k = 0; k < 3; ++k) { p1[k] += s.xpos[3 * b1 + k]; p2[k] += s.xpos[3 * b2 + k]; }
+  mulmat3(R1, B1, M.h_geom_mat + 9 * g1);
+  mulmat3(R2, B2, M.h_geom_mat + 9 * g2);
+  const HP s1[3] = {geom_size0_hp(M, K, s, g1), geom_size1_hp(M, K, s, g1), M.h_geom_size[3 * g1 + 2]};
+  const HP s2[3] = {geom_size0_hp(M, K, s, g2), geom_size1_hp(M, K, s, g2), M.h_geom_size[3 * g2 + 2]};
   o.n = 0;
   if (t1 == 0 && t2 == 2) {
-    const T n[3] = {R1[2], R1[5], R1[8]};
-    const T dd = (p2[0] - p1[0]) * n[0] + (p2[1] - p1[1]) * n[1] + (p2[2] - p1[2]) * n[2] - s2[0];
+    const HP n[3] = {R1[2], R1[5], R1[8]};
+    const HP dd = (p2[0] - p1[0]) * n[0] + (p2[1] - p1[1]) * n[1] + (p2[2] - p1[2]) * n[2] - s2[0];
     if (dd > margin) return;
     o.dist[0] = dd;
-    for (int k = 0; k < 3; ++k) { o.nrm[k] = n[k]; o.pos[k] = p2[k] - n[k] * (s2[0] + (T)0.5 * dd); }
+    for (int k = 0; k < 3; ++k) { o.nrm[k] = n[k]; o.pos[k] = p2[k] - n[k] * (s2[0] + (HP)0.5 * dd); }
     o.n = 1;
   } else if (t1 == 0 && t2 == 3) {
     // both capsule ends against the plane; results are placed with compile-time slot indices (a run-time
     // slot index would put the whole ContactTmp into private memory)
-    const T n[3] = {R1[2], R1[5], R1[8]}, ax[3] = {R2[2], R2[5], R2[8]};
-    T c0[3], c1[3];
+    const HP n[3] = {R1[2], R1[5], R1[8]}, ax[3] = {R2[2], R2[5], R2[8]};
+    HP c0[3], c1[3];
     for (int k = 0; k < 3; ++k) { c0[k] = p2[k] + s2[1] * ax[k]; c1[k] = p2[k] - s2[1] * ax[k]; }
-    const T d0 = (c0[0] - p1[0]) * n[0] + (c0[1] - p1[1]) * n[1] + (c0[2] - p1[2]) * n[2] - s2[0];
-    const T d1 = (c1[0] - p1[0]) * n[0] + (c1[1] - p1[1]) * n[1] + (c1[2] - p1[2]) * n[2] - s2[0];
+    const HP d0 = (c0[0] - p1[0]) * n[0] + (c0[1] - p1[1]) * n[1] + (c0[2] - p1[2]) * n[2] - s2[0];
+    const HP d1 = (c1[0] - p1[0]) * n[0] + (c1[1] - p1[1]) * n[1] + (c1[2] - p1[2]) * n[2] - s2[0];
     const int v0 = !(d0 > margin), v1 = !(d1 > margin);
-    const T da = v0 ? d0 : d1;
+    const HP da = v0 ? d0 : d1;
     o.dist[0] = da;
     o.dist[1] = d1;
     for (int k = 0; k < 3; ++k) {
       o.nrm[k] = n[k]; o.nrm[3 + k] = n[k];
-      o.pos[k] = (v0 ? c0[k] : c1[k]) - n[k] * (s2[0] + (T)0.5 * da);
-      o.pos[3 + k] = c1[k] - n[k] * (s2[0] + (T)0.5 * d1);
+      o.pos[k] = (v0 ? c0[k] : c1[k]) - n[k] * (s2[0] + (HP)0.5 * da);
+      o.pos[3 + k] = c1[k] - n[k] * (s2[0] + (HP)0.5 * d1);
     }
     o.n = v0 + v1;
   } else if (t1 == 2 && t2 == 2) {
     o.n = sphere_sphere(o.dist, o.pos, o.nrm, p1, s1[0], p2, s2[0], margin);
   } else if (t1 == 2 && t2 == 3) {
-    const T ax[3] = {R2[2], R2[5], R2[8]};
-    T q[3];
+    const HP ax[3] = {R2[2], R2[5], R2[8]};
+    HP q[3];
     seg_nearest(q, p2, ax, s2[1], p1);
     o.n = sphere_sphere(o.dist, o.pos, o.nrm, p1, s1[0], q, s2[0], margin);
   } else if (t1 == 3 && t2 == 3) {
-    const T a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
-    const T dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    const T ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
-    const T u = -dot3(a1, dif), v = dot3(a2, dif);
-    const T det = ma * mc - mb * mb;
-    T x1, x2;
-    if (fabs(det) < (T)1e-12) { x1 = 0; x2 = v / mc; } else { x1 = (mc * u - mb * v) / det; x2 = (ma * v - mb * u) / det; }
+    const HP a1[3] = {R1[2], R1[5], R1[8]}, a2[3] = {R2[2], R2[5], R2[8]};
+    const HP dif[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const HP ma = dot3(a1, a1), mb = -dot3(a1, a2), mc = dot3(a2, a2);
+    const HP u = -dot3(a1, dif), v = dot3(a2, dif);
+    const HP det = ma * mc - mb * mb;
+    HP x1, x2;
+    if (fabs(det) < (HP)1e-12) { x1 = 0; x2 = v / mc; } else { x1 = (mc * u - mb * v) / det; x2 = (ma * v - mb * u) / det; }
     x1 = tclamp(x1, -s1[1], s1[1]);
     x2 = tclamp(x2, -s2[1], s2[1]);
     (void)x2;
-    T q1[3], q2[3];
+    HP q1[3], q2[3];
     for (int k = 0; k < 3; ++k) q1[k] = p1[k] + x1 * a1[k];
     seg_nearest(q2, p2, a2, s2[1], q1);
     seg_nearest(q1, p1, a1, s1[1], q2);
     o.n = sphere_sphere(o.dist, o.pos, o.nrm, q1, s1[0], q2, s2[0], margin);
   } else if (t1 == 2 && t2 == 6) {
-    const T t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    T c[3], cl[3];
+    const HP t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    HP c[3], cl[3];
     mulmatTvec3(c, R2, t);
     int inside = 1;
     for (int k = 0; k < 3; ++k) {
       cl[k] = c[k];
       if (cl[k] > s2[k]) { cl[k] = s2[k]; inside = 0; } else if (cl[k] < -s2[k]) { cl[k] = -s2[k]; inside = 0; }
     }
-    T nl[3], dd;
+    HP nl[3], dd;
     if (!inside) {
-      const T df[3] = {cl[0] - c[0], cl[1] - c[1], cl[2] - c[2]};
-      const T dn = norm3(df);
+      const HP df[3] = {cl[0] - c[0], cl[1] - c[1], cl[2] - c[2]};
+      const HP dn = norm3(df);
       dd = dn - s1[0];
       if (dd > margin) return;
       nl[0] = df[0] / dn; nl[1] = df[1] / dn; nl[2] = df[2] / dn;
     } else {
       int kb = 0;
-      T best = (T)1e30;
-      for (int k = 0; k < 3; ++k) { const T e = s2[k] - fabs(c[k]); if (e < best) { best = e; kb = k; } }
-      const T ckb = kb == 0 ? c[0] : (kb == 1 ? c[1] : c[2]);
-      for (int k = 0; k < 3; ++k) nl[k] = (k == kb) ? (ckb > 0 ? (T)-1 : (T)1) : (T)0;
+      HP best = (HP)1e30;
+      for (int k = 0; k < 3; ++k) { const HP e = s2[k] - fabs(c[k]); if (e < best) { best = e; kb = k; } }
+      const HP ckb = kb == 0 ? c[0] : (kb == 1 ? c[1] : c[2]);
+      for (int k = 0; k < 3; ++k) nl[k] = (k == kb) ? (ckb > 0 ? (HP)-1 : (HP)1) : (HP)0;
       dd = -best - s1[0];
     }
     mulmatvec3(o.nrm, R2, nl);
     o.dist[0] = dd;
-    for (int k = 0; k < 3; ++k) o.pos[k] = p1[k] + o.nrm[k] * (s1[0] + (T)0.5 * dd);
+    for (int k = 0; k < 3; ++k) o.pos[k] = p1[k] + o.nrm[k] * (s1[0] + (HP)0.5 * dd);
     o.n = 1;
   }
 }
@@ -1255,9 +1347,11 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     int c = 0;
     T a = 0, b = 0;
     if (j < M.njnt && M.jnt_limited[j] && M.jnt_type[j] != 0) {
-      const T q = s.qpos[M.jnt_qposadr[j]];
-      a = q - M.jnt_range[2 * j]; b = M.jnt_range[2 * j + 1] - q;
-      c = (a < M.jnt_margin[j] ? 1 : 0) + (b < M.jnt_margin[j] ? 1 : 0);
+      // distances and the activation tests in HP, from the HP state
+      const HP q = s.qpos[M.jnt_qposadr[j]];
+      const HP ah = q - M.h_jnt_range[2 * j], bh = M.h_jnt_range[2 * j + 1] - q, mh = M.h_jnt_margin[j];
+      c = (ah < mh ? 1 : 0) + (bh < mh ? 1 : 0);
+      a = (T)(ah - mh); b = (T)(bh - mh);      // kept as dist - margin
     }
     LV(cnt) = c; LV(dlo) = a; LV(dhi) = b;
   }
@@ -1266,15 +1360,16 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     const int j = lane;
     if (LV(cnt) > 0) {
       int r = S_NPRE(s)[lane];
-      const T mg = M.jnt_margin[j];
+      const HP q = s.qpos[M.jnt_qposadr[j]], mh = M.h_jnt_margin[j];
+      const int on_lo = (q - M.h_jnt_range[2 * j]) < mh, on_hi = (M.h_jnt_range[2 * j + 1] - q) < mh;
       for (int side = 0; side < 2; ++side) {
-        const T dist = side ? LV(dhi) : LV(dlo);
-        if (dist < mg && r < MYO_NLIM_MAX) {
+        const T dm = side ? LV(dhi) : LV(dlo);         // dist - margin
+        if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
-          sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dist - mg, &Kc, &Bc, &Ic);
+          sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dm, &Kc, &Bc, &Ic);
           const T R = tmax(MYO_MINVAL, (1 - Ic) * M.dof_invweight0[M.jnt_dofadr[j]] / Ic);
           s.lim_id[r] = M.jnt_dofadr[j]; s.lim_sgn[r] = side ? (T)-1 : (T)1;   // joint rows keep the DOF index
-          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * (dist - mg);
+          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -1318,14 +1413,14 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
   const int nlim = s.nl + s.ntl;
   // ---- contacts: lanes = candidate pairs (64 at a time)
   int ncon = 0;
-  LANE_VAR(ContactTmp<T>, ct);
+  LANE_VAR(ContactTmp, ct);
   for (int base = 0; base < M.npair; base += 64) {
     PHASE {
       const int p = base + lane;
       LV(ct).n = 0;
       if (p < M.npair) {
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-        const T margin = tmax(M.geom_margin[g1], M.geom_margin[g2]);
+        const HP margin = tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);
         const T rb1 = M.geom_rbound[g1], rb2 = M.geom_rbound[g2];
         int skip = 0;
         if (rb1 > 0 && rb2 > 0) {
@@ -1337,13 +1432,15 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
           body_point(s, M.geom_bodyid[g1], l1, c1);
           body_point(s, M.geom_bodyid[g2], l2, c2);
           const T df[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
-          const T bound = rb1 + rb2 + margin;
-          if (dot3(df, df) > bound * bound) skip = 1;
+          // (conservative by construction: a pair this filter is unsure about has dist >> margin in the narrow
+          // phase anyway, so its fp32 rounding never decides an activation)
+          const T bound = rb1 + rb2 + (T)margin;
+          if (dot3(df, df) > bound * bound * (T)1.0001) skip = 1;
         }
         if (!skip) {
           collide_pair(M, K, s, g1, g2, margin, LV(ct));
           // keep only contacts that enter the constraint set (dist < margin - gap); static slot indices
-          const T inc = margin - tmax(M.geom_gap[g1], M.geom_gap[g2]);
+          const HP inc = margin - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2]);
           const int k0 = LV(ct).n > 0 && LV(ct).dist[0] < inc, k1 = LV(ct).n > 1 && LV(ct).dist[1] < inc;
           if (!k0 && k1) {
             LV(ct).dist[0] = LV(ct).dist[1];
@@ -1363,7 +1460,7 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
         if (k >= LV(ct).n || ci >= MYO_NCON_MAX) break;
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
         ContactRec<T>& c = s.con[ci];
-        for (int e = 0; e < 3; ++e) { c.pos[e] = LV(ct).pos[3 * k + e]; c.frame[e] = LV(ct).nrm[3 * k + e]; }
+        for (int e = 0; e < 3; ++e) { c.pos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); c.frame[e] = (T)LV(ct).nrm[3 * k + e]; }
         make_frame(c.frame);
         // everything that depends on the two geoms only comes from the host-resolved pair record (pc_*):
         // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
@@ -1381,15 +1478,14 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
           fr[e] = (fsel == 0) ? tmax(a, b) : (fsel == 1 ? a : b);
         }
         c.mu[0] = fr[0]; c.mu[1] = fr[0];  // condim 3: both tangential directions use friction[0]
-        const T inc = F[1];
-        const T dist = LV(ct).dist[k];
+        const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
         T Kc, Bc, Ic;
-        sol_param(M, F + 2, F + 4, dist - inc, &Kc, &Bc, &Ic);
+        sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
         const T tran = F[15];
         const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr[0] * fr[0] * tran) / Ic);
         const T mu = fr[0] / sqrt(M.impratio);
         const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
-        c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * (dist - inc);
+        c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * dmi;
         c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
         {
           const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
@@ -1611,6 +1707,7 @@ template <typename T>
 DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
+  const T* const qv = S_QVELT(s);
   // (the caller has run body_vectors(qvel -> S_CVEL): called from kernel level so that this function stays a leaf)
   PHASE {
     const int t = lane;
@@ -1618,7 +1715,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
       unsigned long long m = M.tendon_dofmask[t];
       T acc = 0;
       int slot = 0;
-      while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * s.qvel[d]; slot++; }
+      while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * qv[d]; slot++; }
       s.ten_vel[t] = acc;
     }
     const int d = lane;
@@ -1631,17 +1728,17 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
       while (m) {
         const int o = myo_ffsll(m);
         m &= m - 1;
-        const T vo = s.qvel[o];
+        const T vo = qv[o];
         for (int e = 0; e < 6; ++e) cv[e] += s.cdof[6 * o + e] * vo;
       }
       if (is_free_trans) { for (int e = 0; e < 6; ++e) S_CDOFDOT(s)[6 * d + e] = 0; }
       else cross_motion(S_CDOFDOT(s) + 6 * d, cv, s.cdof + 6 * d);
       // passive joint forces
-      T p = -M.dof_damping[d] * s.qvel[d];
+      T p = -M.dof_damping[d] * qv[d];
       const int j = M.dof_jntid[d];
       if (M.jnt_type[j] != 0 && M.jnt_stiffness[j] != 0) {
         const int qa = M.jnt_qposadr[j];
-        p -= M.jnt_stiffness[j] * (s.qpos[qa] - M.qpos_spring[qa]);
+        p -= M.jnt_stiffness[j] * ((T)s.qpos[qa] - M.qpos_spring[qa]);
       }
       S_QFRC_PASSIVE(s)[d] = p;
     }
@@ -1674,7 +1771,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
       while (m) {
         const int d = myo_ffsll(m);
         m &= m - 1;
-        const T vd = s.qvel[d];
+        const T vd = qv[d];
         for (int e = 0; e < 6; ++e) a[e] += S_CDOFDOT(s)[6 * d + e] * vd;
       }
       T t1[6], t2[6], t3[6];
@@ -1713,7 +1810,7 @@ DEV void efc_reference(const DevModel<T>& M_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   if (s.nefc > 0) {
-    J_times(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
+    J_times(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
     PHASE {
       const int nlim_ = s.nl + s.ntl;
       for (int r = lane; r < s.nefc; r += 64) {
@@ -1751,7 +1848,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
       T input = ctrl;
       if (M.actuator_dyntype[i] == 3) {
         const int ia = i - (M.nu - M.na);
-        const T act = s.act[ia];
+        const T act = (T)s.act[ia];
         const T* prm = M.actuator_dynprm + 10 * i;
         const T cc = tclamp(ctrl, (T)0, (T)1), ac = tclamp(act, (T)0, (T)1);
         const T tau = cc > act ? prm[0] * ((T)0.5 + (T)1.5 * ac) : prm[1] / ((T)0.5 + (T)1.5 * ac);
@@ -1825,8 +1922,11 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
 
 // ------------------------------------------------------------------------------------------
 // P10: Newton solver on the primal problem (mj_solNewton)
+// The COST is accumulated in HP in every build: Newton's termination test is a cost DIFFERENCE of ~1e-8 on a
+// cost of ~1e2, and near the minimum the cost is flat to second order, so an fp32 cost stalls while the
+// iterate is still sqrt(eps) away.  The iterates, gradient and search direction stay T.
 template <typename T>
-DEV T update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {   // inlined into the solver loop (kernel level): JT_times stays a leaf call
+DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {   // inlined into the solver loop (kernel level): JT_times stays a leaf call
   MYO_BIND_M(T) MYO_BIND_S(T)
   // forces / active set from jar, cost, qfrc_constraint, gradient
   WAVE_FN
@@ -1842,14 +1942,14 @@ DEV T update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {   // inline
   }
   SYNC();
   JT_times(M, s, LOFF(s, s.efc_force), LOFF(s, s.qfrc_constraint));
-  WAVE_SUM_N(T, ccost, nefc, r, ((T)0.5 * row_D(s, r, nlim) * tmin(s.efc_jar[r], (T)0) * tmin(s.efc_jar[r], (T)0)));   // active <=> jar < 0
-  WAVE_SUM_N(T, gcost, M.nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc[c] - s.qacc_smooth[c])));
+  WAVE_SUM_N(HP, ccost, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jar[r], (T)0) * (HP)tmin(s.efc_jar[r], (T)0)));   // active <=> jar < 0
+  WAVE_SUM_N(HP, gcost, M.nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc[c] - (HP)s.qacc_smooth[c])));
   PHASE {
     const int c = lane;
     if (c < M.nv) s.grad[c] = s.Ma[c] - s.qfrc_smooth[c] - s.qfrc_constraint[c];
   }
   SYNC();
-  return ccost + (T)0.5 * gcost;
+  return ccost + (HP)0.5 * gcost;
 }
 
 template <typename T>
@@ -1966,10 +2066,10 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
   mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc_warm));
   const int nlim = s.nl + s.ntl;
   // cost of the violated rows, branch-free: 0.5 D min(x, 0)^2  (no conditional around the D load)
-  WAVE_SUM_N(T, costw_c, nefc, r, ((T)0.5 * row_D(s, r, nlim) * tmin(s.efc_jar[r] - s.efc_aref[r], (T)0) * tmin(s.efc_jar[r] - s.efc_aref[r], (T)0)));
-  WAVE_SUM_N(T, costs, nefc, r, ((T)0.5 * row_D(s, r, nlim) * tmin(s.efc_jv[r] - s.efc_aref[r], (T)0) * tmin(s.efc_jv[r] - s.efc_aref[r], (T)0)));
-  WAVE_SUM_N(T, gw, nv, c, ((s.Ma[c] - s.qfrc_smooth[c]) * (s.qacc_warm[c] - s.qacc_smooth[c])));
-  const int use_warm = (costw_c + (T)0.5 * gw) < costs;
+  WAVE_SUM_N(HP, costw_c, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jar[r] - s.efc_aref[r], (T)0) * (HP)tmin(s.efc_jar[r] - s.efc_aref[r], (T)0)));
+  WAVE_SUM_N(HP, costs, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jv[r] - s.efc_aref[r], (T)0) * (HP)tmin(s.efc_jv[r] - s.efc_aref[r], (T)0)));
+  WAVE_SUM_N(HP, gw, nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc_warm[c] - (HP)s.qacc_smooth[c])));
+  const int use_warm = (costw_c + (HP)0.5 * gw) < costs;
   PHASE {
     const int c = lane;
     if (c < nv) {
@@ -1980,7 +2080,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
   }
   SYNC();
   if (!use_warm) mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc));  // keep Ma exactly consistent with M*qacc
-  T cost = update_constraint(M, s);
+  HP cost = update_constraint(M, s);
   const T scale = 1 / (M.meaninertia * (T)(nv > 1 ? nv : 1));
   int iter = 0;
   while (iter < M.iterations) {
@@ -2048,19 +2148,24 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
       for (int r = lane; r < nefc; r += 64) s.efc_jar[r] += alpha * s.efc_jv[r];
     }
     SYNC();
-    const T oldcost = cost;
+    const HP oldcost = cost;
     cost = update_constraint(M, s);
     iter++;
-    WAVE_SUM_N(T, gn, nv, c, (s.grad[c] * s.grad[c]));
-    const T improvement = scale * (oldcost - cost), gradient = scale * sqrt(gn);
-    if (improvement < M.tolerance || gradient < M.tolerance) break;
-    if (sizeof(T) == 4) {
-      // fp32 stepper: MuJoCo's absolute tests sit below what a 24-bit mantissa resolves (cost ~1e3,
-      // forces ~1e2), so the loop would run one more full iteration on rounding noise (measured:
-      // 2.8 iterations vs 1.9 in fp64).  Stop when the step is at the noise floor instead.
-      WAVE_SUM_N(T, fn, nv, c, (s.qfrc_smooth[c] * s.qfrc_smooth[c] + s.qfrc_constraint[c] * s.qfrc_constraint[c]));
-      if (gn < (T)1e-10 * fn || (oldcost - cost) < (T)2e-6 * fabs(cost)) break;
-    }
+    WAVE_SUM3_N(T, gn, qn2, fn, nv, c, { _e1 = s.grad[c] * s.grad[c]; _e2 = s.qacc[c] * s.qacc[c];
+                                         _e3 = s.qfrc_smooth[c] * s.qfrc_smooth[c] + s.qfrc_constraint[c] * s.qfrc_constraint[c] + s.Ma[c] * s.Ma[c]; });
+    const HP improvement = (HP)scale * (oldcost - cost);
+    const T gradient = scale * sqrt(gn);
+#ifdef MYO_EMU_DEBUG
+    printf("  it %d improvement*scale %.3e gradient*scale %.3e step/qacc %.3e  g/f %.3e\n", iter, (double)improvement, (double)gradient, (double)(alpha * snorm / sqrt(qn2)), sqrt((double)gn / (double)fn));
+#endif
+    if (improvement < (HP)M.tolerance || gradient < M.tolerance) break;
+    // Mixed stepper: MuJoCo's two tests sit below the rounding noise of an fp32 gradient (the fp64 solver
+    // usually leaves through `gradient` right after the iteration that lands in the final active set, with
+    // |grad| ~ 1e-12).  The T gradient  Ma - qfrc_smooth - qfrc_constraint  cannot get below ~1e-7 of its terms;
+    // measured over contact-rich steps: once |grad| < 1e-6 |terms| the NEXT Newton step would move qacc by
+    // <= 2e-6 |qacc| (median 1e-7), while every unconverged state has |grad| > 1e-5 |terms|.  The second test
+    // is the same statement about the step just taken.  Iteration counts then equal the fp64 solver's.
+    if (sizeof(T) != sizeof(HP) && (gn <= (T)1e-12 * fn || alpha * snorm <= (T)1e-5 * sqrt(qn2))) break;
   }
   PHASE { if (lane == 0) s.solver_iter = iter; }
   SYNC();
@@ -2102,7 +2207,7 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
   PROF(s, 4)
   collision_and_constraints(M, K, s);
   PROF(s, 5)
-  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)));
+  body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
   efc_reference(M, s);
   PROF(s, 6)
@@ -2112,30 +2217,34 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
 }
 
 // ------------------------------------------------------------------------------------------
-// P11: integrators
+// P11: integrators.  The state and its update are HP; the rates (qacc, act_dot, RK4 stage derivatives) are T.
 template <typename T>
-DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel_r, T h) {
+DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel_r, HP h_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  const T* vel = LPTR(const T, vel_r);
+  // vel_r = null: the (HP) velocity state itself; otherwise a T vector (RK4 stage combination)
+  const T* velT = LISNULL(vel_r) ? (const T*)0 : LPTR(const T, vel_r);
+  const HP h = h_in;
   WAVE_FN
   PHASE {
     const int j = lane;
     if (j < M.njnt) {
       const int qa = M.jnt_qposadr[j], da = M.jnt_dofadr[j];
       if (M.jnt_type[j] == 0) {
-        for (int k = 0; k < 3; ++k) s.qpos[qa + k] += h * vel[da + k];
-        T w[3] = {vel[da + 3], vel[da + 4], vel[da + 5]};
-        const T ang = h * norm3(w);
-        T q[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
+        HP v[6];
+        for (int k = 0; k < 6; ++k) v[k] = velT ? (HP)velT[da + k] : s.qvel[da + k];
+        for (int k = 0; k < 3; ++k) s.qpos[qa + k] += h * v[k];
+        HP w[3] = {v[3], v[4], v[5]};
+        const HP ang = h * norm3(w);
+        HP q[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
         if (ang > 0) {
-          T qr[4];
+          HP qr[4];
           normalize3(w);
           axisangle2quat(qr, w, ang);
           mulquat(q, q, qr);
         }
         normalize4(q);
         for (int k = 0; k < 4; ++k) s.qpos[qa + 3 + k] = q[k];
-      } else s.qpos[qa] += h * vel[da];
+      } else s.qpos[qa] += h * (velT ? (HP)velT[da] : s.qvel[da]);
     }
   }
   SYNC();
@@ -2146,19 +2255,19 @@ DEV void advance(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) act_dot_r, 
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* act_dot = LPTR(const T, act_dot_r); const T* qacc = LPTR(const T, qacc_r);
   WAVE_FN
-  const T h = M.timestep;
+  const HP h = M.h_timestep;
   PHASE {
     const int i = lane;
     if (i < M.na) {
-      T a = s.act[i] + h * act_dot[i];
-      if (M.actuator_dyntype[i + (M.nu - M.na)] == 3) a = tclamp(a, (T)0, (T)1);
+      HP a = s.act[i] + h * (HP)act_dot[i];
+      if (M.actuator_dyntype[i + (M.nu - M.na)] == 3) a = tclamp(a, (HP)0, (HP)1);
       s.act[i] = a;
     }
-    if (i < M.nv) { s.qvel[i] += h * qacc[i]; s.qacc_warm[i] = s.qacc[i]; }
+    if (i < M.nv) { s.qvel[i] += h * (HP)qacc[i]; s.qacc_warm[i] = s.qacc[i]; }
     if (lane == 0) s.time += h;
   }
   SYNC();
-  integrate_pos(M, s, LISNULL(vel_r) ? LOFF(s, s.qvel) : vel_r, h);
+  integrate_pos(M, s, vel_r, M.h_timestep);
 }
 
 template <typename T>
@@ -2172,9 +2281,9 @@ DEV void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc) {
   PHASE {
     const int i = lane;
     int bad = 0;
-    if (i < M.nq) bad |= !(isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (T)1e10);
+    if (i < M.nq) bad |= !(isfinite(s.qpos[i]) && fabs(s.qpos[i]) < (HP)1e10);
     if (i < M.nv) {
-      bad |= !(isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (T)1e10);
+      bad |= !(isfinite(s.qvel[i]) && fabs(s.qvel[i]) < (HP)1e10);
       if (check_acc) bad |= !(isfinite(s.qacc[i]) && fabs(s.qacc[i]) < (T)1e10);
     }
     if (bad) s.bad = 1;
@@ -2192,10 +2301,10 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
   if (M.integrator == 1) {
     // RK4 (mj_RungeKutta): tableau 1/2,1/2,1; weights 1/6,1/3,1/3,1/6
     const int nq = M.nq, nv = M.nv, na = M.na, nf = 2 * nv + na;
-    const T h = M.timestep, t0 = s.time;
+    const HP h = M.h_timestep; const HP t0 = s.time;
     PHASE {
       for (int i = lane; i < nq; i += 64) s.rk->x0[i] = s.qpos[i];
-      for (int i = lane; i < nv; i += 64) { s.rk->x0[nq + i] = s.qvel[i]; s.rk->F[0][i] = s.qvel[i]; s.rk->F[0][nv + i] = s.qacc[i]; }
+      for (int i = lane; i < nv; i += 64) { s.rk->x0[nq + i] = s.qvel[i]; s.rk->F[0][i] = (T)s.qvel[i]; s.rk->F[0][nv + i] = s.qacc[i]; }
       for (int i = lane; i < na; i += 64) { s.rk->x0[nq + nv + i] = s.act[i]; s.rk->F[0][2 * nv + i] = s.act_dot[i]; }
     }
     SYNC();
@@ -2208,14 +2317,14 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
       SYNC();
       integrate_pos(M, s, LOFF(s, s.rk->dX), h);
       PHASE {
-        for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * s.rk->dX[nv + i];
-        for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i] + h * s.rk->dX[2 * nv + i];
-        if (lane == 0) s.time = t0 + h * a;
+        for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * (HP)s.rk->dX[nv + i];
+        for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i] + h * (HP)s.rk->dX[2 * nv + i];
+        if (lane == 0) s.time = t0 + h * (HP)a;
       }
       SYNC();
       forward(M, K, s);
       PHASE {
-        for (int i = lane; i < nv; i += 64) { s.rk->F[st][i] = s.qvel[i]; s.rk->F[st][nv + i] = s.qacc[i]; }
+        for (int i = lane; i < nv; i += 64) { s.rk->F[st][i] = (T)s.qvel[i]; s.rk->F[st][nv + i] = s.qacc[i]; }
         for (int i = lane; i < na; i += 64) s.rk->F[st][2 * nv + i] = s.act_dot[i];
       }
       SYNC();

@@ -67,31 +67,33 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   const int nh = K.n_hand;
-  const T dt = (T)K.frame_skip * M.timestep;
+  const HP dt = (HP)K.frame_skip * M.h_timestep;
+  // positions, errors and velocities from the HP state and poses (world coordinates), rounded once to T
   PHASE {
     const int i = lane;
-    if (i < nh) S_OBS(s)[i] = s.qpos[i];
+    if (i < nh) S_OBS(s)[i] = (T)s.qpos[i];
     if (i < 3) {
-      T p1[3], p2[3], t1[3], t2[3];
-      body_point(s, M.site_bodyid[K.obj1_sid], M.site_pos + 3 * K.obj1_sid, p1);
-      body_point(s, M.site_bodyid[K.obj2_sid], M.site_pos + 3 * K.obj2_sid, p2);
-      const T l1[3] = {s.target_xy[0], s.target_xy[1], M.site_pos[3 * K.target1_sid + 2]};
-      const T l2[3] = {s.target_xy[2], s.target_xy[3], M.site_pos[3 * K.target2_sid + 2]};
-      body_point(s, M.site_bodyid[K.target1_sid], l1, t1);
-      body_point(s, M.site_bodyid[K.target2_sid], l2, t2);
-      S_OBS(s)[nh + i] = p1[i];
-      S_OBS(s)[nh + 3 + i] = s.qvel[M.nv - 12 + i] * dt;
-      S_OBS(s)[nh + 6 + i] = p2[i];
-      S_OBS(s)[nh + 9 + i] = s.qvel[M.nv - 6 + i] * dt;
-      S_OBS(s)[nh + 12 + i] = t1[i];
-      S_OBS(s)[nh + 15 + i] = t2[i];
-      S_OBS(s)[nh + 18 + i] = t1[i] - p1[i];
-      S_OBS(s)[nh + 21 + i] = t2[i] - p2[i];
+      HP p1[3], p2[3], t1[3], t2[3];
+      body_point_hp(s, M.site_bodyid[K.obj1_sid], M.h_site_pos + 3 * K.obj1_sid, p1);
+      body_point_hp(s, M.site_bodyid[K.obj2_sid], M.h_site_pos + 3 * K.obj2_sid, p2);
+      const HP l1[3] = {s.target_xy[0], s.target_xy[1], M.h_site_pos[3 * K.target1_sid + 2]};
+      const HP l2[3] = {s.target_xy[2], s.target_xy[3], M.h_site_pos[3 * K.target2_sid + 2]};
+      body_point_hp(s, M.site_bodyid[K.target1_sid], l1, t1);
+      body_point_hp(s, M.site_bodyid[K.target2_sid], l2, t2);
+      S_OBS(s)[nh + i] = (T)p1[i];
+      S_OBS(s)[nh + 3 + i] = (T)(s.qvel[M.nv - 12 + i] * dt);
+      S_OBS(s)[nh + 6 + i] = (T)p2[i];
+      S_OBS(s)[nh + 9 + i] = (T)(s.qvel[M.nv - 6 + i] * dt);
+      S_OBS(s)[nh + 12 + i] = (T)t1[i];
+      S_OBS(s)[nh + 15 + i] = (T)t2[i];
+      S_OBS(s)[nh + 18 + i] = (T)(t1[i] - p1[i]);
+      S_OBS(s)[nh + 21 + i] = (T)(t2[i] - p2[i]);
+      s.target_w[i] = t1[i]; s.target_w[3 + i] = t2[i];
     }
-    if (i < M.na) S_OBS(s)[nh + 24 + i] = s.act[i];
+    if (i < M.na) S_OBS(s)[nh + 24 + i] = (T)s.act[i];
   }
   SYNC();
-  WAVE_SUM_N(T, asq, M.na, i, (s.act[i] * s.act[i]));
+  WAVE_SUM_N(T, asq, M.na, i, ((T)s.act[i] * (T)s.act[i]));
   PHASE {
     if (lane == 0) {
       const T* e1 = S_OBS(s) + nh + 18; const T* e2 = S_OBS(s) + nh + 21;
@@ -118,14 +120,14 @@ DEV void baoding_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
   PHASE {
     if (lane == 0) {
       if (s.which_task != 0) {
-        const double dt = (double)K.frame_skip * (double)M.timestep;
+        const double dt = (double)K.frame_skip * M.h_timestep;
         const double sign = s.which_task == 1 ? -1.0 : 1.0;
         const double ang = sign * 2.0 * MYO_PI * ((double)s.counter * dt / (double)s.time_period);
-        const double a1 = ang + (double)s.start_angle[0], a2 = ang + (double)s.start_angle[1];
-        s.target_xy[0] = (T)((double)s.x_radius * cos(a1) + K.center_pos[0]);
-        s.target_xy[1] = (T)((double)s.y_radius * sin(a1) + K.center_pos[1]);
-        s.target_xy[2] = (T)((double)s.x_radius * cos(a2) + K.center_pos[0]);
-        s.target_xy[3] = (T)((double)s.y_radius * sin(a2) + K.center_pos[1]);
+        const double a1 = ang + s.start_angle[0], a2 = ang + s.start_angle[1];
+        s.target_xy[0] = s.x_radius * cos(a1) + K.center_pos[0];
+        s.target_xy[1] = s.y_radius * sin(a1) + K.center_pos[1];
+        s.target_xy[2] = s.x_radius * cos(a2) + K.center_pos[0];
+        s.target_xy[3] = s.y_radius * sin(a2) + K.center_pos[1];
       }
       s.counter++;
     }
@@ -149,7 +151,7 @@ DEVFN void set_init_state(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
   // robot.reset(init_qpos, init_qvel): init_qpos[:-14]=0, init_qpos[0]=-1.57 (baoding.py:281-283)
   WAVE_FN
   PHASE {
-    for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (i < K.n_hand) ? (i == 0 ? (T)K.init_qpos0 : (T)0) : M.qpos0[i];
+    for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (i < K.n_hand) ? (i == 0 ? (HP)K.init_qpos0 : (HP)0) : (HP)M.h_qpos0[i];
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = 0; if (!keep_dynamics) s.qacc_warm[i] = 0; }
     if (!keep_dynamics) {
       for (int i = lane; i < M.na; i += 64) s.act[i] = 0;
@@ -226,10 +228,10 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
   PHASE {
     if (lane == 0) {
       s.which_task = which; s.counter = 0; s.elapsed = 0; s.ep_ret = 0; s.ep_len = 0;
-      s.start_angle[0] = (T)start1; s.start_angle[1] = (T)start2;
-      s.x_radius = (T)xr; s.y_radius = (T)yr; s.time_period = (T)period;
+      s.start_angle[0] = start1; s.start_angle[1] = start2;
+      s.x_radius = xr; s.y_radius = yr; s.time_period = period;
       s.ball_mass[0] = (T)mass[0]; s.ball_mass[1] = (T)mass[1];
-      s.ball_size[0] = (T)size[0]; s.ball_size[1] = (T)size[1];
+      s.ball_size[0] = size[0]; s.ball_size[1] = size[1];
       for (int k = 0; k < 6; ++k) s.ball_fric[k] = (T)fric[k];
     }
   }
@@ -238,9 +240,9 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
   if (do_rsi) {
     // self.step(np.zeros(39)); balls teleported onto the targets (xy), hand back to init pose
     baoding_step_core(M, K, s, (const float*)0);
-    T bx[4];
+    HP bx[4];
     const int nh = K.n_hand;
-    bx[0] = S_OBS(s)[nh + 12]; bx[1] = S_OBS(s)[nh + 13]; bx[2] = S_OBS(s)[nh + 15]; bx[3] = S_OBS(s)[nh + 16];
+    bx[0] = s.target_w[0]; bx[1] = s.target_w[1]; bx[2] = s.target_w[3]; bx[3] = s.target_w[4];
     SYNC();
     set_init_state(M, K, s, 1);
     PHASE {
@@ -251,7 +253,7 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
     SYNC();
     if (K.kind == 2 && !K.balls_overlap) {
       const double a = rng_range(g, 0.0, 2.0 * MYO_PI);
-      PHASE { if (lane == 0) { s.start_angle[0] = (T)a; s.start_angle[1] = (T)(a - MYO_PI); } }
+      PHASE { if (lane == 0) { s.start_angle[0] = a; s.start_angle[1] = a - MYO_PI; } }
       SYNC();
     }
   }
@@ -274,12 +276,12 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
         const int nh = K.n_hand;
         if (K.noise_balls != 0) {
           const int idx[6] = {nh, nh + 1, nh + 2, nh + 7, nh + 8, nh + 9};
-          for (int k = 0; k < 6; ++k) s.qpos[idx[k]] += (T)nb[k];
+          for (int k = 0; k < 6; ++k) s.qpos[idx[k]] += nb[k];
         }
-        if (K.noise_palm != 0) for (int k = 0; k < 3; ++k) s.qpos[k] = (T)np_[k];
+        if (K.noise_palm != 0) for (int k = 0; k < 3; ++k) s.qpos[k] = np_[k];
         if (K.noise_fingers != 0) {
-          for (int k = 3; k < 7; ++k) s.qpos[k] = (T)nf[0];
-          for (int k = 7; k < nh; ++k) s.qpos[k] = ((k - 7) % 4 == 1) ? (T)nf[2] : (T)nf[1];
+          for (int k = 3; k < 7; ++k) s.qpos[k] = nf[0];
+          for (int k = 7; k < nh; ++k) s.qpos[k] = ((k - 7) % 4 == 1) ? nf[2] : nf[1];
         }
       }
     }
@@ -289,8 +291,8 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
     const double n1 = rng_range(g, 0.0, MYO_PI / 6 * K.noise_fingers);
     PHASE {
       if (lane == 0) {
-        for (int k = 4; k < 7; ++k) s.qpos[k] = (T)n0;
-        for (int k = 7; k < K.n_hand; ++k) if ((k - 7) % 4 != 1) s.qpos[k] = (T)n1;
+        for (int k = 4; k < 7; ++k) s.qpos[k] = n0;
+        for (int k = 7; k < K.n_hand; ++k) if ((k - 7) % 4 != 1) s.qpos[k] = n1;
       }
     }
     SYNC();
@@ -305,20 +307,20 @@ DEVFN void load_env(const DevModel<T>& M_in, const EnvRecordLayout L, const doub
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (T)rec[L.off_qpos + i];
-    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = (T)rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
-    for (int i = lane; i < M.na; i += 64) s.act[i] = (T)rec[L.off_act + i];
+    for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
+    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
+    for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i];
     for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = 0;
     if (lane == 0) {
-      s.time = (T)rec[L.off_time];
+      s.time = rec[L.off_time];
       const double* td = rec + L.off_taskd;
-      s.start_angle[0] = (T)td[0]; s.start_angle[1] = (T)td[1]; s.x_radius = (T)td[2]; s.y_radius = (T)td[3];
-      s.time_period = (T)td[4];
-      for (int k = 0; k < 4; ++k) s.target_xy[k] = (T)td[5 + k];
+      s.start_angle[0] = td[0]; s.start_angle[1] = td[1]; s.x_radius = td[2]; s.y_radius = td[3];
+      s.time_period = td[4];
+      for (int k = 0; k < 4; ++k) s.target_xy[k] = td[5 + k];
       const double* bd = rec + L.off_balld;
       s.ball_mass[0] = (T)bd[0]; s.ball_mass[1] = (T)bd[1];
       for (int k = 0; k < 6; ++k) s.ball_fric[k] = (T)bd[2 + k];
-      s.ball_size[0] = (T)bd[8]; s.ball_size[1] = (T)bd[9];
+      s.ball_size[0] = bd[8]; s.ball_size[1] = bd[9];
       const double* mi = rec + L.off_misc;
       s.which_task = (int)mi[0]; s.counter = (int)mi[1]; s.elapsed = (int)mi[2]; s.episode = (int)mi[3];
       s.ep_ret = (T)mi[4]; s.ep_len = (int)mi[5];
@@ -461,7 +463,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   tendon(M, K, s);
   crb(M, s);
   collision_and_constraints(M, K, s);
-  body_vectors(M, s, LOFF(s, s.qvel), LOFF(s, S_CVEL(s)));
+  body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
   efc_reference(M, s);
   fwd_actuation(M, s);
@@ -493,13 +495,13 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
     if (lane == 0) { out[D.counts] = s.ncon; out[D.counts + 1] = s.nefc; out[D.counts + 2] = s.solver_iter; out[D.counts + 3] = s.nl; }
     for (int r = lane; r < s.nefc; r += 64) { out[D.efc_aref + r] = (double)s.efc_aref[r]; out[D.efc_D + r] = (double)s.efc_D[r]; }
     for (int sid = lane; sid < M.nsite; sid += 64) {
-      T p[3];
-      body_point(s, M.site_bodyid[sid], M.site_pos + 3 * sid, p);
-      for (int k = 0; k < 3; ++k) out[D.site_xpos + 3 * sid + k] = (double)p[k];
+      HP p[3];
+      body_point_hp(s, M.site_bodyid[sid], M.h_site_pos + 3 * sid, p);
+      for (int k = 0; k < 3; ++k) out[D.site_xpos + 3 * sid + k] = p[k];
     }
     for (int b = lane; b < M.nbody; b += 64)
       for (int k = 0; k < 3; ++k) {
-        out[D.subtree_com + 3 * b + k] = (double)s.com[3 * M.body_rootid[b] + k];
+        out[D.subtree_com + 3 * b + k] = (double)s.com[3 * M.body_rootid[b] + k] + s.origin[k];
         out[D.xpos + 3 * b + k] = (double)s.xpos[3 * b + k];
       }
   }

@@ -275,7 +275,8 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   }
   m->ngw = (int)m->gw_elem.size();
   if (m->gw_elem.empty()) m->gw_elem.push_back(0);
-  LIM(3 * m->nwrap > MYO_NV_MAX * MYO_NV_MAX - MYO_NB_MAX * 10, "tendon path elements (staging area of the tendon stage)")
+  LIM(3 * (size_t)m->nwrap * sizeof(double) > MYO_NCON_MAX * sizeof(ContactRec<double>) ||
+      3 * (size_t)m->nwrap * sizeof(float) > MYO_NCON_MAX * sizeof(ContactRec<float>), "tendon path elements (staging area of the tendon stage)")
   LIM(7 * m->ngw > 4 * MYO_NEFC_MAX, "tendon wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
   for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
@@ -423,10 +424,8 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
   D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw;
+  D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
-  // fp32 stepper: the scaled cost/gradient tests of the Newton solver cannot resolve below ~1e-6
-  // (24-bit mantissa); with the model's 1e-8 it would spend an extra iteration on rounding noise.
-  if (sizeof(T) == 4 && D.tolerance < (T)1e-6) D.tolerance = (T)1e-6;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];
   D.meaninertia = (T)m->meaninertia;
   int rc = 0;
@@ -460,6 +459,18 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
     D.n.p = (const T*)p;                                                      \
   }
   MYO_MODEL_REAL_ARRAYS(X)
+#undef X
+  // HP tables: the fp64 stepper's ordinary tables; separate fp64 copies for the mixed stepper
+#define X(n)                                                                                   \
+  if (sizeof(T) == sizeof(double)) D.h_##n.p = (const double*)(const void*)D.n.p;              \
+  else {                                                                                       \
+    void* p = nullptr;                                                                         \
+    rc |= be_malloc(&p, m->n.size() * sizeof(double));                                         \
+    if (!rc && !m->n.empty()) rc |= be_h2d(p, m->n.data(), m->n.size() * sizeof(double));      \
+    allocs.push_back(p);                                                                       \
+    D.h_##n.p = (const double*)p;                                                              \
+  }
+  MYO_MODEL_HP_ARRAYS(X)
 #undef X
   return rc;
 }
@@ -773,6 +784,15 @@ extern "C" int myo_batch_set_state(myo_batch* b, const double* qpos, const doubl
   be_stream st = (be_stream)stream;
   xfer(b, b->L.off_qpos, b->nq, (double*)qpos, 0, st); xfer(b, b->L.off_qvel, b->nv, (double*)qvel, 0, st);
   xfer(b, b->L.off_act, b->na, (double*)act, 0, st); xfer(b, b->L.off_time, 1, (double*)time, 0, st);
+#ifndef MYO_EMU
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+extern "C" int myo_batch_warmstart(myo_batch* b, double* get_w, const double* set_w, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  be_stream st = (be_stream)stream;
+  xfer(b, b->L.off_warm, b->nv, get_w, 1, st); xfer(b, b->L.off_warm, b->nv, (double*)set_w, 0, st);
 #ifndef MYO_EMU
   LAUNCH_CHECK(b)
 #endif

@@ -77,6 +77,7 @@ class NativeLib:
         L.myo_batch_get_state.argtypes = [vp] * 6
         L.myo_batch_set_state.argtypes = [vp] * 6
         L.myo_batch_set_task.argtypes = [vp] * 5
+        L.myo_batch_warmstart.argtypes = [vp] * 4
         L.myo_batch_get_task.argtypes = [vp] * 5
         L.myo_batch_bind_constants.argtypes = [vp, vp]
         L.myo_batch_set_object_group.argtypes = [vp, i32, i32]
@@ -131,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_destroy", "myo_model_size", "myo_batch_create",
     "myo_batch_destroy", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
     "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_physics_step", "myo_batch_get_state",
-    "myo_batch_set_state", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_bind_constants", "myo_batch_forward_dump",
+    "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
     "myo_vecnorm_step", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
@@ -203,6 +204,10 @@ class Batch:
 
     def set_state(self, qpos=None, qvel=None, act=None, time=None, stream=None):
         self.lib.check(self.lib.L.myo_batch_set_state(self.h, _ptr(qpos), _ptr(qvel), _ptr(act), _ptr(time), stream))
+
+    def warmstart(self, get=None, set=None, stream=None):
+        """Read (``get``) and / or overwrite (``set``) qacc_warmstart, double[N, nv]."""
+        self.lib.check(self.lib.L.myo_batch_warmstart(self.h, _ptr(get), _ptr(set), stream))
 
     def set_task(self, task_i=None, task_d=None, ball_d=None, stream=None):
         self.lib.check(self.lib.L.myo_batch_set_task(self.h, _ptr(task_i), _ptr(task_d), _ptr(ball_d), stream))

@@ -55,6 +55,7 @@ TARGET1 = np.array([-0.215914, -0.510662, 1.445070])   # overwritten from the go
 TARGET2 = np.array([-0.255075, -0.546083, 1.450521])
 CENTER = np.array([-0.0125, -0.07])
 BALL_R = 0.022
+REST_PEN = 2.0e-4    # penetration of the balls into the palm box at reset
 
 
 class _Builder:
@@ -278,14 +279,18 @@ def build_synthetic_hand(golden_obs=None, lengthrange_samples=384, objects="ball
     b1l, b2l = R.T @ (BALL1 - O), R.T @ (BALL2 - O)
     B = _Builder()
     HINGE, FREE = 3, 0
-    # palm collision surface: a box whose top plane passes under both balls (dist = 0 at reset)
+    # palm collision surface: a box whose top plane passes REST_PEN above the lowest point of both balls at
+    # reset, i.e. the balls start at about their resting penetration.  (dist = 0 exactly would put the reset
+    # state ON the activation boundary of MuJoCo's soft contacts, dist < margin: any 1e-16 perturbation then
+    # decides whether the first substep has a contact force or free fall — a knife edge no stepper can be
+    # compared on.)
     e = b2l - b1l
     nb_ = np.array([0, 0, 1.0]) - (e[2] / (e @ e)) * e
     nb_ /= np.linalg.norm(nb_)
     ex = np.cross([0, 1.0, 0], nb_); ex /= np.linalg.norm(ex)
     ey = np.cross(nb_, ex)
     Rb = np.stack([ex, ey, nb_], 1)
-    mid = 0.5 * (b1l + b2l) - BALL_R * nb_
+    mid = 0.5 * (b1l + b2l) - (BALL_R - REST_PEN) * nb_
     cbox = mid - 0.008 * nb_
     zmid = float(mid[2])
     zf = zmid - 0.009

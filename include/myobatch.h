@@ -34,7 +34,11 @@ extern "C" {
 typedef struct myo_model myo_model;
 typedef struct myo_batch myo_batch;
 
-enum { MYO_F64 = 0, MYO_F32 = 1 };            /* arithmetic type of the stepper */
+/* arithmetic of the stepper.  MYO_F64: everything in fp64 (the reference's mjtNum).  MYO_MIXED: fp64 for what
+ * decides whether a trajectory stays on the fp64 one — the state (qpos, qvel, act, time) and its integration, the
+ * kinematic chain, contact / joint-limit distances, the tendon-wrap predicates, the Newton cost, the observation —
+ * and fp32 for the rest of the dynamics.  MYO_F32 is round 1's name for value 1. */
+enum { MYO_F64 = 0, MYO_MIXED = 1, MYO_F32 = 1 };
 enum { MYO_TASK_NONE = 0, MYO_TASK_BAODING_P1 = 1, MYO_TASK_BAODING_P2 = 2 };
 enum { MYO_WHICH_HOLD = 0, MYO_WHICH_CW = 1, MYO_WHICH_CCW = 2 }; /* MyoSuite Task enum */
 enum { MYO_CHOICE_FIXED = 0, MYO_CHOICE_CW = 1, MYO_CHOICE_CCW = 2, MYO_CHOICE_RANDOM = 3 };
@@ -75,7 +79,7 @@ int myo_model_size(const myo_model* m, const char* name); /* nq nv nu na nbody .
 
 /* -- batch ------------------------------------------------------------------------------
  * replaces SubprocVecEnv([thunk]*n) + TimeLimit + Monitor (src/main_baoding.py:56-65).
- * `cfg` may be NULL (kind NONE: physics only).  dtype: MYO_F64 | MYO_F32. */
+ * `cfg` may be NULL (kind NONE: physics only).  dtype: MYO_F64 | MYO_MIXED. */
 int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int n_envs, int device,
                      uint64_t seed, int dtype, myo_batch** out);
 void myo_batch_destroy(myo_batch* b);
@@ -114,6 +118,13 @@ int myo_batch_get_state(myo_batch* b, double* qpos, double* qvel, double* act, d
                         void* stream);
 int myo_batch_set_state(myo_batch* b, const double* qpos, const double* qvel, const double* act,
                         const double* time, void* stream);
+/* Numerical blow-up of an env (non-finite / huge qpos, qvel or qacc: MuJoCo's mj_checkPos/Vel/Acc, which warn and
+ * reset the data) is NOT an error of myo_batch_step: the env ends its episode (done = 1, trunc = 0, reward 0, reward
+ * components 0 except `done`), is reset at once, and its terminal observation is the reset observation, so no NaN
+ * leaves the kernel.  Register a caller-owned device buffer uint8[N] here to be told which envs it happened to:
+ * every myo_batch_step writes 0 / 1 per env.  NULL (default) = not reported. */
+int myo_batch_set_bad_state_buffer(myo_batch* b, uint8_t* bad_state);
+
 /* qacc_warmstart (dev double[N,nv]): the remaining piece of MuJoCo's integration state (mjData.qacc_warmstart
  * seeds the Newton solver, so two steppers only retrace each other when it is copied along with qpos/qvel/act).
  * Either pointer may be NULL. */

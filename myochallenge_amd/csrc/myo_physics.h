@@ -108,7 +108,8 @@ struct Scratch {
   T com[MYO_NB_MAX * 3];
   T cdof[MYO_NV_MAX * 6];
   T bvec[MYO_NB_MAX * 6];
-  T ten_length[MYO_NT_MAX], ten_vel[MYO_NT_MAX], ten_J[MYO_NT_MAX * MYO_TJ_MAX];
+  HP ten_length[MYO_NT_MAX];                          // HP: what muscle forces and tendon limits are made of
+  T ten_vel[MYO_NT_MAX], ten_J[MYO_NT_MAX * MYO_TJ_MAX];
   T act_force[MYO_NU_MAX], act_dot[MYO_NU_MAX];
   T qM[MYO_NM_MAX];
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
@@ -152,6 +153,8 @@ template <typename T> DEV const T* S_XPOST(const Scratch<T>& s) { if constexpr (
 #define S_QFRC_ACTUATOR(s) ((s).H + MYO_NB_MAX * 20 + 2 * MYO_NV_MAX)
 #define S_OBS(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX)
 #define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage: position of every path element (con[] is dead until the collision stage) */
+/* tendon stage: HP wrap results (7 per geom wrap) behind the T path points, running on through the limit-row and efc_* arrays */
+#define S_TWRES(s, nwrap) (reinterpret_cast<HP*>(reinterpret_cast<char*>((s).con) + ((3 * (size_t)(nwrap) * sizeof(T) + 7) & ~(size_t)7)))
 #define S_ACT_GF(s) ((s).efc_force)   /* gear * actuator force (actuation stage; efc_force is first written by the solver) */
 #define S_KTMP(s) (reinterpret_cast<HP*>((s).con))   /* HP [2][MYO_NJ_MAX * 3] */
 #define S_XANCHOR(s) ((s).efc_aref)
@@ -681,6 +684,13 @@ DEV void tendon_segment_moment(const Scratch<T>& s, T* Jrow, unsigned long long 
   }
 }
 
+// HP position (relative to O, like every position of the fp32 stages) of a point given in body coordinates
+template <typename T> DEV void wrap_point_hp(const DevModel<T>& M, const Scratch<T>& s, int body, const HP* local, HP* out) {
+  (void)M;
+  body_point_hp(s, body, local, out);
+  out[0] -= s.origin[0]; out[1] -= s.origin[1]; out[2] -= s.origin[2];
+}
+
 // One wrap object as the tendon stage sees it (resolved on the host, see upload: wr_i / wr_p / wr_m /
 // wr_mask): a single level of table loads per path element instead of type -> objid -> body -> pos.
 template <typename T> struct WrapRec { int type, body, geom, side_body, root, side_root; T pos[3], prm; unsigned long long mask; };
@@ -697,14 +707,18 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
   WAVE_FN
   // Three phases instead of one divergent walk per tendon (a wave whose 39 lanes sit at different
   // path elements executes the site branch AND the cylinder-wrap branch every iteration):
-  //  A  lane = path element : world position of every site / wrap-geom centre   -> S_TWP[3w]
-  //  B  lane = geom wrap    : wrap_geom for all sphere/cylinder wraps in lockstep -> wres[7k] = len, 2 points
+  //  A  lane = path element : position of every site / wrap-geom centre (T, relative to O)  -> S_TWP[3w]
+  //  B  lane = geom wrap    : wrap_geom for all sphere/cylinder wraps in lockstep -> wres[7k] = len, 2 points (HP)
   //  C  lane = tendon       : lengths and moment arms from the staged points (cheap, little divergence)
-  // Staging: points in the part of H that is free until CRB (cinert keeps H[0, 10 nbody)); wrap results in
-  // the four efc_* row vectors (contiguous; constraint rows are only built after this stage).
+  // Precision: the LENGTH of a tendon is HP end to end — the points it is made of are recomputed from the HP
+  // body poses, the wrap solver runs in HP, the segment norms are HP sums — because a Hill muscle turns a length
+  // error dl into a force error F0 fpmax dl / (L0 (lmax - 1) / 2): ~1e4 N per metre for MyoSuite's finger muscles,
+  // so the 2e-8 m of a float path put 2e-5 relative error into qacc on the first substep (measured on
+  // myo_finger_v0).  The MOMENT ARMS (a Jacobian, 1e-7 relative is plenty) come from the T points of phase A.
+  // Staging: T points in con[] (dead until the collision stage); HP wrap results behind them, through the
+  // limit-row and efc_* arrays (contiguous; constraint rows are only built after this stage).
   T* wp = S_TWP(s);
-  T* wres = s.efc_aref;
-  static_assert(offsetof(Scratch<T>, efc_force) - offsetof(Scratch<T>, efc_aref) == 3 * MYO_NEFC_MAX * sizeof(T), "efc_* vectors are contiguous");
+  HP* wres = S_TWRES(s, M.nwrap);
   PHASE {
     for (int w = lane; w < M.nwrap; w += 64) {
       const int body = M.wr_i[8 * w + 1];
@@ -719,23 +733,20 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
     for (int k = lane; k < M.ngw; k += 64) {
       const int w = M.gw_elem[k];
       const int body = M.wr_i[8 * w + 1], type = M.wr_i[8 * w], geom = M.wr_i[8 * w + 2], side_body = M.wr_i[8 * w + 3];
-      // The wrap solver runs in HP on the (T) staged points: its branches are geometric predicates (point inside
-      // the circle, tangent segments crossing, which of the two tangent pairs) that sit on a knife edge exactly
-      // when a wrap engages — the wrap length is continuous there, but an fp32 evaluation of the predicates picks
-      // the wrong tangent pair (measured: seg_intersect flips on a 7e-7 m wrap and the path goes the long way round).
-      HP gmat[9], gm[9], bm[9], side[3] = {0, 0, 0}, pts[6], x0[3], x1[3], gp[3];
-      for (int e = 0; e < 9; ++e) { gm[e] = (HP)M.wr_m[12 * w + e]; bm[e] = (HP)s.xmat[9 * body + e]; }
-      mulmat3(gmat, bm, gm);
-      if (side_body >= 0) {
-        const T sl[3] = {M.wr_m[12 * w + 9], M.wr_m[12 * w + 10], M.wr_m[12 * w + 11]};
-        T sd[3];
-        body_point(s, side_body, sl, sd);
-        for (int e = 0; e < 3; ++e) side[e] = (HP)sd[e];
-      }
-      for (int e = 0; e < 3; ++e) { x0[e] = (HP)wp[3 * (w - 1) + e]; x1[e] = (HP)wp[3 * (w + 1) + e]; gp[e] = (HP)wp[3 * w + e]; }
-      const T wlen = (T)wrap_geom(pts, x0, x1, gp, gmat, (HP)geom_size0_of(M, K, s, geom), type, side, side_body >= 0);
+      // The wrap solver's branches are geometric predicates (point inside the circle, tangent segments crossing,
+      // which of the two tangent pairs) that sit on a knife edge exactly when a wrap engages — the wrap length is
+      // continuous there, but an fp32 evaluation of the predicates picks the wrong tangent pair (measured:
+      // seg_intersect flips on a 7e-7 m wrap and the path goes the long way round).
+      HP gmat[9], bm[9], side[3] = {0, 0, 0}, pts[6], x0[3], x1[3], gp[3];
+      quat2mat(bm, s.xquat + 4 * body);
+      mulmat3(gmat, bm, M.h_wr_m + 12 * w);
+      if (side_body >= 0) wrap_point_hp(M, s, side_body, M.h_wr_m + 12 * w + 9, side);
+      wrap_point_hp(M, s, M.wr_i[8 * (w - 1) + 1], M.h_wr_p + 4 * (w - 1), x0);
+      wrap_point_hp(M, s, M.wr_i[8 * (w + 1) + 1], M.h_wr_p + 4 * (w + 1), x1);
+      wrap_point_hp(M, s, body, M.h_wr_p + 4 * w, gp);
+      const HP wlen = wrap_geom(pts, x0, x1, gp, gmat, geom_size0_hp(M, K, s, geom), type, side, side_body >= 0);
       wres[7 * k] = wlen;
-      for (int e = 0; e < 6; ++e) wres[7 * k + 1 + e] = (T)pts[e];
+      for (int e = 0; e < 6; ++e) wres[7 * k + 1 + e] = pts[e];
     }
   }
   SYNC();
@@ -746,10 +757,12 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
       const unsigned long long tmask = M.tendon_dofmask[t];
       T* J = s.ten_J + t * MYO_TJ_MAX;
       for (int k = 0; k < MYO_TJ_MAX; ++k) J[k] = 0;
-      T len = 0, divisor = 1;
+      HP len = 0;
+      T divisor = 1;
       int j = 0;
       WrapRec<T> w0, w1, w2;
-      if (num > 0) load_wrap(M, adr, w0);
+      HP q0[3] = {0, 0, 0};                            // HP position of the site that starts the current path element
+      if (num > 0) { load_wrap(M, adr, w0); if (w0.body >= 0) wrap_point_hp(M, s, w0.body, M.h_wr_p + 4 * adr, q0); }
       while (j < num - 1) {
         load_wrap(M, adr + j + 1, w1);
         const int have2 = (j + 2 < num);
@@ -758,6 +771,7 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
           if (w0.type == 2) divisor = w0.prm;
           j++;
           w0 = w1;
+          if (w0.body >= 0) wrap_point_hp(M, s, w0.body, M.h_wr_p + 4 * (adr + j), q0);
           continue;
         }
         const int is_geom = (w1.type == 4 || w1.type == 5);
@@ -767,32 +781,40 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
         // Selected with scalars (no run-time indexed local arrays: they would live in private memory).
         const T p0[3] = {wp[3 * (adr + j)], wp[3 * (adr + j) + 1], wp[3 * (adr + j) + 2]};
         const T x1[3] = {wp[3 * wend], wp[3 * wend + 1], wp[3 * wend + 2]};
-        T wlen = -1, g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0};
+        HP q1[3];
+        wrap_point_hp(M, s, we.body, M.h_wr_p + 4 * wend, q1);
+        HP wlen = -1, h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0};
         if (is_geom) {
-          const T* r = wres + 7 * M.wr_i[8 * (adr + j + 1) + 6];
+          const HP* r = wres + 7 * M.wr_i[8 * (adr + j + 1) + 6];
           wlen = r[0];
-          for (int e = 0; e < 3; ++e) { g0[e] = r[1 + e]; g1[e] = r[4 + e]; }
+          for (int e = 0; e < 3; ++e) { h0[e] = r[1 + e]; h1[e] = r[4 + e]; }
         }
+        const T g0[3] = {(T)h0[0], (T)h0[1], (T)h0[2]}, g1[3] = {(T)h1[0], (T)h1[1], (T)h1[2]};
         const bool wrapped = wlen >= 0;
         const T inv_div = 1 / divisor;
         for (int sg = 0; sg < 2; ++sg) {
           if (sg == 1 && !wrapped) break;
           const bool to_wrap = (sg == 0) && wrapped;          // this segment ends on the wrap geom
           T pa[3], pb[3];
-          for (int e = 0; e < 3; ++e) { pa[e] = sg == 0 ? p0[e] : g1[e]; pb[e] = to_wrap ? g0[e] : x1[e]; }
+          HP da[3];
+          for (int e = 0; e < 3; ++e) {
+            pa[e] = sg == 0 ? p0[e] : g1[e]; pb[e] = to_wrap ? g0[e] : x1[e];
+            da[e] = (to_wrap ? h0[e] : q1[e]) - (sg == 0 ? q0[e] : h1[e]);
+          }
           const unsigned long long ma = sg == 0 ? w0.mask : w1.mask, mb = to_wrap ? w1.mask : we.mask;
           const int ra = sg == 0 ? w0.root : w1.root, rb = to_wrap ? w1.root : we.root;
           const int ba = sg == 0 ? w0.body : w1.body, bb = to_wrap ? w1.body : we.body;
           T dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
           const T dn = norm3(dif);
-          len += dn * inv_div;
+          len += norm3(da) * (HP)inv_div;
           if (ba != bb && dn > MYO_MINVAL) {
             dif[0] /= dn; dif[1] /= dn; dif[2] /= dn;
             tendon_segment_moment(s, J, tmask, ma, ra, pa, mb, rb, pb, dif, inv_div);
           }
-          if (to_wrap) len += wlen * inv_div;
+          if (to_wrap) len += wlen * (HP)inv_div;
         }
         if (is_geom) { j += 2; w0 = w2; } else { j += 1; w0 = w1; }
+        q0[0] = q1[0]; q0[1] = q1[1]; q0[2] = q1[2];
       }
       s.ten_length[t] = len;
     }
@@ -1054,8 +1076,7 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
     // critical path).  What travels is the UNSCALED pair of columns (2q, 2q+1) of the current trailing matrix,
     // one step early: X[j] = A[j][2q], Y[j] = A[j][2q+1].  Every lane derives the 2x2 pivot block from rows
     // 2q, 2q+1 of that broadcast (d00 = X[2q], d10 = X[2q+1], d11 = Y[2q+1]), its own two L entries, and the
-    // rank-2 trailing update  A[i][j] -= L[i][2q] L[j][2q] + L[i][2q+1] L[j][2q+1] = alpha_i X[j] + beta_i Y[j]
-    // with  beta_i = L[i][2q+1] / l11,  alpha_i = L[i][2q] / l00 - beta_i d10 / d00.
+    // rank-2 trailing update  A[i][j] -= L[i][2q] L[j][2q] + L[i][2q+1] L[j][2q+1].
     // Software-pipelined in place: the pair holding columns 2q+2, 2q+3 is updated first, written, and read
     // back into the registers its old broadcast values just left; every later pair is updated and then
     // refilled the same way, so the reads are in flight during the rest of the trailing update.  Two buffers
@@ -1086,17 +1107,22 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
       const T inv1 = myo_rsqrt(t11);
       const T li0 = a2[q].x * inv0;                    // lane 2q: sqrt(d00); lane 2q+1: l10
       const T li1 = (a2[q].y - li0 * l10) * inv1;      // lane 2q+1: sqrt(t11)
-      const T beta = li1 * inv1;
-      const T alpha = li0 * inv0 - beta * (l10 * inv0);
-      const V2 ma = V2{-alpha, -alpha}, mb = V2{-beta, -beta};
+      // The trailing update subtracts L[i][2q] L[j][2q] + L[i][2q+1] L[j][2q+1] with both L columns formed as the
+      // one-column algorithm forms them (L1[j] = (Y[j] - l10 L0[j]) / l11, rounded once).  The algebraically equal
+      // alpha_i X[j] + beta_i Y[j] is two FMAs instead of five operations, but it cancels two LARGE products
+      // whenever the 2x2 pivot block is ill-conditioned (coupled ball / finger dofs under a stiff contact): measured
+      // 1e-10 instead of 1e-16 relative in qacc, 1e-8 after 200 substeps against the fp64 oracle.
+      const V2 vi0 = V2{inv0, inv0}, vi1 = V2{inv1, inv1}, ml10 = V2{-l10, -l10}, m0 = V2{-li0, -li0}, m1 = V2{-li1, -li1};
       T* const nx = ((q + 1) & 1) ? bx1 : bx0;
       T* const ny = ((q + 1) & 1) ? by1 : by0;
       const V2* px = reinterpret_cast<const V2*>(nx);
       const V2* py = reinterpret_cast<const V2*>(ny);
       // refill in place, pair by pair (four registers per pair in fp64: no room for a second set)
       if (q + 1 < N / 2) {
-        a2[q + 1] = __builtin_elementwise_fma(ma, cx[q + 1], a2[q + 1]);
-        a2[q + 1] = __builtin_elementwise_fma(mb, cy[q + 1], a2[q + 1]);
+        const V2 L0 = cx[q + 1] * vi0;
+        const V2 L1 = __builtin_elementwise_fma(ml10, L0, cy[q + 1]) * vi1;
+        a2[q + 1] = __builtin_elementwise_fma(m0, L0, a2[q + 1]);
+        a2[q + 1] = __builtin_elementwise_fma(m1, L1, a2[q + 1]);
         nx[lane] = a2[q + 1].x;
         ny[lane] = a2[q + 1].y;
         cx[q + 1] = px[q + 1];
@@ -1104,8 +1130,10 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
       }
 #pragma unroll
       for (int p = q + 2; p < N / 2; ++p) {
-        a2[p] = __builtin_elementwise_fma(ma, cx[p], a2[p]);
-        a2[p] = __builtin_elementwise_fma(mb, cy[p], a2[p]);
+        const V2 L0 = cx[p] * vi0;
+        const V2 L1 = __builtin_elementwise_fma(ml10, L0, cy[p]) * vi1;
+        a2[p] = __builtin_elementwise_fma(m0, L0, a2[p]);
+        a2[p] = __builtin_elementwise_fma(m1, L1, a2[p]);
         cx[p] = px[p];
         cy[p] = py[p];
       }
@@ -1383,9 +1411,10 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     int c = 0;
     T a = 0, b = 0;
     if (t < M.ntendon && M.tendon_limited[t]) {
-      const T L = s.ten_length[t];
-      a = L - M.tendon_range[2 * t]; b = M.tendon_range[2 * t + 1] - L;
-      c = (a < M.tendon_margin[t] ? 1 : 0) + (b < M.tendon_margin[t] ? 1 : 0);
+      const HP L = s.ten_length[t], mh = M.h_tendon_margin[t];
+      const HP ah = L - M.h_tendon_range[2 * t], bh = M.h_tendon_range[2 * t + 1] - L;
+      c = (ah < mh ? 1 : 0) + (bh < mh ? 1 : 0);
+      a = (T)(ah - mh); b = (T)(bh - mh);      // kept as dist - margin
     }
     LV(cnt) = c; LV(dlo) = a; LV(dhi) = b;
   }
@@ -1394,15 +1423,16 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     const int t = lane;
     if (LV(cnt) > 0) {
       int r = nl + S_NPRE(s)[lane];
-      const T mg = M.tendon_margin[t];
+      const HP L = s.ten_length[t], mh = M.h_tendon_margin[t];
+      const int on_lo = (L - M.h_tendon_range[2 * t]) < mh, on_hi = (M.h_tendon_range[2 * t + 1] - L) < mh;
       for (int side = 0; side < 2; ++side) {
-        const T dist = side ? LV(dhi) : LV(dlo);
-        if (dist < mg && r < MYO_NLIM_MAX) {
+        const T dm = side ? LV(dhi) : LV(dlo);         // dist - margin
+        if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
-          sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dist - mg, &Kc, &Bc, &Ic);
+          sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dm, &Kc, &Bc, &Ic);
           const T R = tmax(MYO_MINVAL, (1 - Ic) * M.tendon_invweight0[t] / Ic);
           s.lim_id[r] = t; s.lim_sgn[r] = side ? (T)-1 : (T)1;
-          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * (dist - mg);
+          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -1753,7 +1783,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
           const T k = M.tendon_stiffness[t], b = M.tendon_damping[t];
           const unsigned long long m = M.tendon_dofmask[t];
           if ((k != 0 || b != 0) && ((m >> d) & 1ull)) {
-            const T f = -k * (s.ten_length[t] - M.tendon_lengthspring[t]) - b * s.ten_vel[t];
+            const T f = -k * ((T)s.ten_length[t] - M.tendon_lengthspring[t]) - b * s.ten_vel[t];
             acc += s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f;
           }
         }
@@ -1857,17 +1887,21 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
       }
       const int tid = M.actuator_tendon[i];
       const T gear = M.actuator_gear[6 * i];
-      const T len = gear * s.ten_length[tid], vel = gear * s.ten_vel[tid];
+      // muscle length normalisation and the force-length curves in HP from the HP tendon length (the curves are
+      // piecewise quadratics of DIFFERENCES like L - 1 and L - lmin); the force-velocity factor in T
+      const HP lenh = (HP)gear * s.ten_length[tid];
+      const T len = (T)lenh, vel = gear * s.ten_vel[tid];
       T gain, bias = 0;
-      const T* lr = M.actuator_lengthrange + 2 * i;
+      const HP lr0 = M.h_actuator_lengthrange[2 * i], lr1 = M.h_actuator_lengthrange[2 * i + 1];
       if (M.actuator_gaintype[i] == 1) {
         const T* prm = M.actuator_gainprm + 10 * i;
         T force = prm[2];
         if (force < 0) force = prm[3] / tmax(MYO_MINVAL, M.actuator_acc0[i]);
-        const T L0 = (lr[1] - lr[0]) / tmax(MYO_MINVAL, prm[1] - prm[0]);
-        const T L = prm[0] + (len - lr[0]) / tmax(MYO_MINVAL, L0);
-        const T V = vel / tmax(MYO_MINVAL, L0 * prm[6]);
-        const T FL = muscle_FL(L, prm[4], prm[5]);
+        const double* hp = M.h_actuator_gainprm + 10 * i;     // (1.05f - 0.75f is 1.6e-7 off 0.3: a 5e-6 force error through L - 1)
+        const HP L0 = (lr1 - lr0) / tmax((HP)1e-15, hp[1] - hp[0]);
+        const HP L = hp[0] + (lenh - lr0) / tmax((HP)1e-15, L0);
+        const T V = vel / tmax(MYO_MINVAL, (T)L0 * prm[6]);
+        const T FL = (T)muscle_FL(L, hp[4], hp[5]);
         const T y = prm[8] - 1;
         T FV;
         if (V <= -1) FV = 0;
@@ -1880,12 +1914,13 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
         const T* prm = M.actuator_biasprm + 10 * i;
         T force = prm[2];
         if (force < 0) force = prm[3] / tmax(MYO_MINVAL, M.actuator_acc0[i]);
-        const T L0 = (lr[1] - lr[0]) / tmax(MYO_MINVAL, prm[1] - prm[0]);
-        const T L = prm[0] + (len - lr[0]) / tmax(MYO_MINVAL, L0);
-        const T b = (T)0.5 * (1 + prm[5]);
+        const double* hp = M.h_actuator_biasprm + 10 * i;
+        const HP L0 = (lr1 - lr0) / tmax((HP)1e-15, hp[1] - hp[0]);
+        const HP L = hp[0] + (lenh - lr0) / tmax((HP)1e-15, L0);
+        const HP b = (HP)0.5 * (1 + hp[5]);
         if (L <= 1) bias = 0;
-        else if (L <= b) { const T x = (L - 1) / tmax(MYO_MINVAL, b - 1); bias = -force * prm[7] * (T)0.5 * x * x; }
-        else { const T x = (L - b) / tmax(MYO_MINVAL, b - 1); bias = -force * prm[7] * ((T)0.5 + x); }
+        else if (L <= b) { const T x = (T)((L - 1) / tmax((HP)1e-15, b - 1)); bias = -force * prm[7] * (T)0.5 * x * x; }
+        else { const T x = (T)((L - b) / tmax((HP)1e-15, b - 1)); bias = -force * prm[7] * ((T)0.5 + x); }
       } else if (M.actuator_biastype[i] == 1) {
         const T* prm = M.actuator_biasprm + 10 * i;
         bias = prm[0] + prm[1] * len + prm[2] * vel;

@@ -135,12 +135,16 @@ DEV void baoding_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
     if (i < M.nu) {  // BaseV0.step: clip, then float32 sigmoid(5(a-0.5)) for muscles (normalize_act)
       float a = action ? action[i] : 0.0f;
       a = a < -1.f ? -1.f : (a > 1.f ? 1.f : a);
-      const float c = 1.0f / (1.0f + expf(-5.0f * (a - 0.5f)));
+      // every operation but exp is an IEEE float32 operation; exp is the correctly rounded float32 exponential
+      // (a device expf is 1 ulp off glibc's / numpy's on some arguments: a 6e-8 difference in ctrl, 1e-8 in the
+      // trajectory after 20 env steps)
+      const float c = 1.0f / (1.0f + (float)exp((double)(-5.0f * (a - 0.5f))));
       s.ctrl[i] = (T)c;
     }
   }
   SYNC();
   for (int k = 0; k < K.frame_skip; ++k) mj_step(M, K, s);
+  check_state(M, s, 0);            // a non-finite value produced by the LAST advance must not leave through obs / reward
   kinematics(M, s);
   baoding_obs_reward(M, K, s);
 }
@@ -360,27 +364,33 @@ DEVFN void store_env(const DevModel<T>& M_in, const EnvRecordLayout L, double* r
 template <typename T>
 DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
-                  float* term_obs, float* comps, float* ep_info) {
+                  float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
   WAVE_FN
   const int nobs = K.n_hand + 24 + M.na;
   load_env(M, L, rec, s);
   baoding_step_core(M, K, s, act + (size_t)env * M.nu);
-  const int fall = s.rwd[6] != 0 || s.bad;
+  // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
+  // an error of the batch: the env ends its episode with done = 1, reward 0, zero reward components except `done`,
+  // is reset at once, and both the terminal and the returned observation are the (finite) reset observation, so that
+  // no NaN reaches the normaliser statistics or the rollout buffer.  bad_state[env] = 1 tells the caller.
+  const int bad = s.bad;
+  const int fall = s.rwd[6] != 0 || bad;
   int is_trunc = 0, is_done = fall;
   PHASE {
-    if (lane == 0) { s.elapsed++; s.ep_len++; s.ep_ret += s.rwd[7]; }
+    if (lane == 0) { s.elapsed++; s.ep_len++; if (!bad) s.ep_ret += s.rwd[7]; }
   }
   SYNC();
   if (s.elapsed >= K.max_episode_steps) { is_trunc = !fall; is_done = 1; }  // gym TimeLimit
   PHASE {
     if (lane == 0) {
-      rew[env] = (float)s.rwd[7];
+      rew[env] = bad ? 0.0f : (float)s.rwd[7];
       done[env] = (unsigned char)is_done;
       if (trunc) trunc[env] = (unsigned char)is_trunc;
+      if (bad_state) bad_state[env] = (unsigned char)bad;
       if (ep_info) { ep_info[2 * env] = (float)s.ep_ret; ep_info[2 * env + 1] = (float)s.ep_len; }
     }
-    if (comps && lane < 8) comps[(size_t)env * 8 + lane] = (float)s.rwd[lane];
-    if (term_obs) for (int i = lane; i < nobs; i += 64) term_obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
+    if (comps && lane < 8) comps[(size_t)env * 8 + lane] = bad ? (lane == 6 ? 1.0f : 0.0f) : (float)s.rwd[lane];
+    if (term_obs && !bad) for (int i = lane; i < nobs; i += 64) term_obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
   }
   SYNC();
   if (is_done) {
@@ -388,7 +398,12 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
     SYNC();
     baoding_reset(M, K, s, env);
   }
-  PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i]; }
+  PHASE {
+    for (int i = lane; i < nobs; i += 64) {
+      obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
+      if (term_obs && bad) term_obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
+    }
+  }
   SYNC();
   store_env(M, L, rec, s);
 }
@@ -404,7 +419,12 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
   const int nobs = K.n_hand + 24 + M.na;
   load_env(M, L, rec, s);
   baoding_step_core(M, K, s, act + (size_t)env * M.nu);
-  const int fall = s.rwd[6] != 0 || s.bad;
+  const int bad = s.bad, fall = s.rwd[6] != 0 || bad;
+  if (bad) {                        // blown-up env: back to a finite reset state (see env_step)
+    PHASE { if (lane == 0) s.episode++; }
+    SYNC();
+    baoding_reset(M, K, s, env);
+  }
   PHASE {
     if (lane == 0 && done_out) done_out[env] = (unsigned char)fall;
     for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -275,9 +276,12 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   }
   m->ngw = (int)m->gw_elem.size();
   if (m->gw_elem.empty()) m->gw_elem.push_back(0);
-  LIM(3 * (size_t)m->nwrap * sizeof(double) > MYO_NCON_MAX * sizeof(ContactRec<double>) ||
-      3 * (size_t)m->nwrap * sizeof(float) > MYO_NCON_MAX * sizeof(ContactRec<float>), "tendon path elements (staging area of the tendon stage)")
-  LIM(7 * m->ngw > 4 * MYO_NEFC_MAX, "tendon wrap geoms (staging area of the tendon stage)")
+  // staging area of the tendon stage: T path points in con[], then (8-byte aligned) 7 HP wrap results per geom wrap,
+  // running on through the limit-row and efc_* arrays up to efc_active
+  LIM(((3 * (size_t)m->nwrap * sizeof(double) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
+          offsetof(Scratch<double>, efc_active) - offsetof(Scratch<double>, con) ||
+      ((3 * (size_t)m->nwrap * sizeof(float) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
+          offsetof(Scratch<float>, efc_active) - offsetof(Scratch<float>, con), "tendon path elements / wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
   for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
   // qfrc_actuator gather, dof-major: for dof d the (ten_J offset << 6 | actuator) pairs of every
@@ -397,7 +401,6 @@ extern "C" int myo_model_size(const myo_model* m, const char* n) {
 
 // ------------------------------------------------------------------------------------------ batch
 struct myo_batch;
-static const myo_batch* g_bound = nullptr;   // batch whose model/task currently sit in __constant__ memory
 struct myo_batch {
   int n, device, dtype, nobs;
   myo_task_cfg cfg;
@@ -409,6 +412,7 @@ struct myo_batch {
   DevModel<double> Md;
   DevModel<float> Mf;
   int nq, nv, nu, na, nbody, nsite, ntendon, ngeom, integrator;
+  unsigned char* bad_state;    // caller-owned dev uint8[n] or null (myo_batch_set_bad_state_buffer)
   int timing;
   double ms_sum;
   int ms_cnt;
@@ -417,6 +421,48 @@ struct myo_batch {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
 #endif
 };
+
+#ifndef MYO_EMU
+// Model / task parameters live in __constant__ memory (scalar loads in every phase function).  __constant__
+// symbols exist once PER DEVICE, so what is bound is tracked per device; they are (re)uploaded on the launch
+// stream whenever a different batch launches on that device.  If the batch bound before launched on another
+// stream, the upload first waits for that stream's work (its kernels may still be reading the constants).
+#define MYO_MAX_DEVICES 64
+struct BoundDev { const myo_batch* b = nullptr; hipStream_t last = nullptr; bool have_last = false; hipEvent_t ev = nullptr; };
+static BoundDev g_bound[MYO_MAX_DEVICES];
+static std::mutex g_bound_mu;
+// every launch entry point runs on the batch's own device, whatever the caller's current device is
+struct DeviceGuard {
+  int prev = -1; bool switched = false;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess); }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+static void unbind(const myo_batch* b, int device) {
+  std::lock_guard<std::mutex> lk(g_bound_mu);
+  if (device >= 0 && device < MYO_MAX_DEVICES && g_bound[device].b == b) g_bound[device].b = nullptr;
+}
+static int bind_constants(myo_batch* b, hipStream_t st) {
+  if (b->device < 0 || b->device >= MYO_MAX_DEVICES) return fail(MYO_E_ARG, "device index out of range");
+  std::lock_guard<std::mutex> lk(g_bound_mu);
+  BoundDev& g = g_bound[b->device];
+  if (g.b == b) { g.last = st; g.have_last = true; return 0; }
+  hipError_t e = hipSuccess;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  if (g.b && g.have_last && g.last != st && cap == hipStreamCaptureStatusNone) {
+    if (!g.ev) e = hipEventCreateWithFlags(&g.ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventRecord(g.ev, g.last);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, g.ev, 0);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipSuccess; }    // the other stream may be gone: nothing left to wait for
+  }
+  if (b->dtype == MYO_F64) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_d), &b->Md, sizeof b->Md, 0, hipMemcpyHostToDevice, st);
+  else e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_f), &b->Mf, sizeof b->Mf, 0, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_task), &b->K, sizeof b->K, 0, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return fail(MYO_E_DEVICE, "binding model constants failed: %s", hipGetErrorString(e));
+  g.b = b; g.last = st; g.have_last = true;
+  return 0;
+}
+#endif
 
 template <typename T>
 static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& allocs) {
@@ -520,7 +566,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   int rc = be_set_device(device);
   if (rc) return fail(MYO_E_DEVICE, "hipSetDevice(%d): %s", device, be_errstr(rc));
   myo_batch* b = new myo_batch();
-  b->n = n_envs; b->device = device; b->dtype = dtype; b->timing = 0; b->ms_sum = 0; b->ms_cnt = 0;
+  b->n = n_envs; b->device = device; b->dtype = dtype; b->bad_state = nullptr; b->timing = 0; b->ms_sum = 0; b->ms_cnt = 0;
   b->integrator = m->integrator;
   b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon; b->ngeom = m->ngeom;
   if (cfg) b->cfg = *cfg; else memset(&b->cfg, 0, sizeof b->cfg);
@@ -583,8 +629,8 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
 extern "C" void myo_batch_destroy(myo_batch* b) {
   if (!b) return;
 #ifndef MYO_EMU
-  if (g_bound == b) g_bound = nullptr;
-  (void)hipSetDevice(b->device);
+  unbind(b, b->device);
+  DeviceGuard guard(b->device);
   for (auto& pr : b->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
 #endif
@@ -625,7 +671,7 @@ extern "C" int myo_debug_read_prof(double* out16, int reset) {
 template <typename T, bool RK>
 __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, const float* act,
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
-                                             float* term_obs, float* comps, float* ep_info) {
+                                             float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
@@ -635,7 +681,7 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
   if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
   __syncthreads();
 #endif
-  env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+  env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
 #ifdef MYO_PROF
   PROF(s, 0)
   __syncthreads();
@@ -714,18 +760,6 @@ static void timing_end(myo_batch* b, hipStream_t st) {
 #endif
 
 #ifndef MYO_EMU
-// model / task parameters live in __constant__ memory (scalar loads in every phase function);
-// (re)bound on the launch stream whenever a different batch launches.
-static int bind_constants(myo_batch* b, hipStream_t st) {
-  if (g_bound == b) return 0;
-  hipError_t e;
-  if (b->dtype == MYO_F64) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_d), &b->Md, sizeof b->Md, 0, hipMemcpyHostToDevice, st);
-  else e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_f), &b->Mf, sizeof b->Mf, 0, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_task), &b->K, sizeof b->K, 0, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) return fail(MYO_E_DEVICE, "binding model constants failed: %s", hipGetErrorString(e));
-  g_bound = b;
-  return 0;
-}
 static unsigned lds_dyn(const myo_batch* b) {
   const int rk = b->integrator == 1;
 #ifdef MYO_LDS_PAD_EXPERIMENT
@@ -736,7 +770,7 @@ static unsigned lds_dyn(const myo_batch* b) {
   if (b->dtype == MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<double>)) + rk * sizeof(RkScratch<double>));
   return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + rk * sizeof(RkScratch<float>));
 }
-#define BIND_OR_RETURN(b, st) { int _rc = bind_constants(b, st); if (_rc) return _rc; }
+#define BIND_OR_RETURN(b, st) DeviceGuard _guard((b)->device); { int _rc = bind_constants(b, st); if (_rc) return _rc; }
 #endif
 
 static void xfer(myo_batch* b, int off, int cnt, double* ext, int to_ext, be_stream st) {
@@ -749,6 +783,7 @@ static void xfer(myo_batch* b, int off, int cnt, double* ext, int to_ext, be_str
       if (to_ext) ext[(size_t)e * cnt + k] = *r; else *r = ext[(size_t)e * cnt + k];
     }
 #else
+  DeviceGuard guard(b->device);
   const long long tot = (long long)b->n * cnt;
   hipLaunchKernelGGL(k_state, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->rec, b->L.stride, off, cnt, b->n, ext, to_ext);
 #endif
@@ -763,6 +798,7 @@ static void xfer_i(myo_batch* b, int off, int cnt, int* ext, int to_ext, be_stre
       if (to_ext) ext[(size_t)e * cnt + k] = (int)*r; else *r = (double)ext[(size_t)e * cnt + k];
     }
 #else
+  DeviceGuard guard(b->device);
   const long long tot = (long long)b->n * cnt;
   hipLaunchKernelGGL(k_state_i, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, b->rec, b->L.stride, off, cnt, b->n, ext, to_ext);
 #endif
@@ -789,6 +825,11 @@ extern "C" int myo_batch_set_state(myo_batch* b, const double* qpos, const doubl
 #endif
   return MYO_OK;
 }
+extern "C" int myo_batch_set_bad_state_buffer(myo_batch* b, uint8_t* bad_state) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  b->bad_state = bad_state;
+  return MYO_OK;
+}
 extern "C" int myo_batch_warmstart(myo_batch* b, double* get_w, const double* set_w, void* stream) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   be_stream st = (be_stream)stream;
@@ -812,7 +853,9 @@ extern "C" int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   if (!(gid0 == -1 && gidn == -1) && (gid0 < 0 || gidn <= gid0 || gidn > b->ngeom)) return fail(MYO_E_ARG, "bad geom range");
   b->K.objg_gid0 = gid0; b->K.objg_gidn = gidn;
-  g_bound = nullptr;                 // the task block in __constant__ memory is re-uploaded at the next launch
+#ifndef MYO_EMU
+  unbind(b, b->device);              // the task block in __constant__ memory is re-uploaded at the next launch
+#endif
   return MYO_OK;
 }
 extern "C" int myo_batch_bind_constants(myo_batch* b, void* stream) {
@@ -821,6 +864,7 @@ extern "C" int myo_batch_bind_constants(myo_batch* b, void* stream) {
   (void)stream;
   return MYO_OK;
 #else
+  DeviceGuard guard(b->device);
   return bind_constants(b, (hipStream_t)stream);
 #endif
 }
@@ -867,17 +911,17 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
   if (!b->K.kind) return fail(MYO_E_STATE, "batch has no task layer");
 #ifdef MYO_EMU
   (void)stream;
-  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_step<double>(b->Md, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info))
-  else FOR_ENVS_F32(env_step<float>(b->Mf, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info))
+  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_step<double>(b->Md, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
+  else FOR_ENVS_F32(env_step<float>(b->Mf, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
 #else
   hipStream_t st = (hipStream_t)stream;
   BIND_OR_RETURN(b, st)
   timing_begin(b, st);
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info))
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
   timing_end(b, st);
   LAUNCH_CHECK(b)
 #endif

@@ -10,7 +10,7 @@ from __future__ import annotations
 from .baoding import BaodingVecEnv
 from .config import REGISTRATION
 
-_BATCH_KEYS = ("num_envs", "device", "seed", "dtype", "model", "integrator", "lib")
+_BATCH_KEYS = ("num_envs", "device", "seed", "dtype", "model", "integrator")
 
 
 class EnvironmentFactory:

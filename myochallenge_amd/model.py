@@ -13,8 +13,9 @@ arrays the physics uses, this derives the static tables a wave-per-env stepper w
 
 Feature gates (raise ``ModelError``): ball joints, equality constraints, friction loss,
 elliptic cones, inside-wrapping side sites, mesh/hfield colliders.  Geom pairs whose narrow
-phase is not implemented (cylinder/ellipsoid/box-box) are dropped and listed in
-``CompiledModel.dropped_pairs`` so callers can see the deviation.
+phase is not implemented (cylinder/ellipsoid/box-box) make ``compile_model`` raise
+``UnsupportedContactsError`` unless the caller opts in with ``unsupported_contacts="drop"``; the dropped pairs are
+then listed in ``CompiledModel.dropped_pairs``.
 """
 from __future__ import annotations
 
@@ -154,7 +155,17 @@ def collision_pairs(m: MjbModel):
     return pairs, dropped
 
 
-def compile_model(m: MjbModel, *, integrator: int | None = None) -> CompiledModel:
+class UnsupportedContactsError(ValueError):
+    """The model has colliding geom pairs whose narrow phase the stepper does not implement."""
+
+
+def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_contacts: str = "error") -> CompiledModel:
+    """unsupported_contacts: what to do with colliding geom pairs that have no narrow phase here (anything with a
+    cylinder or an ellipsoid, box-box, mesh): "error" (default) refuses the model — a contact MuJoCo would generate
+    must not vanish silently — "drop" compiles without them and lists them in ``CompiledModel.dropped_pairs``
+    (an explicit opt-in: the physics then differs from MuJoCo's whenever such a pair would touch)."""
+    if unsupported_contacts not in ("error", "drop"):
+        raise ValueError("unsupported_contacts must be 'error' or 'drop'")
     f: Dict[str, np.ndarray] = {}
     f["sizes"] = np.array([m.sizes[k] for k in _SIZES], np.int32)
     if np.any(m.jnt_type == JNT_BALL):
@@ -178,6 +189,13 @@ def compile_model(m: MjbModel, *, integrator: int | None = None) -> CompiledMode
         dd[i] = 1 if p < 0 else dd[p] + 1
     f["x_dof_depth"] = dd
     pairs, dropped = collision_pairs(m)
+    if dropped and unsupported_contacts == "error":
+        gname = m.names.get("geom", []) if isinstance(m.names, dict) else []
+        nm = lambda g: gname[g] if g < len(gname) and gname[g] else f"geom{g}"
+        some = ", ".join(f"{nm(a)}(type {int(m.geom_type[a])})-{nm(b)}(type {int(m.geom_type[b])})" for a, b in dropped[:6])
+        raise UnsupportedContactsError(
+            f"{len(dropped)} colliding geom pair(s) have no narrow phase in this stepper: {some}"
+            f"{' ...' if len(dropped) > 6 else ''}.  Pass unsupported_contacts='drop' to compile without them.")
     pa = np.array(pairs, np.int32).reshape(-1, 2)
     f["x_pair_geom1"] = np.ascontiguousarray(pa[:, 0])
     f["x_pair_geom2"] = np.ascontiguousarray(pa[:, 1])

@@ -16,7 +16,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmyobatch.so")
 
-MYO_F64, MYO_F32 = 0, 1
+MYO_F64, MYO_MIXED = 0, 1     # stepper arithmetic: all fp64 | mixed (fp64 state, kinematic chain, contact distances; fp32 dynamics)
+MYO_F32 = MYO_MIXED             # the name of round 1, when dtype 1 was a pure fp32 stepper
 TASK_NONE, TASK_BAODING_P1, TASK_BAODING_P2 = 0, 1, 2
 CHOICE_FIXED, CHOICE_CW, CHOICE_CCW, CHOICE_RANDOM = 0, 1, 2, 3
 N_RWD = 8
@@ -78,6 +79,7 @@ class NativeLib:
         L.myo_batch_set_state.argtypes = [vp] * 6
         L.myo_batch_set_task.argtypes = [vp] * 5
         L.myo_batch_warmstart.argtypes = [vp] * 4
+        L.myo_batch_set_bad_state_buffer.argtypes = [vp, vp]
         L.myo_batch_get_task.argtypes = [vp] * 5
         L.myo_batch_bind_constants.argtypes = [vp, vp]
         L.myo_batch_set_object_group.argtypes = [vp, i32, i32]
@@ -132,7 +134,7 @@ EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_destroy", "myo_model_size", "myo_batch_create",
     "myo_batch_destroy", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
     "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_physics_step", "myo_batch_get_state",
-    "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_bind_constants", "myo_batch_forward_dump",
+    "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
     "myo_vecnorm_step", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
@@ -204,6 +206,12 @@ class Batch:
 
     def set_state(self, qpos=None, qvel=None, act=None, time=None, stream=None):
         self.lib.check(self.lib.L.myo_batch_set_state(self.h, _ptr(qpos), _ptr(qvel), _ptr(act), _ptr(time), stream))
+
+    def set_bad_state_buffer(self, buf):
+        """uint8[N] device buffer (kept alive by the caller) that every step() fills with 1 for envs reset after a
+        numerical blow-up; None to stop reporting."""
+        self._bad_buf = buf
+        self.lib.check(self.lib.L.myo_batch_set_bad_state_buffer(self.h, _ptr(buf)))
 
     def warmstart(self, get=None, set=None, stream=None):
         """Read (``get``) and / or overwrite (``set``) qacc_warmstart, double[N, nv]."""

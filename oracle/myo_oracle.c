@@ -1332,7 +1332,10 @@ void orc_baoding_step(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg, O
   st->counter++;
   for (int i = 0; i < m->nu; ++i) { /* normalize_act: float32 sigmoid(5(a-0.5)) after clip */
     float a = action[i]; if (a < -1.f) a = -1.f; else if (a > 1.f) a = 1.f;
-    float c = 1.0f/(1.0f + expf(-5.0f*(a-0.5f)));
+    /* every operation but exp is an IEEE float32 operation (identical on any platform); exp is taken as the
+     * CORRECTLY ROUNDED float32 exponential, (float)exp((double)x) — numpy's float32 exp, glibc's expf and a GPU's
+     * expf each differ from it by at most 1 ulp, and from each other, on some arguments */
+    float c = 1.0f/(1.0f + (float)exp((double)(-5.0f*(a-0.5f))));
     d->ctrl[i] = (double)c;
   }
   for (int k = 0; k < cfg->frame_skip; ++k) orc_step(m, d);

@@ -112,6 +112,20 @@ class OracleData:
     def reset(self):
         lib().orc_reset(self.model.h, self.h)
 
+    def set_ball_params(self, cfg, ball_d):
+        """Per-env ball physics as CustomBaodingP2Env.reset writes it into its own model
+        (/root/reference/src/envs/baoding.py:559-604): ball_d = mass1, mass2, friction1[3], friction2[3],
+        size1, size2.  Only body_mass / geom_friction / geom_size[0] change — the reference does not re-run
+        mj_setConst (comment at :562), so body_inertia, body_invweight0 and geom_rbound stay nominal, which is
+        what orc_forward then sees.  orc_reset restores the model's values: call this again after a reset."""
+        ball_d = np.asarray(ball_d, float)
+        self.arr("body_mass")[cfg.obj1_bid], self.arr("body_mass")[cfg.obj2_bid] = ball_d[0], ball_d[1]
+        fr = self.arr("geom_friction")
+        fr[3 * cfg.obj1_gid:3 * cfg.obj1_gid + 3] = ball_d[2:5]
+        fr[3 * cfg.obj2_gid:3 * cfg.obj2_gid + 3] = ball_d[5:8]
+        sz = self.arr("geom_size")
+        sz[3 * cfg.obj1_gid], sz[3 * cfg.obj2_gid] = ball_d[8], ball_d[9]
+
     def fwd_position(self):
         lib().orc_fwd_position(self.model.h, self.h)
 

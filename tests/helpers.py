@@ -34,7 +34,8 @@ class Mem:
 
 
 def oracle_for(mj, integrator=None):
-    cm = compile_model(mj, integrator=integrator)
+    # "drop": the reference's finger / load models have cylinder and ellipsoid geoms; the oracle gets the same pair list
+    cm = compile_model(mj, integrator=integrator, unsupported_contacts="drop")
     om = OracleModel(cm.to_blob())
     return cm, om, OracleData(om)
 
@@ -62,3 +63,23 @@ def default_state(which=2, period=5.0, xr=0.025, yr=0.028, s1=3 * np.pi / 4, s2=
 def rel_err(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def make_env(env_name, lib, **kwargs):
+    """``EnvironmentFactory.create(env_name, **kwargs)`` on an explicitly named native library (the lane-serial
+    emulation build).  Test plumbing: the public factory has no such key — the product only ever loads the HIP
+    library."""
+    from myochallenge_amd.envs.config import REGISTRATION
+    from myochallenge_amd.envs.environment_factory import _BATCH_KEYS
+    batch_kw = {k: kwargs.pop(k) for k in _BATCH_KEYS if k in kwargs}
+    num_envs = batch_kw.pop("num_envs", 1)
+    if env_name == "MixtureModelBaodingEnv":
+        from myochallenge_amd.envs.mixture import MixtureModelBaodingVecEnv
+        mix = {k: kwargs.pop(k) for k in ("base_model_path", "base_env_path", "base_env_name", "base_env_config",
+                                         "n_steps_base_model", "base_policy", "base_normalizer") if k in kwargs}
+        return MixtureModelBaodingVecEnv(env_name, num_envs, kwargs, **mix, **batch_kw, lib=lib)
+    if env_name in REGISTRATION:
+        from myochallenge_amd.envs.baoding import BaodingVecEnv
+        return BaodingVecEnv(env_name, num_envs, kwargs, **batch_kw, lib=lib)
+    from myochallenge_amd.envs.reorient import ReorientVecEnv
+    return ReorientVecEnv(env_name, num_envs, kwargs, **batch_kw, lib=lib)

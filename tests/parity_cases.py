@@ -3,11 +3,14 @@ source) and tests/test_gpu_parity.py (-m gpu: the HIP kernels on an MI355X).  Ev
 through the C ABI and compares with the oracle on the same seeded inputs.
 
 Tolerances: fp64 stepper vs fp64 oracle 1e-9 relative (different summation order only);
-fp32 stepper 1e-4 relative per step (north_star's stated tolerance).
+mixed stepper (MYO_MIXED: fp64 state / kinematic chain / contact distances, fp32 dynamics) 1e-4 relative
+over whole episodes (north_star's stated tolerance), see case_episode_trajectory.
 """
 import numpy as np
 
 from helpers import Mem, default_state, forward_dump, oracle_for, rel_err
+from oracle.oracle import OracleData
+from helpers import Mem as _Mem  # noqa: F401
 from myochallenge_amd import native
 from myochallenge_amd.envs.config import make_task_cfg, task_ids
 from oracle.oracle import baoding_step, make_cfg
@@ -42,11 +45,8 @@ def case_forward_stages(lib, models, dtype, tol):
         d.forward()
         cnt = get("counts", 4)
         same = (int(cnt[0]), int(cnt[1]), int(cnt[3])) == (d.ncon, d.nefc, d.nl)
-        # a ball resting at dist = 0 +- 1e-17 may or may not register as a contact in fp32
-        assert same or dtype == native.MYO_F32, (name, cnt)
+        assert same, (name, cnt)                    # contact / limit activation is decided in fp64 by both steppers
         for st in STAGES:
-            if st == "qacc" and not same:
-                continue
             ref = np.array(getattr(d, st))
             assert rel_err(get(st, ref.size), ref) < tol, (name, st, rel_err(get(st, ref.size), ref))
         b.close()
@@ -76,6 +76,99 @@ def case_trajectory(lib, mj, nsteps, dtype, tol, integrator=None, q0=None, seed=
     b.close()
 
 
+def episode_drift(lib, mj, dtype, streams, nsteps=200, integrator=None, env_name="CustomMyoBaodingBallsP1", ball_d=None):
+    """The trajectory-parity measurement the contract names (BASELINE.json north_star: "state-trajectory match
+    to the reference CPU step on identical seeds"): one env per action stream, `nsteps` env steps
+    (x frame_skip substeps) with the VecEnv's auto-reset, HIP (or emulation) stepper against the oracle stepped
+    with the same float32 actions.  streams = [(sigma, seed), ...]: actions ~ clip(N(0, sigma), -1, 1).
+    ball_d ([n, 10], optional): per-env ball mass / friction / size injected into both sides (P2 physics).
+
+    Returns per stream: err_q[t] = max |qpos - qpos_oracle| / max |qpos_oracle|  (the balls' z ~ 1.45 sets the
+    scale), err_obs[t] = max |obs - obs_oracle| on the 86-vector (terminal observation on the steps that end an
+    episode), ends = steps at which an episode ended.  If the two sides end an episode on different steps the
+    stream's errors are 1.0 from that step on."""
+    mem = Mem(lib)
+    cm, om, _ = oracle_for(mj, integrator=integrator)
+    n = len(streams)
+    tc = make_task_cfg(env_name, cm)
+    b = native.Batch(native.Model(cm, lib), tc, n, 0, 77, dtype)
+    obs = mem.zeros((n, 86), np.float32)
+    b.reset(None, obs)
+    if ball_d is not None:
+        b.set_task(None, None, mem.arr(ball_d))
+    ocfg = make_cfg(task_ids(cm))
+    orc = []
+    for e in range(n):
+        d = OracleData(om)
+        d.reset(); d.qpos[:23] = 0; d.qpos[0] = -1.57
+        if ball_d is not None:
+            d.set_ball_params(ocfg, ball_d[e])
+        orc.append([d, default_state(), 0])
+    rngs = [np.random.RandomState(seed) for _, seed in streams]
+    rew, done, trunc = mem.zeros(n, np.float32), mem.zeros(n, np.uint8), mem.zeros(n, np.uint8)
+    term = mem.zeros((n, 86), np.float32)
+    qp = mem.zeros((n, om.nq))
+    err_q, err_obs, ends = np.zeros((n, nsteps)), np.zeros((n, nsteps)), [[] for _ in range(n)]
+    split = [None] * n
+    for t in range(nsteps):
+        a = np.stack([np.clip(r.normal(0, sg, 39), -1, 1) for r, (sg, _) in zip(rngs, streams)]).astype(np.float32)
+        b.step(mem.arr(a, np.float32), obs, rew, done, trunc, term)
+        b.get_state(qp)
+        h_obs, h_term, h_done, h_trunc, h_qp = (mem.host(x) for x in (obs, term, done, trunc, qp))
+        for e in range(n):
+            if split[e] is not None:                     # the two sides ended an episode on different steps:
+                err_q[e, t] = err_obs[e, t] = 1.0        # nothing left to compare on this stream
+                continue
+            d, st, el = orc[e]
+            o, c = baoding_step(d, ocfg, st, a[e])
+            el += 1
+            o_done = bool(c[6]) or el >= 200
+            if bool(h_done[e]) != o_done:
+                split[e] = t
+                err_q[e, t] = err_obs[e, t] = 1.0
+                continue
+            if o_done:
+                assert bool(h_trunc[e]) == (not c[6])
+                err_obs[e, t] = np.abs(h_term[e] - o).max()
+                err_q[e, t] = err_q[e, t - 1] if t else 0.0      # the state was reset on the device: carry the last value
+                ends[e].append(t)
+                d.reset(); d.qpos[:23] = 0; d.qpos[0] = -1.57    # P1 reset without noise / RSI is deterministic
+                if ball_d is not None:
+                    d.set_ball_params(ocfg, ball_d[e])
+                orc[e] = [d, default_state(), 0]
+            else:
+                err_obs[e, t] = np.abs(h_obs[e] - o).max()
+                err_q[e, t] = np.abs(h_qp[e] - d.qpos).max() / np.abs(d.qpos).max()
+                orc[e][2] = el
+    b.close()
+    return {"streams": [list(x) for x in streams], "err_qpos_rel": err_q, "err_obs_abs": err_obs, "episode_ends": ends,
+            "episode_end_disagreement_at": split}
+
+
+def write_drift_record(r, path, dtype_name, integrator_name, nsteps):
+    """Drift table of episode_drift as JSON (every 10th step) — test evidence, copied into profiles/ per round."""
+    import json
+    import os
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    f3 = lambda v: float("%.3g" % v)
+    json.dump({"what": "HIP stepper vs oracle, tests/parity_cases.episode_drift: err_qpos_rel = max|qpos - qpos_oracle| / max|qpos_oracle|, "
+                       "err_obs_abs = max|obs - obs_oracle| (float32 observation, terminal observation on steps that end an episode)",
+               "dtype": dtype_name, "integrator": integrator_name, "env_steps": nsteps, "substeps_per_env_step": 10,
+               "streams (action sigma, seed)": r["streams"], "episode_ends": r["episode_ends"],
+               "episode_end_disagreement_at": r["episode_end_disagreement_at"],
+               "max_err_qpos_rel": [f3(v) for v in r["err_qpos_rel"].max(1)], "max_err_obs_abs": [f3(v) for v in r["err_obs_abs"].max(1)],
+               "err_qpos_rel_every_10th_step": [[f3(v) for v in row[9::10]] for row in r["err_qpos_rel"]],
+               "err_obs_abs_every_10th_step": [[f3(v) for v in row[9::10]] for row in r["err_obs_abs"]]}, open(path, "w"), indent=1)
+
+
+def case_episode_trajectory(lib, mj, dtype, streams, tol, nsteps=200, integrator=None):
+    """assert rel_err(qpos) <= tol and obs error <= max(tol, 1e-7: float32 obs) at EVERY step of `nsteps` env steps, for every stream."""
+    r = episode_drift(lib, mj, dtype, streams, nsteps, integrator)
+    worst_q, worst_o = r["err_qpos_rel"].max(), r["err_obs_abs"].max()
+    assert worst_q <= tol and worst_o <= max(tol, 1e-7), (worst_q, worst_o, r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
+    return r
+
+
 def case_task_step(lib, models, dtype, tol, nsteps=25):
     """env.step parity: obs (86), reward components, done — against the oracle's Baoding step."""
     mem = Mem(lib)
@@ -100,8 +193,8 @@ def case_task_step(lib, models, dtype, tol, nsteps=25):
         ret += c[7]
         dn = mem.host(done)
         got = mem.host(term)[2] if dn[2] else mem.host(obs)[2]
-        assert np.abs(got - o).max() < tol * 10 + 1e-6, (i, np.abs(got - o).max())
-        assert np.abs(mem.host(comps)[2] - c).max() < tol * 50 + 1e-5
+        assert np.abs(got - o).max() < max(tol, 2e-7), (i, np.abs(got - o).max())      # float32 outputs: 1 ulp of 1.45 is 1.2e-7
+        assert np.abs(mem.host(comps)[2] - c).max() < max(tol, 2e-6) * max(1.0, np.abs(c).max()), (i, mem.host(comps)[2], c)
         assert bool(dn[2]) == bool(c[6])
         if dn[2]:
             e = mem.host(ep)[2]
@@ -220,3 +313,86 @@ def case_reset_logic(lib, models, dtype):
                                          limit_init_angle=0.5, beta_init_angle=[0.9, 0.9])
     assert (bd[:, :2] >= 0.03).all() and (bd[:, :2] <= 0.3).all() and (bd[:, 8:] >= 0.018).all() and (bd[:, 8:] <= 0.024).all()
     assert (td[:, 0] >= 3 * np.pi / 4 - np.pi - 1e-9).all() and (td[:, 0] <= 3 * np.pi / 4 + np.pi + 1e-9).all()
+
+
+def case_reset_goldens(lib, models, golden_dir, dtype):
+    """tests/golden/reset_logic_goldens.json records what the REFERENCE reset() did on a recording
+    fake (tools/make_golden.py).  For every archived curriculum config the device reset must
+    touch exactly the same qpos slots, keep the untouched ones at init_qpos, draw the task
+    parameters from the same ranges and take the RSI branch (one zero-action step) when the
+    reference does with probability 0 / 1."""
+    import json
+    import os
+    from myochallenge_amd.envs.config import make_task_cfg
+    from myochallenge_amd.model import compile_model
+    from helpers import Mem
+    cases = json.load(open(os.path.join(golden_dir, "reset_logic_goldens.json")))
+    cm = compile_model(models["hand"])
+    mem = Mem(lib)
+    init = models["hand"].qpos0.copy(); init[:23] = 0; init[0] = -1.57
+    by_cfg = {}
+    for c in cases:
+        by_cfg.setdefault((c["variant"], c["config_index"]), []).append(c)
+    checked = 0
+    for (variant, ci), group in by_cfg.items():
+        cfg = dict(group[0]["config"])
+        name = "CustomMyoBaodingBallsP1" if variant == "p1" else "CustomMyoBaodingBallsP2"
+        # reference side: union over seeds of the slots its final set_state/robot.reset changed
+        ref_changed = np.zeros(37, bool)
+        ref_rsi = []
+        for c in group:
+            finals = [k for k in c["calls"] if k["call"] in ("set_state", "robot.reset")]
+            q = np.array(finals[-1]["qpos"])
+            ginit = np.array(c["calls"][[k["call"] for k in c["calls"]].index("robot.reset")]["qpos"])
+            ref_changed |= np.abs(q - ginit) > 0
+            ref_rsi.append(any(k["call"] == "step" for k in c["calls"]))
+            assert all(np.allclose(k["action"], 0) for k in c["calls"] if k["call"] == "step")   # RSI steps with zeros(39)
+        n = 48
+        b = native.Batch(native.Model(cm, lib), make_task_cfg(name, cm, **cfg), n, 0, 3, dtype)
+        obs = mem.zeros((n, 86), np.float32); b.reset(None, obs)
+        qp, tt = mem.zeros((n, 37)), mem.zeros(n)
+        ti, td, bd = mem.zeros((n, 2), np.int32), mem.zeros((n, 9)), mem.zeros((n, 10))
+        b.get_state(qp, None, None, tt); b.get_task(ti, td, bd)
+        dev_changed = np.abs(mem.host(qp) - init).max(0) > 1e-12
+        # ball xy slots move when RSI fires (targets differ from the init ball xy); the reference fake
+        # returns a random obs, so those 4 slots are marked changed there as well
+        assert (dev_changed == ref_changed).all(), (variant, ci, np.where(dev_changed != ref_changed))
+        dev_rsi = mem.host(ti)[:, 1] == 1
+        p = float(cfg.get("rsi_probability", 1)) if cfg.get("enable_rsi") else 0.0
+        if p in (0.0, 1.0):
+            assert all(r == bool(p) for r in ref_rsi) and (dev_rsi == bool(p)).all()
+        else:
+            assert abs(dev_rsi.mean() - p) < 0.25
+        # parameter ranges the reference sampled from
+        gx, gy, gp = cfg["goal_xrange"], cfg["goal_yrange"], cfg["goal_time_period"]
+        t = mem.host(td)
+        assert (t[:, 2] >= gx[0] - 1e-12).all() and (t[:, 2] <= gx[1] + 1e-12).all()
+        assert (t[:, 3] >= gy[0] - 1e-12).all() and (t[:, 3] <= gy[1] + 1e-12).all()
+        assert (t[:, 4] >= gp[0] - 1e-12).all() and (t[:, 4] <= gp[1] + 1e-12).all()
+        for c in group:
+            assert gx[0] - 1e-12 <= c["x_radius"] <= gx[1] + 1e-12 and gy[0] - 1e-12 <= c["y_radius"] <= gy[1] + 1e-12
+        b.close(); checked += 1
+    assert checked >= 20
+
+
+def p2_ball_params(n, seed=0):
+    """ball_d rows drawn from CustomBaodingP2Env's registration ranges (src/envs/__init__.py:62-73)."""
+    rng = np.random.RandomState(seed)
+    bd = np.zeros((n, 10))
+    bd[:, 0:2] = rng.uniform(0.03, 0.3, (n, 2))
+    for k, (nom, ch) in enumerate(zip((1.0, 0.005, 1e-4), (0.2, 0.001, 2e-5))):
+        bd[:, 2 + k] = rng.uniform(nom - ch, nom + ch, n)
+        bd[:, 5 + k] = rng.uniform(nom - ch, nom + ch, n)
+    bd[:, 8:10] = rng.uniform(0.018, 0.024, (n, 2))
+    return bd
+
+
+def case_p2_ball_physics(lib, mj, dtype, tol, nsteps=25, n=6):
+    """Config C's physics: per-env ball mass / friction / size (what CustomBaodingP2Env.reset writes into its
+    model, baoding.py:559-604, with inertia / invweight / rbound left nominal) injected through
+    myo_batch_set_task on the device and through OracleData.set_ball_params on the oracle."""
+    bd = p2_ball_params(n)
+    r = episode_drift(lib, mj, dtype, [(0.2, s) for s in range(n)], nsteps, ball_d=bd)
+    assert r["err_qpos_rel"].max() <= tol and r["err_obs_abs"].max() <= max(tol, 1e-7), (r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
+    nominal = episode_drift(lib, mj, dtype, [(0.2, 0)], 5)      # and the parameters do reach the physics
+    return r, nominal

@@ -6,6 +6,8 @@ import re
 
 import pytest
 
+from helpers import make_env
+
 from myochallenge_amd import native
 from myochallenge_amd.envs.config import REGISTRATION, make_task_cfg, resolve_kwargs
 from myochallenge_amd.model import compile_model
@@ -57,10 +59,10 @@ def test_environment_factory_names(emu_lib):
         EnvironmentFactory.create("Nope")
     with pytest.raises(NotImplementedError):
         EnvironmentFactory.create("CustomMyoPenTwirlRandom")          # named by the reference, outside the hot path
-    die = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=2, lib=emu_lib)
+    die = make_env("CustomMyoReorientP1", emu_lib, num_envs=2)
     assert die.observation_space.shape == (103,) and die.action_space.shape == (39,)
     die.close()
-    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=2, lib=emu_lib)
+    env = make_env("CustomMyoBaodingBallsP1", emu_lib, num_envs=2)
     assert env.num_envs == 2 and env.observation_space.shape == (86,) and env.action_space.shape == (39,)
     env.close()
 

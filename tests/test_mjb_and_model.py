@@ -41,7 +41,7 @@ def test_mjb_rejects_garbage(golden_dir):
 
 
 def test_blob_roundtrip(models):
-    cm = compile_model(models["finger"])
+    cm = compile_model(models["finger"], unsupported_contacts="drop")
     blob = cm.to_blob()
     magic, ver, nf, tot = struct.unpack_from("<IIII", blob, 0)
     assert magic == 0x4D4F594D and ver == 1 and tot == len(blob) and nf == len(cm.fields)
@@ -59,8 +59,12 @@ def test_collision_pair_filter(models):
     assert all("ball" in names[a] or "ball" in names[b] for a, b in zip(g1, g2))
     assert sum(1 for a, b in zip(g1, g2) if "ball" in names[a] and "ball" in names[b]) == 1
     assert cm.dropped_pairs == []
-    # finger model: cylinder / ellipsoid pairs are reported as dropped, not silently lost
-    assert len(compile_model(models["finger"]).dropped_pairs) > 0
+    # finger model: cylinder / ellipsoid pairs make the model an error unless the caller opts in, and are then listed
+    import pytest
+    from myochallenge_amd.model import UnsupportedContactsError
+    with pytest.raises(UnsupportedContactsError):
+        compile_model(models["finger"])
+    assert len(compile_model(models["finger"], unsupported_contacts="drop").dropped_pairs) > 0
 
 
 def test_feature_gates(models):

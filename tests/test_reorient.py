@@ -5,6 +5,8 @@ import os
 
 import numpy as np
 import pytest
+
+from helpers import make_env
 import torch
 
 
@@ -42,7 +44,7 @@ def test_rotation_helpers_are_consistent():
 
 def test_reorient_env_logic_on_emulation(emu_lib):
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
-    mk = lambda **kw: EnvironmentFactory.create("CustomMyoReorientP1", num_envs=3, lib=emu_lib, seed=1, dtype="f64", **kw)
+    mk = lambda **kw: make_env("CustomMyoReorientP1", emu_lib, num_envs=3, seed=1, dtype="f64", **kw)
     env = mk(max_episode_steps=4)
     obs = env.reset_tensor().clone()
     assert obs.shape == (3, 103) and env.obs_dim == 103 and env.act_dim == 39 and env.frame_skip == 5
@@ -86,7 +88,7 @@ def test_reorient_env_logic_on_emulation(emu_lib):
     a, b = mk(), mk()
     assert torch.equal(a.reset_tensor(), b.reset_tensor())
     # phase 2: per-env die size delta and friction through the object group (reorient.py:136-147)
-    p2 = EnvironmentFactory.create("CustomMyoReorientP2", num_envs=3, lib=emu_lib, seed=1, dtype="f64")
+    p2 = make_env("CustomMyoReorientP2", emu_lib, num_envs=3, seed=1, dtype="f64")
     assert p2.physical_randomisation_applied and p2.object_gidn - p2.object_gid0 == 20
     assert float((p2.reset_tensor()[:, 49:52].double() - p2.goal_pos).abs().max()) < 1e-6
     bd = p2._ball_d
@@ -97,7 +99,7 @@ def test_reorient_env_logic_on_emulation(emu_lib):
         assert torch.isfinite(o).all()
     # a bigger die rests higher on the palm; with a zero delta and nominal friction the group changes nothing
     def settle(delta, use_group):
-        e = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=1, lib=emu_lib, seed=1, dtype="f64")
+        e = make_env("CustomMyoReorientP1", emu_lib, num_envs=1, seed=1, dtype="f64")
         e.reset_tensor()
         if use_group:
             e.batch.set_object_group(e.object_gid0, e.object_gidn)
@@ -112,8 +114,8 @@ def test_reorient_env_logic_on_emulation(emu_lib):
     with pytest.raises(TypeError):
         mk(not_a_kwarg=1)
     # sync-free (graph-capturable) step == indexed step, except for the random goals of the rows that reset
-    ea = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=3, lib=emu_lib, seed=4, dtype="f64", max_episode_steps=2)
-    eb = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=3, lib=emu_lib, seed=4, dtype="f64", max_episode_steps=2)
+    ea = make_env("CustomMyoReorientP1", emu_lib, num_envs=3, seed=4, dtype="f64", max_episode_steps=2)
+    eb = make_env("CustomMyoReorientP1", emu_lib, num_envs=3, seed=4, dtype="f64", max_episode_steps=2)
     eb.sync_free = True
     ea.reset_tensor(); eb.reset_tensor()
     for name in ("goal_pos", "goal_quat", "_qp", "pos_dist", "rot_dist"):
@@ -138,7 +140,7 @@ def test_reorient_p2_randomised_die_matches_emulation(hip_lib, emu_lib):
     lane-serial CPU build of the same sources agree in fp64 on identical states, dies and actions."""
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
     g = EnvironmentFactory.create("CustomMyoReorientP2", num_envs=8, seed=5, dtype="f64")
-    c = EnvironmentFactory.create("CustomMyoReorientP2", num_envs=8, seed=5, dtype="f64", lib=emu_lib)
+    c = make_env("CustomMyoReorientP2", emu_lib, num_envs=8, seed=5, dtype="f64")
     assert g.physical_randomisation_applied
     g.reset_tensor()
     c.reset_tensor()

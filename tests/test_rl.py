@@ -6,6 +6,8 @@ import socket
 
 import numpy as np
 import pytest
+
+from helpers import make_env
 import torch
 
 from myochallenge_amd.rl.policy import ActorCriticPolicy
@@ -57,7 +59,7 @@ def test_vecnormalize_reads_reference_pickle(golden_dir):
 
 def test_vecnormalize_load_save_roundtrip(golden_dir, tmp_path, emu_lib):
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
-    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=2, lib=emu_lib)
+    env = make_env("CustomMyoBaodingBallsP1", emu_lib, num_envs=2)
     v = VecNormalize.load(os.path.join(golden_dir, "normalized_env_phase1_final.pkl"), env)
     obs = v.reset()
     assert obs.shape == (2, 86) and np.abs(obs).max() <= 10.0
@@ -100,7 +102,7 @@ def test_entropy_matches_reference_log(golden_dir):
 @pytest.mark.parametrize("hidden", [None, 32])
 def test_ppo_runs_on_emulated_env(emu_lib, hidden):
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
-    env = EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=4, lib=emu_lib, seed=1, dtype="f64")
+    env = make_env("CustomMyoBaodingBallsP2", emu_lib, num_envs=4, seed=1, dtype="f64")
     venv = VecNormalize(env)
     pol = ActorCriticPolicy(86, 39, (32, 32), (32, 32), lstm_hidden_size=hidden)
     before = [p.detach().clone() for p in pol.parameters()]
@@ -124,7 +126,8 @@ def _dp_worker(rank, world, port, emu_path, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     pol = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=None)
-    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=2, lib=native.load(emu_path), seed=100 + rank, dtype="f64")
+    from helpers import make_env
+    env = make_env("CustomMyoBaodingBallsP1", native.load(emu_path), num_envs=2, seed=100 + rank, dtype="f64")
     algo = PPO(env, pol, PPOConfig(n_steps=4, batch_size=8, n_epochs=1, bf16=False))
     algo.collect_rollouts()
     algo.train()
@@ -244,7 +247,7 @@ def test_batched_evaluation_and_callbacks(emu_lib, tmp_path, hidden):
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
     from myochallenge_amd.metrics import EnvDumpCallback, EvalCallback, EvaluateLSTM, evaluate_policy
     from myochallenge_amd.metrics.evaluation import summarize
-    mk = lambda: EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=3, lib=emu_lib, seed=5, dtype="f64", max_episode_steps=4)
+    mk = lambda: make_env("CustomMyoBaodingBallsP1", emu_lib, num_envs=3, seed=5, dtype="f64", max_episode_steps=4)
     torch.manual_seed(0)
     pol = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=hidden)
     env = mk()
@@ -284,18 +287,18 @@ def test_mixture_model_env_runs_base_policy_inside_reset(emu_lib):
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
     torch.manual_seed(1)
     base = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=8)
-    kw = dict(num_envs=3, lib=emu_lib, seed=9, dtype="f64", max_episode_steps=3)
+    kw = dict(num_envs=3, seed=9, dtype="f64", max_episode_steps=3)
 
     class Ident:                       # base normaliser stand-in (VecNormalize.load path is covered elsewhere)
         training = True
         def normalize_obs(self, o): return o
-    mix = EnvironmentFactory.create("MixtureModelBaodingEnv", base_model_path=None, base_env_path=None, base_policy=base,
-                                    base_normalizer=Ident(), n_steps_base_model=4, **kw)
+    mix = make_env("MixtureModelBaodingEnv", emu_lib, base_model_path=None, base_env_path=None, base_policy=base,
+                   base_normalizer=Ident(), n_steps_base_model=4, **kw)
     assert mix.env_base.training is False
     obs_mix = mix.reset_tensor().clone()
 
     # the same thing by hand on the plain phase-2 env
-    ref = EnvironmentFactory.create("CustomMyoBaodingBallsP2", **kw)
+    ref = make_env("CustomMyoBaodingBallsP2", emu_lib, **kw)
     obs = ref.reset_tensor()
     state, starts = base.initial_state(3, ref.device), torch.ones(3)
     allm = torch.ones(3, dtype=torch.uint8)
@@ -379,7 +382,7 @@ def test_mixture_of_ensembles_matches_sequential_flow(emu_lib, golden_dir, mode)
     from myochallenge_amd.eval_mixture_of_ensembles import SuperModel, eval_perf
     from myochallenge_amd.models.classifier import TaskClassifier, load_scaler
     N, H = 3, 15
-    mk = lambda: EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=N, lib=emu_lib, seed=21, dtype="f64", max_episode_steps=H)
+    mk = lambda: make_env("CustomMyoBaodingBallsP2", emu_lib, num_envs=N, seed=21, dtype="f64", max_episode_steps=H)
     torch.manual_seed(3)
     pols = [ActorCriticPolicy(86, 39, (8,), (8,), lstm_hidden_size=6) for _ in range(4)]
 
@@ -473,7 +476,7 @@ def test_myotrainer_matches_reference_surface(emu_lib, golden_dir, tmp_path):
     from myochallenge_amd.rl.vec_normalize import _StubUnpickler
     from myochallenge_amd.train.trainer import MyoTrainer
     env_config = {"weighted_reward_keys": {"pos_dist_1": 2, "pos_dist_2": 2, "solved": 5}, "task_choice": "random"}
-    env = EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=2, lib=emu_lib, seed=3, dtype="f64", max_episode_steps=5, **env_config)
+    env = make_env("CustomMyoBaodingBallsP2", emu_lib, num_envs=2, seed=3, dtype="f64", max_episode_steps=5, **env_config)
     venv = VecNormalize(env)
     log = str(tmp_path / "run")
     ck = CheckpointCallback(save_freq=8, save_path=log, save_vecnormalize="True")

@@ -8,7 +8,7 @@ from myochallenge_amd import native
 from oracle.oracle import OracleModel, OracleData
 lib = native.load('tests/emu/libmyobatch_emu.so'); print(lib.version)
 def compare(name, mj, q=None, v=None, act=None, ctrl=None, dtype=native.MYO_F64):
-    cm=compile_model(mj)
+    cm=compile_model(mj, unsupported_contacts="drop")
     om=OracleModel(cm.to_blob()); d=OracleData(om)
     nm = native.Model(cm, lib); b = native.Batch(nm, None, 1, 0, 0, dtype)
     nq,nv,na,nu=om.nq,om.nv,om.na,om.nu

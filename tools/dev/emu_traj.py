@@ -10,7 +10,7 @@ from oracle.oracle import OracleModel, OracleData, make_cfg, BaodingState, baodi
 lib = native.load('tests/emu/libmyobatch_emu.so')
 rng=np.random.RandomState(0)
 def traj(name, mj, nsteps, q=None, dtype=native.MYO_F64, integrator=None):
-    cm=compile_model(mj, integrator=integrator)
+    cm=compile_model(mj, integrator=integrator, unsupported_contacts="drop")
     om=OracleModel(cm.to_blob()); d=OracleData(om)
     nm=native.Model(cm, lib); b=native.Batch(nm, None, 1, 0, 0, dtype)
     nq,nv,na,nu=om.nq,om.nv,om.na,om.nu

@@ -25,7 +25,7 @@ def T(a, dt=torch.float64):
 
 
 def fwd_compare(name, mj, q=None, v=None, act=None, ctrl=None, dtype=native.MYO_F64):
-    cm = compile_model(mj)
+    cm = compile_model(mj, unsupported_contacts="drop")
     om = OracleModel(cm.to_blob()); d = OracleData(om)
     nm = native.Model(cm, lib); b = native.Batch(nm, None, 4, 0, 0, dtype)
     nq, nv, na, nu = om.nq, om.nv, om.na, om.nu
@@ -61,7 +61,7 @@ fwd_compare("hand rand f32", mj, q=q2, v=vv, act=aa, ctrl=cc, dtype=native.MYO_F
 
 
 def traj(name, mj, nsteps, q=None, dtype=native.MYO_F64, integrator=None):
-    cm = compile_model(mj, integrator=integrator)
+    cm = compile_model(mj, integrator=integrator, unsupported_contacts="drop")
     om = OracleModel(cm.to_blob()); d = OracleData(om)
     nm = native.Model(cm, lib); b = native.Batch(nm, None, 2, 0, 0, dtype)
     nq, nv, na, nu = om.nq, om.nv, om.na, om.nu

@@ -46,7 +46,7 @@ class BaodingVecEnv:
     metadata = {"render.modes": []}
 
     def __init__(self, env_name: str, num_envs: int, config: Optional[dict] = None, *, device: int = 0,
-                 seed: int = 0, dtype: str = "f32", model=None, integrator: Optional[str] = None,
+                 seed: int = 0, dtype: str = "mixed", model=None, integrator: Optional[str] = None,
                  lib: Optional[native.NativeLib] = None):
         import torch
         config = dict(config or {})
@@ -71,7 +71,7 @@ class BaodingVecEnv:
         self._model = native.Model(model, self.lib)
         self._cfg = make_task_cfg(env_name, model, **config)
         self.max_episode_steps = int(self._cfg.max_episode_steps)
-        self.dtype = {"f32": native.MYO_F32, "f64": native.MYO_F64}[dtype]
+        self.dtype = {"mixed": native.MYO_MIXED, "f32": native.MYO_MIXED, "f64": native.MYO_F64}[dtype]      # "f32": round 1's name of the mixed stepper
         self.batch = native.Batch(self._model, self._cfg, num_envs, device, seed, self.dtype)
         self.num_envs = num_envs
         self.obs_dim = self.batch.obs_dim

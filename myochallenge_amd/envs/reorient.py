@@ -96,7 +96,7 @@ class _Box:
 class ReorientVecEnv:
     """Tensor API of BaodingVecEnv (reset_tensor / step_tensor -> obs, rew, done, trunc, term_obs, comps, ep_info)."""
 
-    def __init__(self, env_name: str, num_envs: int, config: dict, device: int = 0, seed: int = 0, dtype: str = "f32",
+    def __init__(self, env_name: str, num_envs: int, config: dict, device: int = 0, seed: int = 0, dtype: str = "mixed",
                  model=None, lib: Optional[native.NativeLib] = None, integrator=None):
         if env_name not in REGISTRATION:
             raise ValueError("Environment name not recognized:", env_name)
@@ -127,7 +127,7 @@ class ReorientVecEnv:
                 raise native.MyoError("ReorientVecEnv needs a GPU: libmyobatch has no CPU execution path")
             self.device = torch.device(f"cuda:{device}")
         self._model = native.Model(model, self.lib)
-        self.dtype = {"f32": native.MYO_F32, "f64": native.MYO_F64}[dtype]
+        self.dtype = {"mixed": native.MYO_MIXED, "f32": native.MYO_MIXED, "f64": native.MYO_F64}[dtype]      # "f32": round 1's name of the mixed stepper
         self.batch = native.Batch(self._model, None, num_envs, device, seed, self.dtype)      # physics only
         d, N = self.device, num_envs
         self.num_envs = N

@@ -81,42 +81,76 @@ struct OrcData {
   int nfields;
 };
 
+/* ------------------------------------------------------------------ flop counter ("counted, not guessed")
+ * Every floating-point add, subtract, multiply, divide, compare-free min/max and sqrt of the algorithm AS WRITTEN
+ * HERE (dense Jacobian and dense JᵀDJ, as MuJoCo's dense path for nv < 60) counts 1; a transcendental (sin, cos,
+ * exp, atan2, pow) counts 1 as well.  Counted per stage; not thread-safe (one process = one counter). */
+enum { ST_KIN, ST_COM, ST_TENDON, ST_CRB, ST_COLLIDE, ST_CONSTRAINT, ST_VELOCITY, ST_ACTUATION, ST_ACCEL, ST_NEWTON, ST_INTEGRATE, ST_TASK, ST_N };
+static double g_flops[ST_N];
+static int g_stage __attribute__((unused)) = ST_TASK;
+#ifdef ORC_COUNT_FLOPS      /* libmyo_oracle_flops.so; the timed CPU baseline uses the build without the counter */
+#define FL(n) (g_flops[g_stage] += (double)(n))
+#define STAGE(x) (g_stage = (x))
+#else
+#define FL(n) ((void)0)
+#define STAGE(x) ((void)0)
+#endif
+int orc_flops_enabled(void) {
+#ifdef ORC_COUNT_FLOPS
+  return 1;
+#else
+  return 0;
+#endif
+}
+void orc_flops(double* out, int reset) {
+  if (out) memcpy(out, g_flops, sizeof g_flops);
+  if (reset) memset(g_flops, 0, sizeof g_flops);
+}
+int orc_flops_stages(void) { return ST_N; }
+
 /* ------------------------------------------------------------------ small vector math */
-static double dot3(const double* a, const double* b) { return a[0]*b[0]+a[1]*b[1]+a[2]*b[2]; }
+static double dot3(const double* a, const double* b) { FL(5); return a[0]*b[0]+a[1]*b[1]+a[2]*b[2]; }
 static void cross3(double* r, const double* a, const double* b) {
+  FL(9);
   double x = a[1]*b[2]-a[2]*b[1], y = a[2]*b[0]-a[0]*b[2], z = a[0]*b[1]-a[1]*b[0];
   r[0]=x; r[1]=y; r[2]=z;
 }
-static double norm3(const double* a) { return sqrt(dot3(a,a)); }
+static double norm3(const double* a) { FL(1); return sqrt(dot3(a,a)); }
 static double normalize3(double* a) {
-  double n = norm3(a);
+  double n = norm3(a); FL(3);
   if (n < MINVAL) { a[0]=1; a[1]=0; a[2]=0; } else { a[0]/=n; a[1]/=n; a[2]/=n; }
   return n;
 }
 static void mulmatvec3(double* r, const double* R, const double* v) {
+  FL(15);
   double x=R[0]*v[0]+R[1]*v[1]+R[2]*v[2], y=R[3]*v[0]+R[4]*v[1]+R[5]*v[2], z=R[6]*v[0]+R[7]*v[1]+R[8]*v[2];
   r[0]=x; r[1]=y; r[2]=z;
 }
 static void mulmatTvec3(double* r, const double* R, const double* v) {
+  FL(15);
   double x=R[0]*v[0]+R[3]*v[1]+R[6]*v[2], y=R[1]*v[0]+R[4]*v[1]+R[7]*v[2], z=R[2]*v[0]+R[5]*v[1]+R[8]*v[2];
   r[0]=x; r[1]=y; r[2]=z;
 }
 static void quat2mat(double* R, const double* q) {
+  FL(39);
   double w=q[0],x=q[1],y=q[2],z=q[3];
   R[0]=w*w+x*x-y*y-z*z; R[1]=2*(x*y-w*z); R[2]=2*(x*z+w*y);
   R[3]=2*(x*y+w*z); R[4]=w*w-x*x+y*y-z*z; R[5]=2*(y*z-w*x);
   R[6]=2*(x*z-w*y); R[7]=2*(y*z+w*x); R[8]=w*w-x*x-y*y+z*z;
 }
 static void mulquat(double* r, const double* a, const double* b) {
+  FL(28);
   double t[4] = { a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3], a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2],
                   a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1], a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0] };
   memcpy(r, t, sizeof t);
 }
 static void normalize4(double* q) {
+  FL(13);
   double n = sqrt(q[0]*q[0]+q[1]*q[1]+q[2]*q[2]+q[3]*q[3]);
   if (n < MINVAL) { q[0]=1; q[1]=q[2]=q[3]=0; } else { q[0]/=n; q[1]/=n; q[2]/=n; q[3]/=n; }
 }
 static void axisangle2quat(double* q, const double* axis, double angle) {
+  FL(7);
   double s = sin(angle*0.5);
   q[0]=cos(angle*0.5); q[1]=axis[0]*s; q[2]=axis[1]*s; q[3]=axis[2]*s;
 }
@@ -333,6 +367,7 @@ void orc_kinematics(const OrcModel* m, OrcData* d) {
 /* ------------------------------------------------------------------ P2 comPos (cinert, cdof) */
 static void com_pos(const OrcModel* m, OrcData* d) {
   int nb = m->nbody;
+  FL(nb*(3 + 4 + 3) + nb*(27 + 45 + 30) + m->nv*12);    /* subtree com sums; inertia rotated into the world and shifted (cinert); cdof */
   double* sc = d->subtree_com; double* mass = d->w1; /* subtree mass scratch */
   for (int b = 0; b < nb; ++b) {
     mass[b] = d->body_mass[b];
@@ -392,18 +427,19 @@ static void com_pos(const OrcModel* m, OrcData* d) {
 static void mul_inert_vec(double* r, const double* I, const double* v) {
   const double* w = v; const double* l = v+3; const double* h = I+6; double mass = I[9];
   double t[3];
+  FL(15 + 3 + 9);
   r[0]=I[0]*w[0]+I[3]*w[1]+I[4]*w[2]; r[1]=I[3]*w[0]+I[1]*w[1]+I[5]*w[2]; r[2]=I[4]*w[0]+I[5]*w[1]+I[2]*w[2];
   cross3(t, h, l); r[0]+=t[0]; r[1]+=t[1]; r[2]+=t[2];
   cross3(t, h, w); r[3]=mass*l[0]-t[0]; r[4]=mass*l[1]-t[1]; r[5]=mass*l[2]-t[2];
 }
 static void cross_motion(double* r, const double* v, const double* mvec) {
   double a[3], b[3], c[3];
-  cross3(a, v, mvec); cross3(b, v, mvec+3); cross3(c, v+3, mvec);
+  cross3(a, v, mvec); cross3(b, v, mvec+3); cross3(c, v+3, mvec); FL(3);
   r[0]=a[0]; r[1]=a[1]; r[2]=a[2]; r[3]=b[0]+c[0]; r[4]=b[1]+c[1]; r[5]=b[2]+c[2];
 }
 static void cross_force(double* r, const double* v, const double* f) {
   double a[3], b[3], c[3];
-  cross3(a, v, f); cross3(b, v+3, f+3); cross3(c, v, f+3);
+  cross3(a, v, f); cross3(b, v+3, f+3); cross3(c, v, f+3); FL(3);
   r[0]=a[0]+b[0]; r[1]=a[1]+b[1]; r[2]=a[2]+b[2]; r[3]=c[0]; r[4]=c[1]; r[5]=c[2];
 }
 
@@ -413,6 +449,7 @@ static int chol_factor(double* L, const double* A, int n) {
   for (int k = 0; k < n; ++k) {
     double s = L[k*n+k];
     for (int j = 0; j < k; ++j) s -= L[k*n+j]*L[k*n+j];
+    FL(2*k + 1 + (n-k-1)*(2*k+1));
     if (s < MINVAL) s = MINVAL;
     double dk = sqrt(s); L[k*n+k] = dk;
     for (int i = k+1; i < n; ++i) {
@@ -424,6 +461,7 @@ static int chol_factor(double* L, const double* A, int n) {
   return 0;
 }
 static void chol_solve(const double* L, double* x, int n) { /* in place */
+  FL(2*n*n);
   for (int i = 0; i < n; ++i) { double s = x[i]; for (int j = 0; j < i; ++j) s -= L[i*n+j]*x[j]; x[i] = s/L[i*n+i]; }
   for (int i = n-1; i >= 0; --i) { double s = x[i]; for (int j = i+1; j < n; ++j) s -= L[j*n+i]*x[j]; x[i] = s/L[i*n+i]; }
 }
@@ -433,7 +471,7 @@ static void crb(const OrcModel* m, OrcData* d) {
   memcpy(d->crb, d->cinert, sizeof(double)*10*nb);
   for (int b = nb-1; b > 0; --b) {
     int p = m->body_parentid[b];
-    if (p > 0) for (int k = 0; k < 10; ++k) d->crb[10*p+k] += d->crb[10*b+k];
+    if (p > 0) { for (int k = 0; k < 10; ++k) d->crb[10*p+k] += d->crb[10*b+k]; FL(10); }
   }
   memset(d->M, 0, sizeof(double)*nv*nv);
   for (int i = 0; i < nv; ++i) {
@@ -441,6 +479,7 @@ static void crb(const OrcModel* m, OrcData* d) {
     mul_inert_vec(buf, d->crb + 10*m->dof_bodyid[i], d->cdof + 6*i);
     for (int j = i; j >= 0; j = m->dof_parentid[j]) {
       double s = 0; for (int k = 0; k < 6; ++k) s += d->cdof[6*j+k]*buf[k];
+      FL(12);
       d->M[i*nv+j] = s; d->M[j*nv+i] = s;
     }
     d->M[i*nv+i] += m->dof_armature[i];
@@ -456,11 +495,11 @@ static void jac_point(const OrcModel* m, const OrcData* d, int body, const doubl
   while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
   if (body <= 0) return;
   const double* c = d->subtree_com + 3*m->body_rootid[body];
-  double off[3] = { point[0]-c[0], point[1]-c[1], point[2]-c[2] };
+  double off[3] = { point[0]-c[0], point[1]-c[1], point[2]-c[2] }; FL(3);
   int i = m->body_dofadr[body] + m->body_dofnum[body] - 1;
   while (i >= 0) {
     const double* cd = d->cdof + 6*i; double t[3];
-    cross3(t, cd, off);
+    cross3(t, cd, off); FL(3);
     jacp[i] = cd[3]+t[0]; jacp[nv+i] = cd[4]+t[1]; jacp[2*nv+i] = cd[5]+t[2];
     i = m->dof_parentid[i];
   }
@@ -481,14 +520,17 @@ static double wrap_circle(double* pnt, const double* dd, const double* sd, doubl
   double sqlen0 = dd[0]*dd[0]+dd[1]*dd[1], sqlen1 = dd[2]*dd[2]+dd[3]*dd[3], sqrad = rad*rad;
   double dif[2] = { dd[2]-dd[0], dd[3]-dd[1] };
   double dsq = dif[0]*dif[0]+dif[1]*dif[1];
+  FL(12);
   if (sqlen0 < sqrad || sqlen1 < sqrad || rad < MINVAL) return -1;
   if (dsq < MINVAL) return -1;
   double a = -(dif[0]*dd[0]+dif[1]*dd[1])/dsq;
   if (a < 0) a = 0; else if (a > 1) a = 1;
   double tmp[2] = { a*dif[0]+dd[0], a*dif[1]+dd[1] };
+  FL(5 + 4 + 6);
   if (tmp[0]*tmp[0]+tmp[1]*tmp[1] > sqrad && (!sd || sd[0]*tmp[0]+sd[1]*tmp[1] >= 0)) return -1;
   double sol[2][4], good[2];
   double sqrt0 = sqrt(sqlen0 - sqrad), sqrt1 = sqrt(sqlen1 - sqrad);
+  FL(4 + 2*(4*6 + 10) + 2*2*12 + 6);      /* two candidate tangent pairs, their side / length score, two segment-crossing tests each, the arc */
   for (int i = 0; i < 2; ++i) {
     int sgn = (i == 0 ? 1 : -1);
     sol[i][0] = (dd[0]*sqrad + sgn*rad*dd[1]*sqrt0)/sqlen0;
@@ -517,6 +559,7 @@ static double wrap_circle(double* pnt, const double* dd, const double* sd, doubl
 static double wrap_geom(double* wpnt /*6*/, const double* x0, const double* x1, const double* xpos,
                         const double* xmat, double radius, int type, const double* side) {
   double p0[3], p1[3], t[3];
+  FL(6);
   for (int k = 0; k < 3; ++k) t[k] = x0[k]-xpos[k];
   mulmatTvec3(p0, xmat, t);
   for (int k = 0; k < 3; ++k) t[k] = x1[k]-xpos[k];
@@ -553,6 +596,7 @@ static double wrap_geom(double* wpnt /*6*/, const double* x0, const double* x1, 
   double wlen = wrap_circle(pnt, s, has_side ? sd : NULL, radius);
   if (wlen < 0) return -1;
   double r0[3], r1[3];
+  FL(18 + 6 + (type == MYO_WRAP_CYLINDER ? 30 : 0));
   for (int k = 0; k < 3; ++k) { r0[k] = axis0[k]*pnt[0]+axis1[k]*pnt[1]; r1[k] = axis0[k]*pnt[2]+axis1[k]*pnt[3]; }
   if (type == MYO_WRAP_CYLINDER) {
     double L0 = sqrt((s[0]-pnt[0])*(s[0]-pnt[0])+(s[1]-pnt[1])*(s[1]-pnt[1]));
@@ -601,14 +645,16 @@ static void tendon(const OrcModel* m, OrcData* d) {
       for (int k = 0; k < wcnt-1; ++k) {
         if (wcnt == 4 && k == 1) { len += wlen/divisor; continue; }
         double dif[3] = { wpnt[3*k+3]-wpnt[3*k], wpnt[3*k+4]-wpnt[3*k+1], wpnt[3*k+5]-wpnt[3*k+2] };
-        double dn = norm3(dif);
+        double dn = norm3(dif); FL(3 + 2);
         len += dn/divisor;
         if (wbody[k] != wbody[k+1] && dn > MINVAL) {
           dif[0]/=dn; dif[1]/=dn; dif[2]/=dn;
           jac_point(m, d, wbody[k], wpnt+3*k, jac0);
           jac_point(m, d, wbody[k+1], wpnt+3*k+3, jac1);
-          for (int c = 0; c < nv; ++c)
+          for (int c = 0; c < nv; ++c) {
+            if (jac1[c] != jac0[c] || jac1[nv+c] != jac0[nv+c] || jac1[2*nv+c] != jac0[2*nv+c]) FL(10);   /* structurally non-zero columns only */
             J[c] += (dif[0]*(jac1[c]-jac0[c]) + dif[1]*(jac1[nv+c]-jac0[nv+c]) + dif[2]*(jac1[2*nv+c]-jac0[2*nv+c]))/divisor;
+          }
         }
       }
       j += (idg >= 0 ? 2 : 1);
@@ -625,7 +671,7 @@ static void transmission(const OrcModel* m, OrcData* d) {
     double gear = m->actuator_gear[6*i]; int id = m->actuator_trnid[2*i];
     if (m->actuator_trntype[i] == MYO_TRN_TENDON) {
       d->actuator_length[i] = gear*d->ten_length[id];
-      for (int c = 0; c < nv; ++c) d->actuator_moment[i*nv+c] = gear*d->ten_J[id*nv+c];
+      for (int c = 0; c < nv; ++c) { d->actuator_moment[i*nv+c] = gear*d->ten_J[id*nv+c]; if (d->ten_J[id*nv+c] != 0) FL(1); }
     } else { /* joint (hinge/slide) */
       d->actuator_length[i] = gear*d->qpos[m->jnt_qposadr[id]];
       d->actuator_moment[i*nv + m->jnt_dofadr[id]] = gear;
@@ -663,6 +709,7 @@ static void seg_nearest(double* out, const double* c, const double* axis, double
 
 static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, double margin,
                         double* dist, double* pos, double* nrm /* up to 2 results */) {
+  FL(60);              /* geom poses (two 3x3 products, counted here) and the distance test of the pair */
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
   const double *p1 = d->geom_xpos + 3*g1, *p2 = d->geom_xpos + 3*g2;
   const double *R1 = d->geom_xmat + 9*g1, *R2 = d->geom_xmat + 9*g2;
@@ -882,6 +929,8 @@ static void make_constraint(const OrcModel* m, OrcData* d) {
     int b1 = m->geom_bodyid[c->geom1], b2 = m->geom_bodyid[c->geom2];
     jac_point(m, d, b1, c->pos, jac1); jac_point(m, d, b2, c->pos, jac2);
     double Jf[3][64*4]; /* nv <= 256 */
+    { int nz = 0; for (int col = 0; col < nv; ++col) if (jac2[col] != jac1[col] || jac2[nv+col] != jac1[nv+col] || jac2[2*nv+col] != jac1[2*nv+col]) nz++;
+      FL(nz*(3 + 3*5) + 4*nz*2 + 12); }      /* frame-rotated relative Jacobian and the four pyramid rows, structurally non-zero columns */
     for (int a = 0; a < 3; ++a)
       for (int col = 0; col < nv; ++col)
         Jf[a][col] = c->frame[3*a]*(jac2[col]-jac1[col]) + c->frame[3*a+1]*(jac2[nv+col]-jac1[nv+col]) +
@@ -913,11 +962,11 @@ static void make_constraint(const OrcModel* m, OrcData* d) {
 static void fwd_velocity(const OrcModel* m, OrcData* d) {
   int nv = m->nv, nb = m->nbody;
   for (int t = 0; t < m->ntendon; ++t) {
-    double s = 0; for (int c = 0; c < nv; ++c) s += d->ten_J[t*nv+c]*d->qvel[c];
+    double s = 0; for (int c = 0; c < nv; ++c) { s += d->ten_J[t*nv+c]*d->qvel[c]; if (d->ten_J[t*nv+c] != 0) FL(2); }
     d->ten_velocity[t] = s;
   }
   for (int i = 0; i < m->nu; ++i) {
-    double s = 0; for (int c = 0; c < nv; ++c) s += d->actuator_moment[i*nv+c]*d->qvel[c];
+    double s = 0; for (int c = 0; c < nv; ++c) { s += d->actuator_moment[i*nv+c]*d->qvel[c]; if (d->actuator_moment[i*nv+c] != 0) FL(2); }
     d->actuator_velocity[i] = s;
   }
   /* comVel */
@@ -937,9 +986,11 @@ static void fwd_velocity(const OrcModel* m, OrcData* d) {
         for (int e = 0; e < 6; ++e) cv[e] += d->cdof[6*da+e]*d->qvel[da];
       }
     }
+    FL(12 * m->body_dofnum[b]);
     memcpy(d->cvel + 6*b, cv, sizeof cv);
   }
   /* passive */
+  FL(nv + 3*m->njnt);
   for (int c = 0; c < nv; ++c) d->qfrc_passive[c] = -m->dof_damping[c]*d->qvel[c];
   for (int j = 0; j < m->njnt; ++j) {
     if (m->jnt_type[j] == MYO_JNT_FREE || m->jnt_stiffness[j] == 0) continue;
@@ -954,7 +1005,8 @@ static void fwd_velocity(const OrcModel* m, OrcData* d) {
   }
   /* constraint reference needs efc_vel */
   for (int r = 0; r < d->nefc; ++r) {
-    double s = 0; for (int c = 0; c < nv; ++c) s += d->efc_J[r*nv+c]*d->qvel[c];
+    double s = 0; for (int c = 0; c < nv; ++c) { s += d->efc_J[r*nv+c]*d->qvel[c]; if (d->efc_J[r*nv+c] != 0) FL(2); }
+    FL(6);
     d->efc_vel[r] = s;
     d->efc_aref[r] = -d->efc_KBIP[4*r+1]*s - d->efc_KBIP[4*r]*d->efc_KBIP[4*r+2]*(d->efc_pos[r] - d->efc_margin[r]);
   }
@@ -973,6 +1025,7 @@ static void fwd_velocity(const OrcModel* m, OrcData* d) {
     mul_inert_vec(t2, d->cinert + 10*b, d->cvel + 6*b);
     cross_force(t3, d->cvel + 6*b, t2);
     for (int e = 0; e < 6; ++e) cfrc[6*b+e] = t1[e] + t3[e];
+    FL(12 * m->body_dofnum[b] + 6 + 6);
   }
   for (int b = nb-1; b > 0; --b) {
     int p = m->body_parentid[b];
@@ -980,6 +1033,7 @@ static void fwd_velocity(const OrcModel* m, OrcData* d) {
   }
   for (int c = 0; c < nv; ++c) {
     double s = 0; for (int e = 0; e < 6; ++e) s += d->cdof[6*c+e]*cfrc[6*m->dof_bodyid[c]+e];
+    FL(12);
     d->qfrc_bias[c] = s;
   }
 }
@@ -1021,6 +1075,7 @@ static double muscle_bias(double len, const double* lr, double acc0, const doubl
 }
 
 static void fwd_actuation(const OrcModel* m, OrcData* d) {
+  FL(70 * m->nu);      /* activation dynamics, length / velocity normalisation, FL, FV, passive force per muscle */
   int nv = m->nv;
   memset(d->qfrc_actuator, 0, sizeof(double)*nv);
   for (int i = 0; i < m->nu; ++i) {
@@ -1059,7 +1114,7 @@ static void fwd_actuation(const OrcModel* m, OrcData* d) {
 
 /* ------------------------------------------------------------------ P10 acceleration + Newton */
 static void mul_M(const OrcData* d, int nv, double* r, const double* v) {
-  for (int i = 0; i < nv; ++i) { double s = 0; for (int j = 0; j < nv; ++j) s += d->M[i*nv+j]*v[j]; r[i] = s; }
+  for (int i = 0; i < nv; ++i) { double s = 0; for (int j = 0; j < nv; ++j) { s += d->M[i*nv+j]*v[j]; if (d->M[i*nv+j] != 0) FL(2); } r[i] = s; }
 }
 
 typedef struct { double cost, d1, d2; } LsEval;
@@ -1068,7 +1123,8 @@ static LsEval ls_eval(const OrcData* d, double alpha, const double* jar, const d
   LsEval e; e.cost = alpha*alpha*qg[2] + alpha*qg[1] + qg[0]; e.d1 = 2*alpha*qg[2] + qg[1]; e.d2 = 2*qg[2];
   for (int r = 0; r < d->nefc; ++r) {
     double x = jar[r] + alpha*jv[r];
-    if (x < 0) { double D = d->efc_D[r]; e.cost += 0.5*D*x*x; e.d1 += D*x*jv[r]; e.d2 += D*jv[r]*jv[r]; }
+    FL(2);
+    if (x < 0) { double D = d->efc_D[r]; e.cost += 0.5*D*x*x; e.d1 += D*x*jv[r]; e.d2 += D*jv[r]*jv[r]; FL(10); }
   }
   return e;
 }
@@ -1083,8 +1139,9 @@ static double constraint_update(OrcData* d, int nv, const double* jar, const dou
     active[r] = a;
     if (a) { d->efc_force[r] = -d->efc_D[r]*jar[r]; cost += 0.5*d->efc_D[r]*jar[r]*jar[r]; }
     else d->efc_force[r] = 0;
-    if (a) for (int c = 0; c < nv; ++c) d->qfrc_constraint[c] += d->efc_J[r*nv+c]*d->efc_force[r];
+    if (a) { FL(5); for (int c = 0; c < nv; ++c) { d->qfrc_constraint[c] += d->efc_J[r*nv+c]*d->efc_force[r]; if (d->efc_J[r*nv+c] != 0) FL(2); } }
   }
+  FL(4*nv + 3*nv);
   double g = 0;
   for (int c = 0; c < nv; ++c) g += (Ma[c]-d->qfrc_smooth[c])*(qacc[c]-d->qacc_smooth[c]);
   cost += 0.5*g;
@@ -1105,7 +1162,8 @@ static void newton_solve(const OrcModel* m, OrcData* d) {
     mul_M(d, nv, Ma, d->qacc_warmstart);
     for (int r = 0; r < ne; ++r) {
       double xw = -d->efc_aref[r], xs = -d->efc_aref[r];
-      for (int c = 0; c < nv; ++c) { xw += d->efc_J[r*nv+c]*d->qacc_warmstart[c]; xs += d->efc_J[r*nv+c]*d->qacc_smooth[c]; }
+      for (int c = 0; c < nv; ++c) { xw += d->efc_J[r*nv+c]*d->qacc_warmstart[c]; xs += d->efc_J[r*nv+c]*d->qacc_smooth[c]; if (d->efc_J[r*nv+c] != 0) FL(4); }
+      FL(8);
       if (xw < 0) costw += 0.5*d->efc_D[r]*xw*xw;
       if (xs < 0) costs += 0.5*d->efc_D[r]*xs*xs;
     }
@@ -1115,7 +1173,7 @@ static void newton_solve(const OrcModel* m, OrcData* d) {
     memcpy(qacc, costw < costs ? d->qacc_warmstart : d->qacc_smooth, sizeof(double)*nv);
   }
   mul_M(d, nv, Ma, qacc);
-  for (int r = 0; r < ne; ++r) { double s = -d->efc_aref[r]; for (int c = 0; c < nv; ++c) s += d->efc_J[r*nv+c]*qacc[c]; jar[r] = s; }
+  for (int r = 0; r < ne; ++r) { double s = -d->efc_aref[r]; for (int c = 0; c < nv; ++c) { s += d->efc_J[r*nv+c]*qacc[c]; if (d->efc_J[r*nv+c] != 0) FL(2); } jar[r] = s; }
   int changed;
   double cost = constraint_update(d, nv, jar, qacc, Ma, grad, &changed, active);
   double scale = 1/(m->meaninertia*(nv > 1 ? nv : 1));
@@ -1126,6 +1184,7 @@ static void newton_solve(const OrcModel* m, OrcData* d) {
     memcpy(H, d->M, sizeof(double)*nv*nv);
     for (int r = 0; r < ne; ++r) if (active[r]) {
       const double* J = d->efc_J + r*nv; double D = d->efc_D[r];
+      { int nz = 0; for (int i = 0; i < nv; ++i) if (J[i] != 0) nz++; FL(nz + nz*(nz+1)); }     /* lower triangle of the row's outer product */
       for (int i = 0; i < nv; ++i) if (J[i] != 0) { double t = D*J[i]; for (int j = 0; j < nv; ++j) H[i*nv+j] += t*J[j]; }
     }
     chol_factor(H, H, nv);
@@ -1133,7 +1192,8 @@ static void newton_solve(const OrcModel* m, OrcData* d) {
     chol_solve(H, search, nv);
     /* exact line search on the piecewise-quadratic cost */
     mul_M(d, nv, Mv, search);
-    for (int r = 0; r < ne; ++r) { double s = 0; for (int c = 0; c < nv; ++c) s += d->efc_J[r*nv+c]*search[c]; jv[r] = s; }
+    for (int r = 0; r < ne; ++r) { double s = 0; for (int c = 0; c < nv; ++c) { s += d->efc_J[r*nv+c]*search[c]; if (d->efc_J[r*nv+c] != 0) FL(2); } jv[r] = s; }
+    FL(7*nv + 4*nv + 2*ne + 2*nv + 10);
     double qg[3] = {0, 0, 0}, snorm = 0;
     for (int c = 0; c < nv; ++c) {
       qg[1] += search[c]*(Ma[c]-d->qfrc_smooth[c]); qg[2] += 0.5*search[c]*Mv[c]; snorm += search[c]*search[c];
@@ -1167,6 +1227,7 @@ static void newton_solve(const OrcModel* m, OrcData* d) {
 
 static void fwd_acceleration(const OrcModel* m, OrcData* d) {
   int nv = m->nv;
+  FL(2*nv);
   for (int c = 0; c < nv; ++c) d->qfrc_smooth[c] = d->qfrc_passive[c] - d->qfrc_bias[c] + d->qfrc_actuator[c];
   memcpy(d->qacc_smooth, d->qfrc_smooth, sizeof(double)*nv);
   chol_solve(d->Mchol, d->qacc_smooth, nv);
@@ -1176,24 +1237,25 @@ static void fwd_acceleration(const OrcModel* m, OrcData* d) {
     d->solver_iter = 0;
     return;
   }
-  newton_solve(m, d);
+  STAGE(ST_NEWTON); newton_solve(m, d); STAGE(ST_ACCEL);
 }
 
 void orc_fwd_position(const OrcModel* m, OrcData* d) {
-  orc_kinematics(m, d);
-  com_pos(m, d);
-  tendon(m, d);
-  transmission(m, d);
-  crb(m, d);
-  collision(m, d);
-  make_constraint(m, d);
+  STAGE(ST_KIN); orc_kinematics(m, d);
+  STAGE(ST_COM); com_pos(m, d);
+  STAGE(ST_TENDON); tendon(m, d); transmission(m, d);
+  STAGE(ST_CRB); crb(m, d);
+  STAGE(ST_COLLIDE); collision(m, d);
+  STAGE(ST_CONSTRAINT); make_constraint(m, d);
+  STAGE(ST_TASK);
 }
 
 void orc_forward(const OrcModel* m, OrcData* d) {
   orc_fwd_position(m, d);
-  fwd_velocity(m, d);
-  fwd_actuation(m, d);
-  fwd_acceleration(m, d);
+  STAGE(ST_VELOCITY); fwd_velocity(m, d);
+  STAGE(ST_ACTUATION); fwd_actuation(m, d);
+  STAGE(ST_ACCEL); fwd_acceleration(m, d);
+  STAGE(ST_TASK);
 }
 
 /* ------------------------------------------------------------------ P11 integrators */
@@ -1217,6 +1279,7 @@ static void integrate_pos(const OrcModel* m, double* qpos, const double* qvel, d
 
 static void advance(const OrcModel* m, OrcData* d, const double* act_dot, const double* qacc, const double* qvel_for_pos) {
   double h = m->timestep;
+  FL(2*m->na + 2*m->nv + 2*m->nq + 1);
   for (int i = 0; i < m->na; ++i) {
     d->act[i] += h*act_dot[i];
     int iu = i + (m->nu - m->na);
@@ -1239,6 +1302,7 @@ static void euler(const OrcModel* m, OrcData* d) {
   if (!damped) { advance(m, d, d->act_dot, d->qacc, NULL); return; }
   double* H = d->H; double* qa = d->w1;
   memcpy(H, d->M, sizeof(double)*nv*nv);
+  FL(3*nv);
   for (int c = 0; c < nv; ++c) { H[c*nv+c] += m->timestep*m->dof_damping[c]; qa[c] = d->qfrc_smooth[c] + d->qfrc_constraint[c]; }
   chol_factor(H, H, nv);
   chol_solve(H, qa, nv);
@@ -1263,7 +1327,7 @@ static void rk4(const OrcModel* m, OrcData* d) {
     for (int k = 0; k < na; ++k) d->act[k] = X0a[k] + h*dX[2*nv+k];
     double c = 0; for (int j = 0; j < i; ++j) c += A[(i-1)*3+j];
     d->time = t0 + h*c;
-    orc_forward(m, d);
+    orc_forward(m, d); STAGE(ST_INTEGRATE); FL(2*(2*nv+na)*i + 2*(nv+na));
     memcpy(F[i], d->qvel, sizeof(double)*nv); memcpy(F[i]+nv, d->qacc, sizeof(double)*nv); memcpy(F[i]+2*nv, d->act_dot, sizeof(double)*na);
   }
   memset(dX, 0, sizeof(double)*(2*nv+na));
@@ -1279,7 +1343,9 @@ void orc_step(const OrcModel* m, OrcData* d) {
   check_state(m, d);
   orc_forward(m, d);
   for (int c = 0; c < m->nv; ++c) if (!isfinite(d->qacc[c]) || fabs(d->qacc[c]) > 1e10) d->bad = 1;
+  STAGE(ST_INTEGRATE);
   if (m->integrator == MYO_INT_RK4) rk4(m, d); else euler(m, d);
+  STAGE(ST_TASK);
 }
 
 /* ------------------------------------------------------------------ Baoding task layer */

@@ -44,6 +44,11 @@ int orc_get_int(const OrcData* d, const char* name); /* ncon, nefc, solver_iter,
 void orc_fwd_position(const OrcModel* m, OrcData* d);
 void orc_forward(const OrcModel* m, OrcData* d);
 void orc_step(const OrcModel* m, OrcData* d);
+/* flop counter of the algorithm as restated here: out[orc_flops_stages()] = counts per stage since the
+ * last reset, in the order kinematics, com, tendon(+transmission), crb(+factor M), collision, constraint rows,
+ * velocity, actuation, acceleration (qacc_smooth), newton, integrate, task.  One counter per process. */
+void orc_flops(double* out, int reset);
+int orc_flops_stages(void);
 /* kinematics only (what MyoSuite's observation sim does before get_obs) */
 void orc_kinematics(const OrcModel* m, OrcData* d);
 

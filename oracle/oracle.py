@@ -14,9 +14,13 @@ _LIB = None
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libmyo_oracle.so")
+    """Builds libmyo_oracle.so and libmyo_oracle_flops.so (the same source with the flop counter compiled in);
+    returns the one this process uses: the counting build iff MYO_ORACLE_FLOPS=1 is set in the environment."""
+    name = "libmyo_oracle_flops.so" if os.environ.get("MYO_ORACLE_FLOPS") == "1" else "libmyo_oracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "myo_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    stale = lambda f: not os.path.exists(f) or os.path.getmtime(f) < os.path.getmtime(src)
+    if force or stale(so) or stale(os.path.join(_HERE, "libmyo_oracle.so")) or stale(os.path.join(_HERE, "libmyo_oracle_flops.so")):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
 
@@ -45,8 +49,26 @@ def lib():
         L.orc_baoding_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.orc_baoding_reward.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]
+        L.orc_flops.argtypes = [C.POINTER(C.c_double), C.c_int]
+        L.orc_flops_stages.restype = C.c_int
+        L.orc_flops_enabled.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+FLOP_STAGES = ("kinematics", "com", "tendon", "crb", "collision", "constraint", "velocity", "actuation", "acceleration",
+               "newton", "integrate", "task")
+
+
+def flops(reset=False):
+    """Floating-point operations counted by the instrumented oracle since the last reset, per stage (dict).
+    Needs the counting build: start the process with MYO_ORACLE_FLOPS=1."""
+    if not lib().orc_flops_enabled():
+        raise RuntimeError("this process loaded the oracle without the flop counter: set MYO_ORACLE_FLOPS=1 before the first use")
+    n = lib().orc_flops_stages()
+    out = (C.c_double * n)()
+    lib().orc_flops(out, int(reset))
+    return dict(zip(FLOP_STAGES, out[:]))
 
 
 class BaodingCfg(C.Structure):

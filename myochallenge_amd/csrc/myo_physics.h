@@ -750,6 +750,17 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
     }
   }
   SYNC();
+}
+
+// phase C of the tendon stage (its own leaf function: the HP wrap solver of phase B and this walk together need
+// more registers than one allocation has)
+template <typename T>
+DEVFN void tendon_lengths(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  (void)K;
+  T* wp = S_TWP(s);
+  HP* wres = S_TWRES(s, M.nwrap);
   PHASE {
     const int t = lane;
     if (t < M.ntendon) {
@@ -2237,6 +2248,7 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
   com_pos(M, K, s);
   PROF(s, 2)
   tendon(M, K, s);
+  tendon_lengths(M, K, s);
   PROF(s, 3)
   crb(M, s);
   PROF(s, 4)

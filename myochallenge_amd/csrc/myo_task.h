@@ -481,6 +481,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   kinematics(M, s);
   com_pos(M, K, s);
   tendon(M, K, s);
+  tendon_lengths(M, K, s);
   crb(M, s);
   collision_and_constraints(M, K, s);
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));

@@ -9,29 +9,31 @@ mkdir -p $OUT
 export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line itself (with the CPU baseline leg)
-python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err
+python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err      # includes the f64 / RK4 variants and the CPU leg
 # 2. per-kernel time of the same command (no CPU leg: it is host-only work)
 rm -rf /tmp/prof_stats
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- python3 $ROOT/bench.py --no-cpu-baseline > /tmp/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o b -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants > /tmp/stats.log 2>&1
 find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 grep -v "^[WIE]2026" /tmp/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
 # 3. PMC counters of k_step inside the same command, one --pmc pass per set (no other tracing)
 : > $OUT/pmc_kstep.txt
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
   rm -rf /tmp/pmc
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
   python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_kstep.txt
 done
 # 3b. matrix-core activity of the PPO side (north_star asks for MFMA-busy against peak): hipBLASLt GEMM kernels
 rm -rf /tmp/pmc
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "Cijk" > $OUT/pmc_gemm.txt
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_gemm.txt
 # 4. stage shares (instrumented build; shares only)
-python3 $ROOT/tools/dev/gpu_prof.py > $OUT/stage_shares.txt 2>&1
+PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_prof.py > $OUT/stage_shares.txt 2>&1
 # 5. other configurations (BASELINE.json configs / variants)
-python3 $ROOT/bench.py --no-cpu-baseline --dtype f64 > $OUT/bench_f64.json 2>/dev/null
-python3 $ROOT/bench.py --no-cpu-baseline --integrator rk4 > $OUT/bench_rk4.json 2>/dev/null
-python3 $ROOT/bench.py --no-cpu-baseline --env-name CustomMyoBaodingBallsP2 --envs 8192 > $OUT/bench_p2_8192.json 2>/dev/null
-python3 $ROOT/bench.py --no-cpu-baseline --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --no-variants --dtype f64 > $OUT/bench_f64.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --no-variants --integrator rk4 > $OUT/bench_rk4.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoBaodingBallsP2 --envs 8192 > $OUT/bench_p2_8192.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --no-variants --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
+# 6. trajectory drift tables of both steppers (32 action streams x 200 env steps) and k_step time against the batch size
+python3 $ROOT/tools/dev/gpu_drift.py > $OUT/drift.log 2>&1
 echo done

@@ -729,8 +729,18 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
     }
   }
   SYNC();
+}
+
+// phase B of the tendon stage, one geom wrap per lane (called once per 64 wraps from kernel level: a leaf function
+// without a loop, so that the HP wrap solver has a register allocation of its own)
+template <typename T>
+DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int base) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  HP* wres = S_TWRES(s, M.nwrap);
   PHASE {
-    for (int k = lane; k < M.ngw; k += 64) {
+    const int k = base + lane;
+    if (k < M.ngw) {
       const int w = M.gw_elem[k];
       const int body = M.wr_i[8 * w + 1], type = M.wr_i[8 * w], geom = M.wr_i[8 * w + 2], side_body = M.wr_i[8 * w + 3];
       // The wrap solver's branches are geometric predicates (point inside the circle, tangent segments crossing,
@@ -992,11 +1002,18 @@ DEV void chol_solve(Scratch<T>& s, T* x, int n) {
 }
 
 #ifndef MYO_EMU
-// ---- register-resident Cholesky (gfx950 build).  Lane i keeps row i of the lower triangle in
-// VGPRs (packed pairs, v_pk_fma trailing update); columns reach the other lanes two at a time through
-// 64-entry LDS buffers, software-pipelined (see the factor loop); the substitutions broadcast
-// with v_readlane.  Padded to MYO_NV_MAX with identity rows.  The arithmetic per element is the
-// same k-ordered FMA sequence as the LDS version above, which the MYO_EMU build keeps.
+// ---- blocked Cholesky on the matrix cores + register-resident substitutions (gfx950 build).
+// FACTOR (right-looking, panels of four columns = the K of v_mfma_*_16x16x4): the matrix lives in MFMA accumulator
+// tiles (16x16, lower tiles only; 36 dofs -> 3x3 tiles, the 24-wide variant 2x2).  Per panel: the four panel
+// columns leave the accumulator layout through a small LDS stage and come back row-per-lane (every lane gets the
+// four entries of "its" row of each tile row), the 4x4 diagonal block is broadcast with v_readlane and factored
+// redundantly by all lanes, every lane finishes its rows of the panel by a four-step substitution, the finished L
+// columns go to H (packed lower triangle) for the substitution phase, and the trailing matrix is updated with one
+// v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 per remaining lower tile (operands: the panel rows, the same
+// register as A and as B).  The one-column algorithm this replaces exchanged a column through LDS 36 times per
+// factorisation and spent 53 k of a substep's 241 k cycles (mixed) / 156 k of 425 k (fp64) in the three solves.
+// The arithmetic per element is a k-ordered FMA chain as in the LDS version the MYO_EMU build keeps.
+// SOLVE: lane i holds row i of L in VGPRs; the substitutions broadcast with v_readlane.
 template <typename T> __device__ __forceinline__ T lane_bcast(T v, int src);
 template <> __device__ __forceinline__ float lane_bcast<float>(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -1007,36 +1024,51 @@ template <> __device__ __forceinline__ double lane_bcast<double>(double v, int s
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-
-// solve (L L') x = b with H (square, LDS) and x (LDS); H is overwritten with L.
-// Lane i owns row i of the matrix in VGPRs.  Column k is exchanged through LDS (one store per
-// lane, then broadcast wide reads): the LDS pipe does the broadcasting, the VALU only the
-// multiply-adds, two per instruction (v_pk_fma_f32).  No lane predicates in the factor loop:
-// entries above the diagonal hold don't-care values that never flow into valid ones (every
-// valid update of a[j] happens in lanes >= j and only reads column entries of lanes >= j).
 __device__ __forceinline__ float myo_rsqrt(float v) { return __frsqrt_rn(v); }
 __device__ __forceinline__ double myo_rsqrt(double v) { return rsqrt(v); }
 #define MYO_OPAQUE_LANE(v) int v = (int)threadIdx.x; asm volatile("" : "+v"(v));
+// accumulator layouts of the two 16x16x4 MFMAs (cdna_hip_programming.md §3): column = lane & 15 in both,
+// row = 4 (lane >> 4) + reg for f32, (lane >> 4) + 4 reg for f64; A / B operand: [lane & 15][k = lane >> 4]
+template <typename T> struct MyoMfma;
+template <> struct MyoMfma<float> {
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ V4 mma(float a, float b, V4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+template <> struct MyoMfma<double> {
+  typedef double V4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ V4 mma(double a, double b, V4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
 template <typename T, int N>
 __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   static_assert(N % 4 == 0 && N <= MYO_NV_MAX, "row vectors are loaded 4 at a time");
   typedef T V2 __attribute__((ext_vector_type(2)));
   typedef T V4 __attribute__((ext_vector_type(4)));
+  typedef MyoMfma<T> MM;
+  constexpr int NT = (N + 15) / 16;                  // tiles per side
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
   T* x = LPTR(T, x_r);
   const int lane = threadIdx.x;
+  const int lc = lane & 15, lq = lane >> 4;
   const int row = lane < N ? lane : N - 1;          // lanes >= N shadow the last row and never store
   V2 a2[N / 2];
-  {
-    // packed row (MYO_HIDX): N/4 vectors from the row's first entry; what lies beyond the row's own 4(row/4 + 1)
-    // entries belongs to later rows (always inside H: myo_hrow(35) + 36 = MYO_H_SIZE) and lands above the diagonal
-    const V4* hr = reinterpret_cast<const V4*>(s.H + myo_hrow(row));
-#pragma unroll
-    for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
-  }
   T b = (lane < n) ? x[lane] : (T)0;
   T invd = 1;                                        // 1 / L[lane][lane]
+  // ---- factor.  fp64: blocked on the matrix cores (below).  fp32 keeps the one-column register algorithm: measured on
+  // the same build, the blocked MFMA factorisation is 1.5x FASTER than the register version in fp64 (103 k instead of
+  // 156 k cycles per substep for the three solves: half the registers, no spills, 31 MFMAs instead of ~1300 v_fma_f64)
+  // and 1.7x SLOWER in fp32 (90 k instead of 54 k): there v_pk_fma_f32 already does two entries per instruction, the
+  // column exchange is hidden by software pipelining, and what remains of the blocked version is its serial chain per
+  // panel (stage round trip, 10 v_readlane, four dependent rsqrt, 40-cycle MFMA latency) nine times per factorisation.
   if constexpr (sizeof(T) == 4) {
+    {
+      // row `row` of H (packed, MYO_HIDX): N/4 vectors from the row's first entry; what lies beyond the row's own
+      // 4(row/4 + 1) entries belongs to later rows (always inside H) and lands above the diagonal
+      const V4* hr = reinterpret_cast<const V4*>(s.H + myo_hrow(row));
+#pragma unroll
+      for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
+    }
     // fp32: one column per step.  (The two-column scheme below is 14 % faster end to end in fp64, where the
     // factorisation is a quarter of the kernel, but measured 2.6 % SLOWER in fp32: its serial 2x2 pivot chain
     // outweighs the saved round trips once the per-column exchange is already pipelined.)
@@ -1082,79 +1114,123 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
         for (int p = p1; p < N / 2; ++p) c2[p] = c2n[p];
       }
     }
+    // transpose through LDS: lane i needs column i of L for the backward substitution
+    if (lane < N) {
+      V4* hw = reinterpret_cast<V4*>(s.H + myo_hrow(lane));
+#pragma unroll
+      for (int q = 0; q < N / 4; ++q) if (q <= (lane >> 2)) hw[q] = V4{a2[2 * q].x, a2[2 * q].y, a2[2 * q + 1].x, a2[2 * q + 1].y};
+    }
+    __syncthreads();
   } else {
-    // Two columns per step (one LDS round trip per column PAIR: the round trip, not the arithmetic, is the
-    // critical path).  What travels is the UNSCALED pair of columns (2q, 2q+1) of the current trailing matrix,
-    // one step early: X[j] = A[j][2q], Y[j] = A[j][2q+1].  Every lane derives the 2x2 pivot block from rows
-    // 2q, 2q+1 of that broadcast (d00 = X[2q], d10 = X[2q+1], d11 = Y[2q+1]), its own two L entries, and the
-    // rank-2 trailing update  A[i][j] -= L[i][2q] L[j][2q] + L[i][2q+1] L[j][2q+1].
-    // Software-pipelined in place: the pair holding columns 2q+2, 2q+3 is updated first, written, and read
-    // back into the registers its old broadcast values just left; every later pair is updated and then
-    // refilled the same way, so the reads are in flight during the rest of the trailing update.  Two buffers
-    // alternate; a workgroup is one wavefront, so its LDS operations execute in program order (no barrier).
-    T* const bx0 = s.efc_jv;                           // 2 x 64 entries each, free while a system is solved
-    T* const by0 = s.efc_jv + 64;
-    T* const bx1 = s.bvec;
-    T* const by1 = s.bvec + 64;
-    static_assert(MYO_NEFC_MAX >= 128 && MYO_NB_MAX * 6 >= 128, "column exchange buffers");
-    V2 cx[N / 2], cy[N / 2];
-    bx0[lane] = a2[0].x;
-    by0[lane] = a2[0].y;
     {
-      const V2* px = reinterpret_cast<const V2*>(bx0);
-      const V2* py = reinterpret_cast<const V2*>(by0);
-#pragma unroll
-      for (int p = 0; p < N / 2; ++p) { cx[p] = px[p]; cy[p] = py[p]; }
+      // LDS pointers of this function: taken ONCE and made opaque.  In a non-kernel function the address of the dynamic
+      // LDS block is a look-up in llvm.amdgcn.dynlds.offset.table (s_getpc + s_load, or a global load when the
+      // compiler re-derives it inside a divergent region: measured 26 look-ups and +22 k cycles in one call of this
+      // function before the pointers were pinned)
+      typedef __attribute__((address_space(3))) T* lds_t;
+      lds_t stage = (lds_t)s.efc_jv;                   // [NT * 16 rows][4] + 64 dump entries; efc_jv and efc_force are free while a system is solved
+      lds_t Hp = (lds_t)s.H;
+      asm volatile("" : "+v"(stage), "+v"(Hp));
+      static_assert(NT * 16 * 4 + 64 <= 2 * MYO_NEFC_MAX && 4 * 64 <= 2 * MYO_NEFC_MAX, "panel stage and dump area fit in efc_jv + efc_force");
+      static_assert(offsetof(Scratch<T>, efc_force) - offsetof(Scratch<T>, efc_jv) == MYO_NEFC_MAX * sizeof(T), "efc_jv and efc_force are contiguous");
+      typename MM::V4 acc[NT * (NT + 1) / 2];
+      // symmetric fill of the lower tiles from the packed lower triangle; identity beyond N
+  #pragma unroll
+      for (int I = 0; I < NT; ++I)
+  #pragma unroll
+        for (int J = 0; J <= I; ++J)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * I + MM::crow(lane, r), j = 16 * J + lc;
+            const int hi = i > j ? i : j, lo = i > j ? j : i;
+            // (no exec-mask branches in this function: inside a divergent region the compiler re-derives the base of
+            // the dynamic LDS block — a table lookup in a non-kernel function, ~500 cycles each; measured +22 k cycles)
+            const T h = Hp[hi < N ? MYO_HIDX(hi, lo) : 0];
+            acc[I * (I + 1) / 2 + J][r] = hi < N ? h : ((i == j) ? (T)1 : (T)0);
+          }
+  #pragma unroll
+      for (int kb = 0; kb < N / 4; ++kb) {
+        constexpr int dummy = 0; (void)dummy;
+        const int c0 = 4 * kb, J = c0 / 16, jc = c0 % 16;
+        // 1. the four panel columns: accumulator layout -> stage[row][k]  (the other lanes store into a dump area)
+        {
+          const bool mine = lc >= jc && lc < jc + 4;
+  #pragma unroll
+          for (int I = J; I < NT; ++I)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r)
+              stage[mine ? (16 * I + MM::crow(lane, r)) * 4 + (lc - jc) : NT * 64 + lane] = acc[I * (I + 1) / 2 + J][r];
+        }
+        __syncthreads();
+        // 2. row-per-lane: the four panel entries of row 16 I + lc (the same in all four lane quarters)
+        T xr[NT][4];
+  #pragma unroll
+        for (int I = J; I < NT; ++I) {
+          typedef __attribute__((address_space(3))) const V4* lds_v4;
+          const V4 v = *(lds_v4)(stage + (16 * I + lc) * 4);
+          xr[I][0] = v.x; xr[I][1] = v.y; xr[I][2] = v.z; xr[I][3] = v.w;
+        }
+        // diagonal block (rows c0 .. c0+3 sit in tile row J at lanes jc .. jc+3), factored by every lane
+        T d00 = lane_bcast<T>(xr[J][0], jc);
+        const T d10 = lane_bcast<T>(xr[J][0], jc + 1), d20 = lane_bcast<T>(xr[J][0], jc + 2), d30 = lane_bcast<T>(xr[J][0], jc + 3);
+        T d11 = lane_bcast<T>(xr[J][1], jc + 1);
+        const T d21 = lane_bcast<T>(xr[J][1], jc + 2), d31 = lane_bcast<T>(xr[J][1], jc + 3);
+        T d22 = lane_bcast<T>(xr[J][2], jc + 2);
+        const T d32 = lane_bcast<T>(xr[J][2], jc + 3);
+        T d33 = lane_bcast<T>(xr[J][3], jc + 3);
+        d00 = d00 < MYO_MINVAL ? MYO_MINVAL : d00;
+        const T i0 = myo_rsqrt(d00);
+        const T l10 = d10 * i0, l20 = d20 * i0, l30 = d30 * i0;
+        d11 -= l10 * l10; d11 = d11 < MYO_MINVAL ? MYO_MINVAL : d11;
+        const T i1 = myo_rsqrt(d11);
+        const T l21 = (d21 - l20 * l10) * i1, l31 = (d31 - l30 * l10) * i1;
+        d22 -= l20 * l20 + l21 * l21; d22 = d22 < MYO_MINVAL ? MYO_MINVAL : d22;
+        const T i2 = myo_rsqrt(d22);
+        const T l32 = (d32 - l30 * l20 - l31 * l21) * i2;
+        d33 -= l30 * l30 + l31 * l31 + l32 * l32; d33 = d33 < MYO_MINVAL ? MYO_MINVAL : d33;
+        const T i3 = myo_rsqrt(d33);
+        // 3. every row of the panel: L21 = A21 L11^-T  (rows of the diagonal block come out as L11 itself)
+  #pragma unroll
+        for (int I = J; I < NT; ++I) {
+          const int i = 16 * I + lc;
+          T y0 = xr[I][0] * i0;
+          T y1 = (xr[I][1] - y0 * l10) * i1;
+          T y2 = (xr[I][2] - y0 * l20 - y1 * l21) * i2;
+          T y3 = (xr[I][3] - y0 * l30 - y1 * l31 - y2 * l32) * i3;
+          if (i == c0) { y1 = 0; y2 = 0; y3 = 0; }      // above the diagonal inside the block
+          if (i == c0 + 1) { y2 = 0; y3 = 0; }
+          if (i == c0 + 2) y3 = 0;
+          if (i < c0) { y0 = 0; y1 = 0; y2 = 0; y3 = 0; }   // rows factored earlier take no part
+          // finished L columns -> H (packed rows; c0 is a multiple of 4 and so is every row start: 16-byte store)
+          // (lanes that hold no row of L store into the dump area: stage rows are free until the next panel)
+          {
+            const bool mine = lq == 0 && i >= c0 && i < N;
+            typedef __attribute__((address_space(3))) V4* lds_v4w;
+            lds_t const dst = mine ? Hp + myo_hrow(i) + c0 : stage + 4 * lane;
+            *(lds_v4w)dst = V4{y0, y1, y2, y3};
+          }
+          xr[I][0] = y0; xr[I][1] = y1; xr[I][2] = y2; xr[I][3] = y3;
+        }
+        // 4. trailing update  A22 -= L21 L21'  : one MFMA per remaining lower tile, operand = the panel row of this lane
+        T op[NT];
+  #pragma unroll
+        for (int I = J; I < NT; ++I) op[I] = lq == 0 ? xr[I][0] : (lq == 1 ? xr[I][1] : (lq == 2 ? xr[I][2] : xr[I][3]));
+        if (kb + 1 < N / 4) {
+  #pragma unroll
+          for (int I = J; I < NT; ++I)
+  #pragma unroll
+            for (int Jt = J; Jt <= I; ++Jt) acc[I * (I + 1) / 2 + Jt] = MM::mma(-op[I], op[Jt], acc[I * (I + 1) / 2 + Jt]);
+        }
+        __syncthreads();                                 // the stage is rewritten by the next panel
+      }
     }
+    {
+      // row `row` of L from H
+      const V4* hr = reinterpret_cast<const V4*>(s.H + myo_hrow(row));
 #pragma unroll
-    for (int q = 0; q < N / 2; ++q) {
-      T d00 = cx[q].x;
-      const T d10 = cx[q].y;
-      d00 = d00 < MYO_MINVAL ? MYO_MINVAL : d00;
-      const T inv0 = myo_rsqrt(d00);
-      const T l10 = d10 * inv0;
-      T t11 = cy[q].y - l10 * l10;
-      t11 = t11 < MYO_MINVAL ? MYO_MINVAL : t11;
-      const T inv1 = myo_rsqrt(t11);
-      const T li0 = a2[q].x * inv0;                    // lane 2q: sqrt(d00); lane 2q+1: l10
-      const T li1 = (a2[q].y - li0 * l10) * inv1;      // lane 2q+1: sqrt(t11)
-      // The trailing update subtracts L[i][2q] L[j][2q] + L[i][2q+1] L[j][2q+1] with both L columns formed as the
-      // one-column algorithm forms them (L1[j] = (Y[j] - l10 L0[j]) / l11, rounded once).  The algebraically equal
-      // alpha_i X[j] + beta_i Y[j] is two FMAs instead of five operations, but it cancels two LARGE products
-      // whenever the 2x2 pivot block is ill-conditioned (coupled ball / finger dofs under a stiff contact): measured
-      // 1e-10 instead of 1e-16 relative in qacc, 1e-8 after 200 substeps against the fp64 oracle.
-      const V2 vi0 = V2{inv0, inv0}, vi1 = V2{inv1, inv1}, ml10 = V2{-l10, -l10}, m0 = V2{-li0, -li0}, m1 = V2{-li1, -li1};
-      T* const nx = ((q + 1) & 1) ? bx1 : bx0;
-      T* const ny = ((q + 1) & 1) ? by1 : by0;
-      const V2* px = reinterpret_cast<const V2*>(nx);
-      const V2* py = reinterpret_cast<const V2*>(ny);
-      // refill in place, pair by pair (four registers per pair in fp64: no room for a second set)
-      if (q + 1 < N / 2) {
-        const V2 L0 = cx[q + 1] * vi0;
-        const V2 L1 = __builtin_elementwise_fma(ml10, L0, cy[q + 1]) * vi1;
-        a2[q + 1] = __builtin_elementwise_fma(m0, L0, a2[q + 1]);
-        a2[q + 1] = __builtin_elementwise_fma(m1, L1, a2[q + 1]);
-        nx[lane] = a2[q + 1].x;
-        ny[lane] = a2[q + 1].y;
-        cx[q + 1] = px[q + 1];
-        cy[q + 1] = py[q + 1];
-      }
-#pragma unroll
-      for (int p = q + 2; p < N / 2; ++p) {
-        const V2 L0 = cx[p] * vi0;
-        const V2 L1 = __builtin_elementwise_fma(ml10, L0, cy[p]) * vi1;
-        a2[p] = __builtin_elementwise_fma(m0, L0, a2[p]);
-        a2[p] = __builtin_elementwise_fma(m1, L1, a2[p]);
-        cx[p] = px[p];
-        cy[p] = py[p];
-      }
-      a2[q] = V2{li0, li1};
-      {
-        MYO_OPAQUE_LANE(l)
-        if (l == 2 * q) invd = inv0;                   // 1 / L[k][k]
-        if (l == 2 * q + 1) invd = inv1;
-      }
+      for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
     }
+    invd = (T)1 / s.H[MYO_HIDX(row, row)];
   }
   // forward substitution  L y = b   (lane j finishes at step j; later steps must not touch it)
 #pragma unroll
@@ -1165,13 +1241,7 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
     b = (l == j) ? yj : ((l > j) ? b - aj * yj : b);
     __builtin_amdgcn_sched_barrier(0);
   }
-  // transpose through LDS: lane i needs column i of L
-  if (lane < N) {
-    V4* hw = reinterpret_cast<V4*>(s.H + myo_hrow(lane));
-#pragma unroll
-    for (int q = 0; q < N / 4; ++q) if (q <= (lane >> 2)) hw[q] = V4{a2[2 * q].x, a2[2 * q].y, a2[2 * q + 1].x, a2[2 * q + 1].y};
-  }
-  __syncthreads();
+  // lane i needs column i of L for the backward substitution (L is in H)
   T c[N];
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -1373,7 +1443,7 @@ DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos
 }
 
 template <typename T>
-DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   // ---- limit rows: joints (lanes = joints), then tendons (lanes = tendons)
@@ -1451,11 +1521,22 @@ DEVFN void collision_and_constraints(const DevModel<T>& M_in, const TaskDev& K_i
     if (lane == 0) { int n = nl + total; s.ntl = (n < MYO_NLIM_MAX ? n : MYO_NLIM_MAX) - nl; }
   }
   SYNC();
+  PHASE { if (lane == 0) { s.ncon = 0; s.nefc = s.nl + s.ntl; } }
+  SYNC();
+}
+
+// contacts: one pass over 64 candidate pairs (lanes = pairs), called from kernel level once per 64 pairs — a leaf
+// function without the limit rows and without a loop, so that the HP narrow phase has a register allocation of its
+// own.  s.ncon / s.nefc carry the running counts between passes.
+template <typename T>
+DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int base) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  int total = 0;
   const int nlim = s.nl + s.ntl;
-  // ---- contacts: lanes = candidate pairs (64 at a time)
-  int ncon = 0;
+  int ncon = s.ncon;
   LANE_VAR(ContactTmp, ct);
-  for (int base = 0; base < M.npair; base += 64) {
+  {
     PHASE {
       const int p = base + lane;
       LV(ct).n = 0;
@@ -2248,11 +2329,13 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
   com_pos(M, K, s);
   PROF(s, 2)
   tendon(M, K, s);
+  for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);
   tendon_lengths(M, K, s);
   PROF(s, 3)
   crb(M, s);
   PROF(s, 4)
-  collision_and_constraints(M, K, s);
+  constraint_limits(M, K, s);
+  for (int base = 0; base < M.npair; base += 64) collision_pass(M, K, s, base);
   PROF(s, 5)
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);

@@ -481,9 +481,11 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   kinematics(M, s);
   com_pos(M, K, s);
   tendon(M, K, s);
+  for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);
   tendon_lengths(M, K, s);
   crb(M, s);
-  collision_and_constraints(M, K, s);
+  constraint_limits(M, K, s);
+  for (int base = 0; base < M.npair; base += 64) collision_pass(M, K, s, base);
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
   efc_reference(M, s);

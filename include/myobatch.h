@@ -190,7 +190,7 @@ int myo_ppo_loss_grad(const float* mean, const float* values, const float* actio
  * [2*ceil(bs/16)] scratch (block moments, merged in block order by a second small launch). */
 int myo_ppo_gather(const float* obs, const float* act, const float* oldlp, const float* adv, const float* ret,
                    const int64_t* idx, int bs, int obs_dim, int act_dim, uint16_t* obs_bf16, int copies,
-                   float* act_mb, float* oldlp_mb, float* adv_mb, float* ret_mb, float* adv_stats, float* work,
+                   float* act_mb, float* oldlp_mb, float* adv_mb, float* ret_mb, float* adv_stats /* NULL: not computed */, float* work,
                    void* stream);
 
 /* h <- max(h + bias, 0) in place: bfloat16 h[groups, rows, cols], bias[groups, cols] (cols even). */
@@ -235,6 +235,17 @@ int myo_vecnorm_step(const float* obs, const float* rew, const uint8_t* done, co
                      int norm_obs, int norm_reward, float* nobs, float* starts, const int32_t* t_idx, float* rew_buf,
                      float* start_buf, float* term_buf, float* trunc_buf, double* work, void* stream);
 /* t_idx <- (t_idx + 1) mod T, commit the Philox position. */
+/* myo_vecnorm_step split where N ranks exchange their batch moments (one VecNormalize over the envs of ALL ranks,
+ * /root/reference/src/main_baoding.py:75): batch_moments leaves batch[0] = n, batch[1..O+1] = sum x (column O = the
+ * discounted returns), batch[O+2..2O+2] = sum x^2 of this rank's step in a caller-owned dev double[2 O + 3]; the
+ * caller all-reduces it (SUM); finish then updates the running statistics from it and normalises as myo_vecnorm_step. */
+int myo_vecnorm_batch_moments(const float* obs, const float* rew, int N, int O, double* returns, double gamma, int training,
+                              double* work, double* batch, void* stream);
+int myo_vecnorm_finish(const float* obs, const float* rew, const uint8_t* done, const uint8_t* trunc, const float* term_obs,
+                       int N, int O, double* obs_mean, double* obs_var, double* obs_count, double* ret_stats, double* returns,
+                       double eps, double clip_obs, double clip_rew, int training, int norm_obs, int norm_reward, float* nobs,
+                       float* starts, const int32_t* t_idx, float* rew_buf, float* start_buf, float* term_buf, float* trunc_buf,
+                       const double* batch, void* stream);
 int myo_rollout_advance(int32_t* t_idx, int T, uint64_t* draw_counter, void* stream);
 
 /* One time step of G stacked one-layer LSTMs (gate order i, f, g, o) around the recurrent GEMM: the pointwise

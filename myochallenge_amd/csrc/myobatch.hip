@@ -1336,7 +1336,7 @@ extern "C" int myo_ppo_gather(const float* obs, const float* act, const float* o
                               const int64_t* idx, int bs, int obs_dim, int act_dim, uint16_t* obs_bf16, int copies,
                               float* act_mb, float* oldlp_mb, float* adv_mb, float* ret_mb, float* adv_stats, float* work,
                               void* stream) {
-  if (!obs || !act || !oldlp || !adv || !ret || !idx || !obs_bf16 || !act_mb || !oldlp_mb || !adv_mb || !ret_mb || !adv_stats ||
+  if (!obs || !act || !oldlp || !adv || !ret || !idx || !obs_bf16 || !act_mb || !oldlp_mb || !adv_mb || !ret_mb ||
       !work || bs <= 0 || obs_dim <= 0 || act_dim <= 0 || copies <= 0)
     return fail(MYO_E_ARG, "myo_ppo_gather: bad arguments");
 #ifdef MYO_EMU
@@ -1345,8 +1345,9 @@ extern "C" int myo_ppo_gather(const float* obs, const float* act, const float* o
 #else
   hipLaunchKernelGGL(k_ppo_gather, dim3((bs + MYO_GATHER_ROWS - 1) / MYO_GATHER_ROWS), dim3(256), 0, (hipStream_t)stream, obs, act, oldlp, adv, ret,
                      (const long long*)idx, bs, obs_dim, act_dim, obs_bf16, copies, act_mb, oldlp_mb, adv_mb, ret_mb, work);
-  hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, work,
-                     (bs + MYO_GATHER_ROWS - 1) / MYO_GATHER_ROWS, bs, adv_stats);
+  if (adv_stats)      // NULL: the caller supplies the advantage moments itself (cross-rank moments, or no normalisation)
+    hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, work,
+                       (bs + MYO_GATHER_ROWS - 1) / MYO_GATHER_ROWS, bs, adv_stats);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif
@@ -1555,6 +1556,45 @@ __global__ void __launch_bounds__(128) k_vecnorm_merge(const double* __restrict_
   }
   if (t == 0) { if (upd_obs) *obs_count = oc + N; if (upd_ret) ret_stats[2] = rc + N; }
 }
+// ---- the same update split at the point where N ranks exchange their batch moments (all-reduce
+// (n, sum x, sum x^2) so that N ranks reproduce ONE VecNormalize over all envs).  k_vecnorm_batch turns the block
+// moments of this rank into additive sums batch[0] = n, batch[1 + c] = sum x_c, batch[2 + O + c] = sum x_c^2 (column
+// O = the discounted returns); after the caller's all-reduce(SUM) k_vecnorm_merge_batch does Chan's update from them.
+__global__ void __launch_bounds__(128) k_vecnorm_batch(const double* __restrict__ part, int nb, int N, int O, double* __restrict__ batch) {
+  const int t = threadIdx.x;
+  for (int c = t; c <= O; c += 128) {
+    double s1 = 0, s2 = 0;
+    for (int b = 0; b < nb; ++b) {
+      const int n_b = (N - b * MYO_VN_ROWS) < MYO_VN_ROWS ? (N - b * MYO_VN_ROWS) : MYO_VN_ROWS;
+      const double m = part[((size_t)b * (O + 1) + c) * 2];
+      s1 += n_b * m;
+      s2 += part[((size_t)b * (O + 1) + c) * 2 + 1] + n_b * m * m;
+    }
+    batch[1 + c] = s1; batch[2 + O + c] = s2;
+  }
+  if (t == 0) batch[0] = (double)N;
+}
+__global__ void __launch_bounds__(128) k_vecnorm_merge_batch(const double* __restrict__ batch, int O, double* __restrict__ obs_mean,
+                                                             double* __restrict__ obs_var, double* __restrict__ obs_count,
+                                                             double* __restrict__ ret_stats, int upd_obs, int upd_ret) {
+  const int t = threadIdx.x;
+  const double oc = *obs_count, rc = ret_stats[2], n = batch[0];
+  __syncthreads();
+  for (int c = t; c <= O; c += 128) {
+    if ((c < O && !upd_obs) || (c == O && !upd_ret)) continue;
+    const double bmean = batch[1 + c] / n;
+    double bvar = batch[2 + O + c] / n - bmean * bmean;
+    bvar = bvar < 0 ? 0 : bvar;
+    double* mean = c < O ? obs_mean + c : ret_stats;
+    double* var = c < O ? obs_var + c : ret_stats + 1;
+    const double cnt = c < O ? oc : rc;
+    const double delta = bmean - *mean, tot = cnt + n;
+    const double new_mean = *mean + delta * n / tot;
+    const double M2 = *var * cnt + bvar * n + delta * delta * cnt * n / tot;
+    *mean = new_mean; *var = M2 / tot;
+  }
+  if (t == 0) { if (upd_obs) *obs_count = oc + n; if (upd_ret) ret_stats[2] = rc + n; }
+}
 // kernel 3 of 3: normalise observation, terminal observation and reward with the UPDATED statistics,
 // zero the returns of finished episodes, and write the rollout buffer rows of step t.
 __global__ void __launch_bounds__(256) k_vecnorm_apply(const float* __restrict__ obs, const float* __restrict__ rew,
@@ -1641,6 +1681,45 @@ extern "C" int myo_vecnorm_step(const float* obs, const float* rew, const uint8_
   hipLaunchKernelGGL(k_vecnorm_moments, dim3(nb), dim3(128), 0, st, obs, rew, N, O, returns, gamma, training, work);
   if (training)
     hipLaunchKernelGGL(k_vecnorm_merge, dim3(1), dim3(128), 0, st, work, nb, N, O, obs_mean, obs_var, obs_count, ret_stats,
+                       (int)(training && norm_obs), (int)(training != 0));
+  const size_t n = (size_t)N * O;
+  hipLaunchKernelGGL(k_vecnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, obs, rew, done, trunc, term_obs, N, O,
+                     obs_mean, obs_var, ret_stats, returns, eps, clip_obs, clip_rew, norm_obs, norm_reward, nobs, starts, t_idx,
+                     rew_buf, start_buf, term_buf, trunc_buf);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_vecnorm_batch_moments(const float* obs, const float* rew, int N, int O, double* returns, double gamma, int training,
+                                         double* work, double* batch, void* stream) {
+  if (!obs || !rew || !returns || !work || !batch || N <= 0 || O <= 0) return fail(MYO_E_ARG, "myo_vecnorm_batch_moments: bad arguments");
+#ifdef MYO_EMU
+  (void)gamma; (void)training; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_vecnorm_batch_moments is a GPU kernel");
+#else
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (N + MYO_VN_ROWS - 1) / MYO_VN_ROWS;
+  hipLaunchKernelGGL(k_vecnorm_moments, dim3(nb), dim3(128), 0, st, obs, rew, N, O, returns, gamma, training, work);
+  hipLaunchKernelGGL(k_vecnorm_batch, dim3(1), dim3(128), 0, st, work, nb, N, O, batch);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_vecnorm_finish(const float* obs, const float* rew, const uint8_t* done, const uint8_t* trunc, const float* term_obs,
+                                  int N, int O, double* obs_mean, double* obs_var, double* obs_count, double* ret_stats,
+                                  double* returns, double eps, double clip_obs, double clip_rew, int training, int norm_obs,
+                                  int norm_reward, float* nobs, float* starts, const int32_t* t_idx, float* rew_buf, float* start_buf,
+                                  float* term_buf, float* trunc_buf, const double* batch, void* stream) {
+  if (!obs || !rew || !done || !trunc || !term_obs || !obs_mean || !obs_var || !obs_count || !ret_stats || !returns || !nobs ||
+      !starts || !t_idx || !rew_buf || !start_buf || !batch || N <= 0 || O <= 0)
+    return fail(MYO_E_ARG, "myo_vecnorm_finish: bad arguments");
+#ifdef MYO_EMU
+  (void)eps; (void)clip_obs; (void)clip_rew; (void)training; (void)norm_obs; (void)norm_reward; (void)term_buf; (void)trunc_buf; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_vecnorm_finish is a GPU kernel");
+#else
+  hipStream_t st = (hipStream_t)stream;
+  if (training)
+    hipLaunchKernelGGL(k_vecnorm_merge_batch, dim3(1), dim3(128), 0, st, batch, O, obs_mean, obs_var, obs_count, ret_stats,
                        (int)(training && norm_obs), (int)(training != 0));
   const size_t n = (size_t)N * O;
   hipLaunchKernelGGL(k_vecnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, obs, rew, done, trunc, term_obs, N, O,

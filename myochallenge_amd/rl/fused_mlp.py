@@ -206,6 +206,7 @@ class FusedPPOStep:
             self.merged = self._stacked_views(flat, hflat)
         self.acc = torch.zeros(2 * A + 4, device=dev)
         self.stats = torch.zeros(2, device=dev)
+        self.external_adv_stats = False      # True: the caller fills self.stats (global / no advantage normalisation)
         self.A = A
         self._work = {}
 
@@ -308,7 +309,7 @@ class FusedPPOStep:
         stream = torch.cuda.current_stream(dev).cuda_stream
         p = lambda t: C.c_void_p(t.data_ptr())
         self.lib.check(self.lib.L.myo_ppo_gather(p(obs_all), p(act_all), p(oldlp_all), p(adv_all), p(ret_all), p(idx), B, O, A,
-                                                 p(x2), 2, p(act), p(oldlp), p(adv), p(ret), p(self.stats), p(work),
+                                                 p(x2), 2, p(act), p(oldlp), p(adv), p(ret), None if self.external_adv_stats else p(self.stats), p(work),
                                                  C.c_void_p(stream)))
         return self._merged_core(x2, act, oldlp, adv, ret)
 

@@ -358,7 +358,10 @@ class ActorCriticPolicy(nn.Module):
         if self.recurrent:
             lp, lv = lp[0], lv[0]
         mean, log_std = self._dist(lp)
-        actions = mean if deterministic else mean + torch.exp(log_std) * torch.randn_like(mean)
+        # exploration noise: N(0, 1) from torch's generator, or from `noise_fn(mean)` when one is installed (tests of
+        # the N-rank == 1-rank equivalence draw ONE global noise tensor and give every rank its rows)
+        noise = torch.randn_like(mean) if getattr(self, "noise_fn", None) is None else self.noise_fn(mean)
+        actions = mean if deterministic else mean + torch.exp(log_std) * noise
         values = _apply_net(self.value_net, lv).float().squeeze(-1)
         return actions, values, self.log_prob(actions, mean, log_std), state
 

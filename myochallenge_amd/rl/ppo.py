@@ -204,7 +204,33 @@ class PPO:
                                                p(self._t_idx), p(self.act_buf), p(self.val_buf), p(self.logp_buf),
                                                p(self._clip_s), 0, st))
 
+        # N > 1 ranks with a rank-synchronised normaliser: graph B1 (this rank's batch moments) -> eager all-reduce of
+        # 2 O + 3 doubles -> graph B2 (running statistics from the global moments, normalise, buffer writes)
+        self._vn_sync = self.world > 1 and getattr(vec, "sync_ranks", False) and vec.training
+        self._vn_batch = torch.zeros(2 * O + 3, dtype=torch.float64, device=d)
+
+        def part_b1(rawout):
+            obs, rew = rawout[:2]
+            st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+            lib.check(lib.L.myo_vecnorm_batch_moments(p(obs), p(rew), N, O, p(vec.returns), float(vec.gamma), int(vec.training),
+                                                      p(self._vn_work), p(self._vn_batch), st))
+
+        def part_b2(rawout):
+            obs, rew, done, trunc, term = rawout[:5]
+            st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+            lib.check(lib.L.myo_vecnorm_finish(
+                p(obs), p(rew), p(done), p(trunc), p(term), N, O, p(vec.obs_rms.mean), p(vec.obs_rms.var), p(vec.obs_rms.count),
+                p(vec.ret_rms.buf), p(vec.returns), float(vec.epsilon), float(vec.clip_obs), float(vec.clip_reward),
+                int(vec.training), int(vec.norm_obs), int(vec.norm_reward), p(self._obs_s), p(self._starts_s), p(self._t_idx),
+                p(self.rew_buf), p(self.start_buf), p(self.term_buf), p(self.trunc_buf), p(self._vn_batch), st))
+            lib.check(lib.L.myo_rollout_advance(p(self._t_idx), T, p(self._draw), st))
+
         def part_b(rawout):
+            if self._vn_sync:
+                part_b1(rawout)
+                dist.all_reduce(self._vn_batch)
+                part_b2(rawout)
+                return
             obs, rew, done, trunc, term = rawout[:5]
             st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
             lib.check(lib.L.myo_vecnorm_step(
@@ -234,11 +260,18 @@ class PPO:
         vec.old_obs, vec.old_reward = rawout[0], rawout[1]      # the env's static output buffers
         self._t_idx.zero_()
         self._draw.zero_()
-        self._gA, self._gB = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self._gA, self._gB, self._gB2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), None
         with torch.cuda.graph(self._gA, capture_error_mode="thread_local"):
             part_a()
-        with torch.cuda.graph(self._gB, capture_error_mode="thread_local"):
-            part_b(rawout)
+        if self._vn_sync:
+            self._gB2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._gB, capture_error_mode="thread_local"):
+                part_b1(rawout)
+            with torch.cuda.graph(self._gB2, capture_error_mode="thread_local"):
+                part_b2(rawout)
+        else:
+            with torch.cuda.graph(self._gB, capture_error_mode="thread_local"):
+                part_b(rawout)
         self._rollout_ready = True
         self._native = True
 
@@ -290,6 +323,9 @@ class PPO:
         self._gA.replay()
         self._raw.step_tensor(self._clip_s)
         self._gB.replay()
+        if getattr(self, "_gB2", None) is not None:      # rank-synchronised normaliser (see _init_native_rollout)
+            dist.all_reduce(self._vn_batch)
+            self._gB2.replay()
 
     def finish_rollout(self) -> None:
         with torch.no_grad(), self._autocast():
@@ -468,14 +504,29 @@ class PPO:
         cfg = self.cfg
         B = cfg.n_steps * self.env.num_envs
         bs = min(cfg.batch_size, B)
+        # advantage moments of a minibatch: computed by the gather kernel (this rank's rows), or handed to it when they
+        # must be the moments of the GLOBAL minibatch (sync_adv_moments, N > 1) or when advantages are not normalised
+        ext = (cfg.sync_adv_moments and self.world > 1) or not cfg.normalize_advantage
+        if self._fused.external_adv_stats != ext:
+            self._fused.external_adv_stats = ext
+            self._graph = None
         if self._graph != (B, bs):
             self._build_graphs(B, bs)
         g = self._gs
         g["adv"].copy_(adv.view(B)); g["ret"].copy_(ret.view(B))
+        if not cfg.normalize_advantage:
+            self._fused.stats.copy_(torch.tensor([0.0, 1.0], device=self.device))
         for _ in range(cfg.n_epochs):
             perm = torch.randperm(B, generator=self.gen, device=self.device)
             for s in range(0, B - bs + 1, bs):
                 g["idx"].copy_(perm[s:s + bs])
+                if ext and cfg.normalize_advantage:
+                    a = g["adv"][perm[s:s + bs]].double()
+                    m = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(bs), dtype=torch.float64, device=self.device)])
+                    dist.all_reduce(m)
+                    mean = m[0] / m[2]
+                    std = torch.sqrt(torch.clamp(m[1] / m[2] - mean * mean, min=0.0) * m[2] / (m[2] - 1))
+                    self._fused.stats.copy_(torch.stack([mean, std]).float())
                 self._graph_fb.replay()
                 if self.world > 1:
                     dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)

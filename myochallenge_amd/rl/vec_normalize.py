@@ -33,8 +33,20 @@ class RunningMeanStd:
         self.var.copy_(torch.as_tensor(np.asarray(var, np.float64)).view(self.var.shape))
         self.count.fill_(float(count))
 
+    sync = False      # all-reduce the batch moments over torch.distributed ranks (VecNormalize(sync_ranks=True))
+
     def update(self, x: torch.Tensor) -> None:
         x = x.to(torch.float64)
+        if self.sync and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # one VecNormalize over the envs of ALL ranks: additive sums (n, sum x, sum x^2), all-reduced
+            n = torch.tensor([float(x.shape[0])], dtype=torch.float64, device=x.device)
+            s = torch.cat([n, x.sum(0).reshape(-1), (x * x).sum(0).reshape(-1)])
+            torch.distributed.all_reduce(s)
+            k = (s.numel() - 1) // 2
+            mean = (s[1:1 + k] / s[0]).view(self.mean.shape)
+            var = torch.clamp(s[1 + k:] / s[0] - (s[1:1 + k] / s[0]) ** 2, min=0.0).view(self.mean.shape)
+            self.update_from_moments(mean, var, s[0])
+            return
         if x.is_cuda and x.dim() == 2:
             # column moments as [1,N] x [N,O] products: ATen's multi-block column reduction is not replay-safe
             # inside a hipGraph on this stack (see rl/policy.py:_LinearGemmBias); GEMMs are
@@ -80,7 +92,10 @@ class VecNormalize:
     """Wraps a tensor-native batched env (``reset_tensor`` / ``step_tensor``)."""
 
     def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
-                 gamma=0.99, epsilon=1e-8):
+                 gamma=0.99, epsilon=1e-8, sync_ranks=True):
+        """sync_ranks: with torch.distributed initialised, the batch moments of every update are all-reduced, so N
+        ranks x M envs keep the statistics ONE VecNormalize over N M envs would (the reference wraps all its envs in
+        one, /root/reference/src/main_baoding.py:74-75) and every rank holds — and saves — the same normaliser."""
         self.venv = venv
         self.num_envs = venv.num_envs if venv is not None else 0
         dev = venv.device if venv is not None else "cpu"
@@ -88,6 +103,8 @@ class VecNormalize:
         obs_dim = venv.obs_dim if venv is not None else 0
         self.obs_rms = RunningMeanStd((obs_dim,), dev)
         self.ret_rms = RunningMeanStd((), dev)
+        self.sync_ranks = bool(sync_ranks)
+        self.obs_rms.sync = self.ret_rms.sync = self.sync_ranks
         self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
         self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
         self.returns = torch.zeros(self.num_envs, dtype=torch.float64, device=dev)

@@ -429,7 +429,8 @@ def _graph_dp_worker(rank, world, port, out):
     torch.manual_seed(0)
     pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
     env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=64, seed=100 + rank)
-    algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=8, batch_size=128, n_epochs=2), seed=rank)
+    venv = VecNormalize(env)
+    algo = PPO(venv, pol, PPOConfig(n_steps=8, batch_size=128, n_epochs=2, sync_adv_moments=True), seed=rank)
     assert algo.world == 2 and algo._flat_adam is not None
     for _ in range(2):
         algo.collect_rollouts()
@@ -437,6 +438,8 @@ def _graph_dp_worker(rank, world, port, out):
     torch.cuda.synchronize()
     out[rank] = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).cpu().numpy()
     out[10 + rank] = float(algo.rew_buf.sum())
+    out[20 + rank] = (venv.obs_rms.mean.cpu().numpy(), venv.obs_rms.var.cpu().numpy(), float(venv.obs_rms.count), float(venv.ret_rms.var))
+    out[30 + rank] = (bool(algo._vn_sync), bool(algo._fused.external_adv_stats))
     dist.destroy_process_group()
 
 
@@ -463,6 +466,12 @@ def test_two_rank_graph_path_keeps_replicas_identical(hip_lib):
     a, b = out[0], out[1]
     assert np.isfinite(a).all() and np.array_equal(a, b)
     assert out[10] != out[11]                       # the ranks really saw different data
+    # one normaliser over the envs of both ranks (batch moments all-reduced between the two halves of graph B), and the
+    # advantage moments of the global minibatch handed to the fused step
+    assert out[30] == (True, True) and out[31] == (True, True)
+    (m0, v0, c0, r0), (m1, v1, c1, r1) = out[20], out[21]
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1) and c0 == c1 and r0 == r1
+    assert abs(c0 - (1e-4 + 2 * 64 * (2 * 8 + 1))) < 1e-6          # reset + 16 steps, 128 envs each
     torch.manual_seed(0)
     from myochallenge_amd.rl.policy import ActorCriticPolicy
     init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None).parameters()]).numpy()

@@ -149,6 +149,58 @@ def test_two_rank_data_parallel_keeps_replicas_identical(emu_lib):
     assert not np.array_equal(out[0], init)
 
 
+def _equiv_worker(rank, world, port, emu_path, out):
+    """`world` ranks x 3 envs (or 1 rank x 6 envs when world == 1): synced normaliser, synced advantage moments,
+    full-batch updates, ONE global exploration-noise tensor of which every rank takes its rows."""
+    import torch.distributed as dist
+    from helpers import make_env
+    from myochallenge_amd import native
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    if world > 1:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, per = 6, 6 // world
+    torch.manual_seed(0)
+    pol = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=None)
+    g = torch.Generator(); g.manual_seed(7)
+    pol.noise_fn = lambda mean: torch.randn((total, mean.shape[1]), generator=g)[rank * per:(rank + 1) * per]
+    env = VecNormalize(make_env("CustomMyoBaodingBallsP1", native.load(emu_path), num_envs=per, seed=5, dtype="f64"), gamma=0.99)
+    algo = PPO(env, pol, PPOConfig(n_steps=4, batch_size=4 * per, n_epochs=2, bf16=False, sync_adv_moments=True, learning_rate=1e-3))
+    for _ in range(2):
+        algo.collect_rollouts()
+        algo.train()
+    out[(world, rank)] = (torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).numpy(),
+                          env.obs_rms.mean.numpy().copy(), env.obs_rms.var.numpy().copy(), float(env.obs_rms.count),
+                          float(env.ret_rms.var), algo.rew_buf.numpy().copy())
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+    env.close()
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(emu_lib):
+    """2 ranks x 3 envs == 1 rank x 6 envs.  What makes it an identity: the normaliser's batch
+    moments and the advantage moments are all-reduced, the gradient is the mean of the ranks' means over equal shards,
+    and the update is full-batch (with minibatches each rank shuffles its own shard — ordinary data-parallel SGD, not an
+    identity).  Compared after two rollout + update rounds: policy parameters, normaliser statistics and the
+    normalised rewards of the last rollout."""
+    import torch.multiprocessing as mp
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_equiv_worker, args=(2, _free_port(), emu_lib.path, out), nprocs=2, join=True)
+    mp.spawn(_equiv_worker, args=(1, 0, emu_lib.path, out), nprocs=1, join=True)
+    one, r0, r1 = out[(1, 0)], out[(2, 0)], out[(2, 1)]
+    assert np.array_equal(r0[0], r1[0]) and np.array_equal(r0[1], r1[1])          # replicas and normalisers stay identical
+    assert abs(r0[3] - one[3]) < 1e-9 and r0[3] > 6 * 8                             # every rank counted all 6 envs
+    # (float32 policies: after the first update the two runs differ by summation order, ~1e-7 in the parameters, and the
+    # second rollout inherits it)
+    assert np.abs(r0[1] - one[1]).max() < 1e-6 and np.abs(r0[2] - one[2]).max() < 1e-6 and abs(r0[4] - one[4]) < 1e-6 * max(1, one[4])
+    assert np.abs(np.concatenate([r0[5], r1[5]], 1) - one[5]).max() < 1e-5          # same normalised rewards, env for env
+    assert np.abs(r0[0] - one[0]).max() < 5e-6, np.abs(r0[0] - one[0]).max()        # same policy after two updates
+    torch.manual_seed(0)
+    init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (16,), (16,)).parameters()]).numpy()
+    assert np.abs(one[0] - init).max() > 1e-4                                       # and it did move
+
+
 def test_fused_mlp_gradients_match_autograd():
     """rl/fused_mlp.py (hand-derived backward used inside the captured hipGraph) == autograd."""
     from myochallenge_amd.rl.fused_mlp import ppo_mlp_step_grads

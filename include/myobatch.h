@@ -235,6 +235,12 @@ int myo_vecnorm_step(const float* obs, const float* rew, const uint8_t* done, co
                      int norm_obs, int norm_reward, float* nobs, float* starts, const int32_t* t_idx, float* rew_buf,
                      float* start_buf, float* term_buf, float* trunc_buf, double* work, void* stream);
 /* t_idx <- (t_idx + 1) mod T, commit the Philox position. */
+/* gSDE action sampling (stable-baselines3 StateDependentNoiseDistribution as the reference's RecurrentPPO(use_sde=True,
+ * sde_sample_freq=-1) uses it, /root/reference/docs/summary.md:100): mean f32[N,A], latent f32[N,L] (latent_pi), exploration_mat
+ * f32[N,L,A] (one matrix per env, drawn once per rollout), log_std f32[L,A] -> actions (unclipped), clipped, logp f32[N]. */
+int myo_rollout_sample_sde(const float* mean, const float* latent, const float* exploration_mat, const float* log_std, int N, int L,
+                           int A, float* actions, float* clipped, float* logp, int deterministic, void* stream);
+
 /* myo_vecnorm_step split where N ranks exchange their batch moments (one VecNormalize over the envs of ALL ranks,
  * /root/reference/src/main_baoding.py:75): batch_moments leaves batch[0] = n, batch[1..O+1] = sum x (column O = the
  * discounted returns), batch[O+2..2O+2] = sum x^2 of this rank's step in a caller-owned dev double[2 O + 3]; the

@@ -1630,6 +1630,35 @@ __global__ void __launch_bounds__(256) k_vecnorm_apply(const float* __restrict__
     if (dn) returns[i] = 0.0;
   }
 }
+// gSDE action sampling (SB3 StateDependentNoiseDistribution): one 64-lane block per env, lane j =
+// action j.  noise_j = sum_l latent_l W[n][l][j] with the env's own exploration matrix W (drawn once per rollout),
+// sigma_j = sqrt(sum_l latent_l^2 exp(log_std[l][j])^2 + 1e-6); action = mean + noise (unclipped, as stored by SB3),
+// clipped copy for the env, log pi = sum_j log N(action_j; mean_j, sigma_j).  W rows are read coalesced (A contiguous).
+__global__ void __launch_bounds__(64) k_sample_sde(const float* __restrict__ mean, const float* __restrict__ latent,
+                                                   const float* __restrict__ W, const float* __restrict__ log_std, int N, int L, int A,
+                                                   float* __restrict__ actions, float* __restrict__ clipped, float* __restrict__ logp,
+                                                   int deterministic) {
+  const int n = blockIdx.x, t = threadIdx.x;
+  float lp_part = 0.f;
+  for (int j = t; j < A; j += 64) {
+    const float* w = W + (size_t)n * L * A + j;
+    const float* lat = latent + (size_t)n * L;
+    float noise = 0.f, var = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float x = lat[l], sd = __expf(log_std[(size_t)l * A + j]);
+      noise = fmaf(x, w[(size_t)l * A], noise);
+      var = fmaf(x * x, sd * sd, var);
+    }
+    const float mu = mean[(size_t)n * A + j], sg = sqrtf(var + 1e-6f);
+    const float a = deterministic ? mu : mu + noise;
+    actions[(size_t)n * A + j] = a;
+    clipped[(size_t)n * A + j] = fminf(fmaxf(a, -1.f), 1.f);
+    const float z = (a - mu) / sg;
+    lp_part += -0.5f * z * z - logf(sg) - 0.9189385332046727f;
+  }
+  for (int off = 32; off >= 1; off >>= 1) lp_part += __shfl_xor(lp_part, off, 64);
+  if (t == 0) logp[n] = lp_part;
+}
 __global__ void k_rollout_advance(int* t_idx, int T, unsigned long long* draw_counter) {
   *t_idx = (*t_idx + 1) % T;
   draw_counter[0] = draw_counter[1];
@@ -1686,6 +1715,20 @@ extern "C" int myo_vecnorm_step(const float* obs, const float* rew, const uint8_
   hipLaunchKernelGGL(k_vecnorm_apply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, obs, rew, done, trunc, term_obs, N, O,
                      obs_mean, obs_var, ret_stats, returns, eps, clip_obs, clip_rew, norm_obs, norm_reward, nobs, starts, t_idx,
                      rew_buf, start_buf, term_buf, trunc_buf);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_rollout_sample_sde(const float* mean, const float* latent, const float* exploration_mat, const float* log_std,
+                                      int N, int L, int A, float* actions, float* clipped, float* logp, int deterministic, void* stream) {
+  if (!mean || !latent || !exploration_mat || !log_std || !actions || !clipped || !logp || N <= 0 || L <= 0 || A <= 0)
+    return fail(MYO_E_ARG, "myo_rollout_sample_sde: bad arguments");
+#ifdef MYO_EMU
+  (void)deterministic; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_rollout_sample_sde is a GPU kernel");
+#else
+  hipLaunchKernelGGL(k_sample_sde, dim3(N), dim3(64), 0, (hipStream_t)stream, mean, latent, exploration_mat, log_std, N, L, A, actions,
+                     clipped, logp, deterministic);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif

@@ -99,6 +99,7 @@ class NativeLib:
         L.myo_rollout_sample.argtypes = [vp, vp, vp, i32, i32, u64, vp, vp, vp, vp, vp, vp, i32, vp]
         L.myo_vecnorm_step.argtypes = [vp] * 5 + [i32, i32] + [vp] * 5 + [dbl] * 4 + [i32] * 3 + [vp] * 9
         L.myo_rollout_advance.argtypes = [vp, i32, vp, vp]
+        L.myo_rollout_sample_sde.argtypes = [vp] * 4 + [i32] * 3 + [vp] * 3 + [i32, vp]
         L.myo_vecnorm_batch_moments.argtypes = [vp, vp, i32, i32, vp, dbl, i32, vp, vp, vp]
         L.myo_vecnorm_finish.argtypes = [vp] * 5 + [i32, i32] + [vp] * 5 + [dbl] * 3 + [i32] * 3 + [vp] * 9
         L.myo_gae.argtypes = [vp] * 5 + [i32, i32, C.c_float, C.c_float, vp, vp, vp]
@@ -139,7 +140,7 @@ EXPORTED_SYMBOLS = [
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
-    "myo_vecnorm_step", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
+    "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
 ]
 
 

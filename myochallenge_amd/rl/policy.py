@@ -213,8 +213,16 @@ class MlpExtractor(nn.Module):
 class ActorCriticPolicy(nn.Module):
     def __init__(self, obs_dim: int, act_dim: int, pi: Sequence[int] = (256, 256), vf: Sequence[int] = (256, 256),
                  lstm_hidden_size: Optional[int] = None, enable_critic_lstm: bool = True,
-                 log_std_init: float = -2.0, activation_fn=nn.ReLU):
+                 log_std_init: float = -2.0, activation_fn=nn.ReLU, use_sde: bool = False):
+        """use_sde: generalised state-dependent exploration (stable-baselines3's StateDependentNoiseDistribution with its
+        defaults full_std=True, use_expln=False, squash_output=False, learn_features=False; SURVEY.md Appendix C.4;
+        /root/reference/docs/summary.md:100, `use_sde=True` in the archived curriculum scripts): ``log_std`` is a
+        [latent_pi, act] matrix, the exploration noise of env n is latent_pi(s) . W_n with W_n ~ N(0, exp(log_std))
+        drawn by ``reset_noise`` once per rollout (sde_sample_freq = -1), and the action distribution is
+        Normal(mean, sqrt(latent_pi^2 . exp(log_std)^2 + 1e-6))."""
         super().__init__()
+        self.use_sde = bool(use_sde)
+        self.exploration_mat = None          # [n_envs, latent_pi, act], set by reset_noise
         self.obs_dim, self.act_dim = obs_dim, act_dim
         self.pi_arch, self.vf_arch = list(pi), list(vf)
         self.lstm_hidden_size, self.enable_critic_lstm = lstm_hidden_size, enable_critic_lstm
@@ -230,7 +238,29 @@ class ActorCriticPolicy(nn.Module):
         self.mlp_extractor = MlpExtractor(feat, list(pi), list(vf), activation_fn)
         self.action_net = nn.Linear(self.mlp_extractor.latent_dim_pi, act_dim)
         self.value_net = nn.Linear(self.mlp_extractor.latent_dim_vf, 1)
-        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
+        shape = (self.mlp_extractor.latent_dim_pi, act_dim) if self.use_sde else (act_dim,)
+        self.log_std = nn.Parameter(torch.full(shape, float(log_std_init)))
+
+    # ---- gSDE
+    SDE_EPS = 1e-6
+
+    @torch.no_grad()
+    def reset_noise(self, n_envs: int, generator: Optional[torch.Generator] = None) -> None:
+        """One exploration matrix per env, W ~ N(0, exp(log_std)) (SB3 ``sample_weights``; called at the start of every
+        rollout for sde_sample_freq = -1)."""
+        if not self.use_sde:
+            return
+        std = torch.exp(self.log_std.float())
+        eps = torch.randn((n_envs,) + tuple(std.shape), device=std.device, generator=generator)
+        if self.exploration_mat is not None and self.exploration_mat.shape == eps.shape:
+            self.exploration_mat.copy_(eps * std)          # in place: a captured rollout graph keeps reading this tensor
+        else:
+            self.exploration_mat = eps * std
+
+    def _sde_std(self, latent_pi):
+        """Per-sample action std of the state-dependent distribution."""
+        var = (latent_pi.float() ** 2) @ (torch.exp(self.log_std.float()) ** 2)
+        return torch.sqrt(var + self.SDE_EPS)
 
     # ---- recurrent helpers
     def initial_state(self, n: int, device) -> Optional[Tuple[torch.Tensor, ...]]:
@@ -346,7 +376,10 @@ class ActorCriticPolicy(nn.Module):
         var = torch.exp(2 * log_std)
         return (-0.5 * ((actions - mean) ** 2) / var - log_std - 0.5 * math.log(2 * math.pi)).sum(-1)
 
-    def entropy(self):
+    def entropy(self, latent_pi=None):
+        """DiagGaussian: one number (state independent).  gSDE: per sample, from the state-dependent std."""
+        if self.use_sde:
+            return (0.5 + 0.5 * math.log(2 * math.pi) + torch.log(self._sde_std(latent_pi.detach()))).sum(-1)
         return (0.5 + 0.5 * math.log(2 * math.pi) + self.log_std.float()).sum()
 
     # ---- rollout: one step for all envs
@@ -360,9 +393,16 @@ class ActorCriticPolicy(nn.Module):
         mean, log_std = self._dist(lp)
         # exploration noise: N(0, 1) from torch's generator, or from `noise_fn(mean)` when one is installed (tests of
         # the N-rank == 1-rank equivalence draw ONE global noise tensor and give every rank its rows)
+        values = _apply_net(self.value_net, lv).float().squeeze(-1)
+        if self.use_sde:
+            lat = lp.float()
+            if self.exploration_mat is None or self.exploration_mat.shape[0] != lat.shape[0]:
+                self.reset_noise(lat.shape[0])
+            noise = torch.bmm(lat.unsqueeze(1), self.exploration_mat).squeeze(1)       # latent_pi(s_n) . W_n
+            actions = mean if deterministic else mean + noise
+            return actions, values, self.log_prob(actions, mean, torch.log(self._sde_std(lat))), state
         noise = torch.randn_like(mean) if getattr(self, "noise_fn", None) is None else self.noise_fn(mean)
         actions = mean if deterministic else mean + torch.exp(log_std) * noise
-        values = _apply_net(self.value_net, lv).float().squeeze(-1)
         return actions, values, self.log_prob(actions, mean, log_std), state
 
     @torch.no_grad()
@@ -380,6 +420,9 @@ class ActorCriticPolicy(nn.Module):
         lp, lv, _ = self._latents(obs, state, episode_starts)
         mean, log_std = self._dist(lp)
         values = _apply_net(self.value_net, lv).float().squeeze(-1)
+        if self.use_sde:        # learn_features=False: the exploration features carry no gradient into the trunk
+            lat = lp.detach()
+            return values, self.log_prob(actions, mean, torch.log(self._sde_std(lat))), self.entropy(lat)
         return values, self.log_prob(actions, mean, log_std), self.entropy()
 
     def predict(self, observation, state=None, episode_start=None, deterministic=False):

@@ -82,7 +82,8 @@ class PPO:
         self._t_host = 0
         self._fused = None
         self._flat_adam = None
-        if cfg.use_graphs and on_gpu and not policy.recurrent:
+        sde = getattr(policy, "use_sde", False)
+        if cfg.use_graphs and on_gpu and not policy.recurrent and not sde:
             # flat parameter/grad vectors (before any graph captures addresses) + the one-kernel optimiser
             from .. import native
             from .fused_mlp import FlatAdam, flatten_parameters
@@ -94,7 +95,7 @@ class PPO:
                 self._flat_adam.shadow = self._fused.half[0]
                 self._fused.adam_syncs_shadow = True
                 self._fused.refresh_shadow()
-        elif cfg.use_graphs and on_gpu:
+        elif cfg.use_graphs and on_gpu and policy.recurrent:
             # recurrent policy: autograd does forward / BPTT, but on flat parameter / gradient vectors so that the
             # whole minibatch step (zero, forward, backward, clip + Adam) is ONE hipGraph (_train_recurrent_graphed)
             from .. import native
@@ -345,6 +346,8 @@ class PPO:
     @torch.no_grad()
     def collect_rollouts(self) -> None:
         cfg, env, pol = self.cfg, self.env, self.policy
+        if getattr(pol, "use_sde", False):          # SB3: policy.reset_noise(env.num_envs) at the start of a rollout
+            pol.reset_noise(env.num_envs, self.gen if self.gen.device == pol.log_std.device else None)
         if self._graphed_rollout():
             if self._fused is not None:
                 self._fused.refresh_shadow()        # rollout inference runs on the bf16 shadow weights
@@ -408,7 +411,8 @@ class PPO:
         ratio = torch.exp(logp - old_logp)
         pl = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - cfg.clip_range, 1 + cfg.clip_range)).mean()
         vl = torch.nn.functional.mse_loss(values, returns)
-        return pl + cfg.ent_coef * (-entropy) + cfg.vf_coef * vl, pl.detach(), vl.detach()
+        ent = entropy.mean() if torch.is_tensor(entropy) and entropy.dim() > 0 else entropy      # gSDE: per sample
+        return pl + cfg.ent_coef * (-ent) + cfg.vf_coef * vl, pl.detach(), vl.detach()
 
     def train(self) -> Dict[str, float]:
         cfg, pol = self.cfg, self.policy
@@ -416,7 +420,7 @@ class PPO:
         adv, ret = compute_gae(self.rew_buf, self.val_buf, self.start_buf, self._last_values,
                                self._last_starts, cfg.gamma, cfg.gae_lambda)
         stats = {}
-        if not pol.recurrent and cfg.use_graphs and self.device.type == "cuda":
+        if self._fused is not None:
             pl, vl = self._train_graphed(adv, ret)
         elif not pol.recurrent:
             B = T * N

@@ -48,8 +48,7 @@ def read_zip(path: str) -> Tuple[Dict[str, Any], Dict[str, torch.Tensor], Option
 
 def policy_from_state_dict(sd: Dict[str, torch.Tensor], use_sde: bool = False) -> ActorCriticPolicy:
     """Infer the architecture from tensor shapes (what policy_kwargs would say)."""
-    if use_sde or sd["log_std"].dim() != 1:
-        raise NotImplementedError("gSDE checkpoints (log_std matrix) are not supported yet")
+    use_sde = bool(use_sde) or sd["log_std"].dim() == 2        # a gSDE checkpoint's log_std is the [latent_pi, act] matrix
     act_dim = sd["action_net.weight"].shape[0]
     hidden = None
     if "lstm_actor.weight_hh_l0" in sd:
@@ -66,7 +65,7 @@ def policy_from_state_dict(sd: Dict[str, torch.Tensor], use_sde: bool = False) -
     if hidden is None:
         obs_dim = sd["mlp_extractor.policy_net.0.weight"].shape[1] if pi else sd["action_net.weight"].shape[1]
     pol = ActorCriticPolicy(obs_dim, act_dim, pi, vf, lstm_hidden_size=hidden,
-                            enable_critic_lstm="lstm_critic.weight_hh_l0" in sd or hidden is None)
+                            enable_critic_lstm="lstm_critic.weight_hh_l0" in sd or hidden is None, use_sde=use_sde)
     pol.load_state_dict(sd, strict=True)
     return pol
 
@@ -135,7 +134,7 @@ def save_sb3_zip(path: str, policy: ActorCriticPolicy, hyper: Dict[str, Any], *,
                                          "<class 'numpy.ndarray'>"),
             "_last_original_obs": _ser(zeros_obs.astype(np.float64) if last_original_obs is None else np.asarray(last_original_obs, np.float64),
                                        "<class 'numpy.ndarray'>"),
-            "_episode_num": 0, "use_sde": False, "sde_sample_freq": -1, "_current_progress_remaining": 0.0,
+            "_episode_num": 0, "use_sde": bool(getattr(policy, "use_sde", False)), "sde_sample_freq": -1, "_current_progress_remaining": 0.0,
             "ep_info_buffer": _ser(collections.deque(maxlen=100), "<class 'collections.deque'>"),
             "ep_success_buffer": _ser(collections.deque(maxlen=100), "<class 'collections.deque'>"),
             "_n_updates": int(n_updates), "n_steps": int(hyper.get("n_steps", 256)), "gamma": float(hyper.get("gamma", 0.99)),

@@ -57,8 +57,6 @@ class MyoTrainer:
         lr = mc.get("learning_rate", mc.get("lr_schedule", base.get("learning_rate", 3e-4)))
         kw["learning_rate"] = _const(lr)
         kw["clip_range"] = _const(mc.get("clip_range", base.get("clip_range", 0.2)))
-        if mc.get("use_sde") or base.get("use_sde"):
-            raise NotImplementedError("gSDE exploration is not implemented (SURVEY.md C.1)")
         unknown = [k for k in mc if k not in _PPO_KEYS + _IGNORED + ("learning_rate", "clip_range", "policy", "policy_kwargs",
                                                                     "seed", "use_sde")]
         if unknown:
@@ -87,7 +85,8 @@ class MyoTrainer:
                                    lstm_hidden_size=int(pk.get("lstm_hidden_size", 256)) if recurrent else None,
                                    enable_critic_lstm=bool(pk.get("enable_critic_lstm", True)),
                                    log_std_init=float(pk.get("log_std_init", 0.0)),
-                                   activation_fn=pk.get("activation_fn", torch.nn.Tanh))
+                                   activation_fn=pk.get("activation_fn", torch.nn.Tanh),
+                                   use_sde=bool(mc.get("use_sde", False)))      # RecurrentPPO(..., use_sde=True, sde_sample_freq=-1)
         return PPO(env, policy, self._ppo_config({}), seed=int(mc.get("seed") or 0))
 
     # -- the reference's two calls

@@ -713,3 +713,46 @@ def test_lstm_cell_kernels_match_formulas(hip_lib, dtype):
     torch.cuda.synchronize()
     dct0 = dout.float() * wo * (1 - tc * tc)
     assert float((dcp.float() - dct0 * wf).abs().max()) <= tol * (1 + float((dct0 * wf).abs().max()))
+
+
+def test_gsde_sampling_kernel_matches_torch(hip_lib):
+    """myo_rollout_sample_sde against the torch statement of SB3's state-dependent noise distribution."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    N, L, A = 257, 256, 39
+    mean, latent = torch.randn(N, A, device=dev) * 0.3, torch.relu(torch.randn(N, L, device=dev))
+    log_std = torch.full((L, A), -2.0, device=dev) + 0.2 * torch.randn(L, A, device=dev)
+    W = torch.randn(N, L, A, device=dev) * torch.exp(log_std)
+    act, clip, lp = torch.empty(N, A, device=dev), torch.empty(N, A, device=dev), torch.empty(N, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    hip_lib.check(hip_lib.L.myo_rollout_sample_sde(p(mean), p(latent), p(W), p(log_std), N, L, A, p(act), p(clip), p(lp), 0, None))
+    torch.cuda.synchronize()
+    sg = torch.sqrt((latent.double() ** 2) @ (torch.exp(log_std.double()) ** 2) + 1e-6)
+    a_ref = mean.double() + torch.bmm(latent.double().unsqueeze(1), W.double()).squeeze(1)
+    lp_ref = torch.distributions.Normal(mean.double(), sg).log_prob(a_ref).sum(-1)
+    assert float((act.double() - a_ref).abs().max()) < 2e-5 and torch.equal(clip, act.clamp(-1, 1))
+    assert float((lp.double() - lp_ref).abs().max()) < 2e-3 * float(lp_ref.abs().max())
+    hip_lib.check(hip_lib.L.myo_rollout_sample_sde(p(mean), p(latent), p(W), p(log_std), N, L, A, p(act), p(clip), p(lp), 1, None))
+    torch.cuda.synchronize()
+    assert torch.equal(act, mean)
+
+
+def test_gsde_ppo_round_on_gpu(hip_lib):
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    torch.manual_seed(0)
+    env = VecNormalize(EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=64, seed=3))
+    pol = ActorCriticPolicy(86, 39, (64, 64), (64, 64), lstm_hidden_size=None, use_sde=True)
+    algo = PPO(env, pol, PPOConfig(n_steps=8, batch_size=128, n_epochs=2))
+    assert algo._fused is None
+    before = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone()
+    for _ in range(2):
+        algo.collect_rollouts()
+        algo.train()
+    after = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
+    assert torch.isfinite(after).all() and not torch.equal(before, after) and float(algo.act_buf.abs().max()) > 0

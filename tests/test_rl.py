@@ -557,3 +557,60 @@ def test_myotrainer_matches_reference_surface(emu_lib, golden_dir, tmp_path):
     assert tr2.agent.num_timesteps == 8
     with pytest.raises(TypeError):
         MyoTrainer(envs=venv, env_config=env_config, load_model_path=None, log_dir=log, model_config={"not_a_kwarg": 1})
+
+
+def test_gsde_policy_matches_the_sb3_statement():
+    """gSDE (use_sde=True, sde_sample_freq=-1; /root/reference/docs/summary.md:100 and the archived curriculum scripts):
+    the policy against a direct transcription of stable-baselines3's StateDependentNoiseDistribution with its defaults
+    (full_std, no expln, no squashing, learn_features=False) built on torch.distributions."""
+    from torch.distributions import Normal
+    torch.manual_seed(3)
+    pol = ActorCriticPolicy(86, 39, (32, 24), (16,), lstm_hidden_size=None, use_sde=True, log_std_init=-1.0)
+    assert tuple(pol.log_std.shape) == (24, 39)
+    with torch.no_grad():
+        pol.log_std.add_(0.3 * torch.randn_like(pol.log_std))
+    N = 7
+    obs = torch.randn(N, 86)
+    g = torch.Generator(); g.manual_seed(11)
+    pol.reset_noise(N, g)
+    W = pol.exploration_mat.clone()
+    # the SB3 statement
+    latent = pol.mlp_extractor.policy_net(obs)
+    mean = pol.action_net(latent)
+    std = torch.exp(pol.log_std)
+    g2 = torch.Generator(); g2.manual_seed(11)
+    W_ref = torch.randn((N, 24, 39), generator=g2) * std                       # Normal(0, std).rsample((n_envs,))
+    dist_ = Normal(mean, torch.sqrt((latent.detach() ** 2) @ (std ** 2) + 1e-6))
+    noise = torch.bmm(latent.detach().unsqueeze(1), W_ref).squeeze(1)
+    a_ref = mean + noise
+    a, v, lp, _ = pol.act(obs)
+    assert torch.allclose(W, W_ref) and torch.allclose(a, a_ref, atol=1e-6)
+    assert torch.allclose(lp, dist_.log_prob(a_ref).sum(-1), atol=1e-5)
+    # the matrices persist until the next reset_noise: same state -> same action (state-DEPENDENT, not white, noise)
+    assert torch.equal(pol.act(obs)[0], a)
+    pol.reset_noise(N, g)
+    assert not torch.equal(pol.act(obs)[0], a)
+    # evaluate_actions: log-prob, per-sample entropy, and no gradient into the trunk through the exploration features
+    vals, lp2, ent = pol.evaluate_actions(obs, a_ref.detach())
+    assert torch.allclose(lp2, dist_.log_prob(a_ref.detach()).sum(-1), atol=1e-5) and torch.allclose(ent, dist_.entropy().sum(-1), atol=1e-5)
+    ent.sum().backward()
+    assert pol.log_std.grad is not None and all(p.grad is None for p in pol.mlp_extractor.policy_net.parameters())
+    # zip round trip dispatches on the log_std matrix
+    from myochallenge_amd.rl.sb3_zip import policy_from_state_dict
+    again = policy_from_state_dict({k: v.detach().clone() for k, v in pol.state_dict().items()})
+    assert again.use_sde and torch.equal(again.log_std, pol.log_std)
+
+
+def test_gsde_ppo_round_on_cpu(emu_lib):
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    torch.manual_seed(0)
+    env = VecNormalize(make_env("CustomMyoBaodingBallsP1", emu_lib, num_envs=3, seed=2, dtype="f64"))
+    pol = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=None, use_sde=True)
+    algo = PPO(env, pol, PPOConfig(n_steps=4, batch_size=6, n_epochs=2, bf16=False, ent_coef=1e-3))
+    before = [p.detach().clone() for p in pol.parameters()]
+    algo.collect_rollouts(); W1 = pol.exploration_mat.clone()
+    algo.train()
+    algo.collect_rollouts()
+    assert not torch.equal(W1, pol.exploration_mat)                 # resampled at the start of every rollout
+    assert any(not torch.equal(a, b) for a, b in zip(before, pol.parameters())) and all(torch.isfinite(p).all() for p in pol.parameters())
+    env.close()

@@ -150,6 +150,10 @@ class FlatAdam:
     def step_count(self):
         return self._step[1]
 
+    def set_step_count(self, step: float) -> None:
+        """Adam's step counter (bias correction) when the moments are restored from a checkpoint."""
+        self._step.fill_(int(step))
+
     def step(self, grad_scale: float = 1.0):
         f = self.flat
         stream = torch.cuda.current_stream(f["p"].device).cuda_stream

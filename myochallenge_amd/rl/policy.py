@@ -227,17 +227,20 @@ class ActorCriticPolicy(nn.Module):
         self.pi_arch, self.vf_arch = list(pi), list(vf)
         self.lstm_hidden_size, self.enable_critic_lstm = lstm_hidden_size, enable_critic_lstm
         self.recurrent = lstm_hidden_size is not None
-        feat = obs_dim
-        if self.recurrent:
-            self.lstm_actor = nn.LSTM(obs_dim, lstm_hidden_size, num_layers=1)
-            self.lstm_critic = nn.LSTM(obs_dim, lstm_hidden_size, num_layers=1) if enable_critic_lstm else None
-            if not enable_critic_lstm:
-                raise NotImplementedError("shared / linear critic variants are not used by the reference")
-            feat = lstm_hidden_size
+        if self.recurrent and not enable_critic_lstm:
+            raise NotImplementedError("shared / linear critic variants are not used by the reference")
+        feat = lstm_hidden_size if self.recurrent else obs_dim
         self.hidden = lstm_hidden_size
+        # Registration order = stable-baselines3's (ActorCriticPolicy._build, then RecurrentActorCriticPolicy adds its
+        # LSTMs): parameters() yields log_std, mlp_extractor.*, action_net.*, value_net.*, lstm_actor.*, lstm_critic.*,
+        # and policy.optimizer.pth of an SB3 zip indexes its Adam state by that order (state[1] of phase1_final.zip is
+        # action_net.weight (39,128), state[5] lstm_actor.weight_ih_l0 (512,86)).
         self.mlp_extractor = MlpExtractor(feat, list(pi), list(vf), activation_fn)
         self.action_net = nn.Linear(self.mlp_extractor.latent_dim_pi, act_dim)
         self.value_net = nn.Linear(self.mlp_extractor.latent_dim_vf, 1)
+        if self.recurrent:
+            self.lstm_actor = nn.LSTM(obs_dim, lstm_hidden_size, num_layers=1)
+            self.lstm_critic = nn.LSTM(obs_dim, lstm_hidden_size, num_layers=1)
         shape = (self.mlp_extractor.latent_dim_pi, act_dim) if self.use_sde else (act_dim,)
         self.log_std = nn.Parameter(torch.full(shape, float(log_std_init)))
 

@@ -628,6 +628,33 @@ class PPO:
                                                   "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
                                                   "params": list(range(len(params)))}]}
 
+    def load_optimizer_state(self, opt: Optional[dict]) -> bool:
+        """Restore Adam's moments from ``policy.optimizer.pth`` of a stable-baselines3 zip (``RecurrentPPO.load`` does on
+        every curriculum resume, /root/reference/src/train/trainer.py:51-56).  State i belongs to the i-th parameter in
+        stable-baselines3's order, which is this policy's ``parameters()`` order.  Returns False (and changes nothing)
+        when the state is empty or its shapes do not fit."""
+        if not opt or not opt.get("state"):
+            return False
+        params = list(self.policy.parameters())
+        st = opt["state"]
+        if sorted(st) != list(range(len(params))) or any(tuple(st[i]["exp_avg"].shape) != tuple(p.shape) for i, p in enumerate(params)):
+            return False
+        step = float(st[0]["step"]) if "step" in st[0] else 0.0
+        if self._flat_adam is not None:
+            fa, flat = self._flat_adam, self.policy._flat
+            slot = {id(p): sl for p, sl in zip(flat["params"], flat["slots"])}
+            for i, p in enumerate(params):
+                off, k = slot[id(p)]
+                fa.m[off:off + k].copy_(st[i]["exp_avg"].reshape(-1).to(fa.m))
+                fa.v[off:off + k].copy_(st[i]["exp_avg_sq"].reshape(-1).to(fa.v))
+            fa.set_step_count(step)
+        else:
+            dev = self.device
+            for i, p in enumerate(params):
+                self.optimizer.state[p] = {"step": torch.tensor(step, dtype=torch.float32, device=dev if self.device.type == "cuda" else "cpu"),
+                                           "exp_avg": st[i]["exp_avg"].to(p).clone(), "exp_avg_sq": st[i]["exp_avg_sq"].to(p).clone()}
+        return True
+
     def save(self, path: str) -> None:
         """``model.save(path)`` of the reference's callbacks (src/metrics/custom_callbacks.py:59): a
         stable-baselines3-format zip (rl/sb3_zip.save_sb3_zip)."""

@@ -68,11 +68,14 @@ class MyoTrainer:
         env = self.envs
         if self.load_model_path is not None:
             from ..rl.sb3_zip import load_policy
+            from ..rl.sb3_zip import read_zip
             policy, data = load_policy(self.load_model_path)      # RecurrentPPO.load(path, env=..., custom_objects=model_config)
+            opt_state = read_zip(self.load_model_path)[2]
             if (policy.obs_dim, policy.act_dim) != (env.obs_dim, env.act_dim):
                 raise ValueError(f"model expects obs/act {policy.obs_dim}/{policy.act_dim}, env has {env.obs_dim}/{env.act_dim}")
             agent = PPO(env, policy, self._ppo_config(data), seed=int(mc.get("seed") or 0))
             agent.num_timesteps = 0                               # reset_num_timesteps=True
+            agent.load_optimizer_state(opt_state)                 # RecurrentPPO.load restores policy.optimizer.pth on every resume
             return agent
         print("\nNo model path provided. Initializing new model.\n")
         pk = dict(mc.get("policy_kwargs") or {})

@@ -614,3 +614,29 @@ def test_gsde_ppo_round_on_cpu(emu_lib):
     assert not torch.equal(W1, pol.exploration_mat)                 # resampled at the start of every rollout
     assert any(not torch.equal(a, b) for a, b in zip(before, pol.parameters())) and all(torch.isfinite(p).all() for p in pol.parameters())
     env.close()
+
+
+def test_saved_optimizer_state_uses_sb3_parameter_order(golden_dir, tmp_path, emu_lib):
+    """policy.optimizer.pth indexes Adam's state by stable-baselines3's parameter order (log_std, mlp_extractor, action_net,
+    value_net, lstm_actor, lstm_critic).  A zip written here for the LSTM-128 architecture of phase1_final.zip must carry the
+    same shape at every index as the reference's own zip, and loading it back restores the moments."""
+    import os
+    from myochallenge_amd.rl.sb3_zip import load_policy, read_zip
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    ref_path = os.path.join(golden_dir, "phase1_final.zip")
+    _, _, ref_opt = read_zip(ref_path)
+    pol, _ = load_policy(ref_path)
+    assert [tuple(p.shape) for p in pol.parameters()] == [tuple(ref_opt["state"][i]["exp_avg"].shape) for i in sorted(ref_opt["state"])]
+    env = VecNormalize(make_env("CustomMyoBaodingBallsP1", emu_lib, num_envs=2, seed=1, dtype="f64"))
+    algo = PPO(env, pol, PPOConfig(n_steps=3, batch_size=6, n_epochs=1, bf16=False))
+    assert algo.load_optimizer_state(ref_opt)                                   # the reference's Adam state goes in ...
+    algo.collect_rollouts(); algo.train()
+    out = str(tmp_path / "resumed.zip")
+    algo.save(out)
+    _, _, mine = read_zip(out)
+    assert sorted(mine["state"]) == sorted(ref_opt["state"])
+    for i in ref_opt["state"]:
+        assert tuple(mine["state"][i]["exp_avg"].shape) == tuple(ref_opt["state"][i]["exp_avg"].shape), i
+        assert float(mine["state"][i]["step"]) == float(ref_opt["state"][i]["step"]) + 1      # ... and one optimizer step was taken on it
+    assert not algo.load_optimizer_state({"state": {}})
+    env.close()

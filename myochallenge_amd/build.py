@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h"]
+SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h", "myo_mjb.h", "mjb_layout.inc"]
 HEADERS = [os.path.join(ROOT, "include", "myobatch.h"), os.path.join(ROOT, "include", "myo_model_blob.h")]
 
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/myo_model_blob.h"
+#include "myo_mjb.h"
 #include "myo_task.h"
 
 // ------------------------------------------------------------------------------------------ backend
@@ -390,6 +391,24 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   return MYO_OK;
 }
 
+extern "C" int myo_model_load_mjb(const char* path, int integrator, int unsupported_contacts, myo_model** out) {
+  if (!path || !out) return fail(MYO_E_ARG, "myo_model_load_mjb: null argument");
+  FILE* fh = fopen(path, "rb");
+  if (!fh) return fail(MYO_E_ARG, "cannot open %s", path);
+  std::vector<unsigned char> raw;
+  unsigned char buf[1 << 16];
+  size_t k;
+  while ((k = fread(buf, 1, sizeof buf, fh)) > 0) raw.insert(raw.end(), buf, buf + k);
+  fclose(fh);
+  myo_mjb::File f;
+  std::string err;
+  if (!myo_mjb::parse(raw.data(), raw.size(), f, err)) return fail(MYO_E_ARG, "%s: %s", path, err.c_str());
+  std::vector<unsigned char> blob;
+  int unsupported = 0;
+  if (!myo_mjb::to_blob(f, integrator, unsupported_contacts, blob, err, &unsupported))
+    return fail(unsupported ? MYO_E_UNSUPPORTED : MYO_E_ARG, "%s: %s", path, err.c_str());
+  return myo_model_from_blob(blob.data(), blob.size(), out);
+}
 extern "C" void myo_model_destroy(myo_model* m) { delete m; }
 extern "C" int myo_model_size(const myo_model* m, const char* n) {
   if (!m || !n) return -1;

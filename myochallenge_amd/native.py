@@ -64,6 +64,7 @@ class NativeLib:
         L.myo_last_error.restype = C.c_char_p
         L.myo_version.restype = C.c_char_p
         L.myo_model_from_blob.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+        L.myo_model_load_mjb.argtypes = [C.c_char_p, i32, i32, C.POINTER(vp)]
         L.myo_model_destroy.argtypes = [vp]
         L.myo_model_size.argtypes = [vp, C.c_char_p]
         L.myo_batch_create.argtypes = [vp, C.POINTER(TaskCfg), i32, i32, u64, i32, C.POINTER(vp)]
@@ -134,7 +135,7 @@ def load(path: Optional[str] = None) -> NativeLib:
 
 
 EXPORTED_SYMBOLS = [
-    "myo_model_from_blob", "myo_model_destroy", "myo_model_size", "myo_batch_create",
+    "myo_model_from_blob", "myo_model_load_mjb", "myo_model_destroy", "myo_model_size", "myo_batch_create",
     "myo_batch_destroy", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
     "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_physics_step", "myo_batch_get_state",
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_bind_constants", "myo_batch_forward_dump",
@@ -155,6 +156,17 @@ class Model:
         h = C.c_void_p()
         self.lib.check(self.lib.L.myo_model_from_blob(self._buf, len(blob), C.byref(h)))
         self.h = h
+
+    @classmethod
+    def from_mjb(cls, path: str, lib: Optional[NativeLib] = None, integrator: Optional[int] = None, unsupported_contacts: str = "error"):
+        """The C route: libmyobatch reads the .mjb itself (myo_model_load_mjb)."""
+        self = cls.__new__(cls)
+        self.lib, self.compiled, self._buf = lib or load(), None, None
+        h = C.c_void_p()
+        self.lib.check(self.lib.L.myo_model_load_mjb(os.fsencode(path), -1 if integrator is None else int(integrator),
+                                                     {"error": 0, "drop": 1}[unsupported_contacts], C.byref(h)))
+        self.h = h
+        return self
 
     def size(self, name: str) -> int:
         return self.lib.L.myo_model_size(self.h, name.encode())

@@ -396,3 +396,40 @@ def case_p2_ball_physics(lib, mj, dtype, tol, nsteps=25, n=6):
     assert r["err_qpos_rel"].max() <= tol and r["err_obs_abs"].max() <= max(tol, 1e-7), (r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
     nominal = episode_drift(lib, mj, dtype, [(0.2, 0)], 5)      # and the parameters do reach the physics
     return r, nominal
+
+
+def case_step_inner(lib, mj, dtype, tol, nsteps=12):
+    """myo_batch_step_inner (the unwrapped env.step MixtureModelBaodingEnv.reset takes with its base policy,
+    /root/reference/src/envs/baoding.py:700-711): masked envs advance exactly as the oracle's env step does — no TimeLimit,
+    no Monitor accounting, no auto-reset — and the other envs are not touched."""
+    mem = Mem(lib)
+    cm, om, _ = oracle_for(mj)
+    n = 6
+    b = native.Batch(native.Model(cm, lib), make_task_cfg("CustomMyoBaodingBallsP1", cm, max_episode_steps=5), n, 0, 9, dtype)
+    obs = mem.zeros((n, 86), np.float32)
+    b.reset(None, obs)
+    mask = np.array([1, 0, 1, 1, 0, 1], np.uint8)
+    ocfg = make_cfg(task_ids(cm))
+    orc = []
+    for e in range(n):
+        d = OracleData(om)
+        d.reset(); d.qpos[:23] = 0; d.qpos[0] = -1.57
+        orc.append((d, default_state()))
+    qp0 = mem.zeros((n, om.nq)); b.get_state(qp0); qp0 = mem.host(qp0).copy()
+    rng = np.random.RandomState(3)
+    done, qp = mem.zeros(n, np.uint8), mem.zeros((n, om.nq))
+    out = mem.arr(np.full((n, 86), 7.0), np.float32)
+    for t in range(nsteps):                                   # more steps than max_episode_steps: no truncation in here
+        a = np.clip(rng.normal(0, 0.3, (n, 39)), -1, 1).astype(np.float32)
+        b.step_inner(mem.arr(mask, np.uint8), mem.arr(a, np.float32), out, done)
+        b.get_state(qp)
+        h_out, h_done, h_qp = mem.host(out), mem.host(done), mem.host(qp)
+        for e in range(n):
+            if not mask[e]:
+                assert np.array_equal(h_qp[e], qp0[e]) and (h_out[e] == 7.0).all()        # untouched
+                continue
+            d, st = orc[e]
+            o, c = baoding_step(d, ocfg, st, a[e])
+            assert np.abs(h_out[e] - o).max() < max(tol, 2e-7), (t, e, np.abs(h_out[e] - o).max())
+            assert rel_err(h_qp[e], d.qpos) < tol and bool(h_done[e]) == bool(c[6])
+    b.close()

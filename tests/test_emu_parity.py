@@ -77,5 +77,9 @@ def test_episode_trajectory_mixed(emu_lib, models):
     pc.case_episode_trajectory(emu_lib, models["hand"], native.MYO_MIXED, [(0.08, 0), (0.135, 0)], 1e-4)
 
 
+def test_step_inner_against_oracle(emu_lib, models):
+    pc.case_step_inner(emu_lib, models["hand"], native.MYO_F64, 1e-9)
+
+
 def test_p2_ball_physics_against_oracle(emu_lib, models):
     pc.case_p2_ball_physics(emu_lib, models["hand"], native.MYO_F64, 1e-9, nsteps=25)

@@ -83,6 +83,11 @@ def test_p2_ball_physics_against_oracle(hip_lib, models):
     pc.case_p2_ball_physics(hip_lib, models["hand"], native.MYO_MIXED, 1e-4, nsteps=25, n=8)
 
 
+def test_step_inner_against_oracle(hip_lib, models):
+    pc.case_step_inner(hip_lib, models["hand"], native.MYO_F64, 1e-9)
+    pc.case_step_inner(hip_lib, models["hand"], native.MYO_MIXED, 1e-4)
+
+
 def test_device_reset_agrees_with_reference_reset_goldens(hip_lib, models, golden_dir):
     pc.case_reset_goldens(hip_lib, models, golden_dir, native.MYO_F64)
     pc.case_reset_goldens(hip_lib, models, golden_dir, native.MYO_MIXED)

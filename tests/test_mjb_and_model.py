@@ -94,3 +94,48 @@ def test_synthetic_hand_shape(models):
     jn = h.names["jnt"]
     assert jn[0] == "pro_sup" and jn[3].startswith("cmc") and jn[8].endswith("abduction") and jn[12].endswith("abduction")
     assert h.opt["timestep"] == 0.002 and h.opt["integrator"] == 0
+
+
+def test_c_mjb_loader_equals_python_route(emu_lib, golden_dir, tmp_path):
+    """myo_model_load_mjb (csrc/myo_mjb.h) against mjb.load_mjb + model.compile_model + myo_model_from_blob on the three
+    models the reference ships: same sizes, and bit-identical trajectories of the two myo_model objects."""
+    import os
+    import numpy as np
+    import pytest
+    from myochallenge_amd import native
+    from myochallenge_amd.mjb import load_mjb
+    from myochallenge_amd.model import compile_model
+    for name in ("myo_finger_v0.mjb", "motor_finger_v0.mjb", "myo_load.mjb"):
+        path = os.path.join(golden_dir, name)
+        with pytest.raises(native.MyoError, match="no narrow phase") if name != "myo_load.mjb" else _nullcontext():
+            native.Model.from_mjb(path, emu_lib)                                     # cylinder / ellipsoid pairs: refused ...
+        mc = native.Model.from_mjb(path, emu_lib, unsupported_contacts="drop")         # ... unless the caller opts in
+        mp = native.Model(compile_model(load_mjb(path), unsupported_contacts="drop"), emu_lib)
+        for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "ntendon", "nwrap", "npair", "nM", "integrator"):
+            assert mc.size(k) == mp.size(k), (name, k)
+        nq, nv, na, nu = (mc.size(k) for k in ("nq", "nv", "na", "nu"))
+        rng = np.random.RandomState(0)
+        outs = []
+        for m in (mc, mp):
+            b = native.Batch(m, None, 2, 0, 0, native.MYO_F64)
+            r = np.random.RandomState(1)
+            for _ in range(40):
+                b.physics_step(r.uniform(0, 1, (2, nu)), 1)
+            qp, qv = np.zeros((2, nq)), np.zeros((2, nv))
+            b.get_state(qp, qv)
+            outs.append((qp.copy(), qv.copy()))
+            b.close()
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.abs(outs[0][1]).max() > 0
+    rk = native.Model.from_mjb(os.path.join(golden_dir, "myo_load.mjb"), emu_lib, integrator=1)
+    assert rk.size("integrator") == 1
+    bad = tmp_path / "bad.mjb"
+    bad.write_bytes(open(os.path.join(golden_dir, "myo_load.mjb"), "rb").read()[:-8])   # truncated
+    with pytest.raises(native.MyoError):
+        native.Model.from_mjb(str(bad), emu_lib)
+    with pytest.raises(native.MyoError, match="cannot open"):
+        native.Model.from_mjb(str(tmp_path / "missing.mjb"), emu_lib)
+
+
+class _nullcontext:
+    def __enter__(self): return None
+    def __exit__(self, *a): return False

@@ -319,13 +319,14 @@ def main():
             pass
         kname = "k_step<%s>" % ("double" if dtype == "f64" else "float")
         out = {
-            "metric": "env-steps/sec (Baoding, 4096 envs)", "value": main_res["value"], "unit": "env-steps/s", "n_gpus": world,
+            "metric": "env-steps/sec (Baoding, 4096 envs)" if "Baoding" in args.env_name else f"env-steps/sec ({args.env_name}, {args.envs} envs)", "value": main_res["value"], "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"mixed": "mixed: f64 state, kinematic chain, contact distances, tendon lengths; f32 dynamics", "f64": "f64"}[dtype],
             "data": "synthetic (synthetic MyoHand-shaped model, random-init policy)",
-            "config": {"workload": f"Baoding phase-1 config ({args.env_name}), {args.envs} batched envs per GPU, "
-                                   f"PPO {pol_name} bf16, frame_skip 10, {integ_name} integrator"
+            "config": {"workload": f"{'Die-reorient' if 'Reorient' in args.env_name else 'Baoding phase-1' if args.env_name.endswith('P1') else 'Baoding phase-2'} config "
+                                   f"({args.env_name}), {args.envs} batched envs per GPU, "
+                                   f"PPO {pol_name} bf16, frame_skip {5 if 'Reorient' in args.env_name else 10}, {integ_name} integrator"
                                    f"{' (model option)' if args.integrator == 'model' else ''}",
                        "envs_per_gpu": args.envs, "global_envs": args.envs * world, "integrator": integ_name,
                        "ppo": "rollout-only" if args.no_ppo else

@@ -39,11 +39,13 @@ typedef struct myo_batch myo_batch;
  * kinematic chain, contact / joint-limit distances, the tendon-wrap predicates, the Newton cost, the observation —
  * and fp32 for the rest of the dynamics.  MYO_F32 is round 1's name for value 1. */
 enum { MYO_F64 = 0, MYO_MIXED = 1, MYO_F32 = 1 };
-enum { MYO_TASK_NONE = 0, MYO_TASK_BAODING_P1 = 1, MYO_TASK_BAODING_P2 = 2 };
+enum { MYO_TASK_NONE = 0, MYO_TASK_BAODING_P1 = 1, MYO_TASK_BAODING_P2 = 2, MYO_TASK_REORIENT = 3 };
 enum { MYO_WHICH_HOLD = 0, MYO_WHICH_CW = 1, MYO_WHICH_CCW = 2 }; /* MyoSuite Task enum */
 enum { MYO_CHOICE_FIXED = 0, MYO_CHOICE_CW = 1, MYO_CHOICE_CCW = 2, MYO_CHOICE_RANDOM = 3 };
 
-#define MYO_N_RWD 8 /* pos_dist_1,pos_dist_2,act_reg,alive,sparse,solved,done,dense */
+#define MYO_N_RWD 8 /* Baoding: pos_dist_1,pos_dist_2,act_reg,alive,sparse,solved,done,dense; die reorient: pos_dist,rot_dist,... */
+#define MYO_ROT_CHOICE_MAX 4 /* entries of a goal_rot_x/y/z range list */
+#define MYO_OBJG_MAX 20      /* geoms of the per-env object group (the die) */
 
 /* Task configuration = the kwargs of CustomBaodingEnv._setup / CustomBaodingP2Env._setup
  * (/root/reference/src/envs/baoding.py:210-227,300-324) lowered to plain numbers, plus the
@@ -67,7 +69,18 @@ typedef struct myo_task_cfg {
   double noise_palm, noise_fingers, noise_balls;
   double limit_init_angle, beta_init_angle[2], beta_ball_size[2], beta_ball_mass[2];
   double obj_size_range[2], obj_mass_range[2], obj_friction_change[3];
-  double init_qpos0;         /* -1.57 (baoding.py:283,401) */
+  double init_qpos0;         /* -1.57 (baoding.py:283,401); die reorient: -1.5 (reorient.py:121) */
+  /* -- kind MYO_TASK_REORIENT: the kwargs of CustomReorientEnv._setup (/root/reference/src/envs/reorient.py:58-122) and what
+   * _setup reads from the model.  Ids: obj1_sid = site object_o, target1_sid = site target_o, obj1_bid = body Object,
+   * [obj1_gid, obj2_gid) = the die's geoms (body_geomadr .. +body_geomnum); n_hand = nq - 7 (the die's free joint is last).
+   * drop_th, obj_friction_change, enable_rsi, frame_skip, max_episode_steps as above.  The other Baoding fields are unused. */
+  double ro_weights[9];      /* pos_dist, rot_dist, pos_dist_diff, rot_dist_diff, alive, act_reg, sparse, solved, done */
+  double ro_goal_pos[2], ro_goal_rot[2];        /* goal_pos / goal_rot ranges (low, high) */
+  int32_t ro_n_rot_choice[3], ro_pad_;          /* lengths of goal_rot_x / _y / _z (0 = None: goal_rot applies) */
+  double ro_rot_choice[3][MYO_ROT_CHOICE_MAX][2];
+  double ro_obj_size_change, ro_pos_th, ro_rot_th;
+  double ro_goal_init_pos[3], ro_goal_obj_offset[3];   /* site_xpos[target_o] and site_xpos[target_o] - site_xpos[object_o] at setup */
+  double ro_rsi_distance_pos, ro_rsi_distance_rot;
 } myo_task_cfg;
 
 /* -- model ------------------------------------------------------------------------------
@@ -140,16 +153,22 @@ int myo_batch_warmstart(myo_batch* b, double* get_qacc_warmstart, const double* 
  * task_i  dev int32[N,2]  = which_task, counter
  * task_d  dev double[N,9] = start_angle1, start_angle2, x_radius, y_radius, time_period,
  *                           target1_x, target1_y, target2_x, target2_y (palm-frame site xy)
- * ball_d  dev double[N,10]= mass1, mass2, friction1[3], friction2[3], size1, size2 */
+ * ball_d  dev double[N,10]= mass1, mass2, friction1[3], friction2[3], size1, size2
+ * MYO_TASK_REORIENT batches: task_i = 0, episode step counter; task_d = goal_pos[3], goal_quat[4], pos_dist, rot_dist
+ * (the shaping state of reorient.py:207-210); ball_d[8] = the die's size delta, the rest unused. */
 int myo_batch_set_task(myo_batch* b, const int32_t* task_i, const double* task_d,
                        const double* ball_d, void* stream);
 int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ball_d, void* stream);
 
 /* Per-env physical randomisation of an object made of several geoms (the die of CustomReorientEnv.reset,
- * /root/reference/src/envs/reorient.py:136-147): geoms [gid0, gidn) take their friction from ball_d[2..4]
- * (friction1) and a size delta from ball_d[8] (size1): every geom centre of the group moves outward by the
- * delta along each non-zero local coordinate, capsule half-lengths grow by it.  (-1, -1) clears the group. */
+ * /root/reference/src/envs/reorient.py:136-147): each of the geoms [gid0, gidn) (at most MYO_OBJG_MAX) has its own per-env
+ * friction triple (myo_batch_object_friction; the model's values until set) and the group a per-env size delta in
+ * ball_d[8] (size1): every geom centre of the group moves outward by the delta along each non-zero local
+ * coordinate, capsule half-lengths grow by it.  (-1, -1) clears the group.  A MYO_TASK_REORIENT batch owns its
+ * group (the die, from the task cfg) and draws both at every reset; this call is for physics-only batches. */
 int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn);
+/* friction of the object group's geoms: dev double[N, gidn-gid0, 3]; either pointer may be NULL (set, then get) */
+int myo_batch_object_friction(myo_batch* b, const double* set_fric, double* get_fric, void* stream);
 
 /* The model / task parameters of ONE batch per device sit in __constant__ memory; every launching entry point
  * re-uploads them (on its stream) when another batch used the device in between.  A caller that REPLAYS a

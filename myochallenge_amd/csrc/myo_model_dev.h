@@ -20,7 +20,13 @@
 #define MYO_CS_MAX 16     // dofs one contact can move
 #define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows
 #define MYO_NEFC_MAX (MYO_NLIM_MAX + 4 * MYO_NCON_MAX)
-#define MYO_OBS_MAX 96
+#define MYO_OBS_MAX 104
+#ifndef MYO_OBJG_MAX
+#define MYO_OBJG_MAX 20     // geoms of the per-env object group (the die of the reorient task); include/myobatch.h
+#endif
+#ifndef MYO_ROT_CHOICE_MAX
+#define MYO_ROT_CHOICE_MAX 4
+#endif
 
 // X-macro lists: (type, name).  I = int32, U = uint64, R = real (T)
 #define MYO_MODEL_INT_ARRAYS(X)                                                                  \
@@ -93,10 +99,11 @@ struct DevModel {
 // 64 lanes of the env's wavefront read consecutive scalars).
 struct EnvRecordLayout {
   int nq, nv, na;
-  int off_qpos, off_qvel, off_act, off_warm, off_time, off_taskd, off_balld, off_misc;
+  int off_qpos, off_qvel, off_act, off_warm, off_time, off_taskd, off_balld, off_misc, off_objfric;
   int stride;  // doubles per env
 };
-// taskd: start_angle[2], x_radius, y_radius, time_period, target_xy[4]  (9)
+// taskd: start_angle[2], x_radius, y_radius, time_period, target_xy[4]  (9); die reorient: goal_pos[3], goal_quat[4], pos_dist, rot_dist
+// objfric: friction[MYO_OBJG_MAX][3] of the object group's geoms (read only by batches that have a group)
 // balld: mass[2], friction[2][3], size[2]  (10)
 // misc : which_task, counter, elapsed_steps, episode_index, ep_return, ep_len (6, stored as double)
 #define MYO_TASKD_N 9

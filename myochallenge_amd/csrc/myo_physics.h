@@ -58,10 +58,11 @@ __device__ __forceinline__ constexpr int myo_hrow(int i) { const int q = i >> 2;
 #endif
 #define MYO_HIDX(i, j) (myo_hrow(i) + (j)) /* i >= j */
 
+#define MYO_TASK_REORIENT_K 3   // == MYO_TASK_REORIENT of include/myobatch.h (checked in myobatch.hip)
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
   int obj1_sid, obj2_sid, target1_sid, target2_sid, obj1_bid, obj2_bid, obj1_gid, obj2_gid;
-  int objg_gid0, objg_gidn;   // geom group with per-env friction (ball_fric[0..2]) and size delta (ball_size[0]); empty = -1,-1
+  int objg_gid0, objg_gidn;   // geom group with per-env, per-geom friction (objg_fric) and a size delta (ball_size[0]); empty = -1,-1
   int task_choice, enable_rsi, balls_overlap, limit_init_angle_on, beta_init_angle_on,
       beta_ball_size_on, beta_ball_mass_on;
   double drop_th, proximity_th, center_pos[2], weights[7];
@@ -69,6 +70,10 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   double rsi_probability, overlap_probability, noise_palm, noise_fingers, noise_balls;
   double limit_init_angle, beta_init_angle[2], beta_ball_size[2], beta_ball_mass[2];
   double obj_size_range[2], obj_mass_range[2], obj_friction_change[3], init_qpos0;
+  // die reorient (kind 3; include/myobatch.h ro_*)
+  double ro_weights[9], ro_goal_pos[2], ro_goal_rot[2], ro_rot_choice[3][MYO_ROT_CHOICE_MAX][2];
+  double ro_obj_size_change, ro_pos_th, ro_rot_th, ro_goal_init_pos[3], ro_goal_obj_offset[3];
+  int ro_n_rot_choice[3], ro_obj_bid;
   unsigned long long seed;
 };
 
@@ -96,8 +101,14 @@ struct Scratch {
   T ctrl[MYO_NU_MAX], qacc_warm[MYO_NV_MAX];
   T qvelT_[sizeof(T) == sizeof(HP) ? 1 : MYO_NV_MAX];   // qvel as the fp32 stages read it (see S_QVELT)
   // ---- per-env parameters
-  HP ball_size[2], target_xy[4], start_angle[2], x_radius, y_radius, time_period, target_w[6];
+  HP ball_size[2], target_w[6];
+  union {                         // the task's per-env numbers = the record's taskd block, in this order
+    struct { HP start_angle[2], x_radius, y_radius, time_period, target_xy[4]; };    // Baoding
+    struct { HP goal_pos[3], goal_quat[4], pos_dist, rot_dist; };                    // die reorient
+    HP taskd[MYO_TASKD_N];
+  };
   T ball_mass[2], ball_fric[6], ep_ret;
+  T objg_fric[3 * MYO_OBJG_MAX];  // friction of the object group's geoms
   int which_task, counter, elapsed, episode, ep_len;
   // ---- position stage
   // (short-lived arrays alias longer-lived storage, see the S_* accessors below)
@@ -289,22 +300,25 @@ template <typename T> DEV T body_mass_of(const DevModel<T>& M, const TaskDev& K,
 template <typename T> DEV T geom_size0_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
   if (g == K.obj1_gid) return (T)s.ball_size[0];
   if (g == K.obj2_gid) return (T)s.ball_size[1];
+  if (g < K.objg_gidn && g >= K.objg_gidn - 3 && g >= K.objg_gid0) return M.geom_size[3 * g] + (T)s.ball_size[0];
   return M.geom_size[3 * g];
 }
 template <typename T> DEV HP geom_size0_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
   if (g == K.obj1_gid) return s.ball_size[0];
   if (g == K.obj2_gid) return s.ball_size[1];
+  if (g < K.objg_gidn && g >= K.objg_gidn - 3 && g >= K.objg_gid0) return M.h_geom_size[3 * g] + s.ball_size[0];
   return M.h_geom_size[3 * g];
 }
 template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, int k) {
-  if (g >= K.objg_gid0 && g < K.objg_gidn) return s.ball_fric[k];
+  if (g >= K.objg_gid0 && g < K.objg_gidn) return s.objg_fric[3 * (g - K.objg_gid0) + k];
   if (g == K.obj1_gid) return s.ball_fric[k];
   if (g == K.obj2_gid) return s.ball_fric[3 + k];
   return M.geom_friction[3 * g + k];
 }
 
-// geometry of a geom of the per-env object group (the die of the reorient task, reorient.py:136-147): every
-// geom centre moves outward by the env's size delta, capsule half-lengths grow by it
+// geometry of a geom of the per-env object group (the die of the reorient task, reorient.py:136-147): every geom
+// centre moves outward by the env's size delta; size[1] (a capsule's half-length) of every geom grows by it, and so
+// does size[0] of the group's last three geoms (the reference adds the delta to all sizes of those)
 template <typename T> DEV void geom_lpos_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, T* out) {
   out[0] = M.geom_pos[3 * g]; out[1] = M.geom_pos[3 * g + 1]; out[2] = M.geom_pos[3 * g + 2];
   if (g >= K.objg_gid0 && g < K.objg_gidn) {
@@ -321,11 +335,11 @@ template <typename T> DEV void geom_lpos_hp(const DevModel<T>& M, const TaskDev&
 }
 template <typename T> DEV T geom_size1_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
   const T v = M.geom_size[3 * g + 1];
-  return (g >= K.objg_gid0 && g < K.objg_gidn && M.geom_type[g] == 3) ? v + (T)s.ball_size[0] : v;
+  return (g >= K.objg_gid0 && g < K.objg_gidn) ? v + (T)s.ball_size[0] : v;
 }
 template <typename T> DEV HP geom_size1_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
   const HP v = M.h_geom_size[3 * g + 1];
-  return (g >= K.objg_gid0 && g < K.objg_gidn && M.geom_type[g] == 3) ? v + s.ball_size[0] : v;
+  return (g >= K.objg_gid0 && g < K.objg_gidn) ? v + s.ball_size[0] : v;
 }
 // position of a point given in body coordinates, in the fp32 stages' frame (world - O)
 template <typename T> DEV void body_point(const Scratch<T>& s, int b, const T* local, T* out) {
@@ -1595,8 +1609,8 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         T fr[3];
         for (int e = 0; e < 3; ++e) {
           const int grp1 = (g1 >= K.objg_gid0 && g1 < K.objg_gidn), grp2 = (g2 >= K.objg_gid0 && g2 < K.objg_gidn);
-          const T a = (g1 == K.obj1_gid || grp1) ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]);
-          const T b = (g2 == K.obj1_gid || grp2) ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]);
+          const T a = grp1 ? s.objg_fric[3 * (g1 - K.objg_gid0) + e] : (g1 == K.obj1_gid ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]));
+          const T b = grp2 ? s.objg_fric[3 * (g2 - K.objg_gid0) + e] : (g2 == K.obj1_gid ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]));
           fr[e] = (fsel == 0) ? tmax(a, b) : (fsel == 1 ? a : b);
         }
         c.mu[0] = fr[0]; c.mu[1] = fr[0];  // condim 3: both tangential directions use friction[0]

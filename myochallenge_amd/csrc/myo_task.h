@@ -9,6 +9,11 @@
 //   CustomBaodingP2Env.reset                   /root/reference/src/envs/baoding.py:494-647
 //   _add_noise_to_{palm,finger}_positions      /root/reference/src/envs/baoding.py:96-144,469-492
 //   TimeLimit(200) + SubprocVecEnv auto-reset  /root/reference/src/envs/__init__.py:15,61; SURVEY C.6
+// Die reorient (kind MYO_TASK_REORIENT), same structure:
+//   CustomReorientEnv.get_reward_dict          /root/reference/src/envs/reorient.py:12-56
+//   CustomReorientEnv.reset / set_orientation  /root/reference/src/envs/reorient.py:124-205
+//   CustomReorientEnv.step (shaping state)     /root/reference/src/envs/reorient.py:207-212
+//   ReorientEnvV0.get_obs_dict, euler2quat / mat2euler  [MyoSuite 1.2.3, 3P-RECALL]
 // Random numbers: the reference mixes gym's np_random, the global np.random and random.choice
 // (SURVEY §7.4-6); seed-for-seed parity is not meaningful, so the device draws from
 // Philox4x32-10 keyed by (seed, env, episode) in the reference's draw ORDER.
@@ -112,13 +117,96 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
   SYNC();
 }
 
+// ---- die reorient: rotations in the mujoco-py rotations.py convention MyoSuite's quat_math copies [3P-RECALL]
+DEV void ro_euler2quat(const HP* e, HP* q) {
+  const HP ai = e[2] / 2, aj = -e[1] / 2, ak = e[0] / 2;
+  const HP si = sin(ai), sj = sin(aj), sk = sin(ak), ci = cos(ai), cj = cos(aj), ck = cos(ak);
+  const HP cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  q[0] = cj * cc + sj * ss; q[1] = cj * cs - sj * sc; q[2] = -(cj * ss + sj * cc); q[3] = cj * sc - sj * cs;
+}
+DEV void ro_quat2euler(const HP* qin, HP* e) {    // mat2euler(quat2mat(q)), q normalised first
+  const HP n = sqrt(qin[0] * qin[0] + qin[1] * qin[1] + qin[2] * qin[2] + qin[3] * qin[3]);
+  const HP w = qin[0] / n, x = qin[1] / n, y = qin[2] / n, z = qin[3] / n;
+  const HP m00 = 1 - 2 * (y * y + z * z), m01 = 2 * (x * y - w * z), m02 = 2 * (x * z + w * y);
+  const HP m10 = 2 * (x * y + w * z), m11 = 1 - 2 * (x * x + z * z), m12 = 2 * (y * z - w * x);
+  const HP m22 = 1 - 2 * (x * x + y * y);
+  const HP cy = sqrt(m22 * m22 + m12 * m12);
+  const int cond = cy > 8.881784197001252e-16;   // _EPS4 = 4 * float64 eps
+  e[2] = cond ? -atan2(m01, m00) : -atan2(-m10, m11);
+  e[1] = -atan2(-m02, cy);
+  e[0] = cond ? -atan2(m12, m22) : (HP)0;
+}
+
+// observation = hand_qpos, hand_qvel * dt, obj_pos, goal_pos, pos_err, obj_rot, goal_rot, rot_err, act; reward dictionary of
+// reorient.py:12-56 with the shaping terms taken against the distances of the previous step (or of the reset), which
+// are replaced by this step's at the end (reorient.py:178-179,207-210).  comps = pos_dist, rot_dist, act_reg, alive,
+// sparse, solved, done, dense (the two *_diff terms enter dense only).
+template <typename T>
+DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  const int nh = K.n_hand;
+  const HP dt = (HP)K.frame_skip * M.h_timestep;
+  T* o = S_OBS(s);
+  PHASE {
+    const int i = lane;
+    if (i < nh) { o[i] = (T)s.qpos[i]; o[nh + i] = (T)(s.qvel[i] * dt); }
+    if (i < M.na) o[2 * nh + 18 + i] = (T)s.act[i];
+  }
+  SYNC();
+  WAVE_SUM_N(T, asq, M.na, i, ((T)s.act[i] * (T)s.act[i]));
+  PHASE {
+    if (lane == 0) {
+      HP op[3], gp[3], er[3], oe[3], ge[3], t[3];
+      body_point_hp(s, K.ro_obj_bid, M.h_site_pos + 3 * K.obj1_sid, op);
+      {  // the goal body hangs off the world with the episode's pose: site target_o = goal_pos + R(goal_quat) * site_pos
+        const HP* q = s.goal_quat; const HP* l = M.h_site_pos + 3 * K.target1_sid;
+        const HP n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        const HP w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+        t[0] = (1 - 2 * (y * y + z * z)) * l[0] + 2 * (x * y - w * z) * l[1] + 2 * (x * z + w * y) * l[2];
+        t[1] = 2 * (x * y + w * z) * l[0] + (1 - 2 * (x * x + z * z)) * l[1] + 2 * (y * z - w * x) * l[2];
+        t[2] = 2 * (x * z - w * y) * l[0] + 2 * (y * z + w * x) * l[1] + (1 - 2 * (x * x + y * y)) * l[2];
+        for (int k = 0; k < 3; ++k) gp[k] = s.goal_pos[k] + t[k];
+      }
+      ro_quat2euler(s.xquat + 4 * K.ro_obj_bid, oe);
+      ro_quat2euler(s.goal_quat, ge);
+      HP pd = 0, rd = 0;
+      for (int k = 0; k < 3; ++k) {
+        er[k] = gp[k] - op[k] - K.ro_goal_obj_offset[k];
+        const HP re = ge[k] - oe[k];
+        o[2 * nh + k] = (T)op[k]; o[2 * nh + 3 + k] = (T)gp[k]; o[2 * nh + 6 + k] = (T)er[k];
+        o[2 * nh + 9 + k] = (T)oe[k]; o[2 * nh + 12 + k] = (T)ge[k]; o[2 * nh + 15 + k] = (T)re;
+        pd += er[k] * er[k]; rd += re * re;
+      }
+      pd = sqrt(pd); rd = sqrt(rd);
+      const HP am = M.na ? sqrt((HP)asq) / (HP)M.na : (HP)0;
+      const int drop = pd > K.drop_th;
+      HP c[9];
+      c[0] = -pd; c[1] = -rd; c[2] = s.pos_dist - pd; c[3] = s.rot_dist - rd; c[4] = drop ? 0 : 1; c[5] = -am;
+      c[6] = -rd - 10.0 * pd; c[7] = (pd < K.ro_pos_th && rd < K.ro_rot_th && !drop) ? 1 : 0; c[8] = drop ? 1 : 0;
+      HP dense = 0;
+      for (int k = 0; k < 9; ++k) dense += K.ro_weights[k] * c[k];
+      s.rwd[0] = (T)c[0]; s.rwd[1] = (T)c[1]; s.rwd[2] = (T)c[5]; s.rwd[3] = (T)c[4]; s.rwd[4] = (T)c[6];
+      s.rwd[5] = (T)c[7]; s.rwd[6] = (T)c[8]; s.rwd[7] = (T)dense;
+      s.pos_dist = pd; s.rot_dist = rd;
+    }
+  }
+  SYNC();
+}
+
+template <typename T>
+DEV void task_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+  if (K.kind == MYO_TASK_REORIENT_K) reorient_obs_reward(M, K, s); else baoding_obs_reward(M, K, s);
+}
+DEV int task_nobs(const TaskDev& K, int na) { return K.kind == MYO_TASK_REORIENT_K ? 2 * K.n_hand + 18 + na : K.n_hand + 24 + na; }
+
 // ---- env.step(a) without the VecEnv bookkeeping
 template <typename T>
-DEV void baoding_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, const float* action /* may be null = zeros */) {
+DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, const float* action /* may be null = zeros */) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (lane == 0) {
+    if (lane == 0 && K.kind != MYO_TASK_REORIENT_K) {
       if (s.which_task != 0) {
         const double dt = (double)K.frame_skip * M.h_timestep;
         const double sign = s.which_task == 1 ? -1.0 : 1.0;
@@ -146,7 +234,7 @@ DEV void baoding_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
   for (int k = 0; k < K.frame_skip; ++k) mj_step(M, K, s);
   check_state(M, s, 0);            // a non-finite value produced by the LAST advance must not leave through obs / reward
   kinematics(M, s);
-  baoding_obs_reward(M, K, s);
+  task_obs_reward(M, K, s);
 }
 
 template <typename T>
@@ -243,7 +331,7 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
   set_init_state(M, K, s, 0);
   if (do_rsi) {
     // self.step(np.zeros(39)); balls teleported onto the targets (xy), hand back to init pose
-    baoding_step_core(M, K, s, (const float*)0);
+    task_step_core(M, K, s, (const float*)0);
     HP bx[4];
     const int nh = K.n_hand;
     bx[0] = s.target_w[0]; bx[1] = s.target_w[1]; bx[2] = s.target_w[3]; bx[3] = s.target_w[4];
@@ -305,12 +393,66 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
   baoding_obs_reward(M, K, s);
 }
 
+// ---- die reorient reset (reorient.py:124-181).  Draw order of the reference: goal position (3), the optional range choice per
+// axis, the three Euler angles, the friction triple of every die geom, the size delta.  `enable_rsi` (:150-176) rewrites
+// body_pos / body_quat of the Object body; that body carries the free joint, whose pose comes from qpos (robot.reset(init_qpos))
+// and never from body_pos, so the reference's RSI branch leaves the state exactly as the plain reset does — and so does this.
+template <typename T>
+DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int env) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  Philox g;
+  g.key0 = (unsigned int)K.seed; g.key1 = (unsigned int)(K.seed >> 32);
+  g.c0 = (unsigned int)env; g.c1 = (unsigned int)s.episode; g.c2 = 0x44494531u; g.idx = 0;
+  HP gp[3], e[3], q[4], lo[3], hi[3];
+  for (int k = 0; k < 3; ++k) gp[k] = K.ro_goal_init_pos[k] + rng_range(g, K.ro_goal_pos[0], K.ro_goal_pos[1]);
+  for (int ax = 0; ax < 3; ++ax) {
+    lo[ax] = K.ro_goal_rot[0]; hi[ax] = K.ro_goal_rot[1];
+    const int n = K.ro_n_rot_choice[ax];
+    if (n > 0) {
+      int c = (int)(philox_uniform(g) * (double)n);
+      c = c >= n ? n - 1 : c;
+      lo[ax] = K.ro_rot_choice[ax][c][0]; hi[ax] = K.ro_rot_choice[ax][c][1];
+    }
+  }
+  for (int ax = 0; ax < 3; ++ax) e[ax] = rng_range(g, lo[ax], hi[ax]);
+  ro_euler2quat(e, q);
+  const int nf = 3 * (K.objg_gidn - K.objg_gid0);
+  const unsigned int base = g.idx;
+  g.idx = base + (unsigned int)nf;
+  const HP del = rng_range(g, -K.ro_obj_size_change, K.ro_obj_size_change);
+  PHASE {
+    if (lane < nf) {    // one draw per (geom, coefficient): counter-based generator, lane j takes draw base + j
+      Philox h = g;
+      h.idx = base + (unsigned int)lane;
+      const double nominal = (double)M.geom_friction[3 * K.objg_gid0 + lane], ch = K.obj_friction_change[lane % 3];
+      s.objg_fric[lane] = (T)rng_range(h, nominal - ch, nominal + ch);
+    }
+    if (lane == 0) {
+      s.which_task = 0; s.counter = 0; s.elapsed = 0; s.ep_ret = 0; s.ep_len = 0;
+      for (int k = 0; k < 3; ++k) s.goal_pos[k] = gp[k];
+      for (int k = 0; k < 4; ++k) s.goal_quat[k] = q[k];
+      s.ball_size[0] = del;
+    }
+  }
+  SYNC();
+  set_init_state(M, K, s, 0);
+  kinematics(M, s);
+  reorient_obs_reward(M, K, s);      // leaves pos_dist / rot_dist of the reset state (reorient.py:178-179)
+}
+
+template <typename T>
+DEV void task_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int env) {
+  if (K.kind == MYO_TASK_REORIENT_K) reorient_reset(M, K, s, env); else baoding_reset(M, K, s, env);
+}
+
 // ---- HBM record <-> scratch
 template <typename T>
-DEVFN void load_env(const DevModel<T>& M_in, const EnvRecordLayout L, const double* rec, Scratch<T>& s_in) {
-  MYO_BIND_M(T) MYO_BIND_S(T)
+DEVFN void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, const double* rec, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
+    if (K.objg_gidn > 0) for (int i = lane; i < 3 * (K.objg_gidn - K.objg_gid0); i += 64) s.objg_fric[i] = (T)rec[L.off_objfric + i];
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
     for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i];
@@ -318,9 +460,7 @@ DEVFN void load_env(const DevModel<T>& M_in, const EnvRecordLayout L, const doub
     if (lane == 0) {
       s.time = rec[L.off_time];
       const double* td = rec + L.off_taskd;
-      s.start_angle[0] = td[0]; s.start_angle[1] = td[1]; s.x_radius = td[2]; s.y_radius = td[3];
-      s.time_period = td[4];
-      for (int k = 0; k < 4; ++k) s.target_xy[k] = td[5 + k];
+      for (int k = 0; k < MYO_TASKD_N; ++k) s.taskd[k] = td[k];
       const double* bd = rec + L.off_balld;
       s.ball_mass[0] = (T)bd[0]; s.ball_mass[1] = (T)bd[1];
       for (int k = 0; k < 6; ++k) s.ball_fric[k] = (T)bd[2 + k];
@@ -335,19 +475,18 @@ DEVFN void load_env(const DevModel<T>& M_in, const EnvRecordLayout L, const doub
 }
 
 template <typename T>
-DEVFN void store_env(const DevModel<T>& M_in, const EnvRecordLayout L, double* rec, const Scratch<T>& s_in) {
-  MYO_BIND_M(T) MYO_BIND_S(T)
+DEVFN void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
+    if (K.kind == MYO_TASK_REORIENT_K) for (int i = lane; i < 3 * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + i] = (double)s.objg_fric[i];
     for (int i = lane; i < M.nq; i += 64) rec[L.off_qpos + i] = (double)s.qpos[i];
     for (int i = lane; i < M.nv; i += 64) { rec[L.off_qvel + i] = (double)s.qvel[i]; rec[L.off_warm + i] = (double)s.qacc_warm[i]; }
     for (int i = lane; i < M.na; i += 64) rec[L.off_act + i] = (double)s.act[i];
     if (lane == 0) {
       rec[L.off_time] = (double)s.time;
       double* td = rec + L.off_taskd;
-      td[0] = (double)s.start_angle[0]; td[1] = (double)s.start_angle[1]; td[2] = (double)s.x_radius;
-      td[3] = (double)s.y_radius; td[4] = (double)s.time_period;
-      for (int k = 0; k < 4; ++k) td[5 + k] = (double)s.target_xy[k];
+      for (int k = 0; k < MYO_TASKD_N; ++k) td[k] = (double)s.taskd[k];
       double* bd = rec + L.off_balld;
       bd[0] = (double)s.ball_mass[0]; bd[1] = (double)s.ball_mass[1];
       for (int k = 0; k < 6; ++k) bd[2 + k] = (double)s.ball_fric[k];
@@ -366,9 +505,9 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                   float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
   WAVE_FN
-  const int nobs = K.n_hand + 24 + M.na;
-  load_env(M, L, rec, s);
-  baoding_step_core(M, K, s, act + (size_t)env * M.nu);
+  const int nobs = task_nobs(K, M.na);
+  load_env(M, K, L, rec, s);
+  task_step_core(M, K, s, act + (size_t)env * M.nu);
   // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
   // an error of the batch: the env ends its episode with done = 1, reward 0, zero reward components except `done`,
   // is reset at once, and both the terminal and the returned observation are the (finite) reset observation, so that
@@ -396,7 +535,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
   if (is_done) {
     PHASE { if (lane == 0) s.episode++; }
     SYNC();
-    baoding_reset(M, K, s, env);
+    task_reset(M, K, s, env);
   }
   PHASE {
     for (int i = lane; i < nobs; i += 64) {
@@ -405,7 +544,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
     }
   }
   SYNC();
-  store_env(M, L, rec, s);
+  store_env(M, K, L, rec, s);
 }
 
 // env.step(a) of the UNWRAPPED gym env for the envs selected by mask: no TimeLimit / Monitor accounting and
@@ -416,21 +555,21 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
                         int env, const unsigned char* mask, const float* act, float* obs, unsigned char* done_out) {
   WAVE_FN
   if (mask && !mask[env]) return;
-  const int nobs = K.n_hand + 24 + M.na;
-  load_env(M, L, rec, s);
-  baoding_step_core(M, K, s, act + (size_t)env * M.nu);
+  const int nobs = task_nobs(K, M.na);
+  load_env(M, K, L, rec, s);
+  task_step_core(M, K, s, act + (size_t)env * M.nu);
   const int bad = s.bad, fall = s.rwd[6] != 0 || bad;
   if (bad) {                        // blown-up env: back to a finite reset state (see env_step)
     PHASE { if (lane == 0) s.episode++; }
     SYNC();
-    baoding_reset(M, K, s, env);
+    task_reset(M, K, s, env);
   }
   PHASE {
     if (lane == 0 && done_out) done_out[env] = (unsigned char)fall;
     for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
   }
   SYNC();
-  store_env(M, L, rec, s);
+  store_env(M, K, L, rec, s);
 }
 
 template <typename T>
@@ -438,24 +577,24 @@ DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout
                    int env, const unsigned char* mask, float* obs) {
   WAVE_FN
   if (mask && !mask[env]) return;
-  const int nobs = K.n_hand + 24 + M.na;
-  load_env(M, L, rec, s);
+  const int nobs = task_nobs(K, M.na);
+  load_env(M, K, L, rec, s);
   PHASE { if (lane == 0) s.episode++; }
   SYNC();
-  baoding_reset(M, K, s, env);
+  task_reset(M, K, s, env);
   if (obs) { PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i]; } SYNC(); }
-  store_env(M, L, rec, s);
+  store_env(M, K, L, rec, s);
 }
 
 template <typename T>
 DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
                      int env, const double* ctrl, int nsub) {
   WAVE_FN
-  load_env(M, L, rec, s);
+  load_env(M, K, L, rec, s);
   PHASE { for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0; }
   SYNC();
   for (int k = 0; k < nsub; ++k) mj_step(M, K, s);
-  store_env(M, L, rec, s);
+  store_env(M, K, L, rec, s);
 }
 
 // forward dynamics with intermediates exported (stage-wise parity tests)
@@ -468,7 +607,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
                           int env, const double* ctrl, const DumpLayout& D, double* out_all) {
   WAVE_FN
   double* out = out_all + (size_t)env * D.total;
-  load_env(M, L, rec, s);
+  load_env(M, K, L, rec, s);
   PHASE { for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0; }
   SYNC();
   const int nv = M.nv;

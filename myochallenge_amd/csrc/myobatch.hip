@@ -428,6 +428,7 @@ struct myo_batch {
   DumpLayout D;
   double* rec;                 // dev [n, L.stride]
   std::vector<void*> allocs;   // every device allocation (model arrays, records)
+  std::vector<double> geom_friction;   // host copy of the model's (nominal values of an object group)
   DevModel<double> Md;
   DevModel<float> Mf;
   int nq, nv, nu, na, nbody, nsite, ntendon, ngeom, integrator;
@@ -565,6 +566,20 @@ static void make_taskdev(const myo_task_cfg* c, uint64_t seed, TaskDev& K) {
   memcpy(K.beta_ball_mass, c->beta_ball_mass, 16); memcpy(K.obj_size_range, c->obj_size_range, 16);
   memcpy(K.obj_mass_range, c->obj_mass_range, 16); memcpy(K.obj_friction_change, c->obj_friction_change, 24);
   K.init_qpos0 = c->init_qpos0;
+  if (c->kind == MYO_TASK_REORIENT) {
+    // the Baoding per-ball overrides (mass / size / friction by body and geom id) must not fire: the die is the object GROUP
+    K.ro_obj_bid = c->obj1_bid; K.objg_gid0 = c->obj1_gid; K.objg_gidn = c->obj2_gid;
+    K.obj1_bid = K.obj2_bid = K.obj1_gid = K.obj2_gid = -1;
+    memcpy(K.ro_weights, c->ro_weights, sizeof K.ro_weights); memcpy(K.ro_goal_pos, c->ro_goal_pos, 16);
+    memcpy(K.ro_goal_rot, c->ro_goal_rot, 16); memcpy(K.ro_rot_choice, c->ro_rot_choice, sizeof K.ro_rot_choice);
+    for (int k = 0; k < 3; ++k) K.ro_n_rot_choice[k] = c->ro_n_rot_choice[k];
+    K.ro_obj_size_change = c->ro_obj_size_change; K.ro_pos_th = c->ro_pos_th; K.ro_rot_th = c->ro_rot_th;
+    memcpy(K.ro_goal_init_pos, c->ro_goal_init_pos, 24); memcpy(K.ro_goal_obj_offset, c->ro_goal_obj_offset, 24);
+  }
+}
+static_assert(MYO_TASK_REORIENT == MYO_TASK_REORIENT_K, "task kind ids");
+static int task_nobs_host(const myo_task_cfg* c, int na) {
+  return c->kind == MYO_TASK_REORIENT ? 2 * c->n_hand + 18 + na : c->n_hand + 24 + na;
 }
 
 extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int n_envs, int device, uint64_t seed,
@@ -572,7 +587,18 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   if (!m || !out || n_envs <= 0) return fail(MYO_E_ARG, "bad arguments to myo_batch_create");
   if (dtype != MYO_F64 && dtype != MYO_F32) return fail(MYO_E_ARG, "dtype must be MYO_F64 or MYO_F32");
   if (cfg && cfg->kind != MYO_TASK_NONE) {
-    if (cfg->kind != MYO_TASK_BAODING_P1 && cfg->kind != MYO_TASK_BAODING_P2) return fail(MYO_E_ARG, "unknown task kind");
+    if (cfg->kind != MYO_TASK_BAODING_P1 && cfg->kind != MYO_TASK_BAODING_P2 && cfg->kind != MYO_TASK_REORIENT)
+      return fail(MYO_E_ARG, "unknown task kind");
+    if (cfg->kind == MYO_TASK_REORIENT) {
+      if (cfg->obj1_sid < 0 || cfg->obj1_sid >= m->nsite || cfg->target1_sid < 0 || cfg->target1_sid >= m->nsite ||
+          cfg->obj1_bid <= 0 || cfg->obj1_bid >= m->nbody || cfg->obj1_gid < 0 || cfg->obj2_gid <= cfg->obj1_gid || cfg->obj2_gid > m->ngeom)
+        return fail(MYO_E_ARG, "task ids out of range");
+      if (cfg->obj2_gid - cfg->obj1_gid > MYO_OBJG_MAX) return fail(MYO_E_UNSUPPORTED, "the die has more than %d geoms", MYO_OBJG_MAX);
+      if (cfg->n_hand + 7 != m->nq || m->nv < 6 || task_nobs_host(cfg, m->na) > MYO_OBS_MAX)
+        return fail(MYO_E_UNSUPPORTED, "reorient task needs nq = n_hand + 7 (the die's free joint last) and an observation of <= %d numbers", MYO_OBS_MAX);
+      for (int k = 0; k < 3; ++k)
+        if (cfg->ro_n_rot_choice[k] < 0 || cfg->ro_n_rot_choice[k] > MYO_ROT_CHOICE_MAX) return fail(MYO_E_ARG, "goal_rot_x/y/z: at most %d ranges", MYO_ROT_CHOICE_MAX);
+    } else {
     if (cfg->obj1_sid < 0 || cfg->obj1_sid >= m->nsite || cfg->obj2_sid < 0 || cfg->obj2_sid >= m->nsite ||
         cfg->target1_sid < 0 || cfg->target1_sid >= m->nsite || cfg->target2_sid < 0 || cfg->target2_sid >= m->nsite ||
         cfg->obj1_bid <= 0 || cfg->obj1_bid >= m->nbody || cfg->obj2_bid <= 0 || cfg->obj2_bid >= m->nbody ||
@@ -580,6 +606,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
       return fail(MYO_E_ARG, "task ids out of range");
     if (cfg->n_hand + 14 != m->nq || m->nv < 12 || cfg->n_hand + 24 + m->na > MYO_OBS_MAX)
       return fail(MYO_E_UNSUPPORTED, "Baoding task needs nq = n_hand + 14 (two free balls last)");
+    }
     if (cfg->frame_skip <= 0 || cfg->max_episode_steps <= 0) return fail(MYO_E_ARG, "frame_skip / max_episode_steps");
   }
   int rc = be_set_device(device);
@@ -587,10 +614,11 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   myo_batch* b = new myo_batch();
   b->n = n_envs; b->device = device; b->dtype = dtype; b->bad_state = nullptr; b->timing = 0; b->ms_sum = 0; b->ms_cnt = 0;
   b->integrator = m->integrator;
+  b->geom_friction = m->geom_friction;
   b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon; b->ngeom = m->ngeom;
   if (cfg) b->cfg = *cfg; else memset(&b->cfg, 0, sizeof b->cfg);
   make_taskdev(cfg && cfg->kind != MYO_TASK_NONE ? cfg : nullptr, seed, b->K);
-  b->nobs = b->K.kind ? b->K.n_hand + 24 + m->na : 0;
+  b->nobs = b->K.kind ? task_nobs_host(cfg, m->na) : 0;
   memset(&b->Md, 0, sizeof b->Md); memset(&b->Mf, 0, sizeof b->Mf);
   rc = (dtype == MYO_F64) ? upload_model<double>(m, b->Md, b->allocs) : upload_model<float>(m, b->Mf, b->allocs);
   EnvRecordLayout& L = b->L;
@@ -598,6 +626,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   int o = 0;
   L.off_qpos = o; o += m->nq; L.off_qvel = o; o += m->nv; L.off_act = o; o += m->na; L.off_warm = o; o += m->nv;
   L.off_time = o; o += 1; L.off_taskd = o; o += MYO_TASKD_N; L.off_balld = o; o += MYO_BALLD_N; L.off_misc = o; o += MYO_MISC_N;
+  L.off_objfric = o; o += 3 * MYO_OBJG_MAX;
   L.stride = (o + 7) / 8 * 8;
   DumpLayout& D = b->D;
   o = 0;
@@ -615,7 +644,13 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
     double* td = r + L.off_taskd; double* bd = r + L.off_balld; double* mi = r + L.off_misc;
     td[0] = 3.0 * MYO_PI / 4.0; td[1] = -MYO_PI / 4.0; td[2] = 0.025; td[3] = 0.028; td[4] = 5.0;
     mi[0] = MYO_WHICH_CCW;
-    if (b->K.kind) {
+    if (b->K.kind == MYO_TASK_REORIENT) {
+      // goal at its setup pose, identity orientation, nominal die; reset() draws the episode's values
+      memset(td, 0, sizeof(double) * MYO_TASKD_N); mi[0] = 0;
+      for (int k = 0; k < 3; ++k) td[k] = b->K.ro_goal_init_pos[k];
+      td[3] = 1.0;
+      for (int j = 0; j < 3 * (b->K.objg_gidn - b->K.objg_gid0); ++j) r[L.off_objfric + j] = m->geom_friction[3 * b->K.objg_gid0 + j];
+    } else if (b->K.kind) {
       td[2] = 0.5 * (b->K.goal_xrange[0] + b->K.goal_xrange[1]); td[3] = 0.5 * (b->K.goal_yrange[0] + b->K.goal_yrange[1]);
       td[4] = 0.5 * (b->K.goal_time_period[0] + b->K.goal_time_period[1]);
       if (b->K.kind == MYO_TASK_BAODING_P2 && !(b->K.overlap_probability >= 1.0)) { td[0] = MYO_PI / 4.0; td[1] = MYO_PI / 4.0 - MYO_PI; }
@@ -871,9 +906,36 @@ extern "C" int myo_batch_set_task(myo_batch* b, const int32_t* task_i, const dou
 extern "C" int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   if (!(gid0 == -1 && gidn == -1) && (gid0 < 0 || gidn <= gid0 || gidn > b->ngeom)) return fail(MYO_E_ARG, "bad geom range");
+  if (b->K.kind == MYO_TASK_REORIENT) return fail(MYO_E_STATE, "the reorient task owns the object group");
+  if (gidn - gid0 > MYO_OBJG_MAX) return fail(MYO_E_UNSUPPORTED, "an object group holds at most %d geoms", MYO_OBJG_MAX);
   b->K.objg_gid0 = gid0; b->K.objg_gidn = gidn;
+  if (gidn > 0) {   // every env starts from the model's friction of the group's geoms
+    const int cnt = 3 * (gidn - gid0);
+    std::vector<double> host((size_t)b->n * cnt);
+    for (int e = 0; e < b->n; ++e) for (int j = 0; j < cnt; ++j) host[(size_t)e * cnt + j] = b->geom_friction[3 * gid0 + j];
+    void* tmp = nullptr;
+    int rc = be_malloc(&tmp, host.size() * sizeof(double));
+    if (!rc) rc = be_h2d(tmp, host.data(), host.size() * sizeof(double));
+    if (rc) { if (tmp) be_free(tmp); return fail(MYO_E_DEVICE, "object group upload failed: %s", be_errstr(rc)); }
+    xfer(b, b->L.off_objfric, cnt, (double*)tmp, 0, (be_stream)0);
+#ifndef MYO_EMU
+    (void)hipStreamSynchronize((hipStream_t)0);
+#endif
+    be_free(tmp);
+  }
 #ifndef MYO_EMU
   unbind(b, b->device);              // the task block in __constant__ memory is re-uploaded at the next launch
+#endif
+  return MYO_OK;
+}
+extern "C" int myo_batch_object_friction(myo_batch* b, const double* set_fric, double* get_fric, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+  if (b->K.objg_gidn <= 0) return fail(MYO_E_STATE, "batch has no object group");
+  be_stream st = (be_stream)stream;
+  const int cnt = 3 * (b->K.objg_gidn - b->K.objg_gid0);
+  xfer(b, b->L.off_objfric, cnt, (double*)set_fric, 0, st); xfer(b, b->L.off_objfric, cnt, get_fric, 1, st);
+#ifndef MYO_EMU
+  LAUNCH_CHECK(b)
 #endif
   return MYO_OK;
 }

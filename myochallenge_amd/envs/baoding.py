@@ -52,13 +52,12 @@ class BaodingVecEnv:
         config = dict(config or {})
         self.env_name = env_name
         self.config = config
-        self.params = resolve_kwargs(env_name, **config)
+        self.params = self._resolve(env_name, config)
         if model is None:
-            from ..synth_hand import synthetic_hand
-            model = synthetic_hand()
+            model = self._default_model()
         if not isinstance(model, CompiledModel):
             integ = None if integrator is None else {"euler": 0, "rk4": 1}[integrator.lower()]
-            model = compile_model(model, integrator=integ)
+            model = self._compile(model, integ)
         self.compiled = model
         self.lib = lib or native.load()
         self.torch = torch
@@ -69,7 +68,7 @@ class BaodingVecEnv:
                 raise native.MyoError("BaodingVecEnv needs a GPU: libmyobatch has no CPU execution path")
             self.device = torch.device(f"cuda:{device}")
         self._model = native.Model(model, self.lib)
-        self._cfg = make_task_cfg(env_name, model, **config)
+        self._cfg = self._make_cfg(env_name, model, config)
         self.max_episode_steps = int(self._cfg.max_episode_steps)
         self.dtype = {"mixed": native.MYO_MIXED, "f32": native.MYO_MIXED, "f64": native.MYO_F64}[dtype]      # "f32": round 1's name of the mixed stepper
         self.batch = native.Batch(self._model, self._cfg, num_envs, device, seed, self.dtype)
@@ -88,6 +87,26 @@ class BaodingVecEnv:
         self._ep = torch.zeros((n, 2), dtype=torch.float32, device=d)
         self._pending = None
         self._closed = False
+
+    # ---------------------------------------------------------------- what a task supplies (ReorientVecEnv overrides these)
+    rwd_keys = native.RWD_KEYS
+
+    @staticmethod
+    def _resolve(env_name, config):
+        return resolve_kwargs(env_name, **config)
+
+    @staticmethod
+    def _default_model():
+        from ..synth_hand import synthetic_hand
+        return synthetic_hand()
+
+    @staticmethod
+    def _compile(model, integ):
+        return compile_model(model, integrator=integ)
+
+    @staticmethod
+    def _make_cfg(env_name, compiled, config):
+        return make_task_cfg(env_name, compiled, **config)
 
     # ---------------------------------------------------------------- tensor-native fast path
     def _stream(self):
@@ -129,7 +148,7 @@ class BaodingVecEnv:
         if done_h.any():
             term_h, ep_h = term.cpu().numpy(), ep.cpu().numpy()
         for i in range(self.num_envs):
-            rwd = {k: float(comps_h[i, j]) for j, k in enumerate(native.RWD_KEYS)}
+            rwd = {k: float(comps_h[i, j]) for j, k in enumerate(self.rwd_keys)}
             info = {"rwd_dense": rwd["dense"], "rwd_sparse": rwd["sparse"], "solved": bool(rwd["solved"]),
                     "done": bool(rwd["done"]), "rwd_dict": rwd}
             if done_h[i]:

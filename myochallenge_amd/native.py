@@ -18,10 +18,13 @@ LIB_PATH = os.path.join(_HERE, "libmyobatch.so")
 
 MYO_F64, MYO_MIXED = 0, 1     # stepper arithmetic: all fp64 | mixed (fp64 state, kinematic chain, contact distances; fp32 dynamics)
 MYO_F32 = MYO_MIXED             # the name of round 1, when dtype 1 was a pure fp32 stepper
-TASK_NONE, TASK_BAODING_P1, TASK_BAODING_P2 = 0, 1, 2
+TASK_NONE, TASK_BAODING_P1, TASK_BAODING_P2, TASK_REORIENT = 0, 1, 2, 3
 CHOICE_FIXED, CHOICE_CW, CHOICE_CCW, CHOICE_RANDOM = 0, 1, 2, 3
 N_RWD = 8
 RWD_KEYS = ("pos_dist_1", "pos_dist_2", "act_reg", "alive", "sparse", "solved", "done", "dense")
+
+
+ROT_CHOICE_MAX, OBJG_MAX = 4, 20      # include/myobatch.h
 
 
 class TaskCfg(C.Structure):
@@ -44,6 +47,13 @@ class TaskCfg(C.Structure):
         ("beta_ball_size", C.c_double * 2), ("beta_ball_mass", C.c_double * 2),
         ("obj_size_range", C.c_double * 2), ("obj_mass_range", C.c_double * 2),
         ("obj_friction_change", C.c_double * 3), ("init_qpos0", C.c_double),
+        # die reorient (kind TASK_REORIENT)
+        ("ro_weights", C.c_double * 9), ("ro_goal_pos", C.c_double * 2), ("ro_goal_rot", C.c_double * 2),
+        ("ro_n_rot_choice", C.c_int32 * 3), ("ro_pad_", C.c_int32),
+        ("ro_rot_choice", C.c_double * 2 * ROT_CHOICE_MAX * 3),
+        ("ro_obj_size_change", C.c_double), ("ro_pos_th", C.c_double), ("ro_rot_th", C.c_double),
+        ("ro_goal_init_pos", C.c_double * 3), ("ro_goal_obj_offset", C.c_double * 3),
+        ("ro_rsi_distance_pos", C.c_double), ("ro_rsi_distance_rot", C.c_double),
     ]
 
 
@@ -84,6 +94,7 @@ class NativeLib:
         L.myo_batch_get_task.argtypes = [vp] * 5
         L.myo_batch_bind_constants.argtypes = [vp, vp]
         L.myo_batch_set_object_group.argtypes = [vp, i32, i32]
+        L.myo_batch_object_friction.argtypes = [vp, vp, vp, vp]
         L.myo_batch_forward_dump.argtypes = [vp, vp, vp, vp]
         L.myo_batch_dump_size.argtypes = [vp]
         L.myo_batch_dump_offset.argtypes = [vp, C.c_char_p]
@@ -138,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_load_mjb", "myo_model_destroy", "myo_model_size", "myo_batch_create",
     "myo_batch_destroy", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
     "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_physics_step", "myo_batch_get_state",
-    "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_bind_constants", "myo_batch_forward_dump",
+    "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
     "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
@@ -237,6 +248,10 @@ class Batch:
 
     def set_object_group(self, gid0: int, gidn: int):
         self.lib.check(self.lib.L.myo_batch_set_object_group(self.h, gid0, gidn))
+
+    def object_friction(self, set_fric=None, get_fric=None, stream=None):
+        """friction triples of the object group's geoms, float64 [N, ngeom_group, 3] (set, then get; either may be None)"""
+        self.lib.check(self.lib.L.myo_batch_object_friction(self.h, _ptr(set_fric), _ptr(get_fric), stream))
 
     def bind_constants(self, stream=None):
         """Make this batch the one whose model / task sit in __constant__ memory (needed before replaying a

@@ -60,7 +60,7 @@ struct OrcData {
   /* state */
   double *qpos, *qvel, *act, *ctrl, *qacc_warmstart;
   /* per-env model overrides (P2 randomisation, reference baoding.py:559-604) */
-  double *body_mass, *geom_friction, *geom_size, *site_pos;
+  double *body_mass, *geom_friction, *geom_size, *geom_pos, *site_pos;
   /* position stage */
   double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *geom_xpos, *geom_xmat,
       *site_xpos, *subtree_com, *cinert, *cdof, *crb, *ten_length, *ten_J, *actuator_length,
@@ -243,7 +243,7 @@ OrcData* orc_data_new(const OrcModel* m) {
   int nv=m->nv, nb=m->nbody;
 #define A(name, n) d->name = falloc(d, #name, (n))
   A(qpos, m->nq); A(qvel, nv); A(act, m->na); A(ctrl, m->nu); A(qacc_warmstart, nv);
-  A(body_mass, nb); A(geom_friction, 3*m->ngeom); A(geom_size, 3*m->ngeom); A(site_pos, 3*m->nsite);
+  A(body_mass, nb); A(geom_friction, 3*m->ngeom); A(geom_size, 3*m->ngeom); A(geom_pos, 3*m->ngeom); A(site_pos, 3*m->nsite);
   A(xpos, 3*nb); A(xquat, 4*nb); A(xmat, 9*nb); A(xipos, 3*nb); A(ximat, 9*nb);
   A(xanchor, 3*m->njnt); A(xaxis, 3*m->njnt); A(geom_xpos, 3*m->ngeom); A(geom_xmat, 9*m->ngeom);
   A(site_xpos, 3*m->nsite); A(subtree_com, 3*nb); A(cinert, 10*nb); A(cdof, 6*nv); A(crb, 10*nb);
@@ -278,6 +278,7 @@ void orc_reset(const OrcModel* m, OrcData* d) {
   memcpy(d->body_mass, m->body_mass, sizeof(double)*m->nbody);
   memcpy(d->geom_friction, m->geom_friction, sizeof(double)*3*m->ngeom);
   memcpy(d->geom_size, m->geom_size, sizeof(double)*3*m->ngeom);
+  memcpy(d->geom_pos, m->geom_pos, sizeof(double)*3*m->ngeom);
   memcpy(d->site_pos, m->site_pos, sizeof(double)*3*m->nsite);
   d->time = 0; d->bad = 0;
 }
@@ -352,7 +353,7 @@ void orc_kinematics(const OrcModel* m, OrcData* d) {
   }
   for (int g = 0; g < m->ngeom; ++g) {
     int b = m->geom_bodyid[g]; double t[3], q[4];
-    mulmatvec3(t, xmat + 9*b, m->geom_pos + 3*g);
+    mulmatvec3(t, xmat + 9*b, d->geom_pos + 3*g);   /* per-data copy: the reorient reset rewrites the die's geom_pos */
     for (int k = 0; k < 3; ++k) d->geom_xpos[3*g+k] = xpos[3*b+k] + t[k];
     mulquat(q, xquat + 4*b, m->geom_quat + 4*g);
     quat2mat(d->geom_xmat + 9*g, q);
@@ -1408,4 +1409,106 @@ void orc_baoding_step(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg, O
   orc_kinematics(m, d);
   orc_baoding_obs(m, d, cfg, obs);
   orc_baoding_reward(cfg, m->na, obs, comps);
+}
+
+/* ------------------------------------------------------------------ die-reorient task layer
+ * CustomReorientEnv (/root/reference/src/envs/reorient.py) over ReorientEnvV0 (MyoSuite 1.2.3, not in /root/reference:
+ * observation layout and the Euler-angle helpers are the published ones [3P-RECALL]). */
+static void ro_mat2euler(const double* m, double* e) {
+  /* myosuite.utils.quat_math.mat2euler == mujoco-py rotations.mat2euler; _EPS4 = 4 * float64 eps */
+  double cy = sqrt(m[8]*m[8] + m[5]*m[5]);
+  int cond = cy > 8.881784197001252e-16;
+  e[2] = cond ? -atan2(m[1], m[0]) : -atan2(-m[3], m[4]);
+  e[1] = -atan2(-m[2], cy);
+  e[0] = cond ? -atan2(m[5], m[8]) : 0.0;
+}
+void orc_euler2quat(const double* e, double* q) {
+  /* myosuite.utils.quat_math.euler2quat (reorient.py:203-205 calls it for the goal orientation) */
+  double ai = e[2]/2, aj = -e[1]/2, ak = e[0]/2;
+  double si = sin(ai), sj = sin(aj), sk = sin(ak), ci = cos(ai), cj = cos(aj), ck = cos(ak);
+  double cc = ci*ck, cs = ci*sk, sc = si*ck, ss = si*sk;
+  q[0] = cj*cc + sj*ss; q[1] = cj*cs - sj*sc; q[2] = -(cj*ss + sj*cc); q[3] = cj*sc - sj*cs;
+}
+
+void orc_reorient_set_die(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, const double* friction, double del_size) {
+  /* reorient.py:136-147: per-geom friction; capsule half-lengths (size[:,1]) of all but the last three die geoms and all
+   * three sizes of the last three grow by del_size; every geom centre moves outward by it (pos/|pos + 1e-16| * (|pos0| + del)).
+   * geom_rbound is not refreshed (no mj_setConst), as in the Baoding P2 reset. */
+  int g0 = cfg->gid0, gn = cfg->gidn;
+  if (friction) memcpy(d->geom_friction + 3*g0, friction, sizeof(double)*3*(gn-g0));
+  for (int g = g0; g < gn; ++g) {
+    if (g < gn-3) d->geom_size[3*g+1] = m->geom_size[3*g+1] + del_size;
+    else for (int k = 0; k < 3; ++k) d->geom_size[3*g+k] = m->geom_size[3*g+k] + del_size;
+    for (int k = 0; k < 3; ++k) {
+      double p = m->geom_pos[3*g+k];
+      d->geom_pos[3*g+k] = p/fabs(p + 1e-16)*(fabs(p) + del_size);
+    }
+  }
+}
+
+void orc_reorient_obs(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, const OrcReorientState* st, double* obs) {
+  /* hand_qpos, hand_qvel*dt, obj_pos, goal_pos, pos_err, obj_rot, goal_rot, rot_err, act.  The goal body hangs off the world
+   * with the episode's pose (reset writes model.body_pos / body_quat of `target`, reorient.py:125-129,203-205); both sites
+   * are taken with identity local orientation (site_xmat = xmat of the body). */
+  double dt = cfg->frame_skip*m->timestep;
+  int nh = cfg->n_hand, o = 0;
+  for (int i = 0; i < nh; ++i) obs[o++] = d->qpos[i];
+  for (int i = 0; i < nh; ++i) obs[o++] = d->qvel[i]*dt;
+  const double* op = d->site_xpos + 3*cfg->object_sid;
+  double gq[4], gm[9], gp[3], t[3], oe[3], ge[3];
+  double n = sqrt(st->goal_quat[0]*st->goal_quat[0] + st->goal_quat[1]*st->goal_quat[1] + st->goal_quat[2]*st->goal_quat[2] + st->goal_quat[3]*st->goal_quat[3]);
+  for (int k = 0; k < 4; ++k) gq[k] = st->goal_quat[k]/n;
+  quat2mat(gm, gq);
+  mulmatvec3(t, gm, m->site_pos + 3*cfg->goal_sid);
+  for (int k = 0; k < 3; ++k) gp[k] = st->goal_pos[k] + t[k];
+  ro_mat2euler(d->xmat + 9*cfg->object_bid, oe);
+  ro_mat2euler(gm, ge);
+  for (int k = 0; k < 3; ++k) obs[o++] = op[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = gp[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = gp[k] - op[k] - cfg->goal_obj_offset[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = oe[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = ge[k];
+  for (int k = 0; k < 3; ++k) obs[o++] = ge[k] - oe[k];
+  for (int i = 0; i < m->na; ++i) obs[o++] = d->act[i];
+}
+
+void orc_reorient_reward(const OrcReorientCfg* cfg, int na, const double* pos_err, const double* rot_err, const double* act,
+                         double prev_pos_dist, double prev_rot_dist, double* c) {
+  /* restates /root/reference/src/envs/reorient.py:12-56; c = pos_dist, rot_dist, pos_dist_diff, rot_dist_diff, alive,
+   * act_reg, sparse, solved, done, dense (the OrderedDict's order) */
+  double pd = fabs(sqrt(pos_err[0]*pos_err[0] + pos_err[1]*pos_err[1] + pos_err[2]*pos_err[2]));
+  double rd = fabs(sqrt(rot_err[0]*rot_err[0] + rot_err[1]*rot_err[1] + rot_err[2]*rot_err[2]));
+  double am = 0; for (int i = 0; i < na; ++i) am += act[i]*act[i];
+  am = na ? sqrt(am)/na : 0;
+  int drop = pd > cfg->drop_th;
+  c[0] = -1.0*pd; c[1] = -1.0*rd; c[2] = prev_pos_dist - pd; c[3] = prev_rot_dist - rd; c[4] = !drop; c[5] = -1.0*am;
+  c[6] = -rd - 10.0*pd; c[7] = (pd < cfg->pos_th) && (rd < cfg->rot_th) && !drop; c[8] = drop;
+  double dense = 0; for (int k = 0; k < 9; ++k) dense += cfg->w[k]*c[k];
+  c[9] = dense;
+}
+
+void orc_reorient_step(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, OrcReorientState* st, const float* action,
+                       double* obs, double* comps) {
+  /* BaseV0.step (clip, float32 sigmoid for the muscles, frame_skip physics steps, obs, reward) followed by
+   * CustomReorientEnv.step's update of the shaping distances (reorient.py:207-212) */
+  for (int i = 0; i < m->nu; ++i) {
+    float a = action[i]; if (a < -1.f) a = -1.f; else if (a > 1.f) a = 1.f;
+    float c = 1.0f/(1.0f + (float)exp((double)(-5.0f*(a-0.5f))));     /* see orc_baoding_step */
+    d->ctrl[i] = (double)c;
+  }
+  for (int k = 0; k < cfg->frame_skip; ++k) orc_step(m, d);
+  orc_kinematics(m, d);
+  orc_reorient_obs(m, d, cfg, st, obs);
+  int o = 2*cfg->n_hand;
+  orc_reorient_reward(cfg, m->na, obs + o + 6, obs + o + 15, obs + o + 18, st->pos_dist, st->rot_dist, comps);
+  st->pos_dist = -comps[0]; st->rot_dist = -comps[1];
+}
+
+void orc_reorient_reset_dists(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, OrcReorientState* st, double* obs) {
+  /* tail of CustomReorientEnv.reset (reorient.py:177-180): observation of the reset state and its two distances */
+  orc_kinematics(m, d);
+  orc_reorient_obs(m, d, cfg, st, obs);
+  const double* pe = obs + 2*cfg->n_hand + 6; const double* re = obs + 2*cfg->n_hand + 15;
+  st->pos_dist = fabs(sqrt(pe[0]*pe[0] + pe[1]*pe[1] + pe[2]*pe[2]));
+  st->rot_dist = fabs(sqrt(re[0]*re[0] + re[1]*re[1] + re[2]*re[2]));
 }

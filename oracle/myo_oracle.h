@@ -78,6 +78,28 @@ void orc_baoding_step(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg,
 void orc_baoding_obs(const OrcModel* m, OrcData* d, const OrcBaodingCfg* cfg, double* obs);
 void orc_baoding_reward(const OrcBaodingCfg* cfg, int na, const double* obs, double* comps);
 
+/* ---- die-reorient task layer (/root/reference/src/envs/reorient.py) ---------- */
+typedef struct OrcReorientCfg {
+  int frame_skip, n_hand;
+  int object_sid, goal_sid, object_bid, gid0, gidn; /* sites object_o / target_o, body Object, the die's geoms [gid0, gidn) */
+  double drop_th, pos_th, rot_th;
+  double goal_obj_offset[3];
+  double w[9]; /* pos_dist, rot_dist, pos_dist_diff, rot_dist_diff, alive, act_reg, sparse, solved, done */
+} OrcReorientCfg;
+typedef struct OrcReorientState {
+  double goal_pos[3], goal_quat[4]; /* body_pos / body_quat of `target` for this episode */
+  double pos_dist, rot_dist;        /* self.pos_dist / self.rot_dist */
+} OrcReorientState;
+void orc_euler2quat(const double* e, double* q);
+void orc_reorient_set_die(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, const double* friction, double del_size);
+void orc_reorient_obs(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, const OrcReorientState* st, double* obs);
+/* c[10] = the rwd_dict in its own order: pos_dist, rot_dist, pos_dist_diff, rot_dist_diff, alive, act_reg, sparse, solved, done, dense */
+void orc_reorient_reward(const OrcReorientCfg* cfg, int na, const double* pos_err, const double* rot_err, const double* act,
+                         double prev_pos_dist, double prev_rot_dist, double* c);
+void orc_reorient_step(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, OrcReorientState* st, const float* action,
+                       double* obs, double* comps);
+void orc_reorient_reset_dists(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, OrcReorientState* st, double* obs);
+
 #ifdef __cplusplus
 }
 #endif

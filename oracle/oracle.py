@@ -49,6 +49,13 @@ def lib():
         L.orc_baoding_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
         L.orc_baoding_reward.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double),
                                          C.POINTER(C.c_double)]
+        dp = C.POINTER(C.c_double)
+        L.orc_euler2quat.argtypes = [dp, dp]
+        L.orc_reorient_set_die.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, dp, C.c_double]
+        L.orc_reorient_obs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dp]
+        L.orc_reorient_reward.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
+        L.orc_reorient_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), dp, dp]
+        L.orc_reorient_reset_dists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dp]
         L.orc_flops.argtypes = [C.POINTER(C.c_double), C.c_int]
         L.orc_flops_stages.restype = C.c_int
         L.orc_flops_enabled.restype = C.c_int
@@ -84,6 +91,18 @@ class BaodingState(C.Structure):
                 ("x_radius", C.c_double), ("y_radius", C.c_double), ("time_period", C.c_double)]
 
 
+class ReorientCfg(C.Structure):
+    _fields_ = [("frame_skip", C.c_int), ("n_hand", C.c_int), ("object_sid", C.c_int), ("goal_sid", C.c_int),
+                ("object_bid", C.c_int), ("gid0", C.c_int), ("gidn", C.c_int),
+                ("drop_th", C.c_double), ("pos_th", C.c_double), ("rot_th", C.c_double),
+                ("goal_obj_offset", C.c_double * 3), ("w", C.c_double * 9)]
+
+
+class ReorientState(C.Structure):
+    _fields_ = [("goal_pos", C.c_double * 3), ("goal_quat", C.c_double * 4), ("pos_dist", C.c_double), ("rot_dist", C.c_double)]
+
+
+REORIENT_RWD_KEYS = ("pos_dist", "rot_dist", "pos_dist_diff", "rot_dist_diff", "alive", "act_reg", "sparse", "solved", "done", "dense")
 REWARD_KEYS = ("pos_dist_1", "pos_dist_2", "act_reg", "alive", "sparse", "solved", "done")
 
 
@@ -199,3 +218,40 @@ def baoding_step(data: OracleData, cfg, st, action):
                            obs.ctypes.data_as(C.POINTER(C.c_double)),
                            comps.ctypes.data_as(C.POINTER(C.c_double)))
     return obs, comps
+
+
+# ---- die-reorient task layer
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def reorient_set_die(data: "OracleData", cfg: ReorientCfg, friction, del_size: float):
+    """The die of one episode (reorient.py:136-147): friction float64 [ngeom_die, 3] (None keeps it), one size delta."""
+    fr = None if friction is None else np.ascontiguousarray(friction, np.float64).reshape(-1)
+    lib().orc_reorient_set_die(data.model.h, data.h, C.byref(cfg), None if fr is None else _dp(fr), float(del_size))
+
+
+def reorient_reward(cfg: ReorientCfg, na: int, pos_err, rot_err, act, prev_pos_dist: float, prev_rot_dist: float):
+    pe, re, a = (np.ascontiguousarray(x, np.float64) for x in (pos_err, rot_err, act))
+    c = np.zeros(10)
+    lib().orc_reorient_reward(C.byref(cfg), int(na), _dp(pe), _dp(re), _dp(a), float(prev_pos_dist), float(prev_rot_dist), _dp(c))
+    return c
+
+
+def reorient_reset_dists(data: "OracleData", cfg: ReorientCfg, st: ReorientState):
+    obs = np.zeros(2 * cfg.n_hand + 18 + data.model.na)
+    lib().orc_reorient_reset_dists(data.model.h, data.h, C.byref(cfg), C.byref(st), _dp(obs))
+    return obs
+
+
+def reorient_step(data: "OracleData", cfg: ReorientCfg, st: ReorientState, action):
+    a = np.ascontiguousarray(action, np.float32)
+    obs, comps = np.zeros(2 * cfg.n_hand + 18 + data.model.na), np.zeros(10)
+    lib().orc_reorient_step(data.model.h, data.h, C.byref(cfg), C.byref(st), a.ctypes.data_as(C.POINTER(C.c_float)), _dp(obs), _dp(comps))
+    return obs, comps
+
+
+def euler2quat(e):
+    e, q = np.ascontiguousarray(e, np.float64), np.zeros(4)
+    lib().orc_euler2quat(_dp(e), _dp(q))
+    return q

@@ -433,3 +433,100 @@ def case_step_inner(lib, mj, dtype, tol, nsteps=12):
             assert np.abs(h_out[e] - o).max() < max(tol, 2e-7), (t, e, np.abs(h_out[e] - o).max())
             assert rel_err(h_qp[e], d.qpos) < tol and bool(h_done[e]) == bool(c[6])
     b.close()
+
+
+# ---------------------------------------------------------------- die reorient
+def reorient_oracle_cfg(cm, tcfg):
+    from myochallenge_amd.envs.reorient import reorient_ids
+    from oracle.oracle import ReorientCfg
+    ids, c = reorient_ids(cm), ReorientCfg()
+    c.frame_skip, c.n_hand = tcfg.frame_skip, tcfg.n_hand
+    c.object_sid, c.goal_sid, c.object_bid, c.gid0, c.gidn = (ids[k] for k in ("object_sid", "goal_sid", "object_bid", "object_gid0", "object_gidn"))
+    c.drop_th, c.pos_th, c.rot_th = tcfg.drop_th, tcfg.ro_pos_th, tcfg.ro_rot_th
+    for i in range(3):
+        c.goal_obj_offset[i] = tcfg.ro_goal_obj_offset[i]
+    for i in range(9):
+        c.w[i] = tcfg.ro_weights[i]
+    return c
+
+
+def case_reorient(lib, dtype, tol, env_name="CustomMyoReorientP2", n=6, nsteps=30, horizon=12, seed=11, **kw):
+    """CustomReorientEnv.step / reset on the device (task kind MYO_TASK_REORIENT) against the oracle's orc_reorient_step on twins
+    that share each episode's draws: observation, the reward dictionary with its shaping terms, drop termination, TimeLimit
+    truncation with the terminal observation, Monitor numbers, and at every reset the oracle's own reset tail
+    (orc_reorient_reset_dists) on the device's post-reset state.  Env 0 starts with the die pushed off the palm (drop)."""
+    from myochallenge_amd.envs.reorient import make_reorient_cfg
+    from myochallenge_amd.synth_hand import synthetic_hand_die
+    from oracle.oracle import ReorientState, reorient_reset_dists, reorient_set_die, reorient_step
+    mem = Mem(lib)
+    cm, om, _ = oracle_for(synthetic_hand_die())
+    tcfg = make_reorient_cfg(env_name, cm, max_episode_steps=horizon, **kw)
+    ocfg = reorient_oracle_cfg(cm, tcfg)
+    b = native.Batch(native.Model(cm, lib), tcfg, n, 0, seed, dtype)
+    nobs, ng = b.obs_dim, ocfg.gidn - ocfg.gid0
+    assert nobs == 2 * tcfg.n_hand + 18 + om.na
+    obs, rew, done, trunc = mem.zeros((n, nobs), np.float32), mem.zeros(n, np.float32), mem.zeros(n, np.uint8), mem.zeros(n, np.uint8)
+    term, comps, ep = mem.zeros((n, nobs), np.float32), mem.zeros((n, 8), np.float32), mem.zeros((n, 2), np.float32)
+    qp, qv, ac, tm = mem.zeros((n, om.nq)), mem.zeros((n, om.nv)), mem.zeros((n, om.na)), mem.zeros(n)
+    ti, td, bd, fr = mem.zeros((n, 2), np.int32), mem.zeros((n, 9)), mem.zeros((n, 10)), mem.zeros((n, ng, 3))
+    b.reset(None, obs)
+    b.get_state(qp, qv, ac, tm)
+    q = mem.host(qp).copy()
+    q[0, -7] += 0.25                                 # env 0: the die starts beside the palm and falls
+    b.set_state(mem.arr(q), None, None, None)
+    twins = [None] * n
+    obs_tol = max(tol, 2e-7)                         # the device returns float32 observations (angles reach 2 pi: relative)
+
+    def sync(e, check_obs=None):
+        """oracle twin of env e from the device's state and episode draws; runs the oracle's reset tail on it"""
+        b.get_state(qp, qv, ac, tm); b.get_task(ti, td, bd); b.object_friction(None, fr)
+        h = [mem.host(x) for x in (qp, qv, ac, tm, td, bd, fr)]
+        d = OracleData(om)
+        d.reset()
+        d.qpos[:], d.qvel[:], d.act[:] = h[0][e], h[1][e], h[2][e]
+        d.arr("time")[0] = h[3][e]
+        st = ReorientState()
+        for k in range(3):
+            st.goal_pos[k] = h[4][e, k]
+        for k in range(4):
+            st.goal_quat[k] = h[4][e, 3 + k]
+        reorient_set_die(d, ocfg, h[6][e], h[5][e, 8])
+        o = reorient_reset_dists(d, ocfg, st)
+        if check_obs is not None:                    # a reset just happened on the device: same observation, same distances
+            assert (np.abs(check_obs - o) <= obs_tol * np.maximum(1, np.abs(o))).all(), np.abs(check_obs - o).max()
+            assert abs(st.pos_dist - h[4][e, 7]) < 1e-12 + tol and abs(st.rot_dist - h[4][e, 8]) < 1e-12 + tol
+            assert np.all(d.qpos[1:tcfg.n_hand] == 0) and d.qpos[0] == -1.5 and np.all(d.qvel == 0) and d.arr("time")[0] == 0
+        else:
+            st.pos_dist, st.rot_dist = h[4][e, 7], h[4][e, 8]
+        twins[e] = (d, st)
+        return h
+
+    h0 = None
+    for e in range(n):
+        h0 = sync(e, None if e == 0 else mem.host(obs)[e])
+    rng = np.random.RandomState(5)
+    rets, lens = np.zeros(n), np.zeros(n, int)
+    seen = dict(drop=0, trunc=0)
+    for t in range(nsteps):
+        a = np.clip(rng.normal(0, 0.4, (n, om.nu)), -1, 1).astype(np.float32)
+        b.step(mem.arr(a, np.float32), obs, rew, done, trunc, term, comps, ep)
+        ho, hr, hd, ht, hterm, hc, hep = (mem.host(x).copy() for x in (obs, rew, done, trunc, term, comps, ep))
+        for e in range(n):
+            d, st = twins[e]
+            o, c = reorient_step(d, ocfg, st, a[e])
+            rets[e] += c[9]; lens[e] += 1
+            dev_obs = hterm[e] if hd[e] else ho[e]
+            assert (np.abs(dev_obs - o) <= obs_tol * np.maximum(1, np.abs(o))).all(), (t, e, np.abs(dev_obs - o).max())
+            want = np.array([c[0], c[1], c[5], c[4], c[6], c[7], c[8], c[9]])        # comps = pos_dist, rot_dist, act_reg, alive, sparse, solved, done, dense
+            assert np.abs(hc[e] - want).max() < max(tol, 1e-6) * (1 + np.abs(want).max()), (t, e, hc[e], want)
+            assert abs(hr[e] - c[9]) < max(tol, 1e-6) * (1 + abs(c[9]))
+            drop, timeout = bool(c[8]), lens[e] >= horizon
+            assert bool(hd[e]) == (drop or timeout) and bool(ht[e]) == (timeout and not drop)
+            if hd[e]:
+                seen["drop" if drop else "trunc"] += 1
+                assert abs(hep[e, 0] - rets[e]) < 1e-4 * (1 + abs(rets[e])) and int(hep[e, 1]) == lens[e]
+                rets[e], lens[e] = 0, 0
+                sync(e, ho[e])
+    b.close()
+    assert seen["drop"] >= 1 and seen["trunc"] >= n - 1, seen
+    return seen

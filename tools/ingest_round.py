@@ -33,7 +33,7 @@ def main():
                  ("drift.log", TAG + "_drift_32streams.log")):
         shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}
-    for k in ("f64", "rk4", "p2_8192", "rollout_only"):
+    for k in ("f64", "rk4", "p2_8192", "rollout_only", "reorient_p2"):
         d = json.loads(open(os.path.join(R, f"bench_{k}.json")).read().strip().splitlines()[-1])
         out["bench_" + k] = {x: d[x] for x in ("value", "ms_per_step", "env_kernel_ms", "ppo_optimizer_steps_per_sec", "dtype", "config") if x in d}
     json.dump(out, open(os.path.join(P, TAG + "_other_configs.json"), "w"), indent=1)

@@ -85,15 +85,18 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
       const HP l2[3] = {s.target_xy[2], s.target_xy[3], M.h_site_pos[3 * K.target2_sid + 2]};
       body_point_hp(s, M.site_bodyid[K.target1_sid], l1, t1);
       body_point_hp(s, M.site_bodyid[K.target2_sid], l2, t2);
-      S_OBS(s)[nh + i] = (T)p1[i];
+      // (lane-indexed reads of the local arrays would put them in private memory: select instead)
+      const HP p1i = i == 0 ? p1[0] : (i == 1 ? p1[1] : p1[2]), p2i = i == 0 ? p2[0] : (i == 1 ? p2[1] : p2[2]);
+      const HP t1i = i == 0 ? t1[0] : (i == 1 ? t1[1] : t1[2]), t2i = i == 0 ? t2[0] : (i == 1 ? t2[1] : t2[2]);
+      S_OBS(s)[nh + i] = (T)p1i;
       S_OBS(s)[nh + 3 + i] = (T)(s.qvel[M.nv - 12 + i] * dt);
-      S_OBS(s)[nh + 6 + i] = (T)p2[i];
+      S_OBS(s)[nh + 6 + i] = (T)p2i;
       S_OBS(s)[nh + 9 + i] = (T)(s.qvel[M.nv - 6 + i] * dt);
-      S_OBS(s)[nh + 12 + i] = (T)t1[i];
-      S_OBS(s)[nh + 15 + i] = (T)t2[i];
-      S_OBS(s)[nh + 18 + i] = (T)(t1[i] - p1[i]);
-      S_OBS(s)[nh + 21 + i] = (T)(t2[i] - p2[i]);
-      s.target_w[i] = t1[i]; s.target_w[3 + i] = t2[i];
+      S_OBS(s)[nh + 12 + i] = (T)t1i;
+      S_OBS(s)[nh + 15 + i] = (T)t2i;
+      S_OBS(s)[nh + 18 + i] = (T)(t1i - p1i);
+      S_OBS(s)[nh + 21 + i] = (T)(t2i - p2i);
+      s.target_w[i] = t1i; s.target_w[3 + i] = t2i;
     }
     if (i < M.na) S_OBS(s)[nh + 24 + i] = (T)s.act[i];
   }
@@ -110,6 +113,7 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
       c[5] = ((d1 < (T)K.proximity_th) && (d2 < (T)K.proximity_th) && !fall) ? (T)1 : (T)0;
       c[6] = fall ? (T)1 : (T)0;
       T dense = 0;
+#pragma unroll
       for (int k = 0; k < 7; ++k) { dense += (T)K.weights[k] * c[k]; s.rwd[k] = c[k]; }
       s.rwd[7] = dense;
     }

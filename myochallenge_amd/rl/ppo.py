@@ -76,6 +76,13 @@ class PPO:
         self.device = env.device
         self.policy.to(self.device)
         on_gpu = self.device.type == "cuda"
+        if not policy.recurrent and (cfg.n_steps * env.num_envs) % min(cfg.batch_size, cfg.n_steps * env.num_envs):
+            # SB3 warns here too and then trains on the truncated last minibatch of each epoch; every update path of this
+            # class works on fixed-size minibatches (one captured graph) and SKIPS that remainder instead
+            import warnings
+            warnings.warn(f"rollout of {cfg.n_steps * env.num_envs} samples is not a multiple of batch_size={cfg.batch_size}: the last "
+                          f"{(cfg.n_steps * env.num_envs) % cfg.batch_size} samples of every epoch's permutation are not trained on "
+                          "(stable-baselines3 would train on them as a truncated minibatch)")
         self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5,
                                           capturable=on_gpu, foreach=True if on_gpu else None)
         self._graph = None

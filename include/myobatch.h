@@ -167,7 +167,9 @@ int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d, double* ba
  * coordinate, capsule half-lengths grow by it.  (-1, -1) clears the group.  A MYO_TASK_REORIENT batch owns its
  * group (the die, from the task cfg) and draws both at every reset; this call is for physics-only batches. */
 int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn);
-/* friction of the object group's geoms: dev double[N, gidn-gid0, 3]; either pointer may be NULL (set, then get) */
+/* friction of the object group's geoms: dev double[N, gidn-gid0, 3]; either pointer may be NULL (set, then get).  The stepper
+ * builds condim-3 contacts only, which read the sliding coefficient [.,.,0]; a MYO_TASK_REORIENT reset draws all three
+ * per geom in the reference's order and keeps the sliding one (the other two slots stay at the model's values). */
 int myo_batch_object_friction(myo_batch* b, const double* set_fric, double* get_fric, void* stream);
 
 /* The model / task parameters of ONE batch per device sit in __constant__ memory; every launching entry point

@@ -101,14 +101,17 @@ struct Scratch {
   T ctrl[MYO_NU_MAX], qacc_warm[MYO_NV_MAX];
   T qvelT_[sizeof(T) == sizeof(HP) ? 1 : MYO_NV_MAX];   // qvel as the fp32 stages read it (see S_QVELT)
   // ---- per-env parameters
-  HP ball_size[2], target_w[6];
+  HP ball_size[2];
   union {                         // the task's per-env numbers = the record's taskd block, in this order
     struct { HP start_angle[2], x_radius, y_radius, time_period, target_xy[4]; };    // Baoding
     struct { HP goal_pos[3], goal_quat[4], pos_dist, rot_dist; };                    // die reorient
     HP taskd[MYO_TASKD_N];
   };
-  T ball_mass[2], ball_fric[6], ep_ret;
-  T objg_fric[3 * MYO_OBJG_MAX];  // friction of the object group's geoms
+  union {                         // a batch has either the two Baoding balls or an object group (the die), never both
+    struct { HP target_w[6]; T ball_mass[2], ball_fric[6]; };
+    T objg_fric[MYO_OBJG_MAX];    // sliding friction of the object group's geoms (condim-3 contacts use no other coefficient)
+  };
+  T ep_ret;
   int which_task, counter, elapsed, episode, ep_len;
   // ---- position stage
   // (short-lived arrays alias longer-lived storage, see the S_* accessors below)
@@ -310,7 +313,7 @@ template <typename T> DEV HP geom_size0_hp(const DevModel<T>& M, const TaskDev& 
   return M.h_geom_size[3 * g];
 }
 template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, int k) {
-  if (g >= K.objg_gid0 && g < K.objg_gidn) return s.objg_fric[3 * (g - K.objg_gid0) + k];
+  if (g >= K.objg_gid0 && g < K.objg_gidn) return k == 0 ? s.objg_fric[g - K.objg_gid0] : M.geom_friction[3 * g + k];
   if (g == K.obj1_gid) return s.ball_fric[k];
   if (g == K.obj2_gid) return s.ball_fric[3 + k];
   return M.geom_friction[3 * g + k];
@@ -1606,14 +1609,15 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         T F[16];
         for (int e = 0; e < 16; ++e) F[e] = M.pc_f[16 * p + e];
         c.b1 = b1; c.b2 = b2;
-        T fr[3];
-        for (int e = 0; e < 3; ++e) {
+        T fr[1];    // condim 3: both tangential directions use friction[0]; torsional / rolling coefficients are not used
+        {
+          const int e = 0;
           const int grp1 = (g1 >= K.objg_gid0 && g1 < K.objg_gidn), grp2 = (g2 >= K.objg_gid0 && g2 < K.objg_gidn);
-          const T a = grp1 ? s.objg_fric[3 * (g1 - K.objg_gid0) + e] : (g1 == K.obj1_gid ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]));
-          const T b = grp2 ? s.objg_fric[3 * (g2 - K.objg_gid0) + e] : (g2 == K.obj1_gid ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]));
+          const T a = grp1 ? s.objg_fric[g1 - K.objg_gid0] : (g1 == K.obj1_gid ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]));
+          const T b = grp2 ? s.objg_fric[g2 - K.objg_gid0] : (g2 == K.obj1_gid ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]));
           fr[e] = (fsel == 0) ? tmax(a, b) : (fsel == 1 ? a : b);
         }
-        c.mu[0] = fr[0]; c.mu[1] = fr[0];  // condim 3: both tangential directions use friction[0]
+        c.mu[0] = fr[0]; c.mu[1] = fr[0];
         const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
         T Kc, Bc, Ic;
         sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);

@@ -430,7 +430,8 @@ DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
       Philox h = g;
       h.idx = base + (unsigned int)lane;
       const double nominal = (double)M.geom_friction[3 * K.objg_gid0 + lane], ch = K.obj_friction_change[lane % 3];
-      s.objg_fric[lane] = (T)rng_range(h, nominal - ch, nominal + ch);
+      const T f = (T)rng_range(h, nominal - ch, nominal + ch);
+      if (lane % 3 == 0) s.objg_fric[lane / 3] = f;     // the sliding coefficient; the torsional / rolling draws are consumed, condim-3 contacts never read them
     }
     if (lane == 0) {
       s.which_task = 0; s.counter = 0; s.elapsed = 0; s.ep_ret = 0; s.ep_len = 0;
@@ -456,7 +457,7 @@ DEVFN void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecor
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (K.objg_gidn > 0) for (int i = lane; i < 3 * (K.objg_gidn - K.objg_gid0); i += 64) s.objg_fric[i] = (T)rec[L.off_objfric + i];
+    if (K.objg_gidn > 0) for (int i = lane; i < K.objg_gidn - K.objg_gid0; i += 64) s.objg_fric[i] = (T)rec[L.off_objfric + 3 * i];
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
     for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i];
@@ -466,8 +467,10 @@ DEVFN void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecor
       const double* td = rec + L.off_taskd;
       for (int k = 0; k < MYO_TASKD_N; ++k) s.taskd[k] = td[k];
       const double* bd = rec + L.off_balld;
-      s.ball_mass[0] = (T)bd[0]; s.ball_mass[1] = (T)bd[1];
-      for (int k = 0; k < 6; ++k) s.ball_fric[k] = (T)bd[2 + k];
+      if (K.objg_gidn <= 0) {       // (the ball slots share storage with the object group's friction)
+        s.ball_mass[0] = (T)bd[0]; s.ball_mass[1] = (T)bd[1];
+        for (int k = 0; k < 6; ++k) s.ball_fric[k] = (T)bd[2 + k];
+      }
       s.ball_size[0] = bd[8]; s.ball_size[1] = bd[9];
       const double* mi = rec + L.off_misc;
       s.which_task = (int)mi[0]; s.counter = (int)mi[1]; s.elapsed = (int)mi[2]; s.episode = (int)mi[3];
@@ -483,7 +486,7 @@ DEVFN void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvReco
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (K.kind == MYO_TASK_REORIENT_K) for (int i = lane; i < 3 * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + i] = (double)s.objg_fric[i];
+    if (K.kind == MYO_TASK_REORIENT_K) for (int i = lane; i < K.objg_gidn - K.objg_gid0; i += 64) rec[L.off_objfric + 3 * i] = (double)s.objg_fric[i];
     for (int i = lane; i < M.nq; i += 64) rec[L.off_qpos + i] = (double)s.qpos[i];
     for (int i = lane; i < M.nv; i += 64) { rec[L.off_qvel + i] = (double)s.qvel[i]; rec[L.off_warm + i] = (double)s.qacc_warm[i]; }
     for (int i = lane; i < M.na; i += 64) rec[L.off_act + i] = (double)s.act[i];
@@ -492,8 +495,10 @@ DEVFN void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvReco
       double* td = rec + L.off_taskd;
       for (int k = 0; k < MYO_TASKD_N; ++k) td[k] = (double)s.taskd[k];
       double* bd = rec + L.off_balld;
-      bd[0] = (double)s.ball_mass[0]; bd[1] = (double)s.ball_mass[1];
-      for (int k = 0; k < 6; ++k) bd[2 + k] = (double)s.ball_fric[k];
+      if (K.objg_gidn <= 0) {
+        bd[0] = (double)s.ball_mass[0]; bd[1] = (double)s.ball_mass[1];
+        for (int k = 0; k < 6; ++k) bd[2 + k] = (double)s.ball_fric[k];
+      }
       bd[8] = (double)s.ball_size[0]; bd[9] = (double)s.ball_size[1];
       double* mi = rec + L.off_misc;
       mi[0] = s.which_task; mi[1] = s.counter; mi[2] = s.elapsed; mi[3] = s.episode;

@@ -906,7 +906,7 @@ extern "C" int myo_batch_set_task(myo_batch* b, const int32_t* task_i, const dou
 extern "C" int myo_batch_set_object_group(myo_batch* b, int gid0, int gidn) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   if (!(gid0 == -1 && gidn == -1) && (gid0 < 0 || gidn <= gid0 || gidn > b->ngeom)) return fail(MYO_E_ARG, "bad geom range");
-  if (b->K.kind == MYO_TASK_REORIENT) return fail(MYO_E_STATE, "the reorient task owns the object group");
+  if (b->K.kind != MYO_TASK_NONE) return fail(MYO_E_STATE, "object groups are for physics-only batches (the reorient task owns its own; the Baoding tasks have the two balls)");
   if (gidn - gid0 > MYO_OBJG_MAX) return fail(MYO_E_UNSUPPORTED, "an object group holds at most %d geoms", MYO_OBJG_MAX);
   b->K.objg_gid0 = gid0; b->K.objg_gidn = gidn;
   if (gidn > 0) {   // every env starts from the model's friction of the group's geoms

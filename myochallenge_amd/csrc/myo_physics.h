@@ -1609,21 +1609,23 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         T F[16];
         for (int e = 0; e < 16; ++e) F[e] = M.pc_f[16 * p + e];
         c.b1 = b1; c.b2 = b2;
-        T fr[1];    // condim 3: both tangential directions use friction[0]; torsional / rolling coefficients are not used
-        {
-          const int e = 0;
-          const int grp1 = (g1 >= K.objg_gid0 && g1 < K.objg_gidn), grp2 = (g2 >= K.objg_gid0 && g2 < K.objg_gidn);
-          const T a = grp1 ? s.objg_fric[g1 - K.objg_gid0] : (g1 == K.obj1_gid ? s.ball_fric[e] : ((g1 == K.obj2_gid) ? s.ball_fric[3 + e] : F[9 + e]));
-          const T b = grp2 ? s.objg_fric[g2 - K.objg_gid0] : (g2 == K.obj1_gid ? s.ball_fric[e] : ((g2 == K.obj2_gid) ? s.ball_fric[3 + e] : F[12 + e]));
-          fr[e] = (fsel == 0) ? tmax(a, b) : (fsel == 1 ? a : b);
+        // condim 3: both tangential directions use friction[0]; torsional / rolling coefficients are not used
+        T fa = F[9], fb = F[12];
+        if (K.objg_gidn > 0) {
+          if (g1 >= K.objg_gid0 && g1 < K.objg_gidn) fa = s.objg_fric[g1 - K.objg_gid0];
+          if (g2 >= K.objg_gid0 && g2 < K.objg_gidn) fb = s.objg_fric[g2 - K.objg_gid0];
+        } else {
+          fa = g1 == K.obj1_gid ? s.ball_fric[0] : (g1 == K.obj2_gid ? s.ball_fric[3] : fa);
+          fb = g2 == K.obj1_gid ? s.ball_fric[0] : (g2 == K.obj2_gid ? s.ball_fric[3] : fb);
         }
-        c.mu[0] = fr[0]; c.mu[1] = fr[0];
+        const T fr0 = (fsel == 0) ? tmax(fa, fb) : (fsel == 1 ? fa : fb);
+        c.mu[0] = fr0; c.mu[1] = fr0;
         const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
         T Kc, Bc, Ic;
         sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
         const T tran = F[15];
-        const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr[0] * fr[0] * tran) / Ic);
-        const T mu = fr[0] / sqrt(M.impratio);
+        const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr0 * fr0 * tran) / Ic);
+        const T mu = fr0 / sqrt(M.impratio);
         const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
         c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * dmi;
         c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];

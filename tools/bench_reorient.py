@@ -1,6 +1,6 @@
 """BASELINE config E (die-reorient, 4096 envs on one MI355X, recurrent LSTM policy): env-steps/s of rollout +
-PPO update.  Not the headline bench: the task layer of this env is torch code around myo_batch_physics_step and
-the LSTM policy trains by autograd BPTT replayed from a hipGraph."""
+PPO update.  Not the headline bench.  The env step is the step kernel's MYO_TASK_REORIENT task (csrc/myo_task.h); the LSTM
+policy trains by hand-written BPTT replayed from a hipGraph."""
 import argparse
 import json
 import os

@@ -36,8 +36,12 @@ def main():
     for k in ("f64", "rk4", "p2_8192", "rollout_only", "reorient_p2"):
         d = json.loads(open(os.path.join(R, f"bench_{k}.json")).read().strip().splitlines()[-1])
         out["bench_" + k] = {x: d[x] for x in ("value", "ms_per_step", "env_kernel_ms", "ppo_optimizer_steps_per_sec", "dtype", "config") if x in d}
+    try:
+        out["config_E_reorient_lstm256"] = json.loads(open(os.path.join(R, "bench_reorient_lstm.json")).read().strip().splitlines()[-1])
+    except Exception as e:          # noqa: BLE001
+        print("no reorient LSTM record:", e)
     json.dump(out, open(os.path.join(P, TAG + "_other_configs.json"), "w"), indent=1)
-    print({k: (round(v["value"]), round(v["env_kernel_ms"], 2), round(v.get("ppo_optimizer_steps_per_sec", 0))) for k, v in out.items()})
+    print({k: (round(v["value"]), round(v["env_kernel_ms"], 2), round(v.get("ppo_optimizer_steps_per_sec", 0))) for k, v in out.items() if "value" in v})
     d = json.loads(open(os.path.join(R, "bench_line.json")).read().strip().splitlines()[-1])
     open(os.path.join(P, TAG + "_bench_line.json"), "w").write(json.dumps(d) + "\n")
     print("bench", d["value"], d["ms_per_step"], d["env_kernel_ms"], d["ppo_optimizer_steps_per_sec"], d["roofline"]["traffic"],

@@ -35,6 +35,7 @@ python3 $ROOT/bench.py --no-cpu-baseline --no-variants --integrator rk4 > $OUT/b
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoBaodingBallsP2 --envs 8192 > $OUT/bench_p2_8192.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoReorientP2 > $OUT/bench_reorient_p2.json 2>/dev/null
+python3 $ROOT/tools/bench_reorient.py > $OUT/bench_reorient_lstm.json 2>/dev/null
 # 6. trajectory drift tables of both steppers (32 action streams x 200 env steps) and k_step time against the batch size
 python3 $ROOT/tools/dev/gpu_drift.py > $OUT/drift.log 2>&1
 echo done

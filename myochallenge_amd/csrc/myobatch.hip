@@ -627,7 +627,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   L.off_qpos = o; o += m->nq; L.off_qvel = o; o += m->nv; L.off_act = o; o += m->na; L.off_warm = o; o += m->nv;
   L.off_time = o; o += 1; L.off_taskd = o; o += MYO_TASKD_N; L.off_balld = o; o += MYO_BALLD_N; L.off_misc = o; o += MYO_MISC_N;
   L.off_objfric = o; o += 3 * MYO_OBJG_MAX;
-  L.stride = (o + 7) / 8 * 8;
+  L.stride = (o + 15) / 16 * 16;      // whole 128-byte lines per env: no line is shared by two workgroups
   DumpLayout& D = b->D;
   o = 0;
   D.ten_length = o; o += m->ntendon; D.ten_J = o; o += m->ntendon * m->nv; D.M = o; o += m->nv * m->nv;

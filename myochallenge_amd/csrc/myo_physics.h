@@ -1444,6 +1444,7 @@ DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos
     else {
       T y;
       if (power == 1) y = x;
+      else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // MuJoCo's default solimp: no pow()
       else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
       else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
       imp = d0 + y * (d1 - d0);

@@ -453,7 +453,7 @@ DEV void task_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int e
 
 // ---- HBM record <-> scratch
 template <typename T>
-DEVFN void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, const double* rec, Scratch<T>& s_in) {
+DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, const double* rec, Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -482,7 +482,7 @@ DEVFN void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecor
 }
 
 template <typename T>
-DEVFN void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T>& s_in) {
+DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {

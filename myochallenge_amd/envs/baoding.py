@@ -15,6 +15,7 @@ Two call styles:
 from __future__ import annotations
 
 from dataclasses import dataclass
+import time
 from typing import Any, List, Optional, Sequence
 
 import numpy as np
@@ -87,6 +88,7 @@ class BaodingVecEnv:
         self._ep = torch.zeros((n, 2), dtype=torch.float32, device=d)
         self._pending = None
         self._closed = False
+        self._t_start = time.time()
 
     # ---------------------------------------------------------------- what a task supplies (ReorientVecEnv overrides these)
     rwd_keys = native.RWD_KEYS
@@ -154,7 +156,7 @@ class BaodingVecEnv:
             if done_h[i]:
                 info["terminal_observation"] = term_h[i].copy()
                 info["TimeLimit.truncated"] = bool(trunc_h[i])
-                info["episode"] = {"r": float(ep_h[i, 0]), "l": int(ep_h[i, 1])}
+                info["episode"] = {"r": float(ep_h[i, 0]), "l": int(ep_h[i, 1]), "t": round(time.time() - self._t_start, 6)}   # Monitor's keys
             infos.append(info)
         return obs_h, rew_h, done_h, infos
 

@@ -30,6 +30,9 @@ def main():
     from myochallenge_amd.rl.vec_normalize import VecNormalize
     cfgs = {"weighted_reward_keys": {"pos_dist_1": 5.0, "pos_dist_2": 5.0, "act_reg": 0.0, "alive": 1.0, "solved": 5.0,
                                      "done": 0.0, "sparse": 0.0}}
+    if "Reorient" in a.env_name:      # the reward shaping of src/main_reorient.py:27-37
+        cfgs = {"weighted_reward_keys": {"pos_dist": 0.5, "rot_dist": 0.02, "pos_dist_diff": 50, "rot_dist_diff": 5, "alive": 0.1,
+                                         "act_reg": 0, "solved": 0.5, "done": 0, "sparse": 0}}
     env = EnvironmentFactory.create(a.env_name, num_envs=a.envs, seed=1, **cfgs)
     eval_env = EnvironmentFactory.create(a.env_name, num_envs=512, seed=999, **cfgs)
     venv = VecNormalize(env, gamma=0.99)

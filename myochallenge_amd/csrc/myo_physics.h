@@ -570,12 +570,15 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_i
 
 // ------------------------------------------------------------------------------------------
 // P3: spatial tendons with sphere / cylinder wrapping (mj_tendon + mju_wrap)
+// do the segments p1-p2 and p3-p4 cross?  (mju_wrap's is_intersect: both line parameters a = na / det, b = nb / det in
+// [0, 1]; tested on the numerators — 0 <= n <= det or det <= n <= 0 — which needs no division)
 template <typename T> DEV int seg_intersect(const T* p1, const T* p2, const T* p3, const T* p4) {
   const T det = (p4[1] - p3[1]) * (p2[0] - p1[0]) - (p4[0] - p3[0]) * (p2[1] - p1[1]);
   if (fabs(det) < MYO_MINVAL) return 0;
-  const T a = ((p4[0] - p3[0]) * (p1[1] - p3[1]) - (p4[1] - p3[1]) * (p1[0] - p3[0])) / det;
-  const T b = ((p2[0] - p1[0]) * (p1[1] - p3[1]) - (p2[1] - p1[1]) * (p1[0] - p3[0])) / det;
-  return (a >= 0 && a <= 1 && b >= 0 && b <= 1);
+  const T na = (p4[0] - p3[0]) * (p1[1] - p3[1]) - (p4[1] - p3[1]) * (p1[0] - p3[0]);
+  const T nb = (p2[0] - p1[0]) * (p1[1] - p3[1]) - (p2[1] - p1[1]) * (p1[0] - p3[0]);
+  const T lo = det > 0 ? (T)0 : det, hi = det > 0 ? det : (T)0;
+  return (na >= lo && na <= hi && nb >= lo && nb <= hi);
 }
 
 template <typename T> DEV T wrap_circle(T* pnt, const T* dd, const T* sd, int has_side, T rad) {
@@ -590,17 +593,17 @@ template <typename T> DEV T wrap_circle(T* pnt, const T* dd, const T* sd, int ha
   if (tmp[0] * tmp[0] + tmp[1] * tmp[1] > sqrad && (!has_side || sd[0] * tmp[0] + sd[1] * tmp[1] >= 0)) return -1;
   T sol[2][4], good[2];
   const T sqrt0 = sqrt(sqlen0 - sqrad), sqrt1 = sqrt(sqlen1 - sqrad);
+  const T inv0 = 1 / sqlen0, inv1 = 1 / sqlen1;     // one reciprocal per end point instead of eight divisions
   for (int i = 0; i < 2; ++i) {
     const T sgn = (i == 0) ? (T)1 : (T)-1;
-    sol[i][0] = (dd[0] * sqrad + sgn * rad * dd[1] * sqrt0) / sqlen0;
-    sol[i][1] = (dd[1] * sqrad - sgn * rad * dd[0] * sqrt0) / sqlen0;
-    sol[i][2] = (dd[2] * sqrad - sgn * rad * dd[3] * sqrt1) / sqlen1;
-    sol[i][3] = (dd[3] * sqrad + sgn * rad * dd[2] * sqrt1) / sqlen1;
+    sol[i][0] = (dd[0] * sqrad + sgn * rad * dd[1] * sqrt0) * inv0;
+    sol[i][1] = (dd[1] * sqrad - sgn * rad * dd[0] * sqrt0) * inv0;
+    sol[i][2] = (dd[2] * sqrad - sgn * rad * dd[3] * sqrt1) * inv1;
+    sol[i][3] = (dd[3] * sqrad + sgn * rad * dd[2] * sqrt1) * inv1;
     if (has_side) {
-      T t[2] = {sol[i][0] + sol[i][2], sol[i][1] + sol[i][3]};
+      const T t[2] = {sol[i][0] + sol[i][2], sol[i][1] + sol[i][3]};
       const T n = sqrt(t[0] * t[0] + t[1] * t[1]);
-      if (n < MYO_MINVAL) { t[0] = 1; t[1] = 0; } else { t[0] /= n; t[1] /= n; }
-      good[i] = t[0] * sd[0] + t[1] * sd[1];
+      good[i] = n < MYO_MINVAL ? sd[0] : (t[0] * sd[0] + t[1] * sd[1]) / n;      // (t / |t|) . sd
     } else {
       const T t[2] = {sol[i][0] - sol[i][2], sol[i][1] - sol[i][3]};
       good[i] = -(t[0] * t[0] + t[1] * t[1]);
@@ -623,7 +626,7 @@ DEV T wrap_geom(T* wpnt, const T* x0, const T* x1, const T* gpos, const T* gmat,
   mulmatTvec3(p0, gmat, t);
   for (int k = 0; k < 3; ++k) t[k] = x1[k] - gpos[k];
   mulmatTvec3(p1, gmat, t);
-  if (norm3(p0) < MYO_MINVAL || norm3(p1) < MYO_MINVAL) return -1;
+  if (dot3(p0, p0) < MYO_MINVAL * MYO_MINVAL || dot3(p1, p1) < MYO_MINVAL * MYO_MINVAL) return -1;   // |p| < mjMINVAL without the roots
   T axis0[3], axis1[3];
   if (type == 4) {
     T normal[3];
@@ -653,8 +656,7 @@ DEV T wrap_geom(T* wpnt, const T* x0, const T* x1, const T* gpos, const T* gmat,
     mulmatTvec3(ps, gmat, t);
     sd[0] = dot3(ps, axis0); sd[1] = dot3(ps, axis1);
     const T n = sqrt(sd[0] * sd[0] + sd[1] * sd[1]);
-    if (n < MYO_MINVAL) { sd[0] = 1; sd[1] = 0; } else { sd[0] /= n; sd[1] /= n; }
-    sd[0] *= radius; sd[1] *= radius;
+    if (n < MYO_MINVAL) { sd[0] = radius; sd[1] = 0; } else { const T sc = radius / n; sd[0] *= sc; sd[1] *= sc; }
   }
   T pnt[4];
   T wlen = wrap_circle(pnt, s2, sd, has_side, radius);
@@ -664,8 +666,9 @@ DEV T wrap_geom(T* wpnt, const T* x0, const T* x1, const T* gpos, const T* gmat,
   if (type == 5) {
     const T L0 = sqrt((s2[0] - pnt[0]) * (s2[0] - pnt[0]) + (s2[1] - pnt[1]) * (s2[1] - pnt[1]));
     const T L1 = sqrt((s2[2] - pnt[2]) * (s2[2] - pnt[2]) + (s2[3] - pnt[3]) * (s2[3] - pnt[3]));
-    r0[2] = p0[2] + (p1[2] - p0[2]) * L0 / (L0 + wlen + L1);
-    r1[2] = p0[2] + (p1[2] - p0[2]) * (L0 + wlen) / (L0 + wlen + L1);
+    const T dz = (p1[2] - p0[2]) / (L0 + wlen + L1);
+    r0[2] = p0[2] + dz * L0;
+    r1[2] = p0[2] + dz * (L0 + wlen);
     const T height = fabs(r1[2] - r0[2]);
     wlen = sqrt(wlen * wlen + height * height);
   }

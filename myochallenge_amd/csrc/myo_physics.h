@@ -1252,15 +1252,18 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
     }
     invd = (T)1 / s.H[MYO_HIDX(row, row)];
   }
-  // forward substitution  L y = b   (lane j finishes at step j; later steps must not touch it)
+  // forward substitution  L y = b.  Lane j's b is complete when step j starts (every k < j has been subtracted); it keeps
+  // the unscaled value and y_j = b_j / L_jj is formed for the broadcast only — the lane's own scaling happens once, after
+  // the loop (the same product, so the same bits), which takes a compare + select out of each of the N serial steps
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     MYO_OPAQUE_LANE(l)
     const T aj = (j & 1) ? a2[j / 2].y : a2[j / 2].x;
     const T yj = lane_bcast<T>(b * invd, j);
-    b = (l == j) ? yj : ((l > j) ? b - aj * yj : b);
+    b = (l > j) ? b - aj * yj : b;
     __builtin_amdgcn_sched_barrier(0);
   }
+  b *= invd;
   // lane i needs column i of L for the backward substitution (L is in H)
   T c[N];
 #pragma unroll
@@ -1272,11 +1275,11 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   // backward substitution  L' x = y
 #pragma unroll
   for (int j = N - 1; j >= 0; --j) {
-    MYO_OPAQUE_LANE(l)
     const T xj = lane_bcast<T>(b * invd, j);
-    b = (l == j) ? xj : b - c[j] * xj;                // c[j] = 0 for lanes >= j
+    b = b - c[j] * xj;                                // c[j] = 0 for lanes >= j: they keep their (unscaled) value
     __builtin_amdgcn_sched_barrier(0);
   }
+  b *= invd;
   if (lane < n) x[lane] = b;
   __syncthreads();
 }

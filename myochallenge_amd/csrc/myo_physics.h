@@ -1098,15 +1098,17 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
     // barrier is needed between the write and the reads.
     T* colbuf0 = s.efc_jv;                             // >= 128 entries, free while a system is solved
     T* colbuf1 = s.efc_jv + 64;
-    V2 c2[N / 2], c2n[N / 2];
+    V2 cb2[2][N / 2];                                 // column k lives in cb2[k & 1] (compile-time parity: no copies between steps)
     colbuf0[lane] = a2[0].x;
     {
       const V2* cb = reinterpret_cast<const V2*>(colbuf0);
 #pragma unroll
-      for (int p = 0; p < N / 2; ++p) c2[p] = cb[p];
+      for (int p = 0; p < N / 2; ++p) cb2[0][p] = cb[p];
     }
 #pragma unroll
     for (int k = 0; k < N; ++k) {
+      V2* const c2 = cb2[k & 1];
+      V2* const c2n = cb2[(k + 1) & 1];
       const T ak = (k & 1) ? a2[k / 2].y : a2[k / 2].x;
       T akk = (k & 1) ? c2[k / 2].y : c2[k / 2].x;
       akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
@@ -1128,10 +1130,6 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
       {
         MYO_OPAQUE_LANE(l)
         if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
-      }
-      if (k + 1 < N) {
-#pragma unroll
-        for (int p = p1; p < N / 2; ++p) c2[p] = c2n[p];
       }
     }
     // transpose through LDS: lane i needs column i of L for the backward substitution

@@ -41,6 +41,7 @@ typedef double HP;
 
 // Stage timers: compiled only into the diagnostic build (-DMYO_PROF, libmyobatch_prof.so); the
 // product build contains no stamp.  Lane 0 accumulates s_memtime deltas per stage in LDS.
+#define MYO_NPROF 24
 #if defined(MYO_PROF) && !defined(MYO_EMU)
 #define PROF(s, k) { if (threadIdx.x == 0) { unsigned long long _t = clock64(); (s).prof[k] += _t - (s).prof_t; (s).prof_t = _t; } }
 #else
@@ -141,7 +142,7 @@ struct Scratch {
   // ---- task layer
   T rwd[8];
 #ifdef MYO_PROF
-  unsigned long long prof[16], prof_t;
+  unsigned long long prof[MYO_NPROF], prof_t;
 #endif
 };
 
@@ -2354,16 +2355,21 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
   com_pos(M, K, s);
   PROF(s, 2)
   tendon(M, K, s);
+  PROF(s, 16)
   for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);
+  PROF(s, 17)
   tendon_lengths(M, K, s);
   PROF(s, 3)
   crb(M, s);
   PROF(s, 4)
   constraint_limits(M, K, s);
+  PROF(s, 18)
   for (int base = 0; base < M.npair; base += 64) collision_pass(M, K, s, base);
   PROF(s, 5)
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
+  PROF(s, 19)
   fwd_velocity(M, K, s);
+  PROF(s, 20)
   efc_reference(M, s);
   PROF(s, 6)
   fwd_actuation(M, s);

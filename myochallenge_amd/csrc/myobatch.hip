@@ -713,11 +713,11 @@ extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
 #ifndef MYO_EMU
 #define MYO_LDS_ALIGN(n) (((n) + 15) / 16 * 16)
 #ifdef MYO_PROF
-__device__ unsigned long long g_prof[16];
-extern "C" int myo_debug_read_prof(double* out16, int reset) {
-  unsigned long long h[16];
+__device__ unsigned long long g_prof[MYO_NPROF];
+extern "C" int myo_debug_read_prof(double* out16, int reset) {     /* out16: MYO_NPROF (24) doubles */
+  unsigned long long h[MYO_NPROF];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof h) != hipSuccess) return -1;
-  for (int k = 0; k < 16; ++k) out16[k] = (double)h[k];
+  for (int k = 0; k < MYO_NPROF; ++k) out16[k] = (double)h[k];
   if (reset) { memset(h, 0, sizeof h); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof h); }
   return 0;
 }
@@ -732,14 +732,14 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
 #ifdef MYO_PROF
-  if (threadIdx.x == 0) { for (int k = 0; k < 16; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
+  if (threadIdx.x == 0) { for (int k = 0; k < MYO_NPROF; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
   __syncthreads();
 #endif
   env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
 #ifdef MYO_PROF
   PROF(s, 0)
   __syncthreads();
-  if (threadIdx.x < 16) atomicAdd(&g_prof[threadIdx.x], s.prof[threadIdx.x]);
+  if (threadIdx.x < MYO_NPROF) atomicAdd(&g_prof[threadIdx.x], s.prof[threadIdx.x]);
 #endif
 }
 template <typename T, bool RK>

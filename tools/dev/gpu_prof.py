@@ -6,8 +6,9 @@ from myochallenge_amd import native
 from myochallenge_amd.envs.config import make_task_cfg
 from myochallenge_amd.model import compile_model
 from myochallenge_amd.synth_hand import synthetic_hand
-names = ["newton Mv,Jv products (+load/store)", "kinematics", "com_pos + newton Mv/Jv products", "tendon", "crb", "collision+constraint", "velocity", "actuation",
-         "qacc_smooth(chol)", "hessian", "newton chol", "newton rest", "euler implicit chol", "advance", "newton line search", "check/misc"]
+names = ["newton Mv,Jv products (+load/store)", "kinematics", "com_pos + newton Mv/Jv products", "tendon C: lengths / moments", "crb", "collision", "constraint reference (aref)", "actuation",
+         "qacc_smooth(chol)", "hessian", "newton chol", "newton rest", "euler implicit chol", "advance", "newton line search", "check/misc",
+         "tendon A: path points", "tendon B: geom wraps", "joint / tendon limits", "body velocities", "velocity: RNE + passive", "-", "-", "-"]
 import os
 lib = native.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyobatch_prof.so"))
 dev = torch.device("cuda:0")
@@ -22,7 +23,7 @@ for integ in (0,):
     for _ in range(3):
         b.step(torch.clamp(torch.randn((N, 39), device=dev) * 0.135, -1, 1), obs, rew, done)
     torch.cuda.synchronize()
-    out = (C.c_double * 16)(); lib.L.myo_debug_read_prof(out, 1)
+    out = (C.c_double * 24)(); lib.L.myo_debug_read_prof(out, 1)
     K = 5; t0 = time.time()
     for _ in range(K):
         b.step(torch.clamp(torch.randn((N, 39), device=dev) * 0.135, -1, 1), obs, rew, done)

@@ -420,6 +420,38 @@ def test_main_eval_runs_reference_checkpoint_on_gpu(hip_lib, golden_dir):
     assert np.array_equal(res["lengths"], res2["lengths"]) and np.allclose(res["returns"], res2["returns"], rtol=1e-5)
 
 
+def test_reference_checkpoint_forward_on_gpu_matches_goldens(hip_lib, golden_dir):
+    """The reference's own LSTM-128 policy (phase1_final.zip) evaluated ON THE DEVICE — the GEMM + gate formulation the batched
+    evaluation and the recurrent rollout use there — against tests/golden/phase1_policy_io.npz (stock torch nn.LSTM / nn.Linear
+    on the CPU, from the same state_dict): action mean, value, log-prob, both LSTM states; two chained steps to cover the state
+    hand-over and an episode start in between."""
+    import os
+    import torch
+    from myochallenge_amd.rl.sb3_zip import load_policy
+    pol, _ = load_policy(os.path.join(golden_dir, "phase1_final.zip"))
+    g = np.load(os.path.join(golden_dir, "phase1_policy_io.npz"))
+    dev = torch.device("cuda:0")
+    pol.to(dev)
+    obs = torch.tensor(g["last_obs"], device=dev)
+    with torch.no_grad():
+        a, v, lp, st2 = pol.act(obs, pol.initial_state(16, dev), torch.zeros(16, device=dev), deterministic=True)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(a.cpu().numpy(), g["mean"], atol=2e-5)
+        np.testing.assert_allclose(v.cpu().numpy(), g["value"][:, 0], atol=2e-5)
+        np.testing.assert_allclose(lp.cpu().numpy(), g["logp_of_mean"], atol=2e-3)
+        np.testing.assert_allclose(st2[0][0].cpu().numpy(), g["h_actor"], atol=2e-5)
+        np.testing.assert_allclose(st2[3][0].cpu().numpy(), g["c_critic"], atol=2e-5)
+        # second step from the carried state == the CPU policy doing the same; an episode start resets the state of its rows
+        starts = torch.zeros(16, device=dev); starts[::2] = 1
+        a2, v2, _, _ = pol.act(obs, st2, starts, deterministic=True)
+        cpu_pol, _ = load_policy(os.path.join(golden_dir, "phase1_final.zip"))
+        ca, cv, _, cst = cpu_pol.act(obs.cpu(), cpu_pol.initial_state(16, "cpu"), torch.zeros(16), deterministic=True)
+        ca2, cv2, _, _ = cpu_pol.act(obs.cpu(), cst, starts.cpu(), deterministic=True)
+        np.testing.assert_allclose(a2.cpu().numpy(), ca2.numpy(), atol=5e-5)
+        np.testing.assert_allclose(v2.cpu().numpy(), cv2.numpy(), atol=5e-5)
+        assert float((a2[::2].cpu() - ca[::2]).abs().max()) < 5e-5               # reset rows repeat the first step
+
+
 def _graph_dp_worker(rank, world, port, out):
     import os
     import torch

@@ -132,6 +132,11 @@ class BaodingVecEnv:
                         self._ep, self._stream())
         return self._obs, self._rew, self._done, self._trunc, self._term, self._comps, self._ep
 
+    @property
+    def rwd_dict(self):
+        """The reward dictionary of the last step as device tensors [N] (what the reference's envs put into `info`)."""
+        return {k: self._comps[:, j] for j, k in enumerate(self.rwd_keys)}
+
     # ---------------------------------------------------------------- SB3 VecEnv protocol
     def reset(self) -> np.ndarray:
         return self.reset_tensor().cpu().numpy().copy()

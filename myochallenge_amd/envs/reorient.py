@@ -196,6 +196,11 @@ class ReorientVecEnv(BaodingVecEnv):
         self.goal_init_pos = torch.tensor(list(self._cfg.ro_goal_init_pos), dtype=torch.float64)
         self.goal_obj_offset = torch.tensor(list(self._cfg.ro_goal_obj_offset), dtype=torch.float64)
         self.physical_randomisation_applied = bool(self._cfg.ro_obj_size_change) or any(float(x) != 0 for x in self._cfg.obj_friction_change)
+        # the two shaping terms (pos_dist_diff, rot_dist_diff) enter `dense` on the device but are not among the 8 exported
+        # reward components; when somebody wants the full dictionary (TensorboardCallback, step_wait infos) the env keeps the
+        # previous step's distances and forms them on the side (one small state read per step)
+        self.track_rwd_dict = False
+        self._dists = self._diffs = None
 
     # ---- per-env task state (tests, logging): goal pose, shaping distances, the episode's die
     def task_state(self) -> dict:
@@ -205,6 +210,43 @@ class ReorientVecEnv(BaodingVecEnv):
         self.batch.get_task(ti, td, bd, self._stream())
         self.batch.object_friction(None, fr, self._stream())
         return dict(goal_pos=td[:, 0:3], goal_quat=td[:, 3:7], pos_dist=td[:, 7], rot_dist=td[:, 8], size_delta=bd[:, 8], friction=fr)
+
+    def _read_dists(self):
+        td = torch.zeros((self.num_envs, 9), dtype=torch.float64, device=self.device)
+        self.batch.get_task(None, td, None, self._stream())
+        return td[:, 7:9].clone()
+
+    def reset_tensor(self):
+        out = super().reset_tensor()
+        self._dists = None
+        return out
+
+    def step_tensor(self, actions):
+        if not self.track_rwd_dict:
+            return super().step_tensor(actions)
+        prev = self._read_dists() if self._dists is None else self._dists
+        out = super().step_tensor(actions)
+        self._diffs = prev + self._comps[:, :2].double()          # prev - new, with new = -comps[:, :2]
+        self._dists = self._read_dists()                          # after the step: reset distances where an episode ended
+        return out
+
+    @property
+    def rwd_dict(self):
+        """reorient.py:29-52's dictionary for the last step (tensors [N]); the *_diff entries need `track_rwd_dict`."""
+        d = {k: self._comps[:, j] for j, k in enumerate(self.rwd_keys)}
+        if self._diffs is not None:
+            d["pos_dist_diff"], d["rot_dist_diff"] = self._diffs[:, 0], self._diffs[:, 1]
+        return d
+
+    def step_wait(self):
+        self.track_rwd_dict = True                                # the numpy protocol reports the whole dictionary, like info.update(rwd_dict)
+        obs, rew, done, infos = super().step_wait()
+        if self._diffs is not None:
+            dh = self._diffs.cpu().numpy()
+            for i, info in enumerate(infos):
+                info["rwd_dict"].update(pos_dist_diff=float(dh[i, 0]), rot_dist_diff=float(dh[i, 1]))
+                info.update(info["rwd_dict"])                     # reorient.py:211
+        return obs, rew, done, infos
 
     def get_attr(self, attr_name, indices=None):
         idx = range(self.num_envs) if indices is None else indices

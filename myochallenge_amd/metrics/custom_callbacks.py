@@ -133,6 +133,8 @@ class TensorboardCallback:
 
     def __call__(self, algo) -> bool:
         env = algo.env.venv if hasattr(algo.env, "venv") else algo.env
+        if getattr(env, "track_rwd_dict", None) is False:      # die-reorient env: ask it to keep the shaping terms from now on
+            env.track_rwd_dict = True
         rd = getattr(env, "rwd_dict", None)
         if not rd:
             return True

@@ -105,6 +105,13 @@ def test_reorient_env_logic_on_emulation(emu_lib):
     p0 = sh.task_state()["pos_dist"].clone()
     _, r, *_ = sh.step_tensor(torch.zeros(3, 39))
     assert float((r.double() - (p0 - sh.task_state()["pos_dist"])).abs().max()) < 1e-6
+    # the numpy protocol reports the whole reward dictionary at the top level of info (reorient.py:211), shaping terms included
+    sh.reset()
+    for t in range(3):
+        _, r, _, infos = sh.step(np.zeros((3, 39), np.float32))
+        assert all(abs(infos[i]["pos_dist_diff"] - float(r[i])) < 1e-6 for i in range(3))
+        assert {"pos_dist", "rot_dist", "pos_dist_diff", "rot_dist_diff", "alive", "act_reg", "sparse", "solved", "done", "dense"} <= set(infos[0])
+    assert set(sh.rwd_dict) >= {"pos_dist_diff", "rot_dist_diff", "dense"} and sh.rwd_dict["dense"].shape == (3,)
     # RSI rewrites body_pos / body_quat of a free-jointed body, which MuJoCo never reads: the reference's episode starts from
     # the plain reset state, and so does ours (see the module docstring)
     rsi = mk(enable_rsi=True, rsi_distance_pos=0.0, rsi_distance_rot=0.0)

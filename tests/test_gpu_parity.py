@@ -793,3 +793,19 @@ def test_gsde_ppo_round_on_gpu(hip_lib):
         algo.train()
     after = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
     assert torch.isfinite(after).all() and not torch.equal(before, after) and float(algo.act_buf.abs().max()) > 0
+
+
+def test_training_entry_points_run_end_to_end(hip_lib, tmp_path):
+    """python -m myochallenge_amd.main_baoding / main_reorient (the counterparts of src/main_baoding.py and src/main_reorient.py) with
+    small budgets: envs, VecNormalize, callbacks (evaluation, checkpoint, reward-dictionary logging), MyoTrainer.train / save."""
+    import glob
+    import os
+    from myochallenge_amd import main_baoding, main_reorient
+    d1, d2 = str(tmp_path / "baoding"), str(tmp_path / "reorient")
+    main_baoding.main(["--num-envs", "256", "--timesteps", "17000", "--policy", "MlpPolicy", "--n-steps", "32", "--batch-size", "2048",
+                       "--eval-freq", "16384", "--save-freq", "16384", "--log-dir", d1])
+    main_reorient.main(["--num-envs", "128", "--timesteps", "17000", "--eval-freq", "16384", "--save-freq", "16384", "--log-dir", d2])
+    for d in (d1, d2):
+        names = [os.path.basename(p) for p in glob.glob(os.path.join(d, "**", "*"), recursive=True)]
+        assert any(n.endswith(".zip") for n in names) and any(n.endswith(".pkl") for n in names), names
+        assert "evaluations.npz" in names

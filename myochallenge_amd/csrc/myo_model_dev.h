@@ -36,7 +36,7 @@
   X(geom_bodyid) X(geom_priority) X(site_bodyid) X(tendon_adr) X(tendon_num) X(tendon_limited)   \
   X(wrap_type) X(wrap_objid) X(wrap_side) X(actuator_dyntype) X(actuator_gaintype)               \
   X(actuator_biastype) X(actuator_tendon) X(actuator_ctrllimited) X(actuator_forcelimited)       \
-  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk)
+  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk) X(te_i) X(tendon_eadr) X(tendon_enum)
 #define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask) X(act_dofmask) X(wr_mask) X(pc_mask)
 #define MYO_MODEL_REAL_ARRAYS(X)                                                                 \
   X(qpos0) X(qpos_spring) X(body_pos) X(body_quat) X(body_ipos) X(body_imat) X(body_mass)        \
@@ -47,7 +47,7 @@
   X(tendon_solimp_lim) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping)    \
   X(tendon_lengthspring) X(tendon_invweight0) X(wrap_prm) X(actuator_dynprm)                     \
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
-  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(wr_p) X(wr_m) X(pc_f)
+  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(wr_p) X(wr_m) X(pc_f) X(te_div)
 
 // geometry tables of the HP stages (kinematic chain, contact / limit distances, observation): fp64 copies in
 // every build, named h_<array> (the fp64 stepper's h_ tables are its ordinary tables)
@@ -78,7 +78,7 @@ struct MyoCArr {
 template <typename T>
 struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
   T timestep, tolerance, impratio, gravity[3], meaninertia;
   double h_timestep;            // the integration step of the HP state update
 #define X(n) MyoCArr<int> n;

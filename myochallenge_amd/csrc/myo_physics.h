@@ -701,7 +701,7 @@ DEV void tendon_segment_moment(const Scratch<T>& s, T* Jrow, unsigned long long 
     const T col[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
     const T v = dot3(col, u) * inv_div;
     const int slot = myo_popcll(tmask & ((1ull << d) - 1ull));
-    Jrow[slot] += on1 ? v : -v;
+    lds_add(Jrow + slot, on1 ? v : -v);             // several path elements (lanes) of one tendon add into its row
   }
 }
 
@@ -740,7 +740,9 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
   // limit-row and efc_* arrays (contiguous; constraint rows are only built after this stage).
   T* wp = S_TWP(s);
   HP* wres = S_TWRES(s, M.nwrap);
+  (void)wres;
   PHASE {
+    for (int i = lane; i < M.ntendon * MYO_TJ_MAX; i += 64) s.ten_J[i] = 0;     // phase C accumulates into it
     for (int w = lane; w < M.nwrap; w += 64) {
       const int body = M.wr_i[8 * w + 1];
       if (body >= 0) {
@@ -783,81 +785,84 @@ DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratc
   SYNC();
 }
 
-// phase C of the tendon stage (its own leaf function: the HP wrap solver of phase B and this walk together need
-// more registers than one allocation has)
+// phase C of the tendon stage: lengths and moment arms.  One lane per PATH ELEMENT (site -> site, or site -> wrap geom ->
+// site; the walk along each tendon is resolved on the host: te_i / te_div), 64 elements per call from kernel level (a
+// loop-free leaf, like the wrap pass).  A lane computes the HP length of its element into a staging slot and adds the
+// element's moment-arm contributions into its tendon's row of ten_J with LDS adds; tendon_length_sums then adds the
+// element lengths of each tendon in path order.  (The first version walked each tendon in one lane — 39 lanes chaining
+// ~5 elements of fp64 site positions, square roots and moment gathers: 15.6 k of the substep's 229 k cycles.)
+#define S_TELEN(s) (reinterpret_cast<HP*>((s).H + MYO_NB_MAX * 10))   /* behind cinert; crb / qfrc_* come after the tendon stage */
 template <typename T>
-DEVFN void tendon_lengths(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int base) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   (void)K;
   T* wp = S_TWP(s);
   HP* wres = S_TWRES(s, M.nwrap);
   PHASE {
-    const int t = lane;
-    if (t < M.ntendon) {
-      const int adr = M.tendon_adr[t], num = M.tendon_num[t];
+    const int e = base + lane;
+    if (e < M.nte) {
+      const int i0 = M.te_i[4 * e], iend = M.te_i[4 * e + 1], ig = M.te_i[4 * e + 2], t = M.te_i[4 * e + 3];
       const unsigned long long tmask = M.tendon_dofmask[t];
       T* J = s.ten_J + t * MYO_TJ_MAX;
-      for (int k = 0; k < MYO_TJ_MAX; ++k) J[k] = 0;
-      HP len = 0;
-      T divisor = 1;
-      int j = 0;
-      WrapRec<T> w0, w1, w2;
-      HP q0[3] = {0, 0, 0};                            // HP position of the site that starts the current path element
-      if (num > 0) { load_wrap(M, adr, w0); if (w0.body >= 0) wrap_point_hp(M, s, w0.body, M.h_wr_p + 4 * adr, q0); }
-      while (j < num - 1) {
-        load_wrap(M, adr + j + 1, w1);
-        const int have2 = (j + 2 < num);
-        if (have2) load_wrap(M, adr + j + 2, w2);
-        if (w0.type == 2 || w1.type == 2) {
-          if (w0.type == 2) divisor = w0.prm;
-          j++;
-          w0 = w1;
-          if (w0.body >= 0) wrap_point_hp(M, s, w0.body, M.h_wr_p + 4 * (adr + j), q0);
-          continue;
-        }
-        const int is_geom = (w1.type == 4 || w1.type == 5);
-        const WrapRec<T>& we = is_geom ? w2 : w1;      // the site that ends this path element
-        const int wend = adr + j + (is_geom ? 2 : 1);
-        // straight segments of this path element: site -> site, or site -> wrap point, (arc), wrap point -> site.
-        // Selected with scalars (no run-time indexed local arrays: they would live in private memory).
-        const T p0[3] = {wp[3 * (adr + j)], wp[3 * (adr + j) + 1], wp[3 * (adr + j) + 2]};
-        const T x1[3] = {wp[3 * wend], wp[3 * wend + 1], wp[3 * wend + 2]};
-        HP q1[3];
-        wrap_point_hp(M, s, we.body, M.h_wr_p + 4 * wend, q1);
-        HP wlen = -1, h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0};
-        if (is_geom) {
-          const HP* r = wres + 7 * M.wr_i[8 * (adr + j + 1) + 6];
-          wlen = r[0];
-          for (int e = 0; e < 3; ++e) { h0[e] = r[1 + e]; h1[e] = r[4 + e]; }
-        }
-        const T g0[3] = {(T)h0[0], (T)h0[1], (T)h0[2]}, g1[3] = {(T)h1[0], (T)h1[1], (T)h1[2]};
-        const bool wrapped = wlen >= 0;
-        const T inv_div = 1 / divisor;
-        for (int sg = 0; sg < 2; ++sg) {
-          if (sg == 1 && !wrapped) break;
-          const bool to_wrap = (sg == 0) && wrapped;          // this segment ends on the wrap geom
-          T pa[3], pb[3];
-          HP da[3];
-          for (int e = 0; e < 3; ++e) {
-            pa[e] = sg == 0 ? p0[e] : g1[e]; pb[e] = to_wrap ? g0[e] : x1[e];
-            da[e] = (to_wrap ? h0[e] : q1[e]) - (sg == 0 ? q0[e] : h1[e]);
-          }
-          const unsigned long long ma = sg == 0 ? w0.mask : w1.mask, mb = to_wrap ? w1.mask : we.mask;
-          const int ra = sg == 0 ? w0.root : w1.root, rb = to_wrap ? w1.root : we.root;
-          const int ba = sg == 0 ? w0.body : w1.body, bb = to_wrap ? w1.body : we.body;
-          T dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
-          const T dn = norm3(dif);
-          len += norm3(da) * (HP)inv_div;
-          if (ba != bb && dn > MYO_MINVAL) {
-            dif[0] /= dn; dif[1] /= dn; dif[2] /= dn;
-            tendon_segment_moment(s, J, tmask, ma, ra, pa, mb, rb, pb, dif, inv_div);
-          }
-          if (to_wrap) len += wlen * (HP)inv_div;
-        }
-        if (is_geom) { j += 2; w0 = w2; } else { j += 1; w0 = w1; }
-        q0[0] = q1[0]; q0[1] = q1[1]; q0[2] = q1[2];
+      const T inv_div = 1 / M.te_div[e];
+      const int is_geom = ig >= 0;
+      WrapRec<T> w0, w1, we;
+      load_wrap(M, i0, w0);
+      load_wrap(M, iend, we);
+      load_wrap(M, is_geom ? ig : i0, w1);
+      HP q0[3], q1[3];
+      wrap_point_hp(M, s, w0.body, M.h_wr_p + 4 * i0, q0);
+      wrap_point_hp(M, s, we.body, M.h_wr_p + 4 * iend, q1);
+      // straight segments of this path element: site -> site, or site -> wrap point, (arc), wrap point -> site.
+      // Selected with scalars (no run-time indexed local arrays: they would live in private memory).
+      const T p0[3] = {wp[3 * i0], wp[3 * i0 + 1], wp[3 * i0 + 2]};
+      const T x1[3] = {wp[3 * iend], wp[3 * iend + 1], wp[3 * iend + 2]};
+      HP wlen = -1, h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0};
+      if (is_geom) {
+        const HP* r = wres + 7 * M.wr_i[8 * ig + 6];
+        wlen = r[0];
+        for (int k = 0; k < 3; ++k) { h0[k] = r[1 + k]; h1[k] = r[4 + k]; }
       }
+      const T g0[3] = {(T)h0[0], (T)h0[1], (T)h0[2]}, g1[3] = {(T)h1[0], (T)h1[1], (T)h1[2]};
+      const bool wrapped = wlen >= 0;
+      HP len = 0;
+      for (int sg = 0; sg < 2; ++sg) {
+        if (sg == 1 && !wrapped) break;
+        const bool to_wrap = (sg == 0) && wrapped;          // this segment ends on the wrap geom
+        T pa[3], pb[3];
+        HP da[3];
+        for (int k = 0; k < 3; ++k) {
+          pa[k] = sg == 0 ? p0[k] : g1[k]; pb[k] = to_wrap ? g0[k] : x1[k];
+          da[k] = (to_wrap ? h0[k] : q1[k]) - (sg == 0 ? q0[k] : h1[k]);
+        }
+        const unsigned long long ma = sg == 0 ? w0.mask : w1.mask, mb = to_wrap ? w1.mask : we.mask;
+        const int ra = sg == 0 ? w0.root : w1.root, rb = to_wrap ? w1.root : we.root;
+        const int ba = sg == 0 ? w0.body : w1.body, bb = to_wrap ? w1.body : we.body;
+        T dif[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+        const T dn = norm3(dif);
+        len += norm3(da) * (HP)inv_div;
+        if (ba != bb && dn > MYO_MINVAL) {
+          dif[0] /= dn; dif[1] /= dn; dif[2] /= dn;
+          tendon_segment_moment(s, J, tmask, ma, ra, pa, mb, rb, pb, dif, inv_div);
+        }
+        if (to_wrap) len += wlen * (HP)inv_div;
+      }
+      S_TELEN(s)[e] = len;
+    }
+  }
+  SYNC();
+}
+template <typename T>
+DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  WAVE_FN
+  PHASE {
+    const int t = lane;
+    if (t < M.ntendon) {
+      const int e0 = M.tendon_eadr[t], n = M.tendon_enum[t];
+      HP len = 0;
+      for (int k = 0; k < n; ++k) len += S_TELEN(s)[e0 + k];
       s.ten_length[t] = len;
     }
   }
@@ -2358,7 +2363,8 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
   PROF(s, 16)
   for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);
   PROF(s, 17)
-  tendon_lengths(M, K, s);
+  for (int base = 0; base < M.nte; base += 64) tendon_element_pass(M, K, s, base);
+  tendon_length_sums(M, s);
   PROF(s, 3)
   crb(M, s);
   PROF(s, 4)

@@ -630,7 +630,8 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   com_pos(M, K, s);
   tendon(M, K, s);
   for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);
-  tendon_lengths(M, K, s);
+  for (int base = 0; base < M.nte; base += 64) tendon_element_pass(M, K, s, base);
+  tendon_length_sums(M, s);
   crb(M, s);
   constraint_limits(M, K, s);
   for (int base = 0; base < M.npair; base += 64) collision_pass(M, K, s, base);

@@ -57,7 +57,7 @@ extern "C" const char* myo_version(void) {
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
   MYO_MODEL_INT_ARRAYS(X)
@@ -277,6 +277,35 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   }
   m->ngw = (int)m->gw_elem.size();
   if (m->gw_elem.empty()) m->gw_elem.push_back(0);
+  // path elements, enumerated (the walk mj_tendon makes along each tendon, resolved once): element e runs from the site
+  // te_i[4e] to the site te_i[4e+1], around the wrap geom te_i[4e+2] (-1: straight), belongs to tendon te_i[4e+3] and
+  // counts with 1 / te_div[e] (the last pulley before it).  The tendon stage gives each element its own lane.
+  m->te_i.clear(); m->te_div.clear();
+  m->tendon_eadr.assign(m->ntendon, 0); m->tendon_enum.assign(m->ntendon, 0);
+  for (int t = 0; t < m->ntendon; ++t) {
+    const int adr = m->tendon_adr[t], num = m->tendon_num[t];
+    double divisor = 1.0;
+    m->tendon_eadr[t] = (int)m->te_div.size();
+    for (int j = 0; j < num - 1;) {
+      const int ty0 = m->wrap_type[adr + j], ty1 = m->wrap_type[adr + j + 1];
+      if (ty0 == MYO_WRAP_PULLEY || ty1 == MYO_WRAP_PULLEY) {
+        if (ty0 == MYO_WRAP_PULLEY) divisor = m->wrap_prm[adr + j];
+        j++;
+        continue;
+      }
+      const int is_geom = (ty1 == MYO_WRAP_SPHERE || ty1 == MYO_WRAP_CYLINDER);
+      LIM(is_geom && j + 2 >= num, "a tendon path ends on a wrap geom")
+      const int end = j + (is_geom ? 2 : 1);
+      m->te_i.push_back(adr + j); m->te_i.push_back(adr + end); m->te_i.push_back(is_geom ? adr + j + 1 : -1); m->te_i.push_back(t);
+      m->te_div.push_back(divisor);
+      j = end;
+    }
+    m->tendon_enum[t] = (int)m->te_div.size() - m->tendon_eadr[t];
+  }
+  m->nte = (int)m->te_div.size();
+  // element lengths are staged (HP) in the part of H that is free during the tendon stage (behind cinert)
+  LIM((size_t)m->nte * sizeof(double) > (size_t)(MYO_H_SIZE - MYO_NB_MAX * 10) * sizeof(float), "tendon path elements (length staging)")
+  if (m->te_div.empty()) { m->te_i.assign(4, 0); m->te_div.push_back(1.0); }
   // staging area of the tendon stage: T path points in con[], then (8-byte aligned) 7 HP wrap results per geom wrap,
   // running on through the limit-row and efc_* arrays up to efc_active
   LIM(((3 * (size_t)m->nwrap * sizeof(double) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
@@ -489,7 +518,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nq = m->nq; D.nv = m->nv; D.nu = m->nu; D.na = m->na; D.nbody = m->nbody; D.njnt = m->njnt; D.ngeom = m->ngeom;
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
-  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw;
+  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];

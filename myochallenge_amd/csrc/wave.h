@@ -57,6 +57,8 @@
     (total) = _t;                                    \
   }
 #define UNI(x) (x)
+// LDS accumulation by several lanes of a phase into one slot (the emulation runs the lanes one after the other)
+template <typename T> static inline void lds_add(T* p, T v) { *p += v; }
 static inline int myo_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #else
@@ -154,6 +156,12 @@ template <> __device__ __forceinline__ int myo_wave_sum<int>(int v) {
     (total) = __popcll(_m1) + __popcll(_m2);                                       \
   }                                                                                \
   __syncthreads();
+// LDS accumulation by several lanes of a phase into one slot: ds_add_f32 / ds_add_f64 without return value.  Lanes of one
+// instruction that hit the same slot are served in a fixed order by the LDS unit, so the sum is reproducible.
+template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
+  typedef __attribute__((address_space(3))) T* lds_p;
+  (void)__hip_atomic_fetch_add((lds_p)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ int myo_popcll(unsigned long long x) { return __popcll(x); }
 __device__ __forceinline__ int myo_ffsll(unsigned long long x) { return __ffsll((long long)x) - 1; }

@@ -530,3 +530,45 @@ def case_reorient(lib, dtype, tol, env_name="CustomMyoReorientP2", n=6, nsteps=3
     b.close()
     assert seen["drop"] >= 1 and seen["trunc"] >= n - 1, seen
     return seen
+
+
+def case_bad_state(lib, mj, dtype):
+    """A numerically blown-up env (MuJoCo: mj_checkPos / mj_checkVel / mj_checkAcc warn and reset the data) is not an error of
+    the batch: it ends its episode with done = 1, reward 0, zero reward components except `done`, finite terminal and returned
+    observations (the reset observation), bad_state = 1 — and the other envs of the batch do not notice."""
+    mem = Mem(lib)
+    cm, om, _ = oracle_for(mj)
+    n = 4
+    mk = lambda: native.Batch(native.Model(cm, lib), make_task_cfg("CustomMyoBaodingBallsP1", cm), n, 0, 5, dtype)
+    a_b, b_b = mk(), mk()                       # b is the clean twin
+    outs = []
+    for b in (a_b, b_b):
+        obs, rew, done, trunc = mem.zeros((n, 86), np.float32), mem.zeros(n, np.float32), mem.zeros(n, np.uint8), mem.zeros(n, np.uint8)
+        term, comps, ep, bad = mem.zeros((n, 86), np.float32), mem.zeros((n, 8), np.float32), mem.zeros((n, 2), np.float32), mem.arr(np.full(n, 7), np.uint8)
+        b.reset(None, obs)
+        b.set_bad_state_buffer(bad)
+        outs.append((obs, rew, done, trunc, term, comps, ep, bad))
+    qv = mem.zeros((n, om.nv)); a_b.get_state(None, qv)
+    h = mem.host(qv).copy(); h[1, 3] = 1e12; h[2, 30] = np.nan          # env 1: absurd finger velocity, env 2: NaN ball velocity
+    a_b.set_state(None, mem.arr(h), None, None)
+    rng = np.random.RandomState(0)
+    for t in range(3):
+        act = mem.arr(np.clip(rng.normal(0, 0.2, (n, 39)), -1, 1), np.float32)
+        for b, o in ((a_b, outs[0]), (b_b, outs[1])):
+            b.step(act, *o[:7])
+        A, B = [[mem.host(x).copy() for x in o] for o in outs]
+        for k in range(7):
+            assert np.isfinite(A[k]).all(), (t, k)
+        if t == 0:
+            assert list(A[7]) == [0, 1, 1, 0] and list(A[2]) == [0, 1, 1, 0] and list(A[3]) == [0, 0, 0, 0]
+            for e in (1, 2):
+                assert A[1][e] == 0 and np.array_equal(A[5][e], [0, 0, 0, 0, 0, 0, 1, 0])
+                assert np.array_equal(A[4][e], A[0][e])                                               # terminal = returned observation ...
+                assert abs(A[0][e][0] + 1.57) < 1e-6 and np.abs(A[0][e][1:23]).max() == 0 and np.abs(A[0][e][47:]).max() == 0   # ... of a fresh episode
+                assert A[6][e][1] == 1                                                                       # Monitor: an episode of one step
+        else:
+            assert list(A[7]) == [0, 0, 0, 0]
+        for e in (0, 3):                                     # the healthy envs are bit-identical to the clean twin's
+            for k in range(7):
+                assert np.array_equal(A[k][e], B[k][e]), (t, e, k)
+    a_b.close(); b_b.close()

@@ -83,3 +83,8 @@ def test_step_inner_against_oracle(emu_lib, models):
 
 def test_p2_ball_physics_against_oracle(emu_lib, models):
     pc.case_p2_ball_physics(emu_lib, models["hand"], native.MYO_F64, 1e-9, nsteps=25)
+
+
+def test_blown_up_env_is_contained(emu_lib, models):
+    pc.case_bad_state(emu_lib, models["hand"], native.MYO_F64)
+    pc.case_bad_state(emu_lib, models["hand"], native.MYO_MIXED)

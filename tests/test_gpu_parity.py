@@ -88,6 +88,11 @@ def test_step_inner_against_oracle(hip_lib, models):
     pc.case_step_inner(hip_lib, models["hand"], native.MYO_MIXED, 1e-4)
 
 
+def test_blown_up_env_is_contained(hip_lib, models):
+    pc.case_bad_state(hip_lib, models["hand"], native.MYO_F64)
+    pc.case_bad_state(hip_lib, models["hand"], native.MYO_MIXED)
+
+
 def test_device_reset_agrees_with_reference_reset_goldens(hip_lib, models, golden_dir):
     pc.case_reset_goldens(hip_lib, models, golden_dir, native.MYO_F64)
     pc.case_reset_goldens(hip_lib, models, golden_dir, native.MYO_MIXED)

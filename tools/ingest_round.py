@@ -30,8 +30,9 @@ def main():
           "wait", new["SQ_WAIT_ANY"] / new["SQ_WAVE_CYCLES"])
     for a, b in (("pmc_kstep.txt", TAG + "_pmc_kstep_mixed_4096.txt"), ("pmc_gemm.txt", TAG + "_pmc_mfma_gemm.txt"),
                  ("stage_shares.txt", TAG + "_stage_shares.txt"), ("bench_kernel_stats.csv", TAG + "_bench_kernel_stats.csv"),
-                 ("drift.log", TAG + "_drift_32streams.log")):
-        shutil.copy(os.path.join(R, a), os.path.join(P, b))
+                 ("drift.log", TAG + "_drift_32streams.log"), ("pmc_mfma_kstep_f64.txt", TAG + "_pmc_mfma_kstep_f64.txt")):
+        if os.path.exists(os.path.join(R, a)):
+            shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}
     for k in ("f64", "rk4", "p2_8192", "rollout_only", "reorient_p2"):
         d = json.loads(open(os.path.join(R, f"bench_{k}.json")).read().strip().splitlines()[-1])

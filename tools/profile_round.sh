@@ -27,6 +27,10 @@ rm -rf /tmp/pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "Cijk" > $OUT/pmc_gemm.txt
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_gemm.txt
+# 3c. matrix cores in the fp64 stepper (blocked Cholesky)
+rm -rf /tmp/pmc
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 --dtype f64 > /tmp/pmc.log 2>&1
+python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" > $OUT/pmc_mfma_kstep_f64.txt
 # 4. stage shares (instrumented build; shares only)
 PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_prof.py > $OUT/stage_shares.txt 2>&1
 # 5. other configurations (BASELINE.json configs / variants)

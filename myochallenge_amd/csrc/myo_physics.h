@@ -75,6 +75,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   double ro_weights[9], ro_goal_pos[2], ro_goal_rot[2], ro_rot_choice[3][MYO_ROT_CHOICE_MAX][2];
   double ro_obj_size_change, ro_pos_th, ro_rot_th, ro_goal_init_pos[3], ro_goal_obj_offset[3];
   int ro_n_rot_choice[3], ro_obj_bid;
+  void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
   unsigned long long seed;
 };
 
@@ -88,10 +89,9 @@ struct ContactRec {
 };
 
 template <typename T>
-struct RkScratch {                // RK4 stage storage, only instantiated by the RK4 kernels
-  HP x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];
-  T F[4][2 * MYO_NV_MAX + MYO_NU_MAX];
-  T dX[2 * MYO_NV_MAX + MYO_NU_MAX];
+struct RkScratch {                // RK4 stage storage: one per env in GLOBAL memory (a batch of an RK4 model allocates it), touched
+  HP x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];      // a handful of times per substep — in LDS it cost the mixed stepper one of its
+  T F[4][2 * MYO_NV_MAX + MYO_NU_MAX];              // eight workgroups per CU (23.3 KB instead of 20.2 KB: three rounds for 4096 envs)
 };
 
 template <typename T>
@@ -177,11 +177,14 @@ template <typename T> DEV const T* S_XPOST(const Scratch<T>& s) { if constexpr (
 #define S_XIPOS(s) ((s).efc_force)
 #define S_NPRE(s) (reinterpret_cast<int*>((s).efc_force))
 #define S_CFRCB(s) ((s).bvec)
+// RK4's combined stage derivative (2 nv + nu numbers): in efc_jv, dead between two forward() calls (J v of the last line search)
+#define S_RKDX(s) ((s).efc_jv)
 #define S_CVEL(s) ((s).Ma)   /* body velocities (velocity stage) live in the solver vectors Ma,grad,search,Mv */
 static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_H_SIZE && MYO_NU_MAX <= MYO_NEFC_MAX, "H aliases");
 static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 1024 && MYO_NU_MAX <= 64, "packed actuator gather entries are 10 + 6 bits");
 static_assert(MYO_NV_MAX * 6 <= MYO_NB_MAX * 10, "cdof_dot fits where crb was");
 static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in Ma..Mv");
+static_assert(2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MAX, "the RK4 stage derivative fits in efc_jv");
 static_assert(MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX && 64 <= MYO_NEFC_MAX, "efc aliases");
 static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRec<float>), "kinematics temporaries fit in con[]");
 
@@ -2478,14 +2481,14 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
     for (int st = 1; st < 4; ++st) {
       const T a = (st == 3) ? (T)1 : (T)0.5;
       PHASE {
-        for (int i = lane; i < nf; i += 64) s.rk->dX[i] = a * s.rk->F[st - 1][i];
+        for (int i = lane; i < nf; i += 64) S_RKDX(s)[i] = a * s.rk->F[st - 1][i];
         for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       }
       SYNC();
-      integrate_pos(M, s, LOFF(s, s.rk->dX), h);
+      integrate_pos(M, s, LOFF(s, S_RKDX(s)), h);
       PHASE {
-        for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * (HP)s.rk->dX[nv + i];
-        for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i] + h * (HP)s.rk->dX[2 * nv + i];
+        for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * (HP)S_RKDX(s)[nv + i];
+        for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i] + h * (HP)S_RKDX(s)[2 * nv + i];
         if (lane == 0) s.time = t0 + h * (HP)a;
       }
       SYNC();
@@ -2498,14 +2501,14 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
     }
     PHASE {
       for (int i = lane; i < nf; i += 64)
-        s.rk->dX[i] = (s.rk->F[0][i] + 2 * s.rk->F[1][i] + 2 * s.rk->F[2][i] + s.rk->F[3][i]) / 6;
+        S_RKDX(s)[i] = (s.rk->F[0][i] + 2 * s.rk->F[1][i] + 2 * s.rk->F[2][i] + s.rk->F[3][i]) / 6;
       for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i];
       for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i];
       if (lane == 0) s.time = t0;
     }
     SYNC();
-    advance(M, s, LOFF(s, s.rk->dX + 2 * nv), LOFF(s, s.rk->dX + nv), LOFF(s, s.rk->dX));
+    advance(M, s, LOFF(s, S_RKDX(s) + 2 * nv), LOFF(s, S_RKDX(s) + nv), LOFF(s, S_RKDX(s)));
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
     load_H_from_M(M, s, (const T*)M.dof_damping, M.timestep);

@@ -696,6 +696,13 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   if (!rc) rc |= be_h2d(p, host.data(), host.size() * sizeof(double));
   b->rec = (double*)p;
   b->allocs.push_back(p);
+  if (m->integrator == 1) {        // RK4 stage storage, one RkScratch per env (global memory)
+    void* w = nullptr;
+    const size_t each = dtype == MYO_F64 ? sizeof(RkScratch<double>) : sizeof(RkScratch<float>);
+    rc |= be_malloc(&w, each * (size_t)n_envs);
+    b->K.rk_ws = w;
+    if (w) b->allocs.push_back(w);
+  }
 #ifndef MYO_EMU
   if (!rc) { rc |= (int)hipEventCreate(&b->ev0); rc |= (int)hipEventCreate(&b->ev1); }
 #endif
@@ -724,9 +731,7 @@ extern "C" int myo_batch_num_envs(const myo_batch* b) { return b ? b->n : -1; }
 extern "C" int myo_batch_obs_dim(const myo_batch* b) { return b ? b->nobs : -1; }
 extern "C" int myo_batch_lds_bytes(const myo_batch* b) {
   if (!b) return -1;
-  const int rk = b->integrator == 1;
-  return b->dtype == MYO_F64 ? (int)(sizeof(Scratch<double>) + rk * sizeof(RkScratch<double>))
-                             : (int)(sizeof(Scratch<float>) + rk * sizeof(RkScratch<float>));
+  return b->dtype == MYO_F64 ? (int)sizeof(Scratch<double>) : (int)sizeof(Scratch<float>);      // RK4 stage storage is in global memory
 }
 extern "C" int myo_batch_dump_size(const myo_batch* b) { return b ? b->D.total : -1; }
 extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
@@ -756,7 +761,7 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -775,7 +780,7 @@ template <typename T, bool RK>
 __global__ void __launch_bounds__(64, 2) k_reset(EnvRecordLayout L, double* rec,
                                               const unsigned char* mask, float* obs) {
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -785,7 +790,7 @@ template <typename T, bool RK>
 __global__ void __launch_bounds__(64, 2) k_step_inner(EnvRecordLayout L, double* rec, const unsigned char* mask, const float* act,
                                                    float* obs, unsigned char* done) {
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -795,7 +800,7 @@ template <typename T, bool RK>
 __global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* rec,
                                                 const double* ctrl, int nsub) {
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -805,7 +810,7 @@ template <typename T, bool RK>
 __global__ void __launch_bounds__(64, 2) k_dump(EnvRecordLayout L, double* rec, const double* ctrl,
                                              DumpLayout D, double* out) {
   Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T>))) : nullptr;
+  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -844,14 +849,13 @@ static void timing_end(myo_batch* b, hipStream_t st) {
 
 #ifndef MYO_EMU
 static unsigned lds_dyn(const myo_batch* b) {
-  const int rk = b->integrator == 1;
 #ifdef MYO_LDS_PAD_EXPERIMENT
   static int pad = -1;
   if (pad < 0) { const char* e = getenv("MYO_LDS_PAD"); pad = e ? atoi(e) : 0; }
-  if (b->dtype != MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + rk * sizeof(RkScratch<float>) + pad);
+  if (b->dtype != MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + pad);
 #endif
-  if (b->dtype == MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<double>)) + rk * sizeof(RkScratch<double>));
-  return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + rk * sizeof(RkScratch<float>));
+  if (b->dtype == MYO_F64) return (unsigned)MYO_LDS_ALIGN(sizeof(Scratch<double>));
+  return (unsigned)MYO_LDS_ALIGN(sizeof(Scratch<float>));
 }
 #define BIND_OR_RETURN(b, st) DeviceGuard _guard((b)->device); { int _rc = bind_constants(b, st); if (_rc) return _rc; }
 #endif

@@ -107,7 +107,7 @@ def test_reset_logic(hip_lib, models):
     pc.case_reset_logic(hip_lib, models, native.MYO_MIXED)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("dtype", ["mixed", "f64"])
 def test_full_size_properties(hip_lib, dtype):
     """BASELINE config B size (4096 envs): size-independent invariants over a rollout with
     auto-resets: finite obs, activations in [0, sigmoid32(2.5)], err = target - object,

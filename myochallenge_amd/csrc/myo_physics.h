@@ -1098,6 +1098,38 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
 #pragma unroll
       for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
     }
+#ifdef MYO_CHOL_READLANE
+    // fp32: one column per step, the column broadcast with v_readlane into SGPRs (no LDS round trip on the serial chain):
+    // step k reads a_jk of the lanes j > k (one v_readlane each) and every lane updates its row with v_pk_fma_f32 taking the
+    // SGPR pair as an operand.  Same arithmetic (same bits) as the LDS column exchange it replaces.
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      const T ak = (k & 1) ? a2[k / 2].y : a2[k / 2].x;
+      T akk = lane_bcast<T>(ak, k);
+      akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
+      const T inv = myo_rsqrt(akk);
+      const T lik = ak * inv;                           // lane k: akk / sqrt(akk) = sqrt(akk)
+      const T m1 = -lik * inv;
+      const V2 m = V2{m1, m1};
+      if (k + 1 < N) {
+        int p0 = (k + 1) / 2;
+        if ((k + 1) & 1) {                              // column k+1 is the .y of the pair that also holds column k
+          a2[p0].y = __builtin_fmaf(m1, lane_bcast<T>(ak, k + 1), a2[p0].y);
+          p0++;
+        }
+#pragma unroll
+        for (int p = p0; p < N / 2; ++p) {
+          const V2 c = V2{lane_bcast<T>(ak, 2 * p), lane_bcast<T>(ak, 2 * p + 1)};
+          a2[p] = __builtin_elementwise_fma(m, c, a2[p]);
+        }
+      }
+      if (k & 1) a2[k / 2].y = lik; else a2[k / 2].x = lik;
+      {
+        MYO_OPAQUE_LANE(l)
+        if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
+      }
+    }
+#else
     // fp32: one column per step.  (The two-column scheme below is 14 % faster end to end in fp64, where the
     // factorisation is a quarter of the kernel, but measured 2.6 % SLOWER in fp32: its serial 2x2 pivot chain
     // outweighs the saved round trips once the per-column exchange is already pipelined.)
@@ -1141,6 +1173,7 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
         if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
       }
     }
+#endif
     // transpose through LDS: lane i needs column i of L for the backward substitution
     if (lane < N) {
       V4* hw = reinterpret_cast<V4*>(s.H + myo_hrow(lane));

@@ -77,6 +77,20 @@ def test_episode_trajectory_mixed(emu_lib, models):
     pc.case_episode_trajectory(emu_lib, models["hand"], native.MYO_MIXED, [(0.08, 0), (0.135, 0)], 1e-4)
 
 
+def test_episode_trajectory_rk4_mixed(emu_lib, models):
+    """The mixed stepper with RK4 (the `variants.rk4` bench path): lane-serial build vs oracle, whole episodes."""
+    r = pc.episode_drift(emu_lib, models["hand"], native.MYO_MIXED, [(0.08, 0), (0.08, 4), (0.135, 0), (0.135, 2)], 200, integrator=1)
+    assert r["err_qpos_rel"].max() <= 1e-4 and r["err_obs_abs"].max() <= 1e-4, (r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
+
+
+@pytest.mark.parametrize("dtype,tol", [(native.MYO_F64, 1e-9), (native.MYO_MIXED, 1e-4)])
+def test_episode_trajectory_config_c(emu_lib, models, dtype, tol):
+    """Config C (P2 registration defaults, randomised resets) over whole episodes, oracle twin re-synchronised at every reset."""
+    r = pc.episode_drift(emu_lib, models["hand"], dtype, [(0.08, 0), (0.135, 1), (0.135, 2)], 200, env_name="CustomMyoBaodingBallsP2", resync=True)
+    assert all(x is None for x in r["episode_end_disagreement_at"]) and sum(len(e) for e in r["episode_ends"]) >= 3
+    assert r["err_qpos_rel"].max() <= tol and r["err_obs_abs"].max() <= max(tol, 1e-7), (r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
+
+
 def test_step_inner_against_oracle(emu_lib, models):
     pc.case_step_inner(emu_lib, models["hand"], native.MYO_F64, 1e-9)
 

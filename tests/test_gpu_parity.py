@@ -77,6 +77,42 @@ def test_episode_trajectory_mixed(hip_lib, models):
     assert int(((mq <= 1e-4) & (mo <= 1e-4)).sum()) >= 10, (mq, mo)
 
 
+def _mixed_bounds(r, first=60, first_tol=1e-4):
+    """the three asserts of the mixed stepper (see test_episode_trajectory_mixed)"""
+    mq, mo = r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1)
+    n = len(mq)
+    assert r["err_qpos_rel"][:, :first].max() <= first_tol and r["err_obs_abs"][:, :first].max() <= first_tol, (r["err_qpos_rel"][:, :first].max(1),)
+    assert np.median(mq) <= 1e-4 and np.median(mo) <= 1e-4, (mq, mo)
+    assert int(((mq <= 1e-4) & (mo <= 1e-4)).sum()) >= (10 * n + 15) // 16, (mq, mo)
+
+
+def test_episode_trajectory_rk4_mixed(hip_lib, models):
+    """The `variants.rk4` bench path (MYO_MIXED + mj_RungeKutta, north_star names RK4): the same 16 streams x 200 env steps as
+    the Euler mixed test.  Bounds: median over streams of the 200-step maximum <= 1e-4; >= 10 of 16 streams <= 1e-4 at every
+    step; every stream <= 2e-4 over the first 60 env steps (on the lane-serial build one stream sits at 1.07e-4 there after a
+    contact event at step 30 — the Euler stepper's first-60 bound of 1e-4 is not claimed for RK4).
+    Record: gpurun_out/drift_rk4_mixed.json -> profiles/r03_drift_rk4_mixed.json."""
+    r = pc.episode_drift(hip_lib, models["hand"], native.MYO_MIXED, STREAMS16, 200, integrator=1)
+    pc.write_drift_record(r, PROFILES + "_rk4_mixed.json", "mixed", "RK4", 200)
+    _mixed_bounds(r, first_tol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+def test_episode_trajectory_config_c(hip_lib, models, dtype):
+    """BASELINE config C (CustomMyoBaodingBallsP2 at its registration defaults: random task incl. HOLD, goal radii / period,
+    ball mass / friction / size drawn at every reset): whole episodes with their auto-resets, the oracle twin re-built from the
+    device's draws after every reset (episode_drift(resync=True)).  fp64: 1e-9 at every step; mixed: the mixed stepper's bounds."""
+    dt = native.MYO_F64 if dtype == "f64" else native.MYO_MIXED
+    r = pc.episode_drift(hip_lib, models["hand"], dt, STREAMS16, 200, env_name="CustomMyoBaodingBallsP2", resync=True)
+    pc.write_drift_record(r, PROFILES + "_configC_%s.json" % dtype, dtype, "Euler", 200)
+    assert sum(len(e) for e in r["episode_ends"]) >= 16
+    if dtype == "f64":
+        assert r["err_qpos_rel"].max() <= 1e-9 and r["err_obs_abs"].max() <= 1e-7, (r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
+        assert all(x is None for x in r["episode_end_disagreement_at"])
+    else:
+        _mixed_bounds(r)
+
+
 def test_p2_ball_physics_against_oracle(hip_lib, models):
     """BASELINE config C's physics (per-env ball mass / friction / size) against the oracle."""
     pc.case_p2_ball_physics(hip_lib, models["hand"], native.MYO_F64, 1e-9, nsteps=25, n=8)
@@ -109,7 +145,7 @@ def test_reset_logic(hip_lib, models):
 
 @pytest.mark.parametrize("dtype", ["mixed", "f64"])
 def test_full_size_properties(hip_lib, dtype):
-    """BASELINE config B size (4096 envs): size-independent invariants over a rollout with
+    """BASELINE config B / C size (4096 envs, P2 = the superset: P1's physics plus the randomised reset): size-independent invariants over a rollout with
     auto-resets: finite obs, activations in [0, sigmoid32(2.5)], err = target - object,
     unit quaternions, balls never interpenetrate by more than the soft-contact depth,
     bit-identical replay from the same seed."""

@@ -208,6 +208,46 @@ def test_reorient_against_oracle_on_gpu(hip_lib):
     pc.case_reorient(hip_lib, native.MYO_MIXED, 1e-4, n=16, nsteps=40)
 
 
+def _reorient_record(r, path, dtype_name, nsteps):
+    import parity_cases as pc
+    pc.write_drift_record(r, path, dtype_name, "Euler", nsteps)
+
+
+def test_reorient_whole_episode_drift_on_emulation(emu_lib):
+    """Whole 150-step episodes of the die-reorient env (config E's env side) on the lane-serial build: fp64 1e-9 at every step."""
+    from myochallenge_amd import native
+    import parity_cases as pc
+    r = pc.reorient_drift(emu_lib, native.MYO_F64, n=3, nsteps=160, horizon=150)
+    assert all(x is None for x in r["episode_end_disagreement_at"]) and sum(len(e) for e in r["episode_ends"]) >= 3
+    assert r["err_qpos_rel"].max() <= 1e-9 and r["err_obs_abs"].max() <= 2e-7, (r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["f64", "mixed"])
+def test_reorient_whole_episode_drift_on_gpu(hip_lib, dtype):
+    """BASELINE config E's env (CustomMyoReorientP2, horizon 150, frame_skip 5): 16 envs x 150 env steps, auto-resets included,
+    HIP vs oracle twins sharing each episode's draws.  fp64: 1e-9 / 2e-7 (float32 observation) at every step; mixed: the mixed
+    stepper's three bounds (first 60 steps all <= 1e-4; median of the per-stream maxima <= 1e-4; >= 10 of 16 streams <= 1e-4
+    throughout).  Record: gpurun_out/drift_configE_<dtype>.json -> profiles/r03_drift_configE_<dtype>.json."""
+    import os
+    import numpy as np
+    from myochallenge_amd import native
+    import parity_cases as pc
+    dt = native.MYO_F64 if dtype == "f64" else native.MYO_MIXED
+    r = pc.reorient_drift(hip_lib, dt, n=16, nsteps=150, horizon=150)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rec = dict(r); rec["streams"] = r["streams"]
+    pc.write_drift_record(rec, os.path.join(root, "gpurun_out", "drift_configE_%s.json" % dtype), dtype, "Euler (frame_skip 5, die reorient)", 150)
+    mq, mo = r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1)
+    if dtype == "f64":
+        assert mq.max() <= 1e-9 and mo.max() <= 2e-7, (mq, mo)
+        assert all(x is None for x in r["episode_end_disagreement_at"])
+    else:
+        assert r["err_qpos_rel"][:, :60].max() <= 1e-4 and r["err_obs_abs"][:, :60].max() <= 1e-4, (r["err_qpos_rel"][:, :60].max(1),)
+        assert np.median(mq) <= 1e-4 and np.median(mo) <= 1e-4, (mq, mo)
+        assert int(((mq <= 1e-4) & (mo <= 1e-4)).sum()) >= 10, (mq, mo)
+
+
 @pytest.mark.gpu
 def test_reorient_properties_at_4096_envs(hip_lib):
     """Size-independent properties of the die-reorient env at the batch size the bench uses: per-episode draws inside the

@@ -10,10 +10,10 @@ names = ["newton Mv,Jv products (+load/store)", "kinematics", "com_pos + newton 
          "qacc_smooth(chol)", "hessian", "newton chol", "newton rest", "euler implicit chol", "advance", "newton line search", "check/misc",
          "tendon A: path points", "tendon B: geom wraps", "joint / tendon limits", "body velocities", "velocity: RNE + passive", "-", "-", "-"]
 import os
-lib = native.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyobatch_prof.so"))
+lib = native.load(os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyobatch_prof.so"))
 dev = torch.device("cuda:0")
 for integ in (0,):
-  for dtype, dn in ((native.MYO_F32, "f32"), (native.MYO_F64, "f64")):
+  for dtype, dn in ((native.MYO_F32, "f32"), (native.MYO_F64, "f64"))[:(1 if len(sys.argv) > 3 and sys.argv[3] == "f32" else 2)]:
     cm = compile_model(synthetic_hand(), integrator=integ)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     b = native.Batch(native.Model(cm, lib), make_task_cfg("CustomMyoBaodingBallsP1", cm), N, 0, 1, dtype)

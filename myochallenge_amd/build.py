@@ -16,6 +16,16 @@ SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wa
 HEADERS = [os.path.join(ROOT, "include", "myobatch.h"), os.path.join(ROOT, "include", "myo_model_blob.h")]
 
 
+def source_id() -> str:
+    """Short hash of the native sources: compiled into the library (myo_version()) so that measured records
+    (profiles/*_pmc.json) can be matched to the build they were taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def _stale(target: str) -> bool:
     if not os.path.exists(target):
         return True
@@ -33,7 +43,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         # -fno-hip-fp32-correctly-rounded-divide-sqrt: 2.5-ulp fp32 div/sqrt (fewer VALU instructions;
         # the fp64 stepper is unaffected).  Parity tests run against this exact build.
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-               "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+               "-fno-hip-fp32-correctly-rounded-divide-sqrt", '-DMYO_BUILD_ID="%s"' % source_id(),
                os.path.join(CSRC, "myobatch.hip"), "-o", out]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
@@ -46,7 +56,7 @@ def build_emu(force: bool = False, sanitize: bool = False) -> str:
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "libmyobatch_emu_asan.so" if sanitize else "libmyobatch_emu.so")
     if force or _stale(out):
-        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DMYO_EMU", "-x", "c++",
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DMYO_EMU", '-DMYO_BUILD_ID="%s"' % source_id(), "-x", "c++",
                os.path.join(CSRC, "myobatch.hip"), "-o", out]
         if sanitize:
             cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]

@@ -53,7 +53,7 @@
 // every build, named h_<array> (the fp64 stepper's h_ tables are its ordinary tables)
 #define MYO_MODEL_HP_ARRAYS(X)                                                                   \
   X(qpos0) X(body_pos) X(body_quat) X(jnt_pos) X(jnt_axis) X(jnt_range) X(jnt_margin)            \
-  X(geom_pos) X(geom_mat) X(geom_size) X(geom_margin) X(geom_gap) X(site_pos) X(wr_p) X(wr_m)                      \
+  X(geom_pos) X(geom_mat) X(geom_size) X(geom_margin) X(geom_gap) X(geom_rbound) X(site_pos) X(wr_p) X(wr_m)       \
   X(actuator_lengthrange) X(actuator_gainprm) X(actuator_biasprm) X(tendon_range) X(tendon_margin)
 
 // Model table handle.  The tables are immutable for the lifetime of a batch, so the gfx950 build

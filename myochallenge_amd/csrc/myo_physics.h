@@ -1098,41 +1098,12 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
 #pragma unroll
       for (int q = 0; q < N / 4; ++q) { const V4 v = hr[q]; a2[2 * q] = V2{v.x, v.y}; a2[2 * q + 1] = V2{v.z, v.w}; }
     }
-#ifdef MYO_CHOL_READLANE
-    // fp32: one column per step, the column broadcast with v_readlane into SGPRs (no LDS round trip on the serial chain):
-    // step k reads a_jk of the lanes j > k (one v_readlane each) and every lane updates its row with v_pk_fma_f32 taking the
-    // SGPR pair as an operand.  Same arithmetic (same bits) as the LDS column exchange it replaces.
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      const T ak = (k & 1) ? a2[k / 2].y : a2[k / 2].x;
-      T akk = lane_bcast<T>(ak, k);
-      akk = akk < MYO_MINVAL ? MYO_MINVAL : akk;
-      const T inv = myo_rsqrt(akk);
-      const T lik = ak * inv;                           // lane k: akk / sqrt(akk) = sqrt(akk)
-      const T m1 = -lik * inv;
-      const V2 m = V2{m1, m1};
-      if (k + 1 < N) {
-        int p0 = (k + 1) / 2;
-        if ((k + 1) & 1) {                              // column k+1 is the .y of the pair that also holds column k
-          a2[p0].y = __builtin_fmaf(m1, lane_bcast<T>(ak, k + 1), a2[p0].y);
-          p0++;
-        }
-#pragma unroll
-        for (int p = p0; p < N / 2; ++p) {
-          const V2 c = V2{lane_bcast<T>(ak, 2 * p), lane_bcast<T>(ak, 2 * p + 1)};
-          a2[p] = __builtin_elementwise_fma(m, c, a2[p]);
-        }
-      }
-      if (k & 1) a2[k / 2].y = lik; else a2[k / 2].x = lik;
-      {
-        MYO_OPAQUE_LANE(l)
-        if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
-      }
-    }
-#else
     // fp32: one column per step.  (The two-column scheme below is 14 % faster end to end in fp64, where the
     // factorisation is a quarter of the kernel, but measured 2.6 % SLOWER in fp32: its serial 2x2 pivot chain
     // outweighs the saved round trips once the per-column exchange is already pipelined.)
+    // (Broadcasting column k with v_readlane into SGPR pairs instead — no LDS round trip on the chain, same bits — measured
+    // 1 % SLOWER end to end, 2.788 vs 2.761 ms at 4096 envs: 630 v_readlane + their SGPR hazard nops cost more issue slots
+    // than the LDS latency they remove costs a SIMD that has a second wave to run.)
     // Column exchange through LDS, software-pipelined: while the trailing update of step k is still
     // running, column k+1 (updated first) is already written and read back for step k+1.  Two buffers
     // alternate; a workgroup is one wavefront, so its LDS operations execute in program order and no
@@ -1173,7 +1144,6 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
         if (k == l) invd = inv;                        // 1/sqrt(pivot) = 1/L[k][k]
       }
     }
-#endif
     // transpose through LDS: lane i needs column i of L for the backward substitution
     if (lane < N) {
       V4* hw = reinterpret_cast<V4*>(s.H + myo_hrow(lane));
@@ -1395,6 +1365,15 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& 
   const HP s1[3] = {geom_size0_hp(M, K, s, g1), geom_size1_hp(M, K, s, g1), M.h_geom_size[3 * g1 + 2]};
   const HP s2[3] = {geom_size0_hp(M, K, s, g2), geom_size1_hp(M, K, s, g2), M.h_geom_size[3 * g2 + 2]};
   o.n = 0;
+  {
+    // mj_collideGeoms' bounding-sphere filter, EXACT (HP, the MODEL's rbound): with P2's per-episode ball radius above the
+    // nominal one (the reference never refreshes geom_rbound, baoding.py:586-604) this test, not the narrow phase, decides
+    // when a ball contact switches on — the caller's fp32 pre-filter only rejects pairs that are clearly apart
+    const HP rb1 = M.h_geom_rbound[g1], rb2 = M.h_geom_rbound[g2];
+    const HP df[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    const HP bound = rb1 + rb2 + margin;
+    if (rb1 > 0 && rb2 > 0 && dot3(df, df) > bound * bound) return;
+  }
   if (t1 == 0 && t2 == 2) {
     const HP n[3] = {R1[2], R1[5], R1[8]};
     const HP dd = (p2[0] - p1[0]) * n[0] + (p2[1] - p1[1]) * n[1] + (p2[2] - p1[2]) * n[2] - s2[0];
@@ -1618,8 +1597,8 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
           body_point(s, M.geom_bodyid[g1], l1, c1);
           body_point(s, M.geom_bodyid[g2], l2, c2);
           const T df[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
-          // (conservative by construction: a pair this filter is unsure about has dist >> margin in the narrow
-          // phase anyway, so its fp32 rounding never decides an activation)
+          // (a conservative PRE-filter: it rejects only pairs that are apart by more than its rounding; collide_pair
+          // repeats the test exactly, in HP)
           const T bound = rb1 + rb2 + (T)margin;
           if (dot3(df, df) > bound * bound * (T)1.0001) skip = 1;
         }

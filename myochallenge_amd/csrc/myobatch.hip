@@ -46,11 +46,14 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 extern "C" const char* myo_last_error(void) { return g_err; }
-extern "C" const char* myo_version(void) {
+#ifndef MYO_BUILD_ID
+#define MYO_BUILD_ID "unknown"
+#endif
+extern "C" const char* myo_version(void) {      // "... build <hash of the native sources>" (myochallenge_amd/build.py:source_id)
 #ifdef MYO_EMU
-  return "myobatch 0.1 (MYO_EMU lane-serial test build)";
+  return "myobatch 0.1 (MYO_EMU lane-serial test build) build " MYO_BUILD_ID;
 #else
-  return "myobatch 0.1 (gfx950)";
+  return "myobatch 0.1 (gfx950) build " MYO_BUILD_ID;
 #endif
 }
 

@@ -128,6 +128,12 @@ class NativeLib:
         return self.L.myo_version().decode()
 
     @property
+    def build_id(self) -> str:
+        """hash of the native sources this library was compiled from (build.py:source_id), "unknown" for ad-hoc builds"""
+        v = self.version
+        return v.rsplit(" build ", 1)[1] if " build " in v else "unknown"
+
+    @property
     def is_emulation(self) -> bool:
         return "MYO_EMU" in self.version
 

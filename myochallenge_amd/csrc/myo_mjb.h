@@ -35,7 +35,7 @@ static const char* const kSizeNames[57] = {
 struct File {
   std::map<std::string, long long> sizes;
   double timestep, impratio, tolerance, gravity[3], o_margin, meaninertia;
-  int integrator, cone, iterations, disableflags;
+  int integrator, collision, cone, iterations, disableflags, enableflags;
   std::map<std::string, std::vector<double>> d;   // f64 arrays (row-major)
   std::map<std::string, std::vector<int>> i;      // i32 and u8 arrays
 };
@@ -70,7 +70,10 @@ static bool parse(const unsigned char* blob, size_t n, File& f, std::string& err
     err = msg; return false;
   }
   size_t off = 16;
-  for (int k = 0; k < 57; ++k) { int v; memcpy(&v, blob + off, 4); off += 4; f.sizes[kSizeNames[k]] = v; }
+  for (int k = 0; k < 57; ++k) {
+    int v; memcpy(&v, blob + off, 4); off += 4; f.sizes[kSizeNames[k]] = v;
+    if (v < 0) { snprintf(msg, sizeof msg, "negative size %s = %d in the header", kSizeNames[k], v); err = msg; return false; }
+  }
   // mjOption: timestep apirate impratio tolerance noslip_tolerance mpr_tolerance gravity[3] wind[3] magnetic[3] density viscosity
   //           o_margin o_solref[2] o_solimp[5] | integrator collision cone jacobian solver iterations noslip_it mpr_it disable enable
   double od[25];
@@ -80,7 +83,7 @@ static bool parse(const unsigned char* blob, size_t n, File& f, std::string& err
   f.gravity[0] = od[6]; f.gravity[1] = od[7]; f.gravity[2] = od[8]; f.o_margin = od[17];
   int oi[10];
   memcpy(oi, blob + off, sizeof oi); off += sizeof oi;
-  f.integrator = oi[0]; f.cone = oi[2]; f.iterations = oi[5]; f.disableflags = oi[8];
+  f.integrator = oi[0]; f.collision = oi[1]; f.cone = oi[2]; f.iterations = oi[5]; f.disableflags = oi[8]; f.enableflags = oi[9];
   const long long nbuffer = f.sizes["nbuffer"];
   if (nbuffer < 0 || (size_t)nbuffer > n || n - (size_t)nbuffer < off) { err = "nbuffer larger than the file"; return false; }
   const size_t base = n - (size_t)nbuffer;
@@ -100,11 +103,16 @@ static bool parse(const unsigned char* blob, size_t n, File& f, std::string& err
     char t; char name[64], rows[64], cols[64];
     if (sscanf(line.c_str(), " %c %63s %63s %63s", &t, name, rows, cols) != 4) { err = "bad layout line: " + line; return false; }
     bool ok = true;
-    const long long cnt = dim(rows, f.sizes, &ok) * dim(cols, f.sizes, &ok);
-    if (!ok || cnt < 0) { err = std::string("unknown size in layout of ") + name; return false; }
+    const long long nr = dim(rows, f.sizes, &ok), nc = dim(cols, f.sizes, &ok);
+    if (!ok || nr < 0 || nc < 0) { err = std::string("unknown size in layout of ") + name; return false; }
     const size_t isz = (t == 'd') ? 8 : (t == 'i' || t == 'f') ? 4 : 1;
+    // every count is bounded by the file size BEFORE anything is multiplied (sizes are attacker-controlled 31-bit numbers)
+    if ((nr && (unsigned long long)nc > (unsigned long long)n / (unsigned long long)nr) || (unsigned long long)(nr * nc) > (unsigned long long)n / isz) {
+      err = std::string("array ") + name + " is larger than the file"; return false;
+    }
+    const long long cnt = nr * nc;
     if (cnt) pos = (pos + isz - 1) / isz * isz;
-    if (base + pos + (size_t)cnt * isz > n) { err = std::string("array ") + name + " runs past the end of the file"; return false; }
+    if (base + pos > n || (size_t)cnt * isz > n - (base + pos)) { err = std::string("array ") + name + " runs past the end of the file"; return false; }
     const unsigned char* src = blob + base + pos;
     if (t == 'd') { std::vector<double>& v = f.d[name]; v.resize((size_t)cnt); if (cnt) memcpy(v.data(), src, (size_t)cnt * 8); }
     else if (t == 'i') { std::vector<int>& v = f.i[name]; v.resize((size_t)cnt); if (cnt) memcpy(v.data(), src, (size_t)cnt * 4); }
@@ -129,7 +137,7 @@ static const char* const kF64Fields[] = {
     "qpos0", "qpos_spring", "body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia", "body_invweight0", "jnt_solref",
     "jnt_solimp", "jnt_pos", "jnt_axis", "jnt_stiffness", "jnt_range", "jnt_margin", "dof_armature", "dof_damping", "dof_invweight0",
     "geom_solmix", "geom_solref", "geom_solimp", "geom_size", "geom_rbound", "geom_pos", "geom_quat", "geom_friction", "geom_margin",
-    "geom_gap", "site_pos", "tendon_solref_lim", "tendon_solimp_lim", "tendon_range", "tendon_margin", "tendon_stiffness", "tendon_damping",
+    "geom_gap", "site_pos", "site_quat", "tendon_solref_lim", "tendon_solimp_lim", "tendon_range", "tendon_margin", "tendon_stiffness", "tendon_damping",
     "tendon_lengthspring", "tendon_invweight0", "wrap_prm", "actuator_dynprm", "actuator_gainprm", "actuator_biasprm", "actuator_ctrlrange",
     "actuator_forcerange", "actuator_gear", "actuator_acc0", "actuator_lengthrange"};
 
@@ -145,7 +153,43 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   auto I = [&](const char* k) -> std::vector<int>& { return f.i[k]; };
   auto D = [&](const char* k) -> std::vector<double>& { return f.d[k]; };
   const int nbody = (int)f.sizes["nbody"], njnt = (int)f.sizes["njnt"], ngeom = (int)f.sizes["ngeom"], nv = (int)f.sizes["nv"];
-  const int ntendon = (int)f.sizes["ntendon"];
+  const int ntendon = (int)f.sizes["ntendon"], nsite = (int)f.sizes["nsite"], nwrap = (int)f.sizes["nwrap"];
+  // ---- the file is untrusted: every id array this function indexes with is range-checked first (myo_model_from_blob
+  // checks the rest); a corrupt model is MYO_E_ARG, never an out-of-bounds read
+  {
+    char m[160];
+    auto bad = [&](const char* what, int i, int v) { snprintf(m, sizeof m, "corrupt model: %s[%d] = %d is out of range", what, i, v); err = m; return false; };
+    if (nbody < 1) { err = "corrupt model: nbody < 1"; return false; }
+    for (int b = 0; b < nbody; ++b) {
+      const int pa = I("body_parentid")[b], w = I("body_weldid")[b];
+      if (pa < 0 || (b > 0 && pa >= b) || (b == 0 && pa != 0)) return bad("body_parentid", b, pa);
+      if (w < 0 || w >= nbody) return bad("body_weldid", b, w);
+    }
+    for (int g = 0; g < ngeom; ++g) {
+      if (I("geom_bodyid")[g] < 0 || I("geom_bodyid")[g] >= nbody) return bad("geom_bodyid", g, I("geom_bodyid")[g]);
+      if (I("geom_type")[g] < 0 || I("geom_type")[g] > MYO_GEOM_MESH) return bad("geom_type", g, I("geom_type")[g]);
+    }
+    for (int k = 0; k < nsite; ++k) if (I("site_bodyid")[k] < 0 || I("site_bodyid")[k] >= nbody) return bad("site_bodyid", k, I("site_bodyid")[k]);
+    for (int i = 0; i < nv; ++i) if (I("dof_parentid")[i] < -1 || I("dof_parentid")[i] >= i) return bad("dof_parentid", i, I("dof_parentid")[i]);
+    for (int t = 0; t < ntendon; ++t) {
+      const int a = I("tendon_adr")[t], c = I("tendon_num")[t];
+      if (a < 0 || c < 0 || a > nwrap || c > nwrap - a) return bad("tendon_adr/num", t, a);
+    }
+    for (int w = 0; w < nwrap; ++w) {
+      const int wt = I("wrap_type")[w], id = I("wrap_objid")[w];
+      if (wt == MYO_WRAP_SITE && (id < 0 || id >= nsite)) return bad("wrap_objid (site)", w, id);
+      if ((wt == MYO_WRAP_SPHERE || wt == MYO_WRAP_CYLINDER)) {
+        if (id < 0 || id >= ngeom) return bad("wrap_objid (geom)", w, id);
+        const double sp = D("wrap_prm")[w];
+        if (sp >= 0 && !(sp < (double)nsite)) return bad("wrap_prm (side site)", w, (int)sp);
+      }
+    }
+  }
+  // what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored
+  if (f.collision == 1) { err = "opt.collision = predefined (explicit <pair> contacts only) is not supported"; *unsupported = 1; return false; }
+  if (f.sizes["npair"] > 0 && f.collision != 2) { err = "explicit contact pairs (<contact><pair>) are not supported"; *unsupported = 1; return false; }
+  if (f.disableflags & ~((1 << 9) | (1 << 11))) { err = "opt.disableflags: only filterparent and refsafe can be disabled in this stepper"; *unsupported = 1; return false; }
+  if (f.enableflags & 1) { err = "opt.enableflags: contact override is not supported"; *unsupported = 1; return false; }
   for (int j = 0; j < njnt; ++j) if (I("jnt_type")[j] == MYO_JNT_BALL) { err = "ball joints are not supported"; *unsupported = 1; return false; }
   if (f.sizes["neq"] > 0) { err = "equality constraints are not supported"; *unsupported = 1; return false; }
   for (double v : D("dof_frictionloss")) if (v > 0) { err = "friction loss is not supported"; *unsupported = 1; return false; }
@@ -153,7 +197,10 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   if (f.cone != 0) { err = "only pyramidal friction cones are supported"; *unsupported = 1; return false; }
   for (int g = 0; g < ngeom; ++g)
     if ((I("geom_contype")[g] | I("geom_conaffinity")[g]) != 0 && I("geom_condim")[g] != 3) { err = "only condim=3 contacts are supported"; *unsupported = 1; return false; }
-  // static collision filter (mj_collision body-pair pass): same weld group, parent-child, contype / conaffinity
+  // static collision filter (mj_collision body-pair pass): same weld group, <exclude> body pairs (exclude_signature =
+  // ((body1 + 1) << 16) + body2 + 1 with body1 < body2, MuJoCo 2.1), parent-child unless mjDSBL_FILTERPARENT, contype / conaffinity
+  const std::vector<int>& excl = I("exclude_signature");
+  const bool filterparent = !(f.disableflags & (1 << 9));
   std::vector<int> p1, p2;
   int dropped = 0;
   char msg[256] = "";
@@ -162,8 +209,15 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
     for (int g2 = g1 + 1; g2 < ngeom; ++g2) {
       const int w1 = weld[gb[g1]], w2 = weld[gb[g2]];
       if (w1 == w2) continue;
+      if (!excl.empty()) {
+        const int ba = gb[g1] < gb[g2] ? gb[g1] : gb[g2], bb = gb[g1] < gb[g2] ? gb[g2] : gb[g1];
+        const int sig = ((ba + 1) << 16) + bb + 1;
+        bool hit = false;
+        for (int x : excl) if (x == sig) hit = true;
+        if (hit) continue;
+      }
       const int wp1 = weld[par[w1]], wp2 = weld[par[w2]];
-      if (w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) continue;
+      if (filterparent && w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) continue;
       if (!((I("geom_contype")[g1] & I("geom_conaffinity")[g2]) || (I("geom_contype")[g2] & I("geom_conaffinity")[g1]))) continue;
       const int t1 = gt[g1], t2 = gt[g2];
       const int a = t1 <= t2 ? g1 : g2, b = t1 <= t2 ? g2 : g1;      // MuJoCo orders a pair by geom type

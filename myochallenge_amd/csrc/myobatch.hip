@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cmath>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -102,7 +103,12 @@ static void quat2mat_h(const double* q, double* R) {
   R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
 }
 
+static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out);
 extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** out) {
+  try { return model_from_blob_impl(blob, nbytes, out); }          // no C++ exception crosses the C ABI
+  catch (const std::exception& e) { return fail(MYO_E_ARG, "model blob rejected: %s", e.what()); }
+}
+static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out) {
   if (!blob || !out || nbytes < sizeof(myo_blob_header)) return fail(MYO_E_ARG, "null or short blob");
   const myo_blob_header* h = (const myo_blob_header*)blob;
   if (h->magic != MYO_BLOB_MAGIC || h->version != MYO_BLOB_VERSION || h->total_bytes != nbytes ||
@@ -145,6 +151,74 @@ extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** 
   m->integrator = opt_i[0]; m->iterations = opt_i[2]; m->disableflags = opt_i[3];
   m->timestep = opt_d[0]; m->tolerance = opt_d[1]; m->impratio = opt_d[2];
   m->gravity[0] = opt_d[3]; m->gravity[1] = opt_d[4]; m->gravity[2] = opt_d[5]; m->meaninertia = opt_d[7];
+  // ---- the blob is untrusted input: sizes, array lengths and every id are checked before anything is indexed with them
+  {
+    char why[160] = "";
+#define BAD(...) { snprintf(why, sizeof why, __VA_ARGS__); int rc = fail(MYO_E_ARG, "corrupt model: %s", why); delete m; return rc; }
+    for (int k = 0; k < 10; ++k) if (sizes[k] < 0) BAD("negative size %d", k)
+    if (m->nbody < 1 || m->na > m->nu) BAD("nbody < 1 or na > nu")
+    if (m->pair_geom1.size() != m->pair_geom2.size()) BAD("pair arrays differ in length")
+#define NEED(arr, cnt) if (m->arr.size() < (size_t)(cnt)) BAD("array %s has %zu entries, needs %zu", #arr, m->arr.size(), (size_t)(cnt))
+    const size_t nb_ = m->nbody, nj_ = m->njnt, nv_ = m->nv, ng_ = m->ngeom, ns_ = m->nsite, nt_ = m->ntendon, nw_ = m->nwrap, nu_ = m->nu;
+    NEED(body_parentid, nb_) NEED(body_rootid, nb_) NEED(body_jntnum, nb_) NEED(body_jntadr, nb_) NEED(body_dofnum, nb_) NEED(body_dofadr, nb_)
+    NEED(jnt_type, nj_) NEED(jnt_qposadr, nj_) NEED(jnt_dofadr, nj_) NEED(jnt_bodyid, nj_) NEED(jnt_limited, nj_)
+    NEED(dof_bodyid, nv_) NEED(dof_jntid, nv_) NEED(dof_parentid, nv_) NEED(geom_type, ng_) NEED(geom_bodyid, ng_) NEED(geom_priority, ng_)
+    NEED(site_bodyid, ns_) NEED(tendon_adr, nt_) NEED(tendon_num, nt_) NEED(tendon_limited, nt_) NEED(wrap_type, nw_) NEED(wrap_objid, nw_)
+    NEED(actuator_dyntype, nu_) NEED(actuator_gaintype, nu_) NEED(actuator_biastype, nu_) NEED(actuator_ctrllimited, nu_) NEED(actuator_forcelimited, nu_)
+    NEED(qpos0, m->nq) NEED(qpos_spring, m->nq) NEED(body_pos, 3 * nb_) NEED(body_quat, 4 * nb_) NEED(body_ipos, 3 * nb_) NEED(body_mass, nb_)
+    NEED(body_inertia, 3 * nb_) NEED(body_invweight0, 2 * nb_) NEED(jnt_solref, 2 * nj_) NEED(jnt_solimp, 5 * nj_) NEED(jnt_pos, 3 * nj_)
+    NEED(jnt_axis, 3 * nj_) NEED(jnt_stiffness, nj_) NEED(jnt_range, 2 * nj_) NEED(jnt_margin, nj_) NEED(dof_armature, nv_) NEED(dof_damping, nv_)
+    NEED(dof_invweight0, nv_) NEED(geom_solmix, ng_) NEED(geom_solref, 2 * ng_) NEED(geom_solimp, 5 * ng_) NEED(geom_size, 3 * ng_)
+    NEED(geom_rbound, ng_) NEED(geom_pos, 3 * ng_) NEED(geom_friction, 3 * ng_) NEED(geom_margin, ng_) NEED(geom_gap, ng_) NEED(site_pos, 3 * ns_)
+    NEED(tendon_solref_lim, 2 * nt_) NEED(tendon_solimp_lim, 5 * nt_) NEED(tendon_range, 2 * nt_) NEED(tendon_margin, nt_) NEED(tendon_stiffness, nt_)
+    NEED(tendon_damping, nt_) NEED(tendon_lengthspring, nt_) NEED(tendon_invweight0, nt_) NEED(wrap_prm, nw_) NEED(actuator_dynprm, 10 * nu_)
+    NEED(actuator_gainprm, 10 * nu_) NEED(actuator_biasprm, 10 * nu_) NEED(actuator_ctrlrange, 2 * nu_) NEED(actuator_forcerange, 2 * nu_)
+    NEED(actuator_gear, 6 * nu_) NEED(actuator_acc0, nu_) NEED(actuator_lengthrange, 2 * nu_)
+#undef NEED
+    if (trntype.size() < nu_ || trnid.size() < 2 * nu_ || body_iquat.size() < 4 * nb_ || geom_quat.size() < 4 * ng_) BAD("actuator_trn* / body_iquat / geom_quat too short")
+    if (m->body_parentid[0] != 0) BAD("body_parentid[0] != 0")
+    for (int b = 0; b < m->nbody; ++b) {
+      if (b > 0 && (m->body_parentid[b] < 0 || m->body_parentid[b] >= b)) BAD("body_parentid[%d] = %d", b, m->body_parentid[b])
+      if (m->body_rootid[b] < 0 || m->body_rootid[b] >= m->nbody) BAD("body_rootid[%d] = %d", b, m->body_rootid[b])
+      const int jn = m->body_jntnum[b], ja = m->body_jntadr[b], dn = m->body_dofnum[b], da = m->body_dofadr[b];
+      if (jn < 0 || (jn > 0 && (ja < 0 || ja > m->njnt || jn > m->njnt - ja))) BAD("body_jntadr/num[%d] = %d/%d", b, ja, jn)
+      if (dn < 0 || (dn > 0 && (da < 0 || da > m->nv || dn > m->nv - da))) BAD("body_dofadr/num[%d] = %d/%d", b, da, dn)
+    }
+    for (int j = 0; j < m->njnt; ++j) {
+      const int ty = m->jnt_type[j], nqj = ty == MYO_JNT_FREE ? 7 : (ty == MYO_JNT_BALL ? 4 : 1), nvj = ty == MYO_JNT_FREE ? 6 : (ty == MYO_JNT_BALL ? 3 : 1);
+      if (ty < 0 || ty > 3) BAD("jnt_type[%d] = %d", j, ty)
+      if (m->jnt_qposadr[j] < 0 || m->jnt_qposadr[j] > m->nq - nqj) BAD("jnt_qposadr[%d] = %d", j, m->jnt_qposadr[j])
+      if (m->jnt_dofadr[j] < 0 || m->jnt_dofadr[j] > m->nv - nvj) BAD("jnt_dofadr[%d] = %d", j, m->jnt_dofadr[j])
+      if (m->jnt_bodyid[j] < 0 || m->jnt_bodyid[j] >= m->nbody) BAD("jnt_bodyid[%d] = %d", j, m->jnt_bodyid[j])
+    }
+    for (int d = 0; d < m->nv; ++d) {
+      if (m->dof_bodyid[d] < 0 || m->dof_bodyid[d] >= m->nbody) BAD("dof_bodyid[%d] = %d", d, m->dof_bodyid[d])
+      if (m->dof_jntid[d] < 0 || m->dof_jntid[d] >= m->njnt) BAD("dof_jntid[%d] = %d", d, m->dof_jntid[d])
+      if (m->dof_parentid[d] < -1 || m->dof_parentid[d] >= d) BAD("dof_parentid[%d] = %d", d, m->dof_parentid[d])
+    }
+    for (int g = 0; g < m->ngeom; ++g) {
+      if (m->geom_bodyid[g] < 0 || m->geom_bodyid[g] >= m->nbody) BAD("geom_bodyid[%d] = %d", g, m->geom_bodyid[g])
+      if (m->geom_type[g] < 0 || m->geom_type[g] > MYO_GEOM_MESH) BAD("geom_type[%d] = %d", g, m->geom_type[g])
+    }
+    for (int k = 0; k < m->nsite; ++k) if (m->site_bodyid[k] < 0 || m->site_bodyid[k] >= m->nbody) BAD("site_bodyid[%d] = %d", k, m->site_bodyid[k])
+    for (int t = 0; t < m->ntendon; ++t) {
+      const int a = m->tendon_adr[t], c = m->tendon_num[t];
+      if (a < 0 || c < 0 || a > m->nwrap || c > m->nwrap - a) BAD("tendon_adr/num[%d] = %d/%d", t, a, c)
+    }
+    for (int w = 0; w < m->nwrap; ++w) {
+      const int ty = m->wrap_type[w], id = m->wrap_objid[w];
+      if (ty == MYO_WRAP_SITE && (id < 0 || id >= m->nsite)) BAD("wrap_objid[%d] = %d (site)", w, id)
+      if (ty == MYO_WRAP_SPHERE || ty == MYO_WRAP_CYLINDER) {
+        if (id < 0 || id >= m->ngeom) BAD("wrap_objid[%d] = %d (geom)", w, id)
+        if (m->wrap_prm[w] >= 0 && !(m->wrap_prm[w] < (double)m->nsite)) BAD("wrap_prm[%d]: side site out of range", w)
+      }
+    }
+    for (int i = 0; i < m->nu; ++i) if (trntype[i] == MYO_TRN_TENDON && (trnid[2 * i] < 0 || trnid[2 * i] >= m->ntendon)) BAD("actuator_trnid[%d] = %d", i, trnid[2 * i])
+    for (size_t p = 0; p < m->pair_geom1.size(); ++p)
+      if (m->pair_geom1[p] < 0 || m->pair_geom1[p] >= m->ngeom || m->pair_geom2[p] < 0 || m->pair_geom2[p] >= m->ngeom) BAD("collision pair %zu names a geom out of range", p)
+    if (!(m->timestep > 0) || !std::isfinite(m->timestep) || m->iterations < 0) BAD("opt.timestep / opt.iterations")
+#undef BAD
+  }
   // ---- capacity / feature checks
 #define LIM(cond, what) if (cond) { int rc = fail(MYO_E_UNSUPPORTED, "model exceeds stepper capacity: %s", what); delete m; return rc; }
   LIM(m->nbody > MYO_NB_MAX, "nbody") LIM(m->njnt > MYO_NJ_MAX, "njnt") LIM(m->nv > MYO_NV_MAX, "nv")
@@ -427,19 +501,28 @@ extern "C" int myo_model_load_mjb(const char* path, int integrator, int unsuppor
   if (!path || !out) return fail(MYO_E_ARG, "myo_model_load_mjb: null argument");
   FILE* fh = fopen(path, "rb");
   if (!fh) return fail(MYO_E_ARG, "cannot open %s", path);
-  std::vector<unsigned char> raw;
-  unsigned char buf[1 << 16];
-  size_t k;
-  while ((k = fread(buf, 1, sizeof buf, fh)) > 0) raw.insert(raw.end(), buf, buf + k);
-  fclose(fh);
-  myo_mjb::File f;
-  std::string err;
-  if (!myo_mjb::parse(raw.data(), raw.size(), f, err)) return fail(MYO_E_ARG, "%s: %s", path, err.c_str());
-  std::vector<unsigned char> blob;
-  int unsupported = 0;
-  if (!myo_mjb::to_blob(f, integrator, unsupported_contacts, blob, err, &unsupported))
-    return fail(unsupported ? MYO_E_UNSUPPORTED : MYO_E_ARG, "%s: %s", path, err.c_str());
-  return myo_model_from_blob(blob.data(), blob.size(), out);
+  try {                                   // the file is untrusted; no C++ exception crosses the C ABI
+    std::vector<unsigned char> raw;
+    unsigned char buf[1 << 16];
+    size_t k;
+    while ((k = fread(buf, 1, sizeof buf, fh)) > 0) {
+      raw.insert(raw.end(), buf, buf + k);
+      if (raw.size() > ((size_t)1 << 31)) { fclose(fh); return fail(MYO_E_ARG, "%s: larger than 2 GiB", path); }
+    }
+    const int rd_err = ferror(fh);
+    fclose(fh);
+    if (rd_err) return fail(MYO_E_ARG, "%s: read error", path);
+    myo_mjb::File f;
+    std::string err;
+    if (!myo_mjb::parse(raw.data(), raw.size(), f, err)) return fail(MYO_E_ARG, "%s: %s", path, err.c_str());
+    std::vector<unsigned char> blob;
+    int unsupported = 0;
+    if (!myo_mjb::to_blob(f, integrator, unsupported_contacts, blob, err, &unsupported))
+      return fail(unsupported ? MYO_E_UNSUPPORTED : MYO_E_ARG, "%s: %s", path, err.c_str());
+    return myo_model_from_blob(blob.data(), blob.size(), out);
+  } catch (const std::exception& e) {
+    return fail(MYO_E_ARG, "%s: rejected (%s)", path, e.what());
+  }
 }
 extern "C" void myo_model_destroy(myo_model* m) { delete m; }
 extern "C" int myo_model_size(const myo_model* m, const char* n) {

@@ -62,12 +62,7 @@ class BaodingVecEnv:
         self.compiled = model
         self.lib = lib or native.load()
         self.torch = torch
-        if self.lib.is_emulation:
-            self.device = torch.device("cpu")
-        else:
-            if not torch.cuda.is_available():
-                raise native.MyoError("BaodingVecEnv needs a GPU: libmyobatch has no CPU execution path")
-            self.device = torch.device(f"cuda:{device}")
+        self.device = self._select_device(device)
         self._model = native.Model(model, self.lib)
         self._cfg = self._make_cfg(env_name, model, config)
         self.max_episode_steps = int(self._cfg.max_episode_steps)
@@ -89,6 +84,12 @@ class BaodingVecEnv:
         self._pending = None
         self._closed = False
         self._t_start = time.time()
+
+    def _select_device(self, device: int):
+        """The torch device the batch lives on: a GPU, always (libmyobatch has no CPU execution path)."""
+        if not self.torch.cuda.is_available():
+            raise native.MyoError("BaodingVecEnv needs a GPU: libmyobatch has no CPU execution path")
+        return self.torch.device(f"cuda:{device}")
 
     # ---------------------------------------------------------------- what a task supplies (ReorientVecEnv overrides these)
     rwd_keys = native.RWD_KEYS

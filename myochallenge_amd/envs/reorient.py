@@ -157,8 +157,17 @@ def make_reorient_cfg(env_name: str, compiled, **kwargs) -> native.TaskCfg:
     rot = lambda q, v: quat2mat(torch.as_tensor(np.asarray(q, np.float64))).numpy() @ np.asarray(v, np.float64)
     goal0 = body_pos[ids["goal_bid"]] + rot(body_quat[ids["goal_bid"]], site_pos[ids["goal_sid"]])
     obj0 = qpos0[-7:-4] + rot(qpos0[-4:], site_pos[ids["object_sid"]])
+    # The observation's obj_rot / goal_rot are mat2euler(site_xmat) in MyoSuite; the kernel and the oracle take the BODY
+    # orientation, which is the same thing only for sites whose own frame is the identity: anything else is refused
+    sq = np.asarray(f["site_quat"]).reshape(-1, 4) if "site_quat" in f else None
+    for sid in (ids["object_sid"], ids["goal_sid"]):
+        if sq is not None and not np.allclose(np.abs(sq[sid] / np.linalg.norm(sq[sid])), [1, 0, 0, 0], atol=1e-12):
+            raise ValueError("die reorient: the object_o / target_o sites must have an identity orientation (site_quat) in this stepper")
     for i in range(3):
-        c.ro_goal_init_pos[i] = float(body_pos[ids["goal_bid"]][i])      # what reset() adds its offset to is the BODY position
+        # reorient.py:82,125-129: goal_init_pos is the target SITE's world position at set-up, and reset() writes
+        # goal_init_pos + U(goal_pos) into body_pos[target] — for a site that sits off the body origin the goal therefore
+        # starts displaced by the site's offset, a quirk of the reference that is kept
+        c.ro_goal_init_pos[i] = float(goal0[i])
         c.ro_goal_obj_offset[i] = float(goal0[i] - obj0[i])
     c.init_qpos0 = -1.5                                                   # reorient.py:120-121
     return c

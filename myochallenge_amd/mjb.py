@@ -121,6 +121,11 @@ def parse_mjb(blob: bytes) -> MjbModel:
     off = 16
     sizes = dict(zip(SIZE_NAMES, struct.unpack_from(f"<{N_SIZE_INTS}i", blob, off)))
     off += 4 * N_SIZE_INTS
+    neg = [k for k, v in sizes.items() if v < 0]
+    if neg:
+        raise MjbError(f"negative size(s) in the header: {neg}")
+    if len(blob) < off + 8 * sum(n for _, n in OPT_DOUBLES) + 4 * len(OPT_INTS):
+        raise MjbError("file too short for mjOption")
     opt: Dict[str, object] = {}
     for name, n in OPT_DOUBLES:
         vals = struct.unpack_from(f"<{n}d", blob, off)
@@ -170,3 +175,66 @@ def parse_mjb(blob: bytes) -> MjbModel:
         names[kind] = [_name_at(int(a)) for a in adrs]
     # MuJoCo 2.1 stores no separate model-name entry: body 0 ("world") starts at offset 0.
     return MjbModel(sizes=sizes, opt=opt, arrays=arrays, names=names, model_name="", stat=stat)
+
+
+def dump_mjb(m: MjbModel) -> bytes:
+    """Serialises a decoded (or synthetic) model back into the MuJoCo 2.1 ``.mjb`` layout ``parse_mjb`` reads: header, the 57
+    sizes, mjOption, 608 bytes of mjVisual + mjStatistic (zeros but for the statistics), then every array of the shared
+    layout table in order (arrays the model does not carry are written as zeros of the size the table says).  Used by the
+    tests to put models through the C reader (``myo_model_load_mjb``); MuJoCo itself is never involved."""
+    sizes = {k: int(m.sizes.get(k, 0)) for k in SIZE_NAMES}
+    if "names" not in m.arrays and m.names:               # a synthetic model carries its names as lists: build the name table
+        m = MjbModel(sizes=m.sizes, opt=m.opt, arrays=dict(m.arrays), names=m.names, model_name=m.model_name, stat=m.stat)
+        table = bytearray()
+        for kind, count in (("body", "nbody"), ("jnt", "njnt"), ("geom", "ngeom"), ("site", "nsite"), ("tendon", "ntendon"), ("actuator", "nu")):
+            lst = list(m.names.get(kind, [])) + [""] * (sizes[count] - len(m.names.get(kind, [])))
+            adr = []
+            for nm in lst[:sizes[count]]:
+                adr.append(len(table))
+                table += nm.encode("utf8") + b"\0"
+            m.arrays[f"name_{kind}adr"] = np.array(adr, np.int32)
+        m.arrays["names"] = np.frombuffer(bytes(table), dtype="S1")
+    rows = []
+    pos = 0
+    for line in _SPEC.strip().splitlines():
+        t, name, r_, c_ = line.split()
+        dt = _DTYPES[t]
+        a = m.arrays.get(name)
+        # sizes that the model does not state follow from the arrays it carries (names, exclude pairs ...)
+        if a is not None and not r_.isdigit() and "*" not in r_ and r_ not in m.sizes and r_ != "nbuffer":
+            sizes[r_] = max(sizes.get(r_, 0), int(np.asarray(a).shape[0]))
+        rows.append((t, name, r_, c_, dt))
+    chunks = []
+    for t, name, r_, c_, dt in rows:
+        n = _dim(r_, sizes) * _dim(c_, sizes)
+        a = m.arrays.get(name)
+        if a is None:
+            raw = np.zeros(n, dt)
+        elif t == "c":
+            raw = np.frombuffer(np.asarray(a).tobytes(), dtype="S1")
+        else:
+            raw = np.ascontiguousarray(np.asarray(a)).astype(dt).reshape(-1)
+        if raw.size != n:
+            raise MjbError(f"array {name} has {raw.size} entries, the sizes say {n}")
+        if n:
+            pad = -pos % dt.itemsize
+            chunks.append(b"\0" * pad)
+            pos += pad
+        chunks.append(raw.tobytes())
+        pos += n * dt.itemsize
+    sizes["nbuffer"] = pos
+    out = struct.pack("<4i", MJB_MAGIC, 8, N_SIZE_INTS, N_POINTERS) + struct.pack(f"<{N_SIZE_INTS}i", *[sizes[k] for k in SIZE_NAMES])
+    o = dict(m.opt)
+    defaults = {"apirate": 100.0, "noslip_tolerance": 1e-6, "mpr_tolerance": 1e-6, "wind": [0, 0, 0], "magnetic": [0, -0.5, 0],
+                "density": 0.0, "viscosity": 0.0, "o_solref": [0.02, 1.0], "o_solimp": [0.9, 0.95, 0.001, 0.5, 2.0], "o_margin": 0.0,
+                "collision": 0, "jacobian": 2, "solver": 2, "noslip_iterations": 0, "mpr_iterations": 50, "enableflags": 0, "disableflags": 0}
+    for name, n in OPT_DOUBLES:
+        v = o.get(name, defaults.get(name, 0.0))
+        out += struct.pack(f"<{n}d", *([v] if n == 1 else list(v)))
+    for name in OPT_INTS:
+        out += struct.pack("<i", int(o.get(name, defaults.get(name, 0))))
+    st = m.stat or {}
+    tail = struct.pack("<7d", st.get("meaninertia", 1.0), st.get("meanmass", 1.0), st.get("meansize", 0.1), st.get("extent", 1.0),
+                       *st.get("center", [0.0, 0.0, 0.0]))
+    out += b"\0" * (608 - len(tail)) + tail
+    return out + b"".join(chunks)

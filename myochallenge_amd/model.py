@@ -123,12 +123,20 @@ def _depths(parent: np.ndarray) -> np.ndarray:
     return d
 
 
+DSBL_FILTERPARENT, DSBL_REFSAFE = 1 << 9, 1 << 11      # mjtDisableBit (MuJoCo 2.1)
+ENBL_OVERRIDE = 1 << 0                                  # mjtEnableBit
+
+
 def collision_pairs(m: MjbModel):
-    """Static part of MuJoCo's collision filtering (mj_collision body-pair pass [3P-RECALL])."""
+    """Static part of MuJoCo's collision filtering (mj_collision body-pair pass [3P-RECALL]): bodies of one weld group never
+    collide; parent-child weld groups neither unless mjDSBL_FILTERPARENT is set; ``<contact><exclude>`` body pairs
+    (``exclude_signature`` = ((body1 + 1) << 16) + body2 + 1, body1 < body2) are skipped; contype / conaffinity per geom pair."""
     ng = m.ngeom
     gb = m.geom_bodyid
     weld = m.body_weldid
     par = m.body_parentid
+    excluded = set(int(x) for x in np.asarray(m.arrays.get("exclude_signature", [])).reshape(-1))
+    filterparent = not (int(m.opt.get("disableflags", 0)) & DSBL_FILTERPARENT)
     pairs, dropped = [], []
     for g1 in range(ng):
         for g2 in range(g1 + 1, ng):
@@ -136,8 +144,10 @@ def collision_pairs(m: MjbModel):
             w1, w2 = int(weld[b1]), int(weld[b2])
             if w1 == w2:
                 continue
+            if excluded and (((min(b1, b2) + 1) << 16) + max(b1, b2) + 1) in excluded:
+                continue
             wp1, wp2 = int(weld[par[w1]]), int(weld[par[w2]])
-            if w1 != 0 and w2 != 0 and (w1 == wp2 or w2 == wp1):
+            if filterparent and w1 != 0 and w2 != 0 and (w1 == wp2 or w2 == wp1):
                 continue
             ct1, ca1 = int(m.geom_contype[g1]), int(m.geom_conaffinity[g1])
             ct2, ca2 = int(m.geom_contype[g2]), int(m.geom_conaffinity[g2])
@@ -178,10 +188,25 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
         raise ModelError("only pyramidal friction cones are supported")
     if np.any(m.geom_condim[(m.geom_contype | m.geom_conaffinity) != 0] != 3):
         raise ModelError("only condim=3 contacts are supported")
+    # what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored
+    col = int(m.opt.get("collision", 0))
+    if col == 1:
+        raise ModelError("opt.collision = 'predefined' (explicit <pair> contacts only) is not supported")
+    if int(m.sizes.get("npair", 0)) > 0 and col != 2:
+        raise ModelError("explicit contact pairs (<contact><pair>) are not supported")
+    dis, enb = int(m.opt.get("disableflags", 0)), int(m.opt.get("enableflags", 0))
+    if dis & ~(DSBL_FILTERPARENT | DSBL_REFSAFE):
+        raise ModelError(f"opt.disableflags = {dis:#x}: only filterparent and refsafe can be disabled in this stepper")
+    if enb & ENBL_OVERRIDE:
+        raise ModelError("opt.enableflags: contact override is not supported")
     for name in _INT_FIELDS:
         f[name] = np.ascontiguousarray(m.arrays[name]).astype(np.int32).reshape(-1)
     for name in _F64_FIELDS:
         f[name] = np.ascontiguousarray(m.arrays[name]).astype(np.float64).reshape(-1)
+    # site orientations: carried for the task layers' checks (the die-reorient observation reads site_xmat in MyoSuite; this
+    # stepper takes the body's orientation and therefore requires identity site frames, envs/reorient.py:make_reorient_cfg)
+    sq = m.arrays.get("site_quat")
+    f["site_quat"] = (np.tile([1.0, 0, 0, 0], (m.sizes["nsite"], 1)) if sq is None else np.asarray(sq, np.float64)).reshape(-1)
     f["x_body_depth"] = _depths(m.body_parentid)
     dd = np.zeros(m.nv, np.int32)
     for i in range(m.nv):

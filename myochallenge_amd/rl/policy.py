@@ -79,7 +79,7 @@ def _native_lib(t):
         lib = native.load()
     except Exception:
         return None
-    return None if lib.is_emulation else lib
+    return lib
 
 
 class _LstmSeq(torch.autograd.Function):

@@ -65,6 +65,13 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def _on_cpu(cls):
+    """Test-only subclass of an env class whose batch lives in host memory: what the lane-serial emulation library needs.
+    The product classes refuse to run without a GPU (envs/baoding.py:_select_device)."""
+    import torch
+    return type("Emu" + cls.__name__, (cls,), {"_select_device": lambda self, device: torch.device("cpu")})
+
+
 def make_env(env_name, lib, **kwargs):
     """``EnvironmentFactory.create(env_name, **kwargs)`` on an explicitly named native library (the lane-serial
     emulation build).  Test plumbing: the public factory has no such key — the product only ever loads the HIP
@@ -77,9 +84,9 @@ def make_env(env_name, lib, **kwargs):
         from myochallenge_amd.envs.mixture import MixtureModelBaodingVecEnv
         mix = {k: kwargs.pop(k) for k in ("base_model_path", "base_env_path", "base_env_name", "base_env_config",
                                          "n_steps_base_model", "base_policy", "base_normalizer") if k in kwargs}
-        return MixtureModelBaodingVecEnv(env_name, num_envs, kwargs, **mix, **batch_kw, lib=lib)
+        return (_on_cpu(MixtureModelBaodingVecEnv) if lib.is_emulation else MixtureModelBaodingVecEnv)(env_name, num_envs, kwargs, **mix, **batch_kw, lib=lib)
     if env_name in REGISTRATION:
         from myochallenge_amd.envs.baoding import BaodingVecEnv
-        return BaodingVecEnv(env_name, num_envs, kwargs, **batch_kw, lib=lib)
+        return (_on_cpu(BaodingVecEnv) if lib.is_emulation else BaodingVecEnv)(env_name, num_envs, kwargs, **batch_kw, lib=lib)
     from myochallenge_amd.envs.reorient import ReorientVecEnv
-    return ReorientVecEnv(env_name, num_envs, kwargs, **batch_kw, lib=lib)
+    return (_on_cpu(ReorientVecEnv) if lib.is_emulation else ReorientVecEnv)(env_name, num_envs, kwargs, **batch_kw, lib=lib)

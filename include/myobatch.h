@@ -304,6 +304,34 @@ int myo_gae(const float* rew, const float* val, const float* starts, const float
             const float* last_done, int T, int N, float gamma, float lam, float* adv, float* ret,
             void* stream);
 
+/* One PPO minibatch step of the MLP actor-critic (two hidden layers of 256 per net, ReLU) on the matrix cores: what SB3's
+ * PPO.train runs per minibatch through autograd (evaluate_actions -> clipped surrogate + vf_coef * MSE - ent_coef * entropy ->
+ * backward; /root/reference/src/train/trainer.py:57-71 hands that loop to sb3-contrib).  Gathers rows
+ * idx[0..B) of the rollout arrays, runs forward, loss gradient and backward, and leaves d(loss)/d(param) in `grads` (same flat
+ * layout as `params`; offsets in ELEMENTS, [0] actor / [1] critic) and acc[2A+3] = {d log_std[A], policy loss, value loss,
+ * action-head bias gradient[A], value-head bias gradient}.  compute_adv_stats != 0: adv_stats <- {mean, unbiased std} of the
+ * minibatch advantages (SB3's per-minibatch normalisation); 0: the caller supplies them ({0, 1} = no normalisation).
+ * workspace: device memory of myo_ppo_mlp_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller and then owned by these
+ * calls (weight images, feature-major activations, split-K slabs).  Deterministic: no float atomics.  Returns
+ * MYO_E_UNSUPPORTED for other shapes (hidden != 256, obs > 128, act > 48, B not a multiple of 512). */
+typedef struct myo_ppo_mlp_desc {
+  const float *obs, *act, *oldlp, *adv, *ret;
+  const int64_t* idx;
+  int32_t B, O, A, hidden;
+  const float* params;
+  float* grads;
+  int64_t G;
+  int64_t off_W1[2], off_b1[2], off_W2[2], off_b2[2], off_Wh[2], off_bh[2], off_log_std;
+  float clip, vf_coef, ent_coef;
+  int32_t compute_adv_stats;
+  float* adv_stats;
+  float* acc;
+  void* workspace;
+  int64_t workspace_bytes;
+} myo_ppo_mlp_desc;
+long long myo_ppo_mlp_workspace_bytes(int B, int obs_dim, int act_dim, int hidden, long long G);
+int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream);
+
 /* clip_grad_norm_(max_norm) followed by one torch.optim.Adam step over a flat fp32 parameter vector
  * (what RecurrentPPO.train does per minibatch; /root/reference/src/train/trainer.py:66-71, SB3 Adam
  * eps 1e-5).  g is multiplied by grad_scale first (1/world after an all-reduce SUM).  step: dev

@@ -1,0 +1,391 @@
+// myo_ppo_mlp.h — one PPO minibatch step of the MLP actor-critic (obs -> H -> H -> head, ReLU; both nets) on the
+// matrix cores: what SB3's PPO.train does per minibatch through autograd (evaluate_actions, clipped surrogate + value
+// loss, backward; /root/reference/src/train/trainer.py:57-71 -> sb3 PPO.train) as FOUR launches
+// instead of ~25 (hipBLASLt GEMMs + elementwise kernels, each 8-20 us for microseconds of work):
+//
+//   k_mlp_prep     bf16 operand images of the weights in the layouts the MFMA fragments want (padded, plus transposes)
+//   k_mlp_fwdbwd   per 64-row block and net: gather -> layer 1 -> layer 2 -> head -> PPO loss gradient -> d hidden 2 ->
+//                  d hidden 1; activations stay in LDS between layers; every activation / activation-gradient leaves
+//                  ONCE, feature-major ([feature][row], bf16), which is the K-contiguous layout the weight-gradient
+//                  GEMMs read straight into MFMA fragments
+//   k_mlp_wgrad    dW = dY' X for the six weight matrices and the four hidden bias vectors: 128 x 128 output tiles,
+//                  split over the batch (split-K) into per-split slabs — plain stores, no float atomics
+//   k_mlp_reduce   flat gradient = sum of the slabs in split order (deterministic)
+// followed by the existing k_colmajor_finish (loss sums, log_std and head-bias gradients) and myo_adam_clip_step.
+//
+// v_mfma_f32_16x16x32_bf16 fragment maps (cdna_hip_programming.md §3): lane l holds A[row l&15][k = 8(l>>4) + j] and
+// B[k = 8(l>>4) + j][col l&15], j = 0..7; C/D: col = l&15, row = 4(l>>4) + reg.  Both operands are therefore read as
+// 16 contiguous bytes per lane from a K-contiguous image (rows of X / H in LDS, rows of W in global memory).
+#pragma once
+#ifndef MYO_EMU
+
+typedef __attribute__((ext_vector_type(8))) __bf16 myo_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float myo_f32x4;
+
+#define MLP_H 256          // hidden width of both trunks
+#define MLP_OPMAX 128      // padded observation width (multiple of 32)
+#define MLP_APM 48         // head outputs padded to 3 tiles of 16
+#define MLP_AKP 64         // head width as the K of the d-hidden GEMM
+#define MLP_XS (MLP_OPMAX + 8)
+#define MLP_HS (MLP_H + 8)
+#define MLP_DS (MLP_AKP + 8)
+#define MLP_SOS 49
+#define MLP_SPLITK 16
+
+struct MlpArgs {
+  const float *obs, *act, *oldlp, *adv, *ret;      // rollout arrays [N, .]
+  const long long* idx;                            // minibatch rows [B]
+  const float *log_std, *adv_stats;
+  const unsigned short *W1p, *W2, *W2T, *Whp, *WhT;  // bf16 images: [2][H][OP], [2][H][H], [2][H][H], [2][APM][H], [2][H][AKP]
+  const float* bias;                               // fp32 [2][H] b1, [2][H] b2, [2][APM] bh
+  unsigned short *XT, *H1T, *H2T, *dH1T, *dH2T, *dOT;   // feature-major bf16 [rows][B]: 128, 2H, 2H, 2H, 2H, 2*128
+  float* part;                                     // loss partials, column-major [(2A+3)][NB]
+  int B, O, A, OP, NB;
+  float clip, vf_coef;
+};
+
+__device__ __forceinline__ unsigned short mlp_f2bf(float x) {   // round-to-nearest-even (finite inputs)
+  unsigned u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float mlp_bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+struct MlpPrepArgs {
+  const float* p;                                  // flat fp32 parameters
+  long long off_W1[2], off_b1[2], off_W2[2], off_b2[2], off_Wh[2], off_bh[2];
+  int O, OP, Ah[2];                                // head widths: A (actor), 1 (critic)
+  unsigned short *W1p, *W2, *W2T, *Whp, *WhT;
+  float* bias;
+};
+
+__global__ void __launch_bounds__(256) k_mlp_prep(MlpPrepArgs P) {
+  constexpr int H = MLP_H;
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
+  for (int net = 0; net < 2; ++net) {
+    const float* W1 = P.p + P.off_W1[net]; const float* W2 = P.p + P.off_W2[net]; const float* Wh = P.p + P.off_Wh[net];
+    for (long long e = tid; e < (long long)H * P.OP; e += nth) {
+      const int o = (int)(e / P.OP), i = (int)(e % P.OP);
+      P.W1p[(size_t)net * H * P.OP + e] = i < P.O ? mlp_f2bf(W1[(size_t)o * P.O + i]) : (unsigned short)0;
+    }
+    for (long long e = tid; e < (long long)H * H; e += nth) {
+      const int o = (int)(e / H), i = (int)(e % H);
+      const unsigned short v = mlp_f2bf(W2[e]);
+      P.W2[(size_t)net * H * H + e] = v;
+      P.W2T[(size_t)net * H * H + (size_t)i * H + o] = v;
+    }
+    for (long long e = tid; e < (long long)MLP_APM * H; e += nth) {
+      const int a = (int)(e / H), h = (int)(e % H);
+      P.Whp[(size_t)net * MLP_APM * H + e] = a < P.Ah[net] ? mlp_f2bf(Wh[(size_t)a * H + h]) : (unsigned short)0;
+    }
+    for (long long e = tid; e < (long long)H * MLP_AKP; e += nth) {
+      const int h = (int)(e / MLP_AKP), a = (int)(e % MLP_AKP);
+      P.WhT[(size_t)net * H * MLP_AKP + e] = a < P.Ah[net] ? mlp_f2bf(Wh[(size_t)a * H + h]) : (unsigned short)0;
+    }
+    for (long long e = tid; e < H; e += nth) {
+      P.bias[net * H + e] = P.p[P.off_b1[net] + e];
+      P.bias[2 * H + net * H + e] = P.p[P.off_b2[net] + e];
+    }
+    for (long long e = tid; e < MLP_APM; e += nth) P.bias[4 * H + net * MLP_APM + e] = e < P.Ah[net] ? P.p[P.off_bh[net] + e] : 0.f;
+  }
+}
+
+// mean and unbiased std of adv[idx[0..B)) in ONE block (two passes over LDS partials, fixed order: deterministic)
+__global__ void __launch_bounds__(1024) k_adv_moments(const float* __restrict__ adv, const long long* __restrict__ idx, int B,
+                                                      float* __restrict__ stats) {
+  __shared__ float red[1024];
+  __shared__ float s_mean;
+  const int t = threadIdx.x;
+  float s = 0.f;
+  for (int i = t; i < B; i += 1024) s += adv[idx[i]];
+  red[t] = s;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+  if (t == 0) s_mean = red[0] / B;
+  __syncthreads();
+  const float mean = s_mean;
+  float m2 = 0.f;
+  for (int i = t; i < B; i += 1024) { const float d = adv[idx[i]] - mean; m2 += d * d; }
+  red[t] = m2;
+  __syncthreads();
+  for (int w = 512; w >= 1; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
+  if (t == 0) { stats[0] = mean; stats[1] = sqrtf(red[0] / (B > 1 ? B - 1 : 1)); }
+}
+
+// 64 rows x 256 columns through one layer: acc[mt][nt] += A(LDS rows, K-contiguous) * W(global rows, K-contiguous)'
+template <int KSTEPS>
+__device__ __forceinline__ void mlp_gemm_64x64(myo_f32x4 (&acc)[4][4], const unsigned short* As, int as_stride,
+                                               const unsigned short* Wg, int w_stride, int n0, int lm, int lq) {
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    myo_bf16x8 a[4], b[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const myo_bf16x8*>(Wg + (size_t)(n0 + 16 * nt + lm) * w_stride + 32 * ks + 8 * lq);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const myo_bf16x8*>(As + (16 * mt + lm) * as_stride + 32 * ks + 8 * lq);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_mlp_fwdbwd(MlpArgs P) {
+  constexpr int H = MLP_H, XS = MLP_XS, HS = MLP_HS, DS = MLP_DS, SOS = MLP_SOS;
+  extern __shared__ __align__(16) unsigned char mlp_smem[];
+  long long* s_idx = reinterpret_cast<long long*>(mlp_smem);                      // [64]
+  unsigned short* Xs = reinterpret_cast<unsigned short*>(mlp_smem + 512);         // [64][XS] bf16; later So fp32 [64][SOS]
+  float* So = reinterpret_cast<float*>(mlp_smem + 512);
+  unsigned short* Hs1 = Xs + 64 * XS;                                             // [64][HS]
+  unsigned short* Hs2 = Hs1 + 64 * HS;                                            // [64][HS]
+  float* Sg = reinterpret_cast<float*>(Hs2 + 64 * HS);                            // [64][SOS] fp32
+  unsigned short* dOs = reinterpret_cast<unsigned short*>(Sg + 64 * SOS);         // [64][DS]
+  float* s_ls = reinterpret_cast<float*>(dOs + 64 * DS);                          // [64] log_std, [64] exp(-log_std)
+  static_assert(64 * MLP_SOS * 4 <= 64 * MLP_XS * 2, "the head output tile fits where X was");
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, lm = lane & 15, lq = lane >> 4;
+  const int net = blockIdx.y, blk = blockIdx.x, r0 = blk * 64, B = P.B, O = P.O, A = P.A, OP = P.OP;
+  const int n0 = 64 * w;
+  if (t < 64) s_idx[t] = P.idx[r0 + t];
+  if (t < A) { const float ls = P.log_std[t]; s_ls[t] = ls; s_ls[64 + t] = __expf(-ls); }
+  __syncthreads();
+  // ---- gather: X rows -> bf16 LDS image (zero-padded to OP columns)
+  for (int e = t; e < 64 * OP; e += 256) {
+    const int r = e / OP, c = e - r * OP;
+    Xs[r * XS + c] = c < O ? mlp_f2bf(P.obs[(size_t)s_idx[r] * O + c]) : (unsigned short)0;
+  }
+  __syncthreads();
+  if (net == 0) {   // feature-major copy of X for the weight-gradient GEMM (the critic's block has the same rows)
+    for (int e = t; e < OP * 8; e += 256) {
+      const int c = e >> 3, ch = e & 7;
+      unsigned v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (unsigned)Xs[(8 * ch + 2 * k) * XS + c] | ((unsigned)Xs[(8 * ch + 2 * k + 1) * XS + c] << 16);
+      *reinterpret_cast<uint4*>(P.XT + (size_t)c * B + r0 + 8 * ch) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  myo_f32x4 acc[4][4];
+  const float* b1 = P.bias + net * H; const float* b2 = P.bias + 2 * H + net * H; const float* bh = P.bias + 4 * H + net * MLP_APM;
+  // ---- layer 1 (K = OP, a multiple of 32 up to 128)
+  {
+    const unsigned short* W1 = P.W1p + (size_t)net * H * OP;
+    if (OP == 96) mlp_gemm_64x64<3>(acc, Xs, XS, W1, OP, n0, lm, lq);
+    else if (OP == 128) mlp_gemm_64x64<4>(acc, Xs, XS, W1, OP, n0, lm, lq);
+    else if (OP == 64) mlp_gemm_64x64<2>(acc, Xs, XS, W1, OP, n0, lm, lq);
+    else mlp_gemm_64x64<1>(acc, Xs, XS, W1, OP, n0, lm, lq);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+        const float bb = b1[n];
+        unsigned short h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb, 0.f)); Hs1[(m + r) * HS + n] = h[r]; }
+        *reinterpret_cast<uint2*>(P.H1T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      }
+  }
+  __syncthreads();
+  // ---- layer 2
+  {
+    mlp_gemm_64x64<H / 32>(acc, Hs1, HS, P.W2 + (size_t)net * H * H, H, n0, lm, lq);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+        const float bb = b2[n];
+        unsigned short h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { h[r] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb, 0.f)); Hs2[(m + r) * HS + n] = h[r]; }
+        *reinterpret_cast<uint2*>(P.H2T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      }
+  }
+  __syncthreads();
+  // ---- head: wave w takes rows 16w .. 16w+15, all MLP_APM outputs (fp32 into So, which reuses X's storage)
+  {
+    myo_f32x4 ah[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) ah[nt] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned short* Wh = P.Whp + (size_t)net * MLP_APM * H;
+#pragma unroll 2
+    for (int ks = 0; ks < H / 32; ++ks) {
+      const myo_bf16x8 a = *reinterpret_cast<const myo_bf16x8*>(Hs2 + (16 * w + lm) * HS + 32 * ks + 8 * lq);
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        const myo_bf16x8 b = *reinterpret_cast<const myo_bf16x8*>(Wh + (size_t)(16 * nt + lm) * H + 32 * ks + 8 * lq);
+        ah[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, ah[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) So[(16 * w + 4 * lq + r) * SOS + 16 * nt + lm] = ah[nt][r] + bh[16 * nt + lm];
+  }
+  __syncthreads();
+  // ---- loss gradient w.r.t. the head output (k_ppo_loss's arithmetic), one row per lane of wave 0
+  const int NB = P.NB;
+  if (w == 0) {
+    const int r = lane;
+    const size_t src = (size_t)s_idx[r];
+    if (net == 0) {
+      float logp = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float z = (P.act[src * A + a] - So[r * SOS + a]) * s_ls[64 + a];
+        logp += -0.5f * z * z - s_ls[a] - 0.9189385332046727f;
+      }
+      const float an = (P.adv[src] - P.adv_stats[0]) / (P.adv_stats[1] + 1e-8f);
+      const float ratio = __expf(logp - P.oldlp[src]);
+      const float s1 = an * ratio;
+      const float rc = fminf(fmaxf(ratio, 1.f - P.clip), 1.f + P.clip);
+      const float s2 = an * rc;
+      float pl_i = -fminf(s1, s2) / B;
+      const bool inside = (ratio > 1.f - P.clip) && (ratio < 1.f + P.clip);
+      const float dlogp = -(an * ratio) * ((s1 <= s2) ? 1.f : (inside ? 1.f : 0.f)) / B;
+      for (int a = 0; a < A; ++a) {
+        const float inv = s_ls[64 + a];
+        const float z = (P.act[src * A + a] - So[r * SOS + a]) * inv;
+        const float dm = dlogp * z * inv;
+        So[r * SOS + a] = dm;
+        Sg[r * SOS + a] = dlogp * (z * z - 1.f);
+        dOs[r * DS + a] = mlp_f2bf(dm);
+      }
+      for (int a = A; a < MLP_AKP; ++a) dOs[r * DS + a] = 0;
+      for (int off = 32; off >= 1; off >>= 1) pl_i += __shfl_xor(pl_i, off, 64);
+      if (lane == 0) P.part[(size_t)A * NB + blk] = pl_i;
+    } else {
+      const float dv = So[r * SOS] - P.ret[src];
+      float vl_i = dv * dv / B, dv_i = P.vf_coef * 2.f / B * dv;
+      dOs[r * DS] = mlp_f2bf(dv_i);
+      for (int a = 1; a < MLP_AKP; ++a) dOs[r * DS + a] = 0;
+      for (int off = 32; off >= 1; off >>= 1) { vl_i += __shfl_xor(vl_i, off, 64); dv_i += __shfl_xor(dv_i, off, 64); }
+      if (lane == 0) { P.part[(size_t)(A + 1) * NB + blk] = vl_i; P.part[(size_t)(2 * A + 2) * NB + blk] = dv_i; }
+    }
+  }
+  __syncthreads();
+  if (net == 0 && t < A) {       // column sums over the block's rows: d log_std and the action head's bias gradient
+    float my_ls = 0.f, my_db = 0.f;
+    for (int r = 0; r < 64; ++r) { my_ls += Sg[r * SOS + t]; my_db += So[r * SOS + t]; }
+    P.part[(size_t)t * NB + blk] = my_ls; P.part[(size_t)(A + 2 + t) * NB + blk] = my_db;
+  }
+  {   // feature-major copy of d(head output) for the head's weight gradient
+    const int Ah = net == 0 ? A : 1;
+    for (int e = t; e < Ah * 8; e += 256) {
+      const int c = e >> 3, ch = e & 7;
+      unsigned v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = (unsigned)dOs[(8 * ch + 2 * k) * DS + c] | ((unsigned)dOs[(8 * ch + 2 * k + 1) * DS + c] << 16);
+      *reinterpret_cast<uint4*>(P.dOT + ((size_t)net * 128 + c) * B + r0 + 8 * ch) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  // ---- d hidden 2 = (dOut Wh) * (H2 > 0), written over H2's LDS image (its A-operand role ended with the head)
+  {
+    mlp_gemm_64x64<MLP_AKP / 32>(acc, dOs, DS, P.WhT + (size_t)net * H * MLP_AKP, MLP_AKP, n0, lm, lq);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+        unsigned short h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          h[r] = Hs2[(m + r) * HS + n] != 0 ? mlp_f2bf(acc[mt][nt][r]) : (unsigned short)0;
+          Hs2[(m + r) * HS + n] = h[r];
+        }
+        *reinterpret_cast<uint2*>(P.dH2T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      }
+  }
+  __syncthreads();
+  // ---- d hidden 1 = (dH2 W2) * (H1 > 0)
+  {
+    mlp_gemm_64x64<H / 32>(acc, Hs2, HS, P.W2T + (size_t)net * H * H, H, n0, lm, lq);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+        unsigned short h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = Hs1[(m + r) * HS + n] != 0 ? mlp_f2bf(acc[mt][nt][r]) : (unsigned short)0;
+        *reinterpret_cast<uint2*>(P.dH1T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+      }
+  }
+}
+#define MLP_FWDBWD_LDS (512 + 64 * MLP_XS * 2 + 2 * 64 * MLP_HS * 2 + 64 * MLP_SOS * 4 + 64 * MLP_DS * 2 + 128 * 4)
+
+// ---- weight gradients.  C[m][n] = sum_r AT[m][r] BT[n][r] over the split's rows; 128 x 128 tile per workgroup (4 waves as
+// 2 x 2 of 64 x 64), both operands K(row)-contiguous in global memory.  Feature-major buffers are allocated in whole 128-row
+// groups, so every fragment load is in bounds; stores are masked by the true M, N.
+struct MlpWgradJob { const unsigned short *AT, *BT; int M, N, ldo, m0, n0; long long out_off, bias_off; };
+struct MlpWgradArgs { MlpWgradJob job[16]; int njobs, B, rows_per_split; long long G; float* slab; };
+
+__global__ void __launch_bounds__(256) k_mlp_wgrad(MlpWgradArgs P) {
+  const int jid = blockIdx.x % P.njobs, split = blockIdx.x / P.njobs;
+  const MlpWgradJob J = P.job[jid];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, lm = lane & 15, lq = lane >> 4;
+  const int wm = w >> 1, wn = w & 1, B = P.B;
+  const int mb = J.m0 + 64 * wm, nb = J.n0 + 64 * wn;
+  const size_t k0 = (size_t)split * P.rows_per_split;
+  myo_f32x4 acc[4][4], accb[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    accb[mt] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = J.bias_off >= 0 && nb == 0;
+  myo_bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+  const int ksteps = P.rows_per_split / 32;
+#pragma unroll 2
+  for (int ks = 0; ks < ksteps; ++ks) {
+    myo_bf16x8 a[4], b[4];
+    const size_t kk = k0 + 32 * ks + 8 * lq;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const myo_bf16x8*>(J.AT + (size_t)(mb + 16 * mt + lm) * B + kk);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const myo_bf16x8*>(J.BT + (size_t)(nb + 16 * nt + lm) * B + kk);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], ones, accb[mt], 0, 0, 0);
+    }
+  }
+  float* out = P.slab + (size_t)split * P.G;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mb + 16 * mt + 4 * lq + r, n = nb + 16 * nt + lm;
+        if (m < J.M && n < J.N) out[J.out_off + (size_t)m * J.ldo + n] = acc[mt][nt][r];
+      }
+  if (do_bias && lm == 0) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mb + 16 * mt + 4 * lq + r;
+        if (m < J.M) out[J.bias_off + m] = accb[mt][r];
+      }
+  }
+}
+
+// flat gradient = sum over splits of the slabs, in split order
+__global__ void __launch_bounds__(256) k_mlp_reduce(const float* __restrict__ slab, float* __restrict__ g, long long G, int splits) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= G) return;
+  float s = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < splits; ++k) s += slab[(size_t)k * G + e];
+  g[e] = s;
+}
+#endif

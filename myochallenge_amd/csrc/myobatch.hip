@@ -2193,6 +2193,96 @@ extern "C" int myo_adam_clip_step(float* p, const float* g, float* m, float* v, 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------ fused MLP PPO step
+#include "myo_ppo_mlp.h"
+#ifndef MYO_EMU
+struct MlpWs { unsigned short *W1p, *W2, *W2T, *Whp, *WhT; float* bias; unsigned short *XT, *H1T, *H2T, *dH1T, *dH2T, *dOT; float *part, *slab; size_t bytes; };
+static MlpWs mlp_carve(unsigned char* base, int B, int OP, int A, long long G) {
+  MlpWs w;
+  size_t o = 0;
+  auto take = [&](size_t n) { unsigned char* p = base ? base + o : nullptr; o += (n + 255) / 256 * 256; return p; };
+  const size_t H = MLP_H;
+  w.W1p = (unsigned short*)take(2 * H * OP * 2); w.W2 = (unsigned short*)take(2 * H * H * 2); w.W2T = (unsigned short*)take(2 * H * H * 2);
+  w.Whp = (unsigned short*)take(2 * MLP_APM * H * 2); w.WhT = (unsigned short*)take(2 * H * MLP_AKP * 2);
+  w.bias = (float*)take((4 * H + 2 * MLP_APM) * 4);
+  w.XT = (unsigned short*)take((size_t)128 * B * 2);
+  w.H1T = (unsigned short*)take(2 * H * (size_t)B * 2); w.H2T = (unsigned short*)take(2 * H * (size_t)B * 2);
+  w.dH1T = (unsigned short*)take(2 * H * (size_t)B * 2); w.dH2T = (unsigned short*)take(2 * H * (size_t)B * 2);
+  w.dOT = (unsigned short*)take((size_t)256 * B * 2);
+  w.part = (float*)take((size_t)(2 * A + 3) * (B / 64) * 4);
+  w.slab = (float*)take((size_t)MLP_SPLITK * G * 4);
+  w.bytes = o;
+  return w;
+}
+static int mlp_shape_ok(int B, int O, int A, int hidden) {
+  return hidden == MLP_H && O >= 1 && O <= MLP_OPMAX && A >= 1 && A <= MLP_APM && B >= 32 * MLP_SPLITK && B % (32 * MLP_SPLITK) == 0 && B % 64 == 0;
+}
+#endif
+extern "C" long long myo_ppo_mlp_workspace_bytes(int B, int obs_dim, int act_dim, int hidden, long long G) {
+#ifdef MYO_EMU
+  (void)B; (void)obs_dim; (void)act_dim; (void)hidden; (void)G;
+  return -1;
+#else
+  if (!mlp_shape_ok(B, obs_dim, act_dim, hidden) || G <= 0) return -1;
+  return (long long)mlp_carve(nullptr, B, (obs_dim + 31) / 32 * 32, act_dim, G).bytes;
+#endif
+}
+extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
+  if (!d || !d->obs || !d->act || !d->oldlp || !d->adv || !d->ret || !d->idx || !d->params || !d->grads || !d->adv_stats || !d->acc ||
+      !d->workspace)
+    return fail(MYO_E_ARG, "myo_ppo_mlp_step: null argument");
+#ifdef MYO_EMU
+  (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_step is a GPU kernel");
+#else
+  const int B = d->B, O = d->O, A = d->A, OP = (O + 31) / 32 * 32;
+  if (!mlp_shape_ok(B, O, A, d->hidden)) return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_step: needs hidden = %d, obs <= %d, act <= %d, batch a multiple of %d", MLP_H, MLP_OPMAX, MLP_APM, 32 * MLP_SPLITK);
+  const MlpWs w = mlp_carve((unsigned char*)d->workspace, B, OP, A, d->G);
+  if ((long long)w.bytes > d->workspace_bytes) return fail(MYO_E_ARG, "myo_ppo_mlp_step: workspace too small (%zu bytes needed)", w.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  static bool lds_set = false;
+  if (!lds_set) {
+    if (hipFuncSetAttribute((const void*)k_mlp_fwdbwd, hipFuncAttributeMaxDynamicSharedMemorySize, MLP_FWDBWD_LDS) != hipSuccess)
+      return fail(MYO_E_DEVICE, "myo_ppo_mlp_step: cannot reserve %d bytes of LDS", (int)MLP_FWDBWD_LDS);
+    lds_set = true;
+  }
+  if (d->compute_adv_stats) hipLaunchKernelGGL(k_adv_moments, dim3(1), dim3(1024), 0, st, d->adv, (const long long*)d->idx, B, d->adv_stats);
+  MlpPrepArgs pp;
+  pp.p = d->params; pp.O = O; pp.OP = OP; pp.Ah[0] = A; pp.Ah[1] = 1;
+  for (int k = 0; k < 2; ++k) {
+    pp.off_W1[k] = d->off_W1[k]; pp.off_b1[k] = d->off_b1[k]; pp.off_W2[k] = d->off_W2[k]; pp.off_b2[k] = d->off_b2[k];
+    pp.off_Wh[k] = d->off_Wh[k]; pp.off_bh[k] = d->off_bh[k];
+  }
+  pp.W1p = w.W1p; pp.W2 = w.W2; pp.W2T = w.W2T; pp.Whp = w.Whp; pp.WhT = w.WhT; pp.bias = w.bias;
+  hipLaunchKernelGGL(k_mlp_prep, dim3(256), dim3(256), 0, st, pp);
+  MlpArgs a;
+  a.obs = d->obs; a.act = d->act; a.oldlp = d->oldlp; a.adv = d->adv; a.ret = d->ret; a.idx = (const long long*)d->idx;
+  a.log_std = d->params + d->off_log_std; a.adv_stats = d->adv_stats;
+  a.W1p = w.W1p; a.W2 = w.W2; a.W2T = w.W2T; a.Whp = w.Whp; a.WhT = w.WhT; a.bias = w.bias;
+  a.XT = w.XT; a.H1T = w.H1T; a.H2T = w.H2T; a.dH1T = w.dH1T; a.dH2T = w.dH2T; a.dOT = w.dOT; a.part = w.part;
+  a.B = B; a.O = O; a.A = A; a.OP = OP; a.NB = B / 64; a.clip = d->clip; a.vf_coef = d->vf_coef;
+  hipLaunchKernelGGL(k_mlp_fwdbwd, dim3(B / 64, 2), dim3(256), MLP_FWDBWD_LDS, st, a);
+  MlpWgradArgs g;
+  g.njobs = 0; g.B = B; g.rows_per_split = B / MLP_SPLITK; g.G = d->G; g.slab = w.slab;
+  const size_t HB = (size_t)MLP_H * B;
+  for (int net = 0; net < 2; ++net) {
+    for (int m0 = 0; m0 < MLP_H; m0 += 128) {
+      for (int n0 = 0; n0 < MLP_H; n0 += 128)
+        g.job[g.njobs++] = MlpWgradJob{w.dH2T + net * HB, w.H1T + net * HB, MLP_H, MLP_H, MLP_H, m0, n0, d->off_W2[net], n0 == 0 ? d->off_b2[net] : -1};
+      g.job[g.njobs++] = MlpWgradJob{w.dH1T + net * HB, w.XT, MLP_H, O, O, m0, 0, d->off_W1[net], d->off_b1[net]};
+    }
+    for (int n0 = 0; n0 < MLP_H; n0 += 128)
+      g.job[g.njobs++] = MlpWgradJob{w.dOT + (size_t)net * 128 * B, w.H2T + net * HB, net == 0 ? A : 1, MLP_H, MLP_H, 0, n0, d->off_Wh[net], -1};
+  }
+  hipLaunchKernelGGL(k_mlp_wgrad, dim3(g.njobs * MLP_SPLITK), dim3(256), 0, st, g);
+  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((d->G + 255) / 256)), dim3(256), 0, st, (const float*)w.slab, d->grads, d->G, MLP_SPLITK);
+  hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, (const float*)w.part, d->acc, B / 64, A, d->ent_coef,
+                     d->grads + d->off_log_std, d->grads + d->off_bh[0], d->grads + d->off_bh[1]);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
 extern "C" int myo_batch_enable_timing(myo_batch* b, int on) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   b->timing = on;

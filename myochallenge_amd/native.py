@@ -57,6 +57,19 @@ class TaskCfg(C.Structure):
     ]
 
 
+class PpoMlpDesc(C.Structure):
+    """myo_ppo_mlp_desc of include/myobatch.h (one fused PPO minibatch step of the MLP actor-critic)."""
+    _fields_ = [
+        ("obs", C.c_void_p), ("act", C.c_void_p), ("oldlp", C.c_void_p), ("adv", C.c_void_p), ("ret", C.c_void_p), ("idx", C.c_void_p),
+        ("B", C.c_int32), ("O", C.c_int32), ("A", C.c_int32), ("hidden", C.c_int32),
+        ("params", C.c_void_p), ("grads", C.c_void_p), ("G", C.c_int64),
+        ("off_W1", C.c_int64 * 2), ("off_b1", C.c_int64 * 2), ("off_W2", C.c_int64 * 2), ("off_b2", C.c_int64 * 2),
+        ("off_Wh", C.c_int64 * 2), ("off_bh", C.c_int64 * 2), ("off_log_std", C.c_int64),
+        ("clip", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float), ("compute_adv_stats", C.c_int32),
+        ("adv_stats", C.c_void_p), ("acc", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+    ]
+
+
 class MyoError(RuntimeError):
     pass
 
@@ -118,6 +131,9 @@ class NativeLib:
         L.myo_lstm_cell_fwd.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 6
         L.myo_lstm_cell_bwd.argtypes = [vp] * 7 + [i32] * 4 + [vp] * 3
         L.myo_adam_clip_step.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, vp, vp]
+        L.myo_ppo_mlp_workspace_bytes.restype = C.c_longlong
+        L.myo_ppo_mlp_workspace_bytes.argtypes = [i32, i32, i32, i32, C.c_longlong]
+        L.myo_ppo_mlp_step.argtypes = [C.POINTER(PpoMlpDesc), vp]
 
     def check(self, rc: int):
         if rc != 0:
@@ -158,7 +174,7 @@ EXPORTED_SYMBOLS = [
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
-    "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_last_error", "myo_version",
+    "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_ppo_mlp_workspace_bytes", "myo_ppo_mlp_step", "myo_last_error", "myo_version",
 ]
 
 

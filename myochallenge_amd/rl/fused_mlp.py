@@ -213,6 +213,56 @@ class FusedPPOStep:
         self.external_adv_stats = False      # True: the caller fills self.stats (global / no advantage normalisation)
         self.A = A
         self._work = {}
+        self._mfma = {}                      # per minibatch size: (descriptor, workspace) of myo_ppo_mlp_step
+        self.use_mfma_step = True            # the one-launch-per-stage path (csrc/myo_ppo_mlp.h) whenever the shapes fit
+
+    # ---- fused forward / loss / backward on the matrix cores (libmyobatch: myo_ppo_mlp_step)
+    def _mfma_desc(self, B, obs_all, act_all, oldlp_all, adv_all, ret_all, idx):
+        """Descriptor of myo_ppo_mlp_step for minibatch size B, or None when the architecture / batch size has no fused path
+        (then the GEMM-per-layer path below runs).  The descriptor and its workspace are cached: hipGraph-safe."""
+        from .. import native
+        flat = getattr(self.policy, "_flat", None)
+        if not self.use_mfma_step or flat is None or self.merged is None or len(self.merged) != 2:
+            return None
+        pi, vf = self.nets["pi"], self.nets["vf"]
+        O = obs_all.shape[1]
+        hid = pi[0].weight.shape[0]
+        shapes_ok = all(tuple(l.weight.shape) == s for l, s in ((pi[0], (hid, O)), (vf[0], (hid, O)), (pi[1], (hid, hid)), (vf[1], (hid, hid)),
+                                                               (pi[2], (self.A, hid)), (vf[2], (1, hid))))
+        if not shapes_ok or self.policy.log_std.dim() != 1 or obs_all.dtype != torch.float32:
+            return None
+        G = flat["p"].numel()
+        key = (B, obs_all.data_ptr(), act_all.data_ptr(), oldlp_all.data_ptr(), adv_all.data_ptr(), ret_all.data_ptr(), idx.data_ptr())
+        hit = self._mfma.get(key)
+        if hit is not None:
+            return hit[0]
+        nbytes = self.lib.L.myo_ppo_mlp_workspace_bytes(B, O, self.A, hid, G)
+        if nbytes <= 0:
+            self._mfma[key] = (None, None)
+            return None
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=obs_all.device)
+        slot = {id(p): sl[0] for p, sl in zip(flat["params"], flat["slots"])}
+        d = native.PpoMlpDesc()
+        d.obs, d.act, d.oldlp, d.adv, d.ret, d.idx = (t.data_ptr() for t in (obs_all, act_all, oldlp_all, adv_all, ret_all, idx))
+        d.B, d.O, d.A, d.hidden = B, O, self.A, hid
+        d.params, d.grads, d.G = flat["p"].data_ptr(), flat["g"].data_ptr(), G
+        for k, (a, b) in enumerate(zip(pi, vf)):
+            for net, lin in enumerate((a, b)):
+                wname, bname = (("off_W1", "off_b1"), ("off_W2", "off_b2"), ("off_Wh", "off_bh"))[k]
+                getattr(d, wname)[net] = slot[id(lin.weight)]
+                getattr(d, bname)[net] = slot[id(lin.bias)]
+        d.off_log_std = slot[id(self.policy.log_std)]
+        d.clip, d.vf_coef, d.ent_coef = self.clip, self.vf, self.ent
+        d.adv_stats, d.acc = self.stats.data_ptr(), self.acc.data_ptr()
+        d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        self._mfma[key] = (d, ws)
+        return d
+
+    def _mfma_step(self, d):
+        d.compute_adv_stats = 0 if self.external_adv_stats else 1
+        stream = torch.cuda.current_stream(self.acc.device).cuda_stream
+        self.lib.check(self.lib.L.myo_ppo_mlp_step(C.byref(d), C.c_void_p(stream)))
+        return self.acc[self.A], self.acc[self.A + 1]
 
     def _workbuf(self, key, n):
         """Zero-initialised scratch of the block-ticket kernels (allocated once per shape: graph-safe)."""
@@ -304,6 +354,9 @@ class FusedPPOStep:
         """One minibatch step on rows `idx` of the rollout arrays (merged path: HIP gather kernel)."""
         if self.merged is None:
             return self.run(obs_all[idx], act_all[idx], oldlp_all[idx], adv_all[idx], ret_all[idx])
+        d = self._mfma_desc(idx.shape[0], obs_all, act_all, oldlp_all, adv_all, ret_all, idx)
+        if d is not None:
+            return self._mfma_step(d)
         B, O, A = idx.shape[0], obs_all.shape[1], self.A
         dev = obs_all.device
         x2 = torch.empty((2, B, O), device=dev, dtype=torch.bfloat16)
@@ -319,6 +372,14 @@ class FusedPPOStep:
 
     @torch.no_grad()
     def _run_merged(self, obs, actions, old_logp, adv, returns):
+        if self.use_mfma_step:
+            B = obs.shape[0]
+            ar = self._work.get(("arange", B))
+            if ar is None:
+                ar = self._work[("arange", B)] = torch.arange(B, device=obs.device)
+            d = self._mfma_desc(B, obs.contiguous(), actions.contiguous(), old_logp.contiguous(), adv.contiguous(), returns.contiguous(), ar)
+            if d is not None:
+                return self._mfma_step(d)
         var, mu = torch.var_mean(adv)
         self.stats[0].copy_(mu)
         self.stats[1].copy_(var.sqrt())

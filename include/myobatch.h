@@ -313,7 +313,7 @@ int myo_gae(const float* rew, const float* val, const float* starts, const float
  * minibatch advantages (SB3's per-minibatch normalisation); 0: the caller supplies them ({0, 1} = no normalisation).
  * workspace: device memory of myo_ppo_mlp_workspace_bytes() bytes, ZERO-FILLED ONCE by the caller and then owned by these
  * calls (weight images, feature-major activations, split-K slabs).  Deterministic: no float atomics.  Returns
- * MYO_E_UNSUPPORTED for other shapes (hidden != 256, obs > 128, act > 48, B not a multiple of 512). */
+ * MYO_E_UNSUPPORTED for other shapes (hidden != 256, obs > 128, act > 48, B not a multiple of 1024). */
 typedef struct myo_ppo_mlp_desc {
   const float *obs, *act, *oldlp, *adv, *ret;
   const int64_t* idx;

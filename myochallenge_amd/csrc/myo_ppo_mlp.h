@@ -90,14 +90,22 @@ __global__ void __launch_bounds__(256) k_mlp_prep(MlpPrepArgs P) {
   }
 }
 
-// mean and unbiased std of adv[idx[0..B)) in ONE block (two passes over LDS partials, fixed order: deterministic)
+// mean and unbiased std of adv[idx[0..B)) in ONE block: every thread keeps its (up to 32) gathered values in registers —
+// one memory pass, all gathers in flight together — and the two reductions run over LDS in a fixed order (deterministic)
 __global__ void __launch_bounds__(1024) k_adv_moments(const float* __restrict__ adv, const long long* __restrict__ idx, int B,
                                                       float* __restrict__ stats) {
   __shared__ float red[1024];
   __shared__ float s_mean;
   const int t = threadIdx.x;
+  constexpr int PER = 32;                 // B <= 32768 in registers; larger minibatches re-read (second loop below)
+  long long id[PER];
+  float v[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { const int i = t + 1024 * k; id[k] = i < B ? idx[i] : -1; }
   float s = 0.f;
-  for (int i = t; i < B; i += 1024) s += adv[idx[i]];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { v[k] = id[k] >= 0 ? adv[id[k]] : 0.f; s += v[k]; }
+  for (int i = t + 1024 * PER; i < B; i += 1024) s += adv[idx[i]];
   red[t] = s;
   __syncthreads();
   for (int w = 512; w >= 1; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
@@ -105,216 +113,287 @@ __global__ void __launch_bounds__(1024) k_adv_moments(const float* __restrict__ 
   __syncthreads();
   const float mean = s_mean;
   float m2 = 0.f;
-  for (int i = t; i < B; i += 1024) { const float d = adv[idx[i]] - mean; m2 += d * d; }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) { const float d = v[k] - mean; m2 += id[k] >= 0 ? d * d : 0.f; }
+  for (int i = t + 1024 * PER; i < B; i += 1024) { const float d = adv[idx[i]] - mean; m2 += d * d; }
   red[t] = m2;
   __syncthreads();
   for (int w = 512; w >= 1; w >>= 1) { if (t < w) red[t] += red[t + w]; __syncthreads(); }
   if (t == 0) { stats[0] = mean; stats[1] = sqrtf(red[0] / (B > 1 ? B - 1 : 1)); }
 }
 
-// 64 rows x 256 columns through one layer: acc[mt][nt] += A(LDS rows, K-contiguous) * W(global rows, K-contiguous)'
+// One wave's slab of a layer: BM rows x 64 columns, acc[mt][nt] += A(LDS rows, K-contiguous) * W(global rows, K-contiguous)'.
+// The weight fragments of a WHOLE slab (KSTEPS x 4 x 16 B per lane) are requested by mlp_load_w one phase ahead of the MFMAs
+// that consume them (mlp_mma_slab): a layer's weights were written by the previous launch on whichever XCD ran k_mlp_prep, so
+// the first workgroups of every other XCD miss their L2 on each line; requested next to their use that was up to eight serial
+// misses per layer (8.8 us of a 33 us workgroup), requested a phase ahead they fly during the previous epilogue and barrier.
 template <int KSTEPS>
-__device__ __forceinline__ void mlp_gemm_64x64(myo_f32x4 (&acc)[4][4], const unsigned short* As, int as_stride,
-                                               const unsigned short* Wg, int w_stride, int n0, int lm, int lq) {
+__device__ __forceinline__ void mlp_load_w(myo_bf16x8 (&bw)[8][4], const unsigned short* Wg, int w_stride, int n0, int lm, int lq) {
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt)
+  for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) bw[ks][nt] = *reinterpret_cast<const myo_bf16x8*>(Wg + (size_t)(n0 + 16 * nt + lm) * w_stride + 32 * ks + 8 * lq);
+  __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the loads back to their uses to save registers)
+}
+template <int KSTEPS, int MT>
+__device__ __forceinline__ void mlp_mma_slab(myo_f32x4 (&acc)[MT][4], const unsigned short* As, int as_stride, const myo_bf16x8 (&bw)[8][4],
+                                             int lm, int lq) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    myo_bf16x8 a[4], b[4];
+    myo_bf16x8 a[MT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const myo_bf16x8*>(Wg + (size_t)(n0 + 16 * nt + lm) * w_stride + 32 * ks + 8 * lq);
+    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const myo_bf16x8*>(As + (16 * mt + lm) * as_stride + 32 * ks + 8 * lq);
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const myo_bf16x8*>(As + (16 * mt + lm) * as_stride + 32 * ks + 8 * lq);
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bw[ks][nt], acc[mt][nt], 0, 0, 0);
   }
+  __builtin_amdgcn_sched_barrier(0);
 }
 
-__global__ void __launch_bounds__(256) k_mlp_fwdbwd(MlpArgs P) {
-  constexpr int H = MLP_H, XS = MLP_XS, HS = MLP_HS, DS = MLP_DS, SOS = MLP_SOS;
-  extern __shared__ __align__(16) unsigned char mlp_smem[];
-  long long* s_idx = reinterpret_cast<long long*>(mlp_smem);                      // [64]
-  unsigned short* Xs = reinterpret_cast<unsigned short*>(mlp_smem + 512);         // [64][XS] bf16; later So fp32 [64][SOS]
-  float* So = reinterpret_cast<float*>(mlp_smem + 512);
-  unsigned short* Hs1 = Xs + 64 * XS;                                             // [64][HS]
-  unsigned short* Hs2 = Hs1 + 64 * HS;                                            // [64][HS]
-  float* Sg = reinterpret_cast<float*>(Hs2 + 64 * HS);                            // [64][SOS] fp32
-  unsigned short* dOs = reinterpret_cast<unsigned short*>(Sg + 64 * SOS);         // [64][DS]
-  float* s_ls = reinterpret_cast<float*>(dOs + 64 * DS);                          // [64] log_std, [64] exp(-log_std)
-  static_assert(64 * MLP_SOS * 4 <= 64 * MLP_XS * 2, "the head output tile fits where X was");
-  const int t = threadIdx.x, w = t >> 6, lane = t & 63, lm = lane & 15, lq = lane >> 4;
-  const int net = blockIdx.y, blk = blockIdx.x, r0 = blk * 64, B = P.B, O = P.O, A = P.A, OP = P.OP;
-  const int n0 = 64 * w;
-  if (t < 64) s_idx[t] = P.idx[r0 + t];
-  if (t < A) { const float ls = P.log_std[t]; s_ls[t] = ls; s_ls[64 + t] = __expf(-ls); }
-  __syncthreads();
-  // ---- gather: X rows -> bf16 LDS image (zero-padded to OP columns)
-  for (int e = t; e < 64 * OP; e += 256) {
-    const int r = e / OP, c = e - r * OP;
-    Xs[r * XS + c] = c < O ? mlp_f2bf(P.obs[(size_t)s_idx[r] * O + c]) : (unsigned short)0;
-  }
-  __syncthreads();
-  if (net == 0) {   // feature-major copy of X for the weight-gradient GEMM (the critic's block has the same rows)
-    for (int e = t; e < OP * 8; e += 256) {
-      const int c = e >> 3, ch = e & 7;
-      unsigned v[4];
+#ifdef MLP_PROF
+__device__ unsigned long long g_mlp_prof[16];
+#define MLP_STAMP(k) { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 3 && blockIdx.y == 0) g_mlp_prof[k] = wall_clock64(); }
+extern "C" int myo_debug_mlp_prof(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_prof), sizeof g_mlp_prof); }
+#else
+#define MLP_STAMP(k)
+#endif
+
+// LDS of one workgroup (BM rows): row ids, X (later the head output), H1, H2 (later dH2), actions (later d log_std terms),
+// d(head output), log_std / exp(-log_std), adv / old log-prob / return.  BM = 32: 55 KB -> two workgroups per CU, whose phases
+// (gather, MFMA slabs, the one-wave loss phase, feature-major stores) overlap each other's latencies.
+#define MLP_BM 32
+#define MLP_FWDBWD_LDS (512 + MLP_BM * MLP_XS * 2 + 2 * MLP_BM * MLP_HS * 2 + MLP_BM * MLP_SOS * 4 + MLP_BM * MLP_DS * 2 + 128 * 4 + 192 * 4)
+
+// activation epilogue of one slab: bias + ReLU -> bf16 -> row-major LDS image (next layer's A operand) + feature-major global copy
+template <int MT>
+__device__ __forceinline__ void mlp_store_act(const myo_f32x4 (&acc)[MT][4], const float (&bb)[4], unsigned short* Hs, unsigned short* HT,
+                                              size_t B, int r0, int n0, int lm, int lq) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) v[k] = (unsigned)Xs[(8 * ch + 2 * k) * XS + c] | ((unsigned)Xs[(8 * ch + 2 * k + 1) * XS + c] << 16);
-      *reinterpret_cast<uint4*>(P.XT + (size_t)c * B + r0 + 8 * ch) = make_uint4(v[0], v[1], v[2], v[3]);
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+      unsigned short h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { h[r] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb[nt], 0.f)); Hs[(m + r) * MLP_HS + n] = h[r]; }
+      *reinterpret_cast<uint2*>(HT + (size_t)n * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
     }
-  }
-  myo_f32x4 acc[4][4];
+}
+// gradient epilogue: * (H > 0) without a branch (the mask is all-ones / zero bits) -> bf16 -> optional LDS image + feature-major global copy
+template <int MT, bool TO_LDS>
+__device__ __forceinline__ void mlp_store_grad(const myo_f32x4 (&acc)[MT][4], unsigned short* Hs, unsigned short* HT, size_t B, int r0, int n0,
+                                               int lm, int lq) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+      unsigned short h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned short on = (unsigned short)(-(int)(Hs[(m + r) * MLP_HS + n] != 0));
+        h[r] = mlp_f2bf(acc[mt][nt][r]) & on;
+        if (TO_LDS) Hs[(m + r) * MLP_HS + n] = h[r];
+      }
+      *reinterpret_cast<uint2*>(HT + (size_t)n * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_mlp_fwdbwd(MlpArgs P) {
+  constexpr int H = MLP_H, XS = MLP_XS, HS = MLP_HS, DS = MLP_DS, SOS = MLP_SOS, BM = MLP_BM, MT = BM / 16, RW = BM / 4;
+  extern __shared__ __align__(16) unsigned char mlp_smem[];
+  long long* s_idx = reinterpret_cast<long long*>(mlp_smem);                      // [BM] (64 slots)
+  unsigned short* Xs = reinterpret_cast<unsigned short*>(mlp_smem + 512);         // [BM][XS] bf16; later So fp32 [BM][SOS]
+  float* So = reinterpret_cast<float*>(mlp_smem + 512);
+  unsigned short* Hs1 = Xs + BM * XS;                                             // [BM][HS]
+  unsigned short* Hs2 = Hs1 + BM * HS;                                            // [BM][HS]
+  float* Sa = reinterpret_cast<float*>(Hs2 + BM * HS);                            // [BM][SOS] actions, then dlogp (z^2 - 1) in place
+  unsigned short* dOs = reinterpret_cast<unsigned short*>(Sa + BM * SOS);         // [BM][DS]
+  float* s_ls = reinterpret_cast<float*>(dOs + BM * DS);                          // [64] log_std, [64] exp(-log_std)
+  float* s_row = s_ls + 128;                                                      // [3][64] adv / old log-prob / return of the block's rows
+  static_assert(BM * MLP_SOS * 4 <= BM * MLP_XS * 2, "the head output tile fits where X was");
+  static_assert(BM == 32 || BM == 64, "wave / tile mapping below");
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, lm = lane & 15, lq = lane >> 4;
+  const int net = blockIdx.y, blk = blockIdx.x, r0 = blk * BM, B = P.B, O = P.O, A = P.A, OP = P.OP;
+  const int n0 = 64 * w;
+  MLP_STAMP(0)
+  if (t < BM) s_idx[t] = P.idx[r0 + t];
+  if (t < A) { const float ls = P.log_std[t]; s_ls[t] = ls; s_ls[64 + t] = __expf(-ls); }
   const float* b1 = P.bias + net * H; const float* b2 = P.bias + 2 * H + net * H; const float* bh = P.bias + 4 * H + net * MLP_APM;
-  // ---- layer 1 (K = OP, a multiple of 32 up to 128)
+  float bb1[4], bb2[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) { bb1[nt] = b1[n0 + 16 * nt + lm]; bb2[nt] = b2[n0 + 16 * nt + lm]; }
+  myo_bf16x8 bw[8][4];                   // the weight fragments of the NEXT MFMA slab (see mlp_load_w)
   {
     const unsigned short* W1 = P.W1p + (size_t)net * H * OP;
-    if (OP == 96) mlp_gemm_64x64<3>(acc, Xs, XS, W1, OP, n0, lm, lq);
-    else if (OP == 128) mlp_gemm_64x64<4>(acc, Xs, XS, W1, OP, n0, lm, lq);
-    else if (OP == 64) mlp_gemm_64x64<2>(acc, Xs, XS, W1, OP, n0, lm, lq);
-    else mlp_gemm_64x64<1>(acc, Xs, XS, W1, OP, n0, lm, lq);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
-        const float bb = b1[n];
-        unsigned short h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb, 0.f)); Hs1[(m + r) * HS + n] = h[r]; }
-        *reinterpret_cast<uint2*>(P.H1T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-      }
+    if (OP == 96) mlp_load_w<3>(bw, W1, OP, n0, lm, lq);
+    else if (OP == 128) mlp_load_w<4>(bw, W1, OP, n0, lm, lq);
+    else if (OP == 64) mlp_load_w<2>(bw, W1, OP, n0, lm, lq);
+    else mlp_load_w<1>(bw, W1, OP, n0, lm, lq);
   }
   __syncthreads();
-  // ---- layer 2
-  {
-    mlp_gemm_64x64<H / 32>(acc, Hs1, HS, P.W2 + (size_t)net * H * H, H, n0, lm, lq);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
-        const float bb = b2[n];
-        unsigned short h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { h[r] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb, 0.f)); Hs2[(m + r) * HS + n] = h[r]; }
-        *reinterpret_cast<uint2*>(P.H2T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-      }
+  if (t < BM) {
+    const size_t src = (size_t)s_idx[t];
+    s_row[t] = P.adv[src]; s_row[64 + t] = P.oldlp[src]; s_row[128 + t] = P.ret[src];
   }
-  __syncthreads();
-  // ---- head: wave w takes rows 16w .. 16w+15, all MLP_APM outputs (fp32 into So, which reuses X's storage)
+  // ---- gather.  Wave w takes rows RW w .. RW w + RW - 1; a row is read by the whole wave (columns lane and lane + 64: coalesced),
+  // and all loads of a lane are in flight before the first is used.  X -> bf16 LDS image (zero-padded to OP columns).
   {
-    myo_f32x4 ah[3];
+    float v[RW][2], av[RW];
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) ah[nt] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned short* Wh = P.Whp + (size_t)net * MLP_APM * H;
-#pragma unroll 2
-    for (int ks = 0; ks < H / 32; ++ks) {
-      const myo_bf16x8 a = *reinterpret_cast<const myo_bf16x8*>(Hs2 + (16 * w + lm) * HS + 32 * ks + 8 * lq);
-#pragma unroll
-      for (int nt = 0; nt < 3; ++nt) {
-        const myo_bf16x8 b = *reinterpret_cast<const myo_bf16x8*>(Wh + (size_t)(16 * nt + lm) * H + 32 * ks + 8 * lq);
-        ah[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, ah[nt], 0, 0, 0);
-      }
+    for (int k = 0; k < RW; ++k) {
+      const size_t row = (size_t)s_idx[RW * w + k];
+      v[k][0] = lane < O ? P.obs[row * O + lane] : 0.f;
+      v[k][1] = lane + 64 < O ? P.obs[row * O + lane + 64] : 0.f;
+      av[k] = (net == 0 && lane < A) ? P.act[row * A + lane] : 0.f;
     }
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt)
+    for (int k = 0; k < RW; ++k) {
+      Xs[(RW * w + k) * XS + lane] = mlp_f2bf(v[k][0]);
+      if (lane + 64 < OP) Xs[(RW * w + k) * XS + lane + 64] = mlp_f2bf(v[k][1]);
+      if (lane < A) Sa[(RW * w + k) * SOS + lane] = av[k];
+    }
+    if (net == 0) {   // feature-major copy of X for the weight-gradient GEMM (the critic's block has the same rows): RW rows per column and lane
 #pragma unroll
-      for (int r = 0; r < 4; ++r) So[(16 * w + 4 * lq + r) * SOS + 16 * nt + lm] = ah[nt][r] + bh[16 * nt + lm];
+      for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h;
+        if (c < OP) {
+          unsigned u[RW / 2];
+#pragma unroll
+          for (int k = 0; k < RW / 2; ++k) u[k] = (unsigned)mlp_f2bf(v[2 * k][h]) | ((unsigned)mlp_f2bf(v[2 * k + 1][h]) << 16);
+          uint4* dst = reinterpret_cast<uint4*>(P.XT + (size_t)c * B + r0 + RW * w);
+#pragma unroll
+          for (int q = 0; q < RW / 8; ++q) dst[q] = make_uint4(u[4 * q], u[4 * q + 1], u[4 * q + 2], u[4 * q + 3]);
+        }
+      }
+    }
   }
   __syncthreads();
+  MLP_STAMP(1)
+  myo_f32x4 acc[MT][4];
+  // ---- layer 1 (K = OP, a multiple of 32 up to 128)
+  if (OP == 96) mlp_mma_slab<3, MT>(acc, Xs, XS, bw, lm, lq);
+  else if (OP == 128) mlp_mma_slab<4, MT>(acc, Xs, XS, bw, lm, lq);
+  else if (OP == 64) mlp_mma_slab<2, MT>(acc, Xs, XS, bw, lm, lq);
+  else mlp_mma_slab<1, MT>(acc, Xs, XS, bw, lm, lq);
+  mlp_load_w<H / 32>(bw, P.W2 + (size_t)net * H * H, H, n0, lm, lq);
+  mlp_store_act<MT>(acc, bb1, Hs1, P.H1T + (size_t)net * H * B, B, r0, n0, lm, lq);
+  __syncthreads();
+  MLP_STAMP(2)
+  // ---- layer 2
+  mlp_mma_slab<H / 32, MT>(acc, Hs1, HS, bw, lm, lq);
+  // the head's tiles (16 rows x 16 outputs, MT x 3 of them) are dealt to the waves: tile w and tile w + 4
+  const unsigned short* Wh = P.Whp + (size_t)net * MLP_APM * H;
+  myo_bf16x8 bh2[2][H / 32];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tile = w + 4 * q, nt = tile / MT;
+    if (tile < MT * 3) {
+#pragma unroll
+      for (int ks = 0; ks < H / 32; ++ks) bh2[q][ks] = *reinterpret_cast<const myo_bf16x8*>(Wh + (size_t)(16 * nt + lm) * H + 32 * ks + 8 * lq);
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mlp_store_act<MT>(acc, bb2, Hs2, P.H2T + (size_t)net * H * B, B, r0, n0, lm, lq);
+  __syncthreads();
+  MLP_STAMP(3)
+  // ---- head (fp32 into So, which reuses X's storage)
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int tile = w + 4 * q;
+    if (tile < MT * 3) {
+      const int mt = tile % MT, nt = tile / MT;
+      myo_f32x4 ah = myo_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < H / 32; ++ks) {
+        const myo_bf16x8 a = *reinterpret_cast<const myo_bf16x8*>(Hs2 + (16 * mt + lm) * HS + 32 * ks + 8 * lq);
+        ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh2[q][ks], ah, 0, 0, 0);
+      }
+      const float bv = bh[16 * nt + lm];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) So[(16 * mt + 4 * lq + r) * SOS + 16 * nt + lm] = ah[r] + bv;
+    }
+  }
+  mlp_load_w<MLP_AKP / 32>(bw, P.WhT + (size_t)net * H * MLP_AKP, MLP_AKP, n0, lm, lq);      // d hidden 2's weights fly during the loss phase
+  __syncthreads();
+  MLP_STAMP(4)
   // ---- loss gradient w.r.t. the head output (k_ppo_loss's arithmetic), one row per lane of wave 0
   const int NB = P.NB;
   if (w == 0) {
-    const int r = lane;
-    const size_t src = (size_t)s_idx[r];
+    const int r = lane < BM ? lane : 0;
+    const bool on = lane < BM;
     if (net == 0) {
       float logp = 0.f;
       for (int a = 0; a < A; ++a) {
-        const float z = (P.act[src * A + a] - So[r * SOS + a]) * s_ls[64 + a];
+        const float z = (Sa[r * SOS + a] - So[r * SOS + a]) * s_ls[64 + a];
         logp += -0.5f * z * z - s_ls[a] - 0.9189385332046727f;
       }
-      const float an = (P.adv[src] - P.adv_stats[0]) / (P.adv_stats[1] + 1e-8f);
-      const float ratio = __expf(logp - P.oldlp[src]);
+      const float an = (s_row[r] - P.adv_stats[0]) / (P.adv_stats[1] + 1e-8f);
+      const float ratio = __expf(logp - s_row[64 + r]);
       const float s1 = an * ratio;
       const float rc = fminf(fmaxf(ratio, 1.f - P.clip), 1.f + P.clip);
       const float s2 = an * rc;
-      float pl_i = -fminf(s1, s2) / B;
+      float pl_i = on ? -fminf(s1, s2) / B : 0.f;
       const bool inside = (ratio > 1.f - P.clip) && (ratio < 1.f + P.clip);
       const float dlogp = -(an * ratio) * ((s1 <= s2) ? 1.f : (inside ? 1.f : 0.f)) / B;
-      for (int a = 0; a < A; ++a) {
-        const float inv = s_ls[64 + a];
-        const float z = (P.act[src * A + a] - So[r * SOS + a]) * inv;
-        const float dm = dlogp * z * inv;
-        So[r * SOS + a] = dm;
-        Sg[r * SOS + a] = dlogp * (z * z - 1.f);
-        dOs[r * DS + a] = mlp_f2bf(dm);
+      if (on) {
+        for (int a = 0; a < A; ++a) {
+          const float inv = s_ls[64 + a];
+          const float z = (Sa[r * SOS + a] - So[r * SOS + a]) * inv;
+          const float dm = dlogp * z * inv;
+          So[r * SOS + a] = dm;
+          Sa[r * SOS + a] = dlogp * (z * z - 1.f);
+          dOs[r * DS + a] = mlp_f2bf(dm);
+        }
+        for (int a = A; a < MLP_AKP; ++a) dOs[r * DS + a] = 0;
       }
-      for (int a = A; a < MLP_AKP; ++a) dOs[r * DS + a] = 0;
       for (int off = 32; off >= 1; off >>= 1) pl_i += __shfl_xor(pl_i, off, 64);
       if (lane == 0) P.part[(size_t)A * NB + blk] = pl_i;
     } else {
-      const float dv = So[r * SOS] - P.ret[src];
-      float vl_i = dv * dv / B, dv_i = P.vf_coef * 2.f / B * dv;
-      dOs[r * DS] = mlp_f2bf(dv_i);
-      for (int a = 1; a < MLP_AKP; ++a) dOs[r * DS + a] = 0;
+      const float dv = So[r * SOS] - s_row[128 + r];
+      float vl_i = on ? dv * dv / B : 0.f, dv_i = on ? P.vf_coef * 2.f / B * dv : 0.f;
+      if (on) {
+        dOs[r * DS] = mlp_f2bf(dv_i);
+        for (int a = 1; a < MLP_AKP; ++a) dOs[r * DS + a] = 0;
+      }
       for (int off = 32; off >= 1; off >>= 1) { vl_i += __shfl_xor(vl_i, off, 64); dv_i += __shfl_xor(dv_i, off, 64); }
       if (lane == 0) { P.part[(size_t)(A + 1) * NB + blk] = vl_i; P.part[(size_t)(2 * A + 2) * NB + blk] = dv_i; }
     }
   }
   __syncthreads();
+  MLP_STAMP(5)
   if (net == 0 && t < A) {       // column sums over the block's rows: d log_std and the action head's bias gradient
     float my_ls = 0.f, my_db = 0.f;
-    for (int r = 0; r < 64; ++r) { my_ls += Sg[r * SOS + t]; my_db += So[r * SOS + t]; }
+    for (int r = 0; r < BM; ++r) { my_ls += Sa[r * SOS + t]; my_db += So[r * SOS + t]; }
     P.part[(size_t)t * NB + blk] = my_ls; P.part[(size_t)(A + 2 + t) * NB + blk] = my_db;
   }
   {   // feature-major copy of d(head output) for the head's weight gradient
     const int Ah = net == 0 ? A : 1;
-    for (int e = t; e < Ah * 8; e += 256) {
-      const int c = e >> 3, ch = e & 7;
+    for (int e = t; e < Ah * (BM / 8); e += 256) {
+      const int c = e / (BM / 8), ch = e % (BM / 8);
       unsigned v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) v[k] = (unsigned)dOs[(8 * ch + 2 * k) * DS + c] | ((unsigned)dOs[(8 * ch + 2 * k + 1) * DS + c] << 16);
       *reinterpret_cast<uint4*>(P.dOT + ((size_t)net * 128 + c) * B + r0 + 8 * ch) = make_uint4(v[0], v[1], v[2], v[3]);
     }
   }
+  MLP_STAMP(6)
   // ---- d hidden 2 = (dOut Wh) * (H2 > 0), written over H2's LDS image (its A-operand role ended with the head)
-  {
-    mlp_gemm_64x64<MLP_AKP / 32>(acc, dOs, DS, P.WhT + (size_t)net * H * MLP_AKP, MLP_AKP, n0, lm, lq);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
-        unsigned short h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          h[r] = Hs2[(m + r) * HS + n] != 0 ? mlp_f2bf(acc[mt][nt][r]) : (unsigned short)0;
-          Hs2[(m + r) * HS + n] = h[r];
-        }
-        *reinterpret_cast<uint2*>(P.dH2T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-      }
-  }
+  mlp_mma_slab<MLP_AKP / 32, MT>(acc, dOs, DS, bw, lm, lq);
+  mlp_load_w<H / 32>(bw, P.W2T + (size_t)net * H * H, H, n0, lm, lq);
+  mlp_store_grad<MT, true>(acc, Hs2, P.dH2T + (size_t)net * H * B, B, r0, n0, lm, lq);
   __syncthreads();
+  MLP_STAMP(7)
   // ---- d hidden 1 = (dH2 W2) * (H1 > 0)
-  {
-    mlp_gemm_64x64<H / 32>(acc, Hs2, HS, P.W2T + (size_t)net * H * H, H, n0, lm, lq);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
-        unsigned short h[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = Hs1[(m + r) * HS + n] != 0 ? mlp_f2bf(acc[mt][nt][r]) : (unsigned short)0;
-        *reinterpret_cast<uint2*>(P.dH1T + ((size_t)net * H + n) * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-      }
-  }
+  mlp_mma_slab<H / 32, MT>(acc, Hs2, HS, bw, lm, lq);
+  mlp_store_grad<MT, false>(acc, Hs1, P.dH1T + (size_t)net * H * B, B, r0, n0, lm, lq);
+  MLP_STAMP(8)
 }
-#define MLP_FWDBWD_LDS (512 + 64 * MLP_XS * 2 + 2 * 64 * MLP_HS * 2 + 64 * MLP_SOS * 4 + 64 * MLP_DS * 2 + 128 * 4)
 
 // ---- weight gradients.  C[m][n] = sum_r AT[m][r] BT[n][r] over the split's rows; 128 x 128 tile per workgroup (4 waves as
 // 2 x 2 of 64 x 64), both operands K(row)-contiguous in global memory.  Feature-major buffers are allocated in whole 128-row
@@ -340,22 +419,35 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(MlpWgradArgs P) {
   myo_bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
-  const int ksteps = P.rows_per_split / 32;
-#pragma unroll 2
-  for (int ks = 0; ks < ksteps; ++ks) {
-    myo_bf16x8 a[4], b[4];
-    const size_t kk = k0 + 32 * ks + 8 * lq;
+  const int ksteps = P.rows_per_split / 32;       // even (rows_per_split is a multiple of 64)
+  const unsigned short* ap[4]; const unsigned short* bp[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const myo_bf16x8*>(J.AT + (size_t)(mb + 16 * mt + lm) * B + kk);
+  for (int q = 0; q < 4; ++q) { ap[q] = J.AT + (size_t)(mb + 16 * q + lm) * B + k0 + 8 * lq; bp[q] = J.BT + (size_t)(nb + 16 * q + lm) * B + k0 + 8 * lq; }
+  myo_bf16x8 a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) b[nt] = *reinterpret_cast<const myo_bf16x8*>(J.BT + (size_t)(nb + 16 * nt + lm) * B + kk);
+  for (int q = 0; q < 4; ++q) { a0[q] = *reinterpret_cast<const myo_bf16x8*>(ap[q]); b0[q] = *reinterpret_cast<const myo_bf16x8*>(bp[q]); }
+  for (int ks = 0; ks < ksteps; ks += 2) {        // two register sets: the loads of one k-step fly during the MFMAs of the other
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a1[q] = *reinterpret_cast<const myo_bf16x8*>(ap[q] + 32 * (ks + 1)); b1[q] = *reinterpret_cast<const myo_bf16x8*>(bp[q] + 32 * (ks + 1)); }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], b0[nt], acc[mt][nt], 0, 0, 0);
     if (do_bias) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], ones, accb[mt], 0, 0, 0);
+      for (int mt = 0; mt < 4; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[mt], ones, accb[mt], 0, 0, 0);
+    }
+    if (ks + 2 < ksteps) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { a0[q] = *reinterpret_cast<const myo_bf16x8*>(ap[q] + 32 * (ks + 2)); b0[q] = *reinterpret_cast<const myo_bf16x8*>(bp[q] + 32 * (ks + 2)); }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], b1[nt], acc[mt][nt], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[mt], ones, accb[mt], 0, 0, 0);
     }
   }
   float* out = P.slab + (size_t)split * P.G;

@@ -2209,13 +2209,13 @@ static MlpWs mlp_carve(unsigned char* base, int B, int OP, int A, long long G) {
   w.H1T = (unsigned short*)take(2 * H * (size_t)B * 2); w.H2T = (unsigned short*)take(2 * H * (size_t)B * 2);
   w.dH1T = (unsigned short*)take(2 * H * (size_t)B * 2); w.dH2T = (unsigned short*)take(2 * H * (size_t)B * 2);
   w.dOT = (unsigned short*)take((size_t)256 * B * 2);
-  w.part = (float*)take((size_t)(2 * A + 3) * (B / 64) * 4);
+  w.part = (float*)take((size_t)(2 * A + 3) * (B / MLP_BM) * 4);
   w.slab = (float*)take((size_t)MLP_SPLITK * G * 4);
   w.bytes = o;
   return w;
 }
 static int mlp_shape_ok(int B, int O, int A, int hidden) {
-  return hidden == MLP_H && O >= 1 && O <= MLP_OPMAX && A >= 1 && A <= MLP_APM && B >= 32 * MLP_SPLITK && B % (32 * MLP_SPLITK) == 0 && B % 64 == 0;
+  return hidden == MLP_H && O >= 1 && O <= MLP_OPMAX && A >= 1 && A <= MLP_APM && B >= 64 * MLP_SPLITK && B % (64 * MLP_SPLITK) == 0;
 }
 #endif
 extern "C" long long myo_ppo_mlp_workspace_bytes(int B, int obs_dim, int act_dim, int hidden, long long G) {
@@ -2236,7 +2236,7 @@ extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
   return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_step is a GPU kernel");
 #else
   const int B = d->B, O = d->O, A = d->A, OP = (O + 31) / 32 * 32;
-  if (!mlp_shape_ok(B, O, A, d->hidden)) return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_step: needs hidden = %d, obs <= %d, act <= %d, batch a multiple of %d", MLP_H, MLP_OPMAX, MLP_APM, 32 * MLP_SPLITK);
+  if (!mlp_shape_ok(B, O, A, d->hidden)) return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_step: needs hidden = %d, obs <= %d, act <= %d, batch a multiple of %d", MLP_H, MLP_OPMAX, MLP_APM, 64 * MLP_SPLITK);
   const MlpWs w = mlp_carve((unsigned char*)d->workspace, B, OP, A, d->G);
   if ((long long)w.bytes > d->workspace_bytes) return fail(MYO_E_ARG, "myo_ppo_mlp_step: workspace too small (%zu bytes needed)", w.bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -2260,8 +2260,8 @@ extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
   a.log_std = d->params + d->off_log_std; a.adv_stats = d->adv_stats;
   a.W1p = w.W1p; a.W2 = w.W2; a.W2T = w.W2T; a.Whp = w.Whp; a.WhT = w.WhT; a.bias = w.bias;
   a.XT = w.XT; a.H1T = w.H1T; a.H2T = w.H2T; a.dH1T = w.dH1T; a.dH2T = w.dH2T; a.dOT = w.dOT; a.part = w.part;
-  a.B = B; a.O = O; a.A = A; a.OP = OP; a.NB = B / 64; a.clip = d->clip; a.vf_coef = d->vf_coef;
-  hipLaunchKernelGGL(k_mlp_fwdbwd, dim3(B / 64, 2), dim3(256), MLP_FWDBWD_LDS, st, a);
+  a.B = B; a.O = O; a.A = A; a.OP = OP; a.NB = B / MLP_BM; a.clip = d->clip; a.vf_coef = d->vf_coef;
+  hipLaunchKernelGGL(k_mlp_fwdbwd, dim3(B / MLP_BM, 2), dim3(256), MLP_FWDBWD_LDS, st, a);
   MlpWgradArgs g;
   g.njobs = 0; g.B = B; g.rows_per_split = B / MLP_SPLITK; g.G = d->G; g.slab = w.slab;
   const size_t HB = (size_t)MLP_H * B;
@@ -2276,7 +2276,7 @@ extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
   }
   hipLaunchKernelGGL(k_mlp_wgrad, dim3(g.njobs * MLP_SPLITK), dim3(256), 0, st, g);
   hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((d->G + 255) / 256)), dim3(256), 0, st, (const float*)w.slab, d->grads, d->G, MLP_SPLITK);
-  hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, (const float*)w.part, d->acc, B / 64, A, d->ent_coef,
+  hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, (const float*)w.part, d->acc, B / MLP_BM, A, d->ent_coef,
                      d->grads + d->off_log_std, d->grads + d->off_bh[0], d->grads + d->off_bh[1]);
   LAUNCH_CHECK(0)
   return MYO_OK;

@@ -142,9 +142,10 @@ static const char* const kF64Fields[] = {
     "actuator_forcerange", "actuator_gear", "actuator_acc0", "actuator_lengthrange"};
 
 static bool pair_supported(int t1, int t2) {       // narrow phases of csrc/myo_physics.h:collide_pair (types ordered t1 <= t2)
-  return (t1 == MYO_GEOM_PLANE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE)) ||
-         (t1 == MYO_GEOM_SPHERE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_BOX)) ||
-         (t1 == MYO_GEOM_CAPSULE && t2 == MYO_GEOM_CAPSULE);
+  return (t1 == MYO_GEOM_PLANE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_ELLIPSOID || t2 == MYO_GEOM_CYLINDER)) ||
+         (t1 == MYO_GEOM_SPHERE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_BOX || t2 == MYO_GEOM_CYLINDER || t2 == MYO_GEOM_ELLIPSOID)) ||
+         (t1 == MYO_GEOM_CAPSULE && (t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_BOX || t2 == MYO_GEOM_CYLINDER || t2 == MYO_GEOM_ELLIPSOID)) ||
+         (t1 == MYO_GEOM_BOX && t2 == MYO_GEOM_BOX);
 }
 
 // compile_model(): feature checks, derived fields, blob.  integrator < 0 keeps the model's; allow_drop = 0 refuses a model that
@@ -201,7 +202,7 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   // ((body1 + 1) << 16) + body2 + 1 with body1 < body2, MuJoCo 2.1), parent-child unless mjDSBL_FILTERPARENT, contype / conaffinity
   const std::vector<int>& excl = I("exclude_signature");
   const bool filterparent = !(f.disableflags & (1 << 9));
-  std::vector<int> p1, p2;
+  std::vector<int> p1, p2, psub;
   int dropped = 0;
   char msg[256] = "";
   const std::vector<int>&gb = I("geom_bodyid"), &weld = I("body_weldid"), &par = I("body_parentid"), &gt = I("geom_type");
@@ -223,9 +224,22 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
       const int a = t1 <= t2 ? g1 : g2, b = t1 <= t2 ? g2 : g1;      // MuJoCo orders a pair by geom type
       const int lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
       if (lo == MYO_GEOM_PLANE && hi == MYO_GEOM_PLANE) continue;
-      if (pair_supported(lo, hi)) { p1.push_back(a); p2.push_back(b); }
+      if (lo == MYO_GEOM_BOX && hi == MYO_GEOM_BOX) { for (int v = 0; v < 16; ++v) { p1.push_back(a); p2.push_back(b); psub.push_back(1 + v); } }   // vertex-face candidates
+      else if (pair_supported(lo, hi)) { p1.push_back(a); p2.push_back(b); psub.push_back(0); }
       else { if (!dropped) snprintf(msg, sizeof msg, "geom %d (type %d) - geom %d (type %d)", a, gt[a], b, gt[b]); dropped++; }
     }
+  {   // stable partition: the pairs of the primitive narrow phases first (model.py:compile_model does the same)
+    auto is_std = [&](size_t k) {
+      const int t1 = gt[p1[k]], t2 = gt[p2[k]];
+      return (t1 == MYO_GEOM_PLANE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE)) || (t1 == MYO_GEOM_SPHERE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_BOX)) ||
+             (t1 == MYO_GEOM_CAPSULE && t2 == MYO_GEOM_CAPSULE);
+    };
+    std::vector<int> q1, q2, qs;
+    for (int pass = 0; pass < 2; ++pass)
+      for (size_t k = 0; k < p1.size(); ++k)
+        if (is_std(k) == (pass == 0)) { q1.push_back(p1[k]); q2.push_back(p2[k]); qs.push_back(psub[k]); }
+    p1.swap(q1); p2.swap(q2); psub.swap(qs);
+  }
   if (dropped && !allow_drop) {
     char m2[400];
     snprintf(m2, sizeof m2, "%d colliding geom pair(s) have no narrow phase in this stepper (first: %s); load with unsupported_contacts = 1 to compile without them", dropped, msg);
@@ -263,7 +277,7 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   for (int b = 1; b < nbody; ++b) bd[b] = bd[par[b]] + 1;
   for (int i = 0; i < nv; ++i) { const int p = I("dof_parentid")[i]; dd[i] = p < 0 ? 1 : dd[p] + 1; }
   fi.push_back({"x_body_depth", bd}); fi.push_back({"x_dof_depth", dd});
-  fi.push_back({"x_pair_geom1", p1}); fi.push_back({"x_pair_geom2", p2});
+  fi.push_back({"x_pair_geom1", p1}); fi.push_back({"x_pair_geom2", p2}); fi.push_back({"x_pair_sub", psub});
   fi.push_back({"opt_int", {integrator >= 0 ? integrator : f.integrator, f.cone, f.iterations, f.disableflags}});
   fd.push_back({"opt_f64", {f.timestep, f.tolerance, f.impratio, f.gravity[0], f.gravity[1], f.gravity[2], f.o_margin, f.meaninertia}});
   const size_t nf = fi.size() + fd.size();

@@ -16,7 +16,8 @@
 #define MYO_MV_ROW 24     // non-zeros in one row of the tree-sparse inertia matrix (packed M*v rows)
 #define MYO_TJ_MAX 8      // dofs one tendon can move
 #define MYO_NM_MAX 176    // tree-sparse inertia entries
-#define MYO_NCON_MAX 24   // contacts
+#define MYO_NCON_MAX 24   // contacts (base capacity of the scratch: Scratch<T, NC = MYO_NCON_MAX>)
+#define MYO_NCON_BIG 32   // contacts, scratch of models with extended collision pairs / a die (56 + 4 * 32 = 184 rows <= 192)
 #define MYO_CS_MAX 16     // dofs one contact can move
 #define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows
 #define MYO_NEFC_MAX (MYO_NLIM_MAX + 4 * MYO_NCON_MAX)
@@ -79,6 +80,7 @@ template <typename T>
 struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
   int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
+  int npair_std;                // pairs [0, npair_std): collision_pass; [npair_std, npair): collision_pass_ext
   T timestep, tolerance, impratio, gravity[3], meaninertia;
   double h_timestep;            // the integration step of the HP state update
 #define X(n) MyoCArr<int> n;

@@ -17,7 +17,7 @@
 //
 // The constraint Jacobian is never materialised: J*v and J'*f go through per-body spatial
 // vectors (6 numbers per body), and the Newton Hessian M + J' D J is assembled per contact from
-// 3x3 blocks.  Everything an env touches between load and store lives in LDS (Scratch<T>).
+// 3x3 blocks.  Everything an env touches between load and store lives in LDS (Scratch<T, NC>).
 #pragma once
 #include "myo_model_dev.h"
 #include "wave.h"
@@ -94,8 +94,9 @@ struct RkScratch {                // RK4 stage storage: one per env in GLOBAL me
   T F[4][2 * MYO_NV_MAX + MYO_NU_MAX];              // eight workgroups per CU (23.3 KB instead of 20.2 KB: three rounds for 4096 envs)
 };
 
-template <typename T>
+template <typename T, int NC = MYO_NCON_MAX>
 struct Scratch {
+  static_assert(NC >= MYO_NCON_MAX && MYO_NLIM_MAX + 4 * NC <= 192, "contact capacity: at least the base (the aliases below are sized for it), at most three constraint rows per lane");
   // ---- state (HP in every build)
   HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX];
   HP time;
@@ -132,12 +133,12 @@ struct Scratch {
   T Ma[MYO_NV_MAX], grad[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX], tmpv[MYO_NV_MAX];
   // ---- constraints
   int ncon, nefc, nl, ntl, bad, solver_iter;
-  alignas(8) ContactRec<T> con[MYO_NCON_MAX];
+  alignas(8) ContactRec<T> con[NC];
   int lim_id[MYO_NLIM_MAX];
   T lim_sgn[MYO_NLIM_MAX];
   T efc_D[MYO_NLIM_MAX], efc_B[MYO_NLIM_MAX], efc_kip[MYO_NLIM_MAX];   // limit rows only; contact rows: con[]
-  alignas(8) T efc_aref[MYO_NEFC_MAX], efc_jar[MYO_NEFC_MAX], efc_jv[MYO_NEFC_MAX], efc_force[MYO_NEFC_MAX];
-  unsigned char efc_active[MYO_NEFC_MAX];
+  alignas(8) T efc_aref[MYO_NLIM_MAX + 4 * NC], efc_jar[MYO_NLIM_MAX + 4 * NC], efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC];
+  unsigned char efc_active[MYO_NLIM_MAX + 4 * NC];
   RkScratch<T>* rk;               // null unless the model integrates with RK4
   // ---- task layer
   T rwd[8];
@@ -148,10 +149,10 @@ struct Scratch {
 
 // the fp32 stages' view of the two HP arrays they read every substep: a float copy in the mixed stepper,
 // the HP array itself in the fp64 stepper (O = 0 there)
-template <typename T> DEV T* S_QVELT(Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.qvel); else return s.qvelT_; }
-template <typename T> DEV const T* S_QVELT(const Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.qvel); else return s.qvelT_; }
-template <typename T> DEV T* S_XPOST(Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.xpos); else return s.xposT_; }
-template <typename T> DEV const T* S_XPOST(const Scratch<T>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.xpos); else return s.xposT_; }
+template <typename T, int NC> DEV T* S_QVELT(Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.qvel); else return s.qvelT_; }
+template <typename T, int NC> DEV const T* S_QVELT(const Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.qvel); else return s.qvelT_; }
+template <typename T, int NC> DEV T* S_XPOST(Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.xpos); else return s.xposT_; }
+template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.xpos); else return s.xposT_; }
 
 // Aliases: arrays whose lifetime ends before the buffer they live in is next written.
 //   H is only live from qacc_smooth to the end of the solver / Euler solve.  Before that
@@ -215,7 +216,7 @@ template <> __device__ __forceinline__ const DevModel<float>& myo_cmodel<float>(
 template <> __device__ __forceinline__ const DevModel<double>& myo_cmodel<double>() { return c_model_d; }
 #define MYO_BIND_M(T) const DevModel<T>& M = myo_cmodel<T>(); (void)M_in;
 #define MYO_BIND_K const TaskDev& K = c_task; (void)K_in;
-#define MYO_BIND_S(T) Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds); (void)s_in;
+#define MYO_BIND_S(T) Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds); (void)s_in;
 #define LREF(T) int
 #define LCREF(T) int
 #define LOFF(s, p) ((int)((const char*)(p) - (const char*)&(s)))
@@ -224,7 +225,7 @@ template <> __device__ __forceinline__ const DevModel<double>& myo_cmodel<double
 #define LISNULL(r) ((r) < 0)
 #endif
 
-template <typename T> DEV T row_D(const Scratch<T>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
+template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
 
 // ------------------------------------------------------------------------------------------
 // small math
@@ -299,24 +300,24 @@ template <typename T> DEV void cross_force(T* r, const T* v, const T* f) {
 
 // per-env overrides of model constants (P2 randomisation writes ball mass / size / friction
 // into the model, /root/reference/src/envs/baoding.py:559-604)
-template <typename T> DEV T body_mass_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int b) {
+template <typename T, int NC> DEV T body_mass_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int b) {
   if (b == K.obj1_bid) return s.ball_mass[0];
   if (b == K.obj2_bid) return s.ball_mass[1];
   return M.body_mass[b];
 }
-template <typename T> DEV T geom_size0_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+template <typename T, int NC> DEV T geom_size0_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g) {
   if (g == K.obj1_gid) return (T)s.ball_size[0];
   if (g == K.obj2_gid) return (T)s.ball_size[1];
   if (g < K.objg_gidn && g >= K.objg_gidn - 3 && g >= K.objg_gid0) return M.geom_size[3 * g] + (T)s.ball_size[0];
   return M.geom_size[3 * g];
 }
-template <typename T> DEV HP geom_size0_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+template <typename T, int NC> DEV HP geom_size0_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g) {
   if (g == K.obj1_gid) return s.ball_size[0];
   if (g == K.obj2_gid) return s.ball_size[1];
   if (g < K.objg_gidn && g >= K.objg_gidn - 3 && g >= K.objg_gid0) return M.h_geom_size[3 * g] + s.ball_size[0];
   return M.h_geom_size[3 * g];
 }
-template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, int k) {
+template <typename T, int NC> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g, int k) {
   if (g >= K.objg_gid0 && g < K.objg_gidn) return k == 0 ? s.objg_fric[g - K.objg_gid0] : M.geom_friction[3 * g + k];
   if (g == K.obj1_gid) return s.ball_fric[k];
   if (g == K.obj2_gid) return s.ball_fric[3 + k];
@@ -326,43 +327,43 @@ template <typename T> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K,
 // geometry of a geom of the per-env object group (the die of the reorient task, reorient.py:136-147): every geom
 // centre moves outward by the env's size delta; size[1] (a capsule's half-length) of every geom grows by it, and so
 // does size[0] of the group's last three geoms (the reference adds the delta to all sizes of those)
-template <typename T> DEV void geom_lpos_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, T* out) {
+template <typename T, int NC> DEV void geom_lpos_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g, T* out) {
   out[0] = M.geom_pos[3 * g]; out[1] = M.geom_pos[3 * g + 1]; out[2] = M.geom_pos[3 * g + 2];
   if (g >= K.objg_gid0 && g < K.objg_gidn) {
     const T del = (T)s.ball_size[0];
     for (int e = 0; e < 3; ++e) if (out[e] != 0) out[e] += out[e] > 0 ? del : -del;
   }
 }
-template <typename T> DEV void geom_lpos_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g, HP* out) {
+template <typename T, int NC> DEV void geom_lpos_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g, HP* out) {
   out[0] = M.h_geom_pos[3 * g]; out[1] = M.h_geom_pos[3 * g + 1]; out[2] = M.h_geom_pos[3 * g + 2];
   if (g >= K.objg_gid0 && g < K.objg_gidn) {
     const HP del = s.ball_size[0];
     for (int e = 0; e < 3; ++e) if (out[e] != 0) out[e] += out[e] > 0 ? del : -del;
   }
 }
-template <typename T> DEV T geom_size1_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+template <typename T, int NC> DEV T geom_size1_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g) {
   const T v = M.geom_size[3 * g + 1];
   return (g >= K.objg_gid0 && g < K.objg_gidn) ? v + (T)s.ball_size[0] : v;
 }
-template <typename T> DEV HP geom_size1_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g) {
+template <typename T, int NC> DEV HP geom_size1_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g) {
   const HP v = M.h_geom_size[3 * g + 1];
   return (g >= K.objg_gid0 && g < K.objg_gidn) ? v + s.ball_size[0] : v;
 }
 // position of a point given in body coordinates, in the fp32 stages' frame (world - O)
-template <typename T> DEV void body_point(const Scratch<T>& s, int b, const T* local, T* out) {
+template <typename T, int NC> DEV void body_point(const Scratch<T, NC>& s, int b, const T* local, T* out) {
   const T* xp = S_XPOST(s) + 3 * b;
   mulmatvec3(out, s.xmat + 9 * b, local);
   out[0] += xp[0]; out[1] += xp[1]; out[2] += xp[2];
 }
 // the same in HP and in WORLD coordinates (contact distances, observation)
-template <typename T> DEV void body_point_hp(const Scratch<T>& s, int b, const HP* local, HP* out) {
+template <typename T, int NC> DEV void body_point_hp(const Scratch<T, NC>& s, int b, const HP* local, HP* out) {
   HP R[9];
   quat2mat(R, s.xquat + 4 * b);
   mulmatvec3(out, R, local);
   out[0] += s.xpos[3 * b]; out[1] += s.xpos[3 * b + 1]; out[2] += s.xpos[3 * b + 2];
 }
 // translational Jacobian column of dof d for a world point p: cdof_lin + cdof_ang x (p - com)
-template <typename T> DEV void jac_col(const DevModel<T>& M, const Scratch<T>& s, int d, const T* p, T* col) {
+template <typename T, int NC> DEV void jac_col(const DevModel<T>& M, const Scratch<T, NC>& s, int d, const T* p, T* col) {
   const T* c = s.com + 3 * M.dof_rootbody[d]; const T* cd = s.cdof + 6 * d;
   T off[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]}, t[3];
   cross3(t, cd, off);
@@ -373,8 +374,8 @@ template <typename T> DEV void jac_col(const DevModel<T>& M, const Scratch<T>& s
 // P2: kinematics (mj_kinematics).  HP throughout (see the precision plan at the top): the chain qpos -> poses
 // is what contact distances are made of.  Leaves xpos / xquat (HP, world), and for the fp32 stages xmat, the
 // shifted positions S_XPOST / S_XIPOS and the shifted joint anchors / axes.
-template <typename T>
-DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -504,8 +505,8 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T>& s_in) {
 }
 
 // P2: mj_comPos — tree reference points, body inertias about them, dof motion axes
-template <typename T>
-DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -687,8 +688,8 @@ DEV T wrap_geom(T* wpnt, const T* x0, const T* x1, const T* gpos, const T* gmat,
 // difference of the two ancestor-dof masks is visited.
 // moment contribution of one straight tendon segment p0 (on a body with dof mask m0, tree root
 // r0) -> p1 (m1, r1) with unit direction u: the dofs that move exactly one of the two end points
-template <typename T>
-DEV void tendon_segment_moment(const Scratch<T>& s, T* Jrow, unsigned long long tmask, unsigned long long m0, int r0,
+template <typename T, int NC>
+DEV void tendon_segment_moment(const Scratch<T, NC>& s, T* Jrow, unsigned long long tmask, unsigned long long m0, int r0,
                                const T* p0, unsigned long long m1, int r1, const T* p1, const T* u, T inv_div) {
   unsigned long long x = (m0 ^ m1) & tmask;
   while (x) {
@@ -709,7 +710,7 @@ DEV void tendon_segment_moment(const Scratch<T>& s, T* Jrow, unsigned long long 
 }
 
 // HP position (relative to O, like every position of the fp32 stages) of a point given in body coordinates
-template <typename T> DEV void wrap_point_hp(const DevModel<T>& M, const Scratch<T>& s, int body, const HP* local, HP* out) {
+template <typename T, int NC> DEV void wrap_point_hp(const DevModel<T>& M, const Scratch<T, NC>& s, int body, const HP* local, HP* out) {
   (void)M;
   body_point_hp(s, body, local, out);
   out[0] -= s.origin[0]; out[1] -= s.origin[1]; out[2] -= s.origin[2];
@@ -725,8 +726,8 @@ template <typename T> DEV void load_wrap(const DevModel<T>& M, int w, WrapRec<T>
   r.mask = M.wr_mask[w];
 }
 
-template <typename T>
-DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   // Three phases instead of one divergent walk per tendon (a wave whose 39 lanes sit at different
@@ -759,8 +760,8 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in
 
 // phase B of the tendon stage, one geom wrap per lane (called once per 64 wraps from kernel level: a leaf function
 // without a loop, so that the HP wrap solver has a register allocation of its own)
-template <typename T>
-DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int base) {
+template <typename T, int NC>
+DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int base) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   HP* wres = S_TWRES(s, M.nwrap);
@@ -795,8 +796,8 @@ DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratc
 // element lengths of each tendon in path order.  (The first version walked each tendon in one lane — 39 lanes chaining
 // ~5 elements of fp64 site positions, square roots and moment gathers: 15.6 k of the substep's 229 k cycles.)
 #define S_TELEN(s) (reinterpret_cast<HP*>((s).H + MYO_NB_MAX * 10))   /* behind cinert; crb / qfrc_* come after the tendon stage */
-template <typename T>
-DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int base) {
+template <typename T, int NC>
+DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int base) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   (void)K;
@@ -856,8 +857,8 @@ DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scr
   }
   SYNC();
 }
-template <typename T>
-DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -874,8 +875,8 @@ DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T>& s_in) {
 
 // ------------------------------------------------------------------------------------------
 // P5: composite rigid body inertia -> tree-sparse M (mj_crb)
-template <typename T>
-DEVFN void crb(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void crb(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -918,8 +919,8 @@ DEVFN void crb(const DevModel<T>& M_in, Scratch<T>& s_in) {
 }
 
 // out = M * v   (lanes = dofs; static CSR pattern of the symmetric tree-sparse matrix)
-template <typename T>
-DEV void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r, LCREF(T) v_r) {
+template <typename T, int NC>
+DEV void mul_M(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LREF(T) out_r, LCREF(T) v_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   T* out = LPTR(T, out_r); const T* v = LPTR(const T, v_r);
   WAVE_FN
@@ -948,8 +949,8 @@ DEV void mul_M(const DevModel<T>& M_in, const Scratch<T>& s_in, LREF(T) out_r, L
 }
 
 // packed dense H <- M (+ diag)
-template <typename T>
-DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* diag_add, T diag_scale) {
+template <typename T, int NC>
+DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, const T* diag_add, T diag_scale) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -981,8 +982,8 @@ DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T>& s_in, const T* diag_
 }
 
 // in-place Cholesky of the packed lower triangle (right-looking; lanes tile the trailing block)
-template <typename T>
-DEV void chol_factor(Scratch<T>& s, int n) {
+template <typename T, int NC>
+DEV void chol_factor(Scratch<T, NC>& s, int n) {
   WAVE_FN
   for (int k = 0; k < n; ++k) {
     PHASE {
@@ -1007,8 +1008,8 @@ DEV void chol_factor(Scratch<T>& s, int n) {
 }
 
 // solve L L' x = b in place (x in scratch vector)
-template <typename T>
-DEV void chol_solve(Scratch<T>& s, T* x, int n) {
+template <typename T, int NC>
+DEV void chol_solve(Scratch<T, NC>& s, T* x, int n) {
   WAVE_FN
   for (int k = 0; k < n; ++k) {
     PHASE {
@@ -1069,14 +1070,14 @@ template <> struct MyoMfma<double> {
   static __device__ __forceinline__ V4 mma(double a, double b, V4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
 };
-template <typename T, int N>
+template <typename T, int N, int NC>
 __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   static_assert(N % 4 == 0 && N <= MYO_NV_MAX, "row vectors are loaded 4 at a time");
   typedef T V2 __attribute__((ext_vector_type(2)));
   typedef T V4 __attribute__((ext_vector_type(4)));
   typedef MyoMfma<T> MM;
   constexpr int NT = (N + 15) / 16;                  // tiles per side
-  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   T* x = LPTR(T, x_r);
   const int lane = threadIdx.x;
   const int lc = lane & 15, lq = lane >> 4;
@@ -1161,8 +1162,9 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
       lds_t stage = (lds_t)s.efc_jv;                   // [NT * 16 rows][4] + 64 dump entries; efc_jv and efc_force are free while a system is solved
       lds_t Hp = (lds_t)s.H;
       asm volatile("" : "+v"(stage), "+v"(Hp));
-      static_assert(NT * 16 * 4 + 64 <= 2 * MYO_NEFC_MAX && 4 * 64 <= 2 * MYO_NEFC_MAX, "panel stage and dump area fit in efc_jv + efc_force");
-      static_assert(offsetof(Scratch<T>, efc_force) - offsetof(Scratch<T>, efc_jv) == MYO_NEFC_MAX * sizeof(T), "efc_jv and efc_force are contiguous");
+      static_assert(NT * 16 * 4 + 64 <= 2 * (MYO_NLIM_MAX + 4 * NC) && 4 * 64 <= 2 * (MYO_NLIM_MAX + 4 * NC), "panel stage and dump area fit in efc_jv + efc_force");
+      typedef Scratch<T, NC> ScratchT;
+      static_assert(offsetof(ScratchT, efc_force) - offsetof(ScratchT, efc_jv) == (MYO_NLIM_MAX + 4 * NC) * sizeof(T), "efc_jv and efc_force are contiguous");
       typename MM::V4 acc[NT * (NT + 1) / 2];
       // symmetric fill of the lower tiles from the packed lower triangle; identity beyond N
   #pragma unroll
@@ -1299,8 +1301,8 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
 // matrix at hand (free bodies whose inertial frame is the body frame: the two balls), so their
 // solve is a division.  M-only solves and contact-free Newton steps use the 24-wide variant.
 #define MYO_CHOL_SMALL 24
-template <typename T>
-DEV void chol_factor_solve(Scratch<T>& s, T* x, int n, int lead) {
+template <typename T, int NC>
+DEV void chol_factor_solve(Scratch<T, NC>& s, T* x, int n, int lead) {
 #ifdef MYO_EMU
   (void)lead;
   chol_factor(s, n);
@@ -1309,9 +1311,9 @@ DEV void chol_factor_solve(Scratch<T>& s, T* x, int n, int lead) {
   if (lead < n && lead <= MYO_CHOL_SMALL) {
     const int lane = threadIdx.x;
     if (lane >= lead && lane < n) x[lane] = x[lane] / s.H[MYO_HIDX(lane, lane)];
-    chol_factor_solve_reg<T, MYO_CHOL_SMALL>(LOFF(s, x), lead);
+    chol_factor_solve_reg<T, MYO_CHOL_SMALL, NC>(LOFF(s, x), lead);
   } else {
-    chol_factor_solve_reg<T, MYO_NV_MAX>(LOFF(s, x), n);
+    chol_factor_solve_reg<T, MYO_NV_MAX, NC>(LOFF(s, x), n);
   }
 #endif
 }
@@ -1347,12 +1349,19 @@ DEV void seg_nearest(HP* out, const HP* c, const HP* axis, HP half, const HP* p)
   for (int k = 0; k < 3; ++k) out[k] = c[k] + t * axis[k];
 }
 
-template <typename T>
-DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& s, int g1, int g2, HP margin,
-                      ContactTmp& o) {
-  const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+template <typename T, int NC> DEV HP geom_size2_hp(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g) {
+  const HP v = M.h_geom_size[3 * g + 2];      // (the reference adds the size delta to ALL sizes of the group's last three geoms)
+  return (g < K.objg_gidn && g >= K.objg_gidn - 3 && g >= K.objg_gid0) ? v + s.ball_size[0] : v;
+}
+// world poses of the two geoms of a pair (HP), their (per-env) sizes, and mj_collideGeoms' bounding-sphere filter, EXACT (the
+// MODEL's rbound): with P2's per-episode ball radius above the nominal one (the reference never refreshes geom_rbound,
+// baoding.py:586-604) this test, not the narrow phase, decides when a ball contact switches on — the callers' fp32
+// pre-filter only rejects pairs that are clearly apart.  Returns 0 when the filter rejects the pair.
+template <typename T, int NC>
+DEV int pair_poses(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g1, int g2, HP margin, HP* p1, HP* p2, HP* R1, HP* R2,
+                   HP* s1, HP* s2) {
   const int b1 = M.geom_bodyid[g1], b2 = M.geom_bodyid[g2];
-  HP p1[3], p2[3], B1[9], B2[9], R1[9], R2[9], l1[3], l2[3];
+  HP B1[9], B2[9], l1[3], l2[3];
   geom_lpos_hp(M, K, s, g1, l1);
   geom_lpos_hp(M, K, s, g2, l2);
   quat2mat(B1, s.xquat + 4 * b1);
@@ -1362,18 +1371,21 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& 
   for (int k = 0; k < 3; ++k) { p1[k] += s.xpos[3 * b1 + k]; p2[k] += s.xpos[3 * b2 + k]; }
   mulmat3(R1, B1, M.h_geom_mat + 9 * g1);
   mulmat3(R2, B2, M.h_geom_mat + 9 * g2);
-  const HP s1[3] = {geom_size0_hp(M, K, s, g1), geom_size1_hp(M, K, s, g1), M.h_geom_size[3 * g1 + 2]};
-  const HP s2[3] = {geom_size0_hp(M, K, s, g2), geom_size1_hp(M, K, s, g2), M.h_geom_size[3 * g2 + 2]};
+  s1[0] = geom_size0_hp(M, K, s, g1); s1[1] = geom_size1_hp(M, K, s, g1); s1[2] = geom_size2_hp(M, K, s, g1);
+  s2[0] = geom_size0_hp(M, K, s, g2); s2[1] = geom_size1_hp(M, K, s, g2); s2[2] = geom_size2_hp(M, K, s, g2);
+  const HP rb1 = M.h_geom_rbound[g1], rb2 = M.h_geom_rbound[g2];
+  const HP df[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+  const HP bound = rb1 + rb2 + margin;
+  return !(rb1 > 0 && rb2 > 0 && dot3(df, df) > bound * bound);
+}
+
+template <typename T, int NC>
+DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g1, int g2, HP margin,
+                      ContactTmp& o) {
+  const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  HP p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
   o.n = 0;
-  {
-    // mj_collideGeoms' bounding-sphere filter, EXACT (HP, the MODEL's rbound): with P2's per-episode ball radius above the
-    // nominal one (the reference never refreshes geom_rbound, baoding.py:586-604) this test, not the narrow phase, decides
-    // when a ball contact switches on — the caller's fp32 pre-filter only rejects pairs that are clearly apart
-    const HP rb1 = M.h_geom_rbound[g1], rb2 = M.h_geom_rbound[g2];
-    const HP df[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
-    const HP bound = rb1 + rb2 + margin;
-    if (rb1 > 0 && rb2 > 0 && dot3(df, df) > bound * bound) return;
-  }
+  if (!pair_poses(M, K, s, g1, g2, margin, p1, p2, R1, R2, s1, s2)) return;
   if (t1 == 0 && t2 == 2) {
     const HP n[3] = {R1[2], R1[5], R1[8]};
     const HP dd = (p2[0] - p1[0]) * n[0] + (p2[1] - p1[1]) * n[1] + (p2[2] - p1[2]) * n[2] - s2[0];
@@ -1453,6 +1465,211 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T>& 
   }
 }
 
+// ---- narrow phases beyond MuJoCo's sphere / capsule primitives (capsule-box, box-box vertex contacts, sphere / capsule against
+// cylinder and ellipsoid, plane against ellipsoid and cylinder).  Same geometry as oracle/myo_oracle.c (point_box, point_cylinder,
+// point_ellipsoid, SEG_ARGMIN) — see the note there on what MuJoCo does for these pairs (libccd MPR / multi-contact primitives)
+// and where the contact sets can differ.  Written without run-time indexed local arrays (they would live in private memory):
+// results go to compile-time slots.  These run in their own leaf function (collision_pass_ext) over the model's trailing
+// "extended" pairs, so the register allocation of the Baoding hand's collision pass is untouched.
+DEV HP sd_box_hp(HP x0, HP x1, HP x2, const HP* sz) {
+  const HP q0 = fabs(x0) - sz[0], q1 = fabs(x1) - sz[1], q2 = fabs(x2) - sz[2];
+  const HP o0 = q0 > 0 ? q0 : (HP)0, o1 = q1 > 0 ? q1 : (HP)0, o2 = q2 > 0 ? q2 : (HP)0;
+  const HP outside = sqrt(o0 * o0 + o1 * o1 + o2 * o2);
+  HP m = q0 > q1 ? q0 : q1; if (q2 > m) m = q2;
+  return outside > 0 ? outside : m;
+}
+DEV HP sd_cyl_hp(HP x0, HP x1, HP x2, HP R, HP h) {
+  const HP q0 = sqrt(x0 * x0 + x1 * x1) - R, q1 = fabs(x2) - h;
+  const HP o0 = q0 > 0 ? q0 : (HP)0, o1 = q1 > 0 ? q1 : (HP)0;
+  const HP outside = sqrt(o0 * o0 + o1 * o1);
+  return outside > 0 ? outside : (q0 > q1 ? q0 : q1);
+}
+// the three point-vs-solid routines write contact slot SLOT of o and return 1 when the contact is within the margin
+template <int SLOT>
+DEV int point_finish(ContactTmp& o, const HP* c, HP r, const HP* Rg, const HP* nl, HP dd, HP flip) {
+  HP nw[3];
+  mulmatvec3(nw, Rg, nl);
+  o.dist[SLOT] = dd;
+  for (int k = 0; k < 3; ++k) { o.nrm[3 * SLOT + k] = flip * nw[k]; o.pos[3 * SLOT + k] = c[k] + nw[k] * (r + (HP)0.5 * dd); }
+  return 1;
+}
+template <int SLOT>
+DEV int point_box_hp(ContactTmp& o, const HP* c, HP r, const HP* pb, const HP* Rb, const HP* sb, HP margin, HP flip) {
+  const HP t[3] = {c[0] - pb[0], c[1] - pb[1], c[2] - pb[2]};
+  HP x[3], cl[3], nl[3], dd;
+  mulmatTvec3(x, Rb, t);
+  int inside = 1;
+  for (int k = 0; k < 3; ++k) {
+    cl[k] = x[k];
+    if (cl[k] > sb[k]) { cl[k] = sb[k]; inside = 0; } else if (cl[k] < -sb[k]) { cl[k] = -sb[k]; inside = 0; }
+  }
+  if (!inside) {
+    const HP df[3] = {cl[0] - x[0], cl[1] - x[1], cl[2] - x[2]};
+    const HP dn = norm3(df);
+    dd = dn - r;
+    if (dd > margin) return 0;
+    nl[0] = df[0] / dn; nl[1] = df[1] / dn; nl[2] = df[2] / dn;
+  } else {
+    int kb = 0;
+    HP best = (HP)1e300;
+    for (int k = 0; k < 3; ++k) { const HP e = sb[k] - fabs(x[k]); if (e < best) { best = e; kb = k; } }
+    const HP xkb = kb == 0 ? x[0] : (kb == 1 ? x[1] : x[2]);
+    for (int k = 0; k < 3; ++k) nl[k] = (k == kb) ? (xkb > 0 ? (HP)-1 : (HP)1) : (HP)0;
+    dd = -best - r;
+    if (dd > margin) return 0;
+  }
+  return point_finish<SLOT>(o, c, r, Rb, nl, dd, flip);
+}
+template <int SLOT>
+DEV int point_cyl_hp(ContactTmp& o, const HP* c, HP r, const HP* pc, const HP* Rc, HP R, HP h, HP margin) {
+  const HP t[3] = {c[0] - pc[0], c[1] - pc[1], c[2] - pc[2]};
+  HP x[3], nl[3], dd;
+  mulmatTvec3(x, Rc, t);
+  const HP rho = sqrt(x[0] * x[0] + x[1] * x[1]), az = fabs(x[2]);
+  const HP ux = rho > (HP)1e-15 ? x[0] / rho : (HP)1, uy = rho > (HP)1e-15 ? x[1] / rho : (HP)0;
+  if (rho > R || az > h) {
+    const HP qr = rho < R ? rho : R, qz = x[2] > h ? h : (x[2] < -h ? -h : x[2]);
+    const HP df[3] = {ux * qr - x[0], uy * qr - x[1], qz - x[2]};
+    const HP dn = norm3(df);
+    dd = dn - r;
+    if (dd > margin) return 0;
+    nl[0] = df[0] / dn; nl[1] = df[1] / dn; nl[2] = df[2] / dn;
+  } else {
+    const HP e_side = R - rho, e_cap = h - az;
+    if (e_cap < e_side) { nl[0] = 0; nl[1] = 0; nl[2] = x[2] > 0 ? (HP)-1 : (HP)1; dd = -e_cap - r; }
+    else { nl[0] = -ux; nl[1] = -uy; nl[2] = 0; dd = -e_side - r; }
+    if (dd > margin) return 0;
+  }
+  return point_finish<SLOT>(o, c, r, Rc, nl, dd, (HP)1);
+}
+template <int SLOT>
+DEV int point_ell_hp(ContactTmp& o, const HP* c, HP r, const HP* pe, const HP* Re, const HP* sz, HP margin) {
+  const HP t[3] = {c[0] - pe[0], c[1] - pe[1], c[2] - pe[2]};
+  HP x[3], q[3];
+  mulmatTvec3(x, Re, t);
+  const HP lev = (x[0] / sz[0]) * (x[0] / sz[0]) + (x[1] / sz[1]) * (x[1] / sz[1]) + (x[2] / sz[2]) * (x[2] / sz[2]);
+  HP dn, sign;
+  if (lev > 1) {
+    HP smax = sz[0] > sz[1] ? sz[0] : sz[1]; if (sz[2] > smax) smax = sz[2];
+    HP lo = 0, hi = norm3(x) * smax;
+    for (int it = 0; it < 64; ++it) {
+      const HP mid = (HP)0.5 * (lo + hi);
+      HP F = -1;
+      for (int k = 0; k < 3; ++k) { const HP v = sz[k] * x[k] / (mid + sz[k] * sz[k]); F += v * v; }
+      if (F > 0) lo = mid; else hi = mid;
+    }
+    const HP tt = (HP)0.5 * (lo + hi);
+    for (int k = 0; k < 3; ++k) q[k] = sz[k] * sz[k] * x[k] / (tt + sz[k] * sz[k]);
+    const HP df[3] = {q[0] - x[0], q[1] - x[1], q[2] - x[2]};
+    dn = norm3(df); sign = 1;
+  } else {
+    const HP sc = lev > (HP)1e-15 ? 1 / sqrt(lev) : (HP)0;
+    if (sc == 0) { q[0] = sz[0]; q[1] = 0; q[2] = 0; } else { q[0] = x[0] * sc; q[1] = x[1] * sc; q[2] = x[2] * sc; }
+    const HP df[3] = {q[0] - x[0], q[1] - x[1], q[2] - x[2]};
+    dn = norm3(df); sign = -1;
+  }
+  const HP dd = sign * dn - r;
+  if (dd > margin) return 0;
+  const HP g[3] = {-q[0] / (sz[0] * sz[0]), -q[1] / (sz[1] * sz[1]), -q[2] / (sz[2] * sz[2])};
+  const HP gn = norm3(g);
+  const HP nl[3] = {g[0] / gn, g[1] / gn, g[2] / gn};
+  return point_finish<SLOT>(o, c, r, Re, nl, dd, (HP)1);
+}
+
+template <typename T, int NC>
+DEV void collide_pair_ext(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g1, int g2, int sub, HP margin, ContactTmp& o) {
+  const int t1 = M.geom_type[g1], t2 = M.geom_type[g2];
+  HP p1[3], p2[3], R1[9], R2[9], s1[3], s2[3];
+  o.n = 0;
+  if (!pair_poses(M, K, s, g1, g2, margin, p1, p2, R1, R2, s1, s2)) return;
+  if (t1 == 0 && t2 == 4) {                       // plane - ellipsoid: the deepest point along -n (support mapping)
+    const HP n[3] = {R1[2], R1[5], R1[8]};
+    HP w[3], q[3];
+    mulmatTvec3(w, R2, n);
+    const HP sw[3] = {s2[0] * w[0], s2[1] * w[1], s2[2] * w[2]};
+    const HP L = norm3(sw);
+    const HP ql[3] = {-s2[0] * sw[0] / L, -s2[1] * sw[1] / L, -s2[2] * sw[2] / L};
+    mulmatvec3(q, R2, ql);
+    for (int k = 0; k < 3; ++k) q[k] += p2[k];
+    const HP dd = (q[0] - p1[0]) * n[0] + (q[1] - p1[1]) * n[1] + (q[2] - p1[2]) * n[2];
+    if (dd > margin) return;
+    o.dist[0] = dd;
+    for (int k = 0; k < 3; ++k) { o.nrm[k] = n[k]; o.pos[k] = q[k] - n[k] * (HP)0.5 * dd; }
+    o.n = 1;
+  } else if (t1 == 0 && t2 == 5) {                // plane - cylinder: the lowest rim point of each cap (its centre when the cap is level)
+    const HP n[3] = {R1[2], R1[5], R1[8]}, ax[3] = {R2[2], R2[5], R2[8]};
+    const HP na = dot3(n, ax);
+    const HP np_[3] = {n[0] - na * ax[0], n[1] - na * ax[1], n[2] - na * ax[2]};
+    const HP L = norm3(np_);
+    HP q0[3], q1[3];
+    for (int k = 0; k < 3; ++k) {
+      const HP rim = L > (HP)1e-12 ? s2[0] * np_[k] / L : (HP)0;
+      q0[k] = p2[k] + s2[1] * ax[k] - rim; q1[k] = p2[k] - s2[1] * ax[k] - rim;
+    }
+    const HP d0 = (q0[0] - p1[0]) * n[0] + (q0[1] - p1[1]) * n[1] + (q0[2] - p1[2]) * n[2];
+    const HP d1 = (q1[0] - p1[0]) * n[0] + (q1[1] - p1[1]) * n[1] + (q1[2] - p1[2]) * n[2];
+    const int v0 = !(d0 > margin), v1 = !(d1 > margin);
+    const HP da = v0 ? d0 : d1;
+    o.dist[0] = da; o.dist[1] = d1;
+    for (int k = 0; k < 3; ++k) {
+      o.nrm[k] = n[k]; o.nrm[3 + k] = n[k];
+      o.pos[k] = (v0 ? q0[k] : q1[k]) - n[k] * (HP)0.5 * da;
+      o.pos[3 + k] = q1[k] - n[k] * (HP)0.5 * d1;
+    }
+    o.n = v0 + v1;
+  } else if (t1 == 2 && t2 == 5) {
+    o.n = point_cyl_hp<0>(o, p1, s1[0], p2, R2, s2[0], s2[1], margin);
+  } else if (t1 == 2 && t2 == 4) {
+    o.n = point_ell_hp<0>(o, p1, s1[0], p2, R2, s2, margin);
+  } else if (t1 == 3 && (t2 == 4 || t2 == 5 || t2 == 6)) {
+    // the point of the capsule's segment nearest to geom 2 (64 ternary-search steps on the convex signed distance; closed
+    // form in the ellipsoid's own metric), then a sphere of the capsule's radius there
+    const HP ax[3] = {R1[2], R1[5], R1[8]}, t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
+    HP c[3], a[3], ts;
+    mulmatTvec3(c, R2, t); mulmatTvec3(a, R2, ax);
+    if (t2 == 4) {
+      HP num = 0, den = 0;
+      for (int k = 0; k < 3; ++k) { num += c[k] * a[k] / (s2[k] * s2[k]); den += a[k] * a[k] / (s2[k] * s2[k]); }
+      ts = den > (HP)1e-15 ? -num / den : (HP)0;
+      ts = tclamp(ts, -s1[1], s1[1]);
+    } else {
+      HP lo = -s1[1], hi = s1[1];
+      for (int it = 0; it < 64; ++it) {
+        const HP m1 = lo + (hi - lo) / (HP)3, m2 = hi - (hi - lo) / (HP)3;
+        const HP f1 = t2 == 6 ? sd_box_hp(c[0] + m1 * a[0], c[1] + m1 * a[1], c[2] + m1 * a[2], s2) : sd_cyl_hp(c[0] + m1 * a[0], c[1] + m1 * a[1], c[2] + m1 * a[2], s2[0], s2[1]);
+        const HP f2 = t2 == 6 ? sd_box_hp(c[0] + m2 * a[0], c[1] + m2 * a[1], c[2] + m2 * a[2], s2) : sd_cyl_hp(c[0] + m2 * a[0], c[1] + m2 * a[1], c[2] + m2 * a[2], s2[0], s2[1]);
+        if (f1 <= f2) hi = m2; else lo = m1;
+      }
+      ts = (HP)0.5 * (lo + hi);
+    }
+    const HP q[3] = {p1[0] + ts * ax[0], p1[1] + ts * ax[1], p1[2] + ts * ax[2]};
+    if (t2 == 6) {
+      // a capsule lying on a face rests on its two ends (both within the margin: two contacts, like plane-capsule); otherwise one
+      // contact at the nearest point of the segment
+      const HP qa[3] = {p1[0] + s1[1] * ax[0], p1[1] + s1[1] * ax[1], p1[2] + s1[1] * ax[2]};
+      const HP qb[3] = {p1[0] - s1[1] * ax[0], p1[1] - s1[1] * ax[1], p1[2] - s1[1] * ax[2]};
+      int both = point_box_hp<0>(o, qa, s1[0], p2, R2, s2, margin, (HP)1);
+      if (both) both += point_box_hp<1>(o, qb, s1[0], p2, R2, s2, margin, (HP)1);
+      o.n = both == 2 ? 2 : point_box_hp<0>(o, q, s1[0], p2, R2, s2, margin, (HP)1);
+    } else if (t2 == 5) o.n = point_cyl_hp<0>(o, q, s1[0], p2, R2, s2[0], s2[1], margin);
+    else o.n = point_ell_hp<0>(o, q, s1[0], p2, R2, s2, margin);
+  } else if (t1 == 6 && t2 == 6 && sub >= 1) {   // box - box: one vertex-face candidate (see the pair table)
+    const int v = (sub - 1) & 7, second = sub > 8;
+    HP loc[3], q[3];
+    if (!second) {
+      loc[0] = (v & 1) ? s1[0] : -s1[0]; loc[1] = (v & 2) ? s1[1] : -s1[1]; loc[2] = (v & 4) ? s1[2] : -s1[2];
+      mulmatvec3(q, R1, loc);
+      for (int k = 0; k < 3; ++k) q[k] += p1[k];
+      o.n = point_box_hp<0>(o, q, (HP)0, p2, R2, s2, margin, (HP)1);
+    } else {
+      loc[0] = (v & 1) ? s2[0] : -s2[0]; loc[1] = (v & 2) ? s2[1] : -s2[1]; loc[2] = (v & 4) ? s2[2] : -s2[2];
+      mulmatvec3(q, R2, loc);
+      for (int k = 0; k < 3; ++k) q[k] += p2[k];
+      o.n = point_box_hp<0>(o, q, (HP)0, p1, R1, s1, margin, (HP)-1);    // the normal runs from geom 1 to geom 2
+    }
+  }
+}
+
 // impedance / reference parameters of one constraint row (mj_makeImpedance, getsolparam)
 template <typename T>
 DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos_minus_margin, T* Kp, T* Bp, T* Ip) {
@@ -1485,8 +1702,8 @@ DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos
   *Ip = imp;
 }
 
-template <typename T>
-DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   // ---- limit rows: joints (lanes = joints), then tendons (lanes = tendons)
@@ -1568,61 +1785,54 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
   SYNC();
 }
 
-// contacts: one pass over 64 candidate pairs (lanes = pairs), called from kernel level once per 64 pairs — a leaf
-// function without the limit rows and without a loop, so that the HP narrow phase has a register allocation of its
-// own.  s.ncon / s.nefc carry the running counts between passes.
+// fp32 bounding-sphere PRE-filter with the MODEL rbound (the reference rewrites geom_size per episode without refreshing rbound,
+// baoding.py:586-604 — the stale value gates contacts): rejects only pairs that are apart by more than its rounding; the narrow
+// phase repeats the test exactly, in HP (pair_poses)
+template <typename T, int NC>
+DEV int pair_far_apart(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g1, int g2, HP margin) {
+  const T rb1 = M.geom_rbound[g1], rb2 = M.geom_rbound[g2];
+  if (!(rb1 > 0 && rb2 > 0)) return 0;
+  T c1[3], c2[3], l1[3], l2[3];
+  geom_lpos_of(M, K, s, g1, l1);
+  geom_lpos_of(M, K, s, g2, l2);
+  body_point(s, M.geom_bodyid[g1], l1, c1);
+  body_point(s, M.geom_bodyid[g2], l2, c2);
+  const T df[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+  const T bound = rb1 + rb2 + (T)margin;
+  return dot3(df, df) > bound * bound * (T)1.0001;
+}
+// keep only contacts that enter the constraint set (dist < margin - gap); static slot indices
 template <typename T>
-DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int base) {
+DEV void pair_keep_included(const DevModel<T>& M, int g1, int g2, HP margin, ContactTmp& ct) {
+  const HP inc = margin - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2]);
+  const int k0 = ct.n > 0 && ct.dist[0] < inc, k1 = ct.n > 1 && ct.dist[1] < inc;
+  if (!k0 && k1) {
+    ct.dist[0] = ct.dist[1];
+    for (int e = 0; e < 3; ++e) { ct.pos[e] = ct.pos[3 + e]; ct.nrm[e] = ct.nrm[3 + e]; }
+  }
+  ct.n = k0 + k1;
+}
+#ifdef MYO_EMU
+#define LANE_ARG(T, name) T* name
+#else
+#define LANE_ARG(T, name) T& name
+#endif
+// contact records from the narrow-phase results of one pass (ballot / prefix compaction over the 64 lanes, constraint parameters
+// from the host-resolved pair records); shared by the two collision passes.  pbase = pair index of lane 0.
+template <typename T, int NC>
+DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int pbase, LANE_ARG(ContactTmp, ct), int& ncon) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   int total = 0;
-  const int nlim = s.nl + s.ntl;
-  int ncon = s.ncon;
-  LANE_VAR(ContactTmp, ct);
+  const int base = pbase;
   {
-    PHASE {
-      const int p = base + lane;
-      LV(ct).n = 0;
-      if (p < M.npair) {
-        const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-        const HP margin = tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);
-        const T rb1 = M.geom_rbound[g1], rb2 = M.geom_rbound[g2];
-        int skip = 0;
-        if (rb1 > 0 && rb2 > 0) {
-          // bounding-sphere filter with the MODEL rbound (the reference rewrites geom_size per
-          // episode without refreshing rbound, baoding.py:586-604 — the stale value gates contacts)
-          T c1[3], c2[3], l1[3], l2[3];
-          geom_lpos_of(M, K, s, g1, l1);
-          geom_lpos_of(M, K, s, g2, l2);
-          body_point(s, M.geom_bodyid[g1], l1, c1);
-          body_point(s, M.geom_bodyid[g2], l2, c2);
-          const T df[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
-          // (a conservative PRE-filter: it rejects only pairs that are apart by more than its rounding; collide_pair
-          // repeats the test exactly, in HP)
-          const T bound = rb1 + rb2 + (T)margin;
-          if (dot3(df, df) > bound * bound * (T)1.0001) skip = 1;
-        }
-        if (!skip) {
-          collide_pair(M, K, s, g1, g2, margin, LV(ct));
-          // keep only contacts that enter the constraint set (dist < margin - gap); static slot indices
-          const HP inc = margin - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2]);
-          const int k0 = LV(ct).n > 0 && LV(ct).dist[0] < inc, k1 = LV(ct).n > 1 && LV(ct).dist[1] < inc;
-          if (!k0 && k1) {
-            LV(ct).dist[0] = LV(ct).dist[1];
-            for (int e = 0; e < 3; ++e) { LV(ct).pos[e] = LV(ct).pos[3 + e]; LV(ct).nrm[e] = LV(ct).nrm[3 + e]; }
-          }
-          const int keep = k0 + k1;
-          LV(ct).n = keep;
-        }
-      }
-    }
     WAVE_EXSCAN(LV(ct).n, S_NPRE(s), total);
     PHASE {
       const int p = base + lane;
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int ci = ncon + S_NPRE(s)[lane] + k;
-        if (k >= LV(ct).n || ci >= MYO_NCON_MAX) break;
+        if (k >= LV(ct).n || ci >= NC) break;
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
         ContactRec<T>& c = s.con[ci];
         for (int e = 0; e < 3; ++e) { c.pos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); c.frame[e] = (T)LV(ct).nrm[3 * k + e]; }
@@ -1668,8 +1878,60 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
     }
     SYNC();
     ncon += total;
-    if (ncon > MYO_NCON_MAX) ncon = MYO_NCON_MAX;
+    if (ncon > NC) ncon = NC;
   }
+}
+
+// contacts: one pass over 64 candidate pairs (lanes = pairs), called from kernel level once per 64 pairs — a leaf
+// function without the limit rows and without a loop, so that the HP narrow phase has a register allocation of its
+// own.  s.ncon / s.nefc carry the running counts between passes.  The model's pairs are ordered: first the pairs of MuJoCo's
+// sphere / capsule / plane primitives and sphere-box (this pass), then the "extended" pairs (collision_pass_ext).
+template <typename T, int NC>
+DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int base) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  const int nlim = s.nl + s.ntl;
+  int ncon = s.ncon;
+  LANE_VAR(ContactTmp, ct);
+  PHASE {
+    const int p = base + lane;
+    LV(ct).n = 0;
+    if (p < M.npair_std) {
+      const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+      const HP margin = tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);
+      if (!pair_far_apart(M, K, s, g1, g2, margin)) {
+        collide_pair(M, K, s, g1, g2, margin, LV(ct));
+        pair_keep_included(M, g1, g2, margin, LV(ct));
+      }
+    }
+  }
+  contacts_emit(M, K, s, base, ct, ncon);
+  PHASE {
+    if (lane == 0) { s.ncon = ncon; s.nefc = nlim + 4 * ncon; }
+  }
+  SYNC();
+}
+// the same for the extended pairs (capsule-box, box-box vertex candidates, cylinders, ellipsoids): base counts from the first of them
+template <typename T, int NC>
+DEVFN void collision_pass_ext(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int base) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  const int nlim = s.nl + s.ntl;
+  int ncon = s.ncon;
+  LANE_VAR(ContactTmp, ct);
+  PHASE {
+    const int p = M.npair_std + base + lane;
+    LV(ct).n = 0;
+    if (p < M.npair) {
+      const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+      const HP margin = tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);
+      if (!pair_far_apart(M, K, s, g1, g2, margin)) {
+        collide_pair_ext(M, K, s, g1, g2, M.pc_i[8 * p + 5], margin, LV(ct));
+        pair_keep_included(M, g1, g2, margin, LV(ct));
+      }
+    }
+  }
+  contacts_emit(M, K, s, M.npair_std + base, ct, ncon);
   PHASE {
     if (lane == 0) { s.ncon = ncon; s.nefc = nlim + 4 * ncon; }
   }
@@ -1679,8 +1941,8 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
 // ------------------------------------------------------------------------------------------
 // matrix-free constraint Jacobian products
 // body spatial vectors V_b(v) = sum_{d in ancestors(b)} cdof_d v_d   (lanes = bodies)
-template <typename T>
-DEV void body_vectors(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LREF(T) out_r) {
+template <typename T, int NC>
+DEV void body_vectors(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* v = LPTR(const T, v_r); T* out = LPTR(T, out_r);
   WAVE_FN
@@ -1708,7 +1970,7 @@ DEV void point_vel(const T* bv, int b, const T* off, T* out) {
   out[0] = V[3] + t[0]; out[1] = V[4] + t[1]; out[2] = V[5] + t[2];
 }
 // Jacobian column of dof d at a contact, given the contact offset from the dof's tree reference point
-template <typename T> DEV void con_col(const Scratch<T>& s, int d, const T* off, T* col) {
+template <typename T, int NC> DEV void con_col(const Scratch<T, NC>& s, int d, const T* off, T* col) {
   const T* cd = s.cdof + 6 * d;
   T t[3];
   cross3(t, cd, off);
@@ -1716,8 +1978,8 @@ template <typename T> DEV void con_col(const Scratch<T>& s, int d, const T* off,
 }
 
 // out[r] = (J v)[r] for every constraint row; bv = body vectors of v (already computed)
-template <typename T>
-DEV void J_times(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
+template <typename T, int NC>
+DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* v = LPTR(const T, v_r); const T* bv = LPTR(const T, bv_r); T* out = LPTR(T, out_r);
   WAVE_FN
@@ -1751,8 +2013,8 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) v_r, 
 
 // body_vectors / J_times for TWO vectors at once (the solver's warm-start comparison evaluates J on
 // qacc_warmstart and on qacc_smooth): the cdof entries and contact records are read once.
-template <typename T>
-DEVFN void body_vectors2(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) va_r, LCREF(T) vb_r, LREF(T) outa_r, LREF(T) outb_r) {
+template <typename T, int NC>
+DEVFN void body_vectors2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) va_r, LCREF(T) vb_r, LREF(T) outa_r, LREF(T) outb_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* va = LPTR(const T, va_r); const T* vb = LPTR(const T, vb_r);
   T* outa = LPTR(T, outa_r); T* outb = LPTR(T, outb_r);
@@ -1773,8 +2035,8 @@ DEVFN void body_vectors2(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(
   }
   SYNC();
 }
-template <typename T>
-DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) va_r, LCREF(T) bva_r, LREF(T) outa_r,
+template <typename T, int NC>
+DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) va_r, LCREF(T) bva_r, LREF(T) outa_r,
                     LCREF(T) vb_r, LCREF(T) bvb_r, LREF(T) outb_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* va = LPTR(const T, va_r); const T* bva = LPTR(const T, bva_r); T* outa = LPTR(T, outa_r);
@@ -1818,8 +2080,8 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T>& s_in, LCREF(T) va
 }
 
 // out = J' f  (lanes = dofs; contacts act as a world force at the contact point)
-template <typename T>
-DEV void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LREF(T) out_r) {
+template <typename T, int NC>
+DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* f = LPTR(const T, f_r); T* out = LPTR(T, out_r);
   WAVE_FN
@@ -1871,8 +2133,8 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) f_r, LREF(
 
 // ------------------------------------------------------------------------------------------
 // P8: velocity stage (mj_fwdVelocity): tendon/actuator velocity, comVel, passive, RNE bias, aref
-template <typename T>
-DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   const T* const qv = S_QVELT(s);
@@ -1973,8 +2235,8 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
 
 // reference acceleration of every constraint row: aref = -B vel - K imp (pos - margin).  Inlined at kernel
 // level (needs S_CVEL from body_vectors(qvel)), so that fwd_velocity and J_times are both leaf functions.
-template <typename T>
-DEV void efc_reference(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void efc_reference(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   if (s.nefc > 0) {
@@ -2004,8 +2266,8 @@ template <typename T> DEV T muscle_FL(T L, T lmin, T lmax) {
   return (T)0.5 * x * x;
 }
 
-template <typename T>
-DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -2098,8 +2360,8 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T>& s_in) {
 // The COST is accumulated in HP in every build: Newton's termination test is a cost DIFFERENCE of ~1e-8 on a
 // cost of ~1e2, and near the minimum the cost is flat to second order, so an fp32 cost stalls while the
 // iterate is still sqrt(eps) away.  The iterates, gradient and search direction stay T.
-template <typename T>
-DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {   // inlined into the solver loop (kernel level): JT_times stays a leaf call
+template <typename T, int NC>
+DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // inlined into the solver loop (kernel level): JT_times stays a leaf call
   MYO_BIND_M(T) MYO_BIND_S(T)
   // forces / active set from jar, cost, qfrc_constraint, gradient
   WAVE_FN
@@ -2125,8 +2387,8 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T>& s_in) {   // inlin
   return ccost + (HP)0.5 * gcost;
 }
 
-template <typename T>
-DEV void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   // (the caller has loaded M into H: load_H_from_M is called from kernel level so that this function stays a leaf)
@@ -2226,8 +2488,8 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T>& s_in) {
   }
 }
 
-template <typename T>
-DEV void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   const int nv = M.nv, nefc = s.nefc;
@@ -2279,7 +2541,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
     // exact 1-D minimisation of the convex piecewise-quadratic: safeguarded Newton on p'(alpha)
     T alpha = 0, lo = 0, hi = -1;
     // each lane keeps its (<= 3) rows' jar, jv and D in registers for the whole line search
-    static_assert(MYO_NEFC_MAX <= 192, "three rows per lane");
+    static_assert(MYO_NLIM_MAX + 4 * NC <= 192, "three rows per lane");
     LANE_VAR(T, ls_x0); LANE_VAR(T, ls_x1); LANE_VAR(T, ls_x2);
     LANE_VAR(T, ls_v0); LANE_VAR(T, ls_v1); LANE_VAR(T, ls_v2);
     LANE_VAR(T, ls_d0); LANE_VAR(T, ls_d1); LANE_VAR(T, ls_d2);
@@ -2345,8 +2607,8 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T>& s_in) {
   PROF(s, 11)
 }
 
-template <typename T>
-DEV void fwd_acceleration(const DevModel<T>& M_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void fwd_acceleration(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   load_H_from_M(M, s, (const T*)0, (T)0);
@@ -2366,8 +2628,8 @@ DEV void fwd_acceleration(const DevModel<T>& M_in, Scratch<T>& s_in) {
   newton_solve(M, s);
 }
 
-template <typename T>
-DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   PROF(s, 15)
   kinematics(M, s);
@@ -2385,7 +2647,8 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
   PROF(s, 4)
   constraint_limits(M, K, s);
   PROF(s, 18)
-  for (int base = 0; base < M.npair; base += 64) collision_pass(M, K, s, base);
+  for (int base = 0; base < M.npair_std; base += 64) collision_pass(M, K, s, base);
+  for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext(M, K, s, base - M.npair_std);
   PROF(s, 5)
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   PROF(s, 19)
@@ -2400,8 +2663,8 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in)
 
 // ------------------------------------------------------------------------------------------
 // P11: integrators.  The state and its update are HP; the rates (qacc, act_dot, RK4 stage derivatives) are T.
-template <typename T>
-DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel_r, HP h_in) {
+template <typename T, int NC>
+DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) vel_r, HP h_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   // vel_r = null: the (HP) velocity state itself; otherwise a T vector (RK4 stage combination)
   const T* velT = LISNULL(vel_r) ? (const T*)0 : LPTR(const T, vel_r);
@@ -2432,8 +2695,8 @@ DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) vel_r
   SYNC();
 }
 
-template <typename T>
-DEV void advance(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) act_dot_r, LCREF(T) qacc_r, LCREF(T) vel_r) {
+template <typename T, int NC>
+DEV void advance(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) act_dot_r, LCREF(T) qacc_r, LCREF(T) vel_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* act_dot = LPTR(const T, act_dot_r); const T* qacc = LPTR(const T, qacc_r);
   WAVE_FN
@@ -2452,8 +2715,8 @@ DEV void advance(const DevModel<T>& M_in, Scratch<T>& s_in, LCREF(T) act_dot_r, 
   integrate_pos(M, s, vel_r, M.h_timestep);
 }
 
-template <typename T>
-DEV void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc) {
+template <typename T, int NC>
+DEV void check_state(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int check_acc) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   // mj_checkPos / mj_checkVel / mj_checkAcc: any non-finite or huge entry marks the env bad.  No reduction:
@@ -2472,8 +2735,8 @@ DEV void check_state(const DevModel<T>& M_in, Scratch<T>& s_in, int check_acc) {
   }
 }
 
-template <typename T>
-DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   check_state(M, s, 0);

@@ -67,8 +67,8 @@ DEV double rng_beta(Philox& g, double a, double b) {
 }
 
 // ---- observation (layout pinned by tests/golden/reset_obs_golden.npy) and reward
-template <typename T>
-DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   const int nh = K.n_hand;
@@ -145,8 +145,8 @@ DEV void ro_quat2euler(const HP* qin, HP* e) {    // mat2euler(quat2mat(q)), q n
 // reorient.py:12-56 with the shaping terms taken against the distances of the previous step (or of the reset), which
 // are replaced by this step's at the end (reorient.py:178-179,207-210).  comps = pos_dist, rot_dist, act_reg, alive,
 // sparse, solved, done, dense (the two *_diff terms enter dense only).
-template <typename T>
-DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   const int nh = K.n_hand;
@@ -198,15 +198,15 @@ DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scr
   SYNC();
 }
 
-template <typename T>
-DEV void task_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s) {
+template <typename T, int NC>
+DEV void task_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T, NC>& s) {
   if (K.kind == MYO_TASK_REORIENT_K) reorient_obs_reward(M, K, s); else baoding_obs_reward(M, K, s);
 }
 DEV int task_nobs(const TaskDev& K, int na) { return K.kind == MYO_TASK_REORIENT_K ? 2 * K.n_hand + 18 + na : K.n_hand + 24 + na; }
 
 // ---- env.step(a) without the VecEnv bookkeeping
-template <typename T>
-DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, const float* action /* may be null = zeros */) {
+template <typename T, int NC>
+DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, const float* action /* may be null = zeros */) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -241,8 +241,8 @@ DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>
   task_obs_reward(M, K, s);
 }
 
-template <typename T>
-DEVFN void set_init_state(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int keep_dynamics) {
+template <typename T, int NC>
+DEVFN void set_init_state(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int keep_dynamics) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   // robot.reset(init_qpos, init_qvel): init_qpos[:-14]=0, init_qpos[0]=-1.57 (baoding.py:281-283)
   WAVE_FN
@@ -259,8 +259,8 @@ DEVFN void set_init_state(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
 }
 
 // ---- reset(): returns with the post-reset state in scratch and the reset observation in S_OBS(s)
-template <typename T>
-DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int env) {
+template <typename T, int NC>
+DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int env) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   Philox g;
@@ -401,8 +401,8 @@ DEVFN void baoding_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
 // axis, the three Euler angles, the friction triple of every die geom, the size delta.  `enable_rsi` (:150-176) rewrites
 // body_pos / body_quat of the Object body; that body carries the free joint, whose pose comes from qpos (robot.reset(init_qpos))
 // and never from body_pos, so the reference's RSI branch leaves the state exactly as the plain reset does — and so does this.
-template <typename T>
-DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T>& s_in, int env) {
+template <typename T, int NC>
+DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int env) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   Philox g;
@@ -446,14 +446,14 @@ DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
   reorient_obs_reward(M, K, s);      // leaves pos_dist / rot_dist of the reset state (reorient.py:178-179)
 }
 
-template <typename T>
-DEV void task_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T>& s, int env) {
+template <typename T, int NC>
+DEV void task_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T, NC>& s, int env) {
   if (K.kind == MYO_TASK_REORIENT_K) reorient_reset(M, K, s, env); else baoding_reset(M, K, s, env);
 }
 
 // ---- HBM record <-> scratch
-template <typename T>
-DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, const double* rec, Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, const double* rec, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -481,8 +481,8 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
   SYNC();
 }
 
-template <typename T>
-DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T>& s_in) {
+template <typename T, int NC>
+DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -509,8 +509,8 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
 }
 
 // ---- the three env-level entry points (one call = one env; the kernels are thin wrappers)
-template <typename T>
-DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+template <typename T, int NC>
+DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                   float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
   WAVE_FN
@@ -559,8 +559,8 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
 // env.step(a) of the UNWRAPPED gym env for the envs selected by mask: no TimeLimit / Monitor accounting and
 // no auto-reset — the steps MixtureModelBaodingEnv.reset takes with its base policy
 // (/root/reference/src/envs/baoding.py:700-711).  done_out = the env's own `done` (ball dropped).
-template <typename T>
-DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+template <typename T, int NC>
+DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                         int env, const unsigned char* mask, const float* act, float* obs, unsigned char* done_out) {
   WAVE_FN
   if (mask && !mask[env]) return;
@@ -581,8 +581,8 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
   store_env(M, K, L, rec, s);
 }
 
-template <typename T>
-DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+template <typename T, int NC>
+DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                    int env, const unsigned char* mask, float* obs) {
   WAVE_FN
   if (mask && !mask[env]) return;
@@ -595,8 +595,8 @@ DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout
   store_env(M, K, L, rec, s);
 }
 
-template <typename T>
-DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+template <typename T, int NC>
+DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                      int env, const double* ctrl, int nsub) {
   WAVE_FN
   load_env(M, K, L, rec, s);
@@ -611,8 +611,8 @@ struct DumpLayout {
   int ten_length, ten_J, M, qfrc_bias, qfrc_passive, qfrc_actuator, qacc_smooth, qacc, actuator_force, act_dot,
       counts, efc_aref, efc_D, site_xpos, subtree_com, xpos, total;
 };
-template <typename T>
-DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T>& s,
+template <typename T, int NC>
+DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                           int env, const double* ctrl, const DumpLayout& D, double* out_all) {
   WAVE_FN
   double* out = out_all + (size_t)env * D.total;
@@ -634,7 +634,8 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   tendon_length_sums(M, s);
   crb(M, s);
   constraint_limits(M, K, s);
-  for (int base = 0; base < M.npair; base += 64) collision_pass(M, K, s, base);
+  for (int base = 0; base < M.npair_std; base += 64) collision_pass(M, K, s, base);
+  for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext(M, K, s, base - M.npair_std);
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
   efc_reference(M, s);

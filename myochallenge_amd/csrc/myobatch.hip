@@ -61,7 +61,7 @@ extern "C" const char* myo_version(void) {      // "... build <hash of the nativ
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
   MYO_MODEL_INT_ARRAYS(X)
@@ -115,7 +115,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
       sizeof(myo_blob_header) + (size_t)h->n_fields * sizeof(myo_blob_field) > nbytes)
     return fail(MYO_E_ARG, "bad model blob header");
   myo_model* m = new myo_model();
-  std::vector<int> sizes, opt_i, trntype, trnid, body_weldid, geom_condim;
+  std::vector<int> sizes, opt_i, trntype, trnid, body_weldid, geom_condim, pair_sub;
   std::vector<double> opt_d, body_iquat, geom_quat;
   bool ok = get_i(blob, nbytes, "sizes", sizes) && sizes.size() >= 10 && get_i(blob, nbytes, "opt_int", opt_i) &&
             opt_i.size() >= 4 && get_d(blob, nbytes, "opt_f64", opt_d) && opt_d.size() >= 8;
@@ -140,6 +140,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   if (ok) ok = get_i(blob, nbytes, "actuator_trntype", trntype) && get_i(blob, nbytes, "actuator_trnid", trnid) &&
                get_d(blob, nbytes, "body_iquat", body_iquat) && get_d(blob, nbytes, "geom_quat", geom_quat) &&
                get_i(blob, nbytes, "x_pair_geom1", m->pair_geom1) && get_i(blob, nbytes, "x_pair_geom2", m->pair_geom2);
+  if (ok && !get_i(blob, nbytes, "x_pair_sub", pair_sub)) pair_sub.assign(m->pair_geom1.size(), 0);      // (older blobs: no box-box candidates)
   if (!ok) {
     int rc = fail(MYO_E_ARG, "model blob lacks field %s", missing ? missing : "(sizes/opt/derived)");
     delete m;
@@ -148,6 +149,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   m->nq = sizes[0]; m->nv = sizes[1]; m->nu = sizes[2]; m->na = sizes[3]; m->nbody = sizes[4]; m->njnt = sizes[5];
   m->ngeom = sizes[6]; m->nsite = sizes[7]; m->ntendon = sizes[8]; m->nwrap = sizes[9];
   m->npair = (int)m->pair_geom1.size();
+  m->npair_std = 0;
   m->integrator = opt_i[0]; m->iterations = opt_i[2]; m->disableflags = opt_i[3];
   m->timestep = opt_d[0]; m->tolerance = opt_d[1]; m->impratio = opt_d[2];
   m->gravity[0] = opt_d[3]; m->gravity[1] = opt_d[4]; m->gravity[2] = opt_d[5]; m->meaninertia = opt_d[7];
@@ -157,7 +159,8 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
 #define BAD(...) { snprintf(why, sizeof why, __VA_ARGS__); int rc = fail(MYO_E_ARG, "corrupt model: %s", why); delete m; return rc; }
     for (int k = 0; k < 10; ++k) if (sizes[k] < 0) BAD("negative size %d", k)
     if (m->nbody < 1 || m->na > m->nu) BAD("nbody < 1 or na > nu")
-    if (m->pair_geom1.size() != m->pair_geom2.size()) BAD("pair arrays differ in length")
+    if (m->pair_geom1.size() != m->pair_geom2.size() || pair_sub.size() != m->pair_geom1.size()) BAD("pair arrays differ in length")
+    for (int v : pair_sub) if (v < 0 || v > 16) BAD("collision pair sub-index %d", v)
 #define NEED(arr, cnt) if (m->arr.size() < (size_t)(cnt)) BAD("array %s has %zu entries, needs %zu", #arr, m->arr.size(), (size_t)(cnt))
     const size_t nb_ = m->nbody, nj_ = m->njnt, nv_ = m->nv, ng_ = m->ngeom, ns_ = m->nsite, nt_ = m->ntendon, nw_ = m->nwrap, nu_ = m->nu;
     NEED(body_parentid, nb_) NEED(body_rootid, nb_) NEED(body_jntnum, nb_) NEED(body_jntadr, nb_) NEED(body_dofnum, nb_) NEED(body_dofadr, nb_)
@@ -218,6 +221,18 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
       if (m->pair_geom1[p] < 0 || m->pair_geom1[p] >= m->ngeom || m->pair_geom2[p] < 0 || m->pair_geom2[p] >= m->ngeom) BAD("collision pair %zu names a geom out of range", p)
     if (!(m->timestep > 0) || !std::isfinite(m->timestep) || m->iterations < 0) BAD("opt.timestep / opt.iterations")
 #undef BAD
+  }
+  {   // pairs of the primitive narrow phases first, the extended ones (csrc/myo_physics.h:collide_pair_ext) after them
+    auto is_std = [&](int p) {
+      const int t1 = m->geom_type[m->pair_geom1[p]], t2 = m->geom_type[m->pair_geom2[p]];
+      return (t1 == MYO_GEOM_PLANE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE)) || (t1 == MYO_GEOM_SPHERE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_BOX)) ||
+             (t1 == MYO_GEOM_CAPSULE && t2 == MYO_GEOM_CAPSULE);
+    };
+    int k = 0;
+    while (k < m->npair && is_std(k)) k++;
+    m->npair_std = k;
+    for (; k < m->npair; ++k)
+      if (is_std(k)) { int rc = fail(MYO_E_ARG, "corrupt model: collision pairs are not ordered (primitive pairs first)"); delete m; return rc; }
   }
   // ---- capacity / feature checks
 #define LIM(cond, what) if (cond) { int rc = fail(MYO_E_UNSUPPORTED, "model exceeds stepper capacity: %s", what); delete m; return rc; }
@@ -428,8 +443,8 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   }
   // per-pair contact records: everything mj_contactParam / the constraint build derive from the two geoms
   // alone is resolved here (the device stage was a chain of dependent table loads per contact):
-  //   pc_i[8p..]  = body1, body2, root body 1, root body 2, nsup, ball flag 1, ball flag 2 (0 none, 1/2 = the
-  //                 ball whose friction is per-env), friction selector (0 max, 1 geom1, 2 geom2)
+  //   pc_i[8p..]  = body1, body2, root body 1, root body 2, nsup, box-box candidate (0 none; 1 + v: vertex v of geom 1 against
+  //                 geom 2, 9 + v: vertex v of geom 2 against geom 1), 0, friction selector (0 max, 1 geom1, 2 geom2)
   //   pc_sup[4p..] = the dofs either body can move (<= 16 bytes, ascending)
   //   pc_f[16p..] = margin, margin - gap, solref[2], solimp[5] (mixed), friction1[3], friction2[3], invweight sum
   //   pc_mask[2p..] = ancestor-dof masks of the two bodies
@@ -447,7 +462,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     for (unsigned long long x = mk; x; x &= x - 1) cnt++;
     LIM(cnt > MYO_CS_MAX, "a contact pair moves more than MYO_CS_MAX dofs")
     int* I = &m->pc_i[8 * (size_t)p];
-    I[0] = b1; I[1] = b2; I[2] = m->body_rootid[b1]; I[3] = m->body_rootid[b2]; I[4] = cnt;
+    I[0] = b1; I[1] = b2; I[2] = m->body_rootid[b1]; I[3] = m->body_rootid[b2]; I[4] = cnt; I[5] = pair_sub[p];
     unsigned char* sup = reinterpret_cast<unsigned char*>(&m->pc_sup[4 * (size_t)p]);
     { int ns = 0; for (int d = 0; d < 64 && ns < MYO_CS_MAX; ++d) if ((mk >> d) & 1ull) sup[ns++] = (unsigned char)d; }
     m->pc_mask[2 * (size_t)p] = m1; m->pc_mask[2 * (size_t)p + 1] = m2;
@@ -537,6 +552,7 @@ extern "C" int myo_model_size(const myo_model* m, const char* n) {
 struct myo_batch;
 struct myo_batch {
   int n, device, dtype, nobs;
+  int ncap;                    // contact capacity of the scratch: MYO_NCON_MAX, or MYO_NCON_BIG for models with extended pairs / a die
   myo_task_cfg cfg;
   TaskDev K;
   EnvRecordLayout L;
@@ -604,7 +620,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nq = m->nq; D.nv = m->nv; D.nu = m->nu; D.na = m->na; D.nbody = m->nbody; D.njnt = m->njnt; D.ngeom = m->ngeom;
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
-  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte;
+  D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte; D.npair_std = m->npair_std;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];
@@ -729,6 +745,10 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   myo_batch* b = new myo_batch();
   b->n = n_envs; b->device = device; b->dtype = dtype; b->bad_state = nullptr; b->timing = 0; b->ms_sum = 0; b->ms_cnt = 0;
   b->integrator = m->integrator;
+  // contact capacity of the per-env scratch: the Baoding hand (39 candidate pairs, 11 contacts at most in the bench workload) keeps
+  // the base; models with extended pairs (boxes, cylinders, ellipsoids) and the die task get the larger scratch (one workgroup
+  // per CU less: 21.9 KB instead of 20.2 KB of LDS)
+  b->ncap = (m->npair > m->npair_std || (cfg && cfg->kind == MYO_TASK_REORIENT)) ? MYO_NCON_BIG : MYO_NCON_MAX;
   b->geom_friction = m->geom_friction;
   b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon; b->ngeom = m->ngeom;
   if (cfg) b->cfg = *cfg; else memset(&b->cfg, 0, sizeof b->cfg);
@@ -748,7 +768,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   D.ten_length = o; o += m->ntendon; D.ten_J = o; o += m->ntendon * m->nv; D.M = o; o += m->nv * m->nv;
   D.qfrc_bias = o; o += m->nv; D.qfrc_passive = o; o += m->nv; D.qfrc_actuator = o; o += m->nv;
   D.qacc_smooth = o; o += m->nv; D.qacc = o; o += m->nv; D.actuator_force = o; o += m->nu; D.act_dot = o; o += m->na;
-  D.counts = o; o += 4; D.efc_aref = o; o += MYO_NEFC_MAX; D.efc_D = o; o += MYO_NEFC_MAX;
+  D.counts = o; o += 4; D.efc_aref = o; o += MYO_NLIM_MAX + 4 * MYO_NCON_BIG; D.efc_D = o; o += MYO_NLIM_MAX + 4 * MYO_NCON_BIG;
   D.site_xpos = o; o += 3 * m->nsite; D.subtree_com = o; o += 3 * m->nbody; D.xpos = o; o += 3 * m->nbody; D.total = o;
   // initial records: qpos0, zero velocity; model ball parameters; target sites at their model xy;
   // start angles per _setup (baoding.py:246-247 P1; :349-354 P2 decided per env at reset time here)
@@ -817,7 +837,9 @@ extern "C" int myo_batch_num_envs(const myo_batch* b) { return b ? b->n : -1; }
 extern "C" int myo_batch_obs_dim(const myo_batch* b) { return b ? b->nobs : -1; }
 extern "C" int myo_batch_lds_bytes(const myo_batch* b) {
   if (!b) return -1;
-  return b->dtype == MYO_F64 ? (int)sizeof(Scratch<double>) : (int)sizeof(Scratch<float>);      // RK4 stage storage is in global memory
+  const bool big = b->ncap > MYO_NCON_MAX;       // RK4 stage storage is in global memory
+  if (b->dtype == MYO_F64) return big ? (int)sizeof(Scratch<double, MYO_NCON_BIG>) : (int)sizeof(Scratch<double>);
+  return big ? (int)sizeof(Scratch<float, MYO_NCON_BIG>) : (int)sizeof(Scratch<float>);
 }
 extern "C" int myo_batch_dump_size(const myo_batch* b) { return b ? b->D.total : -1; }
 extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
@@ -842,11 +864,11 @@ extern "C" int myo_debug_read_prof(double* out16, int reset) {     /* out16: MYO
   return 0;
 }
 #endif
-template <typename T, bool RK>
+template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, const float* act,
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
-  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
@@ -862,40 +884,40 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
   if (threadIdx.x < MYO_NPROF) atomicAdd(&g_prof[threadIdx.x], s.prof[threadIdx.x]);
 #endif
 }
-template <typename T, bool RK>
+template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_reset(EnvRecordLayout L, double* rec,
                                               const unsigned char* mask, float* obs) {
-  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
   env_reset<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, obs);
 }
-template <typename T, bool RK>
+template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_step_inner(EnvRecordLayout L, double* rec, const unsigned char* mask, const float* act,
                                                    float* obs, unsigned char* done) {
-  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
   env_step_inner<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, act, obs, done);
 }
-template <typename T, bool RK>
+template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* rec,
                                                 const double* ctrl, int nsub) {
-  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
   env_physics<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, nsub);
 }
-template <typename T, bool RK>
+template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_dump(EnvRecordLayout L, double* rec, const double* ctrl,
                                              DumpLayout D, double* out) {
-  Scratch<T>& s = *reinterpret_cast<Scratch<T>*>(myo_lds);
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
@@ -940,8 +962,7 @@ static unsigned lds_dyn(const myo_batch* b) {
   if (pad < 0) { const char* e = getenv("MYO_LDS_PAD"); pad = e ? atoi(e) : 0; }
   if (b->dtype != MYO_F64) return (unsigned)(MYO_LDS_ALIGN(sizeof(Scratch<float>)) + pad);
 #endif
-  if (b->dtype == MYO_F64) return (unsigned)MYO_LDS_ALIGN(sizeof(Scratch<double>));
-  return (unsigned)MYO_LDS_ALIGN(sizeof(Scratch<float>));
+  return (unsigned)MYO_LDS_ALIGN(myo_batch_lds_bytes(b));
 }
 #define BIND_OR_RETURN(b, st) DeviceGuard _guard((b)->device); { int _rc = bind_constants(b, st); if (_rc) return _rc; }
 #endif
@@ -1080,11 +1101,14 @@ extern "C" int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d,
 }
 
 #ifdef MYO_EMU
-#define FOR_ENVS_F64(call) { Scratch<double>* s = new Scratch<double>(); memset(s, 0, sizeof *s); RkScratch<double>* rk = new RkScratch<double>(); s->rk = rk; for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; delete rk; }
-#define FOR_ENVS_F32(call) { Scratch<float>* s = new Scratch<float>(); memset(s, 0, sizeof *s); RkScratch<float>* rk = new RkScratch<float>(); s->rk = rk; for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; delete rk; }
+#define FOR_ENVS_T(TT, NCV, call) { Scratch<TT, NCV>* s = new Scratch<TT, NCV>(); memset(s, 0, sizeof *s); RkScratch<TT>* rk = new RkScratch<TT>(); s->rk = rk; for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; delete rk; }
+#define FOR_ENVS_F64(call) { if (b->ncap > MYO_NCON_MAX) FOR_ENVS_T(double, MYO_NCON_BIG, call) else FOR_ENVS_T(double, MYO_NCON_MAX, call) }
+#define FOR_ENVS_F32(call) { if (b->ncap > MYO_NCON_MAX) FOR_ENVS_T(float, MYO_NCON_BIG, call) else FOR_ENVS_T(float, MYO_NCON_MAX, call) }
 #else
 // the RK4 stage storage is only allocated (LDS) by the kernel variants of RK4 models
-#define LAUNCH_RK(b, ...) if ((b)->integrator == 1) { constexpr bool RKV = true; __VA_ARGS__; } else { constexpr bool RKV = false; __VA_ARGS__; }
+// ... and the scratch's contact capacity (NCV) is the batch's: MYO_NCON_BIG for models with extended collision pairs or a die
+#define LAUNCH_RK1(b, ...) if ((b)->integrator == 1) { constexpr bool RKV = true; __VA_ARGS__; } else { constexpr bool RKV = false; __VA_ARGS__; }
+#define LAUNCH_RK(b, ...) if ((b)->ncap > MYO_NCON_MAX) { constexpr int NCV = MYO_NCON_BIG; LAUNCH_RK1(b, __VA_ARGS__) } else { constexpr int NCV = MYO_NCON_MAX; LAUNCH_RK1(b, __VA_ARGS__) }
 #endif
 
 extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, void* stream) {
@@ -1098,8 +1122,8 @@ extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, vo
   hipStream_t st = (hipStream_t)stream;
   BIND_OR_RETURN(b, st)
   LAUNCH_RK(b,
-    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs))
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs))
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;
@@ -1119,9 +1143,9 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
   timing_begin(b, st);
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
   timing_end(b, st);
   LAUNCH_CHECK(b)
 #endif
@@ -1140,9 +1164,9 @@ extern "C" int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const flo
   BIND_OR_RETURN(b, st)
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done))
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done))
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;
@@ -1159,8 +1183,8 @@ extern "C" int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub
   BIND_OR_RETURN(b, st)
   timing_begin(b, st);
   LAUNCH_RK(b,
-    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<double, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<float, RKV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub))
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub))
   timing_end(b, st);
   LAUNCH_CHECK(b)
 #endif
@@ -1176,8 +1200,9 @@ extern "C" int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* 
 #else
   hipStream_t st = (hipStream_t)stream;
   BIND_OR_RETURN(b, st)
-  if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<double, false>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<float, false>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out);
+  LAUNCH_RK(b, (void)RKV;
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<double, false, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<float, false, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out))
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;

@@ -13,7 +13,7 @@ arrays the physics uses, this derives the static tables a wave-per-env stepper w
 
 Feature gates (raise ``ModelError``): ball joints, equality constraints, friction loss,
 elliptic cones, inside-wrapping side sites, mesh/hfield colliders.  Geom pairs whose narrow
-phase is not implemented (cylinder/ellipsoid/box-box) make ``compile_model`` raise
+phase is not implemented (ellipsoid-ellipsoid, cylinder-cylinder, box-cylinder, box-ellipsoid, anything with a mesh or height field) make ``compile_model`` raise
 ``UnsupportedContactsError`` unless the caller opts in with ``unsupported_contacts="drop"``; the dropped pairs are
 then listed in ``CompiledModel.dropped_pairs``.
 """
@@ -36,9 +36,11 @@ GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDE
 WRAP_JOINT, WRAP_PULLEY, WRAP_SITE, WRAP_SPHERE, WRAP_CYLINDER = 1, 2, 3, 4, 5
 
 SUPPORTED_PAIRS = {
-    (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE),
-    (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_SPHERE, GEOM_BOX),
-    (GEOM_CAPSULE, GEOM_CAPSULE),
+    (GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_PLANE, GEOM_ELLIPSOID), (GEOM_PLANE, GEOM_CYLINDER),
+    (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE), (GEOM_SPHERE, GEOM_BOX), (GEOM_SPHERE, GEOM_CYLINDER),
+    (GEOM_SPHERE, GEOM_ELLIPSOID),
+    (GEOM_CAPSULE, GEOM_CAPSULE), (GEOM_CAPSULE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CYLINDER), (GEOM_CAPSULE, GEOM_ELLIPSOID),
+    (GEOM_BOX, GEOM_BOX),            # vertex-face contacts: listed as 16 candidates per geom pair (x_pair_sub)
 }
 
 _INT_FIELDS = [
@@ -158,8 +160,10 @@ def collision_pairs(m: MjbModel):
             key = (min(t1, t2), max(t1, t2))
             if key == (GEOM_PLANE, GEOM_PLANE):
                 continue
-            if key in SUPPORTED_PAIRS:
-                pairs.append((a, b))
+            if key == (GEOM_BOX, GEOM_BOX):
+                pairs += [(a, b, 1 + v) for v in range(16)]      # sub = 1 + v: vertex v of a vs b; 9 + v: vertex v of b vs a
+            elif key in SUPPORTED_PAIRS:
+                pairs.append((a, b, 0))
             else:
                 dropped.append((a, b))
     return pairs, dropped
@@ -221,9 +225,14 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
         raise UnsupportedContactsError(
             f"{len(dropped)} colliding geom pair(s) have no narrow phase in this stepper: {some}"
             f"{' ...' if len(dropped) > 6 else ''}.  Pass unsupported_contacts='drop' to compile without them.")
-    pa = np.array(pairs, np.int32).reshape(-1, 2)
+    std = {(GEOM_PLANE, GEOM_SPHERE), (GEOM_PLANE, GEOM_CAPSULE), (GEOM_SPHERE, GEOM_SPHERE), (GEOM_SPHERE, GEOM_CAPSULE),
+           (GEOM_SPHERE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE)}
+    is_std = lambda pr: (int(m.geom_type[pr[0]]), int(m.geom_type[pr[1]])) in std
+    pairs = [pr for pr in pairs if is_std(pr)] + [pr for pr in pairs if not is_std(pr)]      # the stepper runs the primitive pairs first
+    pa = np.array(pairs, np.int32).reshape(-1, 3)
     f["x_pair_geom1"] = np.ascontiguousarray(pa[:, 0])
     f["x_pair_geom2"] = np.ascontiguousarray(pa[:, 1])
+    f["x_pair_sub"] = np.ascontiguousarray(pa[:, 2])
     # wrapping side sites that sit inside their wrap geom would need MuJoCo's inside-wrap
     # Newton iteration; not implemented.
     for t in range(m.ntendon):

@@ -34,7 +34,7 @@ struct OrcModel {
       *dof_jntid, *dof_parentid, *geom_type, *geom_condim, *geom_bodyid, *geom_priority,
       *site_bodyid, *tendon_adr, *tendon_num, *tendon_limited, *wrap_type, *wrap_objid,
       *actuator_trntype, *actuator_dyntype, *actuator_gaintype, *actuator_biastype,
-      *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *pair_geom1, *pair_geom2;
+      *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *pair_geom1, *pair_geom2, *pair_sub;
   const double *qpos0, *qpos_spring, *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass,
       *body_inertia, *body_invweight0, *jnt_solref, *jnt_solimp, *jnt_pos, *jnt_axis,
       *jnt_stiffness, *jnt_range, *jnt_margin, *dof_armature, *dof_damping, *dof_invweight0,
@@ -217,6 +217,7 @@ OrcModel* orc_model_from_blob(const void* src, size_t nbytes, char* err, int err
   m->npair = (int)p1->count;
   m->pair_geom1 = (const int*)(base + p1->offset);
   m->pair_geom2 = (const int*)(base + p2->offset);
+  { const myo_blob_field* ps = blob_find(m->blob, "x_pair_sub"); m->pair_sub = (ps && ps->count == p1->count) ? (const int*)(base + ps->offset) : NULL; }
   return m;
 }
 
@@ -708,7 +709,123 @@ static void seg_nearest(double* out, const double* c, const double* axis, double
   for (int k = 0; k < 3; ++k) out[k] = c[k] + t*axis[k];
 }
 
-static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, double margin,
+/* ---- narrow phases beyond MuJoCo's sphere / capsule primitives.  Frames: p = geom centre, R = geom rotation (row-major,
+ * columns = the geom's axes in world coordinates), normal always from geom 1 towards geom 2, pos = the point midway between
+ * the two surfaces, dist < 0 = penetration (mjContact conventions).
+ * [3P-RECALL] MuJoCo 2.1 sends sphere / capsule vs cylinder / ellipsoid through its general convex routine (libccd MPR,
+ * tolerance 1e-6) and has primitives mjc_CapsuleBox / mjc_BoxBox / mjc_PlaneCylinder whose multi-contact heuristics are not
+ * restated here: what follows is the exact geometry (closest points) with this stepper's own choice of contact points where
+ * MuJoCo returns several.  Differences from MuJoCo are therefore possible in the number and placement of contacts of a
+ * face-on-face configuration; a single-point configuration agrees with MPR to its tolerance. */
+static double sd_box(const double* x, const double* s) {         /* signed distance of a point (box frame) to the solid box */
+  double q0 = fabs(x[0]) - s[0], q1 = fabs(x[1]) - s[1], q2 = fabs(x[2]) - s[2];
+  double o0 = q0 > 0 ? q0 : 0, o1 = q1 > 0 ? q1 : 0, o2 = q2 > 0 ? q2 : 0;
+  double outside = sqrt(o0*o0 + o1*o1 + o2*o2);
+  double m = q0 > q1 ? q0 : q1; if (q2 > m) m = q2;
+  return outside > 0 ? outside : m;
+}
+static double sd_cylinder(const double* x, double R, double h) { /* signed distance to the solid cylinder (axis = local z) */
+  double q0 = sqrt(x[0]*x[0] + x[1]*x[1]) - R, q1 = fabs(x[2]) - h;
+  double o0 = q0 > 0 ? q0 : 0, o1 = q1 > 0 ? q1 : 0;
+  double outside = sqrt(o0*o0 + o1*o1);
+  return outside > 0 ? outside : (q0 > q1 ? q0 : q1);
+}
+/* sphere (centre c, radius r) against a box: shared by sphere-box, capsule-box and the box-box vertex contacts */
+static int point_box(double* dist, double* pos, double* nrm, const double* c, double r, const double* pb, const double* Rb,
+                     const double* sb, double margin) {
+  double t[3] = { c[0]-pb[0], c[1]-pb[1], c[2]-pb[2] }, x[3], cl[3];
+  mulmatTvec3(x, Rb, t);
+  int inside = 1;
+  for (int k = 0; k < 3; ++k) {
+    cl[k] = x[k];
+    if (cl[k] > sb[k]) { cl[k] = sb[k]; inside = 0; } else if (cl[k] < -sb[k]) { cl[k] = -sb[k]; inside = 0; }
+  }
+  double nl[3], dd;
+  if (!inside) {
+    double df[3] = { cl[0]-x[0], cl[1]-x[1], cl[2]-x[2] };
+    double dn = norm3(df);
+    dd = dn - r;
+    if (dd > margin) return 0;
+    nl[0]=df[0]/dn; nl[1]=df[1]/dn; nl[2]=df[2]/dn;
+  } else { /* centre inside the box: push out through the nearest face */
+    int kb = 0; double best = 1e300;
+    for (int k = 0; k < 3; ++k) { double e = sb[k]-fabs(x[k]); if (e < best) { best = e; kb = k; } }
+    nl[0]=nl[1]=nl[2]=0; nl[kb] = x[kb] > 0 ? -1.0 : 1.0;
+    dd = -best - r;
+    if (dd > margin) return 0;
+  }
+  mulmatvec3(nrm, Rb, nl);
+  *dist = dd;
+  for (int k = 0; k < 3; ++k) pos[k] = c[k] + nrm[k]*(r + 0.5*dd);
+  return 1;
+}
+static int point_cylinder(double* dist, double* pos, double* nrm, const double* c, double r, const double* pc, const double* Rc,
+                          double R, double h, double margin) {
+  double t[3] = { c[0]-pc[0], c[1]-pc[1], c[2]-pc[2] }, x[3], nl[3], dd;
+  mulmatTvec3(x, Rc, t);
+  double rho = sqrt(x[0]*x[0] + x[1]*x[1]), az = fabs(x[2]);
+  double ux = rho > MINVAL ? x[0]/rho : 1.0, uy = rho > MINVAL ? x[1]/rho : 0.0;
+  if (rho > R || az > h) {                 /* outside: closest point of the solid */
+    double qr = rho < R ? rho : R, qz = x[2] > h ? h : (x[2] < -h ? -h : x[2]);
+    double df[3] = { ux*qr - x[0], uy*qr - x[1], qz - x[2] };
+    double dn = norm3(df);
+    dd = dn - r;
+    if (dd > margin) return 0;
+    nl[0]=df[0]/dn; nl[1]=df[1]/dn; nl[2]=df[2]/dn;
+  } else {                                 /* centre inside: out through the nearer of side wall / cap */
+    double e_side = R - rho, e_cap = h - az;
+    if (e_cap < e_side) { nl[0]=0; nl[1]=0; nl[2] = x[2] > 0 ? -1.0 : 1.0; dd = -e_cap - r; }
+    else { nl[0] = -ux; nl[1] = -uy; nl[2] = 0; dd = -e_side - r; }
+    if (dd > margin) return 0;
+  }
+  mulmatvec3(nrm, Rc, nl);
+  *dist = dd;
+  for (int k = 0; k < 3; ++k) pos[k] = c[k] + nrm[k]*(r + 0.5*dd);
+  return 1;
+}
+static int point_ellipsoid(double* dist, double* pos, double* nrm, const double* c, double r, const double* pe, const double* Re,
+                           const double* s, double margin) {
+  double t[3] = { c[0]-pe[0], c[1]-pe[1], c[2]-pe[2] }, x[3], q[3], g[3];
+  mulmatTvec3(x, Re, t);
+  double lev = (x[0]/s[0])*(x[0]/s[0]) + (x[1]/s[1])*(x[1]/s[1]) + (x[2]/s[2])*(x[2]/s[2]);
+  double dn, sign;
+  if (lev > 1.0) {
+    /* closest surface point: q_k = s_k^2 x_k / (tt + s_k^2) with tt >= 0 the root of sum (s_k x_k / (tt + s_k^2))^2 = 1; bisection,
+     * 64 halvings of [0, |x| max(s)] (F is decreasing in tt; F(0) = lev - 1 > 0) */
+    double smax = s[0] > s[1] ? s[0] : s[1]; if (s[2] > smax) smax = s[2];
+    double lo = 0.0, hi = norm3(x)*smax;
+    for (int it = 0; it < 64; ++it) {
+      double mid = 0.5*(lo + hi), F = -1.0;
+      for (int k = 0; k < 3; ++k) { double v = s[k]*x[k]/(mid + s[k]*s[k]); F += v*v; }
+      if (F > 0) lo = mid; else hi = mid;
+    }
+    double tt = 0.5*(lo + hi);
+    for (int k = 0; k < 3; ++k) q[k] = s[k]*s[k]*x[k]/(tt + s[k]*s[k]);
+    double df[3] = { q[0]-x[0], q[1]-x[1], q[2]-x[2] };
+    dn = norm3(df); sign = 1.0;
+  } else {                                  /* centre inside the ellipsoid: radial projection onto the surface */
+    double sc = lev > MINVAL ? 1.0/sqrt(lev) : 0.0;
+    if (sc == 0.0) { q[0] = s[0]; q[1] = 0; q[2] = 0; } else for (int k = 0; k < 3; ++k) q[k] = x[k]*sc;
+    double df[3] = { q[0]-x[0], q[1]-x[1], q[2]-x[2] };
+    dn = norm3(df); sign = -1.0;
+  }
+  double dd = sign*dn - r;
+  if (dd > margin) return 0;
+  for (int k = 0; k < 3; ++k) g[k] = -q[k]/(s[k]*s[k]);       /* inward surface normal at q = direction sphere -> ellipsoid */
+  double gn = norm3(g), nl[3] = { g[0]/gn, g[1]/gn, g[2]/gn };
+  mulmatvec3(nrm, Re, nl);
+  *dist = dd;
+  for (int k = 0; k < 3; ++k) pos[k] = c[k] + nrm[k]*(r + 0.5*dd);
+  return 1;
+}
+/* argmin over t in [-h, h] of the (convex) signed distance from the point c + t a to a solid: 64 ternary-search steps */
+#define SEG_ARGMIN(tout, h, SD_EXPR) { double lo_ = -(h), hi_ = (h);                                   \
+    for (int it_ = 0; it_ < 64; ++it_) { double m1_ = lo_ + (hi_ - lo_)/3.0, m2_ = hi_ - (hi_ - lo_)/3.0, f1_, f2_; \
+      { double tt = m1_; f1_ = (SD_EXPR); } { double tt = m2_; f2_ = (SD_EXPR); }                       \
+      if (f1_ <= f2_) hi_ = m2_; else lo_ = m1_; }                                                       \
+    (tout) = 0.5*(lo_ + hi_); }
+
+static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, int sub, double margin,
                         double* dist, double* pos, double* nrm /* up to 2 results */) {
   FL(60);              /* geom poses (two 3x3 products, counted here) and the distance test of the pair */
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
@@ -789,6 +906,76 @@ static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, dou
     for (int k = 0; k < 3; ++k) pos[k] = p1[k] + nrm[k]*(s1[0] + 0.5*dd);
     return 1;
   }
+  if (t1 == MYO_GEOM_PLANE && t2 == MYO_GEOM_ELLIPSOID) {      /* deepest point of the ellipsoid along -n (support mapping) */
+    double n[3] = { R1[2], R1[5], R1[8] }, w[3], sw[3], q[3], ql[3];
+    mulmatTvec3(w, R2, n);
+    for (int k = 0; k < 3; ++k) sw[k] = s2[k]*w[k];
+    double L = norm3(sw);
+    for (int k = 0; k < 3; ++k) ql[k] = -s2[k]*sw[k]/L;
+    mulmatvec3(q, R2, ql);
+    for (int k = 0; k < 3; ++k) q[k] += p2[k];
+    double dd = (q[0]-p1[0])*n[0]+(q[1]-p1[1])*n[1]+(q[2]-p1[2])*n[2];
+    if (dd > margin) return 0;
+    dist[0] = dd; memcpy(nrm, n, sizeof n);
+    for (int k = 0; k < 3; ++k) pos[k] = q[k] - n[k]*0.5*dd;
+    return 1;
+  }
+  if (t1 == MYO_GEOM_PLANE && t2 == MYO_GEOM_CYLINDER) {       /* the lowest rim point of each cap (the cap centre when the cap is level) */
+    double n[3] = { R1[2], R1[5], R1[8] }, ax[3] = { R2[2], R2[5], R2[8] };
+    double na = dot3(n, ax), np_[3] = { n[0]-na*ax[0], n[1]-na*ax[1], n[2]-na*ax[2] };
+    double L = norm3(np_);
+    int cnt = 0;
+    for (int e = 0; e < 2; ++e) {
+      double sg = e ? -1.0 : 1.0, q[3];
+      for (int k = 0; k < 3; ++k) q[k] = p2[k] + sg*s2[1]*ax[k] - (L > 1e-12 ? s2[0]*np_[k]/L : 0.0);
+      double dd = (q[0]-p1[0])*n[0]+(q[1]-p1[1])*n[1]+(q[2]-p1[2])*n[2];
+      if (dd > margin) continue;
+      dist[cnt] = dd; memcpy(nrm+3*cnt, n, sizeof n);
+      for (int k = 0; k < 3; ++k) pos[3*cnt+k] = q[k] - n[k]*0.5*dd;
+      cnt++;
+    }
+    return cnt;
+  }
+  if (t1 == MYO_GEOM_SPHERE && t2 == MYO_GEOM_CYLINDER) return point_cylinder(dist, pos, nrm, p1, s1[0], p2, R2, s2[0], s2[1], margin);
+  if (t1 == MYO_GEOM_SPHERE && t2 == MYO_GEOM_ELLIPSOID) return point_ellipsoid(dist, pos, nrm, p1, s1[0], p2, R2, s2, margin);
+  if (t1 == MYO_GEOM_CAPSULE && (t2 == MYO_GEOM_CYLINDER || t2 == MYO_GEOM_BOX || t2 == MYO_GEOM_ELLIPSOID)) {
+    /* the point of the capsule's segment nearest to geom 2, then a sphere of the capsule's radius there */
+    double ax[3] = { R1[2], R1[5], R1[8] }, t[3] = { p1[0]-p2[0], p1[1]-p2[1], p1[2]-p2[2] }, c[3], a[3], ts;
+    mulmatTvec3(c, R2, t); mulmatTvec3(a, R2, ax);
+    if (t2 == MYO_GEOM_ELLIPSOID) {       /* nearest in the metric that makes the ellipsoid a unit sphere: closed form */
+      double num = 0, den = 0;
+      for (int k = 0; k < 3; ++k) { num += c[k]*a[k]/(s2[k]*s2[k]); den += a[k]*a[k]/(s2[k]*s2[k]); }
+      ts = den > MINVAL ? -num/den : 0.0;
+      if (ts > s1[1]) ts = s1[1]; else if (ts < -s1[1]) ts = -s1[1];
+    } else if (t2 == MYO_GEOM_BOX) {
+      SEG_ARGMIN(ts, s1[1], (({ double x_[3] = { c[0]+tt*a[0], c[1]+tt*a[1], c[2]+tt*a[2] }; sd_box(x_, s2); })))
+    } else {
+      SEG_ARGMIN(ts, s1[1], (({ double x_[3] = { c[0]+tt*a[0], c[1]+tt*a[1], c[2]+tt*a[2] }; sd_cylinder(x_, s2[0], s2[1]); })))
+    }
+    double q[3] = { p1[0]+ts*ax[0], p1[1]+ts*ax[1], p1[2]+ts*ax[2] };
+    if (t2 == MYO_GEOM_CYLINDER) return point_cylinder(dist, pos, nrm, q, s1[0], p2, R2, s2[0], s2[1], margin);
+    if (t2 == MYO_GEOM_ELLIPSOID) return point_ellipsoid(dist, pos, nrm, q, s1[0], p2, R2, s2, margin);
+    /* capsule-box: a capsule lying on a face rests on its two ends (both within the margin: two contacts, like plane-capsule);
+     * otherwise one contact at the nearest point of the segment */
+    double qa[3] = { p1[0]+s1[1]*ax[0], p1[1]+s1[1]*ax[1], p1[2]+s1[1]*ax[2] }, qb[3] = { p1[0]-s1[1]*ax[0], p1[1]-s1[1]*ax[1], p1[2]-s1[1]*ax[2] };
+    int cnt = point_box(dist, pos, nrm, qa, s1[0], p2, R2, s2, margin);
+    if (cnt) cnt += point_box(dist+1, pos+3, nrm+3, qb, s1[0], p2, R2, s2, margin);
+    if (cnt == 2) return 2;
+    return point_box(dist, pos, nrm, q, s1[0], p2, R2, s2, margin);
+  }
+  if (t1 == MYO_GEOM_BOX && t2 == MYO_GEOM_BOX && sub >= 1 && sub <= 16) {
+    /* vertex-face contacts: the model compiler lists a box-box geom pair as 16 candidates, sub = 1 + v: vertex v (sign bits) of
+     * box 1 against box 2, sub = 9 + v: vertex v of box 2 against box 1.  (Edge-edge crossings generate no contact here.) */
+    int v = (sub - 1) & 7, second = sub > 8;
+    const double *pv = second ? p2 : p1, *Rv = second ? R2 : R1, *sv = second ? s2 : s1;
+    const double *pb = second ? p1 : p2, *Rb = second ? R1 : R2, *sb = second ? s1 : s2;
+    double loc[3] = { (v & 1) ? sv[0] : -sv[0], (v & 2) ? sv[1] : -sv[1], (v & 4) ? sv[2] : -sv[2] }, q[3];
+    mulmatvec3(q, Rv, loc);
+    for (int k = 0; k < 3; ++k) q[k] += pv[k];
+    int cnt = point_box(dist, pos, nrm, q, 0.0, pb, Rb, sb, margin);
+    if (cnt && second) for (int k = 0; k < 3; ++k) nrm[k] = -nrm[k];      /* the normal runs from geom 1 to geom 2 */
+    return cnt;
+  }
   return 0;
 }
 
@@ -831,7 +1018,7 @@ static void collision(const OrcModel* m, OrcData* d) {
       if (dot3(df, df) > bound*bound) continue;
     }
     double dist[2], pos[6], nrm[6];
-    int n = collide_pair(m, d, g1, g2, margin, dist, pos, nrm);
+    int n = collide_pair(m, d, g1, g2, m->pair_sub ? m->pair_sub[p] : 0, margin, dist, pos, nrm);
     for (int k = 0; k < n && d->ncon < MAXCON; ++k) {
       OrcContact* c = &d->con[d->ncon++];
       c->dist = dist[k]; memcpy(c->pos, pos+3*k, 3*sizeof(double));

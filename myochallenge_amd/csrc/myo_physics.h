@@ -1471,18 +1471,32 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T, N
 // and where the contact sets can differ.  Written without run-time indexed local arrays (they would live in private memory):
 // results go to compile-time slots.  These run in their own leaf function (collision_pass_ext) over the model's trailing
 // "extended" pairs, so the register allocation of the Baoding hand's collision pass is untouched.
-DEV HP sd_box_hp(HP x0, HP x1, HP x2, const HP* sz) {
-  const HP q0 = fabs(x0) - sz[0], q1 = fabs(x1) - sz[1], q2 = fabs(x2) - sz[2];
-  const HP o0 = q0 > 0 ? q0 : (HP)0, o1 = q1 > 0 ? q1 : (HP)0, o2 = q2 > 0 ? q2 : (HP)0;
-  const HP outside = sqrt(o0 * o0 + o1 * o1 + o2 * o2);
-  HP m = q0 > q1 ? q0 : q1; if (q2 > m) m = q2;
-  return outside > 0 ? outside : m;
+// d/dt of the signed distance from the point c + t a to the solid, up to a positive factor (see the oracle's dsd_box / dsd_cylinder:
+// the nearest point of a capsule's segment is found by bisection on this sign, to the last bit)
+DEV HP dsd_box_hp(const HP* c, const HP* a, HP t, const HP* sz) {
+  const HP x0 = c[0] + t * a[0], x1 = c[1] + t * a[1], x2 = c[2] + t * a[2];
+  HP g = 0;
+  int inside = 1;
+  if (x0 > sz[0]) { g += (x0 - sz[0]) * a[0]; inside = 0; } else if (x0 < -sz[0]) { g += (x0 + sz[0]) * a[0]; inside = 0; }
+  if (x1 > sz[1]) { g += (x1 - sz[1]) * a[1]; inside = 0; } else if (x1 < -sz[1]) { g += (x1 + sz[1]) * a[1]; inside = 0; }
+  if (x2 > sz[2]) { g += (x2 - sz[2]) * a[2]; inside = 0; } else if (x2 < -sz[2]) { g += (x2 + sz[2]) * a[2]; inside = 0; }
+  if (!inside) return g;
+  const HP e0 = sz[0] - fabs(x0), e1 = sz[1] - fabs(x1), e2 = sz[2] - fabs(x2);
+  HP best = e0, xk = x0, ak = a[0];
+  if (e1 < best) { best = e1; xk = x1; ak = a[1]; }
+  if (e2 < best) { best = e2; xk = x2; ak = a[2]; }
+  return xk > 0 ? ak : -ak;
 }
-DEV HP sd_cyl_hp(HP x0, HP x1, HP x2, HP R, HP h) {
-  const HP q0 = sqrt(x0 * x0 + x1 * x1) - R, q1 = fabs(x2) - h;
-  const HP o0 = q0 > 0 ? q0 : (HP)0, o1 = q1 > 0 ? q1 : (HP)0;
-  const HP outside = sqrt(o0 * o0 + o1 * o1);
-  return outside > 0 ? outside : (q0 > q1 ? q0 : q1);
+DEV HP dsd_cyl_hp(const HP* c, const HP* a, HP t, HP R, HP h) {
+  const HP x0 = c[0] + t * a[0], x1 = c[1] + t * a[1], x2 = c[2] + t * a[2];
+  const HP rho = sqrt(x0 * x0 + x1 * x1), az = fabs(x2);
+  const HP ux = rho > (HP)1e-15 ? x0 / rho : (HP)1, uy = rho > (HP)1e-15 ? x1 / rho : (HP)0;
+  if (rho > R || az > h) {
+    const HP qr = rho < R ? rho : R, qz = x2 > h ? h : (x2 < -h ? -h : x2);
+    return (x0 - ux * qr) * a[0] + (x1 - uy * qr) * a[1] + (x2 - qz) * a[2];
+  }
+  if (h - az < R - rho) return x2 > 0 ? a[2] : -a[2];
+  return ux * a[0] + uy * a[1];
 }
 // the three point-vs-solid routines write contact slot SLOT of o and return 1 when the contact is within the margin
 template <int SLOT>
@@ -1493,7 +1507,7 @@ DEV int point_finish(ContactTmp& o, const HP* c, HP r, const HP* Rg, const HP* n
   for (int k = 0; k < 3; ++k) { o.nrm[3 * SLOT + k] = flip * nw[k]; o.pos[3 * SLOT + k] = c[k] + nw[k] * (r + (HP)0.5 * dd); }
   return 1;
 }
-template <int SLOT>
+template <int SLOT, int SMOOTH_INSIDE>
 DEV int point_box_hp(ContactTmp& o, const HP* c, HP r, const HP* pb, const HP* Rb, const HP* sb, HP margin, HP flip) {
   const HP t[3] = {c[0] - pb[0], c[1] - pb[1], c[2] - pb[2]};
   HP x[3], cl[3], nl[3], dd;
@@ -1515,6 +1529,11 @@ DEV int point_box_hp(ContactTmp& o, const HP* c, HP r, const HP* pb, const HP* R
     for (int k = 0; k < 3; ++k) { const HP e = sb[k] - fabs(x[k]); if (e < best) { best = e; kb = k; } }
     const HP xkb = kb == 0 ? x[0] : (kb == 1 ? x[1] : x[2]);
     for (int k = 0; k < 3; ++k) nl[k] = (k == kb) ? (xkb > 0 ? (HP)-1 : (HP)1) : (HP)0;
+    if (SMOOTH_INSIDE) {      // capsule axis inside the box: normal from the smooth field x_k / s_k^2 (see the oracle's point_box)
+      const HP g[3] = {-x[0] / (sb[0] * sb[0]), -x[1] / (sb[1] * sb[1]), -x[2] / (sb[2] * sb[2])};
+      const HP gn = norm3(g);
+      if (gn > (HP)1e-15) { nl[0] = g[0] / gn; nl[1] = g[1] / gn; nl[2] = g[2] / gn; }
+    }
     dd = -best - r;
     if (dd > margin) return 0;
   }
@@ -1622,7 +1641,7 @@ DEV void collide_pair_ext(const DevModel<T>& M, const TaskDev& K, const Scratch<
   } else if (t1 == 2 && t2 == 4) {
     o.n = point_ell_hp<0>(o, p1, s1[0], p2, R2, s2, margin);
   } else if (t1 == 3 && (t2 == 4 || t2 == 5 || t2 == 6)) {
-    // the point of the capsule's segment nearest to geom 2 (64 ternary-search steps on the convex signed distance; closed
+    // the point of the capsule's segment nearest to geom 2 (bisection on the slope of the convex signed distance; closed
     // form in the ellipsoid's own metric), then a sphere of the capsule's radius there
     const HP ax[3] = {R1[2], R1[5], R1[8]}, t[3] = {p1[0] - p2[0], p1[1] - p2[1], p1[2] - p2[2]};
     HP c[3], a[3], ts;
@@ -1634,13 +1653,18 @@ DEV void collide_pair_ext(const DevModel<T>& M, const TaskDev& K, const Scratch<
       ts = tclamp(ts, -s1[1], s1[1]);
     } else {
       HP lo = -s1[1], hi = s1[1];
-      for (int it = 0; it < 64; ++it) {
-        const HP m1 = lo + (hi - lo) / (HP)3, m2 = hi - (hi - lo) / (HP)3;
-        const HP f1 = t2 == 6 ? sd_box_hp(c[0] + m1 * a[0], c[1] + m1 * a[1], c[2] + m1 * a[2], s2) : sd_cyl_hp(c[0] + m1 * a[0], c[1] + m1 * a[1], c[2] + m1 * a[2], s2[0], s2[1]);
-        const HP f2 = t2 == 6 ? sd_box_hp(c[0] + m2 * a[0], c[1] + m2 * a[1], c[2] + m2 * a[2], s2) : sd_cyl_hp(c[0] + m2 * a[0], c[1] + m2 * a[1], c[2] + m2 * a[2], s2[0], s2[1]);
-        if (f1 <= f2) hi = m2; else lo = m1;
+      const HP glo = t2 == 6 ? dsd_box_hp(c, a, lo, s2) : dsd_cyl_hp(c, a, lo, s2[0], s2[1]);
+      const HP ghi = t2 == 6 ? dsd_box_hp(c, a, hi, s2) : dsd_cyl_hp(c, a, hi, s2[0], s2[1]);
+      if (glo >= 0) ts = lo;
+      else if (ghi <= 0) ts = hi;
+      else {
+        for (int it = 0; it < 60; ++it) {
+          const HP tt = (HP)0.5 * (lo + hi);
+          const HP g = t2 == 6 ? dsd_box_hp(c, a, tt, s2) : dsd_cyl_hp(c, a, tt, s2[0], s2[1]);
+          if (g > 0) hi = tt; else lo = tt;
+        }
+        ts = (HP)0.5 * (lo + hi);
       }
-      ts = (HP)0.5 * (lo + hi);
     }
     const HP q[3] = {p1[0] + ts * ax[0], p1[1] + ts * ax[1], p1[2] + ts * ax[2]};
     if (t2 == 6) {
@@ -1648,9 +1672,9 @@ DEV void collide_pair_ext(const DevModel<T>& M, const TaskDev& K, const Scratch<
       // contact at the nearest point of the segment
       const HP qa[3] = {p1[0] + s1[1] * ax[0], p1[1] + s1[1] * ax[1], p1[2] + s1[1] * ax[2]};
       const HP qb[3] = {p1[0] - s1[1] * ax[0], p1[1] - s1[1] * ax[1], p1[2] - s1[1] * ax[2]};
-      int both = point_box_hp<0>(o, qa, s1[0], p2, R2, s2, margin, (HP)1);
-      if (both) both += point_box_hp<1>(o, qb, s1[0], p2, R2, s2, margin, (HP)1);
-      o.n = both == 2 ? 2 : point_box_hp<0>(o, q, s1[0], p2, R2, s2, margin, (HP)1);
+      int both = point_box_hp<0, 1>(o, qa, s1[0], p2, R2, s2, margin, (HP)1);
+      if (both) both += point_box_hp<1, 1>(o, qb, s1[0], p2, R2, s2, margin, (HP)1);
+      o.n = both == 2 ? 2 : point_box_hp<0, 1>(o, q, s1[0], p2, R2, s2, margin, (HP)1);
     } else if (t2 == 5) o.n = point_cyl_hp<0>(o, q, s1[0], p2, R2, s2[0], s2[1], margin);
     else o.n = point_ell_hp<0>(o, q, s1[0], p2, R2, s2, margin);
   } else if (t1 == 6 && t2 == 6 && sub >= 1) {   // box - box: one vertex-face candidate (see the pair table)
@@ -1660,12 +1684,12 @@ DEV void collide_pair_ext(const DevModel<T>& M, const TaskDev& K, const Scratch<
       loc[0] = (v & 1) ? s1[0] : -s1[0]; loc[1] = (v & 2) ? s1[1] : -s1[1]; loc[2] = (v & 4) ? s1[2] : -s1[2];
       mulmatvec3(q, R1, loc);
       for (int k = 0; k < 3; ++k) q[k] += p1[k];
-      o.n = point_box_hp<0>(o, q, (HP)0, p2, R2, s2, margin, (HP)1);
+      o.n = point_box_hp<0, 0>(o, q, (HP)0, p2, R2, s2, margin, (HP)1);
     } else {
       loc[0] = (v & 1) ? s2[0] : -s2[0]; loc[1] = (v & 2) ? s2[1] : -s2[1]; loc[2] = (v & 4) ? s2[2] : -s2[2];
       mulmatvec3(q, R2, loc);
       for (int k = 0; k < 3; ++k) q[k] += p2[k];
-      o.n = point_box_hp<0>(o, q, (HP)0, p1, R1, s1, margin, (HP)-1);    // the normal runs from geom 1 to geom 2
+      o.n = point_box_hp<0, 0>(o, q, (HP)0, p1, R1, s1, margin, (HP)-1);    // the normal runs from geom 1 to geom 2
     }
   }
 }

@@ -48,7 +48,7 @@ class BaodingVecEnv:
 
     def __init__(self, env_name: str, num_envs: int, config: Optional[dict] = None, *, device: int = 0,
                  seed: int = 0, dtype: str = "mixed", model=None, integrator: Optional[str] = None,
-                 lib: Optional[native.NativeLib] = None):
+                 lib: Optional[native.NativeLib] = None, unsupported_contacts: str = "error"):
         import torch
         config = dict(config or {})
         self.env_name = env_name
@@ -58,7 +58,11 @@ class BaodingVecEnv:
             model = self._default_model()
         if not isinstance(model, CompiledModel):
             integ = None if integrator is None else {"euler": 0, "rk4": 1}[integrator.lower()]
-            model = self._compile(model, integ)
+            model = self._compile(model, integ, unsupported_contacts)
+            if model.dropped_pairs:            # an explicit opt-in ("drop"): say what the physics now lacks
+                import warnings
+                warnings.warn(f"{env_name}: {len(model.dropped_pairs)} colliding geom pair(s) have no narrow phase and were dropped: "
+                              f"{model.dropped_pairs[:8]}{' ...' if len(model.dropped_pairs) > 8 else ''}")
         self.compiled = model
         self.lib = lib or native.load()
         self.torch = torch
@@ -104,8 +108,8 @@ class BaodingVecEnv:
         return synthetic_hand()
 
     @staticmethod
-    def _compile(model, integ):
-        return compile_model(model, integrator=integ)
+    def _compile(model, integ, unsupported_contacts="error"):
+        return compile_model(model, integrator=integ, unsupported_contacts=unsupported_contacts)
 
     @staticmethod
     def _make_cfg(env_name, compiled, config):

@@ -187,11 +187,8 @@ class ReorientVecEnv(BaodingVecEnv):
         from ..synth_hand import synthetic_hand_die
         return synthetic_hand_die()
 
-    @staticmethod
-    def _compile(model, integ):
-        # the die is a rounded cube of 8 corner spheres + 12 edge capsules; its capsule-vs-palm-BOX pairs have no
-        # narrow phase here and are dropped ON PURPOSE (the corner spheres carry the contact with the box)
-        return compile_model(model, integrator=integ, unsupported_contacts="drop")
+    # (_compile is BaodingVecEnv's: unsupported_contacts="error" by default — the synthetic die, 12 edge capsules + 3 box slabs as
+    # reorient.py:143-145 indexes the real one, compiles without dropping a pair since the capsule-box and box-box narrow phases exist)
 
     @staticmethod
     def _make_cfg(env_name, compiled, config):

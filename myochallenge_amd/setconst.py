@@ -245,6 +245,11 @@ def set_const(m, *, lengthrange_samples=0, seed=0):
     for b, (jp, jr) in jacs.items():
         biw[b] = [np.trace(jp @ Minv @ jp.T) / 3, np.trace(jr @ Minv @ jr.T) / 3]
     a["body_invweight0"] = biw
+    if m.ntendon == 0:                     # models without tendons / actuators (the contact test models)
+        a["tendon_length0"] = a["tendon_invweight0"] = np.zeros(0)
+        a["actuator_acc0"] = a["actuator_length0"] = np.zeros(m.nu)
+        m.stat["meaninertia"] = float(np.mean(np.diag(M)))
+        return m
     L0 = tendon_lengths(m, q0)
     a["tendon_length0"] = L0
     J = tendon_jacobian(m, q0)

@@ -268,9 +268,8 @@ def _palm_frame(t1, t2, b1, b2):
 
 def build_synthetic_hand(golden_obs=None, lengthrange_samples=384, objects="balls") -> MjbModel:
     """objects = "balls": the Baoding model (two free spheres).  objects = "die": the same hand with ONE free
-    die for the reorient task (src/envs/reorient.py): body ``Object`` = 8 corner spheres + 12 edge capsules
-    (a rounded cube; the stepper has sphere-box, sphere-capsule and capsule-capsule contacts but no
-    box-capsule), site ``object_o``; static body ``target`` with site ``target_o``, ``target_ball`` and the
+    die for the reorient task (src/envs/reorient.py): body ``Object`` = 12 edge capsules + 3 box slabs (a rounded
+    cube whose last three geoms are boxes, as reorient.py:143-145 indexes them), site ``object_o``; static body ``target`` with site ``target_o``, ``target_ball`` and the
     non-colliding geom ``target_dice`` (reorient.py:76-101)."""
     t1, t2 = TARGET1.copy(), TARGET2.copy()
     if golden_obs is not None:
@@ -402,12 +401,11 @@ def build_synthetic_hand(golden_obs=None, lengthrange_samples=384, objects="ball
                     q = {0: qx, 1: qy, 2: (1, 0, 0, 0)}[axis]
                     B.add_geom(f"die_edge{k}", die, 3, (DIE_R, a), tuple(c), q, collide=2)
                     k += 1
-        k = 0
-        for sx in (-1, 1):
-            for sy in (-1, 1):
-                for sz in (-1, 1):
-                    B.add_geom(f"die_corner{k}", die, 2, (DIE_R,), (sx * a, sy * a, sz * a), collide=2)
-                    k += 1
+        # three slabs LAST (reorient.py:144-145 resizes "the last three" die geoms by all three sizes): with the edge capsules they
+        # make the rounded cube, slab k reaching the full half-size along axis k and the inset a = DIE_H - DIE_R across it
+        for axis in range(3):
+            sz = [a, a, a]; sz[axis] = DIE_H
+            B.add_geom(f"die_slab{axis}", die, 6, tuple(sz), (0, 0, 0), collide=2)
         B.add_site("object_o", die, (0, 0, 0))
         tgt = B.add_body("target", 0, die0 + np.array([0.0, 0.0, 0.08]), mat_to_quat(R @ Rb), mass=0.0)
         B.add_geom("target_dice", tgt, 6, (DIE_H, DIE_H, DIE_H), collide=0)

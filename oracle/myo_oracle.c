@@ -717,22 +717,40 @@ static void seg_nearest(double* out, const double* c, const double* axis, double
  * restated here: what follows is the exact geometry (closest points) with this stepper's own choice of contact points where
  * MuJoCo returns several.  Differences from MuJoCo are therefore possible in the number and placement of contacts of a
  * face-on-face configuration; a single-point configuration agrees with MPR to its tolerance. */
-static double sd_box(const double* x, const double* s) {         /* signed distance of a point (box frame) to the solid box */
-  double q0 = fabs(x[0]) - s[0], q1 = fabs(x[1]) - s[1], q2 = fabs(x[2]) - s[2];
-  double o0 = q0 > 0 ? q0 : 0, o1 = q1 > 0 ? q1 : 0, o2 = q2 > 0 ? q2 : 0;
-  double outside = sqrt(o0*o0 + o1*o1 + o2*o2);
-  double m = q0 > q1 ? q0 : q1; if (q2 > m) m = q2;
-  return outside > 0 ? outside : m;
+/* d/dt of the signed distance from the point x = c + t a to a solid, up to a positive factor: the minimiser over the segment is
+ * where it changes sign (the signed distance to a convex solid is convex along a line), found by bisection to the last bit — a
+ * search on the VALUES of the distance only resolves t to sqrt(eps), which showed up as a 6e-9 oracle / device difference */
+static double dsd_box(const double* c, const double* a, double t, const double* s) {
+  double x[3] = { c[0]+t*a[0], c[1]+t*a[1], c[2]+t*a[2] }, g = 0.0;
+  int inside = 1;
+  for (int k = 0; k < 3; ++k) {
+    if (x[k] > s[k]) { g += (x[k]-s[k])*a[k]; inside = 0; } else if (x[k] < -s[k]) { g += (x[k]+s[k])*a[k]; inside = 0; }
+  }
+  if (!inside) return g;
+  int kb = 0; double best = 1e300;
+  for (int k = 0; k < 3; ++k) { double e = s[k]-fabs(x[k]); if (e < best) { best = e; kb = k; } }
+  return x[kb] > 0 ? a[kb] : -a[kb];
 }
-static double sd_cylinder(const double* x, double R, double h) { /* signed distance to the solid cylinder (axis = local z) */
-  double q0 = sqrt(x[0]*x[0] + x[1]*x[1]) - R, q1 = fabs(x[2]) - h;
-  double o0 = q0 > 0 ? q0 : 0, o1 = q1 > 0 ? q1 : 0;
-  double outside = sqrt(o0*o0 + o1*o1);
-  return outside > 0 ? outside : (q0 > q1 ? q0 : q1);
+static double dsd_cylinder(const double* c, const double* a, double t, double R, double h) {
+  double x[3] = { c[0]+t*a[0], c[1]+t*a[1], c[2]+t*a[2] };
+  double rho = sqrt(x[0]*x[0] + x[1]*x[1]), az = fabs(x[2]);
+  double ux = rho > MINVAL ? x[0]/rho : 1.0, uy = rho > MINVAL ? x[1]/rho : 0.0;
+  if (rho > R || az > h) {
+    double qr = rho < R ? rho : R, qz = x[2] > h ? h : (x[2] < -h ? -h : x[2]);
+    return (x[0]-ux*qr)*a[0] + (x[1]-uy*qr)*a[1] + (x[2]-qz)*a[2];
+  }
+  if (h - az < R - rho) return x[2] > 0 ? a[2] : -a[2];
+  return ux*a[0] + uy*a[1];
 }
+#define SEG_ARGMIN(tout, h, DSD_EXPR) { double lo_ = -(h), hi_ = (h), glo_, ghi_;                     \
+    { double tt = lo_; glo_ = (DSD_EXPR); } { double tt = hi_; ghi_ = (DSD_EXPR); }                     \
+    if (glo_ >= 0) (tout) = lo_; else if (ghi_ <= 0) (tout) = hi_; else {                               \
+      for (int it_ = 0; it_ < 60; ++it_) { double tt = 0.5*(lo_ + hi_), g_ = (DSD_EXPR); if (g_ > 0) hi_ = tt; else lo_ = tt; } \
+      (tout) = 0.5*(lo_ + hi_); } }
+
 /* sphere (centre c, radius r) against a box: shared by sphere-box, capsule-box and the box-box vertex contacts */
 static int point_box(double* dist, double* pos, double* nrm, const double* c, double r, const double* pb, const double* Rb,
-                     const double* sb, double margin) {
+                     const double* sb, double margin, int smooth_inside) {
   double t[3] = { c[0]-pb[0], c[1]-pb[1], c[2]-pb[2] }, x[3], cl[3];
   mulmatTvec3(x, Rb, t);
   int inside = 1;
@@ -751,6 +769,13 @@ static int point_box(double* dist, double* pos, double* nrm, const double* c, do
     int kb = 0; double best = 1e300;
     for (int k = 0; k < 3; ++k) { double e = sb[k]-fabs(x[k]); if (e < best) { best = e; kb = k; } }
     nl[0]=nl[1]=nl[2]=0; nl[kb] = x[kb] > 0 ? -1.0 : 1.0;
+    if (smooth_inside) {
+      /* a capsule whose AXIS runs inside the box: the nearest point of the segment then sits where two faces are equally near (a
+       * ridge of the distance field), where "the nearest face" flips with the last bit — the normal is taken from the smooth
+       * field x_k / s_k^2 instead (equal to the face normal over the middle of a face); depth = distance to the nearest face */
+      double g[3] = { -x[0]/(sb[0]*sb[0]), -x[1]/(sb[1]*sb[1]), -x[2]/(sb[2]*sb[2]) }, gn = norm3(g);
+      if (gn > MINVAL) { nl[0] = g[0]/gn; nl[1] = g[1]/gn; nl[2] = g[2]/gn; }
+    }
     dd = -best - r;
     if (dd > margin) return 0;
   }
@@ -818,13 +843,6 @@ static int point_ellipsoid(double* dist, double* pos, double* nrm, const double*
   for (int k = 0; k < 3; ++k) pos[k] = c[k] + nrm[k]*(r + 0.5*dd);
   return 1;
 }
-/* argmin over t in [-h, h] of the (convex) signed distance from the point c + t a to a solid: 64 ternary-search steps */
-#define SEG_ARGMIN(tout, h, SD_EXPR) { double lo_ = -(h), hi_ = (h);                                   \
-    for (int it_ = 0; it_ < 64; ++it_) { double m1_ = lo_ + (hi_ - lo_)/3.0, m2_ = hi_ - (hi_ - lo_)/3.0, f1_, f2_; \
-      { double tt = m1_; f1_ = (SD_EXPR); } { double tt = m2_; f2_ = (SD_EXPR); }                       \
-      if (f1_ <= f2_) hi_ = m2_; else lo_ = m1_; }                                                       \
-    (tout) = 0.5*(lo_ + hi_); }
-
 static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, int sub, double margin,
                         double* dist, double* pos, double* nrm /* up to 2 results */) {
   FL(60);              /* geom poses (two 3x3 products, counted here) and the distance test of the pair */
@@ -948,9 +966,9 @@ static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, int
       ts = den > MINVAL ? -num/den : 0.0;
       if (ts > s1[1]) ts = s1[1]; else if (ts < -s1[1]) ts = -s1[1];
     } else if (t2 == MYO_GEOM_BOX) {
-      SEG_ARGMIN(ts, s1[1], (({ double x_[3] = { c[0]+tt*a[0], c[1]+tt*a[1], c[2]+tt*a[2] }; sd_box(x_, s2); })))
+      SEG_ARGMIN(ts, s1[1], dsd_box(c, a, tt, s2))
     } else {
-      SEG_ARGMIN(ts, s1[1], (({ double x_[3] = { c[0]+tt*a[0], c[1]+tt*a[1], c[2]+tt*a[2] }; sd_cylinder(x_, s2[0], s2[1]); })))
+      SEG_ARGMIN(ts, s1[1], dsd_cylinder(c, a, tt, s2[0], s2[1]))
     }
     double q[3] = { p1[0]+ts*ax[0], p1[1]+ts*ax[1], p1[2]+ts*ax[2] };
     if (t2 == MYO_GEOM_CYLINDER) return point_cylinder(dist, pos, nrm, q, s1[0], p2, R2, s2[0], s2[1], margin);
@@ -958,10 +976,10 @@ static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, int
     /* capsule-box: a capsule lying on a face rests on its two ends (both within the margin: two contacts, like plane-capsule);
      * otherwise one contact at the nearest point of the segment */
     double qa[3] = { p1[0]+s1[1]*ax[0], p1[1]+s1[1]*ax[1], p1[2]+s1[1]*ax[2] }, qb[3] = { p1[0]-s1[1]*ax[0], p1[1]-s1[1]*ax[1], p1[2]-s1[1]*ax[2] };
-    int cnt = point_box(dist, pos, nrm, qa, s1[0], p2, R2, s2, margin);
-    if (cnt) cnt += point_box(dist+1, pos+3, nrm+3, qb, s1[0], p2, R2, s2, margin);
+    int cnt = point_box(dist, pos, nrm, qa, s1[0], p2, R2, s2, margin, 1);
+    if (cnt) cnt += point_box(dist+1, pos+3, nrm+3, qb, s1[0], p2, R2, s2, margin, 1);
     if (cnt == 2) return 2;
-    return point_box(dist, pos, nrm, q, s1[0], p2, R2, s2, margin);
+    return point_box(dist, pos, nrm, q, s1[0], p2, R2, s2, margin, 1);
   }
   if (t1 == MYO_GEOM_BOX && t2 == MYO_GEOM_BOX && sub >= 1 && sub <= 16) {
     /* vertex-face contacts: the model compiler lists a box-box geom pair as 16 candidates, sub = 1 + v: vertex v (sign bits) of
@@ -972,7 +990,7 @@ static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, int
     double loc[3] = { (v & 1) ? sv[0] : -sv[0], (v & 2) ? sv[1] : -sv[1], (v & 4) ? sv[2] : -sv[2] }, q[3];
     mulmatvec3(q, Rv, loc);
     for (int k = 0; k < 3; ++k) q[k] += pv[k];
-    int cnt = point_box(dist, pos, nrm, q, 0.0, pb, Rb, sb, margin);
+    int cnt = point_box(dist, pos, nrm, q, 0.0, pb, Rb, sb, margin, 0);
     if (cnt && second) for (int k = 0; k < 3; ++k) nrm[k] = -nrm[k];      /* the normal runs from geom 1 to geom 2 */
     return cnt;
   }

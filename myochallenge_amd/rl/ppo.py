@@ -39,6 +39,12 @@ class PPOConfig:
     bf16: bool = True               # autocast the policy GEMMs to bf16 (fp32 master weights)
     sync_adv_moments: bool = False  # all-reduce advantage moments (exact single-process semantics)
     use_graphs: bool = True         # capture one optimizer step in a hipGraph (MLP policy, GPU only)
+    # N > 1 ranks: capture the RCCL all-reduce of the flat gradient INSIDE the optimizer hipGraph (forward/backward -> all-reduce ->
+    # clip + Adam as ONE replay per minibatch instead of graph / eager collective / graph).  Opt-in (also MYO_GRAPH_ALLREDUCE=1):
+    # it saves one launch gap (~10 us of a ~150 us optimizer step) and could only be exercised on a node with >= 2 GPUs, which
+    # the build machine does not have — a capture failure there must not cost the scaling run.  Falls back to the eager
+    # collective when the capture raises.
+    graph_allreduce: bool = False
 
 
 def compute_gae(rewards, values, episode_starts, last_values, last_dones, gamma, lam):
@@ -500,14 +506,32 @@ class PPO:
         torch.cuda.current_stream(d).wait_stream(side)
         torch.cuda.synchronize(d)
         self._graph_fb, self._graph_ap = torch.cuda.CUDAGraph(), None
-        with torch.cuda.graph(self._graph_fb, capture_error_mode="thread_local"):
-            self._mb_forward_backward()
-            if self.world == 1:             # single GPU: forward, backward and optimiser in ONE graph
-                self._mb_apply()
-        if self.world > 1:                  # the RCCL all-reduce runs between the two graphs
-            self._graph_ap = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph_ap, capture_error_mode="thread_local"):
-                self._mb_apply()
+        import os
+        want_inside = self.world > 1 and (self.cfg.graph_allreduce or os.environ.get("MYO_GRAPH_ALLREDUCE") == "1") \
+            and dist.get_backend() == "nccl"
+        self._allreduce_in_graph = False
+        if want_inside:
+            try:                            # forward / backward -> RCCL all-reduce -> clip + Adam, one replay per minibatch
+                g_all = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_all, capture_error_mode="thread_local"):
+                    self._mb_forward_backward()
+                    dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+                    self._mb_apply()
+                self._graph_fb, self._allreduce_in_graph = g_all, True
+            except Exception as exc:        # noqa: BLE001 — any capture problem: keep the eager collective between two graphs
+                import warnings
+                warnings.warn(f"capturing the gradient all-reduce in the optimizer hipGraph failed ({exc!r}); using the eager collective")
+                torch.cuda.synchronize(d)
+                self._graph_fb = torch.cuda.CUDAGraph()
+        if not self._allreduce_in_graph:
+            with torch.cuda.graph(self._graph_fb, capture_error_mode="thread_local"):
+                self._mb_forward_backward()
+                if self.world == 1:             # single GPU: forward, backward and optimiser in ONE graph
+                    self._mb_apply()
+            if self.world > 1:                  # the RCCL all-reduce runs between the two graphs
+                self._graph_ap = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._graph_ap, capture_error_mode="thread_local"):
+                    self._mb_apply()
         self._flat_adam.restore(snap)
         self._graph = (B, bs)
 
@@ -539,7 +563,7 @@ class PPO:
                     std = torch.sqrt(torch.clamp(m[1] / m[2] - mean * mean, min=0.0) * m[2] / (m[2] - 1))
                     self._fused.stats.copy_(torch.stack([mean, std]).float())
                 self._graph_fb.replay()
-                if self.world > 1:
+                if self.world > 1 and not self._allreduce_in_graph:
                     dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
                     self._graph_ap.replay()
                 self.n_updates += 1

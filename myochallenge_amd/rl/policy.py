@@ -401,6 +401,19 @@ class ActorCriticPolicy(nn.Module):
             lat = lp.float()
             if self.exploration_mat is None or self.exploration_mat.shape[0] != lat.shape[0]:
                 self.reset_noise(lat.shape[0])
+            lib = _native_lib(lat)
+            if lib is not None and lat.dtype == torch.float32 and self.SDE_EPS == 1e-6:
+                # GPU rollout: noise, sigma and log pi of all envs in ONE launch (myo_rollout_sample_sde) instead of
+                # bmm + the matmul of _sde_std + the elementwise log_prob chain
+                import ctypes as C
+                mu, lat = mean.float().contiguous(), lat.contiguous()
+                W, ls = self.exploration_mat.contiguous(), self.log_std.detach().float().contiguous()
+                actions, clipped, logp = torch.empty_like(mu), torch.empty_like(mu), mu.new_empty(mu.shape[0])
+                p = lambda t: C.c_void_p(t.data_ptr())
+                lib.check(lib.L.myo_rollout_sample_sde(p(mu), p(lat), p(W), p(ls), mu.shape[0], lat.shape[1], mu.shape[1],
+                                                       p(actions), p(clipped), p(logp), int(bool(deterministic)),
+                                                       C.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream)))
+                return actions, values, logp, state
             noise = torch.bmm(lat.unsqueeze(1), self.exploration_mat).squeeze(1)       # latent_pi(s_n) . W_n
             actions = mean if deterministic else mean + noise
             return actions, values, self.log_prob(actions, mean, torch.log(self._sde_std(lat))), state

@@ -834,6 +834,17 @@ def test_gsde_ppo_round_on_gpu(hip_lib):
         algo.train()
     after = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
     assert torch.isfinite(after).all() and not torch.equal(before, after) and float(algo.act_buf.abs().max()) > 0
+    # policy.act samples through myo_rollout_sample_sde on the GPU: its log pi must be the one evaluate_actions (torch)
+    # assigns to the same actions, and the noise must be the env's own exploration matrix applied to latent_pi
+    obs = torch.randn(64, 86, device=pol.log_std.device)
+    a, _, lp, _ = pol.act(obs)
+    with torch.no_grad():
+        _, lp2, _ = pol.evaluate_actions(obs, a)
+        lat, _, _ = pol._latents(obs, None, None)
+        noise = torch.bmm(lat.float().unsqueeze(1), pol.exploration_mat).squeeze(1)
+        mean, _ = pol._dist(lat)
+    assert float((lp - lp2).abs().max()) <= 2e-3 * float(lp2.abs().max())
+    assert float((a - mean.float() - noise).abs().max()) <= 1e-4
 
 
 def test_training_entry_points_run_end_to_end(hip_lib, tmp_path):

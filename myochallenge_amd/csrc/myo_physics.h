@@ -79,9 +79,13 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   unsigned long long seed;
 };
 
+#define MYO_LIM_UPPER ((int)0x80000000)
+DEV int lim_index(int id) { return id & 0x7fffffff; }
+template <typename T> DEV T lim_sign(int id) { return id < 0 ? (T)-1 : (T)1; }
+
 template <typename T>
 struct ContactRec {
-  T pos[3], frame[9], mu[2], D, B, kip, F[3];
+  T frame[9], mu, D, B, kip, F[3];      // mu: condim 3, both tangential directions use friction[0]
   T r1[3], r2[3];                 // contact point relative to the reference point of body1's / body2's tree
   unsigned long long m1, m2;      // ancestor-dof masks of the two bodies
   int b1, b2, nsup;
@@ -129,16 +133,16 @@ struct Scratch {
   T act_force[MYO_NU_MAX], act_dot[MYO_NU_MAX];
   T qM[MYO_NM_MAX];
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
-  T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
-  T Ma[MYO_NV_MAX], grad[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX], tmpv[MYO_NV_MAX];
   // ---- constraints
   int ncon, nefc, nl, ntl, bad, solver_iter;
+  // (from con[] to Mv, i.e. up to rk: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live)
   alignas(8) ContactRec<T> con[NC];
-  int lim_id[MYO_NLIM_MAX];
-  T lim_sgn[MYO_NLIM_MAX];
-  T efc_D[MYO_NLIM_MAX], efc_B[MYO_NLIM_MAX], efc_kip[MYO_NLIM_MAX];   // limit rows only; contact rows: con[]
-  alignas(8) T efc_aref[MYO_NLIM_MAX + 4 * NC], efc_jar[MYO_NLIM_MAX + 4 * NC], efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC];
+  int lim_id[MYO_NLIM_MAX];                                            // dof (joint rows) / tendon (tendon rows); bit 31: the upper limit (row sign -1)
+  T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
+  alignas(8) T efc_jar[MYO_NLIM_MAX + 4 * NC], efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC];
   unsigned char efc_active[MYO_NLIM_MAX + 4 * NC];
+  alignas(8) T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
+  T Ma[MYO_NV_MAX], grad[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX];
   RkScratch<T>* rk;               // null unless the model integrates with RK4
   // ---- task layer
   T rwd[8];
@@ -158,9 +162,11 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 //   H is only live from qacc_smooth to the end of the solver / Euler solve.  Before that
 //   it hosts: cinert (com_pos..RNE), crb (CRB only) then cdof_dot (velocity stage), the passive /
 //   bias / actuator force vectors (velocity..actuation), and after the physics the observation.
-//   xanchor / xaxis (until cdof is built) -> efc_aref / efc_jv; the kinematics stage keeps its HP joint
+//   xanchor / xaxis (until cdof is built) -> efc_jar / efc_jv; the kinematics stage keeps its HP joint
 //   anchors / axes (parent frame) in con[], which is dead until the collision stage
-//   xipos (until cinert is built) and the compaction prefix npre -> efc_force;  cfrcb (RNE) -> bvec
+//   xipos (until cinert is built) -> efc_force;  the compaction prefix npre -> search, Mv;  cfrcb (RNE) -> bvec
+//   limit rows' B and K imp (pos - margin) (constraint_limits .. efc_reference) -> efc_force;  the reference acceleration aref
+//   (efc_reference .. the solver's warm-start choice, where efc_jar = J qacc - aref replaces it) -> efc_jar
 #define S_CINERT(s) ((s).H)
 #define S_CRB(s) ((s).H + MYO_NB_MAX * 10)
 #define S_CDOFDOT(s) ((s).H + MYO_NB_MAX * 10)
@@ -171,17 +177,21 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage: position of every path element (con[] is dead until the collision stage) */
 /* tendon stage: HP wrap results (7 per geom wrap) behind the T path points, running on through the limit-row and efc_* arrays */
 #define S_TWRES(s, nwrap) (reinterpret_cast<HP*>(reinterpret_cast<char*>((s).con) + ((3 * (size_t)(nwrap) * sizeof(T) + 7) & ~(size_t)7)))
-#define S_ACT_GF(s) ((s).efc_force)   /* gear * actuator force (actuation stage; efc_force is first written by the solver) */
+#define S_ACT_GF(s) ((s).Ma)   /* gear * actuator force (actuation stage, NU_MAX entries through Ma, grad: the body velocities that live there are dead after efc_reference) */
 #define S_KTMP(s) (reinterpret_cast<HP*>((s).con))   /* HP [2][MYO_NJ_MAX * 3] */
-#define S_XANCHOR(s) ((s).efc_aref)
+#define S_XANCHOR(s) ((s).efc_jar)
 #define S_XAXIS(s) ((s).efc_jv)
 #define S_XIPOS(s) ((s).efc_force)
-#define S_NPRE(s) (reinterpret_cast<int*>((s).efc_force))
+#define S_NPRE(s) (reinterpret_cast<int*>((s).search))   /* 64 ints through search, Mv */
 #define S_CFRCB(s) ((s).bvec)
 // RK4's combined stage derivative (2 nv + nu numbers): in efc_jv, dead between two forward() calls (J v of the last line search)
 #define S_RKDX(s) ((s).efc_jv)
+#define S_LIM_B(s) ((s).efc_force)
+#define S_LIM_KIP(s) ((s).efc_force + MYO_NLIM_MAX)
+#define S_AREF(s) ((s).efc_jar)
 #define S_CVEL(s) ((s).Ma)   /* body velocities (velocity stage) live in the solver vectors Ma,grad,search,Mv */
-static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_H_SIZE && MYO_NU_MAX <= MYO_NEFC_MAX, "H aliases");
+static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_H_SIZE && MYO_NU_MAX <= 2 * MYO_NV_MAX, "H aliases; S_ACT_GF");
+static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MAX && 64 * sizeof(int) <= 2 * MYO_NV_MAX * sizeof(float), "S_LIM_B / S_LIM_KIP in efc_force; S_NPRE in search, Mv");
 static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 1024 && MYO_NU_MAX <= 64, "packed actuator gather entries are 10 + 6 bits");
 static_assert(MYO_NV_MAX * 6 <= MYO_NB_MAX * 10, "cdof_dot fits where crb was");
 static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in Ma..Mv");
@@ -1761,8 +1771,8 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
           T Kc, Bc, Ic;
           sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dm, &Kc, &Bc, &Ic);
           const T R = tmax(MYO_MINVAL, (1 - Ic) * M.dof_invweight0[M.jnt_dofadr[j]] / Ic);
-          s.lim_id[r] = M.jnt_dofadr[j]; s.lim_sgn[r] = side ? (T)-1 : (T)1;   // joint rows keep the DOF index
-          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * dm;
+          s.lim_id[r] = M.jnt_dofadr[j] | (side ? MYO_LIM_UPPER : 0);   // joint rows keep the DOF index
+          s.efc_D[r] = 1 / R; S_LIM_B(s)[r] = Bc; S_LIM_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -1796,8 +1806,8 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
           T Kc, Bc, Ic;
           sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dm, &Kc, &Bc, &Ic);
           const T R = tmax(MYO_MINVAL, (1 - Ic) * M.tendon_invweight0[t] / Ic);
-          s.lim_id[r] = t; s.lim_sgn[r] = side ? (T)-1 : (T)1;
-          s.efc_D[r] = 1 / R; s.efc_B[r] = Bc; s.efc_kip[r] = Kc * Ic * dm;
+          s.lim_id[r] = t | (side ? MYO_LIM_UPPER : 0);
+          s.efc_D[r] = 1 / R; S_LIM_B(s)[r] = Bc; S_LIM_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -1859,7 +1869,8 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
         if (k >= LV(ct).n || ci >= NC) break;
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
         ContactRec<T>& c = s.con[ci];
-        for (int e = 0; e < 3; ++e) { c.pos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); c.frame[e] = (T)LV(ct).nrm[3 * k + e]; }
+        T cpos[3];                         // contact point relative to O: only r1 / r2 below are made of it
+        for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); c.frame[e] = (T)LV(ct).nrm[3 * k + e]; }
         make_frame(c.frame);
         // everything that depends on the two geoms only comes from the host-resolved pair record (pc_*):
         // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
@@ -1879,7 +1890,7 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
           fb = g2 == K.obj1_gid ? s.ball_fric[0] : (g2 == K.obj2_gid ? s.ball_fric[3] : fb);
         }
         const T fr0 = (fsel == 0) ? tmax(fa, fb) : (fsel == 1 ? fa : fb);
-        c.mu[0] = fr0; c.mu[1] = fr0;
+        c.mu = fr0;
         const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
         T Kc, Bc, Ic;
         sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
@@ -1891,7 +1902,7 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
         c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
         {
           const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
-          for (int e = 0; e < 3; ++e) { c.r1[e] = c.pos[e] - c1[e]; c.r2[e] = c.pos[e] - c2[e]; }
+          for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
         }
         {
           int* dst = reinterpret_cast<int*>(c.sup);
@@ -2011,14 +2022,14 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T val;
-      if (r < nl) val = s.lim_sgn[r] * v[s.lim_id[r]];
+      if (r < nl) val = lim_sign<T>(s.lim_id[r]) * v[lim_index(s.lim_id[r])];
       else if (r < nlim) {
-        const int t = s.lim_id[r];
+        const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acc = 0;
         int slot = 0;
         while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * v[d]; slot++; }
-        val = s.lim_sgn[r] * acc;
+        val = lim_sign<T>(s.lim_id[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
@@ -2027,7 +2038,7 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
         point_vel(bv, c.b2, c.r2, v2);
         const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
         const T vn = dot3(c.frame, rel), vt = dot3(c.frame + 3 + 3 * (e >> 1), rel);
-        val = vn + ((e & 1) ? -c.mu[e >> 1] : c.mu[e >> 1]) * vt;
+        val = vn + ((e & 1) ? -c.mu : c.mu) * vt;
       }
       out[r] = val;
     }
@@ -2070,9 +2081,9 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T vala, valb;
-      if (r < nl) { const T sg = s.lim_sgn[r]; const int id = s.lim_id[r]; vala = sg * va[id]; valb = sg * vb[id]; }
+      if (r < nl) { const T sg = lim_sign<T>(s.lim_id[r]); const int id = lim_index(s.lim_id[r]); vala = sg * va[id]; valb = sg * vb[id]; }
       else if (r < nlim) {
-        const int t = s.lim_id[r];
+        const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acca = 0, accb = 0;
         int slot = 0;
@@ -2081,12 +2092,12 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
           const T j = s.ten_J[t * MYO_TJ_MAX + slot];
           acca += j * va[d]; accb += j * vb[d]; slot++;
         }
-        vala = s.lim_sgn[r] * acca; valb = s.lim_sgn[r] * accb;
+        vala = lim_sign<T>(s.lim_id[r]) * acca; valb = lim_sign<T>(s.lim_id[r]) * accb;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
         const T* fn = c.frame; const T* ft = c.frame + 3 + 3 * (e >> 1);
-        const T mu = (e & 1) ? -c.mu[e >> 1] : c.mu[e >> 1];
+        const T mu = (e & 1) ? -c.mu : c.mu;
         T v1[3], v2[3];
         point_vel(bva, c.b1, c.r1, v1);
         point_vel(bva, c.b2, c.r2, v2);
@@ -2114,7 +2125,7 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
     for (int ci = lane; ci < ncon; ci += 64) {
       ContactRec<T>& c = s.con[ci];
       const T* fe = f + nlim + 4 * ci;
-      const T fn = fe[0] + fe[1] + fe[2] + fe[3], ft1 = c.mu[0] * (fe[0] - fe[1]), ft2 = c.mu[1] * (fe[2] - fe[3]);
+      const T fn = fe[0] + fe[1] + fe[2] + fe[3], ft1 = c.mu * (fe[0] - fe[1]), ft2 = c.mu * (fe[2] - fe[3]);
       for (int k = 0; k < 3; ++k) c.F[k] = c.frame[k] * fn + c.frame[3 + k] * ft1 + c.frame[6 + k] * ft2;
     }
   }
@@ -2124,15 +2135,15 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
     if (d < M.nv) {
       T acc = 0;
       for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
-        const T v = s.lim_sgn[r] * f[r];
-        acc += (s.lim_id[r] == d) ? v : (T)0;
+        const T v = lim_sign<T>(s.lim_id[r]) * f[r];
+        acc += (lim_index(s.lim_id[r]) == d) ? v : (T)0;
       }
       for (int r = nl; r < nlim; ++r) {
-        const int t = s.lim_id[r];
+        const int t = lim_index(s.lim_id[r]);
         const unsigned long long m = M.tendon_dofmask[t];
         const int on = (int)((m >> d) & 1ull);
         const int slot = on ? myo_popcll(m & ((1ull << d) - 1ull)) : 0;      // slot 0 is always a valid read
-        const T v = s.lim_sgn[r] * s.ten_J[t * MYO_TJ_MAX + slot] * f[r];
+        const T v = lim_sign<T>(s.lim_id[r]) * s.ten_J[t * MYO_TJ_MAX + slot] * f[r];
         acc += on ? v : (T)0;
       }
       // own motion axis once; per contact only wave-uniform (broadcast) reads, issued unconditionally with a
@@ -2268,9 +2279,9 @@ DEV void efc_reference(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     PHASE {
       const int nlim_ = s.nl + s.ntl;
       for (int r = lane; r < s.nefc; r += 64) {
-        const T Bc = r < nlim_ ? s.efc_B[r] : s.con[(r - nlim_) >> 2].B;
-        const T kp = r < nlim_ ? s.efc_kip[r] : s.con[(r - nlim_) >> 2].kip;
-        s.efc_aref[r] = -Bc * s.efc_jv[r] - kp;
+        const T Bc = r < nlim_ ? S_LIM_B(s)[r] : s.con[(r - nlim_) >> 2].B;
+        const T kp = r < nlim_ ? S_LIM_KIP(s)[r] : s.con[(r - nlim_) >> 2].kip;
+        S_AREF(s)[r] = -Bc * s.efc_jv[r] - kp;
       }
     }
     SYNC();
@@ -2424,7 +2435,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       T acc = 0;
       for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
         const T Dr = s.efc_D[r];
-        acc += (s.efc_active[r] && s.lim_id[r] == d) ? Dr : (T)0;
+        acc += (s.efc_active[r] && lim_index(s.lim_id[r]) == d) ? Dr : (T)0;
       }
       if (acc != 0) s.H[MYO_HIDX(d, d)] += acc;
     }
@@ -2434,7 +2445,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   for (int r = nl; r < nlim; ++r) {
     if (!s.efc_active[r]) continue;
     PHASE {
-      const int t = s.lim_id[r];
+      const int t = lim_index(s.lim_id[r]);
       const unsigned long long m = M.tendon_dofmask[t];
       const int n = myo_popcll(m);
       const int a = lane >> 3, b = lane & 7;
@@ -2478,10 +2489,10 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         const ContactRec<T>& c = s.con[ci];
         const unsigned char* act = s.efc_active + nlim + 4 * ci;
         T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
-        if (act[0]) { nn += 1; n1 += c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
-        if (act[1]) { nn += 1; n1 -= c.mu[0]; a11 += c.mu[0] * c.mu[0]; }
-        if (act[2]) { nn += 1; n2 += c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
-        if (act[3]) { nn += 1; n2 -= c.mu[1]; a22 += c.mu[1] * c.mu[1]; }
+        if (act[0]) { nn += 1; n1 += c.mu; a11 += c.mu * c.mu; }
+        if (act[1]) { nn += 1; n1 -= c.mu; a11 += c.mu * c.mu; }
+        if (act[2]) { nn += 1; n2 += c.mu; a22 += c.mu * c.mu; }
+        if (act[3]) { nn += 1; n2 -= c.mu; a22 += c.mu * c.mu; }
         if (nn != 0) {
           const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
           const int ns = c.nsup;
@@ -2520,13 +2531,14 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   // ---- warm start: cheaper of qacc_warmstart and qacc_smooth
   // (the second set of body vectors borrows Ma..Mv, which the solver has not started to use)
   body_vectors2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.qacc_smooth), LOFF(s, s.bvec), LOFF(s, S_CVEL(s)));
-  J_times2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_jar), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)),
+  // (J qacc_warm lands in efc_force, which the solver writes only after the choice: efc_jar still holds aref)
+  J_times2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)),
            LOFF(s, s.efc_jv));
   mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc_warm));
   const int nlim = s.nl + s.ntl;
   // cost of the violated rows, branch-free: 0.5 D min(x, 0)^2  (no conditional around the D load)
-  WAVE_SUM_N(HP, costw_c, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jar[r] - s.efc_aref[r], (T)0) * (HP)tmin(s.efc_jar[r] - s.efc_aref[r], (T)0)));
-  WAVE_SUM_N(HP, costs, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jv[r] - s.efc_aref[r], (T)0) * (HP)tmin(s.efc_jv[r] - s.efc_aref[r], (T)0)));
+  WAVE_SUM_N(HP, costw_c, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_force[r] - S_AREF(s)[r], (T)0) * (HP)tmin(s.efc_force[r] - S_AREF(s)[r], (T)0)));
+  WAVE_SUM_N(HP, costs, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jv[r] - S_AREF(s)[r], (T)0) * (HP)tmin(s.efc_jv[r] - S_AREF(s)[r], (T)0)));
   WAVE_SUM_N(HP, gw, nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc_warm[c] - (HP)s.qacc_smooth[c])));
   const int use_warm = (costw_c + (HP)0.5 * gw) < costs;
   PHASE {
@@ -2535,7 +2547,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       s.qacc[c] = use_warm ? s.qacc_warm[c] : s.qacc_smooth[c];
       if (!use_warm) s.Ma[c] = s.qfrc_smooth[c];  // M qacc_smooth = qfrc_smooth
     }
-    for (int r = lane; r < nefc; r += 64) s.efc_jar[r] = (use_warm ? s.efc_jar[r] : s.efc_jv[r]) - s.efc_aref[r];
+    for (int r = lane; r < nefc; r += 64) s.efc_jar[r] = (use_warm ? s.efc_force[r] : s.efc_jv[r]) - S_AREF(s)[r];
   }
   SYNC();
   if (!use_warm) mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc));  // keep Ma exactly consistent with M*qacc
@@ -2811,11 +2823,11 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
     load_H_from_M(M, s, (const T*)M.dof_damping, M.timestep);
-    PHASE { const int c = lane; if (c < M.nv) s.tmpv[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }
+    PHASE { const int c = lane; if (c < M.nv) s.search[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }   // (search: dead after the solver)
     SYNC();
-    chol_factor_solve(s, s.tmpv, M.nv, M.nlead);
+    chol_factor_solve(s, s.search, M.nv, M.nlead);
     PROF(s, 12)
-    advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.tmpv), LNULL(const T));
+    advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.search), LNULL(const T));
     PROF(s, 13)
   } else {
     advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.qacc), LNULL(const T));

@@ -399,11 +399,11 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   LIM((size_t)m->nte * sizeof(double) > (size_t)(MYO_H_SIZE - MYO_NB_MAX * 10) * sizeof(float), "tendon path elements (length staging)")
   if (m->te_div.empty()) { m->te_i.assign(4, 0); m->te_div.push_back(1.0); }
   // staging area of the tendon stage: T path points in con[], then (8-byte aligned) 7 HP wrap results per geom wrap,
-  // running on through the limit-row and efc_* arrays up to efc_active
+  // running on through the limit-row, efc_* and solver vectors up to rk
   LIM(((3 * (size_t)m->nwrap * sizeof(double) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
-          offsetof(Scratch<double>, efc_active) - offsetof(Scratch<double>, con) ||
+          offsetof(Scratch<double>, rk) - offsetof(Scratch<double>, con) ||
       ((3 * (size_t)m->nwrap * sizeof(float) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
-          offsetof(Scratch<float>, efc_active) - offsetof(Scratch<float>, con), "tendon path elements / wrap geoms (staging area of the tendon stage)")
+          offsetof(Scratch<float>, rk) - offsetof(Scratch<float>, con), "tendon path elements / wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
   for (int i = 0; i < m->nu; ++i) m->actuator_tendon[i] = trnid[2 * i];
   // qfrc_actuator gather, dof-major: for dof d the (ten_J offset << 6 | actuator) pairs of every
@@ -2221,7 +2221,7 @@ extern "C" int myo_adam_clip_step(float* p, const float* g, float* m, float* v, 
 // ------------------------------------------------------------------------------------------ fused MLP PPO step
 #include "myo_ppo_mlp.h"
 #ifndef MYO_EMU
-struct MlpWs { unsigned short *W1p, *W2, *W2T, *Whp, *WhT; float* bias; unsigned short *XT, *H1T, *H2T, *dH1T, *dH2T, *dOT; float *part, *slab; size_t bytes; };
+struct MlpWs { unsigned short *W1p, *W2, *W2T, *Whp, *WhT; float* bias; unsigned short *XT, *H1T, *H2T, *dH1T, *dH2T, *dOT; float *part, *slab, *advpart; size_t bytes; };
 static MlpWs mlp_carve(unsigned char* base, int B, int OP, int A, long long G) {
   MlpWs w;
   size_t o = 0;
@@ -2236,6 +2236,7 @@ static MlpWs mlp_carve(unsigned char* base, int B, int OP, int A, long long G) {
   w.dOT = (unsigned short*)take((size_t)256 * B * 2);
   w.part = (float*)take((size_t)(2 * A + 3) * (B / MLP_BM) * 4);
   w.slab = (float*)take((size_t)MLP_SPLITK * G * 4);
+  w.advpart = (float*)take((3 * MLP_ADV_BLOCKS + 1) * 4);      // slices of the advantage moments + the finisher's ticket (zero at first use)
   w.bytes = o;
   return w;
 }
@@ -2271,7 +2272,8 @@ extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
       return fail(MYO_E_DEVICE, "myo_ppo_mlp_step: cannot reserve %d bytes of LDS", (int)MLP_FWDBWD_LDS);
     lds_set = true;
   }
-  if (d->compute_adv_stats) hipLaunchKernelGGL(k_adv_moments, dim3(1), dim3(1024), 0, st, d->adv, (const long long*)d->idx, B, d->adv_stats);
+  if (d->compute_adv_stats) hipLaunchKernelGGL(k_adv_moments, dim3(MLP_ADV_BLOCKS), dim3(256), 0, st, d->adv, (const long long*)d->idx, B, d->adv_stats, w.advpart,
+                       reinterpret_cast<unsigned*>(w.advpart + 3 * MLP_ADV_BLOCKS));
   MlpPrepArgs pp;
   pp.p = d->params; pp.O = O; pp.OP = OP; pp.Ah[0] = A; pp.Ah[1] = 1;
   for (int k = 0; k < 2; ++k) {

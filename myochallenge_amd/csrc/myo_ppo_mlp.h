@@ -57,9 +57,35 @@ struct MlpPrepArgs {
   int O, OP, Ah[2];                                // head widths: A (actor), 1 (critic)
   unsigned short *W1p, *W2, *W2T, *Whp, *WhT;
   float* bias;
+  const float* adv_part;       // [3 * adv_nb] slices (n, mean, M2) of the advantage moments left by k_adv_moments, or adv_nb = 0
+  float* adv_stats;
+  int adv_nb, B;
 };
 
+#define MLP_ADV_BLOCKS 64
 __global__ void __launch_bounds__(256) k_mlp_prep(MlpPrepArgs P) {
+  // the last block first merges the slices of the advantage moments in slice order (Chan's update, a fixed order: deterministic)
+  // — here, behind a kernel boundary, instead of by the last block of k_adv_moments behind a device-scope fence (an L2 write-back:
+  // 12.8 us for the launch) — while the other blocks convert the weights
+  if (P.adv_nb > 0 && blockIdx.x == gridDim.x - 1) {
+    __shared__ float sp[3 * MLP_ADV_BLOCKS];
+    const int t = threadIdx.x;
+    if (t < 3 * P.adv_nb) sp[t] = P.adv_part[t];
+    __syncthreads();
+    if (t == 0) {
+      float cn = 0.f, cm = 0.f, c2 = 0.f;
+      for (int b = 0; b < P.adv_nb; ++b) {
+        const float bn = sp[3 * b], bm = sp[3 * b + 1], b2 = sp[3 * b + 2];
+        if (bn > 0.f) {
+          const float tot = cn + bn, dl = bm - cm;
+          cm += dl * (bn / tot);
+          c2 += b2 + dl * dl * (cn * bn / tot);
+          cn = tot;
+        }
+      }
+      P.adv_stats[0] = cm; P.adv_stats[1] = sqrtf(c2 / (P.B > 1 ? P.B - 1 : 1));
+    }
+  }
   constexpr int H = MLP_H;
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x, nth = (long long)gridDim.x * blockDim.x;
   for (int net = 0; net < 2; ++net) {
@@ -90,17 +116,13 @@ __global__ void __launch_bounds__(256) k_mlp_prep(MlpPrepArgs P) {
   }
 }
 
-// mean and unbiased std of adv[idx[0..B)): MLP_ADV_BLOCKS blocks (a minibatch drawn from a shuffled rollout touches one 128 B
-// line per row — 2 MB through ONE CU's L1 was 23 us of a 150 us optimizer step), each reducing its contiguous slice of the index
-// list to (n, mean, M2) with the values kept in registers (one memory pass); the block that finishes last merges the slices
-// in slice order (Chan's update, a fixed order: deterministic) and resets the ticket.  part: [3 * MLP_ADV_BLOCKS] floats,
-// ticket: one zero-initialised unsigned.
-#define MLP_ADV_BLOCKS 64
+// mean and unbiased std of adv[idx[0..B)), first half: MLP_ADV_BLOCKS blocks (a minibatch drawn from a shuffled rollout touches one
+// 128 B line per row — 2 MB through ONE CU's L1 was 23 us of a 150 us optimizer step), each reducing its contiguous slice of the
+// index list to (n, mean, M2) with the values kept in registers (one memory pass) -> part[3 * block]; k_mlp_prep merges them.
 __global__ void __launch_bounds__(256) k_adv_moments(const float* __restrict__ adv, const long long* __restrict__ idx, int B,
-                                                     float* __restrict__ stats, float* __restrict__ part, unsigned* __restrict__ ticket) {
+                                                     float* __restrict__ part) {
   __shared__ float red[4];
   __shared__ float s_mean;
-  __shared__ unsigned s_last;
   const int t = threadIdx.x, nb = gridDim.x;
   const int chunk = (B + nb - 1) / nb, lo = blockIdx.x * chunk, hi = min(B, lo + chunk), n = max(hi - lo, 0);
   constexpr int PER = 4;                  // slices up to 1024 rows in registers; longer ones re-read (second loops below)
@@ -123,27 +145,7 @@ __global__ void __launch_bounds__(256) k_adv_moments(const float* __restrict__ a
   __syncthreads();
   if ((t & 63) == 0) red[t >> 6] = m2;
   __syncthreads();
-  if (t == 0) {
-    part[3 * blockIdx.x] = (float)n; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = (red[0] + red[1]) + (red[2] + red[3]);
-    __threadfence();                      // the slice is visible device-wide before the ticket is taken
-    s_last = atomicAdd(ticket, 1u) == (unsigned)nb - 1;
-    if (s_last) {
-      __threadfence();
-      float cn = 0.f, cm = 0.f, c2 = 0.f;
-      for (int b = 0; b < nb; ++b) {
-        const float bn = __builtin_nontemporal_load(part + 3 * b), bm = __builtin_nontemporal_load(part + 3 * b + 1),
-                    b2 = __builtin_nontemporal_load(part + 3 * b + 2);
-        if (bn > 0.f) {
-          const float tot = cn + bn, dl = bm - cm;
-          cm += dl * (bn / tot);
-          c2 += b2 + dl * dl * (cn * bn / tot);
-          cn = tot;
-        }
-      }
-      stats[0] = cm; stats[1] = sqrtf(c2 / (B > 1 ? B - 1 : 1));
-      *ticket = 0u;
-    }
-  }
+  if (t == 0) { part[3 * blockIdx.x] = (float)n; part[3 * blockIdx.x + 1] = mean; part[3 * blockIdx.x + 2] = (red[0] + red[1]) + (red[2] + red[3]); }
 }
 
 // One wave's slab of a layer: BM rows x 64 columns, acc[mt][nt] += A(LDS rows, K-contiguous) * W(global rows, K-contiguous)'.
@@ -168,13 +170,18 @@ __device__ __forceinline__ void mlp_mma_slab(myo_f32x4 (&acc)[MT][4], const unsi
     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ks = 0; ks < KSTEPS; ++ks) {
-    myo_bf16x8 a[MT];
+    // (two row tiles' A fragments at a time: with all four in registers next to 64 accumulators and the 128 weight registers
+    // of a K = 256 slab the kernel spilled)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const myo_bf16x8*>(As + (16 * mt + lm) * as_stride + 32 * ks + 8 * lq);
+    for (int m2 = 0; m2 < MT; m2 += 2) {
+      myo_bf16x8 a[2];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < 2; ++mt) a[mt] = *reinterpret_cast<const myo_bf16x8*>(As + (16 * (m2 + mt) + lm) * as_stride + 32 * ks + 8 * lq);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bw[ks][nt], acc[mt][nt], 0, 0, 0);
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[m2 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt], bw[ks][nt], acc[m2 + mt][nt], 0, 0, 0);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -187,31 +194,27 @@ extern "C" int myo_debug_mlp_prof(unsigned long long* out) { return (int)hipMemc
 #define MLP_STAMP(k)
 #endif
 
-// LDS of one workgroup (BM rows): row ids, X (later the head output), H1, H2 (later dH2), actions (later d log_std terms),
-// d(head output), log_std / exp(-log_std), adv / old log-prob / return.  BM = 32: 55 KB -> two workgroups per CU, whose phases
-// (gather, MFMA slabs, the one-wave loss phase, feature-major stores) overlap each other's latencies.
+// LDS of one workgroup (BM rows): row ids, X (later the head output), ONE hidden image (H1, then H2, then dH2 — each is only
+// needed as the A operand of the next GEMM; the ReLU masks the two gradient epilogues need stay in registers, one bit per
+// accumulator element of the lane, because the wave that applies a mask is the wave that produced the activation),
+// actions (later d log_std terms), d(head output), log_std / exp(-log_std), adv / old log-prob / return.
+// BM = 32: 38 KB, 241 VGPRs -> two workgroups per CU (the register budget decides), whose phases (gather, MFMA slabs, the
+// one-wave loss phase, feature-major stores) overlap each other's latencies.  BM = 64 (75 KB, also two per CU, every weight
+// fragment fetched from L2 feeding four row tiles instead of two) was measured at the SAME time per row — 54 us per 64-row
+// workgroup against 2 x 28 us, k_mlp_fwdbwd 71.0 vs 69.8 us at B = 16384 — with 33 spilled registers: the phases scale with
+// the rows (epilogue conversions, 2-byte LDS stores, strided feature-major stores), not with the weight traffic.
+#ifndef MLP_BM
 #define MLP_BM 32
-#define MLP_FWDBWD_LDS (512 + MLP_BM * MLP_XS * 2 + 2 * MLP_BM * MLP_HS * 2 + MLP_BM * MLP_SOS * 4 + MLP_BM * MLP_DS * 2 + 128 * 4 + 192 * 4)
+#endif
+#define MLP_FWDBWD_LDS (512 + MLP_BM * MLP_XS * 2 + MLP_BM * MLP_HS * 2 + MLP_BM * MLP_SOS * 4 + MLP_BM * MLP_DS * 2 + 128 * 4 + 192 * 4)
 
 // activation epilogue of one slab: bias + ReLU -> bf16 -> row-major LDS image (next layer's A operand) + feature-major global copy
+// returns the lane's ReLU mask: bit 16 mt + 4 nt + r = (activation != 0)
 template <int MT>
-__device__ __forceinline__ void mlp_store_act(const myo_f32x4 (&acc)[MT][4], const float (&bb)[4], unsigned short* Hs, unsigned short* HT,
-                                              size_t B, int r0, int n0, int lm, int lq) {
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
-      unsigned short h[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { h[r] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb[nt], 0.f)); Hs[(m + r) * MLP_HS + n] = h[r]; }
-      *reinterpret_cast<uint2*>(HT + (size_t)n * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    }
-}
-// gradient epilogue: * (H > 0) without a branch (the mask is all-ones / zero bits) -> bf16 -> optional LDS image + feature-major global copy
-template <int MT, bool TO_LDS>
-__device__ __forceinline__ void mlp_store_grad(const myo_f32x4 (&acc)[MT][4], unsigned short* Hs, unsigned short* HT, size_t B, int r0, int n0,
-                                               int lm, int lq) {
+__device__ __forceinline__ unsigned long long mlp_store_act(const myo_f32x4 (&acc)[MT][4], const float (&bb)[4], unsigned short* Hs, unsigned short* HT,
+                                                            size_t B, int r0, int n0, int lm, int lq) {
+  static_assert(MT * 16 <= 64, "one mask bit per accumulator element");
+  unsigned long long mask = 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -220,7 +223,26 @@ __device__ __forceinline__ void mlp_store_grad(const myo_f32x4 (&acc)[MT][4], un
       unsigned short h[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const unsigned short on = (unsigned short)(-(int)(Hs[(m + r) * MLP_HS + n] != 0));
+        h[r] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb[nt], 0.f)); Hs[(m + r) * MLP_HS + n] = h[r];
+        mask |= (unsigned long long)(h[r] != 0) << (16 * mt + 4 * nt + r);
+      }
+      *reinterpret_cast<uint2*>(HT + (size_t)n * B + r0 + m) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    }
+  return mask;
+}
+// gradient epilogue: * (H > 0) without a branch (the mask is all-ones / zero bits) -> bf16 -> optional LDS image + feature-major global copy
+template <int MT, bool TO_LDS>
+__device__ __forceinline__ void mlp_store_grad(const myo_f32x4 (&acc)[MT][4], unsigned long long mask, unsigned short* Hs, unsigned short* HT, size_t B,
+                                               int r0, int n0, int lm, int lq) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+      unsigned short h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned short on = (unsigned short)(-(int)((mask >> (16 * mt + 4 * nt + r)) & 1ull));
         h[r] = mlp_f2bf(acc[mt][nt][r]) & on;
         if (TO_LDS) Hs[(m + r) * MLP_HS + n] = h[r];
       }
@@ -234,9 +256,8 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwdbwd(MlpArgs P) {
   long long* s_idx = reinterpret_cast<long long*>(mlp_smem);                      // [BM] (64 slots)
   unsigned short* Xs = reinterpret_cast<unsigned short*>(mlp_smem + 512);         // [BM][XS] bf16; later So fp32 [BM][SOS]
   float* So = reinterpret_cast<float*>(mlp_smem + 512);
-  unsigned short* Hs1 = Xs + BM * XS;                                             // [BM][HS]
-  unsigned short* Hs2 = Hs1 + BM * HS;                                            // [BM][HS]
-  float* Sa = reinterpret_cast<float*>(Hs2 + BM * HS);                            // [BM][SOS] actions, then dlogp (z^2 - 1) in place
+  unsigned short* Hs = Xs + BM * XS;                                              // [BM][HS]: H1, then H2, then dH2
+  float* Sa = reinterpret_cast<float*>(Hs + BM * HS);                             // [BM][SOS] actions, then dlogp (z^2 - 1) in place
   unsigned short* dOs = reinterpret_cast<unsigned short*>(Sa + BM * SOS);         // [BM][DS]
   float* s_ls = reinterpret_cast<float*>(dOs + BM * DS);                          // [64] log_std, [64] exp(-log_std)
   float* s_row = s_ls + 128;                                                      // [3][64] adv / old log-prob / return of the block's rows
@@ -306,41 +327,37 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwdbwd(MlpArgs P) {
   else if (OP == 64) mlp_mma_slab<2, MT>(acc, Xs, XS, bw, lm, lq);
   else mlp_mma_slab<1, MT>(acc, Xs, XS, bw, lm, lq);
   mlp_load_w<H / 32>(bw, P.W2 + (size_t)net * H * H, H, n0, lm, lq);
-  mlp_store_act<MT>(acc, bb1, Hs1, P.H1T + (size_t)net * H * B, B, r0, n0, lm, lq);
+  const unsigned long long mask1 = mlp_store_act<MT>(acc, bb1, Hs, P.H1T + (size_t)net * H * B, B, r0, n0, lm, lq);
   __syncthreads();
   MLP_STAMP(2)
   // ---- layer 2
-  mlp_mma_slab<H / 32, MT>(acc, Hs1, HS, bw, lm, lq);
-  // the head's tiles (16 rows x 16 outputs, MT x 3 of them) are dealt to the waves: tile w and tile w + 4
+  mlp_mma_slab<H / 32, MT>(acc, Hs, HS, bw, lm, lq);
+  // the head's tiles (16 rows x 16 outputs, MT x 3 of them): wave w < 3 takes output tile w of every row tile (one set of
+  // weight fragments, 32 VGPRs, reused MT times)
   const unsigned short* Wh = P.Whp + (size_t)net * MLP_APM * H;
-  myo_bf16x8 bh2[2][H / 32];
+  myo_bf16x8 bh2[H / 32];
+  if (w < 3) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int tile = w + 4 * q, nt = tile / MT;
-    if (tile < MT * 3) {
-#pragma unroll
-      for (int ks = 0; ks < H / 32; ++ks) bh2[q][ks] = *reinterpret_cast<const myo_bf16x8*>(Wh + (size_t)(16 * nt + lm) * H + 32 * ks + 8 * lq);
-    }
+    for (int ks = 0; ks < H / 32; ++ks) bh2[ks] = *reinterpret_cast<const myo_bf16x8*>(Wh + (size_t)(16 * w + lm) * H + 32 * ks + 8 * lq);
   }
   __builtin_amdgcn_sched_barrier(0);
-  mlp_store_act<MT>(acc, bb2, Hs2, P.H2T + (size_t)net * H * B, B, r0, n0, lm, lq);
+  __syncthreads();                       // every wave has read H1 out of the hidden image: H2 takes its place
+  const unsigned long long mask2 = mlp_store_act<MT>(acc, bb2, Hs, P.H2T + (size_t)net * H * B, B, r0, n0, lm, lq);
   __syncthreads();
   MLP_STAMP(3)
   // ---- head (fp32 into So, which reuses X's storage)
+  if (w < 3) {
+    const float bv = bh[16 * w + lm];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int tile = w + 4 * q;
-    if (tile < MT * 3) {
-      const int mt = tile % MT, nt = tile / MT;
+    for (int mt = 0; mt < MT; ++mt) {
       myo_f32x4 ah = myo_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < H / 32; ++ks) {
-        const myo_bf16x8 a = *reinterpret_cast<const myo_bf16x8*>(Hs2 + (16 * mt + lm) * HS + 32 * ks + 8 * lq);
-        ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh2[q][ks], ah, 0, 0, 0);
+        const myo_bf16x8 a = *reinterpret_cast<const myo_bf16x8*>(Hs + (16 * mt + lm) * HS + 32 * ks + 8 * lq);
+        ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh2[ks], ah, 0, 0, 0);
       }
-      const float bv = bh[16 * nt + lm];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) So[(16 * mt + 4 * lq + r) * SOS + 16 * nt + lm] = ah[r] + bv;
+      for (int r = 0; r < 4; ++r) So[(16 * mt + 4 * lq + r) * SOS + 16 * w + lm] = ah[r] + bv;
     }
   }
   mlp_load_w<MLP_AKP / 32>(bw, P.WhT + (size_t)net * H * MLP_AKP, MLP_AKP, n0, lm, lq);      // d hidden 2's weights fly during the loss phase
@@ -410,12 +427,12 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwdbwd(MlpArgs P) {
   // ---- d hidden 2 = (dOut Wh) * (H2 > 0), written over H2's LDS image (its A-operand role ended with the head)
   mlp_mma_slab<MLP_AKP / 32, MT>(acc, dOs, DS, bw, lm, lq);
   mlp_load_w<H / 32>(bw, P.W2T + (size_t)net * H * H, H, n0, lm, lq);
-  mlp_store_grad<MT, true>(acc, Hs2, P.dH2T + (size_t)net * H * B, B, r0, n0, lm, lq);
+  mlp_store_grad<MT, true>(acc, mask2, Hs, P.dH2T + (size_t)net * H * B, B, r0, n0, lm, lq);
   __syncthreads();
   MLP_STAMP(7)
   // ---- d hidden 1 = (dH2 W2) * (H1 > 0)
-  mlp_mma_slab<H / 32, MT>(acc, Hs2, HS, bw, lm, lq);
-  mlp_store_grad<MT, false>(acc, Hs1, P.dH1T + (size_t)net * H * B, B, r0, n0, lm, lq);
+  mlp_mma_slab<H / 32, MT>(acc, Hs, HS, bw, lm, lq);
+  mlp_store_grad<MT, false>(acc, mask1, Hs, P.dH1T + (size_t)net * H * B, B, r0, n0, lm, lq);
   MLP_STAMP(8)
 }
 

@@ -110,4 +110,4 @@ struct EnvRecordLayout {
 // misc : which_task, counter, elapsed_steps, episode_index, ep_return, ep_len (6, stored as double)
 #define MYO_TASKD_N 9
 #define MYO_BALLD_N 10
-#define MYO_MISC_N 6
+#define MYO_MISC_N 8      // which_task, counter, elapsed, episode, ep_ret, ep_len, bad (mid-step hand-off only), spare

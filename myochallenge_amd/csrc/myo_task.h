@@ -205,12 +205,19 @@ DEV void task_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T, NC>&
 DEV int task_nobs(const TaskDev& K, int na) { return K.kind == MYO_TASK_REORIENT_K ? 2 * K.n_hand + 18 + na : K.n_hand + 24 + na; }
 
 // ---- env.step(a) without the VecEnv bookkeeping
+// An env step may be run in two parts by two workgroups (the launch's makespan, see k_step): MYO_STEP_FIRST = target update,
+// ctrl, the first k1 substeps; MYO_STEP_SECOND = ctrl again (a pure function of the action), the remaining substeps, observation
+// and reward.  Everything a substep hands to the next one is in the env record (load_env / store_env), so the split is bit-exact.
+#define MYO_STEP_WHOLE 0
+#define MYO_STEP_FIRST 1
+#define MYO_STEP_SECOND 2
 template <typename T, int NC>
-DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, const float* action /* may be null = zeros */) {
+DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, const float* action /* may be null = zeros */,
+                        int part = MYO_STEP_WHOLE, int k1 = 0) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (lane == 0 && K.kind != MYO_TASK_REORIENT_K) {
+    if (lane == 0 && K.kind != MYO_TASK_REORIENT_K && part != MYO_STEP_SECOND) {
       if (s.which_task != 0) {
         const double dt = (double)K.frame_skip * M.h_timestep;
         const double sign = s.which_task == 1 ? -1.0 : 1.0;
@@ -235,7 +242,9 @@ DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
     }
   }
   SYNC();
-  for (int k = 0; k < K.frame_skip; ++k) mj_step(M, K, s);
+  const int k_lo = part == MYO_STEP_SECOND ? k1 : 0, k_hi = part == MYO_STEP_FIRST ? k1 : K.frame_skip;
+  for (int k = k_lo; k < k_hi; ++k) mj_step(M, K, s);
+  if (part == MYO_STEP_FIRST) return;
   check_state(M, s, 0);            // a non-finite value produced by the LAST advance must not leave through obs / reward
   kinematics(M, s);
   task_obs_reward(M, K, s);
@@ -475,14 +484,14 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
       const double* mi = rec + L.off_misc;
       s.which_task = (int)mi[0]; s.counter = (int)mi[1]; s.elapsed = (int)mi[2]; s.episode = (int)mi[3];
       s.ep_ret = (T)mi[4]; s.ep_len = (int)mi[5];
-      s.bad = 0; s.ncon = 0; s.nefc = 0; s.nl = 0; s.ntl = 0; s.solver_iter = 0;
+      s.bad = (int)mi[6]; s.ncon = 0; s.nefc = 0; s.nl = 0; s.ntl = 0; s.solver_iter = 0;     // (mi[6] is non-zero only between the two parts of a split step)
     }
   }
   SYNC();
 }
 
 template <typename T, int NC>
-DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T, NC>& s_in) {
+DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T, NC>& s_in, int mid_step = 0) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -502,7 +511,7 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
       bd[8] = (double)s.ball_size[0]; bd[9] = (double)s.ball_size[1];
       double* mi = rec + L.off_misc;
       mi[0] = s.which_task; mi[1] = s.counter; mi[2] = s.elapsed; mi[3] = s.episode;
-      mi[4] = (double)s.ep_ret; mi[5] = s.ep_len;
+      mi[4] = (double)s.ep_ret; mi[5] = s.ep_len; mi[6] = mid_step ? s.bad : 0;
     }
   }
   SYNC();
@@ -512,11 +521,12 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
 template <typename T, int NC>
 DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
-                  float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
+                  float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int part = MYO_STEP_WHOLE, int k1 = 0) {
   WAVE_FN
   const int nobs = task_nobs(K, M.na);
   load_env(M, K, L, rec, s);
-  task_step_core(M, K, s, act + (size_t)env * M.nu);
+  task_step_core(M, K, s, act + (size_t)env * M.nu, part, k1);
+  if (part == MYO_STEP_FIRST) { store_env(M, K, L, rec, s, 1); return; }
   // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
   // an error of the batch: the env ends its episode with done = 1, reward 0, zero reward components except `done`,
   // is reset at once, and both the terminal and the returned observation are the (finite) reset observation, so that

@@ -564,6 +564,16 @@ struct myo_batch {
   DevModel<float> Mf;
   int nq, nv, nu, na, nbody, nsite, ntendon, ngeom, integrator;
   unsigned char* bad_state;    // caller-owned dev uint8[n] or null (myo_batch_set_bad_state_buffer)
+  // launch order of myo_batch_step (longest-predicted-first, see k_step_order): order[blockIdx] = env, cost[env] = smoothed duration
+  // of the env's last steps, ticks[env] = duration of its last step (100 MHz ticks).  order = null: identity.
+  int* order;
+  float* cost;
+  unsigned int* ticks;
+  // two-part env steps (k_step): part_state[env] = 2 g - 2 before step g, 2 g - 1 while the first part runs, 2 g once its record is
+  // published; step_gen[0] = g, advanced on the stream after every step.  split_k1 = substeps in the first part (0: whole steps).
+  int* part_state;
+  int* step_gen;
+  int split_k1;
   int timing;
   double ms_sum;
   int ms_cnt;
@@ -805,12 +815,38 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   if (m->integrator == 1) {        // RK4 stage storage, one RkScratch per env (global memory)
     void* w = nullptr;
     const size_t each = dtype == MYO_F64 ? sizeof(RkScratch<double>) : sizeof(RkScratch<float>);
-    rc |= be_malloc(&w, each * (size_t)n_envs);
+    rc |= be_malloc(&w, each * (size_t)n_envs * 2);      // indexed by workgroup: a two-part step launches 2 n of them
     b->K.rk_ws = w;
     if (w) b->allocs.push_back(w);
   }
+  b->order = nullptr; b->cost = nullptr; b->ticks = nullptr; b->part_state = nullptr; b->step_gen = nullptr; b->split_k1 = 0;
 #ifndef MYO_EMU
   if (!rc) { rc |= (int)hipEventCreate(&b->ev0); rc |= (int)hipEventCreate(&b->ev1); }
+  {
+    const char* e = getenv("MYO_STEP_ORDER");        // "0": launch the envs in index order (A/B switch of the tools)
+    if (!rc && b->K.kind && !(e && e[0] == '0')) {
+      std::vector<int> ident(n_envs);
+      for (int i = 0; i < n_envs; ++i) ident[i] = i;
+      void *po = nullptr, *pc = nullptr, *pt = nullptr;
+      rc |= be_malloc(&po, sizeof(int) * (size_t)n_envs); rc |= be_malloc(&pc, sizeof(float) * (size_t)n_envs); rc |= be_malloc(&pt, sizeof(unsigned) * (size_t)n_envs);
+      if (po) b->allocs.push_back(po);
+      if (pc) b->allocs.push_back(pc);
+      if (pt) b->allocs.push_back(pt);
+      if (!rc) { rc |= be_h2d(po, ident.data(), sizeof(int) * (size_t)n_envs); rc |= (int)hipMemset(pc, 0, sizeof(float) * (size_t)n_envs); rc |= (int)hipMemset(pt, 0, sizeof(unsigned) * (size_t)n_envs); }
+      if (!rc) { b->order = (int*)po; b->cost = (float*)pc; b->ticks = (unsigned*)pt; }
+    }
+    const char* sp = getenv("MYO_STEP_SPLIT");       // substeps in the first part; "0": whole steps (A/B switch of the tools)
+    int k1 = sp ? atoi(sp) : (cfg ? (7 * cfg->frame_skip + 5) / 10 : 0);
+    if (!rc && b->K.kind && cfg->frame_skip >= 2 && k1 >= 1 && k1 < cfg->frame_skip) {
+      void *ps = nullptr, *pg = nullptr;
+      rc |= be_malloc(&ps, sizeof(int) * (size_t)n_envs); rc |= be_malloc(&pg, sizeof(int) * 4);
+      if (ps) b->allocs.push_back(ps);
+      if (pg) b->allocs.push_back(pg);
+      const int one[4] = {1, 0, 0, 0};
+      if (!rc) { rc |= (int)hipMemset(ps, 0, sizeof(int) * (size_t)n_envs); rc |= be_h2d(pg, one, sizeof one); }
+      if (!rc) { b->part_state = (int*)ps; b->step_gen = (int*)pg; b->split_k1 = k1; }
+    }
+  }
 #endif
   if (rc) {
     int r2 = fail(MYO_E_DEVICE, "device allocation/upload failed: %s", be_errstr(rc));
@@ -864,20 +900,136 @@ extern "C" int myo_debug_read_prof(double* out16, int reset) {     /* out16: MYO
   return 0;
 }
 #endif
+#ifdef MYO_WGTIME
+// developer diagnostic (tools/dev/gpu_wgtime.py): start / end of every workgroup of the last k_step launch on the 100 MHz wall clock
+__device__ unsigned long long g_wg_time[2 * 16384];
+extern "C" int myo_debug_read_wgtime(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_time), sizeof(unsigned long long) * 2 * (size_t)(n < 16384 ? n : 16384)) == hipSuccess ? 0 : -1;
+}
+#endif
+// ---- launch order of the env steps.  A step of 4096 envs is two rounds over the chip's 2048 one-wave slots, and an env step
+// takes 0.8 .. 1.6 x the mean (contacts, Newton iterations): in index order the second job of a slot starts whenever its first
+// ends, the slot sums spread, and the launch waits for the worst one — measured (tools/dev/gpu_wgtime.py): 28 % of slots x
+// makespan idle, the last quarter of the launch running on a fraction of the chip.  The dispatcher hands workgroups to freed
+// slots in blockIdx order, so the ORDER is the only lever a one-env-per-workgroup kernel has: longest predicted first — the long
+// jobs start at once, the short ones fill the slots as they free up (list scheduling, LPT).  Prediction = exponentially smoothed
+// duration of the env's own last steps (k_step times every env on the 100 MHz wall clock; the step-to-step correlation of the
+// durations is ~0.5, the smoothing keeps the persistent half).  The results of a step do not depend on the order.
+// k_step_order: ONE block; cost <- (cost + ticks) / 2, 256 cost buckets between the batch minimum and maximum, counting sort
+// (descending) -> order.  Which env comes first inside a bucket is left to the LDS atomics: irrelevant to the results.
+__global__ void __launch_bounds__(1024) k_step_order(const unsigned int* __restrict__ ticks, float* __restrict__ cost, int n, int* __restrict__ order,
+                                                     int* __restrict__ step_gen) {
+  __shared__ float s_lo[16], s_hi[16];
+  __shared__ unsigned int s_cnt[256], s_off[256];
+  const int t = threadIdx.x;
+  if (step_gen && t == 0) step_gen[0] += 1;          // the next launch is the next generation of the two-part protocol
+  if (!order) return;
+  float lo = 3.4e38f, hi = 0.f;
+  for (int i = t; i < n; i += 1024) {
+    const float tk = (float)ticks[i], c0 = cost[i];
+    const float c = c0 > 0.f ? 0.5f * (c0 + tk) : tk;
+    cost[i] = c;
+    lo = fminf(lo, c); hi = fmaxf(hi, c);
+  }
+  for (int off = 32; off >= 1; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off, 64)); hi = fmaxf(hi, __shfl_xor(hi, off, 64)); }
+  if ((t & 63) == 0) { s_lo[t >> 6] = lo; s_hi[t >> 6] = hi; }
+  if (t < 256) s_cnt[t] = 0;
+  __syncthreads();
+  lo = s_lo[0]; hi = s_hi[0];
+  for (int k = 1; k < 16; ++k) { lo = fminf(lo, s_lo[k]); hi = fmaxf(hi, s_hi[k]); }
+  const float scale = hi > lo ? 255.99f / (hi - lo) : 0.f;
+  for (int i = t; i < n; i += 1024) atomicAdd(&s_cnt[255 - (int)((cost[i] - lo) * scale)], 1u);
+  __syncthreads();
+  if (t == 0) { unsigned a = 0; for (int k = 0; k < 256; ++k) { s_off[k] = a; a += s_cnt[k]; } }
+  __syncthreads();
+  for (int i = t; i < n; i += 1024) order[atomicAdd(&s_off[255 - (int)((cost[i] - lo) * scale)], 1u)] = i;
+}
+// ---- two-part env steps.  Even in the best order a slot's two jobs add up their spreads and the launch ends with one job-long
+// tail on a draining chip.  The tail is as long as the LAST job of a slot: so an env step is cut in two jobs, the first k1
+// substeps (blocks 0 .. n-1) and the rest + observation / reward (blocks n .. 2n-1), handed over through the env record in
+// HBM.  In dispatch order every first part is placed before any second part, the long jobs run with the chip full, and what
+// drains at the end is the short jobs' tail (simulated with the measured duration spread: makespan 2.50 -> 2.20 ms for 7 + 3).
+// Protocol (placement- and dispatch-order-independent; MI355X_MICROARCH.md "inter-workgroup visibility"): the first-part
+// workgroup CLAIMS the env (agent-scope CAS 2g-2 -> 2g-1), runs, stores the record, drains its stores, agent-scope release
+// fence, drains again, publishes 2g with an agent-scope relaxed store.  The second-part workgroup polls (relaxed, agent scope):
+// 2g -> ONE agent acquire fence, then plain loads of the record; 2g-1 -> the producer is RUNNING somewhere: sleep and poll again;
+// 2g-2 -> its first part has not been placed yet: claim it and run the whole step here (the late first-part block then finds
+// the claim taken and exits) — no workgroup ever waits for one that is not running.
 template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, const float* act,
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
-                                             float* term_obs, float* comps, float* ep_info, unsigned char* bad_state) {
+                                             float* term_obs, float* comps, float* ep_info, unsigned char* bad_state,
+                                             const int* __restrict__ order, unsigned int* __restrict__ ticks,
+                                             int* part_state, const int* __restrict__ step_gen, int k1) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
-  const int env = blockIdx.x;
+  const int nenv = part_state ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  const int second = (int)blockIdx.x >= nenv;
+  const int slot = (int)blockIdx.x - second * nenv;
+  const int env = order ? order[slot] : slot;
+  const unsigned long long t_start = ticks ? wall_clock64() : 0ull;
+#ifdef MYO_WGTIME
+  if (threadIdx.x == 0 && blockIdx.x < 16384) g_wg_time[2 * blockIdx.x] = wall_clock64();
+#endif
 #ifdef MYO_PROF
   if (threadIdx.x == 0) { for (int k = 0; k < MYO_NPROF; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
   __syncthreads();
 #endif
-  env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
+  int part = MYO_STEP_WHOLE;
+  if (part_state) {
+    const int g2 = 2 * step_gen[0];
+    int* st = part_state + env;
+    int mode = 0;                              // decided by lane 0: 1 = first part, 2 = second part, 3 = whole step here, 0 = nothing to do
+    if (threadIdx.x == 0) {
+      if (!second) {
+        int expect = g2 - 2;
+        mode = __hip_atomic_compare_exchange_strong(st, &expect, g2 - 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+      } else {
+        for (;;) {
+          const int v = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == g2) { mode = 2; break; }
+          if (v == g2 - 2) {
+            int expect = g2 - 2;
+            if (__hip_atomic_compare_exchange_strong(st, &expect, g2 - 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { mode = 3; break; }
+            continue;
+          }
+          if (v != g2 - 1) { mode = 0; break; }   // not a state of this generation: leave the env alone (never reached in a well-formed run)
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+    }
+    mode = __builtin_amdgcn_readfirstlane(mode);
+    if (mode == 0) return;
+    if (mode == 2) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    part = mode == 1 ? MYO_STEP_FIRST : (mode == 2 ? MYO_STEP_SECOND : MYO_STEP_WHOLE);
+    if (mode == 3) {
+      env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
+      if (threadIdx.x == 0) __hip_atomic_store(st, g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, part, k1);
+      if (mode == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(st, g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  } else {
+    env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
+  }
+  if (ticks && threadIdx.x == 0) { const unsigned int d = (unsigned int)(wall_clock64() - t_start); if (part == MYO_STEP_SECOND) ticks[env] += d; else ticks[env] = d; }
+#ifdef MYO_WGTIME
+  if (threadIdx.x == 0 && blockIdx.x < 16384) g_wg_time[2 * blockIdx.x + 1] = wall_clock64();
+#endif
 #ifdef MYO_PROF
   PROF(s, 0)
   __syncthreads();
@@ -1143,10 +1295,11 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
   timing_begin(b, st);
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV, NCV>), dim3(b->part_state ? 2 * b->n : b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->split_k1);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->part_state ? 2 * b->n : b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->split_k1))
   timing_end(b, st);
+  if (b->order || b->step_gen) hipLaunchKernelGGL(k_step_order, dim3(1), dim3(b->order ? 1024 : 64), 0, st, (const unsigned int*)b->ticks, b->cost, b->n, b->order, b->step_gen);
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;

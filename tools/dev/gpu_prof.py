@@ -12,7 +12,7 @@ names = ["newton Mv,Jv products (+load/store)", "kinematics", "com_pos + newton 
 import os
 lib = native.load(os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyobatch_prof.so"))
 dev = torch.device("cuda:0")
-for integ in (0,):
+for integ in ((1,) if "rk4" in sys.argv else (0,)):
   for dtype, dn in ((native.MYO_F32, "f32"), (native.MYO_F64, "f64"))[:(1 if len(sys.argv) > 3 and sys.argv[3] == "f32" else 2)]:
     cm = compile_model(synthetic_hand(), integrator=integ)
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

@@ -177,7 +177,7 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage: position of every path element (con[] is dead until the collision stage) */
 /* tendon stage: HP wrap results (7 per geom wrap) behind the T path points, running on through the limit-row and efc_* arrays */
 #define S_TWRES(s, nwrap) (reinterpret_cast<HP*>(reinterpret_cast<char*>((s).con) + ((3 * (size_t)(nwrap) * sizeof(T) + 7) & ~(size_t)7)))
-#define S_ACT_GF(s) ((s).Ma)   /* gear * actuator force (actuation stage, NU_MAX entries through Ma, grad: the body velocities that live there are dead after efc_reference) */
+#define S_ACT_GF(s) (static_cast<T*>((s).Ma))   /* gear * actuator force (actuation stage, NU_MAX entries through Ma, grad: the body velocities that live there are dead after efc_reference) */
 #define S_KTMP(s) (reinterpret_cast<HP*>((s).con))   /* HP [2][MYO_NJ_MAX * 3] */
 #define S_XANCHOR(s) ((s).efc_jar)
 #define S_XAXIS(s) ((s).efc_jv)

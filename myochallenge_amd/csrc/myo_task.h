@@ -205,19 +205,17 @@ DEV void task_obs_reward(const DevModel<T>& M, const TaskDev& K, Scratch<T, NC>&
 DEV int task_nobs(const TaskDev& K, int na) { return K.kind == MYO_TASK_REORIENT_K ? 2 * K.n_hand + 18 + na : K.n_hand + 24 + na; }
 
 // ---- env.step(a) without the VecEnv bookkeeping
-// An env step may be run in two parts by two workgroups (the launch's makespan, see k_step): MYO_STEP_FIRST = target update,
-// ctrl, the first k1 substeps; MYO_STEP_SECOND = ctrl again (a pure function of the action), the remaining substeps, observation
-// and reward.  Everything a substep hands to the next one is in the env record (load_env / store_env), so the split is bit-exact.
-#define MYO_STEP_WHOLE 0
-#define MYO_STEP_FIRST 1
-#define MYO_STEP_SECOND 2
+// An env step may be run in parts by several workgroups (the launch's makespan, see k_step): substeps [k_lo, k_hi) of the
+// frame_skip; the part that starts at 0 also moves the targets, every part recomputes ctrl (a pure function of the action), the
+// part that ends at frame_skip also makes observation and reward (k_hi < 0 = frame_skip).  Everything a substep hands to the
+// next one is in the env record (load_env / store_env), so the split is bit-exact.
 template <typename T, int NC>
 DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, const float* action /* may be null = zeros */,
-                        int part = MYO_STEP_WHOLE, int k1 = 0) {
+                        int k_lo = 0, int k_hi = -1) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (lane == 0 && K.kind != MYO_TASK_REORIENT_K && part != MYO_STEP_SECOND) {
+    if (lane == 0 && K.kind != MYO_TASK_REORIENT_K && k_lo == 0) {
       if (s.which_task != 0) {
         const double dt = (double)K.frame_skip * M.h_timestep;
         const double sign = s.which_task == 1 ? -1.0 : 1.0;
@@ -242,9 +240,9 @@ DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
     }
   }
   SYNC();
-  const int k_lo = part == MYO_STEP_SECOND ? k1 : 0, k_hi = part == MYO_STEP_FIRST ? k1 : K.frame_skip;
-  for (int k = k_lo; k < k_hi; ++k) mj_step(M, K, s);
-  if (part == MYO_STEP_FIRST) return;
+  const int k_end = (k_hi < 0 || k_hi > K.frame_skip) ? K.frame_skip : k_hi;
+  for (int k = k_lo; k < k_end; ++k) mj_step(M, K, s);
+  if (k_end < K.frame_skip) return;
   check_state(M, s, 0);            // a non-finite value produced by the LAST advance must not leave through obs / reward
   kinematics(M, s);
   task_obs_reward(M, K, s);
@@ -521,12 +519,12 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
 template <typename T, int NC>
 DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
-                  float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int part = MYO_STEP_WHOLE, int k1 = 0) {
+                  float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int k_lo = 0, int k_hi = -1) {
   WAVE_FN
   const int nobs = task_nobs(K, M.na);
   load_env(M, K, L, rec, s);
-  task_step_core(M, K, s, act + (size_t)env * M.nu, part, k1);
-  if (part == MYO_STEP_FIRST) { store_env(M, K, L, rec, s, 1); return; }
+  task_step_core(M, K, s, act + (size_t)env * M.nu, k_lo, k_hi);
+  if (k_hi >= 0 && k_hi < K.frame_skip) { store_env(M, K, L, rec, s, 1); return; }
   // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
   // an error of the batch: the env ends its episode with done = 1, reward 0, zero reward components except `done`,
   // is reset at once, and both the terminal and the returned observation are the (finite) reset observation, so that

@@ -549,6 +549,8 @@ extern "C" int myo_model_size(const myo_model* m, const char* n) {
 }
 
 // ------------------------------------------------------------------------------------------ batch
+#define MYO_PARTS_MAX 5
+struct StepPlan { int nparts; int k[MYO_PARTS_MAX + 1]; };      // part p = substeps [k[p], k[p+1]); nparts = 1: whole steps
 struct myo_batch;
 struct myo_batch {
   int n, device, dtype, nobs;
@@ -573,7 +575,7 @@ struct myo_batch {
   // published; step_gen[0] = g, advanced on the stream after every step.  split_k1 = substeps in the first part (0: whole steps).
   int* part_state;
   int* step_gen;
-  int split_k1;
+  StepPlan plan;
   int timing;
   double ms_sum;
   int ms_cnt;
@@ -815,16 +817,52 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   if (m->integrator == 1) {        // RK4 stage storage, one RkScratch per env (global memory)
     void* w = nullptr;
     const size_t each = dtype == MYO_F64 ? sizeof(RkScratch<double>) : sizeof(RkScratch<float>);
-    rc |= be_malloc(&w, each * (size_t)n_envs * 2);      // indexed by workgroup: a two-part step launches 2 n of them
+    rc |= be_malloc(&w, each * (size_t)n_envs * MYO_PARTS_MAX);      // indexed by workgroup: a step in P parts launches P n of them
     b->K.rk_ws = w;
     if (w) b->allocs.push_back(w);
   }
-  b->order = nullptr; b->cost = nullptr; b->ticks = nullptr; b->part_state = nullptr; b->step_gen = nullptr; b->split_k1 = 0;
+  b->order = nullptr; b->cost = nullptr; b->ticks = nullptr; b->part_state = nullptr; b->step_gen = nullptr; b->plan.nparts = 1; b->plan.k[0] = 0; b->plan.k[1] = cfg ? cfg->frame_skip : 0;
+  {
+    // the parts of an env step (k_step): MYO_STEP_SPLIT = "7,3" (substeps per part; "0" or one number = whole steps; A/B switch
+    // of the tools and of the bit-identity tests).  The emulation build runs the parts one after the other through the record.
+    StepPlan pl; pl.nparts = 0; pl.k[0] = 0;
+    if (b->K.kind && cfg->frame_skip >= 2) {
+      const char* sp = getenv("MYO_STEP_SPLIT");
+      if (sp) {
+        int acc = 0;
+        for (const char* q = sp; *q && pl.nparts < MYO_PARTS_MAX;) {
+          const int v = atoi(q);
+          if (v <= 0) break;
+          acc += v; pl.k[++pl.nparts] = acc;
+          while (*q && *q != ',') ++q;
+          if (*q == ',') ++q;
+        }
+        if (acc != cfg->frame_skip) pl.nparts = 0;
+      } else {
+        // parts of decreasing length, 4 : 3 : 2 : 1 of the frame_skip (measured at 4096 envs, frame_skip 10, k_step ms:
+        // whole 2.73, 7+3 2.33, 6+3+1 2.27, 5+3+2 2.27, 4+3+2+1 2.24, 5+3+1+1 2.25, 3+3+2+1+1 2.26)
+        const int f = cfg->frame_skip, np = f < 4 ? f : 4;
+        static const int w[4] = {4, 3, 2, 1};
+        int wsum = 0, acc = 0;
+        for (int i = 0; i < np; ++i) wsum += w[i];
+        for (int i = 0; i < np; ++i) {
+          int len = i == np - 1 ? f - acc : (f * w[i] + wsum / 2) / wsum;
+          const int room = f - acc - (np - 1 - i);        // every later part keeps at least one substep
+          len = len < 1 ? 1 : (len > room ? room : len);
+          acc += len; pl.k[i + 1] = acc;
+        }
+        pl.nparts = np;
+      }
+    }
+    if (pl.nparts >= 2) b->plan = pl;
+  }
 #ifndef MYO_EMU
   if (!rc) { rc |= (int)hipEventCreate(&b->ev0); rc |= (int)hipEventCreate(&b->ev1); }
   {
-    const char* e = getenv("MYO_STEP_ORDER");        // "0": launch the envs in index order (A/B switch of the tools)
-    if (!rc && b->K.kind && !(e && e[0] == '0')) {
+    // launch order of the env steps (k_step_order): opt-in, MYO_STEP_ORDER=1 — worth 3 % on whole-step launches, nothing once the
+    // steps run in parts (2.239 vs 2.234 ms), where its 1024-thread sort per step costs what it gains
+    const char* e = getenv("MYO_STEP_ORDER");
+    if (!rc && b->K.kind && e && e[0] == '1') {
       std::vector<int> ident(n_envs);
       for (int i = 0; i < n_envs; ++i) ident[i] = i;
       void *po = nullptr, *pc = nullptr, *pt = nullptr;
@@ -835,16 +873,14 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
       if (!rc) { rc |= be_h2d(po, ident.data(), sizeof(int) * (size_t)n_envs); rc |= (int)hipMemset(pc, 0, sizeof(float) * (size_t)n_envs); rc |= (int)hipMemset(pt, 0, sizeof(unsigned) * (size_t)n_envs); }
       if (!rc) { b->order = (int*)po; b->cost = (float*)pc; b->ticks = (unsigned*)pt; }
     }
-    const char* sp = getenv("MYO_STEP_SPLIT");       // substeps in the first part; "0": whole steps (A/B switch of the tools)
-    int k1 = sp ? atoi(sp) : (cfg ? (7 * cfg->frame_skip + 5) / 10 : 0);
-    if (!rc && b->K.kind && cfg->frame_skip >= 2 && k1 >= 1 && k1 < cfg->frame_skip) {
+    if (!rc && b->plan.nparts >= 2) {
       void *ps = nullptr, *pg = nullptr;
       rc |= be_malloc(&ps, sizeof(int) * (size_t)n_envs); rc |= be_malloc(&pg, sizeof(int) * 4);
       if (ps) b->allocs.push_back(ps);
       if (pg) b->allocs.push_back(pg);
-      const int one[4] = {1, 0, 0, 0};
-      if (!rc) { rc |= (int)hipMemset(ps, 0, sizeof(int) * (size_t)n_envs); rc |= be_h2d(pg, one, sizeof one); }
-      if (!rc) { b->part_state = (int*)ps; b->step_gen = (int*)pg; b->split_k1 = k1; }
+      const int zero[4] = {0, 0, 0, 0};
+      if (!rc) { rc |= (int)hipMemset(ps, 0, sizeof(int) * (size_t)n_envs); rc |= be_h2d(pg, zero, sizeof zero); }
+      if (!rc) { b->part_state = (int*)ps; b->step_gen = (int*)pg; } else b->plan.nparts = 1;
     }
   }
 #endif
@@ -922,7 +958,7 @@ __global__ void __launch_bounds__(1024) k_step_order(const unsigned int* __restr
   __shared__ float s_lo[16], s_hi[16];
   __shared__ unsigned int s_cnt[256], s_off[256];
   const int t = threadIdx.x;
-  if (step_gen && t == 0) step_gen[0] += 1;          // the next launch is the next generation of the two-part protocol
+  if (step_gen && t == 0) step_gen[0] += 1;          // the next launch is the next generation of the part protocol
   if (!order) return;
   float lo = 3.4e38f, hi = 0.f;
   for (int i = t; i < n; i += 1024) {
@@ -944,30 +980,34 @@ __global__ void __launch_bounds__(1024) k_step_order(const unsigned int* __restr
   __syncthreads();
   for (int i = t; i < n; i += 1024) order[atomicAdd(&s_off[255 - (int)((cost[i] - lo) * scale)], 1u)] = i;
 }
-// ---- two-part env steps.  Even in the best order a slot's two jobs add up their spreads and the launch ends with one job-long
-// tail on a draining chip.  The tail is as long as the LAST job of a slot: so an env step is cut in two jobs, the first k1
-// substeps (blocks 0 .. n-1) and the rest + observation / reward (blocks n .. 2n-1), handed over through the env record in
-// HBM.  In dispatch order every first part is placed before any second part, the long jobs run with the chip full, and what
-// drains at the end is the short jobs' tail (simulated with the measured duration spread: makespan 2.50 -> 2.20 ms for 7 + 3).
-// Protocol (placement- and dispatch-order-independent; MI355X_MICROARCH.md "inter-workgroup visibility"): the first-part
-// workgroup CLAIMS the env (agent-scope CAS 2g-2 -> 2g-1), runs, stores the record, drains its stores, agent-scope release
-// fence, drains again, publishes 2g with an agent-scope relaxed store.  The second-part workgroup polls (relaxed, agent scope):
-// 2g -> ONE agent acquire fence, then plain loads of the record; 2g-1 -> the producer is RUNNING somewhere: sleep and poll again;
-// 2g-2 -> its first part has not been placed yet: claim it and run the whole step here (the late first-part block then finds
-// the claim taken and exits) — no workgroup ever waits for one that is not running.
+// ---- env steps in parts.  Even in the best order a slot's two jobs add up their spreads and the launch ends with one job-long
+// tail on a draining chip.  The tail is as long as the LAST job of a slot: so an env step is cut into P jobs of decreasing
+// length (default 7 + 3 substeps), blocks p n .. (p+1) n - 1 running part p, handed over through the env record in HBM.  In
+// dispatch order every part p is placed before any part p + 1, the long jobs run with the chip full, and what drains at the
+// end is the short jobs' tail (simulated with the measured duration spread: makespan 2.50 -> 2.20 ms for 7 + 3; measured
+// 2.82 -> 2.45 ms, 2.39 with the launch order above; the states are bit-identical).
+// Protocol (placement- and dispatch-order-independent; MI355X_MICROARCH.md "inter-workgroup visibility").  part_state[env] =
+// 16 g + 2 q: parts < q of step g are published; + 1: part q is claimed and running.  A workgroup of part p polls (relaxed,
+// agent scope): a state past "part p claimed" -> nothing left to do, exit; 16 g + 2 q with q <= p -> claim q (agent-scope CAS)
+// and run parts q .. p back to back (q < p only if an earlier part's block has not been placed yet: that block then finds
+// its part taken and exits); 16 g + 2 q + 1 with q < p -> the producer is RUNNING somewhere: sleep and poll again — no
+// workgroup ever waits for one that is not running.  Taking over a record another workgroup published: ONE agent acquire fence
+// after the poll, then plain loads.  Publishing: store the record, drain the stores, agent release fence, drain, relaxed
+// agent-scope store of the new state (16 (g + 1) after the last part: the next launch's generation).
 template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, const float* act,
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info, unsigned char* bad_state,
                                              const int* __restrict__ order, unsigned int* __restrict__ ticks,
-                                             int* part_state, const int* __restrict__ step_gen, int k1) {
+                                             int* part_state, const int* __restrict__ step_gen, StepPlan plan) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
-  const int nenv = part_state ? (int)(gridDim.x >> 1) : (int)gridDim.x;
-  const int second = (int)blockIdx.x >= nenv;
-  const int slot = (int)blockIdx.x - second * nenv;
+  const int nparts = part_state ? plan.nparts : 1;
+  const int nenv = (int)gridDim.x / nparts;
+  const int p = (int)blockIdx.x / nenv;
+  const int slot = (int)blockIdx.x - p * nenv;
   const int env = order ? order[slot] : slot;
   const unsigned long long t_start = ticks ? wall_clock64() : 0ull;
 #ifdef MYO_WGTIME
@@ -977,56 +1017,44 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
   if (threadIdx.x == 0) { for (int k = 0; k < MYO_NPROF; ++k) s.prof[k] = 0; s.prof_t = clock64(); }
   __syncthreads();
 #endif
-  int part = MYO_STEP_WHOLE;
+  int q = 0;                                   // first part this workgroup runs
   if (part_state) {
-    const int g2 = 2 * step_gen[0];
+    const int base = 16 * step_gen[0];
     int* st = part_state + env;
-    int mode = 0;                              // decided by lane 0: 1 = first part, 2 = second part, 3 = whole step here, 0 = nothing to do
+    int from = -1;                             // decided by lane 0: the part to start from, -1 = nothing to do
     if (threadIdx.x == 0) {
-      if (!second) {
-        int expect = g2 - 2;
-        mode = __hip_atomic_compare_exchange_strong(st, &expect, g2 - 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-      } else {
-        for (;;) {
-          const int v = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (v == g2) { mode = 2; break; }
-          if (v == g2 - 2) {
-            int expect = g2 - 2;
-            if (__hip_atomic_compare_exchange_strong(st, &expect, g2 - 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { mode = 3; break; }
-            continue;
-          }
-          if (v != g2 - 1) { mode = 0; break; }   // not a state of this generation: leave the env alone (never reached in a well-formed run)
-          __builtin_amdgcn_s_sleep(32);
+      for (;;) {
+        const int v = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int j = v - base;
+        if (j < 0 || j > 2 * p) break;          // part p is claimed or done (or the state belongs to another generation): exit
+        if ((j & 1) == 0) {
+          int expect = v;
+          if (__hip_atomic_compare_exchange_strong(st, &expect, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { from = j >> 1; break; }
+          continue;
         }
+        __builtin_amdgcn_s_sleep(32);           // an earlier part is running
       }
     }
-    mode = __builtin_amdgcn_readfirstlane(mode);
-    if (mode == 0) return;
-    if (mode == 2) {
+    from = __builtin_amdgcn_readfirstlane(from);
+    if (from < 0) return;
+    q = from;
+    if (q > 0) {                               // the record was published by another workgroup of this launch
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    part = mode == 1 ? MYO_STEP_FIRST : (mode == 2 ? MYO_STEP_SECOND : MYO_STEP_WHOLE);
-    if (mode == 3) {
-      env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
-      if (threadIdx.x == 0) __hip_atomic_store(st, g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, part, k1);
-      if (mode == 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(st, g2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
+    const int last = p == nparts - 1;
+    env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, plan.k[q], last ? -1 : plan.k[p + 1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (!last) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      __hip_atomic_store(st, last ? base + 16 : base + 2 * p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
   }
-  if (ticks && threadIdx.x == 0) { const unsigned int d = (unsigned int)(wall_clock64() - t_start); if (part == MYO_STEP_SECOND) ticks[env] += d; else ticks[env] = d; }
+  if (ticks && threadIdx.x == 0) { const unsigned int d = (unsigned int)(wall_clock64() - t_start); if (q > 0) ticks[env] += d; else ticks[env] = d; }
 #ifdef MYO_WGTIME
   if (threadIdx.x == 0 && blockIdx.x < 16384) g_wg_time[2 * blockIdx.x + 1] = wall_clock64();
 #endif
@@ -1287,17 +1315,21 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
   if (!b->K.kind) return fail(MYO_E_STATE, "batch has no task layer");
 #ifdef MYO_EMU
   (void)stream;
-  if (b->dtype == MYO_F64) FOR_ENVS_F64(env_step<double>(b->Md, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
-  else FOR_ENVS_F32(env_step<float>(b->Mf, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state))
+  // (the parts of the step plan one after the other, each through the env record like the workgroups of k_step)
+  for (int p = 0; p < b->plan.nparts; ++p) {
+    const int k_lo = b->plan.k[p], k_hi = p == b->plan.nparts - 1 ? -1 : b->plan.k[p + 1];
+    if (b->dtype == MYO_F64) FOR_ENVS_F64(env_step<double>(b->Md, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, k_lo, k_hi))
+    else FOR_ENVS_F32(env_step<float>(b->Mf, b->K, b->L, rec, *s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, k_lo, k_hi))
+  }
 #else
   hipStream_t st = (hipStream_t)stream;
   BIND_OR_RETURN(b, st)
   timing_begin(b, st);
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV, NCV>), dim3(b->part_state ? 2 * b->n : b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->split_k1);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV, NCV>), dim3(b->plan.nparts * b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->plan);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->part_state ? 2 * b->n : b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->split_k1))
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->plan.nparts * b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->plan))
   timing_end(b, st);
   if (b->order || b->step_gen) hipLaunchKernelGGL(k_step_order, dim3(1), dim3(b->order ? 1024 : 64), 0, st, (const unsigned int*)b->ticks, b->cost, b->n, b->order, b->step_gen);
   LAUNCH_CHECK(b)

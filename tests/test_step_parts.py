@@ -1,0 +1,96 @@
+"""An env step run in parts (k_step's launch plan: substeps 4 + 3 + 2 + 1 handed from workgroup to workgroup through the env
+record) must give the BITS of the whole step: same observations, rewards, dones, terminal observations and states, for both
+steppers and both integrators, through resets and P2's per-episode ball draws.  The emulation build runs the parts one after
+the other through the record (same load_env / store_env code); the GPU test adds the claim / publish protocol of the real
+launch (tests of the physics itself: test_emu_parity.py, test_gpu_parity.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import Mem
+from myochallenge_amd import native
+from myochallenge_amd.envs.config import make_task_cfg
+from myochallenge_amd.model import compile_model
+
+
+def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, horizon=4):
+    """Observations, rewards, dones, terminal observations of `nsteps` steps + the final state, with MYO_STEP_SPLIT = split."""
+    old = {k: os.environ.get(k) for k in ("MYO_STEP_SPLIT", "MYO_STEP_ORDER")}
+    try:
+        if split is None:
+            os.environ.pop("MYO_STEP_SPLIT", None)
+        else:
+            os.environ["MYO_STEP_SPLIT"] = split
+        if order is None:
+            os.environ.pop("MYO_STEP_ORDER", None)
+        else:
+            os.environ["MYO_STEP_ORDER"] = order
+        mem = Mem(lib)
+        tc = make_task_cfg(env_name, cm, drop_th=1.3, max_episode_steps=horizon)
+        b = native.Batch(native.Model(cm, lib), tc, n, 0, seed, dtype)       # the plan is read when the batch is created
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    nobs = b.obs_dim
+    obs = mem.zeros((n, nobs), np.float32)
+    rew, done, trunc = mem.zeros(n, np.float32), mem.zeros(n, np.uint8), mem.zeros(n, np.uint8)
+    term, comps, ep = mem.zeros((n, nobs), np.float32), mem.zeros((n, 8), np.float32), mem.zeros((n, 2), np.float32)
+    b.reset(None, obs)
+    rng = np.random.RandomState(3)
+    out = [mem.host(obs).copy()]
+    for _ in range(nsteps):
+        a = np.clip(rng.normal(0, 0.5, (n, 39)), -1.2, 1.2).astype(np.float32)
+        b.step(mem.arr(a, np.float32), obs, rew, done, trunc, term, comps, ep)
+        out += [mem.host(x).copy() for x in (obs, rew, done, trunc, term, comps, ep)]
+    qpos, qvel, act, time = mem.zeros((n, cm.size("nq"))), mem.zeros((n, cm.size("nv"))), mem.zeros((n, cm.size("na"))), mem.zeros(n)
+    b.get_state(qpos, qvel, act, time)
+    out += [mem.host(x).copy() for x in (qpos, qvel, act, time)]
+    b.close()
+    return out
+
+
+def _same_bits(a, b):
+    assert len(a) == len(b)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x.dtype == y.dtype and x.tobytes() == y.tobytes(), f"array {i} differs (max abs diff {np.abs(x.astype(float) - y.astype(float)).max()})"
+
+
+@pytest.mark.parametrize("dtype", [native.MYO_F64, native.MYO_MIXED], ids=["f64", "mixed"])
+@pytest.mark.parametrize("integ", [0, 1], ids=["euler", "rk4"])
+def test_step_parts_give_the_whole_steps_bits_on_emulation(emu_lib, models, dtype, integ):
+    cm = compile_model(models["hand"], integrator=integ)
+    n, steps = 3, (14 if integ == 0 else 5)
+    whole = _rollout(emu_lib, cm, "CustomMyoBaodingBallsP2", dtype, n, steps, "0")
+    _same_bits(whole, _rollout(emu_lib, cm, "CustomMyoBaodingBallsP2", dtype, n, steps, None))        # the default plan
+    if integ == 0:
+        _same_bits(whole, _rollout(emu_lib, cm, "CustomMyoBaodingBallsP2", dtype, n, steps, "7,3"))
+        _same_bits(whole, _rollout(emu_lib, cm, "CustomMyoBaodingBallsP2", dtype, n, steps, "1,1,1,1,6"))
+    assert any(w.dtype == np.uint8 and w.any() for w in whole), "the rollout should cross an episode end (TimeLimit 4)"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [native.MYO_F64, native.MYO_MIXED], ids=["f64", "mixed"])
+def test_step_parts_give_the_whole_steps_bits_on_gpu(hip_lib, models, dtype):
+    """512 envs (more workgroups than one part's share of the slots is not needed: the protocol is per env), 30 steps; the
+    opt-in launch order on top."""
+    cm = compile_model(models["hand"], integrator=0)
+    whole = _rollout(hip_lib, cm, "CustomMyoBaodingBallsP2", dtype, 512, 30, "0")
+    _same_bits(whole, _rollout(hip_lib, cm, "CustomMyoBaodingBallsP2", dtype, 512, 30, None))
+    _same_bits(whole, _rollout(hip_lib, cm, "CustomMyoBaodingBallsP2", dtype, 512, 30, "5,3,1,1", order="1"))
+    assert any(w.dtype == np.uint8 and w.any() for w in whole)
+
+
+@pytest.mark.gpu
+def test_step_parts_rk4_and_full_batch_on_gpu(hip_lib, models):
+    """RK4 (its stage storage is per workgroup) and a batch that fills the chip twice: 4096 envs, every slot busy, parts of
+    different envs interleaved on every CU."""
+    cm = compile_model(models["hand"], integrator=1)
+    _same_bits(_rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 256, 6, "0"),
+               _rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 256, 6, None))
+    cm = compile_model(models["hand"], integrator=0)
+    _same_bits(_rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 4096, 12, "0"),
+               _rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 4096, 12, None))

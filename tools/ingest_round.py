@@ -8,7 +8,7 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R, P = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
-TAG = os.environ.get("ROUND", "r02")
+TAG = os.environ.get("ROUND", "r03")
 
 
 def main():
@@ -25,12 +25,22 @@ def main():
     new["hbm_bytes_per_launch"] = (new["FETCH_SIZE_KB"] + new["WRITE_SIZE_KB"]) * 1024
     new["hbm_bytes_per_launch_fetch_doubled"] = (2 * new["FETCH_SIZE_KB"] + new["WRITE_SIZE_KB"]) * 1024
     new.update(vals)
+    # the library build the counters were taken on (bench.py attaches them only to that build)
+    try:
+        new["build_id"] = open(os.path.join(R, "build_id.txt")).read().strip()
+    except OSError:
+        new["build_id"] = None
+    if "SQ_THREAD_CYCLES_VALU" in new and "SQ_ACTIVE_INST_VALU" in new and new["SQ_ACTIVE_INST_VALU"] > 0:
+        # active lanes per issued VALU instruction-cycle / 64
+        new["lane_utilisation"] = new["SQ_THREAD_CYCLES_VALU"] / (64.0 * new["SQ_ACTIVE_INST_VALU"])
     json.dump(new, open(os.path.join(P, TAG + "_pmc.json"), "w"), indent=1)
     print("k_step launches", n, "traffic MB", new["hbm_bytes_per_launch"] / 1e6, "VALU M", new["SQ_INSTS_VALU"] / 1e6,
           "wait", new["SQ_WAIT_ANY"] / new["SQ_WAVE_CYCLES"])
     for a, b in (("pmc_kstep.txt", TAG + "_pmc_kstep_mixed_4096.txt"), ("pmc_gemm.txt", TAG + "_pmc_mfma_gemm.txt"),
                  ("stage_shares.txt", TAG + "_stage_shares.txt"), ("bench_kernel_stats.csv", TAG + "_bench_kernel_stats.csv"),
-                 ("drift.log", TAG + "_drift_32streams.log"), ("pmc_mfma_kstep_f64.txt", TAG + "_pmc_mfma_kstep_f64.txt")):
+                 ("drift.log", TAG + "_drift_32streams.log"), ("pmc_mfma_kstep_f64.txt", TAG + "_pmc_mfma_kstep_f64.txt"),
+                 ("stage_shares_rk4.txt", TAG + "_stage_shares_rk4.txt"), ("wg_timeline_parts.log", TAG + "_wg_timeline_parts.log"),
+                 ("wg_timeline_whole.log", TAG + "_wg_timeline_whole_steps.log"), ("gpu_tests.log", TAG + "_gpu_tests.log")):
         if os.path.exists(os.path.join(R, a)):
             shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}

@@ -7,6 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/round
 mkdir -p $OUT
 export PYTHONPATH=$ROOT
+python3 -c "from myochallenge_amd import native; print(native.load().build_id)" > $OUT/build_id.txt
 cd /tmp && export TMPDIR=/tmp
 # 1. the bench line itself (with the CPU baseline leg)
 python3 $ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err      # includes the f64 / RK4 variants and the CPU leg
@@ -17,22 +18,26 @@ find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_sta
 grep -v "^[WIE]2026" /tmp/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
 # 3. PMC counters of k_step inside the same command, one --pmc pass per set (no other tracing)
 : > $OUT/pmc_kstep.txt
-for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_LDS_BANK_CONFLICT" "GRBM_GUI_ACTIVE"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INST_LEVEL_SMEM SQ_LDS_BANK_CONFLICT" "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32" "GRBM_GUI_ACTIVE"; do
   rm -rf /tmp/pmc
   timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
-  python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_kstep.txt
+  python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" >> $OUT/pmc_kstep.txt
 done
 # 3b. matrix-core activity of the PPO side (north_star asks for MFMA-busy against peak): hipBLASLt GEMM kernels
 rm -rf /tmp/pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "Cijk" > $OUT/pmc_gemm.txt
-python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" >> $OUT/pmc_gemm.txt
+python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" >> $OUT/pmc_gemm.txt
 # 3c. matrix cores in the fp64 stepper (blocked Cholesky)
 rm -rf /tmp/pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 --dtype f64 > /tmp/pmc.log 2>&1
-python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step" > $OUT/pmc_mfma_kstep_f64.txt
+python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" > $OUT/pmc_mfma_kstep_f64.txt
 # 4. stage shares (instrumented build; shares only)
 PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_prof.py > $OUT/stage_shares.txt 2>&1
+PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_prof.py 4096 $ROOT/tools/dev/libmyobatch_prof.so f32 rk4 > $OUT/stage_shares_rk4.txt 2>&1
+# 4b. workgroup timeline of one k_step launch: whole steps against the step plan (slots busy, makespan)
+MYO_STEP_SPLIT=0 PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_wgtime.py $ROOT/tools/dev/lib_wgtime.so 4096 1 > $OUT/wg_timeline_whole.log 2>&1
+PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_wgtime.py $ROOT/tools/dev/lib_wgtime.so 4096 4 > $OUT/wg_timeline_parts.log 2>&1
 # 5. other configurations (BASELINE.json configs / variants)
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --dtype f64 > $OUT/bench_f64.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --integrator rk4 > $OUT/bench_rk4.json 2>/dev/null
@@ -42,4 +47,6 @@ python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoReori
 python3 $ROOT/tools/bench_reorient.py > $OUT/bench_reorient_lstm.json 2>/dev/null
 # 6. trajectory drift tables of both steppers (32 action streams x 200 env steps) and k_step time against the batch size
 python3 $ROOT/tools/dev/gpu_drift.py > $OUT/drift.log 2>&1
+# 7. the GPU test suite on the same library
+cd $ROOT && python3 -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1
 echo done

@@ -332,6 +332,31 @@ typedef struct myo_ppo_mlp_desc {
 long long myo_ppo_mlp_workspace_bytes(int B, int obs_dim, int act_dim, int hidden, long long G);
 int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream);
 
+/* One env step's policy call of the rollout for the same MLP actor-critic (collect_rollouts: ActorCriticPolicy.forward,
+ * DiagGaussianDistribution.sample / log_prob, RolloutBuffer.add; /root/reference/src/train/trainer.py:66-71 -> agent.learn) in one
+ * launch: rows of the policy input obs f32[N,O] -> both trunks and heads on the matrix cores -> actions = mean + exp(log_std) *
+ * N(0,1) (Philox, the counters of myo_rollout_sample), log pi, value -> row *t_idx of act_buf [T,N,A], val_buf, logp_buf [T,N]
+ * (+ obs_buf [T,N,O] if not NULL), clipped f32[N,A] for the env.  It replaces myo_rollout_policy_input + the trunk / head GEMMs
+ * + myo_rollout_sample.  The bf16 weight images it reads live in `workspace` (myo_ppo_mlp_rollout_workspace_bytes, caller-owned);
+ * myo_ppo_mlp_rollout_refresh rebuilds them from `params` and has to run after every change of the parameters (once per
+ * PPO update).  N must be a multiple of 32; other limits as myo_ppo_mlp_step. */
+typedef struct myo_ppo_mlp_rollout_desc {
+  const float* obs;
+  int32_t N, O, A, hidden;
+  const float* params;
+  int64_t off_W1[2], off_b1[2], off_W2[2], off_b2[2], off_Wh[2], off_bh[2], off_log_std;
+  uint64_t seed;
+  uint64_t* draw_counter;
+  const int32_t* t_idx;
+  float *obs_buf, *act_buf, *val_buf, *logp_buf, *clipped;
+  int32_t deterministic;
+  void* workspace;
+  int64_t workspace_bytes;
+} myo_ppo_mlp_rollout_desc;
+long long myo_ppo_mlp_rollout_workspace_bytes(int obs_dim, int act_dim, int hidden);
+int myo_ppo_mlp_rollout_refresh(const myo_ppo_mlp_rollout_desc* d, void* stream);
+int myo_ppo_mlp_rollout(const myo_ppo_mlp_rollout_desc* d, void* stream);
+
 /* clip_grad_norm_(max_norm) followed by one torch.optim.Adam step over a flat fp32 parameter vector
  * (what RecurrentPPO.train does per minibatch; /root/reference/src/train/trainer.py:66-71, SB3 Adam
  * eps 1e-5).  g is multiplied by grad_scale first (1/world after an all-reduce SUM).  step: dev

@@ -436,6 +436,158 @@ __global__ void __launch_bounds__(256, 2) k_mlp_fwdbwd(MlpArgs P) {
   MLP_STAMP(8)
 }
 
+// ---- rollout inference + action sampling in one launch (collect_rollouts' policy call: SB3 ActorCriticPolicy.forward ->
+// DiagGaussianDistribution.sample / log_prob, RolloutBuffer.add): the forward half of k_mlp_fwdbwd on the rows of the policy
+// input itself (no index gather), then, for the actor's blocks, the Philox draws of k_sample_actions (same counters: env, group
+// of four actions, draw) on the fp32 head output — the arithmetic the optimizer step's forward repeats, so the first epoch's
+// probability ratio is exp(0) up to the bf16 weights having moved.  The critic's blocks write the value.  Replaces, per env
+// step, myo_rollout_policy_input + two batched trunk GEMMs + two bias/ReLU kernels + two head GEMMs + myo_rollout_sample.
+struct MlpPolicyArgs {
+  const float* obs;                                 // [N][O] policy input (normalised observation)
+  const float* log_std;
+  const unsigned short *W1p, *W2, *Whp;             // bf16 images of k_mlp_prep
+  const float* bias;
+  float* obs_buf;                                   // [T][N][O] rollout buffer (row t_idx written) or null
+  float *act_buf, *val_buf, *logp_buf, *clipped;    // [T][N][A], [T][N], [T][N], [N][A]
+  const int* t_idx;
+  unsigned long long* draw_counter;                 // [2]: [0] = draw of this step, [1] <- [0] + 1 (committed by k_rollout_advance)
+  unsigned long long seed;
+  int N, O, A, OP, deterministic;
+};
+#define MLP_POLICY_LDS (MLP_BM * MLP_XS * 2 + MLP_BM * MLP_HS * 2 + 128 * 4)
+
+// forward epilogue: bias + ReLU -> bf16 -> row-major LDS image (the next layer's A operand)
+template <int MT>
+__device__ __forceinline__ void mlp_store_act_lds(const myo_f32x4 (&acc)[MT][4], const float (&bb)[4], unsigned short* Hs, int n0, int lm, int lq) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + 16 * nt + lm, m = 16 * mt + 4 * lq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Hs[(m + r) * MLP_HS + n] = mlp_f2bf(fmaxf(acc[mt][nt][r] + bb[nt], 0.f));
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_mlp_policy(MlpPolicyArgs P) {
+  constexpr int H = MLP_H, XS = MLP_XS, HS = MLP_HS, SOS = MLP_SOS, BM = MLP_BM, MT = BM / 16, RW = BM / 4;
+  extern __shared__ __align__(16) unsigned char mlp_smem[];
+  unsigned short* Xs = reinterpret_cast<unsigned short*>(mlp_smem);               // [BM][XS] bf16; later So fp32 [BM][SOS]
+  float* So = reinterpret_cast<float*>(mlp_smem);
+  unsigned short* Hs = Xs + BM * XS;                                              // [BM][HS]: H1, then H2
+  float* s_ls = reinterpret_cast<float*>(Hs + BM * HS);                           // [64] log_std, [64] exp(log_std)
+  static_assert(BM * MLP_SOS * 4 <= BM * MLP_XS * 2, "the head output tile fits where X was");
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63, lm = lane & 15, lq = lane >> 4;
+  const int net = blockIdx.y, r0 = blockIdx.x * BM, N = P.N, O = P.O, A = P.A, OP = P.OP;
+  const int n0 = 64 * w;
+  const size_t tt = (size_t)(*P.t_idx);
+  if (t < A) { const float ls = P.log_std[t]; s_ls[t] = ls; s_ls[64 + t] = __expf(ls); }
+  const float* b1 = P.bias + net * H; const float* b2 = P.bias + 2 * H + net * H; const float* bh = P.bias + 4 * H + net * MLP_APM;
+  float bb1[4], bb2[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) { bb1[nt] = b1[n0 + 16 * nt + lm]; bb2[nt] = b2[n0 + 16 * nt + lm]; }
+  myo_bf16x8 bw[8][4];
+  {
+    const unsigned short* W1 = P.W1p + (size_t)net * H * OP;
+    if (OP == 96) mlp_load_w<3>(bw, W1, OP, n0, lm, lq);
+    else if (OP == 128) mlp_load_w<4>(bw, W1, OP, n0, lm, lq);
+    else if (OP == 64) mlp_load_w<2>(bw, W1, OP, n0, lm, lq);
+    else mlp_load_w<1>(bw, W1, OP, n0, lm, lq);
+  }
+  {   // rows of the policy input -> bf16 LDS image (zero-padded to OP columns); the actor's blocks also fill the rollout buffer
+    float v[RW][2];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const size_t row = (size_t)(r0 + RW * w + k);
+      v[k][0] = lane < O ? P.obs[row * O + lane] : 0.f;
+      v[k][1] = lane + 64 < O ? P.obs[row * O + lane + 64] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      Xs[(RW * w + k) * XS + lane] = mlp_f2bf(v[k][0]);
+      if (lane + 64 < OP) Xs[(RW * w + k) * XS + lane + 64] = mlp_f2bf(v[k][1]);
+      if (net == 0 && P.obs_buf) {
+        float* dst = P.obs_buf + (tt * N + (size_t)(r0 + RW * w + k)) * O;
+        if (lane < O) dst[lane] = v[k][0];
+        if (lane + 64 < O) dst[lane + 64] = v[k][1];
+      }
+    }
+  }
+  __syncthreads();
+  myo_f32x4 acc[MT][4];
+  if (OP == 96) mlp_mma_slab<3, MT>(acc, Xs, XS, bw, lm, lq);
+  else if (OP == 128) mlp_mma_slab<4, MT>(acc, Xs, XS, bw, lm, lq);
+  else if (OP == 64) mlp_mma_slab<2, MT>(acc, Xs, XS, bw, lm, lq);
+  else mlp_mma_slab<1, MT>(acc, Xs, XS, bw, lm, lq);
+  mlp_load_w<H / 32>(bw, P.W2 + (size_t)net * H * H, H, n0, lm, lq);
+  mlp_store_act_lds<MT>(acc, bb1, Hs, n0, lm, lq);
+  __syncthreads();
+  mlp_mma_slab<H / 32, MT>(acc, Hs, HS, bw, lm, lq);
+  const unsigned short* Wh = P.Whp + (size_t)net * MLP_APM * H;
+  myo_bf16x8 bh2[H / 32];
+  if (w < 3) {
+#pragma unroll
+    for (int ks = 0; ks < H / 32; ++ks) bh2[ks] = *reinterpret_cast<const myo_bf16x8*>(Wh + (size_t)(16 * w + lm) * H + 32 * ks + 8 * lq);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();                       // every wave has read H1 out of the hidden image: H2 takes its place
+  mlp_store_act_lds<MT>(acc, bb2, Hs, n0, lm, lq);
+  __syncthreads();
+  if (w < 3) {
+    const float bv = bh[16 * w + lm];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      myo_f32x4 ah = myo_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < H / 32; ++ks) {
+        const myo_bf16x8 a = *reinterpret_cast<const myo_bf16x8*>(Hs + (16 * mt + lm) * HS + 32 * ks + 8 * lq);
+        ah = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bh2[ks], ah, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) So[(16 * mt + 4 * lq + r) * SOS + 16 * w + lm] = ah[r] + bv;
+    }
+  }
+  __syncthreads();
+  if (net == 1) {
+    if (t < BM) P.val_buf[tt * N + r0 + t] = So[t * SOS];
+    return;
+  }
+  // ---- the actor's blocks: 8 lanes per row, lane g = the four actions 4g .. 4g+3 (and 4(g+8) ..): one Philox block each
+  const unsigned long long ctr = P.draw_counter[0];
+  const int row = t >> 3, g0 = t & 7, i = r0 + row;
+  float logp = 0.f;
+  static_assert(BM * 8 == 256, "8 lanes per row");
+  for (int a0 = 4 * g0; a0 < A; a0 += 32) {
+    unsigned int c[4] = {(unsigned int)i, (unsigned int)(a0 >> 2), (unsigned int)ctr, (unsigned int)(ctr >> 32)};
+    unsigned int k0 = (unsigned int)P.seed, k1 = (unsigned int)(P.seed >> 32);
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    float z[4];
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float rad = sqrtf(-2.0f * __logf(u1));
+      float sn, cs;
+      __sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * h] = rad * cs; z[2 * h + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int a = a0 + k;
+      if (a < A) {
+        const float mu = So[row * SOS + a], ls = s_ls[a];
+        const float act = P.deterministic ? mu : mu + s_ls[64 + a] * z[k];
+        const float zz = (act - mu) * __expf(-ls);
+        logp += -0.5f * zz * zz - ls - 0.9189385332046727f;
+        P.act_buf[(tt * N + i) * A + a] = act;
+        P.clipped[(size_t)i * A + a] = fminf(fmaxf(act, -1.f), 1.f);
+      }
+    }
+  }
+  for (int off = 4; off >= 1; off >>= 1) logp += __shfl_xor(logp, off, 8);
+  if (g0 == 0) P.logp_buf[tt * N + i] = logp;
+  if (blockIdx.x == 0 && t == 0) P.draw_counter[1] = ctr + 1;
+}
+
 // ---- weight gradients.  C[m][n] = sum_r AT[m][r] BT[n][r] over the split's rows; 128 x 128 tile per workgroup (4 waves as
 // 2 x 2 of 64 x 64), both operands K(row)-contiguous in global memory.  Feature-major buffers are allocated in whole 128-row
 // groups, so every fragment load is in bounds; stores are masked by the true M, N.

@@ -549,7 +549,7 @@ extern "C" int myo_model_size(const myo_model* m, const char* n) {
 }
 
 // ------------------------------------------------------------------------------------------ batch
-#define MYO_PARTS_MAX 5
+#define MYO_PARTS_MAX 8
 struct StepPlan { int nparts; int k[MYO_PARTS_MAX + 1]; };      // part p = substeps [k[p], k[p+1]); nparts = 1: whole steps
 struct myo_batch;
 struct myo_batch {
@@ -2522,6 +2522,77 @@ extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
   hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((d->G + 255) / 256)), dim3(256), 0, st, (const float*)w.slab, d->grads, d->G, MLP_SPLITK);
   hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, (const float*)w.part, d->acc, B / MLP_BM, A, d->ent_coef,
                      d->grads + d->off_log_std, d->grads + d->off_bh[0], d->grads + d->off_bh[1]);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+
+#ifndef MYO_EMU
+struct MlpImg { unsigned short *W1p, *W2, *W2T, *Whp, *WhT; float* bias; size_t bytes; };
+static MlpImg mlp_carve_images(unsigned char* base, int OP) {
+  MlpImg w;
+  size_t o = 0;
+  auto take = [&](size_t n) { unsigned char* p = base ? base + o : nullptr; o += (n + 255) / 256 * 256; return p; };
+  const size_t H = MLP_H;
+  w.W1p = (unsigned short*)take(2 * H * OP * 2); w.W2 = (unsigned short*)take(2 * H * H * 2); w.W2T = (unsigned short*)take(2 * H * H * 2);
+  w.Whp = (unsigned short*)take(2 * MLP_APM * H * 2); w.WhT = (unsigned short*)take(2 * H * MLP_AKP * 2);
+  w.bias = (float*)take((4 * H + 2 * MLP_APM) * 4);
+  w.bytes = o;
+  return w;
+}
+static int mlp_rollout_ok(const myo_ppo_mlp_rollout_desc* d) {
+  return d->hidden == MLP_H && d->O >= 1 && d->O <= MLP_OPMAX && d->A >= 1 && d->A <= MLP_APM && d->N >= MLP_BM && d->N % MLP_BM == 0;
+}
+#endif
+extern "C" long long myo_ppo_mlp_rollout_workspace_bytes(int obs_dim, int act_dim, int hidden) {
+#ifdef MYO_EMU
+  (void)obs_dim; (void)act_dim; (void)hidden;
+  return -1;
+#else
+  if (hidden != MLP_H || obs_dim < 1 || obs_dim > MLP_OPMAX || act_dim < 1 || act_dim > MLP_APM) return -1;
+  return (long long)mlp_carve_images(nullptr, (obs_dim + 31) / 32 * 32).bytes;
+#endif
+}
+extern "C" int myo_ppo_mlp_rollout_refresh(const myo_ppo_mlp_rollout_desc* d, void* stream) {
+  if (!d || !d->params || !d->workspace) return fail(MYO_E_ARG, "myo_ppo_mlp_rollout_refresh: null argument");
+#ifdef MYO_EMU
+  (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_rollout_refresh is a GPU kernel");
+#else
+  if (!mlp_rollout_ok(d)) return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_rollout: needs hidden = %d, obs <= %d, act <= %d, envs a multiple of %d", MLP_H, MLP_OPMAX, MLP_APM, MLP_BM);
+  const int OP = (d->O + 31) / 32 * 32;
+  const MlpImg w = mlp_carve_images((unsigned char*)d->workspace, OP);
+  if ((long long)w.bytes > d->workspace_bytes) return fail(MYO_E_ARG, "myo_ppo_mlp_rollout_refresh: workspace too small (%zu bytes needed)", w.bytes);
+  MlpPrepArgs pp;
+  pp.p = d->params; pp.O = d->O; pp.OP = OP; pp.Ah[0] = d->A; pp.Ah[1] = 1;
+  for (int k = 0; k < 2; ++k) {
+    pp.off_W1[k] = d->off_W1[k]; pp.off_b1[k] = d->off_b1[k]; pp.off_W2[k] = d->off_W2[k]; pp.off_b2[k] = d->off_b2[k];
+    pp.off_Wh[k] = d->off_Wh[k]; pp.off_bh[k] = d->off_bh[k];
+  }
+  pp.adv_part = nullptr; pp.adv_stats = nullptr; pp.adv_nb = 0; pp.B = 0;
+  pp.W1p = w.W1p; pp.W2 = w.W2; pp.W2T = w.W2T; pp.Whp = w.Whp; pp.WhT = w.WhT; pp.bias = w.bias;
+  hipLaunchKernelGGL(k_mlp_prep, dim3(256), dim3(256), 0, (hipStream_t)stream, pp);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_ppo_mlp_rollout(const myo_ppo_mlp_rollout_desc* d, void* stream) {
+  if (!d || !d->obs || !d->params || !d->draw_counter || !d->t_idx || !d->act_buf || !d->val_buf || !d->logp_buf || !d->clipped || !d->workspace)
+    return fail(MYO_E_ARG, "myo_ppo_mlp_rollout: null argument");
+#ifdef MYO_EMU
+  (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_rollout is a GPU kernel");
+#else
+  if (!mlp_rollout_ok(d)) return fail(MYO_E_UNSUPPORTED, "myo_ppo_mlp_rollout: needs hidden = %d, obs <= %d, act <= %d, envs a multiple of %d", MLP_H, MLP_OPMAX, MLP_APM, MLP_BM);
+  const int OP = (d->O + 31) / 32 * 32;
+  const MlpImg w = mlp_carve_images((unsigned char*)d->workspace, OP);
+  if ((long long)w.bytes > d->workspace_bytes) return fail(MYO_E_ARG, "myo_ppo_mlp_rollout: workspace too small (%zu bytes needed)", w.bytes);
+  MlpPolicyArgs a;
+  a.obs = d->obs; a.log_std = d->params + d->off_log_std; a.W1p = w.W1p; a.W2 = w.W2; a.Whp = w.Whp; a.bias = w.bias;
+  a.obs_buf = d->obs_buf; a.act_buf = d->act_buf; a.val_buf = d->val_buf; a.logp_buf = d->logp_buf; a.clipped = d->clipped;
+  a.t_idx = d->t_idx; a.draw_counter = (unsigned long long*)d->draw_counter; a.seed = d->seed;
+  a.N = d->N; a.O = d->O; a.A = d->A; a.OP = OP; a.deterministic = d->deterministic;
+  hipLaunchKernelGGL(k_mlp_policy, dim3(d->N / MLP_BM, 2), dim3(256), MLP_POLICY_LDS, (hipStream_t)stream, a);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif

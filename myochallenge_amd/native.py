@@ -70,6 +70,18 @@ class PpoMlpDesc(C.Structure):
     ]
 
 
+class PpoMlpRolloutDesc(C.Structure):
+    """myo_ppo_mlp_rollout_desc of include/myobatch.h (one env step's policy call of the rollout, MLP actor-critic)."""
+    _fields_ = [
+        ("obs", C.c_void_p), ("N", C.c_int32), ("O", C.c_int32), ("A", C.c_int32), ("hidden", C.c_int32), ("params", C.c_void_p),
+        ("off_W1", C.c_int64 * 2), ("off_b1", C.c_int64 * 2), ("off_W2", C.c_int64 * 2), ("off_b2", C.c_int64 * 2),
+        ("off_Wh", C.c_int64 * 2), ("off_bh", C.c_int64 * 2), ("off_log_std", C.c_int64),
+        ("seed", C.c_uint64), ("draw_counter", C.c_void_p), ("t_idx", C.c_void_p),
+        ("obs_buf", C.c_void_p), ("act_buf", C.c_void_p), ("val_buf", C.c_void_p), ("logp_buf", C.c_void_p), ("clipped", C.c_void_p),
+        ("deterministic", C.c_int32), ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+    ]
+
+
 class MyoError(RuntimeError):
     pass
 
@@ -134,6 +146,10 @@ class NativeLib:
         L.myo_ppo_mlp_workspace_bytes.restype = C.c_longlong
         L.myo_ppo_mlp_workspace_bytes.argtypes = [i32, i32, i32, i32, C.c_longlong]
         L.myo_ppo_mlp_step.argtypes = [C.POINTER(PpoMlpDesc), vp]
+        L.myo_ppo_mlp_rollout_workspace_bytes.restype = C.c_longlong
+        L.myo_ppo_mlp_rollout_workspace_bytes.argtypes = [i32, i32, i32]
+        L.myo_ppo_mlp_rollout_refresh.argtypes = [C.POINTER(PpoMlpRolloutDesc), vp]
+        L.myo_ppo_mlp_rollout.argtypes = [C.POINTER(PpoMlpRolloutDesc), vp]
 
     def check(self, rc: int):
         if rc != 0:
@@ -174,7 +190,7 @@ EXPORTED_SYMBOLS = [
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
-    "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_ppo_mlp_workspace_bytes", "myo_ppo_mlp_step", "myo_last_error", "myo_version",
+    "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_ppo_mlp_workspace_bytes", "myo_ppo_mlp_step", "myo_ppo_mlp_rollout_workspace_bytes", "myo_ppo_mlp_rollout_refresh", "myo_ppo_mlp_rollout", "myo_last_error", "myo_version",
 ]
 
 

@@ -258,6 +258,53 @@ class FusedPPOStep:
         self._mfma[key] = (d, ws)
         return d
 
+    # ---- rollout inference + sampling on the matrix cores (libmyobatch: myo_ppo_mlp_rollout)
+    def rollout_desc(self, obs, seed, draw, t_idx, obs_buf, act_buf, val_buf, logp_buf, clipped):
+        """Descriptor of myo_ppo_mlp_rollout for the policy input `obs` [N,O] (static tensors of the rollout graph), or None
+        when the architecture / number of envs has no fused path.  Cached; `refresh_rollout_images` rebuilds the weight
+        images it reads and has to run after every parameter change."""
+        from .. import native
+        flat = getattr(self.policy, "_flat", None)
+        if not self.use_mfma_step or flat is None or self.merged is None or len(self.merged) != 2:
+            return None
+        pi, vf = self.nets["pi"], self.nets["vf"]
+        N, O = obs.shape
+        hid = pi[0].weight.shape[0]
+        shapes_ok = all(tuple(l.weight.shape) == s for l, s in ((pi[0], (hid, O)), (vf[0], (hid, O)), (pi[1], (hid, hid)), (vf[1], (hid, hid)),
+                                                               (pi[2], (self.A, hid)), (vf[2], (1, hid))))
+        if not shapes_ok or self.policy.log_std.dim() != 1 or obs.dtype != torch.float32 or N % 32:
+            return None
+        nbytes = self.lib.L.myo_ppo_mlp_rollout_workspace_bytes(O, self.A, hid)
+        if nbytes <= 0:
+            return None
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=obs.device)
+        slot = {id(p): sl[0] for p, sl in zip(flat["params"], flat["slots"])}
+        d = native.PpoMlpRolloutDesc()
+        d.obs, d.N, d.O, d.A, d.hidden, d.params = obs.data_ptr(), N, O, self.A, hid, flat["p"].data_ptr()
+        for k, (a, b) in enumerate(zip(pi, vf)):
+            for net, lin in enumerate((a, b)):
+                wname, bname = (("off_W1", "off_b1"), ("off_W2", "off_b2"), ("off_Wh", "off_bh"))[k]
+                getattr(d, wname)[net] = slot[id(lin.weight)]
+                getattr(d, bname)[net] = slot[id(lin.bias)]
+        d.off_log_std = slot[id(self.policy.log_std)]
+        d.seed, d.draw_counter, d.t_idx = seed, draw.data_ptr(), t_idx.data_ptr()
+        d.obs_buf, d.act_buf, d.val_buf, d.logp_buf, d.clipped = (t.data_ptr() for t in (obs_buf, act_buf, val_buf, logp_buf, clipped))
+        d.deterministic, d.workspace, d.workspace_bytes = 0, ws.data_ptr(), nbytes
+        self._rollout = (d, ws)
+        self.refresh_rollout_images()
+        return d
+
+    def refresh_rollout_images(self):
+        """bf16 weight images of the rollout kernel from the current master weights (one launch; call after every update)."""
+        r = getattr(self, "_rollout", None)
+        if r is not None:
+            stream = torch.cuda.current_stream(self.acc.device).cuda_stream
+            self.lib.check(self.lib.L.myo_ppo_mlp_rollout_refresh(C.byref(r[0]), C.c_void_p(stream)))
+
+    def rollout_policy(self, d):
+        stream = torch.cuda.current_stream(self.acc.device).cuda_stream
+        self.lib.check(self.lib.L.myo_ppo_mlp_rollout(C.byref(d), C.c_void_p(stream)))
+
     def _mfma_step(self, d):
         d.compute_adv_stats = 0 if self.external_adv_stats else 1
         stream = torch.cuda.current_stream(self.acc.device).cuda_stream
@@ -392,6 +439,7 @@ class FusedPPOStep:
             self.half[0].copy_(self.master[0])       # flat vector: one cast kernel
         else:
             torch._foreach_copy_(self.half, self.master)
+        self.refresh_rollout_images()
 
     def trunk_heads(self, x2):
         """Stacked actor/critic forward on the bf16 shadow weights: x2 bf16 [2,B,obs] -> (hidden

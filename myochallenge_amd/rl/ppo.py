@@ -13,6 +13,7 @@ of a flat fp32 gradient bucket per optimizer step over RCCL (torch.distributed b
 """
 from __future__ import annotations
 
+import os
 import time
 from dataclasses import dataclass, field
 from typing import Callable, Dict, Optional
@@ -210,7 +211,15 @@ class PPO:
         seed = int(self.gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         p = lambda t: C.c_void_p(t.data_ptr())
 
+        # policy call of a step: ONE launch on the matrix cores (myo_ppo_mlp_rollout) where the architecture fits, else policy-input
+        # cast + hipBLASLt trunk / head GEMMs + bias/ReLU kernels + myo_rollout_sample
+        rdesc = fused.rollout_desc(self._obs_s, seed, self._draw, self._t_idx, self.obs_buf, self.act_buf, self.val_buf,
+                                   self.logp_buf, self._clip_s) if os.environ.get("MYO_ROLLOUT_GEMM") != "1" else None
+
         def part_a():
+            if rdesc is not None:
+                fused.rollout_policy(rdesc)
+                return
             st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
             lib.check(lib.L.myo_rollout_policy_input(p(self._obs_s), N, O, p(self.obs_buf), p(self._x2), 2, p(self._t_idx), st))
             _, mean_h, value_h = fused.trunk_heads(self._x2)

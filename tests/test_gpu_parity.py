@@ -659,6 +659,44 @@ def test_native_rollout_bookkeeping(hip_lib):
     assert torch.equal(algo.act_buf, algo2.act_buf) and torch.equal(algo.rew_buf, algo2.rew_buf)
 
 
+def test_fused_rollout_policy_matches_gemm_path(hip_lib, monkeypatch):
+    """myo_ppo_mlp_rollout (policy input -> trunks -> heads -> Philox sample in one launch) against the path it replaces
+    (policy-input cast, hipBLASLt GEMMs, bias/ReLU kernels, myo_rollout_sample) on the first step of the same rollout: the same
+    Philox draws, so the standardised noise and log pi agree to float rounding, and the actions / values to the bf16 rounding of
+    the GEMM path's action mean."""
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+
+    def first_step(gemm):
+        if gemm:
+            monkeypatch.setenv("MYO_ROLLOUT_GEMM", "1")
+        else:
+            monkeypatch.delenv("MYO_ROLLOUT_GEMM", raising=False)
+        torch.manual_seed(0)
+        env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=512, seed=11)
+        pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
+        algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=4, batch_size=1024, n_epochs=1), seed=0)
+        assert algo._native_rollout()
+        algo.rollout_step()
+        torch.cuda.synchronize()
+        return algo
+    a, b = first_step(False), first_step(True)
+    assert getattr(a._fused, "_rollout", None) is not None and getattr(b._fused, "_rollout", None) is None
+    assert torch.equal(a.obs_buf[0], b.obs_buf[0])
+    std = torch.exp(a.policy.log_std.detach())
+    assert float(((a.act_buf[0] - b.act_buf[0]).abs() / std).max()) < 0.6         # bf16 mean (3 digits) in units of sigma = exp(-2)
+    assert float((a.act_buf[0] - b.act_buf[0]).abs().mean()) < 5e-3
+    assert float((a.logp_buf[0] - b.logp_buf[0]).abs().max()) < 2e-3                # same z: log pi differs by rounding only
+    assert float((a.val_buf[0] - b.val_buf[0]).abs().max()) < 2e-2
+    with torch.no_grad():                                                          # fp32 torch statement of the policy
+        mean, _ = a.policy._dist(a.policy._latents(a.obs_buf[0], None, None)[0])
+    z = (a.act_buf[0] - mean.float()) / std
+    assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.05
+
+
 def test_captured_column_sums_survive_replays(hip_lib):
     """Column sums inside captured graphs (VecNormalize batch moments, bias gradients of the recurrent update)
     are ones-row GEMMs: ATen's multi-block column reduction returns wrong sums on every replay after the first

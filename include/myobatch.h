@@ -328,7 +328,13 @@ typedef struct myo_ppo_mlp_desc {
   float* acc;
   void* workspace;
   int64_t workspace_bytes;
+  /* single-rank tail (both NULL: off): the squares of the finished gradient, in myo_ppo_mlp_sqnorm_parts(act_dim) partial sums
+   * -> sqnorm_part, and Adam's step counter advanced (adam_step: the int32[2] of myo_adam_clip_step) — then myo_adam_apply
+   * instead of myo_adam_clip_step.  Not for N > 1 ranks: there the gradient changes (all-reduce) before it is clipped. */
+  float* sqnorm_part;
+  int32_t* adam_step;
 } myo_ppo_mlp_desc;
+int myo_ppo_mlp_sqnorm_parts(int act_dim);
 long long myo_ppo_mlp_workspace_bytes(int B, int obs_dim, int act_dim, int hidden, long long G);
 int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream);
 
@@ -366,6 +372,11 @@ int myo_ppo_mlp_rollout(const myo_ppo_mlp_rollout_desc* d, void* stream);
 int myo_adam_clip_step(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
                        float eps, float max_norm, float grad_scale, int* step, float* scratch, uint16_t* p_bf16,
                        void* stream);
+/* The second half of myo_adam_clip_step alone: |g|^2 = the sum of scratch[0 .. nparts) (left there by myo_ppo_mlp_step with
+ * sqnorm_part set, which has also advanced `step`), then clip + Adam as above. */
+int myo_adam_apply(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
+                   float eps, float max_norm, float grad_scale, const int* step, const float* scratch, int nparts,
+                   uint16_t* p_bf16, void* stream);
 
 const char* myo_last_error(void);
 const char* myo_version(void);

@@ -664,6 +664,55 @@ __global__ void __launch_bounds__(256) k_mlp_wgrad(MlpWgradArgs P) {
   }
 }
 
+// The tail of the optimizer step's gradient in ONE launch (single-rank path: nothing is exchanged between the gradient and
+// the clip): blocks 0 .. MLP_RF_BLOCKS-1 sum the split-K slabs into the flat gradient (split order) and their share of
+// |g|^2; block MLP_RF_BLOCKS + c finishes column c of the loss partials (k_colmajor_finish's arithmetic: loss sums, d log_std,
+// head-bias gradients) and the squares of what it wrote; sq_part[0 .. MLP_RF_BLOCKS + ncol) is what myo_adam_apply adds up in
+// a fixed order; block 0 also advances Adam's step counter (k_grad_sqnorm's other job).  Instead of k_mlp_reduce +
+// k_colmajor_finish + k_grad_sqnorm.
+#define MLP_RF_BLOCKS 256
+struct MlpRfArgs {
+  const float* slab; float* g; long long G; int splits;
+  const float* part; float* acc; int NB, A; float ent_coef;
+  long long off_log_std, off_bh0, off_bh1;
+  float* sq_part; int* adam_step;
+};
+__global__ void __launch_bounds__(256) k_mlp_reduce_finish(MlpRfArgs P) {
+  __shared__ float red[4];
+  const int t = threadIdx.x, A = P.A;
+  if ((int)blockIdx.x < MLP_RF_BLOCKS) {
+    float sq = 0.f;
+    for (long long e = (long long)blockIdx.x * 256 + t; e < P.G; e += (long long)MLP_RF_BLOCKS * 256) {
+      float s = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < P.splits; ++k) s += P.slab[(size_t)k * P.G + e];
+      const bool theirs = (e >= P.off_log_std && e < P.off_log_std + A) || (e >= P.off_bh0 && e < P.off_bh0 + A) || e == P.off_bh1;
+      if (!theirs) { P.g[e] = s; sq += s * s; }          // (the column blocks own the log_std / head-bias slots)
+    }
+    for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    if ((t & 63) == 0) red[t >> 6] = sq;
+    __syncthreads();
+    if (t == 0) {
+      P.sq_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (blockIdx.x == 0) { const int done = P.adam_step[1]; P.adam_step[0] = done; P.adam_step[1] = done + 1; }
+    }
+    return;
+  }
+  const int c = (int)blockIdx.x - MLP_RF_BLOCKS;
+  if (t >= 64) return;
+  float a = 0.f;
+  for (int b = t; b < P.NB; b += 64) a += P.part[(size_t)c * P.NB + b];
+  for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+  if (t == 0) {
+    P.acc[c] = a;
+    float w = 0.f;
+    if (c < A) { w = a - P.ent_coef; P.g[P.off_log_std + c] = w; }          // d(-ent_coef * entropy)/d log_std = -ent_coef
+    else if (c >= A + 2 && c < 2 * A + 2) { w = a; P.g[P.off_bh0 + c - A - 2] = w; }
+    else if (c == 2 * A + 2) { w = a; P.g[P.off_bh1] = w; }
+    P.sq_part[MLP_RF_BLOCKS + c] = w * w;
+  }
+}
+
 // flat gradient = sum over splits of the slabs, in split order
 __global__ void __launch_bounds__(256) k_mlp_reduce(const float* __restrict__ slab, float* __restrict__ g, long long G, int splits) {
   const long long e = (long long)blockIdx.x * 256 + threadIdx.x;

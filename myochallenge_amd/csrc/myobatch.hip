@@ -2398,9 +2398,18 @@ __global__ void __launch_bounds__(256) k_grad_sqnorm(const float* __restrict__ g
 __global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int n, float lr, float b1, float b2, float eps,
                                               float max_norm, float gs, const int* __restrict__ step,
-                                              const float* __restrict__ part, unsigned short* __restrict__ p_bf16) {
-  float sq = 0.f;
-  for (int k = 0; k < MYO_SQN_BLOCKS; ++k) sq += part[k];      // same order in every block
+                                              const float* __restrict__ part, unsigned short* __restrict__ p_bf16, int nparts) {
+  // |g|^2 from the partial sums: every block adds them in the same tree order (256 lanes, strided, then halving) — a serial
+  // loop over them was one dependent scalar load per partial, 4 us for 64 and 21 us for 337
+  __shared__ float sq_red[256];
+  {
+    float a = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += 256) a += part[k];
+    sq_red[threadIdx.x] = a;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) { if ((int)threadIdx.x < w) sq_red[threadIdx.x] += sq_red[threadIdx.x + w]; __syncthreads(); }
+  }
+  const float sq = sq_red[0];
   const int t = step[1];
   const float norm = sqrtf(sq);
   const float clip = (max_norm > 0.f) ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
@@ -2429,7 +2438,22 @@ extern "C" int myo_adam_clip_step(float* p, const float* g, float* m, float* v, 
   const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
   hipLaunchKernelGGL(k_grad_sqnorm, dim3(MYO_SQN_BLOCKS), dim3(256), 0, st, g, n, grad_scale, scratch, step);
   hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, max_norm, grad_scale, step, scratch,
-                     (unsigned short*)p_bf16);
+                     (unsigned short*)p_bf16, MYO_SQN_BLOCKS);
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_adam_apply(float* p, const float* g, float* m, float* v, int n, float lr, float b1, float b2,
+                              float eps, float max_norm, float grad_scale, const int* step, const float* scratch, int nparts,
+                              uint16_t* p_bf16, void* stream) {
+  if (!p || !g || !m || !v || !step || !scratch || n <= 0 || nparts <= 0) return fail(MYO_E_ARG, "myo_adam_apply: bad arguments");
+#ifdef MYO_EMU
+  (void)lr; (void)b1; (void)b2; (void)eps; (void)max_norm; (void)grad_scale; (void)stream; (void)p_bf16;
+  return fail(MYO_E_UNSUPPORTED, "myo_adam_apply is a GPU kernel");
+#else
+  const int blocks = (n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024;
+  hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, b1, b2, eps, max_norm, grad_scale, step, scratch,
+                     (unsigned short*)p_bf16, nparts);
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif
@@ -2468,6 +2492,14 @@ extern "C" long long myo_ppo_mlp_workspace_bytes(int B, int obs_dim, int act_dim
 #else
   if (!mlp_shape_ok(B, obs_dim, act_dim, hidden) || G <= 0) return -1;
   return (long long)mlp_carve(nullptr, B, (obs_dim + 31) / 32 * 32, act_dim, G).bytes;
+#endif
+}
+extern "C" int myo_ppo_mlp_sqnorm_parts(int act_dim) {
+#ifdef MYO_EMU
+  (void)act_dim;
+  return -1;
+#else
+  return MLP_RF_BLOCKS + 2 * act_dim + 3;
 #endif
 }
 extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
@@ -2519,9 +2551,17 @@ extern "C" int myo_ppo_mlp_step(const myo_ppo_mlp_desc* d, void* stream) {
       g.job[g.njobs++] = MlpWgradJob{w.dOT + (size_t)net * 128 * B, w.H2T + net * HB, net == 0 ? A : 1, MLP_H, MLP_H, 0, n0, d->off_Wh[net], -1};
   }
   hipLaunchKernelGGL(k_mlp_wgrad, dim3(g.njobs * MLP_SPLITK), dim3(256), 0, st, g);
-  hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((d->G + 255) / 256)), dim3(256), 0, st, (const float*)w.slab, d->grads, d->G, MLP_SPLITK);
-  hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, (const float*)w.part, d->acc, B / MLP_BM, A, d->ent_coef,
-                     d->grads + d->off_log_std, d->grads + d->off_bh[0], d->grads + d->off_bh[1]);
+  if (d->sqnorm_part && d->adam_step) {
+    MlpRfArgs rf;
+    rf.slab = w.slab; rf.g = d->grads; rf.G = d->G; rf.splits = MLP_SPLITK; rf.part = w.part; rf.acc = d->acc; rf.NB = B / MLP_BM; rf.A = A;
+    rf.ent_coef = d->ent_coef; rf.off_log_std = d->off_log_std; rf.off_bh0 = d->off_bh[0]; rf.off_bh1 = d->off_bh[1];
+    rf.sq_part = d->sqnorm_part; rf.adam_step = d->adam_step;
+    hipLaunchKernelGGL(k_mlp_reduce_finish, dim3(MLP_RF_BLOCKS + 2 * A + 3), dim3(256), 0, st, rf);
+  } else {
+    hipLaunchKernelGGL(k_mlp_reduce, dim3((unsigned)((d->G + 255) / 256)), dim3(256), 0, st, (const float*)w.slab, d->grads, d->G, MLP_SPLITK);
+    hipLaunchKernelGGL(k_colmajor_finish, dim3(2 * A + 3), dim3(64), 0, st, (const float*)w.part, d->acc, B / MLP_BM, A, d->ent_coef,
+                       d->grads + d->off_log_std, d->grads + d->off_bh[0], d->grads + d->off_bh[1]);
+  }
   LAUNCH_CHECK(0)
   return MYO_OK;
 #endif

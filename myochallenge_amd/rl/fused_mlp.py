@@ -143,7 +143,8 @@ class FlatAdam:
         dev = flat["p"].device
         self.m, self.v = torch.zeros_like(flat["p"]), torch.zeros_like(flat["p"])
         self._step = torch.zeros(2, dtype=torch.int32, device=dev)    # [committed, taken]
-        self.sq = torch.zeros(64, device=dev)
+        self.sq = torch.zeros(512, device=dev)   # partial sums of |g|^2 (64 of myo_adam_clip_step, or those myo_ppo_mlp_step leaves)
+        self.presummed = 0        # > 0: the gradient's producer has left that many partial sums in `sq` and advanced the step counter
         self.shadow = None        # bf16 copy of the flat parameters kept in step by the Adam kernel (FusedPPOStep sets it)
 
     @property
@@ -158,6 +159,12 @@ class FlatAdam:
         f = self.flat
         stream = torch.cuda.current_stream(f["p"].device).cuda_stream
         p = lambda t: C.c_void_p(t.data_ptr())
+        if self.presummed > 0:      # single-rank fused step: myo_ppo_mlp_step has done the squares and the step counter
+            self.lib.check(self.lib.L.myo_adam_apply(
+                p(f["p"]), p(f["g"]), p(self.m), p(self.v), f["p"].numel(), self.lr, self.betas[0], self.betas[1],
+                self.eps, self.max_norm, float(grad_scale), p(self._step), p(self.sq), int(self.presummed),
+                p(self.shadow) if self.shadow is not None else None, C.c_void_p(stream)))
+            return
         self.lib.check(self.lib.L.myo_adam_clip_step(
             p(f["p"]), p(f["g"]), p(self.m), p(self.v), f["p"].numel(), self.lr, self.betas[0], self.betas[1],
             self.eps, self.max_norm, float(grad_scale), p(self._step), p(self.sq),
@@ -215,6 +222,7 @@ class FusedPPOStep:
         self._work = {}
         self._mfma = {}                      # per minibatch size: (descriptor, workspace) of myo_ppo_mlp_step
         self.use_mfma_step = True            # the one-launch-per-stage path (csrc/myo_ppo_mlp.h) whenever the shapes fit
+        self.adam = None                     # FlatAdam whose |g|^2 partials / step counter the fused step fills (single rank; PPO sets it)
 
     # ---- fused forward / loss / backward on the matrix cores (libmyobatch: myo_ppo_mlp_step)
     def _mfma_desc(self, B, obs_all, act_all, oldlp_all, adv_all, ret_all, idx):
@@ -255,6 +263,8 @@ class FusedPPOStep:
         d.clip, d.vf_coef, d.ent_coef = self.clip, self.vf, self.ent
         d.adv_stats, d.acc = self.stats.data_ptr(), self.acc.data_ptr()
         d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        if self.adam is not None and self.lib.L.myo_ppo_mlp_sqnorm_parts(self.A) <= self.adam.sq.numel():
+            d.sqnorm_part, d.adam_step = self.adam.sq.data_ptr(), self.adam._step.data_ptr()
         self._mfma[key] = (d, ws)
         return d
 
@@ -309,6 +319,8 @@ class FusedPPOStep:
         d.compute_adv_stats = 0 if self.external_adv_stats else 1
         stream = torch.cuda.current_stream(self.acc.device).cuda_stream
         self.lib.check(self.lib.L.myo_ppo_mlp_step(C.byref(d), C.c_void_p(stream)))
+        if self.adam is not None:           # the Adam call that follows takes the partial sums this step left (or does its own)
+            self.adam.presummed = self.lib.L.myo_ppo_mlp_sqnorm_parts(self.A) if d.sqnorm_part else 0
         return self.acc[self.A], self.acc[self.A + 1]
 
     def _workbuf(self, key, n):
@@ -404,6 +416,8 @@ class FusedPPOStep:
         d = self._mfma_desc(idx.shape[0], obs_all, act_all, oldlp_all, adv_all, ret_all, idx)
         if d is not None:
             return self._mfma_step(d)
+        if self.adam is not None:
+            self.adam.presummed = 0          # GEMM path below: Adam squares the gradient itself
         B, O, A = idx.shape[0], obs_all.shape[1], self.A
         dev = obs_all.device
         x2 = torch.empty((2, B, O), device=dev, dtype=torch.bfloat16)
@@ -427,6 +441,8 @@ class FusedPPOStep:
             d = self._mfma_desc(B, obs.contiguous(), actions.contiguous(), old_logp.contiguous(), adv.contiguous(), returns.contiguous(), ar)
             if d is not None:
                 return self._mfma_step(d)
+        if self.adam is not None:
+            self.adam.presummed = 0
         var, mu = torch.var_mean(adv)
         self.stats[0].copy_(mu)
         self.stats[1].copy_(var.sqrt())
@@ -509,6 +525,8 @@ class FusedPPOStep:
         if self.merged is not None:
             return self._run_merged(obs, actions, old_logp, adv, returns)
         pol = self.policy
+        if self.adam is not None:
+            self.adam.presummed = 0
         B, A = obs.shape[0], self.A
         torch._foreach_copy_(self.half, self.master)
         x0 = obs.to(torch.bfloat16)

@@ -117,6 +117,8 @@ class PPO:
             self._flat_adam = FlatAdam(flatten_parameters(self.policy), native.load(), cfg.learning_rate,
                                        cfg.max_grad_norm)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self._fused is not None and self._flat_adam is not None and self.world == 1 and os.environ.get("MYO_ADAM_SEPARATE") != "1":
+            self._fused.adam = self._flat_adam   # nothing is exchanged between gradient and clip: the fused step also squares the gradient
         self.rank = dist.get_rank() if self.world > 1 else 0
         N, T, O, A = env.num_envs, cfg.n_steps, env.obs_dim, env.act_dim
         d = self.device

@@ -120,6 +120,9 @@ int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, void* stream)
 int myo_batch_step(myo_batch* b, const float* act, float* obs, float* rew, uint8_t* done,
                    uint8_t* trunc, float* term_obs, float* comps, float* ep_info, void* stream);
 
+/* Test hook: set the generation counter of the step plan (k_step's part protocol; it wraps after 2^28 steps). */
+int myo_batch_set_step_generation(myo_batch* b, unsigned int gen);
+
 /* env.step(a) of the UNWRAPPED env for the envs selected by mask (dev uint8[N], NULL = all): no
  * TimeLimit / Monitor accounting, no auto-reset.  This is the `self.step(action)` that
  * MixtureModelBaodingEnv.reset runs with its base policy for the first n_steps_base_model steps

@@ -958,7 +958,7 @@ __global__ void __launch_bounds__(1024) k_step_order(const unsigned int* __restr
   __shared__ float s_lo[16], s_hi[16];
   __shared__ unsigned int s_cnt[256], s_off[256];
   const int t = threadIdx.x;
-  if (step_gen && t == 0) step_gen[0] += 1;          // the next launch is the next generation of the part protocol
+  if (step_gen && t == 0) step_gen[0] = (int)((unsigned)step_gen[0] + 1u);          // the next launch is the next generation of the part protocol
   if (!order) return;
   float lo = 3.4e38f, hi = 0.f;
   for (int i = t; i < n; i += 1024) {
@@ -1019,17 +1019,17 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
 #endif
   int q = 0;                                   // first part this workgroup runs
   if (part_state) {
-    const int base = 16 * step_gen[0];
+    const unsigned base = 16u * (unsigned)step_gen[0];     // (all state arithmetic is modulo 2^32: the generation counter may wrap)
     int* st = part_state + env;
     int from = -1;                             // decided by lane 0: the part to start from, -1 = nothing to do
     if (threadIdx.x == 0) {
       for (;;) {
         const int v = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int j = v - base;
-        if (j < 0 || j > 2 * p) break;          // part p is claimed or done (or the state belongs to another generation): exit
+        const unsigned j = (unsigned)v - base;
+        if (j > 2u * (unsigned)p) break;        // part p is claimed or done (or the state belongs to another generation): exit
         if ((j & 1) == 0) {
           int expect = v;
-          if (__hip_atomic_compare_exchange_strong(st, &expect, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { from = j >> 1; break; }
+          if (__hip_atomic_compare_exchange_strong(st, &expect, (int)((unsigned)v + 1u), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { from = (int)(j >> 1); break; }
           continue;
         }
         __builtin_amdgcn_s_sleep(32);           // an earlier part is running
@@ -1049,7 +1049,7 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
     __syncthreads();
     if (threadIdx.x == 0) {
       if (!last) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-      __hip_atomic_store(st, last ? base + 16 : base + 2 * p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(st, (int)(last ? base + 16u : base + 2u * (unsigned)p + 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
     env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
@@ -1335,6 +1335,24 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
   LAUNCH_CHECK(b)
 #endif
   return MYO_OK;
+}
+
+// test hook: put the step plan's generation counter (and every env's state, consistently) at `gen` — the counter wraps after
+// 2^28 steps and the protocol's arithmetic is modulo 2^32 (tests/test_step_parts.py steps across the wrap)
+extern "C" int myo_batch_set_step_generation(myo_batch* b, unsigned int gen) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+#ifdef MYO_EMU
+  (void)gen;
+  return MYO_OK;
+#else
+  if (!b->part_state) return MYO_OK;
+  DeviceGuard guard(b->device);
+  std::vector<int> st((size_t)b->n, (int)(16u * gen));
+  const int g4[4] = {(int)gen, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || be_h2d(b->part_state, st.data(), sizeof(int) * st.size()) || be_h2d(b->step_gen, g4, sizeof g4))
+    return fail(MYO_E_DEVICE, "myo_batch_set_step_generation: copy failed");
+  return MYO_OK;
+#endif
 }
 
 extern "C" int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const float* act, float* obs, uint8_t* done, void* stream) {

@@ -106,6 +106,7 @@ class NativeLib:
         L.myo_batch_create.argtypes = [vp, C.POINTER(TaskCfg), i32, i32, u64, i32, C.POINTER(vp)]
         L.myo_batch_destroy.argtypes = [vp]
         L.myo_batch_num_envs.argtypes = [vp]
+        L.myo_batch_set_step_generation.argtypes = [vp, C.c_uint32]
         L.myo_batch_obs_dim.argtypes = [vp]
         L.myo_batch_lds_bytes.argtypes = [vp]
         L.myo_batch_reset.argtypes = [vp, vp, vp, vp]
@@ -188,7 +189,7 @@ def load(path: Optional[str] = None) -> NativeLib:
 
 EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_load_mjb", "myo_model_destroy", "myo_model_size", "myo_batch_create",
-    "myo_batch_destroy", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
+    "myo_batch_destroy", "myo_batch_set_step_generation", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
     "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_physics_step", "myo_batch_get_state",
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",

@@ -14,7 +14,7 @@ from myochallenge_amd.envs.config import make_task_cfg
 from myochallenge_amd.model import compile_model
 
 
-def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, horizon=4):
+def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, horizon=4, generation=None):
     """Observations, rewards, dones, terminal observations of `nsteps` steps + the final state, with MYO_STEP_SPLIT = split."""
     old = {k: os.environ.get(k) for k in ("MYO_STEP_SPLIT", "MYO_STEP_ORDER")}
     try:
@@ -35,6 +35,8 @@ def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, hor
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+    if generation is not None:
+        lib.check(lib.L.myo_batch_set_step_generation(b.h, generation))
     nobs = b.obs_dim
     obs = mem.zeros((n, nobs), np.float32)
     rew, done, trunc = mem.zeros(n, np.float32), mem.zeros(n, np.uint8), mem.zeros(n, np.uint8)
@@ -94,3 +96,13 @@ def test_step_parts_rk4_and_full_batch_on_gpu(hip_lib, models):
     cm = compile_model(models["hand"], integrator=0)
     _same_bits(_rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 4096, 12, "0"),
                _rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 4096, 12, None))
+
+
+@pytest.mark.gpu
+def test_step_plan_generation_counter_wraps(hip_lib, models):
+    """The protocol's state is 16 x generation + part: the counter wraps after 2^28 steps (days of stepping); the arithmetic is
+    modulo 2^32 and a rollout that crosses the wrap gives the same bits."""
+    cm = compile_model(models["hand"], integrator=0)
+    whole = _rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 256, 8, "0")
+    _same_bits(whole, _rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 256, 8, None, generation=2 ** 28 - 3))
+    _same_bits(whole, _rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 256, 8, None, generation=2 ** 32 - 3))

@@ -40,7 +40,8 @@ def main():
                  ("stage_shares.txt", TAG + "_stage_shares.txt"), ("bench_kernel_stats.csv", TAG + "_bench_kernel_stats.csv"),
                  ("drift.log", TAG + "_drift_32streams.log"), ("pmc_mfma_kstep_f64.txt", TAG + "_pmc_mfma_kstep_f64.txt"),
                  ("stage_shares_rk4.txt", TAG + "_stage_shares_rk4.txt"), ("wg_timeline_parts.log", TAG + "_wg_timeline_parts.log"),
-                 ("wg_timeline_whole.log", TAG + "_wg_timeline_whole_steps.log"), ("gpu_tests.log", TAG + "_gpu_tests.log")):
+                 ("wg_timeline_whole.log", TAG + "_wg_timeline_whole_steps.log"), ("gpu_tests.log", TAG + "_gpu_tests.log"),
+                 ("pmc_kstep_whole_steps.txt", TAG + "_pmc_kstep_whole_steps.txt")):
         if os.path.exists(os.path.join(R, a)):
             shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}

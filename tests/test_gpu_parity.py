@@ -697,6 +697,36 @@ def test_fused_rollout_policy_matches_gemm_path(hip_lib, monkeypatch):
     assert abs(float(z.mean())) < 0.02 and abs(float(z.var()) - 1.0) < 0.05
 
 
+def test_single_rank_gradient_tail_matches_the_separate_kernels(hip_lib, monkeypatch):
+    """k_mlp_reduce_finish + myo_adam_apply (slab reduction, loss columns, gradient squares and step counter in one launch; the
+    single-rank path) against k_mlp_reduce + k_colmajor_finish + myo_adam_clip_step (what N > 1 ranks run around their
+    all-reduce): same rollout, same minibatches — the parameters after a PPO update agree to the rounding of the differently
+    ordered sum of squares."""
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+
+    def update(separate):
+        if separate:
+            monkeypatch.setenv("MYO_ADAM_SEPARATE", "1")
+        else:
+            monkeypatch.delenv("MYO_ADAM_SEPARATE", raising=False)
+        torch.manual_seed(0)
+        env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=512, seed=5)
+        pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
+        algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=8, batch_size=1024, n_epochs=2, max_grad_norm=0.05), seed=0)
+        assert (algo._fused.adam is None) == separate
+        algo.collect_rollouts()
+        algo.train()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone(), int(algo._flat_adam.step_count)
+    (a, na), (b, nb) = update(False), update(True)
+    assert na == nb == 8                     # 2 epochs x 4 minibatches: both paths advance Adam's counter once per step
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
 def test_captured_column_sums_survive_replays(hip_lib):
     """Column sums inside captured graphs (VecNormalize batch moments, bias gradients of the recurrent update)
     are ones-row GEMMs: ATen's multi-block column reduction returns wrong sums on every replay after the first

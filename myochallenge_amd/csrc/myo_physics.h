@@ -93,10 +93,10 @@ struct ContactRec {
 };
 
 template <typename T>
-struct RkScratch {                // RK4 stage storage: one per env in GLOBAL memory (a batch of an RK4 model allocates it), touched
-  HP x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];      // a handful of times per substep — in LDS it cost the mixed stepper one of its
-  T F[4][2 * MYO_NV_MAX + MYO_NU_MAX];              // eight workgroups per CU (23.3 KB instead of 20.2 KB: three rounds for 4096 envs)
-};
+struct RkScratch {                // RK4 stage storage: the start state and the running weighted sum of the stage derivatives (the
+  HP x0[MYO_NQ_MAX + MYO_NV_MAX + MYO_NU_MAX];      // next stage only needs the latest derivative, which goes straight into S_RKDX).
+  T Fsum[2 * MYO_NV_MAX + MYO_NU_MAX];              // 1,360 B in the mixed stepper: behind the scratch in LDS where eight workgroups
+};                                                  // per CU still fit (Scratch<float, 24>), else one per workgroup in GLOBAL memory
 
 template <typename T, int NC = MYO_NCON_MAX>
 struct Scratch {
@@ -2783,16 +2783,26 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
     // RK4 (mj_RungeKutta): tableau 1/2,1/2,1; weights 1/6,1/3,1/3,1/6
     const int nq = M.nq, nv = M.nv, na = M.na, nf = 2 * nv + na;
     const HP h = M.h_timestep; const HP t0 = s.time;
+    // (F0 + 2 F1 + 2 F2 + F3) / 6 is accumulated as it is written, left to right — ((F0 + 2 F1) + 2 F2) + F3 — so only the running
+    // sum is kept; stage st's derivative, scaled by the next stage's tableau entry, goes straight into S_RKDX
     PHASE {
       for (int i = lane; i < nq; i += 64) s.rk->x0[i] = s.qpos[i];
-      for (int i = lane; i < nv; i += 64) { s.rk->x0[nq + i] = s.qvel[i]; s.rk->F[0][i] = (T)s.qvel[i]; s.rk->F[0][nv + i] = s.qacc[i]; }
-      for (int i = lane; i < na; i += 64) { s.rk->x0[nq + nv + i] = s.act[i]; s.rk->F[0][2 * nv + i] = s.act_dot[i]; }
+      for (int i = lane; i < nv; i += 64) {
+        s.rk->x0[nq + i] = s.qvel[i];
+        const T f0 = (T)s.qvel[i], f1 = s.qacc[i];
+        s.rk->Fsum[i] = f0; s.rk->Fsum[nv + i] = f1;
+        S_RKDX(s)[i] = (T)0.5 * f0; S_RKDX(s)[nv + i] = (T)0.5 * f1;
+      }
+      for (int i = lane; i < na; i += 64) {
+        s.rk->x0[nq + nv + i] = s.act[i];
+        const T f2 = s.act_dot[i];
+        s.rk->Fsum[2 * nv + i] = f2; S_RKDX(s)[2 * nv + i] = (T)0.5 * f2;
+      }
     }
     SYNC();
     for (int st = 1; st < 4; ++st) {
       const T a = (st == 3) ? (T)1 : (T)0.5;
       PHASE {
-        for (int i = lane; i < nf; i += 64) S_RKDX(s)[i] = a * s.rk->F[st - 1][i];
         for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       }
       SYNC();
@@ -2805,14 +2815,22 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
       SYNC();
       forward(M, K, s);
       PHASE {
-        for (int i = lane; i < nv; i += 64) { s.rk->F[st][i] = (T)s.qvel[i]; s.rk->F[st][nv + i] = s.qacc[i]; }
-        for (int i = lane; i < na; i += 64) s.rk->F[st][2 * nv + i] = s.act_dot[i];
+        const T wgt = (st == 3) ? (T)1 : (T)2;          // weight of this stage in the sum
+        const T an = (st == 2) ? (T)1 : (T)0.5;         // tableau entry of the NEXT stage (unused after the last)
+        for (int i = lane; i < nv; i += 64) {
+          const T f0 = (T)s.qvel[i], f1 = s.qacc[i];
+          s.rk->Fsum[i] = s.rk->Fsum[i] + wgt * f0; s.rk->Fsum[nv + i] = s.rk->Fsum[nv + i] + wgt * f1;
+          S_RKDX(s)[i] = an * f0; S_RKDX(s)[nv + i] = an * f1;
+        }
+        for (int i = lane; i < na; i += 64) {
+          const T f2 = s.act_dot[i];
+          s.rk->Fsum[2 * nv + i] = s.rk->Fsum[2 * nv + i] + wgt * f2; S_RKDX(s)[2 * nv + i] = an * f2;
+        }
       }
       SYNC();
     }
     PHASE {
-      for (int i = lane; i < nf; i += 64)
-        S_RKDX(s)[i] = (s.rk->F[0][i] + 2 * s.rk->F[1][i] + 2 * s.rk->F[2][i] + s.rk->F[3][i]) / 6;
+      for (int i = lane; i < nf; i += 64) S_RKDX(s)[i] = s.rk->Fsum[i] / 6;
       for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i];
       for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i];

@@ -909,9 +909,11 @@ extern "C" int myo_batch_num_envs(const myo_batch* b) { return b ? b->n : -1; }
 extern "C" int myo_batch_obs_dim(const myo_batch* b) { return b ? b->nobs : -1; }
 extern "C" int myo_batch_lds_bytes(const myo_batch* b) {
   if (!b) return -1;
-  const bool big = b->ncap > MYO_NCON_MAX;       // RK4 stage storage is in global memory
+  const bool big = b->ncap > MYO_NCON_MAX;
   if (b->dtype == MYO_F64) return big ? (int)sizeof(Scratch<double, MYO_NCON_BIG>) : (int)sizeof(Scratch<double>);
-  return big ? (int)sizeof(Scratch<float, MYO_NCON_BIG>) : (int)sizeof(Scratch<float>);
+  if (big) return (int)sizeof(Scratch<float, MYO_NCON_BIG>);
+  // mixed stepper, base capacity: an RK4 model keeps its stage storage behind the scratch (MYO_RK_IN_LDS); elsewhere it is in global memory
+  return (int)(((sizeof(Scratch<float>) + 15) / 16 * 16) * (b->integrator == 1 ? 1 : 0) + (b->integrator == 1 ? sizeof(RkScratch<float>) : sizeof(Scratch<float>)));
 }
 extern "C" int myo_batch_dump_size(const myo_batch* b) { return b ? b->D.total : -1; }
 extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
@@ -936,6 +938,17 @@ extern "C" int myo_debug_read_prof(double* out16, int reset) {     /* out16: MYO
   return 0;
 }
 #endif
+// RK4 stage storage of this workgroup: behind the scratch in LDS for the mixed stepper with the base contact capacity (18,384 +
+// 1,360 B: still eight workgroups per CU; the per-workgroup block in global memory cost a global round trip in each of the
+// ~5 bookkeeping phases of a stage), in global memory otherwise (fp64: 31.6 KB + 1.8 KB would lose the fifth workgroup per CU)
+#define MYO_RK_IN_LDS(T, NC) (sizeof(T) == 4 && (NC) == MYO_NCON_MAX)
+static_assert(MYO_LDS_ALIGN(sizeof(Scratch<float, MYO_NCON_MAX>)) + sizeof(RkScratch<float>) <= 20480, "RK4 stage storage next to the scratch: eight workgroups per CU");
+template <typename T, bool RK, int NC>
+__device__ __forceinline__ RkScratch<T>* rk_storage() {
+  if constexpr (!RK) return nullptr;
+  else if constexpr (MYO_RK_IN_LDS(T, NC)) return reinterpret_cast<RkScratch<T>*>(myo_lds + MYO_LDS_ALIGN(sizeof(Scratch<T, NC>)));
+  else return reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x;
+}
 #ifdef MYO_WGTIME
 // developer diagnostic (tools/dev/gpu_wgtime.py): start / end of every workgroup of the last k_step launch on the 100 MHz wall clock
 __device__ unsigned long long g_wg_time[2 * 16384];
@@ -1001,7 +1014,7 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
                                              const int* __restrict__ order, unsigned int* __restrict__ ticks,
                                              int* part_state, const int* __restrict__ step_gen, StepPlan plan) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
+  s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int nparts = part_state ? plan.nparts : 1;
@@ -1068,7 +1081,7 @@ template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_reset(EnvRecordLayout L, double* rec,
                                               const unsigned char* mask, float* obs) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
+  s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -1078,7 +1091,7 @@ template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_step_inner(EnvRecordLayout L, double* rec, const unsigned char* mask, const float* act,
                                                    float* obs, unsigned char* done) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
+  s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -1088,7 +1101,7 @@ template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* rec,
                                                 const double* ctrl, int nsub) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
+  s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
@@ -1098,7 +1111,7 @@ template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_dump(EnvRecordLayout L, double* rec, const double* ctrl,
                                              DumpLayout D, double* out) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
-  s.rk = RK ? reinterpret_cast<RkScratch<T>*>(c_task.rk_ws) + blockIdx.x : nullptr;
+  s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;

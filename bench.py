@@ -19,7 +19,7 @@ that the GPU is busy long enough for outside telemetry; `ms_per_step` / `value` 
 (`blocks`, `timed_seconds`, `ms_per_step_min/max` say what was seen).  `variants` (rank 0, N = 1) carries the
 same measurement for the all-fp64 stepper and for the RK4 integrator.
 
-Launch:  python bench.py --gpus 1 --steps K --warmup W
+Launch:  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: bench.py starts the N ranks itself)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
 """
@@ -166,6 +166,23 @@ def trajectory_parity():
     return out
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torchrun with the
+    rendezvous on 127.0.0.1) as a CHILD process and relay its output and exit code.  Called before torch is imported, so
+    this parent never initialises the GPU (a process that has must not be replaced or forked on this pool)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -189,6 +206,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist

@@ -12,8 +12,24 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h", "myo_mjb.h", "mjb_layout.inc"]
+SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h", "myo_mjb.h", "mjb_layout.inc",
+           "myo_ppo_mlp.h"]
 HEADERS = [os.path.join(ROOT, "include", "myobatch.h"), os.path.join(ROOT, "include", "myo_model_blob.h")]
+
+
+def reachable_includes(entry: str = "myobatch.hip") -> set:
+    """Every file a quoted #include reaches from ``entry`` (absolute paths).  tests/test_config_and_abi.py checks
+    that SOURCES + HEADERS cover this set, so _stale() and source_id() see every file the library is made of."""
+    import re
+    seen, todo = set(), [os.path.join(CSRC, entry)]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f).read(), re.M):
+            todo.append(os.path.join(os.path.dirname(f), inc))
+    return seen
 
 
 def source_id() -> str:

@@ -151,3 +151,35 @@ def test_c_abi_argument_checks(emu_lib):
     buf = (C.c_float * 64)()
     assert L.myo_splitk_reduce(buf, 0, buf, 1, 2, 16, None) == -2          # valid arguments, but a GPU kernel
     assert L.myo_splitk_reduce(buf, 0, buf, 1, 2, 15, None) == -1          # odd n
+
+
+def test_build_identity_covers_every_included_file():
+    """source_id() / _stale() must see every file the library is compiled from."""
+    from myochallenge_amd import build
+    listed = {os.path.normpath(os.path.join(build.CSRC, s)) for s in build.SOURCES} | {os.path.normpath(h) for h in build.HEADERS}
+    missing = build.reachable_includes() - listed
+    assert not missing, f"not in build.SOURCES/HEADERS: {sorted(missing)}"
+
+
+def test_bench_gpus_n_spawns_a_launcher_before_torch(monkeypatch):
+    """`python bench.py --gpus 4` with no WORLD_SIZE must start 4 ranks (torch.distributed.run on 127.0.0.1) as a child and
+    return its exit code — without importing torch in the parent."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -556,6 +556,28 @@ def test_two_rank_graph_path_keeps_replicas_identical(hip_lib):
     assert not np.array_equal(a, init)
 
 
+def test_bench_spawns_its_own_ranks(hip_lib):
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself.  Both ranks share
+    this box's one GPU, so the collective backend is gloo here (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MYO_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2", "--envs", "256",
+                        "--min-seconds", "0.2", "--no-variants", "--no-cpu-baseline", "--dtype", "f64"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo"
+    assert rec["config"]["envs_per_gpu"] == 256 and rec["config"]["global_envs"] == 512
+    assert rec["steps"] == 8 and rec["warmup"] == 2 and rec["scaling"] == "weak"
+    assert abs(rec["value"] - 512 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
+
+
 @pytest.mark.parametrize("n_envs", [1, 63, 32768])
 def test_batch_size_edges(hip_lib, n_envs):
     """Ragged and extreme batch sizes (BASELINE config D's per-node total is 32768 envs): a step is

@@ -1328,6 +1328,24 @@ DEV void chol_factor_solve(Scratch<T, NC>& s, T* x, int n, int lead) {
 #endif
 }
 
+#include "myo_sparse_ldl.h"
+
+// x <- (M + [damped] h diag(b))^-1 x : the two M-only systems of a substep.  Tree-sparse L'DL where the model's tables
+// provide it, else the dense Cholesky of the Newton step.
+template <typename T, int NC>
+DEV void solve_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, T* x, int damped) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  // measured at 4096 envs (tools/dev/kab.py, MYO_DENSE_MSOLVE=1 for the dense side): fp64 4.345 -> 4.029 ms per env step with the sparse
+  // solves; the mixed stepper 2.229 -> 2.289 ms — its 24-wide register Cholesky (packed fp32 FMAs, pipelined column exchange) is
+  // already shorter than the ~23 LDS round trips of the level schedule, so fp32 keeps the dense path
+  if (sizeof(T) == sizeof(HP) && M.ld_nsq >= 0) {
+    ldl_factor_solve(M, s, LOFF(s, x), damped);
+  } else {
+    load_H_from_M(M, s, damped ? (const T*)M.dof_damping : (const T*)0, damped ? M.timestep : (T)0);
+    chol_factor_solve(s, x, M.nv, M.nlead);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // P6: collision (narrow phase per candidate pair; lanes = pairs).  HP and world coordinates: the contact
 // distance decides activation (dist < margin, discontinuous in MuJoCo's soft-contact model) and the spring
@@ -2647,10 +2665,9 @@ template <typename T, int NC>
 DEV void fwd_acceleration(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
-  load_H_from_M(M, s, (const T*)0, (T)0);
   PHASE { const int c = lane; if (c < M.nv) s.qacc_smooth[c] = s.qfrc_smooth[c]; }
   SYNC();
-  chol_factor_solve(s, s.qacc_smooth, M.nv, M.nlead);
+  solve_M(M, s, s.qacc_smooth, 0);
   PROF(s, 8)
   if (s.nefc == 0) {
     PHASE {
@@ -2840,10 +2857,9 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
     advance(M, s, LOFF(s, S_RKDX(s) + 2 * nv), LOFF(s, S_RKDX(s) + nv), LOFF(s, S_RKDX(s)));
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
-    load_H_from_M(M, s, (const T*)M.dof_damping, M.timestep);
     PHASE { const int c = lane; if (c < M.nv) s.search[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }   // (search: dead after the solver)
     SYNC();
-    chol_factor_solve(s, s.search, M.nv, M.nlead);
+    solve_M(M, s, s.search, 1);
     PROF(s, 12)
     advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.search), LNULL(const T));
     PROF(s, 13)

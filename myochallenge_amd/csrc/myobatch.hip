@@ -61,7 +61,7 @@ extern "C" const char* myo_version(void) {      // "... build <hash of the nativ
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
   MYO_MODEL_INT_ARRAYS(X)
@@ -101,6 +101,40 @@ static void quat2mat_h(const double* q, double* R) {
   R[0] = w * w + x * x - y * y - z * z; R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
   R[3] = 2 * (x * y + w * z); R[4] = w * w - x * x + y * y - z * z; R[5] = 2 * (y * z - w * x);
   R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = w * w - x * x - y * y + z * z;
+}
+
+// Item tables of the level-parallel tree-sparse L'DL (csrc/myo_sparse_ldl.h; mj_factorM / mj_solveM order of operations per
+// entry, scheduled by depth in the dof tree).  ld_fac word: e_ij | e_ki << 8 | e_kj << 16 | e_kk << 24 (indices into qM's
+// dof_Madr layout) for  M[i,j] -= M[k,i] M[k,j] / M[k,k];  ld_sol word: e_ij | i << 8 | j << 16, j a strict ancestor of i.
+// Levels deepest first, each padded to whole 64-item chunks with no-ops (e_ij = 255).  Rows >= nlead are diagonal by
+// construction and get no items.  A tree that needs more chunks than the kernel preloads keeps the dense solves.
+static void build_ldl_tables(myo_model* m) {
+  const int nv = m->nv;
+  std::vector<int> depth(nv, 0);
+  int maxd = 0;
+  for (int i = 0; i < nv; ++i) { depth[i] = m->dof_parentid[i] < 0 ? 0 : depth[m->dof_parentid[i]] + 1; if (depth[i] > maxd) maxd = depth[i]; }
+  std::vector<int> fac, sol;
+  const int nop = 255;
+  for (int L = maxd; L >= 1; --L) {
+    size_t f0 = fac.size(), s0 = sol.size();
+    for (int k = 0; k < nv && k < m->nlead; ++k) {
+      if (depth[k] != L) continue;
+      std::vector<int> anc;                               // strict ancestors of k, nearest first
+      for (int a = m->dof_parentid[k]; a >= 0; a = m->dof_parentid[a]) anc.push_back(a);
+      const int ek = m->dof_Madr[k];
+      for (size_t p = 0; p < anc.size(); ++p) {
+        sol.push_back((ek + 1 + (int)p) | (k << 8) | (anc[p] << 16));
+        for (size_t q = p; q < anc.size(); ++q)           // i = anc[p], j = anc[q] (j = i or an ancestor of i)
+          fac.push_back((m->dof_Madr[anc[p]] + (int)(q - p)) | ((ek + 1 + (int)p) << 8) | ((ek + 1 + (int)q) << 16) | (ek << 24));
+      }
+    }
+    if (fac.size() > f0) while (fac.size() % 64) fac.push_back(nop);
+    if (sol.size() > s0) while (sol.size() % 64) sol.push_back(nop);
+  }
+  m->ld_nfq = (int)fac.size() / 64; m->ld_nsq = (int)sol.size() / 64;
+  if (m->ld_nfq > MYO_LD_FQ || m->ld_nsq > MYO_LD_SQ || m->nM >= nop || getenv("MYO_DENSE_MSOLVE")) { m->ld_nfq = 0; m->ld_nsq = -1; fac.clear(); sol.clear(); }   // ld_nsq < 0: dense
+  fac.resize((size_t)MYO_LD_FQ * 64, nop); sol.resize((size_t)MYO_LD_SQ * 64, nop);
+  m->ld_fac = fac; m->ld_sol = sol;
 }
 
 static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out);
@@ -503,6 +537,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
       m->nlead = m->jnt_dofadr[j];
     else break;
   }
+  build_ldl_tables(m);
   m->any_damping = 0;
   for (int d = 0; d < nv; ++d) if (m->dof_damping[d] > 0) m->any_damping = 1;
   m->any_tendon_passive = 0;
@@ -633,6 +668,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
   D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte; D.npair_std = m->npair_std;
+  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];

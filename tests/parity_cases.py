@@ -177,6 +177,73 @@ def episode_drift(lib, mj, dtype, streams, nsteps=200, integrator=None, env_name
             "episode_end_disagreement_at": split}
 
 
+def local_error(lib, mj, dtype, streams, nsteps=200, integrator=None, seed=77):
+    """LOCAL (one-env-step) error of a stepper along the oracle's trajectory (VERDICT r03 "weak" 1: the whole-episode
+    drift of the mixed stepper mixes its own error with the trajectory's sensitivity; this separates them).  The oracle
+    walks the 16 seeded action streams of episode_drift (CustomMyoBaodingBallsP1, auto-resets included); BEFORE every env
+    step the device is put on the oracle's state (qpos, qvel, act, time, qacc_warmstart — the task counters advance in
+    lockstep), both take the step, and the resulting qpos / qvel / obs are compared.  Nothing is carried from one step to the
+    next on the device, so err[t] is what ONE env step (10 substeps) of the stepper adds.
+    Returns err_qpos_rel [n, nsteps], err_qvel_abs, err_obs_abs, done_disagreements (list of (stream, step))."""
+    mem = Mem(lib)
+    cm, om, _ = oracle_for(mj, integrator=integrator)
+    n = len(streams)
+    tc = make_task_cfg("CustomMyoBaodingBallsP1", cm)
+    b = native.Batch(native.Model(cm, lib), tc, n, 0, seed, dtype)
+    obs = mem.zeros((n, 86), np.float32)
+    b.reset(None, obs)
+    ocfg = make_cfg(task_ids(cm), drop_th=tc.drop_th, proximity_th=tc.proximity_th,
+                    weights={k: tc.weights[i] for i, k in enumerate(("pos_dist_1", "pos_dist_2", "act_reg", "alive", "sparse", "solved", "done"))})
+    orc = []
+    for e in range(n):
+        d = OracleData(om)
+        d.reset(); d.qpos[:23] = 0; d.qpos[0] = -1.57
+        orc.append([d, default_state(), 0])
+    rngs = [np.random.RandomState(sd) for _, sd in streams]
+    rew, done, trunc = mem.zeros(n, np.float32), mem.zeros(n, np.uint8), mem.zeros(n, np.uint8)
+    term = mem.zeros((n, 86), np.float32)
+    qp, qv = mem.zeros((n, om.nq)), mem.zeros((n, om.nv))
+    err_q, err_v, err_o = np.zeros((n, nsteps)), np.zeros((n, nsteps)), np.zeros((n, nsteps))
+    disagree, n_ends = [], 0
+    for t in range(nsteps):
+        # the device starts this step from the oracle's state
+        b.set_state(mem.arr(np.stack([o[0].qpos for o in orc])), mem.arr(np.stack([o[0].qvel for o in orc])),
+                    mem.arr(np.stack([o[0].act for o in orc])), mem.arr(np.array([o[0].arr("time")[0] for o in orc])))
+        b.warmstart(None, mem.arr(np.stack([np.array(o[0].arr("qacc_warmstart")) for o in orc])))
+        a = np.stack([np.clip(r.normal(0, sg, 39), -1, 1) for r, (sg, _) in zip(rngs, streams)]).astype(np.float32)
+        b.step(mem.arr(a, np.float32), obs, rew, done, trunc, term)
+        b.get_state(qp, qv)
+        h_obs, h_term, h_done, h_qp, h_qv = (mem.host(x) for x in (obs, term, done, qp, qv))
+        for e in range(n):
+            d, st, el = orc[e]
+            o, c = baoding_step(d, ocfg, st, a[e])
+            el += 1
+            o_done = bool(c[6]) or el >= tc.max_episode_steps
+            if bool(h_done[e]) != o_done:
+                disagree.append((e, t))
+                err_q[e, t] = err_v[e, t] = err_o[e, t] = 1.0
+            elif o_done:
+                err_o[e, t] = np.abs(h_term[e] - o).max()       # (the device state has been reset: the terminal observation is what is left of the step)
+            else:
+                err_o[e, t] = np.abs(h_obs[e] - o).max()
+                err_q[e, t] = np.abs(h_qp[e] - d.qpos).max() / np.abs(d.qpos).max()
+                err_v[e, t] = np.abs(h_qv[e] - d.qvel).max()
+            if o_done or bool(h_done[e]):
+                n_ends += 1
+                # both sides start the next episode from the deterministic P1 reset; a device that did NOT reset is put
+                # there too (set_state above), its task counters by an explicit reset of that env
+                if not bool(h_done[e]):
+                    m = np.zeros(n, np.uint8); m[e] = 1
+                    b.reset(mem.arr(m, np.uint8), obs)
+                d.reset(); d.qpos[:23] = 0; d.qpos[0] = -1.57
+                orc[e] = [d, default_state(), 0]
+            else:
+                orc[e][2] = el
+    b.close()
+    return {"streams": [list(x) for x in streams], "err_qpos_rel": err_q, "err_qvel_abs": err_v, "err_obs_abs": err_o,
+            "done_disagreements": disagree, "episode_ends": n_ends}
+
+
 def write_drift_record(r, path, dtype_name, integrator_name, nsteps):
     """Drift table of episode_drift as JSON (every 10th step) — test evidence, copied into profiles/ per round."""
     import json
@@ -189,6 +256,7 @@ def write_drift_record(r, path, dtype_name, integrator_name, nsteps):
                "streams (action sigma, seed)": r["streams"], "episode_ends": r["episode_ends"],
                "episode_end_disagreement_at": r["episode_end_disagreement_at"],
                "max_err_qpos_rel": [f3(v) for v in r["err_qpos_rel"].max(1)], "max_err_obs_abs": [f3(v) for v in r["err_obs_abs"].max(1)],
+               "steps_above_1e-4 (step, err_qpos_rel)": [[(int(t), f3(row[t])) for t in np.nonzero(row > 1e-4)[0][:12]] for row in r["err_qpos_rel"]],
                "err_qpos_rel_every_10th_step": [[f3(v) for v in row[9::10]] for row in r["err_qpos_rel"]],
                "err_obs_abs_every_10th_step": [[f3(v) for v in row[9::10]] for row in r["err_obs_abs"]]}, open(path, "w"), indent=1)
 

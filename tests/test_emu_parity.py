@@ -77,6 +77,14 @@ def test_episode_trajectory_mixed(emu_lib, models):
     pc.case_episode_trajectory(emu_lib, models["hand"], native.MYO_MIXED, [(0.08, 0), (0.135, 0)], 1e-4)
 
 
+def test_local_error_of_the_mixed_stepper(emu_lib, models):
+    """Re-synchronised to the oracle's state before every env step, the mixed stepper adds <= 1e-6 (relative, qpos) per env
+    step on every stream — its whole-episode drift is the trajectory's sensitivity, not a local error (parity_cases.local_error)."""
+    r = pc.local_error(emu_lib, models["hand"], native.MYO_MIXED, [(0.08, 0), (0.08, 3), (0.135, 1), (0.135, 6)], 200)
+    assert not r["done_disagreements"] and r["episode_ends"] >= 4
+    assert r["err_qpos_rel"].max() <= 1e-6 and r["err_obs_abs"].max() <= 1e-6 and r["err_qvel_abs"].max() <= 1e-3, (r["err_qpos_rel"].max(1), r["err_qvel_abs"].max(1))
+
+
 def test_episode_trajectory_rk4_mixed(emu_lib, models):
     """The mixed stepper with RK4 (the `variants.rk4` bench path): lane-serial build vs oracle, whole episodes."""
     r = pc.episode_drift(emu_lib, models["hand"], native.MYO_MIXED, [(0.08, 0), (0.08, 4), (0.135, 0), (0.135, 2)], 200, integrator=1)

@@ -75,6 +75,52 @@ def test_episode_trajectory_mixed(hip_lib, models):
     assert r["err_qpos_rel"][:, :60].max() <= 1e-4 and r["err_obs_abs"][:, :60].max() <= 1e-4, (r["err_qpos_rel"][:, :60].max(1),)
     assert np.median(mq) <= 1e-4 and np.median(mo) <= 1e-4
     assert int(((mq <= 1e-4) & (mo <= 1e-4)).sum()) >= 10, (mq, mo)
+    # (iv) where the excess sits: only in the run-up to an episode's end (a ball leaving the hand).  Every stream holds 1e-4 at every
+    # step that is more than 25 env steps before its next episode end (either side's), and >= 15 of 16 with a 10-step window.
+    assert _streams_within_outside_endings(r, 25) == len(mq) and _streams_within_outside_endings(r, 10) >= 15, (
+        _streams_within_outside_endings(r, 25), _streams_within_outside_endings(r, 10))
+
+
+def test_local_error_of_the_steppers(hip_lib, models):
+    """VERDICT r03 "weak" 1: the LOCAL error of the benched (mixed) stepper.  The device is put on the oracle's state before
+    every env step (qpos, qvel, act, time, warm start), so nothing accumulates: all 16 streams x 200 env steps, auto-resets
+    included, must stay within 1e-6 (qpos, relative; float32 observation, absolute) of the oracle's step — two orders under
+    north_star's 1e-4 — and both sides must end every episode on the same step.  The fp64 stepper: 1e-12.
+    Record: gpurun_out/drift_local_*.json (committed copy profiles/r04_local_error_*.json)."""
+    import json
+    import os
+    for name, dt, tol_q, tol_o in (("mixed", native.MYO_MIXED, 1e-6, 1e-6), ("f64", native.MYO_F64, 1e-12, 1e-7)):
+        r = pc.local_error(hip_lib, models["hand"], dt, STREAMS16, 200)
+        os.makedirs(os.path.dirname(PROFILES), exist_ok=True)
+        json.dump({"what": "tests/parity_cases.local_error: per-env-step error of the HIP stepper started from the oracle's state at every step",
+                   "dtype": name, "env_steps": 200, "streams (action sigma, seed)": r["streams"], "episode_ends": r["episode_ends"],
+                   "done_disagreements": r["done_disagreements"],
+                   "max_err_qpos_rel": [float("%.3g" % v) for v in r["err_qpos_rel"].max(1)],
+                   "median_err_qpos_rel": float("%.3g" % np.median(r["err_qpos_rel"])),
+                   "max_err_qvel_abs": [float("%.3g" % v) for v in r["err_qvel_abs"].max(1)],
+                   "max_err_obs_abs": [float("%.3g" % v) for v in r["err_obs_abs"].max(1)]}, open(PROFILES + "_local_%s.json" % name, "w"), indent=1)
+        assert not r["done_disagreements"] and r["episode_ends"] >= 16, r["done_disagreements"]
+        assert r["err_qpos_rel"].max() <= tol_q and r["err_obs_abs"].max() <= tol_o, (name, r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))
+
+
+def _streams_within_outside_endings(r, window, tol=1e-4):
+    """number of streams whose qpos error is <= tol at every step that is MORE than `window` env steps before the stream's next
+    episode end (an end seen by either side; a stream whose sides ended an episode on different steps counts that step as an end)"""
+    ok = 0
+    for e, row in enumerate(r["err_qpos_rel"]):
+        ends = list(r["episode_ends"][e]) + ([r["episode_end_disagreement_at"][e]] if r["episode_end_disagreement_at"][e] is not None else [])
+        split = r["episode_end_disagreement_at"][e]
+        good = True
+        for t, v in enumerate(row):
+            if split is not None and t >= split:
+                break                                   # nothing is compared after the sides have separated
+            nxt = min([x for x in ends if x >= t], default=None)
+            if nxt is not None and nxt - t <= window:
+                continue
+            if v > tol:
+                good = False
+        ok += good
+    return ok
 
 
 def _mixed_bounds(r, first=60, first_tol=1e-4):
@@ -560,6 +606,7 @@ def test_bench_spawns_its_own_ranks(hip_lib):
     """`python bench.py --gpus 2` with no launcher around it starts two ranks itself.  Both ranks share
     this box's one GPU, so the collective backend is gloo here (RCCL refuses two ranks on one device)."""
     import json
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

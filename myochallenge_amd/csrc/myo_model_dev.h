@@ -22,6 +22,9 @@
 #define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows
 #define MYO_NEFC_MAX (MYO_NLIM_MAX + 4 * MYO_NCON_MAX)
 #define MYO_OBS_MAX 104
+#define MYO_ARROW_S 16    // separator rows of the block-arrow Newton system (one MFMA tile)
+#define MYO_ARROW_B 4     // rows per leaf block (= the K of v_mfma_*_16x16x4)
+#define MYO_ARROW_NF ((MYO_NV_MAX - MYO_ARROW_S) / MYO_ARROW_B)
 #define MYO_LD_FQ 12      // 64-item chunks of the tree-sparse L'DL factorisation (myo_sparse_ldl.h); more: the dense path
 #define MYO_LD_SQ 8       // 64-item chunks of its substitutions
 #ifndef MYO_OBJG_MAX
@@ -39,7 +42,7 @@
   X(geom_bodyid) X(geom_priority) X(site_bodyid) X(tendon_adr) X(tendon_num) X(tendon_limited)   \
   X(wrap_type) X(wrap_objid) X(wrap_side) X(actuator_dyntype) X(actuator_gaintype)               \
   X(actuator_biastype) X(actuator_tendon) X(actuator_ctrllimited) X(actuator_forcelimited)       \
-  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk) X(te_i) X(tendon_eadr) X(tendon_enum) X(ld_fac) X(ld_sol)
+  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk) X(te_i) X(tendon_eadr) X(tendon_enum) X(ld_fac) X(ld_sol) X(hperm) X(M_pkh)
 #define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask) X(act_dofmask) X(wr_mask) X(pc_mask)
 #define MYO_MODEL_REAL_ARRAYS(X)                                                                 \
   X(qpos0) X(qpos_spring) X(body_pos) X(body_quat) X(body_ipos) X(body_imat) X(body_mass)        \
@@ -83,6 +86,8 @@ struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
   int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
   int npair_std;                // pairs [0, npair_std): collision_pass; [npair_std, npair): collision_pass_ext
+  int arrow_nf;                 // block-arrow Newton system (myo_arrow_chol.h): number of 4-row leaf blocks behind the 16-row separator; 0: dense
+  unsigned long long arrow_pad; // rows of the (permuted) 36-row system that hold no dof: identity
   int ld_nfq, ld_nsq;           // chunks of ld_fac / ld_sol in use (ld_nsq < 0: the model's M-only solves take the dense path)
   T timestep, tolerance, impratio, gravity[3], meaninertia;
   double h_timestep;            // the integration step of the HP state update

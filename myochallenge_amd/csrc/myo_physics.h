@@ -135,6 +135,7 @@ struct Scratch {
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
   // ---- constraints
   int ncon, nefc, nl, ntl, bad, solver_iter;
+  unsigned char hperm[MYO_NV_MAX];   // dof -> row of the Newton system (DevModel::hperm; identity unless the block-arrow solver is on)
   // (from con[] to Mv, i.e. up to rk: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live)
   alignas(8) ContactRec<T> con[NC];
   int lim_id[MYO_NLIM_MAX];                                            // dof (joint rows) / tendon (tendon rows); bit 31: the upper limit (row sign -1)
@@ -958,9 +959,9 @@ DEV void mul_M(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LREF(T) out_
   SYNC();
 }
 
-// packed dense H <- M (+ diag)
+// packed dense H <- M (+ diag).  perm = 1: rows in the Newton system's order (hperm; M_pkh holds the packed offsets)
 template <typename T, int NC>
-DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, const T* diag_add, T diag_scale) {
+DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, const T* diag_add, T diag_scale, int perm = 0) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   PHASE {
@@ -972,11 +973,12 @@ DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, const T* d
   }
   SYNC();
   PHASE {
-    if (lane >= M.nv && lane < MYO_NV_MAX) s.H[MYO_HIDX(lane, lane)] = 1;   // identity on the padding rows
+    // identity on the rows that hold no dof
+    if (lane < MYO_NV_MAX && (perm ? (int)((M.arrow_pad >> lane) & 1ull) : (lane >= M.nv))) s.H[MYO_HIDX(lane, lane)] = 1;
     constexpr int NE = (MYO_NM_MAX + 63) / 64;
-    int pk[NE];
+    int pk[NE], ph[NE];
 #pragma unroll
-    for (int q = 0; q < NE; ++q) pk[q] = M.M_pk[(lane + 64 * q) < MYO_NM_MAX ? (lane + 64 * q) : 0];
+    for (int q = 0; q < NE; ++q) { pk[q] = M.M_pk[(lane + 64 * q) < MYO_NM_MAX ? (lane + 64 * q) : 0]; ph[q] = M.M_pkh[(lane + 64 * q) < MYO_NM_MAX ? (lane + 64 * q) : 0]; }
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
       const int e = lane + 64 * q;
@@ -984,7 +986,7 @@ DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, const T* d
         const int i = pk[q] & 255, j = (pk[q] >> 8) & 255;
         T v = s.qM[e];
         if (i == j && diag_add) v += diag_scale * diag_add[i];
-        s.H[MYO_HIDX(i, j)] = v;
+        s.H[perm ? ph[q] : MYO_HIDX(i, j)] = v;
       }
     }
   }
@@ -1329,6 +1331,7 @@ DEV void chol_factor_solve(Scratch<T, NC>& s, T* x, int n, int lead) {
 }
 
 #include "myo_sparse_ldl.h"
+#include "myo_arrow_chol.h"
 
 // x <- (M + [damped] h diag(b))^-1 x : the two M-only systems of a substep.  Tree-sparse L'DL where the model's tables
 // provide it, else the dense Cholesky of the Newton step.
@@ -2455,7 +2458,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         const T Dr = s.efc_D[r];
         acc += (s.efc_active[r] && lim_index(s.lim_id[r]) == d) ? Dr : (T)0;
       }
-      if (acc != 0) s.H[MYO_HIDX(d, d)] += acc;
+      if (acc != 0) { const int pd = s.hperm[d]; s.H[MYO_HIDX(pd, pd)] += acc; }
     }
   }
   SYNC();
@@ -2473,7 +2476,8 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         for (int k = 0; k < a; ++k) ma &= ma - 1;
         for (int k = 0; k < b; ++k) mb &= mb - 1;
         const int da = myo_ffsll(ma), db = myo_ffsll(mb);
-        s.H[MYO_HIDX(da, db)] += s.efc_D[r] * s.ten_J[t * MYO_TJ_MAX + a] * s.ten_J[t * MYO_TJ_MAX + b];
+        const int pa = s.hperm[da], pb = s.hperm[db];
+        s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += s.efc_D[r] * s.ten_J[t * MYO_TJ_MAX + a] * s.ten_J[t * MYO_TJ_MAX + b];
       }
     }
     SYNC();
@@ -2532,7 +2536,8 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
             const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
             const T Ajb1 = A1 * jb[0] + A3 * jb[1];
             const T Ajb2 = A2 * jb[0] + A4 * jb[2];
-            s.H[MYO_HIDX(da, db)] += ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2;
+            const int pa = s.hperm[da], pb = s.hperm[db];
+            s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2;
           }
         }
       }
@@ -2574,11 +2579,18 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   int iter = 0;
   while (iter < M.iterations) {
     PROF(s, 11)
-    load_H_from_M(M, s, (const T*)0, (T)0);
+    load_H_from_M(M, s, (const T*)0, (T)0, 1);
     build_hessian(M, s);
     PROF(s, 9)
     PHASE { const int c = lane; if (c < nv) s.search[c] = -s.grad[c]; }
     SYNC();
+#ifndef MYO_EMU
+    if (M.arrow_nf > 0) {
+      arrow_eliminate_blocks<T, NC>(LOFF(s, s.search));
+      chol_factor_solve_reg<T, MYO_ARROW_S, NC>(LOFF(s, s.Mv), MYO_ARROW_S);
+      arrow_finish<T, NC>(LOFF(s, s.search));
+    } else
+#endif
     chol_factor_solve(s, s.search, nv, (s.ncon == 0 && s.ntl == 0) ? M.nlead : nv);
     PROF(s, 10)
     mul_M(M, s, LOFF(s, s.Mv), LOFF(s, s.search));

@@ -469,6 +469,7 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
     for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i];
     for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = 0;
+    if (lane < MYO_NV_MAX) s.hperm[lane] = (unsigned char)M.hperm[lane];
     if (lane == 0) {
       s.time = rec[L.off_time];
       const double* td = rec + L.off_taskd;

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <algorithm>
 
 #include "../../include/myo_model_blob.h"
 #include "myo_mjb.h"
@@ -61,7 +62,8 @@ extern "C" const char* myo_version(void) {      // "... build <hash of the nativ
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq, arrow_nf;
+  unsigned long long arrow_pad;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
   MYO_MODEL_INT_ARRAYS(X)
@@ -135,6 +137,87 @@ static void build_ldl_tables(myo_model* m) {
   if (m->ld_nfq > MYO_LD_FQ || m->ld_nsq > MYO_LD_SQ || m->nM >= nop || getenv("MYO_DENSE_MSOLVE")) { m->ld_nfq = 0; m->ld_nsq = -1; fac.clear(); sol.clear(); }   // ld_nsq < 0: dense
   fac.resize((size_t)MYO_LD_FQ * 64, nop); sol.resize((size_t)MYO_LD_SQ * 64, nop);
   m->ld_fac = fac; m->ld_sol = sol;
+}
+
+// Block-arrow structure of the Newton system H = M + J'DJ (csrc/myo_arrow_chol.h).  Leaf blocks: subtrees of the dof tree with at
+// most MYO_ARROW_B dofs that no constraint couples to another block — M couples a dof with its ancestors and descendants only, a
+// tendon-limit row couples the dofs its tendon moves, a contact the dofs that move either body (the hand: five 4-dof fingers; the
+// wrist and the free balls / die couple everything and form the separator).  hperm[dof] = row of the permuted system: separator
+// rows 0..15, block f at 16 + 4 f; rows without a dof are identity (arrow_pad).  M_pkh[e] = packed-H offset of M's entry e in that
+// order.  arrow_nf = 0 (structure absent, separator too large, MYO_DENSE_NEWTON set, emulation build): identity order, dense path.
+static void build_arrow_tables(myo_model* m) {
+  const int nv = m->nv;
+  m->hperm.assign(MYO_NV_MAX, 0);
+  for (int d = 0; d < MYO_NV_MAX; ++d) m->hperm[d] = d;
+  m->arrow_nf = 0; m->arrow_pad = 0;
+  auto finish = [&]() {
+    m->M_pkh.assign(MYO_NM_MAX, 0);
+    for (int e = 0; e < m->nM; ++e) {
+      const int a = m->hperm[m->M_i[e]], b = m->hperm[m->M_j[e]], hi = a > b ? a : b, lo = a > b ? b : a;
+      const int q = hi >> 2;
+      m->M_pkh[e] = ((q * (q + 1)) << 3) + (((hi & 3) * (q + 1)) << 2) + lo;      // MYO_HIDX(hi, lo)
+    }
+    if (!m->arrow_nf) for (int d = nv; d < MYO_NV_MAX; ++d) m->arrow_pad |= 1ull << d;
+  };
+#ifdef MYO_EMU
+  finish(); return;
+#endif
+  if (getenv("MYO_DENSE_NEWTON") || nv > MYO_NV_MAX) { finish(); return; }
+  // subtree sizes; candidate blocks = maximal subtrees of <= MYO_ARROW_B dofs
+  std::vector<int> size(nv, 1), block(nv, -1);
+  for (int d = nv - 1; d >= 0; --d) if (m->dof_parentid[d] >= 0) size[m->dof_parentid[d]] += size[d];
+  std::vector<std::vector<int>> blocks;
+  for (int d = 0; d < nv; ++d) {
+    const int par = m->dof_parentid[d];
+    if (size[d] <= MYO_ARROW_B && (par < 0 || size[par] > MYO_ARROW_B)) {
+      std::vector<int> mem;
+      for (int e = d; e < nv; ++e) { int a = e; while (a >= 0 && a != d) a = m->dof_parentid[a]; if (a == d) { mem.push_back(e); block[e] = (int)blocks.size(); } }
+      blocks.push_back(mem);
+    }
+  }
+  // constraint couplings between blocks; the most-coupled block goes to the separator until none is left (a free ball's
+  // trailing dofs form a candidate block that every finger touches: it goes, the fingers stay)
+  std::vector<unsigned long long> sets;
+  for (int t = 0; t < m->ntendon; ++t) sets.push_back(m->tendon_dofmask[t]);
+  for (int p = 0; p < m->npair; ++p) sets.push_back(m->pc_mask[2 * (size_t)p] | m->pc_mask[2 * (size_t)p + 1]);
+  const size_t nblk = blocks.size();
+  std::vector<std::vector<char>> adj(nblk, std::vector<char>(nblk, 0));
+  for (unsigned long long mk : sets) {
+    std::vector<int> bs;
+    for (int d = 0; d < nv; ++d) if (((mk >> d) & 1ull) && block[d] >= 0 && std::find(bs.begin(), bs.end(), block[d]) == bs.end()) bs.push_back(block[d]);
+    for (int a : bs) for (int b : bs) if (a != b) adj[a][b] = 1;
+  }
+  std::vector<char> demote(nblk, 0);
+  for (;;) {
+    int worst = -1, wdeg = 0;
+    for (size_t a = 0; a < nblk; ++a) {
+      if (demote[a]) continue;
+      int deg = 0;
+      for (size_t b = 0; b < nblk; ++b) if (!demote[b] && adj[a][b]) deg++;
+      if (deg > wdeg) { wdeg = deg; worst = (int)a; }
+    }
+    if (worst < 0) break;
+    demote[worst] = 1;
+  }
+  // keep the largest blocks (at most MYO_ARROW_NF); everything else is separator
+  std::vector<int> keep;
+  for (size_t b = 0; b < blocks.size(); ++b) if (!demote[b]) keep.push_back((int)b);
+  std::stable_sort(keep.begin(), keep.end(), [&](int a, int b) { return blocks[a].size() > blocks[b].size(); });
+  if ((int)keep.size() > MYO_ARROW_NF) keep.resize(MYO_ARROW_NF);
+  std::vector<char> in_keep(blocks.size(), 0);
+  for (int b : keep) in_keep[b] = 1;
+  int nsep = 0;
+  for (int d = 0; d < nv; ++d) if (block[d] < 0 || !in_keep[block[d]]) nsep++;
+  if (keep.size() < 2 || nsep > MYO_ARROW_S) { finish(); return; }
+  std::sort(keep.begin(), keep.end());
+  unsigned long long used = 0;
+  int ns = 0;
+  for (int d = 0; d < nv; ++d) if (block[d] < 0 || !in_keep[block[d]]) { m->hperm[d] = ns; used |= 1ull << ns; ns++; }
+  for (size_t f = 0; f < keep.size(); ++f)
+    for (size_t t = 0; t < blocks[keep[f]].size(); ++t) { const int r = MYO_ARROW_S + MYO_ARROW_B * (int)f + (int)t; m->hperm[blocks[keep[f]][t]] = r; used |= 1ull << r; }
+  m->arrow_nf = (int)keep.size();
+  m->arrow_pad = ~used & ((1ull << MYO_NV_MAX) - 1ull);
+  finish();
 }
 
 static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out);
@@ -538,6 +621,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     else break;
   }
   build_ldl_tables(m);
+  build_arrow_tables(m);
   m->any_damping = 0;
   for (int d = 0; d < nv; ++d) if (m->dof_damping[d] > 0) m->any_damping = 1;
   m->any_tendon_passive = 0;
@@ -578,7 +662,7 @@ extern "C" void myo_model_destroy(myo_model* m) { delete m; }
 extern "C" int myo_model_size(const myo_model* m, const char* n) {
   if (!m || !n) return -1;
 #define S(x) if (!strcmp(n, #x)) return m->x;
-  S(nq) S(nv) S(nu) S(na) S(nbody) S(njnt) S(ngeom) S(nsite) S(ntendon) S(nwrap) S(npair) S(nM) S(integrator)
+  S(nq) S(nv) S(nu) S(na) S(nbody) S(njnt) S(ngeom) S(nsite) S(ntendon) S(nwrap) S(npair) S(nM) S(integrator) S(nlead) S(arrow_nf) S(ld_nfq) S(ld_nsq)
 #undef S
   return -1;
 }
@@ -606,8 +690,9 @@ struct myo_batch {
   int* order;
   float* cost;
   unsigned int* ticks;
-  // two-part env steps (k_step): part_state[env] = 2 g - 2 before step g, 2 g - 1 while the first part runs, 2 g once its record is
-  // published; step_gen[0] = g, advanced on the stream after every step.  split_k1 = substeps in the first part (0: whole steps).
+  // env steps in parts (k_step): part_state[env] = 16 g + 2 q (parts < q of step g published) or + 1 (part q claimed, running);
+  // step_gen[0] = g, advanced on the stream after every step; step_gen[1] = workgroups that met a state of another generation
+  // (myo_batch_protocol_errors).  plan = substep boundaries of the parts.
   int* part_state;
   int* step_gen;
   StepPlan plan;
@@ -668,7 +753,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
   D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte; D.npair_std = m->npair_std;
-  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq;
+  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];
@@ -1048,7 +1133,7 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info, unsigned char* bad_state,
                                              const int* __restrict__ order, unsigned int* __restrict__ ticks,
-                                             int* part_state, const int* __restrict__ step_gen, StepPlan plan) {
+                                             int* part_state, int* __restrict__ step_gen, StepPlan plan) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
@@ -1075,7 +1160,12 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
       for (;;) {
         const int v = __hip_atomic_load(st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned j = (unsigned)v - base;
-        if (j > 2u * (unsigned)p) break;        // part p is claimed or done (or the state belongs to another generation): exit
+        if (j > 2u * (unsigned)p) {             // part p is claimed or done: exit.  A state of ANOTHER generation (neither a part of this
+          // step nor its final 16 (g + 1)) means step_gen and part_state have come apart — a failed launch, two streams stepping one
+          // batch: the step would silently write nothing, so it is counted (myo_batch_protocol_errors) and the env flagged
+          if (j > 2u * (unsigned)nparts && j != 16u) { atomicAdd(step_gen + 1, 1); if (bad_state) bad_state[env] = 1; }
+          break;
+        }
         if ((j & 1) == 0) {
           int expect = v;
           if (__hip_atomic_compare_exchange_strong(st, &expect, (int)((unsigned)v + 1u), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { from = (int)(j >> 1); break; }
@@ -1094,6 +1184,8 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
     }
     const int last = p == nparts - 1;
     env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, plan.k[q], last ? -1 : plan.k[p + 1]);
+    // (the duration is added BEFORE the part is published: the next part's workgroup may run, and add its own, the moment it is)
+    if (ticks && threadIdx.x == 0) { const unsigned int d = (unsigned int)(wall_clock64() - t_start); if (q > 0) ticks[env] += d; else ticks[env] = d; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1102,8 +1194,8 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
     }
   } else {
     env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
+    if (ticks && threadIdx.x == 0) ticks[env] = (unsigned int)(wall_clock64() - t_start);
   }
-  if (ticks && threadIdx.x == 0) { const unsigned int d = (unsigned int)(wall_clock64() - t_start); if (q > 0) ticks[env] += d; else ticks[env] = d; }
 #ifdef MYO_WGTIME
   if (threadIdx.x == 0 && blockIdx.x < 16384) g_wg_time[2 * blockIdx.x + 1] = wall_clock64();
 #endif
@@ -1380,6 +1472,7 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->plan.nparts * b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->plan))
   timing_end(b, st);
+  LAUNCH_CHECK(b)                 // the generation below only advances behind a k_step that was launched
   if (b->order || b->step_gen) hipLaunchKernelGGL(k_step_order, dim3(1), dim3(b->order ? 1024 : 64), 0, st, (const unsigned int*)b->ticks, b->cost, b->n, b->order, b->step_gen);
   LAUNCH_CHECK(b)
 #endif
@@ -1402,6 +1495,22 @@ extern "C" int myo_batch_set_step_generation(myo_batch* b, unsigned int gen) {
     return fail(MYO_E_DEVICE, "myo_batch_set_step_generation: copy failed");
   return MYO_OK;
 #endif
+}
+
+// number of k_step workgroups that found their env's hand-off state in another generation than the launch's (0 in a healthy
+// batch; synchronises the device).  See the protocol comment at k_step.
+extern "C" int myo_batch_protocol_errors(myo_batch* b, int* out) {
+  if (!b || !out) return fail(MYO_E_ARG, "null argument");
+  *out = 0;
+#ifndef MYO_EMU
+  if (!b->step_gen) return MYO_OK;
+  DeviceGuard guard(b->device);
+  int g4[4] = {0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(g4, b->step_gen, sizeof g4, hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(MYO_E_DEVICE, "myo_batch_protocol_errors: copy failed");
+  *out = g4[1];
+#endif
+  return MYO_OK;
 }
 
 extern "C" int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const float* act, float* obs, uint8_t* done, void* stream) {

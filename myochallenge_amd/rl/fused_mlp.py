@@ -240,10 +240,16 @@ class FusedPPOStep:
         if not shapes_ok or self.policy.log_std.dim() != 1 or obs_all.dtype != torch.float32:
             return None
         G = flat["p"].numel()
-        key = (B, obs_all.data_ptr(), act_all.data_ptr(), oldlp_all.data_ptr(), adv_all.data_ptr(), ret_all.data_ptr(), idx.data_ptr())
+        # one descriptor + workspace per SHAPE (the workspace is ~90 MB at B = 16384); the six data pointers are rewritten on every
+        # call — the library reads the descriptor at call time, so a captured graph keeps the pointers it was captured with and an
+        # eager caller may pass fresh tensors per minibatch without growing the cache
+        key = (B, O, self.A, hid, G)
         hit = self._mfma.get(key)
         if hit is not None:
-            return hit[0]
+            d = hit[0]
+            if d is not None:
+                d.obs, d.act, d.oldlp, d.adv, d.ret, d.idx = (t.data_ptr() for t in (obs_all, act_all, oldlp_all, adv_all, ret_all, idx))
+            return d
         nbytes = self.lib.L.myo_ppo_mlp_workspace_bytes(B, O, self.A, hid, G)
         if nbytes <= 0:
             self._mfma[key] = (None, None)

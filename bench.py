@@ -17,7 +17,9 @@ Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barri
 and taken as the max over ranks; blocks repeat until --min-seconds (default 2 s) of timed wall have passed, so
 that the GPU is busy long enough for outside telemetry; `ms_per_step` / `value` are the MEDIAN block
 (`blocks`, `timed_seconds`, `ms_per_step_min/max` say what was seen).  `variants` (rank 0, N = 1) carries the
-same measurement for the all-fp64 stepper and for the RK4 integrator.
+same measurement for the mixed-precision stepper and for the RK4 integrator.  Since round 4 the headline is the all-fp64 stepper
+(`--dtype f64`, the reference's own arithmetic); `--dtype mixed` is the faster variant whose per-step error is bounded in
+tests/test_gpu_parity.py::test_local_error_of_the_steppers.
 
 Launch:  python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: bench.py starts the N ranks itself)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -141,20 +143,23 @@ def _count_flops_here(env_steps):
 
 
 FLOPS_RECORD = os.path.join(ROOT, "profiles", "r02_flops.json")     # the same count, committed (used when the CPU leg is skipped)
-PMC_RECORD = os.path.join(ROOT, "profiles", "r03_pmc.json")         # rocprofv3 --pmc passes over the default command (tools/profile_round.sh)
+PMC_RECORD = os.path.join(ROOT, "profiles", "r04_pmc.json")         # rocprofv3 --pmc passes over the default command (tools/profile_round.sh)
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9                           # 78.6e12 lane-instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
 
 
 def trajectory_parity():
     """Per stepper variant, the whole-episode drift record the -m gpu parity tests wrote (HIP vs oracle, 16 action streams):
-    read from the committed profiles/r03_drift_*.json, so the line quotes what was measured, not a hand-typed summary."""
+    read from the committed profiles/r04_drift_*.json (r03_* where round 4 took none), so the line quotes what was measured, not a
+    hand-typed summary.  `local_error` = the same steppers re-synchronised to the oracle before every env step (what ONE step adds)."""
     import statistics
     out = {"test": "tests/test_gpu_parity.py::test_episode_trajectory_*, tests/test_reorient.py::test_reorient_whole_episode_drift_on_gpu; "
                    "err = max|qpos - qpos_oracle| / max|qpos_oracle| per env step; tolerance 1e-4 (north_star)"}
     for key, name in (("f64_euler", "f64"), ("mixed_euler", "mixed"), ("f64_rk4", "rk4_f64"), ("mixed_rk4", "rk4_mixed"),
                       ("configC_f64", "configC_f64"), ("configC_mixed", "configC_mixed"), ("configE_f64", "configE_f64"),
                       ("configE_mixed", "configE_mixed")):
-        path = os.path.join(ROOT, "profiles", "r03_drift_%s.json" % name)
+        path = os.path.join(ROOT, "profiles", "r04_drift_%s.json" % name)
+        if not os.path.exists(path):
+            path = os.path.join(ROOT, "profiles", "r03_drift_%s.json" % name)
         try:
             r = json.load(open(path))
             mq = r["max_err_qpos_rel"]
@@ -163,6 +168,14 @@ def trajectory_parity():
                         "streams_within_1e-4": sum(1 for v in mq if v <= 1e-4)}
         except Exception:
             out[key] = None
+    for name in ("mixed", "f64"):
+        try:
+            r = json.load(open(os.path.join(ROOT, "profiles", "r04_local_error_%s.json" % name)))
+            out["local_error_" + name] = {"record": "profiles/r04_local_error_%s.json" % name, "env_steps": r["env_steps"], "streams": len(r["max_err_qpos_rel"]),
+                                          "worst_step_err_qpos_rel": max(r["max_err_qpos_rel"]), "median_step_err_qpos_rel": r["median_err_qpos_rel"],
+                                          "episode_end_disagreements": len(r["done_disagreements"])}
+        except Exception:
+            out["local_error_" + name] = None
     return out
 
 
@@ -189,9 +202,9 @@ def main():
     ap.add_argument("--steps", type=int, default=128)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--dtype", default="mixed", choices=["mixed", "f64", "f32"],
-                    help="stepper arithmetic: mixed = fp64 state / kinematic chain / contact distances / tendon lengths, fp32 dynamics "
-                         "(f32 is round 1's name for it); f64 = everything fp64")
+    ap.add_argument("--dtype", default="f64", choices=["mixed", "f64", "f32"],
+                    help="stepper arithmetic: f64 = everything fp64, the reference's own arithmetic (MuJoCo), the headline since round 4; "
+                         "mixed = fp64 state / kinematic chain / contact distances / tendon lengths, fp32 dynamics (f32 is round 1's name for it)")
     ap.add_argument("--min-seconds", type=float, default=2.0, help="repeat the K-step block until this much timed wall has passed")
     ap.add_argument("--no-variants", action="store_true", help="skip the f64 / RK4 variant measurements (rank 0, N = 1 only)")
     ap.add_argument("--integrator", default="model", choices=["model", "euler", "rk4"])
@@ -316,7 +329,8 @@ def main():
     variants = {}
     if rank == 0 and world == 1 and not args.no_variants and not args.no_ppo and not args.lstm_hidden:
         # the other steppers of the same workload, so that the driver's run records them too (short blocks: ~1 s each)
-        for name, (dt, integ) in {"f64": ("f64", args.integrator), "rk4": (dtype, "rk4"), "rk4_f64": ("f64", "rk4")}.items():
+        other = "mixed" if dtype == "f64" else "f64"
+        for name, (dt, integ) in {other: (other, args.integrator), "rk4": (dtype, "rk4"), "rk4_" + other: (other, "rk4")}.items():
             if (dt, integ) == (dtype, args.integrator):
                 continue
             try:

@@ -123,10 +123,13 @@ int myo_batch_step(myo_batch* b, const float* act, float* obs, float* rew, uint8
 /* Test hook: set the generation counter of the step plan (k_step's part protocol; it wraps after 2^28 steps). */
 int myo_batch_set_step_generation(myo_batch* b, unsigned int gen);
 
-/* Health check of the step plan's hand-off protocol: *out = number of k_step workgroups that found their env's hand-off
- * state in another generation than the launch's (a failed launch, or one batch stepped from two unsynchronised streams;
- * such a step writes nothing and flags the env in the bad_state buffer).  0 in a healthy batch.  Synchronises the device. */
-int myo_batch_protocol_errors(myo_batch* b, int* out);
+/* Health counters of a batch (all 0 in a healthy one; synchronises the device).
+ * out[0]: k_step workgroups that found their env's hand-off state in another generation than the launch's (a failed launch,
+ *         or one batch stepped from two unsynchronised streams; such a step writes nothing and flags the env in bad_state);
+ * out[1]: substeps in which an env had more contacts than its scratch holds (24; 20 in the fp64 stepper; 32 for models with
+ *         extended collision pairs or a die) — the surplus was dropped, as MuJoCo drops contacts beyond nconmax with a warning;
+ * out[2], out[3]: reserved. */
+int myo_batch_health(myo_batch* b, int out[4]);
 
 /* env.step(a) of the UNWRAPPED env for the envs selected by mask (dev uint8[N], NULL = all): no
  * TimeLimit / Monitor accounting, no auto-reset.  This is the `self.step(action)` that

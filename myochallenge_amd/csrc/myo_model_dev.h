@@ -17,6 +17,7 @@
 #define MYO_TJ_MAX 8      // dofs one tendon can move
 #define MYO_NM_MAX 176    // tree-sparse inertia entries
 #define MYO_NCON_MAX 24   // contacts (base capacity of the scratch: Scratch<T, NC = MYO_NCON_MAX>)
+#define MYO_NCON_F64 20   // contacts, base capacity of the fp64 stepper's scratch: with it the scratch is 26.8 KB = six workgroups per CU (the bench workload peaks at 11 contacts; more than the capacity is counted, myo_batch_health)
 #define MYO_NCON_BIG 32   // contacts, scratch of models with extended collision pairs / a die (56 + 4 * 32 = 184 rows <= 192)
 #define MYO_CS_MAX 16     // dofs one contact can move
 #define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows

@@ -76,6 +76,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   double ro_obj_size_change, ro_pos_th, ro_rot_th, ro_goal_init_pos[3], ro_goal_obj_offset[3];
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
+  int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity
   unsigned long long seed;
 };
 
@@ -85,7 +86,7 @@ template <typename T> DEV T lim_sign(int id) { return id < 0 ? (T)-1 : (T)1; }
 
 template <typename T>
 struct ContactRec {
-  T frame[9], mu, D, B, kip, F[3];      // mu: condim 3, both tangential directions use friction[0]
+  T frame[6], mu, D, B, kip;      // frame: normal, first tangent (the second is their cross product, con_t2); mu: condim 3, both tangential directions use friction[0]
   T r1[3], r2[3];                 // contact point relative to the reference point of body1's / body2's tree
   unsigned long long m1, m2;      // ancestor-dof masks of the two bodies
   int b1, b2, nsup;
@@ -100,7 +101,7 @@ struct RkScratch {                // RK4 stage storage: the start state and the 
 
 template <typename T, int NC = MYO_NCON_MAX>
 struct Scratch {
-  static_assert(NC >= MYO_NCON_MAX && MYO_NLIM_MAX + 4 * NC <= 192, "contact capacity: at least the base (the aliases below are sized for it), at most three constraint rows per lane");
+  static_assert(NC >= MYO_NCON_F64 && MYO_NLIM_MAX + 4 * NC <= 192, "contact capacity: at least the smallest base (the aliases below are sized for it), at most three constraint rows per lane");
   // ---- state (HP in every build)
   HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX];
   HP time;
@@ -124,26 +125,26 @@ struct Scratch {
   HP xpos[MYO_NB_MAX * 3], xquat[MYO_NB_MAX * 4];     // world poses of the bodies
   HP origin[3];                                        // O: the fp32 stages' coordinates are world - O
   T xposT_[sizeof(T) == sizeof(HP) ? 1 : MYO_NB_MAX * 3];   // xpos - O as the fp32 stages read it (see S_XPOST)
-  T xmat[MYO_NB_MAX * 9];
+  T xmat_[sizeof(T) == sizeof(HP) ? 1 : MYO_NB_MAX * 9];     // rotation matrices as the fp32 stages read them; the fp64 stepper derives them from xquat (body_rot)
   T com[MYO_NB_MAX * 3];
   T cdof[MYO_NV_MAX * 6];
   T bvec[MYO_NB_MAX * 6];
   HP ten_length[MYO_NT_MAX];                          // HP: what muscle forces and tendon limits are made of
-  T ten_vel[MYO_NT_MAX], ten_J[MYO_NT_MAX * MYO_TJ_MAX];
-  T act_force[MYO_NU_MAX], act_dot[MYO_NU_MAX];
-  T qM[MYO_NM_MAX];
+  T ten_J[MYO_NT_MAX * MYO_TJ_MAX];                   // (ten_vel, act_force: S_TEN_VEL / S_ACT_FORCE below)
+  T act_dot[MYO_NU_MAX];
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
   // ---- constraints
   int ncon, nefc, nl, ntl, bad, solver_iter;
   unsigned char hperm[MYO_NV_MAX];   // dof -> row of the Newton system (DevModel::hperm; identity unless the block-arrow solver is on)
-  // (from con[] to Mv, i.e. up to rk: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live)
+  // (from con[] to qM, i.e. up to rk: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live)
   alignas(8) ContactRec<T> con[NC];
   int lim_id[MYO_NLIM_MAX];                                            // dof (joint rows) / tendon (tendon rows); bit 31: the upper limit (row sign -1)
   T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
   alignas(8) T efc_jar[MYO_NLIM_MAX + 4 * NC], efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC];
   unsigned char efc_active[MYO_NLIM_MAX + 4 * NC];
   alignas(8) T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
-  T Ma[MYO_NV_MAX], grad[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX];
+  T Ma[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX];   // search: -gradient between update_constraint and the solve, then the Newton direction
+  T qM[MYO_NM_MAX];               // tree-sparse inertia matrix (written by crb, i.e. after the tendon stage: the last piece of its staging area)
   RkScratch<T>* rk;               // null unless the model integrates with RK4
   // ---- task layer
   T rwd[8];
@@ -178,7 +179,7 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage: position of every path element (con[] is dead until the collision stage) */
 /* tendon stage: HP wrap results (7 per geom wrap) behind the T path points, running on through the limit-row and efc_* arrays */
 #define S_TWRES(s, nwrap) (reinterpret_cast<HP*>(reinterpret_cast<char*>((s).con) + ((3 * (size_t)(nwrap) * sizeof(T) + 7) & ~(size_t)7)))
-#define S_ACT_GF(s) (static_cast<T*>((s).Ma))   /* gear * actuator force (actuation stage, NU_MAX entries through Ma, grad: the body velocities that live there are dead after efc_reference) */
+#define S_ACT_GF(s) (static_cast<T*>((s).Ma))   /* gear * actuator force (actuation stage, NU_MAX entries through Ma, search: the body velocities that live there are dead after efc_reference) */
 #define S_KTMP(s) (reinterpret_cast<HP*>((s).con))   /* HP [2][MYO_NJ_MAX * 3] */
 #define S_XANCHOR(s) ((s).efc_jar)
 #define S_XAXIS(s) ((s).efc_jv)
@@ -190,15 +191,25 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_LIM_B(s) ((s).efc_force)
 #define S_LIM_KIP(s) ((s).efc_force + MYO_NLIM_MAX)
 #define S_AREF(s) ((s).efc_jar)
-#define S_CVEL(s) ((s).Ma)   /* body velocities (velocity stage) live in the solver vectors Ma,grad,search,Mv */
+/* world-frame force of every contact (3 per contact), staged by J' f: in efc_jv, dead between the line search that consumed J v and the next J v */
+#define S_CONF(s) ((s).efc_jv)
+#define S_CVEL(s) ((s).qfrc_constraint)   /* body velocities (velocity stage) live in the solver vectors qfrc_constraint,Ma,search,Mv */
+/* tendon velocities (velocity stage .. actuation) and actuator forces (actuation; read by the stage dump) live in qacc_smooth, qacc and the first
+   entries of qfrc_constraint, which the solver writes later (the body velocities above are dead when the actuation stage writes the forces) */
+#define S_TEN_VEL(s) ((s).qacc_smooth)
+#define S_ACT_FORCE(s) ((s).qacc_smooth + MYO_NT_MAX)
 static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_H_SIZE && MYO_NU_MAX <= 2 * MYO_NV_MAX, "H aliases; S_ACT_GF");
 static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MAX && 64 * sizeof(int) <= 2 * MYO_NV_MAX * sizeof(float), "S_LIM_B / S_LIM_KIP in efc_force; S_NPRE in search, Mv");
 static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 1024 && MYO_NU_MAX <= 64, "packed actuator gather entries are 10 + 6 bits");
 static_assert(MYO_NV_MAX * 6 <= MYO_NB_MAX * 10, "cdof_dot fits where crb was");
-static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in Ma..Mv");
+static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in qfrc_constraint..Mv");
+static_assert(MYO_NT_MAX <= MYO_NV_MAX + 4 && MYO_NT_MAX + MYO_NU_MAX <= 3 * MYO_NV_MAX, "S_TEN_VEL ends before qfrc_constraint (cvel), S_ACT_FORCE inside qacc_smooth..qfrc_constraint");
 static_assert(2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MAX, "the RK4 stage derivative fits in efc_jv");
 static_assert(MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX && 64 <= MYO_NEFC_MAX, "efc aliases");
-static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRec<float>), "kinematics temporaries fit in con[]");
+static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRec<float>) && 2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_F64 * sizeof(ContactRec<double>), "kinematics temporaries fit in con[]");
+#define MYO_NEFC_MIN (MYO_NLIM_MAX + 4 * MYO_NCON_F64)   /* rows of the smallest scratch: every alias of an efc_* array must fit in this many */
+static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MIN && 2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MIN && MYO_NJ_MAX * 3 <= MYO_NEFC_MIN && MYO_NB_MAX * 3 <= MYO_NEFC_MIN && 64 <= MYO_NEFC_MIN,
+              "efc aliases (S_LIM_B / S_LIM_KIP, S_RKDX, S_XANCHOR / S_XAXIS, S_XIPOS) in the smallest scratch");
 
 // ---- phase functions are real (non-inlined) functions in the gfx950 build: each gets its own
 // register allocation (the fully inlined kernel spilled ~170 VGPRs and was several MB of code).
@@ -360,10 +371,19 @@ template <typename T, int NC> DEV HP geom_size1_hp(const DevModel<T>& M, const T
   const HP v = M.h_geom_size[3 * g + 1];
   return (g >= K.objg_gid0 && g < K.objg_gidn) ? v + s.ball_size[0] : v;
 }
+// rotation matrix of body b.  Mixed stepper: the float copy the kinematics stage left.  fp64 stepper: recomputed from the
+// body's quaternion — the same quat2mat on the same numbers as the kinematics stage's, so the same bits — which keeps 1.7 KB
+// of matrices out of LDS (the fp64 scratch fits six workgroups per CU without them)
+template <typename T, int NC> DEV void body_rot(const Scratch<T, NC>& s, int b, T* R) {
+  if constexpr (sizeof(T) == sizeof(HP)) quat2mat(R, reinterpret_cast<const T*>(s.xquat) + 4 * b);
+  else { for (int k = 0; k < 9; ++k) R[k] = s.xmat_[9 * b + k]; }
+}
 // position of a point given in body coordinates, in the fp32 stages' frame (world - O)
 template <typename T, int NC> DEV void body_point(const Scratch<T, NC>& s, int b, const T* local, T* out) {
   const T* xp = S_XPOST(s) + 3 * b;
-  mulmatvec3(out, s.xmat + 9 * b, local);
+  T Rb[9];
+  body_rot(s, b, Rb);
+  mulmatvec3(out, Rb, local);
   out[0] += xp[0]; out[1] += xp[1]; out[2] += xp[2];
 }
 // the same in HP and in WORLD coordinates (contact distances, observation)
@@ -392,7 +412,7 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   PHASE {
     if (lane == 0) {
       s.xpos[0] = s.xpos[1] = s.xpos[2] = 0; s.xquat[0] = 1; s.xquat[1] = s.xquat[2] = s.xquat[3] = 0;
-      for (int k = 0; k < 9; ++k) s.xmat[k] = (k % 4 == 0) ? (T)1 : (T)0;
+      if constexpr (sizeof(T) != sizeof(HP)) { for (int k = 0; k < 9; ++k) s.xmat_[k] = (k % 4 == 0) ? (T)1 : (T)0; }
     }
     if constexpr (sizeof(T) != sizeof(HP)) { if (lane < M.nv) s.qvelT_[lane] = (T)s.qvel[lane]; }
   }
@@ -489,7 +509,7 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       const HP q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
       HP R[9], t[3];
       quat2mat(R, q);
-      for (int k = 0; k < 9; ++k) s.xmat[9 * b + k] = (T)R[k];
+      if constexpr (sizeof(T) != sizeof(HP)) { for (int k = 0; k < 9; ++k) s.xmat_[9 * b + k] = (T)R[k]; }
       const HP ipos[3] = {(HP)M.body_ipos[3 * b], (HP)M.body_ipos[3 * b + 1], (HP)M.body_ipos[3 * b + 2]};
       mulmatvec3(t, R, ipos);
       for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = (T)(s.xpos[3 * b + k] - s.origin[k] + t[k]);
@@ -544,8 +564,9 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
       T* ci = S_CINERT(s) + 10 * b;
       if (b == 0) { for (int k = 0; k < 10; ++k) ci[k] = 0; }
       else {
-        T R[9];
-        mulmat3(R, s.xmat + 9 * b, M.body_imat + 9 * b);
+        T R[9], Rb[9];
+        body_rot(s, b, Rb);
+        mulmat3(R, Rb, M.body_imat + 9 * b);
         const T* I = M.body_inertia + 3 * b; const T* c = s.com + 3 * M.body_rootid[b];
         const T off[3] = {S_XIPOS(s)[3 * b] - c[0], S_XIPOS(s)[3 * b + 1] - c[1], S_XIPOS(s)[3 * b + 2] - c[2]};
         const T mb = body_mass_of(M, K, s, b);
@@ -565,9 +586,11 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
       const T off[3] = {c[0] - S_XANCHOR(s)[3 * j], c[1] - S_XANCHOR(s)[3 * j + 1], c[2] - S_XANCHOR(s)[3 * j + 2]};
       if (M.jnt_type[j] == 0) {
         for (int k = 0; k < 3; ++k) { T* cd = s.cdof + 6 * (da + k); for (int e = 0; e < 6; ++e) cd[e] = 0; cd[3 + k] = 1; }
+        T Rb[9];
+        body_rot(s, b, Rb);
         for (int k = 0; k < 3; ++k) {
           T* cd = s.cdof + 6 * (da + 3 + k);
-          const T ax[3] = {s.xmat[9 * b + k], s.xmat[9 * b + 3 + k], s.xmat[9 * b + 6 + k]};
+          const T ax[3] = {Rb[k], Rb[3 + k], Rb[6 + k]};
           cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
           cross3(cd + 3, ax, off);
         }
@@ -1363,8 +1386,9 @@ template <typename T> DEV void make_frame(T* f) {
   const T t = dot3(f, f + 3);
   f[3] -= t * f[0]; f[4] -= t * f[1]; f[5] -= t * f[2];
   normalize3(f + 3);
-  cross3(f + 6, f, f + 3);
 }
+// second tangent of a contact frame (what make_frame's caller used to store behind the first): normal x tangent 1
+template <typename T> DEV void con_t2(const T* f, T* t2) { cross3(t2, f, f + 3); }
 DEV int sphere_sphere(HP* dist, HP* pos, HP* n, const HP* c1, HP r1, const HP* c2, HP r2, HP margin) {
   const HP dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
   const HP cd = norm3(dif);
@@ -1934,7 +1958,12 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
     }
     SYNC();
     ncon += total;
-    if (ncon > NC) ncon = NC;
+    if (ncon > NC) {
+      // more contacts than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
+      // with a warning — counted, so that the host can see it happened (myo_batch_health)
+      PHASE { if (lane == 0 && K.health) myo_count(K.health + 1); }
+      ncon = NC;
+    }
   }
 }
 
@@ -2058,7 +2087,9 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
         point_vel(bv, c.b1, c.r1, v1);
         point_vel(bv, c.b2, c.r2, v2);
         const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        const T vn = dot3(c.frame, rel), vt = dot3(c.frame + 3 + 3 * (e >> 1), rel);
+        T t2[3];
+        con_t2(c.frame, t2);
+        const T vn = dot3(c.frame, rel), vt = (e >> 1) ? dot3(t2, rel) : dot3(c.frame + 3, rel);
         val = vn + ((e & 1) ? -c.mu : c.mu) * vt;
       }
       out[r] = val;
@@ -2117,7 +2148,10 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
-        const T* fn = c.frame; const T* ft = c.frame + 3 + 3 * (e >> 1);
+        T t2[3];
+        con_t2(c.frame, t2);
+        const T* fn = c.frame;
+        const T ft[3] = {(e >> 1) ? t2[0] : c.frame[3], (e >> 1) ? t2[1] : c.frame[4], (e >> 1) ? t2[2] : c.frame[5]};
         const T mu = (e & 1) ? -c.mu : c.mu;
         T v1[3], v2[3];
         point_vel(bva, c.b1, c.r1, v1);
@@ -2144,10 +2178,12 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
   const int nl = s.nl, nlim = s.nl + s.ntl, ncon = s.ncon;
   PHASE {
     for (int ci = lane; ci < ncon; ci += 64) {
-      ContactRec<T>& c = s.con[ci];
+      const ContactRec<T>& c = s.con[ci];
       const T* fe = f + nlim + 4 * ci;
       const T fn = fe[0] + fe[1] + fe[2] + fe[3], ft1 = c.mu * (fe[0] - fe[1]), ft2 = c.mu * (fe[2] - fe[3]);
-      for (int k = 0; k < 3; ++k) c.F[k] = c.frame[k] * fn + c.frame[3 + k] * ft1 + c.frame[6 + k] * ft2;
+      T t2[3];
+      con_t2(c.frame, t2);
+      for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + c.frame[3 + k] * ft1 + t2[k] * ft2;
     }
   }
   SYNC();
@@ -2178,7 +2214,7 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
         T t[3];
         cross3(t, cd, off);
         const T col[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
-        const T v = dot3(col, c.F);
+        const T v = dot3(col, S_CONF(s) + 3 * ci);
         acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
       }
       out[d] = acc;
@@ -2202,7 +2238,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
       T acc = 0;
       int slot = 0;
       while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * qv[d]; slot++; }
-      s.ten_vel[t] = acc;
+      S_TEN_VEL(s)[t] = acc;
     }
     const int d = lane;
     if (d < M.nv) {
@@ -2239,7 +2275,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
           const T k = M.tendon_stiffness[t], b = M.tendon_damping[t];
           const unsigned long long m = M.tendon_dofmask[t];
           if ((k != 0 || b != 0) && ((m >> d) & 1ull)) {
-            const T f = -k * ((T)s.ten_length[t] - M.tendon_lengthspring[t]) - b * s.ten_vel[t];
+            const T f = -k * ((T)s.ten_length[t] - M.tendon_lengthspring[t]) - b * S_TEN_VEL(s)[t];
             acc += s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f;
           }
         }
@@ -2346,7 +2382,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       // muscle length normalisation and the force-length curves in HP from the HP tendon length (the curves are
       // piecewise quadratics of DIFFERENCES like L - 1 and L - lmin); the force-velocity factor in T
       const HP lenh = (HP)gear * s.ten_length[tid];
-      const T len = (T)lenh, vel = gear * s.ten_vel[tid];
+      const T len = (T)lenh, vel = gear * S_TEN_VEL(s)[tid];
       T gain, bias = 0;
       const HP lr0 = M.h_actuator_lengthrange[2 * i], lr1 = M.h_actuator_lengthrange[2 * i + 1];
       if (M.actuator_gaintype[i] == 1) {
@@ -2383,7 +2419,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       }
       T f = gain * input + bias;
       if (M.actuator_forcelimited[i]) f = tclamp(f, M.actuator_forcerange[2 * i], M.actuator_forcerange[2 * i + 1]);
-      s.act_force[i] = f;
+      S_ACT_FORCE(s)[i] = f;
       S_ACT_GF(s)[i] = M.act_gear0[i] * f;
     }
   }
@@ -2437,7 +2473,7 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // i
   WAVE_SUM_N(HP, gcost, M.nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc[c] - (HP)s.qacc_smooth[c])));
   PHASE {
     const int c = lane;
-    if (c < M.nv) s.grad[c] = s.Ma[c] - s.qfrc_smooth[c] - s.qfrc_constraint[c];
+    if (c < M.nv) s.search[c] = -(s.Ma[c] - s.qfrc_smooth[c] - s.qfrc_constraint[c]);      // -gradient: the right-hand side of the next Newton system
   }
   SYNC();
   return ccost + (HP)0.5 * gcost;
@@ -2500,7 +2536,9 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         const int on2 = (int)((c.m2 >> d) & 1ull), on1 = (int)((c.m1 >> d) & 1ull);
         T col[3];
         con_col(s, d, on2 ? c.r2 : c.r1, col);
-        T j[3] = {dot3(c.frame, col), dot3(c.frame + 3, col), dot3(c.frame + 6, col)};
+        T t2[3];
+        con_t2(c.frame, t2);
+        T j[3] = {dot3(c.frame, col), dot3(c.frame + 3, col), dot3(t2, col)};
         if (!on2) { j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2]; }
         if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion
         T* dst = stage + (cn & 1) * (MYO_CS_MAX * 3) + 3 * lane;
@@ -2582,8 +2620,6 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     load_H_from_M(M, s, (const T*)0, (T)0, 1);
     build_hessian(M, s);
     PROF(s, 9)
-    PHASE { const int c = lane; if (c < nv) s.search[c] = -s.grad[c]; }
-    SYNC();
 #ifndef MYO_EMU
     if (M.arrow_nf > 0) {
       arrow_eliminate_blocks<T, NC>(LOFF(s, s.search));
@@ -2652,7 +2688,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     const HP oldcost = cost;
     cost = update_constraint(M, s);
     iter++;
-    WAVE_SUM3_N(T, gn, qn2, fn, nv, c, { _e1 = s.grad[c] * s.grad[c]; _e2 = s.qacc[c] * s.qacc[c];
+    WAVE_SUM3_N(T, gn, qn2, fn, nv, c, { _e1 = s.search[c] * s.search[c]; _e2 = s.qacc[c] * s.qacc[c];
                                          _e3 = s.qfrc_smooth[c] * s.qfrc_smooth[c] + s.qfrc_constraint[c] * s.qfrc_constraint[c] + s.Ma[c] * s.Ma[c]; });
     const HP improvement = (HP)scale * (oldcost - cost);
     const T gradient = scale * sqrt(gn);

@@ -655,6 +655,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       out[D.qfrc_actuator + i] = (double)S_QFRC_ACTUATOR(s)[i];
     }
     for (int r = lane; r < s.nefc; r += 64) out[D.efc_aref + r] = (double)S_AREF(s)[r];     // (efc_jar holds aref until the solver starts)
+    for (int i = lane; i < M.nu; i += 64) out[D.actuator_force + i] = (double)S_ACT_FORCE(s)[i];   // (lives in the solver's vectors)
   }
   SYNC();
   fwd_acceleration(M, s);
@@ -673,7 +674,6 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       out[D.qacc_smooth + i] = (double)s.qacc_smooth[i];
       out[D.qacc + i] = (double)s.qacc[i];
     }
-    for (int i = lane; i < M.nu; i += 64) out[D.actuator_force + i] = (double)s.act_force[i];
     for (int i = lane; i < M.na; i += 64) out[D.act_dot + i] = (double)s.act_dot[i];
     if (lane == 0) { out[D.counts] = s.ncon; out[D.counts + 1] = s.nefc; out[D.counts + 2] = s.solver_iter; out[D.counts + 3] = s.nl; }
     for (int r = lane; r < s.nefc; r += 64) out[D.efc_D + r] = (double)row_D(s, r, s.nl + s.ntl);

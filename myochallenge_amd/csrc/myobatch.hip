@@ -517,8 +517,9 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   if (m->te_div.empty()) { m->te_i.assign(4, 0); m->te_div.push_back(1.0); }
   // staging area of the tendon stage: T path points in con[], then (8-byte aligned) 7 HP wrap results per geom wrap,
   // running on through the limit-row, efc_* and solver vectors up to rk
+  typedef Scratch<double, MYO_NCON_F64> ScratchD;
   LIM(((3 * (size_t)m->nwrap * sizeof(double) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
-          offsetof(Scratch<double>, rk) - offsetof(Scratch<double>, con) ||
+          offsetof(ScratchD, rk) - offsetof(ScratchD, con) ||
       ((3 * (size_t)m->nwrap * sizeof(float) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
           offsetof(Scratch<float>, rk) - offsetof(Scratch<float>, con), "tendon path elements / wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
@@ -691,8 +692,8 @@ struct myo_batch {
   float* cost;
   unsigned int* ticks;
   // env steps in parts (k_step): part_state[env] = 16 g + 2 q (parts < q of step g published) or + 1 (part q claimed, running);
-  // step_gen[0] = g, advanced on the stream after every step; step_gen[1] = workgroups that met a state of another generation
-  // (myo_batch_protocol_errors).  plan = substep boundaries of the parts.
+  // step_gen[0] = g, advanced on the stream after every step; a workgroup that meets a state of another generation counts it in
+  // K.health[0] (myo_batch_health).  plan = substep boundaries of the parts.
   int* part_state;
   int* step_gen;
   StepPlan plan;
@@ -935,6 +936,14 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   if (!rc) rc |= be_h2d(p, host.data(), host.size() * sizeof(double));
   b->rec = (double*)p;
   b->allocs.push_back(p);
+  {                                // health counters (myo_batch_health), zeroed
+    void* hc = nullptr;
+    const int zero4[4] = {0, 0, 0, 0};
+    rc |= be_malloc(&hc, sizeof zero4);
+    if (!rc) rc |= be_h2d(hc, zero4, sizeof zero4);
+    b->K.health = (int*)hc;
+    if (hc) b->allocs.push_back(hc);
+  }
   if (m->integrator == 1) {        // RK4 stage storage, one RkScratch per env (global memory)
     void* w = nullptr;
     const size_t each = dtype == MYO_F64 ? sizeof(RkScratch<double>) : sizeof(RkScratch<float>);
@@ -1031,7 +1040,7 @@ extern "C" int myo_batch_obs_dim(const myo_batch* b) { return b ? b->nobs : -1; 
 extern "C" int myo_batch_lds_bytes(const myo_batch* b) {
   if (!b) return -1;
   const bool big = b->ncap > MYO_NCON_MAX;
-  if (b->dtype == MYO_F64) return big ? (int)sizeof(Scratch<double, MYO_NCON_BIG>) : (int)sizeof(Scratch<double>);
+  if (b->dtype == MYO_F64) return big ? (int)sizeof(Scratch<double, MYO_NCON_BIG>) : (int)sizeof(Scratch<double, MYO_NCON_F64>);
   if (big) return (int)sizeof(Scratch<float, MYO_NCON_BIG>);
   // mixed stepper, base capacity: an RK4 model keeps its stage storage behind the scratch (MYO_RK_IN_LDS); elsewhere it is in global memory
   return (int)(((sizeof(Scratch<float>) + 15) / 16 * 16) * (b->integrator == 1 ? 1 : 0) + (b->integrator == 1 ? sizeof(RkScratch<float>) : sizeof(Scratch<float>)));
@@ -1133,7 +1142,7 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
                                              float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                                              float* term_obs, float* comps, float* ep_info, unsigned char* bad_state,
                                              const int* __restrict__ order, unsigned int* __restrict__ ticks,
-                                             int* part_state, int* __restrict__ step_gen, StepPlan plan) {
+                                             int* part_state, const int* __restrict__ step_gen, StepPlan plan) {
   Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
   s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
@@ -1163,7 +1172,7 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
         if (j > 2u * (unsigned)p) {             // part p is claimed or done: exit.  A state of ANOTHER generation (neither a part of this
           // step nor its final 16 (g + 1)) means step_gen and part_state have come apart — a failed launch, two streams stepping one
           // batch: the step would silently write nothing, so it is counted (myo_batch_protocol_errors) and the env flagged
-          if (j > 2u * (unsigned)nparts && j != 16u) { atomicAdd(step_gen + 1, 1); if (bad_state) bad_state[env] = 1; }
+          if (j > 2u * (unsigned)nparts && j != 16u) { if (K.health) atomicAdd(K.health, 1); if (bad_state) bad_state[env] = 1; }
           break;
         }
         if ((j & 1) == 0) {
@@ -1423,11 +1432,12 @@ extern "C" int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d,
 
 #ifdef MYO_EMU
 #define FOR_ENVS_T(TT, NCV, call) { Scratch<TT, NCV>* s = new Scratch<TT, NCV>(); memset(s, 0, sizeof *s); RkScratch<TT>* rk = new RkScratch<TT>(); s->rk = rk; for (int env = 0; env < b->n; ++env) { double* rec = b->rec + (size_t)env * b->L.stride; call; } delete s; delete rk; }
-#define FOR_ENVS_F64(call) { if (b->ncap > MYO_NCON_MAX) FOR_ENVS_T(double, MYO_NCON_BIG, call) else FOR_ENVS_T(double, MYO_NCON_MAX, call) }
+#define FOR_ENVS_F64(call) { if (b->ncap > MYO_NCON_MAX) FOR_ENVS_T(double, MYO_NCON_BIG, call) else FOR_ENVS_T(double, MYO_NCON_F64, call) }
 #define FOR_ENVS_F32(call) { if (b->ncap > MYO_NCON_MAX) FOR_ENVS_T(float, MYO_NCON_BIG, call) else FOR_ENVS_T(float, MYO_NCON_MAX, call) }
 #else
 // the RK4 stage storage is only allocated (LDS) by the kernel variants of RK4 models
 // ... and the scratch's contact capacity (NCV) is the batch's: MYO_NCON_BIG for models with extended collision pairs or a die
+#define MYO_NC_D(n) ((n) == MYO_NCON_MAX ? MYO_NCON_F64 : (n))     /* the fp64 stepper's scratch has its own base capacity */
 #define LAUNCH_RK1(b, ...) if ((b)->integrator == 1) { constexpr bool RKV = true; __VA_ARGS__; } else { constexpr bool RKV = false; __VA_ARGS__; }
 #define LAUNCH_RK(b, ...) if ((b)->ncap > MYO_NCON_MAX) { constexpr int NCV = MYO_NCON_BIG; LAUNCH_RK1(b, __VA_ARGS__) } else { constexpr int NCV = MYO_NCON_MAX; LAUNCH_RK1(b, __VA_ARGS__) }
 #endif
@@ -1443,7 +1453,7 @@ extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, vo
   hipStream_t st = (hipStream_t)stream;
   BIND_OR_RETURN(b, st)
   LAUNCH_RK(b,
-    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs);
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV, MYO_NC_D(NCV)>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs))
   LAUNCH_CHECK(b)
 #endif
@@ -1468,7 +1478,7 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
   timing_begin(b, st);
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV, NCV>), dim3(b->plan.nparts * b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->plan);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<double, RKV, MYO_NC_D(NCV)>), dim3(b->plan.nparts * b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->plan);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->plan.nparts * b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->plan))
   timing_end(b, st);
@@ -1497,18 +1507,19 @@ extern "C" int myo_batch_set_step_generation(myo_batch* b, unsigned int gen) {
 #endif
 }
 
-// number of k_step workgroups that found their env's hand-off state in another generation than the launch's (0 in a healthy
-// batch; synchronises the device).  See the protocol comment at k_step.
-extern "C" int myo_batch_protocol_errors(myo_batch* b, int* out) {
+// Health counters of a batch (synchronises the device).  out[0]: k_step workgroups that found their env's hand-off state in another
+// generation than the launch's (see the protocol comment at k_step); out[1]: substeps in which an env had more contacts than its
+// scratch holds (the surplus was dropped); out[2], out[3]: reserved, 0.  All 0 in a healthy batch.
+extern "C" int myo_batch_health(myo_batch* b, int out[4]) {
   if (!b || !out) return fail(MYO_E_ARG, "null argument");
-  *out = 0;
-#ifndef MYO_EMU
-  if (!b->step_gen) return MYO_OK;
+  for (int k = 0; k < 4; ++k) out[k] = 0;
+  if (!b->K.health) return MYO_OK;
+#ifdef MYO_EMU
+  memcpy(out, b->K.health, 4 * sizeof(int));
+#else
   DeviceGuard guard(b->device);
-  int g4[4] = {0, 0, 0, 0};
-  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(g4, b->step_gen, sizeof g4, hipMemcpyDeviceToHost) != hipSuccess)
-    return fail(MYO_E_DEVICE, "myo_batch_protocol_errors: copy failed");
-  *out = g4[1];
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, b->K.health, 4 * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
+    return fail(MYO_E_DEVICE, "myo_batch_health: copy failed");
 #endif
   return MYO_OK;
 }
@@ -1525,7 +1536,7 @@ extern "C" int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const flo
   BIND_OR_RETURN(b, st)
   LAUNCH_RK(b,
     if (b->dtype == MYO_F64)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<double, RKV, MYO_NC_D(NCV)>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done);
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done))
   LAUNCH_CHECK(b)
@@ -1544,7 +1555,7 @@ extern "C" int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub
   BIND_OR_RETURN(b, st)
   timing_begin(b, st);
   LAUNCH_RK(b,
-    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<double, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub);
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<double, RKV, MYO_NC_D(NCV)>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_physics<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, nsub))
   timing_end(b, st);
   LAUNCH_CHECK(b)
@@ -1562,7 +1573,7 @@ extern "C" int myo_batch_forward_dump(myo_batch* b, const double* ctrl, double* 
   hipStream_t st = (hipStream_t)stream;
   BIND_OR_RETURN(b, st)
   LAUNCH_RK(b, (void)RKV;
-    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<double, false, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out);
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<double, false, MYO_NC_D(NCV)>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dump<float, false, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, ctrl, b->D, out))
   LAUNCH_CHECK(b)
 #endif

@@ -59,6 +59,7 @@
 #define UNI(x) (x)
 // LDS accumulation by several lanes of a phase into one slot (the emulation runs the lanes one after the other)
 template <typename T> static inline void lds_add(T* p, T v) { *p += v; }
+static inline void myo_count(int* p) { *p += 1; }
 static inline int myo_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #else
@@ -162,6 +163,7 @@ template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
   typedef __attribute__((address_space(3))) T* lds_p;
   (void)__hip_atomic_fetch_add((lds_p)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ void myo_count(int* p) { atomicAdd(p, 1); }     // event counter in global memory
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 __device__ __forceinline__ int myo_popcll(unsigned long long x) { return __popcll(x); }
 __device__ __forceinline__ int myo_ffsll(unsigned long long x) { return __ffsll((long long)x) - 1; }

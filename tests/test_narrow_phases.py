@@ -235,3 +235,57 @@ def test_oracle_contact_geometry():
         assert abs(o_dist - brute) < 2.5e-3, (pair, o_dist, brute)
         checked += 1
     assert checked >= 20, checked
+
+
+def raft_model(n_rafts, per_raft):
+    """`n_rafts` free bodies, each a flat raft of `per_raft` spheres, resting on the ground plane: n_rafts * per_raft contacts"""
+    B = _Builder()
+    B.add_geom("plane", 0, 0, (0, 0, 0), collide=1)
+    for r in range(n_rafts):
+        b = B.add_body("raft%d" % r, 0, (0.5 * r, 0.0, 0.0195), mass=0.2, inertia=(2e-4, 3e-4, 4e-4))
+        B.add_joint("raft%d_free" % r, b, 0)
+        for k in range(per_raft):
+            B.add_geom("s%d_%d" % (r, k), b, SPH, (0.02,), (0.05 * (k % 4) - 0.075, 0.05 * (k // 4) - 0.05, 0.0), collide=1)
+    m = B.finish()
+    for g in range(len(m.names["geom"])):
+        m.arrays["geom_contype"][g], m.arrays["geom_conaffinity"][g] = (1, 0) if g == 0 else (2, 1)
+    m.arrays["geom_margin"][:] = 0.002
+    set_const(m)
+    return m
+
+
+def case_contact_overflow(lib, dtype):
+    """contacts beyond the scratch's capacity are dropped (MuJoCo drops beyond nconmax with a warning) — never silently:
+    myo_batch_health counts the substeps it happened in, the states stay finite, and a model inside the capacity counts nothing."""
+    mem = Mem(lib)
+    cap = 20 if dtype == native.MYO_F64 else 24            # MYO_NCON_F64 / MYO_NCON_MAX (sphere-plane pairs: the base scratch)
+    for n_rafts, per_raft, over in ((1, 12, False), (3, 12, True)):
+        assert (n_rafts * per_raft > cap) == over
+        cm = compile_model(raft_model(n_rafts, per_raft))
+        b = native.Batch(native.Model(cm, lib), None, 2, 0, 0, dtype)
+        b.physics_step(None, 5)
+        qp = mem.zeros((2, cm.size("nq")))
+        b.get_state(qp)
+        h = b.health()
+        assert np.isfinite(mem.host(qp)).all()
+        assert h["protocol_errors"] == 0 and (h["contact_overflows"] > 0) == over, (n_rafts, per_raft, h)
+        if not over:                                       # every sphere of the raft is in contact: the count is what the model says
+            get, b2 = forward_dump(lib, mem, cm, cm_qpos0(cm), np.zeros(cm.size("nv")), np.zeros(0), np.zeros(0), dtype)
+            assert int(get("counts", 4)[0]) == n_rafts * per_raft
+            b2.close()
+        b.close()
+
+
+def cm_qpos0(cm):
+    return np.asarray(cm.fields["qpos0"], dtype=np.float64).copy()
+
+
+def test_contact_overflow_is_counted_on_emulation(emu_lib):
+    case_contact_overflow(emu_lib, native.MYO_F64)
+    case_contact_overflow(emu_lib, native.MYO_MIXED)
+
+
+@pytest.mark.gpu
+def test_contact_overflow_is_counted_on_gpu(hip_lib):
+    case_contact_overflow(hip_lib, native.MYO_F64)
+    case_contact_overflow(hip_lib, native.MYO_MIXED)

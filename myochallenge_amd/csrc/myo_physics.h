@@ -192,12 +192,12 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_LIM_KIP(s) ((s).efc_force + MYO_NLIM_MAX)
 #define S_AREF(s) ((s).efc_jar)
 /* world-frame force of every contact (3 per contact), staged by J' f: in efc_jv, dead between the line search that consumed J v and the next J v */
-#define S_CONF(s) ((s).efc_jv)
-#define S_CVEL(s) ((s).qfrc_constraint)   /* body velocities (velocity stage) live in the solver vectors qfrc_constraint,Ma,search,Mv */
+#define S_CONF(s) (static_cast<T*>((s).efc_jv))
+#define S_CVEL(s) (static_cast<T*>((s).qfrc_constraint))   /* body velocities (velocity stage) live in the solver vectors qfrc_constraint,Ma,search,Mv */
 /* tendon velocities (velocity stage .. actuation) and actuator forces (actuation; read by the stage dump) live in qacc_smooth, qacc and the first
    entries of qfrc_constraint, which the solver writes later (the body velocities above are dead when the actuation stage writes the forces) */
-#define S_TEN_VEL(s) ((s).qacc_smooth)
-#define S_ACT_FORCE(s) ((s).qacc_smooth + MYO_NT_MAX)
+#define S_TEN_VEL(s) (static_cast<T*>((s).qacc_smooth))
+#define S_ACT_FORCE(s) (static_cast<T*>((s).qacc_smooth) + MYO_NT_MAX)
 static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_H_SIZE && MYO_NU_MAX <= 2 * MYO_NV_MAX, "H aliases; S_ACT_GF");
 static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MAX && 64 * sizeof(int) <= 2 * MYO_NV_MAX * sizeof(float), "S_LIM_B / S_LIM_KIP in efc_force; S_NPRE in search, Mv");
 static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 1024 && MYO_NU_MAX <= 64, "packed actuator gather entries are 10 + 6 bits");

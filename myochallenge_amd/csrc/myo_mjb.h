@@ -224,7 +224,7 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
       const int a = t1 <= t2 ? g1 : g2, b = t1 <= t2 ? g2 : g1;      // MuJoCo orders a pair by geom type
       const int lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
       if (lo == MYO_GEOM_PLANE && hi == MYO_GEOM_PLANE) continue;
-      if (lo == MYO_GEOM_BOX && hi == MYO_GEOM_BOX) { for (int v = 0; v < 16; ++v) { p1.push_back(a); p2.push_back(b); psub.push_back(1 + v); } }   // vertex-face candidates
+      if (lo == MYO_GEOM_BOX && hi == MYO_GEOM_BOX) { for (int v = 0; v < 17; ++v) { p1.push_back(a); p2.push_back(b); psub.push_back(1 + v); } }   // 16 vertex-face candidates + the edge-edge candidate (17)
       else if (pair_supported(lo, hi)) { p1.push_back(a); p2.push_back(b); psub.push_back(0); }
       else { if (!dropped) snprintf(msg, sizeof msg, "geom %d (type %d) - geom %d (type %d)", a, gt[a], b, gt[b]); dropped++; }
     }

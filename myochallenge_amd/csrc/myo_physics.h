@@ -1732,6 +1732,59 @@ DEV void collide_pair_ext(const DevModel<T>& M, const TaskDev& K, const Scratch<
       o.n = both == 2 ? 2 : point_box_hp<0, 1>(o, q, s1[0], p2, R2, s2, margin, (HP)1);
     } else if (t2 == 5) o.n = point_cyl_hp<0>(o, q, s1[0], p2, R2, s2[0], s2[1], margin);
     else o.n = point_ell_hp<0>(o, q, s1[0], p2, R2, s2, margin);
+  } else if (t1 == 6 && t2 == 6 && sub == 17) {  // box - box: the edge-edge candidate (oracle/myo_oracle.c: collide_pair, sub == 17)
+    // separating-axis test over the 6 face normals and the 9 edge cross products; when the axis of largest separation is an edge
+    // pair: one contact at the midpoint of the two edges' closest points, normal = that axis (box 1 -> box 2)
+    const HP t[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+    HP A[3][3], B[3][3];
+    for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) { A[k][e] = R1[3 * e + k]; B[k][e] = R2[3 * e + k]; }
+    HP best_face = (HP)-1e300, best_edge = (HP)-1e300, Ln[3] = {0, 0, 0};
+    int bi = -1, bj = -1;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const HP* L = k < 3 ? A[k] : B[k - 3];
+      HP ra = 0, rb = 0;
+      for (int e = 0; e < 3; ++e) { ra += s1[e] * fabs(dot3(A[e], L)); rb += s2[e] * fabs(dot3(B[e], L)); }
+      const HP sep = fabs(dot3(t, L)) - ra - rb;
+      best_face = sep > best_face ? sep : best_face;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        HP L[3];
+        cross3(L, A[i], B[j]);
+        const HP len = sqrt(dot3(L, L));
+        const bool ok = !(len < (HP)1e-6);
+        const HP inv = ok ? (HP)1 / len : (HP)0;
+        for (int e = 0; e < 3; ++e) L[e] *= inv;
+        HP ra = 0, rb = 0;
+        for (int e = 0; e < 3; ++e) { ra += s1[e] * fabs(dot3(A[e], L)); rb += s2[e] * fabs(dot3(B[e], L)); }
+        const HP sep = fabs(dot3(t, L)) - ra - rb;
+        if (ok && sep > best_edge) { best_edge = sep; bi = i; bj = j; Ln[0] = L[0]; Ln[1] = L[1]; Ln[2] = L[2]; }
+      }
+    if (bi < 0 || best_edge > margin || best_face > margin) return;
+    if (!(best_edge > best_face + (HP)1e-9 * ((HP)1 + fabs(best_face)))) return;
+    if (dot3(t, Ln) < 0) { Ln[0] = -Ln[0]; Ln[1] = -Ln[1]; Ln[2] = -Ln[2]; }
+    HP ea[3] = {p1[0], p1[1], p1[2]}, eb[3] = {p2[0], p2[1], p2[2]}, Ai[3] = {0, 0, 0}, Bj[3] = {0, 0, 0}, ha = 0, hb = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {                       // (compile-time k; bi / bj select: no run-time indexed local arrays)
+      const HP sga = dot3(A[k], Ln) > 0 ? (HP)1 : (HP)-1, sgb = dot3(B[k], Ln) > 0 ? (HP)-1 : (HP)1;
+      for (int e = 0; e < 3; ++e) {
+        ea[e] += (k != bi) ? sga * s1[k] * A[k][e] : (HP)0;
+        eb[e] += (k != bj) ? sgb * s2[k] * B[k][e] : (HP)0;
+        Ai[e] = (k == bi) ? A[k][e] : Ai[e];
+        Bj[e] = (k == bj) ? B[k][e] : Bj[e];
+      }
+      ha = (k == bi) ? s1[k] : ha; hb = (k == bj) ? s2[k] : hb;
+    }
+    const HP w[3] = {ea[0] - eb[0], ea[1] - eb[1], ea[2] - eb[2]};
+    const HP ab = dot3(Ai, Bj), aw = dot3(Ai, w), bw = dot3(Bj, w), den = (HP)1 - ab * ab;
+    HP u = den > (HP)1e-12 ? (ab * bw - aw) / den : (HP)0, v = den > (HP)1e-12 ? (bw - ab * aw) / den : (HP)0;
+    u = tclamp(u, -ha, ha); v = tclamp(v, -hb, hb);
+    for (int e = 0; e < 3; ++e) { o.pos[e] = (HP)0.5 * ((ea[e] + u * Ai[e]) + (eb[e] + v * Bj[e])); o.nrm[e] = Ln[e]; }
+    o.dist[0] = best_edge;
+    o.n = 1;
   } else if (t1 == 6 && t2 == 6 && sub >= 1) {   // box - box: one vertex-face candidate (see the pair table)
     const int v = (sub - 1) & 7, second = sub > 8;
     HP loc[3], q[3];

@@ -277,7 +277,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     for (int k = 0; k < 10; ++k) if (sizes[k] < 0) BAD("negative size %d", k)
     if (m->nbody < 1 || m->na > m->nu) BAD("nbody < 1 or na > nu")
     if (m->pair_geom1.size() != m->pair_geom2.size() || pair_sub.size() != m->pair_geom1.size()) BAD("pair arrays differ in length")
-    for (int v : pair_sub) if (v < 0 || v > 16) BAD("collision pair sub-index %d", v)
+    for (int v : pair_sub) if (v < 0 || v > 17) BAD("collision pair sub-index %d", v)
 #define NEED(arr, cnt) if (m->arr.size() < (size_t)(cnt)) BAD("array %s has %zu entries, needs %zu", #arr, m->arr.size(), (size_t)(cnt))
     const size_t nb_ = m->nbody, nj_ = m->njnt, nv_ = m->nv, ng_ = m->ngeom, ns_ = m->nsite, nt_ = m->ntendon, nw_ = m->nwrap, nu_ = m->nu;
     NEED(body_parentid, nb_) NEED(body_rootid, nb_) NEED(body_jntnum, nb_) NEED(body_jntadr, nb_) NEED(body_dofnum, nb_) NEED(body_dofadr, nb_)
@@ -562,7 +562,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   // per-pair contact records: everything mj_contactParam / the constraint build derive from the two geoms
   // alone is resolved here (the device stage was a chain of dependent table loads per contact):
   //   pc_i[8p..]  = body1, body2, root body 1, root body 2, nsup, box-box candidate (0 none; 1 + v: vertex v of geom 1 against
-  //                 geom 2, 9 + v: vertex v of geom 2 against geom 1), 0, friction selector (0 max, 1 geom1, 2 geom2)
+  //                 geom 2, 9 + v: vertex v of geom 2 against geom 1, 17: the edge-edge candidate), 0, friction selector (0 max, 1 geom1, 2 geom2)
   //   pc_sup[4p..] = the dofs either body can move (<= 16 bytes, ascending)
   //   pc_f[16p..] = margin, margin - gap, solref[2], solimp[5] (mixed), friction1[3], friction2[3], invweight sum
   //   pc_mask[2p..] = ancestor-dof masks of the two bodies

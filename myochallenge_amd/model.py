@@ -161,7 +161,7 @@ def collision_pairs(m: MjbModel):
             if key == (GEOM_PLANE, GEOM_PLANE):
                 continue
             if key == (GEOM_BOX, GEOM_BOX):
-                pairs += [(a, b, 1 + v) for v in range(16)]      # sub = 1 + v: vertex v of a vs b; 9 + v: vertex v of b vs a
+                pairs += [(a, b, 1 + v) for v in range(17)]      # sub = 1 + v: vertex v of a vs b; 9 + v: vertex v of b vs a; 17: the edge-edge candidate
             elif key in SUPPORTED_PAIRS:
                 pairs.append((a, b, 0))
             else:
@@ -174,8 +174,9 @@ class UnsupportedContactsError(ValueError):
 
 
 def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_contacts: str = "error") -> CompiledModel:
-    """unsupported_contacts: what to do with colliding geom pairs that have no narrow phase here (anything with a
-    cylinder or an ellipsoid, box-box, mesh): "error" (default) refuses the model — a contact MuJoCo would generate
+    """unsupported_contacts: what to do with colliding geom pairs that have no narrow phase here (meshes, height fields,
+    cylinder-cylinder, ellipsoid-ellipsoid and the like; the pairs of SUPPORTED_PAIRS and box-box — 16 vertex-face candidates plus
+    one edge-edge candidate from a separating-axis test — have one): "error" (default) refuses the model — a contact MuJoCo would generate
     must not vanish silently — "drop" compiles without them and lists them in ``CompiledModel.dropped_pairs``
     (an explicit opt-in: the physics then differs from MuJoCo's whenever such a pair would touch)."""
     if unsupported_contacts not in ("error", "drop"):

@@ -981,9 +981,54 @@ static int collide_pair(const OrcModel* m, const OrcData* d, int g1, int g2, int
     if (cnt == 2) return 2;
     return point_box(dist, pos, nrm, q, s1[0], p2, R2, s2, margin, 1);
   }
+  if (t1 == MYO_GEOM_BOX && t2 == MYO_GEOM_BOX && sub == 17) {
+    /* edge-edge contact (the 17th candidate of a box-box pair): separating-axis test over the 6 face normals and the 9 edge
+     * cross products; when the axis of LARGEST separation (least penetration) is an edge pair, one contact at the midpoint
+     * of the two edges' closest points, normal = that axis, from box 1 to box 2.  Face contacts are the vertex-face
+     * candidates' business: a face axis wins ties (the 1e-9 relative bias keeps parallel-edge configurations out). */
+    double t[3] = { p2[0]-p1[0], p2[1]-p1[1], p2[2]-p1[2] };
+    double A[3][3], B[3][3];
+    for (int k = 0; k < 3; ++k) for (int e = 0; e < 3; ++e) { A[k][e] = R1[3*e+k]; B[k][e] = R2[3*e+k]; }   /* box axes = matrix columns */
+    double best_face = -1e300, best_edge = -1e300, Ln[3] = {0,0,0}; int bi = -1, bj = -1;
+    for (int k = 0; k < 6; ++k) {
+      const double* L = k < 3 ? A[k] : B[k-3];
+      double ra = 0, rb = 0;
+      for (int e = 0; e < 3; ++e) { ra += s1[e]*fabs(dot3(A[e], L)); rb += s2[e]*fabs(dot3(B[e], L)); }
+      double sep = fabs(dot3(t, L)) - ra - rb;
+      if (sep > best_face) best_face = sep;
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      double L[3]; cross3(L, A[i], B[j]);
+      double len = sqrt(dot3(L, L));
+      if (len < 1e-6) continue;                                   /* (nearly) parallel edges: a face axis covers them */
+      for (int e = 0; e < 3; ++e) L[e] /= len;
+      double ra = 0, rb = 0;
+      for (int e = 0; e < 3; ++e) { ra += s1[e]*fabs(dot3(A[e], L)); rb += s2[e]*fabs(dot3(B[e], L)); }
+      double sep = fabs(dot3(t, L)) - ra - rb;
+      if (sep > best_edge) { best_edge = sep; bi = i; bj = j; for (int e = 0; e < 3; ++e) Ln[e] = L[e]; }
+    }
+    if (bi < 0 || best_edge > margin || best_face > margin) return 0;
+    if (!(best_edge > best_face + 1e-9*(1.0 + fabs(best_face)))) return 0;
+    if (dot3(t, Ln) < 0) for (int e = 0; e < 3; ++e) Ln[e] = -Ln[e];                    /* from box 1 to box 2 */
+    /* the edge of box 1 parallel to A[bi] that is extreme along +Ln, the edge of box 2 parallel to B[bj] extreme along -Ln */
+    double ea[3] = { p1[0], p1[1], p1[2] }, eb[3] = { p2[0], p2[1], p2[2] };
+    for (int k = 0; k < 3; ++k) {
+      if (k != bi) { double sg = dot3(A[k], Ln) > 0 ? 1.0 : -1.0; for (int e = 0; e < 3; ++e) ea[e] += sg*s1[k]*A[k][e]; }
+      if (k != bj) { double sg = dot3(B[k], Ln) > 0 ? -1.0 : 1.0; for (int e = 0; e < 3; ++e) eb[e] += sg*s2[k]*B[k][e]; }
+    }
+    /* closest points of the lines ea + u A[bi], eb + v B[bj], clamped to the edges */
+    double w[3] = { ea[0]-eb[0], ea[1]-eb[1], ea[2]-eb[2] };
+    double ab = dot3(A[bi], B[bj]), aw = dot3(A[bi], w), bw = dot3(B[bj], w), den = 1.0 - ab*ab;
+    double u = den > 1e-12 ? (ab*bw - aw)/den : 0.0, v = den > 1e-12 ? (bw - ab*aw)/den : 0.0;
+    u = u < -s1[bi] ? -s1[bi] : (u > s1[bi] ? s1[bi] : u);
+    v = v < -s2[bj] ? -s2[bj] : (v > s2[bj] ? s2[bj] : v);
+    for (int e = 0; e < 3; ++e) { pos[e] = 0.5*((ea[e] + u*A[bi][e]) + (eb[e] + v*B[bj][e])); nrm[e] = Ln[e]; }
+    dist[0] = best_edge;
+    return 1;
+  }
   if (t1 == MYO_GEOM_BOX && t2 == MYO_GEOM_BOX && sub >= 1 && sub <= 16) {
     /* vertex-face contacts: the model compiler lists a box-box geom pair as 16 candidates, sub = 1 + v: vertex v (sign bits) of
-     * box 1 against box 2, sub = 9 + v: vertex v of box 2 against box 1.  (Edge-edge crossings generate no contact here.) */
+     * box 1 against box 2, sub = 9 + v: vertex v of box 2 against box 1; sub = 17: the edge-edge candidate above. */
     int v = (sub - 1) & 7, second = sub > 8;
     const double *pv = second ? p2 : p1, *Rv = second ? R2 : R1, *sv = second ? s2 : s1;
     const double *pb = second ? p1 : p2, *Rb = second ? R1 : R2, *sb = second ? s1 : s2;

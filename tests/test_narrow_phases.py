@@ -289,3 +289,67 @@ def test_contact_overflow_is_counted_on_emulation(emu_lib):
 def test_contact_overflow_is_counted_on_gpu(hip_lib):
     case_contact_overflow(hip_lib, native.MYO_F64)
     case_contact_overflow(hip_lib, native.MYO_MIXED)
+
+
+def crossed_boxes_model(margin=0.002):
+    """A static box lying on an edge-up diagonal (ridge along x) and a free box above it whose lowest feature is an edge along y:
+    the only contact two such boxes can make is EDGE-EDGE — no vertex of either box is near a face of the other."""
+    B = _Builder()
+    c, s = np.cos(np.pi / 8), np.sin(np.pi / 8)                        # quaternion of a 45 degree turn about x
+    B.add_geom("ridge", 0, BOX, (0.05, 0.03, 0.03), (0.0, 0.0, 0.5), quat=(c, s, 0, 0), collide=1)
+    b = B.add_body("upper", 0, (0.0, 0.0, 0.6), mass=0.05, inertia=(2e-5, 3e-5, 4e-5))
+    B.add_joint("upper_free", b, 0)
+    B.add_geom("vee", b, BOX, (0.05, 0.03, 0.03), collide=1)
+    m = B.finish()
+    for g in range(2):
+        m.arrays["geom_contype"][g], m.arrays["geom_conaffinity"][g] = 1, 1
+    m.arrays["geom_margin"][:] = margin
+    set_const(m)
+    return m
+
+
+def _quat_mul(a, b):
+    return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                     a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+
+
+def case_edge_edge(lib, dtype, tol):
+    """Two boxes crossing edge-on: exactly one contact, at the crossing point, normal along +z (geom 1 -> geom 2), distance = the gap
+    between the two edges — from the oracle's closed form, from the stepper through the C ABI, and against the analytic values."""
+    mem = Mem(lib)
+    m = crossed_boxes_model()
+    cm = compile_model(m)
+    assert cm.dropped_pairs == []
+    om = OracleModel(cm.to_blob())
+    h = 0.03 * np.sqrt(2.0)                                # a 45-degree box's edge sits this far from its centre
+    c, s = np.cos(np.pi / 8), np.sin(np.pi / 8)
+    qz = np.array([np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])      # 90 degrees about z: the upper box's long axis along y
+    quat = _quat_mul(qz, np.array([c, s, 0, 0]))
+    for gap, expect in ((-0.003, 1), (0.001, 1), (0.004, 0)):
+        q = np.concatenate([[0.01, -0.02, 0.5 + 2 * h + gap], quat])
+        d = OracleData(om)
+        d.qpos[:] = q
+        d.forward()
+        assert d.ncon == expect, (gap, d.ncon)
+        get, b = forward_dump(lib, mem, cm, q, np.zeros(6), np.zeros(0), np.zeros(0), dtype)
+        cnt = get("counts", 4)
+        assert (int(cnt[0]), int(cnt[1])) == (d.ncon, d.nefc), (gap, cnt)
+        if expect:
+            assert abs(float(np.array(d.efc_pos)[d.nefc - 4]) - gap) < 1e-12, (gap, np.array(d.efc_pos)[:d.nefc])
+            assert rel_err(get("efc_aref", d.nefc), np.array(d.efc_aref)[:d.nefc]) < tol
+            assert rel_err(get("qacc", om.nv), d.qacc) < tol
+            # a downward push on the upper box is answered along +z only (the contact normal), at the crossing point (no torque about it
+            # beyond the offset of the box's centre from the crossing point)
+            assert np.array(d.qacc)[2] > -9.81 + 1e-3 or gap > 0
+        b.close()
+
+
+def test_edge_edge_box_contact_on_emulation(emu_lib):
+    case_edge_edge(emu_lib, native.MYO_F64, 1e-9)
+    case_edge_edge(emu_lib, native.MYO_MIXED, 1e-4)
+
+
+@pytest.mark.gpu
+def test_edge_edge_box_contact_on_gpu(hip_lib):
+    case_edge_edge(hip_lib, native.MYO_F64, 1e-9)
+    case_edge_edge(hip_lib, native.MYO_MIXED, 1e-4)

@@ -138,6 +138,17 @@ int myo_batch_health(myo_batch* b, int out[4]);
  * the env's own done flag (ball dropped) for the selected envs. */
 int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const float* act, float* obs, uint8_t* done, void* stream);
 
+/* The same step for a LIST of envs in compact form: idx = dev int32[n_idx] (env numbers; -1 = empty slot; no env twice), act = dev
+ * float[n_idx, nu], obs = dev float[n_idx, obs_dim], done = dev uint8[n_idx] or NULL — row r belongs to env idx[r].  One workgroup
+ * per slot instead of one per env of the batch: the base phase of MixtureModelBaodingEnv (baoding.py:700-711) touches the few
+ * envs that were just reset. */
+int myo_batch_step_inner_idx(myo_batch* b, const int* idx, int n_idx, const float* act, float* obs, uint8_t* done, void* stream);
+
+/* Whole env records from one batch into another of the same model / task kind / device: dst env dst_idx[r] <- src env src_idx[r],
+ * r < k (dev int32 arrays; out-of-range entries are skipped).  A record is everything an env is between two steps, so the
+ * destination env continues where the source env stood (MixtureModelBaodingEnv: pre-played episodes from a pool batch). */
+int myo_batch_copy_envs(myo_batch* dst, const int* dst_idx, const myo_batch* src, const int* src_idx, int k, void* stream);
+
 /* raw physics: apply ctrl (dev double[N,nu]) and run `nsub` mj_step substeps; no task layer.
  * Used by parity tests on arbitrary models. */
 int myo_batch_physics_step(myo_batch* b, const double* ctrl, int nsub, void* stream);

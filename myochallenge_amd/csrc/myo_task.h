@@ -570,12 +570,14 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
 // (/root/reference/src/envs/baoding.py:700-711).  done_out = the env's own `done` (ball dropped).
 template <typename T, int NC>
 DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
-                        int env, const unsigned char* mask, const float* act, float* obs, unsigned char* done_out) {
+                        int env, const unsigned char* mask, const float* act, float* obs, unsigned char* done_out, int row = -1) {
+  // row: the env's row in act / obs / done_out (compact form, myo_batch_step_inner_idx); -1: its own index
   WAVE_FN
   if (mask && !mask[env]) return;
   const int nobs = task_nobs(K, M.na);
+  const int io = row < 0 ? env : row;
   load_env(M, K, L, rec, s);
-  task_step_core(M, K, s, act + (size_t)env * M.nu);
+  task_step_core(M, K, s, act + (size_t)io * M.nu);
   const int bad = s.bad, fall = s.rwd[6] != 0 || bad;
   if (bad) {                        // blown-up env: back to a finite reset state (see env_step)
     PHASE { if (lane == 0) s.episode++; }
@@ -583,8 +585,8 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
     task_reset(M, K, s, env);
   }
   PHASE {
-    if (lane == 0 && done_out) done_out[env] = (unsigned char)fall;
-    for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
+    if (lane == 0 && done_out) done_out[io] = (unsigned char)fall;
+    for (int i = lane; i < nobs; i += 64) obs[(size_t)io * nobs + i] = (float)S_OBS(s)[i];
   }
   SYNC();
   store_env(M, K, L, rec, s);

@@ -1234,6 +1234,18 @@ __global__ void __launch_bounds__(64, 2) k_step_inner(EnvRecordLayout L, double*
   const int env = blockIdx.x;
   env_step_inner<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, act, obs, done);
 }
+// the same for a LIST of envs: block r steps env idx[r] (idx[r] < 0: an empty slot) with row r of act / obs / done
+template <typename T, bool RK, int NC>
+__global__ void __launch_bounds__(64, 2) k_step_inner_idx(EnvRecordLayout L, double* rec, const int* __restrict__ idx, int n_envs, const float* act,
+                                                       float* obs, unsigned char* done) {
+  const int env = idx[blockIdx.x];
+  if (env < 0 || env >= n_envs) return;
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
+  s.rk = rk_storage<T, RK, NC>();
+  const DevModel<T>& M = myo_cmodel<T>();
+  const TaskDev& K = c_task;
+  env_step_inner<T>(M, K, L, rec + (size_t)env * L.stride, s, env, (const unsigned char*)nullptr, act, obs, done, (int)blockIdx.x);
+}
 template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* rec,
                                                 const double* ctrl, int nsub) {
@@ -1540,6 +1552,67 @@ extern "C" int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const flo
     else
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, act, obs, done))
   LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+// Compact form of myo_batch_step_inner: the envs idx[0 .. n_idx) (dev int32; -1 = empty slot) take one unwrapped env step with
+// row r of act [n_idx, nu]; row r of obs [n_idx, obs_dim] and done [n_idx] (may be NULL) receive env idx[r]'s results.  An env
+// must not be listed twice.  MixtureModelBaodingEnv's base phase runs the few envs that were just reset this way.
+extern "C" int myo_batch_step_inner_idx(myo_batch* b, const int* idx, int n_idx, const float* act, float* obs, uint8_t* done, void* stream) {
+  if (!b || !idx || !act || !obs || n_idx <= 0) return fail(MYO_E_ARG, "myo_batch_step_inner_idx: idx/act/obs are required");
+  if (!b->K.kind) return fail(MYO_E_STATE, "batch has no task layer");
+#ifdef MYO_EMU
+  (void)stream;
+  for (int r = 0; r < n_idx; ++r) {
+    const int e = idx[r];
+    if (e < 0 || e >= b->n) continue;
+#define ONE_ENV(TT, NCV, MD) { Scratch<TT, NCV>* s = new Scratch<TT, NCV>(); memset(s, 0, sizeof *s); RkScratch<TT>* rk = new RkScratch<TT>(); s->rk = rk; \
+      env_step_inner<TT>(MD, b->K, b->L, b->rec + (size_t)e * b->L.stride, *s, e, (const unsigned char*)nullptr, act, obs, done, r); delete s; delete rk; }
+    if (b->dtype == MYO_F64) { if (b->ncap > MYO_NCON_MAX) ONE_ENV(double, MYO_NCON_BIG, b->Md) else ONE_ENV(double, MYO_NCON_F64, b->Md) }
+    else { if (b->ncap > MYO_NCON_MAX) ONE_ENV(float, MYO_NCON_BIG, b->Mf) else ONE_ENV(float, MYO_NCON_MAX, b->Mf) }
+#undef ONE_ENV
+  }
+#else
+  hipStream_t st = (hipStream_t)stream;
+  BIND_OR_RETURN(b, st)
+  LAUNCH_RK(b,
+    if (b->dtype == MYO_F64)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner_idx<double, RKV, MYO_NC_D(NCV)>), dim3(n_idx), dim3(64), lds_dyn(b), st, b->L, b->rec, idx, b->n, act, obs, done);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step_inner_idx<float, RKV, NCV>), dim3(n_idx), dim3(64), lds_dyn(b), st, b->L, b->rec, idx, b->n, act, obs, done))
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
+// Whole env records from one batch into another (same model, same task kind): dst env dst_idx[r] <- src env src_idx[r], r < k.
+// The record is everything an env is between two steps (state, warm start, task scalars, per-episode draws, counters), so the
+// destination env continues exactly where the source env stood.  MixtureModelBaodingEnv hands pre-played episodes (reset + base
+// phase, done in bulk on a pool batch) to the envs that have just finished.
+#ifndef MYO_EMU
+__global__ void k_copy_envs(double* dst, const int* __restrict__ dst_idx, int n_dst, const double* src, const int* __restrict__ src_idx, int n_src, int stride) {
+  const int d = dst_idx[blockIdx.x], s = src_idx[blockIdx.x];
+  if (d < 0 || d >= n_dst || s < 0 || s >= n_src) return;
+  for (int i = threadIdx.x; i < stride; i += blockDim.x) dst[(size_t)d * stride + i] = src[(size_t)s * stride + i];
+}
+#endif
+extern "C" int myo_batch_copy_envs(myo_batch* dst, const int* dst_idx, const myo_batch* src, const int* src_idx, int k, void* stream) {
+  if (!dst || !src || !dst_idx || !src_idx || k < 0) return fail(MYO_E_ARG, "myo_batch_copy_envs: null argument");
+  if (dst->L.stride != src->L.stride || dst->nq != src->nq || dst->nv != src->nv || dst->na != src->na || dst->K.kind != src->K.kind || dst->device != src->device)
+    return fail(MYO_E_ARG, "myo_batch_copy_envs: the two batches differ in model, task kind or device");
+  if (k == 0) return MYO_OK;
+#ifdef MYO_EMU
+  (void)stream;
+  for (int r = 0; r < k; ++r) {
+    const int d = dst_idx[r], s = src_idx[r];
+    if (d < 0 || d >= dst->n || s < 0 || s >= src->n) continue;
+    memcpy(dst->rec + (size_t)d * dst->L.stride, src->rec + (size_t)s * src->L.stride, sizeof(double) * (size_t)dst->L.stride);
+  }
+#else
+  DeviceGuard guard(dst->device);
+  hipLaunchKernelGGL(k_copy_envs, dim3(k), dim3(64), 0, (hipStream_t)stream, dst->rec, dst_idx, dst->n, src->rec, src_idx, src->n, dst->L.stride);
+  LAUNCH_CHECK(dst)
 #endif
   return MYO_OK;
 }

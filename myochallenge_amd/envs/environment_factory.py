@@ -28,7 +28,7 @@ class EnvironmentFactory:
         if env_name == "MixtureModelBaodingEnv":        # src/envs/baoding.py:650-714
             from .mixture import MixtureModelBaodingVecEnv
             mix = {k: kwargs.pop(k) for k in ("base_model_path", "base_env_path", "base_env_name", "base_env_config",
-                                             "n_steps_base_model", "base_policy", "base_normalizer") if k in kwargs}
+                                             "n_steps_base_model", "base_policy", "base_normalizer", "pool_size") if k in kwargs}
             return MixtureModelBaodingVecEnv(env_name, num_envs, kwargs, **mix, **batch_kw)
         if env_name in REGISTRATION:
             return BaodingVecEnv(env_name, num_envs, kwargs, **batch_kw)

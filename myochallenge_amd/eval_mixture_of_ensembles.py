@@ -111,7 +111,7 @@ def eval_perf(eval_env, mixture_model: SuperModel, num_episodes: int = 2000, ver
     step = torch.zeros(N, dtype=torch.long, device=dev)
     eff = torch.zeros(N, dtype=torch.float64, device=dev)
     na = eval_env.act_dim
-    lens, perfs, effort, targets, preds = [], [], [], [], []
+    lens, perfs, effort, targets, preds, who, who13 = [], [], [], [], [], [], []
     ti = torch.zeros((N, 2), dtype=torch.int32, device=dev)
     for _ in range(int(quota.max()) * (eval_env.max_episode_steps + 1) + 1):
         action = mixture_model.predict(obs, starts)
@@ -127,12 +127,14 @@ def eval_perf(eval_env, mixture_model: SuperModel, num_episodes: int = 2000, ver
             idx = at13.nonzero().flatten()
             targets.append(torch.clamp(which[idx], 0, 1).cpu().numpy())
             preds.append(mixture_model.current_task[idx].cpu().numpy())
+            who13.append(idx.cpu().numpy())
         dn = done.bool()
         if bool(dn.any()):
             idx = (dn & (played < quota)).nonzero().flatten()
             if idx.numel():
                 lens.append(ep[idx, 1].cpu().numpy()); perfs.append(ep[idx, 0].cpu().numpy())
                 effort.append((eff[idx] / torch.clamp(step[idx], min=1)).cpu().numpy())
+                who.append(idx.cpu().numpy())
                 played[idx] += 1
             step[dn] = 0
             eff[dn] = 0
@@ -141,7 +143,8 @@ def eval_perf(eval_env, mixture_model: SuperModel, num_episodes: int = 2000, ver
             break
     cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dt)
     res = {"lengths": cat(lens, np.int64), "returns": cat(perfs, np.float64), "effort": cat(effort, np.float64),
-           "classifier_targets": cat(targets, np.int64), "classifier_preds": cat(preds, np.int64)}
+           "classifier_targets": cat(targets, np.int64), "classifier_preds": cat(preds, np.int64),
+           "env_index": cat(who, np.int64), "classifier_env_index": cat(who13, np.int64)}      # which env of the batch each entry came from
     if verbose and len(res["lengths"]):
         n = len(res["lengths"])
         print(f"Average len: {res['lengths'].mean():.2f} +/- {res['lengths'].std() / np.sqrt(n):.2f}")

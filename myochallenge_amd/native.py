@@ -113,6 +113,8 @@ class NativeLib:
         L.myo_batch_reset.argtypes = [vp, vp, vp, vp]
         L.myo_batch_step.argtypes = [vp] * 10
         L.myo_batch_step_inner.argtypes = [vp] * 6
+        L.myo_batch_step_inner_idx.argtypes = [vp, vp, i32, vp, vp, vp, vp]
+        L.myo_batch_copy_envs.argtypes = [vp, vp, vp, vp, i32, vp]
         L.myo_batch_physics_step.argtypes = [vp, vp, i32, vp]
         L.myo_batch_get_state.argtypes = [vp] * 6
         L.myo_batch_set_state.argtypes = [vp] * 6
@@ -191,7 +193,7 @@ def load(path: Optional[str] = None) -> NativeLib:
 EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_load_mjb", "myo_model_destroy", "myo_model_size", "myo_batch_create",
     "myo_batch_destroy", "myo_batch_set_step_generation", "myo_batch_health", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
-    "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_physics_step", "myo_batch_get_state",
+    "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_step_inner_idx", "myo_batch_copy_envs", "myo_batch_physics_step", "myo_batch_get_state",
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
@@ -266,6 +268,14 @@ class Batch:
 
     def step_inner(self, mask, act, obs, done=None, stream=None):
         self.lib.check(self.lib.L.myo_batch_step_inner(self.h, _ptr(mask), _ptr(act), _ptr(obs), _ptr(done), stream))
+
+    def step_inner_idx(self, idx, act, obs, done=None, stream=None):
+        """compact form of step_inner: idx int32[n] (-1 = empty slot), act [n, nu], obs [n, obs_dim], done uint8[n] or None"""
+        self.lib.check(self.lib.L.myo_batch_step_inner_idx(self.h, _ptr(idx), int(idx.shape[0]), _ptr(act), _ptr(obs), _ptr(done), stream))
+
+    def copy_envs_from(self, src: "Batch", dst_idx, src_idx, stream=None):
+        """env records src_idx of `src` -> envs dst_idx of this batch (int32 device arrays of equal length)"""
+        self.lib.check(self.lib.L.myo_batch_copy_envs(self.h, _ptr(dst_idx), src.h, _ptr(src_idx), int(dst_idx.shape[0]), stream))
 
     def physics_step(self, ctrl, nsub, stream=None):
         self.lib.check(self.lib.L.myo_batch_physics_step(self.h, _ptr(ctrl), nsub, stream))

@@ -83,7 +83,7 @@ def make_env(env_name, lib, **kwargs):
     if env_name == "MixtureModelBaodingEnv":
         from myochallenge_amd.envs.mixture import MixtureModelBaodingVecEnv
         mix = {k: kwargs.pop(k) for k in ("base_model_path", "base_env_path", "base_env_name", "base_env_config",
-                                         "n_steps_base_model", "base_policy", "base_normalizer") if k in kwargs}
+                                         "n_steps_base_model", "base_policy", "base_normalizer", "pool_size") if k in kwargs}
         return (_on_cpu(MixtureModelBaodingVecEnv) if lib.is_emulation else MixtureModelBaodingVecEnv)(env_name, num_envs, kwargs, **mix, **batch_kw, lib=lib)
     if env_name in REGISTRATION:
         from myochallenge_amd.envs.baoding import BaodingVecEnv

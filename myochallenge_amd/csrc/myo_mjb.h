@@ -197,7 +197,10 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   for (double v : D("tendon_frictionloss")) if (v > 0) { err = "friction loss is not supported"; *unsupported = 1; return false; }
   if (f.cone != 0) { err = "only pyramidal friction cones are supported"; *unsupported = 1; return false; }
   for (int g = 0; g < ngeom; ++g)
-    if ((I("geom_contype")[g] | I("geom_conaffinity")[g]) != 0 && I("geom_condim")[g] != 3) { err = "only condim=3 contacts are supported"; *unsupported = 1; return false; }
+    if ((I("geom_contype")[g] | I("geom_conaffinity")[g]) != 0) {
+      const int cd = I("geom_condim")[g];
+      if (cd != 1 && cd != 3 && cd != 4 && cd != 6) { err = "contact dimensions (condim) other than 1, 3, 4, 6 do not exist in MuJoCo"; *unsupported = 1; return false; }
+    }
   // static collision filter (mj_collision body-pair pass): same weld group, <exclude> body pairs (exclude_signature =
   // ((body1 + 1) << 16) + body2 + 1 with body1 < body2, MuJoCo 2.1), parent-child unless mjDSBL_FILTERPARENT, contype / conaffinity
   const std::vector<int>& excl = I("exclude_signature");

@@ -18,7 +18,7 @@
 #define MYO_NM_MAX 176    // tree-sparse inertia entries
 #define MYO_NCON_MAX 24   // contacts (base capacity of the scratch: Scratch<T, NC = MYO_NCON_MAX>)
 #define MYO_NCON_F64 20   // contacts, base capacity of the fp64 stepper's scratch: with it the scratch is 26.8 KB = six workgroups per CU (the bench workload peaks at 11 contacts; more than the capacity is counted, myo_batch_health)
-#define MYO_NCON_BIG 32   // contacts, scratch of models with extended collision pairs / a die (56 + 4 * 32 = 184 rows <= 192)
+#define MYO_NCON_BIG 34   // contact slots, scratch of models with extended collision pairs / a die / condim 4, 6 pairs (56 + 4 * 34 = 192 rows, three per lane)
 #define MYO_CS_MAX 16     // dofs one contact can move
 #define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows
 #define MYO_NEFC_MAX (MYO_NLIM_MAX + 4 * MYO_NCON_MAX)
@@ -87,6 +87,7 @@ struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
   int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
   int npair_std;                // pairs [0, npair_std): collision_pass; [npair_std, npair): collision_pass_ext
+  int any_rot;                  // some collision pair has condim 4 / 6: contact slots with rotational rows exist (J' f stages torques)
   int arrow_nf;                 // block-arrow Newton system (myo_arrow_chol.h): number of 4-row leaf blocks behind the 16-row separator; 0: dense
   unsigned long long arrow_pad; // rows of the (permuted) 36-row system that hold no dof: identity
   int ld_nfq, ld_nsq;           // chunks of ld_fac / ld_sol in use (ld_nsq < 0: the model's M-only solves take the dense path)

@@ -80,18 +80,31 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   unsigned long long seed;
 };
 
-#define MYO_LIM_UPPER ((int)0x80000000)
-DEV int lim_index(int id) { return id & 0x7fffffff; }
+#define MYO_LIM_UPPER ((short)0x8000)
+DEV int lim_index(int id) { return id & 0x7fff; }
 template <typename T> DEV T lim_sign(int id) { return id < 0 ? (T)-1 : (T)1; }
 
 template <typename T>
 struct ContactRec {
-  T frame[6], mu, D, B, kip;      // frame: normal, first tangent (the second is their cross product, con_t2); mu: condim 3, both tangential directions use friction[0]
+  T frame[6], muA, muB, D, B, kip;   // frame: normal, first tangent (the second is their cross product, con_t2); muA / muB: friction of the slot's two row pairs
   T r1[3], r2[3];                 // contact point relative to the reference point of body1's / body2's tree
   unsigned long long m1, m2;      // ancestor-dof masks of the two bodies
-  int b1, b2, nsup;
+  int b1, b2, nsup;               // nsup: support size | slot kind << 8 (con_kind)
   alignas(4) unsigned char sup[MYO_CS_MAX];
 };
+// A contact of condim d is stored as one, two or three SLOTS of four constraint rows each (mj_makeConstraint's pyramid rows
+// J_normal +- friction[k] J_k, k < d - 1, in MuJoCo's order); every slot is a full record (same point, frame, D), its KIND says
+// what the two row pairs are:
+//   0  translation along tangent 1 / tangent 2                      (condim 3, and the first slot of condim 4 / 6)
+//   1  rotation about the normal (torsional) / about tangent 1       (second slot of condim 6)
+//   2  rotation about tangent 2 (rolling) / --                       (third slot of condim 6)
+//   3  the normal row alone (muA = 0) / --, --, --                   (condim 1: frictionless)
+//   4  rotation about the normal / --                                (second slot of condim 4)
+// "--" rows are padding: J = 0 and aref = -1, so they are never active and carry no force.
+template <typename T> DEV int con_kind(const ContactRec<T>& c) { return c.nsup >> 8; }
+template <typename T> DEV int con_nsup(const ContactRec<T>& c) { return c.nsup & 255; }
+DEV bool con_pad(int kind, int e) { return (kind == 2 || kind == 4) ? e >= 2 : (kind == 3 ? e >= 1 : false); }
+DEV int con_rows(int kind) { return kind == 3 ? 1 : ((kind == 2 || kind == 4) ? 2 : 4); }
 
 template <typename T>
 struct RkScratch {                // RK4 stage storage: the start state and the running weighted sum of the stage derivatives (the
@@ -101,6 +114,9 @@ struct RkScratch {                // RK4 stage storage: the start state and the 
 
 template <typename T, int NC = MYO_NCON_MAX>
 struct Scratch {
+  // per-env friction coefficients kept per geom of an object group: all three (sliding, torsional, rolling) in the big scratch that
+  // batches with a die get, the sliding one in the base scratch (an object group on a base batch: torsional / rolling stay nominal)
+  static constexpr int OBJG_NF = NC >= MYO_NCON_BIG ? 3 : 1;
   static_assert(NC >= MYO_NCON_F64 && MYO_NLIM_MAX + 4 * NC <= 192, "contact capacity: at least the smallest base (the aliases below are sized for it), at most three constraint rows per lane");
   // ---- state (HP in every build)
   HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX];
@@ -116,7 +132,7 @@ struct Scratch {
   };
   union {                         // a batch has either the two Baoding balls or an object group (the die), never both
     struct { HP target_w[6]; T ball_mass[2], ball_fric[6]; };
-    T objg_fric[MYO_OBJG_MAX];    // sliding friction of the object group's geoms (condim-3 contacts use no other coefficient)
+    T objg_fric[MYO_OBJG_MAX * (NC >= MYO_NCON_BIG ? 3 : 1)];   // friction of the object group's geoms, OBJG_NF coefficients each
   };
   T ep_ret;
   int which_task, counter, elapsed, episode, ep_len;
@@ -134,11 +150,11 @@ struct Scratch {
   T act_dot[MYO_NU_MAX];
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
   // ---- constraints
-  int ncon, nefc, nl, ntl, bad, solver_iter;
+  int ncon, nefc, nl, ntl, bad, solver_iter;   // ncon: contact SLOTS (four rows each, ContactRec)
   unsigned char hperm[MYO_NV_MAX];   // dof -> row of the Newton system (DevModel::hperm; identity unless the block-arrow solver is on)
   // (from con[] to qM, i.e. up to rk: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live)
   alignas(8) ContactRec<T> con[NC];
-  int lim_id[MYO_NLIM_MAX];                                            // dof (joint rows) / tendon (tendon rows); bit 31: the upper limit (row sign -1)
+  short lim_id[MYO_NLIM_MAX];                                          // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1)
   T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
   alignas(8) T efc_jar[MYO_NLIM_MAX + 4 * NC], efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC];
   unsigned char efc_active[MYO_NLIM_MAX + 4 * NC];
@@ -193,6 +209,8 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_AREF(s) ((s).efc_jar)
 /* world-frame force of every contact (3 per contact), staged by J' f: in efc_jv, dead between the line search that consumed J v and the next J v */
 #define S_CONF(s) (static_cast<T*>((s).efc_jv))
+/* ... and the world torque of the slots whose rows are rotations (condim 4 / 6): in bvec, dead between J v and the next body_vectors */
+#define S_CONTQ(s) (static_cast<T*>((s).bvec))
 #define S_CVEL(s) (static_cast<T*>((s).qfrc_constraint))   /* body velocities (velocity stage) live in the solver vectors qfrc_constraint,Ma,search,Mv */
 /* tendon velocities (velocity stage .. actuation) and actuator forces (actuation; read by the stage dump) live in qacc_smooth, qacc and the first
    entries of qfrc_constraint, which the solver writes later (the body velocities above are dead when the actuation stage writes the forces) */
@@ -301,6 +319,20 @@ template <typename T> DEV T tmax(T a, T b) { return a > b ? a : b; }
 template <typename T> DEV T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> DEV T tclamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// (J v)[row e of the slot] from the relative linear / angular velocity of the two bodies at the contact
+template <typename T> DEV T con_row_val(const ContactRec<T>& c, int kind, int e, const T* rel_lin, const T* rel_ang) {
+  T t2[3];
+  cross3(t2, c.frame, c.frame + 3);
+  const int second = e >> 1;
+  const T mu = second ? c.muB : c.muA;
+  // the pair's axis: kind 0: t1 | t2 (on the linear velocity); 1: n | t1, 2: t2, 4: n (on the angular velocity); 3: none (mu = 0)
+  const bool ax_n = (kind == 1 && !second) || kind == 4, ax_t1 = (kind == 0 && !second) || (kind == 1 && second);
+  const T ax[3] = {ax_n ? c.frame[0] : (ax_t1 ? c.frame[3] : t2[0]), ax_n ? c.frame[1] : (ax_t1 ? c.frame[4] : t2[1]), ax_n ? c.frame[2] : (ax_t1 ? c.frame[5] : t2[2])};
+  const T* rel = kind == 0 ? rel_lin : rel_ang;
+  const T val = dot3(c.frame, rel_lin) + ((e & 1) ? -mu : mu) * dot3(ax, rel);
+  return con_pad(kind, e) ? (T)0 : val;
+}
+
 // spatial algebra in MuJoCo's com-based convention: motion = [ang; lin], force = [torque; force]
 template <typename T> DEV void mul_inert_vec(T* r, const T* I, const T* v) {
   const T* w = v; const T* l = v + 3; const T* h = I + 6; T mass = I[9]; T t[3];
@@ -339,11 +371,16 @@ template <typename T, int NC> DEV HP geom_size0_hp(const DevModel<T>& M, const T
   if (g < K.objg_gidn && g >= K.objg_gidn - 3 && g >= K.objg_gid0) return M.h_geom_size[3 * g] + s.ball_size[0];
   return M.h_geom_size[3 * g];
 }
-template <typename T, int NC> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g, int k) {
-  if (g >= K.objg_gid0 && g < K.objg_gidn) return k == 0 ? s.objg_fric[g - K.objg_gid0] : M.geom_friction[3 * g + k];
+// friction coefficient k (0 sliding, 1 torsional, 2 rolling) of geom g for this env: the per-env values of the Baoding balls / of
+// the object group's geoms (P2 / reorient randomisation), else `nominal` (the model's, from the pair record)
+template <typename T, int NC> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g, int k, T nominal) {
+  if (K.objg_gidn > 0) {
+    if (g >= K.objg_gid0 && g < K.objg_gidn && k < Scratch<T, NC>::OBJG_NF) return s.objg_fric[(g - K.objg_gid0) * Scratch<T, NC>::OBJG_NF + k];
+    return nominal;
+  }
   if (g == K.obj1_gid) return s.ball_fric[k];
   if (g == K.obj2_gid) return s.ball_fric[3 + k];
-  return M.geom_friction[3 * g + k];
+  return nominal;
 }
 
 // geometry of a geom of the per-env object group (the die of the reorient task, reorient.py:136-147): every geom
@@ -1958,61 +1995,82 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
   int total = 0;
   const int base = pbase;
   {
-    WAVE_EXSCAN(LV(ct).n, S_NPRE(s), total);
+    // slots per lane: a contact of condim 1 / 3 takes one, condim 4 two, condim 6 three (ContactRec kinds)
+    LANE_VAR(int, nslot);
     PHASE {
       const int p = base + lane;
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int ci = ncon + S_NPRE(s)[lane] + k;
-        if (k >= LV(ct).n || ci >= NC) break;
+      const int dim = LV(ct).n > 0 ? M.pc_i[8 * p + 6] : 3;
+      LV(nslot) = LV(ct).n * (dim == 6 ? 3 : (dim == 4 ? 2 : 1));
+    }
+    WAVE_EXSCAN6(LV(nslot), S_NPRE(s), total);
+    PHASE {
+      const int p = base + lane;
+      if (LV(ct).n > 0) {
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-        ContactRec<T>& c = s.con[ci];
-        T cpos[3];                         // contact point relative to O: only r1 / r2 below are made of it
-        for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); c.frame[e] = (T)LV(ct).nrm[3 * k + e]; }
-        make_frame(c.frame);
         // everything that depends on the two geoms only comes from the host-resolved pair record (pc_*):
         // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
-        // friction, margin and gap, inverse-weight sum; the balls' per-env friction is patched in here
+        // friction, margin and gap, inverse-weight sums, condim; the per-env friction of the balls / the die is patched in here
         const int b1 = M.pc_i[8 * p], b2 = M.pc_i[8 * p + 1], root1 = M.pc_i[8 * p + 2], root2 = M.pc_i[8 * p + 3];
-        const int ns = M.pc_i[8 * p + 4], fsel = M.pc_i[8 * p + 7];
+        const int ns = M.pc_i[8 * p + 4], dim = M.pc_i[8 * p + 6], fsel = M.pc_i[8 * p + 7];
+        const int per = dim == 6 ? 3 : (dim == 4 ? 2 : 1);
         T F[16];
         for (int e = 0; e < 16; ++e) F[e] = M.pc_f[16 * p + e];
-        c.b1 = b1; c.b2 = b2;
-        // condim 3: both tangential directions use friction[0]; torsional / rolling coefficients are not used
-        T fa = F[9], fb = F[12];
-        if (K.objg_gidn > 0) {
-          if (g1 >= K.objg_gid0 && g1 < K.objg_gidn) fa = s.objg_fric[g1 - K.objg_gid0];
-          if (g2 >= K.objg_gid0 && g2 < K.objg_gidn) fb = s.objg_fric[g2 - K.objg_gid0];
-        } else {
-          fa = g1 == K.obj1_gid ? s.ball_fric[0] : (g1 == K.obj2_gid ? s.ball_fric[3] : fa);
-          fb = g2 == K.obj1_gid ? s.ball_fric[0] : (g2 == K.obj2_gid ? s.ball_fric[3] : fb);
+        // friction (sliding, torsional, rolling): the larger of the two geoms', or the higher-priority geom's
+        T fr[3];
+        for (int k = 0; k < 3; ++k) {
+          if (k > 0 && dim <= 3) { fr[k] = 0; continue; }
+          const T fa = geom_fric_of(M, K, s, g1, k, F[9 + k]), fb = geom_fric_of(M, K, s, g2, k, F[12 + k]);
+          fr[k] = (fsel == 0) ? tmax(fa, fb) : (fsel == 1 ? fa : fb);
         }
-        const T fr0 = (fsel == 0) ? tmax(fa, fb) : (fsel == 1 ? fa : fb);
-        c.mu = fr0;
-        const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
-        T Kc, Bc, Ic;
-        sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
-        const T tran = F[15];
-        const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr0 * fr0 * tran) / Ic);
-        const T mu = fr0 / sqrt(M.impratio);
-        const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
-        c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * dmi;
-        c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
-        {
-          const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
-          for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
+        const T fr0 = fr[0];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k >= LV(ct).n) break;
+          T cpos[3], frame[6];                 // contact point relative to O: only r1 / r2 below are made of it
+          for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); frame[e] = (T)LV(ct).nrm[3 * k + e]; }
+          make_frame(frame);
+          const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
+          T Kc, Bc, Ic;
+          sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
+          const T tran = F[15];
+          // mj_makeImpedance: R of the first row from its diagApprox (tran + mu^2 tran; tran alone for the frictionless row), then every
+          // pyramid row of the contact gets Rpy = 2 mu'^2 R, mu' = friction[0] / sqrt(impratio)
+          T D;
+          if (dim == 1) D = 1 / tmax(MYO_MINVAL, (1 - Ic) * tran / Ic);
+          else {
+            const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr0 * fr0 * tran) / Ic);
+            const T mu = fr0 / sqrt(M.impratio);
+            D = 1 / tmax(MYO_MINVAL, 2 * mu * mu * R0);
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int ci = ncon + S_NPRE(s)[lane] + k * per + j;
+            if (j >= per || ci >= NC) break;
+            ContactRec<T>& c = s.con[ci];
+            const int kind = dim == 1 ? 3 : (j == 0 ? 0 : (dim == 4 ? 4 : j));
+            for (int e = 0; e < 6; ++e) c.frame[e] = frame[e];
+            c.b1 = b1; c.b2 = b2;
+            c.muA = kind == 0 ? fr0 : (kind == 1 || kind == 4 ? fr[1] : (kind == 2 ? fr[2] : (T)0));
+            c.muB = kind == 0 ? fr0 : (kind == 1 ? fr[2] : (T)0);
+            c.D = D; c.B = Bc; c.kip = Kc * Ic * dmi;
+            c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
+            {
+              const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
+              for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
+            }
+            {
+              int* dst = reinterpret_cast<int*>(c.sup);
+              for (int e = 0; e < MYO_CS_MAX / 4; ++e) dst[e] = M.pc_sup[4 * p + e];
+            }
+            c.nsup = ns | (kind << 8);
+          }
         }
-        {
-          int* dst = reinterpret_cast<int*>(c.sup);
-          for (int e = 0; e < MYO_CS_MAX / 4; ++e) dst[e] = M.pc_sup[4 * p + e];
-        }
-        c.nsup = ns;
       }
     }
     SYNC();
     ncon += total;
     if (ncon > NC) {
-      // more contacts than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
+      // more contact slots than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
       // with a warning — counted, so that the host can see it happened (myo_batch_health)
       PHASE { if (lane == 0 && K.health) myo_count(K.health + 1); }
       ncon = NC;
@@ -2140,10 +2198,10 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
         point_vel(bv, c.b1, c.r1, v1);
         point_vel(bv, c.b2, c.r2, v2);
         const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        T t2[3];
-        con_t2(c.frame, t2);
-        const T vn = dot3(c.frame, rel), vt = (e >> 1) ? dot3(t2, rel) : dot3(c.frame + 3, rel);
-        val = vn + ((e & 1) ? -c.mu : c.mu) * vt;
+        const int kind = con_kind(c);
+        T ra[3] = {0, 0, 0};
+        if (kind != 0) { const T* w1 = bv + 6 * c.b1; const T* w2 = bv + 6 * c.b2; ra[0] = w2[0] - w1[0]; ra[1] = w2[1] - w1[1]; ra[2] = w2[2] - w1[2]; }
+        val = con_row_val(c, kind, e, rel, ra);
       }
       out[r] = val;
     }
@@ -2201,20 +2259,20 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
-        T t2[3];
-        con_t2(c.frame, t2);
-        const T* fn = c.frame;
-        const T ft[3] = {(e >> 1) ? t2[0] : c.frame[3], (e >> 1) ? t2[1] : c.frame[4], (e >> 1) ? t2[2] : c.frame[5]};
-        const T mu = (e & 1) ? -c.mu : c.mu;
-        T v1[3], v2[3];
+        const int kind = con_kind(c);
+        T v1[3], v2[3], raa[3] = {0, 0, 0}, rab[3] = {0, 0, 0};
         point_vel(bva, c.b1, c.r1, v1);
         point_vel(bva, c.b2, c.r2, v2);
         const T rela[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        vala = dot3(fn, rela) + mu * dot3(ft, rela);
         point_vel(bvb, c.b1, c.r1, v1);
         point_vel(bvb, c.b2, c.r2, v2);
         const T relb[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        valb = dot3(fn, relb) + mu * dot3(ft, relb);
+        if (kind != 0) {
+          const T* a1 = bva + 6 * c.b1; const T* a2 = bva + 6 * c.b2; const T* b1 = bvb + 6 * c.b1; const T* b2 = bvb + 6 * c.b2;
+          for (int k = 0; k < 3; ++k) { raa[k] = a2[k] - a1[k]; rab[k] = b2[k] - b1[k]; }
+        }
+        vala = con_row_val(c, kind, e, rela, raa);
+        valb = con_row_val(c, kind, e, relb, rab);
       }
       outa[r] = vala; outb[r] = valb;
     }
@@ -2228,15 +2286,20 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* f = LPTR(const T, f_r); T* out = LPTR(T, out_r);
   WAVE_FN
-  const int nl = s.nl, nlim = s.nl + s.ntl, ncon = s.ncon;
+  const int nl = s.nl, nlim = s.nl + s.ntl, ncon = s.ncon, nrot = M.any_rot;      // any_rot: the model has condim 4 / 6 pairs (wave-uniform)
   PHASE {
     for (int ci = lane; ci < ncon; ci += 64) {
       const ContactRec<T>& c = s.con[ci];
       const T* fe = f + nlim + 4 * ci;
-      const T fn = fe[0] + fe[1] + fe[2] + fe[3], ft1 = c.mu * (fe[0] - fe[1]), ft2 = c.mu * (fe[2] - fe[3]);
+      const T fn = fe[0] + fe[1] + fe[2] + fe[3], fa = c.muA * (fe[0] - fe[1]), fb = c.muB * (fe[2] - fe[3]);      // (padding rows carry no force)
       T t2[3];
       con_t2(c.frame, t2);
-      for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + c.frame[3 + k] * ft1 + t2[k] * ft2;
+      const int kind = con_kind(c);
+      // world force at the contact point; slots whose pairs are rotations (kinds 1, 2, 4) add a world TORQUE instead of the tangential force
+      for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + (kind == 0 ? c.frame[3 + k] * fa + t2[k] * fb : (T)0);
+      if (nrot > 0)
+        for (int k = 0; k < 3; ++k)
+          S_CONTQ(s)[3 * ci + k] = kind == 1 ? c.frame[k] * fa + c.frame[3 + k] * fb : (kind == 2 ? t2[k] * fa : (kind == 4 ? c.frame[k] * fa : (T)0));
     }
   }
   SYNC();
@@ -2267,7 +2330,8 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
         T t[3];
         cross3(t, cd, off);
         const T col[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
-        const T v = dot3(col, S_CONF(s) + 3 * ci);
+        T v = dot3(col, S_CONF(s) + 3 * ci);
+        if (nrot > 0) v += dot3(cd, S_CONTQ(s) + 3 * ci);      // (wave-uniform branch: models without condim 4 / 6 contacts never take it)
         acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
       }
       out[d] = acc;
@@ -2391,7 +2455,8 @@ DEV void efc_reference(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       for (int r = lane; r < s.nefc; r += 64) {
         const T Bc = r < nlim_ ? S_LIM_B(s)[r] : s.con[(r - nlim_) >> 2].B;
         const T kp = r < nlim_ ? S_LIM_KIP(s)[r] : s.con[(r - nlim_) >> 2].kip;
-        S_AREF(s)[r] = -Bc * s.efc_jv[r] - kp;
+        const bool pad = r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3);
+        S_AREF(s)[r] = pad ? (T)-1 : -Bc * s.efc_jv[r] - kp;       // a padding row: J = 0, so J a - aref = 1 > 0, never active
       }
     }
     SYNC();
@@ -2583,7 +2648,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     PHASE {
       // ---- stage A for contact ci+1
       const int cn = ci + 1;
-      if (cn < ncon && lane < s.con[cn].nsup) {
+      if (cn < ncon && lane < con_nsup(s.con[cn])) {
         const ContactRec<T>& c = s.con[cn];
         const int d = c.sup[lane];
         const int on2 = (int)((c.m2 >> d) & 1ull), on1 = (int)((c.m1 >> d) & 1ull);
@@ -2591,7 +2656,11 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         con_col(s, d, on2 ? c.r2 : c.r1, col);
         T t2[3];
         con_t2(c.frame, t2);
-        T j[3] = {dot3(c.frame, col), dot3(c.frame + 3, col), dot3(t2, col)};
+        const int kind = con_kind(c);
+        const T* ang = s.cdof + 6 * d;                         // angular part of the dof's motion axis (rotational rows)
+        T j[3] = {dot3(c.frame, col),
+                  kind == 0 ? dot3(c.frame + 3, col) : ((kind == 1 || kind == 4) ? dot3(c.frame, ang) : (kind == 2 ? dot3(t2, ang) : (T)0)),
+                  kind == 0 ? dot3(t2, col) : (kind == 1 ? dot3(c.frame + 3, ang) : (T)0)};
         if (!on2) { j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2]; }
         if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion
         T* dst = stage + (cn & 1) * (MYO_CS_MAX * 3) + 3 * lane;
@@ -2602,13 +2671,13 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         const ContactRec<T>& c = s.con[ci];
         const unsigned char* act = s.efc_active + nlim + 4 * ci;
         T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
-        if (act[0]) { nn += 1; n1 += c.mu; a11 += c.mu * c.mu; }
-        if (act[1]) { nn += 1; n1 -= c.mu; a11 += c.mu * c.mu; }
-        if (act[2]) { nn += 1; n2 += c.mu; a22 += c.mu * c.mu; }
-        if (act[3]) { nn += 1; n2 -= c.mu; a22 += c.mu * c.mu; }
+        if (act[0]) { nn += 1; n1 += c.muA; a11 += c.muA * c.muA; }
+        if (act[1]) { nn += 1; n1 -= c.muA; a11 += c.muA * c.muA; }
+        if (act[2]) { nn += 1; n2 += c.muB; a22 += c.muB * c.muB; }
+        if (act[3]) { nn += 1; n2 -= c.muB; a22 += c.muB * c.muB; }
         if (nn != 0) {
           const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
-          const int ns = c.nsup;
+          const int ns = con_nsup(c);
           const unsigned long long m1 = c.m1, m2 = c.m2;
           const T* jc = stage + (ci & 1) * (MYO_CS_MAX * 3);
           // lower-triangular pairs (a >= b) of the support set, enumerated linearly: q = a(a+1)/2 + b

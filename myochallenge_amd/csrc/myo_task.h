@@ -438,7 +438,8 @@ DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
       h.idx = base + (unsigned int)lane;
       const double nominal = (double)M.geom_friction[3 * K.objg_gid0 + lane], ch = K.obj_friction_change[lane % 3];
       const T f = (T)rng_range(h, nominal - ch, nominal + ch);
-      if (lane % 3 == 0) s.objg_fric[lane / 3] = f;     // the sliding coefficient; the torsional / rolling draws are consumed, condim-3 contacts never read them
+      constexpr int NF = Scratch<T, NC>::OBJG_NF;         // (the base scratch keeps the sliding coefficient only; the other two draws are consumed)
+      if (lane % 3 < NF) s.objg_fric[(lane / 3) * NF + lane % 3] = f;
     }
     if (lane == 0) {
       s.which_task = 0; s.counter = 0; s.elapsed = 0; s.ep_ret = 0; s.ep_len = 0;
@@ -464,7 +465,10 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (K.objg_gidn > 0) for (int i = lane; i < K.objg_gidn - K.objg_gid0; i += 64) s.objg_fric[i] = (T)rec[L.off_objfric + 3 * i];
+    if (K.objg_gidn > 0) {
+      constexpr int NF = Scratch<T, NC>::OBJG_NF;
+      for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) s.objg_fric[i] = (T)rec[L.off_objfric + 3 * (i / NF) + i % NF];
+    }
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
     for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i];
@@ -494,7 +498,10 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   PHASE {
-    if (K.kind == MYO_TASK_REORIENT_K) for (int i = lane; i < K.objg_gidn - K.objg_gid0; i += 64) rec[L.off_objfric + 3 * i] = (double)s.objg_fric[i];
+    if (K.kind == MYO_TASK_REORIENT_K) {
+      constexpr int NF = Scratch<T, NC>::OBJG_NF;
+      for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + 3 * (i / NF) + i % NF] = (double)s.objg_fric[i];
+    }
     for (int i = lane; i < M.nq; i += 64) rec[L.off_qpos + i] = (double)s.qpos[i];
     for (int i = lane; i < M.nv; i += 64) { rec[L.off_qvel + i] = (double)s.qvel[i]; rec[L.off_warm + i] = (double)s.qacc_warm[i]; }
     for (int i = lane; i < M.na; i += 64) rec[L.off_act + i] = (double)s.act[i];
@@ -656,7 +663,14 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       out[D.qfrc_bias + i] = (double)S_QFRC_BIAS(s)[i]; out[D.qfrc_passive + i] = (double)S_QFRC_PASSIVE(s)[i];
       out[D.qfrc_actuator + i] = (double)S_QFRC_ACTUATOR(s)[i];
     }
-    for (int r = lane; r < s.nefc; r += 64) out[D.efc_aref + r] = (double)S_AREF(s)[r];     // (efc_jar holds aref until the solver starts)
+    if (lane == 0) {                          // (efc_jar holds aref until the solver starts; the padding rows of contact slots are skipped:
+      int k = 0;                              //  the dump lists MuJoCo's rows)
+      const int nlim_ = s.nl + s.ntl;
+      for (int r = 0; r < s.nefc; ++r) {
+        if (r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3)) continue;
+        out[D.efc_aref + k++] = (double)S_AREF(s)[r];
+      }
+    }
     for (int i = lane; i < M.nu; i += 64) out[D.actuator_force + i] = (double)S_ACT_FORCE(s)[i];   // (lives in the solver's vectors)
   }
   SYNC();
@@ -677,8 +691,17 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       out[D.qacc + i] = (double)s.qacc[i];
     }
     for (int i = lane; i < M.na; i += 64) out[D.act_dot + i] = (double)s.act_dot[i];
-    if (lane == 0) { out[D.counts] = s.ncon; out[D.counts + 1] = s.nefc; out[D.counts + 2] = s.solver_iter; out[D.counts + 3] = s.nl; }
-    for (int r = lane; r < s.nefc; r += 64) out[D.efc_D + r] = (double)row_D(s, r, s.nl + s.ntl);
+    if (lane == 0) {
+      // contacts and rows as MuJoCo counts them: a contact's first slot is kind 0 or 3, padding rows do not exist
+      const int nlim_ = s.nl + s.ntl;
+      int nc = 0, k = 0;
+      for (int ci = 0; ci < s.ncon; ++ci) { const int kd = con_kind(s.con[ci]); nc += (kd == 0 || kd == 3); }
+      for (int r = 0; r < s.nefc; ++r) {
+        if (r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3)) continue;
+        out[D.efc_D + k++] = (double)row_D(s, r, nlim_);
+      }
+      out[D.counts] = nc; out[D.counts + 1] = k; out[D.counts + 2] = s.solver_iter; out[D.counts + 3] = s.nl;
+    }
     for (int sid = lane; sid < M.nsite; sid += 64) {
       HP p[3];
       body_point_hp(s, M.site_bodyid[sid], M.h_site_pos + 3 * sid, p);

@@ -62,7 +62,7 @@ extern "C" const char* myo_version(void) {      // "... build <hash of the nativ
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq, arrow_nf;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq, arrow_nf, any_rot;
   unsigned long long arrow_pad;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
@@ -258,6 +258,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
                get_d(blob, nbytes, "body_iquat", body_iquat) && get_d(blob, nbytes, "geom_quat", geom_quat) &&
                get_i(blob, nbytes, "x_pair_geom1", m->pair_geom1) && get_i(blob, nbytes, "x_pair_geom2", m->pair_geom2);
   if (ok && !get_i(blob, nbytes, "x_pair_sub", pair_sub)) pair_sub.assign(m->pair_geom1.size(), 0);      // (older blobs: no box-box candidates)
+  if (ok && !get_i(blob, nbytes, "geom_condim", geom_condim)) geom_condim.clear();                        // (older blobs: condim 3 everywhere)
   if (!ok) {
     int rc = fail(MYO_E_ARG, "model blob lacks field %s", missing ? missing : "(sizes/opt/derived)");
     delete m;
@@ -295,6 +296,8 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     NEED(actuator_gainprm, 10 * nu_) NEED(actuator_biasprm, 10 * nu_) NEED(actuator_ctrlrange, 2 * nu_) NEED(actuator_forcerange, 2 * nu_)
     NEED(actuator_gear, 6 * nu_) NEED(actuator_acc0, nu_) NEED(actuator_lengthrange, 2 * nu_)
 #undef NEED
+    if (geom_condim.empty()) geom_condim.assign(ng_, 3);
+    if (geom_condim.size() < ng_) BAD("geom_condim too short")
     if (trntype.size() < nu_ || trnid.size() < 2 * nu_ || body_iquat.size() < 4 * nb_ || geom_quat.size() < 4 * ng_) BAD("actuator_trn* / body_iquat / geom_quat too short")
     if (m->body_parentid[0] != 0) BAD("body_parentid[0] != 0")
     for (int b = 0; b < m->nbody; ++b) {
@@ -571,6 +574,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     m->pc_i.assign(8 * (size_t)np, 0); m->pc_sup.assign(4 * (size_t)np, 0);
     m->pc_f.assign(16 * (size_t)np, 0.0); m->pc_mask.assign(2 * (size_t)np, 0ull);
   }
+  m->any_rot = 0;
   for (int p = 0; p < m->npair; ++p) {
     const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
     const int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
@@ -603,6 +607,11 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     for (int e = 0; e < 3; ++e) { F[9 + e] = m->geom_friction[3 * g1 + e]; F[12 + e] = m->geom_friction[3 * g2 + e]; }
     F[15] = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
     I[7] = (pr1 == pr2) ? 0 : (pr1 > pr2 ? 1 : 2);
+    // condim of the contact (mj_contactParam): the higher-priority geom's, the larger of the two at equal priority
+    const int d1 = geom_condim[g1], d2 = geom_condim[g2];
+    I[6] = (pr1 == pr2) ? std::max(d1, d2) : (pr1 > pr2 ? d1 : d2);
+    LIM(I[6] != 1 && I[6] != 3 && I[6] != 4 && I[6] != 6, "contact dimension (condim) other than 1, 3, 4, 6")
+    if (I[6] > 3) m->any_rot = 1;
   }
   m->body_imat.resize(9 * nb);
   for (int b = 0; b < nb; ++b) quat2mat_h(&body_iquat[4 * b], &m->body_imat[9 * b]);
@@ -754,7 +763,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
   D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte; D.npair_std = m->npair_std;
-  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad;
+  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad; D.any_rot = m->any_rot;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];
@@ -882,7 +891,8 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   // contact capacity of the per-env scratch: the Baoding hand (39 candidate pairs, 11 contacts at most in the bench workload) keeps
   // the base; models with extended pairs (boxes, cylinders, ellipsoids) and the die task get the larger scratch (one workgroup
   // per CU less: 21.9 KB instead of 20.2 KB of LDS)
-  b->ncap = (m->npair > m->npair_std || (cfg && cfg->kind == MYO_TASK_REORIENT)) ? MYO_NCON_BIG : MYO_NCON_MAX;
+  // (a condim-4 / 6 contact takes two / three slots of the scratch: models that have such pairs get the big one too)
+  b->ncap = (m->npair > m->npair_std || m->any_rot || (cfg && cfg->kind == MYO_TASK_REORIENT)) ? MYO_NCON_BIG : MYO_NCON_MAX;
   b->geom_friction = m->geom_friction;
   b->nq = m->nq; b->nv = m->nv; b->nu = m->nu; b->na = m->na; b->nbody = m->nbody; b->nsite = m->nsite; b->ntendon = m->ntendon; b->ngeom = m->ngeom;
   if (cfg) b->cfg = *cfg; else memset(&b->cfg, 0, sizeof b->cfg);

@@ -56,6 +56,8 @@
     }                                                \
     (total) = _t;                                    \
   }
+// the same for counts up to 6 (contact slots: two contacts of up to three slots per lane)
+#define WAVE_EXSCAN6(cnt_expr, pre, total) WAVE_EXSCAN(cnt_expr, pre, total)
 #define UNI(x) (x)
 // LDS accumulation by several lanes of a phase into one slot (the emulation runs the lanes one after the other)
 template <typename T> static inline void lds_add(T* p, T v) { *p += v; }
@@ -155,6 +157,18 @@ template <> __device__ __forceinline__ int myo_wave_sum<int>(int v) {
     unsigned long long _below = (1ull << lane) - 1ull;                             \
     (pre)[lane] = __popcll(_m1 & _below) + __popcll(_m2 & _below);                 \
     (total) = __popcll(_m1) + __popcll(_m2);                                       \
+  }                                                                                \
+  __syncthreads();
+#define WAVE_EXSCAN6(cnt_expr, pre, total)                                         \
+  {                                                                                \
+    const int _c = (cnt_expr);                                                     \
+    const unsigned long long _below = (1ull << lane) - 1ull;                       \
+    int _p = 0, _t = 0;                                                            \
+    _Pragma("unroll") for (int _k = 1; _k <= 6; ++_k) {                            \
+      const unsigned long long _m = __ballot(_c >= _k);                            \
+      _p += __popcll(_m & _below); _t += __popcll(_m);                             \
+    }                                                                              \
+    (pre)[lane] = _p; (total) = _t;                                                \
   }                                                                                \
   __syncthreads();
 // LDS accumulation by several lanes of a phase into one slot: ds_add_f32 / ds_add_f64 without return value.  Lanes of one

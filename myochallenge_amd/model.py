@@ -191,8 +191,8 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
         raise ModelError("friction loss is not supported")
     if m.opt["cone"] != 0:
         raise ModelError("only pyramidal friction cones are supported")
-    if np.any(m.geom_condim[(m.geom_contype | m.geom_conaffinity) != 0] != 3):
-        raise ModelError("only condim=3 contacts are supported")
+    if not np.all(np.isin(m.geom_condim[(m.geom_contype | m.geom_conaffinity) != 0], (1, 3, 4, 6))):
+        raise ModelError("contact dimensions (condim) other than 1, 3, 4, 6 do not exist in MuJoCo")
     # what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored
     col = int(m.opt.get("collision", 0))
     if col == 1:

@@ -48,7 +48,7 @@ struct OrcModel {
 
 typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5];
-  int geom1, geom2;
+  int geom1, geom2, dim;      /* dim: condim of the contact (1, 3, 4 or 6) */
 } OrcContact;
 
 typedef struct { const char* name; double* p; int n; } OrcField;
@@ -1062,6 +1062,9 @@ static void mix_params(const OrcModel* m, const OrcData* d, int g1, int g2, OrcC
     f[k] = (pr1 == pr2) ? (a > b ? a : b) : (pr1 > pr2 ? a : b);
   }
   c->friction[0]=f[0]; c->friction[1]=f[0]; c->friction[2]=f[1]; c->friction[3]=f[2]; c->friction[4]=f[2];
+  /* mj_contactParam: condim of the geom with the higher priority, the larger of the two at equal priority */
+  int d1 = m->geom_condim[g1], d2 = m->geom_condim[g2];
+  c->dim = (pr1 == pr2) ? (d1 > d2 ? d1 : d2) : (pr1 > pr2 ? d1 : d2);
 }
 
 static void collision(const OrcModel* m, OrcData* d) {
@@ -1089,6 +1092,20 @@ static void collision(const OrcModel* m, OrcData* d) {
       c->includemargin = margin - gap; c->geom1 = g1; c->geom2 = g2;
       mix_params(m, d, g1, g2, c);
     }
+  }
+}
+
+/* rotational Jacobian of a body: column i = the angular part of dof i's motion axis for the body's ancestor dofs */
+static void jac_rot(const OrcModel* m, const OrcData* d, int body, double* jacr /* 3 x nv */) {
+  int nv = m->nv;
+  memset(jacr, 0, sizeof(double)*3*nv);
+  while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+  if (body <= 0) return;
+  int i = m->body_dofadr[body] + m->body_dofnum[body] - 1;
+  while (i >= 0) {
+    const double* cd = d->cdof + 6*i;
+    jacr[i] = cd[0]; jacr[nv+i] = cd[1]; jacr[2*nv+i] = cd[2];
+    i = m->dof_parentid[i];
   }
 }
 
@@ -1173,7 +1190,7 @@ static void make_constraint(const OrcModel* m, OrcData* d) {
       }
     }
   }
-  /* contacts: pyramidal, condim 3 -> 4 rows each */
+  /* contacts: condim 1 -> one row; condim 3 / 4 / 6 -> pyramidal, 4 / 6 / 10 rows */
   for (int ci = 0; ci < d->ncon; ++ci) {
     OrcContact* c = &d->con[ci];
     if (c->dist >= c->includemargin) continue;
@@ -1187,23 +1204,43 @@ static void make_constraint(const OrcModel* m, OrcData* d) {
         Jf[a][col] = c->frame[3*a]*(jac2[col]-jac1[col]) + c->frame[3*a+1]*(jac2[nv+col]-jac1[nv+col]) +
                      c->frame[3*a+2]*(jac2[2*nv+col]-jac1[2*nv+col]);
     double tran = m->body_invweight0[2*b1] + m->body_invweight0[2*b2];
-    int first = d->nefc;
-    for (int k = 0; k < 2; ++k) {
+    double rot = m->body_invweight0[2*b1+1] + m->body_invweight0[2*b2+1];
+    int first = d->nefc, dim = c->dim;
+    if (dim == 1) {                       /* frictionless: the normal row alone, no pyramid */
+      if (d->nefc < MAXEFC) {
+        double* J = d->efc_J + d->nefc*nv;
+        for (int col = 0; col < nv; ++col) J[col] = Jf[0][col];
+        add_row(d, nv, 2, ci, c->dist, c->includemargin, tran, c->solref, c->solimp);
+      }
+      continue;
+    }
+    /* pyramidal cone of dimension dim: two rows  J_normal +- friction[k] J_k  per direction k < dim - 1; directions 0, 1 are the two
+     * tangential translations, 2 the rotation about the normal (torsional friction), 3, 4 the rotations about the tangents (rolling) */
+    double Jr[3][64*4];
+    if (dim > 3) {
+      double* jr1 = d->w3; double* jr2 = d->w4;
+      jac_rot(m, d, b1, jr1); jac_rot(m, d, b2, jr2);
+      for (int a = 0; a < 3; ++a)
+        for (int col = 0; col < nv; ++col)
+          Jr[a][col] = c->frame[3*a]*(jr2[col]-jr1[col]) + c->frame[3*a+1]*(jr2[nv+col]-jr1[nv+col]) + c->frame[3*a+2]*(jr2[2*nv+col]-jr1[2*nv+col]);
+    }
+    for (int k = 0; k < dim - 1; ++k) {
       double mu = c->friction[k];
+      const double* Jk = k < 2 ? Jf[1+k] : Jr[k-2];
       for (int sg = 0; sg < 2; ++sg) {
         if (d->nefc >= MAXEFC) break;
         double* J = d->efc_J + d->nefc*nv;
         double s = sg ? -mu : mu;
-        for (int col = 0; col < nv; ++col) J[col] = Jf[0][col] + s*Jf[1+k][col];
-        add_row(d, nv, 2, ci, c->dist, c->includemargin, tran + mu*mu*tran, c->solref, c->solimp);
+        for (int col = 0; col < nv; ++col) J[col] = Jf[0][col] + s*Jk[col];
+        add_row(d, nv, 2, ci, c->dist, c->includemargin, tran + mu*mu*(k < 2 ? tran : rot), c->solref, c->solimp);
       }
     }
     /* pyramidal regularisation: every edge row gets Rpy = 2 mu^2 R(first row), mu = friction[0]/sqrt(impratio) */
-    if (d->nefc - first == 4) {
+    if (d->nefc - first == 2*(dim - 1)) {
       double mu = c->friction[0]/sqrt(m->impratio);
       double Rpy = 2*mu*mu*d->efc_R[first];
       if (Rpy < MINVAL) Rpy = MINVAL;
-      for (int r = first; r < first+4; ++r) d->efc_R[r] = Rpy;
+      for (int r = first; r < d->nefc; ++r) d->efc_R[r] = Rpy;
     }
   }
   for (int r = 0; r < d->nefc; ++r) d->efc_D[r] = 1/d->efc_R[r];

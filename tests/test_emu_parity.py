@@ -110,3 +110,19 @@ def test_p2_ball_physics_against_oracle(emu_lib, models):
 def test_blown_up_env_is_contained(emu_lib, models):
     pc.case_bad_state(emu_lib, models["hand"], native.MYO_F64)
     pc.case_bad_state(emu_lib, models["hand"], native.MYO_MIXED)
+
+
+@pytest.mark.parametrize("condim", [4, 6])
+def test_episode_trajectory_with_torsional_and_rolling_friction(emu_lib, models, condim):
+    """The Baoding hand with condim-4 / 6 balls (what a MyoHand file may carry, VERDICT r03 "missing" 2): whole P2 episodes — per-episode
+    ball mass / size / friction TRIPLE drawn at every reset, the torsional and rolling coefficients now acting — lane-serial build vs
+    oracle, fp64 1e-9 at every step."""
+    import copy
+    mj = copy.deepcopy(models["hand"])
+    for name in ("ball1", "ball2"):
+        g = mj.names["geom"].index(name)
+        mj.arrays["geom_condim"][g] = condim
+        mj.arrays["geom_priority"][g] = 1
+    r = pc.episode_drift(emu_lib, mj, native.MYO_F64, [(0.08, 0), (0.135, 1)], 120, env_name="CustomMyoBaodingBallsP2", resync=True)
+    assert all(x is None for x in r["episode_end_disagreement_at"])
+    assert r["err_qpos_rel"].max() <= 1e-9 and r["err_obs_abs"].max() <= 1e-7, (r["err_qpos_rel"].max(1), r["err_obs_abs"].max(1))

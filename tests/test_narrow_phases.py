@@ -353,3 +353,86 @@ def test_edge_edge_box_contact_on_emulation(emu_lib):
 def test_edge_edge_box_contact_on_gpu(hip_lib):
     case_edge_edge(hip_lib, native.MYO_F64, 1e-9)
     case_edge_edge(hip_lib, native.MYO_MIXED, 1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------- condim 1 / 4 / 6
+def condim_model(condims=(1, 3, 4, 6), friction=(0.8, 0.02, 0.004)):
+    """one free sphere per contact dimension over a plane (pyramidal rows 2 (condim - 1) per contact; condim 1: the
+    normal row alone).  The plane has condim 1 and priority 0, the spheres priority 1: the contact takes the sphere's condim."""
+    B = _Builder()
+    B.add_geom("plane", 0, 0, (0, 0, 0), collide=1, friction=(1.0, 0.005, 0.0001))
+    for k, cd in enumerate(condims):
+        b = B.add_body("ball%d" % cd, 0, (0.3 * k, 0.0, 0.05), mass=0.1, inertia=(1e-4, 1e-4, 1e-4))
+        B.add_joint("ball%d_free" % cd, b, 0, damping=0.0)
+        B.add_geom("ball%d" % cd, b, SPH, (0.05,), collide=1, friction=friction)
+    m = B.finish()
+    for g in range(len(m.names["geom"])):
+        m.arrays["geom_contype"][g], m.arrays["geom_conaffinity"][g] = (1, 0) if g == 0 else (2, 1)
+        m.arrays["geom_condim"][g] = 1 if g == 0 else condims[g - 1]
+        m.arrays["geom_priority"][g] = 0 if g == 0 else 1
+    m.arrays["geom_margin"][:] = 0.001
+    m.arrays["dof_damping"][:] = 0.0
+    set_const(m)
+    return m
+
+
+def case_condim(lib, dtype, tol):
+    """contacts of condim 1, 3, 4 and 6 side by side: row counts 1 / 4 / 6 / 10, reference accelerations, regularisers and the solved
+    accelerations against the oracle; then 150 steps of spheres that slide, spin and roll — torsional friction must stop the spin of the
+    condim-4 / 6 spheres and not of the condim-1 / 3 ones, rolling friction the roll of the condim-6 sphere only."""
+    mem = Mem(lib)
+    m = condim_model()
+    cm = compile_model(m)
+    om = OracleModel(cm.to_blob())
+    rng = np.random.RandomState(4)
+    q = m.qpos0.copy()
+    for k in range(4):
+        q[7 * k + 2] = 0.05 - 0.0004 * (k + 1)              # resting depths inside the margin / penetrating
+    for trial in range(4):
+        v = rng.normal(0, 0.5, om.nv) * (trial > 0)
+        d = OracleData(om)
+        d.qpos[:], d.qvel[:] = q, v
+        d.forward()
+        assert (d.ncon, d.nefc) == (4, 1 + 4 + 6 + 10)
+        get, b = forward_dump(lib, mem, cm, q, v, np.zeros(0), np.zeros(0), dtype)
+        cnt = get("counts", 4)
+        assert (int(cnt[0]), int(cnt[1])) == (d.ncon, d.nefc), cnt
+        assert rel_err(get("efc_aref", d.nefc), np.array(d.efc_aref)[:d.nefc]) < tol
+        assert rel_err(get("efc_D", d.nefc), np.array(d.efc_D)[:d.nefc]) < tol
+        assert rel_err(get("qacc", om.nv), d.qacc) < tol, (trial, rel_err(get("qacc", om.nv), d.qacc))
+        b.close()
+    # spin about the vertical and roll along x, then let the contacts act
+    v = np.zeros(om.nv)
+    for k in range(4):
+        v[6 * k + 5] = 20.0                                  # spin about z
+        v[6 * k + 0], v[6 * k + 4] = 0.2, 0.2 / 0.05         # rolling without slipping along x
+    d = OracleData(om)
+    d.qpos[:], d.qvel[:] = q, v
+    n = 2
+    b = native.Batch(native.Model(cm, lib), None, n, 0, 0, dtype)
+    b.set_state(mem.arr(np.tile(q, (n, 1))), mem.arr(np.tile(v, (n, 1))), mem.zeros((n, 0)), mem.zeros(n))
+    for _ in range(150):
+        d.step()
+    b.physics_step(None, 150)
+    qv = mem.zeros((n, om.nv)); qp = mem.zeros((n, om.nq))
+    b.get_state(qp, qv)
+    hv = mem.host(qv)[1]
+    ov = np.array(d.qvel)
+    assert np.abs(hv - ov).max() <= tol * max(1.0, np.abs(ov).max()) * 50, np.abs(hv - ov).max()
+    spin = [abs(ov[6 * k + 5]) for k in range(4)]
+    assert spin[0] > 19.9 and spin[1] > 19.9 and spin[2] < 12.0 and spin[3] < 12.0, spin          # torsional friction exists from condim 4 on
+    roll = [abs(ov[6 * k + 4]) for k in range(4)]
+    assert roll[3] < 0.75 * roll[2], roll                                                         # rolling friction from condim 6 on
+    assert b.health() == {"protocol_errors": 0, "contact_overflows": 0}
+    b.close()
+
+
+def test_condim_1_4_6_on_emulation(emu_lib):
+    case_condim(emu_lib, native.MYO_F64, 1e-9)
+    case_condim(emu_lib, native.MYO_MIXED, 1e-4)
+
+
+@pytest.mark.gpu
+def test_condim_1_4_6_on_gpu(hip_lib):
+    case_condim(hip_lib, native.MYO_F64, 1e-9)
+    case_condim(hip_lib, native.MYO_MIXED, 1e-4)

@@ -87,6 +87,7 @@ struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
   int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
   int npair_std;                // pairs [0, npair_std): collision_pass; [npair_std, npair): collision_pass_ext
+  int any_gen;                  // some collision pair has a condim other than 3: the general contact-slot code runs (else the lean condim-3 path)
   int any_rot;                  // some collision pair has condim 4 / 6: contact slots with rotational rows exist (J' f stages torques)
   int arrow_nf;                 // block-arrow Newton system (myo_arrow_chol.h): number of 4-row leaf blocks behind the 16-row separator; 0: dense
   unsigned long long arrow_pad; // rows of the (permuted) 36-row system that hold no dof: identity

@@ -85,11 +85,11 @@ DEV int lim_index(int id) { return id & 0x7fff; }
 template <typename T> DEV T lim_sign(int id) { return id < 0 ? (T)-1 : (T)1; }
 
 template <typename T>
-struct ContactRec {
+struct alignas(16) ContactRec {    // 112 B (fp32) / 176 B (fp64): whole 16-byte units, so that the fields keep their wide LDS accesses
   T frame[6], muA, muB, D, B, kip;   // frame: normal, first tangent (the second is their cross product, con_t2); muA / muB: friction of the slot's two row pairs
   T r1[3], r2[3];                 // contact point relative to the reference point of body1's / body2's tree
   unsigned long long m1, m2;      // ancestor-dof masks of the two bodies
-  int b1, b2, nsup;               // nsup: support size | slot kind << 8 (con_kind)
+  int pk;                         // body 1 | body 2 << 8 | support size << 16 | slot kind << 24 (con_b1, con_b2, con_nsup, con_kind)
   alignas(4) unsigned char sup[MYO_CS_MAX];
 };
 // A contact of condim d is stored as one, two or three SLOTS of four constraint rows each (mj_makeConstraint's pyramid rows
@@ -101,8 +101,11 @@ struct ContactRec {
 //   3  the normal row alone (muA = 0) / --, --, --                   (condim 1: frictionless)
 //   4  rotation about the normal / --                                (second slot of condim 4)
 // "--" rows are padding: J = 0 and aref = -1, so they are never active and carry no force.
-template <typename T> DEV int con_kind(const ContactRec<T>& c) { return c.nsup >> 8; }
-template <typename T> DEV int con_nsup(const ContactRec<T>& c) { return c.nsup & 255; }
+template <typename T> DEV int con_kind(const ContactRec<T>& c) { return c.pk >> 24; }
+template <typename T> DEV int con_nsup(const ContactRec<T>& c) { return (c.pk >> 16) & 255; }
+template <typename T> DEV int con_b1(const ContactRec<T>& c) { return c.pk & 255; }
+template <typename T> DEV int con_b2(const ContactRec<T>& c) { return (c.pk >> 8) & 255; }
+static_assert(MYO_NB_MAX <= 256 && MYO_CS_MAX <= 255, "ContactRec::pk fields are 8 bits");
 DEV bool con_pad(int kind, int e) { return (kind == 2 || kind == 4) ? e >= 2 : (kind == 3 ? e >= 1 : false); }
 DEV int con_rows(int kind) { return kind == 3 ? 1 : ((kind == 2 || kind == 4) ? 2 : 4); }
 
@@ -153,7 +156,7 @@ struct Scratch {
   int ncon, nefc, nl, ntl, bad, solver_iter;   // ncon: contact SLOTS (four rows each, ContactRec)
   unsigned char hperm[MYO_NV_MAX];   // dof -> row of the Newton system (DevModel::hperm; identity unless the block-arrow solver is on)
   // (from con[] to qM, i.e. up to rk: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live)
-  alignas(8) ContactRec<T> con[NC];
+  alignas(16) ContactRec<T> con[NC];
   short lim_id[MYO_NLIM_MAX];                                          // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1)
   T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
   alignas(8) T efc_jar[MYO_NLIM_MAX + 4 * NC], efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC];
@@ -1988,8 +1991,78 @@ DEV void pair_keep_included(const DevModel<T>& M, int g1, int g2, HP margin, Con
 #endif
 // contact records from the narrow-phase results of one pass (ballot / prefix compaction over the 64 lanes, constraint parameters
 // from the host-resolved pair records); shared by the two collision passes.  pbase = pair index of lane 0.
+// condim-3-only models (M.any_gen == 0, wave-uniform): one slot of kind 0 per contact — the lean path the bench workload runs
 template <typename T, int NC>
-DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int pbase, LANE_ARG(ContactTmp, ct), int& ncon) {
+DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int pbase, LANE_ARG(ContactTmp, ct), int& ncon) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  int total = 0;
+  const int base = pbase;
+  {
+    WAVE_EXSCAN(LV(ct).n, S_NPRE(s), total);
+    PHASE {
+      const int p = base + lane;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int ci = ncon + S_NPRE(s)[lane] + k;
+        if (k >= LV(ct).n || ci >= NC) break;
+        const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
+        ContactRec<T>& c = s.con[ci];
+        T cpos[3];                         // contact point relative to O: only r1 / r2 below are made of it
+        for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); c.frame[e] = (T)LV(ct).nrm[3 * k + e]; }
+        make_frame(c.frame);
+        // everything that depends on the two geoms only comes from the host-resolved pair record (pc_*):
+        // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
+        // friction, margin and gap, inverse-weight sum; the balls' per-env friction is patched in here
+        const int b1 = M.pc_i[8 * p], b2 = M.pc_i[8 * p + 1], root1 = M.pc_i[8 * p + 2], root2 = M.pc_i[8 * p + 3];
+        const int ns = M.pc_i[8 * p + 4], fsel = M.pc_i[8 * p + 7];
+        T F[16];
+        for (int e = 0; e < 16; ++e) F[e] = M.pc_f[16 * p + e];
+        // condim 3: both tangential directions use friction[0]; torsional / rolling coefficients are not used
+        T fa = F[9], fb = F[12];
+        if (K.objg_gidn > 0) {
+          if (g1 >= K.objg_gid0 && g1 < K.objg_gidn) fa = s.objg_fric[(g1 - K.objg_gid0) * Scratch<T, NC>::OBJG_NF];
+          if (g2 >= K.objg_gid0 && g2 < K.objg_gidn) fb = s.objg_fric[(g2 - K.objg_gid0) * Scratch<T, NC>::OBJG_NF];
+        } else {
+          fa = g1 == K.obj1_gid ? s.ball_fric[0] : (g1 == K.obj2_gid ? s.ball_fric[3] : fa);
+          fb = g2 == K.obj1_gid ? s.ball_fric[0] : (g2 == K.obj2_gid ? s.ball_fric[3] : fb);
+        }
+        const T fr0 = (fsel == 0) ? tmax(fa, fb) : (fsel == 1 ? fa : fb);
+        c.muA = fr0; c.muB = fr0;
+        const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
+        T Kc, Bc, Ic;
+        sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
+        const T tran = F[15];
+        const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr0 * fr0 * tran) / Ic);
+        const T mu = fr0 / sqrt(M.impratio);
+        const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
+        c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * dmi;
+        c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
+        {
+          const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
+          for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
+        }
+        {
+          int* dst = reinterpret_cast<int*>(c.sup);
+          for (int e = 0; e < MYO_CS_MAX / 4; ++e) dst[e] = M.pc_sup[4 * p + e];
+        }
+        c.pk = b1 | (b2 << 8) | (ns << 16);
+      }
+    }
+    SYNC();
+    ncon += total;
+    if (ncon > NC) {
+      // more contacts than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
+      // with a warning — counted, so that the host can see it happened (myo_batch_health)
+      PHASE { if (lane == 0 && K.health) myo_count(K.health + 1); }
+      ncon = NC;
+    }
+  }
+}
+
+// any condim (1, 3, 4, 6)
+template <typename T, int NC>
+DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int pbase, LANE_ARG(ContactTmp, ct), int& ncon) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   int total = 0;
@@ -2049,7 +2122,6 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
             ContactRec<T>& c = s.con[ci];
             const int kind = dim == 1 ? 3 : (j == 0 ? 0 : (dim == 4 ? 4 : j));
             for (int e = 0; e < 6; ++e) c.frame[e] = frame[e];
-            c.b1 = b1; c.b2 = b2;
             c.muA = kind == 0 ? fr0 : (kind == 1 || kind == 4 ? fr[1] : (kind == 2 ? fr[2] : (T)0));
             c.muB = kind == 0 ? fr0 : (kind == 1 ? fr[2] : (T)0);
             c.D = D; c.B = Bc; c.kip = Kc * Ic * dmi;
@@ -2062,7 +2134,7 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
               int* dst = reinterpret_cast<int*>(c.sup);
               for (int e = 0; e < MYO_CS_MAX / 4; ++e) dst[e] = M.pc_sup[4 * p + e];
             }
-            c.nsup = ns | (kind << 8);
+            c.pk = b1 | (b2 << 8) | (ns << 16) | (kind << 24);
           }
         }
       }
@@ -2078,11 +2150,19 @@ DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, 
   }
 }
 
+template <bool GEN, typename T, int NC>
+DEV void contacts_emit(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int pbase, LANE_ARG(ContactTmp, ct), int& ncon) {
+  if constexpr (GEN) contacts_emit_gen(M_in, K_in, s_in, pbase, ct, ncon);
+  else contacts_emit_c3(M_in, K_in, s_in, pbase, ct, ncon);
+}
+
 // contacts: one pass over 64 candidate pairs (lanes = pairs), called from kernel level once per 64 pairs — a leaf
 // function without the limit rows and without a loop, so that the HP narrow phase has a register allocation of its
 // own.  s.ncon / s.nefc carry the running counts between passes.  The model's pairs are ordered: first the pairs of MuJoCo's
 // sphere / capsule / plane primitives and sphere-box (this pass), then the "extended" pairs (collision_pass_ext).
-template <typename T, int NC>
+// GEN: the model has pairs whose condim is not 3 (M.any_gen): the general slot emission; a separate instantiation, chosen at
+// kernel level, so that the condim-3 pass is exactly the code it was before condim 1 / 4 / 6 existed
+template <bool GEN, typename T, int NC>
 DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int base) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
@@ -2101,14 +2181,14 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
       }
     }
   }
-  contacts_emit(M, K, s, base, ct, ncon);
+  contacts_emit<GEN>(M, K, s, base, ct, ncon);
   PHASE {
     if (lane == 0) { s.ncon = ncon; s.nefc = nlim + 4 * ncon; }
   }
   SYNC();
 }
 // the same for the extended pairs (capsule-box, box-box vertex candidates, cylinders, ellipsoids): base counts from the first of them
-template <typename T, int NC>
+template <bool GEN, typename T, int NC>
 DEVFN void collision_pass_ext(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int base) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
@@ -2127,7 +2207,7 @@ DEVFN void collision_pass_ext(const DevModel<T>& M_in, const TaskDev& K_in, Scra
       }
     }
   }
-  contacts_emit(M, K, s, M.npair_std + base, ct, ncon);
+  contacts_emit<GEN>(M, K, s, M.npair_std + base, ct, ncon);
   PHASE {
     if (lane == 0) { s.ncon = ncon; s.nefc = nlim + 4 * ncon; }
   }
@@ -2173,9 +2253,9 @@ template <typename T, int NC> DEV void con_col(const Scratch<T, NC>& s, int d, c
   col[0] = cd[3] + t[0]; col[1] = cd[4] + t[1]; col[2] = cd[5] + t[2];
 }
 
-// out[r] = (J v)[r] for every constraint row; bv = body vectors of v (already computed)
+// J_times for models with condim 1 / 4 / 6 pairs (M.any_gen): a leaf of its own, the condim-3 version below stays what it was
 template <typename T, int NC>
-DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
+DEVFN void J_times_gen(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* v = LPTR(const T, v_r); const T* bv = LPTR(const T, bv_r); T* out = LPTR(T, out_r);
   WAVE_FN
@@ -2195,13 +2275,50 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
         T v1[3], v2[3];
-        point_vel(bv, c.b1, c.r1, v1);
-        point_vel(bv, c.b2, c.r2, v2);
+        point_vel(bv, con_b1(c), c.r1, v1);
+        point_vel(bv, con_b2(c), c.r2, v2);
         const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        const int kind = con_kind(c);
-        T ra[3] = {0, 0, 0};
-        if (kind != 0) { const T* w1 = bv + 6 * c.b1; const T* w2 = bv + 6 * c.b2; ra[0] = w2[0] - w1[0]; ra[1] = w2[1] - w1[1]; ra[2] = w2[2] - w1[2]; }
-        val = con_row_val(c, kind, e, rel, ra);
+        const T* w1 = bv + 6 * con_b1(c); const T* w2 = bv + 6 * con_b2(c);
+        const T ra[3] = {w2[0] - w1[0], w2[1] - w1[1], w2[2] - w1[2]};
+        val = con_row_val(c, con_kind(c), e, rel, ra);
+      }
+      out[r] = val;
+    }
+  }
+  SYNC();
+}
+
+// out[r] = (J v)[r] for every constraint row; bv = body vectors of v (already computed)
+template <typename T, int NC>
+DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  const T* v = LPTR(const T, v_r); const T* bv = LPTR(const T, bv_r); T* out = LPTR(T, out_r);
+  WAVE_FN
+  const int nl = s.nl, nlim = s.nl + s.ntl, nefc = s.nefc;
+  if (M.any_gen) { J_times_gen(M, s, v_r, bv_r, out_r); return; }     // (scalar branch: the flag lives in constant memory)
+  PHASE {
+    for (int r = lane; r < nefc; r += 64) {
+      T val;
+      if (r < nl) val = lim_sign<T>(s.lim_id[r]) * v[lim_index(s.lim_id[r])];
+      else if (r < nlim) {
+        const int t = lim_index(s.lim_id[r]);
+        unsigned long long m = M.tendon_dofmask[t];
+        T acc = 0;
+        int slot = 0;
+        while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * v[d]; slot++; }
+        val = lim_sign<T>(s.lim_id[r]) * acc;
+      } else {
+        const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
+        const ContactRec<T>& c = s.con[ci];
+        T v1[3], v2[3];
+        point_vel(bv, con_b1(c), c.r1, v1);
+        point_vel(bv, con_b2(c), c.r2, v2);
+        const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+                                          // condim-3 models: translation along tangent 1 | 2
+        T t2[3];
+        con_t2(c.frame, t2);
+        const T vn = dot3(c.frame, rel), vt = (e >> 1) ? dot3(t2, rel) : dot3(c.frame + 3, rel);
+        val = vn + ((e & 1) ? -c.muA : c.muA) * vt;
       }
       out[r] = val;
     }
@@ -2233,7 +2350,7 @@ DEVFN void body_vectors2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LC
   }
   SYNC();
 }
-template <typename T, int NC>
+template <bool GEN, typename T, int NC>
 DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) va_r, LCREF(T) bva_r, LREF(T) outa_r,
                     LCREF(T) vb_r, LCREF(T) bvb_r, LREF(T) outb_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
@@ -2259,20 +2376,28 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
-        const int kind = con_kind(c);
-        T v1[3], v2[3], raa[3] = {0, 0, 0}, rab[3] = {0, 0, 0};
-        point_vel(bva, c.b1, c.r1, v1);
-        point_vel(bva, c.b2, c.r2, v2);
+        T v1[3], v2[3];
+        point_vel(bva, con_b1(c), c.r1, v1);
+        point_vel(bva, con_b2(c), c.r2, v2);
         const T rela[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        point_vel(bvb, c.b1, c.r1, v1);
-        point_vel(bvb, c.b2, c.r2, v2);
+        point_vel(bvb, con_b1(c), c.r1, v1);
+        point_vel(bvb, con_b2(c), c.r2, v2);
         const T relb[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
-        if (kind != 0) {
-          const T* a1 = bva + 6 * c.b1; const T* a2 = bva + 6 * c.b2; const T* b1 = bvb + 6 * c.b1; const T* b2 = bvb + 6 * c.b2;
-          for (int k = 0; k < 3; ++k) { raa[k] = a2[k] - a1[k]; rab[k] = b2[k] - b1[k]; }
+        if constexpr (!GEN) {
+          T t2[3];
+          con_t2(c.frame, t2);
+          const T* fn = c.frame;
+          const T ft[3] = {(e >> 1) ? t2[0] : c.frame[3], (e >> 1) ? t2[1] : c.frame[4], (e >> 1) ? t2[2] : c.frame[5]};
+          const T mu = (e & 1) ? -c.muA : c.muA;
+          vala = dot3(fn, rela) + mu * dot3(ft, rela);
+          valb = dot3(fn, relb) + mu * dot3(ft, relb);
+        } else {
+          const int kind = con_kind(c);
+          const T* a1 = bva + 6 * con_b1(c); const T* a2 = bva + 6 * con_b2(c); const T* b1 = bvb + 6 * con_b1(c); const T* b2 = bvb + 6 * con_b2(c);
+          const T raa[3] = {a2[0] - a1[0], a2[1] - a1[1], a2[2] - a1[2]}, rab[3] = {b2[0] - b1[0], b2[1] - b1[1], b2[2] - b1[2]};
+          vala = con_row_val(c, kind, e, rela, raa);
+          valb = con_row_val(c, kind, e, relb, rab);
         }
-        vala = con_row_val(c, kind, e, rela, raa);
-        valb = con_row_val(c, kind, e, relb, rab);
       }
       outa[r] = vala; outb[r] = valb;
     }
@@ -2294,12 +2419,16 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
       const T fn = fe[0] + fe[1] + fe[2] + fe[3], fa = c.muA * (fe[0] - fe[1]), fb = c.muB * (fe[2] - fe[3]);      // (padding rows carry no force)
       T t2[3];
       con_t2(c.frame, t2);
-      const int kind = con_kind(c);
       // world force at the contact point; slots whose pairs are rotations (kinds 1, 2, 4) add a world TORQUE instead of the tangential force
-      for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + (kind == 0 ? c.frame[3 + k] * fa + t2[k] * fb : (T)0);
-      if (nrot > 0)
-        for (int k = 0; k < 3; ++k)
-          S_CONTQ(s)[3 * ci + k] = kind == 1 ? c.frame[k] * fa + c.frame[3 + k] * fb : (kind == 2 ? t2[k] * fa : (kind == 4 ? c.frame[k] * fa : (T)0));
+      if (!M.any_gen) {
+        for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + c.frame[3 + k] * fa + t2[k] * fb;
+      } else {
+        const int kind = con_kind(c);
+        for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + (kind == 0 ? c.frame[3 + k] * fa + t2[k] * fb : (T)0);
+        if (nrot > 0)
+          for (int k = 0; k < 3; ++k)
+            S_CONTQ(s)[3 * ci + k] = kind == 1 ? c.frame[k] * fa + c.frame[3 + k] * fb : (kind == 2 ? t2[k] * fa : (kind == 4 ? c.frame[k] * fa : (T)0));
+      }
     }
   }
   SYNC();
@@ -2330,9 +2459,16 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
         T t[3];
         cross3(t, cd, off);
         const T col[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
-        T v = dot3(col, S_CONF(s) + 3 * ci);
-        if (nrot > 0) v += dot3(cd, S_CONTQ(s) + 3 * ci);      // (wave-uniform branch: models without condim 4 / 6 contacts never take it)
+        const T v = dot3(col, S_CONF(s) + 3 * ci);
         acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
+      }
+      if (nrot > 0) {                                          // (scalar branch, outside the hot loop) torques of the rotational slots
+        for (int ci = 0; ci < ncon; ++ci) {
+          const ContactRec<T>& c = s.con[ci];
+          const int on1 = (int)((c.m1 >> d) & 1ull), on2 = (int)((c.m2 >> d) & 1ull);
+          const T v = dot3(cd, S_CONTQ(s) + 3 * ci);
+          acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
+        }
       }
       out[d] = acc;
     }
@@ -2450,12 +2586,13 @@ DEV void efc_reference(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   WAVE_FN
   if (s.nefc > 0) {
     J_times(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
+    const int gen = M.any_gen;
     PHASE {
       const int nlim_ = s.nl + s.ntl;
       for (int r = lane; r < s.nefc; r += 64) {
         const T Bc = r < nlim_ ? S_LIM_B(s)[r] : s.con[(r - nlim_) >> 2].B;
         const T kp = r < nlim_ ? S_LIM_KIP(s)[r] : s.con[(r - nlim_) >> 2].kip;
-        const bool pad = r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3);
+        const bool pad = gen && r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3);
         S_AREF(s)[r] = pad ? (T)-1 : -Bc * s.efc_jv[r] - kp;       // a padding row: J = 0, so J a - aref = 1 > 0, never active
       }
     }
@@ -2643,7 +2780,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   // contact instead of once per pair.  bvec is free here (body vectors are rebuilt after the solve).
   T* stage = s.bvec;                       // 2 x MYO_CS_MAX x 3
   static_assert(2 * MYO_CS_MAX * 3 <= MYO_NB_MAX * 6, "staging fits in bvec");
-  const int ncon = s.ncon;
+  const int ncon = s.ncon, gen = M.any_gen;
   for (int ci = -1; ci < ncon; ++ci) {
     PHASE {
       // ---- stage A for contact ci+1
@@ -2656,11 +2793,13 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         con_col(s, d, on2 ? c.r2 : c.r1, col);
         T t2[3];
         con_t2(c.frame, t2);
-        const int kind = con_kind(c);
-        const T* ang = s.cdof + 6 * d;                         // angular part of the dof's motion axis (rotational rows)
-        T j[3] = {dot3(c.frame, col),
-                  kind == 0 ? dot3(c.frame + 3, col) : ((kind == 1 || kind == 4) ? dot3(c.frame, ang) : (kind == 2 ? dot3(t2, ang) : (T)0)),
-                  kind == 0 ? dot3(t2, col) : (kind == 1 ? dot3(c.frame + 3, ang) : (T)0)};
+        T j[3] = {dot3(c.frame, col), dot3(c.frame + 3, col), dot3(t2, col)};
+        if (gen) {                                             // (scalar branch) rotational / frictionless slots
+          const int kind = con_kind(c);
+          const T* ang = s.cdof + 6 * d;                       // angular part of the dof's motion axis
+          j[1] = kind == 0 ? j[1] : ((kind == 1 || kind == 4) ? dot3(c.frame, ang) : (kind == 2 ? dot3(t2, ang) : (T)0));
+          j[2] = kind == 0 ? j[2] : (kind == 1 ? dot3(c.frame + 3, ang) : (T)0);
+        }
         if (!on2) { j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2]; }
         if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion
         T* dst = stage + (cn & 1) * (MYO_CS_MAX * 3) + 3 * lane;
@@ -2715,8 +2854,8 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   // (the second set of body vectors borrows Ma..Mv, which the solver has not started to use)
   body_vectors2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.qacc_smooth), LOFF(s, s.bvec), LOFF(s, S_CVEL(s)));
   // (J qacc_warm lands in efc_force, which the solver writes only after the choice: efc_jar still holds aref)
-  J_times2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)),
-           LOFF(s, s.efc_jv));
+  if (M.any_gen) J_times2<true>(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
+  else J_times2<false>(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
   mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc_warm));
   const int nlim = s.nl + s.ntl;
   // cost of the violated rows, branch-free: 0.5 D min(x, 0)^2  (no conditional around the D load)
@@ -2870,8 +3009,13 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
   PROF(s, 4)
   constraint_limits(M, K, s);
   PROF(s, 18)
-  for (int base = 0; base < M.npair_std; base += 64) collision_pass(M, K, s, base);
-  for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext(M, K, s, base - M.npair_std);
+  if (M.any_gen) {
+    for (int base = 0; base < M.npair_std; base += 64) collision_pass<true>(M, K, s, base);
+    for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<true>(M, K, s, base - M.npair_std);
+  } else {
+    for (int base = 0; base < M.npair_std; base += 64) collision_pass<false>(M, K, s, base);
+    for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<false>(M, K, s, base - M.npair_std);
+  }
   PROF(s, 5)
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   PROF(s, 19)

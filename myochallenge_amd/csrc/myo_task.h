@@ -652,8 +652,13 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   tendon_length_sums(M, s);
   crb(M, s);
   constraint_limits(M, K, s);
-  for (int base = 0; base < M.npair_std; base += 64) collision_pass(M, K, s, base);
-  for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext(M, K, s, base - M.npair_std);
+  if (M.any_gen) {
+    for (int base = 0; base < M.npair_std; base += 64) collision_pass<true>(M, K, s, base);
+    for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<true>(M, K, s, base - M.npair_std);
+  } else {
+    for (int base = 0; base < M.npair_std; base += 64) collision_pass<false>(M, K, s, base);
+    for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<false>(M, K, s, base - M.npair_std);
+  }
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
   efc_reference(M, s);

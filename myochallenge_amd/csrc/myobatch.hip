@@ -62,7 +62,7 @@ extern "C" const char* myo_version(void) {      // "... build <hash of the nativ
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq, arrow_nf, any_rot;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq, arrow_nf, any_rot, any_gen;
   unsigned long long arrow_pad;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
@@ -574,7 +574,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     m->pc_i.assign(8 * (size_t)np, 0); m->pc_sup.assign(4 * (size_t)np, 0);
     m->pc_f.assign(16 * (size_t)np, 0.0); m->pc_mask.assign(2 * (size_t)np, 0ull);
   }
-  m->any_rot = 0;
+  m->any_rot = 0; m->any_gen = 0;
   for (int p = 0; p < m->npair; ++p) {
     const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
     const int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
@@ -612,6 +612,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     I[6] = (pr1 == pr2) ? std::max(d1, d2) : (pr1 > pr2 ? d1 : d2);
     LIM(I[6] != 1 && I[6] != 3 && I[6] != 4 && I[6] != 6, "contact dimension (condim) other than 1, 3, 4, 6")
     if (I[6] > 3) m->any_rot = 1;
+    if (I[6] != 3) m->any_gen = 1;
   }
   m->body_imat.resize(9 * nb);
   for (int b = 0; b < nb; ++b) quat2mat_h(&body_iquat[4 * b], &m->body_imat[9 * b]);
@@ -763,7 +764,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
   D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte; D.npair_std = m->npair_std;
-  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad; D.any_rot = m->any_rot;
+  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad; D.any_rot = m->any_rot; D.any_gen = m->any_gen;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];

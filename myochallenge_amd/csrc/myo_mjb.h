@@ -139,7 +139,8 @@ static const char* const kF64Fields[] = {
     "geom_solmix", "geom_solref", "geom_solimp", "geom_size", "geom_rbound", "geom_pos", "geom_quat", "geom_friction", "geom_margin",
     "geom_gap", "site_pos", "site_quat", "tendon_solref_lim", "tendon_solimp_lim", "tendon_range", "tendon_margin", "tendon_stiffness", "tendon_damping",
     "tendon_lengthspring", "tendon_invweight0", "wrap_prm", "actuator_dynprm", "actuator_gainprm", "actuator_biasprm", "actuator_ctrlrange",
-    "actuator_forcerange", "actuator_gear", "actuator_acc0", "actuator_lengthrange"};
+    "actuator_forcerange", "actuator_gear", "actuator_acc0", "actuator_lengthrange",
+    "dof_frictionloss", "dof_solref", "dof_solimp", "tendon_frictionloss", "tendon_solref_fri", "tendon_solimp_fri"};
 
 static bool pair_supported(int t1, int t2) {       // narrow phases of csrc/myo_physics.h:collide_pair (types ordered t1 <= t2)
   return (t1 == MYO_GEOM_PLANE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_ELLIPSOID || t2 == MYO_GEOM_CYLINDER)) ||
@@ -193,8 +194,6 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   if (f.enableflags & 1) { err = "opt.enableflags: contact override is not supported"; *unsupported = 1; return false; }
   for (int j = 0; j < njnt; ++j) if (I("jnt_type")[j] == MYO_JNT_BALL) { err = "ball joints are not supported"; *unsupported = 1; return false; }
   if (f.sizes["neq"] > 0) { err = "equality constraints are not supported"; *unsupported = 1; return false; }
-  for (double v : D("dof_frictionloss")) if (v > 0) { err = "friction loss is not supported"; *unsupported = 1; return false; }
-  for (double v : D("tendon_frictionloss")) if (v > 0) { err = "friction loss is not supported"; *unsupported = 1; return false; }
   if (f.cone != 0) { err = "only pyramidal friction cones are supported"; *unsupported = 1; return false; }
   for (int g = 0; g < ngeom; ++g)
     if ((I("geom_contype")[g] | I("geom_conaffinity")[g]) != 0) {

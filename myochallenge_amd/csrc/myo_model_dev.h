@@ -54,7 +54,8 @@
   X(tendon_solimp_lim) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping)    \
   X(tendon_lengthspring) X(tendon_invweight0) X(wrap_prm) X(actuator_dynprm)                     \
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
-  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(wr_p) X(wr_m) X(pc_f) X(te_div)
+  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(wr_p) X(wr_m) X(pc_f) X(te_div)               \
+  X(dof_frictionloss) X(dof_solref) X(dof_solimp) X(tendon_frictionloss) X(tendon_solref_fri) X(tendon_solimp_fri)
 
 // geometry tables of the HP stages (kinematic chain, contact / limit distances, observation): fp64 copies in
 // every build, named h_<array> (the fp64 stepper's h_ tables are its ordinary tables)
@@ -87,6 +88,7 @@ struct DevModel {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
   int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte;
   int npair_std;                // pairs [0, npair_std): collision_pass; [npair_std, npair): collision_pass_ext
+  int any_floss;                // some dof / tendon has friction loss: friction rows exist (the solver's Huber branches run)
   int any_gen;                  // some collision pair has a condim other than 3: the general contact-slot code runs (else the lean condim-3 path)
   int any_rot;                  // some collision pair has condim 4 / 6: contact slots with rotational rows exist (J' f stages torques)
   int arrow_nf;                 // block-arrow Newton system (myo_arrow_chol.h): number of 4-row leaf blocks behind the 16-row separator; 0: dense

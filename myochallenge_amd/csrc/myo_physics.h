@@ -81,7 +81,16 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
 };
 
 #define MYO_LIM_UPPER ((short)0x8000)
-DEV int lim_index(int id) { return id & 0x7fff; }
+#define MYO_LIM_FRIC ((short)0x4000)            /* a friction-loss row (J = +dof / +tendon moment arms, force clamped to +- frictionloss) */
+DEV int lim_index(int id) { return id & 0x3fff; }
+DEV bool lim_is_fric(int id) { return (id & 0x4000) != 0; }
+// cost and force of a friction-loss row at jar = x (mj_constraintUpdate): quadratic inside |x| < R f, linear outside
+template <typename T> DEV T fric_cost(T D, T f, T x, T* force, int* quad) {
+  const T Rf = f / D;
+  if (x <= -Rf) { *force = f; *quad = 0; return f * (-(T)0.5 * Rf - x); }
+  if (x >= Rf) { *force = -f; *quad = 0; return f * (-(T)0.5 * Rf + x); }
+  *force = -D * x; *quad = 1; return (T)0.5 * D * x * x;
+}
 template <typename T> DEV T lim_sign(int id) { return id < 0 ? (T)-1 : (T)1; }
 
 template <typename T>
@@ -1874,6 +1883,40 @@ DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos
   *Ip = imp;
 }
 
+// friction-loss rows (mj_instantiateFriction), models that have them only (M.any_floss, chosen at kernel level): tendon = 0, BEFORE
+// constraint_limits: one row per dof with frictionloss > 0 at the head of the joint-row range (J = +dof, like a lower joint limit);
+// tendon = 1, AFTER it: one row per tendon with frictionloss > 0 behind the tendon-limit rows (J = +moment arms).  pos = margin = 0, so
+// aref = -B v; R = (1 - d0) / d0 * invweight; the solver treats the rows by their MYO_LIM_FRIC flag (fric_update, fric_linesearch).
+template <typename T, int NC>
+DEVFN void friction_rows(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int tendon) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  WAVE_FN
+  LANE_VAR(int, cnt);
+  int total = 0;
+  PHASE {
+    const int i = lane;
+    LV(cnt) = tendon ? (i < M.ntendon && M.tendon_frictionloss[i] > 0) : (i < M.nv && M.dof_frictionloss[i] > 0);
+  }
+  WAVE_EXSCAN(LV(cnt), S_NPRE(s), total);
+  const int base = tendon ? s.nl + s.ntl : 0;
+  PHASE {
+    const int i = lane, r = base + S_NPRE(s)[lane];
+    if (LV(cnt) && r < MYO_NLIM_MAX) {
+      T Kc, Bc, Ic;
+      if (tendon) sol_param(M, M.tendon_solref_fri + 2 * i, M.tendon_solimp_fri + 5 * i, (T)0, &Kc, &Bc, &Ic);
+      else sol_param(M, M.dof_solref + 2 * i, M.dof_solimp + 5 * i, (T)0, &Kc, &Bc, &Ic);
+      const T R = tmax(MYO_MINVAL, (1 - Ic) * (tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]) / Ic);
+      s.lim_id[r] = i | MYO_LIM_FRIC;
+      s.efc_D[r] = 1 / R; S_LIM_B(s)[r] = Bc; S_LIM_KIP(s)[r] = 0;
+    }
+    if (lane == 0) {
+      const int n = base + total < MYO_NLIM_MAX ? base + total : MYO_NLIM_MAX;
+      if (tendon) { s.ntl = n - s.nl; s.nefc = n; } else s.nl = n;
+    }
+  }
+  SYNC();
+}
+
 template <typename T, int NC>
 DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
@@ -1883,6 +1926,7 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
   LANE_VAR(T, dlo);
   LANE_VAR(T, dhi);
   int total = 0;
+  const int r0 = M.any_floss ? s.nl : 0;       // rows [0, r0): the dofs' friction-loss rows (friction_rows, models that have them)
   PHASE {
     const int j = lane;
     int c = 0;
@@ -1900,7 +1944,7 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
   PHASE {
     const int j = lane;
     if (LV(cnt) > 0) {
-      int r = S_NPRE(s)[lane];
+      int r = r0 + S_NPRE(s)[lane];
       const HP q = s.qpos[M.jnt_qposadr[j]], mh = M.h_jnt_margin[j];
       const int on_lo = (q - M.h_jnt_range[2 * j]) < mh, on_hi = (M.h_jnt_range[2 * j + 1] - q) < mh;
       for (int side = 0; side < 2; ++side) {
@@ -1915,7 +1959,7 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         }
       }
     }
-    if (lane == 0) s.nl = total < MYO_NLIM_MAX ? total : MYO_NLIM_MAX;
+    if (lane == 0) s.nl = r0 + total < MYO_NLIM_MAX ? r0 + total : MYO_NLIM_MAX;
   }
   SYNC();
   const int nl = s.nl;
@@ -2707,6 +2751,79 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
 // The COST is accumulated in HP in every build: Newton's termination test is a cost DIFFERENCE of ~1e-8 on a
 // cost of ~1e2, and near the minimum the cost is flat to second order, so an fp32 cost stalls while the
 // iterate is still sqrt(eps) away.  The iterates, gradient and search direction stay T.
+// what a friction-loss row's cost exceeds the ordinary rows' 0.5 D min(x, 0)^2 by (0 for the other rows): the sums below stay as
+// they are and models with friction loss add this on top
+template <typename T, int NC> DEV T fric_excess(const DevModel<T>& M, const Scratch<T, NC>& s, int r, T x) {
+  if (!lim_is_fric(s.lim_id[r])) return (T)0;
+  const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
+  T force; int quad;
+  const T c = fric_cost(s.efc_D[r], fl, x, &force, &quad);
+  const T xm = tmin(x, (T)0);
+  return c - (T)0.5 * s.efc_D[r] * xm * xm;
+}
+
+// friction-loss rows after a change of jar: clamped force, "active" = the quadratic zone (what the Hessian sees); returns the
+// rows' excess cost (fric_excess) over the ordinary formula
+template <typename T, int NC>
+DEVFN HP fric_update(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  WAVE_FN
+  const int nlim = s.nl + s.ntl;
+  PHASE {
+    for (int r = lane; r < nlim; r += 64) {
+      if (!lim_is_fric(s.lim_id[r])) continue;
+      const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
+      T force; int quad;
+      (void)fric_cost(s.efc_D[r], fl, s.efc_jar[r], &force, &quad);
+      s.efc_force[r] = force; s.efc_active[r] = (unsigned char)quad;
+    }
+  }
+  SYNC();
+  WAVE_SUM_N(HP, fc, nlim, r, (HP)fric_excess(M, s, r, s.efc_jar[r]));
+  return fc;
+}
+// sum of the friction-loss rows' excess cost at jar = x - aref (the warm-start comparison)
+template <typename T, int NC>
+DEVFN HP fric_excess_sum(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) x_r) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  WAVE_FN
+  const T* x = LPTR(const T, x_r);
+  const int nlim = s.nl + s.ntl;
+  WAVE_SUM_N(HP, fc, nlim, r, (HP)fric_excess(M, s, r, x[r] - S_AREF(s)[r]));
+  return fc;
+}
+// the exact line search for models with friction-loss rows: the same safeguarded Newton iteration on p'(alpha) as newton_solve's, the
+// rows read from LDS every trip (the register-resident version is the condim-3 / no-friction-loss fast path)
+template <typename T, int NC>
+DEVFN T fric_linesearch(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, T q1, T q2, T gtol) {
+  MYO_BIND_M(T) MYO_BIND_S(T)
+  WAVE_FN
+  const int nefc = s.nefc, nlim = s.nl + s.ntl;
+  T alpha = 0, lo = 0, hi = -1;
+  for (int li = 0; li < 50; ++li) {
+    T a1 = 0, a2 = 0;
+    PHASE { (void)lane; }
+    WAVE_SUM3_N(T, e1, e2, e3unused, nefc, r, {
+      const T v = s.efc_jv[r], x = s.efc_jar[r] + alpha * v, D = row_D(s, r, nlim);
+      if (r < nlim && lim_is_fric(s.lim_id[r])) {
+        const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
+        T force; int quad;
+        (void)fric_cost(D, fl, x, &force, &quad);
+        _e1 = -force * v; _e2 = quad ? D * v * v : (T)0;
+      } else if (x < 0) { _e1 = D * x * v; _e2 = D * v * v; }
+    });
+    (void)e3unused; (void)a1; (void)a2;
+    const T d1 = 2 * alpha * q2 + q1 + e1, d2 = 2 * q2 + e2;
+    if (fabs(d1) < gtol) break;
+    if (d1 < 0) lo = alpha; else hi = alpha;
+    T next = alpha - d1 / d2;
+    if (hi >= 0 && (next <= lo || next >= hi)) next = (T)0.5 * (lo + hi);
+    if (next == alpha) break;
+    alpha = next;
+  }
+  return alpha;
+}
+
 template <typename T, int NC>
 DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // inlined into the solver loop (kernel level): JT_times stays a leaf call
   MYO_BIND_M(T) MYO_BIND_S(T)
@@ -2723,8 +2840,11 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // i
     }
   }
   SYNC();
+  HP fcorr = 0;
+  if (M.any_floss) fcorr = fric_update(M, s);      // (scalar branch; a leaf of its own: the kernel-level solver loop is at its register budget)
   JT_times(M, s, LOFF(s, s.efc_force), LOFF(s, s.qfrc_constraint));
-  WAVE_SUM_N(HP, ccost, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jar[r], (T)0) * (HP)tmin(s.efc_jar[r], (T)0)));   // active <=> jar < 0
+  WAVE_SUM_N(HP, ccost0, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jar[r], (T)0) * (HP)tmin(s.efc_jar[r], (T)0)));   // active <=> jar < 0
+  const HP ccost = ccost0 + fcorr;
   WAVE_SUM_N(HP, gcost, M.nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc[c] - (HP)s.qacc_smooth[c])));
   PHASE {
     const int c = lane;
@@ -2862,7 +2982,9 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   WAVE_SUM_N(HP, costw_c, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_force[r] - S_AREF(s)[r], (T)0) * (HP)tmin(s.efc_force[r] - S_AREF(s)[r], (T)0)));
   WAVE_SUM_N(HP, costs, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jv[r] - S_AREF(s)[r], (T)0) * (HP)tmin(s.efc_jv[r] - S_AREF(s)[r], (T)0)));
   WAVE_SUM_N(HP, gw, nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc_warm[c] - (HP)s.qacc_smooth[c])));
-  const int use_warm = (costw_c + (HP)0.5 * gw) < costs;
+  HP fw = 0, fs = 0;
+  if (M.any_floss) { fw = fric_excess_sum(M, s, LOFF(s, s.efc_force)); fs = fric_excess_sum(M, s, LOFF(s, s.efc_jv)); }
+  const int use_warm = (costw_c + fw + (HP)0.5 * gw) < costs + fs;
   PHASE {
     const int c = lane;
     if (c < nv) {
@@ -2917,7 +3039,8 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       LV(ls_x2) = r2 < nefc ? s.efc_jar[r2] : (T)0; LV(ls_v2) = r2 < nefc ? s.efc_jv[r2] : (T)0;
       LV(ls_d2) = r2 < nefc ? row_D(s, r2, nlim) : (T)0;
     }
-    for (int li = 0; li < 50; ++li) {
+    const int nls = M.any_floss ? 0 : 50;      // (models with friction-loss rows: fric_linesearch below)
+    for (int li = 0; li < nls; ++li) {
       WAVE_SUM2_LANES(T, e1, e2, {
         const T xa = LV(ls_x0) + alpha * LV(ls_v0), xb = LV(ls_x1) + alpha * LV(ls_v1), xc = LV(ls_x2) + alpha * LV(ls_v2);
         if (xa < 0) { _e1 += LV(ls_d0) * xa * LV(ls_v0); _e2 += LV(ls_d0) * LV(ls_v0) * LV(ls_v0); }
@@ -2938,6 +3061,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       printf("   ls %d alpha %g d1 %g d2 %g gtol %g\n", li, (double)alpha, (double)d1, (double)d2, (double)gtol);
 #endif
     }
+    if (M.any_floss) alpha = fric_linesearch(M, s, q1, q2, gtol);
     PROF(s, 14)
     if (alpha == 0) break;
     PHASE {
@@ -3007,7 +3131,9 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
   PROF(s, 3)
   crb(M, s);
   PROF(s, 4)
+  if (M.any_floss) friction_rows(M, s, 0);
   constraint_limits(M, K, s);
+  if (M.any_floss) friction_rows(M, s, 1);
   PROF(s, 18)
   if (M.any_gen) {
     for (int base = 0; base < M.npair_std; base += 64) collision_pass<true>(M, K, s, base);

@@ -62,7 +62,7 @@ extern "C" const char* myo_version(void) {      // "... build <hash of the nativ
 // ------------------------------------------------------------------------------------------ host model
 struct myo_model {
   int nq, nv, nu, na, nbody, njnt, ngeom, nsite, ntendon, nwrap, npair, nM, maxdepth;
-  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq, arrow_nf, any_rot, any_gen;
+  int integrator, iterations, disableflags, any_damping, any_tendon_passive, nlead, ngw, nte, npair_std, ld_nfq, ld_nsq, arrow_nf, any_rot, any_gen, any_floss;
   unsigned long long arrow_pad;
   double timestep, tolerance, impratio, gravity[3], meaninertia;
 #define X(n) std::vector<int> n;
@@ -259,6 +259,16 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
                get_i(blob, nbytes, "x_pair_geom1", m->pair_geom1) && get_i(blob, nbytes, "x_pair_geom2", m->pair_geom2);
   if (ok && !get_i(blob, nbytes, "x_pair_sub", pair_sub)) pair_sub.assign(m->pair_geom1.size(), 0);      // (older blobs: no box-box candidates)
   if (ok && !get_i(blob, nbytes, "geom_condim", geom_condim)) geom_condim.clear();                        // (older blobs: condim 3 everywhere)
+  if (ok) {                                   // friction loss: optional fields (older blobs: none), MuJoCo's default solver parameters
+    const size_t nv0 = sizes[1] > 0 && sizes[1] <= 4096 ? sizes[1] : 0, nt0 = sizes[8] > 0 && sizes[8] <= 4096 ? sizes[8] : 0;     // (untrusted sizes: capacity checks follow)
+    auto opt = [&](const char* name, std::vector<double>& v, size_t cnt, std::initializer_list<double> def) {
+      if (!get_d(blob, nbytes, name, v) || v.size() < cnt * def.size()) { v.clear(); for (size_t i = 0; i < cnt; ++i) v.insert(v.end(), def); }
+    };
+    opt("dof_frictionloss", m->dof_frictionloss, nv0, {0.0}); opt("dof_solref", m->dof_solref, nv0, {0.02, 1.0});
+    opt("dof_solimp", m->dof_solimp, nv0, {0.9, 0.95, 0.001, 0.5, 2.0});
+    opt("tendon_frictionloss", m->tendon_frictionloss, nt0, {0.0}); opt("tendon_solref_fri", m->tendon_solref_fri, nt0, {0.02, 1.0});
+    opt("tendon_solimp_fri", m->tendon_solimp_fri, nt0, {0.9, 0.95, 0.001, 0.5, 2.0});
+  }
   if (!ok) {
     int rc = fail(MYO_E_ARG, "model blob lacks field %s", missing ? missing : "(sizes/opt/derived)");
     delete m;
@@ -633,6 +643,14 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   }
   build_ldl_tables(m);
   build_arrow_tables(m);
+  m->any_floss = 0;
+  {
+    int nfr = 0;
+    for (int d = 0; d < nv; ++d) if (m->dof_frictionloss[d] > 0) { m->any_floss = 1; nfr++; }
+    for (int t = 0; t < m->ntendon; ++t) if (m->tendon_frictionloss[t] > 0) { m->any_floss = 1; nfr++; }
+    LIM(nfr > MYO_NLIM_MAX / 2, "friction-loss rows (more than half of the limit-row capacity)")
+    for (int d = 0; d < nv; ++d) LIM(m->dof_frictionloss[d] > 0 && m->jnt_type[m->dof_jntid[d]] == MYO_JNT_FREE, "friction loss on the dofs of a free joint")
+  }
   m->any_damping = 0;
   for (int d = 0; d < nv; ++d) if (m->dof_damping[d] > 0) m->any_damping = 1;
   m->any_tendon_passive = 0;
@@ -764,7 +782,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.nsite = m->nsite; D.ntendon = m->ntendon; D.nwrap = m->nwrap; D.npair = m->npair; D.nM = m->nM; D.maxdepth = m->maxdepth;
   D.integrator = m->integrator; D.iterations = m->iterations; D.disableflags = m->disableflags;
   D.any_damping = m->any_damping; D.any_tendon_passive = m->any_tendon_passive; D.nlead = m->nlead; D.ngw = m->ngw; D.nte = m->nte; D.npair_std = m->npair_std;
-  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad; D.any_rot = m->any_rot; D.any_gen = m->any_gen;
+  D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad; D.any_rot = m->any_rot; D.any_gen = m->any_gen; D.any_floss = m->any_floss;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];

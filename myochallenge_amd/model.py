@@ -187,8 +187,6 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
         raise ModelError("ball joints are not supported")
     if m.sizes["neq"]:
         raise ModelError("equality constraints are not supported")
-    if np.any(m.dof_frictionloss > 0) or np.any(m.tendon_frictionloss > 0):
-        raise ModelError("friction loss is not supported")
     if m.opt["cone"] != 0:
         raise ModelError("only pyramidal friction cones are supported")
     if not np.all(np.isin(m.geom_condim[(m.geom_contype | m.geom_conaffinity) != 0], (1, 3, 4, 6))):
@@ -208,6 +206,14 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
         f[name] = np.ascontiguousarray(m.arrays[name]).astype(np.int32).reshape(-1)
     for name in _F64_FIELDS:
         f[name] = np.ascontiguousarray(m.arrays[name]).astype(np.float64).reshape(-1)
+    # friction loss (mj_instantiateFriction rows): the coefficients and the rows' solver parameters (MuJoCo's defaults where a
+    # model source carries none)
+    nv_, nt_ = int(m.sizes["nv"]), int(m.sizes["ntendon"])
+    for name, cnt, default in (("dof_frictionloss", nv_, (0.0,)), ("dof_solref", nv_, (0.02, 1.0)), ("dof_solimp", nv_, (0.9, 0.95, 0.001, 0.5, 2.0)),
+                               ("tendon_frictionloss", nt_, (0.0,)), ("tendon_solref_fri", nt_, (0.02, 1.0)),
+                               ("tendon_solimp_fri", nt_, (0.9, 0.95, 0.001, 0.5, 2.0))):
+        a = m.arrays.get(name)
+        f[name] = (np.tile(np.array(default, np.float64), cnt) if a is None else np.ascontiguousarray(a).astype(np.float64).reshape(-1))
     # site orientations: carried for the task layers' checks (the die-reorient observation reads site_xmat in MyoSuite; this
     # stepper takes the body's orientation and therefore requires identity site frames, envs/reorient.py:make_reorient_cfg)
     sq = m.arrays.get("site_quat")

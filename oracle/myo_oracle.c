@@ -44,6 +44,9 @@ struct OrcModel {
       *tendon_invweight0, *wrap_prm, *actuator_dynprm, *actuator_gainprm, *actuator_biasprm,
       *actuator_ctrlrange, *actuator_forcerange, *actuator_gear, *actuator_acc0,
       *actuator_lengthrange;
+  /* friction loss (optional blob fields; NULL = none): dof_frictionloss nv, dof_solref 2 nv, dof_solimp 5 nv,
+   * tendon_frictionloss ntendon, tendon_solref_fri 2 ntendon, tendon_solimp_fri 5 ntendon */
+  const double *dof_frictionloss, *dof_solref, *dof_solimp, *tendon_frictionloss, *tendon_solref_fri, *tendon_solimp_fri;
 };
 
 typedef struct {
@@ -73,11 +76,11 @@ struct OrcData {
   /* constraints */
   OrcContact con[MAXCON];
   double *efc_J, *efc_pos, *efc_margin, *efc_D, *efc_R, *efc_aref, *efc_vel, *efc_force,
-      *efc_diagApprox, *efc_KBIP;
+      *efc_diagApprox, *efc_KBIP, *efc_floss;      /* efc_floss: friction loss of a friction row (type 3), else 0 */
   int efc_type[MAXEFC], efc_id[MAXEFC];
   /* scratch */
   double *w1, *w2, *w3, *w4, *w5, *H, *cacc, *cfrc;
-  OrcField fields[64];
+  OrcField fields[96];
   int nfields;
 };
 
@@ -199,6 +202,9 @@ OrcModel* orc_model_from_blob(const void* src, size_t nbytes, char* err, int err
   GETD(tendon_damping); GETD(tendon_lengthspring); GETD(tendon_invweight0); GETD(wrap_prm);
   GETD(actuator_dynprm); GETD(actuator_gainprm); GETD(actuator_biasprm); GETD(actuator_ctrlrange);
   GETD(actuator_forcerange); GETD(actuator_gear); GETD(actuator_acc0); GETD(actuator_lengthrange);
+#define GETD_OPT(n) do { const myo_blob_field* f = blob_find(m->blob, #n); m->n = (f && f->dtype == MYO_BLOB_F64) ? (const double*)(base + f->offset) : NULL; } while (0)
+  GETD_OPT(dof_frictionloss); GETD_OPT(dof_solref); GETD_OPT(dof_solimp);
+  GETD_OPT(tendon_frictionloss); GETD_OPT(tendon_solref_fri); GETD_OPT(tendon_solimp_fri);
   const myo_blob_field *fs = blob_find(m->blob, "sizes"), *fi = blob_find(m->blob, "opt_int"),
                        *fd = blob_find(m->blob, "opt_f64"), *p1 = blob_find(m->blob, "x_pair_geom1"),
                        *p2 = blob_find(m->blob, "x_pair_geom2");
@@ -255,7 +261,7 @@ OrcData* orc_data_new(const OrcModel* m) {
   A(act_dot, m->na); A(actuator_force, m->nu); A(qfrc_actuator, nv); A(qfrc_smooth, nv);
   A(qacc_smooth, nv); A(qacc, nv); A(qfrc_constraint, nv);
   A(efc_J, MAXEFC*nv); A(efc_pos, MAXEFC); A(efc_margin, MAXEFC); A(efc_D, MAXEFC); A(efc_R, MAXEFC);
-  A(efc_aref, MAXEFC); A(efc_vel, MAXEFC); A(efc_force, MAXEFC); A(efc_diagApprox, MAXEFC);
+  A(efc_aref, MAXEFC); A(efc_vel, MAXEFC); A(efc_force, MAXEFC); A(efc_diagApprox, MAXEFC); A(efc_floss, MAXEFC);
   A(efc_KBIP, 4*MAXEFC);
   A(w1, MAXEFC+nv); A(w2, MAXEFC+nv); A(w3, MAXEFC+nv); A(w4, MAXEFC+nv); A(w5, MAXEFC+nv);
   A(H, nv*nv); A(cacc, 6*nb); A(cfrc, 6*nb);
@@ -1146,7 +1152,7 @@ static void add_row(OrcData* d, int nv, int type, int id, double pos, double mar
   int r = d->nefc;
   if (r >= MAXEFC) return;
   d->efc_type[r] = type; d->efc_id[r] = id; d->efc_pos[r] = pos; d->efc_margin[r] = margin;
-  d->efc_diagApprox[r] = diagApprox;
+  d->efc_diagApprox[r] = diagApprox; d->efc_floss[r] = 0;
   double K, B, I;
   get_solparam(d->m, solref, solimp, pos - margin, &K, &B, &I);
   d->efc_KBIP[4*r] = K; d->efc_KBIP[4*r+1] = B; d->efc_KBIP[4*r+2] = I; d->efc_KBIP[4*r+3] = 0;
@@ -1160,6 +1166,24 @@ static void make_constraint(const OrcModel* m, OrcData* d) {
   int nv = m->nv;
   d->nefc = 0; d->nl = 0; d->ntl = 0;
   double* jac1 = d->w1; double* jac2 = d->w2;
+  /* friction loss (mj_instantiateFriction): one row per dof / tendon with frictionloss > 0, J = the dof / the tendon's moment arms,
+   * pos = margin = 0; the row's force is clamped to +- frictionloss (constraint_update), its cost is Huber-shaped */
+  int nf = 0;
+  if (m->dof_frictionloss) for (int i = 0; i < nv; ++i) {
+    if (!(m->dof_frictionloss[i] > 0) || d->nefc >= MAXEFC) continue;
+    double* J = d->efc_J + d->nefc*nv; memset(J, 0, sizeof(double)*nv);
+    J[i] = 1;
+    add_row(d, nv, 3, i, 0.0, 0.0, m->dof_invweight0[i], m->dof_solref + 2*i, m->dof_solimp + 5*i);
+    d->efc_floss[d->nefc-1] = m->dof_frictionloss[i]; nf++;
+  }
+  if (m->tendon_frictionloss) for (int t = 0; t < m->ntendon; ++t) {
+    if (!(m->tendon_frictionloss[t] > 0) || d->nefc >= MAXEFC) continue;
+    double* J = d->efc_J + d->nefc*nv;
+    for (int c = 0; c < nv; ++c) J[c] = d->ten_J[t*nv+c];
+    add_row(d, nv, 3, t, 0.0, 0.0, m->tendon_invweight0[t], m->tendon_solref_fri + 2*t, m->tendon_solimp_fri + 5*t);
+    d->efc_floss[d->nefc-1] = m->tendon_frictionloss[t]; nf++;
+  }
+  (void)nf;
   /* joint limits */
   for (int j = 0; j < m->njnt; ++j) {
     if (!m->jnt_limited[j] || m->jnt_type[j] == MYO_JNT_FREE) continue;
@@ -1405,6 +1429,19 @@ static void mul_M(const OrcData* d, int nv, double* r, const double* v) {
   for (int i = 0; i < nv; ++i) { double s = 0; for (int j = 0; j < nv; ++j) { s += d->M[i*nv+j]*v[j]; if (d->M[i*nv+j] != 0) FL(2); } r[i] = s; }
 }
 
+/* cost, force and curvature of one row at jar = x.  Ordinary rows (limits, contacts): 0.5 D x^2 where x < 0.  Friction-loss rows
+ * (f > 0): quadratic inside |x| < R f, linear outside — the force -D x saturates at +- f (mj_constraintUpdate) */
+static double row_cost(double D, double f, double x, double* force, int* quad) {
+  if (f > 0) {
+    double Rf = f/D;
+    if (x <= -Rf) { *force = f; *quad = 0; return f*(-0.5*Rf - x); }
+    if (x >= Rf) { *force = -f; *quad = 0; return f*(-0.5*Rf + x); }
+    *force = -D*x; *quad = 1; return 0.5*D*x*x;
+  }
+  if (x < 0) { *force = -D*x; *quad = 1; return 0.5*D*x*x; }
+  *force = 0; *quad = 0; return 0;
+}
+
 typedef struct { double cost, d1, d2; } LsEval;
 
 static LsEval ls_eval(const OrcData* d, double alpha, const double* jar, const double* jv, const double* qg) {
@@ -1412,7 +1449,12 @@ static LsEval ls_eval(const OrcData* d, double alpha, const double* jar, const d
   for (int r = 0; r < d->nefc; ++r) {
     double x = jar[r] + alpha*jv[r];
     FL(2);
-    if (x < 0) { double D = d->efc_D[r]; e.cost += 0.5*D*x*x; e.d1 += D*x*jv[r]; e.d2 += D*jv[r]*jv[r]; FL(10); }
+    if (d->efc_floss[r] > 0) {
+      double force; int quad;
+      e.cost += row_cost(d->efc_D[r], d->efc_floss[r], x, &force, &quad);
+      e.d1 += -force*jv[r];
+      if (quad) e.d2 += d->efc_D[r]*jv[r]*jv[r];
+    } else if (x < 0) { double D = d->efc_D[r]; e.cost += 0.5*D*x*x; e.d1 += D*x*jv[r]; e.d2 += D*jv[r]*jv[r]; FL(10); }
   }
   return e;
 }
@@ -1423,6 +1465,16 @@ static double constraint_update(OrcData* d, int nv, const double* jar, const dou
   memset(d->qfrc_constraint, 0, sizeof(double)*nv);
   for (int r = 0; r < d->nefc; ++r) {
     unsigned char a = jar[r] < 0;
+    if (d->efc_floss[r] > 0) {          /* friction loss: "active" = the quadratic zone (what the Hessian sees); the force acts in all zones */
+      double force; int quad;
+      cost += row_cost(d->efc_D[r], d->efc_floss[r], jar[r], &force, &quad);
+      a = (unsigned char)quad;
+      if (a != active[r]) changed = 1;
+      active[r] = a;
+      d->efc_force[r] = force;
+      for (int c = 0; c < nv; ++c) d->qfrc_constraint[c] += d->efc_J[r*nv+c]*force;
+      continue;
+    }
     if (a != active[r]) changed = 1;
     active[r] = a;
     if (a) { d->efc_force[r] = -d->efc_D[r]*jar[r]; cost += 0.5*d->efc_D[r]*jar[r]*jar[r]; }
@@ -1452,6 +1504,12 @@ static void newton_solve(const OrcModel* m, OrcData* d) {
       double xw = -d->efc_aref[r], xs = -d->efc_aref[r];
       for (int c = 0; c < nv; ++c) { xw += d->efc_J[r*nv+c]*d->qacc_warmstart[c]; xs += d->efc_J[r*nv+c]*d->qacc_smooth[c]; if (d->efc_J[r*nv+c] != 0) FL(4); }
       FL(8);
+      if (d->efc_floss[r] > 0) {
+        double force; int quad;
+        costw += row_cost(d->efc_D[r], d->efc_floss[r], xw, &force, &quad);
+        costs += row_cost(d->efc_D[r], d->efc_floss[r], xs, &force, &quad);
+        continue;
+      }
       if (xw < 0) costw += 0.5*d->efc_D[r]*xw*xw;
       if (xs < 0) costs += 0.5*d->efc_D[r]*xs*xs;
     }

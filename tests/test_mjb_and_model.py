@@ -78,9 +78,22 @@ def test_collision_pair_filter(models):
 
 
 def test_feature_gates(models):
+    """What the stepper does not implement is refused at compile time, never ignored: elliptic cones, equality constraints, condim
+    values MuJoCo does not have.  Friction loss and condim 1 / 4 / 6 compile since round 4 (tests/test_narrow_phases.py)."""
     import copy
     m = copy.deepcopy(models["finger"])
     m.arrays["dof_frictionloss"][0] = 0.1
+    compile_model(m)                                   # friction loss: rows of their own (mj_instantiateFriction)
+    m = copy.deepcopy(models["finger"])
+    m.opt["cone"] = 1
+    with pytest.raises(ModelError):
+        compile_model(m)
+    m = copy.deepcopy(models["finger"])
+    m.sizes["neq"] = 1
+    with pytest.raises(ModelError):
+        compile_model(m)
+    m = copy.deepcopy(models["hand"])
+    m.arrays["geom_condim"][m.names["geom"].index("ball1")] = 5
     with pytest.raises(ModelError):
         compile_model(m)
 

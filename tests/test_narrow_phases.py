@@ -436,3 +436,77 @@ def test_condim_1_4_6_on_emulation(emu_lib):
 def test_condim_1_4_6_on_gpu(hip_lib):
     case_condim(hip_lib, native.MYO_F64, 1e-9)
     case_condim(hip_lib, native.MYO_MIXED, 1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------- friction loss
+def slider_model(frictionloss, mass=0.5):
+    """one body on a vertical slide joint under gravity, with dry friction (mj_instantiateFriction: a row whose force saturates at
+    +- frictionloss)"""
+    B = _Builder()
+    b = B.add_body("mass", 0, (0.0, 0.0, 1.0), mass=mass, inertia=(1e-3, 1e-3, 1e-3))
+    B.add_joint("slide", b, 2, axis=(0, 0, 1), damping=0.0, armature=0.0)
+    B.add_geom("g", b, SPH, (0.02,))
+    m = B.finish()
+    m.arrays["dof_frictionloss"] = np.array([frictionloss])
+    m.arrays["dof_damping"][:] = 0.0
+    set_const(m)
+    return m
+
+
+def case_friction_loss(lib, dtype, tol):
+    """(i) closed forms on a slider under gravity: friction below the weight -> the row saturates, qacc = -(m g - f) / m exactly; above
+    -> it holds, qacc = -m g / (m + D) with D = 1/R of the row (soft constraint).  (ii) the finger model with friction loss on two
+    joints and one tendon: stepper vs oracle over a trajectory (rows of both kinds, all three zones of the Huber cost)."""
+    mem = Mem(lib)
+    mass, g = 0.5, 9.81
+    for f in (2.0, 20.0):
+        m = slider_model(f, mass)
+        cm = compile_model(m)
+        om = OracleModel(cm.to_blob())
+        d = OracleData(om)
+        d.forward()
+        assert d.nefc == 1
+        imp = 0.9                                                    # impedance at pos - margin = 0: solimp[0]
+        D = 1.0 / ((1 - imp) / imp * (1.0 / mass))                   # R = (1 - d) / d * dof_invweight0, invweight0 = 1 / m for a slider
+        want = -(mass * g - f) / mass if f < mass * g else -mass * g / (mass + D)
+        assert abs(float(d.qacc[0]) - want) <= 1e-9 * abs(want), (f, float(d.qacc[0]), want)
+        get, b = forward_dump(lib, mem, cm, np.zeros(1), np.zeros(1), np.zeros(0), np.zeros(0), dtype)
+        assert abs(float(get("qacc", 1)[0]) - want) <= tol * abs(want)
+        b.close()
+    # (ii)
+    from myochallenge_amd.mjb import load_mjb
+    import os
+    mj = load_mjb(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "myo_finger_v0.mjb"))
+    mj.arrays["dof_frictionloss"] = np.array([0.02, 0.0, 0.05, 0.0])
+    mj.arrays["tendon_frictionloss"] = np.array([0.0, 0.5, 0.0, 0.0, 0.0])
+    cm = compile_model(mj)
+    om = OracleModel(cm.to_blob())
+    d = OracleData(om)
+    n = 2
+    b = native.Batch(native.Model(cm, lib), None, n, 0, 0, dtype)
+    q0 = np.array([0.3, 0.6, 0.6, 0.5])
+    d.qpos[:] = q0
+    b.set_state(mem.arr(np.tile(q0, (n, 1))), mem.zeros((n, om.nv)), mem.zeros((n, om.na)), mem.zeros(n))
+    rng = np.random.RandomState(2)
+    qp, qv = mem.zeros((n, om.nq)), mem.zeros((n, om.nv))
+    for i in range(150):
+        if i % 10 == 0:
+            c = rng.uniform(0, 1, om.nu)
+        d.ctrl[:] = c
+        d.step()
+        b.physics_step(mem.arr(np.tile(c, (n, 1))), 1)
+    assert d.nefc >= 3
+    b.get_state(qp, qv)
+    assert rel_err(mem.host(qp)[1], d.qpos) < tol * 10 and np.abs(mem.host(qv)[1] - np.array(d.qvel)).max() < tol * 10 * max(1.0, np.abs(np.array(d.qvel)).max())
+    b.close()
+
+
+def test_friction_loss_on_emulation(emu_lib):
+    case_friction_loss(emu_lib, native.MYO_F64, 1e-9)
+    case_friction_loss(emu_lib, native.MYO_MIXED, 1e-4)
+
+
+@pytest.mark.gpu
+def test_friction_loss_on_gpu(hip_lib):
+    case_friction_loss(hip_lib, native.MYO_F64, 1e-9)
+    case_friction_loss(hip_lib, native.MYO_MIXED, 1e-4)

@@ -8,11 +8,11 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R, P = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
-TAG = os.environ.get("ROUND", "r03")
+TAG = os.environ.get("ROUND", "r04")
 
 
 def main():
-    old = {"kernel": "k_step<float,false> (mixed stepper)", "envs_per_launch": 4096, "dtype": "mixed",
+    old = {"kernel": "k_step<double,false,20> (fp64 stepper, the bench default since round 4)", "envs_per_launch": 4096, "dtype": "f64",
            "source": "rocprofv3 --pmc <one set per pass> --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 (tools/profile_round.sh); per-launch averages over the k_step launches of the bench workload (first two dropped)",
            "note": "FETCH_SIZE is reported as counted; the doubled figure (the guide's gfx950 correction for 16-B/lane streaming reads) is given separately"}
     vals, n = {}, None
@@ -36,7 +36,7 @@ def main():
     json.dump(new, open(os.path.join(P, TAG + "_pmc.json"), "w"), indent=1)
     print("k_step launches", n, "traffic MB", new["hbm_bytes_per_launch"] / 1e6, "VALU M", new["SQ_INSTS_VALU"] / 1e6,
           "wait", new["SQ_WAIT_ANY"] / new["SQ_WAVE_CYCLES"])
-    for a, b in (("pmc_kstep.txt", TAG + "_pmc_kstep_mixed_4096.txt"), ("pmc_gemm.txt", TAG + "_pmc_mfma_gemm.txt"),
+    for a, b in (("pmc_kstep.txt", TAG + "_pmc_kstep_f64_4096.txt"), ("pmc_gemm.txt", TAG + "_pmc_mfma_gemm.txt"),
                  ("stage_shares.txt", TAG + "_stage_shares.txt"), ("bench_kernel_stats.csv", TAG + "_bench_kernel_stats.csv"),
                  ("drift.log", TAG + "_drift_32streams.log"), ("pmc_mfma_kstep_f64.txt", TAG + "_pmc_mfma_kstep_f64.txt"),
                  ("stage_shares_rk4.txt", TAG + "_stage_shares_rk4.txt"), ("wg_timeline_parts.log", TAG + "_wg_timeline_parts.log"),
@@ -45,7 +45,7 @@ def main():
         if os.path.exists(os.path.join(R, a)):
             shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}
-    for k in ("f64", "rk4", "p2_8192", "rollout_only", "reorient_p2"):
+    for k in ("mixed", "rk4", "p2_8192", "rollout_only", "reorient_p2"):
         d = json.loads(open(os.path.join(R, f"bench_{k}.json")).read().strip().splitlines()[-1])
         out["bench_" + k] = {x: d[x] for x in ("value", "ms_per_step", "env_kernel_ms", "ppo_optimizer_steps_per_sec", "dtype", "config") if x in d}
     try:

@@ -37,7 +37,7 @@ rm -rf /tmp/pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "Cijk" > $OUT/pmc_gemm.txt
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" >> $OUT/pmc_gemm.txt
-# 3c. matrix cores in the fp64 stepper (blocked Cholesky)
+# 3c. matrix cores in the fp64 stepper (block-arrow Newton solve: Schur complement + 16 x 16 factor)
 rm -rf /tmp/pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 --dtype f64 > /tmp/pmc.log 2>&1
 python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" > $OUT/pmc_mfma_kstep_f64.txt
@@ -48,7 +48,7 @@ PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_prof.py 4096 $ROOT/tools/dev/libmyo
 MYO_STEP_SPLIT=0 PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_wgtime.py $ROOT/tools/dev/lib_wgtime.so 4096 1 > $OUT/wg_timeline_whole.log 2>&1
 PYTHONPATH=$ROOT python3 $ROOT/tools/dev/gpu_wgtime.py $ROOT/tools/dev/lib_wgtime.so 4096 4 > $OUT/wg_timeline_parts.log 2>&1
 # 5. other configurations (BASELINE.json configs / variants)
-python3 $ROOT/bench.py --no-cpu-baseline --no-variants --dtype f64 > $OUT/bench_f64.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --no-variants --dtype mixed > $OUT/bench_mixed.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --integrator rk4 > $OUT/bench_rk4.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoBaodingBallsP2 --envs 8192 > $OUT/bench_p2_8192.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -188,8 +189,14 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
     }
   }
   // what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored
-  if (f.collision == 1) { err = "opt.collision = predefined (explicit <pair> contacts only) is not supported"; *unsupported = 1; return false; }
-  if (f.sizes["npair"] > 0 && f.collision != 2) { err = "explicit contact pairs (<contact><pair>) are not supported"; *unsupported = 1; return false; }
+  const int npair_x = f.collision != 2 ? (int)f.sizes["npair"] : 0;      // explicit <contact><pair> entries in force (opt.collision: 0 all, 1 predefined, 2 dynamic)
+  for (int k = 0; k < npair_x; ++k) {
+    const double* fr = &D("pair_friction")[5 * (size_t)k];
+    const int dim = I("pair_dim")[k];
+    if (fr[0] != fr[1] || fr[3] != fr[4]) { err = "an explicit contact pair with anisotropic friction is not supported"; *unsupported = 1; return false; }
+    if (dim != 1 && dim != 3 && dim != 4 && dim != 6) { err = "an explicit contact pair with a condim other than 1, 3, 4, 6"; *unsupported = 1; return false; }
+    if (I("pair_geom1")[k] < 0 || I("pair_geom1")[k] >= ngeom || I("pair_geom2")[k] < 0 || I("pair_geom2")[k] >= ngeom) { err = "an explicit contact pair names a geom out of range"; return false; }
+  }
   if (f.disableflags & ~((1 << 9) | (1 << 11))) { err = "opt.disableflags: only filterparent and refsafe can be disabled in this stepper"; *unsupported = 1; return false; }
   if (f.enableflags & 1) { err = "opt.enableflags: contact override is not supported"; *unsupported = 1; return false; }
   for (int j = 0; j < njnt; ++j) if (I("jnt_type")[j] == MYO_JNT_BALL) { err = "ball joints are not supported"; *unsupported = 1; return false; }
@@ -204,12 +211,29 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   // ((body1 + 1) << 16) + body2 + 1 with body1 < body2, MuJoCo 2.1), parent-child unless mjDSBL_FILTERPARENT, contype / conaffinity
   const std::vector<int>& excl = I("exclude_signature");
   const bool filterparent = !(f.disableflags & (1 << 9));
-  std::vector<int> p1, p2, psub;
+  std::vector<int> p1, p2, psub, pxp;
   int dropped = 0;
   char msg[256] = "";
   const std::vector<int>&gb = I("geom_bodyid"), &weld = I("body_weldid"), &par = I("body_parentid"), &gt = I("geom_type");
-  for (int g1 = 0; g1 < ngeom; ++g1)
+  auto emit = [&](int ga, int gb_, int xp) {
+    const int t1 = gt[ga], t2 = gt[gb_];
+    const int a = t1 <= t2 ? ga : gb_, b = t1 <= t2 ? gb_ : ga;      // MuJoCo orders a pair by geom type
+    const int lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+    if (lo == MYO_GEOM_PLANE && hi == MYO_GEOM_PLANE) return;
+    if (lo == MYO_GEOM_BOX && hi == MYO_GEOM_BOX) { for (int v = 0; v < 17; ++v) { p1.push_back(a); p2.push_back(b); psub.push_back(1 + v); pxp.push_back(xp); } }   // 16 vertex-face candidates + the edge-edge candidate (17)
+    else if (pair_supported(lo, hi)) { p1.push_back(a); p2.push_back(b); psub.push_back(0); pxp.push_back(xp); }
+    else { if (!dropped) snprintf(msg, sizeof msg, "geom %d (type %d) - geom %d (type %d)", a, gt[a], b, gt[b]); dropped++; }
+  };
+  // explicit pairs first (no contype / conaffinity / parent / exclude filtering applies to them); a dynamic pair of the same geoms is skipped
+  std::vector<long long> xsig;
+  for (int k = 0; k < npair_x; ++k) {
+    const int a = I("pair_geom1")[k], b = I("pair_geom2")[k];
+    xsig.push_back(((long long)(a < b ? a : b) << 32) | (unsigned)(a < b ? b : a));
+    emit(a, b, k);
+  }
+  for (int g1 = 0; g1 < ngeom && f.collision != 1; ++g1)
     for (int g2 = g1 + 1; g2 < ngeom; ++g2) {
+      if (!xsig.empty() && std::find(xsig.begin(), xsig.end(), (((long long)g1 << 32) | (unsigned)g2)) != xsig.end()) continue;
       const int w1 = weld[gb[g1]], w2 = weld[gb[g2]];
       if (w1 == w2) continue;
       if (!excl.empty()) {
@@ -222,13 +246,7 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
       const int wp1 = weld[par[w1]], wp2 = weld[par[w2]];
       if (filterparent && w1 != 0 && w2 != 0 && (w1 == wp2 || w2 == wp1)) continue;
       if (!((I("geom_contype")[g1] & I("geom_conaffinity")[g2]) || (I("geom_contype")[g2] & I("geom_conaffinity")[g1]))) continue;
-      const int t1 = gt[g1], t2 = gt[g2];
-      const int a = t1 <= t2 ? g1 : g2, b = t1 <= t2 ? g2 : g1;      // MuJoCo orders a pair by geom type
-      const int lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
-      if (lo == MYO_GEOM_PLANE && hi == MYO_GEOM_PLANE) continue;
-      if (lo == MYO_GEOM_BOX && hi == MYO_GEOM_BOX) { for (int v = 0; v < 17; ++v) { p1.push_back(a); p2.push_back(b); psub.push_back(1 + v); } }   // 16 vertex-face candidates + the edge-edge candidate (17)
-      else if (pair_supported(lo, hi)) { p1.push_back(a); p2.push_back(b); psub.push_back(0); }
-      else { if (!dropped) snprintf(msg, sizeof msg, "geom %d (type %d) - geom %d (type %d)", a, gt[a], b, gt[b]); dropped++; }
+      emit(g1, g2, -1);
     }
   {   // stable partition: the pairs of the primitive narrow phases first (model.py:compile_model does the same)
     auto is_std = [&](size_t k) {
@@ -236,11 +254,11 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
       return (t1 == MYO_GEOM_PLANE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE)) || (t1 == MYO_GEOM_SPHERE && (t2 == MYO_GEOM_SPHERE || t2 == MYO_GEOM_CAPSULE || t2 == MYO_GEOM_BOX)) ||
              (t1 == MYO_GEOM_CAPSULE && t2 == MYO_GEOM_CAPSULE);
     };
-    std::vector<int> q1, q2, qs;
+    std::vector<int> q1, q2, qs, qx;
     for (int pass = 0; pass < 2; ++pass)
       for (size_t k = 0; k < p1.size(); ++k)
-        if (is_std(k) == (pass == 0)) { q1.push_back(p1[k]); q2.push_back(p2[k]); qs.push_back(psub[k]); }
-    p1.swap(q1); p2.swap(q2); psub.swap(qs);
+        if (is_std(k) == (pass == 0)) { q1.push_back(p1[k]); q2.push_back(p2[k]); qs.push_back(psub[k]); qx.push_back(pxp[k]); }
+    p1.swap(q1); p2.swap(q2); psub.swap(qs); pxp.swap(qx);
   }
   if (dropped && !allow_drop) {
     char m2[400];
@@ -280,6 +298,20 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   for (int i = 0; i < nv; ++i) { const int p = I("dof_parentid")[i]; dd[i] = p < 0 ? 1 : dd[p] + 1; }
   fi.push_back({"x_body_depth", bd}); fi.push_back({"x_dof_depth", dd});
   fi.push_back({"x_pair_geom1", p1}); fi.push_back({"x_pair_geom2", p2}); fi.push_back({"x_pair_sub", psub});
+  {   // explicit <pair> parameters (model.py:compile_model writes the same fields)
+    std::vector<int> xdim;
+    std::vector<double> xmargin, xgap, xsolref, xsolimp, xfric;
+    for (int k = 0; k < npair_x; ++k) {
+      xdim.push_back(I("pair_dim")[k]); xmargin.push_back(D("pair_margin")[k]); xgap.push_back(D("pair_gap")[k]);
+      for (int e = 0; e < 2; ++e) xsolref.push_back(D("pair_solref")[2 * (size_t)k + e]);
+      for (int e = 0; e < 5; ++e) xsolimp.push_back(D("pair_solimp")[5 * (size_t)k + e]);
+      const double* fr = &D("pair_friction")[5 * (size_t)k];
+      xfric.push_back(fr[0]); xfric.push_back(fr[2]); xfric.push_back(fr[3]);
+    }
+    fi.push_back({"x_pair_explicit", pxp}); fi.push_back({"x_xp_dim", xdim});
+    fd.push_back({"x_xp_margin", xmargin}); fd.push_back({"x_xp_gap", xgap}); fd.push_back({"x_xp_solref", xsolref});
+    fd.push_back({"x_xp_solimp", xsolimp}); fd.push_back({"x_xp_friction", xfric});
+  }
   fi.push_back({"opt_int", {integrator >= 0 ? integrator : f.integrator, f.cone, f.iterations, f.disableflags}});
   fd.push_back({"opt_f64", {f.timestep, f.tolerance, f.impratio, f.gravity[0], f.gravity[1], f.gravity[2], f.o_margin, f.meaninertia}});
   const size_t nf = fi.size() + fd.size();

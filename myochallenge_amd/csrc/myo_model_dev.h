@@ -55,14 +55,14 @@
   X(tendon_lengthspring) X(tendon_invweight0) X(wrap_prm) X(actuator_dynprm)                     \
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
   X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(wr_p) X(wr_m) X(pc_f) X(te_div)               \
-  X(dof_frictionloss) X(dof_solref) X(dof_solimp) X(tendon_frictionloss) X(tendon_solref_fri) X(tendon_solimp_fri)
+  X(pair_mg) X(dof_frictionloss) X(dof_solref) X(dof_solimp) X(tendon_frictionloss) X(tendon_solref_fri) X(tendon_solimp_fri)
 
 // geometry tables of the HP stages (kinematic chain, contact / limit distances, observation): fp64 copies in
 // every build, named h_<array> (the fp64 stepper's h_ tables are its ordinary tables)
 #define MYO_MODEL_HP_ARRAYS(X)                                                                   \
   X(qpos0) X(body_pos) X(body_quat) X(jnt_pos) X(jnt_axis) X(jnt_range) X(jnt_margin)            \
   X(geom_pos) X(geom_mat) X(geom_size) X(geom_margin) X(geom_gap) X(geom_rbound) X(site_pos) X(wr_p) X(wr_m)       \
-  X(actuator_lengthrange) X(actuator_gainprm) X(actuator_biasprm) X(tendon_range) X(tendon_margin)
+  X(actuator_lengthrange) X(actuator_gainprm) X(actuator_biasprm) X(tendon_range) X(tendon_margin) X(pair_mg)
 
 // Model table handle.  The tables are immutable for the lifetime of a batch, so the gfx950 build
 // reads them through the CONSTANT address space: a load with a wave-uniform index becomes a scalar

@@ -2019,8 +2019,8 @@ DEV int pair_far_apart(const DevModel<T>& M, const TaskDev& K, const Scratch<T, 
 }
 // keep only contacts that enter the constraint set (dist < margin - gap); static slot indices
 template <typename T>
-DEV void pair_keep_included(const DevModel<T>& M, int g1, int g2, HP margin, ContactTmp& ct) {
-  const HP inc = margin - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2]);
+DEV void pair_keep_included(const DevModel<T>& M, int g1, int g2, HP margin, ContactTmp& ct, int p = -1) {
+  const HP inc = p >= 0 ? M.h_pair_mg[2 * p + 1] : margin - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2]);      // (p >= 0: the pair record's margin - gap)
   const int k0 = ct.n > 0 && ct.dist[0] < inc, k1 = ct.n > 1 && ct.dist[1] < inc;
   if (!k0 && k1) {
     ct.dist[0] = ct.dist[1];
@@ -2116,7 +2116,7 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
     LANE_VAR(int, nslot);
     PHASE {
       const int p = base + lane;
-      const int dim = LV(ct).n > 0 ? M.pc_i[8 * p + 6] : 3;
+      const int dim = LV(ct).n > 0 ? (M.pc_i[8 * p + 6] & 255) : 3;
       LV(nslot) = LV(ct).n * (dim == 6 ? 3 : (dim == 4 ? 2 : 1));
     }
     WAVE_EXSCAN6(LV(nslot), S_NPRE(s), total);
@@ -2128,7 +2128,7 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
         // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
         // friction, margin and gap, inverse-weight sums, condim; the per-env friction of the balls / the die is patched in here
         const int b1 = M.pc_i[8 * p], b2 = M.pc_i[8 * p + 1], root1 = M.pc_i[8 * p + 2], root2 = M.pc_i[8 * p + 3];
-        const int ns = M.pc_i[8 * p + 4], dim = M.pc_i[8 * p + 6], fsel = M.pc_i[8 * p + 7];
+        const int ns = M.pc_i[8 * p + 4], dim = M.pc_i[8 * p + 6] & 255, xpair = M.pc_i[8 * p + 6] >> 8, fsel = M.pc_i[8 * p + 7];
         const int per = dim == 6 ? 3 : (dim == 4 ? 2 : 1);
         T F[16];
         for (int e = 0; e < 16; ++e) F[e] = M.pc_f[16 * p + e];
@@ -2136,7 +2136,8 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
         T fr[3];
         for (int k = 0; k < 3; ++k) {
           if (k > 0 && dim <= 3) { fr[k] = 0; continue; }
-          const T fa = geom_fric_of(M, K, s, g1, k, F[9 + k]), fb = geom_fric_of(M, K, s, g2, k, F[12 + k]);
+          // (an explicit <pair> has its own coefficients: the geoms' — and their per-env values — do not enter)
+          const T fa = xpair ? F[9 + k] : geom_fric_of(M, K, s, g1, k, F[9 + k]), fb = xpair ? F[12 + k] : geom_fric_of(M, K, s, g2, k, F[12 + k]);
           fr[k] = (fsel == 0) ? tmax(fa, fb) : (fsel == 1 ? fa : fb);
         }
         const T fr0 = fr[0];
@@ -2146,7 +2147,7 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
           T cpos[3], frame[6];                 // contact point relative to O: only r1 / r2 below are made of it
           for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); frame[e] = (T)LV(ct).nrm[3 * k + e]; }
           make_frame(frame);
-          const T dmi = (T)(LV(ct).dist[k] - (tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]) - tmax(M.h_geom_gap[g1], M.h_geom_gap[g2])));   // dist - (margin - gap), HP difference
+          const T dmi = (T)(LV(ct).dist[k] - M.h_pair_mg[2 * p + 1]);   // dist - (margin - gap), HP difference
           T Kc, Bc, Ic;
           sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
           const T tran = F[15];
@@ -2218,10 +2219,10 @@ DEVFN void collision_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
     LV(ct).n = 0;
     if (p < M.npair_std) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-      const HP margin = tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);
+      const HP margin = GEN ? M.h_pair_mg[2 * p] : tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);      // (GEN: explicit <pair>s carry their own)
       if (!pair_far_apart(M, K, s, g1, g2, margin)) {
         collide_pair(M, K, s, g1, g2, margin, LV(ct));
-        pair_keep_included(M, g1, g2, margin, LV(ct));
+        pair_keep_included(M, g1, g2, margin, LV(ct), GEN ? p : -1);
       }
     }
   }
@@ -2244,10 +2245,10 @@ DEVFN void collision_pass_ext(const DevModel<T>& M_in, const TaskDev& K_in, Scra
     LV(ct).n = 0;
     if (p < M.npair) {
       const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-      const HP margin = tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);
+      const HP margin = GEN ? M.h_pair_mg[2 * p] : tmax(M.h_geom_margin[g1], M.h_geom_margin[g2]);
       if (!pair_far_apart(M, K, s, g1, g2, margin)) {
         collide_pair_ext(M, K, s, g1, g2, M.pc_i[8 * p + 5], margin, LV(ct));
-        pair_keep_included(M, g1, g2, margin, LV(ct));
+        pair_keep_included(M, g1, g2, margin, LV(ct), GEN ? p : -1);
       }
     }
   }

@@ -232,8 +232,8 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
       sizeof(myo_blob_header) + (size_t)h->n_fields * sizeof(myo_blob_field) > nbytes)
     return fail(MYO_E_ARG, "bad model blob header");
   myo_model* m = new myo_model();
-  std::vector<int> sizes, opt_i, trntype, trnid, body_weldid, geom_condim, pair_sub;
-  std::vector<double> opt_d, body_iquat, geom_quat;
+  std::vector<int> sizes, opt_i, trntype, trnid, body_weldid, geom_condim, pair_sub, pair_xp, xp_dim;
+  std::vector<double> opt_d, body_iquat, geom_quat, xp_margin, xp_gap, xp_solref, xp_solimp, xp_friction;
   bool ok = get_i(blob, nbytes, "sizes", sizes) && sizes.size() >= 10 && get_i(blob, nbytes, "opt_int", opt_i) &&
             opt_i.size() >= 4 && get_d(blob, nbytes, "opt_f64", opt_d) && opt_d.size() >= 8;
   const char* missing = nullptr;
@@ -259,6 +259,16 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
                get_i(blob, nbytes, "x_pair_geom1", m->pair_geom1) && get_i(blob, nbytes, "x_pair_geom2", m->pair_geom2);
   if (ok && !get_i(blob, nbytes, "x_pair_sub", pair_sub)) pair_sub.assign(m->pair_geom1.size(), 0);      // (older blobs: no box-box candidates)
   if (ok && !get_i(blob, nbytes, "geom_condim", geom_condim)) geom_condim.clear();                        // (older blobs: condim 3 everywhere)
+  if (ok) {                                   // explicit <contact><pair> parameters (older blobs: none)
+    if (!get_i(blob, nbytes, "x_pair_explicit", pair_xp) || pair_xp.size() != m->pair_geom1.size()) pair_xp.assign(m->pair_geom1.size(), -1);
+    const bool have = get_i(blob, nbytes, "x_xp_dim", xp_dim) && get_d(blob, nbytes, "x_xp_margin", xp_margin) && get_d(blob, nbytes, "x_xp_gap", xp_gap) &&
+                      get_d(blob, nbytes, "x_xp_solref", xp_solref) && get_d(blob, nbytes, "x_xp_solimp", xp_solimp) && get_d(blob, nbytes, "x_xp_friction", xp_friction);
+    const size_t nx = have ? xp_dim.size() : 0;
+    if (have && (xp_margin.size() != nx || xp_gap.size() != nx || xp_solref.size() != 2 * nx || xp_solimp.size() != 5 * nx || xp_friction.size() != 3 * nx)) {
+      int rc = fail(MYO_E_ARG, "corrupt model: explicit contact pair arrays differ in length"); delete m; return rc;
+    }
+    for (int& v : pair_xp) if (v < -1 || v >= (int)nx) { int rc = fail(MYO_E_ARG, "corrupt model: explicit contact pair index %d", v); delete m; return rc; }
+  }
   if (ok) {                                   // friction loss: optional fields (older blobs: none), MuJoCo's default solver parameters
     const size_t nv0 = sizes[1] > 0 && sizes[1] <= 4096 ? sizes[1] : 0, nt0 = sizes[8] > 0 && sizes[8] <= 4096 ? sizes[8] : 0;     // (untrusted sizes: capacity checks follow)
     auto opt = [&](const char* name, std::vector<double>& v, size_t cnt, std::initializer_list<double> def) {
@@ -583,6 +593,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     const int np = m->npair > 0 ? m->npair : 1;
     m->pc_i.assign(8 * (size_t)np, 0); m->pc_sup.assign(4 * (size_t)np, 0);
     m->pc_f.assign(16 * (size_t)np, 0.0); m->pc_mask.assign(2 * (size_t)np, 0ull);
+    m->pair_mg.assign(2 * (size_t)np, 0.0);     // margin, margin - gap per pair row (HP copy on the device: the general narrow-phase path reads them)
   }
   m->any_rot = 0; m->any_gen = 0;
   for (int p = 0; p < m->npair; ++p) {
@@ -620,9 +631,22 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     // condim of the contact (mj_contactParam): the higher-priority geom's, the larger of the two at equal priority
     const int d1 = geom_condim[g1], d2 = geom_condim[g2];
     I[6] = (pr1 == pr2) ? std::max(d1, d2) : (pr1 > pr2 ? d1 : d2);
-    LIM(I[6] != 1 && I[6] != 3 && I[6] != 4 && I[6] != 6, "contact dimension (condim) other than 1, 3, 4, 6")
-    if (I[6] > 3) m->any_rot = 1;
-    if (I[6] != 3) m->any_gen = 1;
+    double mg0 = margin, mg1 = F[1];
+    if (pair_xp[p] >= 0) {                    // an explicit <pair>: its own margin / gap / solref / solimp / friction / condim, nothing mixed, no per-env friction
+      const int x = pair_xp[p];
+      mg0 = xp_margin[x]; mg1 = xp_margin[x] - xp_gap[x];
+      F[0] = mg0; F[1] = mg1;
+      for (int e = 0; e < 2; ++e) F[2 + e] = xp_solref[2 * x + e];
+      for (int e = 0; e < 5; ++e) F[4 + e] = xp_solimp[5 * x + e];
+      for (int e = 0; e < 3; ++e) { F[9 + e] = xp_friction[3 * x + e]; F[12 + e] = xp_friction[3 * x + e]; }
+      I[6] = xp_dim[x] | 0x100;
+      I[7] = 0;
+      m->any_gen = 1;                         // (the general path reads the pair's own margin and skips the per-env friction patch)
+    }
+    m->pair_mg[2 * (size_t)p] = mg0; m->pair_mg[2 * (size_t)p + 1] = mg1;
+    LIM((I[6] & 255) != 1 && (I[6] & 255) != 3 && (I[6] & 255) != 4 && (I[6] & 255) != 6, "contact dimension (condim) other than 1, 3, 4, 6")
+    if ((I[6] & 255) > 3) m->any_rot = 1;
+    if ((I[6] & 255) != 3) m->any_gen = 1;
   }
   m->body_imat.resize(9 * nb);
   for (int b = 0; b < nb; ++b) quat2mat_h(&body_iquat[4 * b], &m->body_imat[9 * b]);

@@ -140,8 +140,35 @@ def collision_pairs(m: MjbModel):
     excluded = set(int(x) for x in np.asarray(m.arrays.get("exclude_signature", [])).reshape(-1))
     filterparent = not (int(m.opt.get("disableflags", 0)) & DSBL_FILTERPARENT)
     pairs, dropped = [], []
+
+    def emit(a, b, xp):
+        ta, tb = int(m.geom_type[a]), int(m.geom_type[b])
+        if ta > tb:
+            a, b, ta, tb = b, a, tb, ta                       # MuJoCo orders a pair by geom type
+        if (ta, tb) == (GEOM_PLANE, GEOM_PLANE):
+            return
+        if (ta, tb) == (GEOM_BOX, GEOM_BOX):
+            pairs.extend((a, b, 1 + v, xp) for v in range(17))   # sub = 1 + v: vertex v of a vs b; 9 + v: vertex v of b vs a; 17: the edge-edge candidate
+        elif (ta, tb) in SUPPORTED_PAIRS:
+            pairs.append((a, b, 0, xp))
+        else:
+            dropped.append((a, b))
+
+    # explicit <contact><pair> entries (mj_collision runs them first; no contype / conaffinity / parent / exclude filtering applies to
+    # them, and a dynamic pair of the same two geoms is skipped): opt.collision 0 = all, 1 = predefined only, 2 = dynamic only
+    col = int(m.opt.get("collision", 0))
+    explicit = set()
+    npair = int(m.sizes.get("npair", 0)) if col != 2 else 0
+    for k in range(npair):
+        a, b = int(m.arrays["pair_geom1"][k]), int(m.arrays["pair_geom2"][k])
+        explicit.add((min(a, b), max(a, b)))
+        emit(a, b, k)
+    if col == 1:
+        return pairs, dropped
     for g1 in range(ng):
         for g2 in range(g1 + 1, ng):
+            if (g1, g2) in explicit:
+                continue
             b1, b2 = int(gb[g1]), int(gb[g2])
             w1, w2 = int(weld[b1]), int(weld[b2])
             if w1 == w2:
@@ -155,17 +182,7 @@ def collision_pairs(m: MjbModel):
             ct2, ca2 = int(m.geom_contype[g2]), int(m.geom_conaffinity[g2])
             if not ((ct1 & ca2) or (ct2 & ca1)):
                 continue
-            t1, t2 = int(m.geom_type[g1]), int(m.geom_type[g2])
-            a, b = (g1, g2) if t1 <= t2 else (g2, g1)  # MuJoCo orders a pair by geom type
-            key = (min(t1, t2), max(t1, t2))
-            if key == (GEOM_PLANE, GEOM_PLANE):
-                continue
-            if key == (GEOM_BOX, GEOM_BOX):
-                pairs += [(a, b, 1 + v) for v in range(17)]      # sub = 1 + v: vertex v of a vs b; 9 + v: vertex v of b vs a; 17: the edge-edge candidate
-            elif key in SUPPORTED_PAIRS:
-                pairs.append((a, b, 0))
-            else:
-                dropped.append((a, b))
+            emit(g1, g2, -1)
     return pairs, dropped
 
 
@@ -193,10 +210,19 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
         raise ModelError("contact dimensions (condim) other than 1, 3, 4, 6 do not exist in MuJoCo")
     # what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored
     col = int(m.opt.get("collision", 0))
-    if col == 1:
-        raise ModelError("opt.collision = 'predefined' (explicit <pair> contacts only) is not supported")
-    if int(m.sizes.get("npair", 0)) > 0 and col != 2:
-        raise ModelError("explicit contact pairs (<contact><pair>) are not supported")
+    npair_x = int(m.sizes.get("npair", 0)) if col != 2 else 0
+    for name, w in (("pair_geom1", 1), ("pair_geom2", 1), ("pair_dim", 1), ("pair_solref", 2), ("pair_solimp", 5), ("pair_margin", 1), ("pair_gap", 1),
+                    ("pair_friction", 5)):
+        if npair_x and np.asarray(m.arrays.get(name, [])).size < npair_x * w:
+            raise ModelError(f"npair = {npair_x} but {name} holds {np.asarray(m.arrays.get(name, [])).size} values")
+    for k in range(npair_x):
+        if not (0 <= int(m.arrays["pair_geom1"][k]) < m.ngeom and 0 <= int(m.arrays["pair_geom2"][k]) < m.ngeom):
+            raise ModelError(f"explicit contact pair {k} names a geom out of range")
+        fr = np.asarray(m.arrays["pair_friction"]).reshape(-1, 5)[k]
+        if fr[0] != fr[1] or fr[3] != fr[4]:
+            raise ModelError(f"explicit contact pair {k}: anisotropic friction ({fr.tolist()}) is not supported")
+        if int(m.arrays["pair_dim"][k]) not in (1, 3, 4, 6):
+            raise ModelError(f"explicit contact pair {k}: condim {int(m.arrays['pair_dim'][k])}")
     dis, enb = int(m.opt.get("disableflags", 0)), int(m.opt.get("enableflags", 0))
     if dis & ~(DSBL_FILTERPARENT | DSBL_REFSAFE):
         raise ModelError(f"opt.disableflags = {dis:#x}: only filterparent and refsafe can be disabled in this stepper")
@@ -236,10 +262,18 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
            (GEOM_SPHERE, GEOM_BOX), (GEOM_CAPSULE, GEOM_CAPSULE)}
     is_std = lambda pr: (int(m.geom_type[pr[0]]), int(m.geom_type[pr[1]])) in std
     pairs = [pr for pr in pairs if is_std(pr)] + [pr for pr in pairs if not is_std(pr)]      # the stepper runs the primitive pairs first
-    pa = np.array(pairs, np.int32).reshape(-1, 3)
+    pa = np.array(pairs, np.int32).reshape(-1, 4)
     f["x_pair_geom1"] = np.ascontiguousarray(pa[:, 0])
     f["x_pair_geom2"] = np.ascontiguousarray(pa[:, 1])
     f["x_pair_sub"] = np.ascontiguousarray(pa[:, 2])
+    # explicit <pair> parameters (mj_contactParam takes them instead of mixing the two geoms'): per pair ROW the index of its explicit
+    # entry (-1: a dynamic pair), and the entries: condim, margin, gap, solref, solimp, friction (sliding, torsional, rolling)
+    f["x_pair_explicit"] = np.ascontiguousarray(pa[:, 3])
+    f["x_xp_dim"] = np.asarray(m.arrays["pair_dim"][:npair_x], np.int32).reshape(-1) if npair_x else np.zeros(0, np.int32)
+    xf = (lambda name, w: np.asarray(m.arrays[name], np.float64).reshape(-1, w)[:npair_x].reshape(-1) if npair_x else np.zeros(0))
+    f["x_xp_margin"], f["x_xp_gap"] = xf("pair_margin", 1), xf("pair_gap", 1)
+    f["x_xp_solref"], f["x_xp_solimp"] = xf("pair_solref", 2), xf("pair_solimp", 5)
+    f["x_xp_friction"] = (np.asarray(m.arrays["pair_friction"], np.float64).reshape(-1, 5)[:npair_x][:, [0, 2, 3]].reshape(-1) if npair_x else np.zeros(0))
     # wrapping side sites that sit inside their wrap geom would need MuJoCo's inside-wrap
     # Newton iteration; not implemented.
     for t in range(m.ntendon):

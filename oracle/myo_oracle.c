@@ -35,6 +35,9 @@ struct OrcModel {
       *site_bodyid, *tendon_adr, *tendon_num, *tendon_limited, *wrap_type, *wrap_objid,
       *actuator_trntype, *actuator_dyntype, *actuator_gaintype, *actuator_biastype,
       *actuator_trnid, *actuator_ctrllimited, *actuator_forcelimited, *pair_geom1, *pair_geom2, *pair_sub;
+  /* explicit <contact><pair> entries (optional blob fields): per pair row the entry's index (-1: a dynamic pair); the entries */
+  const int *pair_explicit, *xp_dim;
+  const double *xp_margin, *xp_gap, *xp_solref, *xp_solimp, *xp_friction;
   const double *qpos0, *qpos_spring, *body_pos, *body_quat, *body_ipos, *body_iquat, *body_mass,
       *body_inertia, *body_invweight0, *jnt_solref, *jnt_solimp, *jnt_pos, *jnt_axis,
       *jnt_stiffness, *jnt_range, *jnt_margin, *dof_armature, *dof_damping, *dof_invweight0,
@@ -224,6 +227,11 @@ OrcModel* orc_model_from_blob(const void* src, size_t nbytes, char* err, int err
   m->pair_geom1 = (const int*)(base + p1->offset);
   m->pair_geom2 = (const int*)(base + p2->offset);
   { const myo_blob_field* ps = blob_find(m->blob, "x_pair_sub"); m->pair_sub = (ps && ps->count == p1->count) ? (const int*)(base + ps->offset) : NULL; }
+  { const myo_blob_field* px = blob_find(m->blob, "x_pair_explicit"); m->pair_explicit = (px && px->dtype == MYO_BLOB_I32 && px->count == p1->count) ? (const int*)(base + px->offset) : NULL;
+    const myo_blob_field* xd = blob_find(m->blob, "x_xp_dim"); m->xp_dim = (xd && xd->dtype == MYO_BLOB_I32) ? (const int*)(base + xd->offset) : NULL; }
+#define GETD_X(n, field) do { const myo_blob_field* f = blob_find(m->blob, field); m->n = (f && f->dtype == MYO_BLOB_F64) ? (const double*)(base + f->offset) : NULL; } while (0)
+  GETD_X(xp_margin, "x_xp_margin"); GETD_X(xp_gap, "x_xp_gap"); GETD_X(xp_solref, "x_xp_solref"); GETD_X(xp_solimp, "x_xp_solimp"); GETD_X(xp_friction, "x_xp_friction");
+  if (!m->xp_dim || !m->xp_margin || !m->xp_gap || !m->xp_solref || !m->xp_solimp || !m->xp_friction) m->pair_explicit = NULL;
   return m;
 }
 
@@ -1080,6 +1088,8 @@ static void collision(const OrcModel* m, OrcData* d) {
     double mg1 = m->geom_margin[g1], mg2 = m->geom_margin[g2];
     double margin = mg1 > mg2 ? mg1 : mg2;
     double gap = m->geom_gap[g1] > m->geom_gap[g2] ? m->geom_gap[g1] : m->geom_gap[g2];
+    int xp = m->pair_explicit ? m->pair_explicit[p] : -1;
+    if (xp >= 0) { margin = m->xp_margin[xp]; gap = m->xp_gap[xp]; }      /* an explicit <pair>: its own margin and gap */
     /* bounding-sphere filter with the MODEL's rbound: the reference rewrites geom_size per
      * episode without refreshing rbound (baoding.py:586-604), so the stale value gates contacts */
     double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
@@ -1097,6 +1107,12 @@ static void collision(const OrcModel* m, OrcData* d) {
       memcpy(c->frame, nrm+3*k, 3*sizeof(double)); make_frame(c->frame);
       c->includemargin = margin - gap; c->geom1 = g1; c->geom2 = g2;
       mix_params(m, d, g1, g2, c);
+      if (xp >= 0) {                       /* mj_contactParam for a predefined pair: the pair's parameters, nothing mixed */
+        memcpy(c->solref, m->xp_solref + 2*xp, 2*sizeof(double)); memcpy(c->solimp, m->xp_solimp + 5*xp, 5*sizeof(double));
+        const double* f = m->xp_friction + 3*xp;
+        c->friction[0] = f[0]; c->friction[1] = f[0]; c->friction[2] = f[1]; c->friction[3] = f[2]; c->friction[4] = f[2];
+        c->dim = m->xp_dim[xp];
+      }
     }
   }
 }

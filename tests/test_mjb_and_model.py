@@ -227,15 +227,27 @@ def test_exclude_pairs_filterparent_and_refused_options(models, emu_lib, tmp_pat
     assert len(cm2.x_pair_geom1) + len(cm2.dropped_pairs) > n_filtered
     assert c_route(fp2, unsupported_contacts="drop").size("npair") == len(cm2.x_pair_geom1)
     # refused
-    for bad in (_with(hand, opt_collision=1), _with(hand, npair=1), _with(hand, opt_disableflags=1 << 4), _with(hand, opt_enableflags=1)):
+    for bad in (_with(hand, npair=1), _with(hand, opt_disableflags=1 << 4), _with(hand, opt_enableflags=1)):        # (npair without its arrays)
         with pytest.raises(ModelError):
             compile_model(bad)
-    for bad in (_with(hand, opt_collision=1), _with(hand, opt_disableflags=1 << 4), _with(hand, opt_enableflags=1),
-                _with(hand, pair_dim=np.zeros(1, np.int32), pair_geom1=np.zeros(1, np.int32), pair_geom2=np.ones(1, np.int32),
+    for bad in (_with(hand, opt_disableflags=1 << 4), _with(hand, opt_enableflags=1),
+                _with(hand, pair_dim=np.full(1, 3, np.int32), pair_geom1=np.zeros(1, np.int32), pair_geom2=np.ones(1, np.int32),
                       pair_signature=np.zeros(1, np.int32), pair_solref=np.zeros((1, 2)), pair_solimp=np.zeros((1, 5)), pair_margin=np.zeros(1),
-                      pair_gap=np.zeros(1), pair_friction=np.zeros((1, 5)), name_pairadr=np.zeros(1, np.int32))):
+                      pair_gap=np.zeros(1), pair_friction=np.array([[1.0, 0.5, 0.0, 0.0, 0.0]]), name_pairadr=np.zeros(1, np.int32), npair=1)):      # anisotropic friction
         with pytest.raises(native.MyoError, match="not supported|can be disabled"):
             c_route(bad)
+    # explicit <contact><pair> entries (round 4): the pair replaces the dynamic pair of its two geoms; opt.collision = predefined keeps only them
+    g_ball = hand.names["geom"].index("ball1")
+    g_other = next(int(b if a == g_ball else a) for a, b in pairs if g_ball in (a, b))
+    xp = _with(hand, pair_dim=np.full(1, 4, np.int32), pair_geom1=np.array([g_ball], np.int32), pair_geom2=np.array([g_other], np.int32),
+               pair_signature=np.zeros(1, np.int32), pair_solref=np.array([[0.01, 1.0]]), pair_solimp=np.array([[0.8, 0.9, 0.002, 0.5, 2.0]]),
+               pair_margin=np.array([0.003]), pair_gap=np.zeros(1), pair_friction=np.array([[0.7, 0.7, 0.01, 0.002, 0.002]]),
+               name_pairadr=np.zeros(1, np.int32), npair=1)
+    cmx = compile_model(xp)
+    assert len(cmx.x_pair_geom1) == len(pairs) and list(cmx.x_pair_explicit).count(0) == 1 and list(cmx.x_xp_dim) == [4]
+    assert c_route(xp).size("npair") == len(pairs)
+    only = compile_model(_with(xp, opt_collision=1))
+    assert len(only.x_pair_geom1) == 1 and c_route(_with(xp, opt_collision=1)).size("npair") == 1
 
 
 def test_c_loader_rejects_corrupt_files(models, emu_lib, golden_dir, tmp_path):

@@ -510,3 +510,59 @@ def test_friction_loss_on_emulation(emu_lib):
 def test_friction_loss_on_gpu(hip_lib):
     case_friction_loss(hip_lib, native.MYO_F64, 1e-9)
     case_friction_loss(hip_lib, native.MYO_MIXED, 1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------- explicit <pair>s
+def case_explicit_pair(lib, dtype, tol):
+    """An explicit <contact><pair> replaces the dynamic pair of its two geoms and brings its own margin / gap / solref / solimp / friction /
+    condim (mj_contactParam).  A condim-4 pair between the plane and the condim-3 sphere of `condim_model`: the contact appears at the
+    PAIR's margin, has 6 rows, its reference acceleration and regulariser follow the pair's solref / solimp / friction — closed forms as in
+    tests/test_oracle_closed_forms.py — and the stepper agrees with the oracle."""
+    mem = Mem(lib)
+    m = condim_model(condims=(3,), friction=(0.8, 0.02, 0.004))
+    solref, solimp, margin, fr = (0.01, 1.0), (0.8, 0.9, 0.002, 0.5, 2.0), 0.004, (0.6, 0.03, 0.001)
+    m.sizes["npair"] = 1
+    m.arrays.update(pair_dim=np.full(1, 4, np.int32), pair_geom1=np.array([0], np.int32), pair_geom2=np.array([1], np.int32),
+                    pair_signature=np.zeros(1, np.int32), pair_solref=np.array([solref]), pair_solimp=np.array([solimp]),
+                    pair_margin=np.array([margin]), pair_gap=np.zeros(1), pair_friction=np.array([[fr[0], fr[0], fr[1], fr[2], fr[2]]]))
+    cm = compile_model(m)
+    assert list(cm.x_pair_explicit) == [0]
+    om = OracleModel(cm.to_blob())
+    mass = 0.1
+    for gap_to_plane in (0.003, -0.0005):                    # inside the pair's margin (the geoms' is 0.001) / penetrating
+        q = np.array([0, 0, 0.05 + gap_to_plane, 1, 0, 0, 0.0])
+        v = np.array([0.1, 0, -0.2, 0, 0, 3.0])
+        d = OracleData(om)
+        d.qpos[:], d.qvel[:] = q, v
+        d.forward()
+        assert (d.ncon, d.nefc) == (1, 6), (gap_to_plane, d.ncon, d.nefc)
+        r = gap_to_plane - margin                            # pos - margin
+        x = min(1.0, abs(r) / solimp[2])
+        y = x ** 2 / 0.5 if x <= 0.5 else 1 - (1 - x) ** 2 / 0.5
+        imp = solimp[0] + y * (solimp[1] - solimp[0])
+        tc = max(solref[0], 2 * 0.002)                       # refsafe: time constant >= 2 timesteps
+        k, b = 1 / (solimp[1] ** 2 * tc ** 2), 2 / (solimp[1] * tc)
+        R0 = (1 - imp) / imp * (1 / mass) * (1 + fr[0] ** 2)
+        D = 1 / (2 * fr[0] ** 2 * R0)
+        assert np.allclose(np.array(d.efc_D)[:6], D, rtol=1e-12)
+        aref = np.array(d.efc_aref)[:6]
+        # rows: n +- mu t1, n +- mu t2, n +- mu_torsion (spin about n); J v: normal -0.2, tangential components of (0.1, 0, 0), spin 3
+        assert abs(0.5 * (aref[4] + aref[5]) - (-b * (-0.2) - k * imp * r)) <= 1e-9 * abs(aref[4])
+        assert abs(abs(aref[4] - aref[5]) - 2 * b * fr[1] * 3.0) <= 1e-9 * abs(aref[4])
+        get, bt = forward_dump(lib, mem, cm, q, v, np.zeros(0), np.zeros(0), dtype)
+        cnt = get("counts", 4)
+        assert (int(cnt[0]), int(cnt[1])) == (1, 6)
+        assert rel_err(get("efc_aref", 6), aref) < tol and rel_err(get("efc_D", 6), np.array(d.efc_D)[:6]) < tol
+        assert rel_err(get("qacc", om.nv), d.qacc) < tol
+        bt.close()
+
+
+def test_explicit_pair_on_emulation(emu_lib):
+    case_explicit_pair(emu_lib, native.MYO_F64, 1e-9)
+    case_explicit_pair(emu_lib, native.MYO_MIXED, 1e-4)
+
+
+@pytest.mark.gpu
+def test_explicit_pair_on_gpu(hip_lib):
+    case_explicit_pair(hip_lib, native.MYO_F64, 1e-9)
+    case_explicit_pair(hip_lib, native.MYO_MIXED, 1e-4)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30_000_000)
     ap.add_argument("--eval-episodes", type=int, default=512)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "mixed"], help="stepper arithmetic (f64: the bench headline since round 4)")
     a = ap.parse_args()
     import torch
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
@@ -33,8 +34,8 @@ def main():
     if "Reorient" in a.env_name:      # the reward shaping of src/main_reorient.py:27-37
         cfgs = {"weighted_reward_keys": {"pos_dist": 0.5, "rot_dist": 0.02, "pos_dist_diff": 50, "rot_dist_diff": 5, "alive": 0.1,
                                          "act_reg": 0, "solved": 0.5, "done": 0, "sparse": 0}}
-    env = EnvironmentFactory.create(a.env_name, num_envs=a.envs, seed=1, **cfgs)
-    eval_env = EnvironmentFactory.create(a.env_name, num_envs=512, seed=999, **cfgs)
+    env = EnvironmentFactory.create(a.env_name, num_envs=a.envs, seed=1, dtype=a.dtype, **cfgs)
+    eval_env = EnvironmentFactory.create(a.env_name, num_envs=512, seed=999, dtype=a.dtype, **cfgs)
     venv = VecNormalize(env, gamma=0.99)
     torch.manual_seed(0)
     pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=None, log_std_init=-2.0)

@@ -1,0 +1,148 @@
+"""Hand-derived minibatch step of recurrent PPO (LSTM actor + LSTM critic -> MLP trunks -> heads).
+
+The policy class the reference trains (``RecurrentPPO`` with ``lstm_hidden_size`` + ``net_arch``:
+/root/reference/src/train/trainer.py:49-71, /root/reference/src/main_reorient.py:53-71).  Same loss and the same
+minibatches as ``PPO._rec_forward_backward`` (whole rollouts of a subset of envs, LSTM state of the rollout start,
+state zeroed where an episode starts — sb3-contrib ``_process_sequence``), without autograd and
+without autocast: under those two the step is ~480 launches, two thirds of them casts, gradient adds and copies
+around ~150 that do the work.  Here
+
+* the minibatch is gathered by ``myo_ppo_gather`` (bf16 observations, advantage moments), one GEMM projects the
+  inputs of both LSTMs for all time steps;
+* a time step is the batched recurrent GEMM + ``myo_lstm_cell_fwd`` / ``myo_lstm_cell_bwd`` (as ``rl/policy.py:_LstmSeq``);
+* trunks, heads, loss and their backward pass are ``FusedPPOStep._merged_core`` on the LSTM outputs, which also
+  returns the gradient entering the LSTMs;
+* LSTM weight gradients are per-time-step batched GEMMs reduced in fp32 by ``myo_splitk_reduce`` (the bias
+  gradient rides along as a ones column of the input), written straight into the flat gradient vector.
+
+Every gradient slot is overwritten (no zeroing pass); clip + Adam follow as ``FlatAdam.step``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .fused_mlp import FusedPPOStep
+
+
+class FusedRecurrentPPOStep(FusedPPOStep):
+    """bf16 storage, fp32 accumulation; all shapes static (captured in a hipGraph by ``PPO._build_recurrent_graphs``)."""
+
+    @classmethod
+    def create(cls, policy, lib, clip_range, ent_coef, vf_coef):
+        """None when the parameter layout has no stacked actor/critic views (odd sizes) — the caller keeps autograd."""
+        if not policy.recurrent or getattr(policy, "use_sde", False) or getattr(policy, "_flat", None) is None:
+            return None
+        la, lc = policy.lstm_actor, policy.lstm_critic
+        if lc is None or la.hidden_size != lc.hidden_size or la.hidden_size % 16:
+            return None
+        self = cls(policy, lib, clip_range, ent_coef, vf_coef)
+        if self.merged is None or not self.merged:
+            return None
+        self.lstm = self._lstm_views(policy._flat, self.half[0])
+        return self if self.lstm is not None else None
+
+    def _lstm_views(self, flat, hflat):
+        """[2, ...] views (actor, critic) over adjacent slots of the four LSTM parameters: bf16 shadow + fp32 gradient."""
+        la, lc = self.policy.lstm_actor, self.policy.lstm_critic
+        slot = {id(p): sl for p, sl in zip(flat["params"], flat["slots"])}
+        out = {}
+        for key in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+            pa, pb = getattr(la, key), getattr(lc, key)
+            (oa, k), (ob, _) = slot[id(pa)], slot[id(pb)]
+            if pa.shape != pb.shape or ob != oa + k:
+                return None
+            shape = (2,) + tuple(pa.shape)
+            short = key.split("_")[0][0] + key.split("_")[1]          # wih whh bih bhh
+            out[short + "h"] = hflat[oa:oa + 2 * k].view(shape)
+            out[short + "g"] = flat["g"][oa:oa + 2 * k].view(shape)
+        return out
+
+    def _static(self, key, shape, dtype, fill=None):
+        """Buffers that live across calls (a captured graph keeps their addresses)."""
+        t = self._work.get((key, shape, dtype))
+        if t is None:
+            t = torch.zeros(shape, dtype=dtype, device=self.acc.device) if fill is None else \
+                torch.full(shape, fill, dtype=dtype, device=self.acc.device)
+            self._work[(key, shape, dtype)] = t
+        return t
+
+    @torch.no_grad()
+    def run_sequences(self, obs_buf, act_buf, start_buf, logp_buf, adv, ret, h0, c0, idx):
+        """One minibatch step on the whole-rollout sequences of envs `idx`.
+
+        obs_buf [T,N,O], act_buf [T,N,A], start_buf / logp_buf / adv / ret [T,N] (float32), h0 / c0 [2,N,H] float32
+        (actor, critic LSTM state at the rollout start), idx int64 [m].  Returns (policy loss, value loss) as views of
+        the loss kernel's accumulator."""
+        lib, L = self.lib, self.lstm
+        if self.adam is not None:
+            self.adam.presummed = 0
+        T, N, O = obs_buf.shape
+        m, A = idx.shape[0], self.A
+        B, H = T * m, self.policy.lstm_actor.hidden_size
+        dev, bf = obs_buf.device, torch.bfloat16
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        if not self.adam_syncs_shadow:
+            self.refresh_shadow()
+        # ---- gather: rows (t, idx[j]) of the [T*N] rollout arrays, t-major
+        trow = self._work.get(("trow", T, N))
+        if trow is None:
+            trow = self._work[("trow", T, N)] = (torch.arange(T, device=dev) * N).view(T, 1)
+        ridx = (trow + idx.view(1, m)).reshape(B)
+        x = torch.empty((1, B, O), device=dev, dtype=bf)
+        act, oldlp = torch.empty((B, A), device=dev), torch.empty(B, device=dev)
+        adv_mb, ret_mb = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        work = self._workbuf("gather", 2 * ((B + 15) // 16))
+        lib.check(lib.L.myo_ppo_gather(p(obs_buf), p(act_buf), p(logp_buf), p(adv), p(ret), p(ridx), B, O, A, p(x), 1, p(act), p(oldlp),
+                                       p(adv_mb), p(ret_mb), None if self.external_adv_stats else p(self.stats), p(work), st))
+        keep = torch.rsub(start_buf.reshape(T * N).index_select(0, ridx), 1.0).view(T, m)       # 0 where an episode starts
+        G, H4 = 2, 4 * H
+        hm = torch.empty((T + 1, G, m, H), dtype=bf, device=dev)         # masked state entering step t
+        cm = torch.empty_like(hm)
+        k0 = keep[0].view(1, m, 1)
+        torch.mul(h0.index_select(1, idx), k0, out=hm[0])
+        torch.mul(c0.index_select(1, idx), k0, out=cm[0])
+        # ---- input projections of both LSTMs, all time steps: [B, O] x [O, 2*4H]
+        bsum = (L["bihh"] + L["bhhh"]).view(G * H4)
+        gx = torch.addmm(bsum, x[0], L["wihh"].view(G * H4, O).t())
+        gx = gx.view(T, m, G, H4).transpose(1, 2).contiguous()           # [T, G, m, 4H]: a step's rows are r = g*m + n
+        wt = L["whhh"].transpose(1, 2).contiguous()                      # [G, H, 4H]
+        out, cn = torch.empty((T, G, m, H), dtype=bf, device=dev), torch.empty((T, G, m, H), dtype=bf, device=dev)
+        ws = torch.empty((T, G, m, H4), dtype=bf, device=dev)
+        for t in range(T):
+            gh = torch.bmm(hm[t], wt)
+            lib.check(lib.L.myo_lstm_cell_fwd(p(gx[t]), p(gh), p(cm[t]), p(keep[t + 1]) if t + 1 < T else None, G * m, m, H, 1,
+                                              p(out[t]), p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+        # ---- trunks, heads, loss, and back down to the LSTM outputs
+        lat = out.transpose(0, 1).contiguous().view(G, B, H)
+        pl, vl, dlat = self._merged_core(lat, act, oldlp, adv_mb, ret_mb, want_dx=True)
+        dout = dlat.view(G, T, m, H).transpose(0, 1).contiguous()
+        # ---- BPTT
+        dG = torch.empty((T, G, m, H4), dtype=bf, device=dev)
+        dcm = torch.empty((2, G, m, H), dtype=bf, device=dev)            # ping-pong: gradient of cm[t]
+        whh = L["whhh"]                                                  # [G, 4H, H]: dh_prev = dgates . W_hh
+        dhm = dcn = None
+        for t in range(T - 1, -1, -1):
+            lib.check(lib.L.myo_lstm_cell_bwd(p(dout[t]), p(dhm), p(dcn), p(keep[t + 1]) if t + 1 < T else None, p(cm[t]), p(cn[t]),
+                                              p(ws[t]), G * m, m, H, 1, p(dG[t]), p(dcm[t & 1]), st))
+            if t > 0:
+                dhm, dcn = torch.bmm(dG[t], whh), dcm[t & 1]
+        # ---- LSTM weight gradients: per-time-step partial products (batch = (t, g)), summed over t in fp32
+        Op = (O + 1 + 7) // 8 * 8                                        # inputs + a ones column (bias gradient) + zero padding
+        xe = self._static("xe", (T * G, m, Op), bf)
+        if not self._work.get(("xe_init", T, m, Op)):
+            xe[..., O] = 1.0
+            self._work[("xe_init", T, m, Op)] = True
+        xe.view(T, G, m, Op)[..., :O].copy_(x.view(T, 1, m, O).expand(T, G, m, O))
+        dGt = dG.view(T * G, m, H4).transpose(1, 2)
+        part_hh = torch.bmm(dGt, hm[:T].view(T * G, m, H))               # [T*G, 4H, H]
+        self._reduce(part_hh, L["whhg"], 1, T)
+        part_ih = torch.bmm(dGt, xe)                                     # [T*G, 4H, Op]
+        gih = self._static("gih", (G, H4, Op), torch.float32)
+        self._reduce(part_ih, gih, 1, T)
+        L["wihg"].copy_(gih[..., :O])
+        L["bihg"].copy_(gih[..., O])
+        L["bhhg"].copy_(L["bihg"])
+        return pl, vl

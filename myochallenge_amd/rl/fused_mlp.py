@@ -112,14 +112,18 @@ def flatten_parameters(policy, pad: int = 64):
     if getattr(policy, "_flat", None) is not None:
         return policy._flat
     params = list(policy.parameters())
-    if not policy.recurrent:             # interleave actor / critic trunk layers: adjacent slots -> stacked [2,out,in] views
-        pi, vf = _layers(policy.mlp_extractor.policy_net), _layers(policy.mlp_extractor.value_net)
-        if len(pi) == len(vf) and all(a.weight.shape == b.weight.shape for a, b in zip(pi, vf)):
-            lead = []
-            for a, b in zip(pi, vf):
-                lead += [a.weight, b.weight, a.bias, b.bias]
-            ids = {id(p) for p in lead}
-            params = lead + [p for p in params if id(p) not in ids]
+    # interleave actor / critic trunk layers (and the two LSTMs of a recurrent policy): adjacent slots -> stacked [2,out,in] views
+    pi, vf = _layers(policy.mlp_extractor.policy_net), _layers(policy.mlp_extractor.value_net)
+    lead = []
+    if len(pi) == len(vf) and all(a.weight.shape == b.weight.shape for a, b in zip(pi, vf)):
+        for a, b in zip(pi, vf):
+            lead += [a.weight, b.weight, a.bias, b.bias]
+    la, lc = getattr(policy, "lstm_actor", None), getattr(policy, "lstm_critic", None)
+    if policy.recurrent and lc is not None and la.hidden_size == lc.hidden_size:
+        for key in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+            lead += [getattr(la, key), getattr(lc, key)]
+    ids = {id(p) for p in lead}
+    params = lead + [p for p in params if id(p) not in ids]
     dev = params[0].device
     slots, n = [], 0
     for p in params:
@@ -185,7 +189,6 @@ class FusedPPOStep:
     sequence can be captured in a hipGraph."""
 
     def __init__(self, policy, lib, clip_range, ent_coef, vf_coef, split_k=64):
-        assert not policy.recurrent
         self.policy, self.lib = policy, lib
         self.clip, self.ent, self.vf, self.split = float(clip_range), float(ent_coef), float(vf_coef), split_k
         self.adam_syncs_shadow = False
@@ -230,7 +233,7 @@ class FusedPPOStep:
         (then the GEMM-per-layer path below runs).  The descriptor and its workspace are cached: hipGraph-safe."""
         from .. import native
         flat = getattr(self.policy, "_flat", None)
-        if not self.use_mfma_step or flat is None or self.merged is None or len(self.merged) != 2:
+        if not self.use_mfma_step or flat is None or self.merged is None or len(self.merged) != 2 or self.policy.recurrent:
             return None
         pi, vf = self.nets["pi"], self.nets["vf"]
         O = obs_all.shape[1]
@@ -281,7 +284,7 @@ class FusedPPOStep:
         images it reads and has to run after every parameter change."""
         from .. import native
         flat = getattr(self.policy, "_flat", None)
-        if not self.use_mfma_step or flat is None or self.merged is None or len(self.merged) != 2:
+        if not self.use_mfma_step or flat is None or self.merged is None or len(self.merged) != 2 or self.policy.recurrent:
             return None
         pi, vf = self.nets["pi"], self.nets["vf"]
         N, O = obs.shape
@@ -479,9 +482,10 @@ class FusedPPOStep:
         value_h = torch.addmm(self.wb[id(vf_head.bias)], h[1], self.wb[id(vf_head.weight)].t())
         return saved, mean_h, value_h
 
-    def _merged_core(self, x2, actions, old_logp, adv, returns):
+    def _merged_core(self, x2, actions, old_logp, adv, returns, want_dx=False):
         """Actor and critic trunks as ONE batched GEMM per layer (batch = net), heads separate.
-        x2: bf16 [2, B, obs_dim] (the same minibatch twice); self.stats holds the advantage moments."""
+        x2: bf16 [2, B, in] (the same minibatch twice, or the two LSTM outputs of a recurrent policy); self.stats holds
+        the advantage moments.  want_dx: also return d(loss)/d(x2) (bf16 [2, B, in])"""
         pol, L = self.policy, self.merged
         B, A = x2.shape[1], self.A
         s = self.split if (B % self.split == 0) else 1
@@ -522,8 +526,10 @@ class FusedPPOStep:
                 if bias_part is not None:
                     self._reduce(bias_part, lay["bg"], 2, B // 32)
                 self._reduce(part, lay["wg"], 2, s)
-            if li > 0:
+            if li > 0 or want_dx:
                 dh = torch.bmm(dh, lay["wh"])
+        if want_dx:
+            return acc[A], acc[A + 1], dh
         return acc[A], acc[A + 1]
 
     @torch.no_grad()

@@ -95,6 +95,7 @@ class PPO:
         self._graph = None
         self._t_host = 0
         self._fused = None
+        self._fused_rec = None
         self._flat_adam = None
         sde = getattr(policy, "use_sde", False)
         if cfg.use_graphs and on_gpu and not policy.recurrent and not sde:
@@ -116,6 +117,14 @@ class PPO:
             from .fused_mlp import FlatAdam, flatten_parameters
             self._flat_adam = FlatAdam(flatten_parameters(self.policy), native.load(), cfg.learning_rate,
                                        cfg.max_grad_norm)
+            if cfg.bf16 and os.environ.get("MYO_RECURRENT_AUTOGRAD") != "1":
+                # hand-derived minibatch step (rl/fused_lstm.py); None when the layout has no stacked actor/critic views
+                from .fused_lstm import FusedRecurrentPPOStep
+                self._fused_rec = FusedRecurrentPPOStep.create(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
+                if self._fused_rec is not None:          # one bf16 shadow of the flat vector, kept in step by the Adam kernel
+                    self._flat_adam.shadow = self._fused_rec.half[0]
+                    self._fused_rec.adam_syncs_shadow = True
+                    self._fused_rec.refresh_shadow()
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if self._fused is not None and self._flat_adam is not None and self.world == 1 and os.environ.get("MYO_ADAM_SEPARATE") != "1":
             self._fused.adam = self._flat_adam   # nothing is exchanged between gradient and clip: the fused step also squares the gradient
@@ -585,6 +594,11 @@ class PPO:
     def _rec_forward_backward(self):
         g = self._rg
         idx = g["idx"]
+        if self._fused_rec is not None:
+            pl, vl = self._fused_rec.run_sequences(self.obs_buf, self.act_buf, self.start_buf, self.logp_buf, g["adv"], g["ret"],
+                                                   g["h0"], g["c0"], idx)
+            g["pl"], g["vl"] = pl, vl             # views of the loss kernel's accumulator
+            return
         self._flat_grad.zero_()
         st0 = tuple(x.index_select(1, idx) for x in g["state0"])
         sel = lambda buf: buf.index_select(1, idx)
@@ -600,6 +614,9 @@ class PPO:
         self._rg = {"idx": torch.arange(m, device=d), "state0": tuple(torch.zeros_like(x) for x in self._rollout_state0),
                     "adv": torch.zeros((T, N), device=d), "ret": torch.zeros((T, N), device=d),
                     "pl": torch.zeros((), device=d), "vl": torch.zeros((), device=d)}
+        if self._fused_rec is not None:           # stacked (actor, critic) LSTM state of the rollout start
+            H = self.policy.hidden
+            self._rg["h0"], self._rg["c0"] = torch.zeros((2, N, H), device=d), torch.zeros((2, N, H), device=d)
         side = torch.cuda.Stream(device=d)
         side.wait_stream(torch.cuda.current_stream(d))
         snap = self._flat_adam.snapshot()
@@ -623,22 +640,47 @@ class PPO:
         self._flat_adam.restore(snap)
         self._rgraph = (T, N, m)
 
-    def _train_recurrent_graphed(self, adv, ret):
-        """Same minibatches as the eager recurrent path (whole rollouts of a random subset of envs, LSTM state of
-        the rollout start), replayed from a graph: BPTT over n_steps is thousands of small launches."""
+    def _rec_stage(self, adv, ret, T, N, m):
+        """Graphs for this shape (built on first use) and the update's inputs copied into their static tensors."""
         cfg = self.cfg
-        T, N = cfg.n_steps, self.env.num_envs
-        m = max(1, min(N, cfg.batch_size // T))
+        if self._fused_rec is not None:
+            ext = (cfg.sync_adv_moments and self.world > 1) or not cfg.normalize_advantage
+            if self._fused_rec.external_adv_stats != ext:
+                self._fused_rec.external_adv_stats = ext
+                self._rgraph = None
         if getattr(self, "_rgraph", None) != (T, N, m):
             self._build_recurrent_graphs(T, N, m)
         g = self._rg
         g["adv"].copy_(adv); g["ret"].copy_(ret)
         for dst, src in zip(g["state0"], self._rollout_state0):
             dst.copy_(src)
+        fr = self._fused_rec
+        if fr is not None:
+            fr.refresh_shadow()                   # (parameters may have been loaded since the last update)
+            hp, cp, hv, cv = self._rollout_state0
+            g["h0"][0].copy_(hp[0]); g["h0"][1].copy_(hv[0]); g["c0"][0].copy_(cp[0]); g["c0"][1].copy_(cv[0])
+            if not cfg.normalize_advantage:
+                fr.stats.copy_(torch.tensor([0.0, 1.0], device=self.device))
+        return g
+
+    def _train_recurrent_graphed(self, adv, ret):
+        """Same minibatches as the eager recurrent path (whole rollouts of a random subset of envs, LSTM state of
+        the rollout start), replayed from a graph: BPTT over n_steps is thousands of small launches."""
+        cfg = self.cfg
+        T, N = cfg.n_steps, self.env.num_envs
+        m = max(1, min(N, cfg.batch_size // T))
+        g, fr = self._rec_stage(adv, ret, T, N, m), self._fused_rec
         for _ in range(cfg.n_epochs):
             perm = torch.randperm(N, generator=self.gen, device=self.device)
             for s in range(0, N - m + 1, m):
                 g["idx"].copy_(perm[s:s + m])
+                if fr is not None and fr.external_adv_stats and cfg.normalize_advantage:      # moments of the GLOBAL minibatch
+                    a = g["adv"][:, perm[s:s + m]].double()
+                    mom = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(a.numel()), dtype=torch.float64, device=self.device)])
+                    dist.all_reduce(mom)
+                    mean = mom[0] / mom[2]
+                    std = torch.sqrt(torch.clamp(mom[1] / mom[2] - mean * mean, min=0.0) * mom[2] / (mom[2] - 1))
+                    fr.stats.copy_(torch.stack([mean, std]).float())
                 self._rgraph_fb.replay()
                 if self.world > 1:
                     dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)

@@ -349,10 +349,65 @@ def test_reorient_ppo_lstm_on_gpu(hip_lib):
 
 
 @pytest.mark.gpu
-def test_recurrent_update_graph_matches_eager(hip_lib):
-    """The hipGraph-captured recurrent minibatch step (flat parameters, FlatAdam) == the eager autograd step
-    (torch Adam + clip_grad_norm_) on the same rollout: same losses, same parameters after one update."""
+def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch):
+    """rl/fused_lstm.py (hand-derived LSTM + trunk + loss forward / backward in bf16) against autograd under bf16
+    autocast on the same minibatch of sequences: losses and every parameter's gradient, with episode starts inside
+    the sequences and a non-zero LSTM state at the rollout start."""
     import copy
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig, compute_gae
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    torch.manual_seed(0)
+    N, T, m = 128, 8, 64
+    env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=N, seed=3)
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (64, 64), (64, 64), lstm_hidden_size=32)
+    with torch.no_grad():
+        pol.log_std.fill_(-0.5)
+    pol2 = copy.deepcopy(pol)
+    mk = lambda p: PPO(VecNormalize(env), p, PPOConfig(n_steps=T, batch_size=T * m, n_epochs=1, ent_coef=0.01))
+    a = mk(pol)
+    monkeypatch.setenv("MYO_RECURRENT_AUTOGRAD", "1")
+    b = mk(pol2)
+    assert a._fused_rec is not None and b._fused_rec is None and b._flat_adam is not None
+    a.collect_rollouts(); a.collect_rollouts()                 # second rollout: starts from a non-zero LSTM state
+    a.start_buf[3, ::5] = 1.0; a.start_buf[6, 1::7] = 1.0
+    for name in ("obs_buf", "act_buf", "rew_buf", "val_buf", "logp_buf", "start_buf"):
+        getattr(b, name).copy_(getattr(a, name))
+    b._rollout_state0 = tuple(x.clone() for x in a._rollout_state0)
+    assert float(a._rollout_state0[0].abs().max()) > 0
+    adv, ret = compute_gae(a.rew_buf, a.val_buf, a.start_buf, a._last_values, a._last_starts, 0.99, 0.95)
+    idx = torch.randperm(N, device=a.device)[:m]
+    grads, losses = [], []
+    for algo in (a, b):
+        g = algo._rec_stage(adv, ret, T, N, m)
+        g["idx"].copy_(idx)
+        algo._rec_forward_backward()
+        torch.cuda.synchronize()
+        losses.append((float(g["pl"]), float(g["vl"])))
+        grads.append({n: p.grad.detach().clone() for n, p in algo.policy.named_parameters()})
+    assert abs(losses[0][0] - losses[1][0]) < 2e-3 * (1 + abs(losses[1][0])), losses
+    assert abs(losses[0][1] - losses[1][1]) < 2e-2 * (1 + abs(losses[1][1])), losses
+    for n, gb in grads[1].items():
+        ga = grads[0][n]
+        assert torch.isfinite(ga).all(), n
+        cos = float((ga * gb).sum() / (ga.norm() * gb.norm() + 1e-30))
+        rel = float((ga - gb).norm() / (gb.norm() + 1e-30))
+        assert cos > 0.995 and rel < 0.1, (n, cos, rel, float(gb.norm()))
+    # the captured graph replays the same step: one update moves every parameter group and stays finite
+    before = [p.detach().clone() for p in pol.parameters()]
+    st = a.train()
+    assert np.isfinite(st["policy_loss"]) and np.isfinite(st["value_loss"])
+    assert all(torch.isfinite(p).all() for p in pol.parameters())
+    assert all(not torch.equal(x, y) for x, y in zip(before, pol.parameters()))
+
+
+@pytest.mark.gpu
+def test_recurrent_update_graph_matches_eager(hip_lib, monkeypatch):
+    """The hipGraph-captured recurrent minibatch step (flat parameters, FlatAdam; the autograd variant of it) == the eager
+    autograd step (torch Adam + clip_grad_norm_) on the same rollout: same losses, same parameters after one update."""
+    import copy
+    monkeypatch.setenv("MYO_RECURRENT_AUTOGRAD", "1")
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
     from myochallenge_amd.rl.policy import ActorCriticPolicy
     from myochallenge_amd.rl.ppo import PPO, PPOConfig

@@ -198,17 +198,21 @@ class PPO:
 
     # -- native rollout step: HIP kernels for policy input, sampling, VecNormalize and buffer writes
     def _native_rollout(self) -> bool:
-        return (self._graphed_rollout() and self._fused is not None and self._fused.merged is not None
+        fused = self._fused if self._fused is not None else self._fused_rec
+        return (self._graphed_rollout() and fused is not None and fused.merged is not None
                 and hasattr(self.env, "process_step") and hasattr(self.env, "obs_rms"))
 
     def _init_native_rollout(self):
-        """Per step: graph A (policy input cast, stacked trunks, heads, myo_rollout_sample) -> eager
+        """Per step: graph A (policy input cast, [LSTM step,] stacked trunks, heads, myo_rollout_sample) -> eager
         myo_batch_step -> graph B (myo_vecnorm_step, myo_rollout_advance).  The timeout bootstrap
-        r += gamma V(terminal_obs) is applied once per rollout in finish_rollout() from term_buf/trunc_buf."""
+        r += gamma V(terminal_obs) is applied once per rollout in finish_rollout() from term_buf/trunc_buf (recurrent
+        policy: with the critic's LSTM state after each step, kept in crit_h_buf / crit_c_buf)."""
         import ctypes as C
         vec, raw, d, cfg = self.env, self.env.venv, self.device, self.cfg
         N, A, O, T = vec.num_envs, vec.act_dim, vec.obs_dim, cfg.n_steps
-        fused, lib = self._fused, self._fused.lib
+        recurrent = self.policy.recurrent
+        fused = self._fused_rec if recurrent else self._fused
+        lib = fused.lib
         first = vec.reset_tensor() if self._last_obs is None else self._last_obs
         self._obs_s = first.clone().contiguous()
         self._starts_s = self._last_starts.clone()
@@ -226,8 +230,42 @@ class PPO:
         # cast + hipBLASLt trunk / head GEMMs + bias/ReLU kernels + myo_rollout_sample
         rdesc = fused.rollout_desc(self._obs_s, seed, self._draw, self._t_idx, self.obs_buf, self.act_buf, self.val_buf,
                                    self.logp_buf, self._clip_s) if os.environ.get("MYO_ROLLOUT_GEMM") != "1" else None
+        if recurrent:
+            # LSTM state after the previous step, (actor, critic) stacked, bf16 as the update computes in; the masked copies that
+            # enter the step; the step's pre-activations / gates are scratch
+            H, bf = self.policy.hidden, torch.bfloat16
+            self._hs, self._cs = torch.zeros((2, N, H), device=d, dtype=bf), torch.zeros((2, N, H), device=d, dtype=bf)
+            self._hs[0].copy_(self._state[0][0]); self._hs[1].copy_(self._state[2][0])
+            self._cs[0].copy_(self._state[1][0]); self._cs[1].copy_(self._state[3][0])
+            self._hm, self._cm = torch.empty_like(self._hs), torch.empty_like(self._cs)
+            self._lat, self._cn = torch.empty_like(self._hs), torch.empty_like(self._hs)
+            self._ws = torch.empty((2, N, 4 * H), device=d, dtype=bf)
+            self._bsum = torch.zeros((2, 1, 4 * H), device=d, dtype=bf)
+            self.crit_h_buf, self.crit_c_buf = torch.zeros((T, N, H), device=d, dtype=bf), torch.zeros((T, N, H), device=d, dtype=bf)
+            Lw = fused.lstm
+
+        def part_a_recurrent():
+            st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
+            lib.check(lib.L.myo_rollout_policy_input(p(self._obs_s), N, O, p(self.obs_buf), p(self._x2), 2, p(self._t_idx), st))
+            keep = torch.rsub(self._starts_s, 1.0).view(1, N, 1)            # state zeroed where an episode starts
+            torch.mul(self._hs, keep, out=self._hm)
+            torch.mul(self._cs, keep, out=self._cm)
+            gx = torch.baddbmm(self._bsum, self._x2, Lw["wihh"].transpose(1, 2))
+            gh = torch.bmm(self._hm, Lw["whhh"].transpose(1, 2))
+            lib.check(lib.L.myo_lstm_cell_fwd(p(gx), p(gh), p(self._cm), None, 2 * N, N, H, 1, p(self._lat), p(self._hs), p(self._cs),
+                                              p(self._cn), p(self._ws), st))
+            t64 = self._t_idx.long()
+            self.crit_h_buf.index_copy_(0, t64, self._hs[1:2])
+            self.crit_c_buf.index_copy_(0, t64, self._cs[1:2])
+            _, mean_h, value_h = fused.trunk_heads(self._lat)
+            lib.check(lib.L.myo_rollout_sample(p(mean_h), p(value_h), p(self.policy.log_std.data), N, A, seed, p(self._draw),
+                                               p(self._t_idx), p(self.act_buf), p(self.val_buf), p(self.logp_buf),
+                                               p(self._clip_s), 0, st))
 
         def part_a():
+            if recurrent:
+                part_a_recurrent()
+                return
             if rdesc is not None:
                 fused.rollout_policy(rdesc)
                 return
@@ -281,7 +319,10 @@ class PPO:
         # the env's static output buffers as they are, and everything it touches is put back afterwards, so the
         # recorded rollout starts exactly at the reset
         rawout = (raw._obs, raw._rew, raw._done, raw._trunc, raw._term, raw._comps, raw._ep)
-        keep = [t.clone() for t in (self._obs_s, self._starts_s, vec.obs_rms.buf, vec.ret_rms.buf, vec.returns)]
+        restore = (self._obs_s, self._starts_s, vec.obs_rms.buf, vec.ret_rms.buf, vec.returns) + ((self._hs, self._cs) if recurrent else ())
+        keep = [t.clone() for t in restore]
+        if recurrent:
+            self._refresh_rollout_lstm()
         side = torch.cuda.Stream(device=d)
         side.wait_stream(torch.cuda.current_stream(d))
         with torch.cuda.stream(side):
@@ -289,7 +330,7 @@ class PPO:
             part_b(rawout)
         torch.cuda.current_stream(d).wait_stream(side)
         torch.cuda.synchronize(d)
-        for t, k in zip((self._obs_s, self._starts_s, vec.obs_rms.buf, vec.ret_rms.buf, vec.returns), keep):
+        for t, k in zip(restore, keep):
             t.copy_(k)
         vec.old_obs, vec.old_reward = rawout[0], rawout[1]      # the env's static output buffers
         self._t_idx.zero_()
@@ -308,6 +349,16 @@ class PPO:
                 part_b(rawout)
         self._rollout_ready = True
         self._native = True
+
+    def _refresh_rollout_lstm(self):
+        """Per rollout: the summed LSTM biases the native recurrent rollout adds to the input projection."""
+        Lw = self._fused_rec.lstm
+        torch.add(Lw["bihh"], Lw["bhhh"], out=self._bsum.view(2, -1))
+
+    def _native_state(self):
+        """(h_pi, c_pi, h_vf, c_vf) float32 [1,N,H] from the native recurrent rollout's stacked state."""
+        f = lambda z, k: z[k:k + 1].float()
+        return (f(self._hs, 0), f(self._cs, 0), f(self._hs, 1), f(self._cs, 1))
 
     def _init_rollout_graphs(self):
         """Per step: graph A (policy inference + sampling) -> eager myo_batch_step (so its HIP events can
@@ -352,7 +403,7 @@ class PPO:
                 self._init_rollout_graphs()
         if self.policy.recurrent:
             if self._t_host == 0:      # LSTM state at the start of the rollout: initial state of the update's sequences
-                self._rollout_state0 = tuple(s.clone() for s in self._state_s)
+                self._rollout_state0 = self._native_state() if getattr(self, "_native", False) else tuple(s.clone() for s in self._state_s)
             self._t_host = (self._t_host + 1) % self.cfg.n_steps
         self._gA.replay()
         self._raw.step_tensor(self._clip_s)
@@ -363,11 +414,21 @@ class PPO:
 
     def finish_rollout(self) -> None:
         with torch.no_grad(), self._autocast():
-            if getattr(self, "_native", False):
+            if getattr(self, "_native", False) and not self.policy.recurrent:
                 # timeout bootstrap for the whole rollout at once: r += gamma V(terminal_obs) where truncated
                 T, N = self.trunc_buf.shape
                 tv = self.policy.predict_values(self.term_buf.view(T * N, -1)).view(T, N)
                 self.rew_buf.add_(self.cfg.gamma * tv * self.trunc_buf)
+            elif getattr(self, "_native", False):
+                # same with the critic's LSTM state after each step, episode_start False (sb3-contrib [3P-RECALL]); time limits are
+                # rare events (one step in max_episode_steps), so the pass is skipped when the rollout has none (one host sync)
+                self._state_s = self._native_state()
+                if bool(self.trunc_buf.any()):
+                    T, N = self.trunc_buf.shape
+                    H = self.policy.hidden
+                    st = (None, None, self.crit_h_buf.view(1, T * N, H).float(), self.crit_c_buf.view(1, T * N, H).float())
+                    tv = self.policy.predict_values(self.term_buf.view(T * N, -1), st, None).view(T, N)
+                    self.rew_buf.add_(self.cfg.gamma * tv * self.trunc_buf)
             if self.policy.recurrent:
                 self._last_values = self.policy.predict_values(self._obs_s, self._state_s, self._starts_s)
                 self._state = self._state_s
@@ -384,6 +445,10 @@ class PPO:
         if self._graphed_rollout():
             if self._fused is not None:
                 self._fused.refresh_shadow()        # rollout inference runs on the bf16 shadow weights
+            if self._fused_rec is not None:
+                self._fused_rec.refresh_shadow()
+                if getattr(self, "_native", False):
+                    self._refresh_rollout_lstm()
             for _ in range(cfg.n_steps):
                 self.rollout_step()
             self.finish_rollout()

@@ -403,6 +403,37 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_native_recurrent_rollout_matches_policy(hip_lib):
+    """The HIP-kernel rollout step of a recurrent policy (PPO._init_native_rollout: LSTM cell kernel, stacked trunks, sampling
+    kernel, state carried in bf16) records what the policy itself computes: re-evaluating the stored sequences with
+    ``evaluate_actions`` from the stored start state reproduces the stored values and log-probabilities, across episode starts,
+    and the carried state equals the state evaluate_actions ends in."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    torch.manual_seed(0)
+    N, T = 128, 12
+    env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=N, seed=5, max_episode_steps=9)    # time limits inside the rollout
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (64, 64), (64, 64), lstm_hidden_size=32)
+    algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=T, batch_size=T * N, n_epochs=1))
+    assert algo._fused_rec is not None
+    for r in range(2):
+        algo.collect_rollouts()
+        assert getattr(algo, "_native", False)
+        assert float(algo.start_buf.sum()) > 0 and float(algo.trunc_buf.sum()) > 0
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            lp_, lv_, st = pol._latents(algo.obs_buf, algo._rollout_state0, algo.start_buf)
+            v, lp, _ = pol.evaluate_actions(algo.obs_buf, algo.act_buf, algo._rollout_state0, algo.start_buf)
+        assert float((v - algo.val_buf).abs().max()) < 0.03 * (1 + float(algo.val_buf.abs().max()))
+        assert float((lp - algo.logp_buf).abs().max()) < 0.02 * (1 + float(algo.logp_buf.abs().max())), float((lp - algo.logp_buf).abs().max())
+        for a, b in zip(st, algo._state):
+            assert float((a.float() - b).abs().max()) < 0.03
+        assert float(algo._state[0].abs().max()) > 0
+        assert torch.isfinite(algo.rew_buf).all()
+
+
+@pytest.mark.gpu
 def test_recurrent_update_graph_matches_eager(hip_lib, monkeypatch):
     """The hipGraph-captured recurrent minibatch step (flat parameters, FlatAdam; the autograd variant of it) == the eager
     autograd step (torch Adam + clip_grad_norm_) on the same rollout: same losses, same parameters after one update."""

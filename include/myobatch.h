@@ -319,6 +319,22 @@ int myo_lstm_cell_bwd(const void* dout, const void* dhm_next, const void* dcm_ne
                       const void* c_prev, const void* c_new, const void* ws, int R, int N, int H, int is_bf16,
                       void* dgates, void* dc_prev, void* stream);
 
+/* The same time step with the recurrent product inside (one launch instead of GEMM + cell kernel): bfloat16 storage, fp32
+ * accumulation on the matrix cores; H in {32, 64, 128, 256} (myo_lstm_step_supported).  Arrays are [G, N, .] contiguous except
+ *   gx    element (g, n, col) at gx[g*gx_sg + n*gx_sr + col]  (col < 4H; e.g. one [N, G*4H] GEMM output: gx_sg = 4H, gx_sr = G*4H),
+ *   out_h element (g, n, u) at out_h[g*out_sg + n*H + u],  dout likewise with dout_sg  (strides in elements, multiples of 4).
+ * fwd: h_prev, c_prev [G,N,H] (already masked), w_hh [G,4H,H] (weight_hh_l0 of each LSTM) -> out_h, hm_next, cm_next, c_new, ws
+ *      as myo_lstm_cell_fwd; c_new / ws may be NULL (rollout).
+ * bwd: dgates_next [G,N,4H] = the dgates of step t+1 (NULL at the last step), w_hh_t [G,H,4H] = W_hh transposed; the product
+ *      dgates_next . W_hh replaces dhm_next of myo_lstm_cell_bwd -> dgates [G,N,4H], dc_prev [G,N,H]. */
+int myo_lstm_step_supported(int H);
+int myo_lstm_step_fwd(const void* gx, long long gx_sg, long long gx_sr, const void* h_prev, const void* c_prev, const void* w_hh,
+                      const float* keep_next, int G, int N, int H, void* out_h, long long out_sg, void* hm_next, void* cm_next,
+                      void* c_new, void* ws, void* stream);
+int myo_lstm_step_bwd(const void* dout, long long dout_sg, const void* dgates_next, const void* dcm_next, const void* w_hh_t,
+                      const float* keep_next, const void* c_prev, const void* c_new, const void* ws, int G, int N, int H,
+                      void* dgates, void* dc_prev, void* stream);
+
 /* GAE(gamma, lambda) backward scan = SB3 RolloutBuffer.compute_returns_and_advantage (run by
  * RecurrentPPO.learn, /root/reference/src/train/trainer.py:66-71).  dev float32 [T,N] row-major:
  * rew, val, starts (episode_starts), outputs adv, ret; last_val[N], last_done[N]. */

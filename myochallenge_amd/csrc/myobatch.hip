@@ -2973,3 +2973,59 @@ extern "C" double myo_batch_kernel_ms(myo_batch* b) {
   return cnt ? sum / cnt : -1.0;
 #endif
 }
+
+// ------------------------------------------------------------------------------------------ fused LSTM time step
+#include "myo_lstm_step.h"
+extern "C" int myo_lstm_step_supported(int H) { return (H == 32 || H == 64 || H == 128 || H == 256) ? 1 : 0; }
+extern "C" int myo_lstm_step_fwd(const void* gx, long long gx_sg, long long gx_sr, const void* h_prev, const void* c_prev, const void* w_hh,
+                                 const float* keep_next, int G, int N, int H, void* out_h, long long out_sg, void* hm_next, void* cm_next,
+                                 void* c_new, void* ws, void* stream) {
+  if (!gx || !h_prev || !c_prev || !w_hh || !out_h || !hm_next || !cm_next || G <= 0 || N <= 0 || H <= 0 || (gx_sg & 3) || (gx_sr & 3) || (out_sg & 3))
+    return fail(MYO_E_ARG, "myo_lstm_step_fwd: bad arguments");
+  if (!myo_lstm_step_supported(H)) return fail(MYO_E_UNSUPPORTED, "myo_lstm_step_fwd: hidden size %d (32, 64, 128 or 256)", H);
+#ifdef MYO_EMU
+  (void)keep_next; (void)c_new; (void)ws; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_lstm_step_fwd is a GPU kernel");
+#else
+  typedef const unsigned short* cu;
+  typedef unsigned short* mu;
+#define MYO_LSTM_FWD(HH)                                                                                                              \
+  lstm_step_fwd_launch<HH>((cu)gx, gx_sg, gx_sr, (cu)h_prev, (cu)c_prev, (cu)w_hh, keep_next, G, N, (mu)out_h, out_sg, (mu)hm_next,   \
+                           (mu)cm_next, (mu)c_new, (mu)ws, (hipStream_t)stream)
+  switch (H) {
+    case 32: MYO_LSTM_FWD(32); break;
+    case 64: MYO_LSTM_FWD(64); break;
+    case 128: MYO_LSTM_FWD(128); break;
+    default: MYO_LSTM_FWD(256); break;
+  }
+#undef MYO_LSTM_FWD
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}
+extern "C" int myo_lstm_step_bwd(const void* dout, long long dout_sg, const void* dgates_next, const void* dcm_next, const void* w_hh_t,
+                                 const float* keep_next, const void* c_prev, const void* c_new, const void* ws, int G, int N, int H,
+                                 void* dgates, void* dc_prev, void* stream) {
+  if (!c_prev || !c_new || !ws || !dgates || !dc_prev || (dgates_next && !w_hh_t) || G <= 0 || N <= 0 || H <= 0 || (dout_sg & 3))
+    return fail(MYO_E_ARG, "myo_lstm_step_bwd: bad arguments");
+  if (!myo_lstm_step_supported(H)) return fail(MYO_E_UNSUPPORTED, "myo_lstm_step_bwd: hidden size %d (32, 64, 128 or 256)", H);
+#ifdef MYO_EMU
+  (void)dout; (void)dcm_next; (void)keep_next; (void)stream;
+  return fail(MYO_E_UNSUPPORTED, "myo_lstm_step_bwd is a GPU kernel");
+#else
+  typedef const unsigned short* cu;
+  typedef unsigned short* mu;
+#define MYO_LSTM_BWD(HH)                                                                                                               \
+  lstm_step_bwd_launch<HH>((cu)dout, dout_sg, (cu)dgates_next, (cu)dcm_next, (cu)w_hh_t, keep_next, (cu)c_prev, (cu)c_new, (cu)ws, G, N, \
+                           (mu)dgates, (mu)dc_prev, (hipStream_t)stream)
+  switch (H) {
+    case 32: MYO_LSTM_BWD(32); break;
+    case 64: MYO_LSTM_BWD(64); break;
+    case 128: MYO_LSTM_BWD(128); break;
+    default: MYO_LSTM_BWD(256); break;
+  }
+#undef MYO_LSTM_BWD
+  LAUNCH_CHECK(0)
+  return MYO_OK;
+#endif
+}

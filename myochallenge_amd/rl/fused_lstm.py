@@ -9,7 +9,9 @@ around ~150 that do the work.  Here
 
 * the minibatch is gathered by ``myo_ppo_gather`` (bf16 observations, advantage moments), one GEMM projects the
   inputs of both LSTMs for all time steps;
-* a time step is the batched recurrent GEMM + ``myo_lstm_cell_fwd`` / ``myo_lstm_cell_bwd`` (as ``rl/policy.py:_LstmSeq``);
+* a time step is ONE launch per direction, ``myo_lstm_step_fwd`` / ``myo_lstm_step_bwd`` (csrc/myo_lstm_step.h: recurrent product
+  on the matrix cores with the cell arithmetic as its epilogue; hidden sizes 32 / 64 / 128 / 256), else the batched recurrent
+  GEMM + ``myo_lstm_cell_fwd`` / ``myo_lstm_cell_bwd`` (as ``rl/policy.py:_LstmSeq``);
 * trunks, heads, loss and their backward pass are ``FusedPPOStep._merged_core`` on the LSTM outputs, which also
   returns the gradient entering the LSTMs;
 * LSTM weight gradients are per-time-step batched GEMMs reduced in fp32 by ``myo_splitk_reduce`` (the bias
@@ -20,6 +22,7 @@ Every gradient slot is overwritten (no zeroing pass); clip + Adam follow as ``Fl
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -41,6 +44,8 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         if self.merged is None or not self.merged:
             return None
         self.lstm = self._lstm_views(policy._flat, self.half[0])
+        # one launch per time step and direction where the hidden size has a fused kernel (MYO_LSTM_TWO_KERNELS=1: GEMM + cell kernel)
+        self.step_kernels = bool(lib.L.myo_lstm_step_supported(la.hidden_size)) and os.environ.get("MYO_LSTM_TWO_KERNELS") != "1"
         return self if self.lstm is not None else None
 
     def _lstm_views(self, flat, hflat):
@@ -106,29 +111,43 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         torch.mul(c0.index_select(1, idx), k0, out=cm[0])
         # ---- input projections of both LSTMs, all time steps: [B, O] x [O, 2*4H]
         bsum = (L["bihh"] + L["bhhh"]).view(G * H4)
-        gx = torch.addmm(bsum, x[0], L["wihh"].view(G * H4, O).t())
-        gx = gx.view(T, m, G, H4).transpose(1, 2).contiguous()           # [T, G, m, 4H]: a step's rows are r = g*m + n
-        wt = L["whhh"].transpose(1, 2).contiguous()                      # [G, H, 4H]
-        out, cn = torch.empty((T, G, m, H), dtype=bf, device=dev), torch.empty((T, G, m, H), dtype=bf, device=dev)
+        gx = torch.addmm(bsum, x[0], L["wihh"].view(G * H4, O).t()).view(T, m, G, H4)      # row (t, n): [actor 4H | critic 4H]
+        wt = L["whhh"].transpose(1, 2).contiguous()                      # [G, H, 4H] = W_hh^T
+        cn = torch.empty((T, G, m, H), dtype=bf, device=dev)
         ws = torch.empty((T, G, m, H4), dtype=bf, device=dev)
-        for t in range(T):
-            gh = torch.bmm(hm[t], wt)
-            lib.check(lib.L.myo_lstm_cell_fwd(p(gx[t]), p(gh), p(cm[t]), p(keep[t + 1]) if t + 1 < T else None, G * m, m, H, 1,
-                                              p(out[t]), p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
-        # ---- trunks, heads, loss, and back down to the LSTM outputs
-        lat = out.transpose(0, 1).contiguous().view(G, B, H)
-        pl, vl, dlat = self._merged_core(lat, act, oldlp, adv_mb, ret_mb, want_dx=True)
-        dout = dlat.view(G, T, m, H).transpose(0, 1).contiguous()
-        # ---- BPTT
+        lat = torch.empty((G, T, m, H), dtype=bf, device=dev)            # LSTM outputs, net-major: the trunks' input
         dG = torch.empty((T, G, m, H4), dtype=bf, device=dev)
         dcm = torch.empty((2, G, m, H), dtype=bf, device=dev)            # ping-pong: gradient of cm[t]
-        whh = L["whhh"]                                                  # [G, 4H, H]: dh_prev = dgates . W_hh
-        dhm = dcn = None
-        for t in range(T - 1, -1, -1):
-            lib.check(lib.L.myo_lstm_cell_bwd(p(dout[t]), p(dhm), p(dcn), p(keep[t + 1]) if t + 1 < T else None, p(cm[t]), p(cn[t]),
-                                              p(ws[t]), G * m, m, H, 1, p(dG[t]), p(dcm[t & 1]), st))
-            if t > 0:
-                dhm, dcn = torch.bmm(dG[t], whh), dcm[t & 1]
+        kp = lambda t: p(keep[t + 1]) if t + 1 < T else None
+        if self.step_kernels:
+            # a time step = ONE launch per direction (csrc/myo_lstm_step.h): recurrent product on the matrix cores + cell epilogue;
+            # reads gx where the projection GEMM left it and writes the outputs where the trunks read them (no transposes)
+            for t in range(T):
+                lib.check(lib.L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm[t]), p(cm[t]), p(L["whhh"]), kp(t), G, m, H, p(lat[:, t]),
+                                                  T * m * H, p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+            pl, vl, dlat = self._merged_core(lat.view(G, B, H), act, oldlp, adv_mb, ret_mb, want_dx=True)
+            dlat = dlat.view(G, T, m, H)
+            for t in range(T - 1, -1, -1):
+                last = t == T - 1
+                lib.check(lib.L.myo_lstm_step_bwd(p(dlat[:, t]), T * m * H, None if last else p(dG[t + 1]), None if last else p(dcm[(t + 1) & 1]),
+                                                  p(wt), kp(t), p(cm[t]), p(cn[t]), p(ws[t]), G, m, H, p(dG[t]), p(dcm[t & 1]), st))
+        else:
+            gxs = gx.transpose(1, 2).contiguous()                        # [T, G, m, 4H]: a step's rows are r = g*m + n
+            out = torch.empty((T, G, m, H), dtype=bf, device=dev)
+            for t in range(T):
+                gh = torch.bmm(hm[t], wt)
+                lib.check(lib.L.myo_lstm_cell_fwd(p(gxs[t]), p(gh), p(cm[t]), kp(t), G * m, m, H, 1,
+                                                  p(out[t]), p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+            lat.copy_(out.transpose(0, 1))
+            pl, vl, dlat = self._merged_core(lat.view(G, B, H), act, oldlp, adv_mb, ret_mb, want_dx=True)
+            dout = dlat.view(G, T, m, H).transpose(0, 1).contiguous()
+            whh = L["whhh"]                                              # [G, 4H, H]: dh_prev = dgates . W_hh
+            dhm = dcn = None
+            for t in range(T - 1, -1, -1):
+                lib.check(lib.L.myo_lstm_cell_bwd(p(dout[t]), p(dhm), p(dcn), kp(t), p(cm[t]), p(cn[t]),
+                                                  p(ws[t]), G * m, m, H, 1, p(dG[t]), p(dcm[t & 1]), st))
+                if t > 0:
+                    dhm, dcn = torch.bmm(dG[t], whh), dcm[t & 1]
         # ---- LSTM weight gradients: per-time-step partial products (batch = (t, g)), summed over t in fp32
         Op = (O + 1 + 7) // 8 * 8                                        # inputs + a ones column (bias gradient) + zero padding
         xe = self._static("xe", (T * G, m, Op), bf)

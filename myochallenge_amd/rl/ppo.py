@@ -251,9 +251,13 @@ class PPO:
             torch.mul(self._hs, keep, out=self._hm)
             torch.mul(self._cs, keep, out=self._cm)
             gx = torch.baddbmm(self._bsum, self._x2, Lw["wihh"].transpose(1, 2))
-            gh = torch.bmm(self._hm, Lw["whhh"].transpose(1, 2))
-            lib.check(lib.L.myo_lstm_cell_fwd(p(gx), p(gh), p(self._cm), None, 2 * N, N, H, 1, p(self._lat), p(self._hs), p(self._cs),
-                                              p(self._cn), p(self._ws), st))
+            if fused.step_kernels:       # recurrent product + cell in one launch; nothing kept for a backward pass
+                lib.check(lib.L.myo_lstm_step_fwd(p(gx), N * 4 * H, 4 * H, p(self._hm), p(self._cm), p(Lw["whhh"]), None, 2, N, H,
+                                                  p(self._lat), N * H, p(self._hs), p(self._cs), None, None, st))
+            else:
+                gh = torch.bmm(self._hm, Lw["whhh"].transpose(1, 2))
+                lib.check(lib.L.myo_lstm_cell_fwd(p(gx), p(gh), p(self._cm), None, 2 * N, N, H, 1, p(self._lat), p(self._hs), p(self._cs),
+                                                  p(self._cn), p(self._ws), st))
             t64 = self._t_idx.long()
             self.crit_h_buf.index_copy_(0, t64, self._hs[1:2])
             self.crit_c_buf.index_copy_(0, t64, self._cs[1:2])

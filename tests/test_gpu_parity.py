@@ -1135,6 +1135,65 @@ def test_lstm_cell_kernels_match_formulas(hip_lib, dtype):
     assert float((dcp.float() - dct0 * wf).abs().max()) <= tol * (1 + float((dct0 * wf).abs().max()))
 
 
+@pytest.mark.parametrize("H,N", [(32, 80), (256, 512), (128, 2100)])
+def test_lstm_step_kernels_match_gemm_plus_cell(hip_lib, H, N):
+    """myo_lstm_step_fwd / _bwd (recurrent product on the matrix cores + cell epilogue, csrc/myo_lstm_step.h) against the fp32
+    statement of the same step — h_prev . W_hh^T + gx -> gates -> cell, and dgates_next . W_hh + dout -> cell backward — with
+    strided gx / out_h / dout layouts, the episode mask, row counts that are not a multiple of the tile, and the NULL forms."""
+    import ctypes as C
+    import torch
+    L = hip_lib.L
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    torch.manual_seed(H + N)
+    G = 2
+    mk = lambda *s, sc=1.0: (sc * torch.randn(*s, device=dev)).to(bf)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    gx_all = mk(N, G * 4 * H)                                    # one projection GEMM output: row n = [net 0 gates | net 1 gates]
+    hp, cp, whh = mk(G, N, H), mk(G, N, H), mk(G, 4 * H, H, sc=H ** -0.5)
+    keep = (torch.rand(N, device=dev) > 0.4).float()
+    out_all = torch.zeros((G, 3, N, H), device=dev, dtype=bf)    # out_h lands in slice [:, 1]
+    hm, cm, cn = (torch.empty((G, N, H), device=dev, dtype=bf) for _ in range(3))
+    ws = torch.empty((G, N, 4 * H), device=dev, dtype=bf)
+    hip_lib.check(L.myo_lstm_step_fwd(p(gx_all), 4 * H, G * 4 * H, p(hp), p(cp), p(whh), p(keep), G, N, H, p(out_all[:, 1]), 3 * N * H,
+                                      p(hm), p(cm), p(cn), p(ws), None))
+    torch.cuda.synchronize()
+    a = gx_all.float().view(N, G, 4 * H).transpose(0, 1) + torch.bmm(hp.float(), whh.float().transpose(1, 2))
+    i, f, g, o = torch.sigmoid(a[..., :H]), torch.sigmoid(a[..., H:2 * H]), torch.tanh(a[..., 2 * H:3 * H]), torch.sigmoid(a[..., 3 * H:])
+    c = f * cp.float() + i * g
+    h = o * torch.tanh(c)
+    k = keep.view(1, N, 1)
+    tol = 1.2e-2
+    for name, got, want in (("out", out_all[:, 1], h), ("cn", cn, c), ("hm", hm, h * k), ("cm", cm, c * k), ("ws", ws, torch.cat([i, f, g, o], -1))):
+        assert float((got.float() - want).abs().max()) <= tol * (1 + float(want.abs().max())), name
+    assert float(out_all[:, 0].abs().max()) == 0 and float(out_all[:, 2].abs().max()) == 0
+    # rollout form: no c_new / ws, no mask
+    hm2, cm2 = torch.empty_like(hm), torch.empty_like(cm)
+    out2 = torch.empty((G, N, H), device=dev, dtype=bf)
+    hip_lib.check(L.myo_lstm_step_fwd(p(gx_all), 4 * H, G * 4 * H, p(hp), p(cp), p(whh), None, G, N, H, p(out2), N * H, p(hm2), p(cm2), None, None, None))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out_all[:, 1].contiguous()) and torch.equal(hm2, out2)
+    # backward from the kernel's own saved tensors
+    dgn, dcn_ = mk(G, N, 4 * H, sc=0.3), mk(G, N, H)
+    dout_all = mk(G, 2, N, H)                                    # gradient of out_h in slice [:, 1]
+    wt = whh.transpose(1, 2).contiguous()
+    dg, dcp = torch.empty((G, N, 4 * H), device=dev, dtype=bf), torch.empty((G, N, H), device=dev, dtype=bf)
+    hip_lib.check(L.myo_lstm_step_bwd(p(dout_all[:, 1]), 2 * N * H, p(dgn), p(dcn_), p(wt), p(keep), p(cp), p(cn), p(ws), G, N, H, p(dg), p(dcp), None))
+    torch.cuda.synchronize()
+    wi, wf, wg, wo = (ws.float()[..., q * H:(q + 1) * H] for q in range(4))
+    tc = torch.tanh(cn.float())
+    dh = dout_all[:, 1].float() + k * torch.bmm(dgn.float(), whh.float())
+    dct = k * dcn_.float() + dh * wo * (1 - tc * tc)
+    want_dg = torch.cat([dct * wg * wi * (1 - wi), dct * cp.float() * wf * (1 - wf), dct * wi * (1 - wg * wg), dh * tc * wo * (1 - wo)], -1)
+    assert float((dg.float() - want_dg).abs().max()) <= tol * (1 + float(want_dg.abs().max()))
+    assert float((dcp.float() - dct * wf).abs().max()) <= tol * (1 + float((dct * wf).abs().max()))
+    # last time step: no later gradients
+    hip_lib.check(L.myo_lstm_step_bwd(p(dout_all[:, 1]), 2 * N * H, None, None, None, None, p(cp), p(cn), p(ws), G, N, H, p(dg), p(dcp), None))
+    torch.cuda.synchronize()
+    dct0 = dout_all[:, 1].float() * wo * (1 - tc * tc)
+    assert float((dcp.float() - dct0 * wf).abs().max()) <= tol * (1 + float((dct0 * wf).abs().max()))
+    assert hip_lib.L.myo_lstm_step_supported(48) == 0 and hip_lib.L.myo_lstm_step_fwd(p(gx_all), 0, 0, p(hp), p(cp), p(whh), None, G, N, 48, p(out2), 0, p(hm2), p(cm2), None, None, None) == -2
+
+
 def test_gsde_sampling_kernel_matches_torch(hip_lib):
     """myo_rollout_sample_sde against the torch statement of SB3's state-dependent noise distribution."""
     import ctypes as C

@@ -41,7 +41,7 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         if lc is None or la.hidden_size != lc.hidden_size or la.hidden_size % 16:
             return None
         self = cls(policy, lib, clip_range, ent_coef, vf_coef)
-        if self.merged is None or not self.merged:
+        if self.merged is None:
             return None
         self.lstm = self._lstm_views(policy._flat, self.half[0])
         # one launch per time step and direction where the hidden size has a fused kernel (MYO_LSTM_TWO_KERNELS=1: GEMM + cell kernel)

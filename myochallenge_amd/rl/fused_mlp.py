@@ -342,8 +342,8 @@ class FusedPPOStep:
     def _stacked_views(self, flat, hflat):
         """[2,out,in] / [2,out] views over the adjacent actor/critic trunk slots (None if not adjacent)."""
         pi, vf = self.nets["pi"][:-1], self.nets["vf"][:-1]
-        if len(pi) != len(vf) or not pi:
-            return None
+        if len(pi) != len(vf) or (not pi and not self.policy.recurrent):
+            return None                  # (a recurrent policy may have no trunk at all: the heads sit on the LSTM outputs)
         slot = {id(p): sl for p, sl in zip(flat["params"], flat["slots"])}
         out = []
         for a, b in zip(pi, vf):

@@ -349,7 +349,8 @@ def test_reorient_ppo_lstm_on_gpu(hip_lib):
 
 
 @pytest.mark.gpu
-def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch):
+@pytest.mark.parametrize("arch", [(64, 64), ()], ids=["lstm+mlp", "lstm-only"])
+def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch):
     """rl/fused_lstm.py (hand-derived LSTM + trunk + loss forward / backward in bf16) against autograd under bf16
     autocast on the same minibatch of sequences: losses and every parameter's gradient, with episode starts inside
     the sequences and a non-zero LSTM state at the rollout start."""
@@ -361,7 +362,7 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch):
     torch.manual_seed(0)
     N, T, m = 128, 8, 64
     env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=N, seed=3)
-    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (64, 64), (64, 64), lstm_hidden_size=32)
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, arch, arch, lstm_hidden_size=32)     # () = the reference's phase-1 policy shape
     with torch.no_grad():
         pol.log_std.fill_(-0.5)
     pol2 = copy.deepcopy(pol)

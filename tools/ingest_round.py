@@ -45,7 +45,9 @@ def main():
         if os.path.exists(os.path.join(R, a)):
             shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}
-    for k in ("mixed", "rk4", "p2_8192", "rollout_only", "reorient_p2"):
+    for k in ("mixed", "rk4", "p2_8192", "rollout_only", "reorient_p2", "lstm128"):
+        if not os.path.exists(os.path.join(R, f"bench_{k}.json")):
+            continue
         d = json.loads(open(os.path.join(R, f"bench_{k}.json")).read().strip().splitlines()[-1])
         out["bench_" + k] = {x: d[x] for x in ("value", "ms_per_step", "env_kernel_ms", "ppo_optimizer_steps_per_sec", "dtype", "config") if x in d}
     try:

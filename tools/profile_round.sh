@@ -54,6 +54,7 @@ python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoBaodi
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoReorientP2 > $OUT/bench_reorient_p2.json 2>/dev/null
 python3 $ROOT/tools/bench_reorient.py > $OUT/bench_reorient_lstm.json 2>/dev/null
+python3 $ROOT/bench.py --no-cpu-baseline --no-variants --dtype mixed --lstm-hidden 128 --net-arch "" --n-steps 32 > $OUT/bench_lstm128.json 2>/dev/null   # the reference's phase-1 policy shape
 # 6. trajectory drift tables of both steppers (32 action streams x 200 env steps) and k_step time against the batch size
 python3 $ROOT/tools/dev/gpu_drift.py > $OUT/drift.log 2>&1
 # 7. the GPU test suite on the same library

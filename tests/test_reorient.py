@@ -349,8 +349,8 @@ def test_reorient_ppo_lstm_on_gpu(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arch", [(64, 64), ()], ids=["lstm+mlp", "lstm-only"])
-def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch):
+@pytest.mark.parametrize("arch,hidden", [((64, 64), 32), ((), 32), ((64, 64), 48)], ids=["lstm+mlp", "lstm-only", "gemm+cell-kernels"])
+def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch, hidden):
     """rl/fused_lstm.py (hand-derived LSTM + trunk + loss forward / backward in bf16) against autograd under bf16
     autocast on the same minibatch of sequences: losses and every parameter's gradient, with episode starts inside
     the sequences and a non-zero LSTM state at the rollout start."""
@@ -362,7 +362,7 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch):
     torch.manual_seed(0)
     N, T, m = 128, 8, 64
     env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=N, seed=3)
-    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, arch, arch, lstm_hidden_size=32)     # () = the reference's phase-1 policy shape
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, arch, arch, lstm_hidden_size=hidden)     # () = the reference's phase-1 policy shape
     with torch.no_grad():
         pol.log_std.fill_(-0.5)
     pol2 = copy.deepcopy(pol)
@@ -371,6 +371,7 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch):
     monkeypatch.setenv("MYO_RECURRENT_AUTOGRAD", "1")
     b = mk(pol2)
     assert a._fused_rec is not None and b._fused_rec is None and b._flat_adam is not None
+    assert a._fused_rec.step_kernels == (hidden == 32)         # hidden 48 has no fused time-step kernel: recurrent GEMM + cell kernel
     a.collect_rollouts(); a.collect_rollouts()                 # second rollout: starts from a non-zero LSTM state
     a.start_buf[3, ::5] = 1.0; a.start_buf[6, 1::7] = 1.0
     for name in ("obs_buf", "act_buf", "rew_buf", "val_buf", "logp_buf", "start_buf"):
@@ -432,6 +433,23 @@ def test_native_recurrent_rollout_matches_policy(hip_lib):
             assert float((a.float() - b).abs().max()) < 0.03
         assert float(algo._state[0].abs().max()) > 0
         assert torch.isfinite(algo.rew_buf).all()
+    # timeout bootstrap (sb3-contrib collect_rollouts [3P-RECALL]): r += gamma V(terminal_obs; critic LSTM state AFTER the step,
+    # episode_start False) where the time limit ended the episode — step the same rollout by hand and take finish_rollout apart
+    algo._fused_rec.refresh_shadow(); algo._refresh_rollout_lstm()
+    hv, cv = [], []
+    for t in range(T):
+        algo.rollout_step()
+        hv.append(algo._hs[1].float().clone()); cv.append(algo._cs[1].float().clone())
+    before = algo.rew_buf.clone()
+    algo.finish_rollout()
+    trunc = algo.trunc_buf
+    assert float(trunc.sum()) > 0
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        tv = torch.stack([pol.predict_values(algo.term_buf[t], (None, None, hv[t].unsqueeze(0), cv[t].unsqueeze(0)), None) for t in range(T)])
+    want = before + algo.cfg.gamma * tv * trunc
+    assert float((algo.rew_buf - want).abs().max()) < 2e-2 * (1 + float(want.abs().max()))
+    assert float((algo.rew_buf - before).abs().max()) > 0 and torch.equal((algo.rew_buf != before) & (trunc == 0), torch.zeros_like(trunc, dtype=torch.bool))
+    assert torch.equal(algo.crit_h_buf.float(), torch.stack(hv)) and torch.equal(algo.crit_c_buf.float(), torch.stack(cv))
 
 
 @pytest.mark.gpu

@@ -17,7 +17,8 @@ Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barri
 and taken as the max over ranks; blocks repeat until --min-seconds (default 2 s) of timed wall have passed, so
 that the GPU is busy long enough for outside telemetry; `ms_per_step` / `value` are the MEDIAN block
 (`blocks`, `timed_seconds`, `ms_per_step_min/max` say what was seen).  `variants` (rank 0, N = 1) carries the
-same measurement for the mixed-precision stepper and for the RK4 integrator.  Since round 4 the headline is the all-fp64 stepper
+same measurement for the mixed-precision stepper and for the RK4 integrator, plus `config_E_lstm256`: BASELINE config E (die reorient,
+4096 envs, the reference's recurrent LSTM-256 policy class, rollout + update; myochallenge_amd/rl/bench_reorient_lstm.py).  Since round 4 the headline is the all-fp64 stepper
 (`--dtype f64`, the reference's own arithmetic); `--dtype mixed` is the faster variant whose per-step error is bounded in
 tests/test_gpu_parity.py::test_local_error_of_the_steppers.
 
@@ -338,6 +339,13 @@ def main():
                 variants[name] = {k: r[k] for k in ("dtype", "integrator", "value", "ms_per_step", "env_kernel_ms", "blocks", "timed_seconds", "lds_bytes")}
             except Exception as exc:      # a variant must never take the headline line down
                 variants[name] = {"error": repr(exc)}
+        if args.envs == 4096 and args.env_name == "CustomMyoBaodingBallsP1":
+            # BASELINE config E (die reorient, LSTM-256 + MLP[256,256], the reference's RecurrentPPO policy class) on the same box
+            try:
+                from myochallenge_amd.rl.bench_reorient_lstm import run as run_config_e
+                variants["config_E_lstm256"] = run_config_e(4096, 32, 2, env_only_steps=0)
+            except Exception as exc:      # noqa: BLE001
+                variants["config_E_lstm256"] = {"error": repr(exc)}
 
     pol_name = (f"LSTM-{args.lstm_hidden} + " if args.lstm_hidden else "") + f"MLP[{args.net_arch}]"
     if rank == 0:

@@ -275,6 +275,51 @@ def test_fused_ppo_step_matches_fp32_reference(hip_lib, merged):
             assert float((p.grad - r).abs().max()) <= 1e-4 * float(r.abs().max()) + 1e-9, name
 
 
+def test_fused_ppo_gradient_error_is_noise_not_bias(hip_lib):
+    """The loose bounds of test_fused_ppo_step_matches_fp32_reference come from cancellation on signal-free advantages.  With a
+    learning signal in the data (advantages that favour one action direction, returns that are a function of the observation) the
+    bf16 path is within 1 % of the fp32 gradient on every parameter but the first actor layer (5 %) and log_std (2 %), and its
+    error is noise: it shrinks in the sum over 16 minibatches, which is what a training run integrates."""
+    import copy
+    import torch
+    from myochallenge_amd.rl.fused_mlp import FusedPPOStep, flatten_parameters, ppo_mlp_step_grads
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None).to(dev)
+    ref_pol = copy.deepcopy(pol)
+    flatten_parameters(pol)
+    step = FusedPPOStep(pol, hip_lib, 0.2, 0.01, 0.7)
+    B, K = 16384, 16
+    wa, wo = torch.randn(39, device=dev), torch.randn(86, device=dev) / 9
+    names = [n for n, _ in pol.named_parameters()]
+    noisy = {"log_std": 0.04, "mlp_extractor.policy_net.0.weight": 0.08}
+    acc_f = [torch.zeros_like(p) for p in pol.parameters()]
+    acc_r = [torch.zeros_like(p) for p in ref_pol.parameters()]
+    per_batch = {n: [] for n in names}
+    for k in range(K):
+        obs = torch.randn(B, 86, device=dev)
+        with torch.no_grad():
+            act = pol.act(obs, None, None)[0]
+            mean = ref_pol._dist(ref_pol.mlp_extractor.policy_net(obs))[0]
+            oldlp = pol.evaluate_actions(obs, act)[1] + torch.randn(B, device=dev) * 0.05
+        adv = torch.tanh(((act - mean) * torch.exp(-ref_pol.log_std)) @ wa / 6) + 0.3 * torch.randn(B, device=dev)
+        ret = torch.sin(obs @ wo) + 0.1 * torch.randn(B, device=dev)
+        ppo_mlp_step_grads(ref_pol, obs, act, oldlp, adv, ret, 0.2, 0.01, 0.7, bf16=False)
+        step.run(obs, act, oldlp, adv, ret)
+        torch.cuda.synchronize()
+        for i, (n, p, r) in enumerate(zip(names, pol.parameters(), ref_pol.parameters())):
+            acc_f[i] += p.grad; acc_r[i] += r.grad
+            err = float((p.grad - r.grad).norm() / (r.grad.norm() + 1e-12))
+            per_batch[n].append(err)
+            assert err < noisy.get(n, 0.02), (k, n, err)
+    for n, a, b in zip(names, acc_f, acc_r):
+        err = float((a - b).norm() / (b.norm() + 1e-12))
+        assert err < (0.03 if n in noisy else 0.012), (n, err)
+        if n in noisy:                                   # averages out: well under the single-minibatch error
+            assert err < 0.6 * sum(per_batch[n]) / K, (n, err, per_batch[n])
+
+
 def test_ppo_elementwise_kernels_exact(hip_lib):
     """myo_ppo_loss_grad, myo_ppo_gather, myo_bias_relu_bf16, myo_relu_bwd_colsum_bf16 and
     myo_splitk_reduce against plain torch on the same inputs (fp32 formulas: tight tolerances)."""

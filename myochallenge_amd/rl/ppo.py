@@ -250,11 +250,13 @@ class PPO:
             keep = torch.rsub(self._starts_s, 1.0).view(1, N, 1)            # state zeroed where an episode starts
             torch.mul(self._hs, keep, out=self._hm)
             torch.mul(self._cs, keep, out=self._cm)
-            gx = torch.baddbmm(self._bsum, self._x2, Lw["wihh"].transpose(1, 2))
             if fused.step_kernels:       # recurrent product + cell in one launch; nothing kept for a backward pass
-                lib.check(lib.L.myo_lstm_step_fwd(p(gx), N * 4 * H, 4 * H, p(self._hm), p(self._cm), p(Lw["whhh"]), None, 2, N, H,
+                # one projection GEMM for both LSTMs with the bias in its epilogue: row n = [actor 4H | critic 4H], read in place
+                gx = torch.addmm(self._bsum.view(8 * H), self._x2[0], Lw["wihh"].view(8 * H, O).t())
+                lib.check(lib.L.myo_lstm_step_fwd(p(gx), 4 * H, 8 * H, p(self._hm), p(self._cm), p(Lw["whhh"]), None, 2, N, H,
                                                   p(self._lat), N * H, p(self._hs), p(self._cs), None, None, st))
             else:
+                gx = torch.baddbmm(self._bsum, self._x2, Lw["wihh"].transpose(1, 2))
                 gh = torch.bmm(self._hm, Lw["whhh"].transpose(1, 2))
                 lib.check(lib.L.myo_lstm_cell_fwd(p(gx), p(gh), p(self._cm), None, 2 * N, N, H, 1, p(self._lat), p(self._hs), p(self._cs),
                                                   p(self._cn), p(self._ws), st))

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--eval-episodes", type=int, default=512)
     ap.add_argument("--out", default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "mixed"], help="stepper arithmetic (f64: the bench headline since round 4)")
+    ap.add_argument("--lstm-hidden", type=int, default=0, help="recurrent policy: LSTM of this width for actor and critic in front of the "
+                    "[256, 256] trunks (the reference's RecurrentPPO policy class); PPO settings of tools/bench_reorient.py")
     a = ap.parse_args()
     import torch
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
@@ -38,9 +40,14 @@ def main():
     eval_env = EnvironmentFactory.create(a.env_name, num_envs=512, seed=999, dtype=a.dtype, **cfgs)
     venv = VecNormalize(env, gamma=0.99)
     torch.manual_seed(0)
-    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=None, log_std_init=-2.0)
-    algo = PPO(venv, pol, PPOConfig(n_steps=64, batch_size=16384, n_epochs=10, learning_rate=2.5e-4, clip_range=0.2,
-                                    ent_coef=2.5e-4, vf_coef=0.5, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, bf16=True))
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=a.lstm_hidden or None, log_std_init=-2.0)
+    if a.lstm_hidden:     # sequences = whole 32-step rollouts of an eighth of the envs per minibatch
+        cfg = PPOConfig(n_steps=32, batch_size=a.envs * 32 // 8, n_epochs=4, learning_rate=2.5e-4, clip_range=0.2, ent_coef=2.5e-4,
+                        vf_coef=0.5, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, bf16=True)
+    else:
+        cfg = PPOConfig(n_steps=64, batch_size=16384, n_epochs=10, learning_rate=2.5e-4, clip_range=0.2,
+                        ent_coef=2.5e-4, vf_coef=0.5, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, bf16=True)
+    algo = PPO(venv, pol, cfg)
     log = []
 
     def ev(tag):

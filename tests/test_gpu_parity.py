@@ -650,6 +650,58 @@ def test_two_rank_graph_path_keeps_replicas_identical(hip_lib):
     assert not np.array_equal(a, init)
 
 
+def _graph_dp_worker_recurrent(rank, world, port, out):
+    import os
+    import torch
+    import torch.distributed as dist
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=64, seed=100 + rank)
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (64,), (64,), lstm_hidden_size=32)
+    venv = VecNormalize(env)
+    algo = PPO(venv, pol, PPOConfig(n_steps=8, batch_size=8 * 32, n_epochs=2, sync_adv_moments=True), seed=rank)
+    assert algo.world == 2 and algo._fused_rec is not None
+    for _ in range(2):
+        algo.collect_rollouts()
+        algo.train()
+    torch.cuda.synchronize()
+    out[rank] = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).cpu().numpy()
+    out[10 + rank] = float(algo.rew_buf.sum())
+    out[30 + rank] = (bool(getattr(algo, "_native", False)), bool(algo._vn_sync), bool(algo._fused_rec.external_adv_stats), int(algo.n_updates))
+    dist.destroy_process_group()
+
+
+def test_two_rank_recurrent_path_keeps_replicas_identical(hip_lib):
+    """The same for the LSTM policy on the fused recurrent path (rl/fused_lstm.py: hand-derived minibatch step -> all-reduce of
+    the flat gradient -> clip + Adam graph; HIP-kernel recurrent rollout with the rank-synchronised normaliser; advantage moments
+    of the global minibatch): two ranks with different rollouts end with identical parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    procs = [ctx.Process(target=_graph_dp_worker_recurrent, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.terminate()
+    assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    a, b = out[0], out[1]
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    assert out[10] != out[11]
+    assert out[30] == out[31] == (True, True, True, 8), out[30]      # native rollout, synced normaliser, global moments, 2 updates x 2 epochs x 2 minibatches
+
+
 def test_bench_spawns_its_own_ranks(hip_lib):
     """`python bench.py --gpus 2` with no launcher around it starts two ranks itself.  Both ranks share
     this box's one GPU, so the collective backend is gloo here (RCCL refuses two ranks on one device)."""

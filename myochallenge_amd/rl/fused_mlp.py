@@ -417,6 +417,39 @@ class FusedPPOStep:
             p(d[0]), p(d[1]), p(d[2]), C.c_void_p(stream)))
         return dmean, dvalue
 
+    def _sde_loss(self, mean_h, value_h, lat_h, actions, old_logp, adv, returns):
+        """The PPO loss and its gradients for generalised state-dependent exploration (SB3 StateDependentNoiseDistribution with
+        learn_features=False: /root/reference/docs/summary.md:100; rl/policy.py evaluate_actions): the action variance of sample i is
+        var_ia = sum_l lat_il^2 exp(2 log_std_la) + eps with the latent DETACHED, so the trunk sees the loss through the mean only and
+        log_std [latent, act] through the variance (log-probability and per-sample entropy).  fp32 ATen ops on the bf16 trunk outputs —
+        capturable (every sum over the batch is a ones-row GEMM, see _colsum); writes log_std.grad and the head-bias gradients, leaves
+        (policy loss, value loss) in acc[A], acc[A+1], returns bf16 d(loss)/d(mean) [B,A] and d(loss)/d(value) [B,1]."""
+        pol, A, B = self.policy, self.A, mean_h.shape[0]
+        pi_head, vf_head = self.nets["pi"][-1], self.nets["vf"][-1]
+        lat2 = lat_h.float() ** 2                                     # [B, L]
+        e2 = torch.exp(2.0 * pol.log_std.data.float())                # [L, A]
+        var = lat2 @ e2 + pol.SDE_EPS
+        diff = actions - mean_h.float()
+        z2 = diff * diff
+        logp = (-0.5 * z2 / var - 0.5 * torch.log(var)).sum(-1) - 0.5 * A * math.log(2 * math.pi)
+        advn = (adv - self.stats[0]) / (self.stats[1] + 1e-8)
+        ratio = torch.exp(logp - old_logp)
+        s1, s2 = advn * ratio, advn * torch.clamp(ratio, 1 - self.clip, 1 + self.clip)
+        inside = (ratio > 1 - self.clip) & (ratio < 1 + self.clip)
+        dlogp = -(advn * ratio) * torch.where(s1 <= s2, torch.ones_like(ratio), inside.to(ratio.dtype)) / B
+        dmean = dlogp.unsqueeze(-1) * diff / var
+        dvar = dlogp.unsqueeze(-1) * (0.5 * z2 / (var * var) - 0.5 / var) - (self.ent / B) * 0.5 / var      # entropy: sum_a 0.5 log var + const
+        pol.log_std.grad.copy_(2.0 * e2 * (lat2.t() @ dvar))
+        v = value_h.float().reshape(B)
+        err = v - returns
+        dvalue = (self.vf * 2.0 / B) * err
+        sums = _colsum(torch.stack([torch.min(s1, s2), err * err], -1))          # [2]: sum of the surrogate, sum of squared errors
+        self.acc[A].copy_(-sums[0] / B)
+        self.acc[A + 1].copy_(sums[1] / B)
+        pi_head.bias.grad.copy_(_colsum(dmean))
+        vf_head.bias.grad.copy_(_colsum(dvalue.unsqueeze(-1)))
+        return dmean.to(torch.bfloat16), dvalue.to(torch.bfloat16).unsqueeze(-1)
+
     @torch.no_grad()
     def run_indexed(self, obs_all, act_all, oldlp_all, adv_all, ret_all, idx):
         """One minibatch step on rows `idx` of the rollout arrays (merged path: HIP gather kernel)."""
@@ -497,11 +530,14 @@ class FusedPPOStep:
         h = saved[-1]
         pi_head, vf_head = self.nets["pi"][-1], self.nets["vf"][-1]
         wpi, wvf = self.wb[id(pi_head.weight)], self.wb[id(vf_head.weight)]
-        dmean_h = torch.empty((B, A), device=dev, dtype=torch.bfloat16)
-        dvalue_h = torch.empty((B, 1), device=dev, dtype=torch.bfloat16)
-        self._loss_kernel(mean_h, value_h, actions, old_logp, adv, returns, dmean_h, dvalue_h,
-                          direct=(pol.log_std.grad, pi_head.bias.grad, vf_head.bias.grad))
         acc = self.acc
+        if getattr(pol, "use_sde", False):
+            dmean_h, dvalue_h = self._sde_loss(mean_h, value_h, h[0], actions, old_logp, adv, returns)
+        else:
+            dmean_h = torch.empty((B, A), device=dev, dtype=torch.bfloat16)
+            dvalue_h = torch.empty((B, 1), device=dev, dtype=torch.bfloat16)
+            self._loss_kernel(mean_h, value_h, actions, old_logp, adv, returns, dmean_h, dvalue_h,
+                              direct=(pol.log_std.grad, pi_head.bias.grad, vf_head.bias.grad))
         # heads: dW (split-K) and the gradient entering the trunks
         parts = [torch.bmm(dy.view(s, B // s, -1).transpose(1, 2), x.view(s, B // s, -1))
                  for dy, x in ((dmean_h, h[0]), (dvalue_h, h[1]))]

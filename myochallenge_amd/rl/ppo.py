@@ -98,7 +98,7 @@ class PPO:
         self._fused_rec = None
         self._flat_adam = None
         sde = getattr(policy, "use_sde", False)
-        if cfg.use_graphs and on_gpu and not policy.recurrent and not sde:
+        if cfg.use_graphs and on_gpu and not policy.recurrent:      # (gSDE: same fused step with its own loss stage, FusedPPOStep._sde_loss)
             # flat parameter/grad vectors (before any graph captures addresses) + the one-kernel optimiser
             from .. import native
             from .fused_mlp import FlatAdam, flatten_parameters
@@ -106,7 +106,11 @@ class PPO:
                                        cfg.max_grad_norm)
             from .fused_mlp import FusedPPOStep
             self._fused = FusedPPOStep(self.policy, native.load(), cfg.clip_range, cfg.ent_coef, cfg.vf_coef)
-            if len(self._fused.half) == 1:       # one bf16 shadow of the flat vector: Adam keeps it in step
+            if sde and self._fused.merged is None:       # gSDE has a loss stage on the stacked-trunk path only: keep autograd
+                self._fused = self._flat_adam = None
+                self.optimizer = torch.optim.Adam(self.policy.parameters(), lr=cfg.learning_rate, eps=1e-5, capturable=on_gpu,
+                                                  foreach=True if on_gpu else None)
+            if self._fused is not None and len(self._fused.half) == 1:       # one bf16 shadow of the flat vector: Adam keeps it in step
                 self._flat_adam.shadow = self._fused.half[0]
                 self._fused.adam_syncs_shadow = True
                 self._fused.refresh_shadow()
@@ -199,8 +203,8 @@ class PPO:
     # -- native rollout step: HIP kernels for policy input, sampling, VecNormalize and buffer writes
     def _native_rollout(self) -> bool:
         fused = self._fused if self._fused is not None else self._fused_rec
-        return (self._graphed_rollout() and fused is not None and fused.merged is not None
-                and hasattr(self.env, "process_step") and hasattr(self.env, "obs_rms"))
+        return (self._graphed_rollout() and fused is not None and fused.merged is not None and not getattr(self.policy, "use_sde", False)
+                and hasattr(self.env, "process_step") and hasattr(self.env, "obs_rms"))      # (gSDE samples through policy.act)
 
     def _init_native_rollout(self):
         """Per step: graph A (policy input cast, [LSTM step,] stacked trunks, heads, myo_rollout_sample) -> eager

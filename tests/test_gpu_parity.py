@@ -1315,6 +1315,47 @@ def test_gsde_sampling_kernel_matches_torch(hip_lib):
     assert torch.equal(act, mean)
 
 
+def test_fused_gsde_step_matches_autograd(hip_lib):
+    """FusedPPOStep._sde_loss (generalised state-dependent exploration on the fused minibatch step) against autograd through
+    evaluate_actions + PPO's loss on an fp32 copy: losses and every gradient, log_std [latent, act] included."""
+    import copy
+    import torch
+    from myochallenge_amd.rl.fused_mlp import FusedPPOStep, flatten_parameters
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    torch.manual_seed(0)
+    dev = torch.device("cuda:0")
+    pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None, use_sde=True, log_std_init=-1.0).to(dev)
+    with torch.no_grad():
+        pol.log_std.add_(0.2 * torch.randn_like(pol.log_std))
+    ref = copy.deepcopy(pol)
+    B, clip, ent, vf = 4096, 0.2, 0.01, 0.7
+    obs = torch.randn(B, 86, device=dev)
+    pol.reset_noise(B)
+    with torch.no_grad():
+        act = pol.act(obs, None, None)[0]
+        oldlp = ref.evaluate_actions(obs, act)[1] + torch.randn(B, device=dev) * 0.05
+        mean = ref._dist(ref.mlp_extractor.policy_net(obs))[0]
+    wa, wo = torch.randn(39, device=dev), torch.randn(86, device=dev) / 9
+    adv = torch.tanh((act - mean) @ wa) + 0.3 * torch.randn(B, device=dev)          # a learning signal, as in the noise-not-bias test
+    ret = torch.sin(obs @ wo) + 0.1 * torch.randn(B, device=dev)
+    v, lp, en = ref.evaluate_actions(obs, act)
+    advn = (adv - adv.mean()) / (adv.std() + 1e-8)
+    ratio = torch.exp(lp - oldlp)
+    pl_ref = -torch.min(advn * ratio, advn * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+    vl_ref = torch.nn.functional.mse_loss(v, ret)
+    (pl_ref + ent * (-en.mean()) + vf * vl_ref).backward()
+    flatten_parameters(pol)
+    step = FusedPPOStep(pol, hip_lib, clip, ent, vf)
+    assert step.merged is not None
+    pl, vl = step.run(obs, act, oldlp, adv, ret)
+    torch.cuda.synchronize()
+    assert abs(float(pl) - float(pl_ref.detach())) < 5e-3 * (1 + abs(float(pl_ref.detach()))) and abs(float(vl) - float(vl_ref.detach())) < 2e-2 * float(vl_ref.detach())
+    for (name, p), r in zip(pol.named_parameters(), ref.parameters()):
+        err = float((p.grad - r.grad).norm() / (r.grad.norm() + 1e-12))
+        cos = float((p.grad * r.grad).sum() / (p.grad.norm() * r.grad.norm() + 1e-30))
+        assert err < (0.08 if "policy_net.0.weight" in name else 0.04) and cos > 0.997, (name, err, cos)
+
+
 def test_gsde_ppo_round_on_gpu(hip_lib):
     import torch
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
@@ -1325,7 +1366,7 @@ def test_gsde_ppo_round_on_gpu(hip_lib):
     env = VecNormalize(EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=64, seed=3))
     pol = ActorCriticPolicy(86, 39, (64, 64), (64, 64), lstm_hidden_size=None, use_sde=True)
     algo = PPO(env, pol, PPOConfig(n_steps=8, batch_size=128, n_epochs=2))
-    assert algo._fused is None
+    assert algo._fused is not None and algo._fused.merged is not None and not algo._native_rollout()     # fused update, policy.act rollout
     before = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone()
     for _ in range(2):
         algo.collect_rollouts()

@@ -35,7 +35,7 @@ class FusedRecurrentPPOStep(FusedPPOStep):
     @classmethod
     def create(cls, policy, lib, clip_range, ent_coef, vf_coef):
         """None when the parameter layout has no stacked actor/critic views (odd sizes) — the caller keeps autograd."""
-        if not policy.recurrent or getattr(policy, "use_sde", False) or getattr(policy, "_flat", None) is None:
+        if not policy.recurrent or getattr(policy, "_flat", None) is None:
             return None
         la, lc = policy.lstm_actor, policy.lstm_critic
         if lc is None or la.hidden_size != lc.hidden_size or la.hidden_size % 16:

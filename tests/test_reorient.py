@@ -349,8 +349,9 @@ def test_reorient_ppo_lstm_on_gpu(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arch,hidden", [((64, 64), 32), ((), 32), ((64, 64), 48)], ids=["lstm+mlp", "lstm-only", "gemm+cell-kernels"])
-def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch, hidden):
+@pytest.mark.parametrize("arch,hidden,sde", [((64, 64), 32, False), ((), 32, False), ((64, 64), 48, False), ((), 32, True), ((64,), 32, True)],
+                         ids=["lstm+mlp", "lstm-only", "gemm+cell-kernels", "lstm-only-gsde", "lstm+mlp-gsde"])
+def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch, hidden, sde):
     """rl/fused_lstm.py (hand-derived LSTM + trunk + loss forward / backward in bf16) against autograd under bf16
     autocast on the same minibatch of sequences: losses and every parameter's gradient, with episode starts inside
     the sequences and a non-zero LSTM state at the rollout start."""
@@ -362,9 +363,12 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch, hidde
     torch.manual_seed(0)
     N, T, m = 128, 8, 64
     env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=N, seed=3)
-    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, arch, arch, lstm_hidden_size=hidden)     # () = the reference's phase-1 policy shape
+    # () = the reference's phase-1 policy shape; with gSDE: the FIRST_TASK branch of the archived curriculum scripts (LSTM-128, net_arch=[], use_sde)
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, arch, arch, lstm_hidden_size=hidden, use_sde=sde)
     with torch.no_grad():
         pol.log_std.fill_(-0.5)
+        if sde:
+            pol.log_std.add_(0.2 * torch.randn_like(pol.log_std))
     pol2 = copy.deepcopy(pol)
     mk = lambda p: PPO(VecNormalize(env), p, PPOConfig(n_steps=T, batch_size=T * m, n_epochs=1, ent_coef=0.01))
     a = mk(pol)
@@ -395,7 +399,8 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch, hidde
         assert torch.isfinite(ga).all(), n
         cos = float((ga * gb).sum() / (ga.norm() * gb.norm() + 1e-30))
         rel = float((ga - gb).norm() / (gb.norm() + 1e-30))
-        assert cos > 0.995 and rel < 0.1, (n, cos, rel, float(gb.norm()))
+        # (both sides compute in bf16; with gSDE the actor gradient also carries the variance terms' cancellation: looser bound)
+        assert cos > (0.99 if sde else 0.995) and rel < (0.15 if sde else 0.1), (n, cos, rel, float(gb.norm()))
     # the captured graph replays the same step: one update moves every parameter group and stays finite
     before = [p.detach().clone() for p in pol.parameters()]
     st = a.train()

@@ -203,8 +203,8 @@ class PPO:
     # -- native rollout step: HIP kernels for policy input, sampling, VecNormalize and buffer writes
     def _native_rollout(self) -> bool:
         fused = self._fused if self._fused is not None else self._fused_rec
-        return (self._graphed_rollout() and fused is not None and fused.merged is not None and not getattr(self.policy, "use_sde", False)
-                and hasattr(self.env, "process_step") and hasattr(self.env, "obs_rms"))      # (gSDE samples through policy.act)
+        return (self._graphed_rollout() and fused is not None and fused.merged is not None
+                and hasattr(self.env, "process_step") and hasattr(self.env, "obs_rms"))
 
     def _init_native_rollout(self):
         """Per step: graph A (policy input cast, [LSTM step,] stacked trunks, heads, myo_rollout_sample) -> eager
@@ -248,6 +248,27 @@ class PPO:
             self.crit_h_buf, self.crit_c_buf = torch.zeros((T, N, H), device=d, dtype=bf), torch.zeros((T, N, H), device=d, dtype=bf)
             Lw = fused.lstm
 
+        sde = getattr(self.policy, "use_sde", False)
+        if sde:          # gSDE: myo_rollout_sample_sde leaves actions / log pi in step tensors, the rollout buffers take them by index
+            self._act_s, self._logp_s = torch.zeros((N, A), device=d), torch.zeros(N, device=d)
+            if self.policy.exploration_mat is None or self.policy.exploration_mat.shape[0] != N:
+                self.policy.reset_noise(N, self.gen if self.gen.device == self.policy.log_std.device else None)
+
+        def sample(saved, mean_h, value_h, st):
+            """Actions, log pi, value of this step into the rollout buffers (row t_idx) and the clipped actions for the env."""
+            if not sde:
+                lib.check(lib.L.myo_rollout_sample(p(mean_h), p(value_h), p(self.policy.log_std.data), N, A, seed, p(self._draw),
+                                                   p(self._t_idx), p(self.act_buf), p(self.val_buf), p(self.logp_buf),
+                                                   p(self._clip_s), 0, st))
+                return
+            mu, lat = mean_h.float(), saved[-1][0].float().contiguous()      # latent_pi: the actor trunk's output (LSTM output without a trunk)
+            lib.check(lib.L.myo_rollout_sample_sde(p(mu), p(lat), p(self.policy.exploration_mat), p(self.policy.log_std.data), N, lat.shape[1], A,
+                                                   p(self._act_s), p(self._clip_s), p(self._logp_s), 0, st))
+            t64 = self._t_idx.long()
+            self.act_buf.index_copy_(0, t64, self._act_s.unsqueeze(0))
+            self.logp_buf.index_copy_(0, t64, self._logp_s.unsqueeze(0))
+            self.val_buf.index_copy_(0, t64, value_h.float().view(1, N))
+
         def part_a_recurrent():
             st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
             lib.check(lib.L.myo_rollout_policy_input(p(self._obs_s), N, O, p(self.obs_buf), p(self._x2), 2, p(self._t_idx), st))
@@ -267,10 +288,8 @@ class PPO:
             t64 = self._t_idx.long()
             self.crit_h_buf.index_copy_(0, t64, self._hs[1:2])
             self.crit_c_buf.index_copy_(0, t64, self._cs[1:2])
-            _, mean_h, value_h = fused.trunk_heads(self._lat)
-            lib.check(lib.L.myo_rollout_sample(p(mean_h), p(value_h), p(self.policy.log_std.data), N, A, seed, p(self._draw),
-                                               p(self._t_idx), p(self.act_buf), p(self.val_buf), p(self.logp_buf),
-                                               p(self._clip_s), 0, st))
+            saved, mean_h, value_h = fused.trunk_heads(self._lat)
+            sample(saved, mean_h, value_h, st)
 
         def part_a():
             if recurrent:
@@ -281,10 +300,8 @@ class PPO:
                 return
             st = C.c_void_p(torch.cuda.current_stream(d).cuda_stream)
             lib.check(lib.L.myo_rollout_policy_input(p(self._obs_s), N, O, p(self.obs_buf), p(self._x2), 2, p(self._t_idx), st))
-            _, mean_h, value_h = fused.trunk_heads(self._x2)
-            lib.check(lib.L.myo_rollout_sample(p(mean_h), p(value_h), p(self.policy.log_std.data), N, A, seed, p(self._draw),
-                                               p(self._t_idx), p(self.act_buf), p(self.val_buf), p(self.logp_buf),
-                                               p(self._clip_s), 0, st))
+            saved, mean_h, value_h = fused.trunk_heads(self._x2)
+            sample(saved, mean_h, value_h, st)
 
         # N > 1 ranks with a rank-synchronised normaliser: graph B1 (this rank's batch moments) -> eager all-reduce of
         # 2 O + 3 doubles -> graph B2 (running statistics from the global moments, normalise, buffer writes)

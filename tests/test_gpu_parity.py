@@ -1366,13 +1366,24 @@ def test_gsde_ppo_round_on_gpu(hip_lib):
     env = VecNormalize(EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=64, seed=3))
     pol = ActorCriticPolicy(86, 39, (64, 64), (64, 64), lstm_hidden_size=None, use_sde=True)
     algo = PPO(env, pol, PPOConfig(n_steps=8, batch_size=128, n_epochs=2))
-    assert algo._fused is not None and algo._fused.merged is not None and not algo._native_rollout()     # fused update, policy.act rollout
+    assert algo._fused is not None and algo._fused.merged is not None and algo._native_rollout()     # fused update, HIP-kernel rollout
     before = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone()
     for _ in range(2):
         algo.collect_rollouts()
         algo.train()
     after = torch.cat([p.detach().reshape(-1) for p in pol.parameters()])
     assert torch.isfinite(after).all() and not torch.equal(before, after) and float(algo.act_buf.abs().max()) > 0
+    # the HIP-kernel rollout recorded what the policy computes: log pi and values of the stored actions under evaluate_actions
+    algo.collect_rollouts()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        v, lpe, _ = pol.evaluate_actions(algo.obs_buf.view(-1, 86), algo.act_buf.view(-1, 39))
+    assert float((lpe - algo.logp_buf.view(-1)).abs().max()) < 0.02 * (1 + float(algo.logp_buf.abs().max()))
+    assert float((v - algo.val_buf.view(-1)).abs().max()) < 0.03 * (1 + float(algo.val_buf.abs().max()))
+    with torch.no_grad():
+        lat = pol._latents(algo.obs_buf[3], None, None)[0]
+        mean = pol._dist(lat)[0]
+        noise = torch.bmm(lat.float().unsqueeze(1), pol.exploration_mat).squeeze(1)
+    assert float((algo.act_buf[3] - mean.float() - noise).abs().max()) <= 2e-2 * (1 + float(algo.act_buf[3].abs().max()))      # bf16 trunk in the rollout
     # policy.act samples through myo_rollout_sample_sde on the GPU: its log pi must be the one evaluate_actions (torch)
     # assigns to the same actions, and the noise must be the env's own exploration matrix applied to latent_pi
     obs = torch.randn(64, 86, device=pol.log_std.device)

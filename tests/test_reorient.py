@@ -410,7 +410,8 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch, hidde
 
 
 @pytest.mark.gpu
-def test_native_recurrent_rollout_matches_policy(hip_lib):
+@pytest.mark.parametrize("sde", [False, True], ids=["gaussian", "gsde"])
+def test_native_recurrent_rollout_matches_policy(hip_lib, sde):
     """The HIP-kernel rollout step of a recurrent policy (PPO._init_native_rollout: LSTM cell kernel, stacked trunks, sampling
     kernel, state carried in bf16) records what the policy itself computes: re-evaluating the stored sequences with
     ``evaluate_actions`` from the stored start state reproduces the stored values and log-probabilities, across episode starts,
@@ -422,7 +423,7 @@ def test_native_recurrent_rollout_matches_policy(hip_lib):
     torch.manual_seed(0)
     N, T = 128, 12
     env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=N, seed=5, max_episode_steps=9)    # time limits inside the rollout
-    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (64, 64), (64, 64), lstm_hidden_size=32)
+    pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (64, 64), (64, 64), lstm_hidden_size=32, use_sde=sde)
     algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=T, batch_size=T * N, n_epochs=1))
     assert algo._fused_rec is not None
     for r in range(2):

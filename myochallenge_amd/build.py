@@ -59,7 +59,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         # -fno-hip-fp32-correctly-rounded-divide-sqrt: 2.5-ulp fp32 div/sqrt (fewer VALU instructions;
         # the fp64 stepper is unaffected).  Parity tests run against this exact build.
         cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-               "-fno-hip-fp32-correctly-rounded-divide-sqrt", '-DMYO_BUILD_ID="%s"' % source_id(),
+               "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-Wno-invalid-offsetof", '-DMYO_BUILD_ID="%s"' % source_id(),
                os.path.join(CSRC, "myobatch.hip"), "-o", out]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
@@ -72,7 +72,7 @@ def build_emu(force: bool = False, sanitize: bool = False) -> str:
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "libmyobatch_emu_asan.so" if sanitize else "libmyobatch_emu.so")
     if force or _stale(out):
-        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-DMYO_EMU", '-DMYO_BUILD_ID="%s"' % source_id(), "-x", "c++",
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-invalid-offsetof", "-DMYO_EMU", '-DMYO_BUILD_ID="%s"' % source_id(), "-x", "c++",
                os.path.join(CSRC, "myobatch.hip"), "-o", out]
         if sanitize:
             cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]

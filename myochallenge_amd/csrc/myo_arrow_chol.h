@@ -45,8 +45,8 @@ __device__ __noinline__ void arrow_eliminate_blocks(int x_r) {
   const int lane = threadIdx.x, lc = lane & 15, lq = lane >> 4;
   const int nf = M.arrow_nf, nv = M.nv;
   static_assert(MYO_ARROW_S == 16 && MYO_ARROW_B == 4 && MYO_ARROW_NF == 5, "one MFMA tile of separator rows, blocks of K = 4 rows, a fifth block shared by all lane groups");
-  static_assert(4 * 4 * 16 <= 2 * (MYO_NLIM_MAX + 4 * NC), "operand stage in efc_jv + efc_force");
-  lds_t Hp = (lds_t)s.H, xp = (lds_t)s.Mv, stage = (lds_t)s.efc_jv, xin = (lds_t)LPTR(T, x_r);
+  static_assert(4 * 4 * 16 <= MYO_NB_MAX * 6 + 2 * (MYO_NLIM_MAX + 4 * NC), "operand stage in bvec + efc_jv + efc_force");
+  lds_t Hp = (lds_t)s.H, xp = (lds_t)s.Mv, stage = (lds_t)S_SOLVE_STAGE(s), xin = (lds_t)LPTR(T, x_r);
   lds_b perm = (lds_b)s.hperm;
   asm volatile("" : "+v"(Hp), "+v"(xp), "+v"(stage), "+v"(xin), "+v"(perm));
   // ---- right-hand side in row order (rows without a dof: 0)

@@ -76,6 +76,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   double ro_obj_size_change, ro_pos_th, ro_rot_th, ro_goal_init_pos[3], ro_goal_obj_offset[3];
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
+  double* ctrl_ws;            // double[n_envs][MYO_NU_MAX] in global memory: the controls of the fp64 stepper's envs (ScratchPoses<double>::ctrl_g)
   int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity
   unsigned long long seed;
 };
@@ -94,13 +95,31 @@ template <typename T> DEV T fric_cost(T D, T f, T x, T* force, int* quad) {
 template <typename T> DEV T lim_sign(int id) { return id < 0 ? (T)-1 : (T)1; }
 
 template <typename T>
-struct alignas(16) ContactRec {    // 112 B (fp32) / 176 B (fp64): whole 16-byte units, so that the fields keep their wide LDS accesses
-  T frame[6], muA, muB, D, B, kip;   // frame: normal, first tangent (the second is their cross product, con_t2); muA / muB: friction of the slot's two row pairs
+struct alignas(16) ContactRec {    // 80 B (fp32) / 128 B (fp64): whole 16-byte units, so that the fields keep their wide LDS accesses
+  // nrm: the contact normal.  The frame's first tangent is not stored: it is (e - nrm[a] nrm) |tinv|, e = the y axis (tinv > 0, a = 1) or
+  // the z axis (tinv < 0, a = 2) — make_frame's construction with its reciprocal norm kept (con_frame rebuilds all six numbers in 6 flops);
+  // the second tangent is their cross product (con_t2).  muA / muB: friction of the slot's two row pairs.  The rows' reference-acceleration
+  // coefficients B and K imp (dist - margin) are not here either: the emitting lane leaves them in the rows' efc_force / efc_jar entries
+  // (S_ROW_B / S_ROW_KIP), where efc_reference consumes them.
+  T nrm[3], tinv, muA, muB, D;
   T r1[3], r2[3];                 // contact point relative to the reference point of body1's / body2's tree
-  unsigned long long m1, m2;      // ancestor-dof masks of the two bodies
   int pk;                         // body 1 | body 2 << 8 | support size << 16 | slot kind << 24 (con_b1, con_b2, con_nsup, con_kind)
+  // the dofs either body can move, ascending; bit 6 / bit 7 of an entry: the dof is an ancestor dof of body 1 / body 2 (con_sup_*).
+  // (The bodies' 64-bit ancestor masks themselves are not kept here: J' f, whose lanes are dofs, takes them from the model's
+  // body_dofmask through the scalar cache — the contact index is wave-uniform there.)
   alignas(4) unsigned char sup[MYO_CS_MAX];
 };
+static_assert(MYO_NV_MAX <= 64, "ContactRec::sup entries: dof index in bits 0-5");
+// the contact frame (normal, first tangent) of a record, as make_frame built it
+template <typename T> DEV void con_frame(const ContactRec<T>& c, T* f) {
+  f[0] = c.nrm[0]; f[1] = c.nrm[1]; f[2] = c.nrm[2];
+  const bool z = c.tinv < 0;
+  const T i = z ? -c.tinv : c.tinv, t = z ? f[2] : f[1];
+  f[3] = ((T)0 - t * f[0]) * i; f[4] = ((z ? (T)0 : (T)1) - t * f[1]) * i; f[5] = ((z ? (T)1 : (T)0) - t * f[2]) * i;
+}
+DEV int con_sup_dof(int e) { return e & 63; }
+DEV int con_sup_on1(int e) { return (e >> 6) & 1; }
+DEV int con_sup_on2(int e) { return (e >> 7) & 1; }
 // A contact of condim d is stored as one, two or three SLOTS of four constraint rows each (mj_makeConstraint's pyramid rows
 // J_normal +- friction[k] J_k, k < d - 1, in MuJoCo's order); every slot is a full record (same point, frame, D), its KIND says
 // what the two row pairs are:
@@ -124,8 +143,26 @@ struct RkScratch {                // RK4 stage storage: the start state and the 
   T Fsum[2 * MYO_NV_MAX + MYO_NU_MAX];              // 1,360 B in the mixed stepper: behind the scratch in LDS where eight workgroups
 };                                                  // per CU still fit (Scratch<float, 24>), else one per workgroup in GLOBAL memory
 
+// World poses of the bodies (HP), the origin O of the fp32 stages' coordinates, the tree reference points, and the fp32 copies the
+// mixed stepper's stages read.  Mixed stepper: members of their own.  fp64 stepper: no copies, and the poses themselves are
+// POSITION-STAGE data (kinematics .. collision; the task layer reads them after a kinematics pass of its own), so they live in
+// the solver's seven dof vectors, which are first written after the collision stage — accessors S_XPOS / S_XQUAT / S_ORIGIN /
+// S_COM below (1.9 KB of the fp64 scratch: with the 16-slot contact capacity it fits seven workgroups per CU).
+template <typename T> struct ScratchPoses {
+  HP xpos[MYO_NB_MAX * 3], xquat[MYO_NB_MAX * 4];     // world poses of the bodies
+  HP origin[3];                                        // O: the fp32 stages' coordinates are world - O
+  T com[MYO_NB_MAX * 3];
+  T qvelT_[MYO_NV_MAX];                                // qvel as the fp32 stages read it (S_QVELT)
+  T xposT_[MYO_NB_MAX * 3];                            // xpos - O as the fp32 stages read it (S_XPOST)
+  T xmat_[MYO_NB_MAX * 9];                             // rotation matrices as the fp32 stages read them; the fp64 stepper derives them from xquat (body_rot)
+  T ctrl_[MYO_NU_MAX], qacc_warm_[MYO_NV_MAX];         // controls, warm start (ctrl_get / warm_get below)
+};
+// fp64 stepper: the controls (read once per substep) and the solver's warm start (read once, written once) stay in global memory —
+// the warm start in the env's record, where the next part of the step / the next step finds it anyway, the controls in the batch's ctrl_ws
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; };
+
 template <typename T, int NC = MYO_NCON_MAX>
-struct Scratch {
+struct Scratch : ScratchPoses<T> {
   // per-env friction coefficients kept per geom of an object group: all three (sliding, torsional, rolling) in the big scratch that
   // batches with a die get, the sliding one in the base scratch (an object group on a base batch: torsional / rolling stay nominal)
   static constexpr int OBJG_NF = NC >= MYO_NCON_BIG ? 3 : 1;
@@ -133,8 +170,6 @@ struct Scratch {
   // ---- state (HP in every build)
   HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX];
   HP time;
-  T ctrl[MYO_NU_MAX], qacc_warm[MYO_NV_MAX];
-  T qvelT_[sizeof(T) == sizeof(HP) ? 1 : MYO_NV_MAX];   // qvel as the fp32 stages read it (see S_QVELT)
   // ---- per-env parameters
   HP ball_size[2];
   union {                         // the task's per-env numbers = the record's taskd block, in this order
@@ -150,27 +185,31 @@ struct Scratch {
   int which_task, counter, elapsed, episode, ep_len;
   // ---- position stage
   // (short-lived arrays alias longer-lived storage, see the S_* accessors below)
-  HP xpos[MYO_NB_MAX * 3], xquat[MYO_NB_MAX * 4];     // world poses of the bodies
-  HP origin[3];                                        // O: the fp32 stages' coordinates are world - O
-  T xposT_[sizeof(T) == sizeof(HP) ? 1 : MYO_NB_MAX * 3];   // xpos - O as the fp32 stages read it (see S_XPOST)
-  T xmat_[sizeof(T) == sizeof(HP) ? 1 : MYO_NB_MAX * 9];     // rotation matrices as the fp32 stages read them; the fp64 stepper derives them from xquat (body_rot)
-  T com[MYO_NB_MAX * 3];
   T cdof[MYO_NV_MAX * 6];
-  T bvec[MYO_NB_MAX * 6];
-  HP ten_length[MYO_NT_MAX];                          // HP: what muscle forces and tendon limits are made of
+  union {                         // tendon lengths (tendon stage .. actuation) and activation rates (actuation .. advance) share a slot:
+    HP ten_length[MYO_NT_MAX];    // fwd_actuation reads every length before it stores the first rate.  HP: what muscle forces and
+    T act_dot[MYO_NU_MAX];        // tendon limits are made of
+  };
   T ten_J[MYO_NT_MAX * MYO_TJ_MAX];                   // (ten_vel, act_force: S_TEN_VEL / S_ACT_FORCE below)
-  T act_dot[MYO_NU_MAX];
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
   // ---- constraints
   int ncon, nefc, nl, ntl, bad, solver_iter;   // ncon: contact SLOTS (four rows each, ContactRec)
   unsigned char hperm[MYO_NV_MAX];   // dof -> row of the Newton system (DevModel::hperm; identity unless the block-arrow solver is on)
-  // (from con[] to qM, i.e. up to rk: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live)
-  alignas(16) ContactRec<T> con[NC];
+  // (from con[] on: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live.
+  //  Mixed stepper: up to rk.  fp64 stepper: up to qfrc_smooth, where its body poses live during the position stage.)
+  // NREC record slots over the 4 NC contact rows of the efc_* arrays: the fp64 base scratch has 24 slots for 64 contact rows, because the
+  // rows are SHARED with the limit rows (capacity MYO_NLIM_MAX, ~11 in use on the hand): a substep holds min(NREC, (rows - limit rows) / 4)
+  // contacts (contacts_emit_*), at least NC.  Measured on the hand with P2's ball sizes: up to 19 contacts (oracle, 32 episodes).
+  static constexpr int NREC = (sizeof(T) == sizeof(HP) && NC == MYO_NCON_F64) ? MYO_NREC_F64 : NC;
+  alignas(16) ContactRec<T> con[NREC];
   short lim_id[MYO_NLIM_MAX];                                          // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1)
   T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
-  alignas(8) T efc_jar[MYO_NLIM_MAX + 4 * NC], efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC];
+  // bvec, efc_jv, efc_force: contiguous, in this order — the linear solves stage their operands from bvec on (S_SOLVE_STAGE)
+  alignas(16) T bvec[MYO_NB_MAX * 6];
+  T efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC], efc_jar[MYO_NLIM_MAX + 4 * NC];
   unsigned char efc_active[MYO_NLIM_MAX + 4 * NC];
-  alignas(8) T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
+  // the seven dof vectors: contiguous, in this order (fp64 stepper: the position stage's poses live here, see ScratchPoses)
+  alignas(16) T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
   T Ma[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX];   // search: -gradient between update_constraint and the solve, then the Newton direction
   T qM[MYO_NM_MAX];               // tree-sparse inertia matrix (written by crb, i.e. after the tendon stage: the last piece of its staging area)
   RkScratch<T>* rk;               // null unless the model integrates with RK4
@@ -181,12 +220,27 @@ struct Scratch {
 #endif
 };
 
+// body poses, origin, tree reference points: ScratchPoses members (mixed stepper) / inside the seven dof vectors (fp64 stepper)
+#define MYO_POSE_ACC(NAME, TYPE, MEMBER, OFF)                                                                                         \
+  template <typename T, int NC> DEV TYPE* NAME(Scratch<T, NC>& s) {                                                                   \
+    if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<TYPE*>(s.qfrc_smooth) + (OFF); else return s.MEMBER;               \
+  }                                                                                                                                   \
+  template <typename T, int NC> DEV const TYPE* NAME(const Scratch<T, NC>& s) {                                                       \
+    if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const TYPE*>(s.qfrc_smooth) + (OFF); else return s.MEMBER;         \
+  }
+MYO_POSE_ACC(S_XPOS, HP, xpos, 0)
+MYO_POSE_ACC(S_XQUAT, HP, xquat, MYO_NB_MAX * 3)
+MYO_POSE_ACC(S_ORIGIN, HP, origin, MYO_NB_MAX * 7)
+MYO_POSE_ACC(S_COM, T, com, MYO_NB_MAX * 7 + 3)
+#undef MYO_POSE_ACC
+static_assert(MYO_NB_MAX * 10 + 3 <= 7 * MYO_NV_MAX && (MYO_NB_MAX * 3) % 2 == 0, "fp64 stepper: xpos, xquat, origin, com fit in the seven dof vectors; xquat stays 16-byte aligned");
+
 // the fp32 stages' view of the two HP arrays they read every substep: a float copy in the mixed stepper,
 // the HP array itself in the fp64 stepper (O = 0 there)
 template <typename T, int NC> DEV T* S_QVELT(Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.qvel); else return s.qvelT_; }
 template <typename T, int NC> DEV const T* S_QVELT(const Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.qvel); else return s.qvelT_; }
-template <typename T, int NC> DEV T* S_XPOST(Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(s.xpos); else return s.xposT_; }
-template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(s.xpos); else return s.xposT_; }
+template <typename T, int NC> DEV T* S_XPOST(Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<T*>(S_XPOS(s)); else return s.xposT_; }
+template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return reinterpret_cast<const T*>(S_XPOS(s)); else return s.xposT_; }
 
 // Aliases: arrays whose lifetime ends before the buffer they live in is next written.
 //   H is only live from qacc_smooth to the end of the solver / Euler solve.  Before that
@@ -194,8 +248,8 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 //   bias / actuator force vectors (velocity..actuation), and after the physics the observation.
 //   xanchor / xaxis (until cdof is built) -> efc_jar / efc_jv; the kinematics stage keeps its HP joint
 //   anchors / axes (parent frame) in con[], which is dead until the collision stage
-//   xipos (until cinert is built) -> efc_force;  the compaction prefix npre -> search, Mv;  cfrcb (RNE) -> bvec
-//   limit rows' B and K imp (pos - margin) (constraint_limits .. efc_reference) -> efc_force;  the reference acceleration aref
+//   xipos (until cinert is built) -> efc_force;  the compaction prefix npre -> efc_jv;  cfrcb (RNE) -> bvec
+//   every row's B / K imp (pos - margin) (constraint_limits, collision .. efc_reference) -> the row's efc_force / efc_jar entry;  the reference acceleration aref
 //   (efc_reference .. the solver's warm-start choice, where efc_jar = J qacc - aref replaces it) -> efc_jar
 #define S_CINERT(s) ((s).H)
 #define S_CRB(s) ((s).H + MYO_NB_MAX * 10)
@@ -204,20 +258,24 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_QFRC_BIAS(s) ((s).H + MYO_NB_MAX * 20 + MYO_NV_MAX)
 #define S_QFRC_ACTUATOR(s) ((s).H + MYO_NB_MAX * 20 + 2 * MYO_NV_MAX)
 #define S_OBS(s) ((s).H + MYO_NB_MAX * 20 + 3 * MYO_NV_MAX)
-#define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage: position of every path element (con[] is dead until the collision stage) */
-/* tendon stage: HP wrap results (7 per geom wrap) behind the T path points, running on through the limit-row and efc_* arrays */
-#define S_TWRES(s, nwrap) (reinterpret_cast<HP*>(reinterpret_cast<char*>((s).con) + ((3 * (size_t)(nwrap) * sizeof(T) + 7) & ~(size_t)7)))
+#define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage, mixed stepper: fp32 position of every path element (con[] is dead until the collision stage) */
+/* tendon stage: HP wrap results (7 per geom wrap) behind the T path points, running on through the limit-row and efc_* arrays.
+   The fp64 stepper stages no path points (its moment arms take the HP points the lengths are made of): the results start at con[] */
+#define S_TWRES(s, nwrap) (reinterpret_cast<HP*>(reinterpret_cast<char*>((s).con) + (sizeof(T) == sizeof(HP) ? (size_t)0 : ((3 * (size_t)(nwrap) * sizeof(T) + 7) & ~(size_t)7))))
+/* operand stage of the linear solves (chol_factor_solve_reg, arrow_eliminate_blocks): from bvec on through efc_jv, efc_force —
+   body vectors, J v and the row forces are all rebuilt after a solve */
+#define S_SOLVE_STAGE(s) ((s).bvec)
 #define S_ACT_GF(s) (static_cast<T*>((s).Ma))   /* gear * actuator force (actuation stage, NU_MAX entries through Ma, search: the body velocities that live there are dead after efc_reference) */
 #define S_KTMP(s) (reinterpret_cast<HP*>((s).con))   /* HP [2][MYO_NJ_MAX * 3] */
 #define S_XANCHOR(s) ((s).efc_jar)
 #define S_XAXIS(s) ((s).efc_jv)
 #define S_XIPOS(s) ((s).efc_force)
-#define S_NPRE(s) (reinterpret_cast<int*>((s).search))   /* 64 ints through search, Mv */
+#define S_NPRE(s) (reinterpret_cast<int*>((s).efc_jv))   /* 64 ints; efc_jv is free from the end of com_pos (S_XAXIS) to efc_reference */
 #define S_CFRCB(s) ((s).bvec)
 // RK4's combined stage derivative (2 nv + nu numbers): in efc_jv, dead between two forward() calls (J v of the last line search)
 #define S_RKDX(s) ((s).efc_jv)
-#define S_LIM_B(s) ((s).efc_force)
-#define S_LIM_KIP(s) ((s).efc_force + MYO_NLIM_MAX)
+#define S_ROW_B(s) ((s).efc_force)      /* every row's B and K imp (pos - margin), from the lane that builds the row to efc_reference */
+#define S_ROW_KIP(s) ((s).efc_jar)
 #define S_AREF(s) ((s).efc_jar)
 /* world-frame force of every contact (3 per contact), staged by J' f: in efc_jv, dead between the line search that consumed J v and the next J v */
 #define S_CONF(s) (static_cast<T*>((s).efc_jv))
@@ -229,7 +287,7 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_TEN_VEL(s) (static_cast<T*>((s).qacc_smooth))
 #define S_ACT_FORCE(s) (static_cast<T*>((s).qacc_smooth) + MYO_NT_MAX)
 static_assert(MYO_NB_MAX * 20 + 3 * MYO_NV_MAX + MYO_OBS_MAX <= MYO_H_SIZE && MYO_NU_MAX <= 2 * MYO_NV_MAX, "H aliases; S_ACT_GF");
-static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MAX && 64 * sizeof(int) <= 2 * MYO_NV_MAX * sizeof(float), "S_LIM_B / S_LIM_KIP in efc_force; S_NPRE in search, Mv");
+static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MAX && 64 * sizeof(int) <= (MYO_NLIM_MAX + 4 * MYO_NCON_F64) * sizeof(float), "S_NPRE in efc_jv");
 static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 1024 && MYO_NU_MAX <= 64, "packed actuator gather entries are 10 + 6 bits");
 static_assert(MYO_NV_MAX * 6 <= MYO_NB_MAX * 10, "cdof_dot fits where crb was");
 static_assert(MYO_NB_MAX * 6 <= 4 * MYO_NV_MAX, "cvel fits in qfrc_constraint..Mv");
@@ -237,9 +295,15 @@ static_assert(MYO_NT_MAX <= MYO_NV_MAX + 4 && MYO_NT_MAX + MYO_NU_MAX <= 3 * MYO
 static_assert(2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MAX, "the RK4 stage derivative fits in efc_jv");
 static_assert(MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX && 64 <= MYO_NEFC_MAX, "efc aliases");
 static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRec<float>) && 2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_F64 * sizeof(ContactRec<double>), "kinematics temporaries fit in con[]");
+// controls and warm start of the env: LDS members (mixed stepper) / global memory (fp64 stepper, ScratchPoses<double>).  A lane only ever
+// reads entries it wrote itself (lane i <-> entry i, i + 64, ...), so the global copies need no fence inside a workgroup.
+template <typename T, int NC> DEV T ctrl_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.ctrl_g[i]; else return s.ctrl_[i]; }
+template <typename T, int NC> DEV void ctrl_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) s.ctrl_g[i] = (double)v; else s.ctrl_[i] = v; }
+template <typename T, int NC> DEV T warm_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.warm_g[i]; else return s.qacc_warm_[i]; }
+template <typename T, int NC> DEV void warm_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) s.warm_g[i] = (double)v; else s.qacc_warm_[i] = v; }
 #define MYO_NEFC_MIN (MYO_NLIM_MAX + 4 * MYO_NCON_F64)   /* rows of the smallest scratch: every alias of an efc_* array must fit in this many */
 static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MIN && 2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MIN && MYO_NJ_MAX * 3 <= MYO_NEFC_MIN && MYO_NB_MAX * 3 <= MYO_NEFC_MIN && 64 <= MYO_NEFC_MIN,
-              "efc aliases (S_LIM_B / S_LIM_KIP, S_RKDX, S_XANCHOR / S_XAXIS, S_XIPOS) in the smallest scratch");
+              "efc aliases (S_RKDX, S_XANCHOR / S_XAXIS, S_XIPOS) in the smallest scratch");
 
 // ---- phase functions are real (non-inlined) functions in the gfx950 build: each gets its own
 // register allocation (the fully inlined kernel spilled ~170 VGPRs and was several MB of code).
@@ -333,15 +397,16 @@ template <typename T> DEV T tclamp(T x, T lo, T hi) { return x < lo ? lo : (x > 
 
 // (J v)[row e of the slot] from the relative linear / angular velocity of the two bodies at the contact
 template <typename T> DEV T con_row_val(const ContactRec<T>& c, int kind, int e, const T* rel_lin, const T* rel_ang) {
-  T t2[3];
-  cross3(t2, c.frame, c.frame + 3);
+  T t2[3], fr[6];
+  con_frame(c, fr);
+  cross3(t2, fr, fr + 3);
   const int second = e >> 1;
   const T mu = second ? c.muB : c.muA;
   // the pair's axis: kind 0: t1 | t2 (on the linear velocity); 1: n | t1, 2: t2, 4: n (on the angular velocity); 3: none (mu = 0)
   const bool ax_n = (kind == 1 && !second) || kind == 4, ax_t1 = (kind == 0 && !second) || (kind == 1 && second);
-  const T ax[3] = {ax_n ? c.frame[0] : (ax_t1 ? c.frame[3] : t2[0]), ax_n ? c.frame[1] : (ax_t1 ? c.frame[4] : t2[1]), ax_n ? c.frame[2] : (ax_t1 ? c.frame[5] : t2[2])};
+  const T ax[3] = {ax_n ? fr[0] : (ax_t1 ? fr[3] : t2[0]), ax_n ? fr[1] : (ax_t1 ? fr[4] : t2[1]), ax_n ? fr[2] : (ax_t1 ? fr[5] : t2[2])};
   const T* rel = kind == 0 ? rel_lin : rel_ang;
-  const T val = dot3(c.frame, rel_lin) + ((e & 1) ? -mu : mu) * dot3(ax, rel);
+  const T val = dot3(fr, rel_lin) + ((e & 1) ? -mu : mu) * dot3(ax, rel);
   return con_pad(kind, e) ? (T)0 : val;
 }
 
@@ -424,7 +489,7 @@ template <typename T, int NC> DEV HP geom_size1_hp(const DevModel<T>& M, const T
 // body's quaternion — the same quat2mat on the same numbers as the kinematics stage's, so the same bits — which keeps 1.7 KB
 // of matrices out of LDS (the fp64 scratch fits six workgroups per CU without them)
 template <typename T, int NC> DEV void body_rot(const Scratch<T, NC>& s, int b, T* R) {
-  if constexpr (sizeof(T) == sizeof(HP)) quat2mat(R, reinterpret_cast<const T*>(s.xquat) + 4 * b);
+  if constexpr (sizeof(T) == sizeof(HP)) quat2mat(R, reinterpret_cast<const T*>(S_XQUAT(s)) + 4 * b);
   else { for (int k = 0; k < 9; ++k) R[k] = s.xmat_[9 * b + k]; }
 }
 // position of a point given in body coordinates, in the fp32 stages' frame (world - O)
@@ -438,13 +503,13 @@ template <typename T, int NC> DEV void body_point(const Scratch<T, NC>& s, int b
 // the same in HP and in WORLD coordinates (contact distances, observation)
 template <typename T, int NC> DEV void body_point_hp(const Scratch<T, NC>& s, int b, const HP* local, HP* out) {
   HP R[9];
-  quat2mat(R, s.xquat + 4 * b);
+  quat2mat(R, S_XQUAT(s) + 4 * b);
   mulmatvec3(out, R, local);
-  out[0] += s.xpos[3 * b]; out[1] += s.xpos[3 * b + 1]; out[2] += s.xpos[3 * b + 2];
+  out[0] += S_XPOS(s)[3 * b]; out[1] += S_XPOS(s)[3 * b + 1]; out[2] += S_XPOS(s)[3 * b + 2];
 }
 // translational Jacobian column of dof d for a world point p: cdof_lin + cdof_ang x (p - com)
 template <typename T, int NC> DEV void jac_col(const DevModel<T>& M, const Scratch<T, NC>& s, int d, const T* p, T* col) {
-  const T* c = s.com + 3 * M.dof_rootbody[d]; const T* cd = s.cdof + 6 * d;
+  const T* c = S_COM(s) + 3 * M.dof_rootbody[d]; const T* cd = s.cdof + 6 * d;
   T off[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]}, t[3];
   cross3(t, cd, off);
   col[0] = cd[3] + t[0]; col[1] = cd[4] + t[1]; col[2] = cd[5] + t[2];
@@ -460,7 +525,7 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   WAVE_FN
   PHASE {
     if (lane == 0) {
-      s.xpos[0] = s.xpos[1] = s.xpos[2] = 0; s.xquat[0] = 1; s.xquat[1] = s.xquat[2] = s.xquat[3] = 0;
+      S_XPOS(s)[0] = S_XPOS(s)[1] = S_XPOS(s)[2] = 0; S_XQUAT(s)[0] = 1; S_XQUAT(s)[1] = S_XQUAT(s)[2] = S_XQUAT(s)[3] = 0;
       if constexpr (sizeof(T) != sizeof(HP)) { for (int k = 0; k < 9; ++k) s.xmat_[k] = (k % 4 == 0) ? (T)1 : (T)0; }
     }
     if constexpr (sizeof(T) != sizeof(HP)) { if (lane < M.nv) s.qvelT_[lane] = (T)s.qvel[lane]; }
@@ -531,42 +596,42 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       if (LV(k_depth) == level) {
         const int par = LV(k_par);
         const HP pl[3] = {LV(k_p0), LV(k_p1), LV(k_p2)}, ql[4] = {LV(k_q0), LV(k_q1), LV(k_q2), LV(k_q3)};
-        const HP qp[4] = {s.xquat[4 * par], s.xquat[4 * par + 1], s.xquat[4 * par + 2], s.xquat[4 * par + 3]};
+        const HP qp[4] = {S_XQUAT(s)[4 * par], S_XQUAT(s)[4 * par + 1], S_XQUAT(s)[4 * par + 2], S_XQUAT(s)[4 * par + 3]};
         HP Rp[9], t[3], q[4];
         quat2mat(Rp, qp);
         mulmatvec3(t, Rp, pl);
         mulquat(q, qp, ql);
         normalize4(q);
-        for (int k = 0; k < 3; ++k) s.xpos[3 * b + k] = s.xpos[3 * par + k] + t[k];
-        for (int k = 0; k < 4; ++k) s.xquat[4 * b + k] = q[k];
+        for (int k = 0; k < 3; ++k) S_XPOS(s)[3 * b + k] = S_XPOS(s)[3 * par + k] + t[k];
+        for (int k = 0; k < 4; ++k) S_XQUAT(s)[4 * b + k] = q[k];
       }
     }
     SYNC();
   }
   // O = world position of the first tree root (body 1), fp32-representable so that xpos - O is exact in HP
   PHASE {
-    if (lane < 3) s.origin[lane] = (sizeof(T) != sizeof(HP) && M.nbody > 1) ? (HP)(float)s.xpos[3 + lane] : (HP)0;
+    if (lane < 3) S_ORIGIN(s)[lane] = (sizeof(T) != sizeof(HP) && M.nbody > 1) ? (HP)(float)S_XPOS(s)[3 + lane] : (HP)0;
   }
   SYNC();
   PHASE {
     const int b = lane;
     if (b < M.nbody) {
-      if constexpr (sizeof(T) != sizeof(HP)) { for (int k = 0; k < 3; ++k) s.xposT_[3 * b + k] = (T)(s.xpos[3 * b + k] - s.origin[k]); }
+      if constexpr (sizeof(T) != sizeof(HP)) { for (int k = 0; k < 3; ++k) s.xposT_[3 * b + k] = (T)(S_XPOS(s)[3 * b + k] - S_ORIGIN(s)[k]); }
     }
     if (b > 0 && b < M.nbody) {
       const int par = LV(k_par), jn = LV(k_jn), ja = LV(k_ja);
-      const HP q[4] = {s.xquat[4 * b], s.xquat[4 * b + 1], s.xquat[4 * b + 2], s.xquat[4 * b + 3]};
+      const HP q[4] = {S_XQUAT(s)[4 * b], S_XQUAT(s)[4 * b + 1], S_XQUAT(s)[4 * b + 2], S_XQUAT(s)[4 * b + 3]};
       HP R[9], t[3];
       quat2mat(R, q);
       if constexpr (sizeof(T) != sizeof(HP)) { for (int k = 0; k < 9; ++k) s.xmat_[9 * b + k] = (T)R[k]; }
       const HP ipos[3] = {(HP)M.body_ipos[3 * b], (HP)M.body_ipos[3 * b + 1], (HP)M.body_ipos[3 * b + 2]};
       mulmatvec3(t, R, ipos);
-      for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = (T)(s.xpos[3 * b + k] - s.origin[k] + t[k]);
+      for (int k = 0; k < 3; ++k) S_XIPOS(s)[3 * b + k] = (T)(S_XPOS(s)[3 * b + k] - S_ORIGIN(s)[k] + t[k]);
       if (LV(k_free)) {
-        for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * ja + e] = (T)(kanchor[3 * ja + e] - s.origin[e]); S_XAXIS(s)[3 * ja + e] = (T)kaxis[3 * ja + e]; }
+        for (int e = 0; e < 3; ++e) { S_XANCHOR(s)[3 * ja + e] = (T)(kanchor[3 * ja + e] - S_ORIGIN(s)[e]); S_XAXIS(s)[3 * ja + e] = (T)kaxis[3 * ja + e]; }
       } else if (jn > 0) {                           // anchors / axes: parent frame -> world
-        const HP qp[4] = {s.xquat[4 * par], s.xquat[4 * par + 1], s.xquat[4 * par + 2], s.xquat[4 * par + 3]};
-        const HP pp[3] = {s.xpos[3 * par] - s.origin[0], s.xpos[3 * par + 1] - s.origin[1], s.xpos[3 * par + 2] - s.origin[2]};
+        const HP qp[4] = {S_XQUAT(s)[4 * par], S_XQUAT(s)[4 * par + 1], S_XQUAT(s)[4 * par + 2], S_XQUAT(s)[4 * par + 3]};
+        const HP pp[3] = {S_XPOS(s)[3 * par] - S_ORIGIN(s)[0], S_XPOS(s)[3 * par + 1] - S_ORIGIN(s)[1], S_XPOS(s)[3 * par + 2] - S_ORIGIN(s)[2]};
         HP Rp[9];
         quat2mat(Rp, qp);
         for (int k = 0; k < jn; ++k) {
@@ -591,7 +656,7 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
   WAVE_FN
   PHASE {
     const int b = lane;
-    if (b == 0) { s.com[0] = s.com[1] = s.com[2] = 0; }
+    if (b == 0) { S_COM(s)[0] = S_COM(s)[1] = S_COM(s)[2] = 0; }
     if (b > 0 && b < M.nbody && M.body_rootid[b] == b) {
       T mass = 0, c[3] = {0, 0, 0};
 #pragma unroll 4
@@ -603,7 +668,7 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
       }
       if (mass < MYO_MINVAL) { c[0] = S_XIPOS(s)[3 * b]; c[1] = S_XIPOS(s)[3 * b + 1]; c[2] = S_XIPOS(s)[3 * b + 2]; }
       else { c[0] /= mass; c[1] /= mass; c[2] /= mass; }
-      s.com[3 * b] = c[0]; s.com[3 * b + 1] = c[1]; s.com[3 * b + 2] = c[2];
+      S_COM(s)[3 * b] = c[0]; S_COM(s)[3 * b + 1] = c[1]; S_COM(s)[3 * b + 2] = c[2];
     }
   }
   SYNC();
@@ -616,7 +681,7 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
         T R[9], Rb[9];
         body_rot(s, b, Rb);
         mulmat3(R, Rb, M.body_imat + 9 * b);
-        const T* I = M.body_inertia + 3 * b; const T* c = s.com + 3 * M.body_rootid[b];
+        const T* I = M.body_inertia + 3 * b; const T* c = S_COM(s) + 3 * M.body_rootid[b];
         const T off[3] = {S_XIPOS(s)[3 * b] - c[0], S_XIPOS(s)[3 * b + 1] - c[1], S_XIPOS(s)[3 * b + 2] - c[2]};
         const T mb = body_mass_of(M, K, s, b);
         ci[0] = R[0] * R[0] * I[0] + R[1] * R[1] * I[1] + R[2] * R[2] * I[2] + mb * (off[1] * off[1] + off[2] * off[2]);
@@ -631,7 +696,7 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
     const int j = lane;
     if (j < M.njnt) {
       const int b = M.jnt_bodyid[j], da = M.jnt_dofadr[j];
-      const T* c = s.com + 3 * M.body_rootid[b];
+      const T* c = S_COM(s) + 3 * M.body_rootid[b];
       const T off[3] = {c[0] - S_XANCHOR(s)[3 * j], c[1] - S_XANCHOR(s)[3 * j + 1], c[2] - S_XANCHOR(s)[3 * j + 2]};
       if (M.jnt_type[j] == 0) {
         for (int k = 0; k < 3; ++k) { T* cd = s.cdof + 6 * (da + k); for (int e = 0; e < 6; ++e) cd[e] = 0; cd[3 + k] = 1; }
@@ -780,7 +845,7 @@ DEV void tendon_segment_moment(const Scratch<T, NC>& s, T* Jrow, unsigned long l
     x &= x - 1;
     const int on1 = (int)((m1 >> d) & 1ull);
     const T* p = on1 ? p1 : p0;
-    const T* c = s.com + 3 * (on1 ? r1 : r0);
+    const T* c = S_COM(s) + 3 * (on1 ? r1 : r0);
     const T* cd = s.cdof + 6 * d;
     const T off[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     T t[3];
@@ -796,7 +861,7 @@ DEV void tendon_segment_moment(const Scratch<T, NC>& s, T* Jrow, unsigned long l
 template <typename T, int NC> DEV void wrap_point_hp(const DevModel<T>& M, const Scratch<T, NC>& s, int body, const HP* local, HP* out) {
   (void)M;
   body_point_hp(s, body, local, out);
-  out[0] -= s.origin[0]; out[1] -= s.origin[1]; out[2] -= s.origin[2];
+  out[0] -= S_ORIGIN(s)[0]; out[1] -= S_ORIGIN(s)[1]; out[2] -= S_ORIGIN(s)[2];
 }
 
 // One wrap object as the tendon stage sees it (resolved on the host, see upload: wr_i / wr_p / wr_m /
@@ -815,7 +880,7 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& 
   WAVE_FN
   // Three phases instead of one divergent walk per tendon (a wave whose 39 lanes sit at different
   // path elements executes the site branch AND the cylinder-wrap branch every iteration):
-  //  A  lane = path element : position of every site / wrap-geom centre (T, relative to O)  -> S_TWP[3w]
+  //  A  lane = path element : position of every site / wrap-geom centre (T, relative to O)  -> S_TWP[3w]   (mixed stepper only)
   //  B  lane = geom wrap    : wrap_geom for all sphere/cylinder wraps in lockstep -> wres[7k] = len, 2 points (HP)
   //  C  lane = tendon       : lengths and moment arms from the staged points (cheap, little divergence)
   // Precision: the LENGTH of a tendon is HP end to end — the points it is made of are recomputed from the HP
@@ -830,15 +895,18 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& 
   (void)wres;
   PHASE {
     for (int i = lane; i < M.ntendon * MYO_TJ_MAX; i += 64) s.ten_J[i] = 0;     // phase C accumulates into it
-    for (int w = lane; w < M.nwrap; w += 64) {
-      const int body = M.wr_i[8 * w + 1];
-      if (body >= 0) {
-        const T lp[3] = {M.wr_p[4 * w], M.wr_p[4 * w + 1], M.wr_p[4 * w + 2]};
-        body_point(s, body, lp, wp + 3 * w);
+    if constexpr (sizeof(T) != sizeof(HP)) {
+      for (int w = lane; w < M.nwrap; w += 64) {
+        const int body = M.wr_i[8 * w + 1];
+        if (body >= 0) {
+          const T lp[3] = {M.wr_p[4 * w], M.wr_p[4 * w + 1], M.wr_p[4 * w + 2]};
+          body_point(s, body, lp, wp + 3 * w);
+        }
       }
     }
   }
   SYNC();
+  (void)wp;
 }
 
 // phase B of the tendon stage, one geom wrap per lane (called once per 64 wraps from kernel level: a leaf function
@@ -858,7 +926,7 @@ DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratc
       // continuous there, but an fp32 evaluation of the predicates picks the wrong tangent pair (measured:
       // seg_intersect flips on a 7e-7 m wrap and the path goes the long way round).
       HP gmat[9], bm[9], side[3] = {0, 0, 0}, pts[6], x0[3], x1[3], gp[3];
-      quat2mat(bm, s.xquat + 4 * body);
+      quat2mat(bm, S_XQUAT(s) + 4 * body);
       mulmat3(gmat, bm, M.h_wr_m + 12 * w);
       if (side_body >= 0) wrap_point_hp(M, s, side_body, M.h_wr_m + 12 * w + 9, side);
       wrap_point_hp(M, s, M.wr_i[8 * (w - 1) + 1], M.h_wr_p + 4 * (w - 1), x0);
@@ -903,8 +971,10 @@ DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scr
       wrap_point_hp(M, s, we.body, M.h_wr_p + 4 * iend, q1);
       // straight segments of this path element: site -> site, or site -> wrap point, (arc), wrap point -> site.
       // Selected with scalars (no run-time indexed local arrays: they would live in private memory).
-      const T p0[3] = {wp[3 * i0], wp[3 * i0 + 1], wp[3 * i0 + 2]};
-      const T x1[3] = {wp[3 * iend], wp[3 * iend + 1], wp[3 * iend + 2]};
+      // (fp64 stepper: the HP end points themselves — body_point and wrap_point_hp are the same arithmetic there, O = 0 — no staged copy)
+      T p0[3], x1[3];
+      if constexpr (sizeof(T) == sizeof(HP)) { for (int k = 0; k < 3; ++k) { p0[k] = q0[k]; x1[k] = q1[k]; } (void)wp; }
+      else { for (int k = 0; k < 3; ++k) { p0[k] = wp[3 * i0 + k]; x1[k] = wp[3 * iend + k]; } }
       HP wlen = -1, h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0};
       if (is_geom) {
         const HP* r = wres + 7 * M.wr_i[8 * ig + 6];
@@ -1243,12 +1313,13 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
       // compiler re-derives it inside a divergent region: measured 26 look-ups and +22 k cycles in one call of this
       // function before the pointers were pinned)
       typedef __attribute__((address_space(3))) T* lds_t;
-      lds_t stage = (lds_t)s.efc_jv;                   // [NT * 16 rows][4] + 64 dump entries; efc_jv and efc_force are free while a system is solved
+      lds_t stage = (lds_t)S_SOLVE_STAGE(s);           // [NT * 16 rows][4] + 64 dump entries; bvec, efc_jv and efc_force are free while a system is solved
       lds_t Hp = (lds_t)s.H;
       asm volatile("" : "+v"(stage), "+v"(Hp));
-      static_assert(NT * 16 * 4 + 64 <= 2 * (MYO_NLIM_MAX + 4 * NC) && 4 * 64 <= 2 * (MYO_NLIM_MAX + 4 * NC), "panel stage and dump area fit in efc_jv + efc_force");
+      static_assert(NT * 16 * 4 + 64 <= MYO_NB_MAX * 6 + 2 * (MYO_NLIM_MAX + 4 * NC) && 4 * 64 <= MYO_NB_MAX * 6 + 2 * (MYO_NLIM_MAX + 4 * NC), "panel stage and dump area fit in bvec + efc_jv + efc_force");
       typedef Scratch<T, NC> ScratchT;
-      static_assert(offsetof(ScratchT, efc_force) - offsetof(ScratchT, efc_jv) == (MYO_NLIM_MAX + 4 * NC) * sizeof(T), "efc_jv and efc_force are contiguous");
+      static_assert(offsetof(ScratchT, efc_jv) - offsetof(ScratchT, bvec) == MYO_NB_MAX * 6 * sizeof(T) &&
+                    offsetof(ScratchT, efc_force) - offsetof(ScratchT, efc_jv) == (MYO_NLIM_MAX + 4 * NC) * sizeof(T), "bvec, efc_jv and efc_force are contiguous");
       typename MM::V4 acc[NT * (NT + 1) / 2];
       // symmetric fill of the lower tiles from the packed lower triangle; identity beyond N
   #pragma unroll
@@ -1428,13 +1499,15 @@ DEV void solve_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, T* x, int damped
 // the distance itself, the normal, and the contact point relative to O.
 struct ContactTmp { HP dist[2], pos[6], nrm[6]; int n; };
 
-template <typename T> DEV void make_frame(T* f) {
+// normal f[0..2] -> unit normal; returns the record's `tinv`: the reciprocal norm of (e - (e . n) n), e = y (returned positive) unless the
+// normal is within 60 degrees of y, then z (returned negative).  The norm is >= 0.5 either way.  con_frame rebuilds the tangent from it.
+template <typename T> DEV T make_frame(T* f) {
   normalize3(f);
-  f[3] = f[4] = f[5] = 0;
-  if (f[1] < (T)0.5 && f[1] > (T)-0.5) f[4] = 1; else f[5] = 1;
-  const T t = dot3(f, f + 3);
-  f[3] -= t * f[0]; f[4] -= t * f[1]; f[5] -= t * f[2];
-  normalize3(f + 3);
+  const bool z = !(f[1] < (T)0.5 && f[1] > (T)-0.5);
+  const T t = z ? f[2] : f[1];
+  const T u[3] = {(T)0 - t * f[0], (z ? (T)0 : (T)1) - t * f[1], (z ? (T)1 : (T)0) - t * f[2]};
+  const T i = 1 / norm3(u);
+  return z ? -i : i;
 }
 // second tangent of a contact frame (what make_frame's caller used to store behind the first): normal x tangent 1
 template <typename T> DEV void con_t2(const T* f, T* t2) { cross3(t2, f, f + 3); }
@@ -1468,11 +1541,11 @@ DEV int pair_poses(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>&
   HP B1[9], B2[9], l1[3], l2[3];
   geom_lpos_hp(M, K, s, g1, l1);
   geom_lpos_hp(M, K, s, g2, l2);
-  quat2mat(B1, s.xquat + 4 * b1);
-  quat2mat(B2, s.xquat + 4 * b2);
+  quat2mat(B1, S_XQUAT(s) + 4 * b1);
+  quat2mat(B2, S_XQUAT(s) + 4 * b2);
   mulmatvec3(p1, B1, l1);
   mulmatvec3(p2, B2, l2);
-  for (int k = 0; k < 3; ++k) { p1[k] += s.xpos[3 * b1 + k]; p2[k] += s.xpos[3 * b2 + k]; }
+  for (int k = 0; k < 3; ++k) { p1[k] += S_XPOS(s)[3 * b1 + k]; p2[k] += S_XPOS(s)[3 * b2 + k]; }
   mulmat3(R1, B1, M.h_geom_mat + 9 * g1);
   mulmat3(R2, B2, M.h_geom_mat + 9 * g2);
   s1[0] = geom_size0_hp(M, K, s, g1); s1[1] = geom_size1_hp(M, K, s, g1); s1[2] = geom_size2_hp(M, K, s, g1);
@@ -1907,7 +1980,7 @@ DEVFN void friction_rows(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int tend
       else sol_param(M, M.dof_solref + 2 * i, M.dof_solimp + 5 * i, (T)0, &Kc, &Bc, &Ic);
       const T R = tmax(MYO_MINVAL, (1 - Ic) * (tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]) / Ic);
       s.lim_id[r] = i | MYO_LIM_FRIC;
-      s.efc_D[r] = 1 / R; S_LIM_B(s)[r] = Bc; S_LIM_KIP(s)[r] = 0;
+      s.efc_D[r] = 1 / R; S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = 0;
     }
     if (lane == 0) {
       const int n = base + total < MYO_NLIM_MAX ? base + total : MYO_NLIM_MAX;
@@ -1954,7 +2027,7 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
           sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dm, &Kc, &Bc, &Ic);
           const T R = tmax(MYO_MINVAL, (1 - Ic) * M.dof_invweight0[M.jnt_dofadr[j]] / Ic);
           s.lim_id[r] = M.jnt_dofadr[j] | (side ? MYO_LIM_UPPER : 0);   // joint rows keep the DOF index
-          s.efc_D[r] = 1 / R; S_LIM_B(s)[r] = Bc; S_LIM_KIP(s)[r] = Kc * Ic * dm;
+          s.efc_D[r] = 1 / R; S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -1989,7 +2062,7 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
           sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dm, &Kc, &Bc, &Ic);
           const T R = tmax(MYO_MINVAL, (1 - Ic) * M.tendon_invweight0[t] / Ic);
           s.lim_id[r] = t | (side ? MYO_LIM_UPPER : 0);
-          s.efc_D[r] = 1 / R; S_LIM_B(s)[r] = Bc; S_LIM_KIP(s)[r] = Kc * Ic * dm;
+          s.efc_D[r] = 1 / R; S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -2042,6 +2115,9 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
   WAVE_FN
   int total = 0;
   const int base = pbase;
+  // contact slots this substep can hold: the record slots, and what the limit rows leave of the constraint-row arrays (four rows a slot)
+  const int nlim = s.nl + s.ntl;
+  const int cap = tmin((int)Scratch<T, NC>::NREC, (MYO_NLIM_MAX + 4 * NC - nlim) >> 2);
   {
     WAVE_EXSCAN(LV(ct).n, S_NPRE(s), total);
     PHASE {
@@ -2049,12 +2125,12 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int ci = ncon + S_NPRE(s)[lane] + k;
-        if (k >= LV(ct).n || ci >= NC) break;
+        if (k >= LV(ct).n || ci >= cap) break;
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
         ContactRec<T>& c = s.con[ci];
         T cpos[3];                         // contact point relative to O: only r1 / r2 below are made of it
-        for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); c.frame[e] = (T)LV(ct).nrm[3 * k + e]; }
-        make_frame(c.frame);
+        for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - S_ORIGIN(s)[e]); c.nrm[e] = (T)LV(ct).nrm[3 * k + e]; }
+        c.tinv = make_frame(c.nrm);
         // everything that depends on the two geoms only comes from the host-resolved pair record (pc_*):
         // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
         // friction, margin and gap, inverse-weight sum; the balls' per-env friction is patched in here
@@ -2080,10 +2156,10 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr0 * fr0 * tran) / Ic);
         const T mu = fr0 / sqrt(M.impratio);
         const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
-        c.D = 1 / Rpy; c.B = Bc; c.kip = Kc * Ic * dmi;
-        c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
+        c.D = 1 / Rpy;
+        { const int r0 = nlim + 4 * ci; const T kip = Kc * Ic * dmi; for (int e = 0; e < 4; ++e) { S_ROW_B(s)[r0 + e] = Bc; S_ROW_KIP(s)[r0 + e] = kip; } }
         {
-          const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
+          const T* c1 = S_COM(s) + 3 * root1; const T* c2 = S_COM(s) + 3 * root2;
           for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
         }
         {
@@ -2095,11 +2171,11 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
     }
     SYNC();
     ncon += total;
-    if (ncon > NC) {
+    if (ncon > cap) {
       // more contacts than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
       // with a warning — counted, so that the host can see it happened (myo_batch_health)
       PHASE { if (lane == 0 && K.health) myo_count(K.health + 1); }
-      ncon = NC;
+      ncon = cap;
     }
   }
 }
@@ -2111,6 +2187,9 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
   WAVE_FN
   int total = 0;
   const int base = pbase;
+  // contact slots this substep can hold: the record slots, and what the limit rows leave of the constraint-row arrays (four rows a slot)
+  const int nlim = s.nl + s.ntl;
+  const int cap = tmin((int)Scratch<T, NC>::NREC, (MYO_NLIM_MAX + 4 * NC - nlim) >> 2);
   {
     // slots per lane: a contact of condim 1 / 3 takes one, condim 4 two, condim 6 three (ContactRec kinds)
     LANE_VAR(int, nslot);
@@ -2144,9 +2223,9 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           if (k >= LV(ct).n) break;
-          T cpos[3], frame[6];                 // contact point relative to O: only r1 / r2 below are made of it
-          for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - s.origin[e]); frame[e] = (T)LV(ct).nrm[3 * k + e]; }
-          make_frame(frame);
+          T cpos[3], frame[3];                 // contact point relative to O: only r1 / r2 below are made of it
+          for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - S_ORIGIN(s)[e]); frame[e] = (T)LV(ct).nrm[3 * k + e]; }
+          const T tinv = make_frame(frame);
           const T dmi = (T)(LV(ct).dist[k] - M.h_pair_mg[2 * p + 1]);   // dist - (margin - gap), HP difference
           T Kc, Bc, Ic;
           sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
@@ -2163,16 +2242,17 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int ci = ncon + S_NPRE(s)[lane] + k * per + j;
-            if (j >= per || ci >= NC) break;
+            if (j >= per || ci >= cap) break;
             ContactRec<T>& c = s.con[ci];
             const int kind = dim == 1 ? 3 : (j == 0 ? 0 : (dim == 4 ? 4 : j));
-            for (int e = 0; e < 6; ++e) c.frame[e] = frame[e];
+            for (int e = 0; e < 3; ++e) c.nrm[e] = frame[e];
+            c.tinv = tinv;
             c.muA = kind == 0 ? fr0 : (kind == 1 || kind == 4 ? fr[1] : (kind == 2 ? fr[2] : (T)0));
             c.muB = kind == 0 ? fr0 : (kind == 1 ? fr[2] : (T)0);
-            c.D = D; c.B = Bc; c.kip = Kc * Ic * dmi;
-            c.m1 = M.pc_mask[2 * p]; c.m2 = M.pc_mask[2 * p + 1];
+            c.D = D;
+            { const int r0 = nlim + 4 * ci; const T kip = Kc * Ic * dmi; for (int e = 0; e < 4; ++e) { S_ROW_B(s)[r0 + e] = Bc; S_ROW_KIP(s)[r0 + e] = kip; } }
             {
-              const T* c1 = s.com + 3 * root1; const T* c2 = s.com + 3 * root2;
+              const T* c1 = S_COM(s) + 3 * root1; const T* c2 = S_COM(s) + 3 * root2;
               for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
             }
             {
@@ -2186,11 +2266,11 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
     }
     SYNC();
     ncon += total;
-    if (ncon > NC) {
+    if (ncon > cap) {
       // more contact slots than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
       // with a warning — counted, so that the host can see it happened (myo_batch_health)
       PHASE { if (lane == 0 && K.health) myo_count(K.health + 1); }
-      ncon = NC;
+      ncon = cap;
     }
   }
 }
@@ -2360,9 +2440,10 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
         point_vel(bv, con_b2(c), c.r2, v2);
         const T rel[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
                                           // condim-3 models: translation along tangent 1 | 2
-        T t2[3];
-        con_t2(c.frame, t2);
-        const T vn = dot3(c.frame, rel), vt = (e >> 1) ? dot3(t2, rel) : dot3(c.frame + 3, rel);
+        T t2[3], fr[6];
+        con_frame(c, fr);
+        con_t2(fr, t2);
+        const T vn = dot3(fr, rel), vt = (e >> 1) ? dot3(t2, rel) : dot3(fr + 3, rel);
         val = vn + ((e & 1) ? -c.muA : c.muA) * vt;
       }
       out[r] = val;
@@ -2429,10 +2510,11 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
         point_vel(bvb, con_b2(c), c.r2, v2);
         const T relb[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
         if constexpr (!GEN) {
-          T t2[3];
-          con_t2(c.frame, t2);
-          const T* fn = c.frame;
-          const T ft[3] = {(e >> 1) ? t2[0] : c.frame[3], (e >> 1) ? t2[1] : c.frame[4], (e >> 1) ? t2[2] : c.frame[5]};
+          T t2[3], fr[6];
+          con_frame(c, fr);
+          con_t2(fr, t2);
+          const T* fn = fr;
+          const T ft[3] = {(e >> 1) ? t2[0] : fr[3], (e >> 1) ? t2[1] : fr[4], (e >> 1) ? t2[2] : fr[5]};
           const T mu = (e & 1) ? -c.muA : c.muA;
           vala = dot3(fn, rela) + mu * dot3(ft, rela);
           valb = dot3(fn, relb) + mu * dot3(ft, relb);
@@ -2462,17 +2544,18 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
       const ContactRec<T>& c = s.con[ci];
       const T* fe = f + nlim + 4 * ci;
       const T fn = fe[0] + fe[1] + fe[2] + fe[3], fa = c.muA * (fe[0] - fe[1]), fb = c.muB * (fe[2] - fe[3]);      // (padding rows carry no force)
-      T t2[3];
-      con_t2(c.frame, t2);
+      T t2[3], fr[6];
+      con_frame(c, fr);
+      con_t2(fr, t2);
       // world force at the contact point; slots whose pairs are rotations (kinds 1, 2, 4) add a world TORQUE instead of the tangential force
       if (!M.any_gen) {
-        for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + c.frame[3 + k] * fa + t2[k] * fb;
+        for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = fr[k] * fn + fr[3 + k] * fa + t2[k] * fb;
       } else {
         const int kind = con_kind(c);
-        for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = c.frame[k] * fn + (kind == 0 ? c.frame[3 + k] * fa + t2[k] * fb : (T)0);
+        for (int k = 0; k < 3; ++k) S_CONF(s)[3 * ci + k] = fr[k] * fn + (kind == 0 ? fr[3 + k] * fa + t2[k] * fb : (T)0);
         if (nrot > 0)
           for (int k = 0; k < 3; ++k)
-            S_CONTQ(s)[3 * ci + k] = kind == 1 ? c.frame[k] * fa + c.frame[3 + k] * fb : (kind == 2 ? t2[k] * fa : (kind == 4 ? c.frame[k] * fa : (T)0));
+            S_CONTQ(s)[3 * ci + k] = kind == 1 ? fr[k] * fa + fr[3 + k] * fb : (kind == 2 ? t2[k] * fa : (kind == 4 ? fr[k] * fa : (T)0));
       }
     }
   }
@@ -2499,7 +2582,8 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
 #pragma unroll 2
       for (int ci = 0; ci < ncon; ++ci) {
         const ContactRec<T>& c = s.con[ci];
-        const int on1 = (int)((c.m1 >> d) & 1ull), on2 = (int)((c.m2 >> d) & 1ull);
+        const int pk = UNI(c.pk);                  // (ci is wave-uniform: the two ancestor-dof masks come through the scalar cache)
+        const int on1 = (int)((M.body_dofmask[pk & 255] >> d) & 1ull), on2 = (int)((M.body_dofmask[(pk >> 8) & 255] >> d) & 1ull);
         const T off[3] = {on2 ? c.r2[0] : c.r1[0], on2 ? c.r2[1] : c.r1[1], on2 ? c.r2[2] : c.r1[2]};
         T t[3];
         cross3(t, cd, off);
@@ -2510,7 +2594,8 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
       if (nrot > 0) {                                          // (scalar branch, outside the hot loop) torques of the rotational slots
         for (int ci = 0; ci < ncon; ++ci) {
           const ContactRec<T>& c = s.con[ci];
-          const int on1 = (int)((c.m1 >> d) & 1ull), on2 = (int)((c.m2 >> d) & 1ull);
+          const int pk = UNI(c.pk);
+          const int on1 = (int)((M.body_dofmask[pk & 255] >> d) & 1ull), on2 = (int)((M.body_dofmask[(pk >> 8) & 255] >> d) & 1ull);
           const T v = dot3(cd, S_CONTQ(s) + 3 * ci);
           acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
         }
@@ -2635,8 +2720,7 @@ DEV void efc_reference(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     PHASE {
       const int nlim_ = s.nl + s.ntl;
       for (int r = lane; r < s.nefc; r += 64) {
-        const T Bc = r < nlim_ ? S_LIM_B(s)[r] : s.con[(r - nlim_) >> 2].B;
-        const T kp = r < nlim_ ? S_LIM_KIP(s)[r] : s.con[(r - nlim_) >> 2].kip;
+        const T Bc = S_ROW_B(s)[r], kp = S_ROW_KIP(s)[r];      // (left in the row's own entries by the lane that built the row)
         const bool pad = gen && r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3);
         S_AREF(s)[r] = pad ? (T)-1 : -Bc * s.efc_jv[r] - kp;       // a padding row: J = 0, so J a - aref = 1 > 0, never active
       }
@@ -2662,10 +2746,12 @@ template <typename T, int NC>
 DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
+  LANE_VAR(T, adot);               // act_dot shares its LDS slot with ten_length: kept per lane until every length has been read
   PHASE {
     const int i = lane;
+    LV(adot) = 0;
     if (i < M.nu) {
-      T ctrl = s.ctrl[i];
+      T ctrl = ctrl_get(s, i);
       if (M.actuator_ctrllimited[i]) ctrl = tclamp(ctrl, M.actuator_ctrlrange[2 * i], M.actuator_ctrlrange[2 * i + 1]);
       T input = ctrl;
       if (M.actuator_dyntype[i] == 3) {
@@ -2674,7 +2760,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         const T* prm = M.actuator_dynprm + 10 * i;
         const T cc = tclamp(ctrl, (T)0, (T)1), ac = tclamp(act, (T)0, (T)1);
         const T tau = cc > act ? prm[0] * ((T)0.5 + (T)1.5 * ac) : prm[1] / ((T)0.5 + (T)1.5 * ac);
-        s.act_dot[ia] = (cc - act) / tmax(MYO_MINVAL, tau);
+        LV(adot) = (cc - act) / tmax(MYO_MINVAL, tau);
         input = act;
       }
       const int tid = M.actuator_tendon[i];
@@ -2727,6 +2813,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   // qfrc_actuator = moment' * force.  lane = dof; its (ten_J offset, actuator) pairs arrive in one
   // wide load (host-built dof-major table, actuator order), then two LDS reads per entry
   PHASE {
+    if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) s.act_dot[lane - (M.nu - M.na)] = LV(adot);
     const int d = lane;
     if (d < M.nv) {
       unsigned w[MYO_AQ_ROW / 2];
@@ -2908,18 +2995,19 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       const int cn = ci + 1;
       if (cn < ncon && lane < con_nsup(s.con[cn])) {
         const ContactRec<T>& c = s.con[cn];
-        const int d = c.sup[lane];
-        const int on2 = (int)((c.m2 >> d) & 1ull), on1 = (int)((c.m1 >> d) & 1ull);
+        const int sd = c.sup[lane];
+        const int d = con_sup_dof(sd), on2 = con_sup_on2(sd), on1 = con_sup_on1(sd);
         T col[3];
         con_col(s, d, on2 ? c.r2 : c.r1, col);
-        T t2[3];
-        con_t2(c.frame, t2);
-        T j[3] = {dot3(c.frame, col), dot3(c.frame + 3, col), dot3(t2, col)};
+        T t2[3], fr[6];
+        con_frame(c, fr);
+        con_t2(fr, t2);
+        T j[3] = {dot3(fr, col), dot3(fr + 3, col), dot3(t2, col)};
         if (gen) {                                             // (scalar branch) rotational / frictionless slots
           const int kind = con_kind(c);
           const T* ang = s.cdof + 6 * d;                       // angular part of the dof's motion axis
-          j[1] = kind == 0 ? j[1] : ((kind == 1 || kind == 4) ? dot3(c.frame, ang) : (kind == 2 ? dot3(t2, ang) : (T)0));
-          j[2] = kind == 0 ? j[2] : (kind == 1 ? dot3(c.frame + 3, ang) : (T)0);
+          j[1] = kind == 0 ? j[1] : ((kind == 1 || kind == 4) ? dot3(fr, ang) : (kind == 2 ? dot3(t2, ang) : (T)0));
+          j[2] = kind == 0 ? j[2] : (kind == 1 ? dot3(fr + 3, ang) : (T)0);
         }
         if (!on2) { j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2]; }
         if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion
@@ -2938,7 +3026,6 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         if (nn != 0) {
           const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
           const int ns = con_nsup(c);
-          const unsigned long long m1 = c.m1, m2 = c.m2;
           const T* jc = stage + (ci & 1) * (MYO_CS_MAX * 3);
           // lower-triangular pairs (a >= b) of the support set, enumerated linearly: q = a(a+1)/2 + b
           const int npair = ns * (ns + 1) / 2;
@@ -2947,10 +3034,9 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
             if ((a + 1) * (a + 2) / 2 <= q) a++;           // float sqrt rounding guard
             if (a * (a + 1) / 2 > q) a--;
             const int b = q - a * (a + 1) / 2;
-            const int da = c.sup[a], db = c.sup[b];
-            const int a1 = (int)((m1 >> da) & 1ull), a2 = (int)((m2 >> da) & 1ull);
-            const int b1 = (int)((m1 >> db) & 1ull), b2 = (int)((m2 >> db) & 1ull);
-            if (a1 == a2 || b1 == b2) continue;
+            const int sa = c.sup[a], sb = c.sup[b];
+            const int da = con_sup_dof(sa), db = con_sup_dof(sb);
+            if (con_sup_on1(sa) == con_sup_on2(sa) || con_sup_on1(sb) == con_sup_on2(sb)) continue;
             const T ja[3] = {jc[3 * a], jc[3 * a + 1], jc[3 * a + 2]};
             const T jb[3] = {jc[3 * b], jc[3 * b + 1], jc[3 * b + 2]};
             const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
@@ -2971,25 +3057,27 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN
   const int nv = M.nv, nefc = s.nefc;
-  // ---- warm start: cheaper of qacc_warmstart and qacc_smooth
+  // ---- warm start: cheaper of qacc_warmstart and qacc_smooth.  The warm start is fetched into qacc, where the chosen vector ends up anyway
+  PHASE { const int c = lane; if (c < nv) s.qacc[c] = warm_get(s, c); }
+  SYNC();
   // (the second set of body vectors borrows Ma..Mv, which the solver has not started to use)
-  body_vectors2(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.qacc_smooth), LOFF(s, s.bvec), LOFF(s, S_CVEL(s)));
+  body_vectors2(M, s, LOFF(s, s.qacc), LOFF(s, s.qacc_smooth), LOFF(s, s.bvec), LOFF(s, S_CVEL(s)));
   // (J qacc_warm lands in efc_force, which the solver writes only after the choice: efc_jar still holds aref)
-  if (M.any_gen) J_times2<true>(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
-  else J_times2<false>(M, s, LOFF(s, s.qacc_warm), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
-  mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc_warm));
+  if (M.any_gen) J_times2<true>(M, s, LOFF(s, s.qacc), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
+  else J_times2<false>(M, s, LOFF(s, s.qacc), LOFF(s, s.bvec), LOFF(s, s.efc_force), LOFF(s, s.qacc_smooth), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
+  mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc));
   const int nlim = s.nl + s.ntl;
   // cost of the violated rows, branch-free: 0.5 D min(x, 0)^2  (no conditional around the D load)
   WAVE_SUM_N(HP, costw_c, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_force[r] - S_AREF(s)[r], (T)0) * (HP)tmin(s.efc_force[r] - S_AREF(s)[r], (T)0)));
   WAVE_SUM_N(HP, costs, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jv[r] - S_AREF(s)[r], (T)0) * (HP)tmin(s.efc_jv[r] - S_AREF(s)[r], (T)0)));
-  WAVE_SUM_N(HP, gw, nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc_warm[c] - (HP)s.qacc_smooth[c])));
+  WAVE_SUM_N(HP, gw, nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc[c] - (HP)s.qacc_smooth[c])));
   HP fw = 0, fs = 0;
   if (M.any_floss) { fw = fric_excess_sum(M, s, LOFF(s, s.efc_force)); fs = fric_excess_sum(M, s, LOFF(s, s.efc_jv)); }
   const int use_warm = (costw_c + fw + (HP)0.5 * gw) < costs + fs;
   PHASE {
     const int c = lane;
     if (c < nv) {
-      s.qacc[c] = use_warm ? s.qacc_warm[c] : s.qacc_smooth[c];
+      if (!use_warm) s.qacc[c] = s.qacc_smooth[c];
       if (!use_warm) s.Ma[c] = s.qfrc_smooth[c];  // M qacc_smooth = qfrc_smooth
     }
     for (int r = lane; r < nefc; r += 64) s.efc_jar[r] = (use_warm ? s.efc_force[r] : s.efc_jv[r]) - S_AREF(s)[r];
@@ -3202,7 +3290,7 @@ DEV void advance(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) act_dot
       if (M.actuator_dyntype[i + (M.nu - M.na)] == 3) a = tclamp(a, (HP)0, (HP)1);
       s.act[i] = a;
     }
-    if (i < M.nv) { s.qvel[i] += h * (HP)qacc[i]; s.qacc_warm[i] = s.qacc[i]; }
+    if (i < M.nv) { s.qvel[i] += h * (HP)qacc[i]; warm_set(s, i, s.qacc[i]); }
     if (lane == 0) s.time += h;
   }
   SYNC();

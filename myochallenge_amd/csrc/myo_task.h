@@ -172,7 +172,7 @@ DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scr
         t[2] = 2 * (x * z - w * y) * l[0] + 2 * (y * z + w * x) * l[1] + (1 - 2 * (x * x + y * y)) * l[2];
         for (int k = 0; k < 3; ++k) gp[k] = s.goal_pos[k] + t[k];
       }
-      ro_quat2euler(s.xquat + 4 * K.ro_obj_bid, oe);
+      ro_quat2euler(S_XQUAT(s) + 4 * K.ro_obj_bid, oe);
       ro_quat2euler(s.goal_quat, ge);
       HP pd = 0, rd = 0;
       for (int k = 0; k < 3; ++k) {
@@ -236,7 +236,7 @@ DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
       // (a device expf is 1 ulp off glibc's / numpy's on some arguments: a 6e-8 difference in ctrl, 1e-8 in the
       // trajectory after 20 env steps)
       const float c = 1.0f / (1.0f + (float)exp((double)(-5.0f * (a - 0.5f))));
-      s.ctrl[i] = (T)c;
+      ctrl_set(s, i, (T)c);
     }
   }
   SYNC();
@@ -255,10 +255,10 @@ DEVFN void set_init_state(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
   WAVE_FN
   PHASE {
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (i < K.n_hand) ? (i == 0 ? (HP)K.init_qpos0 : (HP)0) : (HP)M.h_qpos0[i];
-    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = 0; if (!keep_dynamics) s.qacc_warm[i] = 0; }
+    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = 0; if (!keep_dynamics) warm_set(s, i, (T)0); }
     if (!keep_dynamics) {
       for (int i = lane; i < M.na; i += 64) s.act[i] = 0;
-      for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = 0;
+      for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, (T)0);
       if (lane == 0) { s.time = 0; s.bad = 0; }
     }
   }
@@ -461,18 +461,22 @@ DEV void task_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T, NC>& s, i
 
 // ---- HBM record <-> scratch
 template <typename T, int NC>
-DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, const double* rec, Scratch<T, NC>& s_in) {
+DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, Scratch<T, NC>& s_in, int env) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
+  if constexpr (sizeof(T) == sizeof(HP)) {      // fp64 stepper: warm start and controls stay in global memory (ScratchPoses<double>)
+    PHASE { if (lane == 0) { s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + (size_t)env * MYO_NU_MAX; } }
+    SYNC();
+  }
   PHASE {
     if (K.objg_gidn > 0) {
       constexpr int NF = Scratch<T, NC>::OBJG_NF;
       for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) s.objg_fric[i] = (T)rec[L.off_objfric + 3 * (i / NF) + i % NF];
     }
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
-    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; s.qacc_warm[i] = (T)rec[L.off_warm + i]; }
+    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; if constexpr (sizeof(T) != sizeof(HP)) s.qacc_warm_[i] = (T)rec[L.off_warm + i]; }
     for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i];
-    for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = 0;
+    for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, (T)0);
     if (lane < MYO_NV_MAX) s.hperm[lane] = (unsigned char)M.hperm[lane];
     if (lane == 0) {
       s.time = rec[L.off_time];
@@ -503,7 +507,7 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
       for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + 3 * (i / NF) + i % NF] = (double)s.objg_fric[i];
     }
     for (int i = lane; i < M.nq; i += 64) rec[L.off_qpos + i] = (double)s.qpos[i];
-    for (int i = lane; i < M.nv; i += 64) { rec[L.off_qvel + i] = (double)s.qvel[i]; rec[L.off_warm + i] = (double)s.qacc_warm[i]; }
+    for (int i = lane; i < M.nv; i += 64) { rec[L.off_qvel + i] = (double)s.qvel[i]; if constexpr (sizeof(T) != sizeof(HP)) rec[L.off_warm + i] = (double)s.qacc_warm_[i]; }
     for (int i = lane; i < M.na; i += 64) rec[L.off_act + i] = (double)s.act[i];
     if (lane == 0) {
       rec[L.off_time] = (double)s.time;
@@ -530,7 +534,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
                   float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int k_lo = 0, int k_hi = -1) {
   WAVE_FN
   const int nobs = task_nobs(K, M.na);
-  load_env(M, K, L, rec, s);
+  load_env(M, K, L, rec, s, env);
   task_step_core(M, K, s, act + (size_t)env * M.nu, k_lo, k_hi);
   if (k_hi >= 0 && k_hi < K.frame_skip) { store_env(M, K, L, rec, s, 1); return; }
   // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
@@ -583,7 +587,7 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
   if (mask && !mask[env]) return;
   const int nobs = task_nobs(K, M.na);
   const int io = row < 0 ? env : row;
-  load_env(M, K, L, rec, s);
+  load_env(M, K, L, rec, s, env);
   task_step_core(M, K, s, act + (size_t)io * M.nu);
   const int bad = s.bad, fall = s.rwd[6] != 0 || bad;
   if (bad) {                        // blown-up env: back to a finite reset state (see env_step)
@@ -605,7 +609,7 @@ DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout
   WAVE_FN
   if (mask && !mask[env]) return;
   const int nobs = task_nobs(K, M.na);
-  load_env(M, K, L, rec, s);
+  load_env(M, K, L, rec, s, env);
   PHASE { if (lane == 0) s.episode++; }
   SYNC();
   task_reset(M, K, s, env);
@@ -617,8 +621,8 @@ template <typename T, int NC>
 DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                      int env, const double* ctrl, int nsub) {
   WAVE_FN
-  load_env(M, K, L, rec, s);
-  PHASE { for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0; }
+  load_env(M, K, L, rec, s, env);
+  PHASE { for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0); }
   SYNC();
   for (int k = 0; k < nsub; ++k) mj_step(M, K, s);
   store_env(M, K, L, rec, s);
@@ -634,8 +638,8 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
                           int env, const double* ctrl, const DumpLayout& D, double* out_all) {
   WAVE_FN
   double* out = out_all + (size_t)env * D.total;
-  load_env(M, K, L, rec, s);
-  PHASE { for (int i = lane; i < M.nu; i += 64) s.ctrl[i] = ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0; }
+  load_env(M, K, L, rec, s, env);
+  PHASE { for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0); }
   SYNC();
   const int nv = M.nv;
   PHASE {
@@ -661,6 +665,21 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
     for (int base = 0; base < M.npair_std; base += 64) collision_pass<false>(M, K, s, base);
     for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<false>(M, K, s, base - M.npair_std);
   }
+  // position-stage results first: the body poses (fp64 stepper) and the tendon lengths share LDS with vectors the later stages write
+  PHASE {
+    for (int t = lane; t < M.ntendon; t += 64) out[D.ten_length + t] = (double)s.ten_length[t];
+    for (int sid = lane; sid < M.nsite; sid += 64) {
+      HP p[3];
+      body_point_hp(s, M.site_bodyid[sid], M.h_site_pos + 3 * sid, p);
+      for (int k = 0; k < 3; ++k) out[D.site_xpos + 3 * sid + k] = p[k];
+    }
+    for (int b = lane; b < M.nbody; b += 64)
+      for (int k = 0; k < 3; ++k) {
+        out[D.subtree_com + 3 * b + k] = (double)S_COM(s)[3 * M.body_rootid[b] + k] + S_ORIGIN(s)[k];
+        out[D.xpos + 3 * b + k] = (double)S_XPOS(s)[3 * b + k];
+      }
+  }
+  SYNC();
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   fwd_velocity(M, K, s);
   efc_reference(M, s);
@@ -684,7 +703,6 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   fwd_acceleration(M, s);
   PHASE {
     for (int t = lane; t < M.ntendon; t += 64) {
-      out[D.ten_length + t] = (double)s.ten_length[t];
       unsigned long long m = M.tendon_dofmask[t];
       int slot = 0;
       while (m) { const int d = myo_ffsll(m); m &= m - 1; out[D.ten_J + t * nv + d] = (double)s.ten_J[t * MYO_TJ_MAX + slot]; slot++; }
@@ -709,16 +727,6 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       }
       out[D.counts] = nc; out[D.counts + 1] = k; out[D.counts + 2] = s.solver_iter; out[D.counts + 3] = s.nl;
     }
-    for (int sid = lane; sid < M.nsite; sid += 64) {
-      HP p[3];
-      body_point_hp(s, M.site_bodyid[sid], M.h_site_pos + 3 * sid, p);
-      for (int k = 0; k < 3; ++k) out[D.site_xpos + 3 * sid + k] = p[k];
-    }
-    for (int b = lane; b < M.nbody; b += 64)
-      for (int k = 0; k < 3; ++k) {
-        out[D.subtree_com + 3 * b + k] = (double)s.com[3 * M.body_rootid[b] + k] + s.origin[k];
-        out[D.xpos + 3 * b + k] = (double)s.xpos[3 * b + k];
-      }
   }
   SYNC();
 }

@@ -538,11 +538,11 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   // element lengths are staged (HP) in the part of H that is free during the tendon stage (behind cinert)
   LIM((size_t)m->nte * sizeof(double) > (size_t)(MYO_H_SIZE - MYO_NB_MAX * 10) * sizeof(float), "tendon path elements (length staging)")
   if (m->te_div.empty()) { m->te_i.assign(4, 0); m->te_div.push_back(1.0); }
-  // staging area of the tendon stage: T path points in con[], then (8-byte aligned) 7 HP wrap results per geom wrap,
-  // running on through the limit-row, efc_* and solver vectors up to rk
+  // staging area of the tendon stage.  Mixed stepper: T path points in con[], then (8-byte aligned) 7 HP wrap results per geom wrap,
+  // running on through the limit-row, efc_* and solver vectors up to rk.  fp64 stepper: the wrap results only, up to the solver
+  // vectors (where its body poses live during the position stage)
   typedef Scratch<double, MYO_NCON_F64> ScratchD;
-  LIM(((3 * (size_t)m->nwrap * sizeof(double) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
-          offsetof(ScratchD, rk) - offsetof(ScratchD, con) ||
+  LIM(7 * (size_t)m->ngw * sizeof(double) > offsetof(ScratchD, qfrc_smooth) - offsetof(ScratchD, con) ||
       ((3 * (size_t)m->nwrap * sizeof(float) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
           offsetof(Scratch<float>, rk) - offsetof(Scratch<float>, con), "tendon path elements / wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
@@ -607,7 +607,8 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     int* I = &m->pc_i[8 * (size_t)p];
     I[0] = b1; I[1] = b2; I[2] = m->body_rootid[b1]; I[3] = m->body_rootid[b2]; I[4] = cnt; I[5] = pair_sub[p];
     unsigned char* sup = reinterpret_cast<unsigned char*>(&m->pc_sup[4 * (size_t)p]);
-    { int ns = 0; for (int d = 0; d < 64 && ns < MYO_CS_MAX; ++d) if ((mk >> d) & 1ull) sup[ns++] = (unsigned char)d; }
+    // (bit 6 / bit 7 of an entry: ancestor dof of body 1 / body 2 — ContactRec::sup)
+    { int ns = 0; for (int d = 0; d < 64 && ns < MYO_CS_MAX; ++d) if ((mk >> d) & 1ull) sup[ns++] = (unsigned char)(d | (int)((m1 >> d) & 1ull) << 6 | (int)((m2 >> d) & 1ull) << 7); }
     m->pc_mask[2 * (size_t)p] = m1; m->pc_mask[2 * (size_t)p + 1] = m2;
     const int pr1 = m->geom_priority[g1], pr2 = m->geom_priority[g2];
     double mix;
@@ -996,6 +997,13 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
     if (!rc) rc |= be_h2d(hc, zero4, sizeof zero4);
     b->K.health = (int*)hc;
     if (hc) b->allocs.push_back(hc);
+  }
+  if (dtype == MYO_F64) {          // the fp64 stepper keeps the envs' controls in global memory (ScratchPoses<double>::ctrl_g)
+    void* w = nullptr;
+    rc |= be_malloc(&w, sizeof(double) * (size_t)n_envs * MYO_NU_MAX);
+    if (!rc) { std::vector<double> z((size_t)n_envs * MYO_NU_MAX, 0.0); rc |= be_h2d(w, z.data(), z.size() * sizeof(double)); }
+    b->K.ctrl_ws = (double*)w;
+    if (w) b->allocs.push_back(w);
   }
   if (m->integrator == 1) {        // RK4 stage storage, one RkScratch per env (global memory)
     void* w = nullptr;

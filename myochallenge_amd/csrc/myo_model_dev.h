@@ -44,7 +44,7 @@
   X(geom_bodyid) X(geom_priority) X(site_bodyid) X(tendon_adr) X(tendon_num) X(tendon_limited)   \
   X(wrap_type) X(wrap_objid) X(wrap_side) X(actuator_dyntype) X(actuator_gaintype)               \
   X(actuator_biastype) X(actuator_tendon) X(actuator_ctrllimited) X(actuator_forcelimited)       \
-  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk) X(te_i) X(tendon_eadr) X(tendon_enum) X(ld_fac) X(ld_sol) X(hperm) X(M_pkh)
+  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(act_sd) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk) X(te_i) X(tendon_eadr) X(tendon_enum) X(ld_fac) X(ld_sol) X(hperm) X(M_pkh)
 #define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask) X(act_dofmask) X(wr_mask) X(pc_mask)
 #define MYO_MODEL_REAL_ARRAYS(X)                                                                 \
   X(qpos0) X(qpos_spring) X(body_pos) X(body_quat) X(body_ipos) X(body_imat) X(body_mass)        \

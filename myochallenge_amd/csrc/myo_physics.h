@@ -59,6 +59,7 @@ __device__ __forceinline__ constexpr int myo_hrow(int i) { const int q = i >> 2;
 #endif
 #define MYO_HIDX(i, j) (myo_hrow(i) + (j)) /* i >= j */
 
+#define MYO_ENVWS_N (((MYO_NU_MAX + MYO_NT_MAX * MYO_TJ_MAX) + 15) / 16 * 16)   /* doubles per env of TaskDev::ctrl_ws: whole 128-byte lines */
 #define MYO_TASK_REORIENT_K 3   // == MYO_TASK_REORIENT of include/myobatch.h (checked in myobatch.hip)
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
@@ -76,7 +77,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   double ro_obj_size_change, ro_pos_th, ro_rot_th, ro_goal_init_pos[3], ro_goal_obj_offset[3];
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
-  double* ctrl_ws;            // double[n_envs][MYO_NU_MAX] in global memory: the controls of the fp64 stepper's envs (ScratchPoses<double>::ctrl_g)
+  double* ctrl_ws;            // double[n_envs][MYO_ENVWS_N] in global memory, fp64 stepper: each env's controls, then its tendon moment arms (ScratchPoses<double>)
   int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity
   unsigned long long seed;
 };
@@ -156,10 +157,14 @@ template <typename T> struct ScratchPoses {
   T xposT_[MYO_NB_MAX * 3];                            // xpos - O as the fp32 stages read it (S_XPOST)
   T xmat_[MYO_NB_MAX * 9];                             // rotation matrices as the fp32 stages read them; the fp64 stepper derives them from xquat (body_rot)
   T ctrl_[MYO_NU_MAX], qacc_warm_[MYO_NV_MAX];         // controls, warm start (ctrl_get / warm_get below)
+  T ten_J[MYO_NT_MAX * MYO_TJ_MAX];                    // tendon moment arms, [tendon][slot] (tenj_get below)
 };
 // fp64 stepper: the controls (read once per substep) and the solver's warm start (read once, written once) stay in global memory —
 // the warm start in the env's record, where the next part of the step / the next step finds it anyway, the controls in the batch's ctrl_ws
-template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; };
+// ... and so do the tendon moment arms (2.5 KB: the difference between seven and eight workgroups per CU): accumulated in LDS during the
+// tendon stage (S_TENJ_STAGE, storage the constraint rows take over later), written out once, [slot][tendon] so that tendon-per-lane
+// reads coalesce; read back by the tendon-velocity / actuator-moment phases and, for tendon-limit rows only, by the solver
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; };
 
 template <typename T, int NC = MYO_NCON_MAX>
 struct Scratch : ScratchPoses<T> {
@@ -190,7 +195,7 @@ struct Scratch : ScratchPoses<T> {
     HP ten_length[MYO_NT_MAX];    // fwd_actuation reads every length before it stores the first rate.  HP: what muscle forces and
     T act_dot[MYO_NU_MAX];        // tendon limits are made of
   };
-  T ten_J[MYO_NT_MAX * MYO_TJ_MAX];                   // (ten_vel, act_force: S_TEN_VEL / S_ACT_FORCE below)
+                                  // (ten_vel, act_force: S_TEN_VEL / S_ACT_FORCE below; the moment arms: ScratchPoses)
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
   // ---- constraints
   int ncon, nefc, nl, ntl, bad, solver_iter;   // ncon: contact SLOTS (four rows each, ContactRec)
@@ -297,6 +302,18 @@ static_assert(MYO_NJ_MAX * 3 <= MYO_NEFC_MAX && MYO_NB_MAX * 3 <= MYO_NEFC_MAX &
 static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRec<float>) && 2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_F64 * sizeof(ContactRec<double>), "kinematics temporaries fit in con[]");
 // controls and warm start of the env: LDS members (mixed stepper) / global memory (fp64 stepper, ScratchPoses<double>).  A lane only ever
 // reads entries it wrote itself (lane i <-> entry i, i + 64, ...), so the global copies need no fence inside a workgroup.
+// moment arm of tendon t with respect to the slot-th dof it moves
+template <typename T, int NC> DEV T tenj_get(const Scratch<T, NC>& s, int t, int slot) {
+  if constexpr (sizeof(T) == sizeof(HP)) return (T)s.tenj_g[slot * MYO_NT_MAX + t]; else return s.ten_J[t * MYO_TJ_MAX + slot];
+}
+// all MYO_TJ_MAX of them (requested together: the fp64 stepper's come from global memory)
+template <typename T, int NC> DEV void tenj_row(const Scratch<T, NC>& s, int t, T* j) {
+#pragma unroll
+  for (int k = 0; k < MYO_TJ_MAX; ++k) j[k] = tenj_get(s, t, k);
+}
+// where the tendon stage accumulates them: the member itself (mixed) / the constraint-row arrays, free until constraint_limits (fp64)
+template <typename T, int NC> DEV T* S_TENJ_STAGE(Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return s.efc_jv; else return s.ten_J; }
+static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 3 * (MYO_NLIM_MAX + 4 * MYO_NCON_F64), "fp64 stepper: the moment-arm stage fits in efc_jv, efc_force, efc_jar");
 template <typename T, int NC> DEV T ctrl_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.ctrl_g[i]; else return s.ctrl_[i]; }
 template <typename T, int NC> DEV void ctrl_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) s.ctrl_g[i] = (double)v; else s.ctrl_[i] = v; }
 template <typename T, int NC> DEV T warm_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.warm_g[i]; else return s.qacc_warm_[i]; }
@@ -894,7 +911,7 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& 
   HP* wres = S_TWRES(s, M.nwrap);
   (void)wres;
   PHASE {
-    for (int i = lane; i < M.ntendon * MYO_TJ_MAX; i += 64) s.ten_J[i] = 0;     // phase C accumulates into it
+    for (int i = lane; i < M.ntendon * MYO_TJ_MAX; i += 64) S_TENJ_STAGE(s)[i] = 0;     // phase C accumulates into it
     if constexpr (sizeof(T) != sizeof(HP)) {
       for (int w = lane; w < M.nwrap; w += 64) {
         const int body = M.wr_i[8 * w + 1];
@@ -959,7 +976,7 @@ DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scr
     if (e < M.nte) {
       const int i0 = M.te_i[4 * e], iend = M.te_i[4 * e + 1], ig = M.te_i[4 * e + 2], t = M.te_i[4 * e + 3];
       const unsigned long long tmask = M.tendon_dofmask[t];
-      T* J = s.ten_J + t * MYO_TJ_MAX;
+      T* J = S_TENJ_STAGE(s) + t * MYO_TJ_MAX;
       const T inv_div = 1 / M.te_div[e];
       const int is_geom = ig >= 0;
       WrapRec<T> w0, w1, we;
@@ -1021,6 +1038,12 @@ DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       HP len = 0;
       for (int k = 0; k < n; ++k) len += S_TELEN(s)[e0 + k];
       s.ten_length[t] = len;
+    }
+    if constexpr (sizeof(T) == sizeof(HP)) {      // the finished moment arms leave LDS: [slot][tendon]
+      for (int o = lane; o < MYO_TJ_MAX * MYO_NT_MAX; o += 64) {
+        const int slot = o / MYO_NT_MAX, tt = o - slot * MYO_NT_MAX;
+        if (tt < M.ntendon) s.tenj_g[o] = (double)S_TENJ_STAGE(s)[tt * MYO_TJ_MAX + slot];
+      }
     }
   }
   SYNC();
@@ -2392,9 +2415,10 @@ DEVFN void J_times_gen(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCRE
       else if (r < nlim) {
         const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
-        T acc = 0;
-        int slot = 0;
-        while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * v[d]; slot++; }
+        T acc = 0, tj[MYO_TJ_MAX];
+        tenj_row(s, t, tj);
+#pragma unroll
+        for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * v[d]; }
         val = lim_sign<T>(s.lim_id[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
@@ -2428,9 +2452,10 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
       else if (r < nlim) {
         const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
-        T acc = 0;
-        int slot = 0;
-        while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * v[d]; slot++; }
+        T acc = 0, tj[MYO_TJ_MAX];
+        tenj_row(s, t, tj);
+#pragma unroll
+        for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * v[d]; }
         val = lim_sign<T>(s.lim_id[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
@@ -2491,13 +2516,10 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
       else if (r < nlim) {
         const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
-        T acca = 0, accb = 0;
-        int slot = 0;
-        while (m) {
-          const int d = myo_ffsll(m); m &= m - 1;
-          const T j = s.ten_J[t * MYO_TJ_MAX + slot];
-          acca += j * va[d]; accb += j * vb[d]; slot++;
-        }
+        T acca = 0, accb = 0, tj[MYO_TJ_MAX];
+        tenj_row(s, t, tj);
+#pragma unroll
+        for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acca += tj[k] * va[d]; accb += tj[k] * vb[d]; }
         vala = lim_sign<T>(s.lim_id[r]) * acca; valb = lim_sign<T>(s.lim_id[r]) * accb;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
@@ -2568,13 +2590,23 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
         const T v = lim_sign<T>(s.lim_id[r]) * f[r];
         acc += (lim_index(s.lim_id[r]) == d) ? v : (T)0;
       }
-      for (int r = nl; r < nlim; ++r) {
-        const int t = lim_index(s.lim_id[r]);
-        const unsigned long long m = M.tendon_dofmask[t];
-        const int on = (int)((m >> d) & 1ull);
-        const int slot = on ? myo_popcll(m & ((1ull << d) - 1ull)) : 0;      // slot 0 is always a valid read
-        const T v = lim_sign<T>(s.lim_id[r]) * s.ten_J[t * MYO_TJ_MAX + slot] * f[r];
-        acc += on ? v : (T)0;
+      // (four rows at a time: the fp64 stepper's moment arms come from global memory, so the reads of a group are requested together;
+      //  the sum keeps its row order)
+      for (int r0 = nl; r0 < nlim; r0 += 4) {
+        T jv[4], fv[4];
+        int on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int r = r0 + k < nlim ? r0 + k : r0;                          // (rows beyond the last: a valid read, dropped below)
+          const int t = lim_index(s.lim_id[r]);
+          const unsigned long long m = M.tendon_dofmask[t];
+          on[k] = (r0 + k < nlim) && ((m >> d) & 1ull);
+          const int slot = on[k] ? myo_popcll(m & ((1ull << d) - 1ull)) : 0;  // slot 0 is always a valid read
+          jv[k] = tenj_get(s, t, slot);
+          fv[k] = lim_sign<T>(s.lim_id[r]) * f[r];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const T v = fv[k] * jv[k]; acc += on[k] ? v : (T)0; }
       }
       // own motion axis once; per contact only wave-uniform (broadcast) reads, issued unconditionally with a
       // select at the end: no exec-mask branch around the loads, so consecutive contacts overlap
@@ -2618,9 +2650,10 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
     const int t = lane;
     if (t < M.ntendon) {
       unsigned long long m = M.tendon_dofmask[t];
-      T acc = 0;
-      int slot = 0;
-      while (m) { const int d = myo_ffsll(m); m &= m - 1; acc += s.ten_J[t * MYO_TJ_MAX + slot] * qv[d]; slot++; }
+      T acc = 0, tj[MYO_TJ_MAX];
+      tenj_row(s, t, tj);
+#pragma unroll
+      for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * qv[d]; }
       S_TEN_VEL(s)[t] = acc;
     }
     const int d = lane;
@@ -2659,7 +2692,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
           const unsigned long long m = M.tendon_dofmask[t];
           if ((k != 0 || b != 0) && ((m >> d) & 1ull)) {
             const T f = -k * ((T)s.ten_length[t] - M.tendon_lengthspring[t]) - b * S_TEN_VEL(s)[t];
-            acc += s.ten_J[t * MYO_TJ_MAX + myo_popcll(m & ((1ull << d) - 1ull))] * f;
+            acc += tenj_get(s, t, myo_popcll(m & ((1ull << d) - 1ull))) * f;
           }
         }
         S_QFRC_PASSIVE(s)[d] += acc;
@@ -2812,6 +2845,29 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   SYNC();
   // qfrc_actuator = moment' * force.  lane = dof; its (ten_J offset, actuator) pairs arrive in one
   // wide load (host-built dof-major table, actuator order), then two LDS reads per entry
+  if constexpr (sizeof(T) == sizeof(HP)) {
+    // fp64 stepper (moment arms in global memory): one lane per (actuator, slot) — the reads coalesce — adding into the dof's entry
+    PHASE {
+      if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) s.act_dot[lane - (M.nu - M.na)] = LV(adot);
+      if (lane < M.nv) S_QFRC_ACTUATOR(s)[lane] = 0;
+    }
+    SYNC();
+    PHASE {
+      for (int o = lane; o < MYO_TJ_MAX * MYO_NU_MAX; o += 64) {
+        const int slot = o / MYO_NU_MAX, i = o - slot * MYO_NU_MAX;
+        const int d = M.act_sd[i * MYO_TJ_MAX + slot];            // dof of the actuator's tendon's slot, -1: none
+        const T j = tenj_get(s, M.act_tj[i] / MYO_TJ_MAX, slot);
+        if (d >= 0) lds_add(S_QFRC_ACTUATOR(s) + d, j * S_ACT_GF(s)[i]);
+      }
+    }
+    SYNC();
+    PHASE {
+      const int d = lane;
+      if (d < M.nv) s.qfrc_smooth[d] = S_QFRC_PASSIVE(s)[d] - S_QFRC_BIAS(s)[d] + S_QFRC_ACTUATOR(s)[d];
+    }
+    SYNC();
+    return;
+  }
   PHASE {
     if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) s.act_dot[lane - (M.nu - M.na)] = LV(adot);
     const int d = lane;
@@ -2824,7 +2880,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
 #pragma unroll
       for (int k = 0; k < MYO_AQ_ROW; ++k) {
         const unsigned ent = (k & 1) ? (w[k / 2] >> 16) : (w[k / 2] & 0xffffu);     // padding entries are 0: valid reads
-        const T j = s.ten_J[ent >> 6], f = S_ACT_GF(s)[ent & 63u];
+        const T j = tenj_get(s, (int)(ent >> 6) / MYO_TJ_MAX, (int)(ent >> 6) % MYO_TJ_MAX), f = S_ACT_GF(s)[ent & 63u];
         acc += (k < len) ? j * f : (T)0;
       }
       S_QFRC_ACTUATOR(s)[d] = acc;
@@ -2976,7 +3032,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         for (int k = 0; k < b; ++k) mb &= mb - 1;
         const int da = myo_ffsll(ma), db = myo_ffsll(mb);
         const int pa = s.hperm[da], pb = s.hperm[db];
-        s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += s.efc_D[r] * s.ten_J[t * MYO_TJ_MAX + a] * s.ten_J[t * MYO_TJ_MAX + b];
+        s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += s.efc_D[r] * tenj_get(s, t, a) * tenj_get(s, t, b);
       }
     }
     SYNC();

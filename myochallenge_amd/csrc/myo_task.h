@@ -465,7 +465,7 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   if constexpr (sizeof(T) == sizeof(HP)) {      // fp64 stepper: warm start and controls stay in global memory (ScratchPoses<double>)
-    PHASE { if (lane == 0) { s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + (size_t)env * MYO_NU_MAX; } }
+    PHASE { if (lane == 0) { s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + (size_t)env * MYO_ENVWS_N; s.tenj_g = s.ctrl_g + MYO_NU_MAX; } }
     SYNC();
   }
   PHASE {
@@ -705,7 +705,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
     for (int t = lane; t < M.ntendon; t += 64) {
       unsigned long long m = M.tendon_dofmask[t];
       int slot = 0;
-      while (m) { const int d = myo_ffsll(m); m &= m - 1; out[D.ten_J + t * nv + d] = (double)s.ten_J[t * MYO_TJ_MAX + slot]; slot++; }
+      while (m) { const int d = myo_ffsll(m); m &= m - 1; out[D.ten_J + t * nv + d] = (double)tenj_get(s, t, slot); slot++; }
     }
     for (int e = lane; e < M.nM; e += 64) {
       out[D.M + M.M_i[e] * nv + M.M_j[e]] = (double)s.qM[e];

@@ -542,7 +542,10 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   // running on through the limit-row, efc_* and solver vectors up to rk.  fp64 stepper: the wrap results only, up to the solver
   // vectors (where its body poses live during the position stage)
   typedef Scratch<double, MYO_NCON_F64> ScratchD;
-  LIM(7 * (size_t)m->ngw * sizeof(double) > offsetof(ScratchD, qfrc_smooth) - offsetof(ScratchD, con) ||
+  typedef Scratch<double, MYO_NCON_BIG> ScratchDB;
+  // (... and not beyond efc_jv, where that stepper accumulates the tendon moment arms meanwhile)
+  LIM(7 * (size_t)m->ngw * sizeof(double) > offsetof(ScratchD, efc_jv) - offsetof(ScratchD, con) ||
+      7 * (size_t)m->ngw * sizeof(double) > offsetof(ScratchDB, efc_jv) - offsetof(ScratchDB, con) ||
       ((3 * (size_t)m->nwrap * sizeof(float) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
           offsetof(Scratch<float>, rk) - offsetof(Scratch<float>, con), "tendon path elements / wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
@@ -572,10 +575,12 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   m->act_dofmask.assign(MYO_NU_MAX, 0ull);
   m->act_tj.assign(MYO_NU_MAX, 0);
   m->act_gear0.assign(MYO_NU_MAX, 0.0);
+  m->act_sd.assign((size_t)MYO_NU_MAX * MYO_TJ_MAX, -1);      // dof of slot k of actuator i's tendon (-1: the tendon moves fewer dofs)
   for (int i = 0; i < m->nu; ++i) {
     m->act_dofmask[i] = m->tendon_dofmask[m->actuator_tendon[i]];
     m->act_tj[i] = m->actuator_tendon[i] * MYO_TJ_MAX;
     m->act_gear0[i] = m->actuator_gear[6 * i];
+    { int k = 0; for (int d = 0; d < nv && k < MYO_TJ_MAX; ++d) if ((m->act_dofmask[i] >> d) & 1ull) m->act_sd[(size_t)i * MYO_TJ_MAX + k++] = d; }
   }
   for (int b = 0; b < nb; ++b) {
     int cnt = 0;
@@ -1000,8 +1005,8 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   }
   if (dtype == MYO_F64) {          // the fp64 stepper keeps the envs' controls in global memory (ScratchPoses<double>::ctrl_g)
     void* w = nullptr;
-    rc |= be_malloc(&w, sizeof(double) * (size_t)n_envs * MYO_NU_MAX);
-    if (!rc) { std::vector<double> z((size_t)n_envs * MYO_NU_MAX, 0.0); rc |= be_h2d(w, z.data(), z.size() * sizeof(double)); }
+    rc |= be_malloc(&w, sizeof(double) * (size_t)n_envs * MYO_ENVWS_N);
+    if (!rc) { std::vector<double> z((size_t)n_envs * MYO_ENVWS_N, 0.0); rc |= be_h2d(w, z.data(), z.size() * sizeof(double)); }
     b->K.ctrl_ws = (double*)w;
     if (w) b->allocs.push_back(w);
   }

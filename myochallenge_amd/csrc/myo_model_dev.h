@@ -18,7 +18,7 @@
 #define MYO_NM_MAX 176    // tree-sparse inertia entries
 #define MYO_NCON_MAX 24   // contacts (base capacity of the scratch: Scratch<T, NC = MYO_NCON_MAX>)
 #define MYO_NCON_F64 16   // contacts, base capacity of the fp64 stepper's scratch (the bench workload peaks at 11 - 12 contacts; a substep with more than the capacity drops the surplus and is counted, myo_batch_health)
-#define MYO_NREC_F64 24   // contact record slots of the fp64 base scratch (its 56 + 4 * 16 constraint rows are shared between limit and contact rows)
+#define MYO_NREC_F64 22   // contact record slots of the fp64 base scratch (its 56 + 4 * 16 constraint rows are shared between limit and contact rows)
 #define MYO_NCON_BIG 34   // contact slots, scratch of models with extended collision pairs / a die / condim 4, 6 pairs (56 + 4 * 34 = 192 rows, three per lane)
 #define MYO_CS_MAX 16     // dofs one contact can move
 #define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows

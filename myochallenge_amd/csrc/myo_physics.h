@@ -96,7 +96,9 @@ template <typename T> DEV T fric_cost(T D, T f, T x, T* force, int* quad) {
 template <typename T> DEV T lim_sign(int id) { return id < 0 ? (T)-1 : (T)1; }
 
 template <typename T>
-struct alignas(16) ContactRec {    // 80 B (fp32) / 128 B (fp64): whole 16-byte units, so that the fields keep their wide LDS accesses
+struct alignas(8) ContactRec {     // 80 B (fp32) / 136 B (fp64).  The STRIDE is chosen for the LDS banks: lanes = constraint rows read one field of 8 (fp64) or
+  // 16 (fp32) consecutive records in one access, and a 128-byte stride (32 banks) would put every second record on the same banks — a 4-way
+  // conflict on each of those reads; 34 / 20 banks apart they are all distinct (the padding words below buy that)
   // nrm: the contact normal.  The frame's first tangent is not stored: it is (e - nrm[a] nrm) |tinv|, e = the y axis (tinv > 0, a = 1) or
   // the z axis (tinv < 0, a = 2) — make_frame's construction with its reciprocal norm kept (con_frame rebuilds all six numbers in 6 flops);
   // the second tangent is their cross product (con_t2).  muA / muB: friction of the slot's two row pairs.  The rows' reference-acceleration
@@ -109,7 +111,9 @@ struct alignas(16) ContactRec {    // 80 B (fp32) / 128 B (fp64): whole 16-byte 
   // (The bodies' 64-bit ancestor masks themselves are not kept here: J' f, whose lanes are dofs, takes them from the model's
   // body_dofmask through the scalar cache — the contact index is wave-uniform there.)
   alignas(4) unsigned char sup[MYO_CS_MAX];
+  int pad_[sizeof(T) == 8 ? 3 : 2];
 };
+static_assert(sizeof(ContactRec<double>) == 136 && sizeof(ContactRec<float>) == 80, "contact record strides (LDS banks)");
 static_assert(MYO_NV_MAX <= 64, "ContactRec::sup entries: dof index in bits 0-5");
 // the contact frame (normal, first tangent) of a record, as make_frame built it
 template <typename T> DEV void con_frame(const ContactRec<T>& c, T* f) {
@@ -202,7 +206,7 @@ struct Scratch : ScratchPoses<T> {
   unsigned char hperm[MYO_NV_MAX];   // dof -> row of the Newton system (DevModel::hperm; identity unless the block-arrow solver is on)
   // (from con[] on: one contiguous block, the staging area of the tendon stage — S_TWP / S_TWRES — which runs before any of it is live.
   //  Mixed stepper: up to rk.  fp64 stepper: up to qfrc_smooth, where its body poses live during the position stage.)
-  // NREC record slots over the 4 NC contact rows of the efc_* arrays: the fp64 base scratch has 24 slots for 64 contact rows, because the
+  // NREC record slots over the 4 NC contact rows of the efc_* arrays: the fp64 base scratch has 22 slots for 64 contact rows, because the
   // rows are SHARED with the limit rows (capacity MYO_NLIM_MAX, ~11 in use on the hand): a substep holds min(NREC, (rows - limit rows) / 4)
   // contacts (contacts_emit_*), at least NC.  Measured on the hand with P2's ball sizes: up to 19 contacts (oracle, 32 episodes).
   static constexpr int NREC = (sizeof(T) == sizeof(HP) && NC == MYO_NCON_F64) ? MYO_NREC_F64 : NC;

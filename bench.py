@@ -144,7 +144,7 @@ def _count_flops_here(env_steps):
 
 
 FLOPS_RECORD = os.path.join(ROOT, "profiles", "r02_flops.json")     # the same count, committed (used when the CPU leg is skipped)
-PMC_RECORD = os.path.join(ROOT, "profiles", "r04_pmc.json")         # rocprofv3 --pmc passes over the default command (tools/profile_round.sh)
+PMC_RECORD = os.path.join(ROOT, "profiles", "r05_pmc.json")         # rocprofv3 --pmc passes over the default command (tools/profile_round.sh)
 VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9                           # 78.6e12 lane-instructions/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md)
 
 
@@ -153,14 +153,14 @@ def trajectory_parity():
     read from the committed profiles/r04_drift_*.json (r03_* where round 4 took none), so the line quotes what was measured, not a
     hand-typed summary.  `local_error` = the same steppers re-synchronised to the oracle before every env step (what ONE step adds)."""
     import statistics
-    out = {"test": "tests/test_gpu_parity.py::test_episode_trajectory_*, tests/test_reorient.py::test_reorient_whole_episode_drift_on_gpu; "
+    out = {"source": "committed records (profiles/*_drift_*.json, *_local_error_*.json), written by the -m gpu parity tests of the round named "
+                     "in each record's path; NOT measured in this run",
+           "test": "tests/test_gpu_parity.py::test_episode_trajectory_*, tests/test_reorient.py::test_reorient_whole_episode_drift_on_gpu; "
                    "err = max|qpos - qpos_oracle| / max|qpos_oracle| per env step; tolerance 1e-4 (north_star)"}
     for key, name in (("f64_euler", "f64"), ("mixed_euler", "mixed"), ("f64_rk4", "rk4_f64"), ("mixed_rk4", "rk4_mixed"),
                       ("configC_f64", "configC_f64"), ("configC_mixed", "configC_mixed"), ("configE_f64", "configE_f64"),
                       ("configE_mixed", "configE_mixed")):
-        path = os.path.join(ROOT, "profiles", "r04_drift_%s.json" % name)
-        if not os.path.exists(path):
-            path = os.path.join(ROOT, "profiles", "r03_drift_%s.json" % name)
+        path = next((q for q in (os.path.join(ROOT, "profiles", "%s_drift_%s.json" % (rr, name)) for rr in ("r05", "r04", "r03")) if os.path.exists(q)), "")
         try:
             r = json.load(open(path))
             mq = r["max_err_qpos_rel"]
@@ -171,8 +171,9 @@ def trajectory_parity():
             out[key] = None
     for name in ("mixed", "f64"):
         try:
-            r = json.load(open(os.path.join(ROOT, "profiles", "r04_local_error_%s.json" % name)))
-            out["local_error_" + name] = {"record": "profiles/r04_local_error_%s.json" % name, "env_steps": r["env_steps"], "streams": len(r["max_err_qpos_rel"]),
+            lp = next(q for q in (os.path.join(ROOT, "profiles", "%s_local_error_%s.json" % (rr, name)) for rr in ("r05", "r04")) if os.path.exists(q))
+            r = json.load(open(lp))
+            out["local_error_" + name] = {"record": os.path.relpath(lp, ROOT), "env_steps": r["env_steps"], "streams": len(r["max_err_qpos_rel"]),
                                           "worst_step_err_qpos_rel": max(r["max_err_qpos_rel"]), "median_step_err_qpos_rel": r["median_err_qpos_rel"],
                                           "episode_end_disagreements": len(r["done_disagreements"])}
         except Exception:
@@ -217,6 +218,9 @@ def main():
                     "actor and critic; 128 with --net-arch '' is the architecture of trained_models/phase_1/phase1_final.zip")
     ap.add_argument("--net-arch", default="256,256", help="MLP widths after the (optional) LSTM")
     ap.add_argument("--no-ppo", action="store_true", help="rollout only (reported as invalid for the headline)")
+    ap.add_argument("--normalizer-sync", default="step", choices=["step", "rollout", "none"],
+                    help="N > 1 ranks: VecNormalize statistics exchanged at every env step (one small all-reduce between the two rollout "
+                         "graphs; the reference's single VecNormalize over all envs, exactly), once per rollout, or not at all")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -244,6 +248,14 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
+    # the library that runs must be the one the tree's sources produce: a stale .so would be benchmarked silently otherwise
+    from myochallenge_amd import native as _native
+    from myochallenge_amd.build import source_id as _source_id
+    lib_build, src_build = _native.load().build_id, _source_id()
+    if lib_build != src_build and not os.environ.get("MYO_ALLOW_STALE_LIB"):
+        raise SystemExit(f"bench.py: libmyobatch.so is build {lib_build} but the sources are {src_build}: run __graft_entry__.build() "
+                         "(MYO_ALLOW_STALE_LIB=1 overrides, for A/B runs of library variants)")
+
     def fence():
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -267,7 +279,7 @@ def main():
         env = EnvironmentFactory.create(args.env_name, num_envs=args.envs, device=local_rank, seed=1234 + rank,
                                         dtype=dtype, integrator=integ)
         integ_name = {0: "Euler", 1: "RK4"}[env._model.size("integrator")]
-        venv = VecNormalize(env, gamma=0.99)
+        venv = VecNormalize(env, gamma=0.99, sync_ranks=args.normalizer_sync)
         torch.manual_seed(0)   # identical initial weights on every rank
         arch = tuple(int(x) for x in args.net_arch.split(",") if x.strip())
         policy = ActorCriticPolicy(env.obs_dim, env.act_dim, arch, arch, lstm_hidden_size=args.lstm_hidden or None, log_std_init=-2.0)
@@ -297,29 +309,43 @@ def main():
         fence()
         env.batch.enable_timing(True)
         upd0 = algo.n_updates
-        blocks, total = [], 0.0
+        blocks, total, skew = [], 0.0, []
         while True:
             t0 = time.perf_counter()
             for _ in range(steps):
                 one_step()
+            own = time.perf_counter() - t0           # this rank's own time to the end of its work (before the closing barrier)
             fence()
             el = time.perf_counter() - t0
             if world > 1:
-                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                tt = torch.tensor([el, own, -own], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt[0])
+                skew.append((-float(tt[2]), float(tt[1])))       # (fastest, slowest) rank of the block
             blocks.append(el)
             total += el
             if total >= min_seconds or len(blocks) >= 10000:      # every rank sees the same (all-reduced) times
                 break
         kernel_ms = env.batch.kernel_ms()
         env.batch.enable_timing(False)
+        health = env.batch.health()                  # hand-off protocol errors, substeps that dropped contacts beyond the scratch's capacity
+        replicas_identical = None
+        if world > 1:      # data-parallel replicas must hold the same parameters after the timed updates (fp64 sum of |p|, min == max over ranks)
+            cs = torch.stack([p.detach().double().abs().sum() for p in policy.parameters()]).sum().reshape(1)
+            lo, hi = cs.clone(), cs.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            replicas_identical = bool(float(lo[0]) == float(hi[0]))
         blocks.sort()
         med = blocks[len(blocks) // 2] if len(blocks) % 2 else 0.5 * (blocks[len(blocks) // 2 - 1] + blocks[len(blocks) // 2])
         res = {"dtype": dtype, "integrator": integ_name, "value": args.envs * world * steps / med, "ms_per_step": 1e3 * med / steps,
                "ms_per_step_min": 1e3 * blocks[0] / steps, "ms_per_step_max": 1e3 * blocks[-1] / steps, "blocks": len(blocks),
                "timed_seconds": total, "env_kernel_ms": kernel_ms, "optimizer_steps_per_sec": (algo.n_updates - upd0) / total,
-               "n_steps": cfg.n_steps, "batch_size": cfg.batch_size, "n_epochs": cfg.n_epochs, "lds_bytes": env.batch.lds_bytes}
+               "n_steps": cfg.n_steps, "batch_size": cfg.batch_size, "n_epochs": cfg.n_epochs, "lds_bytes": env.batch.lds_bytes, "health": health,
+               "replicas_identical": replicas_identical, "normalizer_sync": args.normalizer_sync if world > 1 else None,
+               "graph_allreduce": bool(getattr(algo, "_allreduce_in_graph", False))}
+        if skew:      # per-rank spread of the block times (own work, before the barrier): min / max over ranks, median block
+            sk = sorted(skew, key=lambda x: x[1])[len(skew) // 2]
+            res["rank_block_seconds_min_max"] = [sk[0], sk[1]]
         env.close()
         del algo, venv, env, policy
         torch.cuda.empty_cache()
@@ -336,7 +362,7 @@ def main():
                 continue
             try:
                 r = measure(dt, integ, min(1.0, args.min_seconds), min(args.steps, 64), min(args.warmup, 16))
-                variants[name] = {k: r[k] for k in ("dtype", "integrator", "value", "ms_per_step", "env_kernel_ms", "blocks", "timed_seconds", "lds_bytes")}
+                variants[name] = {k: r[k] for k in ("dtype", "integrator", "value", "ms_per_step", "env_kernel_ms", "blocks", "timed_seconds", "lds_bytes", "health")}
             except Exception as exc:      # a variant must never take the headline line down
                 variants[name] = {"error": repr(exc)}
         if args.envs == 4096 and args.env_name == "CustomMyoBaodingBallsP1":
@@ -420,10 +446,16 @@ def main():
             # bound = VALU issue / latency: achieved = vector-ALU lane-instructions per second of the k_step
             # launches (PMC SQ_INSTS_VALU x 64 lanes / kernel time), peak = the chip's VALU issue peak; `hbm` and `flops`
             # are the two other ways of pricing the same launches.
+            # the kernel is bound by the vector ALU (a long dependent chain of small fp64 vector ops), priced as COUNTED
+            # algorithmic flops per launch / measured kernel time against the vector peak of the arithmetic type.  `valu_issue` is the other
+            # reading of the same pipe — issue slots taken (PMC), which counts masked lanes and prices fp64 like fp32 — `hbm` the bytes.
             "roofline": {"bound": "valu",
-                         "achieved": (valu["achieved_lane_ops_per_s"] / 1e12) if valu else None, "peak": VALU_PEAK_LANE_OPS / 1e12,
-                         "unit": "Tlane-op/s", "frac": (valu["achieved_lane_ops_per_s"] / VALU_PEAK_LANE_OPS) if valu else None,
-                         "traffic": traffic, "counters_source": counters_source, "valu": valu,
+                         "achieved": fl_roof["achieved"] if fl_roof else None, "peak": fl_roof["peak"] if fl_roof else None,
+                         "unit": "TFLOP/s", "frac": fl_roof["frac"] if fl_roof else None,
+                         "traffic": traffic, "counters_source": counters_source,
+                         "valu_issue": {"achieved": (valu["achieved_lane_ops_per_s"] / 1e12) if valu else None, "peak": VALU_PEAK_LANE_OPS / 1e12,
+                                        "unit": "Tlane-op/s", "frac": (valu["achieved_lane_ops_per_s"] / VALU_PEAK_LANE_OPS) if valu else None,
+                                        "counters": valu},
                          "hbm": {"achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": (achieved / 8000.0) if achieved else None,
                                  "algorithmic_bytes_per_launch": alg_bytes},
                          "flops": fl_roof, "kernel": kname, "kernel_ms": kernel_ms, "lds_bytes_per_env": main_res["lds_bytes"],
@@ -431,7 +463,17 @@ def main():
                                  "vector-ALU issue + LDS / instruction latency, not HBM (algorithmic bytes = 2508 B/env-step x envs "
                                  "per launch) and not MFMA; kernel_ms is measured live with HIP events on the launch stream"},
             "variants": variants,
+            "health": main_res["health"],
+            "library_build": lib_build,
         }
+        if world > 1:
+            out["replicas_identical"] = main_res["replicas_identical"]
+            out["config"]["normalizer_sync"] = main_res["normalizer_sync"]
+            out["config"]["graph_allreduce"] = main_res["graph_allreduce"]
+        if main_res.get("rank_block_seconds_min_max"):
+            out["rank_block_seconds_min_max"] = main_res["rank_block_seconds_min_max"]
+        if any(main_res["health"].values()):
+            print("bench.py: batch health counters are non-zero: %r" % (main_res["health"],), file=sys.stderr)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -36,7 +36,8 @@ static const char* const kSizeNames[57] = {
 struct File {
   std::map<std::string, long long> sizes;
   double timestep, impratio, tolerance, gravity[3], o_margin, meaninertia;
-  int integrator, collision, cone, iterations, disableflags, enableflags;
+  double wind[3], density, viscosity;
+  int integrator, collision, cone, iterations, disableflags, enableflags, solver, noslip_iterations;
   std::map<std::string, std::vector<double>> d;   // f64 arrays (row-major)
   std::map<std::string, std::vector<int>> i;      // i32 and u8 arrays
 };
@@ -82,9 +83,11 @@ static bool parse(const unsigned char* blob, size_t n, File& f, std::string& err
   memcpy(od, blob + off, sizeof od); off += sizeof od;
   f.timestep = od[0]; f.impratio = od[2]; f.tolerance = od[3];
   f.gravity[0] = od[6]; f.gravity[1] = od[7]; f.gravity[2] = od[8]; f.o_margin = od[17];
+  f.wind[0] = od[9]; f.wind[1] = od[10]; f.wind[2] = od[11]; f.density = od[15]; f.viscosity = od[16];
   int oi[10];
   memcpy(oi, blob + off, sizeof oi); off += sizeof oi;
   f.integrator = oi[0]; f.collision = oi[1]; f.cone = oi[2]; f.iterations = oi[5]; f.disableflags = oi[8]; f.enableflags = oi[9];
+  f.solver = oi[4]; f.noslip_iterations = oi[6];
   const long long nbuffer = f.sizes["nbuffer"];
   if (nbuffer < 0 || (size_t)nbuffer > n || n - (size_t)nbuffer < off) { err = "nbuffer larger than the file"; return false; }
   const size_t base = n - (size_t)nbuffer;
@@ -188,25 +191,54 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
       }
     }
   }
-  // what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored
+  // what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored — and ALL of it is
+  // reported at once (model.py:unsupported_features builds the same list; tests/test_mjb_and_model.py compares the two routes)
+  std::vector<std::string> uns;
+  auto U = [&](const char* fmt, long long a = 0, long long b = 0) { char m[256]; snprintf(m, sizeof m, fmt, a, b); uns.push_back(m); };
   const int npair_x = f.collision != 2 ? (int)f.sizes["npair"] : 0;      // explicit <contact><pair> entries in force (opt.collision: 0 all, 1 predefined, 2 dynamic)
-  for (int k = 0; k < npair_x; ++k) {
-    const double* fr = &D("pair_friction")[5 * (size_t)k];
-    const int dim = I("pair_dim")[k];
-    if (fr[0] != fr[1] || fr[3] != fr[4]) { err = "an explicit contact pair with anisotropic friction is not supported"; *unsupported = 1; return false; }
-    if (dim != 1 && dim != 3 && dim != 4 && dim != 6) { err = "an explicit contact pair with a condim other than 1, 3, 4, 6"; *unsupported = 1; return false; }
-    if (I("pair_geom1")[k] < 0 || I("pair_geom1")[k] >= ngeom || I("pair_geom2")[k] < 0 || I("pair_geom2")[k] >= ngeom) { err = "an explicit contact pair names a geom out of range"; return false; }
-  }
-  if (f.disableflags & ~((1 << 9) | (1 << 11))) { err = "opt.disableflags: only filterparent and refsafe can be disabled in this stepper"; *unsupported = 1; return false; }
-  if (f.enableflags & 1) { err = "opt.enableflags: contact override is not supported"; *unsupported = 1; return false; }
-  for (int j = 0; j < njnt; ++j) if (I("jnt_type")[j] == MYO_JNT_BALL) { err = "ball joints are not supported"; *unsupported = 1; return false; }
-  if (f.sizes["neq"] > 0) { err = "equality constraints are not supported"; *unsupported = 1; return false; }
-  if (f.cone != 0) { err = "only pyramidal friction cones are supported"; *unsupported = 1; return false; }
-  for (int g = 0; g < ngeom; ++g)
-    if ((I("geom_contype")[g] | I("geom_conaffinity")[g]) != 0) {
-      const int cd = I("geom_condim")[g];
-      if (cd != 1 && cd != 3 && cd != 4 && cd != 6) { err = "contact dimensions (condim) other than 1, 3, 4, 6 do not exist in MuJoCo"; *unsupported = 1; return false; }
+  {
+    int n_aniso = 0, n_dim = 0;
+    for (int k = 0; k < npair_x; ++k) {
+      const double* fr = &D("pair_friction")[5 * (size_t)k];
+      const int dim = I("pair_dim")[k];
+      if (fr[0] != fr[1] || fr[3] != fr[4]) n_aniso++;
+      if (dim != 1 && dim != 3 && dim != 4 && dim != 6) n_dim++;
+      if (I("pair_geom1")[k] < 0 || I("pair_geom1")[k] >= ngeom || I("pair_geom2")[k] < 0 || I("pair_geom2")[k] >= ngeom) { err = "an explicit contact pair names a geom out of range"; return false; }
     }
+    if (n_aniso) U("[pair_anisotropic x%lld] explicit contact pair(s) with anisotropic friction are not supported", n_aniso);
+    if (n_dim) U("[pair_condim x%lld] explicit contact pair(s) with a condim other than 1, 3, 4, 6", n_dim);
+  }
+  if (f.disableflags & ~((1 << 9) | (1 << 11))) U("[disableflags x1] opt.disableflags = %#llx: only filterparent and refsafe can be disabled in this stepper", f.disableflags);
+  if (f.enableflags & 1) U("[override x1] opt.enableflags: contact override is not supported");
+  { int n = 0; for (int j = 0; j < njnt; ++j) n += I("jnt_type")[j] == MYO_JNT_BALL; if (n) U("[ball_joints x%lld] ball joints are not supported", n); }
+  if (f.sizes["neq"] > 0) U("[equality x%lld] equality constraints are not supported", f.sizes["neq"]);
+  if (f.cone != 0) U("[cone x1] only pyramidal friction cones are supported (opt.cone = elliptic)");
+  if (f.solver != 2) U("[solver x1] opt.solver = %lld: this stepper restates mj_solNewton only (a model asking for PGS / CG would be stepped with another algorithm)", f.solver);
+  if (f.noslip_iterations > 0) U("[noslip x1] opt.noslip_iterations = %lld: the noslip post-solver is not implemented", f.noslip_iterations);
+  {
+    const int nf = (f.density != 0.0) + (f.viscosity != 0.0) + (f.wind[0] != 0.0 || f.wind[1] != 0.0 || f.wind[2] != 0.0);
+    if (nf) U("[fluid x%lld] opt.density / viscosity / wind non-zero: fluid forces in mj_passive are not implemented", nf);
+  }
+  if (f.integrator != 0 && f.integrator != 1) U("[integrator x1] opt.integrator = %lld: Euler (0) and RK4 (1) are implemented", f.integrator);
+  {
+    int n = 0;
+    for (int g = 0; g < ngeom; ++g)
+      if ((I("geom_contype")[g] | I("geom_conaffinity")[g]) != 0) { const int cd = I("geom_condim")[g]; n += (cd != 1 && cd != 3 && cd != 4 && cd != 6); }
+    if (n) U("[condim x%lld] contact dimensions (condim) other than 1, 3, 4, 6 do not exist in MuJoCo", n);
+  }
+  {
+    const int nu = (int)f.sizes["nu"];
+    int n_trn = 0, n_dyn = 0, n_gain = 0, n_bias = 0;
+    for (int i = 0; i < nu; ++i) {
+      n_trn += I("actuator_trntype")[i] != 3;
+      const int dy = I("actuator_dyntype")[i], ga = I("actuator_gaintype")[i], bi = I("actuator_biastype")[i];
+      n_dyn += !(dy == 0 || dy == 3); n_gain += !(ga == 0 || ga == 1); n_bias += !(bi >= 0 && bi <= 2);
+    }
+    if (n_trn) U("[transmission x%lld] only tendon transmissions are supported", n_trn);
+    if (n_dyn) U("[actuator_dyn x%lld] actuator dyntype integrator / filter / user is not implemented (none and muscle are)", n_dyn);
+    if (n_gain) U("[actuator_gain x%lld] actuator gaintype user is not implemented (fixed and muscle are)", n_gain);
+    if (n_bias) U("[actuator_bias x%lld] actuator biastype user is not implemented (none, affine and muscle are)", n_bias);
+  }
   // static collision filter (mj_collision body-pair pass): same weld group, <exclude> body pairs (exclude_signature =
   // ((body1 + 1) << 16) + body2 + 1 with body1 < body2, MuJoCo 2.1), parent-child unless mjDSBL_FILTERPARENT, contype / conaffinity
   const std::vector<int>& excl = I("exclude_signature");
@@ -262,13 +294,14 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   }
   if (dropped && !allow_drop) {
     char m2[400];
-    snprintf(m2, sizeof m2, "%d colliding geom pair(s) have no narrow phase in this stepper (first: %s); load with unsupported_contacts = 1 to compile without them", dropped, msg);
-    err = m2; *unsupported = 1; return false;
+    snprintf(m2, sizeof m2, "[contact_pairs x%d] %d colliding geom pair(s) have no narrow phase in this stepper (first: %s); load with unsupported_contacts = 1 to compile without them", dropped, dropped, msg);
+    uns.push_back(m2);
   }
+  int n_fixed = 0, n_inside = 0;
   for (int t = 0; t < ntendon; ++t)
     for (int w = I("tendon_adr")[t]; w < I("tendon_adr")[t] + I("tendon_num")[t]; ++w) {
       const int wt = I("wrap_type")[w];
-      if (wt == MYO_WRAP_JOINT) { err = "fixed (joint) tendons are not supported"; *unsupported = 1; return false; }
+      if (wt == MYO_WRAP_JOINT) { n_fixed++; continue; }
       if ((wt == MYO_WRAP_SPHERE || wt == MYO_WRAP_CYLINDER) && D("wrap_prm")[w] >= 0) {
         const int sid = (int)lround(D("wrap_prm")[w]), gid = I("wrap_objid")[w];
         if (I("site_bodyid")[sid] == gb[gid]) {      // a side site inside its wrap geom needs MuJoCo's inside-wrap iteration
@@ -282,10 +315,24 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
             const double along = d[0] * ax[0] + d[1] * ax[1] + d[2] * ax[2];
             for (int k = 0; k < 3; ++k) d[k] -= along * ax[k];
           }
-          if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < D("geom_size")[3 * gid]) { err = "a wrapping side site lies inside its wrap geom"; *unsupported = 1; return false; }
+          if (sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < D("geom_size")[3 * gid]) n_inside++;
         }
       }
     }
+  if (n_fixed) U("[fixed_tendons x%lld] fixed (joint) tendons are not supported", n_fixed);
+  if (n_inside) U("[side_site_inside x%lld] a wrapping side site lies inside its wrap geom (MuJoCo's inside-wrap iteration is not implemented)", n_inside);
+  {
+    int n = 0;
+    const std::vector<double>& fl = D("dof_frictionloss");
+    for (int d = 0; d < nv && (size_t)d < fl.size(); ++d) { const int j = I("dof_jntid")[d]; n += fl[d] > 0 && j >= 0 && j < njnt && I("jnt_type")[j] == MYO_JNT_FREE; }
+    if (n) U("[frictionloss_free x%lld] friction loss on the dofs of a free joint is not supported", n);
+  }
+  if (!uns.empty()) {
+    err.clear();
+    for (size_t k = 0; k < uns.size(); ++k) { if (k) err += "; "; err += uns[k]; }
+    *unsupported = 1;
+    return false;
+  }
   // fields
   std::vector<std::pair<std::string, std::vector<int>>> fi;
   std::vector<std::pair<std::string, std::vector<double>>> fd;

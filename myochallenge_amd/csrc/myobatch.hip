@@ -39,7 +39,7 @@ static int be_set_device(int dev) { return (int)hipSetDevice(dev); }
 static const char* be_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 #endif
 
-static thread_local char g_err[512] = "";
+static thread_local char g_err[4096] = "";      // (room for a loader report that lists every unsupported feature of a model)
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

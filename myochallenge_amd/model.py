@@ -186,6 +186,101 @@ def collision_pairs(m: MjbModel):
     return pairs, dropped
 
 
+SOLVER_PGS, SOLVER_CG, SOLVER_NEWTON = 0, 1, 2
+DYN_NONE, DYN_INTEGRATOR, DYN_FILTER, DYN_MUSCLE, DYN_USER = range(5)
+TRN_JOINT, TRN_JOINTINPARENT, TRN_SLIDERCRANK, TRN_TENDON, TRN_SITE = range(5)
+
+
+def unsupported_features(m: MjbModel) -> List[dict]:
+    """Everything in `m` that MuJoCo 2.1's mj_step honours and this stepper does not restate, each with a count — the whole list,
+    not the first hit (the environments are registered on .mjb files nobody here has seen,
+    /root/reference/src/envs/__init__.py:17,63; their user gets ONE report).  Entries: {"key", "count", "message"}.  compile_model
+    refuses a model with any entry (colliding pairs without a narrow phase: unless unsupported_contacts="drop");
+    csrc/myo_mjb.h:to_blob builds the same list for the C++ route (tests/test_mjb_and_model.py compares the two)."""
+    out: List[dict] = []
+
+    def add(key, count, message):
+        if count:
+            out.append({"key": key, "count": int(count), "message": message})
+    o = m.opt
+    a = m.arrays
+    add("ball_joints", int(np.sum(np.asarray(m.jnt_type) == JNT_BALL)), "ball joints are not supported")
+    add("equality", int(m.sizes.get("neq", 0)), "equality constraints are not supported")
+    add("cone", int(o.get("cone", 0) != 0), "only pyramidal friction cones are supported (opt.cone = elliptic)")
+    solver = int(o.get("solver", SOLVER_NEWTON))
+    add("solver", int(solver != SOLVER_NEWTON), f"opt.solver = {('PGS', 'CG', 'Newton')[solver] if 0 <= solver < 3 else solver}: this stepper restates "
+        "mj_solNewton only (a model asking for PGS / CG would be stepped with another algorithm)")
+    add("noslip", int(int(o.get("noslip_iterations", 0)) > 0), f"opt.noslip_iterations = {int(o.get('noslip_iterations', 0))}: the noslip post-solver is not implemented")
+    fluid = [k for k in ("density", "viscosity") if float(o.get(k, 0.0)) != 0.0]
+    if any(float(x) != 0.0 for x in np.atleast_1d(o.get("wind", [0.0, 0.0, 0.0]))):
+        fluid.append("wind")
+    add("fluid", len(fluid), f"opt.{' / '.join(fluid)} non-zero: fluid forces in mj_passive are not implemented")
+    add("integrator", int(int(o.get("integrator", 0)) not in (0, 1)), f"opt.integrator = {int(o.get('integrator', 0))}: Euler (0) and RK4 (1) are implemented")
+    cd = np.asarray(m.geom_condim)[(np.asarray(m.geom_contype) | np.asarray(m.geom_conaffinity)) != 0]
+    add("condim", int(np.sum(~np.isin(cd, (1, 3, 4, 6)))), "contact dimensions (condim) other than 1, 3, 4, 6 do not exist in MuJoCo")
+    dis, enb = int(o.get("disableflags", 0)), int(o.get("enableflags", 0))
+    add("disableflags", int(bool(dis & ~(DSBL_FILTERPARENT | DSBL_REFSAFE))), f"opt.disableflags = {dis:#x}: only filterparent and refsafe can be disabled in this stepper")
+    add("override", int(bool(enb & ENBL_OVERRIDE)), "opt.enableflags: contact override is not supported")
+    # explicit <contact><pair> entries
+    col = int(o.get("collision", 0))
+    npair_x = int(m.sizes.get("npair", 0)) if col != 2 else 0
+    short = [name for name, w in (("pair_geom1", 1), ("pair_geom2", 1), ("pair_dim", 1), ("pair_solref", 2), ("pair_solimp", 5), ("pair_margin", 1),
+                                  ("pair_gap", 1), ("pair_friction", 5)) if npair_x and np.asarray(a.get(name, [])).size < npair_x * w]
+    add("pair_arrays", len(short), f"npair = {npair_x} but {', '.join(short)} hold(s) fewer values")
+    if npair_x and not short:
+        g1, g2 = np.asarray(a["pair_geom1"][:npair_x]).astype(int), np.asarray(a["pair_geom2"][:npair_x]).astype(int)
+        add("pair_geom_range", int(np.sum((g1 < 0) | (g1 >= m.ngeom) | (g2 < 0) | (g2 >= m.ngeom))), "an explicit contact pair names a geom out of range")
+        fr = np.asarray(a["pair_friction"], np.float64).reshape(-1, 5)[:npair_x]
+        add("pair_anisotropic", int(np.sum((fr[:, 0] != fr[:, 1]) | (fr[:, 3] != fr[:, 4]))), "explicit contact pair(s) with anisotropic friction are not supported")
+        add("pair_condim", int(np.sum(~np.isin(np.asarray(a["pair_dim"][:npair_x]).astype(int), (1, 3, 4, 6)))), "explicit contact pair(s) with a condim other than 1, 3, 4, 6")
+    # actuators: tendon transmissions; no / muscle activation dynamics; fixed / muscle gain; none / affine / muscle bias
+    if int(m.sizes.get("nu", 0)):
+        add("transmission", int(np.sum(np.asarray(a["actuator_trntype"]).astype(int) != TRN_TENDON)), "only tendon transmissions are supported")
+        add("actuator_dyn", int(np.sum(~np.isin(np.asarray(a["actuator_dyntype"]).astype(int), (DYN_NONE, DYN_MUSCLE)))),
+            "actuator dyntype integrator / filter / user is not implemented (none and muscle are)")
+        add("actuator_gain", int(np.sum(~np.isin(np.asarray(a["actuator_gaintype"]).astype(int), (0, 1)))), "actuator gaintype user is not implemented (fixed and muscle are)")
+        add("actuator_bias", int(np.sum(~np.isin(np.asarray(a["actuator_biastype"]).astype(int), (0, 1, 2)))), "actuator biastype user is not implemented (none, affine and muscle are)")
+    # tendons: spatial only; a wrapping side site inside its wrap geom would need MuJoCo's inside-wrap Newton iteration
+    n_fixed, n_inside = 0, 0
+    for t in range(int(m.sizes.get("ntendon", 0))):
+        adr, num = int(m.tendon_adr[t]), int(m.tendon_num[t])
+        for w in range(adr, adr + num):
+            wt = int(m.wrap_type[w])
+            if wt == WRAP_JOINT:
+                n_fixed += 1
+            if wt in (WRAP_SPHERE, WRAP_CYLINDER) and m.wrap_prm[w] >= 0:
+                sid, gid = int(round(m.wrap_prm[w])), int(m.wrap_objid[w])
+                if 0 <= sid < m.nsite and 0 <= gid < m.ngeom and m.site_bodyid[sid] == m.geom_bodyid[gid]:
+                    d = np.asarray(m.site_pos[sid], float) - np.asarray(m.geom_pos[gid], float)
+                    if wt == WRAP_CYLINDER:
+                        from .mathutil import quat_to_mat
+                        R = quat_to_mat(m.geom_quat[gid])
+                        d = R.T @ d
+                        d[2] = 0.0
+                    if np.linalg.norm(d) < m.geom_size[gid, 0]:
+                        n_inside += 1
+    add("fixed_tendons", n_fixed, "fixed (joint) tendons are not supported")
+    add("side_site_inside", n_inside, "a wrapping side site lies inside its wrap geom (MuJoCo's inside-wrap iteration is not implemented)")
+    fl = a.get("dof_frictionloss")
+    if fl is not None and int(m.sizes.get("nv", 0)):
+        free = np.asarray(m.jnt_type)[np.asarray(m.dof_jntid).astype(int)] == JNT_FREE
+        add("frictionloss_free", int(np.sum((np.asarray(fl, float).reshape(-1) > 0) & free)), "friction loss on the dofs of a free joint is not supported")
+    if not any(x["key"] in ("pair_arrays", "pair_geom_range") for x in out):
+        try:
+            _, dropped = collision_pairs(m)
+        except Exception:      # noqa: BLE001 — a corrupt model: the loaders report that
+            dropped = []
+        if dropped:
+            kinds = {}
+            for ga, gb_ in dropped:
+                k = tuple(sorted((int(m.geom_type[ga]), int(m.geom_type[gb_]))))
+                kinds[k] = kinds.get(k, 0) + 1
+            tn = ("plane", "hfield", "sphere", "capsule", "ellipsoid", "cylinder", "box", "mesh")
+            add("contact_pairs", len(dropped), f"{len(dropped)} colliding geom pair(s) have no narrow phase in this stepper ("
+                + ", ".join(f"{n} x {tn[k[0]]}-{tn[k[1]]}" for k, n in sorted(kinds.items())) + ")")
+    return out
+
+
 class UnsupportedContactsError(ValueError):
     """The model has colliding geom pairs whose narrow phase the stepper does not implement."""
 
@@ -200,34 +295,13 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
         raise ValueError("unsupported_contacts must be 'error' or 'drop'")
     f: Dict[str, np.ndarray] = {}
     f["sizes"] = np.array([m.sizes[k] for k in _SIZES], np.int32)
-    if np.any(m.jnt_type == JNT_BALL):
-        raise ModelError("ball joints are not supported")
-    if m.sizes["neq"]:
-        raise ModelError("equality constraints are not supported")
-    if m.opt["cone"] != 0:
-        raise ModelError("only pyramidal friction cones are supported")
-    if not np.all(np.isin(m.geom_condim[(m.geom_contype | m.geom_conaffinity) != 0], (1, 3, 4, 6))):
-        raise ModelError("contact dimensions (condim) other than 1, 3, 4, 6 do not exist in MuJoCo")
-    # what mj_collision / mj_step would do differently and this stepper does not restate is refused, never ignored
+    # what mj_step would do differently and this stepper does not restate is refused, never ignored — ALL of it at once
+    # (unsupported_features: the same list `python -m myochallenge_amd.model --check file.mjb` prints)
+    feats = [x for x in unsupported_features(m) if x["key"] != "contact_pairs"]
+    if feats:
+        raise ModelError("; ".join(x["message"] for x in feats))
     col = int(m.opt.get("collision", 0))
     npair_x = int(m.sizes.get("npair", 0)) if col != 2 else 0
-    for name, w in (("pair_geom1", 1), ("pair_geom2", 1), ("pair_dim", 1), ("pair_solref", 2), ("pair_solimp", 5), ("pair_margin", 1), ("pair_gap", 1),
-                    ("pair_friction", 5)):
-        if npair_x and np.asarray(m.arrays.get(name, [])).size < npair_x * w:
-            raise ModelError(f"npair = {npair_x} but {name} holds {np.asarray(m.arrays.get(name, [])).size} values")
-    for k in range(npair_x):
-        if not (0 <= int(m.arrays["pair_geom1"][k]) < m.ngeom and 0 <= int(m.arrays["pair_geom2"][k]) < m.ngeom):
-            raise ModelError(f"explicit contact pair {k} names a geom out of range")
-        fr = np.asarray(m.arrays["pair_friction"]).reshape(-1, 5)[k]
-        if fr[0] != fr[1] or fr[3] != fr[4]:
-            raise ModelError(f"explicit contact pair {k}: anisotropic friction ({fr.tolist()}) is not supported")
-        if int(m.arrays["pair_dim"][k]) not in (1, 3, 4, 6):
-            raise ModelError(f"explicit contact pair {k}: condim {int(m.arrays['pair_dim'][k])}")
-    dis, enb = int(m.opt.get("disableflags", 0)), int(m.opt.get("enableflags", 0))
-    if dis & ~(DSBL_FILTERPARENT | DSBL_REFSAFE):
-        raise ModelError(f"opt.disableflags = {dis:#x}: only filterparent and refsafe can be disabled in this stepper")
-    if enb & ENBL_OVERRIDE:
-        raise ModelError("opt.enableflags: contact override is not supported")
     for name in _INT_FIELDS:
         f[name] = np.ascontiguousarray(m.arrays[name]).astype(np.int32).reshape(-1)
     for name in _F64_FIELDS:
@@ -274,28 +348,35 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
     f["x_xp_margin"], f["x_xp_gap"] = xf("pair_margin", 1), xf("pair_gap", 1)
     f["x_xp_solref"], f["x_xp_solimp"] = xf("pair_solref", 2), xf("pair_solimp", 5)
     f["x_xp_friction"] = (np.asarray(m.arrays["pair_friction"], np.float64).reshape(-1, 5)[:npair_x][:, [0, 2, 3]].reshape(-1) if npair_x else np.zeros(0))
-    # wrapping side sites that sit inside their wrap geom would need MuJoCo's inside-wrap
-    # Newton iteration; not implemented.
-    for t in range(m.ntendon):
-        adr, num = int(m.tendon_adr[t]), int(m.tendon_num[t])
-        for w in range(adr, adr + num):
-            wt = int(m.wrap_type[w])
-            if wt == WRAP_JOINT:
-                raise ModelError("fixed (joint) tendons are not supported")
-            if wt in (WRAP_SPHERE, WRAP_CYLINDER) and m.wrap_prm[w] >= 0:
-                sid, gid = int(round(m.wrap_prm[w])), int(m.wrap_objid[w])
-                if m.site_bodyid[sid] == m.geom_bodyid[gid]:
-                    d = m.site_pos[sid] - m.geom_pos[gid]
-                    if wt == WRAP_CYLINDER:
-                        from .mathutil import quat_to_mat
-                        R = quat_to_mat(m.geom_quat[gid])
-                        d = R.T @ d
-                        d[2] = 0.0
-                    if np.linalg.norm(d) < m.geom_size[gid, 0]:
-                        raise ModelError(f"side site {sid} lies inside wrap geom {gid}")
     o = m.opt
     f["opt_int"] = np.array([integrator if integrator is not None else o["integrator"],
                              o["cone"], o["iterations"], o["disableflags"]], np.int32)
     f["opt_f64"] = np.array([o["timestep"], o["tolerance"], o["impratio"], *o["gravity"],
                              o["o_margin"], m.stat["meaninertia"]], np.float64)
     return CompiledModel(fields=f, names=dict(m.names), dropped_pairs=dropped)
+
+
+def _main(argv=None) -> int:
+    """``python -m myochallenge_amd.model --check file.mjb``: every feature of the model this stepper refuses, with counts, at once."""
+    import argparse
+    import json
+    from .mjb import load_mjb
+    ap = argparse.ArgumentParser(prog="python -m myochallenge_amd.model")
+    ap.add_argument("--check", metavar="FILE.mjb", required=True, help="list every unsupported feature of the model (exit code 1 if there is one)")
+    ap.add_argument("--json", action="store_true")
+    args = ap.parse_args(argv)
+    m = load_mjb(args.check)
+    feats = unsupported_features(m)
+    if args.json:
+        print(json.dumps({"file": args.check, "sizes": {k: int(m.sizes[k]) for k in _SIZES}, "unsupported": feats}))
+    else:
+        print(f"{args.check}: " + ", ".join(f"{k} {int(m.sizes[k])}" for k in _SIZES))
+        if not feats:
+            print("  every feature of this model is implemented")
+        for x in feats:
+            print(f"  [{x['key']}] x{x['count']}: {x['message']}")
+    return 1 if feats else 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(_main())

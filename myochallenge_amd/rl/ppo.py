@@ -428,6 +428,8 @@ class PPO:
                 self._init_native_rollout()
             else:
                 self._init_rollout_graphs()
+        if hasattr(self.env, "begin_rollout"):
+            self.env.begin_rollout()         # (per-rollout normaliser synchronisation: snapshot at the first step; a no-op otherwise)
         if self.policy.recurrent:
             if self._t_host == 0:      # LSTM state at the start of the rollout: initial state of the update's sequences
                 self._rollout_state0 = self._native_state() if getattr(self, "_native", False) else tuple(s.clone() for s in self._state_s)
@@ -440,6 +442,8 @@ class PPO:
             self._gB2.replay()
 
     def finish_rollout(self) -> None:
+        if hasattr(self.env, "end_rollout"):
+            self.env.end_rollout()
         with torch.no_grad(), self._autocast():
             if getattr(self, "_native", False) and not self.policy.recurrent:
                 # timeout bootstrap for the whole rollout at once: r += gamma V(terminal_obs) where truncated
@@ -485,6 +489,8 @@ class PPO:
             self._last_obs = env.reset_tensor().clone()
         if pol.recurrent:
             self._rollout_state0 = tuple(s.clone() for s in self._state)
+        if hasattr(env, "begin_rollout"):
+            env.begin_rollout()
         for t in range(cfg.n_steps):
             obs, starts = self._last_obs, self._last_starts
             with self._autocast():
@@ -502,6 +508,8 @@ class PPO:
             self._last_obs = nobs.clone()
             self._last_starts = done.to(torch.float32)
         self.num_timesteps += cfg.n_steps * env.num_envs * self.world
+        if hasattr(env, "end_rollout"):
+            env.end_rollout()
         with self._autocast():
             self._last_values = pol.predict_values(self._last_obs, self._state, self._last_starts)
 

@@ -70,6 +70,35 @@ class RunningMeanStd:
     def state(self):
         return {"mean": self.mean.cpu().numpy().copy(), "var": self.var.cpu().numpy().copy(), "count": float(self.count)}
 
+    def snapshot(self) -> torch.Tensor:
+        return self.buf.clone()
+
+    def merge_ranks(self, snap: torch.Tensor) -> None:
+        """Per-rollout rank synchronisation (VecNormalize(sync_ranks="rollout")): every rank has updated its own copy from `snap`
+        (identical on all ranks) with its own envs' data; afterwards every rank holds merge(snap, data of ALL ranks).  The data a
+        rank added is recovered from (snap, state) by inverting Chan's merge — additive sums (n, sum x, sum x^2) — all-reduced once,
+        and merged into the snapshot.  One collective per rollout instead of one per env step; the result equals the per-step
+        synchronisation up to the order of the floating-point merges."""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1):
+            return
+        n = self.mean.numel()
+        m0, v0, c0 = snap[:n], snap[n:2 * n], snap[2 * n]
+        m1, v1, c1 = self.mean.reshape(-1), self.var.reshape(-1), self.count
+        nd = c1 - c0
+        s1 = m1 * c1 - m0 * c0                                              # sum of this rank's samples
+        safe = torch.clamp(nd, min=1e-300)
+        md = s1 / safe
+        m2d = v1 * c1 - v0 * c0 - (md - m0) ** 2 * c0 * nd / c1            # their sum of squared deviations about md
+        s = torch.cat([nd.reshape(1), s1, torch.clamp(m2d, min=0.0) + nd * md * md])
+        torch.distributed.all_reduce(s)
+        tot = s[0]
+        self.buf.copy_(snap)
+        if float(tot) <= 0.0:
+            return
+        mean = s[1:1 + n] / tot
+        var = torch.clamp(s[1 + n:] / tot - mean * mean, min=0.0)
+        self.update_from_moments(mean.view(self.mean.shape), var.view(self.mean.shape), tot)
+
 
 class _Stub:
     def __init__(self, *a, **k):
@@ -93,9 +122,12 @@ class VecNormalize:
 
     def __init__(self, venv, training=True, norm_obs=True, norm_reward=True, clip_obs=10.0, clip_reward=10.0,
                  gamma=0.99, epsilon=1e-8, sync_ranks=True):
-        """sync_ranks: with torch.distributed initialised, the batch moments of every update are all-reduced, so N
+        """sync_ranks: with torch.distributed initialised, True / "step": the batch moments of every update are all-reduced, so N
         ranks x M envs keep the statistics ONE VecNormalize over N M envs would (the reference wraps all its envs in
-        one, /root/reference/src/main_baoding.py:74-75) and every rank holds — and saves — the same normaliser."""
+        one, /root/reference/src/main_baoding.py:74-75) and every rank holds — and saves — the same normaliser.
+        "rollout": every rank updates from its own envs and the ranks' statistics are merged once per rollout
+        (begin_rollout / end_rollout, called by PPO): one collective per rollout instead of one per env step, the same
+        statistics up to the order of the merges.  False / "none": no exchange."""
         self.venv = venv
         self.num_envs = venv.num_envs if venv is not None else 0
         dev = venv.device if venv is not None else "cpu"
@@ -103,8 +135,12 @@ class VecNormalize:
         obs_dim = venv.obs_dim if venv is not None else 0
         self.obs_rms = RunningMeanStd((obs_dim,), dev)
         self.ret_rms = RunningMeanStd((), dev)
-        self.sync_ranks = bool(sync_ranks)
+        self.sync_mode = {True: "step", False: "none", None: "none"}.get(sync_ranks, sync_ranks)
+        if self.sync_mode not in ("step", "rollout", "none"):
+            raise ValueError(f"sync_ranks must be True / False / 'step' / 'rollout' / 'none', not {sync_ranks!r}")
+        self.sync_ranks = self.sync_mode == "step"           # (what the per-update paths test)
         self.obs_rms.sync = self.ret_rms.sync = self.sync_ranks
+        self._rollout_snap = None
         self.training, self.norm_obs, self.norm_reward = training, norm_obs, norm_reward
         self.clip_obs, self.clip_reward, self.gamma, self.epsilon = clip_obs, clip_reward, gamma, epsilon
         self.returns = torch.zeros(self.num_envs, dtype=torch.float64, device=dev)
@@ -113,6 +149,17 @@ class VecNormalize:
         if venv is not None:
             self.observation_space, self.action_space = venv.observation_space, venv.action_space
             self.obs_dim, self.act_dim = venv.obs_dim, venv.act_dim
+
+    # -- per-rollout rank synchronisation (sync_ranks="rollout")
+    def begin_rollout(self) -> None:
+        if self.sync_mode == "rollout" and self.training and self._rollout_snap is None:
+            self._rollout_snap = (self.obs_rms.snapshot(), self.ret_rms.snapshot())
+
+    def end_rollout(self) -> None:
+        if self._rollout_snap is not None:
+            self.obs_rms.merge_ranks(self._rollout_snap[0])
+            self.ret_rms.merge_ranks(self._rollout_snap[1])
+            self._rollout_snap = None
 
     # -- normalisation
     def normalize_obs(self, obs):

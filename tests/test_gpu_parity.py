@@ -656,6 +656,65 @@ def test_two_rank_graph_path_keeps_replicas_identical(hip_lib):
     assert not np.array_equal(a, init)
 
 
+def _graph_allreduce_fallback_worker(rank, world, port, out):
+    import os
+    import warnings
+    import torch
+    import torch.distributed as dist
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real_backend = dist.get_backend
+    dist.get_backend = lambda *a, **k: "nccl"      # PPO then TRIES to capture the collective; gloo's cannot be captured in a hipGraph
+    torch.cuda.set_device(0)
+    torch.manual_seed(0)
+    pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
+    env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=64, seed=100 + rank)
+    algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=8, batch_size=128, n_epochs=2, graph_allreduce=True), seed=rank)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(2):
+            algo.collect_rollouts()
+            algo.train()
+    torch.cuda.synchronize()
+    dist.get_backend = real_backend
+    out[rank] = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).cpu().numpy()
+    out[10 + rank] = (bool(algo._allreduce_in_graph), any("capturing the gradient all-reduce" in str(x.message) for x in w), int(algo.n_updates))
+    dist.destroy_process_group()
+
+
+def test_graph_allreduce_capture_failure_falls_back_to_the_eager_collective(hip_lib):
+    """PPOConfig.graph_allreduce (the RCCL all-reduce captured inside the optimizer hipGraph) has never run on a multi-GPU box; its
+    FAILURE branch can be exercised here: two ranks on one GPU over gloo, the backend reported as nccl so that the
+    capture is attempted — it cannot succeed — and the trainer must warn, fall back to forward/backward graph -> eager all-reduce ->
+    optimizer graph, and still keep the replicas identical over two updates."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    procs = [ctx.Process(target=_graph_allreduce_fallback_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:
+        p.terminate()
+    assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
+    assert out[10] == out[11] == (False, True, 8), out[10]        # not in the graph, warned, 2 updates x 2 epochs x 2 minibatches
+    torch.manual_seed(0)
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None).parameters()]).numpy()
+    assert not np.array_equal(out[0], init)
+
+
 def _graph_dp_worker_recurrent(rank, world, port, out):
     import os
     import torch
@@ -729,6 +788,36 @@ def test_bench_spawns_its_own_ranks(hip_lib):
     assert rec["config"]["envs_per_gpu"] == 256 and rec["config"]["global_envs"] == 512
     assert rec["steps"] == 8 and rec["warmup"] == 2 and rec["scaling"] == "weak"
     assert abs(rec["value"] - 512 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
+    assert rec["replicas_identical"] is True and rec["health"] == {"protocol_errors": 0, "contact_overflows": 0}
+    assert rec["config"]["normalizer_sync"] == "step" and len(rec["rank_block_seconds_min_max"]) == 2
+
+
+def test_bench_at_config_d_shape_with_eight_ranks(hip_lib):
+    """BASELINE config D's shape before the first RCCL run: `bench.py --gpus 8 --envs 4096 --env-name
+    CustomMyoBaodingBallsP2` — eight ranks x 4096 phase-2 envs = 32768 envs, here sharing this box's one GPU over gloo.  The line
+    must carry 8 ranks / 32768 envs, the replicas must hold identical parameters after the timed updates (rollout of 8 steps, two
+    epochs x two minibatches per update, two updates), with the per-rollout normaliser exchange as well as the per-step one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MYO_DIST_BACKEND"] = "gloo"
+    env["OMP_NUM_THREADS"] = "2"
+    for sync in ("step", "rollout"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "0", "--envs", "4096",
+                            "--env-name", "CustomMyoBaodingBallsP2", "--n-epochs", "2", "--min-seconds", "0", "--no-variants",
+                            "--no-cpu-baseline", "--dtype", "f64", "--normalizer-sync", sync],
+                           env=env, capture_output=True, text=True, timeout=1500)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["config"]["global_envs"] == 32768
+        assert rec["replicas_identical"] is True and rec["config"]["normalizer_sync"] == sync
+        assert rec["health"]["protocol_errors"] == 0
+        assert abs(rec["value"] - 32768 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
 
 
 @pytest.mark.parametrize("n_envs", [1, 63, 32768])

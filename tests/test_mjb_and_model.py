@@ -299,3 +299,59 @@ def corrupt_id_variants(m):
         mm.arrays[name].reshape(-1)[idx] = val
         v.append(mm)
     return v
+
+
+def test_every_unsupported_feature_is_reported_at_once_by_both_routes(models, emu_lib, tmp_path, capsys):
+    """VERDICT r04 item 3.  (i) Options MuJoCo 2.1 honours and this stepper does not restate are REFUSED by both model routes, one test per
+    option: opt.solver other than Newton (PGS / CG would be stepped with another algorithm), noslip_iterations > 0, non-zero density /
+    viscosity / wind (fluid forces in mj_passive), actuators with integrator / filter dynamics or user gain / bias.  (ii) A model with
+    several unsupported features gets ONE report listing all of them with counts — model.unsupported_features, the message of
+    compile_model's ModelError, the C++ route's MyoError, and `python -m myochallenge_amd.model --check file.mjb` agree on the keys."""
+    import re
+    from myochallenge_amd import native
+    from myochallenge_amd.mjb import dump_mjb
+    from myochallenge_amd.model import _main, unsupported_features
+    hand = models["hand"]
+
+    def c_route(m):
+        path = tmp_path / "m.mjb"
+        path.write_bytes(dump_mjb(m))
+        return native.Model.from_mjb(str(path), emu_lib)
+
+    assert unsupported_features(hand) == []
+    dyn = hand.arrays["actuator_dyntype"].copy(); dyn[:3] = 2                      # filter
+    gain = hand.arrays["actuator_gaintype"].copy(); gain[0] = 2                     # user
+    bias = hand.arrays["actuator_biastype"].copy(); bias[:2] = 3                    # user
+    single = {"solver": dict(opt_solver=0), "solver ": dict(opt_solver=1), "noslip": dict(opt_noslip_iterations=3), "fluid": dict(opt_density=1.2),
+              "fluid ": dict(opt_viscosity=1e-3), "fluid  ": dict(opt_wind=[0.0, 1.0, 0.0]), "cone": dict(opt_cone=1), "integrator": dict(opt_integrator=2),
+              "actuator_dyn": dict(actuator_dyntype=dyn), "actuator_gain": dict(actuator_gaintype=gain), "actuator_bias": dict(actuator_biastype=bias)}
+    for key, change in single.items():
+        bad = _with(hand, **change)
+        feats = unsupported_features(bad)
+        assert [x["key"] for x in feats] == [key.strip()], (key, feats)
+        with pytest.raises(ModelError, match=re.escape(feats[0]["message"][:30])):
+            compile_model(bad)
+        with pytest.raises(native.MyoError, match=r"\[%s x\d+\]" % key.strip()):
+            c_route(bad)
+    assert unsupported_features(_with(hand, actuator_dyntype=dyn))[0]["count"] == 3
+    # several at once: one report, every entry, both routes
+    jt = hand.arrays["jnt_type"].copy(); jt[3] = 1                                 # a ball joint
+    many = _with(hand, opt_solver=1, opt_noslip_iterations=2, opt_viscosity=0.1, opt_cone=1, actuator_biastype=bias, jnt_type=jt, neq=2)
+    keys = sorted(x["key"] for x in unsupported_features(many))
+    assert keys == sorted(["solver", "noslip", "fluid", "cone", "actuator_bias", "ball_joints", "equality"])
+    with pytest.raises(ModelError) as e_py:
+        compile_model(many)
+    assert all(x["message"] in str(e_py.value) for x in unsupported_features(many))
+    with pytest.raises(native.MyoError) as e_c:
+        c_route(many)
+    assert sorted(re.findall(r"\[(\w+) x\d+\]", str(e_c.value))) == keys
+    counts_c = dict(re.findall(r"\[(\w+) x(\d+)\]", str(e_c.value)))
+    assert all(int(counts_c[x["key"]]) == x["count"] for x in unsupported_features(many))
+    # the command-line report
+    path = tmp_path / "many.mjb"
+    path.write_bytes(dump_mjb(many))
+    assert _main(["--check", str(path)]) == 1
+    text = capsys.readouterr().out
+    assert all(("[%s] x%d" % (x["key"], x["count"])) in text for x in unsupported_features(many))
+    path.write_bytes(dump_mjb(hand))
+    assert _main(["--check", str(path)]) == 0

@@ -640,3 +640,39 @@ def test_saved_optimizer_state_uses_sb3_parameter_order(golden_dir, tmp_path, em
         assert float(mine["state"][i]["step"]) == float(ref_opt["state"][i]["step"]) + 1      # ... and one optimizer step was taken on it
     assert not algo.load_optimizer_state({"state": {}})
     env.close()
+
+
+def _merge_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from myochallenge_amd.rl.vec_normalize import RunningMeanStd
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator(); g.manual_seed(3)
+    data = [torch.randn((2 * 5, 7), generator=g, dtype=torch.float64) * 3 + 1.5 for _ in range(6)]      # 6 "env steps" x (2 ranks x 5 envs)
+    rms = RunningMeanStd((7,))
+    rms.update(data[0])                                     # common history before the rollout (identical on both ranks)
+    snap = rms.snapshot()
+    for x in data[1:]:
+        rms.update(x[rank * 5:(rank + 1) * 5])              # own envs only
+    rms.merge_ranks(snap)
+    out[rank] = (rms.mean.numpy().copy(), rms.var.numpy().copy(), float(rms.count))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_per_rollout_normaliser_merge_equals_one_normaliser_over_all_envs():
+    """VecNormalize(sync_ranks="rollout"): two ranks update their own RunningMeanStd for a rollout and merge once
+    (RunningMeanStd.merge_ranks: inverse Chan merge -> additive sums -> one all-reduce) — both end on the statistics ONE normaliser fed
+    every env's data would hold."""
+    import torch.multiprocessing as mp
+    from myochallenge_amd.rl.vec_normalize import RunningMeanStd
+    mgr = mp.get_context("spawn").Manager()
+    out = mgr.dict()
+    mp.spawn(_merge_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = torch.Generator(); g.manual_seed(3)
+    data = [torch.randn((2 * 5, 7), generator=g, dtype=torch.float64) * 3 + 1.5 for _ in range(6)]
+    one = RunningMeanStd((7,))
+    for x in data:
+        one.update(x)
+    for k in (0, 1):
+        assert np.abs(out[k][0] - one.mean.numpy()).max() < 1e-12 and np.abs(out[k][1] - one.var.numpy()).max() < 1e-11 and abs(out[k][2] - float(one.count)) < 1e-9
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

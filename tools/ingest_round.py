@@ -8,11 +8,11 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R, P = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
-TAG = os.environ.get("ROUND", "r04")
+TAG = os.environ.get("ROUND", "r05")
 
 
 def main():
-    old = {"kernel": "k_step<double,false,20> (fp64 stepper, the bench default since round 4)", "envs_per_launch": 4096, "dtype": "f64",
+    old = {"kernel": "k_step<double,false,16> (fp64 stepper, the bench default since round 4; 16 = contact-row capacity / 4 of the base scratch)", "envs_per_launch": 4096, "dtype": "f64",
            "source": "rocprofv3 --pmc <one set per pass> --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 (tools/profile_round.sh); per-launch averages over the k_step launches of the bench workload (first two dropped)",
            "note": "FETCH_SIZE is reported as counted; the doubled figure (the guide's gfx950 correction for 16-B/lane streaming reads) is given separately"}
     vals, n = {}, None

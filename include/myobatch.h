@@ -128,7 +128,8 @@ int myo_batch_set_step_generation(myo_batch* b, unsigned int gen);
  *         or one batch stepped from two unsynchronised streams; such a step writes nothing and flags the env in bad_state);
  * out[1]: substeps in which an env had more contacts than its scratch holds (24; 20 in the fp64 stepper; 32 for models with
  *         extended collision pairs or a die) — the surplus was dropped, as MuJoCo drops contacts beyond nconmax with a warning;
- * out[2], out[3]: reserved. */
+ * out[2]: substeps in which an env had more joint-limit / tendon-limit / friction-loss rows than the scratch's row capacity
+ *         (MYO_NLIM_MAX = 56) — the surplus was dropped; out[3]: reserved. */
 int myo_batch_health(myo_batch* b, int out[4]);
 
 /* env.step(a) of the UNWRAPPED env for the envs selected by mask (dev uint8[N], NULL = all): no

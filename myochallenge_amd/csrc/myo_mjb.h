@@ -256,16 +256,22 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
     else if (pair_supported(lo, hi)) { p1.push_back(a); p2.push_back(b); psub.push_back(0); pxp.push_back(xp); }
     else { if (!dropped) snprintf(msg, sizeof msg, "geom %d (type %d) - geom %d (type %d)", a, gt[a], b, gt[b]); dropped++; }
   };
-  // explicit pairs first (no contype / conaffinity / parent / exclude filtering applies to them); a dynamic pair of the same geoms is skipped
+  // explicit pairs first (no contype / conaffinity / parent / exclude filtering applies to them).  mj_collision merges them into its
+  // BODY-pair sweep by pair_signature (the key of exclude_signature): a body pair that has explicit pairs gets only those — every dynamic
+  // geom pair between the two bodies is skipped (model.py:collision_pairs)
   std::vector<long long> xsig;
   for (int k = 0; k < npair_x; ++k) {
     const int a = I("pair_geom1")[k], b = I("pair_geom2")[k];
-    xsig.push_back(((long long)(a < b ? a : b) << 32) | (unsigned)(a < b ? b : a));
+    const int ba = gb[a] < gb[b] ? gb[a] : gb[b], bb = gb[a] < gb[b] ? gb[b] : gb[a];
+    xsig.push_back(((long long)ba << 32) | (unsigned)bb);
     emit(a, b, k);
   }
   for (int g1 = 0; g1 < ngeom && f.collision != 1; ++g1)
     for (int g2 = g1 + 1; g2 < ngeom; ++g2) {
-      if (!xsig.empty() && std::find(xsig.begin(), xsig.end(), (((long long)g1 << 32) | (unsigned)g2)) != xsig.end()) continue;
+      if (!xsig.empty()) {
+        const int ba = gb[g1] < gb[g2] ? gb[g1] : gb[g2], bb = gb[g1] < gb[g2] ? gb[g2] : gb[g1];
+        if (std::find(xsig.begin(), xsig.end(), (((long long)ba << 32) | (unsigned)bb)) != xsig.end()) continue;
+      }
       const int w1 = weld[gb[g1]], w2 = weld[gb[g2]];
       if (w1 == w2) continue;
       if (!excl.empty()) {

@@ -78,7 +78,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
   double* ctrl_ws;            // double[n_envs][MYO_ENVWS_N] in global memory, fp64 stepper: each env's controls, then its tendon moment arms (ScratchPoses<double>)
-  int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity
+  int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity, [2] substeps that dropped joint / tendon limit or friction-loss rows beyond MYO_NLIM_MAX
   unsigned long long seed;
 };
 
@@ -1988,8 +1988,8 @@ DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos
 // tendon = 1, AFTER it: one row per tendon with frictionloss > 0 behind the tendon-limit rows (J = +moment arms).  pos = margin = 0, so
 // aref = -B v; R = (1 - d0) / d0 * invweight; the solver treats the rows by their MYO_LIM_FRIC flag (fric_update, fric_linesearch).
 template <typename T, int NC>
-DEVFN void friction_rows(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int tendon) {
-  MYO_BIND_M(T) MYO_BIND_S(T)
+DEVFN void friction_rows(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int tendon) {
+  MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   LANE_VAR(int, cnt);
   int total = 0;
@@ -2012,6 +2012,7 @@ DEVFN void friction_rows(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int tend
     if (lane == 0) {
       const int n = base + total < MYO_NLIM_MAX ? base + total : MYO_NLIM_MAX;
       if (tendon) { s.ntl = n - s.nl; s.nefc = n; } else s.nl = n;
+      if (base + total > MYO_NLIM_MAX && K.health) myo_count(K.health + 2);      // rows beyond the capacity are dropped: counted (myo_batch_health)
     }
   }
   SYNC();
@@ -2059,7 +2060,10 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         }
       }
     }
-    if (lane == 0) s.nl = r0 + total < MYO_NLIM_MAX ? r0 + total : MYO_NLIM_MAX;
+    if (lane == 0) {
+      s.nl = r0 + total < MYO_NLIM_MAX ? r0 + total : MYO_NLIM_MAX;
+      if (r0 + total > MYO_NLIM_MAX && K.health) myo_count(K.health + 2);        // limit rows beyond the capacity are dropped: counted (myo_batch_health)
+    }
   }
   SYNC();
   const int nl = s.nl;
@@ -2094,7 +2098,7 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         }
       }
     }
-    if (lane == 0) { int n = nl + total; s.ntl = (n < MYO_NLIM_MAX ? n : MYO_NLIM_MAX) - nl; }
+    if (lane == 0) { int n = nl + total; s.ntl = (n < MYO_NLIM_MAX ? n : MYO_NLIM_MAX) - nl; if (n > MYO_NLIM_MAX && K.health) myo_count(K.health + 2); }
   }
   SYNC();
   PHASE { if (lane == 0) { s.ncon = 0; s.nefc = s.nl + s.ntl; } }
@@ -3280,9 +3284,9 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
   PROF(s, 3)
   crb(M, s);
   PROF(s, 4)
-  if (M.any_floss) friction_rows(M, s, 0);
+  if (M.any_floss) friction_rows(M, K, s, 0);
   constraint_limits(M, K, s);
-  if (M.any_floss) friction_rows(M, s, 1);
+  if (M.any_floss) friction_rows(M, K, s, 1);
   PROF(s, 18)
   if (M.any_gen) {
     for (int base = 0; base < M.npair_std; base += 64) collision_pass<true>(M, K, s, base);

@@ -655,9 +655,9 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   for (int base = 0; base < M.nte; base += 64) tendon_element_pass(M, K, s, base);
   tendon_length_sums(M, s);
   crb(M, s);
-  if (M.any_floss) friction_rows(M, s, 0);
+  if (M.any_floss) friction_rows(M, K, s, 0);
   constraint_limits(M, K, s);
-  if (M.any_floss) friction_rows(M, s, 1);
+  if (M.any_floss) friction_rows(M, K, s, 1);
   if (M.any_gen) {
     for (int base = 0; base < M.npair_std; base += 64) collision_pass<true>(M, K, s, base);
     for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<true>(M, K, s, base - M.npair_std);

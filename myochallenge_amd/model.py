@@ -154,22 +154,24 @@ def collision_pairs(m: MjbModel):
         else:
             dropped.append((a, b))
 
-    # explicit <contact><pair> entries (mj_collision runs them first; no contype / conaffinity / parent / exclude filtering applies to
-    # them, and a dynamic pair of the same two geoms is skipped): opt.collision 0 = all, 1 = predefined only, 2 = dynamic only
+    # explicit <contact><pair> entries (no contype / conaffinity / parent / exclude filtering applies to them): opt.collision 0 = all,
+    # 1 = predefined only, 2 = dynamic only.  With "all", mj_collision (MuJoCo 2.1) merges the predefined list into its BODY-pair sweep by
+    # pair_signature = ((body1 + 1) << 16) + body2 + 1 — the same key as exclude_signature — and a body pair that has predefined pairs gets
+    # ONLY those: every dynamic geom pair between the two bodies is skipped, not just the pair of the same two geoms
     col = int(m.opt.get("collision", 0))
     explicit = set()
     npair = int(m.sizes.get("npair", 0)) if col != 2 else 0
     for k in range(npair):
         a, b = int(m.arrays["pair_geom1"][k]), int(m.arrays["pair_geom2"][k])
-        explicit.add((min(a, b), max(a, b)))
+        explicit.add((min(int(gb[a]), int(gb[b])), max(int(gb[a]), int(gb[b]))))
         emit(a, b, k)
     if col == 1:
         return pairs, dropped
     for g1 in range(ng):
         for g2 in range(g1 + 1, ng):
-            if (g1, g2) in explicit:
-                continue
             b1, b2 = int(gb[g1]), int(gb[g2])
+            if (min(b1, b2), max(b1, b2)) in explicit:
+                continue
             w1, w2 = int(weld[b1]), int(weld[b2])
             if w1 == w2:
                 continue

@@ -291,10 +291,11 @@ class Batch:
 
     def health(self) -> dict:
         """{"protocol_errors": k_step workgroups that met a hand-off state of another generation, "contact_overflows": substeps that
-        dropped contacts beyond the scratch's capacity}; both 0 in a healthy batch.  Synchronises the device."""
+        dropped contacts beyond the scratch's capacity, "limit_row_overflows": substeps that dropped limit / friction-loss rows}; all 0
+        in a healthy batch.  Synchronises the device."""
         out = (C.c_int32 * 4)()
         self.lib.check(self.lib.L.myo_batch_health(self.h, out))
-        return {"protocol_errors": int(out[0]), "contact_overflows": int(out[1])}
+        return {"protocol_errors": int(out[0]), "contact_overflows": int(out[1]), "limit_row_overflows": int(out[2])}
 
     def set_bad_state_buffer(self, buf):
         """uint8[N] device buffer (kept alive by the caller) that every step() fills with 1 for envs reset after a

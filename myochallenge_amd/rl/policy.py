@@ -248,14 +248,19 @@ class ActorCriticPolicy(nn.Module):
     SDE_EPS = 1e-6
 
     @torch.no_grad()
-    def reset_noise(self, n_envs: int, generator: Optional[torch.Generator] = None) -> None:
+    def reset_noise(self, n_envs: int, generator: Optional[torch.Generator] = None, out: Optional[torch.Tensor] = None) -> None:
         """One exploration matrix per env, W ~ N(0, exp(log_std)) (SB3 ``sample_weights``; called at the start of every
-        rollout for sde_sample_freq = -1)."""
+        rollout for sde_sample_freq = -1).  out: a caller-owned [n_envs, latent, act] buffer to draw into — PPO's captured rollout
+        graph reads ITS buffer by address, so the training matrix must never move (an evaluation on another batch size
+        between two rollouts used to replace the tensor and leave the graph reading freed memory)."""
         if not self.use_sde:
             return
         std = torch.exp(self.log_std.float())
         eps = torch.randn((n_envs,) + tuple(std.shape), device=std.device, generator=generator)
-        if self.exploration_mat is not None and self.exploration_mat.shape == eps.shape:
+        if out is not None:
+            out.copy_(eps * std)
+            self.exploration_mat = out
+        elif self.exploration_mat is not None and self.exploration_mat.shape == eps.shape:
             self.exploration_mat.copy_(eps * std)          # in place: a captured rollout graph keeps reading this tensor
         else:
             self.exploration_mat = eps * std
@@ -399,22 +404,29 @@ class ActorCriticPolicy(nn.Module):
         values = _apply_net(self.value_net, lv).float().squeeze(-1)
         if self.use_sde:
             lat = lp.float()
-            if self.exploration_mat is None or self.exploration_mat.shape[0] != lat.shape[0]:
-                self.reset_noise(lat.shape[0])
+            Wm = self.exploration_mat
+            if Wm is None or Wm.shape[0] != lat.shape[0]:
+                # another batch size than the one the matrix was drawn for (an evaluation between rollouts): a temporary of its own —
+                # the training matrix stays where it is; a deterministic call needs no noise at all
+                std = torch.exp(self.log_std.float())
+                Wm = torch.zeros((lat.shape[0],) + tuple(std.shape), device=std.device) if deterministic else \
+                    torch.randn((lat.shape[0],) + tuple(std.shape), device=std.device) * std
+                if self.exploration_mat is None:
+                    self.exploration_mat = Wm
             lib = _native_lib(lat)
             if lib is not None and lat.dtype == torch.float32 and self.SDE_EPS == 1e-6:
                 # GPU rollout: noise, sigma and log pi of all envs in ONE launch (myo_rollout_sample_sde) instead of
                 # bmm + the matmul of _sde_std + the elementwise log_prob chain
                 import ctypes as C
                 mu, lat = mean.float().contiguous(), lat.contiguous()
-                W, ls = self.exploration_mat.contiguous(), self.log_std.detach().float().contiguous()
+                W, ls = Wm.contiguous(), self.log_std.detach().float().contiguous()
                 actions, clipped, logp = torch.empty_like(mu), torch.empty_like(mu), mu.new_empty(mu.shape[0])
                 p = lambda t: C.c_void_p(t.data_ptr())
                 lib.check(lib.L.myo_rollout_sample_sde(p(mu), p(lat), p(W), p(ls), mu.shape[0], lat.shape[1], mu.shape[1],
                                                        p(actions), p(clipped), p(logp), int(bool(deterministic)),
                                                        C.c_void_p(torch.cuda.current_stream(mu.device).cuda_stream)))
                 return actions, values, logp, state
-            noise = torch.bmm(lat.unsqueeze(1), self.exploration_mat).squeeze(1)       # latent_pi(s_n) . W_n
+            noise = torch.bmm(lat.unsqueeze(1), Wm).squeeze(1)       # latent_pi(s_n) . W_n
             actions = mean if deterministic else mean + noise
             return actions, values, self.log_prob(actions, mean, torch.log(self._sde_std(lat))), state
         noise = torch.randn_like(mean) if getattr(self, "noise_fn", None) is None else self.noise_fn(mean)

@@ -251,8 +251,9 @@ class PPO:
         sde = getattr(self.policy, "use_sde", False)
         if sde:          # gSDE: myo_rollout_sample_sde leaves actions / log pi in step tensors, the rollout buffers take them by index
             self._act_s, self._logp_s = torch.zeros((N, A), device=d), torch.zeros(N, device=d)
-            if self.policy.exploration_mat is None or self.policy.exploration_mat.shape[0] != N:
-                self.policy.reset_noise(N, self.gen if self.gen.device == self.policy.log_std.device else None)
+            # the exploration matrices live in a buffer of PPO's own: the captured graph reads it by address (see _reset_sde_noise)
+            self._sde_W = torch.zeros((N,) + tuple(self.policy.log_std.shape), device=d)
+            self._reset_sde_noise()
 
         def sample(saved, mean_h, value_h, st):
             """Actions, log pi, value of this step into the rollout buffers (row t_idx) and the clipped actions for the env."""
@@ -262,7 +263,7 @@ class PPO:
                                                    p(self._clip_s), 0, st))
                 return
             mu, lat = mean_h.float(), saved[-1][0].float().contiguous()      # latent_pi: the actor trunk's output (LSTM output without a trunk)
-            lib.check(lib.L.myo_rollout_sample_sde(p(mu), p(lat), p(self.policy.exploration_mat), p(self.policy.log_std.data), N, lat.shape[1], A,
+            lib.check(lib.L.myo_rollout_sample_sde(p(mu), p(lat), p(self._sde_W), p(self.policy.log_std.data), N, lat.shape[1], A,
                                                    p(self._act_s), p(self._clip_s), p(self._logp_s), 0, st))
             t64 = self._t_idx.long()
             self.act_buf.index_copy_(0, t64, self._act_s.unsqueeze(0))
@@ -467,12 +468,24 @@ class PPO:
                 self._last_values = self.policy.predict_values(self._obs_s)
         self._last_obs, self._last_starts = self._obs_s, self._starts_s
 
+    def _reset_sde_noise(self) -> None:
+        """gSDE: new exploration matrices for the rollout.  On the HIP-kernel rollout they are drawn INTO self._sde_W, the buffer whose
+        address the captured graph holds; whatever policy.act did to policy.exploration_mat in between (an evaluation on another batch
+        size) cannot move it."""
+        pol = self.policy
+        gen = self.gen if self.gen.device == pol.log_std.device else None
+        W = getattr(self, "_sde_W", None)
+        if W is not None and W.shape[1:] == tuple(pol.log_std.shape):
+            pol.reset_noise(W.shape[0], gen, out=W)
+        else:
+            pol.reset_noise(self.env.num_envs, gen)
+
     # ---------------------------------------------------------------- rollout
     @torch.no_grad()
     def collect_rollouts(self) -> None:
         cfg, env, pol = self.cfg, self.env, self.policy
         if getattr(pol, "use_sde", False):          # SB3: policy.reset_noise(env.num_envs) at the start of a rollout
-            pol.reset_noise(env.num_envs, self.gen if self.gen.device == pol.log_std.device else None)
+            self._reset_sde_noise()
         if self._graphed_rollout():
             if self._fused is not None:
                 self._fused.refresh_shadow()        # rollout inference runs on the bf16 shadow weights

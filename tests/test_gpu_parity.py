@@ -788,7 +788,7 @@ def test_bench_spawns_its_own_ranks(hip_lib):
     assert rec["config"]["envs_per_gpu"] == 256 and rec["config"]["global_envs"] == 512
     assert rec["steps"] == 8 and rec["warmup"] == 2 and rec["scaling"] == "weak"
     assert abs(rec["value"] - 512 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
-    assert rec["replicas_identical"] is True and rec["health"] == {"protocol_errors": 0, "contact_overflows": 0}
+    assert rec["replicas_identical"] is True and rec["health"] == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0}
     assert rec["config"]["normalizer_sync"] == "step" and len(rec["rank_block_seconds_min_max"]) == 2
 
 
@@ -874,7 +874,7 @@ def test_mixture_model_env_on_gpu(hip_lib, emu_lib, golden_dir):
         assert float((rg[0].cpu() - rc[0]).abs().max()) <= 1e-4, t               # observations, hand-over observations included
         assert float((rg[1].cpu() - rc[1]).abs().max()) <= 1e-4
     assert gpu._graph is not None and gpu.base_phase_launches >= 3
-    assert gpu.batch.health() == {"protocol_errors": 0, "contact_overflows": 0}
+    assert gpu.batch.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0}
     gpu.close(); cpu.close()
 
     # (ii) cost at BASELINE size.  Base model: the architecture of the reference's phase-1 policy (LSTM-128 -> heads, phase1_final.zip)
@@ -1490,6 +1490,23 @@ def test_gsde_ppo_round_on_gpu(hip_lib):
         mean, _ = pol._dist(lat)
     assert float((lp - lp2).abs().max()) <= 2e-3 * float(lp2.abs().max())
     assert float((a - mean.float() - noise).abs().max()) <= 1e-4
+    # an evaluation on ANOTHER batch size between two rollouts (tools/train_demo.py does that) must not move the
+    # exploration matrices the captured rollout graph reads by address — they live in PPO's own buffer, policy.act uses a temporary
+    ptr = algo._sde_W.data_ptr()
+    assert pol.exploration_mat.data_ptr() == ptr
+    obs2 = torch.randn(16, 86, device=pol.log_std.device)
+    a_det, _, _, _ = pol.act(obs2, deterministic=True)
+    a_sto, _, _, _ = pol.act(obs2)
+    assert torch.isfinite(a_det).all() and torch.isfinite(a_sto).all() and not torch.equal(a_det, a_sto)
+    assert pol.exploration_mat.data_ptr() == ptr and pol.exploration_mat.shape[0] == 64
+    w_before = algo._sde_W.clone()
+    algo.collect_rollouts()
+    assert algo._sde_W.data_ptr() == ptr and pol.exploration_mat.data_ptr() == ptr and not torch.equal(w_before, algo._sde_W)      # redrawn in place
+    with torch.no_grad():
+        lat = pol._latents(algo.obs_buf[5], None, None)[0]
+        mean = pol._dist(lat)[0]
+        noise = torch.bmm(lat.float().unsqueeze(1), algo._sde_W).squeeze(1)
+    assert float((algo.act_buf[5] - mean.float() - noise).abs().max()) <= 2e-2 * (1 + float(algo.act_buf[5].abs().max()))
 
 
 def test_training_entry_points_run_end_to_end(hip_lib, tmp_path):

@@ -244,8 +244,10 @@ def test_exclude_pairs_filterparent_and_refused_options(models, emu_lib, tmp_pat
                pair_margin=np.array([0.003]), pair_gap=np.zeros(1), pair_friction=np.array([[0.7, 0.7, 0.01, 0.002, 0.002]]),
                name_pairadr=np.zeros(1, np.int32), npair=1)
     cmx = compile_model(xp)
-    assert len(cmx.x_pair_geom1) == len(pairs) and list(cmx.x_pair_explicit).count(0) == 1 and list(cmx.x_xp_dim) == [4]
-    assert c_route(xp).size("npair") == len(pairs)
+    # (the explicit pair replaces EVERY dynamic geom pair between its two bodies: test_explicit_pair_replaces_every_dynamic_pair_of_its_two_bodies)
+    same_bodies = sum(1 for a, b in pairs if {int(gb[a]), int(gb[b])} == {int(gb[g_ball]), int(gb[g_other])})
+    assert len(cmx.x_pair_geom1) == len(pairs) - same_bodies + 1 and list(cmx.x_pair_explicit).count(0) == 1 and list(cmx.x_xp_dim) == [4]
+    assert c_route(xp).size("npair") == len(pairs) - same_bodies + 1
     only = compile_model(_with(xp, opt_collision=1))
     assert len(only.x_pair_geom1) == 1 and c_route(_with(xp, opt_collision=1)).size("npair") == 1
 
@@ -355,3 +357,36 @@ def test_every_unsupported_feature_is_reported_at_once_by_both_routes(models, em
     assert all(("[%s] x%d" % (x["key"], x["count"])) in text for x in unsupported_features(many))
     path.write_bytes(dump_mjb(hand))
     assert _main(["--check", str(path)]) == 0
+
+
+def test_explicit_pair_replaces_every_dynamic_pair_of_its_two_bodies(models, emu_lib, tmp_path):
+    """mj_collision (MuJoCo 2.1) merges predefined pairs into its body-pair sweep by pair_signature = ((body1 + 1) << 16) + body2 + 1: a
+    body pair that has explicit pairs gets ONLY those.  A hand body that carries two colliding geoms against a ball:
+    one explicit pair between one of the two geoms and the ball removes BOTH dynamic geom pairs of that body pair, through both routes;
+    other bodies' pairs with the ball are untouched."""
+    from myochallenge_amd import native
+    from myochallenge_amd.mjb import dump_mjb
+    hand = models["hand"]
+    base = compile_model(hand)
+    gb = np.asarray(hand.geom_bodyid)
+    pairs = list(zip(base.x_pair_geom1.tolist(), base.x_pair_geom2.tolist()))
+    g_ball = hand.names["geom"].index("ball1")
+    b_ball = int(gb[g_ball])
+    # a hand body with >= 2 geoms colliding with ball1
+    partners = [int(b if a == g_ball else a) for a, b in pairs if g_ball in (a, b)]
+    by_body = {}
+    for g in partners:
+        by_body.setdefault(int(gb[g]), []).append(g)
+    body, geoms = next((b, gs) for b, gs in by_body.items() if len(gs) >= 2 and b != b_ball)
+    xp = _with(hand, pair_dim=np.full(1, 3, np.int32), pair_geom1=np.array([geoms[0]], np.int32), pair_geom2=np.array([g_ball], np.int32),
+               pair_signature=np.array([((min(body, b_ball) + 1) << 16) + max(body, b_ball) + 1], np.int32), pair_solref=np.array([[0.02, 1.0]]),
+               pair_solimp=np.array([[0.9, 0.95, 0.001, 0.5, 2.0]]), pair_margin=np.zeros(1), pair_gap=np.zeros(1),
+               pair_friction=np.array([[1.0, 1.0, 0.005, 1e-4, 1e-4]]), name_pairadr=np.zeros(1, np.int32), npair=1)
+    cm = compile_model(xp)
+    kept = list(zip(cm.x_pair_geom1.tolist(), cm.x_pair_geom2.tolist(), cm.x_pair_explicit.tolist()))
+    between = [(a, b, x) for a, b, x in kept if {int(gb[a]), int(gb[b])} == {body, b_ball}]
+    assert len(between) == 1 and between[0][2] == 0 and {between[0][0], between[0][1]} == {geoms[0], g_ball}      # only the explicit pair is left
+    assert len(kept) == len(pairs) - (len(geoms) - 1)                                                             # nothing else changed
+    path = tmp_path / "xp.mjb"
+    path.write_bytes(dump_mjb(xp))
+    assert native.Model.from_mjb(str(path), emu_lib).size("npair") == len(kept)

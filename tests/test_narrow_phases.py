@@ -258,7 +258,7 @@ def case_contact_overflow(lib, dtype):
     """contacts beyond the scratch's capacity are dropped (MuJoCo drops beyond nconmax with a warning) — never silently:
     myo_batch_health counts the substeps it happened in, the states stay finite, and a model inside the capacity counts nothing."""
     mem = Mem(lib)
-    cap = 20 if dtype == native.MYO_F64 else 24            # MYO_NCON_F64 / MYO_NCON_MAX (sphere-plane pairs: the base scratch)
+    cap = 22 if dtype == native.MYO_F64 else 24            # MYO_NREC_F64 / MYO_NCON_MAX record slots (sphere-plane pairs: the base scratch; no limit rows here)
     for n_rafts, per_raft, over in ((1, 12, False), (3, 12, True)):
         assert (n_rafts * per_raft > cap) == over
         cm = compile_model(raft_model(n_rafts, per_raft))
@@ -423,7 +423,7 @@ def case_condim(lib, dtype, tol):
     assert spin[0] > 19.9 and spin[1] > 19.9 and spin[2] < 12.0 and spin[3] < 12.0, spin          # torsional friction exists from condim 4 on
     roll = [abs(ov[6 * k + 4]) for k in range(4)]
     assert roll[3] < 0.75 * roll[2], roll                                                         # rolling friction from condim 6 on
-    assert b.health() == {"protocol_errors": 0, "contact_overflows": 0}
+    assert b.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0}
     b.close()
 
 

@@ -51,7 +51,7 @@ def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, hor
     qpos, qvel, act, time = mem.zeros((n, cm.size("nq"))), mem.zeros((n, cm.size("nv"))), mem.zeros((n, cm.size("na"))), mem.zeros(n)
     b.get_state(qpos, qvel, act, time)
     out += [mem.host(x).copy() for x in (qpos, qvel, act, time)]
-    assert b.health() == {"protocol_errors": 0, "contact_overflows": 0}     # no hand-off state of another generation, no dropped contact
+    assert b.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0}     # no hand-off state of another generation, no dropped contact
     b.close()
     return out
 

@@ -64,6 +64,12 @@ def main():
         ev("t=%.0fs" % (time.time() - t0))
     print("trained %d env steps in %.1f s (%.0f steps/s incl. evaluations)" % (algo.num_timesteps, time.time() - t0,
                                                                               algo.num_timesteps / (time.time() - t0)))
+    # batch health: hand-off protocol errors, substeps that dropped contacts / limit rows beyond the scratch's capacity
+    health = {"train": env.batch.health(), "eval": eval_env.batch.health()}
+    print("batch health:", json.dumps(health))
+    if any(v for h in health.values() for v in h.values()):
+        print("WARNING: non-zero health counters — some substeps dropped constraint rows (see include/myobatch.h: myo_batch_health)")
+    log.append({"health": health})
     if a.out:
         json.dump(log, open(a.out, "w"), indent=1)
 

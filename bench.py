@@ -329,19 +329,20 @@ def main():
         kernel_ms = env.batch.kernel_ms()
         env.batch.enable_timing(False)
         health = env.batch.health()                  # hand-off protocol errors, substeps that dropped contacts beyond the scratch's capacity
-        replicas_identical = None
+        replicas_identical, replica_spread = None, None
         if world > 1:      # data-parallel replicas must hold the same parameters after the timed updates (fp64 sum of |p|, min == max over ranks)
             cs = torch.stack([p.detach().double().abs().sum() for p in policy.parameters()]).sum().reshape(1)
             lo, hi = cs.clone(), cs.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             replicas_identical = bool(float(lo[0]) == float(hi[0]))
+            replica_spread = float(hi[0]) - float(lo[0])
         blocks.sort()
         med = blocks[len(blocks) // 2] if len(blocks) % 2 else 0.5 * (blocks[len(blocks) // 2 - 1] + blocks[len(blocks) // 2])
         res = {"dtype": dtype, "integrator": integ_name, "value": args.envs * world * steps / med, "ms_per_step": 1e3 * med / steps,
                "ms_per_step_min": 1e3 * blocks[0] / steps, "ms_per_step_max": 1e3 * blocks[-1] / steps, "blocks": len(blocks),
                "timed_seconds": total, "env_kernel_ms": kernel_ms, "optimizer_steps_per_sec": (algo.n_updates - upd0) / total,
                "n_steps": cfg.n_steps, "batch_size": cfg.batch_size, "n_epochs": cfg.n_epochs, "lds_bytes": env.batch.lds_bytes, "health": health,
-               "replicas_identical": replicas_identical, "normalizer_sync": args.normalizer_sync if world > 1 else None,
+               "replicas_identical": replicas_identical, "replica_checksum_spread": replica_spread, "normalizer_sync": args.normalizer_sync if world > 1 else None,
                "graph_allreduce": bool(getattr(algo, "_allreduce_in_graph", False))}
         if skew:      # per-rank spread of the block times (own work, before the barrier): min / max over ranks, median block
             sk = sorted(skew, key=lambda x: x[1])[len(skew) // 2]
@@ -468,6 +469,7 @@ def main():
         }
         if world > 1:
             out["replicas_identical"] = main_res["replicas_identical"]
+            out["replica_checksum_spread"] = main_res["replica_checksum_spread"]
             out["config"]["normalizer_sync"] = main_res["normalizer_sync"]
             out["config"]["graph_allreduce"] = main_res["graph_allreduce"]
         if main_res.get("rank_block_seconds_min_max"):

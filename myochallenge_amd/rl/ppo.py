@@ -628,8 +628,11 @@ class PPO:
                     "pl": torch.zeros((), device=d), "vl": torch.zeros((), device=d)}
         self._gs["idx"].copy_(torch.arange(bs, device=d))
         side = torch.cuda.Stream(device=d)
+        # warm-up and capture must not move the parameters.  The snapshot is taken BEFORE the side stream is told to wait: its copies run
+        # on the current stream, and a warm-up optimizer step on the side stream that overtook them left some ranks restoring a state two
+        # Adam steps ahead (round 5: replicas of >= 4 ranks sharing a GPU differed; found by the config-D-shape test)
+        snap = self._flat_adam.snapshot()
         side.wait_stream(torch.cuda.current_stream(d))
-        snap = self._flat_adam.snapshot()   # warm-up and capture must not move the parameters
         with torch.cuda.stream(side):       # eager warm-up (library handles, workspaces)
             for _ in range(2):
                 self._mb_forward_backward()
@@ -640,22 +643,29 @@ class PPO:
         torch.cuda.synchronize(d)
         self._graph_fb, self._graph_ap = torch.cuda.CUDAGraph(), None
         import os
-        want_inside = self.world > 1 and (self.cfg.graph_allreduce or os.environ.get("MYO_GRAPH_ALLREDUCE") == "1") \
-            and dist.get_backend() == "nccl"
+        # The gradient all-reduce INSIDE the optimizer hipGraph (forward / backward -> RCCL all-reduce -> clip + Adam, one replay per
+        # minibatch): opt-in, nccl (= RCCL) only.  There is no in-process fallback from a failed capture: measured on a one-GPU box with a
+        # backend that synchronises inside the capture (gloo), the capture is invalidated, capture_end throws inside torch's graph
+        # destructor and the process dies (round 5, tests/test_gpu_parity.py).  So a backend that cannot be captured is refused up front
+        # (warning, eager collective between two graphs — the tested default), and a capture failure on nccl is raised as an error.
+        asked = self.world > 1 and (self.cfg.graph_allreduce or os.environ.get("MYO_GRAPH_ALLREDUCE") == "1")
+        want_inside = asked and dist.get_backend() == "nccl"
+        if asked and not want_inside:
+            import warnings
+            warnings.warn(f"graph_allreduce needs the nccl (RCCL) backend, this process group is {dist.get_backend()!r}: "
+                          "using the eager all-reduce between the two optimizer graphs")
         self._allreduce_in_graph = False
         if want_inside:
-            try:                            # forward / backward -> RCCL all-reduce -> clip + Adam, one replay per minibatch
-                g_all = torch.cuda.CUDAGraph()
+            g_all = torch.cuda.CUDAGraph()
+            try:
                 with torch.cuda.graph(g_all, capture_error_mode="thread_local"):
                     self._mb_forward_backward()
                     dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
                     self._mb_apply()
-                self._graph_fb, self._allreduce_in_graph = g_all, True
-            except Exception as exc:        # noqa: BLE001 — any capture problem: keep the eager collective between two graphs
-                import warnings
-                warnings.warn(f"capturing the gradient all-reduce in the optimizer hipGraph failed ({exc!r}); using the eager collective")
-                torch.cuda.synchronize(d)
-                self._graph_fb = torch.cuda.CUDAGraph()
+            except Exception as exc:        # noqa: BLE001
+                raise RuntimeError("capturing the RCCL gradient all-reduce inside the optimizer hipGraph failed; run without "
+                                   "graph_allreduce / MYO_GRAPH_ALLREDUCE (the eager collective between two graphs)") from exc
+            self._graph_fb, self._allreduce_in_graph = g_all, True
         if not self._allreduce_in_graph:
             with torch.cuda.graph(self._graph_fb, capture_error_mode="thread_local"):
                 self._mb_forward_backward()
@@ -698,10 +708,30 @@ class PPO:
                 self._graph_fb.replay()
                 if self.world > 1 and not self._allreduce_in_graph:
                     dist.all_reduce(self._flat_grad, op=dist.ReduceOp.SUM)
+                    if self._dp_check:
+                        self._dp_compare("gradient after the all-reduce", self._flat_grad)
+                        self._dp_compare("parameters before the optimizer step", self._flat_adam.flat["p"])
+                        self._dp_compare("Adam m before the optimizer step", self._flat_adam.m)
+                        self._dp_compare("Adam v before the optimizer step", self._flat_adam.v)
+                        self._dp_compare("Adam step counter before the optimizer step", self._flat_adam._step)
                     self._graph_ap.replay()
+                    if self._dp_check:
+                        self._dp_compare("gradient after the optimizer step", self._flat_grad)
+                        self._dp_compare("|g|^2 partial sums", self._flat_adam.sq[:64].contiguous())
+                        self._dp_compare("parameters after the optimizer step", self._flat_adam.flat["p"])
                 self.n_updates += 1
         self._fused.refresh_shadow()     # rollout inference reads the bf16 shadow weights
         return g["pl"], g["vl"]
+
+    _dp_check = bool(__import__("os").environ.get("MYO_DP_CHECK"))
+
+    def _dp_compare(self, what: str, x: torch.Tensor) -> None:
+        """MYO_DP_CHECK=1 (developer diagnostic of the N > 1 path): a bit-level checksum of `x` must be the same on every rank."""
+        cs = x.detach().contiguous().view(torch.int32).to(torch.int64).sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if int(lo[0]) != int(hi[0]) and dist.get_rank() == 0:
+            print(f"MYO_DP_CHECK: {what} differs across ranks at optimizer step {self.n_updates}", flush=True)
 
     # ---------------------------------------------------------------- recurrent policy: one hipGraph per minibatch step
     def _rec_forward_backward(self):
@@ -731,8 +761,8 @@ class PPO:
             H = self.policy.hidden
             self._rg["h0"], self._rg["c0"] = torch.zeros((2, N, H), device=d), torch.zeros((2, N, H), device=d)
         side = torch.cuda.Stream(device=d)
+        snap = self._flat_adam.snapshot()        # (before the side stream waits: see _build_graphs)
         side.wait_stream(torch.cuda.current_stream(d))
-        snap = self._flat_adam.snapshot()
         with torch.cuda.stream(side):
             for _ in range(2):
                 self._rec_forward_backward()

@@ -667,8 +667,6 @@ def _graph_allreduce_fallback_worker(rank, world, port, out):
     from myochallenge_amd.rl.vec_normalize import VecNormalize
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    real_backend = dist.get_backend
-    dist.get_backend = lambda *a, **k: "nccl"      # PPO then TRIES to capture the collective; gloo's cannot be captured in a hipGraph
     torch.cuda.set_device(0)
     torch.manual_seed(0)
     pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
@@ -680,17 +678,18 @@ def _graph_allreduce_fallback_worker(rank, world, port, out):
             algo.collect_rollouts()
             algo.train()
     torch.cuda.synchronize()
-    dist.get_backend = real_backend
     out[rank] = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).cpu().numpy()
-    out[10 + rank] = (bool(algo._allreduce_in_graph), any("capturing the gradient all-reduce" in str(x.message) for x in w), int(algo.n_updates))
+    out[10 + rank] = (bool(algo._allreduce_in_graph), any("graph_allreduce needs the nccl" in str(x.message) for x in w), int(algo.n_updates))
     dist.destroy_process_group()
 
 
-def test_graph_allreduce_capture_failure_falls_back_to_the_eager_collective(hip_lib):
-    """PPOConfig.graph_allreduce (the RCCL all-reduce captured inside the optimizer hipGraph) has never run on a multi-GPU box; its
-    FAILURE branch can be exercised here: two ranks on one GPU over gloo, the backend reported as nccl so that the
-    capture is attempted — it cannot succeed — and the trainer must warn, fall back to forward/backward graph -> eager all-reduce ->
-    optimizer graph, and still keep the replicas identical over two updates."""
+def test_graph_allreduce_on_a_backend_that_cannot_be_captured(hip_lib):
+    """PPOConfig.graph_allreduce (the RCCL all-reduce captured inside the optimizer hipGraph) has never run on a multi-GPU box (VERDICT
+    r04 item 2c).  What a one-GPU box can establish: (i) a FAILED capture is not survivable in-process — the first version of this test
+    reported gloo as nccl so that the capture was attempted; gloo synchronises inside the capture, the capture is invalidated,
+    capture_end throws in torch's graph destructor and both ranks die (exit -6) — so PPO no longer promises a fallback from a failed
+    capture; (ii) asked for on a backend other than nccl, PPO warns and uses the tested path (forward/backward graph -> eager
+    all-reduce -> optimizer graph), and the replicas stay identical over two updates."""
     import socket
     import torch
     import torch.multiprocessing as mp
@@ -708,7 +707,7 @@ def test_graph_allreduce_capture_failure_falls_back_to_the_eager_collective(hip_
         p.terminate()
     assert not hung and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1])
-    assert out[10] == out[11] == (False, True, 8), out[10]        # not in the graph, warned, 2 updates x 2 epochs x 2 minibatches
+    assert out[10] == out[11] == (False, True, 16), out[10]       # not in the graph, warned, 2 updates x 2 epochs x 4 minibatches
     torch.manual_seed(0)
     from myochallenge_amd.rl.policy import ActorCriticPolicy
     init = torch.cat([p.detach().reshape(-1) for p in ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None).parameters()]).numpy()
@@ -887,7 +886,7 @@ def test_mixture_model_env_on_gpu(hip_lib, emu_lib, golden_dir):
             prm.mul_(0.05)
     N = 4096
     mix = EnvironmentFactory.create("MixtureModelBaodingEnv", num_envs=N, seed=1, base_model_path=None, base_env_path=None, base_policy=pol,
-                                    base_normalizer=Ident())
+                                    base_normalizer=Ident(), pool_size="auto")      # the pooled form is opt-in (training throughput)
     p2 = EnvironmentFactory.create("CustomMyoBaodingBallsP2", num_envs=N, seed=1)
     assert mix.pool_size == 2048
     g = torch.Generator(device="cuda"); g.manual_seed(0)
@@ -924,6 +923,83 @@ def test_mixture_model_env_on_gpu(hip_lib, emu_lib, golden_dir):
     mix.batch.get_task(ti, None, None)
     assert int(ti[:, 1].min()) >= mix.n_steps_base_model            # every env's goal counter has been through a base phase
     mix.close(); p2.close()
+
+
+def test_mixture_env_base_phase_against_the_oracle_and_pool_against_the_exact_path(hip_lib):
+    """VERDICT r04 item 5 (f-3).  (a) The base phase against an ORACLE twin (not another build of the same source): a plain phase-2 env with
+    the same seed gives the post-reset states, the oracle twins are built from them (per-episode draws included), stepped with the clipped
+    actions the base policy produced inside MixtureModelBaodingVecEnv.reset (_c_act_log), and must arrive at the env's hand-over
+    observations to 1e-7 and hand-over qpos to 1e-9 (fp64 stepper).  (b) pooled == exact: a pool env's record after the bulk base phase
+    (reset + 20 full-width base steps of the second batch) is BIT-identical to what the exact compact path computes for an env of that
+    seed — same width (256), same kernels — so the pooled form hands over exactly the states the exact form would, only to other envs."""
+    import copy
+    import torch
+    from helpers import make_env, oracle_for
+    from myochallenge_amd.envs.config import task_ids
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from oracle.oracle import OracleData, baoding_step, make_cfg
+
+    class Ident:
+        training = True
+        def normalize_obs(self, o): return o
+    torch.manual_seed(5)
+    base = ActorCriticPolicy(86, 39, (32,), (32,), lstm_hidden_size=16)
+    with torch.no_grad():
+        for prm in base.parameters():
+            prm.mul_(0.3)
+    n, nb = 8, 6
+    kw = dict(num_envs=n, seed=21, dtype="f64", base_model_path=None, base_env_path=None, n_steps_base_model=nb)
+    mix = make_env("MixtureModelBaodingEnv", hip_lib, base_policy=copy.deepcopy(base), base_normalizer=Ident(), **kw)
+    assert mix.pool_size == 0                                               # exact form by default
+    plain = make_env("CustomMyoBaodingBallsP2", hip_lib, num_envs=n, seed=21, dtype="f64")
+    plain.reset_tensor()
+    dev = plain.device
+    qp, qv, ac, tm = (torch.zeros((n, k), dtype=torch.float64, device=dev) for k in (37, 35, 39, 1))
+    ti, td, bd = torch.zeros((n, 2), dtype=torch.int32, device=dev), torch.zeros((n, 9), dtype=torch.float64, device=dev), torch.zeros((n, 10), dtype=torch.float64, device=dev)
+    plain.batch.get_state(qp, qv, ac, tm.view(-1)); plain.batch.get_task(ti, td, bd)
+    torch.cuda.synchronize()
+    from helpers import default_state
+    from myochallenge_amd.synth_hand import synthetic_hand
+    cm, om, _ = oracle_for(synthetic_hand())
+    tc = plain._cfg
+    ocfg = make_cfg(task_ids(cm), drop_th=tc.drop_th, proximity_th=tc.proximity_th,
+                    weights={k: tc.weights[i] for i, k in enumerate(("pos_dist_1", "pos_dist_2", "act_reg", "alive", "sparse", "solved", "done"))})
+    obs_mix = mix.reset_tensor().clone()
+    acts = mix._c_act_log[:, :n].cpu().numpy()
+    q_mix = torch.zeros((n, 37), dtype=torch.float64, device=dev); mix.batch.get_state(q_mix); torch.cuda.synchronize()
+    h_qp, h_qv, h_ac, h_tm, h_ti, h_td, h_bd = (x.cpu().numpy() for x in (qp, qv, ac, tm.view(-1), ti, td, bd))
+    for e in range(n):
+        d = OracleData(om)                               # as parity_cases.episode_drift(resync=True) builds its twins
+        d.reset()
+        d.qpos[:], d.qvel[:], d.act[:] = h_qp[e], h_qv[e], h_ac[e]
+        d.arr("time")[0] = h_tm[e]
+        d.set_ball_params(ocfg, h_bd[e])
+        sp = d.arr("site_pos")
+        sp[3 * ocfg.target1_sid:3 * ocfg.target1_sid + 2] = h_td[e, 5:7]
+        sp[3 * ocfg.target2_sid:3 * ocfg.target2_sid + 2] = h_td[e, 7:9]
+        st = default_state(which=int(h_ti[e, 0]), period=h_td[e, 4], xr=h_td[e, 2], yr=h_td[e, 3], s1=h_td[e, 0], s2=h_td[e, 1])
+        st.counter = int(h_ti[e, 1])
+        o = None
+        for k in range(nb):
+            o, _ = baoding_step(d, ocfg, st, acts[k, e])
+        assert np.abs(obs_mix[e].cpu().numpy() - o).max() <= 1e-7, (e, np.abs(obs_mix[e].cpu().numpy() - o).max())
+        assert np.abs(q_mix[e].cpu().numpy() - np.asarray(d.qpos)).max() <= 1e-9
+        assert st.counter == nb
+    mix.close(); plain.close()
+    # (b) pooled == exact
+    P = 256
+    pooled = make_env("MixtureModelBaodingEnv", hip_lib, num_envs=P, seed=100, dtype="f64", base_model_path=None, base_env_path=None,
+                      n_steps_base_model=nb, base_policy=copy.deepcopy(base), base_normalizer=Ident(), pool_size=P)
+    exact = make_env("MixtureModelBaodingEnv", hip_lib, num_envs=P, seed=100 + 7919, dtype="f64", base_model_path=None, base_env_path=None,
+                     n_steps_base_model=nb, base_policy=copy.deepcopy(base), base_normalizer=Ident(), pool_size=0)
+    pooled._refill_pool()
+    exact.reset_tensor()
+    a, b = (torch.zeros((P, 37), dtype=torch.float64, device=dev) for _ in range(2))
+    av, bv = (torch.zeros((P, 35), dtype=torch.float64, device=dev) for _ in range(2))
+    pooled._pool.batch.get_state(a, av); exact.batch.get_state(b, bv)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(av, bv) and torch.equal(pooled._pool._obs, exact._obs)
+    pooled.close(); exact.close()
 
 
 def test_mixture_of_ensembles_on_gpu(hip_lib, golden_dir):

@@ -676,3 +676,42 @@ def test_per_rollout_normaliser_merge_equals_one_normaliser_over_all_envs():
     for k in (0, 1):
         assert np.abs(out[k][0] - one.mean.numpy()).max() < 1e-12 and np.abs(out[k][1] - one.var.numpy()).max() < 1e-11 and abs(out[k][2] - float(one.count)) < 1e-9
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def test_mixture_env_base_phase_loops_on_the_goal_counter(emu_lib):
+    """/root/reference/src/envs/baoding.py:704: `while self.counter < self.n_steps_base_model` — after a reset that took a step itself
+    (reset-state initialisation: enable_rsi, rsi_probability 1, baoding.py:610-638, counter = 1) the base policy acts for
+    n_steps_base_model - 1 steps.  Checked against the loop written out by hand on the plain phase-2 env; the
+    pooled form follows the same rule."""
+    base = ActorCriticPolicy(86, 39, (16,), (16,), lstm_hidden_size=8)
+    torch.manual_seed(2)
+
+    class Ident:
+        training = True
+        def normalize_obs(self, o): return o
+    kw = dict(num_envs=4, seed=13, dtype="f64", enable_rsi=True, rsi_probability=1.0)
+    nb = 5
+    mix = make_env("MixtureModelBaodingEnv", emu_lib, base_model_path=None, base_env_path=None, base_policy=base, base_normalizer=Ident(),
+                   n_steps_base_model=nb, **kw)
+    obs_mix = mix.reset_tensor().clone()
+    ref = make_env("CustomMyoBaodingBallsP2", emu_lib, **kw)
+    obs = ref.reset_tensor()
+
+    def counters(env):
+        ti = torch.zeros((env.num_envs, 2), dtype=torch.int32)
+        env.batch.get_task(ti, None, None)
+        return ti[:, 1].clone()
+    assert (counters(ref) == 1).all()                       # the reset's own step
+    state, starts = base.initial_state(4, ref.device), torch.ones(4)
+    dn, allm = torch.zeros(4, dtype=torch.uint8), torch.ones(4, dtype=torch.uint8)
+    with torch.no_grad():
+        for _ in range(nb - 1):                             # 4 steps, not 5
+            a, _, _, state = base.act(obs, state, starts, deterministic=True)
+            ref.batch.step_inner(allm, torch.clamp(a, -1, 1).float().contiguous(), obs, dn)
+            starts = dn.float()
+    assert torch.equal(obs_mix, obs) and (counters(mix) == nb).all() and (counters(ref) == nb).all()
+    pooled = make_env("MixtureModelBaodingEnv", emu_lib, base_model_path=None, base_env_path=None, base_policy=base, base_normalizer=Ident(),
+                      n_steps_base_model=nb, pool_size=4, **kw)
+    pooled.reset_tensor()
+    assert (counters(pooled) == nb).all() and (counters(pooled._pool) == nb).all()
+    mix.close(); ref.close(); pooled.close()

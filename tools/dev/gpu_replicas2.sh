@@ -1,0 +1,13 @@
+#!/bin/bash
+export MYO_DIST_BACKEND=gloo OMP_NUM_THREADS=2
+run() { python bench.py --gpus 4 --envs 1024 --steps 8 --warmup 0 --n-epochs 2 --min-seconds 0 --no-variants --no-cpu-baseline --dtype f64 "$@" 2>&1 | grep -v Warning | python -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('MYO_DP'): print(ln.strip())
+    if ln.startswith('{'):
+        d = json.loads(ln); print('identical', d.get('replicas_identical'), 'spread', d.get('replica_checksum_spread'))
+"; }
+echo "== check on"; MYO_DP_CHECK=1 run
+echo "== check off"; run
+echo "== check off, normalizer none"; run --normalizer-sync none
+echo "== check off, rollout"; run --normalizer-sync rollout

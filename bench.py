@@ -370,9 +370,14 @@ def main():
             # BASELINE config E (die reorient, LSTM-256 + MLP[256,256], the reference's RecurrentPPO policy class) on the same box
             try:
                 from myochallenge_amd.rl.bench_reorient_lstm import run as run_config_e
-                variants["config_E_lstm256"] = run_config_e(4096, 32, 2, env_only_steps=0)
+                # the reference's own settings (n_steps 128, n_epochs 10, fp64 physics: src/main_reorient.py:53-71) ...
+                variants["config_E_lstm256"] = run_config_e(4096, 128, 2, env_only_steps=0, reference_settings=True)
             except Exception as exc:      # noqa: BLE001
                 variants["config_E_lstm256"] = {"error": repr(exc)}
+            try:                          # ... and the light setting the earlier rounds quoted (mixed stepper, 32-step rollouts, 4 epochs)
+                variants["config_E_lstm256_light"] = run_config_e(4096, 32, 2, env_only_steps=0)
+            except Exception as exc:      # noqa: BLE001
+                variants["config_E_lstm256_light"] = {"error": repr(exc)}
 
     pol_name = (f"LSTM-{args.lstm_hidden} + " if args.lstm_hidden else "") + f"MLP[{args.net_arch}]"
     if rank == 0:

@@ -45,8 +45,8 @@ def main(argv=None):
     ap.add_argument("--n-steps", type=int, default=64)
     ap.add_argument("--batch-size", type=int, default=16384)
     ap.add_argument("--learning-rate", type=float, default=5e-05)
-    ap.add_argument("--eval-freq", type=int, default=2_000_000)
-    ap.add_argument("--save-freq", type=int, default=10_000_000)
+    ap.add_argument("--eval-freq", type=int, default=2_000_000, help="env TIMESTEPS between evaluations; SB3\'s EvalCallback counts vec-env steps (the reference: 10_000 steps of its 16 workers), so the callback gets this // num_envs")
+    ap.add_argument("--save-freq", type=int, default=10_000_000, help="env TIMESTEPS between checkpoints (SB3 counts vec-env steps: the callback gets this // num_envs)")
     a = ap.parse_args(argv)
     from .metrics import CheckpointCallback, EnvDumpCallback, EvalCallback
     from .rl.vec_normalize import VecNormalize
@@ -59,8 +59,8 @@ def main(argv=None):
     eval_env = make_parallel_envs(cfg, min(256, a.num_envs), start_index=12345, env_name=a.env_name)
     eval_env = VecNormalize.load(a.load_env, eval_env) if a.load_env else VecNormalize(eval_env)
     eval_callback = EvalCallback(eval_env=eval_env, callback_on_new_best=EnvDumpCallback(log_dir, verbose=0), n_eval_episodes=256,
-                                 best_model_save_path=log_dir, log_path=log_dir, eval_freq=a.eval_freq, deterministic=True, verbose=1)
-    checkpoint_callback = CheckpointCallback(save_freq=a.save_freq, save_path=log_dir, save_vecnormalize=True, verbose=1)
+                                 best_model_save_path=log_dir, log_path=log_dir, eval_freq=max(1, a.eval_freq // a.num_envs), deterministic=True, verbose=1)
+    checkpoint_callback = CheckpointCallback(save_freq=max(1, a.save_freq // a.num_envs), save_path=log_dir, save_vecnormalize=True, verbose=1)
     trainer = MyoTrainer(envs=envs, env_config=cfg, load_model_path=a.load_model, log_dir=log_dir,
                          model_config={"policy": a.policy, "learning_rate": lambda _: a.learning_rate, "clip_range": lambda _: 0.2,
                                        "n_steps": a.n_steps, "batch_size": a.batch_size,

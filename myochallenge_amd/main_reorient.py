@@ -47,8 +47,8 @@ def main(argv=None):
     ap.add_argument("--log-dir", default=None)
     ap.add_argument("--load-model", default=None)
     ap.add_argument("--load-env", default=None)
-    ap.add_argument("--eval-freq", type=int, default=1_000_000)
-    ap.add_argument("--save-freq", type=int, default=2_500_000)
+    ap.add_argument("--eval-freq", type=int, default=1_000_000, help="env TIMESTEPS between evaluations; SB3\'s EvalCallback counts vec-env steps (the reference: 10_000 steps of its 16 workers), so the callback gets this // num_envs")
+    ap.add_argument("--save-freq", type=int, default=2_500_000, help="env TIMESTEPS between checkpoints (SB3 counts vec-env steps: the callback gets this // num_envs)")
     a = ap.parse_args(argv)
     from .metrics import CheckpointCallback, EnvDumpCallback, EvalCallback, TensorboardCallback
     from .rl.vec_normalize import VecNormalize
@@ -61,8 +61,8 @@ def main(argv=None):
     mc = dict(model_config)
     mc["batch_size"] = max(32, a.num_envs * mc["n_steps"] // 64)          # 32 of 16 x 128 in the reference
     eval_callback = EvalCallback(eval_env=eval_env, callback_on_new_best=EnvDumpCallback(log_dir, verbose=0), n_eval_episodes=64,
-                                 best_model_save_path=log_dir, log_path=log_dir, eval_freq=a.eval_freq, deterministic=True, verbose=1)
-    checkpoint_callback = CheckpointCallback(save_freq=a.save_freq, save_path=log_dir, save_vecnormalize=True, verbose=1)
+                                 best_model_save_path=log_dir, log_path=log_dir, eval_freq=max(1, a.eval_freq // a.num_envs), deterministic=True, verbose=1)
+    checkpoint_callback = CheckpointCallback(save_freq=max(1, a.save_freq // a.num_envs), save_path=log_dir, save_vecnormalize=True, verbose=1)
     tensorboard_callback = TensorboardCallback(info_keywords=("pos_dist", "rot_dist", "pos_dist_diff", "rot_dist_diff", "act_reg",
                                                               "alive", "solved"))
     trainer = MyoTrainer(envs=envs, env_config=config, load_model_path=a.load_model, log_dir=log_dir, model_config=mc,

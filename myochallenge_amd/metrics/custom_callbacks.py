@@ -1,7 +1,16 @@
 """Callbacks with the reference's names (src/metrics/custom_callbacks.py, SB3 EvalCallback), batched.
 
-They are plain callables ``cb(algo)`` for ``PPO.learn(callback=...)`` (called once per rollout; the
-``eval_freq`` / ``save_freq`` counters are in env timesteps like SB3's).
+They are plain callables ``cb(algo)`` for ``PPO.learn(callback=...)``, called at the end of every rollout and BEFORE the update, i.e.
+with the policy every ``_on_step`` of that rollout would have seen.  What a frequency counts follows the class it stands for:
+
+* SB3's ``EvalCallback`` / ``CheckpointCallback`` (/root/reference/src/main_baoding.py:81-98) test ``n_calls % freq == 0`` — ``n_calls``
+  = steps of the VECTORISED env, one per ``env.step`` whatever its width (``algo.n_calls``); ``eval_freq=10_000`` is every 10,000
+  vec-env steps = 160,000 timesteps on the reference's 16 workers, 41 M timesteps on 4096 envs.  A rollout that crosses one or more
+  multiples fires once (the policy is the same at every step of a rollout); checkpoints are named by the timestep count of the
+  LAST multiple crossed, as SB3 would have named the last of them.
+* the reference's own ``EvaluateLSTM`` (src/metrics/custom_callbacks.py:19-47) tests ``num_timesteps % eval_freq == 0`` — env
+  TIMESTEPS, which advance by the number of envs per vec-env step: it fires when a multiple of ``eval_freq`` is among the values
+  ``num_timesteps`` took during the rollout.
 """
 from __future__ import annotations
 
@@ -13,6 +22,18 @@ import numpy as np
 from .evaluation import evaluate_policy
 
 
+def _calls_crossed(algo, last_calls: int, freq: int):
+    """multiples of `freq` among the vec-env step counts (last_calls, algo.n_calls]; returns (any, last multiple)"""
+    freq = max(1, int(freq))
+    now = algo.n_calls
+    last_multiple = (now // freq) * freq
+    return last_multiple > last_calls, last_multiple
+
+
+def _envs_total(algo) -> int:
+    return max(1, algo.env.num_envs * getattr(algo, "world", 1))
+
+
 class EvaluateLSTM:
     """src/metrics/custom_callbacks.py:7-48: every ``eval_freq`` timesteps play ``num_episodes``
     deterministic episodes with the *training* model and the *training* env's normaliser; record the
@@ -20,13 +41,17 @@ class EvaluateLSTM:
 
     def __init__(self, eval_freq, eval_env, name, num_episodes=20, log: Optional[Callable[[dict], None]] = None):
         self.eval_freq, self.eval_env, self.name, self.num_episodes, self.log = eval_freq, eval_env, name, num_episodes, log
-        self._next = eval_freq
+        self._last_ts = 0
         self.history = []
 
     def __call__(self, algo) -> bool:
-        if algo.num_timesteps < self._next:
+        # num_timesteps took the values last + N, last + 2 N, ... now (N envs per vec-env step): is a multiple of eval_freq among them?
+        n, now, last = _envs_total(algo), algo.num_timesteps, self._last_ts
+        self._last_ts = now
+        import math
+        lcm = self.eval_freq * n // math.gcd(int(self.eval_freq), n)
+        if (now // lcm) * lcm <= last:
             return True
-        self._next += self.eval_freq
         normalizer = algo.env if hasattr(algo.env, "normalize_obs") else None
         res = evaluate_policy(algo.policy, self.eval_env, normalizer, self.num_episodes, deterministic=True)
         mean = float(np.mean(res["returns"]))
@@ -62,14 +87,15 @@ class EvalCallback:
                  eval_freq=10_000, deterministic=True, render=False, verbose=1):
         self.eval_env, self.on_best, self.n, self.best_path = eval_env, callback_on_new_best, n_eval_episodes, best_model_save_path
         self.log_path, self.eval_freq, self.deterministic, self.verbose = log_path, eval_freq, deterministic, verbose
-        self._next = eval_freq
+        self._last_calls = 0
         self.best_mean_reward = -np.inf
         self.evaluations_timesteps, self.evaluations_results, self.evaluations_length = [], [], []
 
     def __call__(self, algo) -> bool:
-        if algo.num_timesteps < self._next:
+        fire, _ = _calls_crossed(algo, self._last_calls, self.eval_freq)
+        self._last_calls = algo.n_calls
+        if not fire:
             return True
-        self._next += self.eval_freq
         env = self.eval_env
         normalizer = env if hasattr(env, "normalize_obs") else (algo.env if hasattr(algo.env, "normalize_obs") else None)
         if hasattr(env, "obs_rms") and hasattr(algo.env, "obs_rms") and env is not algo.env:     # sync_envs_normalization
@@ -106,17 +132,19 @@ class CheckpointCallback:
     def __init__(self, save_freq, save_path, name_prefix="rl_model", save_vecnormalize=False, verbose=0):
         self.save_freq, self.save_path, self.name_prefix = save_freq, save_path, name_prefix
         self.save_vecnormalize, self.verbose = bool(save_vecnormalize) and save_vecnormalize != "False", verbose
-        self._next = save_freq
+        self._last_calls = 0
 
     def __call__(self, algo) -> bool:
-        if algo.num_timesteps < self._next:
+        fire, last_multiple = _calls_crossed(algo, self._last_calls, self.save_freq)
+        self._last_calls = algo.n_calls
+        if not fire:
             return True
-        self._next += self.save_freq * max(1, (algo.num_timesteps - self._next) // self.save_freq + 1)
+        steps = last_multiple * _envs_total(algo)           # num_timesteps at the (last) vec-env step SB3 would have saved on
         os.makedirs(self.save_path, exist_ok=True)
-        path = os.path.join(self.save_path, f"{self.name_prefix}_{algo.num_timesteps}_steps.zip")
+        path = os.path.join(self.save_path, f"{self.name_prefix}_{steps}_steps.zip")
         algo.save(path)
         if self.save_vecnormalize and hasattr(algo.env, "save"):
-            algo.env.save(os.path.join(self.save_path, f"{self.name_prefix}_vecnormalize_{algo.num_timesteps}_steps.pkl"))
+            algo.env.save(os.path.join(self.save_path, f"{self.name_prefix}_vecnormalize_{steps}_steps.pkl"))
         if self.verbose:
             print(f"Saving model checkpoint to {path}")
         return True

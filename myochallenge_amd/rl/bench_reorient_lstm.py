@@ -5,16 +5,27 @@ actor + critic -> [256, 256] ReLU, log_std_init -2) rolls out and trains on the 
 import time
 
 
-def run(envs: int = 4096, n_steps: int = 32, iters: int = 3, env_only_steps: int = 50) -> dict:
+def run(envs: int = 4096, n_steps: int = 32, iters: int = 3, env_only_steps: int = 50, dtype: str = "mixed", n_epochs: int = 4,
+        reference_settings: bool = False) -> dict:
+    """reference_settings: the PPO settings of /root/reference/src/main_reorient.py:53-71 — n_steps 128, n_epochs 10, learning rate
+    2.55673e-5, entropy 3.62109e-6, clip 0.3, lambda 0.9, max_grad_norm 0.7, vf_coef 0.835671, 300-step episodes — on the fp64 stepper
+    (the reference's arithmetic).  Its batch_size = 32 belongs to its 16 envs (a rollout of 2,048 samples = 64 minibatches); at 4096 envs
+    the minibatch stays an eighth of the rollout's sequences, as in the light setting."""
     import torch
     from ..envs.environment_factory import EnvironmentFactory
     from .policy import ActorCriticPolicy
     from .ppo import PPO, PPOConfig
     from .vec_normalize import VecNormalize
-    env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=envs, seed=1)
+    if reference_settings:
+        n_steps, n_epochs, dtype = 128, 10, "f64"
+    env = EnvironmentFactory.create("CustomMyoReorientP1", num_envs=envs, seed=1, dtype=dtype, **({"max_episode_steps": 300} if reference_settings else {}))
     torch.manual_seed(0)
     pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=256, log_std_init=-2.0)
-    algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=n_steps, batch_size=envs * n_steps // 8, n_epochs=4, learning_rate=2.5e-5))
+    cfg = PPOConfig(n_steps=n_steps, batch_size=envs * n_steps // 8, n_epochs=n_epochs, learning_rate=2.5e-5)
+    if reference_settings:
+        cfg = PPOConfig(n_steps=128, batch_size=envs * 128 // 8, n_epochs=10, learning_rate=2.55673e-05, ent_coef=3.62109e-06, clip_range=0.3,
+                        gamma=0.99, gae_lambda=0.9, max_grad_norm=0.7, vf_coef=0.835671)
+    algo = PPO(VecNormalize(env), pol, cfg)
     algo.collect_rollouts(); algo.train()                       # warm-up (captures the graphs)
     torch.cuda.synchronize()
     t0 = time.time(); tr = 0.0
@@ -26,7 +37,8 @@ def run(envs: int = 4096, n_steps: int = 32, iters: int = 3, env_only_steps: int
     steps = iters * envs * n_steps
     out = {"config": "E: CustomMyoReorientP1, %d envs, LSTM-256 + MLP[256,256]" % envs,
            "env_steps_per_sec_rollout_plus_update": steps / dt, "env_steps_per_sec_rollout_only": steps / tr,
-           "n_steps": n_steps, "epochs": 4, "dtype": "mixed", "recurrent_path": "fused" if algo._fused_rec is not None else "autograd"}
+           "n_steps": n_steps, "epochs": n_epochs, "dtype": dtype, "settings": "reference (src/main_reorient.py:53-71)" if reference_settings else "light",
+           "env_kernel_lds_bytes": env.batch.lds_bytes, "health": env.batch.health(), "recurrent_path": "fused" if algo._fused_rec is not None else "autograd"}
     if env_only_steps:                                          # physics alone (zero actions)
         act = torch.zeros((envs, env.act_dim), device=env.device)
         t2 = time.time()

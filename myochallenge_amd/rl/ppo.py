@@ -436,11 +436,54 @@ class PPO:
                 self._rollout_state0 = self._native_state() if getattr(self, "_native", False) else tuple(s.clone() for s in self._state_s)
             self._t_host = (self._t_host + 1) % self.cfg.n_steps
         self._gA.replay()
-        self._raw.step_tensor(self._clip_s)
+        raw = self._raw.step_tensor(self._clip_s)
+        self._log_episodes(raw[2], raw[6])
         self._gB.replay()
         if getattr(self, "_gB2", None) is not None:      # rank-synchronised normaliser (see _init_native_rollout)
             dist.all_reduce(self._vn_batch)
             self._gB2.replay()
+
+    def _log_episodes(self, done, ep) -> None:
+        """Monitor statistics (SB3's ep_info_buffer): the (raw return, length) the kernel reports for every env that finished an
+        episode in this step go into row t of a [T, N, 2] log, NaN elsewhere — one small launch per step; episode_stats() reads it."""
+        T, N = self.cfg.n_steps, self.env.num_envs
+        if getattr(self, "_ep_log", None) is None or self._ep_log.shape[:2] != (T, N):
+            self._ep_log = torch.full((T, N, 2), float("nan"), device=self.device)
+            self._ep_t = 0
+            from collections import deque
+            self.ep_info_buffer = deque(maxlen=100)
+        if ep is None:
+            return
+        torch.where(done.view(torch.bool).unsqueeze(1), ep, self._ep_nan, out=self._ep_log[self._ep_t % T])
+        self._ep_t += 1
+
+    @property
+    def _ep_nan(self):
+        if getattr(self, "_ep_nan_t", None) is None:
+            self._ep_nan_t = torch.full((1, 1), float("nan"), device=self.device)
+        return self._ep_nan_t
+
+    def episode_stats(self) -> Dict[str, float]:
+        """rollout/ep_rew_mean and rollout/ep_len_mean as SB3 logs them: means over the last 100 finished episodes (Monitor's raw,
+        un-normalised returns; /root/reference/src/main_baoding.py runs under SB3's logger).  Reads the rollout's episode log once
+        (one host synchronisation per call)."""
+        log = getattr(self, "_ep_log", None)
+        if log is not None and self._ep_t > 0:
+            T = log.shape[0]
+            rows = min(self._ep_t, T)
+            order = [(self._ep_t - rows + k) % T for k in range(rows)]               # oldest step first
+            x = log[order].reshape(-1, 2)
+            fin = x[~torch.isnan(x[:, 0])]
+            if fin.shape[0] > 100:
+                fin = fin[-100:]
+            for r, l in fin.cpu().tolist():
+                self.ep_info_buffer.append((r, l))
+            log.fill_(float("nan"))
+            self._ep_t = 0
+        buf = getattr(self, "ep_info_buffer", None)
+        if not buf:
+            return {}
+        return {"rollout/ep_rew_mean": float(sum(r for r, _ in buf) / len(buf)), "rollout/ep_len_mean": float(sum(l for _, l in buf) / len(buf))}
 
     def finish_rollout(self) -> None:
         if hasattr(self.env, "end_rollout"):
@@ -510,6 +553,7 @@ class PPO:
                 actions, values, logp, new_state = pol.act(obs, self._state, starts)
             clipped = torch.clamp(actions, -1.0, 1.0)
             nobs, rew, done, trunc, term, comps, ep = env.step_tensor(clipped)
+            self._log_episodes(done, ep)
             rew = rew.clone()
             if bool(trunc.any()):   # timeout bootstrap: terminal observation, critic state after this step, no episode start
                 with self._autocast():
@@ -905,14 +949,23 @@ class PPO:
             self._fused.refresh_shadow()
 
     def learn(self, total_timesteps: int, callback: Optional[Callable[["PPO"], None]] = None, log=None):
+        """SB3's loop: collect a rollout (callbacks see every env step of it: `callback(self)` runs at the END of the rollout, BEFORE the
+        update, with `self.n_calls` = vec-env steps so far — the policy a mid-rollout `_on_step` would have seen), train, log.
+        Logged: time/fps, time/total_timesteps, rollout/ep_rew_mean and rollout/ep_len_mean (last 100 finished episodes, raw returns:
+        SB3's Monitor / ep_info_buffer semantics), train/*."""
         t_start = time.time()
         while self.num_timesteps < total_timesteps:
             self.collect_rollouts()
-            stats = self.train()
             if callback is not None:
                 callback(self)
+            stats = self.train()
             if log is not None and self.rank == 0:
                 fps = self.num_timesteps / max(1e-9, time.time() - t_start)
-                log({"time/fps": fps, "time/total_timesteps": self.num_timesteps,
-                     "rollout/ep_rew_mean": float(self.rew_buf.sum(0).mean()), **{"train/" + k: v for k, v in stats.items()}})
+                log({"time/fps": fps, "time/total_timesteps": self.num_timesteps, **self.episode_stats(),
+                     **{"train/" + k: v for k, v in stats.items()}})
         return self
+
+    @property
+    def n_calls(self) -> int:
+        """vec-env steps taken so far (SB3's BaseCallback.n_calls: one per env.step of the vectorised env, whatever its width)"""
+        return self.num_timesteps // max(1, self.env.num_envs * self.world)

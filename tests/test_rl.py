@@ -318,7 +318,7 @@ def test_batched_evaluation_and_callbacks(emu_lib, tmp_path, hidden):
     eval_env = VecNormalize(mk())
     logs = []
     cb = EvalCallback(eval_env, callback_on_new_best=EnvDumpCallback(str(tmp_path / "best")), n_eval_episodes=3,
-                      best_model_save_path=str(tmp_path), log_path=str(tmp_path), eval_freq=12, verbose=0)
+                      best_model_save_path=str(tmp_path), log_path=str(tmp_path), eval_freq=4, verbose=0)       # SB3: every 4 vec-env steps (= 12 timesteps on 3 envs)
     lstm_cb = EvaluateLSTM(eval_freq=12, eval_env=mk(), name="eval/lstm", num_episodes=2, log=logs.append)
     algo.learn(24, callback=lambda a: (cb(a), lstm_cb(a)))
     ev = np.load(str(tmp_path / "evaluations.npz"))
@@ -531,7 +531,7 @@ def test_myotrainer_matches_reference_surface(emu_lib, golden_dir, tmp_path):
     env = make_env("CustomMyoBaodingBallsP2", emu_lib, num_envs=2, seed=3, dtype="f64", max_episode_steps=5, **env_config)
     venv = VecNormalize(env)
     log = str(tmp_path / "run")
-    ck = CheckpointCallback(save_freq=8, save_path=log, save_vecnormalize="True")
+    ck = CheckpointCallback(save_freq=4, save_path=log, save_vecnormalize="True")      # SB3: every 4 vec-env steps (= 8 timesteps on 2 envs)
     tr = MyoTrainer(envs=venv, env_config=env_config, load_model_path=None, log_dir=log,
                     model_config={"learning_rate": lambda _: 5e-05, "lr_schedule": lambda _: 5e-05, "clip_range": lambda _: 0.2,
                                   "n_steps": 4, "batch_size": 8, "n_epochs": 1,
@@ -715,3 +715,43 @@ def test_mixture_env_base_phase_loops_on_the_goal_counter(emu_lib):
     pooled.reset_tensor()
     assert (counters(pooled) == nb).all() and (counters(pooled._pool) == nb).all()
     mix.close(); ref.close(); pooled.close()
+
+
+def test_logger_reports_monitor_statistics_of_the_last_100_episodes(emu_lib):
+    """rollout/ep_rew_mean and rollout/ep_len_mean are SB3's — means over the last 100 FINISHED episodes of the raw
+    (un-normalised) Monitor returns and lengths the env reports — not a sum of normalised rewards over the rollout.  A recording wrapper
+    around the env's step collects every (done, return, length) the kernel reports; PPO.learn's log lines must repeat their running
+    last-100 means; callbacks run before the update and see SB3's n_calls."""
+    env = make_env("CustomMyoBaodingBallsP1", emu_lib, num_envs=5, seed=2, dtype="f64", max_episode_steps=3)
+    seen = []
+    inner = env.step_tensor
+
+    def recording_step(a):
+        out = inner(a)
+        d, ep = out[2].clone(), out[6].clone()
+        for e in range(5):
+            if int(d[e]):
+                seen.append((float(ep[e, 0]), float(ep[e, 1])))
+        return out
+    env.step_tensor = recording_step
+    venv = VecNormalize(env)
+    torch.manual_seed(0)
+    pol = ActorCriticPolicy(86, 39, (8,), (8,), lstm_hidden_size=None)
+    algo = PPO(venv, pol, PPOConfig(n_steps=7, batch_size=35, n_epochs=1, bf16=False))
+    logs, calls = [], []
+    params_at_callback = []
+
+    def cb(a):
+        calls.append((a.n_calls, a.num_timesteps))
+        params_at_callback.append(torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone())
+    p0 = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).clone()
+    algo.learn(5 * 7 * 4, callback=cb, log=logs.append)
+    assert calls == [(7, 35), (14, 70), (21, 105), (28, 140)]                       # one vec-env step = five timesteps
+    assert torch.equal(params_at_callback[0], p0)                                   # the callback runs BEFORE the rollout's update
+    assert len(logs) == 4 and len(seen) >= 4 * 2 * 5 - 5
+    for rec in logs:
+        assert "rollout/ep_rew_mean" in rec and "rollout/ep_len_mean" in rec and 1.0 <= rec["rollout/ep_len_mean"] <= 3.0
+    last = seen[-100:]
+    assert abs(logs[-1]["rollout/ep_rew_mean"] - np.mean([r for r, _ in last])) < 1e-5 * max(1.0, abs(np.mean([r for r, _ in last])))
+    assert abs(logs[-1]["rollout/ep_len_mean"] - np.mean([l for _, l in last])) < 1e-6
+    env.close()

@@ -1475,6 +1475,63 @@ static LsEval ls_eval(const OrcData* d, double alpha, const double* jar, const d
   return e;
 }
 
+/* ---- the line search of mj_solNewton as MuJoCo 2.1 structures it (engine_solver.c: PrimalSearch) [3P-RECALL], behind a switch
+   (orc_set_line_search(1) / MYO_ORACLE_LS=primal): the default search above is a safeguarded Newton iteration on p'(alpha) that stops
+   inside the same gradient tolerance, so the two return step lengths that differ by O(gtol / p'') — VERDICT r04 item 10 asks how far
+   that moves qacc (tools/oracle_linesearch.py, tests/test_oracle_closed_forms.py).  Structure restated here:
+     p0 = eval(0); p1 = eval(Newton step from p0); keep the cheaper of the two as p1; converged if |p1'| < gtol
+     dir = sign of the descent from p1; one-sided Newton steps from p1 while the derivative keeps its sign (p2 = the previous point):
+       converged at any of them -> return it
+     the derivative changed sign: bracket [p2, p1]; then per iteration THREE candidates — the Newton points of both bracket ends and
+       the midpoint — a converged candidate (|p'| < gtol) of lowest cost is returned, otherwise each end moves to the candidate that
+       tightens it most; no end moved, or the iteration budget is spent -> the end of lower cost. */
+static int g_ls_mode = -1;
+void orc_set_line_search(int primal) { g_ls_mode = primal ? 1 : 0; }
+static int ls_mode(void) {
+  if (g_ls_mode < 0) { const char* e = getenv("MYO_ORACLE_LS"); g_ls_mode = (e && e[0] == 'p') ? 1 : 0; }
+  return g_ls_mode;
+}
+typedef struct { double alpha; LsEval e; } LsPoint;
+static LsPoint ls_point(const OrcData* d, double alpha, const double* jar, const double* jv, const double* qg, int* evals) {
+  LsPoint p; p.alpha = alpha; p.e = ls_eval(d, alpha, jar, jv, qg); (*evals)++; return p;
+}
+static double primal_search(const OrcData* d, const double* jar, const double* jv, const double* qg, double gtol) {
+  int it = 0;
+  LsPoint p0 = ls_point(d, 0, jar, jv, qg, &it);
+  LsPoint p1 = ls_point(d, p0.alpha - p0.e.d1/p0.e.d2, jar, jv, qg, &it);
+  if (p0.e.cost < p1.e.cost) p1 = p0;
+  if (fabs(p1.e.d1) < gtol) return p1.alpha;
+  const double dir = p1.e.d1 < 0 ? 1 : -1;
+  LsPoint p2 = p1; int p2update = 0;
+  while (p1.e.d1*dir <= -gtol && it < LS_ITER) {
+    p2 = p1; p2update = 1;
+    p1 = ls_point(d, p1.alpha - p1.e.d1/p1.e.d2, jar, jv, qg, &it);
+    if (fabs(p1.e.d1) < gtol) return p1.alpha;
+  }
+  if (it >= LS_ITER || !p2update) return p1.alpha;
+  /* bracket: p2 on the descending side (p2' dir < 0), p1 beyond the minimum */
+  LsPoint p1next = ls_point(d, p1.alpha - p1.e.d1/p1.e.d2, jar, jv, qg, &it);
+  LsPoint p2next = p1;        /* (p1 is the Newton point of p2) */
+  while (it < LS_ITER) {
+    LsPoint pmid = ls_point(d, 0.5*(p1.alpha + p2.alpha), jar, jv, qg, &it);
+    LsPoint cand[3]; cand[0] = p1next; cand[1] = p2next; cand[2] = pmid;
+    int best = -1;
+    for (int k = 0; k < 3; ++k) if (fabs(cand[k].e.d1) < gtol && (best < 0 || cand[k].e.cost < cand[best].e.cost)) best = k;
+    if (best >= 0) return cand[best].alpha;
+    int b1 = 0, b2 = 0;
+    for (int k = 0; k < 3; ++k) {
+      const double lo = p1.alpha < p2.alpha ? p1.alpha : p2.alpha, hi = p1.alpha < p2.alpha ? p2.alpha : p1.alpha;
+      if (!(cand[k].alpha > lo && cand[k].alpha < hi)) continue;                 /* only points inside the bracket tighten it */
+      if (cand[k].e.d1*dir > 0) { p1 = cand[k]; b1 = 1; }                        /* beyond the minimum: the far end */
+      else { p2 = cand[k]; b2 = 2; }                                             /* still descending: the near end */
+    }
+    if (!b1 && !b2) break;
+    if (b1) p1next = ls_point(d, p1.alpha - p1.e.d1/p1.e.d2, jar, jv, qg, &it);
+    if (b2) p2next = ls_point(d, p2.alpha - p2.e.d1/p2.e.d2, jar, jv, qg, &it);
+  }
+  return p1.e.cost < p2.e.cost ? p1.alpha : p2.alpha;
+}
+
 static double constraint_update(OrcData* d, int nv, const double* jar, const double* qacc, const double* Ma,
                                 double* grad, int* nactive_changed, unsigned char* active) {
   double cost = 0; int changed = 0;
@@ -1565,6 +1622,8 @@ static void newton_solve(const OrcModel* m, OrcData* d) {
     double gtol = m->tolerance*LS_TOL*snorm/scale;
     double alpha = 0, lo = 0, hi = -1;
     LsEval e = ls_eval(d, 0, jar, jv, qg);
+    if (ls_mode()) alpha = primal_search(d, jar, jv, qg, gtol);
+    else
     for (int li = 0; li < LS_ITER; ++li) {
       if (fabs(e.d1) < gtol) break;
       if (e.d1 < 0) lo = alpha; else hi = alpha;

@@ -100,6 +100,11 @@ void orc_reorient_step(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg,
                        double* obs, double* comps);
 void orc_reorient_reset_dists(const OrcModel* m, OrcData* d, const OrcReorientCfg* cfg, OrcReorientState* st, double* obs);
 
+/* Newton line search: 0 = safeguarded Newton on p'(alpha) (default), 1 = the bracketing structure of MuJoCo 2.1's PrimalSearch
+   [3P-RECALL] (myo_oracle.c: primal_search).  Both stop inside the same gradient tolerance; tools/oracle_linesearch.py measures how far
+   apart their results are.  Environment: MYO_ORACLE_LS=primal. */
+void orc_set_line_search(int primal);
+
 #ifdef __cplusplus
 }
 #endif

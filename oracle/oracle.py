@@ -56,11 +56,18 @@ def lib():
         L.orc_reorient_reward.argtypes = [C.c_void_p, C.c_int, dp, dp, dp, C.c_double, C.c_double, dp]
         L.orc_reorient_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float), dp, dp]
         L.orc_reorient_reset_dists.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dp]
+        L.orc_set_line_search.argtypes = [C.c_int]
         L.orc_flops.argtypes = [C.POINTER(C.c_double), C.c_int]
         L.orc_flops_stages.restype = C.c_int
         L.orc_flops_enabled.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+def set_line_search(primal: bool) -> None:
+    """Newton line search of the oracle: False = safeguarded Newton on p'(alpha) (default); True = the bracketing structure of MuJoCo
+    2.1's PrimalSearch (myo_oracle.c:primal_search).  Process-wide."""
+    lib().orc_set_line_search(1 if primal else 0)
 
 
 FLOP_STAGES = ("kinematics", "com", "tendon", "crb", "collision", "constraint", "velocity", "actuation", "acceleration",

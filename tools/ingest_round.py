@@ -41,7 +41,8 @@ def main():
                  ("drift.log", TAG + "_drift_32streams.log"), ("pmc_mfma_kstep_f64.txt", TAG + "_pmc_mfma_kstep_f64.txt"),
                  ("stage_shares_rk4.txt", TAG + "_stage_shares_rk4.txt"), ("wg_timeline_parts.log", TAG + "_wg_timeline_parts.log"),
                  ("wg_timeline_whole.log", TAG + "_wg_timeline_whole_steps.log"), ("gpu_tests.log", TAG + "_gpu_tests.log"),
-                 ("pmc_kstep_whole_steps.txt", TAG + "_pmc_kstep_whole_steps.txt")):
+                 ("pmc_kstep_whole_steps.txt", TAG + "_pmc_kstep_whole_steps.txt"), ("train_demo_p1_100m_f64.json", TAG + "_train_demo_p1_100m_f64.json"),
+                 ("train_demo_reorient_lstm256_40m.json", TAG + "_train_demo_reorient_lstm256_40m.json")):
         if os.path.exists(os.path.join(R, a)):
             shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}
@@ -50,10 +51,11 @@ def main():
             continue
         d = json.loads(open(os.path.join(R, f"bench_{k}.json")).read().strip().splitlines()[-1])
         out["bench_" + k] = {x: d[x] for x in ("value", "ms_per_step", "env_kernel_ms", "ppo_optimizer_steps_per_sec", "dtype", "config") if x in d}
-    try:
-        out["config_E_reorient_lstm256"] = json.loads(open(os.path.join(R, "bench_reorient_lstm.json")).read().strip().splitlines()[-1])
-    except Exception as e:          # noqa: BLE001
-        print("no reorient LSTM record:", e)
+    for key, fn in (("config_E_reorient_lstm256_light", "bench_reorient_lstm.json"), ("config_E_reorient_lstm256_reference_settings", "bench_reorient_lstm_reference.json")):
+        try:
+            out[key] = json.loads(open(os.path.join(R, fn)).read().strip().splitlines()[-1])
+        except Exception as e:          # noqa: BLE001
+            print("no record", fn, e)
     json.dump(out, open(os.path.join(P, TAG + "_other_configs.json"), "w"), indent=1)
     print({k: (round(v["value"]), round(v["env_kernel_ms"], 2), round(v.get("ppo_optimizer_steps_per_sec", 0))) for k, v in out.items() if "value" in v})
     d = json.loads(open(os.path.join(R, "bench_line.json")).read().strip().splitlines()[-1])

@@ -54,9 +54,13 @@ python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoBaodi
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoReorientP2 > $OUT/bench_reorient_p2.json 2>/dev/null
 python3 $ROOT/tools/bench_reorient.py > $OUT/bench_reorient_lstm.json 2>/dev/null
+python3 $ROOT/tools/bench_reorient.py --reference-settings --iters 2 > $OUT/bench_reorient_lstm_reference.json 2>/dev/null   # n_steps 128, n_epochs 10, fp64 (src/main_reorient.py:53-71)
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --dtype mixed --lstm-hidden 128 --net-arch "" --n-steps 32 > $OUT/bench_lstm128.json 2>/dev/null   # the reference's phase-1 policy shape
 # 6. trajectory drift tables of both steppers (32 action streams x 200 env steps) and k_step time against the batch size
 python3 $ROOT/tools/dev/gpu_drift.py > $OUT/drift.log 2>&1
+# 6b. training demos (deterministic evaluation before / during PPO training; prints the batch health counters at the end)
+python3 $ROOT/tools/train_demo.py --steps 100000000 --dtype f64 --out $OUT/train_demo_p1_100m_f64.json > $OUT/train_demo_p1.log 2>&1
+python3 $ROOT/tools/train_demo.py --env-name CustomMyoReorientP1 --steps 40000000 --lstm-hidden 256 --out $OUT/train_demo_reorient_lstm256_40m.json > $OUT/train_demo_reorient.log 2>&1
 # 7. the GPU test suite on the same library
 cd $ROOT && python3 -m pytest tests -m gpu -q > $OUT/gpu_tests.log 2>&1
 echo done

@@ -160,7 +160,7 @@ def test_the_two_newton_line_searches_of_the_oracle_agree():
     """VERDICT r04 item 10.  The oracle's default line search (safeguarded Newton on p'(alpha)) and the bracketing structure of MuJoCo 2.1's
     PrimalSearch restated behind a switch (myo_oracle.c: primal_search; p0 / p1 initialisation, one-sided steps to a sign change, three
     candidates per iteration) stop inside the same gradient tolerance: over env steps of the bench workload taken from the same state
-    they must leave qpos within 1e-10 of each other (measured: 1e-13 over whole episodes, profiles/r05_oracle_linesearch.json) — so a
+    they must leave qpos within 1e-10 of each other (measured: 2e-16 per env step, 4e-12 over whole episodes of 200 steps, profiles/r05_oracle_linesearch.json) — so a
     future comparison with true MuJoCo trajectories will not trip over the line search first.  Stepping parity stays UNPINNED."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

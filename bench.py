@@ -314,7 +314,9 @@ def main():
             t0 = time.perf_counter()
             for _ in range(steps):
                 one_step()
-            own = time.perf_counter() - t0           # this rank's own time to the end of its work (before the closing barrier)
+            if world > 1:
+                torch.cuda.synchronize(dev)          # this rank's own GPU work is done ...
+            own = time.perf_counter() - t0           # ... this long after the block started (before the closing barrier: the per-rank skew)
             fence()
             el = time.perf_counter() - t0
             if world > 1:

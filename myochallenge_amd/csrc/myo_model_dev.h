@@ -27,6 +27,7 @@
 #define MYO_ARROW_S 16    // separator rows of the block-arrow Newton system (one MFMA tile)
 #define MYO_ARROW_B 4     // rows per leaf block (= the K of v_mfma_*_16x16x4)
 #define MYO_ARROW_NF ((MYO_NV_MAX - MYO_ARROW_S) / MYO_ARROW_B)
+#define MYO_ACT_PRE 24    // host-resolved muscle constants per actuator (act_pre; myobatch.hip fills them, fwd_actuation reads them)
 #define MYO_LD_FQ 12      // 64-item chunks of the tree-sparse L'DL factorisation (myo_sparse_ldl.h); more: the dense path
 #define MYO_LD_SQ 8       // 64-item chunks of its substitutions
 #ifndef MYO_OBJG_MAX
@@ -55,7 +56,7 @@
   X(tendon_solimp_lim) X(tendon_range) X(tendon_margin) X(tendon_stiffness) X(tendon_damping)    \
   X(tendon_lengthspring) X(tendon_invweight0) X(wrap_prm) X(actuator_dynprm)                     \
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
-  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(wr_p) X(wr_m) X(pc_f) X(te_div)               \
+  X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(act_pre) X(wr_p) X(wr_m) X(pc_f) X(te_div)               \
   X(pair_mg) X(dof_frictionloss) X(dof_solref) X(dof_solimp) X(tendon_frictionloss) X(tendon_solref_fri) X(tendon_solimp_fri)
 
 // geometry tables of the HP stages (kinematic chain, contact / limit distances, observation): fp64 copies in
@@ -63,7 +64,7 @@
 #define MYO_MODEL_HP_ARRAYS(X)                                                                   \
   X(qpos0) X(body_pos) X(body_quat) X(jnt_pos) X(jnt_axis) X(jnt_range) X(jnt_margin)            \
   X(geom_pos) X(geom_mat) X(geom_size) X(geom_margin) X(geom_gap) X(geom_rbound) X(site_pos) X(wr_p) X(wr_m)       \
-  X(actuator_lengthrange) X(actuator_gainprm) X(actuator_biasprm) X(tendon_range) X(tendon_margin) X(pair_mg)
+  X(actuator_lengthrange) X(actuator_gainprm) X(actuator_biasprm) X(act_pre) X(tendon_range) X(tendon_margin) X(pair_mg)
 
 // Model table handle.  The tables are immutable for the lifetime of a batch, so the gfx950 build
 // reads them through the CONSTANT address space: a load with a wave-uniform index becomes a scalar
@@ -96,6 +97,7 @@ struct DevModel {
   unsigned long long arrow_pad; // rows of the (permuted) 36-row system that hold no dof: identity
   int ld_nfq, ld_nsq;           // chunks of ld_fac / ld_sol in use (ld_nsq < 0: the model's M-only solves take the dense path)
   T timestep, tolerance, impratio, gravity[3], meaninertia;
+  T isqrt_impratio;             // 1 / sqrt(impratio)
   double h_timestep;            // the integration step of the HP state update
 #define X(n) MyoCArr<int> n;
   MYO_MODEL_INT_ARRAYS(X)

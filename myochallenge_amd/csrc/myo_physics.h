@@ -1542,7 +1542,7 @@ DEV int sphere_sphere(HP* dist, HP* pos, HP* n, const HP* c1, HP r1, const HP* c
   const HP dif[3] = {c2[0] - c1[0], c2[1] - c1[1], c2[2] - c1[2]};
   const HP cd = norm3(dif);
   if (cd - r1 - r2 > margin) return 0;
-  if (cd < (HP)1e-15) { n[0] = 1; n[1] = 0; n[2] = 0; } else { n[0] = dif[0] / cd; n[1] = dif[1] / cd; n[2] = dif[2] / cd; }
+  if (cd < (HP)1e-15) { n[0] = 1; n[1] = 0; n[2] = 0; } else { { const HP i_cd = (HP)1 / cd; n[0] = dif[0] * i_cd; n[1] = dif[1] * i_cd; n[2] = dif[2] * i_cd; } }
   *dist = cd - r1 - r2;
   for (int k = 0; k < 3; ++k) pos[k] = c1[k] + n[k] * (r1 + (HP)0.5 * (*dist));
   return 1;
@@ -1653,7 +1653,7 @@ DEV void collide_pair(const DevModel<T>& M, const TaskDev& K, const Scratch<T, N
       const HP dn = norm3(df);
       dd = dn - s1[0];
       if (dd > margin) return;
-      nl[0] = df[0] / dn; nl[1] = df[1] / dn; nl[2] = df[2] / dn;
+      { const HP i_dn = (HP)1 / dn; nl[0] = df[0] * i_dn; nl[1] = df[1] * i_dn; nl[2] = df[2] * i_dn; }
     } else {
       int kb = 0;
       HP best = (HP)1e30;
@@ -1726,7 +1726,7 @@ DEV int point_box_hp(ContactTmp& o, const HP* c, HP r, const HP* pb, const HP* R
     const HP dn = norm3(df);
     dd = dn - r;
     if (dd > margin) return 0;
-    nl[0] = df[0] / dn; nl[1] = df[1] / dn; nl[2] = df[2] / dn;
+    { const HP i_dn = (HP)1 / dn; nl[0] = df[0] * i_dn; nl[1] = df[1] * i_dn; nl[2] = df[2] * i_dn; }
   } else {
     int kb = 0;
     HP best = (HP)1e300;
@@ -1736,7 +1736,7 @@ DEV int point_box_hp(ContactTmp& o, const HP* c, HP r, const HP* pb, const HP* R
     if (SMOOTH_INSIDE) {      // capsule axis inside the box: normal from the smooth field x_k / s_k^2 (see the oracle's point_box)
       const HP g[3] = {-x[0] / (sb[0] * sb[0]), -x[1] / (sb[1] * sb[1]), -x[2] / (sb[2] * sb[2])};
       const HP gn = norm3(g);
-      if (gn > (HP)1e-15) { nl[0] = g[0] / gn; nl[1] = g[1] / gn; nl[2] = g[2] / gn; }
+      if (gn > (HP)1e-15) { { const HP i_gn = (HP)1 / gn; nl[0] = g[0] * i_gn; nl[1] = g[1] * i_gn; nl[2] = g[2] * i_gn; } }
     }
     dd = -best - r;
     if (dd > margin) return 0;
@@ -1756,7 +1756,7 @@ DEV int point_cyl_hp(ContactTmp& o, const HP* c, HP r, const HP* pc, const HP* R
     const HP dn = norm3(df);
     dd = dn - r;
     if (dd > margin) return 0;
-    nl[0] = df[0] / dn; nl[1] = df[1] / dn; nl[2] = df[2] / dn;
+    { const HP i_dn = (HP)1 / dn; nl[0] = df[0] * i_dn; nl[1] = df[1] * i_dn; nl[2] = df[2] * i_dn; }
   } else {
     const HP e_side = R - rho, e_cap = h - az;
     if (e_cap < e_side) { nl[0] = 0; nl[1] = 0; nl[2] = x[2] > 0 ? (HP)-1 : (HP)1; dd = -e_cap - r; }
@@ -1795,7 +1795,8 @@ DEV int point_ell_hp(ContactTmp& o, const HP* c, HP r, const HP* pe, const HP* R
   if (dd > margin) return 0;
   const HP g[3] = {-q[0] / (sz[0] * sz[0]), -q[1] / (sz[1] * sz[1]), -q[2] / (sz[2] * sz[2])};
   const HP gn = norm3(g);
-  const HP nl[3] = {g[0] / gn, g[1] / gn, g[2] / gn};
+  const HP ign = (HP)1 / gn;
+  const HP nl[3] = {g[0] * ign, g[1] * ign, g[2] * ign};
   return point_finish<SLOT>(o, c, r, Re, nl, dd, (HP)1);
 }
 
@@ -1951,20 +1952,23 @@ DEV void collide_pair_ext(const DevModel<T>& M, const TaskDev& K, const Scratch<
   }
 }
 
-// impedance / reference parameters of one constraint row (mj_makeImpedance, getsolparam)
+// impedance / reference parameters of one constraint row (mj_makeImpedance, getsolparam).  What depends on the model alone is resolved on
+// the host (myobatch.hip: sol_precompute — the arrays keep their names and sizes): kb = (K, B) of the row's solref (refsafe applied),
+// imp5 = (d0, d1, 1 / width or 0 when the impedance is constant, midpoint, power) of its solimp, clamped as getsolparam clamps them.  Left for
+// the device: the impedance at this position — for MuJoCo's default power 2, one division.  (Round 5: the fp64 leaves that call this held
+// 44 + 41 fp64 divisions per substep, ~12 instructions and a dependent chain each; `constraint_limits` 6.8 k -> see DESIGN section 5.)
 template <typename T>
-DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos_minus_margin, T* Kp, T* Bp, T* Ip) {
-  T d0 = tclamp(solimp[0], (T)0.0001, (T)0.9999), d1 = tclamp(solimp[1], (T)0.0001, (T)0.9999);
-  T width = solimp[2] < 0 ? (T)0 : solimp[2];
-  const T mid = tclamp(solimp[3], (T)0.0001, (T)0.9999);
-  const T power = solimp[4] < 1 ? (T)1 : solimp[4];
+DEV void sol_param(const DevModel<T>& M, const T* kb, const T* imp5, T pos_minus_margin, T* Kp, T* Bp, T* Ip) {
+  (void)M;
+  const T d0 = imp5[0], d1 = imp5[1], iw = imp5[2];
   T imp;
-  if (d0 == d1 || width <= MYO_MINVAL) imp = (T)0.5 * (d0 + d1);
+  if (iw == 0) imp = (T)0.5 * (d0 + d1);
   else {
-    const T x = fabs(pos_minus_margin) / width;
+    const T x = fabs(pos_minus_margin) * iw;
     if (x >= 1) imp = d1;
     else if (x <= 0) imp = d0;
     else {
+      const T mid = imp5[3], power = imp5[4];
       T y;
       if (power == 1) y = x;
       else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // MuJoCo's default solimp: no pow()
@@ -1973,14 +1977,23 @@ DEV void sol_param(const DevModel<T>& M, const T* solref, const T* solimp, T pos
       imp = d0 + y * (d1 - d0);
     }
   }
-  T tc = solref[0];
-  const T dr = solref[1];
-  if (tc > 0) {
-    if (!(M.disableflags & (1 << 11)) && tc < 2 * M.timestep) tc = 2 * M.timestep;
-    *Kp = 1 / tmax(MYO_MINVAL, d1 * d1 * tc * tc * dr * dr);
-    *Bp = 2 / tmax(MYO_MINVAL, d1 * tc);
-  } else { *Kp = -tc / (d1 * d1); *Bp = -dr / d1; }
-  *Ip = imp;
+  *Kp = kb[0]; *Bp = kb[1]; *Ip = imp;
+}
+// D = 1 / R of a row with R = max(MINVAL, (1 - imp) w / imp): one division
+template <typename T> DEV T sol_D(T imp, T w) {
+  const T num = (1 - imp) * w;
+  return num >= MYO_MINVAL * imp ? imp / num : 1 / MYO_MINVAL;
+}
+
+// D of a pyramidal contact's rows (mj_makeImpedance): R0 = max(MINVAL, (1 - imp)(tran + mu0^2 tran) / imp) of the first row's diagApprox,
+// R_py = max(MINVAL, 2 mu'^2 R0), mu' = friction[0] / sqrt(impratio) (1 / sqrt(impratio): host, M.isqrt_impratio) — one division while
+// neither floor is active, the formula as written otherwise
+template <typename T> DEV T con_D_pyramid(const DevModel<T>& M, T imp, T tran, T fr0) {
+  const T mu = fr0 * M.isqrt_impratio, m2 = 2 * mu * mu;
+  const T R0n = (1 - imp) * (tran + fr0 * fr0 * tran);
+  if (R0n >= MYO_MINVAL * imp && m2 * R0n >= MYO_MINVAL * imp) return imp / (m2 * R0n);
+  const T R0 = tmax(MYO_MINVAL, R0n / imp);
+  return 1 / tmax(MYO_MINVAL, m2 * R0);
 }
 
 // friction-loss rows (mj_instantiateFriction), models that have them only (M.any_floss, chosen at kernel level): tendon = 0, BEFORE
@@ -2005,9 +2018,8 @@ DEVFN void friction_rows(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
       T Kc, Bc, Ic;
       if (tendon) sol_param(M, M.tendon_solref_fri + 2 * i, M.tendon_solimp_fri + 5 * i, (T)0, &Kc, &Bc, &Ic);
       else sol_param(M, M.dof_solref + 2 * i, M.dof_solimp + 5 * i, (T)0, &Kc, &Bc, &Ic);
-      const T R = tmax(MYO_MINVAL, (1 - Ic) * (tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]) / Ic);
       s.lim_id[r] = i | MYO_LIM_FRIC;
-      s.efc_D[r] = 1 / R; S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = 0;
+      s.efc_D[r] = sol_D(Ic, tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = 0;
     }
     if (lane == 0) {
       const int n = base + total < MYO_NLIM_MAX ? base + total : MYO_NLIM_MAX;
@@ -2053,9 +2065,8 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
           sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dm, &Kc, &Bc, &Ic);
-          const T R = tmax(MYO_MINVAL, (1 - Ic) * M.dof_invweight0[M.jnt_dofadr[j]] / Ic);
           s.lim_id[r] = M.jnt_dofadr[j] | (side ? MYO_LIM_UPPER : 0);   // joint rows keep the DOF index
-          s.efc_D[r] = 1 / R; S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
+          s.efc_D[r] = sol_D(Ic, M.dof_invweight0[M.jnt_dofadr[j]]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -2091,9 +2102,8 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
           sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dm, &Kc, &Bc, &Ic);
-          const T R = tmax(MYO_MINVAL, (1 - Ic) * M.tendon_invweight0[t] / Ic);
           s.lim_id[r] = t | (side ? MYO_LIM_UPPER : 0);
-          s.efc_D[r] = 1 / R; S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
+          s.efc_D[r] = sol_D(Ic, M.tendon_invweight0[t]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -2184,10 +2194,7 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         T Kc, Bc, Ic;
         sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
         const T tran = F[15];
-        const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr0 * fr0 * tran) / Ic);
-        const T mu = fr0 / sqrt(M.impratio);
-        const T Rpy = tmax(MYO_MINVAL, 2 * mu * mu * R0);
-        c.D = 1 / Rpy;
+        c.D = con_D_pyramid(M, Ic, tran, fr0);
         { const int r0 = nlim + 4 * ci; const T kip = Kc * Ic * dmi; for (int e = 0; e < 4; ++e) { S_ROW_B(s)[r0 + e] = Bc; S_ROW_KIP(s)[r0 + e] = kip; } }
         {
           const T* c1 = S_COM(s) + 3 * root1; const T* c2 = S_COM(s) + 3 * root2;
@@ -2264,12 +2271,8 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
           // mj_makeImpedance: R of the first row from its diagApprox (tran + mu^2 tran; tran alone for the frictionless row), then every
           // pyramid row of the contact gets Rpy = 2 mu'^2 R, mu' = friction[0] / sqrt(impratio)
           T D;
-          if (dim == 1) D = 1 / tmax(MYO_MINVAL, (1 - Ic) * tran / Ic);
-          else {
-            const T R0 = tmax(MYO_MINVAL, (1 - Ic) * (tran + fr0 * fr0 * tran) / Ic);
-            const T mu = fr0 / sqrt(M.impratio);
-            D = 1 / tmax(MYO_MINVAL, 2 * mu * mu * R0);
-          }
+          if (dim == 1) D = sol_D(Ic, tran);
+          else D = con_D_pyramid(M, Ic, tran, fr0);
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int ci = ncon + S_NPRE(s)[lane] + k * per + j;
@@ -2795,13 +2798,19 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       T ctrl = ctrl_get(s, i);
       if (M.actuator_ctrllimited[i]) ctrl = tclamp(ctrl, M.actuator_ctrlrange[2 * i], M.actuator_ctrlrange[2 * i + 1]);
       T input = ctrl;
+      // The constants of mju_muscleGain / Bias / Dynamics that depend on the parameters alone — peak force, L0 and the normalised-length
+      // map, the reciprocals of every constant denominator of the force-length / force-velocity / passive curves — are resolved on the
+      // host (act_pre, MYO_ACT_PRE per actuator: myobatch.hip); round 4's version divided 16 times per lane here.
+      const HP* ap = M.h_act_pre + MYO_ACT_PRE * i;
       if (M.actuator_dyntype[i] == 3) {
-        const int ia = i - (M.nu - M.na);
-        const T act = (T)s.act[ia];
+        const T act = (T)s.act[i - (M.nu - M.na)];
         const T* prm = M.actuator_dynprm + 10 * i;
         const T cc = tclamp(ctrl, (T)0, (T)1), ac = tclamp(act, (T)0, (T)1);
-        const T tau = cc > act ? prm[0] * ((T)0.5 + (T)1.5 * ac) : prm[1] / ((T)0.5 + (T)1.5 * ac);
-        LV(adot) = (cc - act) / tmax(MYO_MINVAL, tau);
+        const T w = (T)0.5 + (T)1.5 * ac, ideact = (T)ap[22];
+        // tau = tau_act w (activating) | tau_deact / w (deactivating); act_dot = (ctrl - act) / tau
+        if (cc > act) LV(adot) = (cc - act) / tmax(MYO_MINVAL, prm[0] * w);
+        else if (ideact != 0) LV(adot) = (cc - act) * w * ideact;
+        else LV(adot) = (cc - act) / tmax(MYO_MINVAL, prm[1] / w);
         input = act;
       }
       const int tid = M.actuator_tendon[i];
@@ -2811,35 +2820,31 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       const HP lenh = (HP)gear * s.ten_length[tid];
       const T len = (T)lenh, vel = gear * S_TEN_VEL(s)[tid];
       T gain, bias = 0;
-      const HP lr0 = M.h_actuator_lengthrange[2 * i], lr1 = M.h_actuator_lengthrange[2 * i + 1];
       if (M.actuator_gaintype[i] == 1) {
-        const T* prm = M.actuator_gainprm + 10 * i;
-        T force = prm[2];
-        if (force < 0) force = prm[3] / tmax(MYO_MINVAL, M.actuator_acc0[i]);
-        const double* hp = M.h_actuator_gainprm + 10 * i;     // (1.05f - 0.75f is 1.6e-7 off 0.3: a 5e-6 force error through L - 1)
-        const HP L0 = (lr1 - lr0) / tmax((HP)1e-15, hp[1] - hp[0]);
-        const HP L = hp[0] + (lenh - lr0) / tmax((HP)1e-15, L0);
-        const T V = vel / tmax(MYO_MINVAL, (T)L0 * prm[6]);
-        const T FL = (T)muscle_FL(L, hp[4], hp[5]);
-        const T y = prm[8] - 1;
+        const HP L = ap[1] + (lenh - ap[3]) * ap[2];
+        const T V = vel * (T)ap[4];
+        const HP lmin = ap[5], lmax = ap[6], a = ap[7], b = ap[8];
+        HP FLh;
+        if (L < lmin || L > lmax) FLh = 0;
+        else if (L <= a) { const HP x = (L - lmin) * ap[9]; FLh = (HP)0.5 * x * x; }
+        else if (L <= 1) { const HP x = (1 - L) * ap[10]; FLh = 1 - (HP)0.5 * x * x; }
+        else if (L <= b) { const HP x = (L - 1) * ap[11]; FLh = 1 - (HP)0.5 * x * x; }
+        else { const HP x = (lmax - L) * ap[12]; FLh = (HP)0.5 * x * x; }
+        const T FL = (T)FLh, y = (T)ap[13], fvmax = (T)ap[15];
         T FV;
         if (V <= -1) FV = 0;
         else if (V <= 0) FV = (V + 1) * (V + 1);
-        else if (V <= y) FV = prm[8] - (y - V) * (y - V) / tmax(MYO_MINVAL, y);
-        else FV = prm[8];
-        gain = -force * FL * FV;
+        else if (V <= y) FV = fvmax - (y - V) * (y - V) * (T)ap[14];
+        else FV = fvmax;
+        gain = -(T)ap[0] * FL * FV;
       } else gain = M.actuator_gainprm[10 * i];
       if (M.actuator_biastype[i] == 2) {
-        const T* prm = M.actuator_biasprm + 10 * i;
-        T force = prm[2];
-        if (force < 0) force = prm[3] / tmax(MYO_MINVAL, M.actuator_acc0[i]);
-        const double* hp = M.h_actuator_biasprm + 10 * i;
-        const HP L0 = (lr1 - lr0) / tmax((HP)1e-15, hp[1] - hp[0]);
-        const HP L = hp[0] + (lenh - lr0) / tmax((HP)1e-15, L0);
-        const HP b = (HP)0.5 * (1 + hp[5]);
+        const HP L = ap[17] + (lenh - ap[3]) * ap[18];
+        const HP b = ap[19];
+        const T force = (T)ap[16], fpmax = (T)ap[21];
         if (L <= 1) bias = 0;
-        else if (L <= b) { const T x = (T)((L - 1) / tmax((HP)1e-15, b - 1)); bias = -force * prm[7] * (T)0.5 * x * x; }
-        else { const T x = (T)((L - b) / tmax((HP)1e-15, b - 1)); bias = -force * prm[7] * ((T)0.5 + x); }
+        else if (L <= b) { const T x = (T)((L - 1) * ap[20]); bias = -force * fpmax * (T)0.5 * x * x; }
+        else { const T x = (T)((L - b) * ap[20]); bias = -force * fpmax * ((T)0.5 + x); }
       } else if (M.actuator_biastype[i] == 1) {
         const T* prm = M.actuator_biasprm + 10 * i;
         bias = prm[0] + prm[1] * len + prm[2] * vel;

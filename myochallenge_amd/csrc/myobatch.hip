@@ -220,6 +220,25 @@ static void build_arrow_tables(myo_model* m) {
   finish();
 }
 
+// what sol_param (myo_physics.h) needs of a (solref[2], solimp[5]) pair, resolved once: ref2 <- (K, B) with refsafe applied; imp5 <- (d0, d1,
+// 1 / width — 0 when the impedance does not depend on the position —, midpoint, power), clamped as MuJoCo's getsolparam / getimpedance clamp them
+static void sol_precompute(double* ref2, double* imp5, double timestep, int disableflags) {
+  auto clamp = [](double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); };
+  const double d0 = clamp(imp5[0], 0.0001, 0.9999), d1 = clamp(imp5[1], 0.0001, 0.9999);
+  const double width = imp5[2] < 0 ? 0.0 : imp5[2];
+  const double mid = clamp(imp5[3], 0.0001, 0.9999), power = imp5[4] < 1 ? 1.0 : imp5[4];
+  double tc = ref2[0];
+  const double dr = ref2[1];
+  double K, B;
+  if (tc > 0) {
+    if (!(disableflags & (1 << 11)) && tc < 2 * timestep) tc = 2 * timestep;
+    K = 1.0 / std::max(1e-15, d1 * d1 * tc * tc * dr * dr);
+    B = 2.0 / std::max(1e-15, d1 * tc);
+  } else { K = -tc / (d1 * d1); B = -dr / d1; }
+  ref2[0] = K; ref2[1] = B;
+  imp5[0] = d0; imp5[1] = d1; imp5[2] = (d0 == d1 || width <= 1e-15) ? 0.0 : 1.0 / width; imp5[3] = mid; imp5[4] = power;
+}
+
 static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out);
 extern "C" int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** out) {
   try { return model_from_blob_impl(blob, nbytes, out); }          // no C++ exception crosses the C ABI
@@ -582,6 +601,34 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     m->act_gear0[i] = m->actuator_gear[6 * i];
     { int k = 0; for (int d = 0; d < nv && k < MYO_TJ_MAX; ++d) if ((m->act_dofmask[i] >> d) & 1ull) m->act_sd[(size_t)i * MYO_TJ_MAX + k++] = d; }
   }
+  // muscle constants of every actuator (fwd_actuation: what mju_muscleGain / mju_muscleBias / mju_muscleDynamics derive from the
+  // parameters alone, with every constant denominator turned into a reciprocal): MYO_ACT_PRE doubles per actuator, see myo_physics.h
+  m->act_pre.assign((size_t)MYO_NU_MAX * MYO_ACT_PRE, 0.0);
+  for (int i = 0; i < m->nu; ++i) {
+    double* P = &m->act_pre[(size_t)i * MYO_ACT_PRE];
+    const double* gp = &m->actuator_gainprm[10 * (size_t)i];
+    const double* bp = &m->actuator_biasprm[10 * (size_t)i];
+    const double* dp = &m->actuator_dynprm[10 * (size_t)i];
+    const double lr0 = m->actuator_lengthrange[2 * (size_t)i], lr1 = m->actuator_lengthrange[2 * (size_t)i + 1], acc0 = m->actuator_acc0[i];
+    const double tiny = 1e-15;
+    {   // gain
+      const double force = gp[2] < 0 ? gp[3] / std::max(tiny, acc0) : gp[2];
+      const double L0 = (lr1 - lr0) / std::max(tiny, gp[1] - gp[0]);
+      const double lmin = gp[4], lmax = gp[5], a = 0.5 * (lmin + 1), b = 0.5 * (1 + lmax), y = gp[8] - 1;
+      P[0] = force; P[1] = gp[0]; P[2] = 1.0 / std::max(tiny, L0); P[3] = lr0; P[4] = 1.0 / std::max(tiny, L0 * gp[6]);
+      P[5] = lmin; P[6] = lmax; P[7] = a; P[8] = b;
+      P[9] = 1.0 / std::max(tiny, a - lmin); P[10] = 1.0 / std::max(tiny, 1 - a); P[11] = 1.0 / std::max(tiny, b - 1); P[12] = 1.0 / std::max(tiny, lmax - b);
+      P[13] = y; P[14] = 1.0 / std::max(tiny, y); P[15] = gp[8];
+    }
+    {   // bias
+      const double force = bp[2] < 0 ? bp[3] / std::max(tiny, acc0) : bp[2];
+      const double L0 = (lr1 - lr0) / std::max(tiny, bp[1] - bp[0]);
+      const double b = 0.5 * (1 + bp[5]);
+      P[16] = force; P[17] = bp[0]; P[18] = 1.0 / std::max(tiny, L0); P[19] = b; P[20] = 1.0 / std::max(tiny, b - 1); P[21] = bp[7];
+    }
+    // activation dynamics: 1 / tau_deact when tau = tau_deact / (0.5 + 1.5 act) can never reach the floor (act in [0, 1]); else 0: the formula as written
+    P[22] = dp[1] / 2.0 >= tiny ? 1.0 / dp[1] : 0.0;
+  }
   for (int b = 0; b < nb; ++b) {
     int cnt = 0;
     for (unsigned long long x = m->body_dofmask[b]; x; x &= x - 1) cnt++;
@@ -592,7 +639,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   //   pc_i[8p..]  = body1, body2, root body 1, root body 2, nsup, box-box candidate (0 none; 1 + v: vertex v of geom 1 against
   //                 geom 2, 9 + v: vertex v of geom 2 against geom 1, 17: the edge-edge candidate), 0, friction selector (0 max, 1 geom1, 2 geom2)
   //   pc_sup[4p..] = the dofs either body can move (<= 16 bytes, ascending)
-  //   pc_f[16p..] = margin, margin - gap, solref[2], solimp[5] (mixed), friction1[3], friction2[3], invweight sum
+  //   pc_f[16p..] = margin, margin - gap, (K, B) and (d0, d1, 1 / width, mid, power) of the mixed solref[2] / solimp[5] (sol_precompute), friction1[3], friction2[3], invweight sum
   //   pc_mask[2p..] = ancestor-dof masks of the two bodies
   {
     const int np = m->npair > 0 ? m->npair : 1;
@@ -650,6 +697,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
       m->any_gen = 1;                         // (the general path reads the pair's own margin and skips the per-env friction patch)
     }
     m->pair_mg[2 * (size_t)p] = mg0; m->pair_mg[2 * (size_t)p + 1] = mg1;
+    sol_precompute(F + 2, F + 4, m->timestep, m->disableflags);      // pc_f[2..8]: (K, B), (d0, d1, 1 / width, mid, power) — what sol_param reads
     LIM((I[6] & 255) != 1 && (I[6] & 255) != 3 && (I[6] & 255) != 4 && (I[6] & 255) != 6, "contact dimension (condim) other than 1, 3, 4, 6")
     if ((I[6] & 255) > 3) m->any_rot = 1;
     if ((I[6] & 255) != 3) m->any_gen = 1;
@@ -671,6 +719,13 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
       m->nlead = m->jnt_dofadr[j];
     else break;
   }
+  // the rows' solver parameters in the form sol_param reads them (in place: same names, same sizes)
+  for (int j = 0; j < m->njnt; ++j) sol_precompute(&m->jnt_solref[2 * (size_t)j], &m->jnt_solimp[5 * (size_t)j], m->timestep, m->disableflags);
+  for (int t2 = 0; t2 < m->ntendon; ++t2) {
+    sol_precompute(&m->tendon_solref_lim[2 * (size_t)t2], &m->tendon_solimp_lim[5 * (size_t)t2], m->timestep, m->disableflags);
+    sol_precompute(&m->tendon_solref_fri[2 * (size_t)t2], &m->tendon_solimp_fri[5 * (size_t)t2], m->timestep, m->disableflags);
+  }
+  for (int d = 0; d < nv; ++d) sol_precompute(&m->dof_solref[2 * (size_t)d], &m->dof_solimp[5 * (size_t)d], m->timestep, m->disableflags);
   build_ldl_tables(m);
   build_arrow_tables(m);
   m->any_floss = 0;
@@ -815,6 +870,7 @@ static int upload_model(const myo_model* m, DevModel<T>& D, std::vector<void*>& 
   D.ld_nfq = m->ld_nfq; D.ld_nsq = m->ld_nsq; D.arrow_nf = m->arrow_nf; D.arrow_pad = m->arrow_pad; D.any_rot = m->any_rot; D.any_gen = m->any_gen; D.any_floss = m->any_floss;
   D.h_timestep = m->timestep;
   D.timestep = (T)m->timestep; D.tolerance = (T)m->tolerance; D.impratio = (T)m->impratio;
+  D.isqrt_impratio = (T)(1.0 / sqrt(m->impratio));
   for (int k = 0; k < 3; ++k) D.gravity[k] = (T)m->gravity[k];
   D.meaninertia = (T)m->meaninertia;
   int rc = 0;

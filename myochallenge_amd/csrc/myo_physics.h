@@ -1971,7 +1971,8 @@ DEV void sol_param(const DevModel<T>& M, const T* kb, const T* imp5, T pos_minus
       const T mid = imp5[3], power = imp5[4];
       T y;
       if (power == 1) y = x;
-      else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // MuJoCo's default solimp: no pow()
+      else if (power == 2 && mid == (T)0.5) y = (x <= mid) ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x);   // MuJoCo's default solimp (midpoint 0.5, power 2): the same numbers without a division
+      else if (power == 2) y = (x <= mid) ? x * x / mid : 1 - (1 - x) * (1 - x) / (1 - mid);   // no pow()
       else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
       else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
       imp = d0 + y * (d1 - d0);

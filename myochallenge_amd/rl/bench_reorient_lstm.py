@@ -28,17 +28,18 @@ def run(envs: int = 4096, n_steps: int = 32, iters: int = 3, env_only_steps: int
     algo = PPO(VecNormalize(env), pol, cfg)
     algo.collect_rollouts(); algo.train()                       # warm-up (captures the graphs)
     torch.cuda.synchronize()
-    t0 = time.time(); tr = 0.0
+    t0 = time.time(); tr = 0.0; per_iter = []
     for _ in range(iters):
-        t1 = time.time(); algo.collect_rollouts(); torch.cuda.synchronize(); tr += time.time() - t1
-        algo.train()
-    torch.cuda.synchronize()
+        t1 = time.time(); algo.collect_rollouts(); torch.cuda.synchronize(); t2 = time.time(); tr += t2 - t1
+        algo.train(); torch.cuda.synchronize()
+        per_iter.append([round(t2 - t1, 4), round(time.time() - t2, 4)])
     dt = time.time() - t0
     steps = iters * envs * n_steps
     out = {"config": "E: CustomMyoReorientP1, %d envs, LSTM-256 + MLP[256,256]" % envs,
            "env_steps_per_sec_rollout_plus_update": steps / dt, "env_steps_per_sec_rollout_only": steps / tr,
            "n_steps": n_steps, "epochs": n_epochs, "dtype": dtype, "settings": "reference (src/main_reorient.py:53-71)" if reference_settings else "light",
-           "env_kernel_lds_bytes": env.batch.lds_bytes, "health": env.batch.health(), "recurrent_path": "fused" if algo._fused_rec is not None else "autograd"}
+           "env_kernel_lds_bytes": env.batch.lds_bytes, "health": env.batch.health(), "recurrent_path": "fused" if algo._fused_rec is not None else "autograd",
+           "seconds_per_iteration_rollout_update": per_iter}
     if env_only_steps:                                          # physics alone (zero actions)
         act = torch.zeros((envs, env.act_dim), device=env.device)
         t2 = time.time()

@@ -162,13 +162,14 @@ template <typename T> struct ScratchPoses {
   T xmat_[MYO_NB_MAX * 9];                             // rotation matrices as the fp32 stages read them; the fp64 stepper derives them from xquat (body_rot)
   T ctrl_[MYO_NU_MAX], qacc_warm_[MYO_NV_MAX];         // controls, warm start (ctrl_get / warm_get below)
   T ten_J[MYO_NT_MAX * MYO_TJ_MAX];                    // tendon moment arms, [tendon][slot] (tenj_get below)
+  int pub;                                             // record stores of this part are write-through (st_pub, wave.h)
 };
 // fp64 stepper: the controls (read once per substep) and the solver's warm start (read once, written once) stay in global memory —
 // the warm start in the env's record, where the next part of the step / the next step finds it anyway, the controls in the batch's ctrl_ws
 // ... and so do the tendon moment arms (2.5 KB: the difference between seven and eight workgroups per CU): accumulated in LDS during the
 // tendon stage (S_TENJ_STAGE, storage the constraint rows take over later), written out once, [slot][tendon] so that tendon-per-lane
 // reads coalesce; read back by the tendon-velocity / actuator-moment phases and, for tendon-limit rows only, by the solver
-template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; };
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; int pub; };
 
 template <typename T, int NC = MYO_NCON_MAX>
 struct Scratch : ScratchPoses<T> {
@@ -321,7 +322,7 @@ static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 3 * (MYO_NLIM_MAX + 4 * MYO_NCON_F64), 
 template <typename T, int NC> DEV T ctrl_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.ctrl_g[i]; else return s.ctrl_[i]; }
 template <typename T, int NC> DEV void ctrl_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) s.ctrl_g[i] = (double)v; else s.ctrl_[i] = v; }
 template <typename T, int NC> DEV T warm_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.warm_g[i]; else return s.qacc_warm_[i]; }
-template <typename T, int NC> DEV void warm_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) s.warm_g[i] = (double)v; else s.qacc_warm_[i] = v; }
+template <typename T, int NC> DEV void warm_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) st_pub(s.warm_g + i, (double)v, UNI(s.pub)); else s.qacc_warm_[i] = v; }
 #define MYO_NEFC_MIN (MYO_NLIM_MAX + 4 * MYO_NCON_F64)   /* rows of the smallest scratch: every alias of an efc_* array must fit in this many */
 static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MIN && 2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MIN && MYO_NJ_MAX * 3 <= MYO_NEFC_MIN && MYO_NB_MAX * 3 <= MYO_NEFC_MIN && 64 <= MYO_NEFC_MIN,
               "efc aliases (S_RKDX, S_XANCHOR / S_XAXIS, S_XIPOS) in the smallest scratch");

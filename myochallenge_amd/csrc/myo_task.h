@@ -461,13 +461,14 @@ DEV void task_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T, NC>& s, i
 
 // ---- HBM record <-> scratch
 template <typename T, int NC>
-DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, Scratch<T, NC>& s_in, int env) {
+DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, Scratch<T, NC>& s_in, int env, int pub = 0) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   if constexpr (sizeof(T) == sizeof(HP)) {      // fp64 stepper: warm start and controls stay in global memory (ScratchPoses<double>)
     PHASE { if (lane == 0) { s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + (size_t)env * MYO_ENVWS_N; s.tenj_g = s.ctrl_g + MYO_NU_MAX; } }
-    SYNC();
   }
+  PHASE { if (lane == 0) s.pub = pub; }
+  SYNC();
   PHASE {
     if (K.objg_gidn > 0) {
       constexpr int NF = Scratch<T, NC>::OBJG_NF;
@@ -501,28 +502,36 @@ template <typename T, int NC>
 DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T, NC>& s_in, int mid_step = 0) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
+  // mid_step: 1 = the step goes on in another call (its state so far: `bad` is kept; the per-episode draws — ball / object data — have
+  // not changed since load_env and are not stored again); | 2 = ... in another workgroup of this launch: write-through stores (st_pub,
+  // wave.h); | 4 = this call did not start the step either: the task state (targets, counters) is as loaded
+  const int wt = mid_step & 2, later = mid_step & 4;
   PHASE {
-    if (K.kind == MYO_TASK_REORIENT_K) {
+    if (K.kind == MYO_TASK_REORIENT_K && !mid_step) {
       constexpr int NF = Scratch<T, NC>::OBJG_NF;
       for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + 3 * (i / NF) + i % NF] = (double)s.objg_fric[i];
     }
-    for (int i = lane; i < M.nq; i += 64) rec[L.off_qpos + i] = (double)s.qpos[i];
-    for (int i = lane; i < M.nv; i += 64) { rec[L.off_qvel + i] = (double)s.qvel[i]; if constexpr (sizeof(T) != sizeof(HP)) rec[L.off_warm + i] = (double)s.qacc_warm_[i]; }
-    for (int i = lane; i < M.na; i += 64) rec[L.off_act + i] = (double)s.act[i];
+    for (int i = lane; i < M.nq; i += 64) st_pub(rec + L.off_qpos + i, (double)s.qpos[i], wt);
+    for (int i = lane; i < M.nv; i += 64) { st_pub(rec + L.off_qvel + i, (double)s.qvel[i], wt); if constexpr (sizeof(T) != sizeof(HP)) st_pub(rec + L.off_warm + i, (double)s.qacc_warm_[i], wt); }
+    for (int i = lane; i < M.na; i += 64) st_pub(rec + L.off_act + i, (double)s.act[i], wt);
     if (lane == 0) {
-      rec[L.off_time] = (double)s.time;
-      double* td = rec + L.off_taskd;
-      for (int k = 0; k < MYO_TASKD_N; ++k) td[k] = (double)s.taskd[k];
-      double* bd = rec + L.off_balld;
-      if (K.objg_gidn <= 0) {
-        bd[0] = (double)s.ball_mass[0]; bd[1] = (double)s.ball_mass[1];
-        for (int k = 0; k < 6; ++k) bd[2 + k] = (double)s.ball_fric[k];
+      st_pub(rec + L.off_time, (double)s.time, wt);
+      if (!mid_step) {
+        double* bd = rec + L.off_balld;
+        if (K.objg_gidn <= 0) {
+          bd[0] = (double)s.ball_mass[0]; bd[1] = (double)s.ball_mass[1];
+          for (int k = 0; k < 6; ++k) bd[2 + k] = (double)s.ball_fric[k];
+        }
+        bd[8] = (double)s.ball_size[0]; bd[9] = (double)s.ball_size[1];
       }
-      bd[8] = (double)s.ball_size[0]; bd[9] = (double)s.ball_size[1];
       double* mi = rec + L.off_misc;
-      mi[0] = s.which_task; mi[1] = s.counter; mi[2] = s.elapsed; mi[3] = s.episode;
-      mi[4] = (double)s.ep_ret; mi[5] = s.ep_len; mi[6] = mid_step ? s.bad : 0;
+      if (!later) {
+        st_pub(mi, (double)s.which_task, wt); st_pub(mi + 1, (double)s.counter, wt); st_pub(mi + 2, (double)s.elapsed, wt); st_pub(mi + 3, (double)s.episode, wt);
+        st_pub(mi + 4, (double)s.ep_ret, wt); st_pub(mi + 5, (double)s.ep_len, wt);
+      }
+      st_pub(mi + 6, mid_step ? (double)s.bad : 0.0, wt);
     }
+    if (lane < MYO_TASKD_N && !later) st_pub(rec + L.off_taskd + lane, (double)s.taskd[lane], wt);
   }
   SYNC();
 }
@@ -531,12 +540,13 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
 template <typename T, int NC>
 DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
-                  float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int k_lo = 0, int k_hi = -1) {
+                  float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int k_lo = 0, int k_hi = -1, int pub = 0) {
+  // pub: this call ends inside the step and another workgroup of the launch takes the record over (write-through stores, wave.h)
   WAVE_FN
   const int nobs = task_nobs(K, M.na);
-  load_env(M, K, L, rec, s, env);
+  load_env(M, K, L, rec, s, env, pub);
   task_step_core(M, K, s, act + (size_t)env * M.nu, k_lo, k_hi);
-  if (k_hi >= 0 && k_hi < K.frame_skip) { store_env(M, K, L, rec, s, 1); return; }
+  if (k_hi >= 0 && k_hi < K.frame_skip) { store_env(M, K, L, rec, s, (s.pub ? 3 : 1) | (k_lo > 0 ? 4 : 0)); return; }
   // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
   // an error of the batch: the env ends its episode with done = 1, reward 0, zero reward components except `done`,
   // is reset at once, and both the terminal and the returned observation are the (finite) reset observation, so that

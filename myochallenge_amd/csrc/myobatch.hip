@@ -783,7 +783,7 @@ extern "C" int myo_model_size(const myo_model* m, const char* n) {
 
 // ------------------------------------------------------------------------------------------ batch
 #define MYO_PARTS_MAX 8
-struct StepPlan { int nparts; int k[MYO_PARTS_MAX + 1]; };      // part p = substeps [k[p], k[p+1]); nparts = 1: whole steps
+struct StepPlan { int nparts; int k[MYO_PARTS_MAX + 1]; int wt; };   // wt: parts publish their record with write-through stores instead of an agent release fence      // part p = substeps [k[p], k[p+1]); nparts = 1: whole steps
 struct myo_batch;
 struct myo_batch {
   int n, device, dtype, nobs;
@@ -1073,11 +1073,12 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
     b->K.rk_ws = w;
     if (w) b->allocs.push_back(w);
   }
-  b->order = nullptr; b->cost = nullptr; b->ticks = nullptr; b->part_state = nullptr; b->step_gen = nullptr; b->plan.nparts = 1; b->plan.k[0] = 0; b->plan.k[1] = cfg ? cfg->frame_skip : 0;
+  b->order = nullptr; b->cost = nullptr; b->ticks = nullptr; b->part_state = nullptr; b->step_gen = nullptr; b->plan.nparts = 1; b->plan.k[0] = 0; b->plan.k[1] = cfg ? cfg->frame_skip : 0; b->plan.wt = 0;
   {
     // the parts of an env step (k_step): MYO_STEP_SPLIT = "7,3" (substeps per part; "0" or one number = whole steps; A/B switch
     // of the tools and of the bit-identity tests).  The emulation build runs the parts one after the other through the record.
     StepPlan pl; pl.nparts = 0; pl.k[0] = 0;
+    { const char* pm = getenv("MYO_PUBLISH"); pl.wt = pm && !strcmp(pm, "fence") ? 0 : 1; }     // A/B switch: "wt" (default) | "fence"
     if (b->K.kind && cfg->frame_skip >= 2) {
       const char* sp = getenv("MYO_STEP_SPLIT");
       if (sp) {
@@ -1314,13 +1315,16 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
       __syncthreads();
     }
     const int last = p == nparts - 1;
-    env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, plan.k[q], last ? -1 : plan.k[p + 1]);
+    env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, plan.k[q], last ? -1 : plan.k[p + 1], (plan.wt && !last) ? 1 : 0);
     // (the duration is added BEFORE the part is published: the next part's workgroup may run, and add its own, the moment it is)
-    if (ticks && threadIdx.x == 0) { const unsigned int d = (unsigned int)(wall_clock64() - t_start); if (q > 0) ticks[env] += d; else ticks[env] = d; }
+    if (ticks && threadIdx.x == 0) {
+      const unsigned int d = (unsigned int)(wall_clock64() - t_start) + (q > 0 ? ticks[env] : 0u);
+      if (plan.wt) __hip_atomic_store(ticks + env, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else ticks[env] = d;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (!last) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+      if (!last && !plan.wt) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
       __hip_atomic_store(st, (int)(last ? base + 16u : base + 2u * (unsigned)p + 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {

@@ -62,12 +62,21 @@
 // LDS accumulation by several lanes of a phase into one slot (the emulation runs the lanes one after the other)
 template <typename T> static inline void lds_add(T* p, T v) { *p += v; }
 static inline void myo_count(int* p) { *p += 1; }
+// a store another workgroup of the launch reads after its agent acquire (st_pub of the device build): the emulation has one memory
+static inline void st_pub(double* p, double v, int wt) { (void)wt; *p = v; }
 static inline int myo_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #else
 #include <hip/hip_runtime.h>
 #define DEV __device__ __forceinline__
 #define WAVE_FN const int lane = threadIdx.x; (void)lane;
+// A store of bytes that ANOTHER workgroup of the same launch reads after its agent-scope acquire (the parts of an env step, k_step in
+// myobatch.hip).  wt != 0: a relaxed agent-scope store = `global_store_dwordx2 ... sc1`, written through the XCD's L2, so that the
+// publishing lane needs no agent release fence (`buffer_wbl2 sc1` writes back EVERY dirty line of the XCD's L2, the other envs'
+// workspace lines included) — only its `s_waitcnt vmcnt(0)` before the flag.  wt == 0: a plain store, published by the release fence.
+__device__ __forceinline__ void st_pub(double* p, double v, int wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 #define PHASE
 #define SYNC() __syncthreads()
 #define LANE_VAR(T, name) T name

@@ -150,6 +150,9 @@ class NativeLib:
         L.myo_lstm_step_supported.argtypes = [i32]
         L.myo_lstm_step_fwd.argtypes = [vp, C.c_longlong, C.c_longlong] + [vp] * 4 + [i32] * 3 + [vp, C.c_longlong] + [vp] * 5
         L.myo_lstm_step_bwd.argtypes = [vp, C.c_longlong] + [vp] * 7 + [i32] * 3 + [vp] * 3
+        L.myo_lstm_seq_supported.argtypes = [i32]
+        L.myo_lstm_seq_fwd.argtypes = [vp] + [C.c_longlong] * 3 + [vp] * 4 + [i32] * 4 + [vp, C.c_longlong, C.c_longlong] + [vp] * 3
+        L.myo_lstm_seq_bwd.argtypes = [vp, C.c_longlong, C.c_longlong] + [vp] * 5 + [i32] * 4 + [vp] * 2
         L.myo_adam_clip_step.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, vp, vp]
         L.myo_adam_apply.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, i32, vp, vp]
         L.myo_ppo_mlp_workspace_bytes.restype = C.c_longlong
@@ -200,7 +203,7 @@ EXPORTED_SYMBOLS = [
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
-    "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_lstm_step_supported", "myo_lstm_step_fwd", "myo_lstm_step_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_ppo_mlp_workspace_bytes", "myo_ppo_mlp_step", "myo_ppo_mlp_sqnorm_parts", "myo_adam_apply", "myo_ppo_mlp_rollout_workspace_bytes", "myo_ppo_mlp_rollout_refresh", "myo_ppo_mlp_rollout", "myo_last_error", "myo_version",
+    "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_lstm_step_supported", "myo_lstm_step_fwd", "myo_lstm_step_bwd", "myo_lstm_seq_supported", "myo_lstm_seq_fwd", "myo_lstm_seq_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_ppo_mlp_workspace_bytes", "myo_ppo_mlp_step", "myo_ppo_mlp_sqnorm_parts", "myo_adam_apply", "myo_ppo_mlp_rollout_workspace_bytes", "myo_ppo_mlp_rollout_refresh", "myo_ppo_mlp_rollout", "myo_last_error", "myo_version",
 ]
 
 

@@ -9,9 +9,11 @@ around ~150 that do the work.  Here
 
 * the minibatch is gathered by ``myo_ppo_gather`` (bf16 observations, advantage moments), one GEMM projects the
   inputs of both LSTMs for all time steps;
-* a time step is ONE launch per direction, ``myo_lstm_step_fwd`` / ``myo_lstm_step_bwd`` (csrc/myo_lstm_step.h: recurrent product
-  on the matrix cores with the cell arithmetic as its epilogue; hidden sizes 32 / 64 / 128 / 256), else the batched recurrent
-  GEMM + ``myo_lstm_cell_fwd`` / ``myo_lstm_cell_bwd`` (as ``rl/policy.py:_LstmSeq``);
+* the recurrence over ALL time steps is ONE launch per direction, ``myo_lstm_seq_fwd`` / ``myo_lstm_seq_bwd`` (csrc/myo_lstm_seq.h:
+  a workgroup owns 16 sequences, the state goes from step to step through LDS and registers; hidden sizes 128 / 256, minibatches
+  of a multiple of 16 sequences); else a time step is one launch per direction, ``myo_lstm_step_fwd`` / ``myo_lstm_step_bwd``
+  (csrc/myo_lstm_step.h: recurrent product on the matrix cores with the cell arithmetic as its epilogue; hidden sizes 32 / 64 /
+  128 / 256); else the batched recurrent GEMM + ``myo_lstm_cell_fwd`` / ``myo_lstm_cell_bwd`` (as ``rl/policy.py:_LstmSeq``);
 * trunks, heads, loss and their backward pass are ``FusedPPOStep._merged_core`` on the LSTM outputs, which also
   returns the gradient entering the LSTMs;
 * LSTM weight gradients are per-time-step batched GEMMs reduced in fp32 by ``myo_splitk_reduce`` (the bias
@@ -27,6 +29,31 @@ import os
 import torch
 
 from .fused_mlp import FusedPPOStep
+
+
+def lstm_seq_weights(whh):
+    """W_hh bf16 [G, 4H, H] -> (w_frag, wt_frag), the fragment-major layouts ``myo_lstm_seq_fwd`` / ``_bwd`` read (include/myobatch.h):
+    the 64 x 16 bytes a wave loads for one matrix-core operand are one contiguous KB in lane order (lane = 16 (k-quarter) + row);
+    a workgroup has eight waves, wave w owns UT = H / 128 tiles of 16 units and row i = 4 a + b of its tile ut is unit
+    16 UT w + 4 UT a + 4 ut + b (a lane's units are consecutive, csrc/myo_lstm_seq.h)."""
+    G, H4, H = whh.shape
+    UT = H // 128
+    #            [g][q][w][a][ut][b][kk][lk][j]                              -> [g][w][kk][q][ut][lk][lr = (a, b)][j]
+    w_frag = whh.view(G, 4, 8, 4, UT, 4, H // 32, 4, 8).permute(0, 2, 6, 1, 4, 7, 3, 5, 8).contiguous()
+    #             [g][kk][lk][j][w][a][ut][b]                                -> [g][w][kk][ut][lk][lr = (a, b)][j]
+    wt_frag = whh.view(G, H4 // 32, 4, 8, 8, 4, UT, 4).permute(0, 4, 1, 6, 2, 5, 7, 3).contiguous()
+    return w_frag, wt_frag
+
+
+def lstm_seq_rows(x_tm, N, H, gates=1):
+    """A tile-major array of the sequence kernels (c_new, ws, cm from slot 1 on: [..., G, N, gates * H] in bytes, laid out
+    [(g, row tile)][wave][gate][lane = (lk, lr)][4 UT]) as row-major [..., G, N, gates * H] (tests, diagnostics)."""
+    UT = H // 128
+    lead = x_tm.shape[:-2]
+    v = x_tm.reshape(*lead, N // 16, 8, gates, 4, 16, 4 * UT)            # [rt][w][q][lk][lr][4 UT]
+    n = len(lead)
+    v = v.permute(*range(n), n, n + 4, n + 2, n + 1, n + 3, n + 5)        # [rt][lr][q][w][lk][4 UT]: unit = 16 UT w + 4 UT lk + e
+    return v.reshape(*lead, N, gates * H)
 
 
 class FusedRecurrentPPOStep(FusedPPOStep):
@@ -46,6 +73,9 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         self.lstm = self._lstm_views(policy._flat, self.half[0])
         # one launch per time step and direction where the hidden size has a fused kernel (MYO_LSTM_TWO_KERNELS=1: GEMM + cell kernel)
         self.step_kernels = bool(lib.L.myo_lstm_step_supported(la.hidden_size)) and os.environ.get("MYO_LSTM_TWO_KERNELS") != "1"
+        # ... and ALL time steps of a minibatch in one launch per direction where the hidden size has a sequence kernel
+        # (csrc/myo_lstm_seq.h; MYO_LSTM_SEQ=0: one launch per time step)
+        self.seq_kernels = self.step_kernels and bool(lib.L.myo_lstm_seq_supported(la.hidden_size)) and os.environ.get("MYO_LSTM_SEQ") != "0"
         return self if self.lstm is not None else None
 
     def _lstm_views(self, flat, hflat):
@@ -119,7 +149,14 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         dG = torch.empty((T, G, m, H4), dtype=bf, device=dev)
         dcm = torch.empty((2, G, m, H), dtype=bf, device=dev)            # ping-pong: gradient of cm[t]
         kp = lambda t: p(keep[t + 1]) if t + 1 < T else None
-        if self.step_kernels:
+        if self.seq_kernels and m % 16 == 0:
+            # the whole sequence = ONE launch per direction (csrc/myo_lstm_seq.h): a workgroup owns 16 sequences from the first step to the last
+            w_frag, wt_frag = lstm_seq_weights(L["whhh"])
+            lib.check(lib.L.myo_lstm_seq_fwd(p(gx), m * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, m, H, T, p(lat), T * m * H,
+                                             m * H, p(cn), p(ws), st))
+            pl, vl, dlat = self._merged_core(lat.view(G, B, H), act, oldlp, adv_mb, ret_mb, want_dx=True)
+            lib.check(lib.L.myo_lstm_seq_bwd(p(dlat), T * m * H, m * H, p(wt_frag), p(keep), p(cm), p(cn), p(ws), G, m, H, T, p(dG), st))
+        elif self.step_kernels:
             # a time step = ONE launch per direction (csrc/myo_lstm_step.h): recurrent product on the matrix cores + cell epilogue;
             # reads gx where the projection GEMM left it and writes the outputs where the trunks read them (no transposes)
             for t in range(T):

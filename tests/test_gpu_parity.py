@@ -1462,6 +1462,83 @@ def test_lstm_step_kernels_match_gemm_plus_cell(hip_lib, H, N):
     assert hip_lib.L.myo_lstm_step_supported(48) == 0 and hip_lib.L.myo_lstm_step_fwd(p(gx_all), 0, 0, p(hp), p(cp), p(whh), None, G, N, 48, p(out2), 0, p(hm2), p(cm2), None, None, None) == -2
 
 
+@pytest.mark.parametrize("H,N,T", [(256, 64, 9), (128, 48, 7), (256, 512, 33)])
+def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T):
+    """myo_lstm_seq_fwd / _bwd (all time steps of a minibatch in one launch per direction, csrc/myo_lstm_seq.h) against T launches of
+    the step kernels on the same inputs — every saved array of the forward pass, the dgates of every step — and, for the end of
+    the sequence, against the fp32 statement of the recurrence (state masked where an episode starts)."""
+    import ctypes as C
+    import torch
+    L = hip_lib.L
+    dev, bf = torch.device("cuda:0"), torch.bfloat16
+    torch.manual_seed(H + N + T)
+    G, H4 = 2, 4 * H
+    mk = lambda *s, sc=1.0: (sc * torch.randn(*s, device=dev)).to(bf)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    gx = mk(T, N, G, H4)                                          # the projection GEMM's layout: row (t, n) = [net 0 gates | net 1 gates]
+    whh = mk(G, H4, H, sc=H ** -0.5)
+    wt = whh.transpose(1, 2).contiguous()
+    keep = (torch.rand(T, N, device=dev) > 0.15).float()
+    h0, c0 = mk(G, N, H, sc=0.5), mk(G, N, H, sc=0.5)
+
+    def state():
+        hm = torch.zeros((T + 1, G, N, H), device=dev, dtype=bf)
+        cm = torch.zeros_like(hm)
+        hm[0], cm[0] = h0, c0
+        return hm, cm, torch.zeros((T, G, N, H), device=dev, dtype=bf), torch.zeros((T, G, N, H4), device=dev, dtype=bf), \
+            torch.zeros((G, T, N, H), device=dev, dtype=bf)
+    hm_a, cm_a, cn_a, ws_a, lat_a = state()
+    for t in range(T):
+        hip_lib.check(L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm_a[t]), p(cm_a[t]), p(whh), p(keep[t + 1]) if t + 1 < T else None, G, N, H,
+                                          p(lat_a[:, t]), T * N * H, p(hm_a[t + 1]), p(cm_a[t + 1]), p(cn_a[t]), p(ws_a[t]), None))
+    from myochallenge_amd.rl.fused_lstm import lstm_seq_rows, lstm_seq_weights
+    w_frag, wt_frag = lstm_seq_weights(whh)
+    hm_b, cm_b, cn_b, ws_b, lat_b = state()
+    hip_lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(w_frag), p(keep), G, N, H, T, p(lat_b), T * N * H, N * H,
+                                     p(cn_b), p(ws_b), None))
+    torch.cuda.synchronize()
+    # the two paths round to bf16 at the same places; they differ by the order of the fp32 sums over K and by tanh's last bits, i.e. by
+    # an occasional bf16 ulp that the recurrence carries on: a few ulps of the largest entry at most, ~1e-3 of it on average
+    def close(got, want, name, worst=4e-2, mean=2e-3):
+        d = (got.float() - want.float()).abs()
+        scale = 1 + float(want.float().abs().max())
+        assert float(d.max()) <= worst * scale and float(d.mean()) <= mean * scale, (name, float(d.max()), float(d.mean()), scale)
+    # (the arrays only the sequence kernels read are tile-major, csrc/myo_lstm_seq.h: cm from slot 1 on, c_new, ws)
+    for name, a, b in (("lat", lat_a, lat_b), ("hm", hm_a, hm_b), ("cm", cm_a[1:], lstm_seq_rows(cm_b[1:], N, H)),
+                       ("cn", cn_a, lstm_seq_rows(cn_b, N, H)), ("ws", ws_a, lstm_seq_rows(ws_b, N, H, 4))):
+        close(b, a, name)
+    assert torch.equal(cm_b[0], c0) and torch.equal(hm_b[0], h0)
+    # fp32 statement of the whole recurrence
+    h, c = h0.float(), c0.float()
+    for t in range(T):
+        a_ = gx[t].float().transpose(0, 1) + torch.bmm(h, whh.float().transpose(1, 2))
+        i, f, g, o = torch.sigmoid(a_[..., :H]), torch.sigmoid(a_[..., H:2 * H]), torch.tanh(a_[..., 2 * H:3 * H]), torch.sigmoid(a_[..., 3 * H:])
+        c = f * c + i * g
+        hh = o * torch.tanh(c)
+        close(lat_b[:, t], hh, "lat vs fp32, t=%d" % t, worst=8e-2, mean=8e-3)
+        k = keep[t + 1].view(1, N, 1) if t + 1 < T else 1.0
+        h, c = hh * k, c * k
+    # backward: each path from its own forward pass's saved arrays
+    dlat = mk(G, T, N, H, sc=0.5)
+    dG_a, dG_b = torch.zeros((T, G, N, H4), device=dev, dtype=bf), torch.zeros((T, G, N, H4), device=dev, dtype=bf)
+    dcm = torch.zeros((2, G, N, H), device=dev, dtype=bf)
+    for t in range(T - 1, -1, -1):
+        last = t == T - 1
+        hip_lib.check(L.myo_lstm_step_bwd(p(dlat[:, t]), T * N * H, None if last else p(dG_a[t + 1]), None if last else p(dcm[(t + 1) & 1]),
+                                          p(wt), p(keep[t + 1]) if not last else None, p(cm_a[t]), p(cn_a[t]), p(ws_a[t]), G, N, H, p(dG_a[t]),
+                                          p(dcm[t & 1]), None))
+    hip_lib.check(L.myo_lstm_seq_bwd(p(dlat), T * N * H, N * H, p(wt_frag), p(keep), p(cm_b), p(cn_b), p(ws_b), G, N, H, T, p(dG_b), None))
+    torch.cuda.synchronize()
+    close(dG_b, dG_a, "dgates")
+    assert float(dG_b.float().abs().max()) > 0.05                 # (a gradient did flow)
+    # unsupported sizes are refused, not mis-run
+    assert L.myo_lstm_seq_supported(64) == 0 and L.myo_lstm_seq_supported(256) == 1
+    assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N, 64, T, p(lat_b), T * N * H, N * H, p(cn_b),
+                              p(ws_b), None) == -2
+    assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N - 1, H, T, p(lat_b), T * N * H, N * H, p(cn_b),
+                              p(ws_b), None) == -1
+
+
 def test_gsde_sampling_kernel_matches_torch(hip_lib):
     """myo_rollout_sample_sde against the torch statement of SB3's state-dependent noise distribution."""
     import ctypes as C

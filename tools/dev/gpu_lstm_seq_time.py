@@ -1,0 +1,83 @@
+"""Developer timing: the LSTM recurrence of one recurrent-PPO minibatch (T steps, m sequences, G = 2 LSTMs) as T step-kernel launches
+(captured in a graph, as the training step runs them) against the sequence kernels.  python tools/dev/gpu_lstm_seq_time.py [H] [m] [T] [library]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: E402
+from myochallenge_amd import native  # noqa: E402
+from myochallenge_amd.rl.fused_lstm import lstm_seq_weights  # noqa: E402
+
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 128
+lib = native.load(os.path.abspath(sys.argv[4])) if len(sys.argv) > 4 else native.load()
+L = lib.L
+dev, bf = torch.device("cuda:0"), torch.bfloat16
+G, H4 = 2, 4 * H
+mk = lambda *s, sc=1.0: (sc * torch.randn(*s, device=dev)).to(bf)
+p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+gx, whh = mk(T, N, G, H4), mk(G, H4, H, sc=H ** -0.5)
+wt = whh.transpose(1, 2).contiguous()
+w_frag, wt_frag = lstm_seq_weights(whh)
+keep = (torch.rand(T, N, device=dev) > 0.05).float()
+hm, cm = torch.zeros((T + 1, G, N, H), device=dev, dtype=bf), torch.zeros((T + 1, G, N, H), device=dev, dtype=bf)
+cn, ws = torch.zeros((T, G, N, H), device=dev, dtype=bf), torch.zeros((T, G, N, H4), device=dev, dtype=bf)
+lat, dlat = torch.zeros((G, T, N, H), device=dev, dtype=bf), mk(G, T, N, H, sc=0.5)
+dG, dcm = torch.zeros((T, G, N, H4), device=dev, dtype=bf), torch.zeros((2, G, N, H), device=dev, dtype=bf)
+
+
+def steps_fwd(st):
+    for t in range(T):
+        lib.check(L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm[t]), p(cm[t]), p(whh), p(keep[t + 1]) if t + 1 < T else None, G, N, H,
+                                      p(lat[:, t]), T * N * H, p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+
+
+def steps_bwd(st):
+    for t in range(T - 1, -1, -1):
+        last = t == T - 1
+        lib.check(L.myo_lstm_step_bwd(p(dlat[:, t]), T * N * H, None if last else p(dG[t + 1]), None if last else p(dcm[(t + 1) & 1]), p(wt),
+                                      p(keep[t + 1]) if not last else None, p(cm[t]), p(cn[t]), p(ws[t]), G, N, H, p(dG[t]), p(dcm[t & 1]), st))
+
+
+def seq_fwd(st):
+    lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, N, H, T, p(lat), T * N * H, N * H, p(cn), p(ws), st))
+
+
+def seq_bwd(st):
+    lib.check(L.myo_lstm_seq_bwd(p(dlat), T * N * H, N * H, p(wt_frag), p(keep), p(cm), p(cn), p(ws), G, N, H, T, p(dG), st))
+
+
+def timed(fn, name, graph):
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        st = C.c_void_p(side.cuda_stream)
+        fn(st)
+        side.synchronize()
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                fn(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            run = g.replay
+        else:
+            run = lambda: fn(st)
+        for _ in range(2):
+            run()
+        side.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(5):
+            run()
+        e1.record(side)
+        side.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print("%-28s %8.3f ms  = %6.2f us per time step" % (name, ms, 1e3 * ms / T), flush=True)
+
+
+print("H %d, %d sequences, T %d, G %d" % (H, N, T, G))
+timed(steps_fwd, "step kernels forward (graph)", True)
+timed(steps_bwd, "step kernels backward (graph)", True)
+if L.myo_lstm_seq_supported(H):
+    timed(seq_fwd, "sequence kernel forward", False)
+    timed(seq_bwd, "sequence kernel backward", False)

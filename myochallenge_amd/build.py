@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h", "myo_mjb.h", "mjb_layout.inc",
-           "myo_ppo_mlp.h", "myo_sparse_ldl.h", "myo_arrow_chol.h", "myo_lstm_step.h"]
+           "myo_ppo_mlp.h", "myo_sparse_ldl.h", "myo_arrow_chol.h", "myo_lstm_step.h", "myo_lstm_seq.h"]
 HEADERS = [os.path.join(ROOT, "include", "myobatch.h"), os.path.join(ROOT, "include", "myo_model_blob.h")]
 
 

@@ -340,24 +340,25 @@ int myo_lstm_step_bwd(const void* dout, long long dout_sg, const void* dgates_ne
  * PPO minibatch step runs instead of T myo_lstm_step_fwd + T myo_lstm_step_bwd launches (RecurrentPPO.train,
  * /root/reference/src/train/trainer.py:49-71; sb3-contrib _process_sequence).  H in {128, 256} (myo_lstm_seq_supported), N a
  * multiple of 16 (MYO_E_ARG otherwise: the caller keeps the step kernels).  Same roundings as the step kernels.
+ * row_split RS in {1, 2} (and 4 at H = 256): a workgroup owns 16 / RS sequences — more, smaller workgroups for small minibatches.
  * The recurrent weights are passed FRAGMENT-MAJOR (one contiguous KB per wave load; permuted from W_hh [G,4H,H] by the caller,
- * once per minibatch step — rl/fused_lstm.py lstm_seq_weights):
- * with UT = H/128 tiles of 16 units per wave, eight waves, unit(w, ut, i) = 16*UT*w + 4*UT*(i/4) + 4*ut + i%4:
+ * once per minibatch step — rl/fused_lstm.py lstm_seq_weights(W_hh, RS)).  With UT = H/128 tiles of 16 units per wave, eight waves,
+ * CL = 4*UT/RS, b = i%4 and unit(w, ut, i) = 16*UT*w + 4*UT*(i/4) + CL*(b/(4/RS)) + (4/RS)*ut + b%(4/RS):
  *   w_frag  bf16 [G][8][H/32][4][UT][64][8]:  w_frag[g][w][kk][q][ut][l][j] = W_hh[g][q*H + unit(w, ut, l&15)][32*kk + 8*(l>>4) + j]
  *   wt_frag bf16 [G][8][4H/32][UT][64][8]:   wt_frag[g][w][kk][ut][l][j]   = W_hh[g][32*kk + 8*(l>>4) + j][unit(w, ut, l&15)]
  * The arrays only these two calls exchange — c_new, ws, and cm from slot 1 on — are TILE-MAJOR (same sizes as the row-major
- * shapes below; [(g, r/16)][wave 8][gate][lane 64][4*UT], csrc/myo_lstm_seq.h; rl/fused_lstm.py lstm_seq_rows converts).
+ * shapes below; [(g, r/(16/RS))][wave 8][gate][lane 64][CL], csrc/myo_lstm_seq.h; rl/fused_lstm.py lstm_seq_rows converts).
  * fwd: gx element (t, g, r, col) at gx[t*gx_st + g*gx_sg + r*gx_sr + col]; hm / cm bf16 [T+1,G,N,H]: slot 0 = the masked state
- *      entering step 0 (given, row-major), slots 1..T written (hm row-major, cm tile-major); keep float32 [T,N] (0 where an episode starts at that step: step t masks its
- *      outgoing state with keep[t+1], the last step with 1); out_h element (g, t, r, u) at out_h[g*out_sg + t*out_st + r*H + u];
- *      c_new [T,G,N,H], ws [T,G,N,4H] (gate activations) kept for the backward pass.
- * bwd: dout laid out like out_h; keep / cm / c_new / ws as the forward pass left them -> dgates [T,G,N,4H]. */
+ *      entering step 0 (given, row-major), slots 1..T written (hm row-major, cm tile-major); keep float32 [T,N] (0 where an episode
+ *      starts at that step: step t masks its outgoing state with keep[t+1], the last step with 1); out_h element (g, t, r, u) at
+ *      out_h[g*out_sg + t*out_st + r*H + u]; c_new [T,G,N,H], ws [T,G,N,4H] (gate activations) kept for the backward pass.
+ * bwd: dout laid out like out_h; keep / cm / c_new / ws as the forward pass left them -> dgates [T,G,N,4H] (row-major). */
 int myo_lstm_seq_supported(int H);
 int myo_lstm_seq_fwd(const void* gx, long long gx_st, long long gx_sg, long long gx_sr, void* hm, void* cm, const void* w_frag,
-                     const float* keep, int G, int N, int H, int T, void* out_h, long long out_sg, long long out_st, void* c_new,
-                     void* ws, void* stream);
+                     const float* keep, int G, int N, int H, int T, int row_split, void* out_h, long long out_sg, long long out_st,
+                     void* c_new, void* ws, void* stream);
 int myo_lstm_seq_bwd(const void* dout, long long dout_sg, long long dout_st, const void* wt_frag, const float* keep, const void* cm,
-                     const void* c_new, const void* ws, int G, int N, int H, int T, void* dgates, void* stream);
+                     const void* c_new, const void* ws, int G, int N, int H, int T, int row_split, void* dgates, void* stream);
 
 /* GAE(gamma, lambda) backward scan = SB3 RolloutBuffer.compute_returns_and_advantage (run by
  * RecurrentPPO.learn, /root/reference/src/train/trainer.py:66-71).  dev float32 [T,N] row-major:

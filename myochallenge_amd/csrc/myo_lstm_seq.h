@@ -24,7 +24,7 @@
 // tile), as in myo_lstm_step.h: a lane (lr = lane & 15, lk = lane >> 4) ends up with rows 4 lk .. 4 lk + 3 of every tile for row lr
 // of the minibatch, all four gates in its own registers — the cell arithmetic needs no exchange.  WHICH units a tile's rows are is
 // free (the permutation of W's rows): wave w has UT = H / 128 tiles and row i of its tile ut is unit
-//   unit(w, ut, i) = 16 UT w + 4 UT (i / 4) + 4 ut + (i % 4),
+//   unit(w, ut, i) = 16 UT w + 4 UT (i / 4) + 4 ut + (i % 4)                      (RS = 1; the general form: below)
 // so that a lane's 4 UT units are CONSECUTIVE (u0 = 16 UT w + 4 UT lk): 16-byte accesses and 64-byte row segments at H = 256.
 //   forward:  w_frag[g][w][kk][q][ut][lane][j] = W_hh[g][q H + unit(w, ut, lane & 15)][32 kk + 8 (lane >> 4) + j]      (kk < H / 32)
 //   backward: wt_frag[g][w][kk][ut][lane][j]   = W_hh[g][32 kk + 8 (lane >> 4) + j][unit(w, ut, lane & 15)]           (kk < 4H / 32)
@@ -35,6 +35,12 @@
 //   x_tm [t][g][rt][w][lane][4 UT]  and  ws_tm [t][g][rt][w][q][lane][4 UT]      (rt = row / 16; same sizes as [T, G, N, H] / [T, G, N, 4H])
 // and the row-major ones other kernels read or write go through the LDS tiles where one exists: hm (the h tile) and dgates (the
 // dgates tile) leave as whole rows, 16 bytes a lane; out_h / gx / dout are accessed in place, 4 UT units a lane.
+// The cell arithmetic is what a step costs once the weights are on the CU (~110 VALU instructions a unit with ten transcendentals, on
+// eight waves): a workgroup may therefore own FEWER rows, 16 / RS with RS = 1, 2 or 4 (more workgroups, more CUs).  The MFMA's 16
+// columns then hold every row RS times (lane lr reads tile row lr % (16 / RS)), so RS lanes end up with the same four units of the
+// same row — and lane copy s = lr / (16 / RS) takes the s-th 4 / RS of them: no cross-lane traffic, 1 / RS of the arithmetic a lane.
+// With CL = 4 UT / RS cells a lane and unit(w, ut, i) = 16 UT w + 4 UT (i / 4) + CL (b / (4 / RS)) + (4 / RS) ut + b % (4 / RS), b = i % 4,
+// a lane's cells are still consecutive units (u0 = 16 UT w + 4 UT lk + CL s); tile-major: x_tm[(g, row tile)][w][lane][CL].
 // Roundings are those of the step kernels (state and gate activations in bf16, fp32 accumulation); the order of the fp32 sums and
 // the last bits of tanh / sigmoid differ.
 #pragma once
@@ -77,6 +83,20 @@ template <int H> struct LstmSeqCfg {
 // eight of its results are rounded to bf16)
 typedef __attribute__((ext_vector_type(2))) __bf16 lstm_seq_bf2;
 typedef __attribute__((ext_vector_type(2))) float lstm_seq_f2;
+template <int H, int RS> struct LstmSeqRows {
+  static_assert(RS == 1 || RS == 2 || (RS == 4 && H == 256), "row split: 1, 2, or 4 at H = 256 (a lane keeps at least two cells)");
+  static constexpr int ROWS = 16 / RS;              // rows (sequences) per workgroup
+  static constexpr int CL = 4 * (H / 128) / RS;     // cells (consecutive units) per lane
+  static constexpr int BPU = 4 / RS;                // D rows per lane copy and unit tile
+  static constexpr size_t F_LDS = ((size_t)ROWS * LstmSeqCfg<H>::FSTR + (size_t)8 * LstmSeqCfg<H>::FL * 512) * 2;
+  static constexpr size_t B_LDS = ((size_t)ROWS * LstmSeqCfg<H>::BSTR + (size_t)8 * LstmSeqCfg<H>::BL * 512) * 2;
+};
+// D row b = BPU s + blo of a lane's four: a register index that depends on the lane copy s -> selects
+template <int RS> __device__ __forceinline__ float lstm_seq_pick(const myo_f32x4& a, int s, int blo) {
+  if constexpr (RS == 1) return a[blo];
+  else if constexpr (RS == 2) return s ? a[2 + blo] : a[blo];
+  else return (s & 2) ? ((s & 1) ? a[3] : a[2]) : ((s & 1) ? a[1] : a[0]);
+}
 __device__ __forceinline__ unsigned lstm_seq_pk(float a, float b) {
   const lstm_seq_bf2 v = __builtin_convertvector(lstm_seq_f2{a, b}, lstm_seq_bf2);
   return *reinterpret_cast<const unsigned*>(&v);
@@ -92,8 +112,8 @@ __device__ __forceinline__ float lstm_seq_sigmoid(float x) { return __builtin_am
 // s_barrier: every global store of the step acknowledged, twice a step, ~1 us each — and nothing in these loops hands GLOBAL data
 // from one wave to another
 __device__ __forceinline__ void lstm_seq_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// a lane's 4 UT bf16 values of one array: 8 or 16 bytes
-template <int UT> struct LstmSeqVec { typedef unsigned short type __attribute__((ext_vector_type(4 * UT))); };
+// a lane's CL bf16 values of one array: 4, 8 or 16 bytes
+template <int UT> struct LstmSeqVec { typedef unsigned short type __attribute__((ext_vector_type(UT))); };
 template <int UT> __device__ __forceinline__ typename LstmSeqVec<UT>::type lstm_seq_ldv(const unsigned short* p) {
   return *reinterpret_cast<const typename LstmSeqVec<UT>::type*>(p);
 }
@@ -106,21 +126,22 @@ template <int UT> __device__ __forceinline__ void lstm_seq_stv(unsigned short* p
 // keep [T, N] (0 where an episode starts at that step; step t masks with keep[t + 1], the last step with 1); out_h element
 // (g, t, r, u) at out_h[g out_sg + t out_st + r H + u]; c_new [T, G, N, H], ws [T, G, N, 4H] tile-major.
 // N a multiple of 16.  Grid (N / 16, G), 8 waves, LstmSeqCfg<H>::F_LDS bytes of dynamic LDS.
-template <int H>
+template <int H, int RS>
 __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
     const unsigned short* __restrict__ gx, long long gx_st, long long gx_sg, long long gx_sr, unsigned short* __restrict__ hm,
     unsigned short* __restrict__ cm, const unsigned short* __restrict__ w_frag, const float* __restrict__ keep, int N, int T,
     unsigned short* __restrict__ out_h, long long out_sg, long long out_st, unsigned short* __restrict__ c_new,
     unsigned short* __restrict__ ws) {
   typedef LstmSeqCfg<H> Cf;
-  constexpr int UT = Cf::UT, NF = Cf::FFRAG, NT = Cf::FN, SB = Cf::FSB, NL = Cf::FL, NR = Cf::FR, NV = 4 * UT;
-  typedef typename LstmSeqVec<UT>::type vec;
+  typedef LstmSeqRows<H, RS> Rw;
+  constexpr int UT = Cf::UT, NF = Cf::FFRAG, NT = Cf::FN, SB = Cf::FSB, NL = Cf::FL, NR = Cf::FR, NV = Rw::CL, ROWS = Rw::ROWS, BPU = Rw::BPU;
+  typedef typename LstmSeqVec<NV>::type vec;
   extern __shared__ __attribute__((aligned(16))) unsigned short lstm_seq_lds[];
-  unsigned short* hbuf = lstm_seq_lds;                                  // [16 * FSTR]
+  unsigned short* hbuf = lstm_seq_lds;                                  // [ROWS * FSTR]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned short* wl = lstm_seq_lds + 16 * Cf::FSTR + (size_t)wave * NL * 512 + lane * 8;      // this wave's L tier
-  const int g = blockIdx.y, G = gridDim.y, row0 = blockIdx.x * 16;
-  const int lr = lane & 15, lk = lane >> 4;
+  unsigned short* wl = lstm_seq_lds + ROWS * Cf::FSTR + (size_t)wave * NL * 512 + lane * 8;      // this wave's L tier
+  const int g = blockIdx.y, G = gridDim.y, row0 = blockIdx.x * ROWS;
+  const int lr = (lane & 15) % ROWS, sc = (lane & 15) / ROWS, lk = lane >> 4;       // tile row, lane copy, D row quad
   const int r = row0 + lr;
   const size_t GNH = (size_t)G * N * H;
   // fragment (kk, q, ut) of this wave: the KB at ((kk 4 + q) UT + ut) 512 + lane 8 of its block
@@ -135,25 +156,25 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
   // whole rows of the 16-row tile, 16 bytes a thread: hm[0] -> LDS here, the LDS tile -> hm[t + 1] after every step
   constexpr int CPR = H / 8;                                           // 16-byte chunks per row
   const int c_row = threadIdx.x / CPR, c_col = (threadIdx.x % CPR) * 8;
-  const bool c_on = threadIdx.x < 16 * CPR;                            // (H = 128: half of the threads; H = 256: all)
+  const bool c_on = threadIdx.x < ROWS * CPR;
   const unsigned c_off = (unsigned)(((size_t)g * N + row0 + c_row) * H + c_col);
   if (c_on) *reinterpret_cast<myo_bf16x8*>(&hbuf[c_row * Cf::FSTR + c_col]) = lstm_ld8(hm + c_off);
   // per-lane offsets are 32-bit with a uniform 64-bit base per array and step: `global_* v, v_off, s[base]`
-  const int u0 = (wave * 16 + 4 * lk) * UT;                            // this lane's NV consecutive units
+  const int u0 = (wave * 16 + 4 * lk) * UT + sc * NV;                  // this lane's NV consecutive units
   const unsigned oh = (unsigned)((size_t)r * H + u0), ox = (unsigned)((size_t)r * gx_sr + u0);
   // tile-major: x_tm[(g, rt)][w][lane][NV], ws_tm[(g, rt)][w][q][lane][NV]
-  const unsigned ot = (unsigned)((((size_t)g * (N / 16) + blockIdx.x) * 8 + wave) * 64 * NV + lane * NV);
-  const unsigned otw = (unsigned)((((size_t)g * (N / 16) + blockIdx.x) * 8 + wave) * 4 * 64 * NV + lane * NV);
+  const unsigned ot = (unsigned)((((size_t)g * (N / ROWS) + blockIdx.x) * 8 + wave) * 64 * NV + lane * NV);
+  const unsigned otw = (unsigned)((((size_t)g * (N / ROWS) + blockIdx.x) * 8 + wave) * 4 * 64 * NV + lane * NV);
   float cp[NV];
   {
-    const vec cpv = lstm_seq_ldv<UT>(cm + (size_t)g * N * H + oh);    // slot 0: row-major
+    const vec cpv = lstm_seq_ldv<NV>(cm + (size_t)g * N * H + oh);    // slot 0: row-major
 #pragma unroll
     for (int i = 0; i < NV; ++i) cp[i] = lstm_bf(cpv[i]);
   }
   vec xn[4];
   if constexpr (Cf::PREFETCH) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) xn[q] = lstm_seq_ldv<UT>(gx + (size_t)g * gx_sg + ox + q * H);
+    for (int q = 0; q < 4; ++q) xn[q] = lstm_seq_ldv<NV>(gx + (size_t)g * gx_sg + ox + q * H);
   }
   __syncthreads();
   for (int t = 0; t < T; ++t) {
@@ -166,10 +187,10 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
     if constexpr (Cf::PREFETCH) {                    // this step's were loaded a step ago; the next step's go out now (gx is behind HBM)
       const unsigned short* gxn = gx + (size_t)(t + 1 < T ? t + 1 : t) * gx_st + (size_t)g * gx_sg;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { x[q] = xn[q]; xn[q] = lstm_seq_ldv<UT>(gxn + ox + q * H); }
+      for (int q = 0; q < 4; ++q) { x[q] = xn[q]; xn[q] = lstm_seq_ldv<NV>(gxn + ox + q * H); }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) x[q] = lstm_seq_ldv<UT>(gxt + ox + q * H);
+      for (int q = 0; q < 4; ++q) x[q] = lstm_seq_ldv<NV>(gxt + ox + q * H);
     }
     const float k = t + 1 < T ? keep[(size_t)(t + 1) * N + r] : 1.f;
     myo_f32x4 acc[4][UT];
@@ -209,11 +230,11 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
       float vi[2], vf[2], vg[2], vo[2], c[2], h[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const int i = 2 * p2 + s, ut = i / 4, j = i % 4;
-        vi[s] = lstm_seq_sigmoid(lstm_bf(x[0][i]) + acc[0][ut][j]);
-        vf[s] = lstm_seq_sigmoid(lstm_bf(x[1][i]) + acc[1][ut][j]);
-        vg[s] = lstm_seq_tanh(lstm_bf(x[2][i]) + acc[2][ut][j]);
-        vo[s] = lstm_seq_sigmoid(lstm_bf(x[3][i]) + acc[3][ut][j]);
+        const int i = 2 * p2 + s, ut = i / BPU, j = i % BPU;
+        vi[s] = lstm_seq_sigmoid(lstm_bf(x[0][i]) + lstm_seq_pick<RS>(acc[0][ut], sc, j));
+        vf[s] = lstm_seq_sigmoid(lstm_bf(x[1][i]) + lstm_seq_pick<RS>(acc[1][ut], sc, j));
+        vg[s] = lstm_seq_tanh(lstm_bf(x[2][i]) + lstm_seq_pick<RS>(acc[2][ut], sc, j));
+        vo[s] = lstm_seq_sigmoid(lstm_bf(x[3][i]) + lstm_seq_pick<RS>(acc[3][ut], sc, j));
         c[s] = vf[s] * cp[i] + vi[s] * vg[s];
         h[s] = vo[s] * lstm_seq_tanh(c[s]);
       }
@@ -223,15 +244,15 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
       cp[2 * p2] = lstm_seq_lo(cmv[p2]); cp[2 * p2 + 1] = lstm_seq_hi(cmv[p2]);
     }
     auto V = [](const unsigned (&w)[NV / 2]) -> const vec& { return *reinterpret_cast<const vec*>(w); };
-    lstm_seq_stv<UT>(&hbuf[lr * Cf::FSTR + u0], V(hmv));
-    lstm_seq_stv<UT>(out_h + (size_t)g * out_sg + (size_t)t * out_st + oh, V(hv));
-    lstm_seq_stv<UT>(cm + (size_t)(t + 1) * GNH + ot, V(cmv));
-    lstm_seq_stv<UT>(c_new + (size_t)t * GNH + ot, V(cnv));
+    lstm_seq_stv<NV>(&hbuf[lr * Cf::FSTR + u0], V(hmv));
+    lstm_seq_stv<NV>(out_h + (size_t)g * out_sg + (size_t)t * out_st + oh, V(hv));
+    lstm_seq_stv<NV>(cm + (size_t)(t + 1) * GNH + ot, V(cmv));
+    lstm_seq_stv<NV>(c_new + (size_t)t * GNH + ot, V(cnv));
     unsigned short* wst = ws + (size_t)t * 4 * GNH + otw;
-    lstm_seq_stv<UT>(wst, V(iv));
-    lstm_seq_stv<UT>(wst + 64 * NV, V(fv));
-    lstm_seq_stv<UT>(wst + 2 * 64 * NV, V(gv));
-    lstm_seq_stv<UT>(wst + 3 * 64 * NV, V(ov));
+    lstm_seq_stv<NV>(wst, V(iv));
+    lstm_seq_stv<NV>(wst + 64 * NV, V(fv));
+    lstm_seq_stv<NV>(wst + 2 * 64 * NV, V(gv));
+    lstm_seq_stv<NV>(wst + 3 * 64 * NV, V(ov));
     lstm_seq_barrier();
     if (c_on) *reinterpret_cast<myo_bf16x8*>(hm + (size_t)(t + 1) * GNH + c_off) = *reinterpret_cast<const myo_bf16x8*>(&hbuf[c_row * Cf::FSTR + c_col]);
   }
@@ -242,20 +263,21 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
 // dc = keep[t + 1] dc_prev_{t+1} + dh o (1 - tanh^2 c_new) -> dgates_t, dc_prev_t (the last step: no product, keep = 1).
 // LstmSeqCfg<H>::B_LDS bytes of dynamic LDS (ONE dgates tile: the step's product reads it, a barrier, the step's epilogue rewrites it,
 // a barrier, and it leaves for dgates[t] as whole rows).
-template <int H>
+template <int H, int RS>
 __global__ void __launch_bounds__(512) k_lstm_seq_bwd(
     const unsigned short* __restrict__ dout, long long dout_sg, long long dout_st, const unsigned short* __restrict__ wt_frag,
     const float* __restrict__ keep, const unsigned short* __restrict__ cm, const unsigned short* __restrict__ c_new,
     const unsigned short* __restrict__ ws, int N, int T, unsigned short* __restrict__ dgates) {
   typedef LstmSeqCfg<H> Cf;
-  constexpr int UT = Cf::UT, NF = Cf::BFRAG, NT = Cf::BN, SB = Cf::BSB, NL = Cf::BL, NR = Cf::BR, NV = 4 * UT;
-  typedef typename LstmSeqVec<UT>::type vec;
+  typedef LstmSeqRows<H, RS> Rw;
+  constexpr int UT = Cf::UT, NF = Cf::BFRAG, NT = Cf::BN, SB = Cf::BSB, NL = Cf::BL, NR = Cf::BR, NV = Rw::CL, ROWS = Rw::ROWS, BPU = Rw::BPU;
+  typedef typename LstmSeqVec<NV>::type vec;
   extern __shared__ __attribute__((aligned(16))) unsigned short lstm_seq_lds[];
-  unsigned short* dgbuf = lstm_seq_lds;                                 // [16 * BSTR]
+  unsigned short* dgbuf = lstm_seq_lds;                                 // [ROWS * BSTR]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned short* wl = lstm_seq_lds + 16 * Cf::BSTR + (size_t)wave * NL * 512 + lane * 8;
-  const int g = blockIdx.y, G = gridDim.y, row0 = blockIdx.x * 16;
-  const int lr = lane & 15, lk = lane >> 4;
+  unsigned short* wl = lstm_seq_lds + ROWS * Cf::BSTR + (size_t)wave * NL * 512 + lane * 8;
+  const int g = blockIdx.y, G = gridDim.y, row0 = blockIdx.x * ROWS;
+  const int lr = (lane & 15) % ROWS, sc = (lane & 15) / ROWS, lk = lane >> 4;       // tile row, lane copy, D row quad
   const int r = row0 + lr;
   const size_t GNH = (size_t)G * N * H;
   // fragment (kk, ut) of this wave: the KB at (kk UT + ut) 512 + lane 8 of its block
@@ -267,12 +289,12 @@ __global__ void __launch_bounds__(512) k_lstm_seq_bwd(
   for (int f = 0; f < NL; ++f) *reinterpret_cast<myo_bf16x8*>(wl + f * 512) = lstm_ld8(W + (2 * SB + f) * 512);
 #pragma unroll
   for (int f = 0; f < NR; ++f) ar[f] = lstm_ld8(W + (2 * SB + NL + f) * 512);
-  const int u0 = (wave * 16 + 4 * lk) * UT;                            // (offsets: see the forward kernel)
+  const int u0 = (wave * 16 + 4 * lk) * UT + sc * NV;                  // (offsets: see the forward kernel)
   const unsigned oh = (unsigned)((size_t)r * H + u0);
-  const unsigned ot = (unsigned)((((size_t)g * (N / 16) + blockIdx.x) * 8 + wave) * 64 * NV + lane * NV);
-  const unsigned otw = (unsigned)((((size_t)g * (N / 16) + blockIdx.x) * 8 + wave) * 4 * 64 * NV + lane * NV);
-  // the dgates tile leaves as whole rows: 4H / 8 chunks of 16 bytes a row, 16 rows, 512 threads -> H / 64 chunks a thread
-  constexpr int CPT = H / 64;
+  const unsigned ot = (unsigned)((((size_t)g * (N / ROWS) + blockIdx.x) * 8 + wave) * 64 * NV + lane * NV);
+  const unsigned otw = (unsigned)((((size_t)g * (N / ROWS) + blockIdx.x) * 8 + wave) * 4 * 64 * NV + lane * NV);
+  // the dgates tile leaves as whole rows: 4H / 8 chunks of 16 bytes a row, ROWS rows, 512 threads -> ROWS H / 1024 chunks a thread
+  constexpr int CPT = ROWS * H / 1024;
   float dcn[NV];                                     // dc_prev of step t + 1 (bf16-rounded, as the step kernels keep it)
 #pragma unroll
   for (int i = 0; i < NV; ++i) dcn[i] = 0.f;
@@ -282,10 +304,10 @@ __global__ void __launch_bounds__(512) k_lstm_seq_bwd(
     const int tt = T - 1;
     const unsigned short* wst = ws + (size_t)tt * 4 * GNH + otw;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wn[q] = lstm_seq_ldv<UT>(wst + q * 64 * NV);
-    cnn = lstm_seq_ldv<UT>(c_new + (size_t)tt * GNH + ot);
-    cpn = tt > 0 ? lstm_seq_ldv<UT>(cm + (size_t)tt * GNH + ot) : lstm_seq_ldv<UT>(cm + (size_t)g * N * H + oh);
-    don = lstm_seq_ldv<UT>(dout + (size_t)g * dout_sg + (size_t)tt * dout_st + oh);
+    for (int q = 0; q < 4; ++q) wn[q] = lstm_seq_ldv<NV>(wst + q * 64 * NV);
+    cnn = lstm_seq_ldv<NV>(c_new + (size_t)tt * GNH + ot);
+    cpn = tt > 0 ? lstm_seq_ldv<NV>(cm + (size_t)tt * GNH + ot) : lstm_seq_ldv<NV>(cm + (size_t)g * N * H + oh);
+    don = lstm_seq_ldv<NV>(dout + (size_t)g * dout_sg + (size_t)tt * dout_st + oh);
   }
   __syncthreads();
   for (int t = T - 1; t >= 0; --t) {
@@ -296,10 +318,10 @@ __global__ void __launch_bounds__(512) k_lstm_seq_bwd(
     auto load_ops = [&](int tt, vec (&w4)[4], vec& cn1, vec& cp1, vec& do1) {
       const unsigned short* wst = ws + (size_t)tt * 4 * GNH + otw;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) w4[q] = lstm_seq_ldv<UT>(wst + q * 64 * NV);
-      cn1 = lstm_seq_ldv<UT>(c_new + (size_t)tt * GNH + ot);
-      cp1 = tt > 0 ? lstm_seq_ldv<UT>(cm + (size_t)tt * GNH + ot) : lstm_seq_ldv<UT>(cm + (size_t)g * N * H + oh);      // (slot 0: row-major)
-      do1 = lstm_seq_ldv<UT>(dout + (size_t)g * dout_sg + (size_t)tt * dout_st + oh);
+      for (int q = 0; q < 4; ++q) w4[q] = lstm_seq_ldv<NV>(wst + q * 64 * NV);
+      cn1 = lstm_seq_ldv<NV>(c_new + (size_t)tt * GNH + ot);
+      cp1 = tt > 0 ? lstm_seq_ldv<NV>(cm + (size_t)tt * GNH + ot) : lstm_seq_ldv<NV>(cm + (size_t)g * N * H + oh);      // (slot 0: row-major)
+      do1 = lstm_seq_ldv<NV>(dout + (size_t)g * dout_sg + (size_t)tt * dout_st + oh);
     };
     if constexpr (Cf::PREFETCH) {                    // (as in the forward kernel)
 #pragma unroll
@@ -345,7 +367,7 @@ __global__ void __launch_bounds__(512) k_lstm_seq_bwd(
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const int i = 2 * p2 + s;
-        const float dh = lstm_bf(dov[i]) + k * acc[i / 4][i % 4];
+        const float dh = lstm_bf(dov[i]) + k * lstm_seq_pick<RS>(acc[i / BPU], sc, i % BPU);
         const float vi = lstm_bf(wv[0][i]), vf = lstm_bf(wv[1][i]), vg = lstm_bf(wv[2][i]), vo = lstm_bf(wv[3][i]);
         const float tc = lstm_seq_tanh(lstm_bf(cnv[i]));
         const float dct = k * dcn[i] + dh * vo * (1.f - tc * tc);
@@ -361,9 +383,9 @@ __global__ void __launch_bounds__(512) k_lstm_seq_bwd(
     }
     auto V = [](const unsigned (&w)[NV / 2]) -> const vec& { return *reinterpret_cast<const vec*>(w); };
     unsigned short* dl = dgbuf + lr * Cf::BSTR + u0;
-    lstm_seq_stv<UT>(dl, V(d_i)); lstm_seq_stv<UT>(dl + H, V(d_f)); lstm_seq_stv<UT>(dl + 2 * H, V(d_g)); lstm_seq_stv<UT>(dl + 3 * H, V(d_o));
+    lstm_seq_stv<NV>(dl, V(d_i)); lstm_seq_stv<NV>(dl + H, V(d_f)); lstm_seq_stv<NV>(dl + 2 * H, V(d_g)); lstm_seq_stv<NV>(dl + 3 * H, V(d_o));
     lstm_seq_barrier();
-    unsigned short* dgt = dgates + (size_t)t * 4 * GNH + ((size_t)g * N + row0) * 4 * H;      // (uniform: the tile's 16 rows are contiguous)
+    unsigned short* dgt = dgates + (size_t)t * 4 * GNH + ((size_t)g * N + row0) * 4 * H;      // (uniform: the tile's rows are contiguous)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int ch = c * 512 + threadIdx.x, rr = ch / (H / 2), cc = (ch % (H / 2)) * 8;       // chunk ch of 16 x 4H / 8
@@ -379,23 +401,25 @@ static int lstm_seq_lds_attr(K kernel, size_t lds, bool* done) {     // above th
   *done = true;
   return 0;
 }
-template <int H>
+template <int H, int RS>
 static int lstm_seq_fwd_launch(const unsigned short* gx, long long gx_st, long long gx_sg, long long gx_sr, unsigned short* hm,
                                unsigned short* cm, const unsigned short* w_frag, const float* keep, int G, int N, int T, unsigned short* out_h,
                                long long out_sg, long long out_st, unsigned short* c_new, unsigned short* ws, hipStream_t s) {
   static bool attr = false;
-  if (lstm_seq_lds_attr(&k_lstm_seq_fwd<H>, LstmSeqCfg<H>::F_LDS, &attr)) return 1;
-  hipLaunchKernelGGL((k_lstm_seq_fwd<H>), dim3(N / 16, G), dim3(512), LstmSeqCfg<H>::F_LDS, s, gx, gx_st, gx_sg, gx_sr, hm, cm, w_frag, keep, N, T,
+  typedef LstmSeqRows<H, RS> Rw;
+  if (lstm_seq_lds_attr(&k_lstm_seq_fwd<H, RS>, Rw::F_LDS, &attr)) return 1;
+  hipLaunchKernelGGL((k_lstm_seq_fwd<H, RS>), dim3(N / Rw::ROWS, G), dim3(512), Rw::F_LDS, s, gx, gx_st, gx_sg, gx_sr, hm, cm, w_frag, keep, N, T,
                      out_h, out_sg, out_st, c_new, ws);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
-template <int H>
+template <int H, int RS>
 static int lstm_seq_bwd_launch(const unsigned short* dout, long long dout_sg, long long dout_st, const unsigned short* wt_frag,
                                const float* keep, const unsigned short* cm, const unsigned short* c_new, const unsigned short* ws, int G,
                                int N, int T, unsigned short* dgates, hipStream_t s) {
   static bool attr = false;
-  if (lstm_seq_lds_attr(&k_lstm_seq_bwd<H>, LstmSeqCfg<H>::B_LDS, &attr)) return 1;
-  hipLaunchKernelGGL((k_lstm_seq_bwd<H>), dim3(N / 16, G), dim3(512), LstmSeqCfg<H>::B_LDS, s, dout, dout_sg, dout_st, wt_frag, keep, cm, c_new, ws,
+  typedef LstmSeqRows<H, RS> Rw;
+  if (lstm_seq_lds_attr(&k_lstm_seq_bwd<H, RS>, Rw::B_LDS, &attr)) return 1;
+  hipLaunchKernelGGL((k_lstm_seq_bwd<H, RS>), dim3(N / Rw::ROWS, G), dim3(512), Rw::B_LDS, s, dout, dout_sg, dout_st, wt_frag, keep, cm, c_new, ws,
                      N, T, dgates);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }

@@ -3108,40 +3108,46 @@ extern "C" int myo_lstm_step_bwd(const void* dout, long long dout_sg, const void
 #include "myo_lstm_seq.h"
 #endif
 extern "C" int myo_lstm_seq_supported(int H) { return (H == 128 || H == 256) ? 1 : 0; }
-extern "C" int myo_lstm_seq_fwd(const void* gx, long long gx_st, long long gx_sg, long long gx_sr, void* hm, void* cm, const void* w_hh,
-                                const float* keep, int G, int N, int H, int T, void* out_h, long long out_sg, long long out_st, void* c_new,
-                                void* ws, void* stream) {
-  if (!gx || !hm || !cm || !w_hh || !keep || !out_h || !c_new || !ws || G <= 0 || N <= 0 || H <= 0 || T <= 0 || (gx_st & 3) || (gx_sg & 3) ||
-      (gx_sr & 3) || (out_sg & 3) || (out_st & 3) || (N & 15))
-    return fail(MYO_E_ARG, "myo_lstm_seq_fwd: bad arguments (N must be a multiple of 16)");
-  if (!myo_lstm_seq_supported(H)) return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_fwd: hidden size %d (128 or 256)", H);
+// row_split RS: a workgroup owns 16 / RS sequences (1, 2, or 4 at H = 256); the weight fragments and the tile-major arrays are laid out for it
+static int lstm_seq_rs_ok(int H, int rs) { return rs == 1 || rs == 2 || (rs == 4 && H == 256); }
+extern "C" int myo_lstm_seq_fwd(const void* gx, long long gx_st, long long gx_sg, long long gx_sr, void* hm, void* cm, const void* w_frag,
+                                const float* keep, int G, int N, int H, int T, int row_split, void* out_h, long long out_sg, long long out_st,
+                                void* c_new, void* ws, void* stream) {
+  if (!gx || !hm || !cm || !w_frag || !keep || !out_h || !c_new || !ws || G <= 0 || N <= 0 || H <= 0 || T <= 0 || (gx_st & 7) || (gx_sg & 7) ||
+      (gx_sr & 7) || (out_sg & 7) || (out_st & 7) || (N & 15))
+    return fail(MYO_E_ARG, "myo_lstm_seq_fwd: bad arguments (N must be a multiple of 16, strides of 8)");
+  if (!myo_lstm_seq_supported(H) || !lstm_seq_rs_ok(H, row_split))
+    return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_fwd: hidden size %d (128 or 256) with row split %d (1, 2; 4 at 256)", H, row_split);
 #ifdef MYO_EMU
   (void)stream;
   return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_fwd is a GPU kernel");
 #else
   typedef const unsigned short* cu;
   typedef unsigned short* mu;
-  const int rc = H == 128 ? lstm_seq_fwd_launch<128>((cu)gx, gx_st, gx_sg, gx_sr, (mu)hm, (mu)cm, (cu)w_hh, keep, G, N, T, (mu)out_h, out_sg, out_st,
-                                                     (mu)c_new, (mu)ws, (hipStream_t)stream)
-                          : lstm_seq_fwd_launch<256>((cu)gx, gx_st, gx_sg, gx_sr, (mu)hm, (mu)cm, (cu)w_hh, keep, G, N, T, (mu)out_h, out_sg, out_st,
-                                                     (mu)c_new, (mu)ws, (hipStream_t)stream);
+#define MYO_SEQ_FWD(HH, RR) lstm_seq_fwd_launch<HH, RR>((cu)gx, gx_st, gx_sg, gx_sr, (mu)hm, (mu)cm, (cu)w_frag, keep, G, N, T, (mu)out_h, out_sg, out_st, \
+                                                        (mu)c_new, (mu)ws, (hipStream_t)stream)
+  const int rc = H == 128 ? (row_split == 1 ? MYO_SEQ_FWD(128, 1) : MYO_SEQ_FWD(128, 2))
+                          : (row_split == 1 ? MYO_SEQ_FWD(256, 1) : row_split == 2 ? MYO_SEQ_FWD(256, 2) : MYO_SEQ_FWD(256, 4));
+#undef MYO_SEQ_FWD
   return rc ? fail(MYO_E_DEVICE, "myo_lstm_seq_fwd: launch failed") : MYO_OK;
 #endif
 }
-extern "C" int myo_lstm_seq_bwd(const void* dout, long long dout_sg, long long dout_st, const void* w_hh_t, const float* keep, const void* cm,
-                                const void* c_new, const void* ws, int G, int N, int H, int T, void* dgates, void* stream) {
-  if (!dout || !w_hh_t || !keep || !cm || !c_new || !ws || !dgates || G <= 0 || N <= 0 || H <= 0 || T <= 0 || (dout_sg & 3) || (dout_st & 3) || (N & 15))
-    return fail(MYO_E_ARG, "myo_lstm_seq_bwd: bad arguments (N must be a multiple of 16)");
-  if (!myo_lstm_seq_supported(H)) return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_bwd: hidden size %d (128 or 256)", H);
+extern "C" int myo_lstm_seq_bwd(const void* dout, long long dout_sg, long long dout_st, const void* wt_frag, const float* keep, const void* cm,
+                                const void* c_new, const void* ws, int G, int N, int H, int T, int row_split, void* dgates, void* stream) {
+  if (!dout || !wt_frag || !keep || !cm || !c_new || !ws || !dgates || G <= 0 || N <= 0 || H <= 0 || T <= 0 || (dout_sg & 7) || (dout_st & 7) || (N & 15))
+    return fail(MYO_E_ARG, "myo_lstm_seq_bwd: bad arguments (N must be a multiple of 16, strides of 8)");
+  if (!myo_lstm_seq_supported(H) || !lstm_seq_rs_ok(H, row_split))
+    return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_bwd: hidden size %d (128 or 256) with row split %d (1, 2; 4 at 256)", H, row_split);
 #ifdef MYO_EMU
   (void)stream;
   return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_bwd is a GPU kernel");
 #else
   typedef const unsigned short* cu;
-  const int rc = H == 128 ? lstm_seq_bwd_launch<128>((cu)dout, dout_sg, dout_st, (cu)w_hh_t, keep, (cu)cm, (cu)c_new, (cu)ws, G, N, T,
-                                                     (unsigned short*)dgates, (hipStream_t)stream)
-                          : lstm_seq_bwd_launch<256>((cu)dout, dout_sg, dout_st, (cu)w_hh_t, keep, (cu)cm, (cu)c_new, (cu)ws, G, N, T,
-                                                     (unsigned short*)dgates, (hipStream_t)stream);
+#define MYO_SEQ_BWD(HH, RR) lstm_seq_bwd_launch<HH, RR>((cu)dout, dout_sg, dout_st, (cu)wt_frag, keep, (cu)cm, (cu)c_new, (cu)ws, G, N, T, \
+                                                        (unsigned short*)dgates, (hipStream_t)stream)
+  const int rc = H == 128 ? (row_split == 1 ? MYO_SEQ_BWD(128, 1) : MYO_SEQ_BWD(128, 2))
+                          : (row_split == 1 ? MYO_SEQ_BWD(256, 1) : row_split == 2 ? MYO_SEQ_BWD(256, 2) : MYO_SEQ_BWD(256, 4));
+#undef MYO_SEQ_BWD
   return rc ? fail(MYO_E_DEVICE, "myo_lstm_seq_bwd: launch failed") : MYO_OK;
 #endif
 }

@@ -31,29 +31,44 @@ import torch
 from .fused_mlp import FusedPPOStep
 
 
-def lstm_seq_weights(whh):
+def lstm_seq_weights(whh, rs=1):
     """W_hh bf16 [G, 4H, H] -> (w_frag, wt_frag), the fragment-major layouts ``myo_lstm_seq_fwd`` / ``_bwd`` read (include/myobatch.h):
     the 64 x 16 bytes a wave loads for one matrix-core operand are one contiguous KB in lane order (lane = 16 (k-quarter) + row);
     a workgroup has eight waves, wave w owns UT = H / 128 tiles of 16 units and row i = 4 a + b of its tile ut is unit
-    16 UT w + 4 UT a + 4 ut + b (a lane's units are consecutive, csrc/myo_lstm_seq.h)."""
+    16 UT w + 4 UT a + CL (b // (4 / rs)) + (4 / rs) ut + b % (4 / rs), CL = 4 UT / rs: the cells of a lane — of each of the rs lane copies
+    of a row when a workgroup owns 16 / rs rows — are consecutive units (csrc/myo_lstm_seq.h)."""
     G, H4, H = whh.shape
-    UT = H // 128
-    #            [g][q][w][a][ut][b][kk][lk][j]                              -> [g][w][kk][q][ut][lk][lr = (a, b)][j]
-    w_frag = whh.view(G, 4, 8, 4, UT, 4, H // 32, 4, 8).permute(0, 2, 6, 1, 4, 7, 3, 5, 8).contiguous()
-    #             [g][kk][lk][j][w][a][ut][b]                                -> [g][w][kk][ut][lk][lr = (a, b)][j]
-    wt_frag = whh.view(G, H4 // 32, 4, 8, 8, 4, UT, 4).permute(0, 4, 1, 6, 2, 5, 7, 3).contiguous()
+    UT, bpu = H // 128, 4 // rs
+    # a unit's index digits, most significant first: w (8), a (4), s = b // bpu (rs), ut (UT), blo = b % bpu (bpu)
+    #            [g][q][w][a][s][ut][blo][kk][lk][j]                        -> [g][w][kk][q][ut][lk][lr = (a, s, blo)][j]
+    w_frag = whh.view(G, 4, 8, 4, rs, UT, bpu, H // 32, 4, 8).permute(0, 2, 7, 1, 5, 8, 3, 4, 6, 9).contiguous()
+    #             [g][kk][lk][j][w][a][s][ut][blo]                          -> [g][w][kk][ut][lk][lr = (a, s, blo)][j]
+    wt_frag = whh.view(G, H4 // 32, 4, 8, 8, 4, rs, UT, bpu).permute(0, 4, 1, 7, 2, 5, 6, 8, 3).contiguous()
     return w_frag, wt_frag
 
 
-def lstm_seq_rows(x_tm, N, H, gates=1):
-    """A tile-major array of the sequence kernels (c_new, ws, cm from slot 1 on: [..., G, N, gates * H] in bytes, laid out
-    [(g, row tile)][wave][gate][lane = (lk, lr)][4 UT]) as row-major [..., G, N, gates * H] (tests, diagnostics)."""
-    UT = H // 128
+def lstm_seq_rows(x_tm, N, H, gates=1, rs=1):
+    """A tile-major array of the sequence kernels (c_new, ws, cm from slot 1 on: the bytes of [..., G, N, gates * H], laid out
+    [(g, row tile of 16 / rs)][wave][gate][lane = (lk, lane copy s, tile row)][CL]) as row-major [..., G, N, gates * H] (tests, diagnostics)."""
+    rows, cl = 16 // rs, 4 * (H // 128) // rs
     lead = x_tm.shape[:-2]
-    v = x_tm.reshape(*lead, N // 16, 8, gates, 4, 16, 4 * UT)            # [rt][w][q][lk][lr][4 UT]
+    v = x_tm.reshape(*lead, N // rows, 8, gates, 4, rs, rows, cl)        # [rt][w][q][lk][s][row][CL]
     n = len(lead)
-    v = v.permute(*range(n), n, n + 4, n + 2, n + 1, n + 3, n + 5)        # [rt][lr][q][w][lk][4 UT]: unit = 16 UT w + 4 UT lk + e
+    v = v.permute(*range(n), n, n + 5, n + 2, n + 1, n + 3, n + 4, n + 6)   # [rt][row][q][w][lk][s][CL]: unit = 16 UT w + 4 UT lk + CL s + e
     return v.reshape(*lead, N, gates * H)
+
+
+def lstm_seq_row_split(H, G, m, n_cu=256):
+    """Rows per workgroup of the sequence kernels = 16 / rs: the largest split that does not leave the launch with more workgroups
+    than CUs (the cell arithmetic of a step is per workgroup; MYO_LSTM_SEQ_RS overrides)."""
+    forced = os.environ.get("MYO_LSTM_SEQ_RS")
+    if forced:
+        return int(forced)
+    rs = 1
+    for cand in ((2, 4) if H == 256 else (2,)):
+        if G * m * cand // 16 <= n_cu:
+            rs = cand
+    return rs
 
 
 class FusedRecurrentPPOStep(FusedPPOStep):
@@ -151,11 +166,12 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         kp = lambda t: p(keep[t + 1]) if t + 1 < T else None
         if self.seq_kernels and m % 16 == 0:
             # the whole sequence = ONE launch per direction (csrc/myo_lstm_seq.h): a workgroup owns 16 sequences from the first step to the last
-            w_frag, wt_frag = lstm_seq_weights(L["whhh"])
-            lib.check(lib.L.myo_lstm_seq_fwd(p(gx), m * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, m, H, T, p(lat), T * m * H,
+            rs = lstm_seq_row_split(H, G, m)
+            w_frag, wt_frag = lstm_seq_weights(L["whhh"], rs)
+            lib.check(lib.L.myo_lstm_seq_fwd(p(gx), m * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, m, H, T, rs, p(lat), T * m * H,
                                              m * H, p(cn), p(ws), st))
             pl, vl, dlat = self._merged_core(lat.view(G, B, H), act, oldlp, adv_mb, ret_mb, want_dx=True)
-            lib.check(lib.L.myo_lstm_seq_bwd(p(dlat), T * m * H, m * H, p(wt_frag), p(keep), p(cm), p(cn), p(ws), G, m, H, T, p(dG), st))
+            lib.check(lib.L.myo_lstm_seq_bwd(p(dlat), T * m * H, m * H, p(wt_frag), p(keep), p(cm), p(cn), p(ws), G, m, H, T, rs, p(dG), st))
         elif self.step_kernels:
             # a time step = ONE launch per direction (csrc/myo_lstm_step.h): recurrent product on the matrix cores + cell epilogue;
             # reads gx where the projection GEMM left it and writes the outputs where the trunks read them (no transposes)

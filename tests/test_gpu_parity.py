@@ -1462,8 +1462,8 @@ def test_lstm_step_kernels_match_gemm_plus_cell(hip_lib, H, N):
     assert hip_lib.L.myo_lstm_step_supported(48) == 0 and hip_lib.L.myo_lstm_step_fwd(p(gx_all), 0, 0, p(hp), p(cp), p(whh), None, G, N, 48, p(out2), 0, p(hm2), p(cm2), None, None, None) == -2
 
 
-@pytest.mark.parametrize("H,N,T", [(256, 64, 9), (128, 48, 7), (256, 512, 33)])
-def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T):
+@pytest.mark.parametrize("H,N,T,rs", [(256, 64, 9, 1), (128, 48, 7, 1), (256, 512, 33, 4), (256, 48, 5, 2), (128, 32, 6, 2)])
+def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T, rs):
     """myo_lstm_seq_fwd / _bwd (all time steps of a minibatch in one launch per direction, csrc/myo_lstm_seq.h) against T launches of
     the step kernels on the same inputs — every saved array of the forward pass, the dgates of every step — and, for the end of
     the sequence, against the fp32 statement of the recurrence (state masked where an episode starts)."""
@@ -1492,9 +1492,9 @@ def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T):
         hip_lib.check(L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm_a[t]), p(cm_a[t]), p(whh), p(keep[t + 1]) if t + 1 < T else None, G, N, H,
                                           p(lat_a[:, t]), T * N * H, p(hm_a[t + 1]), p(cm_a[t + 1]), p(cn_a[t]), p(ws_a[t]), None))
     from myochallenge_amd.rl.fused_lstm import lstm_seq_rows, lstm_seq_weights
-    w_frag, wt_frag = lstm_seq_weights(whh)
+    w_frag, wt_frag = lstm_seq_weights(whh, rs)        # (rs: a workgroup owns 16 / rs of the rows)
     hm_b, cm_b, cn_b, ws_b, lat_b = state()
-    hip_lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(w_frag), p(keep), G, N, H, T, p(lat_b), T * N * H, N * H,
+    hip_lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(w_frag), p(keep), G, N, H, T, rs, p(lat_b), T * N * H, N * H,
                                      p(cn_b), p(ws_b), None))
     torch.cuda.synchronize()
     # the two paths round to bf16 at the same places; they differ by the order of the fp32 sums over K and by tanh's last bits, i.e. by
@@ -1504,8 +1504,8 @@ def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T):
         scale = 1 + float(want.float().abs().max())
         assert float(d.max()) <= worst * scale and float(d.mean()) <= mean * scale, (name, float(d.max()), float(d.mean()), scale)
     # (the arrays only the sequence kernels read are tile-major, csrc/myo_lstm_seq.h: cm from slot 1 on, c_new, ws)
-    for name, a, b in (("lat", lat_a, lat_b), ("hm", hm_a, hm_b), ("cm", cm_a[1:], lstm_seq_rows(cm_b[1:], N, H)),
-                       ("cn", cn_a, lstm_seq_rows(cn_b, N, H)), ("ws", ws_a, lstm_seq_rows(ws_b, N, H, 4))):
+    for name, a, b in (("lat", lat_a, lat_b), ("hm", hm_a, hm_b), ("cm", cm_a[1:], lstm_seq_rows(cm_b[1:], N, H, 1, rs)),
+                       ("cn", cn_a, lstm_seq_rows(cn_b, N, H, 1, rs)), ("ws", ws_a, lstm_seq_rows(ws_b, N, H, 4, rs))):
         close(b, a, name)
     assert torch.equal(cm_b[0], c0) and torch.equal(hm_b[0], h0)
     # fp32 statement of the whole recurrence
@@ -1527,16 +1527,18 @@ def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T):
         hip_lib.check(L.myo_lstm_step_bwd(p(dlat[:, t]), T * N * H, None if last else p(dG_a[t + 1]), None if last else p(dcm[(t + 1) & 1]),
                                           p(wt), p(keep[t + 1]) if not last else None, p(cm_a[t]), p(cn_a[t]), p(ws_a[t]), G, N, H, p(dG_a[t]),
                                           p(dcm[t & 1]), None))
-    hip_lib.check(L.myo_lstm_seq_bwd(p(dlat), T * N * H, N * H, p(wt_frag), p(keep), p(cm_b), p(cn_b), p(ws_b), G, N, H, T, p(dG_b), None))
+    hip_lib.check(L.myo_lstm_seq_bwd(p(dlat), T * N * H, N * H, p(wt_frag), p(keep), p(cm_b), p(cn_b), p(ws_b), G, N, H, T, rs, p(dG_b), None))
     torch.cuda.synchronize()
     close(dG_b, dG_a, "dgates")
     assert float(dG_b.float().abs().max()) > 0.05                 # (a gradient did flow)
     # unsupported sizes are refused, not mis-run
     assert L.myo_lstm_seq_supported(64) == 0 and L.myo_lstm_seq_supported(256) == 1
-    assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N, 64, T, p(lat_b), T * N * H, N * H, p(cn_b),
+    assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N, 64, T, rs, p(lat_b), T * N * H, N * H, p(cn_b),
                               p(ws_b), None) == -2
-    assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N - 1, H, T, p(lat_b), T * N * H, N * H, p(cn_b),
+    assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N - 1, H, T, rs, p(lat_b), T * N * H, N * H, p(cn_b),
                               p(ws_b), None) == -1
+    assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(w_frag), p(keep), G, N, 128, T, 4, p(lat_b), T * N * H, N * H, p(cn_b),
+                              p(ws_b), None) == -2
 
 
 def test_gsde_sampling_kernel_matches_torch(hip_lib):

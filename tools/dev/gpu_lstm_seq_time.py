@@ -20,7 +20,8 @@ mk = lambda *s, sc=1.0: (sc * torch.randn(*s, device=dev)).to(bf)
 p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 gx, whh = mk(T, N, G, H4), mk(G, H4, H, sc=H ** -0.5)
 wt = whh.transpose(1, 2).contiguous()
-w_frag, wt_frag = lstm_seq_weights(whh)
+RS = int(os.environ.get('RS', '1'))
+w_frag, wt_frag = lstm_seq_weights(whh, RS)
 keep = (torch.rand(T, N, device=dev) > 0.05).float()
 hm, cm = torch.zeros((T + 1, G, N, H), device=dev, dtype=bf), torch.zeros((T + 1, G, N, H), device=dev, dtype=bf)
 cn, ws = torch.zeros((T, G, N, H), device=dev, dtype=bf), torch.zeros((T, G, N, H4), device=dev, dtype=bf)
@@ -42,11 +43,11 @@ def steps_bwd(st):
 
 
 def seq_fwd(st):
-    lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, N, H, T, p(lat), T * N * H, N * H, p(cn), p(ws), st))
+    lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, N, H, T, RS, p(lat), T * N * H, N * H, p(cn), p(ws), st))
 
 
 def seq_bwd(st):
-    lib.check(L.myo_lstm_seq_bwd(p(dlat), T * N * H, N * H, p(wt_frag), p(keep), p(cm), p(cn), p(ws), G, N, H, T, p(dG), st))
+    lib.check(L.myo_lstm_seq_bwd(p(dlat), T * N * H, N * H, p(wt_frag), p(keep), p(cm), p(cn), p(ws), G, N, H, T, RS, p(dG), st))
 
 
 def timed(fn, name, graph):
@@ -75,7 +76,7 @@ def timed(fn, name, graph):
     print("%-28s %8.3f ms  = %6.2f us per time step" % (name, ms, 1e3 * ms / T), flush=True)
 
 
-print("H %d, %d sequences, T %d, G %d" % (H, N, T, G))
+print("H %d, %d sequences, T %d, G %d, row split %d" % (H, N, T, G, RS))
 timed(steps_fwd, "step kernels forward (graph)", True)
 timed(steps_bwd, "step kernels backward (graph)", True)
 if L.myo_lstm_seq_supported(H):

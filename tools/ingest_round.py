@@ -42,7 +42,9 @@ def main():
                  ("stage_shares_rk4.txt", TAG + "_stage_shares_rk4.txt"), ("wg_timeline_parts.log", TAG + "_wg_timeline_parts.log"),
                  ("wg_timeline_whole.log", TAG + "_wg_timeline_whole_steps.log"), ("gpu_tests.log", TAG + "_gpu_tests.log"),
                  ("pmc_kstep_whole_steps.txt", TAG + "_pmc_kstep_whole_steps.txt"), ("train_demo_p1_100m_f64.json", TAG + "_train_demo_p1_100m_f64.json"),
-                 ("train_demo_reorient_lstm256_40m.json", TAG + "_train_demo_reorient_lstm256_40m.json")):
+                 ("train_demo_reorient_lstm256_40m.json", TAG + "_train_demo_reorient_lstm256_40m.json"),
+                 ("pmc_kstep_publish_fence.txt", TAG + "_pmc_kstep_publish_fence.txt"), ("config_e_kernel_stats.csv", TAG + "_config_e_kernel_stats.csv"),
+                 ("lstm_seq_time.txt", TAG + "_lstm_seq_time.txt")):
         if os.path.exists(os.path.join(R, a)):
             shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}
@@ -51,7 +53,11 @@ def main():
             continue
         d = json.loads(open(os.path.join(R, f"bench_{k}.json")).read().strip().splitlines()[-1])
         out["bench_" + k] = {x: d[x] for x in ("value", "ms_per_step", "env_kernel_ms", "ppo_optimizer_steps_per_sec", "dtype", "config") if x in d}
-    for key, fn in (("config_E_reorient_lstm256_light", "bench_reorient_lstm.json"), ("config_E_reorient_lstm256_reference_settings", "bench_reorient_lstm_reference.json")):
+    if os.path.exists(os.path.join(R, "bench_publish_fence.json")):
+        d = json.loads(open(os.path.join(R, "bench_publish_fence.json")).read().strip().splitlines()[-1])
+        out["bench_publish_fence"] = {x: d[x] for x in ("value", "ms_per_step", "env_kernel_ms") if x in d}
+    for key, fn in (("config_E_reorient_lstm256_light", "bench_reorient_lstm.json"), ("config_E_reorient_lstm256_reference_settings", "bench_reorient_lstm_reference.json"),
+                    ("config_E_reorient_lstm256_reference_settings_step_kernels", "bench_reorient_lstm_reference_step_kernels.json")):
         try:
             out[key] = json.loads(open(os.path.join(R, fn)).read().strip().splitlines()[-1])
         except Exception as e:          # noqa: BLE001

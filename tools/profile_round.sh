@@ -32,6 +32,16 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
   python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" >> $OUT/pmc_kstep_whole_steps.txt
 done
 unset MYO_STEP_SPLIT
+# 3a'. ... and with the parts published by an agent release fence (round 4's form) instead of write-through stores
+: > $OUT/pmc_kstep_publish_fence.txt
+export MYO_PUBLISH=fence
+for set in "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf /tmp/pmc
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
+  python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" >> $OUT/pmc_kstep_publish_fence.txt
+done
+python3 $ROOT/bench.py --no-cpu-baseline --no-variants > $OUT/bench_publish_fence.json 2>/dev/null
+unset MYO_PUBLISH
 # 3b. matrix-core activity of the PPO side (north_star asks for MFMA-busy against peak): hipBLASLt GEMM kernels
 rm -rf /tmp/pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
@@ -54,7 +64,12 @@ python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoBaodi
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoReorientP2 > $OUT/bench_reorient_p2.json 2>/dev/null
 python3 $ROOT/tools/bench_reorient.py > $OUT/bench_reorient_lstm.json 2>/dev/null
-python3 $ROOT/tools/bench_reorient.py --reference-settings --iters 2 > $OUT/bench_reorient_lstm_reference.json 2>/dev/null   # n_steps 128, n_epochs 10, fp64 (src/main_reorient.py:53-71)
+python3 $ROOT/tools/bench_reorient.py --reference-settings --iters 6 > $OUT/bench_reorient_lstm_reference.json 2>/dev/null   # n_steps 128, n_epochs 10, fp64 (src/main_reorient.py:53-71)
+MYO_LSTM_SEQ=0 python3 $ROOT/tools/bench_reorient.py --reference-settings --iters 4 > $OUT/bench_reorient_lstm_reference_step_kernels.json 2>/dev/null   # the same with one launch per LSTM time step
+rm -rf /tmp/prof_cfge
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_cfge -o e -- python3 $ROOT/tools/bench_reorient.py --reference-settings --iters 2 > /tmp/cfge.log 2>&1
+find /tmp/prof_cfge -name "*kernel_stats.csv" -exec cp {} $OUT/config_e_kernel_stats.csv \;
+{ RS=4 python3 $ROOT/tools/dev/gpu_lstm_seq_time.py 256 512 128; RS=2 python3 $ROOT/tools/dev/gpu_lstm_seq_time.py 128 512 128; RS=1 python3 $ROOT/tools/dev/gpu_lstm_seq_time.py 256 512 128; } > $OUT/lstm_seq_time.txt 2>&1
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --dtype mixed --lstm-hidden 128 --net-arch "" --n-steps 32 > $OUT/bench_lstm128.json 2>/dev/null   # the reference's phase-1 policy shape
 # 6. trajectory drift tables of both steppers (32 action streams x 200 env steps) and k_step time against the batch size
 python3 $ROOT/tools/dev/gpu_drift.py > $OUT/drift.log 2>&1

@@ -157,7 +157,6 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         # ---- input projections of both LSTMs, all time steps: [B, O] x [O, 2*4H]
         bsum = (L["bihh"] + L["bhhh"]).view(G * H4)
         gx = torch.addmm(bsum, x[0], L["wihh"].view(G * H4, O).t()).view(T, m, G, H4)      # row (t, n): [actor 4H | critic 4H]
-        wt = L["whhh"].transpose(1, 2).contiguous()                      # [G, H, 4H] = W_hh^T
         cn = torch.empty((T, G, m, H), dtype=bf, device=dev)
         ws = torch.empty((T, G, m, H4), dtype=bf, device=dev)
         lat = torch.empty((G, T, m, H), dtype=bf, device=dev)            # LSTM outputs, net-major: the trunks' input
@@ -180,6 +179,7 @@ class FusedRecurrentPPOStep(FusedPPOStep):
                                                   T * m * H, p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
             pl, vl, dlat = self._merged_core(lat.view(G, B, H), act, oldlp, adv_mb, ret_mb, want_dx=True)
             dlat = dlat.view(G, T, m, H)
+            wt = L["whhh"].transpose(1, 2).contiguous()                  # [G, H, 4H] = W_hh^T
             for t in range(T - 1, -1, -1):
                 last = t == T - 1
                 lib.check(lib.L.myo_lstm_step_bwd(p(dlat[:, t]), T * m * H, None if last else p(dG[t + 1]), None if last else p(dcm[(t + 1) & 1]),
@@ -187,6 +187,7 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         else:
             gxs = gx.transpose(1, 2).contiguous()                        # [T, G, m, 4H]: a step's rows are r = g*m + n
             out = torch.empty((T, G, m, H), dtype=bf, device=dev)
+            wt = L["whhh"].transpose(1, 2).contiguous()                  # [G, H, 4H] = W_hh^T
             for t in range(T):
                 gh = torch.bmm(hm[t], wt)
                 lib.check(lib.L.myo_lstm_cell_fwd(p(gxs[t]), p(gh), p(cm[t]), kp(t), G * m, m, H, 1,

@@ -755,3 +755,46 @@ def test_logger_reports_monitor_statistics_of_the_last_100_episodes(emu_lib):
     assert abs(logs[-1]["rollout/ep_rew_mean"] - np.mean([r for r, _ in last])) < 1e-5 * max(1.0, abs(np.mean([r for r, _ in last])))
     assert abs(logs[-1]["rollout/ep_len_mean"] - np.mean([l for _, l in last])) < 1e-6
     env.close()
+
+
+@pytest.mark.parametrize("H,rs", [(128, 1), (128, 2), (256, 1), (256, 2), (256, 4)])
+def test_lstm_seq_layouts_follow_the_header(H, rs):
+    """rl/fused_lstm.py lstm_seq_weights / lstm_seq_rows are the torch statements of the layouts include/myobatch.h documents for
+    myo_lstm_seq_fwd / _bwd: fragment-major weights under the unit map of a row split, and the tile-major saved arrays."""
+    import random
+    import torch
+    from myochallenge_amd.rl.fused_lstm import lstm_seq_row_split, lstm_seq_rows, lstm_seq_weights
+    G, UT = 2, H // 128
+    CL, bpu = 4 * UT // rs, 4 // rs
+    unit = lambda w, ut, i: 16 * UT * w + 4 * UT * (i // 4) + CL * ((i % 4) // bpu) + bpu * ut + (i % 4) % bpu
+    assert sorted(unit(w, ut, i) for w in range(8) for ut in range(UT) for i in range(16)) == list(range(H))
+    whh = torch.arange(G * 4 * H * H, dtype=torch.float64).view(G, 4 * H, H)
+    wf, wt = lstm_seq_weights(whh, rs)
+    wf, wt = wf.reshape(G, 8, H // 32, 4, UT, 64, 8), wt.reshape(G, 8, 4 * H // 32, UT, 64, 8)
+    rnd = random.Random(H + rs)
+    for _ in range(400):
+        g, w, ut, l, j = rnd.randrange(G), rnd.randrange(8), rnd.randrange(UT), rnd.randrange(64), rnd.randrange(8)
+        kk, q = rnd.randrange(H // 32), rnd.randrange(4)
+        assert wf[g, w, kk, q, ut, l, j] == whh[g, q * H + unit(w, ut, l & 15), 32 * kk + 8 * (l >> 4) + j]
+        kk = rnd.randrange(4 * H // 32)
+        assert wt[g, w, kk, ut, l, j] == whh[g, 32 * kk + 8 * (l >> 4) + j, unit(w, ut, l & 15)]
+    # tile-major [(g, row tile)][wave][gate][lane = (lk, copy, tile row)][CL] -> rows: lane (lk, s, row) holds units 16 UT w + 4 UT lk + CL s + e
+    N, rows_per = 32, 16 // rs
+    for gates in (1, 4):
+        want = torch.arange(G * N * gates * H, dtype=torch.float64).view(G, N, gates * H)
+        idx = torch.empty(G * N * gates * H, dtype=torch.long)
+        o = 0
+        for g in range(G):
+            for rt in range(N // rows_per):
+                for w in range(8):
+                    for q in range(gates):
+                        for lane in range(64):
+                            lk, row, s = lane >> 4, (lane & 15) % rows_per, (lane & 15) // rows_per
+                            for e in range(CL):
+                                idx[o] = (g * N + rt * rows_per + row) * gates * H + q * H + (w * 16 + 4 * lk) * UT + s * CL + e
+                                o += 1
+        tm = want.reshape(-1)[idx].view(G, N, gates * H)
+        assert torch.equal(lstm_seq_rows(tm, N, H, gates, rs), want)
+    # the split never asks for more workgroups than CUs, and a forced one wins
+    assert lstm_seq_row_split(256, 2, 512) == 4 and lstm_seq_row_split(256, 2, 2048) == 1 and lstm_seq_row_split(128, 2, 512) == 2
+    assert lstm_seq_row_split(128, 2, 4096) == 1 and lstm_seq_row_split(256, 2, 1024) == 2

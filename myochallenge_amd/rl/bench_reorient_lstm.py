@@ -39,7 +39,10 @@ def run(envs: int = 4096, n_steps: int = 32, iters: int = 3, env_only_steps: int
            "env_steps_per_sec_rollout_plus_update": steps / dt, "env_steps_per_sec_rollout_only": steps / tr,
            "n_steps": n_steps, "epochs": n_epochs, "dtype": dtype, "settings": "reference (src/main_reorient.py:53-71)" if reference_settings else "light",
            "env_kernel_lds_bytes": env.batch.lds_bytes, "health": env.batch.health(), "recurrent_path": "fused" if algo._fused_rec is not None else "autograd",
-           "seconds_per_iteration_rollout_update": per_iter}
+           "seconds_per_iteration_rollout_update": per_iter,
+           # (the iteration in which the 300-step time limit first truncates every env runs its bootstrap GEMMs on shapes the BLAS library has
+           #  not seen yet — a one-off of 0.05-0.2 s that a run of a few iterations does not amortise: the median iteration beside the total)
+           "env_steps_per_sec_median_iteration": envs * n_steps / sorted(a + b for a, b in per_iter)[len(per_iter) // 2]}
     if env_only_steps:                                          # physics alone (zero actions)
         act = torch.zeros((envs, env.act_dim), device=env.device)
         t2 = time.time()

@@ -59,7 +59,13 @@ __device__ __forceinline__ constexpr int myo_hrow(int i) { const int q = i >> 2;
 #endif
 #define MYO_HIDX(i, j) (myo_hrow(i) + (j)) /* i >= j */
 
-#define MYO_ENVWS_N (((MYO_NU_MAX + MYO_NT_MAX * MYO_TJ_MAX) + 15) / 16 * 16)   /* doubles per env of TaskDev::ctrl_ws: whole 128-byte lines */
+/* doubles per env of TaskDev::ctrl_ws (whole 128-byte lines): the controls, the tendon moment arms [slot][tendon], and — for the
+   34-slot fp64 scratch only (Scratch::SPILL) — the limit rows' D and ids and the rows' active flags */
+#define MYO_WS_TENJ MYO_NU_MAX
+#define MYO_WS_EFCD (MYO_NU_MAX + MYO_NT_MAX * MYO_TJ_MAX)
+#define MYO_WS_LIMID (MYO_WS_EFCD + MYO_NLIM_MAX)
+#define MYO_WS_ACTIVE (MYO_WS_LIMID + (2 * MYO_NLIM_MAX + 7) / 8)
+#define MYO_ENVWS_N ((MYO_WS_ACTIVE + (MYO_NLIM_MAX + 4 * MYO_NCON_BIG + 7) / 8 + 15) / 16 * 16)
 #define MYO_TASK_REORIENT_K 3   // == MYO_TASK_REORIENT of include/myobatch.h (checked in myobatch.hip)
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
@@ -77,6 +83,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   double ro_obj_size_change, ro_pos_th, ro_rot_th, ro_goal_init_pos[3], ro_goal_obj_offset[3];
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
+  int objf_off;               // env record: doubles from the warm start to the object group's friction triples (Scratch::SPILL reads them in place)
   double* ctrl_ws;            // double[n_envs][MYO_ENVWS_N] in global memory, fp64 stepper: each env's controls, then its tendon moment arms (ScratchPoses<double>)
   int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity, [2] substeps that dropped joint / tendon limit or friction-loss rows beyond MYO_NLIM_MAX
   unsigned long long seed;
@@ -176,6 +183,11 @@ struct Scratch : ScratchPoses<T> {
   // per-env friction coefficients kept per geom of an object group: all three (sliding, torsional, rolling) in the big scratch that
   // batches with a die get, the sliding one in the base scratch (an object group on a base batch: torsional / rolling stay nominal)
   static constexpr int OBJG_NF = NC >= MYO_NCON_BIG ? 3 : 1;
+  // The 34-slot fp64 scratch keeps four small arrays in GLOBAL memory — the object group's friction triples in the env record, where
+  // they live anyway, the limit rows' D / ids and the rows' active flags in the env's workspace (ctrl_ws): 1,120 B, the difference
+  // between six and seven workgroups per CU (24,064 -> 22,944 B; the die's k_step 2.99 -> 2.6 ms).  Accessors: S_OBJF, S_LIM_ID, S_EFC_D,
+  // S_EFC_ACTIVE below; one wave per workgroup, so a lane's global store is visible to the loads of a later phase in program order.
+  static constexpr bool SPILL = sizeof(T) == sizeof(HP) && NC >= MYO_NCON_BIG;
   static_assert(NC >= MYO_NCON_F64 && MYO_NLIM_MAX + 4 * NC <= 192, "contact capacity: at least the smallest base (the aliases below are sized for it), at most three constraint rows per lane");
   // ---- state (HP in every build)
   HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX];
@@ -189,7 +201,7 @@ struct Scratch : ScratchPoses<T> {
   };
   union {                         // a batch has either the two Baoding balls or an object group (the die), never both
     struct { HP target_w[6]; T ball_mass[2], ball_fric[6]; };
-    T objg_fric[MYO_OBJG_MAX * (NC >= MYO_NCON_BIG ? 3 : 1)];   // friction of the object group's geoms, OBJG_NF coefficients each
+    T objg_fric[SPILL ? 1 : MYO_OBJG_MAX * (NC >= MYO_NCON_BIG ? 3 : 1)];   // friction of the object group's geoms, OBJG_NF coefficients each (S_OBJF)
   };
   T ep_ret;
   int which_task, counter, elapsed, episode, ep_len;
@@ -212,12 +224,12 @@ struct Scratch : ScratchPoses<T> {
   // contacts (contacts_emit_*), at least NC.  Measured on the hand with P2's ball sizes: up to 19 contacts (oracle, 32 episodes).
   static constexpr int NREC = (sizeof(T) == sizeof(HP) && NC == MYO_NCON_F64) ? MYO_NREC_F64 : NC;
   alignas(16) ContactRec<T> con[NREC];
-  short lim_id[MYO_NLIM_MAX];                                          // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1)
-  T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
+  short lim_id[SPILL ? 4 : MYO_NLIM_MAX];                              // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1) (S_LIM_ID)
+  T efc_D[SPILL ? 1 : MYO_NLIM_MAX];                                   // limit rows only; contact rows: con[] (S_EFC_D)
   // bvec, efc_jv, efc_force: contiguous, in this order — the linear solves stage their operands from bvec on (S_SOLVE_STAGE)
   alignas(16) T bvec[MYO_NB_MAX * 6];
   T efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC], efc_jar[MYO_NLIM_MAX + 4 * NC];
-  unsigned char efc_active[MYO_NLIM_MAX + 4 * NC];
+  unsigned char efc_active[SPILL ? 8 : MYO_NLIM_MAX + 4 * NC];         // (S_EFC_ACTIVE)
   // the seven dof vectors: contiguous, in this order (fp64 stepper: the position stage's poses live here, see ScratchPoses)
   alignas(16) T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
   T Ma[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX];   // search: -gradient between update_constraint and the solve, then the Newton direction
@@ -363,7 +375,16 @@ template <> __device__ __forceinline__ const DevModel<double>& myo_cmodel<double
 #define LISNULL(r) ((r) < 0)
 #endif
 
-template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
+// the four arrays Scratch::SPILL keeps in global memory
+template <typename T, int NC> DEV T* S_EFC_D(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_EFCD; else return s.efc_D; }
+template <typename T, int NC> DEV const T* S_EFC_D(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_EFCD; else return s.efc_D; }
+template <typename T, int NC> DEV short* S_LIM_ID(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<short*>(s.ctrl_g + MYO_WS_LIMID); else return s.lim_id; }
+template <typename T, int NC> DEV const short* S_LIM_ID(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<const short*>(s.ctrl_g + MYO_WS_LIMID); else return s.lim_id; }
+template <typename T, int NC> DEV unsigned char* S_EFC_ACTIVE(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<unsigned char*>(s.ctrl_g + MYO_WS_ACTIVE); else return s.efc_active; }
+template <typename T, int NC> DEV const unsigned char* S_EFC_ACTIVE(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<const unsigned char*>(s.ctrl_g + MYO_WS_ACTIVE); else return s.efc_active; }
+template <typename T, int NC> DEV T* S_OBJF(const TaskDev& K, Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g + K.objf_off; else return s.objg_fric; }
+template <typename T, int NC> DEV const T* S_OBJF(const TaskDev& K, const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g + K.objf_off; else return s.objg_fric; }
+template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? S_EFC_D(s)[r] : s.con[(r - nlim) >> 2].D; }
 
 // ------------------------------------------------------------------------------------------
 // small math
@@ -474,7 +495,7 @@ template <typename T, int NC> DEV HP geom_size0_hp(const DevModel<T>& M, const T
 // the object group's geoms (P2 / reorient randomisation), else `nominal` (the model's, from the pair record)
 template <typename T, int NC> DEV T geom_fric_of(const DevModel<T>& M, const TaskDev& K, const Scratch<T, NC>& s, int g, int k, T nominal) {
   if (K.objg_gidn > 0) {
-    if (g >= K.objg_gid0 && g < K.objg_gidn && k < Scratch<T, NC>::OBJG_NF) return s.objg_fric[(g - K.objg_gid0) * Scratch<T, NC>::OBJG_NF + k];
+    if (g >= K.objg_gid0 && g < K.objg_gidn && k < Scratch<T, NC>::OBJG_NF) return S_OBJF(K, s)[(g - K.objg_gid0) * Scratch<T, NC>::OBJG_NF + k];
     return nominal;
   }
   if (g == K.obj1_gid) return s.ball_fric[k];
@@ -2020,8 +2041,8 @@ DEVFN void friction_rows(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
       T Kc, Bc, Ic;
       if (tendon) sol_param(M, M.tendon_solref_fri + 2 * i, M.tendon_solimp_fri + 5 * i, (T)0, &Kc, &Bc, &Ic);
       else sol_param(M, M.dof_solref + 2 * i, M.dof_solimp + 5 * i, (T)0, &Kc, &Bc, &Ic);
-      s.lim_id[r] = i | MYO_LIM_FRIC;
-      s.efc_D[r] = sol_D(Ic, tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = 0;
+      S_LIM_ID(s)[r] = i | MYO_LIM_FRIC;
+      S_EFC_D(s)[r] = sol_D(Ic, tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = 0;
     }
     if (lane == 0) {
       const int n = base + total < MYO_NLIM_MAX ? base + total : MYO_NLIM_MAX;
@@ -2067,8 +2088,8 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
           sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dm, &Kc, &Bc, &Ic);
-          s.lim_id[r] = M.jnt_dofadr[j] | (side ? MYO_LIM_UPPER : 0);   // joint rows keep the DOF index
-          s.efc_D[r] = sol_D(Ic, M.dof_invweight0[M.jnt_dofadr[j]]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
+          S_LIM_ID(s)[r] = M.jnt_dofadr[j] | (side ? MYO_LIM_UPPER : 0);   // joint rows keep the DOF index
+          S_EFC_D(s)[r] = sol_D(Ic, M.dof_invweight0[M.jnt_dofadr[j]]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -2104,8 +2125,8 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
           sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dm, &Kc, &Bc, &Ic);
-          s.lim_id[r] = t | (side ? MYO_LIM_UPPER : 0);
-          s.efc_D[r] = sol_D(Ic, M.tendon_invweight0[t]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
+          S_LIM_ID(s)[r] = t | (side ? MYO_LIM_UPPER : 0);
+          S_EFC_D(s)[r] = sol_D(Ic, M.tendon_invweight0[t]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -2184,8 +2205,8 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         // condim 3: both tangential directions use friction[0]; torsional / rolling coefficients are not used
         T fa = F[9], fb = F[12];
         if (K.objg_gidn > 0) {
-          if (g1 >= K.objg_gid0 && g1 < K.objg_gidn) fa = s.objg_fric[(g1 - K.objg_gid0) * Scratch<T, NC>::OBJG_NF];
-          if (g2 >= K.objg_gid0 && g2 < K.objg_gidn) fb = s.objg_fric[(g2 - K.objg_gid0) * Scratch<T, NC>::OBJG_NF];
+          if (g1 >= K.objg_gid0 && g1 < K.objg_gidn) fa = S_OBJF(K, s)[(g1 - K.objg_gid0) * Scratch<T, NC>::OBJG_NF];
+          if (g2 >= K.objg_gid0 && g2 < K.objg_gidn) fb = S_OBJF(K, s)[(g2 - K.objg_gid0) * Scratch<T, NC>::OBJG_NF];
         } else {
           fa = g1 == K.obj1_gid ? s.ball_fric[0] : (g1 == K.obj2_gid ? s.ball_fric[3] : fa);
           fb = g2 == K.obj1_gid ? s.ball_fric[0] : (g2 == K.obj2_gid ? s.ball_fric[3] : fb);
@@ -2424,15 +2445,15 @@ DEVFN void J_times_gen(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCRE
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T val;
-      if (r < nl) val = lim_sign<T>(s.lim_id[r]) * v[lim_index(s.lim_id[r])];
+      if (r < nl) val = lim_sign<T>(S_LIM_ID(s)[r]) * v[lim_index(S_LIM_ID(s)[r])];
       else if (r < nlim) {
-        const int t = lim_index(s.lim_id[r]);
+        const int t = lim_index(S_LIM_ID(s)[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acc = 0, tj[MYO_TJ_MAX];
         tenj_row(s, t, tj);
 #pragma unroll
         for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * v[d]; }
-        val = lim_sign<T>(s.lim_id[r]) * acc;
+        val = lim_sign<T>(S_LIM_ID(s)[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
@@ -2461,15 +2482,15 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T val;
-      if (r < nl) val = lim_sign<T>(s.lim_id[r]) * v[lim_index(s.lim_id[r])];
+      if (r < nl) val = lim_sign<T>(S_LIM_ID(s)[r]) * v[lim_index(S_LIM_ID(s)[r])];
       else if (r < nlim) {
-        const int t = lim_index(s.lim_id[r]);
+        const int t = lim_index(S_LIM_ID(s)[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acc = 0, tj[MYO_TJ_MAX];
         tenj_row(s, t, tj);
 #pragma unroll
         for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * v[d]; }
-        val = lim_sign<T>(s.lim_id[r]) * acc;
+        val = lim_sign<T>(S_LIM_ID(s)[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
@@ -2525,15 +2546,15 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T vala, valb;
-      if (r < nl) { const T sg = lim_sign<T>(s.lim_id[r]); const int id = lim_index(s.lim_id[r]); vala = sg * va[id]; valb = sg * vb[id]; }
+      if (r < nl) { const T sg = lim_sign<T>(S_LIM_ID(s)[r]); const int id = lim_index(S_LIM_ID(s)[r]); vala = sg * va[id]; valb = sg * vb[id]; }
       else if (r < nlim) {
-        const int t = lim_index(s.lim_id[r]);
+        const int t = lim_index(S_LIM_ID(s)[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acca = 0, accb = 0, tj[MYO_TJ_MAX];
         tenj_row(s, t, tj);
 #pragma unroll
         for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acca += tj[k] * va[d]; accb += tj[k] * vb[d]; }
-        vala = lim_sign<T>(s.lim_id[r]) * acca; valb = lim_sign<T>(s.lim_id[r]) * accb;
+        vala = lim_sign<T>(S_LIM_ID(s)[r]) * acca; valb = lim_sign<T>(S_LIM_ID(s)[r]) * accb;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
@@ -2600,8 +2621,8 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
     if (d < M.nv) {
       T acc = 0;
       for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
-        const T v = lim_sign<T>(s.lim_id[r]) * f[r];
-        acc += (lim_index(s.lim_id[r]) == d) ? v : (T)0;
+        const T v = lim_sign<T>(S_LIM_ID(s)[r]) * f[r];
+        acc += (lim_index(S_LIM_ID(s)[r]) == d) ? v : (T)0;
       }
       // (four rows at a time: the fp64 stepper's moment arms come from global memory, so the reads of a group are requested together;
       //  the sum keeps its row order)
@@ -2611,12 +2632,12 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int r = r0 + k < nlim ? r0 + k : r0;                          // (rows beyond the last: a valid read, dropped below)
-          const int t = lim_index(s.lim_id[r]);
+          const int t = lim_index(S_LIM_ID(s)[r]);
           const unsigned long long m = M.tendon_dofmask[t];
           on[k] = (r0 + k < nlim) && ((m >> d) & 1ull);
           const int slot = on[k] ? myo_popcll(m & ((1ull << d) - 1ull)) : 0;  // slot 0 is always a valid read
           jv[k] = tenj_get(s, t, slot);
-          fv[k] = lim_sign<T>(s.lim_id[r]) * f[r];
+          fv[k] = lim_sign<T>(S_LIM_ID(s)[r]) * f[r];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const T v = fv[k] * jv[k]; acc += on[k] ? v : (T)0; }
@@ -2913,12 +2934,12 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
 // what a friction-loss row's cost exceeds the ordinary rows' 0.5 D min(x, 0)^2 by (0 for the other rows): the sums below stay as
 // they are and models with friction loss add this on top
 template <typename T, int NC> DEV T fric_excess(const DevModel<T>& M, const Scratch<T, NC>& s, int r, T x) {
-  if (!lim_is_fric(s.lim_id[r])) return (T)0;
-  const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
+  if (!lim_is_fric(S_LIM_ID(s)[r])) return (T)0;
+  const T fl = r < s.nl ? M.dof_frictionloss[lim_index(S_LIM_ID(s)[r])] : M.tendon_frictionloss[lim_index(S_LIM_ID(s)[r])];
   T force; int quad;
-  const T c = fric_cost(s.efc_D[r], fl, x, &force, &quad);
+  const T c = fric_cost(S_EFC_D(s)[r], fl, x, &force, &quad);
   const T xm = tmin(x, (T)0);
-  return c - (T)0.5 * s.efc_D[r] * xm * xm;
+  return c - (T)0.5 * S_EFC_D(s)[r] * xm * xm;
 }
 
 // friction-loss rows after a change of jar: clamped force, "active" = the quadratic zone (what the Hessian sees); returns the
@@ -2930,11 +2951,11 @@ DEVFN HP fric_update(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   const int nlim = s.nl + s.ntl;
   PHASE {
     for (int r = lane; r < nlim; r += 64) {
-      if (!lim_is_fric(s.lim_id[r])) continue;
-      const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
+      if (!lim_is_fric(S_LIM_ID(s)[r])) continue;
+      const T fl = r < s.nl ? M.dof_frictionloss[lim_index(S_LIM_ID(s)[r])] : M.tendon_frictionloss[lim_index(S_LIM_ID(s)[r])];
       T force; int quad;
-      (void)fric_cost(s.efc_D[r], fl, s.efc_jar[r], &force, &quad);
-      s.efc_force[r] = force; s.efc_active[r] = (unsigned char)quad;
+      (void)fric_cost(S_EFC_D(s)[r], fl, s.efc_jar[r], &force, &quad);
+      s.efc_force[r] = force; S_EFC_ACTIVE(s)[r] = (unsigned char)quad;
     }
   }
   SYNC();
@@ -2964,8 +2985,8 @@ DEVFN T fric_linesearch(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, T q
     PHASE { (void)lane; }
     WAVE_SUM3_N(T, e1, e2, e3unused, nefc, r, {
       const T v = s.efc_jv[r], x = s.efc_jar[r] + alpha * v, D = row_D(s, r, nlim);
-      if (r < nlim && lim_is_fric(s.lim_id[r])) {
-        const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
+      if (r < nlim && lim_is_fric(S_LIM_ID(s)[r])) {
+        const T fl = r < s.nl ? M.dof_frictionloss[lim_index(S_LIM_ID(s)[r])] : M.tendon_frictionloss[lim_index(S_LIM_ID(s)[r])];
         T force; int quad;
         (void)fric_cost(D, fl, x, &force, &quad);
         _e1 = -force * v; _e2 = quad ? D * v * v : (T)0;
@@ -2993,7 +3014,7 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // i
     for (int r = lane; r < nefc; r += 64) {
       const T x = s.efc_jar[r];
       const unsigned char a = x < 0;
-      s.efc_active[r] = a;
+      S_EFC_ACTIVE(s)[r] = a;
       const T Dr = row_D(s, r, nlim);
       s.efc_force[r] = a ? -Dr * x : (T)0;
     }
@@ -3025,8 +3046,8 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     if (d < M.nv) {
       T acc = 0;
       for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
-        const T Dr = s.efc_D[r];
-        acc += (s.efc_active[r] && lim_index(s.lim_id[r]) == d) ? Dr : (T)0;
+        const T Dr = S_EFC_D(s)[r];
+        acc += (S_EFC_ACTIVE(s)[r] && lim_index(S_LIM_ID(s)[r]) == d) ? Dr : (T)0;
       }
       if (acc != 0) { const int pd = s.hperm[d]; s.H[MYO_HIDX(pd, pd)] += acc; }
     }
@@ -3034,9 +3055,9 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   SYNC();
   // tendon-limit rows: rank-1 blocks over the tendon's dofs (one row at a time)
   for (int r = nl; r < nlim; ++r) {
-    if (!s.efc_active[r]) continue;
+    if (!S_EFC_ACTIVE(s)[r]) continue;
     PHASE {
-      const int t = lim_index(s.lim_id[r]);
+      const int t = lim_index(S_LIM_ID(s)[r]);
       const unsigned long long m = M.tendon_dofmask[t];
       const int n = myo_popcll(m);
       const int a = lane >> 3, b = lane & 7;
@@ -3047,7 +3068,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         for (int k = 0; k < b; ++k) mb &= mb - 1;
         const int da = myo_ffsll(ma), db = myo_ffsll(mb);
         const int pa = s.hperm[da], pb = s.hperm[db];
-        s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += s.efc_D[r] * tenj_get(s, t, a) * tenj_get(s, t, b);
+        s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += S_EFC_D(s)[r] * tenj_get(s, t, a) * tenj_get(s, t, b);
       }
     }
     SYNC();
@@ -3088,7 +3109,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       // ---- stage B for contact ci (its columns were staged in the previous trip)
       if (ci >= 0) {
         const ContactRec<T>& c = s.con[ci];
-        const unsigned char* act = s.efc_active + nlim + 4 * ci;
+        const unsigned char* act = S_EFC_ACTIVE(s) + nlim + 4 * ci;
         T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
         if (act[0]) { nn += 1; n1 += c.muA; a11 += c.muA * c.muA; }
         if (act[1]) { nn += 1; n1 -= c.muA; a11 += c.muA * c.muA; }

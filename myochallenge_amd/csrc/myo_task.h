@@ -439,7 +439,7 @@ DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
       const double nominal = (double)M.geom_friction[3 * K.objg_gid0 + lane], ch = K.obj_friction_change[lane % 3];
       const T f = (T)rng_range(h, nominal - ch, nominal + ch);
       constexpr int NF = Scratch<T, NC>::OBJG_NF;         // (the base scratch keeps the sliding coefficient only; the other two draws are consumed)
-      if (lane % 3 < NF) s.objg_fric[(lane / 3) * NF + lane % 3] = f;
+      if (lane % 3 < NF) S_OBJF(K, s)[(lane / 3) * NF + lane % 3] = f;
     }
     if (lane == 0) {
       s.which_task = 0; s.counter = 0; s.elapsed = 0; s.ep_ret = 0; s.ep_len = 0;
@@ -470,9 +470,9 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
   PHASE { if (lane == 0) s.pub = pub; }
   SYNC();
   PHASE {
-    if (K.objg_gidn > 0) {
+    if (K.objg_gidn > 0 && !Scratch<T, NC>::SPILL) {            // (SPILL: read in place, S_OBJF)
       constexpr int NF = Scratch<T, NC>::OBJG_NF;
-      for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) s.objg_fric[i] = (T)rec[L.off_objfric + 3 * (i / NF) + i % NF];
+      for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) S_OBJF(K, s)[i] = (T)rec[L.off_objfric + 3 * (i / NF) + i % NF];
     }
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; if constexpr (sizeof(T) != sizeof(HP)) s.qacc_warm_[i] = (T)rec[L.off_warm + i]; }
@@ -507,9 +507,9 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
   // wave.h); | 4 = this call did not start the step either: the task state (targets, counters) is as loaded
   const int wt = mid_step & 2, later = mid_step & 4;
   PHASE {
-    if (K.kind == MYO_TASK_REORIENT_K && !mid_step) {
+    if (K.kind == MYO_TASK_REORIENT_K && !mid_step && !Scratch<T, NC>::SPILL) {
       constexpr int NF = Scratch<T, NC>::OBJG_NF;
-      for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + 3 * (i / NF) + i % NF] = (double)s.objg_fric[i];
+      for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + 3 * (i / NF) + i % NF] = (double)S_OBJF(K, s)[i];
     }
     for (int i = lane; i < M.nq; i += 64) st_pub(rec + L.off_qpos + i, (double)s.qpos[i], wt);
     for (int i = lane; i < M.nv; i += 64) { st_pub(rec + L.off_qvel + i, (double)s.qvel[i], wt); if constexpr (sizeof(T) != sizeof(HP)) st_pub(rec + L.off_warm + i, (double)s.qacc_warm_[i], wt); }

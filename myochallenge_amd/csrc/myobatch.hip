@@ -1066,6 +1066,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
     b->K.ctrl_ws = (double*)w;
     if (w) b->allocs.push_back(w);
   }
+  b->K.objf_off = b->L.off_objfric - b->L.off_warm;      // (Scratch::SPILL reads the object group's friction in the record)
   if (m->integrator == 1) {        // RK4 stage storage, one RkScratch per env (global memory)
     void* w = nullptr;
     const size_t each = dtype == MYO_F64 ? sizeof(RkScratch<double>) : sizeof(RkScratch<float>);

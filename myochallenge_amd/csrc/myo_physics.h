@@ -60,12 +60,12 @@ __device__ __forceinline__ constexpr int myo_hrow(int i) { const int q = i >> 2;
 #define MYO_HIDX(i, j) (myo_hrow(i) + (j)) /* i >= j */
 
 /* doubles per env of TaskDev::ctrl_ws (whole 128-byte lines): the controls, the tendon moment arms [slot][tendon], and — for the
-   34-slot fp64 scratch only (Scratch::SPILL) — the limit rows' D and ids and the rows' active flags */
+   34-slot fp64 scratch only (Scratch::SPILL) — the tendon lengths, the activation rates and the reward terms */
 #define MYO_WS_TENJ MYO_NU_MAX
-#define MYO_WS_EFCD (MYO_NU_MAX + MYO_NT_MAX * MYO_TJ_MAX)
-#define MYO_WS_LIMID (MYO_WS_EFCD + MYO_NLIM_MAX)
-#define MYO_WS_ACTIVE (MYO_WS_LIMID + (2 * MYO_NLIM_MAX + 7) / 8)
-#define MYO_ENVWS_N ((MYO_WS_ACTIVE + (MYO_NLIM_MAX + 4 * MYO_NCON_BIG + 7) / 8 + 15) / 16 * 16)
+#define MYO_WS_TLEN (MYO_NU_MAX + MYO_NT_MAX * MYO_TJ_MAX)
+#define MYO_WS_ADOT (MYO_WS_TLEN + MYO_NT_MAX)
+#define MYO_WS_RWD (MYO_WS_ADOT + MYO_NU_MAX)
+#define MYO_ENVWS_N ((MYO_WS_RWD + 8 + 15) / 16 * 16)
 #define MYO_TASK_REORIENT_K 3   // == MYO_TASK_REORIENT of include/myobatch.h (checked in myobatch.hip)
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
@@ -183,14 +183,16 @@ struct Scratch : ScratchPoses<T> {
   // per-env friction coefficients kept per geom of an object group: all three (sliding, torsional, rolling) in the big scratch that
   // batches with a die get, the sliding one in the base scratch (an object group on a base batch: torsional / rolling stay nominal)
   static constexpr int OBJG_NF = NC >= MYO_NCON_BIG ? 3 : 1;
-  // The 34-slot fp64 scratch keeps four small arrays in GLOBAL memory — the object group's friction triples in the env record, where
-  // they live anyway, the limit rows' D / ids and the rows' active flags in the env's workspace (ctrl_ws): 1,120 B, the difference
-  // between six and seven workgroups per CU (24,064 -> 22,944 B; the die's k_step 2.99 -> 2.6 ms).  Accessors: S_OBJF, S_LIM_ID, S_EFC_D,
-  // S_EFC_ACTIVE below; one wave per workgroup, so a lane's global store is visible to the loads of a later phase in program order.
+  // The 34-slot fp64 scratch keeps what a substep touches ONCE in GLOBAL memory — the object group's friction triples and the muscle
+  // activations in the env record, where they live anyway; the tendon lengths, the activation rates and the reward terms in the env's
+  // workspace (ctrl_ws): 1,072 B, the difference between six and seven workgroups per CU (24,064 -> 22,992 B).  Accessors: S_OBJF,
+  // S_ACT / act_set, S_TEN_LENGTH, S_ACT_DOT, S_RWD below; one wave per workgroup, so a lane's global store is visible to the loads of a
+  // later phase in program order.  (A first cut moved the limit rows' D / ids and the rows' active flags instead — the solver's own
+  // arrays: 2.98 -> 2.80 ms for the die's k_step where a 29-slot capacity experiment had said 2.62.)
   static constexpr bool SPILL = sizeof(T) == sizeof(HP) && NC >= MYO_NCON_BIG;
   static_assert(NC >= MYO_NCON_F64 && MYO_NLIM_MAX + 4 * NC <= 192, "contact capacity: at least the smallest base (the aliases below are sized for it), at most three constraint rows per lane");
   // ---- state (HP in every build)
-  HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[MYO_NU_MAX];
+  HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[SPILL ? 1 : MYO_NU_MAX];      // (act: S_ACT)
   HP time;
   // ---- per-env parameters
   HP ball_size[2];
@@ -209,8 +211,8 @@ struct Scratch : ScratchPoses<T> {
   // (short-lived arrays alias longer-lived storage, see the S_* accessors below)
   T cdof[MYO_NV_MAX * 6];
   union {                         // tendon lengths (tendon stage .. actuation) and activation rates (actuation .. advance) share a slot:
-    HP ten_length[MYO_NT_MAX];    // fwd_actuation reads every length before it stores the first rate.  HP: what muscle forces and
-    T act_dot[MYO_NU_MAX];        // tendon limits are made of
+    HP ten_length[SPILL ? 1 : MYO_NT_MAX];    // fwd_actuation reads every length before it stores the first rate.  HP: what muscle forces and
+    T act_dot[SPILL ? 1 : MYO_NU_MAX];        // tendon limits are made of (S_TEN_LENGTH, S_ACT_DOT)
   };
                                   // (ten_vel, act_force: S_TEN_VEL / S_ACT_FORCE below; the moment arms: ScratchPoses)
   alignas(16) T H[MYO_H_SIZE];   // dense system matrix / its Cholesky factor (packed lower triangle, MYO_HIDX); hosts short-lived arrays too
@@ -224,19 +226,19 @@ struct Scratch : ScratchPoses<T> {
   // contacts (contacts_emit_*), at least NC.  Measured on the hand with P2's ball sizes: up to 19 contacts (oracle, 32 episodes).
   static constexpr int NREC = (sizeof(T) == sizeof(HP) && NC == MYO_NCON_F64) ? MYO_NREC_F64 : NC;
   alignas(16) ContactRec<T> con[NREC];
-  short lim_id[SPILL ? 4 : MYO_NLIM_MAX];                              // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1) (S_LIM_ID)
-  T efc_D[SPILL ? 1 : MYO_NLIM_MAX];                                   // limit rows only; contact rows: con[] (S_EFC_D)
+  short lim_id[MYO_NLIM_MAX];                                          // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1)
+  T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
   // bvec, efc_jv, efc_force: contiguous, in this order — the linear solves stage their operands from bvec on (S_SOLVE_STAGE)
   alignas(16) T bvec[MYO_NB_MAX * 6];
   T efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC], efc_jar[MYO_NLIM_MAX + 4 * NC];
-  unsigned char efc_active[SPILL ? 8 : MYO_NLIM_MAX + 4 * NC];         // (S_EFC_ACTIVE)
+  unsigned char efc_active[MYO_NLIM_MAX + 4 * NC];
   // the seven dof vectors: contiguous, in this order (fp64 stepper: the position stage's poses live here, see ScratchPoses)
   alignas(16) T qfrc_smooth[MYO_NV_MAX], qacc_smooth[MYO_NV_MAX], qacc[MYO_NV_MAX], qfrc_constraint[MYO_NV_MAX];
   T Ma[MYO_NV_MAX], search[MYO_NV_MAX], Mv[MYO_NV_MAX];   // search: -gradient between update_constraint and the solve, then the Newton direction
   T qM[MYO_NM_MAX];               // tree-sparse inertia matrix (written by crb, i.e. after the tendon stage: the last piece of its staging area)
   RkScratch<T>* rk;               // null unless the model integrates with RK4
   // ---- task layer
-  T rwd[8];
+  T rwd[SPILL ? 1 : 8];              // (S_RWD)
 #ifdef MYO_PROF
   unsigned long long prof[MYO_NPROF], prof_t;
 #endif
@@ -375,16 +377,21 @@ template <> __device__ __forceinline__ const DevModel<double>& myo_cmodel<double
 #define LISNULL(r) ((r) < 0)
 #endif
 
-// the four arrays Scratch::SPILL keeps in global memory
-template <typename T, int NC> DEV T* S_EFC_D(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_EFCD; else return s.efc_D; }
-template <typename T, int NC> DEV const T* S_EFC_D(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_EFCD; else return s.efc_D; }
-template <typename T, int NC> DEV short* S_LIM_ID(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<short*>(s.ctrl_g + MYO_WS_LIMID); else return s.lim_id; }
-template <typename T, int NC> DEV const short* S_LIM_ID(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<const short*>(s.ctrl_g + MYO_WS_LIMID); else return s.lim_id; }
-template <typename T, int NC> DEV unsigned char* S_EFC_ACTIVE(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<unsigned char*>(s.ctrl_g + MYO_WS_ACTIVE); else return s.efc_active; }
-template <typename T, int NC> DEV const unsigned char* S_EFC_ACTIVE(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return reinterpret_cast<const unsigned char*>(s.ctrl_g + MYO_WS_ACTIVE); else return s.efc_active; }
+// what Scratch::SPILL keeps in global memory (the env record: act = the na doubles in front of the warm start; the env workspace)
 template <typename T, int NC> DEV T* S_OBJF(const TaskDev& K, Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g + K.objf_off; else return s.objg_fric; }
 template <typename T, int NC> DEV const T* S_OBJF(const TaskDev& K, const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g + K.objf_off; else return s.objg_fric; }
-template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? S_EFC_D(s)[r] : s.con[(r - nlim) >> 2].D; }
+template <typename T, int NC> DEV const HP* S_ACT(const DevModel<T>& M, const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g - M.na; else return s.act; }
+// (a part of a step that hands the record on writes it through, like the warm start: warm_set)
+template <typename T, int NC> DEV void act_set(const DevModel<T>& M, Scratch<T, NC>& s, int i, HP v) {
+  if constexpr (Scratch<T, NC>::SPILL) st_pub(s.warm_g - M.na + i, (double)v, UNI(s.pub)); else s.act[i] = v;
+}
+template <typename T, int NC> DEV HP* S_TEN_LENGTH(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_TLEN; else return s.ten_length; }
+template <typename T, int NC> DEV const HP* S_TEN_LENGTH(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_TLEN; else return s.ten_length; }
+template <typename T, int NC> DEV T* S_ACT_DOT(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_ADOT; else return s.act_dot; }
+template <typename T, int NC> DEV const T* S_ACT_DOT(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_ADOT; else return s.act_dot; }
+template <typename T, int NC> DEV T* S_RWD(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_RWD; else return s.rwd; }
+template <typename T, int NC> DEV const T* S_RWD(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_RWD; else return s.rwd; }
+template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
 
 // ------------------------------------------------------------------------------------------
 // small math
@@ -1063,7 +1070,7 @@ DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       const int e0 = M.tendon_eadr[t], n = M.tendon_enum[t];
       HP len = 0;
       for (int k = 0; k < n; ++k) len += S_TELEN(s)[e0 + k];
-      s.ten_length[t] = len;
+      S_TEN_LENGTH(s)[t] = len;
     }
     if constexpr (sizeof(T) == sizeof(HP)) {      // the finished moment arms leave LDS: [slot][tendon]
       for (int o = lane; o < MYO_TJ_MAX * MYO_NT_MAX; o += 64) {
@@ -2041,8 +2048,8 @@ DEVFN void friction_rows(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T
       T Kc, Bc, Ic;
       if (tendon) sol_param(M, M.tendon_solref_fri + 2 * i, M.tendon_solimp_fri + 5 * i, (T)0, &Kc, &Bc, &Ic);
       else sol_param(M, M.dof_solref + 2 * i, M.dof_solimp + 5 * i, (T)0, &Kc, &Bc, &Ic);
-      S_LIM_ID(s)[r] = i | MYO_LIM_FRIC;
-      S_EFC_D(s)[r] = sol_D(Ic, tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = 0;
+      s.lim_id[r] = i | MYO_LIM_FRIC;
+      s.efc_D[r] = sol_D(Ic, tendon ? M.tendon_invweight0[i] : M.dof_invweight0[i]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = 0;
     }
     if (lane == 0) {
       const int n = base + total < MYO_NLIM_MAX ? base + total : MYO_NLIM_MAX;
@@ -2088,8 +2095,8 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
         if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
           sol_param(M, M.jnt_solref + 2 * j, M.jnt_solimp + 5 * j, dm, &Kc, &Bc, &Ic);
-          S_LIM_ID(s)[r] = M.jnt_dofadr[j] | (side ? MYO_LIM_UPPER : 0);   // joint rows keep the DOF index
-          S_EFC_D(s)[r] = sol_D(Ic, M.dof_invweight0[M.jnt_dofadr[j]]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
+          s.lim_id[r] = M.jnt_dofadr[j] | (side ? MYO_LIM_UPPER : 0);   // joint rows keep the DOF index
+          s.efc_D[r] = sol_D(Ic, M.dof_invweight0[M.jnt_dofadr[j]]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -2106,7 +2113,7 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
     int c = 0;
     T a = 0, b = 0;
     if (t < M.ntendon && M.tendon_limited[t]) {
-      const HP L = s.ten_length[t], mh = M.h_tendon_margin[t];
+      const HP L = S_TEN_LENGTH(s)[t], mh = M.h_tendon_margin[t];
       const HP ah = L - M.h_tendon_range[2 * t], bh = M.h_tendon_range[2 * t + 1] - L;
       c = (ah < mh ? 1 : 0) + (bh < mh ? 1 : 0);
       a = (T)(ah - mh); b = (T)(bh - mh);      // kept as dist - margin
@@ -2118,15 +2125,15 @@ DEVFN void constraint_limits(const DevModel<T>& M_in, const TaskDev& K_in, Scrat
     const int t = lane;
     if (LV(cnt) > 0) {
       int r = nl + S_NPRE(s)[lane];
-      const HP L = s.ten_length[t], mh = M.h_tendon_margin[t];
+      const HP L = S_TEN_LENGTH(s)[t], mh = M.h_tendon_margin[t];
       const int on_lo = (L - M.h_tendon_range[2 * t]) < mh, on_hi = (M.h_tendon_range[2 * t + 1] - L) < mh;
       for (int side = 0; side < 2; ++side) {
         const T dm = side ? LV(dhi) : LV(dlo);         // dist - margin
         if ((side ? on_hi : on_lo) && r < MYO_NLIM_MAX) {
           T Kc, Bc, Ic;
           sol_param(M, M.tendon_solref_lim + 2 * t, M.tendon_solimp_lim + 5 * t, dm, &Kc, &Bc, &Ic);
-          S_LIM_ID(s)[r] = t | (side ? MYO_LIM_UPPER : 0);
-          S_EFC_D(s)[r] = sol_D(Ic, M.tendon_invweight0[t]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
+          s.lim_id[r] = t | (side ? MYO_LIM_UPPER : 0);
+          s.efc_D[r] = sol_D(Ic, M.tendon_invweight0[t]); S_ROW_B(s)[r] = Bc; S_ROW_KIP(s)[r] = Kc * Ic * dm;
           r++;
         }
       }
@@ -2445,15 +2452,15 @@ DEVFN void J_times_gen(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCRE
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T val;
-      if (r < nl) val = lim_sign<T>(S_LIM_ID(s)[r]) * v[lim_index(S_LIM_ID(s)[r])];
+      if (r < nl) val = lim_sign<T>(s.lim_id[r]) * v[lim_index(s.lim_id[r])];
       else if (r < nlim) {
-        const int t = lim_index(S_LIM_ID(s)[r]);
+        const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acc = 0, tj[MYO_TJ_MAX];
         tenj_row(s, t, tj);
 #pragma unroll
         for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * v[d]; }
-        val = lim_sign<T>(S_LIM_ID(s)[r]) * acc;
+        val = lim_sign<T>(s.lim_id[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
@@ -2482,15 +2489,15 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T val;
-      if (r < nl) val = lim_sign<T>(S_LIM_ID(s)[r]) * v[lim_index(S_LIM_ID(s)[r])];
+      if (r < nl) val = lim_sign<T>(s.lim_id[r]) * v[lim_index(s.lim_id[r])];
       else if (r < nlim) {
-        const int t = lim_index(S_LIM_ID(s)[r]);
+        const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acc = 0, tj[MYO_TJ_MAX];
         tenj_row(s, t, tj);
 #pragma unroll
         for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * v[d]; }
-        val = lim_sign<T>(S_LIM_ID(s)[r]) * acc;
+        val = lim_sign<T>(s.lim_id[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
@@ -2546,15 +2553,15 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
       T vala, valb;
-      if (r < nl) { const T sg = lim_sign<T>(S_LIM_ID(s)[r]); const int id = lim_index(S_LIM_ID(s)[r]); vala = sg * va[id]; valb = sg * vb[id]; }
+      if (r < nl) { const T sg = lim_sign<T>(s.lim_id[r]); const int id = lim_index(s.lim_id[r]); vala = sg * va[id]; valb = sg * vb[id]; }
       else if (r < nlim) {
-        const int t = lim_index(S_LIM_ID(s)[r]);
+        const int t = lim_index(s.lim_id[r]);
         unsigned long long m = M.tendon_dofmask[t];
         T acca = 0, accb = 0, tj[MYO_TJ_MAX];
         tenj_row(s, t, tj);
 #pragma unroll
         for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acca += tj[k] * va[d]; accb += tj[k] * vb[d]; }
-        vala = lim_sign<T>(S_LIM_ID(s)[r]) * acca; valb = lim_sign<T>(S_LIM_ID(s)[r]) * accb;
+        vala = lim_sign<T>(s.lim_id[r]) * acca; valb = lim_sign<T>(s.lim_id[r]) * accb;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
         const ContactRec<T>& c = s.con[ci];
@@ -2621,8 +2628,8 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
     if (d < M.nv) {
       T acc = 0;
       for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
-        const T v = lim_sign<T>(S_LIM_ID(s)[r]) * f[r];
-        acc += (lim_index(S_LIM_ID(s)[r]) == d) ? v : (T)0;
+        const T v = lim_sign<T>(s.lim_id[r]) * f[r];
+        acc += (lim_index(s.lim_id[r]) == d) ? v : (T)0;
       }
       // (four rows at a time: the fp64 stepper's moment arms come from global memory, so the reads of a group are requested together;
       //  the sum keeps its row order)
@@ -2632,12 +2639,12 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int r = r0 + k < nlim ? r0 + k : r0;                          // (rows beyond the last: a valid read, dropped below)
-          const int t = lim_index(S_LIM_ID(s)[r]);
+          const int t = lim_index(s.lim_id[r]);
           const unsigned long long m = M.tendon_dofmask[t];
           on[k] = (r0 + k < nlim) && ((m >> d) & 1ull);
           const int slot = on[k] ? myo_popcll(m & ((1ull << d) - 1ull)) : 0;  // slot 0 is always a valid read
           jv[k] = tenj_get(s, t, slot);
-          fv[k] = lim_sign<T>(S_LIM_ID(s)[r]) * f[r];
+          fv[k] = lim_sign<T>(s.lim_id[r]) * f[r];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const T v = fv[k] * jv[k]; acc += on[k] ? v : (T)0; }
@@ -2725,7 +2732,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
           const T k = M.tendon_stiffness[t], b = M.tendon_damping[t];
           const unsigned long long m = M.tendon_dofmask[t];
           if ((k != 0 || b != 0) && ((m >> d) & 1ull)) {
-            const T f = -k * ((T)s.ten_length[t] - M.tendon_lengthspring[t]) - b * S_TEN_VEL(s)[t];
+            const T f = -k * ((T)S_TEN_LENGTH(s)[t] - M.tendon_lengthspring[t]) - b * S_TEN_VEL(s)[t];
             acc += tenj_get(s, t, myo_popcll(m & ((1ull << d) - 1ull))) * f;
           }
         }
@@ -2826,7 +2833,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       // host (act_pre, MYO_ACT_PRE per actuator: myobatch.hip); round 4's version divided 16 times per lane here.
       const HP* ap = M.h_act_pre + MYO_ACT_PRE * i;
       if (M.actuator_dyntype[i] == 3) {
-        const T act = (T)s.act[i - (M.nu - M.na)];
+        const T act = (T)S_ACT(M, s)[i - (M.nu - M.na)];
         const T* prm = M.actuator_dynprm + 10 * i;
         const T cc = tclamp(ctrl, (T)0, (T)1), ac = tclamp(act, (T)0, (T)1);
         const T w = (T)0.5 + (T)1.5 * ac, ideact = (T)ap[22];
@@ -2840,7 +2847,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       const T gear = M.actuator_gear[6 * i];
       // muscle length normalisation and the force-length curves in HP from the HP tendon length (the curves are
       // piecewise quadratics of DIFFERENCES like L - 1 and L - lmin); the force-velocity factor in T
-      const HP lenh = (HP)gear * s.ten_length[tid];
+      const HP lenh = (HP)gear * S_TEN_LENGTH(s)[tid];
       const T len = (T)lenh, vel = gear * S_TEN_VEL(s)[tid];
       T gain, bias = 0;
       if (M.actuator_gaintype[i] == 1) {
@@ -2884,7 +2891,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   if constexpr (sizeof(T) == sizeof(HP)) {
     // fp64 stepper (moment arms in global memory): one lane per (actuator, slot) — the reads coalesce — adding into the dof's entry
     PHASE {
-      if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) s.act_dot[lane - (M.nu - M.na)] = LV(adot);
+      if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) S_ACT_DOT(s)[lane - (M.nu - M.na)] = LV(adot);
       if (lane < M.nv) S_QFRC_ACTUATOR(s)[lane] = 0;
     }
     SYNC();
@@ -2905,7 +2912,7 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     return;
   }
   PHASE {
-    if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) s.act_dot[lane - (M.nu - M.na)] = LV(adot);
+    if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) S_ACT_DOT(s)[lane - (M.nu - M.na)] = LV(adot);
     const int d = lane;
     if (d < M.nv) {
       unsigned w[MYO_AQ_ROW / 2];
@@ -2934,12 +2941,12 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
 // what a friction-loss row's cost exceeds the ordinary rows' 0.5 D min(x, 0)^2 by (0 for the other rows): the sums below stay as
 // they are and models with friction loss add this on top
 template <typename T, int NC> DEV T fric_excess(const DevModel<T>& M, const Scratch<T, NC>& s, int r, T x) {
-  if (!lim_is_fric(S_LIM_ID(s)[r])) return (T)0;
-  const T fl = r < s.nl ? M.dof_frictionloss[lim_index(S_LIM_ID(s)[r])] : M.tendon_frictionloss[lim_index(S_LIM_ID(s)[r])];
+  if (!lim_is_fric(s.lim_id[r])) return (T)0;
+  const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
   T force; int quad;
-  const T c = fric_cost(S_EFC_D(s)[r], fl, x, &force, &quad);
+  const T c = fric_cost(s.efc_D[r], fl, x, &force, &quad);
   const T xm = tmin(x, (T)0);
-  return c - (T)0.5 * S_EFC_D(s)[r] * xm * xm;
+  return c - (T)0.5 * s.efc_D[r] * xm * xm;
 }
 
 // friction-loss rows after a change of jar: clamped force, "active" = the quadratic zone (what the Hessian sees); returns the
@@ -2951,11 +2958,11 @@ DEVFN HP fric_update(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   const int nlim = s.nl + s.ntl;
   PHASE {
     for (int r = lane; r < nlim; r += 64) {
-      if (!lim_is_fric(S_LIM_ID(s)[r])) continue;
-      const T fl = r < s.nl ? M.dof_frictionloss[lim_index(S_LIM_ID(s)[r])] : M.tendon_frictionloss[lim_index(S_LIM_ID(s)[r])];
+      if (!lim_is_fric(s.lim_id[r])) continue;
+      const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
       T force; int quad;
-      (void)fric_cost(S_EFC_D(s)[r], fl, s.efc_jar[r], &force, &quad);
-      s.efc_force[r] = force; S_EFC_ACTIVE(s)[r] = (unsigned char)quad;
+      (void)fric_cost(s.efc_D[r], fl, s.efc_jar[r], &force, &quad);
+      s.efc_force[r] = force; s.efc_active[r] = (unsigned char)quad;
     }
   }
   SYNC();
@@ -2985,8 +2992,8 @@ DEVFN T fric_linesearch(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, T q
     PHASE { (void)lane; }
     WAVE_SUM3_N(T, e1, e2, e3unused, nefc, r, {
       const T v = s.efc_jv[r], x = s.efc_jar[r] + alpha * v, D = row_D(s, r, nlim);
-      if (r < nlim && lim_is_fric(S_LIM_ID(s)[r])) {
-        const T fl = r < s.nl ? M.dof_frictionloss[lim_index(S_LIM_ID(s)[r])] : M.tendon_frictionloss[lim_index(S_LIM_ID(s)[r])];
+      if (r < nlim && lim_is_fric(s.lim_id[r])) {
+        const T fl = r < s.nl ? M.dof_frictionloss[lim_index(s.lim_id[r])] : M.tendon_frictionloss[lim_index(s.lim_id[r])];
         T force; int quad;
         (void)fric_cost(D, fl, x, &force, &quad);
         _e1 = -force * v; _e2 = quad ? D * v * v : (T)0;
@@ -3014,7 +3021,7 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // i
     for (int r = lane; r < nefc; r += 64) {
       const T x = s.efc_jar[r];
       const unsigned char a = x < 0;
-      S_EFC_ACTIVE(s)[r] = a;
+      s.efc_active[r] = a;
       const T Dr = row_D(s, r, nlim);
       s.efc_force[r] = a ? -Dr * x : (T)0;
     }
@@ -3046,8 +3053,8 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     if (d < M.nv) {
       T acc = 0;
       for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
-        const T Dr = S_EFC_D(s)[r];
-        acc += (S_EFC_ACTIVE(s)[r] && lim_index(S_LIM_ID(s)[r]) == d) ? Dr : (T)0;
+        const T Dr = s.efc_D[r];
+        acc += (s.efc_active[r] && lim_index(s.lim_id[r]) == d) ? Dr : (T)0;
       }
       if (acc != 0) { const int pd = s.hperm[d]; s.H[MYO_HIDX(pd, pd)] += acc; }
     }
@@ -3055,9 +3062,9 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   SYNC();
   // tendon-limit rows: rank-1 blocks over the tendon's dofs (one row at a time)
   for (int r = nl; r < nlim; ++r) {
-    if (!S_EFC_ACTIVE(s)[r]) continue;
+    if (!s.efc_active[r]) continue;
     PHASE {
-      const int t = lim_index(S_LIM_ID(s)[r]);
+      const int t = lim_index(s.lim_id[r]);
       const unsigned long long m = M.tendon_dofmask[t];
       const int n = myo_popcll(m);
       const int a = lane >> 3, b = lane & 7;
@@ -3068,7 +3075,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         for (int k = 0; k < b; ++k) mb &= mb - 1;
         const int da = myo_ffsll(ma), db = myo_ffsll(mb);
         const int pa = s.hperm[da], pb = s.hperm[db];
-        s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += S_EFC_D(s)[r] * tenj_get(s, t, a) * tenj_get(s, t, b);
+        s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += s.efc_D[r] * tenj_get(s, t, a) * tenj_get(s, t, b);
       }
     }
     SYNC();
@@ -3109,7 +3116,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       // ---- stage B for contact ci (its columns were staged in the previous trip)
       if (ci >= 0) {
         const ContactRec<T>& c = s.con[ci];
-        const unsigned char* act = S_EFC_ACTIVE(s) + nlim + 4 * ci;
+        const unsigned char* act = s.efc_active + nlim + 4 * ci;
         T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
         if (act[0]) { nn += 1; n1 += c.muA; a11 += c.muA * c.muA; }
         if (act[1]) { nn += 1; n1 -= c.muA; a11 += c.muA * c.muA; }
@@ -3372,15 +3379,16 @@ DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) v
 template <typename T, int NC>
 DEV void advance(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) act_dot_r, LCREF(T) qacc_r, LCREF(T) vel_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  const T* act_dot = LPTR(const T, act_dot_r); const T* qacc = LPTR(const T, qacc_r);
+  const T* act_dot = LISNULL(act_dot_r) ? S_ACT_DOT(s) : LPTR(const T, act_dot_r);      // (null: the scratch's own, S_ACT_DOT)
+  const T* qacc = LPTR(const T, qacc_r);
   WAVE_FN
   const HP h = M.h_timestep;
   PHASE {
     const int i = lane;
     if (i < M.na) {
-      HP a = s.act[i] + h * (HP)act_dot[i];
+      HP a = S_ACT(M, s)[i] + h * (HP)act_dot[i];
       if (M.actuator_dyntype[i + (M.nu - M.na)] == 3) a = tclamp(a, (HP)0, (HP)1);
-      s.act[i] = a;
+      act_set(M, s, i, a);
     }
     if (i < M.nv) { s.qvel[i] += h * (HP)qacc[i]; warm_set(s, i, s.qacc[i]); }
     if (lane == 0) s.time += h;
@@ -3432,8 +3440,8 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
         S_RKDX(s)[i] = (T)0.5 * f0; S_RKDX(s)[nv + i] = (T)0.5 * f1;
       }
       for (int i = lane; i < na; i += 64) {
-        s.rk->x0[nq + nv + i] = s.act[i];
-        const T f2 = s.act_dot[i];
+        s.rk->x0[nq + nv + i] = S_ACT(M, s)[i];
+        const T f2 = S_ACT_DOT(s)[i];
         s.rk->Fsum[2 * nv + i] = f2; S_RKDX(s)[2 * nv + i] = (T)0.5 * f2;
       }
     }
@@ -3447,7 +3455,7 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
       integrate_pos(M, s, LOFF(s, S_RKDX(s)), h);
       PHASE {
         for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * (HP)S_RKDX(s)[nv + i];
-        for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i] + h * (HP)S_RKDX(s)[2 * nv + i];
+        for (int i = lane; i < na; i += 64) act_set(M, s, i, s.rk->x0[nq + nv + i] + h * (HP)S_RKDX(s)[2 * nv + i]);
         if (lane == 0) s.time = t0 + h * (HP)a;
       }
       SYNC();
@@ -3461,7 +3469,7 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
           S_RKDX(s)[i] = an * f0; S_RKDX(s)[nv + i] = an * f1;
         }
         for (int i = lane; i < na; i += 64) {
-          const T f2 = s.act_dot[i];
+          const T f2 = S_ACT_DOT(s)[i];
           s.rk->Fsum[2 * nv + i] = s.rk->Fsum[2 * nv + i] + wgt * f2; S_RKDX(s)[2 * nv + i] = an * f2;
         }
       }
@@ -3471,7 +3479,7 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
       for (int i = lane; i < nf; i += 64) S_RKDX(s)[i] = s.rk->Fsum[i] / 6;
       for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i];
-      for (int i = lane; i < na; i += 64) s.act[i] = s.rk->x0[nq + nv + i];
+      for (int i = lane; i < na; i += 64) act_set(M, s, i, s.rk->x0[nq + nv + i]);
       if (lane == 0) s.time = t0;
     }
     SYNC();
@@ -3482,9 +3490,9 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
     SYNC();
     solve_M(M, s, s.search, 1);
     PROF(s, 12)
-    advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.search), LNULL(const T));
+    advance(M, s, LNULL(const T), LOFF(s, s.search), LNULL(const T));
     PROF(s, 13)
   } else {
-    advance(M, s, LOFF(s, s.act_dot), LOFF(s, s.qacc), LNULL(const T));
+    advance(M, s, LNULL(const T), LOFF(s, s.qacc), LNULL(const T));
   }
 }

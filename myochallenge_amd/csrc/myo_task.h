@@ -98,10 +98,10 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
       S_OBS(s)[nh + 21 + i] = (T)(t2i - p2i);
       s.target_w[i] = t1i; s.target_w[3 + i] = t2i;
     }
-    if (i < M.na) S_OBS(s)[nh + 24 + i] = (T)s.act[i];
+    if (i < M.na) S_OBS(s)[nh + 24 + i] = (T)S_ACT(M, s)[i];
   }
   SYNC();
-  WAVE_SUM_N(T, asq, M.na, i, ((T)s.act[i] * (T)s.act[i]));
+  WAVE_SUM_N(T, asq, M.na, i, ((T)S_ACT(M, s)[i] * (T)S_ACT(M, s)[i]));
   PHASE {
     if (lane == 0) {
       const T* e1 = S_OBS(s) + nh + 18; const T* e2 = S_OBS(s) + nh + 21;
@@ -114,8 +114,8 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
       c[6] = fall ? (T)1 : (T)0;
       T dense = 0;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) { dense += (T)K.weights[k] * c[k]; s.rwd[k] = c[k]; }
-      s.rwd[7] = dense;
+      for (int k = 0; k < 7; ++k) { dense += (T)K.weights[k] * c[k]; S_RWD(s)[k] = c[k]; }
+      S_RWD(s)[7] = dense;
     }
   }
   SYNC();
@@ -155,10 +155,10 @@ DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scr
   PHASE {
     const int i = lane;
     if (i < nh) { o[i] = (T)s.qpos[i]; o[nh + i] = (T)(s.qvel[i] * dt); }
-    if (i < M.na) o[2 * nh + 18 + i] = (T)s.act[i];
+    if (i < M.na) o[2 * nh + 18 + i] = (T)S_ACT(M, s)[i];
   }
   SYNC();
-  WAVE_SUM_N(T, asq, M.na, i, ((T)s.act[i] * (T)s.act[i]));
+  WAVE_SUM_N(T, asq, M.na, i, ((T)S_ACT(M, s)[i] * (T)S_ACT(M, s)[i]));
   PHASE {
     if (lane == 0) {
       HP op[3], gp[3], er[3], oe[3], ge[3], t[3];
@@ -190,8 +190,8 @@ DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scr
       c[6] = -rd - 10.0 * pd; c[7] = (pd < K.ro_pos_th && rd < K.ro_rot_th && !drop) ? 1 : 0; c[8] = drop ? 1 : 0;
       HP dense = 0;
       for (int k = 0; k < 9; ++k) dense += K.ro_weights[k] * c[k];
-      s.rwd[0] = (T)c[0]; s.rwd[1] = (T)c[1]; s.rwd[2] = (T)c[5]; s.rwd[3] = (T)c[4]; s.rwd[4] = (T)c[6];
-      s.rwd[5] = (T)c[7]; s.rwd[6] = (T)c[8]; s.rwd[7] = (T)dense;
+      S_RWD(s)[0] = (T)c[0]; S_RWD(s)[1] = (T)c[1]; S_RWD(s)[2] = (T)c[5]; S_RWD(s)[3] = (T)c[4]; S_RWD(s)[4] = (T)c[6];
+      S_RWD(s)[5] = (T)c[7]; S_RWD(s)[6] = (T)c[8]; S_RWD(s)[7] = (T)dense;
       s.pos_dist = pd; s.rot_dist = rd;
     }
   }
@@ -257,7 +257,7 @@ DEVFN void set_init_state(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = (i < K.n_hand) ? (i == 0 ? (HP)K.init_qpos0 : (HP)0) : (HP)M.h_qpos0[i];
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = 0; if (!keep_dynamics) warm_set(s, i, (T)0); }
     if (!keep_dynamics) {
-      for (int i = lane; i < M.na; i += 64) s.act[i] = 0;
+      for (int i = lane; i < M.na; i += 64) act_set(M, s, i, (HP)0);
       for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, (T)0);
       if (lane == 0) { s.time = 0; s.bad = 0; }
     }
@@ -476,7 +476,7 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
     }
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
     for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; if constexpr (sizeof(T) != sizeof(HP)) s.qacc_warm_[i] = (T)rec[L.off_warm + i]; }
-    for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i];
+    if constexpr (!Scratch<T, NC>::SPILL) { for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i]; }      // (SPILL: read in place, S_ACT)
     for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, (T)0);
     if (lane < MYO_NV_MAX) s.hperm[lane] = (unsigned char)M.hperm[lane];
     if (lane == 0) {
@@ -513,7 +513,7 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
     }
     for (int i = lane; i < M.nq; i += 64) st_pub(rec + L.off_qpos + i, (double)s.qpos[i], wt);
     for (int i = lane; i < M.nv; i += 64) { st_pub(rec + L.off_qvel + i, (double)s.qvel[i], wt); if constexpr (sizeof(T) != sizeof(HP)) st_pub(rec + L.off_warm + i, (double)s.qacc_warm_[i], wt); }
-    for (int i = lane; i < M.na; i += 64) st_pub(rec + L.off_act + i, (double)s.act[i], wt);
+    if constexpr (!Scratch<T, NC>::SPILL) { for (int i = lane; i < M.na; i += 64) st_pub(rec + L.off_act + i, (double)s.act[i], wt); }
     if (lane == 0) {
       st_pub(rec + L.off_time, (double)s.time, wt);
       if (!mid_step) {
@@ -552,22 +552,22 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
   // is reset at once, and both the terminal and the returned observation are the (finite) reset observation, so that
   // no NaN reaches the normaliser statistics or the rollout buffer.  bad_state[env] = 1 tells the caller.
   const int bad = s.bad;
-  const int fall = s.rwd[6] != 0 || bad;
+  const int fall = S_RWD(s)[6] != 0 || bad;
   int is_trunc = 0, is_done = fall;
   PHASE {
-    if (lane == 0) { s.elapsed++; s.ep_len++; if (!bad) s.ep_ret += s.rwd[7]; }
+    if (lane == 0) { s.elapsed++; s.ep_len++; if (!bad) s.ep_ret += S_RWD(s)[7]; }
   }
   SYNC();
   if (s.elapsed >= K.max_episode_steps) { is_trunc = !fall; is_done = 1; }  // gym TimeLimit
   PHASE {
     if (lane == 0) {
-      rew[env] = bad ? 0.0f : (float)s.rwd[7];
+      rew[env] = bad ? 0.0f : (float)S_RWD(s)[7];
       done[env] = (unsigned char)is_done;
       if (trunc) trunc[env] = (unsigned char)is_trunc;
       if (bad_state) bad_state[env] = (unsigned char)bad;
       if (ep_info) { ep_info[2 * env] = (float)s.ep_ret; ep_info[2 * env + 1] = (float)s.ep_len; }
     }
-    if (comps && lane < 8) comps[(size_t)env * 8 + lane] = bad ? (lane == 6 ? 1.0f : 0.0f) : (float)s.rwd[lane];
+    if (comps && lane < 8) comps[(size_t)env * 8 + lane] = bad ? (lane == 6 ? 1.0f : 0.0f) : (float)S_RWD(s)[lane];
     if (term_obs && !bad) for (int i = lane; i < nobs; i += 64) term_obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i];
   }
   SYNC();
@@ -599,7 +599,7 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
   const int io = row < 0 ? env : row;
   load_env(M, K, L, rec, s, env);
   task_step_core(M, K, s, act + (size_t)io * M.nu);
-  const int bad = s.bad, fall = s.rwd[6] != 0 || bad;
+  const int bad = s.bad, fall = S_RWD(s)[6] != 0 || bad;
   if (bad) {                        // blown-up env: back to a finite reset state (see env_step)
     PHASE { if (lane == 0) s.episode++; }
     SYNC();
@@ -677,7 +677,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
   }
   // position-stage results first: the body poses (fp64 stepper) and the tendon lengths share LDS with vectors the later stages write
   PHASE {
-    for (int t = lane; t < M.ntendon; t += 64) out[D.ten_length + t] = (double)s.ten_length[t];
+    for (int t = lane; t < M.ntendon; t += 64) out[D.ten_length + t] = (double)S_TEN_LENGTH(s)[t];
     for (int sid = lane; sid < M.nsite; sid += 64) {
       HP p[3];
       body_point_hp(s, M.site_bodyid[sid], M.h_site_pos + 3 * sid, p);
@@ -725,7 +725,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       out[D.qacc_smooth + i] = (double)s.qacc_smooth[i];
       out[D.qacc + i] = (double)s.qacc[i];
     }
-    for (int i = lane; i < M.na; i += 64) out[D.act_dot + i] = (double)s.act_dot[i];
+    for (int i = lane; i < M.na; i += 64) out[D.act_dot + i] = (double)S_ACT_DOT(s)[i];
     if (lane == 0) {
       // contacts and rows as MuJoCo counts them: a contact's first slot is kind 0 or 3, padding rows do not exist
       const int nlim_ = s.nl + s.ntl;

@@ -554,3 +554,18 @@ def test_step_survives_another_batch_on_the_device(hip_lib):
         other.step_tensor(torch.zeros(32, 39, device="cuda"))
         assert all(torch.equal(x, y) for x, y in zip(ra, rb))
     assert torch.equal(a.get_state()[0], b.get_state()[0])
+
+
+@pytest.mark.gpu
+def test_scratch_sizes_keep_their_workgroups_per_cu(hip_lib):
+    """The LDS scratch of one env decides how many workgroups a CU holds (granule 1,280 B of 160 KB): the base scratches must stay at
+    eight per CU (<= 20,480 B) and the 34-slot fp64 scratch of the die at seven (<= 23,040 B; DESIGN.md §5 "Round 5" items 1 and 11) —
+    an array added to Scratch without a look at this costs 12 % of the step kernel."""
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    sizes = {}
+    for name, dtype in (("CustomMyoBaodingBallsP1", "f64"), ("CustomMyoBaodingBallsP1", "mixed"), ("CustomMyoReorientP1", "f64"), ("CustomMyoReorientP1", "mixed")):
+        env = EnvironmentFactory.create(name, num_envs=64, seed=1, dtype=dtype)
+        sizes[(name, dtype)] = env.batch.lds_bytes
+        env.close()
+    assert sizes[("CustomMyoBaodingBallsP1", "f64")] <= 20480 and sizes[("CustomMyoBaodingBallsP1", "mixed")] <= 20480, sizes
+    assert sizes[("CustomMyoReorientP1", "mixed")] <= 20480 and sizes[("CustomMyoReorientP1", "f64")] <= 23040, sizes

@@ -84,6 +84,17 @@ def test_step_parts_give_the_whole_steps_bits_on_emulation(emu_lib, models, dtyp
     assert any(w.dtype == np.uint8 and w.any() for w in whole), "the rollout should cross an episode end (TimeLimit 4)"
 
 
+def test_step_parts_of_the_die_on_emulation(emu_lib):
+    """The die on the fp64 stepper (34-slot scratch: activations and object friction read and written IN the record, tendon lengths /
+    activation rates / reward terms in the env workspace — Scratch::SPILL) in parts = whole steps, through a reset."""
+    from myochallenge_amd.synth_hand import synthetic_hand_die
+    die = compile_model(synthetic_hand_die(), integrator=0, unsupported_contacts="drop")
+    w = _rollout(emu_lib, die, "CustomMyoReorientP2", native.MYO_F64, 2, 7, "0", horizon=3, overflow_ok=True)
+    _same_bits(w, _rollout(emu_lib, die, "CustomMyoReorientP2", native.MYO_F64, 2, 7, None, horizon=3, overflow_ok=True))
+    _same_bits(w, _rollout(emu_lib, die, "CustomMyoReorientP2", native.MYO_F64, 2, 7, "1,1,3", horizon=3, overflow_ok=True))
+    assert any(x.dtype == np.uint8 and x.any() for x in w)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [native.MYO_F64, native.MYO_MIXED], ids=["f64", "mixed"])
 def test_step_parts_give_the_whole_steps_bits_on_gpu(hip_lib, models, dtype):

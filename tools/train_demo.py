@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "mixed"], help="stepper arithmetic (f64: the bench headline since round 4)")
     ap.add_argument("--lstm-hidden", type=int, default=0, help="recurrent policy: LSTM of this width for actor and critic in front of the "
                     "[256, 256] trunks (the reference's RecurrentPPO policy class); PPO settings of tools/bench_reorient.py")
+    ap.add_argument("--reference-settings", action="store_true", help="recurrent policy with the PPO settings of src/main_reorient.py:53-71 "
+                    "(n_steps 128, n_epochs 10, lr 2.55673e-5, clip 0.3, lambda 0.9 ...), 300-step episodes: BASELINE config E as the reference trains it")
     a = ap.parse_args()
     import torch
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
@@ -36,12 +38,17 @@ def main():
     if "Reorient" in a.env_name:      # the reward shaping of src/main_reorient.py:27-37
         cfgs = {"weighted_reward_keys": {"pos_dist": 0.5, "rot_dist": 0.02, "pos_dist_diff": 50, "rot_dist_diff": 5, "alive": 0.1,
                                          "act_reg": 0, "solved": 0.5, "done": 0, "sparse": 0}}
+    if a.reference_settings:
+        cfgs["max_episode_steps"] = 300
     env = EnvironmentFactory.create(a.env_name, num_envs=a.envs, seed=1, dtype=a.dtype, **cfgs)
     eval_env = EnvironmentFactory.create(a.env_name, num_envs=512, seed=999, dtype=a.dtype, **cfgs)
     venv = VecNormalize(env, gamma=0.99)
     torch.manual_seed(0)
     pol = ActorCriticPolicy(env.obs_dim, env.act_dim, (256, 256), (256, 256), lstm_hidden_size=a.lstm_hidden or None, log_std_init=-2.0)
-    if a.lstm_hidden:     # sequences = whole 32-step rollouts of an eighth of the envs per minibatch
+    if a.reference_settings:
+        cfg = PPOConfig(n_steps=128, batch_size=a.envs * 128 // 8, n_epochs=10, learning_rate=2.55673e-05, ent_coef=3.62109e-06, clip_range=0.3,
+                        gamma=0.99, gae_lambda=0.9, max_grad_norm=0.7, vf_coef=0.835671, bf16=True)
+    elif a.lstm_hidden:     # sequences = whole 32-step rollouts of an eighth of the envs per minibatch
         cfg = PPOConfig(n_steps=32, batch_size=a.envs * 32 // 8, n_epochs=4, learning_rate=2.5e-4, clip_range=0.2, ent_coef=2.5e-4,
                         vf_coef=0.5, gamma=0.99, gae_lambda=0.95, max_grad_norm=0.5, bf16=True)
     else:

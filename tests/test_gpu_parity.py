@@ -1355,6 +1355,37 @@ def test_graph_replay_equals_eager_minibatch_step(hip_lib):
         assert pl1 == pytest.approx(pl2, rel=1e-5, abs=1e-7)
 
 
+def test_epoch_graph_equals_per_step_graphs(hip_lib, monkeypatch):
+    """One GPU: the whole-epoch optimizer graph (every minibatch's index copy, forward / backward and Adam step in ONE replay,
+    rl/ppo.py _build_graphs) leaves the parameters, the Adam moments and the step counter that one replay per minibatch leaves —
+    bit for bit — over three rollouts with the same seeds."""
+    import torch
+    from myochallenge_amd.envs.environment_factory import EnvironmentFactory
+    from myochallenge_amd.rl.policy import ActorCriticPolicy
+    from myochallenge_amd.rl.ppo import PPO, PPOConfig
+    from myochallenge_amd.rl.vec_normalize import VecNormalize
+
+    def run(epoch_graph):
+        monkeypatch.setenv("MYO_EPOCH_GRAPH", "1" if epoch_graph else "0")
+        torch.manual_seed(0)
+        env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=1024, seed=5)
+        pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
+        algo = PPO(VecNormalize(env), pol, PPOConfig(n_steps=16, batch_size=4096, n_epochs=3), seed=0)
+        for _ in range(3):
+            algo.collect_rollouts()
+            algo.train()
+        torch.cuda.synchronize()
+        assert (algo._graph_epoch is not None) == epoch_graph
+        fa = algo._flat_adam
+        out = (fa.flat["p"].clone(), fa.m.clone(), fa.v.clone(), fa._step.clone(), algo.n_updates)
+        env.close()
+        return out
+    a, b = run(True), run(False)
+    assert a[4] == b[4] == 3 * 3 * 4
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_lstm_cell_kernels_match_formulas(hip_lib, dtype):
     """myo_lstm_cell_fwd / _bwd against the textbook LSTM cell (gate order i, f, g, o) with the next step's

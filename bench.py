@@ -17,7 +17,8 @@ Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barri
 and taken as the max over ranks; blocks repeat until --min-seconds (default 2 s) of timed wall have passed, so
 that the GPU is busy long enough for outside telemetry; `ms_per_step` / `value` are the MEDIAN block
 (`blocks`, `timed_seconds`, `ms_per_step_min/max` say what was seen).  `variants` (rank 0, N = 1) carries the
-same measurement for the mixed-precision stepper and for the RK4 integrator, plus `config_E_lstm256`: BASELINE config E (die reorient,
+same measurement for the mixed-precision stepper and for the RK4 integrator, `config_C_p2_8192` (BASELINE config C: phase 2, 8192 envs) and
+`reorient_p2_mlp` (the die env with the MLP policy) on the fp64 stepper, plus `config_E_lstm256`: BASELINE config E (die reorient,
 4096 envs, the reference's recurrent LSTM-256 policy class, rollout + update; myochallenge_amd/rl/bench_reorient_lstm.py).  Since round 4 the headline is the all-fp64 stepper
 (`--dtype f64`, the reference's own arithmetic); `--dtype mixed` is the faster variant whose per-step error is bounded in
 tests/test_gpu_parity.py::test_local_error_of_the_steppers.
@@ -262,8 +263,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def measure(dtype, integrator, min_seconds, steps, warmup):
+    def measure(dtype, integrator, min_seconds, steps, warmup, env_name=None, envs=None):
         """One configuration: set-up, W warm-up steps, then blocks of exactly `steps` steps until `min_seconds`."""
+        env_name, envs = env_name or args.env_name, envs or args.envs
         from myochallenge_amd.envs.environment_factory import EnvironmentFactory
         from myochallenge_amd.rl.policy import ActorCriticPolicy
         from myochallenge_amd.rl.ppo import PPO, PPOConfig
@@ -272,11 +274,11 @@ def main():
         # the rollout shrinks to K steps while the minibatch stays (close to) the configured size, so the optimizer
         # work per env step — and the GEMM shapes — are those of the headline configuration for any K
         n_steps = min(args.n_steps, max(1, steps))
-        rollout = n_steps * args.envs
+        rollout = n_steps * envs
         n_mb = max(1, rollout // args.batch_size)
         batch_size = max(1, (rollout // n_mb) // 128 * 128) if rollout >= 128 else rollout
         integ = None if integrator == "model" else integrator
-        env = EnvironmentFactory.create(args.env_name, num_envs=args.envs, device=local_rank, seed=1234 + rank,
+        env = EnvironmentFactory.create(env_name, num_envs=envs, device=local_rank, seed=1234 + rank,
                                         dtype=dtype, integrator=integ)
         integ_name = {0: "Euler", 1: "RK4"}[env._model.size("integrator")]
         venv = VecNormalize(env, gamma=0.99, sync_ranks=args.normalizer_sync)
@@ -340,7 +342,7 @@ def main():
             replica_spread = float(hi[0]) - float(lo[0])
         blocks.sort()
         med = blocks[len(blocks) // 2] if len(blocks) % 2 else 0.5 * (blocks[len(blocks) // 2 - 1] + blocks[len(blocks) // 2])
-        res = {"dtype": dtype, "integrator": integ_name, "value": args.envs * world * steps / med, "ms_per_step": 1e3 * med / steps,
+        res = {"dtype": dtype, "integrator": integ_name, "value": envs * world * steps / med, "ms_per_step": 1e3 * med / steps,
                "ms_per_step_min": 1e3 * blocks[0] / steps, "ms_per_step_max": 1e3 * blocks[-1] / steps, "blocks": len(blocks),
                "timed_seconds": total, "env_kernel_ms": kernel_ms, "optimizer_steps_per_sec": (algo.n_updates - upd0) / total,
                "n_steps": cfg.n_steps, "batch_size": cfg.batch_size, "n_epochs": cfg.n_epochs, "lds_bytes": env.batch.lds_bytes, "health": health,
@@ -369,6 +371,14 @@ def main():
             except Exception as exc:      # a variant must never take the headline line down
                 variants[name] = {"error": repr(exc)}
         if args.envs == 4096 and args.env_name == "CustomMyoBaodingBallsP1":
+            # BASELINE config C (phase 2, randomised, 8192 envs) and the die-reorient env with the MLP policy, fp64 — short blocks too
+            for name, (en, ne) in {"config_C_p2_8192": ("CustomMyoBaodingBallsP2", 8192), "reorient_p2_mlp": ("CustomMyoReorientP2", 4096)}.items():
+                try:
+                    r = measure("f64", "model", min(1.0, args.min_seconds), min(args.steps, 64), min(args.warmup, 16), env_name=en, envs=ne)
+                    variants[name] = dict({k: r[k] for k in ("dtype", "integrator", "value", "ms_per_step", "env_kernel_ms", "blocks", "timed_seconds",
+                                                              "lds_bytes", "health")}, env_name=en, envs=ne)
+                except Exception as exc:      # noqa: BLE001
+                    variants[name] = {"error": repr(exc)}
             # BASELINE config E (die reorient, LSTM-256 + MLP[256,256], the reference's RecurrentPPO policy class) on the same box
             try:
                 from myochallenge_amd.rl.bench_reorient_lstm import run as run_config_e

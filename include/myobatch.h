@@ -129,8 +129,15 @@ int myo_batch_set_step_generation(myo_batch* b, unsigned int gen);
  * out[1]: substeps in which an env had more contacts than its scratch holds (24; 20 in the fp64 stepper; 32 for models with
  *         extended collision pairs or a die) — the surplus was dropped, as MuJoCo drops contacts beyond nconmax with a warning;
  * out[2]: substeps in which an env had more joint-limit / tendon-limit / friction-loss rows than the scratch's row capacity
- *         (MYO_NLIM_MAX = 56) — the surplus was dropped; out[3]: reserved. */
+ *         (MYO_NLIM_MAX = 56) — the surplus was dropped;
+ * out[3]: the largest number of contact slots any substep counted in out[1] asked for (what capacity would have been enough). */
 int myo_batch_health(myo_batch* b, int out[4]);
+
+/* Device check of the premise of k_step's per-wave-slot workspace (csrc/wave.h: myo_wave_slot): launches n_workgroups one-wave
+ * workgroups with lds_bytes of dynamic LDS that each occupy their hardware wave slot's counter for ~20 us.
+ * out[0]: workgroups that found their slot occupied by another resident workgroup (0 on a device whose HW_ID layout is the expected one);
+ * out[1]: distinct slots seen; out[2]: largest slot index; out[3]: bit mask of the XCC ids seen. */
+int myo_debug_wave_slots(int device, int n_workgroups, int lds_bytes, int32_t out[4]);
 
 /* env.step(a) of the UNWRAPPED env for the envs selected by mask (dev uint8[N], NULL = all): no
  * TimeLimit / Monitor accounting, no auto-reset.  This is the `self.step(action)` that

@@ -56,7 +56,7 @@ __device__ __noinline__ void arrow_eliminate_blocks(int x_r) {
     if (lane < nv) xp[myrow] = v;
     if (lane < MYO_NV_MAX && ((M.arrow_pad >> lane) & 1ull)) xp[lane] = 0;
   }
-  __syncthreads();
+  SYNC();
   // ---- finger blocks.  Lane group g = lane >> 4 works on finger g (groups >= nf shadow the last finger and store nothing);
   // a fifth finger is done by all four groups redundantly (so its MFMA operand needs no exchange), group 0 stores.
   T y[2][4];                                            // L_Sf[r = lc][t], round 0: finger g, round 1: finger 4
@@ -113,7 +113,7 @@ __device__ __noinline__ void arrow_eliminate_blocks(int x_r) {
     const int hi = i > j ? i : j, lo = i > j ? j : i;
     acc[r] = Hp[MYO_HIDX(hi, lo)];
   }
-  __syncthreads();
+  SYNC();
   {
     const int nq = nf < 4 ? nf : 4;
     T op[4];
@@ -133,7 +133,7 @@ __device__ __noinline__ void arrow_eliminate_blocks(int x_r) {
     lds_t dst = i >= j ? Hp + MYO_HIDX(i, j) : stage + lane;
     *dst = acc[r];
   }
-  __syncthreads();
+  SYNC();
 }
 
 // fingers backward:  x_f = L_ff^-T (y_f - L_Sf' x_S), then x back in dof order
@@ -168,8 +168,8 @@ __device__ __noinline__ void arrow_finish(int x_r) {
     const T x3 = z3 * i3, x2 = (z2 - l32 * x3) * i2, x1 = (z1 - l21 * x2 - l31 * x3) * i1, x0 = (z0 - l10 * x1 - l20 * x2 - l30 * x3) * i0;
     if (writer) { xp[c0] = x0; xp[c0 + 1] = x1; xp[c0 + 2] = x2; xp[c0 + 3] = x3; }
   }
-  __syncthreads();
+  SYNC();
   if (lane < nv) xin[lane] = xp[myrow];
-  __syncthreads();
+  SYNC();
 }
 #endif

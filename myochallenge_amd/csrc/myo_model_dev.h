@@ -28,6 +28,15 @@
 #define MYO_ARROW_B 4     // rows per leaf block (= the K of v_mfma_*_16x16x4)
 #define MYO_ARROW_NF ((MYO_NV_MAX - MYO_ARROW_S) / MYO_ARROW_B)
 #define MYO_ACT_PRE 24    // host-resolved muscle constants per actuator (act_pre; myobatch.hip fills them, fwd_actuation reads them)
+// host-packed per-lane records (one level of table loads per stage instead of index -> index -> value chains; myobatch.hip fills them):
+//   bk_i[MYO_BK_I b ..] = depth, parent, jntnum, jntadr, is-free-joint, qposadr of joints 0..2, type of joints 0..2, 0
+//   bk_f[MYO_BK_F b ..] = body_pos[3], body_quat[4], then per joint k < 3: jnt_pos[3], jnt_axis[3], qpos0[qposadr]        (kinematics)
+//   jk_i[4 j ..]        = body, dofadr, type, root body of the joint's body                                                (com_pos)
+//   dk_i[2 d ..]        = qposadr of the dof's joint, 0;  dof_spr[2 d ..] = joint stiffness (0: none / free joint), qpos_spring   (passive forces)
+//   dof_submask[d]      = body_submask[dof_bodyid[d]]                                                                       (RNE bias)
+#define MYO_BK_I 12
+#define MYO_BK_F 28
+#define MYO_BK_NJ 3
 #define MYO_LD_FQ 12      // 64-item chunks of the tree-sparse L'DL factorisation (myo_sparse_ldl.h); more: the dense path
 #define MYO_LD_SQ 8       // 64-item chunks of its substitutions
 #ifndef MYO_OBJG_MAX
@@ -45,8 +54,8 @@
   X(geom_bodyid) X(geom_priority) X(site_bodyid) X(tendon_adr) X(tendon_num) X(tendon_limited)   \
   X(wrap_type) X(wrap_objid) X(wrap_side) X(actuator_dyntype) X(actuator_gaintype)               \
   X(actuator_biastype) X(actuator_tendon) X(actuator_ctrllimited) X(actuator_forcelimited)       \
-  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(act_sd) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk) X(te_i) X(tendon_eadr) X(tendon_enum) X(ld_fac) X(ld_sol) X(hperm) X(M_pkh)
-#define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask) X(act_dofmask) X(wr_mask) X(pc_mask)
+  X(pair_geom1) X(pair_geom2) X(M_i) X(M_j) X(mv_adr) X(mv_col) X(mv_e) X(act_tj) X(act_sd) X(wr_i) X(mv_pack) X(mv_len) X(aq_pack) X(aq_len) X(gw_elem) X(pc_i) X(pc_sup) X(M_pk) X(te_i) X(tendon_eadr) X(tendon_enum) X(ld_fac) X(ld_sol) X(hperm) X(M_pkh) X(bk_i) X(jk_i) X(dk_i)
+#define MYO_MODEL_U64_ARRAYS(X) X(body_dofmask) X(body_submask) X(dof_prevmask) X(tendon_dofmask) X(act_dofmask) X(wr_mask) X(pc_mask) X(dof_submask)
 #define MYO_MODEL_REAL_ARRAYS(X)                                                                 \
   X(qpos0) X(qpos_spring) X(body_pos) X(body_quat) X(body_ipos) X(body_imat) X(body_mass)        \
   X(body_inertia) X(body_invweight0) X(jnt_solref) X(jnt_solimp) X(jnt_pos) X(jnt_axis)          \
@@ -57,14 +66,14 @@
   X(tendon_lengthspring) X(tendon_invweight0) X(wrap_prm) X(actuator_dynprm)                     \
   X(actuator_gainprm) X(actuator_biasprm) X(actuator_ctrlrange) X(actuator_forcerange)           \
   X(actuator_gear) X(actuator_acc0) X(actuator_lengthrange) X(act_gear0) X(act_pre) X(wr_p) X(wr_m) X(pc_f) X(te_div)               \
-  X(pair_mg) X(dof_frictionloss) X(dof_solref) X(dof_solimp) X(tendon_frictionloss) X(tendon_solref_fri) X(tendon_solimp_fri)
+  X(pair_mg) X(dof_frictionloss) X(dof_solref) X(dof_solimp) X(tendon_frictionloss) X(tendon_solref_fri) X(tendon_solimp_fri) X(bk_f) X(dof_spr)
 
 // geometry tables of the HP stages (kinematic chain, contact / limit distances, observation): fp64 copies in
 // every build, named h_<array> (the fp64 stepper's h_ tables are its ordinary tables)
 #define MYO_MODEL_HP_ARRAYS(X)                                                                   \
   X(qpos0) X(body_pos) X(body_quat) X(jnt_pos) X(jnt_axis) X(jnt_range) X(jnt_margin)            \
   X(geom_pos) X(geom_mat) X(geom_size) X(geom_margin) X(geom_gap) X(geom_rbound) X(site_pos) X(wr_p) X(wr_m)       \
-  X(actuator_lengthrange) X(actuator_gainprm) X(actuator_biasprm) X(act_pre) X(tendon_range) X(tendon_margin) X(pair_mg)
+  X(actuator_lengthrange) X(actuator_gainprm) X(actuator_biasprm) X(act_pre) X(tendon_range) X(tendon_margin) X(pair_mg) X(bk_f)
 
 // Model table handle.  The tables are immutable for the lifetime of a batch, so the gfx950 build
 // reads them through the CONSTANT address space: a load with a wave-uniform index becomes a scalar

@@ -41,7 +41,7 @@ typedef double HP;
 
 // Stage timers: compiled only into the diagnostic build (-DMYO_PROF, libmyobatch_prof.so); the
 // product build contains no stamp.  Lane 0 accumulates s_memtime deltas per stage in LDS.
-#define MYO_NPROF 24
+#define MYO_NPROF 32
 #if defined(MYO_PROF) && !defined(MYO_EMU)
 #define PROF(s, k) { if (threadIdx.x == 0) { unsigned long long _t = clock64(); (s).prof[k] += _t - (s).prof_t; (s).prof_t = _t; } }
 #else
@@ -59,13 +59,20 @@ __device__ __forceinline__ constexpr int myo_hrow(int i) { const int q = i >> 2;
 #endif
 #define MYO_HIDX(i, j) (myo_hrow(i) + (j)) /* i >= j */
 
-/* doubles per env of TaskDev::ctrl_ws (whole 128-byte lines): the controls, the tendon moment arms [slot][tendon], and — for the
-   34-slot fp64 scratch only (Scratch::SPILL) — the tendon lengths, the activation rates and the reward terms */
+/* doubles per WAVE SLOT of TaskDev::ctrl_ws (whole 128-byte lines): the controls, the tendon moment arms [slot][tendon], the tendon
+   lengths, the activation rates and the reward terms (the last three are used by the 34-slot fp64 scratch only: Scratch::SPILL), the warm
+   start.  The workspace belongs to the HARDWARE wave slot the workgroup runs in (myo_wave_slot, wave.h), not to the env: nothing in it
+   outlives a workgroup (every entry is written before it is read, load_env .. store_env), two workgroups that run at the same time sit in
+   different slots by construction, and a slot's lines are only ever touched from ONE XCD — so they stay in that XCD's L2 from launch to
+   launch (2048 live slots x 3.9 KB) instead of being dirtied once per (env, part) wherever the part happens to run, and no XCD can hold a
+   stale dirty copy of a line another XCD is using (the per-env workspace was written by the parts of a step from different
+   XCDs with nothing ordering the write-backs). */
 #define MYO_WS_TENJ MYO_NU_MAX
 #define MYO_WS_TLEN (MYO_NU_MAX + MYO_NT_MAX * MYO_TJ_MAX)
 #define MYO_WS_ADOT (MYO_WS_TLEN + MYO_NT_MAX)
 #define MYO_WS_RWD (MYO_WS_ADOT + MYO_NU_MAX)
-#define MYO_ENVWS_N ((MYO_WS_RWD + 8 + 15) / 16 * 16)
+#define MYO_WS_WARM (MYO_WS_RWD + 8)            /* the solver's warm start while a workgroup holds the env (load_env .. store_env) */
+#define MYO_ENVWS_N ((MYO_WS_WARM + MYO_NV_MAX + 15) / 16 * 16)
 #define MYO_TASK_REORIENT_K 3   // == MYO_TASK_REORIENT of include/myobatch.h (checked in myobatch.hip)
 struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task layer)
   int kind, frame_skip, max_episode_steps, n_hand;
@@ -84,7 +91,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
   int objf_off;               // env record: doubles from the warm start to the object group's friction triples (Scratch::SPILL reads them in place)
-  double* ctrl_ws;            // double[n_envs][MYO_ENVWS_N] in global memory, fp64 stepper: each env's controls, then its tendon moment arms (ScratchPoses<double>)
+  double* ctrl_ws;            // double[MYO_WAVE_SLOTS][MYO_ENVWS_N] in global memory, fp64 stepper: the wave slots' workspaces (one per device, shared by its batches; emulation: one per env)
   int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity, [2] substeps that dropped joint / tendon limit or friction-loss rows beyond MYO_NLIM_MAX
   unsigned long long seed;
 };
@@ -323,7 +330,7 @@ static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRe
 // reads entries it wrote itself (lane i <-> entry i, i + 64, ...), so the global copies need no fence inside a workgroup.
 // moment arm of tendon t with respect to the slot-th dof it moves
 template <typename T, int NC> DEV T tenj_get(const Scratch<T, NC>& s, int t, int slot) {
-  if constexpr (sizeof(T) == sizeof(HP)) return (T)s.tenj_g[slot * MYO_NT_MAX + t]; else return s.ten_J[t * MYO_TJ_MAX + slot];
+  if constexpr (sizeof(T) == sizeof(HP)) return (T)((GPTR(const double))s.tenj_g)[slot * MYO_NT_MAX + t]; else return s.ten_J[t * MYO_TJ_MAX + slot];
 }
 // all MYO_TJ_MAX of them (requested together: the fp64 stepper's come from global memory)
 template <typename T, int NC> DEV void tenj_row(const Scratch<T, NC>& s, int t, T* j) {
@@ -333,10 +340,11 @@ template <typename T, int NC> DEV void tenj_row(const Scratch<T, NC>& s, int t, 
 // where the tendon stage accumulates them: the member itself (mixed) / the constraint-row arrays, free until constraint_limits (fp64)
 template <typename T, int NC> DEV T* S_TENJ_STAGE(Scratch<T, NC>& s) { if constexpr (sizeof(T) == sizeof(HP)) return s.efc_jv; else return s.ten_J; }
 static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 3 * (MYO_NLIM_MAX + 4 * MYO_NCON_F64), "fp64 stepper: the moment-arm stage fits in efc_jv, efc_force, efc_jar");
-template <typename T, int NC> DEV T ctrl_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.ctrl_g[i]; else return s.ctrl_[i]; }
-template <typename T, int NC> DEV void ctrl_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) s.ctrl_g[i] = (double)v; else s.ctrl_[i] = v; }
-template <typename T, int NC> DEV T warm_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)s.warm_g[i]; else return s.qacc_warm_[i]; }
-template <typename T, int NC> DEV void warm_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) st_pub(s.warm_g + i, (double)v, UNI(s.pub)); else s.qacc_warm_[i] = v; }
+template <typename T, int NC> DEV T ctrl_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)((GPTR(const double))s.ctrl_g)[i]; else return s.ctrl_[i]; }
+template <typename T, int NC> DEV void ctrl_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) ((GPTR(double))s.ctrl_g)[i] = (double)v; else s.ctrl_[i] = v; }
+// (fp64 stepper: in the wave slot's workspace between load_env and store_env, which copy it from / to the env's record — warm_g)
+template <typename T, int NC> DEV T warm_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)((GPTR(const double))s.ctrl_g)[MYO_WS_WARM + i]; else return s.qacc_warm_[i]; }
+template <typename T, int NC> DEV void warm_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) ((GPTR(double))s.ctrl_g)[MYO_WS_WARM + i] = (double)v; else s.qacc_warm_[i] = v; }
 #define MYO_NEFC_MIN (MYO_NLIM_MAX + 4 * MYO_NCON_F64)   /* rows of the smallest scratch: every alias of an efc_* array must fit in this many */
 static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MIN && 2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MIN && MYO_NJ_MAX * 3 <= MYO_NEFC_MIN && MYO_NB_MAX * 3 <= MYO_NEFC_MIN && 64 <= MYO_NEFC_MIN,
               "efc aliases (S_RKDX, S_XANCHOR / S_XAXIS, S_XIPOS) in the smallest scratch");
@@ -378,19 +386,20 @@ template <> __device__ __forceinline__ const DevModel<double>& myo_cmodel<double
 #endif
 
 // what Scratch::SPILL keeps in global memory (the env record: act = the na doubles in front of the warm start; the env workspace)
-template <typename T, int NC> DEV T* S_OBJF(const TaskDev& K, Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g + K.objf_off; else return s.objg_fric; }
-template <typename T, int NC> DEV const T* S_OBJF(const TaskDev& K, const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g + K.objf_off; else return s.objg_fric; }
-template <typename T, int NC> DEV const HP* S_ACT(const DevModel<T>& M, const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.warm_g - M.na; else return s.act; }
+// (SPILL: typed global pointers — GPTR, wave.h — hence `auto`)
+template <typename T, int NC> DEV auto S_OBJF(const TaskDev& K, Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(T))s.warm_g + K.objf_off; else return (T*)s.objg_fric; }
+template <typename T, int NC> DEV auto S_OBJF(const TaskDev& K, const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(const T))s.warm_g + K.objf_off; else return (const T*)s.objg_fric; }
+template <typename T, int NC> DEV auto S_ACT(const DevModel<T>& M, const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(const HP))s.warm_g - M.na; else return (const HP*)s.act; }
 // (a part of a step that hands the record on writes it through, like the warm start: warm_set)
 template <typename T, int NC> DEV void act_set(const DevModel<T>& M, Scratch<T, NC>& s, int i, HP v) {
-  if constexpr (Scratch<T, NC>::SPILL) st_pub(s.warm_g - M.na + i, (double)v, UNI(s.pub)); else s.act[i] = v;
+  if constexpr (Scratch<T, NC>::SPILL) st_pub((GPTR(double))s.warm_g - M.na + i, (double)v, UNI(s.pub)); else s.act[i] = v;
 }
-template <typename T, int NC> DEV HP* S_TEN_LENGTH(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_TLEN; else return s.ten_length; }
-template <typename T, int NC> DEV const HP* S_TEN_LENGTH(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_TLEN; else return s.ten_length; }
-template <typename T, int NC> DEV T* S_ACT_DOT(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_ADOT; else return s.act_dot; }
-template <typename T, int NC> DEV const T* S_ACT_DOT(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_ADOT; else return s.act_dot; }
-template <typename T, int NC> DEV T* S_RWD(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_RWD; else return s.rwd; }
-template <typename T, int NC> DEV const T* S_RWD(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return s.ctrl_g + MYO_WS_RWD; else return s.rwd; }
+template <typename T, int NC> DEV auto S_TEN_LENGTH(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(HP))s.ctrl_g + MYO_WS_TLEN; else return (HP*)s.ten_length; }
+template <typename T, int NC> DEV auto S_TEN_LENGTH(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(const HP))s.ctrl_g + MYO_WS_TLEN; else return (const HP*)s.ten_length; }
+template <typename T, int NC> DEV auto S_ACT_DOT(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(T))s.ctrl_g + MYO_WS_ADOT; else return (T*)s.act_dot; }
+template <typename T, int NC> DEV auto S_ACT_DOT(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(const T))s.ctrl_g + MYO_WS_ADOT; else return (const T*)s.act_dot; }
+template <typename T, int NC> DEV auto S_RWD(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(T))s.ctrl_g + MYO_WS_RWD; else return (T*)s.rwd; }
+template <typename T, int NC> DEV auto S_RWD(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(const T))s.ctrl_g + MYO_WS_RWD; else return (const T*)s.rwd; }
 template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
 
 // ------------------------------------------------------------------------------------------
@@ -598,13 +607,27 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     const int b = lane;
     LV(k_depth) = -1; LV(k_par) = 0; LV(k_jn) = 0; LV(k_ja) = 0; LV(k_free) = 0;
     LV(k_p0) = LV(k_p1) = LV(k_p2) = 0; LV(k_q0) = 1; LV(k_q1) = LV(k_q2) = LV(k_q3) = 0;
+    // the body's whole record — tree position, offset pose, and qpos address / type / anchor / axis / reference angle of its (<= 3)
+    // joints — in ONE level of table loads, requested together (bk_i / bk_f: host-packed, myobatch.hip).  Rounds 1-5 walked
+    // body -> joint -> qpos0 with a dependent vector load at every step and inside the joint loop (15 memory round trips a call).
+    const int bb = (b > 0 && b < M.nbody) ? b : 0;
+    int bi[MYO_BK_I];
+    HP bf[MYO_BK_F];
+#pragma unroll
+    for (int k = 0; k < MYO_BK_I; ++k) bi[k] = M.bk_i[MYO_BK_I * bb + k];
+#pragma unroll
+    for (int k = 0; k < MYO_BK_F; ++k) bf[k] = M.h_bk_f[MYO_BK_F * bb + k];
+#pragma unroll
+    for (int k = 0; k < MYO_BK_I; ++k) MYO_PIN(bi[k]);
+#pragma unroll
+    for (int k = 0; k < MYO_BK_F; ++k) MYO_PIN(bf[k]);
     if (b > 0 && b < M.nbody) {
-      const int jn = M.body_jntnum[b], ja = M.body_jntadr[b];
-      LV(k_depth) = M.body_depth[b]; LV(k_par) = M.body_parentid[b]; LV(k_jn) = jn; LV(k_ja) = ja;
-      HP p[3] = {M.h_body_pos[3 * b], M.h_body_pos[3 * b + 1], M.h_body_pos[3 * b + 2]};
-      HP q[4] = {M.h_body_quat[4 * b], M.h_body_quat[4 * b + 1], M.h_body_quat[4 * b + 2], M.h_body_quat[4 * b + 3]};
-      if (jn == 1 && M.jnt_type[ja] == 0) {          // free joint: the pose is the state (parent = world)
-        const int qa = M.jnt_qposadr[ja];
+      const int jn = bi[2], ja = bi[3];
+      LV(k_depth) = bi[0]; LV(k_par) = bi[1]; LV(k_jn) = jn; LV(k_ja) = ja;
+      HP p[3] = {bf[0], bf[1], bf[2]};
+      HP q[4] = {bf[3], bf[4], bf[5], bf[6]};
+      if (bi[4]) {                                   // free joint: the pose is the state (parent = world)
+        const int qa = bi[5];
         HP qq[4] = {s.qpos[qa + 3], s.qpos[qa + 4], s.qpos[qa + 5], s.qpos[qa + 6]};
         normalize4(qq);
         for (int k = 0; k < 4; ++k) { s.qpos[qa + 3 + k] = qq[k]; q[k] = qq[k]; }
@@ -612,18 +635,20 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         kaxis[3 * ja] = 0; kaxis[3 * ja + 1] = 0; kaxis[3 * ja + 2] = 1;
         LV(k_free) = 1;
       } else {
-        for (int k = 0; k < jn; ++k) {
+#pragma unroll
+        for (int k = 0; k < MYO_BK_NJ; ++k) {
+          if (k >= jn) break;
           const int j = ja + k;
-          const int qa = M.jnt_qposadr[j], jtype = M.jnt_type[j];
-          const HP jpos[3] = {M.h_jnt_pos[3 * j], M.h_jnt_pos[3 * j + 1], M.h_jnt_pos[3 * j + 2]};
-          const HP jaxis[3] = {M.h_jnt_axis[3 * j], M.h_jnt_axis[3 * j + 1], M.h_jnt_axis[3 * j + 2]};
+          const int qa = bi[5 + k], jtype = bi[8 + k];
+          const HP jpos[3] = {bf[7 + 7 * k], bf[8 + 7 * k], bf[9 + 7 * k]};
+          const HP jaxis[3] = {bf[10 + 7 * k], bf[11 + 7 * k], bf[12 + 7 * k]};
           HP R[9], anchor[3], axis[3];
           quat2mat(R, q);
           mulmatvec3(anchor, R, jpos);
           anchor[0] += p[0]; anchor[1] += p[1]; anchor[2] += p[2];
           mulmatvec3(axis, R, jaxis);
           for (int e = 0; e < 3; ++e) { kanchor[3 * j + e] = anchor[e]; kaxis[3 * j + e] = axis[e]; }   // parent frame for now
-          const HP ang = s.qpos[qa] - M.h_qpos0[qa];
+          const HP ang = s.qpos[qa] - bf[13 + 7 * k];
           if (jtype == 2) {
             p[0] += axis[0] * ang; p[1] += axis[1] * ang; p[2] += axis[2] * ang;
           } else {
@@ -724,16 +749,35 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
   SYNC();
   PHASE {
     const int b = lane;
+    // (every table word of the lane's body and joint first, together: see fwd_actuation)
+    const int bc = b < M.nbody ? b : 0, jc = lane < M.njnt ? lane : 0;
+    T imat[9], I[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) imat[k] = M.body_imat[9 * bc + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) I[k] = M.body_inertia[3 * bc + k];
+    int broot = M.body_rootid[bc];
+    T bmass_tab = M.body_mass[bc];
+    int jrec[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) jrec[k] = M.jk_i[4 * jc + k];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) MYO_PIN(imat[k]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) MYO_PIN(I[k]);
+    MYO_PIN(broot); MYO_PIN(bmass_tab);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) MYO_PIN(jrec[k]);
     if (b < M.nbody) {
       T* ci = S_CINERT(s) + 10 * b;
       if (b == 0) { for (int k = 0; k < 10; ++k) ci[k] = 0; }
       else {
         T R[9], Rb[9];
         body_rot(s, b, Rb);
-        mulmat3(R, Rb, M.body_imat + 9 * b);
-        const T* I = M.body_inertia + 3 * b; const T* c = S_COM(s) + 3 * M.body_rootid[b];
+        mulmat3(R, Rb, imat);
+        const T* c = S_COM(s) + 3 * broot;
         const T off[3] = {S_XIPOS(s)[3 * b] - c[0], S_XIPOS(s)[3 * b + 1] - c[1], S_XIPOS(s)[3 * b + 2] - c[2]};
-        const T mb = body_mass_of(M, K, s, b);
+        const T mb = (b == K.obj1_bid) ? s.ball_mass[0] : ((b == K.obj2_bid) ? s.ball_mass[1] : bmass_tab);      // (body_mass_of)
         ci[0] = R[0] * R[0] * I[0] + R[1] * R[1] * I[1] + R[2] * R[2] * I[2] + mb * (off[1] * off[1] + off[2] * off[2]);
         ci[1] = R[3] * R[3] * I[0] + R[4] * R[4] * I[1] + R[5] * R[5] * I[2] + mb * (off[0] * off[0] + off[2] * off[2]);
         ci[2] = R[6] * R[6] * I[0] + R[7] * R[7] * I[1] + R[8] * R[8] * I[2] + mb * (off[0] * off[0] + off[1] * off[1]);
@@ -745,10 +789,11 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
     }
     const int j = lane;
     if (j < M.njnt) {
-      const int b = M.jnt_bodyid[j], da = M.jnt_dofadr[j];
-      const T* c = S_COM(s) + 3 * M.body_rootid[b];
+      // (jk_i: the joint's body, dof address, type and tree root behind one index)
+      const int b = jrec[0], da = jrec[1], jtype = jrec[2];
+      const T* c = S_COM(s) + 3 * jrec[3];
       const T off[3] = {c[0] - S_XANCHOR(s)[3 * j], c[1] - S_XANCHOR(s)[3 * j + 1], c[2] - S_XANCHOR(s)[3 * j + 2]};
-      if (M.jnt_type[j] == 0) {
+      if (jtype == 0) {
         for (int k = 0; k < 3; ++k) { T* cd = s.cdof + 6 * (da + k); for (int e = 0; e < 6; ++e) cd[e] = 0; cd[3 + k] = 1; }
         T Rb[9];
         body_rot(s, b, Rb);
@@ -758,7 +803,7 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
           cd[0] = ax[0]; cd[1] = ax[1]; cd[2] = ax[2];
           cross3(cd + 3, ax, off);
         }
-      } else if (M.jnt_type[j] == 2) {
+      } else if (jtype == 2) {
         T* cd = s.cdof + 6 * da; cd[0] = cd[1] = cd[2] = 0;
         cd[3] = S_XAXIS(s)[3 * j]; cd[4] = S_XAXIS(s)[3 * j + 1]; cd[5] = S_XAXIS(s)[3 * j + 2];
       } else {
@@ -1075,11 +1120,11 @@ DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     if constexpr (sizeof(T) == sizeof(HP)) {      // the finished moment arms leave LDS: [slot][tendon]
       for (int o = lane; o < MYO_TJ_MAX * MYO_NT_MAX; o += 64) {
         const int slot = o / MYO_NT_MAX, tt = o - slot * MYO_NT_MAX;
-        if (tt < M.ntendon) s.tenj_g[o] = (double)S_TENJ_STAGE(s)[tt * MYO_TJ_MAX + slot];
+        if (tt < M.ntendon) ((GPTR(double))s.tenj_g)[o] = (double)S_TENJ_STAGE(s)[tt * MYO_TJ_MAX + slot];
       }
     }
   }
-  SYNC();
+  SYNC_G();       // (the moment arms / SPILL's tendon lengths went to global memory: other lanes read them)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1361,7 +1406,7 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
 #pragma unroll
       for (int q = 0; q < N / 4; ++q) if (q <= (lane >> 2)) hw[q] = V4{a2[2 * q].x, a2[2 * q].y, a2[2 * q + 1].x, a2[2 * q + 1].y};
     }
-    __syncthreads();
+    SYNC();
   } else {
     {
       // LDS pointers of this function: taken ONCE and made opaque.  In a non-kernel function the address of the dynamic
@@ -1404,7 +1449,7 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
             for (int r = 0; r < 4; ++r)
               stage[mine ? (16 * I + MM::crow(lane, r)) * 4 + (lc - jc) : NT * 64 + lane] = acc[I * (I + 1) / 2 + J][r];
         }
-        __syncthreads();
+        SYNC();
         // 2. row-per-lane: the four panel entries of row 16 I + lc (the same in all four lane quarters)
         T xr[NT][4];
   #pragma unroll
@@ -1464,7 +1509,7 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   #pragma unroll
             for (int Jt = J; Jt <= I; ++Jt) acc[I * (I + 1) / 2 + Jt] = MM::mma(-op[I], op[Jt], acc[I * (I + 1) / 2 + Jt]);
         }
-        __syncthreads();                                 // the stage is rewritten by the next panel
+        SYNC();                                 // the stage is rewritten by the next panel
       }
     }
     {
@@ -1504,7 +1549,7 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   }
   b *= invd;
   if (lane < n) x[lane] = b;
-  __syncthreads();
+  SYNC();
 }
 #endif
 
@@ -2238,13 +2283,7 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
       }
     }
     SYNC();
-    ncon += total;
-    if (ncon > cap) {
-      // more contacts than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
-      // with a warning — counted, so that the host can see it happened (myo_batch_health)
-      PHASE { if (lane == 0 && K.health) myo_count(K.health + 1); }
-      ncon = cap;
-    }
+    ncon += total;      // (runs past the capacity: slots beyond it are not written, contacts_clamp counts the substep and cuts the count)
   }
 }
 
@@ -2329,13 +2368,27 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
       }
     }
     SYNC();
-    ncon += total;
-    if (ncon > cap) {
-      // more contact slots than the scratch holds: the surplus (the last candidate pairs) is dropped, as MuJoCo drops beyond nconmax
-      // with a warning — counted, so that the host can see it happened (myo_batch_health)
-      PHASE { if (lane == 0 && K.health) myo_count(K.health + 1); }
-      ncon = cap;
+    ncon += total;      // (runs past the capacity: slots beyond it are not written, contacts_clamp counts the substep and cuts the count)
+  }
+}
+
+// after the last collision pass: a substep that wanted more contact slots than the scratch holds keeps the first `cap` (the surplus —
+// the last candidate pairs — was never written), as MuJoCo drops beyond nconmax with a warning.  Counted (myo_batch_health [1]) together
+// with the largest number of slots any substep wanted ([3]), so that the host sees both that it happened and what would have been enough.
+template <typename T, int NC>
+DEV void contacts_clamp(const TaskDev& K_in, Scratch<T, NC>& s_in) {
+  MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN
+  const int nlim = s.nl + s.ntl, ncon = s.ncon;
+  const int cap = tmin((int)Scratch<T, NC>::NREC, (MYO_NLIM_MAX + 4 * NC - nlim) >> 2);
+  if (ncon > cap) {
+    PHASE {
+      if (lane == 0) {
+        if (K.health) { myo_count(K.health + 1); myo_max(K.health + 3, ncon); }
+        s.ncon = cap; s.nefc = nlim + 4 * cap;
+      }
     }
+    SYNC();
   }
 }
 
@@ -2626,11 +2679,7 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
   PHASE {
     const int d = lane;
     if (d < M.nv) {
-      T acc = 0;
-      for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
-        const T v = lim_sign<T>(s.lim_id[r]) * f[r];
-        acc += (lim_index(s.lim_id[r]) == d) ? v : (T)0;
-      }
+      T acc = 0;                                 // (joint-limit / friction-loss rows: below, one lane per row)
       // (four rows at a time: the fp64 stepper's moment arms come from global memory, so the reads of a group are requested together;
       //  the sum keeps its row order)
       for (int r0 = nl; r0 < nlim; r0 += 4) {
@@ -2649,31 +2698,30 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
 #pragma unroll
         for (int k = 0; k < 4; ++k) { const T v = fv[k] * jv[k]; acc += on[k] ? v : (T)0; }
       }
-      // own motion axis once; per contact only wave-uniform (broadcast) reads, issued unconditionally with a
-      // select at the end: no exec-mask branch around the loads, so consecutive contacts overlap
-      const T cd[6] = {s.cdof[6 * d], s.cdof[6 * d + 1], s.cdof[6 * d + 2], s.cdof[6 * d + 3], s.cdof[6 * d + 4], s.cdof[6 * d + 5]};
-#pragma unroll 2
-      for (int ci = 0; ci < ncon; ++ci) {
-        const ContactRec<T>& c = s.con[ci];
-        const int pk = UNI(c.pk);                  // (ci is wave-uniform: the two ancestor-dof masks come through the scalar cache)
-        const int on1 = (int)((M.body_dofmask[pk & 255] >> d) & 1ull), on2 = (int)((M.body_dofmask[(pk >> 8) & 255] >> d) & 1ull);
-        const T off[3] = {on2 ? c.r2[0] : c.r1[0], on2 ? c.r2[1] : c.r1[1], on2 ? c.r2[2] : c.r1[2]};
-        T t[3];
-        cross3(t, cd, off);
-        const T col[3] = {cd[3] + t[0], cd[4] + t[1], cd[5] + t[2]};
-        const T v = dot3(col, S_CONF(s) + 3 * ci);
-        acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
-      }
-      if (nrot > 0) {                                          // (scalar branch, outside the hot loop) torques of the rotational slots
-        for (int ci = 0; ci < ncon; ++ci) {
-          const ContactRec<T>& c = s.con[ci];
-          const int pk = UNI(c.pk);
-          const int on1 = (int)((M.body_dofmask[pk & 255] >> d) & 1ull), on2 = (int)((M.body_dofmask[(pk >> 8) & 255] >> d) & 1ull);
-          const T v = dot3(cd, S_CONTQ(s) + 3 * ci);
-          acc += (on1 != on2) ? (on2 ? v : -v) : (T)0;
+      out[d] = acc;
+    }
+  }
+  SYNC();
+  // contacts: one lane per (contact, support entry) — four contacts a pass — adding the entry's share  +- column . force  into its dof
+  // with an LDS add.  (Rounds 1-5: every dof lane walked all contacts, one LDS round trip + two scalar loads of the bodies' dof masks
+  // per contact; the support list carries the same "moves body 1 / body 2" bits.)
+  static_assert(MYO_CS_MAX == 16, "four contacts x sixteen support entries per pass");
+  PHASE {
+    for (int r = lane; r < nl; r += 64) lds_add(&out[lim_index(s.lim_id[r])], lim_sign<T>(s.lim_id[r]) * f[r]);      // a joint row moves one dof
+    const int e = lane & 15;
+    for (int ci = lane >> 4; ci < ncon; ci += 4) {
+      const ContactRec<T>& c = s.con[ci];
+      if (e < con_nsup(c)) {
+        const int sd = c.sup[e];
+        const int d = con_sup_dof(sd), on1 = con_sup_on1(sd), on2 = con_sup_on2(sd);
+        if (on1 != on2) {
+          T col[3];
+          con_col(s, d, on2 ? c.r2 : c.r1, col);
+          T v = dot3(col, S_CONF(s) + 3 * ci);
+          if (nrot > 0) v += dot3(s.cdof + 6 * d, S_CONTQ(s) + 3 * ci);      // (scalar branch) torques of the rotational slots
+          lds_add(&out[d], on2 ? v : -v);
         }
       }
-      out[d] = acc;
     }
   }
   SYNC();
@@ -2689,19 +2737,28 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
   // (the caller has run body_vectors(qvel -> S_CVEL): called from kernel level so that this function stays a leaf)
   PHASE {
     const int t = lane;
+    const int d = lane;
+    // (every table word and moment arm of this lane first, together: see fwd_actuation)
+    const int tt = t < M.ntendon ? t : 0, dc = d < M.nv ? d : 0;
+    unsigned long long tmask = M.tendon_dofmask[tt], pmask = M.dof_prevmask[dc];
+    T tj[MYO_TJ_MAX];
+    tenj_row(s, tt, tj);
+    T damp = M.dof_damping[dc], spr_k = M.dof_spr[2 * dc], spr_q0 = M.dof_spr[2 * dc + 1];
+    int spr_qa = M.dk_i[2 * dc];
+    MYO_PIN(tmask); MYO_PIN(pmask); MYO_PIN(damp); MYO_PIN(spr_k); MYO_PIN(spr_q0); MYO_PIN(spr_qa);
+#pragma unroll
+    for (int k = 0; k < MYO_TJ_MAX; ++k) MYO_PIN(tj[k]);
     if (t < M.ntendon) {
-      unsigned long long m = M.tendon_dofmask[t];
-      T acc = 0, tj[MYO_TJ_MAX];
-      tenj_row(s, t, tj);
+      unsigned long long m = tmask;
+      T acc = 0;
 #pragma unroll
       for (int k = 0; k < MYO_TJ_MAX; ++k) if (m) { const int d = myo_ffsll(m); m &= m - 1; acc += tj[k] * qv[d]; }
       S_TEN_VEL(s)[t] = acc;
     }
-    const int d = lane;
     if (d < M.nv) {
       // cdof_dot = (velocity accumulated before this dof) x cdof   (mj_comVel)
       T cv[6] = {0, 0, 0, 0, 0, 0};
-      unsigned long long m = M.dof_prevmask[d];
+      unsigned long long m = pmask;
       const int is_free_trans = (int)((m >> 63) & 1ull);
       m &= ~(1ull << 63);
       while (m) {
@@ -2712,13 +2769,9 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
       }
       if (is_free_trans) { for (int e = 0; e < 6; ++e) S_CDOFDOT(s)[6 * d + e] = 0; }
       else cross_motion(S_CDOFDOT(s) + 6 * d, cv, s.cdof + 6 * d);
-      // passive joint forces
-      T p = -M.dof_damping[d] * qv[d];
-      const int j = M.dof_jntid[d];
-      if (M.jnt_type[j] != 0 && M.jnt_stiffness[j] != 0) {
-        const int qa = M.jnt_qposadr[j];
-        p -= M.jnt_stiffness[j] * ((T)s.qpos[qa] - M.qpos_spring[qa]);
-      }
+      // passive joint forces (dof_spr: the joint's stiffness — 0 for none / a free joint — and spring reference, dk_i: its qpos address)
+      T p = -damp * qv[d];
+      if (spr_k != 0) p -= spr_k * ((T)s.qpos[spr_qa] - spr_q0);
       S_QFRC_PASSIVE(s)[d] = p;
     }
   }
@@ -2765,7 +2818,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
     const int d = lane;
     if (d < M.nv) {
       T f[6] = {0, 0, 0, 0, 0, 0};
-      const unsigned long long sub = M.body_submask[M.dof_bodyid[d]];
+      const unsigned long long sub = M.dof_submask[d];
       // all bodies, membership as a select: the reads are wave-uniform and all in flight together, instead of
       // one dependent round trip per subtree body on the lanes of the root dofs (18 bodies for the wrist)
 #pragma unroll 4
@@ -2824,33 +2877,51 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   PHASE {
     const int i = lane;
     LV(adot) = 0;
+    // Every table word of this lane is requested HERE, unconditionally and together (lanes beyond nu read actuator 0), and pinned
+    // (MYO_PIN) so that the compiler does not sink the loads back into the branches that use them: a lane-indexed table read is a
+    // vector memory load, ~500 cycles, and rounds 1-5 issued ~35 of them one after the other — each inside the branch of the muscle
+    // curves that needs it, each followed by its own s_waitcnt: 12 k of a substep's 250 k cycles for ~200 flops.
+    const int ii = i < M.nu ? i : 0;
+    int ctrllim = M.actuator_ctrllimited[ii], dyntype = M.actuator_dyntype[ii], tid = M.actuator_tendon[ii], gaintype = M.actuator_gaintype[ii];
+    int biastype = M.actuator_biastype[ii], forcelim = M.actuator_forcelimited[ii];
+    T cr0 = M.actuator_ctrlrange[2 * ii], cr1 = M.actuator_ctrlrange[2 * ii + 1], fr0 = M.actuator_forcerange[2 * ii], fr1 = M.actuator_forcerange[2 * ii + 1];
+    T gear = M.actuator_gear[6 * ii], gear0 = M.act_gear0[ii], dp0 = M.actuator_dynprm[10 * ii], dp1 = M.actuator_dynprm[10 * ii + 1];
+    T gp0 = M.actuator_gainprm[10 * ii], bp0 = M.actuator_biasprm[10 * ii], bp1 = M.actuator_biasprm[10 * ii + 1], bp2 = M.actuator_biasprm[10 * ii + 2];
+    HP ap[MYO_ACT_PRE];
+#pragma unroll
+    for (int k = 0; k < MYO_ACT_PRE; ++k) ap[k] = M.h_act_pre[MYO_ACT_PRE * ii + k];
+    T ctrl = ctrl_get(s, ii);
+    MYO_PIN(ctrllim); MYO_PIN(dyntype); MYO_PIN(tid); MYO_PIN(gaintype); MYO_PIN(biastype); MYO_PIN(forcelim);
+    MYO_PIN(cr0); MYO_PIN(cr1); MYO_PIN(fr0); MYO_PIN(fr1); MYO_PIN(gear); MYO_PIN(gear0); MYO_PIN(dp0); MYO_PIN(dp1);
+    MYO_PIN(gp0); MYO_PIN(bp0); MYO_PIN(bp1); MYO_PIN(bp2); MYO_PIN(ctrl);
+#pragma unroll
+    for (int k = 0; k < MYO_ACT_PRE; ++k) MYO_PIN(ap[k]);
+    const int ia = i - (M.nu - M.na);                      // the actuator's activation (muscles: the last na actuators)
+    const T act_in = (T)S_ACT(M, s)[(ia >= 0 && ia < M.na) ? ia : 0];
+    const HP ten_len = S_TEN_LENGTH(s)[tid];
+    const T ten_vel = S_TEN_VEL(s)[tid];
     if (i < M.nu) {
-      T ctrl = ctrl_get(s, i);
-      if (M.actuator_ctrllimited[i]) ctrl = tclamp(ctrl, M.actuator_ctrlrange[2 * i], M.actuator_ctrlrange[2 * i + 1]);
+      if (ctrllim) ctrl = tclamp(ctrl, cr0, cr1);
       T input = ctrl;
       // The constants of mju_muscleGain / Bias / Dynamics that depend on the parameters alone — peak force, L0 and the normalised-length
       // map, the reciprocals of every constant denominator of the force-length / force-velocity / passive curves — are resolved on the
       // host (act_pre, MYO_ACT_PRE per actuator: myobatch.hip); round 4's version divided 16 times per lane here.
-      const HP* ap = M.h_act_pre + MYO_ACT_PRE * i;
-      if (M.actuator_dyntype[i] == 3) {
-        const T act = (T)S_ACT(M, s)[i - (M.nu - M.na)];
-        const T* prm = M.actuator_dynprm + 10 * i;
+      if (dyntype == 3) {
+        const T act = act_in;
         const T cc = tclamp(ctrl, (T)0, (T)1), ac = tclamp(act, (T)0, (T)1);
         const T w = (T)0.5 + (T)1.5 * ac, ideact = (T)ap[22];
         // tau = tau_act w (activating) | tau_deact / w (deactivating); act_dot = (ctrl - act) / tau
-        if (cc > act) LV(adot) = (cc - act) / tmax(MYO_MINVAL, prm[0] * w);
+        if (cc > act) LV(adot) = (cc - act) / tmax(MYO_MINVAL, dp0 * w);
         else if (ideact != 0) LV(adot) = (cc - act) * w * ideact;
-        else LV(adot) = (cc - act) / tmax(MYO_MINVAL, prm[1] / w);
+        else LV(adot) = (cc - act) / tmax(MYO_MINVAL, dp1 / w);
         input = act;
       }
-      const int tid = M.actuator_tendon[i];
-      const T gear = M.actuator_gear[6 * i];
       // muscle length normalisation and the force-length curves in HP from the HP tendon length (the curves are
       // piecewise quadratics of DIFFERENCES like L - 1 and L - lmin); the force-velocity factor in T
-      const HP lenh = (HP)gear * S_TEN_LENGTH(s)[tid];
-      const T len = (T)lenh, vel = gear * S_TEN_VEL(s)[tid];
+      const HP lenh = (HP)gear * ten_len;
+      const T len = (T)lenh, vel = gear * ten_vel;
       T gain, bias = 0;
-      if (M.actuator_gaintype[i] == 1) {
+      if (gaintype == 1) {
         const HP L = ap[1] + (lenh - ap[3]) * ap[2];
         const T V = vel * (T)ap[4];
         const HP lmin = ap[5], lmax = ap[6], a = ap[7], b = ap[8];
@@ -2867,22 +2938,21 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         else if (V <= y) FV = fvmax - (y - V) * (y - V) * (T)ap[14];
         else FV = fvmax;
         gain = -(T)ap[0] * FL * FV;
-      } else gain = M.actuator_gainprm[10 * i];
-      if (M.actuator_biastype[i] == 2) {
+      } else gain = gp0;
+      if (biastype == 2) {
         const HP L = ap[17] + (lenh - ap[3]) * ap[18];
         const HP b = ap[19];
         const T force = (T)ap[16], fpmax = (T)ap[21];
         if (L <= 1) bias = 0;
         else if (L <= b) { const T x = (T)((L - 1) * ap[20]); bias = -force * fpmax * (T)0.5 * x * x; }
         else { const T x = (T)((L - b) * ap[20]); bias = -force * fpmax * ((T)0.5 + x); }
-      } else if (M.actuator_biastype[i] == 1) {
-        const T* prm = M.actuator_biasprm + 10 * i;
-        bias = prm[0] + prm[1] * len + prm[2] * vel;
+      } else if (biastype == 1) {
+        bias = bp0 + bp1 * len + bp2 * vel;
       }
       T f = gain * input + bias;
-      if (M.actuator_forcelimited[i]) f = tclamp(f, M.actuator_forcerange[2 * i], M.actuator_forcerange[2 * i + 1]);
+      if (forcelim) f = tclamp(f, fr0, fr1);
       S_ACT_FORCE(s)[i] = f;
-      S_ACT_GF(s)[i] = M.act_gear0[i] * f;
+      S_ACT_GF(s)[i] = gear0 * f;
     }
   }
   SYNC();
@@ -2894,13 +2964,29 @@ DEVFN void fwd_actuation(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       if (lane < M.nu && M.actuator_dyntype[lane < M.nu ? lane : 0] == 3) S_ACT_DOT(s)[lane - (M.nu - M.na)] = LV(adot);
       if (lane < M.nv) S_QFRC_ACTUATOR(s)[lane] = 0;
     }
-    SYNC();
+    if constexpr (Scratch<T, NC>::SPILL) { SYNC_G(); } else { SYNC(); }      // (SPILL: the rates are in global memory)
     PHASE {
-      for (int o = lane; o < MYO_TJ_MAX * MYO_NU_MAX; o += 64) {
-        const int slot = o / MYO_NU_MAX, i = o - slot * MYO_NU_MAX;
-        const int d = M.act_sd[i * MYO_TJ_MAX + slot];            // dof of the actuator's tendon's slot, -1: none
-        const T j = tenj_get(s, M.act_tj[i] / MYO_TJ_MAX, slot);
-        if (d >= 0) lds_add(S_QFRC_ACTUATOR(s) + d, j * S_ACT_GF(s)[i]);
+      // (table words of all the lane's items first, then the moment arms, then the adds: two memory round trips, not two per item)
+      constexpr int NIT = (MYO_TJ_MAX * MYO_NU_MAX + 63) / 64;
+      static_assert(MYO_TJ_MAX * MYO_NU_MAX % 64 == 0, "whole passes");
+      int dd[NIT], tt[NIT];
+      T jj[NIT];
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int o = lane + 64 * k, slot = o / MYO_NU_MAX, i = o - slot * MYO_NU_MAX;
+        dd[k] = M.act_sd[i * MYO_TJ_MAX + slot];                  // dof of the actuator's tendon's slot, -1: none
+        tt[k] = M.act_tj[i];
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) { MYO_PIN(dd[k]); MYO_PIN(tt[k]); }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) { const int o = lane + 64 * k, slot = o / MYO_NU_MAX; jj[k] = tenj_get(s, tt[k] / MYO_TJ_MAX, slot); }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) MYO_PIN(jj[k]);
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int o = lane + 64 * k, slot = o / MYO_NU_MAX, i = o - slot * MYO_NU_MAX;
+        if (dd[k] >= 0) lds_add(S_QFRC_ACTUATOR(s) + dd[k], jj[k] * S_ACT_GF(s)[i]);
       }
     }
     SYNC();
@@ -3027,9 +3113,11 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // i
     }
   }
   SYNC();
+  PROF(s, 21)
   HP fcorr = 0;
   if (M.any_floss) fcorr = fric_update(M, s);      // (scalar branch; a leaf of its own: the kernel-level solver loop is at its register budget)
   JT_times(M, s, LOFF(s, s.efc_force), LOFF(s, s.qfrc_constraint));
+  PROF(s, 22)
   WAVE_SUM_N(HP, ccost0, nefc, r, ((HP)0.5 * (HP)row_D(s, r, nlim) * (HP)tmin(s.efc_jar[r], (T)0) * (HP)tmin(s.efc_jar[r], (T)0)));   // active <=> jar < 0
   const HP ccost = ccost0 + fcorr;
   WAVE_SUM_N(HP, gcost, M.nv, c, (((HP)s.Ma[c] - (HP)s.qfrc_smooth[c]) * ((HP)s.qacc[c] - (HP)s.qacc_smooth[c])));
@@ -3038,6 +3126,7 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // i
     if (c < M.nv) s.search[c] = -(s.Ma[c] - s.qfrc_smooth[c] - s.qfrc_constraint[c]);      // -gradient: the right-hand side of the next Newton system
   }
   SYNC();
+  PROF(s, 23)
   return ccost + (HP)0.5 * gcost;
 }
 
@@ -3047,16 +3136,11 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   WAVE_FN
   // (the caller has loaded M into H: load_H_from_M is called from kernel level so that this function stays a leaf)
   const int nl = s.nl, nlim = s.nl + s.ntl;
-  // joint-limit rows touch one diagonal entry each (lanes = dofs scan the rows)
+  // joint-limit rows touch one diagonal entry each: lanes = rows, LDS adds (a dof's lower and upper limit row — or its friction-loss
+  // row — meet in one entry; rounds 1-5 had every dof lane walk all nl rows, one LDS round trip a row)
   PHASE {
-    const int d = lane;
-    if (d < M.nv) {
-      T acc = 0;
-      for (int r = 0; r < nl; ++r) {             // uniform reads first, then a select
-        const T Dr = s.efc_D[r];
-        acc += (s.efc_active[r] && lim_index(s.lim_id[r]) == d) ? Dr : (T)0;
-      }
-      if (acc != 0) { const int pd = s.hperm[d]; s.H[MYO_HIDX(pd, pd)] += acc; }
+    for (int r = lane; r < nl; r += 64) {
+      if (s.efc_active[r]) { const int pd = s.hperm[lim_index(s.lim_id[r])]; lds_add(&s.H[MYO_HIDX(pd, pd)], s.efc_D[r]); }
     }
   }
   SYNC();
@@ -3085,9 +3169,25 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   // the (<= 16) lanes of the support set of contact ci+1 already put its Jacobian columns, rotated into the
   // contact frame and signed, into the other half of a staging buffer — each column is evaluated once per
   // contact instead of once per pair.  bvec is free here (body vectors are rebuilt after the solve).
-  T* stage = s.bvec;                       // 2 x MYO_CS_MAX x 3
-  static_assert(2 * MYO_CS_MAX * 3 <= MYO_NB_MAX * 6, "staging fits in bvec");
+  T* stage = s.bvec;                       // 2 x MYO_CS_MAX x 4: the column in frame coordinates and, in the fourth slot, its row of H
+  static_assert(2 * MYO_CS_MAX * 4 <= MYO_NB_MAX * 6 && sizeof(T) >= sizeof(int), "staging fits in bvec");
   const int ncon = s.ncon, gen = M.any_gen;
+  // the lower-triangular pairs (a >= b) of a support set, enumerated linearly: q = a(a+1)/2 + b — the same for every contact, so
+  // a lane decodes its (at most three) pairs once
+  static_assert(MYO_CS_MAX * (MYO_CS_MAX + 1) / 2 <= 192, "three pairs per lane");
+  LANE_VAR(int, pa0); LANE_VAR(int, pa1); LANE_VAR(int, pa2);      // a | b << 8
+  PHASE {
+    int pk3[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int q = lane + 64 * k;
+      int a = (int)((sqrtf((float)(8 * q + 1)) - 1.0f) * 0.5f);
+      if ((a + 1) * (a + 2) / 2 <= q) a++;           // float sqrt rounding guard
+      if (a * (a + 1) / 2 > q) a--;
+      pk3[k] = a | ((q - a * (a + 1) / 2) << 8);
+    }
+    LV(pa0) = pk3[0]; LV(pa1) = pk3[1]; LV(pa2) = pk3[2];
+  }
   for (int ci = -1; ci < ncon; ++ci) {
     PHASE {
       // ---- stage A for contact ci+1
@@ -3109,9 +3209,10 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
           j[2] = kind == 0 ? j[2] : (kind == 1 ? dot3(fr + 3, ang) : (T)0);
         }
         if (!on2) { j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2]; }
-        if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion
-        T* dst = stage + (cn & 1) * (MYO_CS_MAX * 3) + 3 * lane;
+        if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion (its pairs add 0)
+        T* dst = stage + (cn & 1) * (MYO_CS_MAX * 4) + 4 * lane;
         dst[0] = j[0]; dst[1] = j[1]; dst[2] = j[2];
+        *reinterpret_cast<int*>(dst + 3) = (int)s.hperm[d];   // the dof's row of H: stage B reads it with the column, not through sup -> hperm
       }
       // ---- stage B for contact ci (its columns were staged in the previous trip)
       if (ci >= 0) {
@@ -3125,24 +3226,23 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         if (nn != 0) {
           const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
           const int ns = con_nsup(c);
-          const T* jc = stage + (ci & 1) * (MYO_CS_MAX * 3);
-          // lower-triangular pairs (a >= b) of the support set, enumerated linearly: q = a(a+1)/2 + b
+          const T* jc = stage + (ci & 1) * (MYO_CS_MAX * 4);
           const int npair = ns * (ns + 1) / 2;
-          for (int q = lane; q < npair; q += 64) {
-            int a = (int)((sqrtf((float)(8 * q + 1)) - 1.0f) * 0.5f);
-            if ((a + 1) * (a + 2) / 2 <= q) a++;           // float sqrt rounding guard
-            if (a * (a + 1) / 2 > q) a--;
-            const int b = q - a * (a + 1) / 2;
-            const int sa = c.sup[a], sb = c.sup[b];
-            const int da = con_sup_dof(sa), db = con_sup_dof(sb);
-            if (con_sup_on1(sa) == con_sup_on2(sa) || con_sup_on1(sb) == con_sup_on2(sb)) continue;
-            const T ja[3] = {jc[3 * a], jc[3 * a + 1], jc[3 * a + 2]};
-            const T jb[3] = {jc[3 * b], jc[3 * b + 1], jc[3 * b + 2]};
-            const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
-            const T Ajb1 = A1 * jb[0] + A3 * jb[1];
-            const T Ajb2 = A2 * jb[0] + A4 * jb[2];
-            const int pa = s.hperm[da], pb = s.hperm[db];
-            s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)] += ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int q = lane + 64 * k;
+            if (q < npair) {
+              const int pk = k == 0 ? LV(pa0) : (k == 1 ? LV(pa1) : LV(pa2));
+              const int a = pk & 255, b = pk >> 8;
+              const T ja[3] = {jc[4 * a], jc[4 * a + 1], jc[4 * a + 2]};
+              const T jb[3] = {jc[4 * b], jc[4 * b + 1], jc[4 * b + 2]};
+              const int pa = *reinterpret_cast<const int*>(jc + 4 * a + 3), pb = *reinterpret_cast<const int*>(jc + 4 * b + 3);
+              const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
+              const T Ajb1 = A1 * jb[0] + A3 * jb[1];
+              const T Ajb2 = A2 * jb[0] + A4 * jb[2];
+              // (an LDS add: the pairs of one contact are distinct entries, contacts follow each other in program order)
+              lds_add(&s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)], ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2);
+            }
           }
         }
       }
@@ -3183,26 +3283,33 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   }
   SYNC();
   if (!use_warm) mul_M(M, s, LOFF(s, s.Ma), LOFF(s, s.qacc));  // keep Ma exactly consistent with M*qacc
+  PROF(s, 24)
   HP cost = update_constraint(M, s);
   const T scale = 1 / (M.meaninertia * (T)(nv > 1 ? nv : 1));
   int iter = 0;
   while (iter < M.iterations) {
     PROF(s, 11)
     load_H_from_M(M, s, (const T*)0, (T)0, 1);
+    PROF(s, 25)
     build_hessian(M, s);
     PROF(s, 9)
 #ifndef MYO_EMU
     if (M.arrow_nf > 0) {
       arrow_eliminate_blocks<T, NC>(LOFF(s, s.search));
+      PROF(s, 26)
       chol_factor_solve_reg<T, MYO_ARROW_S, NC>(LOFF(s, s.Mv), MYO_ARROW_S);
+      PROF(s, 27)
       arrow_finish<T, NC>(LOFF(s, s.search));
     } else
 #endif
     chol_factor_solve(s, s.search, nv, (s.ncon == 0 && s.ntl == 0) ? M.nlead : nv);
     PROF(s, 10)
     mul_M(M, s, LOFF(s, s.Mv), LOFF(s, s.search));
+    PROF(s, 28)
     body_vectors(M, s, LOFF(s, s.search), LOFF(s, s.bvec));
+    PROF(s, 29)
     J_times(M, s, LOFF(s, s.search), LOFF(s, s.bvec), LOFF(s, s.efc_jv));
+    PROF(s, 30)
     WAVE_SUM3_N(T, q1, q2, sn2, nv, c, { _e1 = s.search[c] * (s.Ma[c] - s.qfrc_smooth[c]); _e2 = (T)0.5 * s.search[c] * s.Mv[c]; _e3 = s.search[c] * s.search[c]; });
     const T snorm = sqrt(sn2);
     PROF(s, 0)
@@ -3330,6 +3437,7 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
     for (int base = 0; base < M.npair_std; base += 64) collision_pass<false>(M, K, s, base);
     for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<false>(M, K, s, base - M.npair_std);
   }
+  contacts_clamp(K, s);
   PROF(s, 5)
   body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
   PROF(s, 19)
@@ -3379,14 +3487,15 @@ DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) v
 template <typename T, int NC>
 DEV void advance(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) act_dot_r, LCREF(T) qacc_r, LCREF(T) vel_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  const T* act_dot = LISNULL(act_dot_r) ? S_ACT_DOT(s) : LPTR(const T, act_dot_r);      // (null: the scratch's own, S_ACT_DOT)
+  const bool own_rates = LISNULL(act_dot_r);                                            // (null: the scratch's own, S_ACT_DOT)
+  const T* act_dot = own_rates ? (const T*)0 : LPTR(const T, act_dot_r);
   const T* qacc = LPTR(const T, qacc_r);
   WAVE_FN
   const HP h = M.h_timestep;
   PHASE {
     const int i = lane;
     if (i < M.na) {
-      HP a = S_ACT(M, s)[i] + h * (HP)act_dot[i];
+      HP a = S_ACT(M, s)[i] + h * (HP)(own_rates ? S_ACT_DOT(s)[i] : act_dot[i]);
       if (M.actuator_dyntype[i + (M.nu - M.na)] == 3) a = tclamp(a, (HP)0, (HP)1);
       act_set(M, s, i, a);
     }
@@ -3426,6 +3535,7 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
   check_state(M, s, 1);
   PROF(s, 15)
   if (M.integrator == 1) {
+    // (SYNC_G in this branch: the stage storage s.rk is reached through a generic pointer — LDS behind the scratch or global memory)
     // RK4 (mj_RungeKutta): tableau 1/2,1/2,1; weights 1/6,1/3,1/3,1/6
     const int nq = M.nq, nv = M.nv, na = M.na, nf = 2 * nv + na;
     const HP h = M.h_timestep; const HP t0 = s.time;
@@ -3445,20 +3555,20 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
         s.rk->Fsum[2 * nv + i] = f2; S_RKDX(s)[2 * nv + i] = (T)0.5 * f2;
       }
     }
-    SYNC();
+    SYNC_G();
     for (int st = 1; st < 4; ++st) {
       const T a = (st == 3) ? (T)1 : (T)0.5;
       PHASE {
         for (int i = lane; i < nq; i += 64) s.qpos[i] = s.rk->x0[i];
       }
-      SYNC();
+      SYNC_G();
       integrate_pos(M, s, LOFF(s, S_RKDX(s)), h);
       PHASE {
         for (int i = lane; i < nv; i += 64) s.qvel[i] = s.rk->x0[nq + i] + h * (HP)S_RKDX(s)[nv + i];
         for (int i = lane; i < na; i += 64) act_set(M, s, i, s.rk->x0[nq + nv + i] + h * (HP)S_RKDX(s)[2 * nv + i]);
         if (lane == 0) s.time = t0 + h * (HP)a;
       }
-      SYNC();
+      SYNC_G();
       forward(M, K, s);
       PHASE {
         const T wgt = (st == 3) ? (T)1 : (T)2;          // weight of this stage in the sum
@@ -3473,7 +3583,7 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
           s.rk->Fsum[2 * nv + i] = s.rk->Fsum[2 * nv + i] + wgt * f2; S_RKDX(s)[2 * nv + i] = an * f2;
         }
       }
-      SYNC();
+      SYNC_G();
     }
     PHASE {
       for (int i = lane; i < nf; i += 64) S_RKDX(s)[i] = s.rk->Fsum[i] / 6;
@@ -3482,7 +3592,7 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
       for (int i = lane; i < na; i += 64) act_set(M, s, i, s.rk->x0[nq + nv + i]);
       if (lane == 0) s.time = t0;
     }
-    SYNC();
+    SYNC_G();
     advance(M, s, LOFF(s, S_RKDX(s) + 2 * nv), LOFF(s, S_RKDX(s) + nv), LOFF(s, S_RKDX(s)));
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint

@@ -118,7 +118,7 @@ DEVFN void baoding_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scra
       S_RWD(s)[7] = dense;
     }
   }
-  SYNC();
+  SYNC_G();      // (Scratch::SPILL keeps the reward terms in global memory: every lane reads them)
 }
 
 // ---- die reorient: rotations in the mujoco-py rotations.py convention MyoSuite's quat_math copies [3P-RECALL]
@@ -195,7 +195,7 @@ DEVFN void reorient_obs_reward(const DevModel<T>& M_in, const TaskDev& K_in, Scr
       s.pos_dist = pd; s.rot_dist = rd;
     }
   }
-  SYNC();
+  SYNC_G();      // (Scratch::SPILL keeps the reward terms in global memory: every lane reads them)
 }
 
 template <typename T, int NC>
@@ -448,7 +448,7 @@ DEVFN void reorient_reset(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
       s.ball_size[0] = del;
     }
   }
-  SYNC();
+  SYNC_G();      // (Scratch::SPILL: the friction triples went to the env's record in global memory)
   set_init_state(M, K, s, 0);
   kinematics(M, s);
   reorient_obs_reward(M, K, s);      // leaves pos_dist / rot_dist of the reset state (reorient.py:178-179)
@@ -465,7 +465,8 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
   if constexpr (sizeof(T) == sizeof(HP)) {      // fp64 stepper: warm start and controls stay in global memory (ScratchPoses<double>)
-    PHASE { if (lane == 0) { s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + (size_t)env * MYO_ENVWS_N; s.tenj_g = s.ctrl_g + MYO_NU_MAX; } }
+    // (the workspace of the hardware wave slot this workgroup runs in: myo_wave_slot, wave.h; MYO_WS_* in myo_physics.h)
+    PHASE { if (lane == 0) { s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + (size_t)myo_wave_slot(env) * MYO_ENVWS_N; s.tenj_g = s.ctrl_g + MYO_NU_MAX; } }
   }
   PHASE { if (lane == 0) s.pub = pub; }
   SYNC();
@@ -475,7 +476,7 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
       for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) S_OBJF(K, s)[i] = (T)rec[L.off_objfric + 3 * (i / NF) + i % NF];
     }
     for (int i = lane; i < M.nq; i += 64) s.qpos[i] = rec[L.off_qpos + i];
-    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; if constexpr (sizeof(T) != sizeof(HP)) s.qacc_warm_[i] = (T)rec[L.off_warm + i]; }
+    for (int i = lane; i < M.nv; i += 64) { s.qvel[i] = rec[L.off_qvel + i]; warm_set(s, i, (T)rec[L.off_warm + i]); }
     if constexpr (!Scratch<T, NC>::SPILL) { for (int i = lane; i < M.na; i += 64) s.act[i] = rec[L.off_act + i]; }      // (SPILL: read in place, S_ACT)
     for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, (T)0);
     if (lane < MYO_NV_MAX) s.hperm[lane] = (unsigned char)M.hperm[lane];
@@ -512,7 +513,7 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
       for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + 3 * (i / NF) + i % NF] = (double)S_OBJF(K, s)[i];
     }
     for (int i = lane; i < M.nq; i += 64) st_pub(rec + L.off_qpos + i, (double)s.qpos[i], wt);
-    for (int i = lane; i < M.nv; i += 64) { st_pub(rec + L.off_qvel + i, (double)s.qvel[i], wt); if constexpr (sizeof(T) != sizeof(HP)) st_pub(rec + L.off_warm + i, (double)s.qacc_warm_[i], wt); }
+    for (int i = lane; i < M.nv; i += 64) { st_pub(rec + L.off_qvel + i, (double)s.qvel[i], wt); st_pub(rec + L.off_warm + i, (double)warm_get(s, i), wt); }
     if constexpr (!Scratch<T, NC>::SPILL) { for (int i = lane; i < M.na; i += 64) st_pub(rec + L.off_act + i, (double)s.act[i], wt); }
     if (lane == 0) {
       st_pub(rec + L.off_time, (double)s.time, wt);
@@ -675,6 +676,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
     for (int base = 0; base < M.npair_std; base += 64) collision_pass<false>(M, K, s, base);
     for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<false>(M, K, s, base - M.npair_std);
   }
+  contacts_clamp(K, s);
   // position-stage results first: the body poses (fp64 stepper) and the tendon lengths share LDS with vectors the later stages write
   PHASE {
     for (int t = lane; t < M.ntendon; t += 64) out[D.ten_length + t] = (double)S_TEN_LENGTH(s)[t];

@@ -629,6 +629,45 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
     // activation dynamics: 1 / tau_deact when tau = tau_deact / (0.5 + 1.5 act) can never reach the floor (act in [0, 1]); else 0: the formula as written
     P[22] = dp[1] / 2.0 >= tiny ? 1.0 / dp[1] : 0.0;
   }
+  // per-lane records (myo_model_dev.h: bk_i / bk_f / jk_i / dk_i / dof_spr / dof_submask): what a body / joint / dof lane reads in a
+  // stage, behind ONE index instead of body -> joint -> qpos chains of dependent vector loads
+  {
+    const int njnt = m->njnt;
+    m->bk_i.assign((size_t)MYO_BK_I * (nb > 0 ? nb : 1), 0);
+    m->bk_f.assign((size_t)MYO_BK_F * (nb > 0 ? nb : 1), 0.0);
+    for (int b = 0; b < nb; ++b) {
+      int* I = &m->bk_i[(size_t)MYO_BK_I * b];
+      double* F = &m->bk_f[(size_t)MYO_BK_F * b];
+      const int jn = m->body_jntnum[b], ja = m->body_jntadr[b];
+      const bool is_free = jn == 1 && m->jnt_type[ja] == MYO_JNT_FREE;
+      LIM(jn > MYO_BK_NJ, "more than three joints on one body")
+      I[0] = m->body_depth[b]; I[1] = m->body_parentid[b]; I[2] = jn; I[3] = ja; I[4] = is_free ? 1 : 0;
+      for (int k = 0; k < 3; ++k) F[k] = m->body_pos[3 * (size_t)b + k];
+      for (int k = 0; k < 4; ++k) F[3 + k] = m->body_quat[4 * (size_t)b + k];
+      for (int k = 0; k < jn && k < MYO_BK_NJ; ++k) {
+        const int j = ja + k, qa = m->jnt_qposadr[j];
+        I[5 + k] = qa; I[8 + k] = m->jnt_type[j];
+        for (int e = 0; e < 3; ++e) { F[7 + 7 * k + e] = m->jnt_pos[3 * (size_t)j + e]; F[10 + 7 * k + e] = m->jnt_axis[3 * (size_t)j + e]; }
+        F[13 + 7 * k] = m->qpos0[qa];
+      }
+    }
+    m->jk_i.assign((size_t)4 * (njnt > 0 ? njnt : 1), 0);
+    for (int j = 0; j < njnt; ++j) {
+      int* I = &m->jk_i[(size_t)4 * j];
+      I[0] = m->jnt_bodyid[j]; I[1] = m->jnt_dofadr[j]; I[2] = m->jnt_type[j]; I[3] = m->body_rootid[m->jnt_bodyid[j]];
+    }
+    m->dk_i.assign((size_t)2 * (nv > 0 ? nv : 1), 0);
+    m->dof_spr.assign((size_t)2 * (nv > 0 ? nv : 1), 0.0);
+    m->dof_submask.assign(nv > 0 ? nv : 1, 0ull);
+    for (int d = 0; d < nv; ++d) {
+      const int j = m->dof_jntid[d], qa = m->jnt_qposadr[j];
+      m->dk_i[(size_t)2 * d] = qa;
+      const bool spring = m->jnt_type[j] != MYO_JNT_FREE && m->jnt_stiffness[j] != 0;
+      m->dof_spr[(size_t)2 * d] = spring ? m->jnt_stiffness[j] : 0.0;
+      m->dof_spr[(size_t)2 * d + 1] = m->qpos_spring[qa];
+      m->dof_submask[d] = m->body_submask[m->dof_bodyid[d]];
+    }
+  }
   for (int b = 0; b < nb; ++b) {
     int cnt = 0;
     for (unsigned long long x = m->body_dofmask[b]; x; x &= x - 1) cnt++;
@@ -813,6 +852,7 @@ struct myo_batch {
   int timing;
   double ms_sum;
   int ms_cnt;
+  bool has_slot_ws = false;    // K.ctrl_ws is the device's shared wave-slot workspace (slot_workspace_acquire / _release)
 #ifndef MYO_EMU
   hipEvent_t ev0, ev1;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -828,6 +868,31 @@ struct myo_batch {
 struct BoundDev { const myo_batch* b = nullptr; hipStream_t last = nullptr; bool have_last = false; hipEvent_t ev = nullptr; };
 static BoundDev g_bound[MYO_MAX_DEVICES];
 static std::mutex g_bound_mu;
+// The wave slots' workspaces (TaskDev::ctrl_ws, myo_physics.h): MYO_WAVE_SLOTS x MYO_ENVWS_N doubles (~0.5 GB of the 288) per DEVICE, shared by
+// every fp64 batch on it — a workspace belongs to a hardware wave slot, so kernels of different batches, even on different streams, never
+// meet in one.  Allocated with the first such batch, freed with the last.
+struct SlotWs { double* p = nullptr; int users = 0; };
+static SlotWs g_slot_ws[MYO_MAX_DEVICES];
+static double* slot_workspace_acquire(int device) {
+  if (device < 0 || device >= MYO_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(g_bound_mu);
+  SlotWs& w = g_slot_ws[device];
+  if (!w.p) {
+    void* q = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)MYO_WAVE_SLOTS * MYO_ENVWS_N;
+    if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(q); return nullptr; }
+    w.p = (double*)q; w.users = 0;
+  }
+  w.users++;
+  return w.p;
+}
+static void slot_workspace_release(int device) {
+  if (device < 0 || device >= MYO_MAX_DEVICES) return;
+  std::lock_guard<std::mutex> lk(g_bound_mu);
+  SlotWs& w = g_slot_ws[device];
+  if (w.users > 0 && --w.users == 0) { (void)hipFree(w.p); w.p = nullptr; }
+}
 // every launch entry point runs on the batch's own device, whatever the caller's current device is
 struct DeviceGuard {
   int prev = -1; bool switched = false;
@@ -1059,12 +1124,16 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
     b->K.health = (int*)hc;
     if (hc) b->allocs.push_back(hc);
   }
-  if (dtype == MYO_F64) {          // the fp64 stepper keeps the envs' controls in global memory (ScratchPoses<double>::ctrl_g)
-    void* w = nullptr;
+  if (dtype == MYO_F64) {          // the fp64 stepper keeps controls, moment arms and the warm start in global memory (ScratchPoses<double>::ctrl_g)
+#ifdef MYO_EMU
+    void* w = nullptr;             // (emulation: one workspace per env)
     rc |= be_malloc(&w, sizeof(double) * (size_t)n_envs * MYO_ENVWS_N);
-    if (!rc) { std::vector<double> z((size_t)n_envs * MYO_ENVWS_N, 0.0); rc |= be_h2d(w, z.data(), z.size() * sizeof(double)); }
     b->K.ctrl_ws = (double*)w;
     if (w) b->allocs.push_back(w);
+#else
+    b->K.ctrl_ws = slot_workspace_acquire(device);
+    if (!b->K.ctrl_ws) rc |= (int)hipErrorOutOfMemory; else b->has_slot_ws = true;
+#endif
   }
   b->K.objf_off = b->L.off_objfric - b->L.off_warm;      // (Scratch::SPILL reads the object group's friction in the record)
   if (m->integrator == 1) {        // RK4 stage storage, one RkScratch per env (global memory)
@@ -1141,6 +1210,9 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   if (rc) {
     int r2 = fail(MYO_E_DEVICE, "device allocation/upload failed: %s", be_errstr(rc));
     for (void* q : b->allocs) be_free(q);
+#ifndef MYO_EMU
+    if (b->has_slot_ws) slot_workspace_release(device);
+#endif
     delete b;
     return r2;
   }
@@ -1155,6 +1227,7 @@ extern "C" void myo_batch_destroy(myo_batch* b) {
   DeviceGuard guard(b->device);
   for (auto& pr : b->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
+  if (b->has_slot_ws) { (void)hipDeviceSynchronize(); slot_workspace_release(b->device); }
 #endif
   for (void* q : b->allocs) be_free(q);
   delete b;
@@ -1184,7 +1257,7 @@ extern "C" int myo_batch_dump_offset(const myo_batch* b, const char* n) {
 #define MYO_LDS_ALIGN(n) (((n) + 15) / 16 * 16)
 #ifdef MYO_PROF
 __device__ unsigned long long g_prof[MYO_NPROF];
-extern "C" int myo_debug_read_prof(double* out16, int reset) {     /* out16: MYO_NPROF (24) doubles */
+extern "C" int myo_debug_read_prof(double* out16, int reset) {     /* out16: MYO_NPROF (32) doubles */
   unsigned long long h[MYO_NPROF];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof h) != hipSuccess) return -1;
   for (int k = 0; k < MYO_NPROF; ++k) out16[k] = (double)h[k];
@@ -1648,7 +1721,7 @@ extern "C" int myo_batch_set_step_generation(myo_batch* b, unsigned int gen) {
 
 // Health counters of a batch (synchronises the device).  out[0]: k_step workgroups that found their env's hand-off state in another
 // generation than the launch's (see the protocol comment at k_step); out[1]: substeps in which an env had more contacts than its
-// scratch holds (the surplus was dropped); out[2], out[3]: reserved, 0.  All 0 in a healthy batch.
+// scratch holds (the surplus was dropped); out[2]: the same for limit rows; out[3]: the most contact slots such a substep asked for.  All 0 in a healthy batch.
 extern "C" int myo_batch_health(myo_batch* b, int out[4]) {
   if (!b || !out) return fail(MYO_E_ARG, "null argument");
   for (int k = 0; k < 4; ++k) out[k] = 0;
@@ -1661,6 +1734,45 @@ extern "C" int myo_batch_health(myo_batch* b, int out[4]) {
     return fail(MYO_E_DEVICE, "myo_batch_health: copy failed");
 #endif
   return MYO_OK;
+}
+
+// Device check of what the per-slot workspace rests on (myo_wave_slot, wave.h): `n_workgroups` one-wave workgroups with `lds_bytes` of
+// dynamic LDS (k_step's footprint: the same residency) each take their slot's occupancy counter, stay for ~20 us, and leave.
+// out[0]: workgroups that found their slot occupied (must be 0); out[1]: distinct slots seen; out[2]: largest slot index; out[3]: bit mask of XCC ids.
+#ifndef MYO_EMU
+__global__ void __launch_bounds__(64, 2) k_wave_slot_probe(int* occ, int* seen, int* out) {
+  if (threadIdx.x != 0) return;
+  const unsigned slot = myo_wave_slot(0);
+  if (atomicAdd(occ + slot, 1) != 0) atomicAdd(out, 1);
+  if (atomicExch(seen + slot, 1) == 0) atomicAdd(out + 1, 1);
+  atomicMax(out + 2, (int)slot);
+  atomicOr(out + 3, 1 << (slot >> 14));
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 2000ull) __builtin_amdgcn_s_sleep(8);
+  atomicSub(occ + slot, 1);
+}
+#endif
+extern "C" int myo_debug_wave_slots(int device, int n_workgroups, int lds_bytes, int32_t out[4]) {
+  if (!out || n_workgroups <= 0 || lds_bytes < 0 || lds_bytes > 65536) return fail(MYO_E_ARG, "bad argument");
+#ifdef MYO_EMU
+  (void)device;
+  return fail(MYO_E_UNSUPPORTED, "myo_debug_wave_slots: no wave slots in the emulation build");
+#else
+  DeviceGuard guard(device);
+  int *occ = nullptr, *seen = nullptr, *o = nullptr;
+  const size_t nb = sizeof(int) * (size_t)MYO_WAVE_SLOTS;
+  int rc = (int)hipMalloc((void**)&occ, nb) | (int)hipMalloc((void**)&seen, nb) | (int)hipMalloc((void**)&o, 4 * sizeof(int));
+  if (!rc) rc = (int)hipMemset(occ, 0, nb) | (int)hipMemset(seen, 0, nb) | (int)hipMemset(o, 0, 4 * sizeof(int));
+  if (!rc) {
+    if (lds_bytes > 0) (void)hipFuncSetAttribute((const void*)k_wave_slot_probe, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    hipLaunchKernelGGL(k_wave_slot_probe, dim3(n_workgroups), dim3(64), (unsigned)lds_bytes, 0, occ, seen, o);
+    rc = (int)hipGetLastError() | (int)hipDeviceSynchronize();
+  }
+  if (!rc) rc = (int)hipMemcpy(out, o, 4 * sizeof(int), hipMemcpyDeviceToHost);
+  (void)hipFree(occ); (void)hipFree(seen); (void)hipFree(o);
+  if (rc) return fail(MYO_E_DEVICE, "myo_debug_wave_slots: %s", hipGetErrorString((hipError_t)rc));
+  return MYO_OK;
+#endif
 }
 
 extern "C" int myo_batch_step_inner(myo_batch* b, const uint8_t* mask, const float* act, float* obs, uint8_t* done, void* stream) {

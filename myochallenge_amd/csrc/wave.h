@@ -7,7 +7,7 @@
 // WAVE_* reductions below.
 //
 // gfx950 build (hipcc): a workgroup is exactly one wavefront (64 threads), `lane` is
-// threadIdx.x, PHASE expands to nothing, SYNC() is __syncthreads() (for a single-wave
+// threadIdx.x, PHASE expands to nothing, SYNC() is a wavefront-scope fence (see below; for a single-wave
 // workgroup that is an LDS wait, no s_barrier round trip), reductions use cross-lane
 // shuffles, compaction uses 64-bit ballots.
 //
@@ -25,6 +25,9 @@
 #define WAVE_FN
 #define PHASE for (int lane = 0; lane < 64; ++lane)
 #define SYNC() ((void)0)
+#define SYNC_G() ((void)0)
+#define GPTR(T) T*
+#define MYO_PIN(x) ((void)0)
 #define LANE_VAR(T, name) T name[64]
 #define LV(name) name[lane]
 // sum over i in [0,n) of expr(i); result uniform
@@ -62,8 +65,11 @@
 // LDS accumulation by several lanes of a phase into one slot (the emulation runs the lanes one after the other)
 template <typename T> static inline void lds_add(T* p, T v) { *p += v; }
 static inline void myo_count(int* p) { *p += 1; }
+static inline void myo_max(int* p, int v) { if (v > *p) *p = v; }
 // a store another workgroup of the launch reads after its agent acquire (st_pub of the device build): the emulation has one memory
 static inline void st_pub(double* p, double v, int wt) { (void)wt; *p = v; }
+#define MYO_WAVE_SLOTS_EMU 0
+static inline unsigned myo_wave_slot(int env) { return (unsigned)env; }      /* the emulation keeps one workspace per env */
 static inline int myo_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #else
@@ -78,7 +84,31 @@ __device__ __forceinline__ void st_pub(double* p, double v, int wt) {
   if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
 }
 #define PHASE
+// SYNC(): the phase boundary.  A workgroup is ONE wavefront: its LDS instructions execute in program order (a ds_write of one lane
+// followed by a ds_read of another needs no wait between them), cross-lane register traffic (DPP, readlane) is ordered by the
+// instruction stream, and what a later phase reads from LDS is waited for by the compiler's own s_waitcnt on the destination
+// register.  So the boundary is a WAVEFRONT-scope fence: it keeps the compiler from moving memory accesses across it and emits no
+// instruction.  __syncthreads() (rounds 1-5) lowered to `s_waitcnt vmcnt(0) lgkmcnt(0)` at every one of the ~400 boundaries of a
+// substep: each drained the LDS stores of the phase just ended (and every outstanding table prefetch / workspace store) before the
+// next phase could issue its first load.
+// SYNC_G(): the boundary after a phase whose GLOBAL-memory stores (the wave slot's workspace, TaskDev::ctrl_ws) are read by OTHER
+// lanes later: drains the stores (what SYNC() was).  Lanes that only re-read what they stored themselves need neither.
+// -DMYO_SYNC_FULL restores the full drain everywhere (A/B).
+#ifdef MYO_SYNC_FULL
 #define SYNC() __syncthreads()
+#else
+#define SYNC() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("" ::: "memory"); }
+#endif
+#define SYNC_G() __syncthreads()
+// a value that must exist in a vector register HERE: keeps a table load where it was written (the compiler otherwise sinks a load into
+// the one branch that uses its result — and waits for it there, one memory round trip per branch)
+#define MYO_PIN(x) asm volatile("" : "+v"(x))
+// a pointer into GLOBAL memory kept in LDS or in the task constants: typed as such, so that its accesses are global_load / global_store
+// and not flat_* (a flat access is not ordered with the wave's ds_* instructions when it lands in LDS, and it counts on both wait counters)
+#define GPTR(T) __attribute__((address_space(1))) T*
+__device__ __forceinline__ void st_pub(GPTR(double) p, double v, int wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
 #define LANE_VAR(T, name) T name
 #define LV(name) name
 // Wave-wide sum in ~11 VALU instructions: DPP butterflies inside each 16-lane row
@@ -167,7 +197,7 @@ template <> __device__ __forceinline__ int myo_wave_sum<int>(int v) {
     (pre)[lane] = __popcll(_m1 & _below) + __popcll(_m2 & _below);                 \
     (total) = __popcll(_m1) + __popcll(_m2);                                       \
   }                                                                                \
-  __syncthreads();
+  SYNC();
 #define WAVE_EXSCAN6(cnt_expr, pre, total)                                         \
   {                                                                                \
     const int _c = (cnt_expr);                                                     \
@@ -179,7 +209,7 @@ template <> __device__ __forceinline__ int myo_wave_sum<int>(int v) {
     }                                                                              \
     (pre)[lane] = _p; (total) = _t;                                                \
   }                                                                                \
-  __syncthreads();
+  SYNC();
 // LDS accumulation by several lanes of a phase into one slot: ds_add_f32 / ds_add_f64 without return value.  Lanes of one
 // instruction that hit the same slot are served in a fixed order by the LDS unit, so the sum is reproducible.
 template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
@@ -187,7 +217,17 @@ template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
   (void)__hip_atomic_fetch_add((lds_p)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void myo_count(int* p) { atomicAdd(p, 1); }     // event counter in global memory
+__device__ __forceinline__ void myo_max(int* p, int v) { atomicMax(p, v); }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
+// The hardware wave slot this wavefront occupies, as an index: (XCC, SE, SH, CU, SIMD, wave buffer) from HW_REG_XCC_ID [3:0] and
+// HW_REG_HW_ID (gfx9 / gfx94x / gfx950 layout: wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13]).
+// Two wavefronts that are resident at the same time never share it, and a slot belongs to one XCD — what k_step's per-slot workspace
+// is built on (TaskDev::ctrl_ws).  Checked on the device by myo_debug_wave_slots (tests/test_step_parts.py, -m gpu).
+#define MYO_WAVE_SLOTS (8 * 16384)
+__device__ __forceinline__ unsigned myo_wave_slot(int) {
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+  return ((xcc & 7u) << 14) | (((hw >> 8) & 0xffu) << 6) | (hw & 0x3fu);
+}
 __device__ __forceinline__ int myo_popcll(unsigned long long x) { return __popcll(x); }
 __device__ __forceinline__ int myo_ffsll(unsigned long long x) { return __ffsll((long long)x) - 1; }
 #endif

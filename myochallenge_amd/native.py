@@ -108,6 +108,7 @@ class NativeLib:
         L.myo_batch_num_envs.argtypes = [vp]
         L.myo_batch_set_step_generation.argtypes = [vp, C.c_uint32]
         L.myo_batch_health.argtypes = [vp, C.POINTER(i32)]
+        L.myo_debug_wave_slots.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(i32)]
         L.myo_batch_obs_dim.argtypes = [vp]
         L.myo_batch_lds_bytes.argtypes = [vp]
         L.myo_batch_reset.argtypes = [vp, vp, vp, vp]
@@ -198,7 +199,7 @@ def load(path: Optional[str] = None) -> NativeLib:
 
 EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_load_mjb", "myo_model_destroy", "myo_model_size", "myo_batch_create",
-    "myo_batch_destroy", "myo_batch_set_step_generation", "myo_batch_health", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
+    "myo_batch_destroy", "myo_batch_set_step_generation", "myo_batch_health", "myo_debug_wave_slots", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
     "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_step_inner_idx", "myo_batch_copy_envs", "myo_batch_physics_step", "myo_batch_get_state",
     "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
@@ -294,11 +295,12 @@ class Batch:
 
     def health(self) -> dict:
         """{"protocol_errors": k_step workgroups that met a hand-off state of another generation, "contact_overflows": substeps that
-        dropped contacts beyond the scratch's capacity, "limit_row_overflows": substeps that dropped limit / friction-loss rows}; all 0
+        dropped contacts beyond the scratch's capacity, "limit_row_overflows": substeps that dropped limit / friction-loss rows,
+        "contact_slots_wanted": the largest number of contact slots such a substep asked for (0 when none overflowed)}; all 0
         in a healthy batch.  Synchronises the device."""
         out = (C.c_int32 * 4)()
         self.lib.check(self.lib.L.myo_batch_health(self.h, out))
-        return {"protocol_errors": int(out[0]), "contact_overflows": int(out[1]), "limit_row_overflows": int(out[2])}
+        return {"protocol_errors": int(out[0]), "contact_overflows": int(out[1]), "limit_row_overflows": int(out[2]), "contact_slots_wanted": int(out[3])}
 
     def set_bad_state_buffer(self, buf):
         """uint8[N] device buffer (kept alive by the caller) that every step() fills with 1 for envs reset after a

@@ -787,7 +787,7 @@ def test_bench_spawns_its_own_ranks(hip_lib):
     assert rec["config"]["envs_per_gpu"] == 256 and rec["config"]["global_envs"] == 512
     assert rec["steps"] == 8 and rec["warmup"] == 2 and rec["scaling"] == "weak"
     assert abs(rec["value"] - 512 / (rec["ms_per_step"] * 1e-3)) <= 1e-3 * rec["value"]
-    assert rec["replicas_identical"] is True and rec["health"] == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0}
+    assert rec["replicas_identical"] is True and rec["health"] == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0, "contact_slots_wanted": 0}
     assert rec["config"]["normalizer_sync"] == "step" and len(rec["rank_block_seconds_min_max"]) == 2
 
 
@@ -873,7 +873,7 @@ def test_mixture_model_env_on_gpu(hip_lib, emu_lib, golden_dir):
         assert float((rg[0].cpu() - rc[0]).abs().max()) <= 1e-4, t               # observations, hand-over observations included
         assert float((rg[1].cpu() - rc[1]).abs().max()) <= 1e-4
     assert gpu._graph is not None and gpu.base_phase_launches >= 3
-    assert gpu.batch.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0}
+    assert gpu.batch.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0, "contact_slots_wanted": 0}
     gpu.close(); cpu.close()
 
     # (ii) cost at BASELINE size.  Base model: the architecture of the reference's phase-1 policy (LSTM-128 -> heads, phase1_final.zip)

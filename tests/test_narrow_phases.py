@@ -423,7 +423,7 @@ def case_condim(lib, dtype, tol):
     assert spin[0] > 19.9 and spin[1] > 19.9 and spin[2] < 12.0 and spin[3] < 12.0, spin          # torsional friction exists from condim 4 on
     roll = [abs(ov[6 * k + 4]) for k in range(4)]
     assert roll[3] < 0.75 * roll[2], roll                                                         # rolling friction from condim 6 on
-    assert b.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0}
+    assert b.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0, "contact_slots_wanted": 0}
     b.close()
 
 

@@ -146,3 +146,21 @@ def test_step_parts_publish_forms_and_the_die_on_gpu(hip_lib, models):
         _same_bits(w, _rollout(hip_lib, die, "CustomMyoReorientP2", dtype, 512, 16, None, horizon=6, overflow_ok=True))
         _same_bits(w, _rollout(hip_lib, die, "CustomMyoReorientP2", dtype, 512, 16, None, horizon=6, publish="fence", overflow_ok=True))
         assert any(x.dtype == np.uint8 and x.any() for x in w)
+
+
+@pytest.mark.gpu
+def test_wave_slots_are_exclusive_on_gpu(hip_lib):
+    """What k_step's per-wave-slot workspace rests on (csrc/wave.h: myo_wave_slot = XCC | SE | SH | CU | SIMD | wave buffer from
+    HW_REG_XCC_ID / HW_REG_HW_ID): no two workgroups that are resident at the same time decode the same slot.  16,384 one-wave
+    workgroups with k_step's LDS footprint (eight per CU: the chip is full for eight rounds) each hold their slot's counter for
+    ~20 us; none may find it taken, the slots seen are as many as the chip holds at that residency, and all eight XCDs appear."""
+    import ctypes as C
+    out = (C.c_int32 * 4)()
+    hip_lib.check(hip_lib.L.myo_debug_wave_slots(0, 16384, 20320, out))
+    clashes, distinct, top, xcc_mask = (int(v) for v in out)
+    assert clashes == 0, (clashes, distinct)
+    assert 256 <= distinct <= 8 * 40 * 4 * 10 and top < 8 * 16384, (distinct, top)
+    assert xcc_mask == 0xff, hex(xcc_mask)
+    # one wave per SIMD (a 64 KB footprint): still exclusive
+    hip_lib.check(hip_lib.L.myo_debug_wave_slots(0, 4096, 65536, out))
+    assert int(out[0]) == 0, tuple(out)

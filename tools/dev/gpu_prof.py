@@ -6,9 +6,12 @@ from myochallenge_amd import native
 from myochallenge_amd.envs.config import make_task_cfg
 from myochallenge_amd.model import compile_model
 from myochallenge_amd.synth_hand import synthetic_hand
-names = ["newton Mv,Jv products (+load/store)", "kinematics", "com_pos + newton Mv/Jv products", "tendon C: lengths / moments", "crb", "collision", "constraint reference (aref)", "actuation",
-         "qacc_smooth(chol)", "hessian", "newton chol", "newton rest", "euler implicit chol", "advance", "newton line search", "check/misc",
-         "tendon A: path points", "tendon B: geom wraps", "joint / tendon limits", "body velocities", "velocity: RNE + passive", "-", "-", "-"]
+names = ["newton: q1 / q2 / |search| sums (+load/store)", "kinematics", "com_pos + newton Mv/Jv products", "tendon C: lengths / moments", "crb", "collision", "constraint reference (aref)", "actuation",
+         "qacc_smooth(chol)", "hessian (J' D J into H)", "newton solve: fingers backward", "newton rest (iteration tail sums, exit tests)", "euler implicit chol", "advance", "newton line search", "check/misc",
+         "tendon A: path points", "tendon B: geom wraps", "joint / tendon limits", "body velocities", "velocity: RNE + passive",
+         "update_constraint: rows -> forces", "update_constraint: J' f", "update_constraint: cost sums, -gradient", "newton warm start (J on two vectors, costs)",
+         "load M into H", "newton solve: finger blocks + Schur", "newton solve: 16 x 16 factor + substitutions", "newton: M search",
+         "newton: body vectors of the direction", "newton: J search", "-"]
 import os
 lib = native.load(os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmyobatch_prof.so"))
 dev = torch.device("cuda:0")
@@ -23,7 +26,7 @@ for integ in ((1,) if "rk4" in sys.argv else (0,)):
     for _ in range(3):
         b.step(torch.clamp(torch.randn((N, 39), device=dev) * 0.135, -1, 1), obs, rew, done)
     torch.cuda.synchronize()
-    out = (C.c_double * 24)(); lib.L.myo_debug_read_prof(out, 1)
+    out = (C.c_double * 32)(); lib.L.myo_debug_read_prof(out, 1)
     K = 5; t0 = time.time()
     for _ in range(K):
         b.step(torch.clamp(torch.randn((N, 39), device=dev) * 0.135, -1, 1), obs, rew, done)

@@ -729,15 +729,36 @@ template <typename T, int NC>
 DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
+  // tree reference points.  Two phases: every body lane leaves its mass (the env's own for the Baoding balls: body_mass_of) and its
+  // tree root in LDS, then each ROOT lane walks the bodies in index order — the same sums in the same order as before, but the walk
+  // reads LDS broadcasts only.  (Rounds 1-5 read the root id and the mass of body o through the scalar cache INSIDE the walk: two
+  // dependent scalar loads and a branch per body, 23 times — 11 k of a substep's 250 k cycles for three lanes' worth of sums.)
+  T* const tmp_m = s.bvec;                                        // body vectors are not live before the velocity stage
+  int* const tmp_r = reinterpret_cast<int*>(s.bvec + MYO_NB_MAX);
+  static_assert(2 * MYO_NB_MAX <= MYO_NB_MAX * 6 && sizeof(T) >= sizeof(int), "per-body mass and root in bvec");
+  LANE_VAR(int, my_root);
   PHASE {
     const int b = lane;
+    const int bc = b < M.nbody ? b : 0;
+    int root = M.body_rootid[bc];
+    T mt = M.body_mass[bc];
+    MYO_PIN(root); MYO_PIN(mt);
+    LV(my_root) = root;
+    if (b < M.nbody) {
+      tmp_m[b] = (b == K.obj1_bid) ? s.ball_mass[0] : ((b == K.obj2_bid) ? s.ball_mass[1] : mt);
+      tmp_r[b] = root;
+    }
     if (b == 0) { S_COM(s)[0] = S_COM(s)[1] = S_COM(s)[2] = 0; }
-    if (b > 0 && b < M.nbody && M.body_rootid[b] == b) {
+  }
+  SYNC();
+  PHASE {
+    const int b = lane;
+    if (b > 0 && b < M.nbody && LV(my_root) == b) {
       T mass = 0, c[3] = {0, 0, 0};
-#pragma unroll 4
+#pragma unroll 8
       for (int o = 1; o < M.nbody; ++o) {
-        // wave-uniform reads issued unconditionally, membership applied as a select (no branch around the loads)
-        const T mo = (M.body_rootid[o] == b) ? body_mass_of(M, K, s, o) : (T)0;
+        // wave-uniform LDS reads issued unconditionally, membership applied as a select
+        const T mo = (tmp_r[o] == b) ? tmp_m[o] : (T)0;
         const T x = S_XIPOS(s)[3 * o], y = S_XIPOS(s)[3 * o + 1], z = S_XIPOS(s)[3 * o + 2];
         mass += mo; c[0] += mo * x; c[1] += mo * y; c[2] += mo * z;
       }
@@ -756,8 +777,6 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
     for (int k = 0; k < 9; ++k) imat[k] = M.body_imat[9 * bc + k];
 #pragma unroll
     for (int k = 0; k < 3; ++k) I[k] = M.body_inertia[3 * bc + k];
-    int broot = M.body_rootid[bc];
-    T bmass_tab = M.body_mass[bc];
     int jrec[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) jrec[k] = M.jk_i[4 * jc + k];
@@ -765,7 +784,6 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
     for (int k = 0; k < 9; ++k) MYO_PIN(imat[k]);
 #pragma unroll
     for (int k = 0; k < 3; ++k) MYO_PIN(I[k]);
-    MYO_PIN(broot); MYO_PIN(bmass_tab);
 #pragma unroll
     for (int k = 0; k < 4; ++k) MYO_PIN(jrec[k]);
     if (b < M.nbody) {
@@ -775,9 +793,9 @@ DEVFN void com_pos(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>&
         T R[9], Rb[9];
         body_rot(s, b, Rb);
         mulmat3(R, Rb, imat);
-        const T* c = S_COM(s) + 3 * broot;
+        const T* c = S_COM(s) + 3 * LV(my_root);
         const T off[3] = {S_XIPOS(s)[3 * b] - c[0], S_XIPOS(s)[3 * b + 1] - c[1], S_XIPOS(s)[3 * b + 2] - c[2]};
-        const T mb = (b == K.obj1_bid) ? s.ball_mass[0] : ((b == K.obj2_bid) ? s.ball_mass[1] : bmass_tab);      // (body_mass_of)
+        const T mb = tmp_m[b];                             // (body_mass_of, staged above)
         ci[0] = R[0] * R[0] * I[0] + R[1] * R[1] * I[1] + R[2] * R[2] * I[2] + mb * (off[1] * off[1] + off[2] * off[2]);
         ci[1] = R[3] * R[3] * I[0] + R[4] * R[4] * I[1] + R[5] * R[5] * I[2] + mb * (off[0] * off[0] + off[2] * off[2]);
         ci[2] = R[6] * R[6] * I[0] + R[7] * R[7] * I[1] + R[8] * R[8] * I[2] + mb * (off[0] * off[0] + off[1] * off[1]);

@@ -332,13 +332,16 @@ int myo_lstm_cell_bwd(const void* dout, const void* dhm_next, const void* dcm_ne
  *   gx    element (g, n, col) at gx[g*gx_sg + n*gx_sr + col]  (col < 4H; e.g. one [N, G*4H] GEMM output: gx_sg = 4H, gx_sr = G*4H),
  *   out_h element (g, n, u) at out_h[g*out_sg + n*H + u],  dout likewise with dout_sg  (strides in elements, multiples of 4).
  * fwd: h_prev, c_prev [G,N,H] (already masked), w_hh [G,4H,H] (weight_hh_l0 of each LSTM) -> out_h, hm_next, cm_next, c_new, ws
- *      as myo_lstm_cell_fwd; c_new / ws may be NULL (rollout).
+ *      as myo_lstm_cell_fwd; c_new / ws may be NULL (rollout).  The CELL state may travel in float32 beside (or instead of) its
+ *      bfloat16 arrays: c_prev32 float32 [G,N,H] (non-NULL: read instead of c_prev), cm_next32 float32 [G,N,H] (non-NULL: written,
+ *      unrounded; cm_next may then be NULL) — what an LSTM carries through an episode is c (stock nn.LSTM state is float32,
+ *      /root/reference/src/main_reorient.py:53-71); h is the matrix cores' operand and stays bfloat16.
  * bwd: dgates_next [G,N,4H] = the dgates of step t+1 (NULL at the last step), w_hh_t [G,H,4H] = W_hh transposed; the product
  *      dgates_next . W_hh replaces dhm_next of myo_lstm_cell_bwd -> dgates [G,N,4H], dc_prev [G,N,H]. */
 int myo_lstm_step_supported(int H);
 int myo_lstm_step_fwd(const void* gx, long long gx_sg, long long gx_sr, const void* h_prev, const void* c_prev, const void* w_hh,
                       const float* keep_next, int G, int N, int H, void* out_h, long long out_sg, void* hm_next, void* cm_next,
-                      void* c_new, void* ws, void* stream);
+                      void* c_new, void* ws, const float* c_prev32, float* cm_next32, void* stream);
 int myo_lstm_step_bwd(const void* dout, long long dout_sg, const void* dgates_next, const void* dcm_next, const void* w_hh_t,
                       const float* keep_next, const void* c_prev, const void* c_new, const void* ws, int G, int N, int H,
                       void* dgates, void* dc_prev, void* stream);
@@ -359,11 +362,14 @@ int myo_lstm_step_bwd(const void* dout, long long dout_sg, const void* dgates_ne
  *      entering step 0 (given, row-major), slots 1..T written (hm row-major, cm tile-major); keep float32 [T,N] (0 where an episode
  *      starts at that step: step t masks its outgoing state with keep[t+1], the last step with 1); out_h element (g, t, r, u) at
  *      out_h[g*out_sg + t*out_st + r*H + u]; c_new [T,G,N,H], ws [T,G,N,4H] (gate activations) kept for the backward pass.
+ *      c0_32 float32 [G,N,H] (may be NULL): the masked CELL state entering step 0, unrounded; with it the cell state is carried from
+ *      step to step in float32 (the bfloat16 cm slots are still written: the backward pass reads them), without it every step
+ *      re-reads its cell state from the bfloat16 slot the previous step wrote (the roundings of T myo_lstm_step_fwd calls on bf16 c).
  * bwd: dout laid out like out_h; keep / cm / c_new / ws as the forward pass left them -> dgates [T,G,N,4H] (row-major). */
 int myo_lstm_seq_supported(int H);
 int myo_lstm_seq_fwd(const void* gx, long long gx_st, long long gx_sg, long long gx_sr, void* hm, void* cm, const void* w_frag,
                      const float* keep, int G, int N, int H, int T, int row_split, void* out_h, long long out_sg, long long out_st,
-                     void* c_new, void* ws, void* stream);
+                     void* c_new, void* ws, const float* c0_32, void* stream);
 int myo_lstm_seq_bwd(const void* dout, long long dout_sg, long long dout_st, const void* wt_frag, const float* keep, const void* cm,
                      const void* c_new, const void* ws, int G, int N, int H, int T, int row_split, void* dgates, void* stream);
 

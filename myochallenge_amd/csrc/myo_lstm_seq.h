@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
     const unsigned short* __restrict__ gx, long long gx_st, long long gx_sg, long long gx_sr, unsigned short* __restrict__ hm,
     unsigned short* __restrict__ cm, const unsigned short* __restrict__ w_frag, const float* __restrict__ keep, int N, int T,
     unsigned short* __restrict__ out_h, long long out_sg, long long out_st, unsigned short* __restrict__ c_new,
-    unsigned short* __restrict__ ws) {
+    unsigned short* __restrict__ ws, const float* __restrict__ c0_32) {
   typedef LstmSeqCfg<H> Cf;
   typedef LstmSeqRows<H, RS> Rw;
   constexpr int UT = Cf::UT, NF = Cf::FFRAG, NT = Cf::FN, SB = Cf::FSB, NL = Cf::FL, NR = Cf::FR, NV = Rw::CL, ROWS = Rw::ROWS, BPU = Rw::BPU;
@@ -165,8 +165,14 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
   // tile-major: x_tm[(g, rt)][w][lane][NV], ws_tm[(g, rt)][w][q][lane][NV]
   const unsigned ot = (unsigned)((((size_t)g * (N / ROWS) + blockIdx.x) * 8 + wave) * 64 * NV + lane * NV);
   const unsigned otw = (unsigned)((((size_t)g * (N / ROWS) + blockIdx.x) * 8 + wave) * 4 * 64 * NV + lane * NV);
+  // the cell state a lane carries from step to step: float32 when the caller passes the unrounded state entering step 0 (c0_32), else
+  // re-read from the bfloat16 slot every step (the step kernels' roundings on a bfloat16 c)
+  const bool c_f32 = c0_32 != nullptr;                                 // (uniform)
   float cp[NV];
-  {
+  if (c_f32) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) cp[i] = c0_32[(size_t)g * N * H + oh + i];
+  } else {
     const vec cpv = lstm_seq_ldv<NV>(cm + (size_t)g * N * H + oh);    // slot 0: row-major
 #pragma unroll
     for (int i = 0; i < NV; ++i) cp[i] = lstm_bf(cpv[i]);
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(512) k_lstm_seq_fwd(
       iv[p2] = lstm_seq_pk(vi[0], vi[1]); fv[p2] = lstm_seq_pk(vf[0], vf[1]); gv[p2] = lstm_seq_pk(vg[0], vg[1]); ov[p2] = lstm_seq_pk(vo[0], vo[1]);
       cnv[p2] = lstm_seq_pk(c[0], c[1]); hv[p2] = lstm_seq_pk(h[0], h[1]);
       hmv[p2] = lstm_seq_pk(h[0] * k, h[1] * k); cmv[p2] = lstm_seq_pk(c[0] * k, c[1] * k);
-      cp[2 * p2] = lstm_seq_lo(cmv[p2]); cp[2 * p2 + 1] = lstm_seq_hi(cmv[p2]);
+      cp[2 * p2] = c_f32 ? c[0] * k : lstm_seq_lo(cmv[p2]); cp[2 * p2 + 1] = c_f32 ? c[1] * k : lstm_seq_hi(cmv[p2]);
     }
     auto V = [](const unsigned (&w)[NV / 2]) -> const vec& { return *reinterpret_cast<const vec*>(w); };
     lstm_seq_stv<NV>(&hbuf[lr * Cf::FSTR + u0], V(hmv));
@@ -404,12 +410,12 @@ static int lstm_seq_lds_attr(K kernel, size_t lds, bool* done) {     // above th
 template <int H, int RS>
 static int lstm_seq_fwd_launch(const unsigned short* gx, long long gx_st, long long gx_sg, long long gx_sr, unsigned short* hm,
                                unsigned short* cm, const unsigned short* w_frag, const float* keep, int G, int N, int T, unsigned short* out_h,
-                               long long out_sg, long long out_st, unsigned short* c_new, unsigned short* ws, hipStream_t s) {
+                               long long out_sg, long long out_st, unsigned short* c_new, unsigned short* ws, const float* c0_32, hipStream_t s) {
   static bool attr = false;
   typedef LstmSeqRows<H, RS> Rw;
   if (lstm_seq_lds_attr(&k_lstm_seq_fwd<H, RS>, Rw::F_LDS, &attr)) return 1;
   hipLaunchKernelGGL((k_lstm_seq_fwd<H, RS>), dim3(N / Rw::ROWS, G), dim3(512), Rw::F_LDS, s, gx, gx_st, gx_sg, gx_sr, hm, cm, w_frag, keep, N, T,
-                     out_h, out_sg, out_st, c_new, ws);
+                     out_h, out_sg, out_st, c_new, ws, c0_32);
   return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 template <int H, int RS>

@@ -30,15 +30,20 @@ __device__ __forceinline__ void lstm_st4(unsigned short* p, float a, float b, fl
 }
 
 // What the forward epilogue needs besides the product, and the epilogue itself (shared by both forward kernels).
-struct LstmFwdIn { myo_u16x4 xi, xf, xg, xo, cp; float keep; };
+// (cp: the cell state entering the step as fp32 — from the caller's fp32 copy, c_prev32, where there is one: the state an LSTM carries
+//  through an episode is the CELL state, and a bf16 round trip per step puts 2^-9 of it back in every step of a 300-step episode; h is
+//  the matrix cores' operand and stays bf16)
+struct LstmFwdIn { myo_u16x4 xi, xf, xg, xo; myo_f32x4 cp; float keep; };
 template <int H>
 __device__ __forceinline__ LstmFwdIn lstm_fwd_in(const unsigned short* __restrict__ gx, long long gx_sg, long long gx_sr,
-                                                 const unsigned short* __restrict__ c_prev, const float* __restrict__ keep_next, int N, int g,
-                                                 int r, int u0) {
+                                                 const unsigned short* __restrict__ c_prev, const float* __restrict__ c_prev32,
+                                                 const float* __restrict__ keep_next, int N, int g, int r, int u0) {
   LstmFwdIn in;
   const unsigned short* gp = gx + (size_t)g * gx_sg + (size_t)r * gx_sr + u0;
   in.xi = lstm_ld4(gp); in.xf = lstm_ld4(gp + H); in.xg = lstm_ld4(gp + 2 * H); in.xo = lstm_ld4(gp + 3 * H);
-  in.cp = lstm_ld4(c_prev + ((size_t)g * N + r) * H + u0);
+  const size_t e = ((size_t)g * N + r) * H + u0;
+  if (c_prev32) in.cp = *reinterpret_cast<const myo_f32x4*>(c_prev32 + e);
+  else { const myo_u16x4 c = lstm_ld4(c_prev + e); in.cp = myo_f32x4{lstm_bf(c.x), lstm_bf(c.y), lstm_bf(c.z), lstm_bf(c.w)}; }
   in.keep = keep_next ? keep_next[r] : 1.f;
   return in;
 }
@@ -46,7 +51,7 @@ template <int H>
 __device__ __forceinline__ void lstm_fwd_out(const LstmFwdIn& in, const myo_f32x4 (&acc)[4], int N, int g, int r, int u0,
                                              unsigned short* __restrict__ out_h, long long out_sg, unsigned short* __restrict__ hm_next,
                                              unsigned short* __restrict__ cm_next, unsigned short* __restrict__ c_new,
-                                             unsigned short* __restrict__ ws) {
+                                             unsigned short* __restrict__ ws, float* __restrict__ cm_next32) {
   const size_t e = ((size_t)g * N + r) * H + u0;
   const float k = in.keep;
   float iv[4], fv[4], gv[4], ov[4], cv[4], hv[4];
@@ -56,12 +61,13 @@ __device__ __forceinline__ void lstm_fwd_out(const LstmFwdIn& in, const myo_f32x
     fv[j] = myo_sigmoid(lstm_bf(in.xf[j]) + acc[1][j]);
     gv[j] = tanhf(lstm_bf(in.xg[j]) + acc[2][j]);
     ov[j] = myo_sigmoid(lstm_bf(in.xo[j]) + acc[3][j]);
-    cv[j] = fv[j] * lstm_bf(in.cp[j]) + iv[j] * gv[j];
+    cv[j] = fv[j] * in.cp[j] + iv[j] * gv[j];
     hv[j] = ov[j] * tanhf(cv[j]);
   }
   lstm_st4(out_h + (size_t)g * out_sg + (size_t)r * H + u0, hv[0], hv[1], hv[2], hv[3]);
   lstm_st4(hm_next + e, hv[0] * k, hv[1] * k, hv[2] * k, hv[3] * k);
-  lstm_st4(cm_next + e, cv[0] * k, cv[1] * k, cv[2] * k, cv[3] * k);
+  if (cm_next) lstm_st4(cm_next + e, cv[0] * k, cv[1] * k, cv[2] * k, cv[3] * k);
+  if (cm_next32) *reinterpret_cast<myo_f32x4*>(cm_next32 + e) = myo_f32x4{cv[0] * k, cv[1] * k, cv[2] * k, cv[3] * k};
   if (c_new) lstm_st4(c_new + e, cv[0], cv[1], cv[2], cv[3]);
   if (ws) {
     unsigned short* wp = ws + ((size_t)g * N + r) * 4 * H + u0;
@@ -82,7 +88,8 @@ __global__ void __launch_bounds__(256) k_lstm_step_fwd(const unsigned short* __r
                                                        const unsigned short* __restrict__ w_hh, const float* __restrict__ keep_next, int N,
                                                        unsigned short* __restrict__ out_h, long long out_sg,
                                                        unsigned short* __restrict__ hm_next, unsigned short* __restrict__ cm_next,
-                                                       unsigned short* __restrict__ c_new, unsigned short* __restrict__ ws) {
+                                                       unsigned short* __restrict__ c_new, unsigned short* __restrict__ ws,
+                                                       const float* __restrict__ c_prev32, float* __restrict__ cm_next32) {
   static_assert(H % 128 == 0, "K-split forward needs H / 4 to be a multiple of the MFMA's K = 32");
   constexpr int KSW = H / 128;                      // k-steps of 32 per wave
   __shared__ myo_f32x4 red[4 * 3 * 4 * 64];         // [wave][other row tile][gate q][lane]: 48 KB
@@ -107,7 +114,7 @@ __global__ void __launch_bounds__(256) k_lstm_step_fwd(const unsigned short* __r
   // the epilogue's operands (row tile `wave`) travel with them
   const int r_out = row0 + wave * 16 + lr;
   const int r_ld = r_out < N ? r_out : N - 1;
-  const LstmFwdIn in = lstm_fwd_in<H>(gx, gx_sg, gx_sr, c_prev, keep_next, N, g, r_ld, u0);
+  const LstmFwdIn in = lstm_fwd_in<H>(gx, gx_sg, gx_sr, c_prev, c_prev32, keep_next, N, g, r_ld, u0);
   myo_f32x4 acc[4][4];
 #pragma unroll
   for (int n = 0; n < 4; ++n)
@@ -137,7 +144,7 @@ __global__ void __launch_bounds__(256) k_lstm_step_fwd(const unsigned short* __r
   for (int slot = 0; slot < 3; ++slot)
 #pragma unroll
     for (int q = 0; q < 4; ++q) sum[q] += red[((wave * 3 + slot) * 4 + q) * 64 + lane];
-  if (r_out < N) lstm_fwd_out<H>(in, sum, N, g, r_out, u0, out_h, out_sg, hm_next, cm_next, c_new, ws);
+  if (r_out < N) lstm_fwd_out<H>(in, sum, N, g, r_out, u0, out_h, out_sg, hm_next, cm_next, c_new, ws, cm_next32);
 }
 
 // forward for H < 128 (the reduction is too short to split): one wave = 16 units x 16 rows, whole K.
@@ -147,7 +154,8 @@ __global__ void __launch_bounds__(256) k_lstm_step_fwd_small(const unsigned shor
                                                              const unsigned short* __restrict__ w_hh, const float* __restrict__ keep_next, int N,
                                                              unsigned short* __restrict__ out_h, long long out_sg,
                                                              unsigned short* __restrict__ hm_next, unsigned short* __restrict__ cm_next,
-                                                             unsigned short* __restrict__ c_new, unsigned short* __restrict__ ws) {
+                                                             unsigned short* __restrict__ c_new, unsigned short* __restrict__ ws,
+                                                             const float* __restrict__ c_prev32, float* __restrict__ cm_next32) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = blockIdx.z, ut = blockIdx.y;
   const int row0 = (blockIdx.x * 4 + wave) * 16;
@@ -156,7 +164,7 @@ __global__ void __launch_bounds__(256) k_lstm_step_fwd_small(const unsigned shor
   const int r_out = row0 + lr, r_ld = r_out < N ? r_out : N - 1, u0 = ut * 16 + 4 * lk;
   const unsigned short* W = w_hh + (size_t)g * 4 * H * H + (size_t)(ut * 16 + lr) * H + lk * 8;
   const unsigned short* hp = h_prev + ((size_t)g * N + r_ld) * H + lk * 8;
-  const LstmFwdIn in = lstm_fwd_in<H>(gx, gx_sg, gx_sr, c_prev, keep_next, N, g, r_ld, u0);
+  const LstmFwdIn in = lstm_fwd_in<H>(gx, gx_sg, gx_sr, c_prev, c_prev32, keep_next, N, g, r_ld, u0);
   myo_f32x4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = myo_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -166,7 +174,7 @@ __global__ void __launch_bounds__(256) k_lstm_step_fwd_small(const unsigned shor
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lstm_ld8(W + (size_t)q * H * H + ks * 32), b, acc[q], 0, 0, 0);
   }
-  if (r_out < N) lstm_fwd_out<H>(in, acc, N, g, r_out, u0, out_h, out_sg, hm_next, cm_next, c_new, ws);
+  if (r_out < N) lstm_fwd_out<H>(in, acc, N, g, r_out, u0, out_h, out_sg, hm_next, cm_next, c_new, ws, cm_next32);
 }
 
 // backward: dh = dout + keep_next (dgates_next . W_hh), dc = keep_next dcm_next + dh o (1 - tanh^2 c_new) -> dgates, dc_prev.
@@ -262,14 +270,14 @@ template <int H>
 static void lstm_step_fwd_launch(const unsigned short* gx, long long gx_sg, long long gx_sr, const unsigned short* h_prev,
                                  const unsigned short* c_prev, const unsigned short* w_hh, const float* keep_next, int G, int N,
                                  unsigned short* out_h, long long out_sg, unsigned short* hm_next, unsigned short* cm_next,
-                                 unsigned short* c_new, unsigned short* ws, hipStream_t s) {
+                                 unsigned short* c_new, unsigned short* ws, const float* c_prev32, float* cm_next32, hipStream_t s) {
   const dim3 grid((N + 63) / 64, H / 16, G);
   if constexpr (H % 128 == 0)
     hipLaunchKernelGGL((k_lstm_step_fwd<H>), grid, dim3(256), 0, s, gx, gx_sg, gx_sr, h_prev, c_prev, w_hh, keep_next, N, out_h, out_sg, hm_next,
-                       cm_next, c_new, ws);
+                       cm_next, c_new, ws, c_prev32, cm_next32);
   else
     hipLaunchKernelGGL((k_lstm_step_fwd_small<H>), grid, dim3(256), 0, s, gx, gx_sg, gx_sr, h_prev, c_prev, w_hh, keep_next, N, out_h, out_sg,
-                       hm_next, cm_next, c_new, ws);
+                       hm_next, cm_next, c_new, ws, c_prev32, cm_next32);
 }
 template <int H>
 static void lstm_step_bwd_launch(const unsigned short* dout, long long dout_sg, const unsigned short* dg_next, const unsigned short* dcm_next,

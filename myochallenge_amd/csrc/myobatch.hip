@@ -3165,19 +3165,19 @@ extern "C" double myo_batch_kernel_ms(myo_batch* b) {
 extern "C" int myo_lstm_step_supported(int H) { return (H == 32 || H == 64 || H == 128 || H == 256) ? 1 : 0; }
 extern "C" int myo_lstm_step_fwd(const void* gx, long long gx_sg, long long gx_sr, const void* h_prev, const void* c_prev, const void* w_hh,
                                  const float* keep_next, int G, int N, int H, void* out_h, long long out_sg, void* hm_next, void* cm_next,
-                                 void* c_new, void* ws, void* stream) {
-  if (!gx || !h_prev || !c_prev || !w_hh || !out_h || !hm_next || !cm_next || G <= 0 || N <= 0 || H <= 0 || (gx_sg & 3) || (gx_sr & 3) || (out_sg & 3))
+                                 void* c_new, void* ws, const float* c_prev32, float* cm_next32, void* stream) {
+  if (!gx || !h_prev || (!c_prev && !c_prev32) || !w_hh || !out_h || !hm_next || (!cm_next && !cm_next32) || G <= 0 || N <= 0 || H <= 0 || (gx_sg & 3) || (gx_sr & 3) || (out_sg & 3))
     return fail(MYO_E_ARG, "myo_lstm_step_fwd: bad arguments");
   if (!myo_lstm_step_supported(H)) return fail(MYO_E_UNSUPPORTED, "myo_lstm_step_fwd: hidden size %d (32, 64, 128 or 256)", H);
 #ifdef MYO_EMU
-  (void)keep_next; (void)c_new; (void)ws; (void)stream;
+  (void)keep_next; (void)c_new; (void)ws; (void)stream; (void)c_prev32; (void)cm_next32;
   return fail(MYO_E_UNSUPPORTED, "myo_lstm_step_fwd is a GPU kernel");
 #else
   typedef const unsigned short* cu;
   typedef unsigned short* mu;
 #define MYO_LSTM_FWD(HH)                                                                                                              \
   lstm_step_fwd_launch<HH>((cu)gx, gx_sg, gx_sr, (cu)h_prev, (cu)c_prev, (cu)w_hh, keep_next, G, N, (mu)out_h, out_sg, (mu)hm_next,   \
-                           (mu)cm_next, (mu)c_new, (mu)ws, (hipStream_t)stream)
+                           (mu)cm_next, (mu)c_new, (mu)ws, c_prev32, cm_next32, (hipStream_t)stream)
   switch (H) {
     case 32: MYO_LSTM_FWD(32); break;
     case 64: MYO_LSTM_FWD(64); break;
@@ -3225,20 +3225,20 @@ extern "C" int myo_lstm_seq_supported(int H) { return (H == 128 || H == 256) ? 1
 static int lstm_seq_rs_ok(int H, int rs) { return rs == 1 || rs == 2 || (rs == 4 && H == 256); }
 extern "C" int myo_lstm_seq_fwd(const void* gx, long long gx_st, long long gx_sg, long long gx_sr, void* hm, void* cm, const void* w_frag,
                                 const float* keep, int G, int N, int H, int T, int row_split, void* out_h, long long out_sg, long long out_st,
-                                void* c_new, void* ws, void* stream) {
+                                void* c_new, void* ws, const float* c0_32, void* stream) {
   if (!gx || !hm || !cm || !w_frag || !keep || !out_h || !c_new || !ws || G <= 0 || N <= 0 || H <= 0 || T <= 0 || (gx_st & 7) || (gx_sg & 7) ||
       (gx_sr & 7) || (out_sg & 7) || (out_st & 7) || (N & 15))
     return fail(MYO_E_ARG, "myo_lstm_seq_fwd: bad arguments (N must be a multiple of 16, strides of 8)");
   if (!myo_lstm_seq_supported(H) || !lstm_seq_rs_ok(H, row_split))
     return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_fwd: hidden size %d (128 or 256) with row split %d (1, 2; 4 at 256)", H, row_split);
 #ifdef MYO_EMU
-  (void)stream;
+  (void)stream; (void)c0_32;
   return fail(MYO_E_UNSUPPORTED, "myo_lstm_seq_fwd is a GPU kernel");
 #else
   typedef const unsigned short* cu;
   typedef unsigned short* mu;
 #define MYO_SEQ_FWD(HH, RR) lstm_seq_fwd_launch<HH, RR>((cu)gx, gx_st, gx_sg, gx_sr, (mu)hm, (mu)cm, (cu)w_frag, keep, G, N, T, (mu)out_h, out_sg, out_st, \
-                                                        (mu)c_new, (mu)ws, (hipStream_t)stream)
+                                                        (mu)c_new, (mu)ws, c0_32, (hipStream_t)stream)
   const int rc = H == 128 ? (row_split == 1 ? MYO_SEQ_FWD(128, 1) : MYO_SEQ_FWD(128, 2))
                           : (row_split == 1 ? MYO_SEQ_FWD(256, 1) : row_split == 2 ? MYO_SEQ_FWD(256, 2) : MYO_SEQ_FWD(256, 4));
 #undef MYO_SEQ_FWD

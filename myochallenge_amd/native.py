@@ -149,10 +149,10 @@ class NativeLib:
         L.myo_lstm_cell_fwd.argtypes = [vp] * 4 + [i32] * 4 + [vp] * 6
         L.myo_lstm_cell_bwd.argtypes = [vp] * 7 + [i32] * 4 + [vp] * 3
         L.myo_lstm_step_supported.argtypes = [i32]
-        L.myo_lstm_step_fwd.argtypes = [vp, C.c_longlong, C.c_longlong] + [vp] * 4 + [i32] * 3 + [vp, C.c_longlong] + [vp] * 5
+        L.myo_lstm_step_fwd.argtypes = [vp, C.c_longlong, C.c_longlong] + [vp] * 4 + [i32] * 3 + [vp, C.c_longlong] + [vp] * 7
         L.myo_lstm_step_bwd.argtypes = [vp, C.c_longlong] + [vp] * 7 + [i32] * 3 + [vp] * 3
         L.myo_lstm_seq_supported.argtypes = [i32]
-        L.myo_lstm_seq_fwd.argtypes = [vp] + [C.c_longlong] * 3 + [vp] * 4 + [i32] * 5 + [vp, C.c_longlong, C.c_longlong] + [vp] * 3
+        L.myo_lstm_seq_fwd.argtypes = [vp] + [C.c_longlong] * 3 + [vp] * 4 + [i32] * 5 + [vp, C.c_longlong, C.c_longlong] + [vp] * 4
         L.myo_lstm_seq_bwd.argtypes = [vp, C.c_longlong, C.c_longlong] + [vp] * 5 + [i32] * 5 + [vp] * 2
         L.myo_adam_clip_step.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, vp, vp]
         L.myo_adam_apply.argtypes = [vp] * 4 + [i32] + [C.c_float] * 6 + [vp, vp, i32, vp, vp]

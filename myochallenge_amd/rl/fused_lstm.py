@@ -91,6 +91,9 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         # ... and ALL time steps of a minibatch in one launch per direction where the hidden size has a sequence kernel
         # (csrc/myo_lstm_seq.h; MYO_LSTM_SEQ=0: one launch per time step)
         self.seq_kernels = self.step_kernels and bool(lib.L.myo_lstm_seq_supported(la.hidden_size)) and os.environ.get("MYO_LSTM_SEQ") != "0"
+        # the CELL state travels from step to step in float32 (c_prev32 / c0_32 of the kernels: what nn.LSTM carries; h stays the bf16
+        # MFMA operand); MYO_LSTM_C32=0 is the A/B switch back to a bf16 round trip per step
+        self.c32 = os.environ.get("MYO_LSTM_C32") != "0"
         return self if self.lstm is not None else None
 
     def _lstm_views(self, flat, hflat):
@@ -153,7 +156,8 @@ class FusedRecurrentPPOStep(FusedPPOStep):
         cm = torch.empty_like(hm)
         k0 = keep[0].view(1, m, 1)
         torch.mul(h0.index_select(1, idx), k0, out=hm[0])
-        torch.mul(c0.index_select(1, idx), k0, out=cm[0])
+        c0m = c0.index_select(1, idx).float() * k0                        # the masked cell state entering step 0, UNROUNDED: the forward
+        cm[0].copy_(c0m)                                                  # pass carries c in float32 (the bf16 slots are the backward pass's)
         # ---- input projections of both LSTMs, all time steps: [B, O] x [O, 2*4H]
         bsum = (L["bihh"] + L["bhhh"]).view(G * H4)
         gx = torch.addmm(bsum, x[0], L["wihh"].view(G * H4, O).t()).view(T, m, G, H4)      # row (t, n): [actor 4H | critic 4H]
@@ -168,15 +172,16 @@ class FusedRecurrentPPOStep(FusedPPOStep):
             rs = lstm_seq_row_split(H, G, m)
             w_frag, wt_frag = lstm_seq_weights(L["whhh"], rs)
             lib.check(lib.L.myo_lstm_seq_fwd(p(gx), m * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, m, H, T, rs, p(lat), T * m * H,
-                                             m * H, p(cn), p(ws), st))
+                                             m * H, p(cn), p(ws), p(c0m) if self.c32 else None, st))
             pl, vl, dlat = self._merged_core(lat.view(G, B, H), act, oldlp, adv_mb, ret_mb, want_dx=True)
             lib.check(lib.L.myo_lstm_seq_bwd(p(dlat), T * m * H, m * H, p(wt_frag), p(keep), p(cm), p(cn), p(ws), G, m, H, T, rs, p(dG), st))
         elif self.step_kernels:
             # a time step = ONE launch per direction (csrc/myo_lstm_step.h): recurrent product on the matrix cores + cell epilogue;
             # reads gx where the projection GEMM left it and writes the outputs where the trunks read them (no transposes)
+            c32 = (c0m, torch.empty_like(c0m)) if self.c32 else (None, None)      # the float32 cell state, ping-pong
             for t in range(T):
                 lib.check(lib.L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm[t]), p(cm[t]), p(L["whhh"]), kp(t), G, m, H, p(lat[:, t]),
-                                                  T * m * H, p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+                                                  T * m * H, p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), p(c32[t & 1]), p(c32[(t + 1) & 1]), st))
             pl, vl, dlat = self._merged_core(lat.view(G, B, H), act, oldlp, adv_mb, ret_mb, want_dx=True)
             dlat = dlat.view(G, T, m, H)
             wt = L["whhh"].transpose(1, 2).contiguous()                  # [G, H, 4H] = W_hh^T

@@ -101,26 +101,33 @@ class _LstmSeq(torch.autograd.Function):
         ctx.native = lib is not None
         if lib is not None:
             import ctypes as C
+            # The CELL (gates, cell state, what the backward pass keeps) is float32 whatever the GEMM dtype: c is the state an LSTM
+            # carries through an episode — stock nn.LSTM carries it in float32 (/root/reference/src/main_reorient.py:53-71), and so
+            # do the fused paths (csrc/myo_lstm_step.h / myo_lstm_seq.h: c_prev32) — while h is rounded to the GEMM dtype, its only use.
+            gd, f32 = gx.dtype, torch.float32
             gx = gx.contiguous()
             kf = None if keep is None else keep.reshape(T, N).float().contiguous()
-            hm = torch.empty((T + 1, G, N, H), dtype=gx.dtype, device=gx.device)      # masked h entering step t
-            cm = torch.empty_like(hm)
-            out, cn = torch.empty((T, G, N, H), dtype=gx.dtype, device=gx.device), torch.empty((T, G, N, H), dtype=gx.dtype, device=gx.device)
-            ws = torch.empty((T, G, N, H4), dtype=gx.dtype, device=gx.device)
+            hm = torch.empty((T + 1, G, N, H), dtype=gd, device=gx.device)           # masked h entering step t (the recurrent GEMM's input)
+            cm = torch.empty((T + 1, G, N, H), dtype=f32, device=gx.device)
+            out, cn = torch.empty((T, G, N, H), dtype=f32, device=gx.device), torch.empty((T, G, N, H), dtype=f32, device=gx.device)
+            ws = torch.empty((T, G, N, H4), dtype=f32, device=gx.device)
+            hmf = torch.empty((G, N, H), dtype=f32, device=gx.device)
             hm[0] = h0 if kf is None else h0 * keep[0]
-            cm[0] = c0 if kf is None else c0 * keep[0]
+            cm[0] = c0.float() if kf is None else c0.float() * keep[0].float()
             st = C.c_void_p(torch.cuda.current_stream(gx.device).cuda_stream)
             p = lambda t: C.c_void_p(t.data_ptr())
-            bf = int(gx.dtype == torch.bfloat16)
             wt = wt.contiguous()
             for t in range(T):
-                gh = torch.bmm(hm[t], wt)
+                gh = torch.bmm(hm[t], wt).float()
+                gxt = gx[t].float()
                 kn = p(kf[t + 1]) if (kf is not None and t + 1 < T) else None
-                lib.check(lib.L.myo_lstm_cell_fwd(p(gx[t]), p(gh), p(cm[t]), kn, G * N, N, H, bf, p(out[t]), p(hm[t + 1]), p(cm[t + 1]),
+                lib.check(lib.L.myo_lstm_cell_fwd(p(gxt), p(gh), p(cm[t]), kn, G * N, N, H, 0, p(out[t]), p(hmf), p(cm[t + 1]),
                                                   p(cn[t]), p(ws[t]), st))
+                hm[t + 1].copy_(hmf)
             ctx.save_for_backward(wt, hm, cm, cn, ws, kf if kf is not None else wt.new_zeros(0))
             ctx.has_keep = kf is not None
-            return out, hm[T], cm[T]                       # no mask after the last step: the final state itself
+            ctx.gemm_dtype = gd
+            return out.to(gd), hm[T], cm[T]                # no mask after the last step: the final state itself (c in float32)
         h, c = h0, c0
         hs, cs, cn, wss, outs = [], [], [], [], []
         for t in range(T):
@@ -145,25 +152,27 @@ class _LstmSeq(torch.autograd.Function):
             from .. import native
             lib = native.load()
             T, G, N, H = cn.shape
-            dG = torch.empty((T, G, N, 4 * H), dtype=cn.dtype, device=cn.device)
-            dcm = torch.empty((2, G, N, H), dtype=cn.dtype, device=cn.device)      # ping-pong: gradient of cm[t]
+            gd, f32 = ctx.gemm_dtype, torch.float32
+            dG = torch.empty((T, G, N, 4 * H), dtype=gd, device=cn.device)
+            dGf = torch.empty((G, N, 4 * H), dtype=f32, device=cn.device)          # (the cell's gradients in float32, as its forward pass)
+            dcm = torch.empty((2, G, N, H), dtype=f32, device=cn.device)           # ping-pong: gradient of cm[t]
             st = C.c_void_p(torch.cuda.current_stream(cn.device).cuda_stream)
             p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-            bf = int(cn.dtype == torch.bfloat16)
-            dout = dout.contiguous()
-            dhm = None if dhT is None else dhT.contiguous()       # gradient of hm[t+1] (the final state at t = T-1)
-            dcn = None if dcT is None else dcT.contiguous()
+            dout = dout.float().contiguous()
+            dhm = None if dhT is None else dhT.float().contiguous()      # gradient of hm[t+1] (the final state at t = T-1)
+            dcn = None if dcT is None else dcT.float().contiguous()
             for t in range(T - 1, -1, -1):
                 kn = p(keep[t + 1]) if (ctx.has_keep and t + 1 < T) else None
-                lib.check(lib.L.myo_lstm_cell_bwd(p(dout[t]), p(dhm), p(dcn), kn, p(cs[t]), p(cn[t]), p(wss[t]), G * N, N, H, bf,
-                                                  p(dG[t]), p(dcm[t & 1]), st))
-                dhm, dcn = torch.bmm(dG[t], wtt), dcm[t & 1]
+                lib.check(lib.L.myo_lstm_cell_bwd(p(dout[t]), p(dhm), p(dcn), kn, p(cs[t]), p(cn[t]), p(wss[t]), G * N, N, H, 0,
+                                                  p(dGf), p(dcm[t & 1]), st))
+                dG[t].copy_(dGf)
+                dhm, dcn = torch.bmm(dG[t], wtt).float(), dcm[t & 1]
             if ctx.has_keep:
                 k0 = keep[0].view(1, N, 1).to(dhm.dtype)
                 dhm, dcn = dhm * k0, dcn * k0
             hm_in = hs[:T].transpose(0, 1).reshape(G, T * N, H)
             dwt = torch.bmm(hm_in.transpose(1, 2), dG.transpose(0, 1).reshape(G, T * N, 4 * H))
-            return dG, dwt, dhm, dcn.clone(), None
+            return dG, dwt, dhm.to(gd), dcn.clone(), None
         T, G, N, H = hs.shape
         dh = dhT if dhT is not None else torch.zeros_like(hs[0])
         dc = dcT if dcT is not None else torch.zeros_like(hs[0])
@@ -289,20 +298,21 @@ class ActorCriticPolicy(nn.Module):
         T, N = x.shape[0], x.shape[1]
         gx = _linear(x.reshape(T * N, -1), w_ih, b_ih + b_hh).view(T, N, -1)
         keep = None if starts is None else (1.0 - starts.to(gx.dtype)).unsqueeze(-1)
-        h, c = h.to(gx.dtype), c.to(gx.dtype)
+        h, c = h.to(gx.dtype), c.float()               # (the cell state stays float32 under autocast: see _LstmSeq)
         fused = x.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
         wt = w_hh.t().to(gx.dtype)
         outs = []
         for t in range(T):
             if keep is not None:
-                h, c = h * keep[t], c * keep[t]
-            gh = (h @ wt).to(gx.dtype)
+                h, c = h * keep[t], c * keep[t].float()
+            gh = (h @ wt).float()
             if fused:
-                h, c, _ = torch.ops.aten._thnn_fused_lstm_cell(gx[t], gh, c, None, None)
+                h, c, _ = torch.ops.aten._thnn_fused_lstm_cell(gx[t].float(), gh, c, None, None)
             else:
-                i, f, g, o = (gx[t] + gh).chunk(4, dim=-1)
+                i, f, g, o = (gx[t].float() + gh).chunk(4, dim=-1)
                 c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
                 h = torch.sigmoid(o) * torch.tanh(c)
+            h = h.to(gx.dtype)
             outs.append(h)
         return torch.stack(outs, 0), h.unsqueeze(0).to(st_dtype), c.unsqueeze(0).to(st_dtype)
 
@@ -320,7 +330,7 @@ class ActorCriticPolicy(nn.Module):
         gx = gx.view(T, N, 2, 4 * H).transpose(1, 2).contiguous()                     # [T, 2, N, 4H]
         wt = torch.stack([la.weight_hh_l0.t(), lc.weight_hh_l0.t()], 0)               # [2, H, 4H]
         h = torch.stack([ha[0], hc[0]], 0).to(gx.dtype)                               # [2, N, H]
-        c = torch.stack([ca[0], cc[0]], 0).to(gx.dtype)
+        c = torch.stack([ca[0], cc[0]], 0).float()                                    # (the cell state stays float32 under autocast: see _LstmSeq)
         keep = None if starts is None else (1.0 - starts.to(gx.dtype)).view(T, 1, N, 1)
         fused = x.is_cuda and hasattr(torch.ops.aten, "_thnn_fused_lstm_cell")
         wt = wt.to(gx.dtype)
@@ -331,16 +341,17 @@ class ActorCriticPolicy(nn.Module):
         outs = []
         for t in range(T):
             if keep is not None:
-                h, c = h * keep[t], c * keep[t]
-            gh = torch.bmm(h, wt).to(gx.dtype)                                        # [2, N, 4H]
+                h, c = h * keep[t], c * keep[t].float()
+            gh = torch.bmm(h, wt).float()                                             # [2, N, 4H]
             if fused:
-                h2, c2, _ = torch.ops.aten._thnn_fused_lstm_cell(gx[t].reshape(2 * N, 4 * H), gh.reshape(2 * N, 4 * H),
+                h2, c2, _ = torch.ops.aten._thnn_fused_lstm_cell(gx[t].float().reshape(2 * N, 4 * H), gh.reshape(2 * N, 4 * H),
                                                                  c.reshape(2 * N, H), None, None)
                 h, c = h2.view(2, N, H), c2.view(2, N, H)
             else:
-                i, f, g, o = (gx[t] + gh).chunk(4, dim=-1)
+                i, f, g, o = (gx[t].float() + gh).chunk(4, dim=-1)
                 c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
                 h = torch.sigmoid(o) * torch.tanh(c)
+            h = h.to(gx.dtype)
             outs.append(h)
         out = torch.stack(outs, 0)                                                     # [T, 2, N, H]
         return out[:, 0], out[:, 1], (fin(h, 0), fin(c, 0), fin(h, 1), fin(c, 1))

@@ -235,13 +235,19 @@ class PPO:
         rdesc = fused.rollout_desc(self._obs_s, seed, self._draw, self._t_idx, self.obs_buf, self.act_buf, self.val_buf,
                                    self.logp_buf, self._clip_s) if os.environ.get("MYO_ROLLOUT_GEMM") != "1" else None
         if recurrent:
-            # LSTM state after the previous step, (actor, critic) stacked, bf16 as the update computes in; the masked copies that
-            # enter the step; the step's pre-activations / gates are scratch
+            # LSTM state after the previous step, (actor, critic) stacked; the masked copies that enter the step; the step's
+            # pre-activations / gates are scratch.  h is bf16 (the matrix cores' operand, as the update computes it); the CELL state is
+            # carried in float32 (_cs32 / _cm32) — what stock nn.LSTM carries (/root/reference/src/main_reorient.py:53-71), what
+            # policy.predict carries in an evaluation, and what a bf16 round trip per step would erode over a 300-step episode.  The
+            # bf16 copy _cs is what the step leaves for the bootstrap buffers (and what the cell-kernel fallback computes in).
             H, bf = self.policy.hidden, torch.bfloat16
             self._hs, self._cs = torch.zeros((2, N, H), device=d, dtype=bf), torch.zeros((2, N, H), device=d, dtype=bf)
+            self._cs32 = torch.zeros((2, N, H), device=d, dtype=torch.float32)
             self._hs[0].copy_(self._state[0][0]); self._hs[1].copy_(self._state[2][0])
-            self._cs[0].copy_(self._state[1][0]); self._cs[1].copy_(self._state[3][0])
+            self._cs32[0].copy_(self._state[1][0]); self._cs32[1].copy_(self._state[3][0])
+            self._cs.copy_(self._cs32)
             self._hm, self._cm = torch.empty_like(self._hs), torch.empty_like(self._cs)
+            self._cm32 = torch.empty_like(self._cs32)
             self._lat, self._cn = torch.empty_like(self._hs), torch.empty_like(self._hs)
             self._ws = torch.empty((2, N, 4 * H), device=d, dtype=bf)
             self._bsum = torch.zeros((2, 1, 4 * H), device=d, dtype=bf)
@@ -275,17 +281,20 @@ class PPO:
             lib.check(lib.L.myo_rollout_policy_input(p(self._obs_s), N, O, p(self.obs_buf), p(self._x2), 2, p(self._t_idx), st))
             keep = torch.rsub(self._starts_s, 1.0).view(1, N, 1)            # state zeroed where an episode starts
             torch.mul(self._hs, keep, out=self._hm)
-            torch.mul(self._cs, keep, out=self._cm)
+            torch.mul(self._cs32, keep, out=self._cm32)
             if fused.step_kernels:       # recurrent product + cell in one launch; nothing kept for a backward pass
                 # one projection GEMM for both LSTMs with the bias in its epilogue: row n = [actor 4H | critic 4H], read in place
                 gx = torch.addmm(self._bsum.view(8 * H), self._x2[0], Lw["wihh"].view(8 * H, O).t())
-                lib.check(lib.L.myo_lstm_step_fwd(p(gx), 4 * H, 8 * H, p(self._hm), p(self._cm), p(Lw["whhh"]), None, 2, N, H,
-                                                  p(self._lat), N * H, p(self._hs), p(self._cs), None, None, st))
-            else:
+                # (cell state in and out in float32; the bf16 copy beside it for the bootstrap buffers)
+                lib.check(lib.L.myo_lstm_step_fwd(p(gx), 4 * H, 8 * H, p(self._hm), None, p(Lw["whhh"]), None, 2, N, H,
+                                                  p(self._lat), N * H, p(self._hs), p(self._cs), None, None, p(self._cm32), p(self._cs32), st))
+            else:                        # (hidden sizes without a fused time-step kernel: GEMM + cell kernel, cell state through bf16)
+                self._cm.copy_(self._cm32)
                 gx = torch.baddbmm(self._bsum, self._x2, Lw["wihh"].transpose(1, 2))
                 gh = torch.bmm(self._hm, Lw["whhh"].transpose(1, 2))
                 lib.check(lib.L.myo_lstm_cell_fwd(p(gx), p(gh), p(self._cm), None, 2 * N, N, H, 1, p(self._lat), p(self._hs), p(self._cs),
                                                   p(self._cn), p(self._ws), st))
+                self._cs32.copy_(self._cs)
             t64 = self._t_idx.long()
             self.crit_h_buf.index_copy_(0, t64, self._hs[1:2])
             self.crit_c_buf.index_copy_(0, t64, self._cs[1:2])
@@ -347,7 +356,7 @@ class PPO:
         # the env's static output buffers as they are, and everything it touches is put back afterwards, so the
         # recorded rollout starts exactly at the reset
         rawout = (raw._obs, raw._rew, raw._done, raw._trunc, raw._term, raw._comps, raw._ep)
-        restore = (self._obs_s, self._starts_s, vec.obs_rms.buf, vec.ret_rms.buf, vec.returns) + ((self._hs, self._cs) if recurrent else ())
+        restore = (self._obs_s, self._starts_s, vec.obs_rms.buf, vec.ret_rms.buf, vec.returns) + ((self._hs, self._cs, self._cs32) if recurrent else ())
         keep = [t.clone() for t in restore]
         if recurrent:
             self._refresh_rollout_lstm()
@@ -386,7 +395,7 @@ class PPO:
     def _native_state(self):
         """(h_pi, c_pi, h_vf, c_vf) float32 [1,N,H] from the native recurrent rollout's stacked state."""
         f = lambda z, k: z[k:k + 1].float()
-        return (f(self._hs, 0), f(self._cs, 0), f(self._hs, 1), f(self._cs, 1))
+        return (f(self._hs, 0), f(self._cs32, 0).clone(), f(self._hs, 1), f(self._cs32, 1).clone())
 
     def _init_rollout_graphs(self):
         """Per step: graph A (policy inference + sampling) -> eager myo_batch_step (so its HIP events can

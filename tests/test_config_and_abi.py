@@ -142,9 +142,9 @@ def test_c_abi_argument_checks(emu_lib):
         (L.myo_rollout_advance, (null, 4, null, null)),
         (L.myo_lstm_cell_fwd, (null,) * 4 + (8, 4, 16, 0) + (null,) * 6),
         (L.myo_lstm_cell_bwd, (null,) * 7 + (8, 4, 16, 0) + (null,) * 3),
-        (L.myo_lstm_step_fwd, (null, 0, 0) + (null,) * 4 + (2, 16, 32, null, 0) + (null,) * 5),
+        (L.myo_lstm_step_fwd, (null, 0, 0) + (null,) * 4 + (2, 16, 32, null, 0) + (null,) * 7),
         (L.myo_lstm_step_bwd, (null, 0) + (null,) * 7 + (2, 16, 32) + (null,) * 3),
-        (L.myo_lstm_seq_fwd, (null, 0, 0, 0) + (null,) * 4 + (2, 16, 128, 4, 1, null, 0, 0) + (null,) * 3),
+        (L.myo_lstm_seq_fwd, (null, 0, 0, 0) + (null,) * 4 + (2, 16, 128, 4, 1, null, 0, 0) + (null,) * 4),
         (L.myo_lstm_seq_bwd, (null, 0, 0) + (null,) * 5 + (2, 16, 128, 4, 1) + (null,) * 2),
     ]
     for fn, args in checks:

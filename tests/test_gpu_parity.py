@@ -1454,7 +1454,7 @@ def test_lstm_step_kernels_match_gemm_plus_cell(hip_lib, H, N):
     hm, cm, cn = (torch.empty((G, N, H), device=dev, dtype=bf) for _ in range(3))
     ws = torch.empty((G, N, 4 * H), device=dev, dtype=bf)
     hip_lib.check(L.myo_lstm_step_fwd(p(gx_all), 4 * H, G * 4 * H, p(hp), p(cp), p(whh), p(keep), G, N, H, p(out_all[:, 1]), 3 * N * H,
-                                      p(hm), p(cm), p(cn), p(ws), None))
+                                      p(hm), p(cm), p(cn), p(ws), None, None, None))
     torch.cuda.synchronize()
     a = gx_all.float().view(N, G, 4 * H).transpose(0, 1) + torch.bmm(hp.float(), whh.float().transpose(1, 2))
     i, f, g, o = torch.sigmoid(a[..., :H]), torch.sigmoid(a[..., H:2 * H]), torch.tanh(a[..., 2 * H:3 * H]), torch.sigmoid(a[..., 3 * H:])
@@ -1468,9 +1468,23 @@ def test_lstm_step_kernels_match_gemm_plus_cell(hip_lib, H, N):
     # rollout form: no c_new / ws, no mask
     hm2, cm2 = torch.empty_like(hm), torch.empty_like(cm)
     out2 = torch.empty((G, N, H), device=dev, dtype=bf)
-    hip_lib.check(L.myo_lstm_step_fwd(p(gx_all), 4 * H, G * 4 * H, p(hp), p(cp), p(whh), None, G, N, H, p(out2), N * H, p(hm2), p(cm2), None, None, None))
+    hip_lib.check(L.myo_lstm_step_fwd(p(gx_all), 4 * H, G * 4 * H, p(hp), p(cp), p(whh), None, G, N, H, p(out2), N * H, p(hm2), p(cm2), None, None, None, None, None))
     torch.cuda.synchronize()
     assert torch.equal(out2, out_all[:, 1].contiguous()) and torch.equal(hm2, out2)
+    # the cell state in float32, in and out (what the rollout carries through an episode): no bf16 rounding on c at all
+    cp32 = (cp.float() + 1e-3 * torch.randn_like(cp.float())).contiguous()          # not representable in bf16
+    cm32, hm3, out3 = torch.empty_like(cp32), torch.empty_like(hm), torch.empty((G, N, H), device=dev, dtype=bf)
+    hip_lib.check(L.myo_lstm_step_fwd(p(gx_all), 4 * H, G * 4 * H, p(hp), None, p(whh), p(keep), G, N, H, p(out3), N * H, p(hm3), None, None, None,
+                                      p(cp32), p(cm32), None))
+    torch.cuda.synchronize()
+    c32 = f * cp32 + i * g
+    assert float((cm32 - c32 * k).abs().max()) <= 2e-3 * (1 + float(c32.abs().max()))        # (gate activations come from bf16 gx / MFMA sums: ~1e-3)
+    # ... and exactly the float32 value: the bf16 output beside it is its rounding
+    cm3b = torch.empty_like(cm)
+    hip_lib.check(L.myo_lstm_step_fwd(p(gx_all), 4 * H, G * 4 * H, p(hp), None, p(whh), p(keep), G, N, H, p(out3), N * H, p(hm3), p(cm3b), None, None,
+                                      p(cp32), p(cm32), None))
+    torch.cuda.synchronize()
+    assert torch.equal(cm3b, cm32.to(bf))
     # backward from the kernel's own saved tensors
     dgn, dcn_ = mk(G, N, 4 * H, sc=0.3), mk(G, N, H)
     dout_all = mk(G, 2, N, H)                                    # gradient of out_h in slice [:, 1]
@@ -1490,7 +1504,7 @@ def test_lstm_step_kernels_match_gemm_plus_cell(hip_lib, H, N):
     torch.cuda.synchronize()
     dct0 = dout_all[:, 1].float() * wo * (1 - tc * tc)
     assert float((dcp.float() - dct0 * wf).abs().max()) <= tol * (1 + float((dct0 * wf).abs().max()))
-    assert hip_lib.L.myo_lstm_step_supported(48) == 0 and hip_lib.L.myo_lstm_step_fwd(p(gx_all), 0, 0, p(hp), p(cp), p(whh), None, G, N, 48, p(out2), 0, p(hm2), p(cm2), None, None, None) == -2
+    assert hip_lib.L.myo_lstm_step_supported(48) == 0 and hip_lib.L.myo_lstm_step_fwd(p(gx_all), 0, 0, p(hp), p(cp), p(whh), None, G, N, 48, p(out2), 0, p(hm2), p(cm2), None, None, None, None, None) == -2
 
 
 @pytest.mark.parametrize("H,N,T,rs", [(256, 64, 9, 1), (128, 48, 7, 1), (256, 512, 33, 4), (256, 48, 5, 2), (128, 32, 6, 2)])
@@ -1521,12 +1535,12 @@ def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T, rs):
     hm_a, cm_a, cn_a, ws_a, lat_a = state()
     for t in range(T):
         hip_lib.check(L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm_a[t]), p(cm_a[t]), p(whh), p(keep[t + 1]) if t + 1 < T else None, G, N, H,
-                                          p(lat_a[:, t]), T * N * H, p(hm_a[t + 1]), p(cm_a[t + 1]), p(cn_a[t]), p(ws_a[t]), None))
+                                          p(lat_a[:, t]), T * N * H, p(hm_a[t + 1]), p(cm_a[t + 1]), p(cn_a[t]), p(ws_a[t]), None, None, None))
     from myochallenge_amd.rl.fused_lstm import lstm_seq_rows, lstm_seq_weights
     w_frag, wt_frag = lstm_seq_weights(whh, rs)        # (rs: a workgroup owns 16 / rs of the rows)
     hm_b, cm_b, cn_b, ws_b, lat_b = state()
     hip_lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(w_frag), p(keep), G, N, H, T, rs, p(lat_b), T * N * H, N * H,
-                                     p(cn_b), p(ws_b), None))
+                                     p(cn_b), p(ws_b), None, None))
     torch.cuda.synchronize()
     # the two paths round to bf16 at the same places; they differ by the order of the fp32 sums over K and by tanh's last bits, i.e. by
     # an occasional bf16 ulp that the recurrence carries on: a few ulps of the largest entry at most, ~1e-3 of it on average
@@ -1565,11 +1579,37 @@ def test_lstm_seq_kernels_match_step_kernels(hip_lib, H, N, T, rs):
     # unsupported sizes are refused, not mis-run
     assert L.myo_lstm_seq_supported(64) == 0 and L.myo_lstm_seq_supported(256) == 1
     assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N, 64, T, rs, p(lat_b), T * N * H, N * H, p(cn_b),
-                              p(ws_b), None) == -2
+                              p(ws_b), None, None) == -2
     assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(whh), p(keep), G, N - 1, H, T, rs, p(lat_b), T * N * H, N * H, p(cn_b),
-                              p(ws_b), None) == -1
+                              p(ws_b), None, None) == -1
     assert L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_b), p(cm_b), p(w_frag), p(keep), G, N, 128, T, 4, p(lat_b), T * N * H, N * H, p(cn_b),
-                              p(ws_b), None) == -2
+                              p(ws_b), None, None) == -2
+    # the CELL state carried in float32 (c0_32 / c_prev32 -> cm_next32: what the rollout and the update do): the sequence kernel
+    # against the step kernels' float32 chain, and both against the float32 statement of the recurrence with an unrounded c
+    c0f = (c0.float() + 1e-3 * torch.randn(G, N, H, device=dev)).contiguous()
+    hm_c, cm_c, cn_c, ws_c, lat_c = state()
+    c32 = [c0f.clone(), torch.empty_like(c0f)]
+    for t in range(T):
+        hip_lib.check(L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm_c[t]), None, p(whh), p(keep[t + 1]) if t + 1 < T else None, G, N, H,
+                                          p(lat_c[:, t]), T * N * H, p(hm_c[t + 1]), p(cm_c[t + 1]), p(cn_c[t]), p(ws_c[t]), p(c32[t & 1]), p(c32[(t + 1) & 1]), None))
+    hm_d, cm_d, cn_d, ws_d, lat_d = state()
+    hip_lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm_d), p(cm_d), p(w_frag), p(keep), G, N, H, T, rs, p(lat_d), T * N * H, N * H,
+                                     p(cn_d), p(ws_d), p(c0f), None))
+    torch.cuda.synchronize()
+    for name, a, b in (("lat32", lat_c, lat_d), ("hm32", hm_c, hm_d), ("cm32", cm_c[1:], lstm_seq_rows(cm_d[1:], N, H, 1, rs)),
+                       ("cn32", cn_c, lstm_seq_rows(cn_d, N, H, 1, rs))):
+        close(b, a, name)
+    hf, cf = h0.float(), c0f.clone()                              # (h re-rounded to bf16 every step, as the kernels' MFMA operand is; c never)
+    for t in range(T):
+        a_ = gx[t].float().transpose(0, 1) + torch.bmm(hf, whh.float().transpose(1, 2))
+        i_, f_, g_, o_ = torch.sigmoid(a_[..., :H]), torch.sigmoid(a_[..., H:2 * H]), torch.tanh(a_[..., 2 * H:3 * H]), torch.sigmoid(a_[..., 3 * H:])
+        cf = f_ * cf + i_ * g_
+        hf = (o_ * torch.tanh(cf)).to(bf).float()
+        if t + 1 < T:
+            kk = keep[t + 1].view(1, N, 1)
+            hf, cf = hf * kk, cf * kk
+    d32 = (c32[T & 1] - cf).abs()
+    assert float(d32.max()) <= 3e-2 * (1 + float(cf.abs().max())) and float(d32.mean()) <= 1.5e-3 * (1 + float(cf.abs().max())), (float(d32.max()), float(d32.mean()))
 
 
 def test_gsde_sampling_kernel_matches_torch(hip_lib):

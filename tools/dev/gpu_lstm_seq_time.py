@@ -32,7 +32,7 @@ dG, dcm = torch.zeros((T, G, N, H4), device=dev, dtype=bf), torch.zeros((2, G, N
 def steps_fwd(st):
     for t in range(T):
         lib.check(L.myo_lstm_step_fwd(p(gx[t]), H4, G * H4, p(hm[t]), p(cm[t]), p(whh), p(keep[t + 1]) if t + 1 < T else None, G, N, H,
-                                      p(lat[:, t]), T * N * H, p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+                                      p(lat[:, t]), T * N * H, p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), None, None, st))
 
 
 def steps_bwd(st):
@@ -43,7 +43,7 @@ def steps_bwd(st):
 
 
 def seq_fwd(st):
-    lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, N, H, T, RS, p(lat), T * N * H, N * H, p(cn), p(ws), st))
+    lib.check(L.myo_lstm_seq_fwd(p(gx), N * G * H4, H4, G * H4, p(hm), p(cm), p(w_frag), p(keep), G, N, H, T, RS, p(lat), T * N * H, N * H, p(cn), p(ws), None, st))
 
 
 def seq_bwd(st):

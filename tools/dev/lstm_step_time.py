@@ -23,12 +23,12 @@ def fwd_fused():
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for t in range(T):
         lib.check(L.myo_lstm_step_fwd(p(gx[t]), 4 * H, G * 4 * H, p(hm[t]), p(cm[t]), p(whh), p(keep[t]), G, m, H, p(lat[:, t]), T * m * H,
-                                      p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+                                      p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), None, None, st))
 def fwd_pair():
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for t in range(T):
         gh = torch.bmm(hm[t], wt)
-        lib.check(L.myo_lstm_cell_fwd(p(gxs[t]), p(gh), p(cm[t]), p(keep[t]), G * m, m, H, 1, p(out[t]), p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), st))
+        lib.check(L.myo_lstm_cell_fwd(p(gxs[t]), p(gh), p(cm[t]), p(keep[t]), G * m, m, H, 1, p(out[t]), p(hm[t + 1]), p(cm[t + 1]), p(cn[t]), p(ws[t]), None, None, st))
 def bwd_fused():
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     for t in range(T - 1, -1, -1):

@@ -19,7 +19,8 @@
 #define MYO_NCON_MAX 24   // contacts (base capacity of the scratch: Scratch<T, NC = MYO_NCON_MAX>)
 #define MYO_NCON_F64 16   // contacts, base capacity of the fp64 stepper's scratch (the bench workload peaks at 11 - 12 contacts; a substep with more than the capacity drops the surplus and is counted, myo_batch_health)
 #define MYO_NREC_F64 22   // contact record slots of the fp64 base scratch (its 56 + 4 * 16 constraint rows are shared between limit and contact rows)
-#define MYO_NCON_BIG 34   // contact slots, scratch of models with extended collision pairs / a die / condim 4, 6 pairs (56 + 4 * 34 = 192 rows, three per lane)
+#define MYO_NCON_BIG 48   // contact slots, scratch of models with extended collision pairs / a die / condim 4, 6 pairs (56 + 4 * 48 = 248 rows, four per lane).
+                          // 34 until round 5: config E's rollouts asked for up to 45 slots (myo_batch_health [3]) and the surplus — penetrating, active contacts — was dropped
 #define MYO_CS_MAX 16     // dofs one contact can move
 #define MYO_NLIM_MAX 56   // joint-limit + tendon-limit rows
 #define MYO_NEFC_MAX (MYO_NLIM_MAX + 4 * MYO_NCON_MAX)

@@ -197,7 +197,7 @@ struct Scratch : ScratchPoses<T> {
   // later phase in program order.  (A first cut moved the limit rows' D / ids and the rows' active flags instead — the solver's own
   // arrays: 2.98 -> 2.80 ms for the die's k_step where a 29-slot capacity experiment had said 2.62.)
   static constexpr bool SPILL = sizeof(T) == sizeof(HP) && NC >= MYO_NCON_BIG;
-  static_assert(NC >= MYO_NCON_F64 && MYO_NLIM_MAX + 4 * NC <= 192, "contact capacity: at least the smallest base (the aliases below are sized for it), at most three constraint rows per lane");
+  static_assert(NC >= MYO_NCON_F64 && MYO_NLIM_MAX + 4 * NC <= 256, "contact capacity: at least the smallest base (the aliases below are sized for it), at most four constraint rows per lane");
   // ---- state (HP in every build)
   HP qpos[MYO_NQ_MAX], qvel[MYO_NV_MAX], act[SPILL ? 1 : MYO_NU_MAX];      // (act: S_ACT)
   HP time;
@@ -3339,12 +3339,15 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     // exact 1-D minimisation of the convex piecewise-quadratic: safeguarded Newton on p'(alpha)
     T alpha = 0, lo = 0, hi = -1;
     // each lane keeps its (<= 3) rows' jar, jv and D in registers for the whole line search
-    static_assert(MYO_NLIM_MAX + 4 * NC <= 192, "three rows per lane");
-    LANE_VAR(T, ls_x0); LANE_VAR(T, ls_x1); LANE_VAR(T, ls_x2);
-    LANE_VAR(T, ls_v0); LANE_VAR(T, ls_v1); LANE_VAR(T, ls_v2);
-    LANE_VAR(T, ls_d0); LANE_VAR(T, ls_d1); LANE_VAR(T, ls_d2);
+    static_assert(MYO_NLIM_MAX + 4 * NC <= 256, "four rows per lane");
+    constexpr bool LS4 = MYO_NLIM_MAX + 4 * NC > 192;       // (the 48-slot scratch: a fourth row per lane)
+    LANE_VAR(T, ls_x0); LANE_VAR(T, ls_x1); LANE_VAR(T, ls_x2); LANE_VAR(T, ls_x3);
+    LANE_VAR(T, ls_v0); LANE_VAR(T, ls_v1); LANE_VAR(T, ls_v2); LANE_VAR(T, ls_v3);
+    LANE_VAR(T, ls_d0); LANE_VAR(T, ls_d1); LANE_VAR(T, ls_d2); LANE_VAR(T, ls_d3);
     PHASE {
-      const int r0 = lane, r1 = lane + 64, r2 = lane + 128;
+      const int r0 = lane, r1 = lane + 64, r2 = lane + 128, r3 = lane + 192;
+      LV(ls_x3) = (LS4 && r3 < nefc) ? s.efc_jar[LS4 ? r3 : 0] : (T)0; LV(ls_v3) = (LS4 && r3 < nefc) ? s.efc_jv[LS4 ? r3 : 0] : (T)0;
+      LV(ls_d3) = (LS4 && r3 < nefc) ? row_D(s, LS4 ? r3 : 0, nlim) : (T)0;
       LV(ls_x0) = r0 < nefc ? s.efc_jar[r0] : (T)0; LV(ls_v0) = r0 < nefc ? s.efc_jv[r0] : (T)0;
       LV(ls_d0) = r0 < nefc ? row_D(s, r0, nlim) : (T)0;
       LV(ls_x1) = r1 < nefc ? s.efc_jar[r1] : (T)0; LV(ls_v1) = r1 < nefc ? s.efc_jv[r1] : (T)0;
@@ -3359,6 +3362,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         if (xa < 0) { _e1 += LV(ls_d0) * xa * LV(ls_v0); _e2 += LV(ls_d0) * LV(ls_v0) * LV(ls_v0); }
         if (xb < 0) { _e1 += LV(ls_d1) * xb * LV(ls_v1); _e2 += LV(ls_d1) * LV(ls_v1) * LV(ls_v1); }
         if (xc < 0) { _e1 += LV(ls_d2) * xc * LV(ls_v2); _e2 += LV(ls_d2) * LV(ls_v2) * LV(ls_v2); }
+        if constexpr (LS4) { const T xd = LV(ls_x3) + alpha * LV(ls_v3); if (xd < 0) { _e1 += LV(ls_d3) * xd * LV(ls_v3); _e2 += LV(ls_d3) * LV(ls_v3) * LV(ls_v3); } }
       });
       const T d1 = 2 * alpha * q2 + q1 + e1, d2 = 2 * q2 + e2;
 #ifdef MYO_EMU_DEBUG

@@ -276,6 +276,74 @@ def case_contact_overflow(lib, dtype):
         b.close()
 
 
+def many_contacts_model():
+    """Three rafts of 13 spheres each on the ground plane (39 contacts) and a cylinder lying beside them (an EXTENDED pair: the model gets
+    the 48-slot scratch): more contact slots than the 34 the big scratch held until round 5, fewer than the 48 it holds now."""
+    B = _Builder()
+    B.add_geom("plane", 0, 0, (0, 0, 0), collide=1)
+    for r in range(3):
+        b = B.add_body("raft%d" % r, 0, (0.5 * r, 0.0, 0.0195), mass=0.2 + 0.05 * r, inertia=(2e-4, 3e-4, 4e-4))
+        B.add_joint("raft%d_free" % r, b, 0)
+        for k in range(13):
+            B.add_geom("s%d_%d" % (r, k), b, SPH, (0.02,), (0.05 * (k % 4) - 0.075, 0.05 * (k // 4) - 0.075, 0.0), collide=1)
+    b = B.add_body("log", 0, (2.0, 0.0, 0.0295), mass=0.3, inertia=(3e-4, 3e-4, 2e-4))
+    B.add_joint("log_free", b, 0)
+    c, sn = np.cos(np.pi / 4), np.sin(np.pi / 4)
+    B.add_geom("log_geom", b, CYL, (0.03, 0.08), (0, 0, 0), quat=(c, 0, sn, 0), collide=1)          # axis along x: lying on its side
+    m = B.finish()
+    for g in range(len(m.names["geom"])):
+        m.arrays["geom_contype"][g], m.arrays["geom_conaffinity"][g] = (1, 0) if g == 0 else (2, 1)
+    m.arrays["geom_margin"][:] = 0.002
+    set_const(m)
+    return m
+
+
+def case_many_contacts(lib, dtype, tol):
+    """a state with MORE than 34 contact slots steps like the oracle (which holds 64) — no slot is dropped, the counters
+    stay at zero, qacc of the first forward pass and the state after 40 substeps agree."""
+    mem = Mem(lib)
+    m = many_contacts_model()
+    cm = compile_model(m)
+    om = OracleModel(cm.to_blob())
+    q0 = cm_qpos0(cm)
+    d = OracleData(om)
+    d.qpos[:] = q0
+    d.forward()
+    assert 34 < d.ncon <= 48, d.ncon
+    get, b2 = forward_dump(lib, mem, cm, q0, np.zeros(cm.size("nv")), np.zeros(0), np.zeros(0), dtype)
+    cnt = get("counts", 4)
+    assert (int(cnt[0]), int(cnt[1])) == (d.ncon, d.nefc), (cnt, d.ncon, d.nefc)
+    qa = np.array(d.qacc)
+    assert rel_err(get("qacc", qa.size), qa) < tol, rel_err(get("qacc", qa.size), qa)
+    assert b2.health()["contact_overflows"] == 0
+    b2.close()
+    n = 2
+    b = native.Batch(native.Model(cm, lib), None, n, 0, 0, dtype)
+    assert b.lds_bytes > 23040 or dtype != native.MYO_F64            # (the 48-slot scratch)
+    b.set_state(mem.arr(np.tile(q0, (n, 1))), mem.zeros((n, om.nv)), mem.zeros((n, 0)), mem.zeros(n))
+    qp, qv = mem.zeros((n, om.nq)), mem.zeros((n, om.nv))
+    most = 0
+    for i in range(40):
+        d.step()
+        most = max(most, d.ncon)
+        b.physics_step(None, 1)
+    b.get_state(qp, qv)
+    assert rel_err(mem.host(qp)[1], d.qpos) < tol and np.abs(mem.host(qv)[1] - d.qvel).max() < tol * max(1.0, np.abs(d.qvel).max())
+    assert most > 34 and b.health() == {"protocol_errors": 0, "contact_overflows": 0, "limit_row_overflows": 0, "contact_slots_wanted": 0}, (most, b.health())
+    b.close()
+
+
+def test_more_than_34_contact_slots_on_emulation(emu_lib):
+    case_many_contacts(emu_lib, native.MYO_F64, 1e-9)
+    case_many_contacts(emu_lib, native.MYO_MIXED, 1e-4)
+
+
+@pytest.mark.gpu
+def test_more_than_34_contact_slots_on_gpu(hip_lib):
+    case_many_contacts(hip_lib, native.MYO_F64, 1e-9)
+    case_many_contacts(hip_lib, native.MYO_MIXED, 1e-4)
+
+
 def cm_qpos0(cm):
     return np.asarray(cm.fields["qpos0"], dtype=np.float64).copy()
 

@@ -414,7 +414,7 @@ def test_fused_recurrent_step_matches_autograd(hip_lib, monkeypatch, arch, hidde
         #  float32 autograd yardstick says the deviation is the fused path's (tools/dev/gpu_gsde_grad_check.py prints all three, also
         #  with MYO_LSTM_C32=0: the same numbers, so it is the data, not the cell state's precision).  gSDE is not in BASELINE.json's
         #  configs (config E is Gaussian); recorded as open in DESIGN.md §10, the bound for those parameters is what was measured.)
-        actor_path = sde and len(arch) > 0 and (n.startswith("mlp_extractor.policy_net") or (n.startswith("lstm_actor") and "hh" not in n))
+        actor_path = sde and len(arch) > 0 and (n.startswith("mlp_extractor.policy_net") or (n.startswith("lstm_actor") and "weight_hh" not in n))
         assert cos > (0.94 if actor_path else (0.99 if sde else 0.995)) and rel < (0.35 if actor_path else (0.15 if sde else 0.1)), (n, cos, rel, float(gb.norm()))
     # the captured graph replays the same step: one update moves every parameter group and stays finite
     before = [p.detach().clone() for p in pol.parameters()]
@@ -565,8 +565,8 @@ def test_step_survives_another_batch_on_the_device(hip_lib):
 @pytest.mark.gpu
 def test_scratch_sizes_keep_their_workgroups_per_cu(hip_lib):
     """The LDS scratch of one env decides how many workgroups a CU holds (granule 1,280 B of 160 KB): the base scratches must stay at
-    eight per CU (<= 20,480 B) and the 34-slot fp64 scratch of the die at seven (<= 23,040 B; DESIGN.md §5 "Round 5" items 1 and 11) —
-    an array added to Scratch without a look at this costs 12 % of the step kernel."""
+    eight per CU (<= 20,480 B), the 48-slot scratch of the die (round 6: the capacity config E's rollouts ask for) at eight
+    for the mixed stepper and at six (<= 26,880 B) for fp64 — an array added to Scratch without a look at this costs 12 % of the step kernel."""
     from myochallenge_amd.envs.environment_factory import EnvironmentFactory
     sizes = {}
     for name, dtype in (("CustomMyoBaodingBallsP1", "f64"), ("CustomMyoBaodingBallsP1", "mixed"), ("CustomMyoReorientP1", "f64"), ("CustomMyoReorientP1", "mixed")):
@@ -574,7 +574,7 @@ def test_scratch_sizes_keep_their_workgroups_per_cu(hip_lib):
         sizes[(name, dtype)] = env.batch.lds_bytes
         env.close()
     assert sizes[("CustomMyoBaodingBallsP1", "f64")] <= 20480 and sizes[("CustomMyoBaodingBallsP1", "mixed")] <= 20480, sizes
-    assert sizes[("CustomMyoReorientP1", "mixed")] <= 20480 and sizes[("CustomMyoReorientP1", "f64")] <= 23040, sizes
+    assert sizes[("CustomMyoReorientP1", "mixed")] <= 20480 and sizes[("CustomMyoReorientP1", "f64")] <= 26880, sizes
 
 
 @pytest.mark.gpu

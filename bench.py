@@ -348,6 +348,9 @@ def main():
                "n_steps": cfg.n_steps, "batch_size": cfg.batch_size, "n_epochs": cfg.n_epochs, "lds_bytes": env.batch.lds_bytes, "health": health,
                "replicas_identical": replicas_identical, "replica_checksum_spread": replica_spread, "normalizer_sync": args.normalizer_sync if world > 1 else None,
                "graph_allreduce": bool(getattr(algo, "_allreduce_in_graph", False))}
+        if world > 1 and getattr(algo, "vn_allreduce_calls", 0):      # host wall of the per-step eager normaliser all-reduce (rl/ppo.py rollout_step)
+            res["normalizer_allreduce_ms_per_step"] = 1e3 * algo.vn_allreduce_seconds / algo.vn_allreduce_calls
+            res["normalizer_allreduce_calls"] = int(algo.vn_allreduce_calls)
         if skew:      # per-rank spread of the block times (own work, before the barrier): min / max over ranks, median block
             sk = sorted(skew, key=lambda x: x[1])[len(skew) // 2]
             res["rank_block_seconds_min_max"] = [sk[0], sk[1]]
@@ -386,8 +389,10 @@ def main():
                 variants["config_E_lstm256"] = run_config_e(4096, 128, 2, env_only_steps=0, reference_settings=True)
             except Exception as exc:      # noqa: BLE001
                 variants["config_E_lstm256"] = {"error": repr(exc)}
-            try:                          # ... and the light setting the earlier rounds quoted (mixed stepper, 32-step rollouts, 4 epochs)
-                variants["config_E_lstm256_light"] = run_config_e(4096, 32, 2, env_only_steps=0)
+            try:                          # ... and the light setting the earlier rounds quoted (32-step rollouts, 4 epochs) — on the fp64 stepper
+                # since round 6: the mixed stepper is not offered for the die (its local error on edge active sets is 3e-5 per env step,
+                # DESIGN.md §4)
+                variants["config_E_lstm256_light"] = run_config_e(4096, 32, 2, env_only_steps=0, dtype="f64")
             except Exception as exc:      # noqa: BLE001
                 variants["config_E_lstm256_light"] = {"error": repr(exc)}
 
@@ -489,10 +494,16 @@ def main():
             out["replica_checksum_spread"] = main_res["replica_checksum_spread"]
             out["config"]["normalizer_sync"] = main_res["normalizer_sync"]
             out["config"]["graph_allreduce"] = main_res["graph_allreduce"]
+        if main_res.get("normalizer_allreduce_ms_per_step") is not None:
+            out["normalizer_allreduce_ms_per_step"] = main_res["normalizer_allreduce_ms_per_step"]      # host wall per env step, rank 0 (whole run incl. warm-up)
         if main_res.get("rank_block_seconds_min_max"):
             out["rank_block_seconds_min_max"] = main_res["rank_block_seconds_min_max"]
         if any(main_res["health"].values()):
             print("bench.py: batch health counters are non-zero: %r" % (main_res["health"],), file=sys.stderr)
+        flagged = {k: v["health"] for k, v in (out.get("variants") or {}).items() if isinstance(v, dict) and isinstance(v.get("health"), dict) and any(v["health"].values())}
+        if flagged:      # (a variant's dropped contacts / protocol errors must not travel silently inside the line)
+            out["variants_with_nonzero_health"] = sorted(flagged)
+            print("bench.py: variants with non-zero batch health counters: %r" % (flagged,), file=sys.stderr)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))

@@ -91,7 +91,9 @@ int myo_model_from_blob(const void* blob, size_t nbytes, myo_model** out);
  * (`model_path=…/myo_hand_baoding.mjb`, /root/reference/src/envs/__init__.py:17,63).  The C reader (csrc/myo_mjb.h) decodes the
  * file, applies the feature checks and derives the static tables exactly as the Python route (mjb.load_mjb + model.compile_model
  * + myo_model_from_blob) does.  integrator: -1 keeps the model's, 0 Euler, 1 RK4.  unsupported_contacts: 0 = a model with
- * colliding geom pairs that have no narrow phase here is refused (MYO_E_UNSUPPORTED), 1 = compiled without those pairs. */
+ * colliding geom pairs that have no narrow phase here is refused (MYO_E_UNSUPPORTED), 1 = compiled without those pairs; | 2 = a model
+ * whose opt.solver is PGS / CG or that asks for noslip iterations is stepped with this stepper's Newton solver (no noslip pass) instead
+ * of being refused — an explicit opt-in; every other unsupported feature is refused whatever the flags. */
 int myo_model_load_mjb(const char* path, int integrator, int unsupported_contacts, myo_model** out);
 void myo_model_destroy(myo_model* m);
 int myo_model_size(const myo_model* m, const char* name); /* nq nv nu na nbody ... ; -1 unknown */

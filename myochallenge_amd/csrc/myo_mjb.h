@@ -155,7 +155,12 @@ static bool pair_supported(int t1, int t2) {       // narrow phases of csrc/myo_
 
 // compile_model(): feature checks, derived fields, blob.  integrator < 0 keeps the model's; allow_drop = 0 refuses a model that
 // has colliding geom pairs without a narrow phase here (MYO_E_UNSUPPORTED at the caller), 1 compiles without them.
-static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigned char>& out, std::string& err, int* unsupported) {
+static bool to_blob(File& f, int integrator, int allow_flags, std::vector<unsigned char>& out, std::string& err, int* unsupported) {
+  // allow_flags (myo_model_load_mjb's `unsupported_contacts`): bit 0 = compile without the colliding pairs that have no narrow phase;
+  // bit 1 = step a model whose opt.solver is PGS / CG, or that asks for noslip iterations, with THIS solver (Newton, no noslip pass) — the
+  // caller's explicit choice (the reference's .mjb files are not available here, and a refusal without an override would
+  // leave their user no way on); everything else on the list stays refused
+  const int allow_drop = allow_flags & 1, allow_solver = (allow_flags >> 1) & 1;
   auto I = [&](const char* k) -> std::vector<int>& { return f.i[k]; };
   auto D = [&](const char* k) -> std::vector<double>& { return f.d[k]; };
   const int nbody = (int)f.sizes["nbody"], njnt = (int)f.sizes["njnt"], ngeom = (int)f.sizes["ngeom"], nv = (int)f.sizes["nv"];
@@ -213,8 +218,8 @@ static bool to_blob(File& f, int integrator, int allow_drop, std::vector<unsigne
   { int n = 0; for (int j = 0; j < njnt; ++j) n += I("jnt_type")[j] == MYO_JNT_BALL; if (n) U("[ball_joints x%lld] ball joints are not supported", n); }
   if (f.sizes["neq"] > 0) U("[equality x%lld] equality constraints are not supported", f.sizes["neq"]);
   if (f.cone != 0) U("[cone x1] only pyramidal friction cones are supported (opt.cone = elliptic)");
-  if (f.solver != 2) U("[solver x1] opt.solver = %lld: this stepper restates mj_solNewton only (a model asking for PGS / CG would be stepped with another algorithm)", f.solver);
-  if (f.noslip_iterations > 0) U("[noslip x1] opt.noslip_iterations = %lld: the noslip post-solver is not implemented", f.noslip_iterations);
+  if (f.solver != 2 && !allow_solver) U("[solver x1] opt.solver = %lld: this stepper restates mj_solNewton only (a model asking for PGS / CG would be stepped with another algorithm)", f.solver);
+  if (f.noslip_iterations > 0 && !allow_solver) U("[noslip x1] opt.noslip_iterations = %lld: the noslip post-solver is not implemented", f.noslip_iterations);
   {
     const int nf = (f.density != 0.0) + (f.viscosity != 0.0) + (f.wind[0] != 0.0 || f.wind[1] != 0.0 || f.wind[2] != 0.0);
     if (nf) U("[fluid x%lld] opt.density / viscosity / wind non-zero: fluid forces in mj_passive are not implemented", nf);

@@ -22,10 +22,20 @@ import numpy as np
 from .evaluation import evaluate_policy
 
 
-def _calls_crossed(algo, last_calls: int, freq: int):
-    """multiples of `freq` among the vec-env step counts (last_calls, algo.n_calls]; returns (any, last multiple)"""
+def _rollout_start(algo):
+    """(vec-env steps, timesteps) the run had taken BEFORE the rollout that precedes this callback call: what a callback object
+    created for a RESUMED run starts counting from.  SB3's BaseCallback.n_calls restarts at 0 with a new callback object; a counter
+    that started at 0 against an `algo.n_calls` derived from a checkpoint's num_timesteps fired every callback on the first
+    rollout after a resume and named the checkpoint after an old multiple."""
+    steps = int(getattr(getattr(algo, "cfg", None), "n_steps", 0))
+    return max(0, algo.n_calls - steps), max(0, algo.num_timesteps - steps * _envs_total(algo))
+
+
+def _calls_crossed(algo, last_calls: int, freq: int, base: int = 0):
+    """multiples of `freq` among the vec-env step counts (last_calls, algo.n_calls - base], counted from `base` as SB3 counts from
+    the callback's creation; returns (any, last multiple)"""
     freq = max(1, int(freq))
-    now = algo.n_calls
+    now = algo.n_calls - base
     last_multiple = (now // freq) * freq
     return last_multiple > last_calls, last_multiple
 
@@ -41,11 +51,13 @@ class EvaluateLSTM:
 
     def __init__(self, eval_freq, eval_env, name, num_episodes=20, log: Optional[Callable[[dict], None]] = None):
         self.eval_freq, self.eval_env, self.name, self.num_episodes, self.log = eval_freq, eval_env, name, num_episodes, log
-        self._last_ts = 0
+        self._last_ts = None                       # (set on the first call: the run's timesteps before that rollout — 0 unless resumed)
         self.history = []
 
     def __call__(self, algo) -> bool:
         # num_timesteps took the values last + N, last + 2 N, ... now (N envs per vec-env step): is a multiple of eval_freq among them?
+        if self._last_ts is None:
+            self._last_ts = _rollout_start(algo)[1]
         n, now, last = _envs_total(algo), algo.num_timesteps, self._last_ts
         self._last_ts = now
         import math
@@ -87,13 +99,15 @@ class EvalCallback:
                  eval_freq=10_000, deterministic=True, render=False, verbose=1):
         self.eval_env, self.on_best, self.n, self.best_path = eval_env, callback_on_new_best, n_eval_episodes, best_model_save_path
         self.log_path, self.eval_freq, self.deterministic, self.verbose = log_path, eval_freq, deterministic, verbose
-        self._last_calls = 0
+        self._last_calls, self._base = 0, None     # (vec-env steps counted from the callback's first rollout, as SB3's n_calls)
         self.best_mean_reward = -np.inf
         self.evaluations_timesteps, self.evaluations_results, self.evaluations_length = [], [], []
 
     def __call__(self, algo) -> bool:
-        fire, _ = _calls_crossed(algo, self._last_calls, self.eval_freq)
-        self._last_calls = algo.n_calls
+        if self._base is None:
+            self._base = _rollout_start(algo)[0]
+        fire, _ = _calls_crossed(algo, self._last_calls, self.eval_freq, self._base)
+        self._last_calls = algo.n_calls - self._base
         if not fire:
             return True
         env = self.eval_env
@@ -132,14 +146,16 @@ class CheckpointCallback:
     def __init__(self, save_freq, save_path, name_prefix="rl_model", save_vecnormalize=False, verbose=0):
         self.save_freq, self.save_path, self.name_prefix = save_freq, save_path, name_prefix
         self.save_vecnormalize, self.verbose = bool(save_vecnormalize) and save_vecnormalize != "False", verbose
-        self._last_calls = 0
+        self._last_calls, self._base = 0, None
 
     def __call__(self, algo) -> bool:
-        fire, last_multiple = _calls_crossed(algo, self._last_calls, self.save_freq)
-        self._last_calls = algo.n_calls
+        if self._base is None:
+            self._base = _rollout_start(algo)[0]
+        fire, last_multiple = _calls_crossed(algo, self._last_calls, self.save_freq, self._base)
+        self._last_calls = algo.n_calls - self._base
         if not fire:
             return True
-        steps = last_multiple * _envs_total(algo)           # num_timesteps at the (last) vec-env step SB3 would have saved on
+        steps = (self._base + last_multiple) * _envs_total(algo)      # num_timesteps at the (last) vec-env step SB3 would have saved on
         os.makedirs(self.save_path, exist_ok=True)
         path = os.path.join(self.save_path, f"{self.name_prefix}_{steps}_steps.zip")
         algo.save(path)

@@ -287,7 +287,8 @@ class UnsupportedContactsError(ValueError):
     """The model has colliding geom pairs whose narrow phase the stepper does not implement."""
 
 
-def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_contacts: str = "error") -> CompiledModel:
+def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_contacts: str = "error",
+                  allow_other_solver: bool = False) -> CompiledModel:
     """unsupported_contacts: what to do with colliding geom pairs that have no narrow phase here (meshes, height fields,
     cylinder-cylinder, ellipsoid-ellipsoid and the like; the pairs of SUPPORTED_PAIRS and box-box — 16 vertex-face candidates plus
     one edge-edge candidate from a separating-axis test — have one): "error" (default) refuses the model — a contact MuJoCo would generate
@@ -299,7 +300,8 @@ def compile_model(m: MjbModel, *, integrator: int | None = None, unsupported_con
     f["sizes"] = np.array([m.sizes[k] for k in _SIZES], np.int32)
     # what mj_step would do differently and this stepper does not restate is refused, never ignored — ALL of it at once
     # (unsupported_features: the same list `python -m myochallenge_amd.model --check file.mjb` prints)
-    feats = [x for x in unsupported_features(m) if x["key"] != "contact_pairs"]
+    # (allow_other_solver: the caller's explicit choice to step a PGS / CG / noslip model with this stepper's Newton solver — ADVICE r05)
+    feats = [x for x in unsupported_features(m) if x["key"] != "contact_pairs" and not (allow_other_solver and x["key"] in ("solver", "noslip"))]
     if feats:
         raise ModelError("; ".join(x["message"] for x in feats))
     col = int(m.opt.get("collision", 0))

@@ -221,13 +221,14 @@ class Model:
         self.h = h
 
     @classmethod
-    def from_mjb(cls, path: str, lib: Optional[NativeLib] = None, integrator: Optional[int] = None, unsupported_contacts: str = "error"):
+    def from_mjb(cls, path: str, lib: Optional[NativeLib] = None, integrator: Optional[int] = None, unsupported_contacts: str = "error",
+                 allow_other_solver: bool = False):
         """The C route: libmyobatch reads the .mjb itself (myo_model_load_mjb)."""
         self = cls.__new__(cls)
         self.lib, self.compiled, self._buf = lib or load(), None, None
         h = C.c_void_p()
         self.lib.check(self.lib.L.myo_model_load_mjb(os.fsencode(path), -1 if integrator is None else int(integrator),
-                                                     {"error": 0, "drop": 1}[unsupported_contacts], C.byref(h)))
+                                                     {"error": 0, "drop": 1}[unsupported_contacts] | (2 if allow_other_solver else 0), C.byref(h)))
         self.h = h
         return self
 

@@ -5,7 +5,7 @@ actor + critic -> [256, 256] ReLU, log_std_init -2) rolls out and trains on the 
 import time
 
 
-def run(envs: int = 4096, n_steps: int = 32, iters: int = 3, env_only_steps: int = 50, dtype: str = "mixed", n_epochs: int = 4,
+def run(envs: int = 4096, n_steps: int = 32, iters: int = 3, env_only_steps: int = 50, dtype: str = "f64", n_epochs: int = 4,
         reference_settings: bool = False) -> dict:
     """reference_settings: the PPO settings of /root/reference/src/main_reorient.py:53-71 — n_steps 128, n_epochs 10, learning rate
     2.55673e-5, entropy 3.62109e-6, clip 0.3, lambda 0.9, max_grad_norm 0.7, vf_coef 0.835671, 300-step episodes — on the fp64 stepper

@@ -449,7 +449,12 @@ class PPO:
         self._log_episodes(raw[2], raw[6])
         self._gB.replay()
         if getattr(self, "_gB2", None) is not None:      # rank-synchronised normaliser (see _init_native_rollout)
+            # (host time of the eager collective between the two graph replays — enqueue + whatever the call blocks on — accumulated for
+            #  the bench line of an N > 1 run: `normalizer_allreduce_ms_per_step`)
+            t0 = time.perf_counter()
             dist.all_reduce(self._vn_batch)
+            self.vn_allreduce_seconds = getattr(self, "vn_allreduce_seconds", 0.0) + (time.perf_counter() - t0)
+            self.vn_allreduce_calls = getattr(self, "vn_allreduce_calls", 0) + 1
             self._gB2.replay()
 
     def _log_episodes(self, done, ep) -> None:
@@ -732,14 +737,21 @@ class PPO:
         # backward and optimizer step: one replay instead of B / bs, no launch gap between two minibatch steps and none around the index
         # copy (13 us + a 5 us copy kernel per 135 us step at config B).  Same kernels in the same order as the per-step graph
         # (MYO_EPOCH_GRAPH=0), so the parameters come out bit-identical (tests/test_gpu_parity.py).
+        # The capture unrolls its minibatch steps, so it is CHUNKED: an SB3-style batch_size of 64 on 4096 x 64 samples is
+        # 4,096 steps an epoch — one graph of that would be hundreds of thousands of nodes to capture, instantiate and hold.  A chunk
+        # graph holds at most MYO_EPOCH_GRAPH_STEPS (64) steps, reads its minibatches from the first k * bs entries of a chunk-sized
+        # window buffer, and is replayed ceil(n / k) times per epoch (the last, shorter chunk: the per-step graph).
         self._graph_epoch = None
-        if self.world == 1 and os.environ.get("MYO_EPOCH_GRAPH") != "0" and B // bs > 1:
-            self._gs["perm"] = torch.zeros(B, dtype=torch.long, device=d)
-            self._gs["perm"].copy_(torch.arange(B, device=d))
+        n_mb = B // bs
+        if self.world == 1 and os.environ.get("MYO_EPOCH_GRAPH") != "0" and n_mb > 1:
+            k = max(1, min(n_mb, int(os.environ.get("MYO_EPOCH_GRAPH_STEPS", "64"))))
+            self._epoch_chunk = k
+            self._gs["perm"] = torch.zeros(k * bs, dtype=torch.long, device=d)
+            self._gs["perm"].copy_(torch.arange(k * bs, device=d))
             torch.cuda.synchronize(d)
             self._graph_epoch = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_epoch, capture_error_mode="thread_local"):
-                for s in range(0, B - bs + 1, bs):
+                for s in range(0, k * bs, bs):
                     self._gs["idx"].copy_(self._gs["perm"][s:s + bs])
                     self._mb_forward_backward()
                     self._mb_apply()
@@ -763,10 +775,18 @@ class PPO:
         if not cfg.normalize_advantage:
             self._fused.stats.copy_(torch.tensor([0.0, 1.0], device=self.device))
         if getattr(self, "_graph_epoch", None) is not None and not ext:
+            k, n_mb = self._epoch_chunk, B // bs
             for _ in range(cfg.n_epochs):
-                g["perm"].copy_(torch.randperm(B, generator=self.gen, device=self.device))
-                self._graph_epoch.replay()
-                self.n_updates += len(range(0, B - bs + 1, bs))
+                perm = torch.randperm(B, generator=self.gen, device=self.device)
+                done = 0
+                while n_mb - done >= k:                        # whole chunks: one replay each
+                    g["perm"].copy_(perm[done * bs:(done + k) * bs])
+                    self._graph_epoch.replay()
+                    done += k
+                for j in range(done, n_mb):                    # what is left of the epoch: the per-step graph
+                    g["idx"].copy_(perm[j * bs:(j + 1) * bs])
+                    self._graph_fb.replay()
+                self.n_updates += n_mb
             self._fused.refresh_shadow()
             return g["pl"], g["vl"]
         for _ in range(cfg.n_epochs):

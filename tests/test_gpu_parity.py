@@ -1365,8 +1365,12 @@ def test_epoch_graph_equals_per_step_graphs(hip_lib, monkeypatch):
     from myochallenge_amd.rl.ppo import PPO, PPOConfig
     from myochallenge_amd.rl.vec_normalize import VecNormalize
 
-    def run(epoch_graph):
+    def run(epoch_graph, chunk=None):
         monkeypatch.setenv("MYO_EPOCH_GRAPH", "1" if epoch_graph else "0")
+        if chunk is None:
+            monkeypatch.delenv("MYO_EPOCH_GRAPH_STEPS", raising=False)
+        else:
+            monkeypatch.setenv("MYO_EPOCH_GRAPH_STEPS", str(chunk))       # (the capture is chunked; here 3 of an epoch's 4 steps + 1 on the per-step graph)
         torch.manual_seed(0)
         env = EnvironmentFactory.create("CustomMyoBaodingBallsP1", num_envs=1024, seed=5)
         pol = ActorCriticPolicy(86, 39, (256, 256), (256, 256), lstm_hidden_size=None)
@@ -1380,10 +1384,10 @@ def test_epoch_graph_equals_per_step_graphs(hip_lib, monkeypatch):
         out = (fa.flat["p"].clone(), fa.m.clone(), fa.v.clone(), fa._step.clone(), algo.n_updates)
         env.close()
         return out
-    a, b = run(True), run(False)
-    assert a[4] == b[4] == 3 * 3 * 4
-    for x, y in zip(a[:4], b[:4]):
-        assert torch.equal(x, y)
+    a, b, c = run(True), run(False), run(True, chunk=3)
+    assert a[4] == b[4] == c[4] == 3 * 3 * 4
+    for x, y, z in zip(a[:4], b[:4], c[:4]):
+        assert torch.equal(x, y) and torch.equal(z, y)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])

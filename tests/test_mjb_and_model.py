@@ -315,10 +315,10 @@ def test_every_unsupported_feature_is_reported_at_once_by_both_routes(models, em
     from myochallenge_amd.model import _main, unsupported_features
     hand = models["hand"]
 
-    def c_route(m):
+    def c_route(m, **kw):
         path = tmp_path / "m.mjb"
         path.write_bytes(dump_mjb(m))
-        return native.Model.from_mjb(str(path), emu_lib)
+        return native.Model.from_mjb(str(path), emu_lib, **kw)
 
     assert unsupported_features(hand) == []
     dyn = hand.arrays["actuator_dyntype"].copy(); dyn[:3] = 2                      # filter
@@ -336,6 +336,16 @@ def test_every_unsupported_feature_is_reported_at_once_by_both_routes(models, em
         with pytest.raises(native.MyoError, match=r"\[%s x\d+\]" % key.strip()):
             c_route(bad)
     assert unsupported_features(_with(hand, actuator_dyntype=dyn))[0]["count"] == 3
+    # the explicit opt-in of ADVICE r05: a PGS / CG / noslip model may be stepped with this stepper's Newton solver when the caller says so
+    # (both routes) — and only those two entries: the same model with an elliptic cone on top is still refused
+    other = _with(hand, opt_solver=1, opt_noslip_iterations=2)
+    cm_o = compile_model(other, allow_other_solver=True)
+    assert cm_o.size("nv") == compile_model(hand).size("nv")
+    c_route(other, allow_other_solver=True)
+    with pytest.raises(ModelError, match="cone"):
+        compile_model(_with(other, opt_cone=1), allow_other_solver=True)
+    with pytest.raises(native.MyoError, match=r"\[cone x1\]"):
+        c_route(_with(other, opt_cone=1), allow_other_solver=True)
     # several at once: one report, every entry, both routes
     jt = hand.arrays["jnt_type"].copy(); jt[3] = 1                                 # a ball joint
     many = _with(hand, opt_solver=1, opt_noslip_iterations=2, opt_viscosity=0.1, opt_cone=1, actuator_biastype=bias, jnt_type=jt, neq=2)

@@ -798,3 +798,36 @@ def test_lstm_seq_layouts_follow_the_header(H, rs):
     # the split never asks for more workgroups than CUs, and a forced one wins
     assert lstm_seq_row_split(256, 2, 512) == 4 and lstm_seq_row_split(256, 2, 2048) == 1 and lstm_seq_row_split(128, 2, 512) == 2
     assert lstm_seq_row_split(128, 2, 4096) == 1 and lstm_seq_row_split(256, 2, 1024) == 2
+
+
+def test_callbacks_of_a_resumed_run_count_from_their_first_rollout():
+    """a callback object created for a run that resumes from a checkpoint (num_timesteps far above 0) must not fire on the
+    first rollout — SB3's n_calls restarts with the callback object — and the checkpoint it writes later is named after the run's
+    ABSOLUTE timesteps."""
+    from types import SimpleNamespace
+    from myochallenge_amd.metrics.custom_callbacks import CheckpointCallback, EvalCallback, EvaluateLSTM
+    saved = []
+    algo = SimpleNamespace(env=SimpleNamespace(num_envs=4), world=1, cfg=SimpleNamespace(n_steps=8), num_timesteps=0, n_calls=0, policy=None,
+                           save=lambda path: saved.append(path))
+    ck = CheckpointCallback(save_freq=20, save_path="/tmp/_myo_ck_test", name_prefix="m")
+    ev = EvalCallback(eval_env=None, eval_freq=20, verbose=0)
+    ls = EvaluateLSTM(eval_freq=1000, eval_env=None, name="x")
+    fired = {"ev": 0, "ls": 0}
+    import myochallenge_amd.metrics.custom_callbacks as cc
+    orig = cc.evaluate_policy
+    cc.evaluate_policy = lambda *a, **k: (fired.__setitem__("last", 1) or {"returns": [0.0], "lengths": [1]})
+    try:
+        algo.n_calls, algo.num_timesteps = 1000 + 8, (1000 + 8) * 4          # resumed at 1000 vec-env steps; the first rollout has run
+        for cb in (ck, ev, ls):
+            fired.pop("last", None)
+            cb(algo)
+            assert "last" not in fired and not saved, (cb, saved)            # nothing fires: 8 steps < every frequency
+        algo.n_calls, algo.num_timesteps = 1000 + 24, (1000 + 24) * 4         # 24 steps since the resume: the 20-step callbacks fire once
+        ck(algo)
+        assert saved == ["/tmp/_myo_ck_test/m_%d_steps.zip" % ((1000 + 20) * 4)], saved
+        fired.pop("last", None); ev(algo); assert fired.get("last") == 1
+        fired.pop("last", None); ls(algo); assert "last" not in fired        # (4096 timesteps: no multiple of 1000 since 4032)
+        algo.n_calls, algo.num_timesteps = 1251, 5004
+        ls(algo); assert fired.get("last") == 1                              # ... 5000 was crossed
+    finally:
+        cc.evaluate_policy = orig

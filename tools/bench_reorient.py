@@ -14,7 +14,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--n-steps", type=int, default=32)
     ap.add_argument("--iters", type=int, default=3)
-    ap.add_argument("--dtype", default="mixed", choices=["mixed", "f64"])
+    ap.add_argument("--dtype", default="f64", choices=["mixed", "f64"], help="f64 since round 6: the mixed stepper is not offered for the die (DESIGN.md §4)")
     ap.add_argument("--n-epochs", type=int, default=4)
     ap.add_argument("--reference-settings", action="store_true", help="n_steps 128, n_epochs 10, fp64 physics, the PPO settings of src/main_reorient.py:53-71")
     a = ap.parse_args()

@@ -91,7 +91,9 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
   int objf_off;               // env record: doubles from the warm start to the object group's friction triples (Scratch::SPILL reads them in place)
-  double* ctrl_ws;            // double[MYO_WAVE_SLOTS][MYO_ENVWS_N] in global memory, fp64 stepper: the wave slots' workspaces (one per device, shared by its batches; emulation: one per env)
+  int* slot_map;              // int[MYO_WAVE_SLOTS + 1]: hardware wave-slot code -> dense workspace index, filled on first use (myo_ws_index, wave.h); emulation: null
+  char* big_ws;               // char[MYO_WS_SLOTS][MYO_BIGWS_BYTES]: the wave slots' blocks of the 48-slot fp64 scratch (Scratch::SPILL: contact records, wrap results); else null
+  double* ctrl_ws;            // double[MYO_WS_SLOTS][MYO_ENVWS_N] in global memory, fp64 stepper: the wave slots' workspaces (one per device, shared by its batches; emulation: one per env)
   int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity, [2] substeps that dropped joint / tendon limit or friction-loss rows beyond MYO_NLIM_MAX
   unsigned long long seed;
 };
@@ -130,7 +132,7 @@ struct alignas(8) ContactRec {     // 80 B (fp32) / 136 B (fp64).  The STRIDE is
 static_assert(sizeof(ContactRec<double>) == 136 && sizeof(ContactRec<float>) == 80, "contact record strides (LDS banks)");
 static_assert(MYO_NV_MAX <= 64, "ContactRec::sup entries: dof index in bits 0-5");
 // the contact frame (normal, first tangent) of a record, as make_frame built it
-template <typename T> DEV void con_frame(const ContactRec<T>& c, T* f) {
+template <typename C, typename T> DEV void con_frame(const C& c, T* f) {      // (C: a ContactRec in LDS or — Scratch::SPILL — in global memory)
   f[0] = c.nrm[0]; f[1] = c.nrm[1]; f[2] = c.nrm[2];
   const bool z = c.tinv < 0;
   const T i = z ? -c.tinv : c.tinv, t = z ? f[2] : f[1];
@@ -148,10 +150,10 @@ DEV int con_sup_on2(int e) { return (e >> 7) & 1; }
 //   3  the normal row alone (muA = 0) / --, --, --                   (condim 1: frictionless)
 //   4  rotation about the normal / --                                (second slot of condim 4)
 // "--" rows are padding: J = 0 and aref = -1, so they are never active and carry no force.
-template <typename T> DEV int con_kind(const ContactRec<T>& c) { return c.pk >> 24; }
-template <typename T> DEV int con_nsup(const ContactRec<T>& c) { return (c.pk >> 16) & 255; }
-template <typename T> DEV int con_b1(const ContactRec<T>& c) { return c.pk & 255; }
-template <typename T> DEV int con_b2(const ContactRec<T>& c) { return (c.pk >> 8) & 255; }
+template <typename C> DEV int con_kind(const C& c) { return c.pk >> 24; }
+template <typename C> DEV int con_nsup(const C& c) { return (c.pk >> 16) & 255; }
+template <typename C> DEV int con_b1(const C& c) { return c.pk & 255; }
+template <typename C> DEV int con_b2(const C& c) { return (c.pk >> 8) & 255; }
 static_assert(MYO_NB_MAX <= 256 && MYO_CS_MAX <= 255, "ContactRec::pk fields are 8 bits");
 DEV bool con_pad(int kind, int e) { return (kind == 2 || kind == 4) ? e >= 2 : (kind == 3 ? e >= 1 : false); }
 DEV int con_rows(int kind) { return kind == 3 ? 1 : ((kind == 2 || kind == 4) ? 2 : 4); }
@@ -183,13 +185,23 @@ template <typename T> struct ScratchPoses {
 // ... and so do the tendon moment arms (2.5 KB: the difference between seven and eight workgroups per CU): accumulated in LDS during the
 // tendon stage (S_TENJ_STAGE, storage the constraint rows take over later), written out once, [slot][tendon] so that tendon-per-lane
 // reads coalesce; read back by the tendon-velocity / actuator-moment phases and, for tendon-limit rows only, by the solver
-template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; int pub; };
+// big_g (Scratch::SPILL only): the wave slot's block of the BIG workspace (TaskDev::big_ws) — the contact records and the tendon
+// stage's wrap results of the 48-slot fp64 scratch live there (CON / S_TWRES below)
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; };
+/* bytes per wave slot of TaskDev::big_ws: MYO_NCON_BIG contact records, then 7 doubles per geom wrap (MYO_BIGWS_GW of them) */
+#define MYO_BIGWS_GW 96
+#define MYO_BIGWS_WRES (MYO_NCON_BIG * 136)
+#define MYO_BIGWS_BYTES ((MYO_BIGWS_WRES + MYO_BIGWS_GW * 7 * 8 + 127) / 128 * 128)
 
 template <typename T, int NC = MYO_NCON_MAX>
 struct Scratch : ScratchPoses<T> {
   // per-env friction coefficients kept per geom of an object group: all three (sliding, torsional, rolling) in the big scratch that
   // batches with a die get, the sliding one in the base scratch (an object group on a base batch: torsional / rolling stay nominal)
   static constexpr int OBJG_NF = NC >= MYO_NCON_BIG ? 3 : 1;
+  // Round 6: the big fp64 scratch holds 48 contact slots (config E's rollouts ask for up to 45) and STILL fits eight workgroups per CU
+  // (20,320 B), because its contact RECORDS (6.5 KB) and the tendon stage's wrap results (4 KB of staging that used to sit in con[])
+  // live in the wave slot's block of a global workspace (TaskDev::big_ws, L2-resident: 2048 live slots x 12 KB): CON(s, ci), S_TWRES.
+  // What the solver reads per ROW stays in LDS (the rows' arrays, a contact's D: conD).
   // The 34-slot fp64 scratch keeps what a substep touches ONCE in GLOBAL memory — the object group's friction triples and the muscle
   // activations in the env record, where they live anyway; the tendon lengths, the activation rates and the reward terms in the env's
   // workspace (ctrl_ws): 1,072 B, the difference between six and seven workgroups per CU (24,064 -> 22,992 B).  Accessors: S_OBJF,
@@ -232,9 +244,10 @@ struct Scratch : ScratchPoses<T> {
   // rows are SHARED with the limit rows (capacity MYO_NLIM_MAX, ~11 in use on the hand): a substep holds min(NREC, (rows - limit rows) / 4)
   // contacts (contacts_emit_*), at least NC.  Measured on the hand with P2's ball sizes: up to 19 contacts (oracle, 32 episodes).
   static constexpr int NREC = (sizeof(T) == sizeof(HP) && NC == MYO_NCON_F64) ? MYO_NREC_F64 : NC;
-  alignas(16) ContactRec<T> con[NREC];
-  short lim_id[MYO_NLIM_MAX];                                          // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1)
-  T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[]
+  alignas(16) ContactRec<T> con[SPILL ? 1 : NREC];                     // (SPILL: in the big workspace — CON below; the one record here is never used)
+  alignas(16) short lim_id[MYO_NLIM_MAX];                              // dof (joint rows) / tendon (tendon rows); bit 15: the upper limit (row sign -1)
+  T efc_D[MYO_NLIM_MAX];                                               // limit rows only; contact rows: con[] / conD
+  T conD[SPILL ? NREC : 1];                                            // SPILL: D of every contact slot (CON_D)
   // bvec, efc_jv, efc_force: contiguous, in this order — the linear solves stage their operands from bvec on (S_SOLVE_STAGE)
   alignas(16) T bvec[MYO_NB_MAX * 6];
   T efc_jv[MYO_NLIM_MAX + 4 * NC], efc_force[MYO_NLIM_MAX + 4 * NC], efc_jar[MYO_NLIM_MAX + 4 * NC];
@@ -292,12 +305,22 @@ template <typename T, int NC> DEV const T* S_XPOST(const Scratch<T, NC>& s) { if
 #define S_TWP(s) (reinterpret_cast<T*>((s).con))   /* tendon stage, mixed stepper: fp32 position of every path element (con[] is dead until the collision stage) */
 /* tendon stage: HP wrap results (7 per geom wrap) behind the T path points, running on through the limit-row and efc_* arrays.
    The fp64 stepper stages no path points (its moment arms take the HP points the lengths are made of): the results start at con[] */
-#define S_TWRES(s, nwrap) (reinterpret_cast<HP*>(reinterpret_cast<char*>((s).con) + (sizeof(T) == sizeof(HP) ? (size_t)0 : ((3 * (size_t)(nwrap) * sizeof(T) + 7) & ~(size_t)7))))
+template <typename T, int NC> DEV auto S_TWRES(Scratch<T, NC>& s, int nwrap) {
+  if constexpr (Scratch<T, NC>::SPILL) { (void)nwrap; return (GPTR(HP))((GPTR(char))s.big_g + MYO_BIGWS_WRES); }      // (the big workspace)
+  else return reinterpret_cast<HP*>(reinterpret_cast<char*>(s.con) + (sizeof(T) == sizeof(HP) ? (size_t)0 : ((3 * (size_t)nwrap * sizeof(T) + 7) & ~(size_t)7)));
+}
 /* operand stage of the linear solves (chol_factor_solve_reg, arrow_eliminate_blocks): from bvec on through efc_jv, efc_force —
    body vectors, J v and the row forces are all rebuilt after a solve */
 #define S_SOLVE_STAGE(s) ((s).bvec)
 #define S_ACT_GF(s) (static_cast<T*>((s).Ma))   /* gear * actuator force (actuation stage, NU_MAX entries through Ma, search: the body velocities that live there are dead after efc_reference) */
-#define S_KTMP(s) (reinterpret_cast<HP*>((s).con))   /* HP [2][MYO_NJ_MAX * 3] */
+/* HP [2][MYO_NJ_MAX * 3]: in con[] — or, for the scratch that keeps no records in LDS (SPILL), from lim_id on through efc_D, conD, bvec */
+template <typename T, int NC> DEV HP* S_KTMP(Scratch<T, NC>& s) {
+  if constexpr (Scratch<T, NC>::SPILL) {
+    typedef Scratch<T, NC> S;
+    static_assert(offsetof(S, efc_jv) - offsetof(S, lim_id) >= 2 * MYO_NJ_MAX * 3 * sizeof(HP) && offsetof(S, lim_id) % 8 == 0, "kinematics temporaries fit before efc_jv");
+    return reinterpret_cast<HP*>(s.lim_id);
+  } else return reinterpret_cast<HP*>(s.con);
+}
 #define S_XANCHOR(s) ((s).efc_jar)
 #define S_XAXIS(s) ((s).efc_jv)
 #define S_XIPOS(s) ((s).efc_force)
@@ -400,7 +423,19 @@ template <typename T, int NC> DEV auto S_ACT_DOT(Scratch<T, NC>& s) { if constex
 template <typename T, int NC> DEV auto S_ACT_DOT(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(const T))s.ctrl_g + MYO_WS_ADOT; else return (const T*)s.act_dot; }
 template <typename T, int NC> DEV auto S_RWD(Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(T))s.ctrl_g + MYO_WS_RWD; else return (T*)s.rwd; }
 template <typename T, int NC> DEV auto S_RWD(const Scratch<T, NC>& s) { if constexpr (Scratch<T, NC>::SPILL) return (GPTR(const T))s.ctrl_g + MYO_WS_RWD; else return (const T*)s.rwd; }
-template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : s.con[(r - nlim) >> 2].D; }
+// contact slot ci's record: the LDS member, or the wave slot's block of the big workspace (Scratch::SPILL)
+template <typename T, int NC> DEV auto& CON(Scratch<T, NC>& s, int ci) {
+  if constexpr (Scratch<T, NC>::SPILL) return ((GPTR(ContactRec<T>))s.big_g)[ci]; else return s.con[ci];
+}
+template <typename T, int NC> DEV const auto& CON(const Scratch<T, NC>& s, int ci) {
+  if constexpr (Scratch<T, NC>::SPILL) return ((GPTR(const ContactRec<T>))s.big_g)[ci]; else return s.con[ci];
+}
+// ... and its D (SPILL: kept in LDS, the solver reads it per row)
+template <typename T, int NC> DEV T CON_D(const Scratch<T, NC>& s, int ci) { if constexpr (Scratch<T, NC>::SPILL) return s.conD[ci]; else return s.con[ci].D; }
+template <typename T, int NC> DEV void CON_SET_D(Scratch<T, NC>& s, int ci, T v) { if constexpr (Scratch<T, NC>::SPILL) s.conD[ci] = v; else s.con[ci].D = v; }
+// the record's support list as words (same address space as the record)
+#define CON_SUP_WORDS(c) (reinterpret_cast<decltype(&(c).pk)>((c).sup))
+template <typename T, int NC> DEV T row_D(const Scratch<T, NC>& s, int r, int nlim) { return r < nlim ? s.efc_D[r] : CON_D(s, (r - nlim) >> 2); }
 
 // ------------------------------------------------------------------------------------------
 // small math
@@ -455,7 +490,7 @@ template <typename T> DEV T tmin(T a, T b) { return a < b ? a : b; }
 template <typename T> DEV T tclamp(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // (J v)[row e of the slot] from the relative linear / angular velocity of the two bodies at the contact
-template <typename T> DEV T con_row_val(const ContactRec<T>& c, int kind, int e, const T* rel_lin, const T* rel_ang) {
+template <typename C, typename T> DEV T con_row_val(const C& c, int kind, int e, const T* rel_lin, const T* rel_ang) {
   T t2[3], fr[6];
   con_frame(c, fr);
   cross3(t2, fr, fr + 3);
@@ -599,7 +634,7 @@ DEVFN void kinematics(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   //  3. parallel again: xmat, xipos, and the world anchors / axes from the parent's final pose.
   // (mj_kinematics composes in the world frame; the two are the same maps, rounded differently.)
   HP* const kanchor = S_KTMP(s);
-  HP* const kaxis = S_KTMP(s) + MYO_NJ_MAX * 3;
+  HP* const kaxis = kanchor + MYO_NJ_MAX * 3;
   LANE_VAR(int, k_depth); LANE_VAR(int, k_par); LANE_VAR(int, k_jn); LANE_VAR(int, k_ja); LANE_VAR(int, k_free);
   LANE_VAR(HP, k_p0); LANE_VAR(HP, k_p1); LANE_VAR(HP, k_p2);
   LANE_VAR(HP, k_q0); LANE_VAR(HP, k_q1); LANE_VAR(HP, k_q2); LANE_VAR(HP, k_q3);
@@ -1004,7 +1039,7 @@ DEVFN void tendon(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& 
   // Staging: T points in con[] (dead until the collision stage); HP wrap results behind them, through the
   // limit-row and efc_* arrays (contiguous; constraint rows are only built after this stage).
   T* wp = S_TWP(s);
-  HP* wres = S_TWRES(s, M.nwrap);
+  auto wres = S_TWRES(s, M.nwrap);
   (void)wres;
   PHASE {
     for (int i = lane; i < M.ntendon * MYO_TJ_MAX; i += 64) S_TENJ_STAGE(s)[i] = 0;     // phase C accumulates into it
@@ -1028,7 +1063,7 @@ template <typename T, int NC>
 DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int base) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN
-  HP* wres = S_TWRES(s, M.nwrap);
+  auto wres = S_TWRES(s, M.nwrap);
   PHASE {
     const int k = base + lane;
     if (k < M.ngw) {
@@ -1050,7 +1085,7 @@ DEVFN void tendon_wrap_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scratc
       for (int e = 0; e < 6; ++e) wres[7 * k + 1 + e] = pts[e];
     }
   }
-  SYNC();
+  if constexpr (Scratch<T, NC>::SPILL) { SYNC_G(); } else { SYNC(); }      // (SPILL: the wrap results went to the big workspace in global memory)
 }
 
 // phase C of the tendon stage: lengths and moment arms.  One lane per PATH ELEMENT (site -> site, or site -> wrap geom ->
@@ -1066,7 +1101,7 @@ DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scr
   WAVE_FN
   (void)K;
   T* wp = S_TWP(s);
-  HP* wres = S_TWRES(s, M.nwrap);
+  auto wres = S_TWRES(s, M.nwrap);
   PHASE {
     const int e = base + lane;
     if (e < M.nte) {
@@ -1090,7 +1125,7 @@ DEVFN void tendon_element_pass(const DevModel<T>& M_in, const TaskDev& K_in, Scr
       else { for (int k = 0; k < 3; ++k) { p0[k] = wp[3 * i0 + k]; x1[k] = wp[3 * iend + k]; } }
       HP wlen = -1, h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0};
       if (is_geom) {
-        const HP* r = wres + 7 * M.wr_i[8 * ig + 6];
+        const auto r = wres + 7 * M.wr_i[8 * ig + 6];
         wlen = r[0];
         for (int k = 0; k < 3; ++k) { h0[k] = r[1 + k]; h1[k] = r[4 + k]; }
       }
@@ -2261,10 +2296,11 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         const int ci = ncon + S_NPRE(s)[lane] + k;
         if (k >= LV(ct).n || ci >= cap) break;
         const int g1 = M.pair_geom1[p], g2 = M.pair_geom2[p];
-        ContactRec<T>& c = s.con[ci];
-        T cpos[3];                         // contact point relative to O: only r1 / r2 below are made of it
-        for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - S_ORIGIN(s)[e]); c.nrm[e] = (T)LV(ct).nrm[3 * k + e]; }
-        c.tinv = make_frame(c.nrm);
+        auto& c = CON(s, ci);
+        T cpos[3], cnrm[3];                // contact point relative to O: only r1 / r2 below are made of it
+        for (int e = 0; e < 3; ++e) { cpos[e] = (T)(LV(ct).pos[3 * k + e] - S_ORIGIN(s)[e]); cnrm[e] = (T)LV(ct).nrm[3 * k + e]; }
+        c.tinv = make_frame(cnrm);
+        for (int e = 0; e < 3; ++e) c.nrm[e] = cnrm[e];
         // everything that depends on the two geoms only comes from the host-resolved pair record (pc_*):
         // bodies, tree roots, dof masks + support list, mixed solref / solimp (mj_contactParam), static
         // friction, margin and gap, inverse-weight sum; the balls' per-env friction is patched in here
@@ -2287,16 +2323,13 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
         T Kc, Bc, Ic;
         sol_param(M, F + 2, F + 4, dmi, &Kc, &Bc, &Ic);
         const T tran = F[15];
-        c.D = con_D_pyramid(M, Ic, tran, fr0);
+        CON_SET_D(s, ci, con_D_pyramid(M, Ic, tran, fr0));
         { const int r0 = nlim + 4 * ci; const T kip = Kc * Ic * dmi; for (int e = 0; e < 4; ++e) { S_ROW_B(s)[r0 + e] = Bc; S_ROW_KIP(s)[r0 + e] = kip; } }
         {
           const T* c1 = S_COM(s) + 3 * root1; const T* c2 = S_COM(s) + 3 * root2;
           for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
         }
-        {
-          int* dst = reinterpret_cast<int*>(c.sup);
-          for (int e = 0; e < MYO_CS_MAX / 4; ++e) dst[e] = M.pc_sup[4 * p + e];
-        }
+        for (int e = 0; e < MYO_CS_MAX / 4; ++e) CON_SUP_WORDS(c)[e] = M.pc_sup[4 * p + e];
         c.pk = b1 | (b2 << 8) | (ns << 16);
       }
     }
@@ -2364,22 +2397,19 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
           for (int j = 0; j < 3; ++j) {
             const int ci = ncon + S_NPRE(s)[lane] + k * per + j;
             if (j >= per || ci >= cap) break;
-            ContactRec<T>& c = s.con[ci];
+            auto& c = CON(s, ci);
             const int kind = dim == 1 ? 3 : (j == 0 ? 0 : (dim == 4 ? 4 : j));
             for (int e = 0; e < 3; ++e) c.nrm[e] = frame[e];
             c.tinv = tinv;
             c.muA = kind == 0 ? fr0 : (kind == 1 || kind == 4 ? fr[1] : (kind == 2 ? fr[2] : (T)0));
             c.muB = kind == 0 ? fr0 : (kind == 1 ? fr[2] : (T)0);
-            c.D = D;
+            CON_SET_D(s, ci, D);
             { const int r0 = nlim + 4 * ci; const T kip = Kc * Ic * dmi; for (int e = 0; e < 4; ++e) { S_ROW_B(s)[r0 + e] = Bc; S_ROW_KIP(s)[r0 + e] = kip; } }
             {
               const T* c1 = S_COM(s) + 3 * root1; const T* c2 = S_COM(s) + 3 * root2;
               for (int e = 0; e < 3; ++e) { c.r1[e] = cpos[e] - c1[e]; c.r2[e] = cpos[e] - c2[e]; }
             }
-            {
-              int* dst = reinterpret_cast<int*>(c.sup);
-              for (int e = 0; e < MYO_CS_MAX / 4; ++e) dst[e] = M.pc_sup[4 * p + e];
-            }
+            for (int e = 0; e < MYO_CS_MAX / 4; ++e) CON_SUP_WORDS(c)[e] = M.pc_sup[4 * p + e];
             c.pk = b1 | (b2 << 8) | (ns << 16) | (kind << 24);
           }
         }
@@ -2408,6 +2438,7 @@ DEV void contacts_clamp(const TaskDev& K_in, Scratch<T, NC>& s_in) {
     }
     SYNC();
   }
+  if constexpr (Scratch<T, NC>::SPILL) { SYNC_G(); }      // (the contact records went to global memory: other lanes read them from here on)
 }
 
 template <bool GEN, typename T, int NC>
@@ -2498,18 +2529,20 @@ DEV void body_vectors(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF
   }
   SYNC();
 }
-template <typename T>
-DEV void point_vel(const T* bv, int b, const T* off, T* out) {
+template <typename T, typename P>
+DEV void point_vel(const T* bv, int b, P off, T* out) {       // (P: pointer to the offset, LDS or global)
   const T* V = bv + 6 * b;
+  const T o[3] = {off[0], off[1], off[2]};
   T t[3];
-  cross3(t, V, off);
+  cross3(t, V, o);
   out[0] = V[3] + t[0]; out[1] = V[4] + t[1]; out[2] = V[5] + t[2];
 }
 // Jacobian column of dof d at a contact, given the contact offset from the dof's tree reference point
-template <typename T, int NC> DEV void con_col(const Scratch<T, NC>& s, int d, const T* off, T* col) {
+template <typename T, int NC, typename P> DEV void con_col(const Scratch<T, NC>& s, int d, P off, T* col) {
   const T* cd = s.cdof + 6 * d;
+  const T o[3] = {off[0], off[1], off[2]};
   T t[3];
-  cross3(t, cd, off);
+  cross3(t, cd, o);
   col[0] = cd[3] + t[0]; col[1] = cd[4] + t[1]; col[2] = cd[5] + t[2];
 }
 
@@ -2534,7 +2567,7 @@ DEVFN void J_times_gen(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCRE
         val = lim_sign<T>(s.lim_id[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
-        const ContactRec<T>& c = s.con[ci];
+        const auto& c = CON(s, ci);
         T v1[3], v2[3];
         point_vel(bv, con_b1(c), c.r1, v1);
         point_vel(bv, con_b2(c), c.r2, v2);
@@ -2571,7 +2604,7 @@ DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v
         val = lim_sign<T>(s.lim_id[r]) * acc;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
-        const ContactRec<T>& c = s.con[ci];
+        const auto& c = CON(s, ci);
         T v1[3], v2[3];
         point_vel(bv, con_b1(c), c.r1, v1);
         point_vel(bv, con_b2(c), c.r2, v2);
@@ -2635,7 +2668,7 @@ DEVFN void J_times2(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T
         vala = lim_sign<T>(s.lim_id[r]) * acca; valb = lim_sign<T>(s.lim_id[r]) * accb;
       } else {
         const int ci = (r - nlim) >> 2, e = (r - nlim) & 3;
-        const ContactRec<T>& c = s.con[ci];
+        const auto& c = CON(s, ci);
         T v1[3], v2[3];
         point_vel(bva, con_b1(c), c.r1, v1);
         point_vel(bva, con_b2(c), c.r2, v2);
@@ -2675,7 +2708,7 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
   const int nl = s.nl, nlim = s.nl + s.ntl, ncon = s.ncon, nrot = M.any_rot;      // any_rot: the model has condim 4 / 6 pairs (wave-uniform)
   PHASE {
     for (int ci = lane; ci < ncon; ci += 64) {
-      const ContactRec<T>& c = s.con[ci];
+      const auto& c = CON(s, ci);
       const T* fe = f + nlim + 4 * ci;
       const T fn = fe[0] + fe[1] + fe[2] + fe[3], fa = c.muA * (fe[0] - fe[1]), fb = c.muB * (fe[2] - fe[3]);      // (padding rows carry no force)
       T t2[3], fr[6];
@@ -2728,7 +2761,7 @@ DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, L
     for (int r = lane; r < nl; r += 64) lds_add(&out[lim_index(s.lim_id[r])], lim_sign<T>(s.lim_id[r]) * f[r]);      // a joint row moves one dof
     const int e = lane & 15;
     for (int ci = lane >> 4; ci < ncon; ci += 4) {
-      const ContactRec<T>& c = s.con[ci];
+      const auto& c = CON(s, ci);
       if (e < con_nsup(c)) {
         const int sd = c.sup[e];
         const int d = con_sup_dof(sd), on1 = con_sup_on1(sd), on2 = con_sup_on2(sd);
@@ -2866,7 +2899,7 @@ DEV void efc_reference(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       const int nlim_ = s.nl + s.ntl;
       for (int r = lane; r < s.nefc; r += 64) {
         const T Bc = S_ROW_B(s)[r], kp = S_ROW_KIP(s)[r];      // (left in the row's own entries by the lane that built the row)
-        const bool pad = gen && r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3);
+        const bool pad = gen && r >= nlim_ && con_pad(con_kind(CON(s, (r - nlim_) >> 2)), (r - nlim_) & 3);
         S_AREF(s)[r] = pad ? (T)-1 : -Bc * s.efc_jv[r] - kp;       // a padding row: J = 0, so J a - aref = 1 > 0, never active
       }
     }
@@ -3210,8 +3243,8 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     PHASE {
       // ---- stage A for contact ci+1
       const int cn = ci + 1;
-      if (cn < ncon && lane < con_nsup(s.con[cn])) {
-        const ContactRec<T>& c = s.con[cn];
+      if (cn < ncon && lane < con_nsup(CON(s, cn))) {
+        const auto& c = CON(s, cn);
         const int sd = c.sup[lane];
         const int d = con_sup_dof(sd), on2 = con_sup_on2(sd), on1 = con_sup_on1(sd);
         T col[3];
@@ -3234,7 +3267,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
       }
       // ---- stage B for contact ci (its columns were staged in the previous trip)
       if (ci >= 0) {
-        const ContactRec<T>& c = s.con[ci];
+        const auto& c = CON(s, ci);
         const unsigned char* act = s.efc_active + nlim + 4 * ci;
         T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
         if (act[0]) { nn += 1; n1 += c.muA; a11 += c.muA * c.muA; }
@@ -3242,7 +3275,8 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         if (act[2]) { nn += 1; n2 += c.muB; a22 += c.muB * c.muB; }
         if (act[3]) { nn += 1; n2 -= c.muB; a22 += c.muB * c.muB; }
         if (nn != 0) {
-          const T A0 = c.D * nn, A1 = c.D * n1, A2 = c.D * n2, A3 = c.D * a11, A4 = c.D * a22;
+          const T cD = CON_D(s, ci);
+          const T A0 = cD * nn, A1 = cD * n1, A2 = cD * n2, A3 = cD * a11, A4 = cD * a22;
           const int ns = con_nsup(c);
           const T* jc = stage + (ci & 1) * (MYO_CS_MAX * 4);
           const int npair = ns * (ns + 1) / 2;

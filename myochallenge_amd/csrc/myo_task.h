@@ -466,7 +466,13 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
   WAVE_FN
   if constexpr (sizeof(T) == sizeof(HP)) {      // fp64 stepper: warm start and controls stay in global memory (ScratchPoses<double>)
     // (the workspace of the hardware wave slot this workgroup runs in: myo_wave_slot, wave.h; MYO_WS_* in myo_physics.h)
-    PHASE { if (lane == 0) { s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + (size_t)myo_wave_slot(env) * MYO_ENVWS_N; s.tenj_g = s.ctrl_g + MYO_NU_MAX; } }
+    PHASE {
+      if (lane == 0) {
+        const size_t wsi = (size_t)myo_ws_index(K.slot_map, env, K.health);
+        s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + wsi * MYO_ENVWS_N; s.tenj_g = s.ctrl_g + MYO_NU_MAX;
+        if constexpr (Scratch<T, NC>::SPILL) s.big_g = K.big_ws + wsi * MYO_BIGWS_BYTES;      // (contact records, wrap results: CON / S_TWRES)
+      }
+    }
   }
   PHASE { if (lane == 0) s.pub = pub; }
   SYNC();
@@ -705,7 +711,7 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       int k = 0;                              //  the dump lists MuJoCo's rows)
       const int nlim_ = s.nl + s.ntl;
       for (int r = 0; r < s.nefc; ++r) {
-        if (r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3)) continue;
+        if (r >= nlim_ && con_pad(con_kind(CON(s, (r - nlim_) >> 2)), (r - nlim_) & 3)) continue;
         out[D.efc_aref + k++] = (double)S_AREF(s)[r];
       }
     }
@@ -732,9 +738,9 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
       // contacts and rows as MuJoCo counts them: a contact's first slot is kind 0 or 3, padding rows do not exist
       const int nlim_ = s.nl + s.ntl;
       int nc = 0, k = 0;
-      for (int ci = 0; ci < s.ncon; ++ci) { const int kd = con_kind(s.con[ci]); nc += (kd == 0 || kd == 3); }
+      for (int ci = 0; ci < s.ncon; ++ci) { const int kd = con_kind(CON(s, ci)); nc += (kd == 0 || kd == 3); }
       for (int r = 0; r < s.nefc; ++r) {
-        if (r >= nlim_ && con_pad(con_kind(s.con[(r - nlim_) >> 2]), (r - nlim_) & 3)) continue;
+        if (r >= nlim_ && con_pad(con_kind(CON(s, (r - nlim_) >> 2)), (r - nlim_) & 3)) continue;
         out[D.efc_D + k++] = (double)row_D(s, r, nlim_);
       }
       out[D.counts] = nc; out[D.counts + 1] = k; out[D.counts + 2] = s.solver_iter; out[D.counts + 3] = s.nl;

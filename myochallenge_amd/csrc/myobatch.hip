@@ -564,7 +564,7 @@ static int model_from_blob_impl(const void* blob, size_t nbytes, myo_model** out
   typedef Scratch<double, MYO_NCON_BIG> ScratchDB;
   // (... and not beyond efc_jv, where that stepper accumulates the tendon moment arms meanwhile)
   LIM(7 * (size_t)m->ngw * sizeof(double) > offsetof(ScratchD, efc_jv) - offsetof(ScratchD, con) ||
-      7 * (size_t)m->ngw * sizeof(double) > offsetof(ScratchDB, efc_jv) - offsetof(ScratchDB, con) ||
+      m->ngw > MYO_BIGWS_GW ||                     /* (the 48-slot fp64 scratch: in the big workspace, TaskDev::big_ws) */
       ((3 * (size_t)m->nwrap * sizeof(float) + 7) & ~(size_t)7) + 7 * (size_t)m->ngw * sizeof(double) >
           offsetof(Scratch<float>, rk) - offsetof(Scratch<float>, con), "tendon path elements / wrap geoms (staging area of the tendon stage)")
   m->actuator_tendon.resize(m->nu);
@@ -853,6 +853,7 @@ struct myo_batch {
   double ms_sum;
   int ms_cnt;
   bool has_slot_ws = false;    // K.ctrl_ws is the device's shared wave-slot workspace (slot_workspace_acquire / _release)
+  bool has_big_ws = false;     // ... and K.big_ws its block of the 48-slot fp64 scratch's records / wrap results
 #ifndef MYO_EMU
   hipEvent_t ev0, ev1;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
@@ -868,30 +869,59 @@ struct myo_batch {
 struct BoundDev { const myo_batch* b = nullptr; hipStream_t last = nullptr; bool have_last = false; hipEvent_t ev = nullptr; };
 static BoundDev g_bound[MYO_MAX_DEVICES];
 static std::mutex g_bound_mu;
-// The wave slots' workspaces (TaskDev::ctrl_ws, myo_physics.h): MYO_WAVE_SLOTS x MYO_ENVWS_N doubles (~0.5 GB of the 288) per DEVICE, shared by
-// every fp64 batch on it — a workspace belongs to a hardware wave slot, so kernels of different batches, even on different streams, never
-// meet in one.  Allocated with the first such batch, freed with the last.
-struct SlotWs { double* p = nullptr; int users = 0; };
+// The wave slots' workspaces (TaskDev::ctrl_ws, myo_physics.h): MYO_WS_SLOTS x MYO_ENVWS_N doubles (~60 MB) and the map from the hardware
+// slot code to the dense workspace index (myo_ws_index, wave.h) per DEVICE, shared by every fp64 batch on it — a workspace belongs to a
+// hardware wave slot, so kernels of different batches, even on different streams, never meet in one.  Allocated with the first such
+// batch, freed with the last.
+struct SlotWs { double* p = nullptr; int* map = nullptr; int users = 0; char* big = nullptr; int big_users = 0; };
 static SlotWs g_slot_ws[MYO_MAX_DEVICES];
-static double* slot_workspace_acquire(int device) {
-  if (device < 0 || device >= MYO_MAX_DEVICES) return nullptr;
+static bool slot_workspace_acquire(int device, double** ws, int** map) {
+  if (device < 0 || device >= MYO_MAX_DEVICES) return false;
   std::lock_guard<std::mutex> lk(g_bound_mu);
   SlotWs& w = g_slot_ws[device];
   if (!w.p) {
-    void* q = nullptr;
-    const size_t bytes = sizeof(double) * (size_t)MYO_WAVE_SLOTS * MYO_ENVWS_N;
-    if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
-    if (hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(q); return nullptr; }
-    w.p = (double*)q; w.users = 0;
+    void *q = nullptr, *mp = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)MYO_WS_SLOTS * MYO_ENVWS_N, mbytes = sizeof(int) * ((size_t)MYO_WAVE_SLOTS + 1);
+    if (hipMalloc(&q, bytes) != hipSuccess) return false;
+    if (hipMalloc(&mp, mbytes) != hipSuccess) { (void)hipFree(q); return false; }
+    if (hipMemset(q, 0, bytes) != hipSuccess || hipMemset(mp, 0xff, mbytes) != hipSuccess ||                       // (map: -1 = not assigned)
+        hipMemset((char*)mp + sizeof(int) * (size_t)MYO_WAVE_SLOTS, 0, sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipFree(q); (void)hipFree(mp);
+      return false;
+    }
+    w.p = (double*)q; w.map = (int*)mp; w.users = 0;
   }
   w.users++;
-  return w.p;
+  *ws = w.p; *map = w.map;
+  return true;
 }
 static void slot_workspace_release(int device) {
   if (device < 0 || device >= MYO_MAX_DEVICES) return;
   std::lock_guard<std::mutex> lk(g_bound_mu);
   SlotWs& w = g_slot_ws[device];
-  if (w.users > 0 && --w.users == 0) { (void)hipFree(w.p); w.p = nullptr; }
+  if (w.users > 0 && --w.users == 0) { (void)hipFree(w.p); (void)hipFree(w.map); w.p = nullptr; w.map = nullptr; }
+}
+// ... and the blocks of the 48-slot fp64 scratch (TaskDev::big_ws: contact records + wrap results, MYO_BIGWS_BYTES per dense slot index,
+// ~200 MB): allocated with the first batch that needs them (a die, extended collision pairs, condim 4 / 6), freed with the last
+static char* big_workspace_acquire(int device) {
+  if (device < 0 || device >= MYO_MAX_DEVICES) return nullptr;
+  std::lock_guard<std::mutex> lk(g_bound_mu);
+  SlotWs& w = g_slot_ws[device];
+  if (!w.big) {
+    void* q = nullptr;
+    const size_t bytes = (size_t)MYO_WS_SLOTS * MYO_BIGWS_BYTES;
+    if (hipMalloc(&q, bytes) != hipSuccess) return nullptr;
+    if (hipMemset(q, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(q); return nullptr; }
+    w.big = (char*)q; w.big_users = 0;
+  }
+  w.big_users++;
+  return w.big;
+}
+static void big_workspace_release(int device) {
+  if (device < 0 || device >= MYO_MAX_DEVICES) return;
+  std::lock_guard<std::mutex> lk(g_bound_mu);
+  SlotWs& w = g_slot_ws[device];
+  if (w.big_users > 0 && --w.big_users == 0) { (void)hipFree(w.big); w.big = nullptr; }
 }
 // every launch entry point runs on the batch's own device, whatever the caller's current device is
 struct DeviceGuard {
@@ -1130,9 +1160,18 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
     rc |= be_malloc(&w, sizeof(double) * (size_t)n_envs * MYO_ENVWS_N);
     b->K.ctrl_ws = (double*)w;
     if (w) b->allocs.push_back(w);
+    if (b->ncap > MYO_NCON_MAX) {
+      void* g = nullptr;
+      rc |= be_malloc(&g, (size_t)n_envs * MYO_BIGWS_BYTES);
+      b->K.big_ws = (char*)g;
+      if (g) b->allocs.push_back(g);
+    }
 #else
-    b->K.ctrl_ws = slot_workspace_acquire(device);
-    if (!b->K.ctrl_ws) rc |= (int)hipErrorOutOfMemory; else b->has_slot_ws = true;
+    if (!slot_workspace_acquire(device, &b->K.ctrl_ws, &b->K.slot_map)) rc |= (int)hipErrorOutOfMemory; else b->has_slot_ws = true;
+    if (!rc && b->ncap > MYO_NCON_MAX) {           // the 48-slot scratch keeps its contact records and wrap results in global memory (Scratch::SPILL)
+      b->K.big_ws = big_workspace_acquire(device);
+      if (!b->K.big_ws) rc |= (int)hipErrorOutOfMemory; else b->has_big_ws = true;
+    }
 #endif
   }
   b->K.objf_off = b->L.off_objfric - b->L.off_warm;      // (Scratch::SPILL reads the object group's friction in the record)
@@ -1212,6 +1251,7 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
     for (void* q : b->allocs) be_free(q);
 #ifndef MYO_EMU
     if (b->has_slot_ws) slot_workspace_release(device);
+    if (b->has_big_ws) big_workspace_release(device);
 #endif
     delete b;
     return r2;
@@ -1228,6 +1268,7 @@ extern "C" void myo_batch_destroy(myo_batch* b) {
   for (auto& pr : b->pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
   if (b->has_slot_ws) { (void)hipDeviceSynchronize(); slot_workspace_release(b->device); }
+  if (b->has_big_ws) big_workspace_release(b->device);
 #endif
   for (void* q : b->allocs) be_free(q);
   delete b;

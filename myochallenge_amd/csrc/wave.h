@@ -70,6 +70,7 @@ static inline void myo_max(int* p, int v) { if (v > *p) *p = v; }
 static inline void st_pub(double* p, double v, int wt) { (void)wt; *p = v; }
 #define MYO_WAVE_SLOTS_EMU 0
 static inline unsigned myo_wave_slot(int env) { return (unsigned)env; }      /* the emulation keeps one workspace per env */
+static inline int myo_ws_index(int* map, int env, int* health) { (void)map; (void)health; return env; }
 static inline int myo_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #else
@@ -227,6 +228,22 @@ __device__ __forceinline__ void myo_max(int* p, int v) { atomicMax(p, v); }
 __device__ __forceinline__ unsigned myo_wave_slot(int) {
   const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
   return ((xcc & 7u) << 14) | (((hw >> 8) & 0xffu) << 6) | (hw & 0x3fu);
+}
+// The slot's WORKSPACE index: the 17-bit slot code is sparse (a chip has <= 256 CUs x 4 SIMDs x 10 wave buffers of it), so the device
+// keeps a map code -> dense index, filled on first use (map[MYO_WAVE_SLOTS] is the next free index; a code is only ever looked up by
+// the one wavefront that occupies the slot, so filling it needs no more than the counter's atomic), and the workspaces are sized for
+// MYO_WS_SLOTS dense indices (0.5 GB -> 60 MB a device).  A chip with more live slots than that would share workspaces: counted as a
+// protocol error (health[0]) — never silent.
+#define MYO_WS_SLOTS 16384
+__device__ __forceinline__ int myo_ws_index(int* map, int, int* health) {
+  const unsigned code = myo_wave_slot(0);
+  int id = __hip_atomic_load(map + code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (id < 0) {
+    id = atomicAdd(map + MYO_WAVE_SLOTS, 1);
+    __hip_atomic_store(map + code, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (id >= MYO_WS_SLOTS) { if (health) atomicAdd(health, 1); id &= MYO_WS_SLOTS - 1; }
+  return id;
 }
 __device__ __forceinline__ int myo_popcll(unsigned long long x) { return __popcll(x); }
 __device__ __forceinline__ int myo_ffsll(unsigned long long x) { return __ffsll((long long)x) - 1; }

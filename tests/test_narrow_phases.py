@@ -319,7 +319,7 @@ def case_many_contacts(lib, dtype, tol):
     b2.close()
     n = 2
     b = native.Batch(native.Model(cm, lib), None, n, 0, 0, dtype)
-    assert b.lds_bytes > 23040 or dtype != native.MYO_F64            # (the 48-slot scratch)
+    assert b.lds_bytes <= 20480                                       # (the 48-slot scratch: records in the big workspace, eight workgroups per CU)
     b.set_state(mem.arr(np.tile(q0, (n, 1))), mem.zeros((n, om.nv)), mem.zeros((n, 0)), mem.zeros(n))
     qp, qv = mem.zeros((n, om.nq)), mem.zeros((n, om.nv))
     most = 0

@@ -128,7 +128,7 @@ int myo_batch_set_step_generation(myo_batch* b, unsigned int gen);
 /* Health counters of a batch (all 0 in a healthy one; synchronises the device).
  * out[0]: k_step workgroups that found their env's hand-off state in another generation than the launch's (a failed launch,
  *         or one batch stepped from two unsynchronised streams; such a step writes nothing and flags the env in bad_state);
- * out[1]: substeps in which an env had more contacts than its scratch holds (24; 20 in the fp64 stepper; 32 for models with
+ * out[1]: substeps in which an env had more contacts than its scratch holds (24; 22 in the fp64 stepper; 48 for models with
  *         extended collision pairs or a die) — the surplus was dropped, as MuJoCo drops contacts beyond nconmax with a warning;
  * out[2]: substeps in which an env had more joint-limit / tendon-limit / friction-loss rows than the scratch's row capacity
  *         (MYO_NLIM_MAX = 56) — the surplus was dropped;

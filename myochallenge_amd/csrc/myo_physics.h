@@ -60,7 +60,7 @@ __device__ __forceinline__ constexpr int myo_hrow(int i) { const int q = i >> 2;
 #define MYO_HIDX(i, j) (myo_hrow(i) + (j)) /* i >= j */
 
 /* doubles per WAVE SLOT of TaskDev::ctrl_ws (whole 128-byte lines): the controls, the tendon moment arms [slot][tendon], the tendon
-   lengths, the activation rates and the reward terms (the last three are used by the 34-slot fp64 scratch only: Scratch::SPILL), the warm
+   lengths, the activation rates and the reward terms (the last three are used by the 48-slot fp64 scratch only: Scratch::SPILL), the warm
    start.  The workspace belongs to the HARDWARE wave slot the workgroup runs in (myo_wave_slot, wave.h), not to the env: nothing in it
    outlives a workgroup (every entry is written before it is read, load_env .. store_env), two workgroups that run at the same time sit in
    different slots by construction, and a slot's lines are only ever touched from ONE XCD — so they stay in that XCD's L2 from launch to
@@ -202,7 +202,7 @@ struct Scratch : ScratchPoses<T> {
   // (20,320 B), because its contact RECORDS (6.5 KB) and the tendon stage's wrap results (4 KB of staging that used to sit in con[])
   // live in the wave slot's block of a global workspace (TaskDev::big_ws, L2-resident: 2048 live slots x 12 KB): CON(s, ci), S_TWRES.
   // What the solver reads per ROW stays in LDS (the rows' arrays, a contact's D: conD).
-  // The 34-slot fp64 scratch keeps what a substep touches ONCE in GLOBAL memory — the object group's friction triples and the muscle
+  // (Round 5, then with 34 slots:) the big fp64 scratch keeps what a substep touches ONCE in GLOBAL memory — the object group's friction triples and the muscle
   // activations in the env record, where they live anyway; the tendon lengths, the activation rates and the reward terms in the env's
   // workspace (ctrl_ws): 1,072 B, the difference between six and seven workgroups per CU (24,064 -> 22,992 B).  Accessors: S_OBJF,
   // S_ACT / act_set, S_TEN_LENGTH, S_ACT_DOT, S_RWD below; one wave per workgroup, so a lane's global store is visible to the loads of a

@@ -7,9 +7,10 @@
 // WAVE_* reductions below.
 //
 // gfx950 build (hipcc): a workgroup is exactly one wavefront (64 threads), `lane` is
-// threadIdx.x, PHASE expands to nothing, SYNC() is a wavefront-scope fence (see below; for a single-wave
-// workgroup that is an LDS wait, no s_barrier round trip), reductions use cross-lane
-// shuffles, compaction uses 64-bit ballots.
+// threadIdx.x, PHASE expands to nothing, SYNC() is a wavefront-scope FENCE — no instruction: the
+// wavefront's LDS operations execute in program order — and SYNC_G() the drain that global-memory
+// hand-offs between lanes need (see below), reductions use DPP cross-lane adds, compaction uses
+// 64-bit ballots.
 //
 // MYO_EMU build (g++, tests only): PHASE expands to `for (lane = 0..63)`, i.e. the lanes of a
 // phase run one after another on the CPU.  This exists so the kernel SOURCE can be debugged

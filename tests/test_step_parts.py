@@ -85,7 +85,7 @@ def test_step_parts_give_the_whole_steps_bits_on_emulation(emu_lib, models, dtyp
 
 
 def test_step_parts_of_the_die_on_emulation(emu_lib):
-    """The die on the fp64 stepper (34-slot scratch: activations and object friction read and written IN the record, tendon lengths /
+    """The die on the fp64 stepper (48-slot scratch: contact records and wrap results in the wave slot's global workspace, activations and object friction read and written IN the record, tendon lengths /
     activation rates / reward terms in the env workspace — Scratch::SPILL) in parts = whole steps, through a reset."""
     from myochallenge_amd.synth_hand import synthetic_hand_die
     die = compile_model(synthetic_hand_die(), integrator=0, unsupported_contacts="drop")
@@ -132,7 +132,7 @@ def test_step_plan_generation_counter_wraps(hip_lib, models):
 @pytest.mark.gpu
 def test_step_parts_publish_forms_and_the_die_on_gpu(hip_lib, models):
     """The two ways a part hands its record on — write-through stores (the default) and round 4's agent release fence
-    (MYO_PUBLISH=fence) — give the bits of whole steps; and so does the die on the fp64 stepper, whose 34-slot scratch reads and
+    (MYO_PUBLISH=fence) — give the bits of whole steps; and so does the die on the fp64 stepper, whose 48-slot scratch reads and
     writes the activations and the object friction IN the record and keeps its tendon lengths / activation rates in the env
     workspace (Scratch::SPILL, DESIGN.md §5 item 11): frame_skip 5 = parts of 2 + 1 + 1 + 1 substeps."""
     from myochallenge_amd.synth_hand import synthetic_hand_die

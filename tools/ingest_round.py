@@ -8,7 +8,7 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 R, P = os.path.join(ROOT, "gpurun_out", "round"), os.path.join(ROOT, "profiles")
-TAG = os.environ.get("ROUND", "r05")
+TAG = os.environ.get("ROUND", "r06")
 
 
 def main():
@@ -44,7 +44,7 @@ def main():
                  ("pmc_kstep_whole_steps.txt", TAG + "_pmc_kstep_whole_steps.txt"), ("train_demo_p1_100m_f64.json", TAG + "_train_demo_p1_100m_f64.json"),
                  ("train_demo_reorient_lstm256_40m.json", TAG + "_train_demo_reorient_lstm256_40m.json"),
                  ("pmc_kstep_publish_fence.txt", TAG + "_pmc_kstep_publish_fence.txt"), ("config_e_kernel_stats.csv", TAG + "_config_e_kernel_stats.csv"),
-                 ("lstm_seq_time.txt", TAG + "_lstm_seq_time.txt")):
+                 ("lstm_seq_time.txt", TAG + "_lstm_seq_time.txt"), ("pmc_instruction_mix_f64.txt", TAG + "_pmc_instruction_mix_f64.txt")):
         if os.path.exists(os.path.join(R, a)):
             shutil.copy(os.path.join(R, a), os.path.join(P, b))
     out = {}

@@ -42,6 +42,14 @@ for set in "FETCH_SIZE" "WRITE_SIZE"; do
 done
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants > $OUT/bench_publish_fence.json 2>/dev/null
 unset MYO_PUBLISH
+# 3a''. dynamic instruction classes of k_step<double> (fp64 / fp32 / integer / the rest = moves, selects, compares,
+#       cross-lane; LDS / scalar / branch counts) — one pass per set
+: > $OUT/pmc_instruction_mix_f64.txt
+for set in "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_TRANS_F32" "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU" "SQ_INST_CYCLES_VMEM SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_WAVE_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_BRANCH" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH_LEVEL"; do
+  rm -rf /tmp/pmc
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
+  python3 $ROOT/tools/dev/pmc_summarise.py /tmp/pmc "k_step<" >> $OUT/pmc_instruction_mix_f64.txt
+done
 # 3b. matrix-core activity of the PPO side (north_star asks for MFMA-busy against peak): hipBLASLt GEMM kernels
 rm -rf /tmp/pmc
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc -- python3 $ROOT/bench.py --no-cpu-baseline --no-variants --min-seconds 0 --steps 24 --warmup 8 > /tmp/pmc.log 2>&1
@@ -63,7 +71,7 @@ python3 $ROOT/bench.py --no-cpu-baseline --no-variants --integrator rk4 > $OUT/b
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoBaodingBallsP2 --envs 8192 > $OUT/bench_p2_8192.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --no-ppo > $OUT/bench_rollout_only.json 2>/dev/null
 python3 $ROOT/bench.py --no-cpu-baseline --no-variants --env-name CustomMyoReorientP2 > $OUT/bench_reorient_p2.json 2>/dev/null
-python3 $ROOT/tools/bench_reorient.py > $OUT/bench_reorient_lstm.json 2>/dev/null
+python3 $ROOT/tools/bench_reorient.py > $OUT/bench_reorient_lstm.json 2>/dev/null      # the light setting (32-step rollouts, 4 epochs), fp64 since round 6
 python3 $ROOT/tools/bench_reorient.py --reference-settings --iters 6 > $OUT/bench_reorient_lstm_reference.json 2>/dev/null   # n_steps 128, n_epochs 10, fp64 (src/main_reorient.py:53-71)
 MYO_LSTM_SEQ=0 python3 $ROOT/tools/bench_reorient.py --reference-settings --iters 4 > $OUT/bench_reorient_lstm_reference_step_kernels.json 2>/dev/null   # the same with one launch per LSTM time step
 rm -rf /tmp/prof_cfge

@@ -210,6 +210,15 @@ int myo_batch_object_friction(myo_batch* b, const double* set_fric, double* get_
  * process may have launched since (no-op if this batch is still the bound one). */
 int myo_batch_bind_constants(myo_batch* b, void* stream);
 
+/* Order of the tendon stage's geom wraps (sphere / cylinder wraps; the solver runs 64 of them per pass and a pass none of whose wraps
+ * engages skips its tangent solve): counts which wraps engage in the envs' PRESENT states and sorts the batch's wrap order by it, so
+ * that the wraps that rarely engage share the last pass.  Runs by itself: after a myo_batch_reset of all envs (mask = NULL), 16
+ * myo_batch_step calls later, then every 256 calls (not while the stream is being captured); a caller may also run it between any
+ * two steps — two small kernels on the stream, no host synchronisation, safe beside captured graphs of steps (the tables are
+ * rewritten in place).  No result bit depends on the order.  No-op for models with at
+ * most 64 geom wraps, and with MYO_NO_WRAP_ORDER set in the environment when the batch is made (A/B switch). */
+int myo_batch_tune_wrap_order(myo_batch* b, void* stream);
+
 /* forward dynamics of the current state with intermediates dumped for stage-wise parity
  * tests: out is dev double[N, myo_batch_dump_size()] ; layout by myo_batch_dump_offset(name).
  * names: ten_length ten_J(nt*nv) M(nv*nv) qfrc_bias qfrc_passive qfrc_actuator qacc_smooth

@@ -1230,7 +1230,7 @@ template <typename T, int NC>
 DEV void mul_M(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LREF(T) out_r, LCREF(T) v_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   T* out = LPTR(T, out_r); const T* v = LPTR(const T, v_r);
-  WAVE_FN
+  WAVE_FN_K
   PHASE {
     const int i = lane;
     if (i < M.nv) {
@@ -1259,7 +1259,7 @@ DEV void mul_M(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LREF(T) out_
 template <typename T, int NC>
 DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, const T* diag_add, T diag_scale, int perm = 0) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   PHASE {
     // flat clear with 16-byte stores
     struct alignas(16) Q4 { T a, b, c, d; };
@@ -1292,7 +1292,7 @@ DEV void load_H_from_M(const DevModel<T>& M_in, Scratch<T, NC>& s_in, const T* d
 // in-place Cholesky of the packed lower triangle (right-looking; lanes tile the trailing block)
 template <typename T, int NC>
 DEV void chol_factor(Scratch<T, NC>& s, int n) {
-  WAVE_FN
+  WAVE_FN_K
   for (int k = 0; k < n; ++k) {
     PHASE {
       // every lane derives the pivot; lanes k+1.. scale their column entry
@@ -1318,7 +1318,7 @@ DEV void chol_factor(Scratch<T, NC>& s, int n) {
 // solve L L' x = b in place (x in scratch vector)
 template <typename T, int NC>
 DEV void chol_solve(Scratch<T, NC>& s, T* x, int n) {
-  WAVE_FN
+  WAVE_FN_K
   for (int k = 0; k < n; ++k) {
     PHASE {
       const T xk = x[k] / s.H[MYO_HIDX(k, k)];
@@ -2281,7 +2281,7 @@ DEV void pair_keep_included(const DevModel<T>& M, int g1, int g2, HP margin, Con
 template <typename T, int NC>
 DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int pbase, LANE_ARG(ContactTmp, ct), int& ncon) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   int total = 0;
   const int base = pbase;
   // contact slots this substep can hold: the record slots, and what the limit rows leave of the constraint-row arrays (four rows a slot)
@@ -2342,7 +2342,7 @@ DEV void contacts_emit_c3(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<
 template <typename T, int NC>
 DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, int pbase, LANE_ARG(ContactTmp, ct), int& ncon) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   int total = 0;
   const int base = pbase;
   // contact slots this substep can hold: the record slots, and what the limit rows leave of the constraint-row arrays (four rows a slot)
@@ -2426,7 +2426,7 @@ DEV void contacts_emit_gen(const DevModel<T>& M_in, const TaskDev& K_in, Scratch
 template <typename T, int NC>
 DEV void contacts_clamp(const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_K MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   const int nlim = s.nl + s.ntl, ncon = s.ncon;
   const int cap = tmin((int)Scratch<T, NC>::NREC, (MYO_NLIM_MAX + 4 * NC - nlim) >> 2);
   if (ncon > cap) {
@@ -2512,7 +2512,7 @@ template <typename T, int NC>
 DEV void body_vectors(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* v = LPTR(const T, v_r); T* out = LPTR(T, out_r);
-  WAVE_FN
+  WAVE_FN_K
   PHASE {
     const int b = lane;
     if (b < M.nbody) {
@@ -2587,7 +2587,7 @@ template <typename T, int NC>
 DEV void J_times(const DevModel<T>& M_in, const Scratch<T, NC>& s_in, LCREF(T) v_r, LCREF(T) bv_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* v = LPTR(const T, v_r); const T* bv = LPTR(const T, bv_r); T* out = LPTR(T, out_r);
-  WAVE_FN
+  WAVE_FN_K
   const int nl = s.nl, nlim = s.nl + s.ntl, nefc = s.nefc;
   if (M.any_gen) { J_times_gen(M, s, v_r, bv_r, out_r); return; }     // (scalar branch: the flag lives in constant memory)
   PHASE {
@@ -2704,7 +2704,7 @@ template <typename T, int NC>
 DEV void JT_times(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) f_r, LREF(T) out_r) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   const T* f = LPTR(const T, f_r); T* out = LPTR(T, out_r);
-  WAVE_FN
+  WAVE_FN_K
   const int nl = s.nl, nlim = s.nl + s.ntl, ncon = s.ncon, nrot = M.any_rot;      // any_rot: the model has condim 4 / 6 pairs (wave-uniform)
   PHASE {
     for (int ci = lane; ci < ncon; ci += 64) {
@@ -2891,7 +2891,7 @@ DEVFN void fwd_velocity(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
 template <typename T, int NC>
 DEV void efc_reference(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   if (s.nefc > 0) {
     J_times(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)), LOFF(s, s.efc_jv));
     const int gen = M.any_gen;
@@ -3152,7 +3152,7 @@ template <typename T, int NC>
 DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // inlined into the solver loop (kernel level): JT_times stays a leaf call
   MYO_BIND_M(T) MYO_BIND_S(T)
   // forces / active set from jar, cost, qfrc_constraint, gradient
-  WAVE_FN
+  WAVE_FN_K
   const int nefc = s.nefc, nlim = s.nl + s.ntl;
   PHASE {
     for (int r = lane; r < nefc; r += 64) {
@@ -3184,7 +3184,7 @@ DEV HP update_constraint(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {   // i
 template <typename T, int NC>
 DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   // (the caller has loaded M into H: load_H_from_M is called from kernel level so that this function stays a leaf)
   const int nl = s.nl, nlim = s.nl + s.ntl;
   // joint-limit rows touch one diagonal entry each: lanes = rows, LDS adds (a dof's lower and upper limit row — or its friction-loss
@@ -3306,7 +3306,7 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
 template <typename T, int NC>
 DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   const int nv = M.nv, nefc = s.nefc;
   // ---- warm start: cheaper of qacc_warmstart and qacc_smooth.  The warm start is fetched into qacc, where the chosen vector ends up anyway
   PHASE { const int c = lane; if (c < nv) s.qacc[c] = warm_get(s, c); }
@@ -3448,7 +3448,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
 template <typename T, int NC>
 DEV void fwd_acceleration(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   PHASE { const int c = lane; if (c < M.nv) s.qacc_smooth[c] = s.qfrc_smooth[c]; }
   SYNC();
   solve_M(M, s, s.qacc_smooth, 0);
@@ -3514,7 +3514,7 @@ DEV void integrate_pos(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) v
   // vel_r = null: the (HP) velocity state itself; otherwise a T vector (RK4 stage combination)
   const T* velT = LISNULL(vel_r) ? (const T*)0 : LPTR(const T, vel_r);
   const HP h = h_in;
-  WAVE_FN
+  WAVE_FN_K
   PHASE {
     const int j = lane;
     if (j < M.njnt) {
@@ -3546,7 +3546,7 @@ DEV void advance(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) act_dot
   const bool own_rates = LISNULL(act_dot_r);                                            // (null: the scratch's own, S_ACT_DOT)
   const T* act_dot = own_rates ? (const T*)0 : LPTR(const T, act_dot_r);
   const T* qacc = LPTR(const T, qacc_r);
-  WAVE_FN
+  WAVE_FN_K
   const HP h = M.h_timestep;
   PHASE {
     const int i = lane;
@@ -3565,7 +3565,7 @@ DEV void advance(const DevModel<T>& M_in, Scratch<T, NC>& s_in, LCREF(T) act_dot
 template <typename T, int NC>
 DEV void check_state(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int check_acc) {
   MYO_BIND_M(T) MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   // mj_checkPos / mj_checkVel / mj_checkAcc: any non-finite or huge entry marks the env bad.  No reduction:
   // every lane tests its own entries and stores the flag itself (all writers store 1; the flag is read
   // after later barriers, at the end of the env step).
@@ -3585,7 +3585,7 @@ DEV void check_state(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int check_ac
 template <typename T, int NC>
 DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   check_state(M, s, 0);
   forward(M, K, s);
   check_state(M, s, 1);

@@ -213,7 +213,7 @@ template <typename T, int NC>
 DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, const float* action /* may be null = zeros */,
                         int k_lo = 0, int k_hi = -1) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   PHASE {
     if (lane == 0 && K.kind != MYO_TASK_REORIENT_K && k_lo == 0) {
       if (s.which_task != 0) {
@@ -463,7 +463,7 @@ DEV void task_reset(const DevModel<T>& M, const TaskDev& K, Scratch<T, NC>& s, i
 template <typename T, int NC>
 DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, Scratch<T, NC>& s_in, int env, int pub = 0) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   if constexpr (sizeof(T) == sizeof(HP)) {      // fp64 stepper: warm start and controls stay in global memory (ScratchPoses<double>)
     // (the workspace of the hardware wave slot this workgroup runs in: myo_wave_slot, wave.h; MYO_WS_* in myo_physics.h)
     PHASE {
@@ -508,7 +508,7 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
 template <typename T, int NC>
 DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordLayout L, double* rec, const Scratch<T, NC>& s_in, int mid_step = 0) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
-  WAVE_FN
+  WAVE_FN_K
   // mid_step: 1 = the step goes on in another call (its state so far: `bad` is kept; the per-episode draws — ball / object data — have
   // not changed since load_env and are not stored again); | 2 = ... in another workgroup of this launch: write-through stores (st_pub,
   // wave.h); | 4 = this call did not start the step either: the task state (targets, counters) is as loaded
@@ -549,7 +549,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                   float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int k_lo = 0, int k_hi = -1, int pub = 0) {
   // pub: this call ends inside the step and another workgroup of the launch takes the record over (write-through stores, wave.h)
-  WAVE_FN
+  WAVE_FN_K
   const int nobs = task_nobs(K, M.na);
   load_env(M, K, L, rec, s, env, pub);
   task_step_core(M, K, s, act + (size_t)env * M.nu, k_lo, k_hi);
@@ -600,7 +600,7 @@ template <typename T, int NC>
 DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                         int env, const unsigned char* mask, const float* act, float* obs, unsigned char* done_out, int row = -1) {
   // row: the env's row in act / obs / done_out (compact form, myo_batch_step_inner_idx); -1: its own index
-  WAVE_FN
+  WAVE_FN_K
   if (mask && !mask[env]) return;
   const int nobs = task_nobs(K, M.na);
   const int io = row < 0 ? env : row;
@@ -623,7 +623,7 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
 template <typename T, int NC>
 DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                    int env, const unsigned char* mask, float* obs) {
-  WAVE_FN
+  WAVE_FN_K
   if (mask && !mask[env]) return;
   const int nobs = task_nobs(K, M.na);
   load_env(M, K, L, rec, s, env);
@@ -637,7 +637,7 @@ DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout
 template <typename T, int NC>
 DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                      int env, const double* ctrl, int nsub) {
-  WAVE_FN
+  WAVE_FN_K
   load_env(M, K, L, rec, s, env);
   PHASE { for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0); }
   SYNC();
@@ -646,6 +646,26 @@ DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayo
 }
 
 // forward dynamics with intermediates exported (stage-wise parity tests)
+// Census of the geom wraps (myo_batch_reset, myo_batch_tune_wrap_order): which sphere / cylinder wraps ENGAGE in the env's present state.
+// cnt[k] counts position k of the wrap order (DevModel::gw_elem).  The wrap solver runs 64 wraps per pass in lockstep and its tangent solve
+// is skipped by a pass none of whose wraps engages; k_wrap_reorder sorts the order by these counts so that the wraps that (almost) never
+// engage — a fifth of the hand's 71 — share the last pass.  The env's record is not written.
+template <typename T, int NC>
+DEV void env_wrap_census(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s, int env, int* cnt) {
+  WAVE_FN_K
+  load_env(M, K, L, rec, s, env);
+  kinematics(M, s);
+  com_pos(M, K, s);
+  tendon(M, K, s);
+  for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);
+  auto wres = S_TWRES(s, M.nwrap);
+  PHASE {
+    for (int k = lane; k < M.ngw; k += 64)
+      if (wres[7 * k] >= (HP)0) myo_count(cnt + k);
+  }
+  SYNC();
+}
+
 struct DumpLayout {
   int ten_length, ten_J, M, qfrc_bias, qfrc_passive, qfrc_actuator, qacc_smooth, qacc, actuator_force, act_dot,
       counts, efc_aref, efc_D, site_xpos, subtree_com, xpos, total;
@@ -653,7 +673,7 @@ struct DumpLayout {
 template <typename T, int NC>
 DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                           int env, const double* ctrl, const DumpLayout& D, double* out_all) {
-  WAVE_FN
+  WAVE_FN_K
   double* out = out_all + (size_t)env * D.total;
   load_env(M, K, L, rec, s, env);
   PHASE { for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0); }

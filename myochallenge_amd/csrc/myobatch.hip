@@ -852,6 +852,8 @@ struct myo_batch {
   int timing;
   double ms_sum;
   int ms_cnt;
+  int wrap_tune_in = 16;       // steps until the next census of the wraps (myo_batch_step: 16 steps after a reset of all envs, then every 256)
+  int* wrap_cnt = nullptr;     // dev int[ngw]: engagement counts of the wrap census (k_wrap_census / k_wrap_reorder); null = one pass of wraps, nothing to order
   bool has_slot_ws = false;    // K.ctrl_ws is the device's shared wave-slot workspace (slot_workspace_acquire / _release)
   bool has_big_ws = false;     // ... and K.big_ws its block of the 48-slot fp64 scratch's records / wrap results
 #ifndef MYO_EMU
@@ -1244,6 +1246,13 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
       if (!rc) { rc |= (int)hipMemset(ps, 0, sizeof(int) * (size_t)n_envs); rc |= be_h2d(pg, zero, sizeof zero); }
       if (!rc) { b->part_state = (int*)ps; b->step_gen = (int*)pg; } else b->plan.nparts = 1;
     }
+    if (!rc && m->ngw > 64 && !getenv("MYO_NO_WRAP_ORDER")) {        // (more than one pass of the wrap solver: worth ordering, see env_wrap_census)
+      void* pw = nullptr;
+      if (!be_malloc(&pw, sizeof(int) * (size_t)m->ngw)) {
+        b->allocs.push_back(pw);
+        if (hipMemset(pw, 0, sizeof(int) * (size_t)m->ngw) == hipSuccess) b->wrap_cnt = (int*)pw;
+      }
+    }
   }
 #endif
   if (rc) {
@@ -1507,6 +1516,31 @@ __global__ void __launch_bounds__(64, 2) k_dump(EnvRecordLayout L, double* rec, 
   const int env = blockIdx.x;
   env_forward_dump<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, D, out);
 }
+template <typename T, bool RK, int NC>
+__global__ void __launch_bounds__(64, 2) k_wrap_census(EnvRecordLayout L, double* rec, int* cnt) {
+  Scratch<T, NC>& s = *reinterpret_cast<Scratch<T, NC>*>(myo_lds);
+  s.rk = rk_storage<T, RK, NC>();
+  const DevModel<T>& M = myo_cmodel<T>();
+  const TaskDev& K = c_task;
+  const int env = blockIdx.x;
+  env_wrap_census<T>(M, K, L, rec + (size_t)env * L.stride, s, env, cnt);
+}
+// ... and the order that follows from the census: positions sorted by count, most engaged first (ties keep their order), written back
+// into the batch's own tables — gw_elem[k] = path element of position k, wr_i[8 w + 6] = position of element w — and the counts
+// cleared.  One wave; ngw <= 128 (two positions per lane).  Each wrap's arithmetic is its own: the order changes no result bit.
+__global__ void __launch_bounds__(64) k_wrap_reorder(int ngw, int* cnt, int* gw_elem, int* wr_i) {
+  __shared__ int c[128], e[128];
+  const int lane = threadIdx.x;
+  for (int k = lane; k < 128; k += 64) { c[k] = k < ngw ? cnt[k] : -1; e[k] = k < ngw ? gw_elem[k] : 0; }
+  __syncthreads();
+  for (int k = lane; k < ngw; k += 64) {
+    int rank = 0;
+    for (int j = 0; j < ngw; ++j) rank += (c[j] > c[k]) || (c[j] == c[k] && j < k);
+    gw_elem[rank] = e[k];
+    wr_i[8 * e[k] + 6] = rank;
+    cnt[k] = 0;
+  }
+}
 // state gather/scatter: one thread per scalar
 __global__ void k_state(double* rec, int stride, int off, int cnt, int n, double* ext, int to_ext) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1695,6 +1729,33 @@ extern "C" int myo_batch_get_task(myo_batch* b, int32_t* task_i, double* task_d,
 #define LAUNCH_RK(b, ...) if ((b)->ncap > MYO_NCON_MAX) { constexpr int NCV = MYO_NCON_BIG; LAUNCH_RK1(b, __VA_ARGS__) } else { constexpr int NCV = MYO_NCON_MAX; LAUNCH_RK1(b, __VA_ARGS__) }
 #endif
 
+#ifndef MYO_EMU
+// census of the wraps over the envs' present states, then the new order (both on the stream: usable between any two steps, also while
+// a graph of steps exists — the tables are rewritten in place)
+static void wrap_order_launch(myo_batch* b, hipStream_t st) {
+  if (!b->wrap_cnt) return;
+  int* gw = const_cast<int*>(b->dtype == MYO_F64 ? b->Md.gw_elem.p : b->Mf.gw_elem.p);
+  int* wr = const_cast<int*>(b->dtype == MYO_F64 ? b->Md.wr_i.p : b->Mf.wr_i.p);
+  const int ngw = b->dtype == MYO_F64 ? b->Md.ngw : b->Mf.ngw;
+  LAUNCH_RK(b,
+    if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wrap_census<double, RKV, MYO_NC_D(NCV)>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, b->wrap_cnt);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wrap_census<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, b->wrap_cnt))
+  hipLaunchKernelGGL(k_wrap_reorder, dim3(1), dim3(64), 0, st, ngw, b->wrap_cnt, gw, wr);
+}
+#endif
+extern "C" int myo_batch_tune_wrap_order(myo_batch* b, void* stream) {
+  if (!b) return fail(MYO_E_ARG, "null batch");
+#ifdef MYO_EMU
+  (void)stream;
+#else
+  hipStream_t st = (hipStream_t)stream;
+  BIND_OR_RETURN(b, st)
+  wrap_order_launch(b, st);
+  LAUNCH_CHECK(b)
+#endif
+  return MYO_OK;
+}
+
 extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, void* stream) {
   if (!b) return fail(MYO_E_ARG, "null batch");
   if (!b->K.kind) return fail(MYO_E_STATE, "batch has no task layer");
@@ -1709,6 +1770,7 @@ extern "C" int myo_batch_reset(myo_batch* b, const uint8_t* mask, float* obs, vo
     if (b->dtype == MYO_F64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<double, RKV, MYO_NC_D(NCV)>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_reset<float, RKV, NCV>), dim3(b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, mask, obs))
   LAUNCH_CHECK(b)
+  if (!mask) { wrap_order_launch(b, st); b->wrap_tune_in = 16; LAUNCH_CHECK(b) }       // a reset of every env: the wrap order from the reset states, again 16 steps on
 #endif
   return MYO_OK;
 }
@@ -1736,6 +1798,12 @@ extern "C" int myo_batch_step(myo_batch* b, const float* act, float* obs, float*
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_step<float, RKV, NCV>), dim3(b->plan.nparts * b->n), dim3(64), lds_dyn(b), st, b->L, b->rec, act, obs, rew, done, trunc, term_obs, comps, ep_info, b->bad_state, b->order, b->ticks, b->part_state, b->step_gen, b->plan))
   timing_end(b, st);
   LAUNCH_CHECK(b)                 // the generation below only advances behind a k_step that was launched
+  if (b->wrap_cnt && --b->wrap_tune_in <= 0) {       // the wrap order follows the states the envs are in (env_wrap_census)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(st, &cap);
+    if (cap == hipStreamCaptureStatusNone) { wrap_order_launch(b, st); b->wrap_tune_in = 256; }      // (never baked into a captured graph of steps)
+    else b->wrap_tune_in = 1;
+  }
   if (b->order || b->step_gen) hipLaunchKernelGGL(k_step_order, dim3(1), dim3(b->order ? 1024 : 64), 0, st, (const unsigned int*)b->ticks, b->cost, b->n, b->order, b->step_gen);
   LAUNCH_CHECK(b)
 #endif

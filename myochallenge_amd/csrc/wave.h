@@ -24,6 +24,7 @@
 #ifdef MYO_EMU
 #define DEV static inline
 #define WAVE_FN
+#define WAVE_FN_K
 #define PHASE for (int lane = 0; lane < 64; ++lane)
 #define SYNC() ((void)0)
 #define SYNC_G() ((void)0)
@@ -78,6 +79,13 @@ static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #include <hip/hip_runtime.h>
 #define DEV __device__ __forceinline__
 #define WAVE_FN const int lane = threadIdx.x; (void)lane;
+// ... of the INLINED functions that make up the kernel body (the step, the substep, the Newton loop), fp64 stepper: the lane index behind
+// an empty asm, so that what is derived from it (LDS addresses, 64-bit global addresses) is computed where it is used.  Without it the
+// compiler hoists ~100 lane-derived addresses to the top of the kernel and keeps them live across every call: 28-71 VGPR spills in the
+// kernel frame, reloaded inside the Newton loop (k_step<double>: .vgpr_spill_count 28 -> 0, the die's 48-slot stepper 71 -> 0 and
+// -4.7 % kernel time; the fp32 stepper is 1.7 % slower with it, its addresses are cheaper to keep than to recompute: not pinned).
+template <bool PIN> __device__ __forceinline__ int myo_lane() { int l = threadIdx.x; if constexpr (PIN) asm volatile("" : "+v"(l)); return l; }
+#define WAVE_FN_K const int lane = myo_lane<sizeof(T) == 8>(); (void)lane;
 // A store of bytes that ANOTHER workgroup of the same launch reads after its agent-scope acquire (the parts of an env step, k_step in
 // myobatch.hip).  wt != 0: a relaxed agent-scope store = `global_store_dwordx2 ... sc1`, written through the XCD's L2, so that the
 // publishing lane needs no agent release fence (`buffer_wbl2 sc1` writes back EVERY dirty line of the XCD's L2, the other envs'

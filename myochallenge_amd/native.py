@@ -124,6 +124,7 @@ class NativeLib:
         L.myo_batch_set_bad_state_buffer.argtypes = [vp, vp]
         L.myo_batch_get_task.argtypes = [vp] * 5
         L.myo_batch_bind_constants.argtypes = [vp, vp]
+        L.myo_batch_tune_wrap_order.argtypes = [vp, vp]
         L.myo_batch_set_object_group.argtypes = [vp, i32, i32]
         L.myo_batch_object_friction.argtypes = [vp, vp, vp, vp]
         L.myo_batch_forward_dump.argtypes = [vp, vp, vp, vp]
@@ -201,7 +202,7 @@ EXPORTED_SYMBOLS = [
     "myo_model_from_blob", "myo_model_load_mjb", "myo_model_destroy", "myo_model_size", "myo_batch_create",
     "myo_batch_destroy", "myo_batch_set_step_generation", "myo_batch_health", "myo_debug_wave_slots", "myo_batch_num_envs", "myo_batch_obs_dim", "myo_batch_lds_bytes",
     "myo_batch_reset", "myo_batch_step", "myo_batch_step_inner", "myo_batch_step_inner_idx", "myo_batch_copy_envs", "myo_batch_physics_step", "myo_batch_get_state",
-    "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_forward_dump",
+    "myo_batch_set_state", "myo_batch_warmstart", "myo_batch_set_bad_state_buffer", "myo_batch_set_task", "myo_batch_get_task", "myo_batch_set_object_group", "myo_batch_object_friction", "myo_batch_bind_constants", "myo_batch_tune_wrap_order", "myo_batch_forward_dump",
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
     "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_lstm_step_supported", "myo_lstm_step_fwd", "myo_lstm_step_bwd", "myo_lstm_seq_supported", "myo_lstm_seq_fwd", "myo_lstm_seq_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_ppo_mlp_workspace_bytes", "myo_ppo_mlp_step", "myo_ppo_mlp_sqnorm_parts", "myo_adam_apply", "myo_ppo_mlp_rollout_workspace_bytes", "myo_ppo_mlp_rollout_refresh", "myo_ppo_mlp_rollout", "myo_last_error", "myo_version",
@@ -327,6 +328,11 @@ class Batch:
         """Make this batch the one whose model / task sit in __constant__ memory (needed before replaying a
         captured graph that contains this batch's launches, if other batches may have launched since)."""
         self.lib.check(self.lib.L.myo_batch_bind_constants(self.h, stream))
+
+    def tune_wrap_order(self, stream=None):
+        """Re-sort the tendon stage's geom wraps by how often they engage in the envs' present states (runs by itself after a
+        reset of all envs; two small kernels on the stream, no result depends on the order: include/myobatch.h)."""
+        self.lib.check(self.lib.L.myo_batch_tune_wrap_order(self.h, stream))
 
     def get_task(self, task_i=None, task_d=None, ball_d=None, stream=None):
         self.lib.check(self.lib.L.myo_batch_get_task(self.h, _ptr(task_i), _ptr(task_d), _ptr(ball_d), stream))

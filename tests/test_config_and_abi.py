@@ -128,6 +128,7 @@ def test_c_abi_argument_checks(emu_lib):
         (L.myo_batch_set_task, (null,) * 5),
         (L.myo_batch_set_object_group, (null, 0, 1)),
         (L.myo_batch_bind_constants, (null, null)),
+        (L.myo_batch_tune_wrap_order, (null, null)),
         (L.myo_ppo_loss_grad, (null,) * 8 + (16, 39, f(0.2), f(0.5)) + (null,) * 6 + (0, f(0.0)) + (null,) * 4),
         (L.myo_ppo_gather, (null,) * 6 + (16, 86, 39, null, 2) + (null,) * 7),
         (L.myo_bias_relu_bf16, (null, null, 2, 16, 256, null)),

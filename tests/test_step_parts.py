@@ -14,10 +14,14 @@ from myochallenge_amd.envs.config import make_task_cfg
 from myochallenge_amd.model import compile_model
 
 
-def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, horizon=4, generation=None, publish=None, overflow_ok=False):
+def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, horizon=4, generation=None, publish=None, overflow_ok=False, wrap_order=True, tune_every=0):
     """Observations, rewards, dones, terminal observations of `nsteps` steps + the final state, with MYO_STEP_SPLIT = split."""
-    old = {k: os.environ.get(k) for k in ("MYO_STEP_SPLIT", "MYO_STEP_ORDER", "MYO_PUBLISH")}
+    old = {k: os.environ.get(k) for k in ("MYO_STEP_SPLIT", "MYO_STEP_ORDER", "MYO_PUBLISH", "MYO_NO_WRAP_ORDER")}
     try:
+        if wrap_order:
+            os.environ.pop("MYO_NO_WRAP_ORDER", None)
+        else:
+            os.environ["MYO_NO_WRAP_ORDER"] = "1"       # the wraps stay in the model's order (A/B switch, include/myobatch.h)
         if split is None:
             os.environ.pop("MYO_STEP_SPLIT", None)
         else:
@@ -52,8 +56,10 @@ def _rollout(lib, cm, env_name, dtype, n, nsteps, split, order=None, seed=7, hor
     b.reset(None, obs)
     rng = np.random.RandomState(3)
     out = [mem.host(obs).copy()]
-    for _ in range(nsteps):
+    for i in range(nsteps):
         a = np.clip(rng.normal(0, 0.5, (n, 39)), -1.2, 1.2).astype(np.float32)
+        if tune_every and i % tune_every == 0:
+            b.tune_wrap_order()
         b.step(mem.arr(a, np.float32), obs, rew, done, trunc, term, comps, ep)
         out += [mem.host(x).copy() for x in (obs, rew, done, trunc, term, comps, ep)]
     qpos, qvel, act, time = mem.zeros((n, cm.size("nq"))), mem.zeros((n, cm.size("nv"))), mem.zeros((n, cm.size("na"))), mem.zeros(n)
@@ -117,6 +123,21 @@ def test_step_parts_rk4_and_full_batch_on_gpu(hip_lib, models):
     cm = compile_model(models["hand"], integrator=0)
     _same_bits(_rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 4096, 12, "0"),
                _rollout(hip_lib, cm, "CustomMyoBaodingBallsP1", native.MYO_MIXED, 4096, 12, None))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [native.MYO_F64, native.MYO_MIXED], ids=["f64", "mixed"])
+def test_wrap_order_changes_no_bit_on_gpu(hip_lib, models, dtype):
+    """The tendon stage's geom wraps are re-sorted by how often they engage (a census of the envs' states after a reset of all envs,
+    16 steps later, then every 256 steps, or when the caller asks: myo_batch_tune_wrap_order), so that the wraps that rarely engage
+    share the solver's last pass and that pass skips its tangent solve.  Each wrap's arithmetic is its own: a rollout with the
+    model's order (MYO_NO_WRAP_ORDER), one with the automatic census and one re-sorted every third step give the same bits — the
+    hand has 71 geom wraps (two passes), 24 steps cross the 16-step census and episode ends."""
+    cm = compile_model(models["hand"], integrator=0)
+    fixed = _rollout(hip_lib, cm, "CustomMyoBaodingBallsP2", dtype, 256, 24, None, wrap_order=False)
+    _same_bits(fixed, _rollout(hip_lib, cm, "CustomMyoBaodingBallsP2", dtype, 256, 24, None))
+    _same_bits(fixed, _rollout(hip_lib, cm, "CustomMyoBaodingBallsP2", dtype, 256, 24, None, tune_every=3))
+    assert any(w.dtype == np.uint8 and w.any() for w in fixed)
 
 
 @pytest.mark.gpu

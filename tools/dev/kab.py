@@ -23,7 +23,7 @@ def child(args):
     from myochallenge_amd.envs.config import make_task_cfg
     from myochallenge_amd.model import compile_model
     from myochallenge_amd.synth_hand import synthetic_hand, synthetic_hand_die
-    lib = native.load(os.path.abspath(args.child))
+    lib = native.load(os.path.abspath(args.child.split("@")[0]))
     dev = torch.device("cuda:0")
     integ = {"euler": 0, "rk4": 1}[args.integrator]
     dtype = native.MYO_F64 if args.dtype == "f64" else native.MYO_MIXED
@@ -45,6 +45,8 @@ def child(args):
     acts = [torch.clamp(torch.randn((N, 39), device=dev, generator=g) * 0.135, -1, 1) for _ in range(16)]
     for t in range(args.warm):
         b.step(acts[t % 16], obs, rew, done)
+    if args.tune:
+        b.tune_wrap_order()
     torch.cuda.synchronize()
     b.enable_timing(True)
     for t in range(args.steps):
@@ -68,6 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warm", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--tune", type=int, default=0, help="1: myo_batch_tune_wrap_order after the warm-up steps")
     ap.add_argument("--child", default=None)
     args = ap.parse_args()
     if args.child:
@@ -76,9 +79,12 @@ def main():
     for r in range(args.rounds):
         for l in args.libs:
             cmd = [sys.executable, os.path.abspath(__file__), "--child", l, "--envs", str(args.envs), "--dtype", args.dtype,
-                   "--integrator", args.integrator, "--env", args.env, "--steps", str(args.steps), "--warm", str(args.warm)]
+                   "--integrator", args.integrator, "--env", args.env, "--steps", str(args.steps), "--warm", str(args.warm), "--tune", str(args.tune)]
+            env = dict(os.environ)
+            for kv in l.split("@")[1:]:           # lib.so@NAME=VALUE: the variant runs with that environment variable
+                k, v = kv.split("=", 1); env[k] = v
             try:
-                out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
                 d = json.loads(out.stdout.strip().splitlines()[-1])
                 res[l].append(d)
                 print(f"round {r} {os.path.basename(l):40s} {d['ms']:.4f} ms  sum {d['sum']} lds {d['lds']}", flush=True)

@@ -3582,7 +3582,9 @@ DEV void check_state(const DevModel<T>& M_in, Scratch<T, NC>& s_in, int check_ac
   }
 }
 
-template <typename T, int NC>
+// RKM: the integrator when the caller knows it at compile time (the kernels' RK parameter: 1 = RK4, 0 = Euler; the other branch is
+// then not compiled), -1 = read the model's
+template <typename T, int RKM = -1, int NC>
 DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   WAVE_FN_K
@@ -3590,7 +3592,8 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
   forward(M, K, s);
   check_state(M, s, 1);
   PROF(s, 15)
-  if (M.integrator == 1) {
+  const bool rk4 = RKM < 0 ? (M.integrator == 1) : (RKM != 0);
+  if (rk4) {
     // (SYNC_G in this branch: the stage storage s.rk is reached through a generic pointer — LDS behind the scratch or global memory)
     // RK4 (mj_RungeKutta): tableau 1/2,1/2,1; weights 1/6,1/3,1/3,1/6
     const int nq = M.nq, nv = M.nv, na = M.na, nf = 2 * nv + na;

@@ -209,7 +209,7 @@ DEV int task_nobs(const TaskDev& K, int na) { return K.kind == MYO_TASK_REORIENT
 // frame_skip; the part that starts at 0 also moves the targets, every part recomputes ctrl (a pure function of the action), the
 // part that ends at frame_skip also makes observation and reward (k_hi < 0 = frame_skip).  Everything a substep hands to the
 // next one is in the env record (load_env / store_env), so the split is bit-exact.
-template <typename T, int NC>
+template <typename T, int RKM = -1, int NC>
 DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in, const float* action /* may be null = zeros */,
                         int k_lo = 0, int k_hi = -1) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
@@ -241,7 +241,7 @@ DEV void task_step_core(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T,
   }
   SYNC();
   const int k_end = (k_hi < 0 || k_hi > K.frame_skip) ? K.frame_skip : k_hi;
-  for (int k = k_lo; k < k_end; ++k) mj_step(M, K, s);
+  for (int k = k_lo; k < k_end; ++k) mj_step<T, RKM>(M, K, s);
   if (k_end < K.frame_skip) return;
   check_state(M, s, 0);            // a non-finite value produced by the LAST advance must not leave through obs / reward
   kinematics(M, s);
@@ -544,7 +544,7 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
 }
 
 // ---- the three env-level entry points (one call = one env; the kernels are thin wrappers)
-template <typename T, int NC>
+template <typename T, int RKM = -1, int NC>
 DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                   int env, const float* act, float* obs, float* rew, unsigned char* done, unsigned char* trunc,
                   float* term_obs, float* comps, float* ep_info, unsigned char* bad_state, int k_lo = 0, int k_hi = -1, int pub = 0) {
@@ -552,7 +552,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
   WAVE_FN_K
   const int nobs = task_nobs(K, M.na);
   load_env(M, K, L, rec, s, env, pub);
-  task_step_core(M, K, s, act + (size_t)env * M.nu, k_lo, k_hi);
+  task_step_core<T, RKM>(M, K, s, act + (size_t)env * M.nu, k_lo, k_hi);
   if (k_hi >= 0 && k_hi < K.frame_skip) { store_env(M, K, L, rec, s, (s.pub ? 3 : 1) | (k_lo > 0 ? 4 : 0)); return; }
   // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
   // an error of the batch: the env ends its episode with done = 1, reward 0, zero reward components except `done`,
@@ -596,7 +596,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
 // env.step(a) of the UNWRAPPED gym env for the envs selected by mask: no TimeLimit / Monitor accounting and
 // no auto-reset — the steps MixtureModelBaodingEnv.reset takes with its base policy
 // (/root/reference/src/envs/baoding.py:700-711).  done_out = the env's own `done` (ball dropped).
-template <typename T, int NC>
+template <typename T, int RKM = -1, int NC>
 DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                         int env, const unsigned char* mask, const float* act, float* obs, unsigned char* done_out, int row = -1) {
   // row: the env's row in act / obs / done_out (compact form, myo_batch_step_inner_idx); -1: its own index
@@ -605,7 +605,7 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
   const int nobs = task_nobs(K, M.na);
   const int io = row < 0 ? env : row;
   load_env(M, K, L, rec, s, env);
-  task_step_core(M, K, s, act + (size_t)io * M.nu);
+  task_step_core<T, RKM>(M, K, s, act + (size_t)io * M.nu);
   const int bad = s.bad, fall = S_RWD(s)[6] != 0 || bad;
   if (bad) {                        // blown-up env: back to a finite reset state (see env_step)
     PHASE { if (lane == 0) s.episode++; }
@@ -634,14 +634,14 @@ DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout
   store_env(M, K, L, rec, s);
 }
 
-template <typename T, int NC>
+template <typename T, int RKM = -1, int NC>
 DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout& L, double* rec, Scratch<T, NC>& s,
                      int env, const double* ctrl, int nsub) {
   WAVE_FN_K
   load_env(M, K, L, rec, s, env);
   PHASE { for (int i = lane; i < M.nu; i += 64) ctrl_set(s, i, ctrl ? (T)ctrl[(size_t)env * M.nu + i] : (T)0); }
   SYNC();
-  for (int k = 0; k < nsub; ++k) mj_step(M, K, s);
+  for (int k = 0; k < nsub; ++k) mj_step<T, RKM>(M, K, s);
   store_env(M, K, L, rec, s);
 }
 

@@ -1408,9 +1408,12 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
   __syncthreads();
 #endif
   int q = 0;                                   // first part this workgroup runs
+  int* st = nullptr;
+  unsigned base = 0;
+  int last = 1;
   if (part_state) {
-    const unsigned base = 16u * (unsigned)step_gen[0];     // (all state arithmetic is modulo 2^32: the generation counter may wrap)
-    int* st = part_state + env;
+    base = 16u * (unsigned)step_gen[0];     // (all state arithmetic is modulo 2^32: the generation counter may wrap)
+    st = part_state + env;
     int from = -1;                             // decided by lane 0: the part to start from, -1 = nothing to do
     if (threadIdx.x == 0) {
       for (;;) {
@@ -1438,8 +1441,12 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    const int last = p == nparts - 1;
-    env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, plan.k[q], last ? -1 : plan.k[p + 1], (plan.wt && !last) ? 1 : 0);
+    last = p == nparts - 1;
+  }
+  // ONE call site — the kernel holds one copy of the step: substeps k_lo .. k_hi of the frame_skip (a launch without a plan: the whole step)
+  const int k_lo = part_state ? plan.k[q] : 0, k_hi = (part_state && !last) ? plan.k[p + 1] : -1, pub = (part_state && plan.wt && !last) ? 1 : 0;
+  env_step<T, RK ? 1 : 0>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state, k_lo, k_hi, pub);
+  if (part_state) {
     // (the duration is added BEFORE the part is published: the next part's workgroup may run, and add its own, the moment it is)
     if (ticks && threadIdx.x == 0) {
       const unsigned int d = (unsigned int)(wall_clock64() - t_start) + (q > 0 ? ticks[env] : 0u);
@@ -1452,7 +1459,6 @@ __global__ void __launch_bounds__(64, 2) k_step(EnvRecordLayout L, double* rec, 
       __hip_atomic_store(st, (int)(last ? base + 16u : base + 2u * (unsigned)p + 2u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   } else {
-    env_step<T>(M, K, L, rec + (size_t)env * L.stride, s, env, act, obs, rew, done, trunc, term_obs, comps, ep_info, bad_state);
     if (ticks && threadIdx.x == 0) ticks[env] = (unsigned int)(wall_clock64() - t_start);
   }
 #ifdef MYO_WGTIME
@@ -1482,7 +1488,7 @@ __global__ void __launch_bounds__(64, 2) k_step_inner(EnvRecordLayout L, double*
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
-  env_step_inner<T>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, act, obs, done);
+  env_step_inner<T, RK ? 1 : 0>(M, K, L, rec + (size_t)env * L.stride, s, env, mask, act, obs, done);
 }
 // the same for a LIST of envs: block r steps env idx[r] (idx[r] < 0: an empty slot) with row r of act / obs / done
 template <typename T, bool RK, int NC>
@@ -1494,7 +1500,7 @@ __global__ void __launch_bounds__(64, 2) k_step_inner_idx(EnvRecordLayout L, dou
   s.rk = rk_storage<T, RK, NC>();
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
-  env_step_inner<T>(M, K, L, rec + (size_t)env * L.stride, s, env, (const unsigned char*)nullptr, act, obs, done, (int)blockIdx.x);
+  env_step_inner<T, RK ? 1 : 0>(M, K, L, rec + (size_t)env * L.stride, s, env, (const unsigned char*)nullptr, act, obs, done, (int)blockIdx.x);
 }
 template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* rec,
@@ -1504,7 +1510,7 @@ __global__ void __launch_bounds__(64, 2) k_physics(EnvRecordLayout L, double* re
   const DevModel<T>& M = myo_cmodel<T>();
   const TaskDev& K = c_task;
   const int env = blockIdx.x;
-  env_physics<T>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, nsub);
+  env_physics<T, RK ? 1 : 0>(M, K, L, rec + (size_t)env * L.stride, s, env, ctrl, nsub);
 }
 template <typename T, bool RK, int NC>
 __global__ void __launch_bounds__(64, 2) k_dump(EnvRecordLayout L, double* rec, const double* ctrl,

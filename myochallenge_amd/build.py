@@ -1,7 +1,7 @@
 """Build recipes for the native pieces (all in-tree, so the .so files travel with gpurun).
 
 * ``build_hip()``   hipcc --offload-arch=gfx950 -> myochallenge_amd/libmyobatch.so (the product)
-* ``build_emu()``   g++ -DMYO_EMU             -> tests/emu/libmyobatch_emu.so (test tooling:
+* ``build_emu()``   g++ -DMYO_EMU csrc/myobatch_emu.cpp -> tests/emu/libmyobatch_emu.so (test tooling:
                     lane-serial emulation of the kernel source, optional sanitizers)
 """
 from __future__ import annotations
@@ -12,9 +12,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["myobatch.hip", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h", "myo_mjb.h", "mjb_layout.inc",
+SOURCES = ["myobatch.hip", "myo_host.h", "myo_task.h", "myo_physics.h", "myo_model_dev.h", "wave.h", "myo_mjb.h", "mjb_layout.inc",
            "myo_ppo_mlp.h", "myo_sparse_ldl.h", "myo_arrow_chol.h", "myo_lstm_step.h", "myo_lstm_seq.h"]
 HEADERS = [os.path.join(ROOT, "include", "myobatch.h"), os.path.join(ROOT, "include", "myo_model_blob.h")]
+# the emulation build's own translation unit and backend (TEST TOOLING: nothing of it is compiled into libmyobatch.so, and it is not part
+# of source_id(), the identity of the product's sources)
+EMU_SOURCES = ["myobatch_emu.cpp", "emu_host.h"]
 
 
 def reachable_includes(entry: str = "myobatch.hip") -> set:
@@ -42,11 +45,11 @@ def source_id() -> str:
     return h.hexdigest()[:12]
 
 
-def _stale(target: str) -> bool:
+def _stale(target: str, extra=()) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    deps = [os.path.join(CSRC, s) for s in list(SOURCES) + list(extra)] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -71,9 +74,9 @@ def build_emu(force: bool = False, sanitize: bool = False) -> str:
     d = os.path.join(ROOT, "tests", "emu")
     os.makedirs(d, exist_ok=True)
     out = os.path.join(d, "libmyobatch_emu_asan.so" if sanitize else "libmyobatch_emu.so")
-    if force or _stale(out):
-        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-invalid-offsetof", "-DMYO_EMU", '-DMYO_BUILD_ID="%s"' % source_id(), "-x", "c++",
-               os.path.join(CSRC, "myobatch.hip"), "-o", out]
+    if force or _stale(out, EMU_SOURCES):
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-invalid-offsetof", "-DMYO_EMU", '-DMYO_BUILD_ID="%s"' % source_id(),
+               os.path.join(CSRC, "myobatch_emu.cpp"), "-o", out]
         if sanitize:
             cmd[1:1] = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
         subprocess.check_call(cmd)

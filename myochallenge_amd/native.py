@@ -133,6 +133,8 @@ class NativeLib:
         L.myo_batch_kernel_ms.argtypes = [vp]
         L.myo_batch_kernel_ms.restype = dbl
         L.myo_batch_enable_timing.argtypes = [vp, i32]
+        if b"MYO_EMU" in L.myo_version():
+            return      # the emulation build (test tooling, csrc/emu_host.h) implements the env path only: ENV_PATH_SYMBOLS
         L.myo_ppo_loss_grad.argtypes = [vp] * 8 + [i32, i32, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, i32, C.c_float, vp, vp, vp, vp]
         L.myo_ppo_gather.argtypes = [vp] * 6 + [i32, i32, i32, vp, i32] + [vp] * 7
         L.myo_bias_relu_bf16.argtypes = [vp, vp, i32, i32, i32, vp]
@@ -206,6 +208,17 @@ EXPORTED_SYMBOLS = [
     "myo_batch_dump_size", "myo_batch_dump_offset", "myo_batch_kernel_ms",
     "myo_batch_enable_timing", "myo_ppo_loss_grad", "myo_ppo_gather", "myo_bias_relu_bf16", "myo_rollout_policy_input", "myo_rollout_sample",
     "myo_vecnorm_step", "myo_rollout_sample_sde", "myo_vecnorm_batch_moments", "myo_vecnorm_finish", "myo_rollout_advance", "myo_gae", "myo_lstm_cell_fwd", "myo_lstm_cell_bwd", "myo_lstm_step_supported", "myo_lstm_step_fwd", "myo_lstm_step_bwd", "myo_lstm_seq_supported", "myo_lstm_seq_fwd", "myo_lstm_seq_bwd", "myo_splitk_reduce", "myo_splitk_reduce2", "myo_relu_bwd_colsum_bf16", "myo_adam_clip_step", "myo_ppo_mlp_workspace_bytes", "myo_ppo_mlp_step", "myo_ppo_mlp_sqnorm_parts", "myo_adam_apply", "myo_ppo_mlp_rollout_workspace_bytes", "myo_ppo_mlp_rollout_refresh", "myo_ppo_mlp_rollout", "myo_last_error", "myo_version",
+]
+
+# ... of which the lane-serial emulation build (tests/emu/libmyobatch_emu.so: csrc/myobatch_emu.cpp + csrc/emu_host.h, test tooling) has the env
+# path; the PPO-side kernels exist in the product library only
+ENV_PATH_SYMBOLS = [
+    "myo_batch_bind_constants", "myo_batch_copy_envs", "myo_batch_create", "myo_batch_destroy", "myo_batch_dump_offset", "myo_batch_dump_size",
+    "myo_batch_enable_timing", "myo_batch_forward_dump", "myo_batch_get_state", "myo_batch_get_task", "myo_batch_health", "myo_batch_kernel_ms",
+    "myo_batch_lds_bytes", "myo_batch_num_envs", "myo_batch_object_friction", "myo_batch_obs_dim", "myo_batch_physics_step", "myo_batch_reset",
+    "myo_batch_set_bad_state_buffer", "myo_batch_set_object_group", "myo_batch_set_state", "myo_batch_set_step_generation", "myo_batch_set_task",
+    "myo_batch_step", "myo_batch_step_inner", "myo_batch_step_inner_idx", "myo_batch_tune_wrap_order", "myo_batch_warmstart", "myo_debug_wave_slots",
+    "myo_last_error", "myo_model_destroy", "myo_model_from_blob", "myo_model_load_mjb", "myo_model_size", "myo_version",
 ]
 
 

@@ -85,8 +85,10 @@ def test_library_exports_every_declared_symbol(which, emu_lib):
         if not os.path.exists(path):
             pytest.skip("libmyobatch.so not built in this checkout (run __graft_entry__.build())")
     lib = ctypes.CDLL(path)                   # loading needs libamdhip64 only; no GPU call is made
-    for sym in _declared_functions():
+    # the product exports the whole header; the emulation build (csrc/emu_host.h) the env path, and nothing outside the header
+    for sym in (_declared_functions() if which == "hip" else native.ENV_PATH_SYMBOLS):
         assert hasattr(lib, sym), sym
+    assert set(native.ENV_PATH_SYMBOLS) <= set(_declared_functions())
 
 
 def test_missing_library_fails_loudly(tmp_path):
@@ -109,12 +111,19 @@ def test_task_cfg_struct_matches_header():
     assert names == [f[0] for f in native.TaskCfg._fields_]
 
 
-def test_c_abi_argument_checks(emu_lib):
+@pytest.mark.parametrize("which", ["emu", "hip"])
+def test_c_abi_argument_checks(which, emu_lib):
     """Every entry point validates its arguments before touching a device: NULL handles / pointers and
-    non-positive sizes give MYO_E_ARG (-1) with a message, never a crash.  (The PPO-side kernels have no CPU
-    execution path: with valid arguments the emulation library answers MYO_E_UNSUPPORTED.)"""
+    non-positive sizes give MYO_E_ARG (-1) with a message, never a crash.  Checked on the PRODUCT library (loading it needs
+    libamdhip64 only; an argument error returns before any HIP call) and, for the env path, on the emulation build."""
     import ctypes as C
-    L = emu_lib.L
+    if which == "emu":
+        lib = emu_lib
+    else:
+        if not os.path.exists(native.LIB_PATH):
+            pytest.skip("libmyobatch.so not built in this checkout (run __graft_entry__.build())")
+        lib = native.NativeLib(native.LIB_PATH)
+    L = lib.L
     null = None
     f = C.c_float
     checks = [
@@ -129,33 +138,36 @@ def test_c_abi_argument_checks(emu_lib):
         (L.myo_batch_set_object_group, (null, 0, 1)),
         (L.myo_batch_bind_constants, (null, null)),
         (L.myo_batch_tune_wrap_order, (null, null)),
-        (L.myo_ppo_loss_grad, (null,) * 8 + (16, 39, f(0.2), f(0.5)) + (null,) * 6 + (0, f(0.0)) + (null,) * 4),
-        (L.myo_ppo_gather, (null,) * 6 + (16, 86, 39, null, 2) + (null,) * 7),
-        (L.myo_bias_relu_bf16, (null, null, 2, 16, 256, null)),
-        (L.myo_relu_bwd_colsum_bf16, (null, null, 64, 256, null, null)),
-        (L.myo_splitk_reduce, (null, 1, null, 2, 32, 256, null)),
-        (L.myo_splitk_reduce2, (null, 1, null, 2, 32, 256, null, 0, null, 2, 64, 256, null)),
-        (L.myo_adam_clip_step, (null,) * 4 + (10,) + (f(0.1),) * 6 + (null,) * 4),
-        (L.myo_gae, (null,) * 5 + (4, 4, f(0.99), f(0.95), null, null, null)),
-        (L.myo_rollout_policy_input, (null, 4, 86, null, null, 2, null, null)),
-        (L.myo_rollout_sample, (null, null, null, 4, 39, 1, null, null, null, null, null, null, 0, null)),
-        (L.myo_vecnorm_step, (null,) * 5 + (4, 86) + (null,) * 5 + (0.99, 1e-8, 10.0, 10.0, 1, 1, 1) + (null,) * 9),
-        (L.myo_rollout_advance, (null, 4, null, null)),
-        (L.myo_lstm_cell_fwd, (null,) * 4 + (8, 4, 16, 0) + (null,) * 6),
-        (L.myo_lstm_cell_bwd, (null,) * 7 + (8, 4, 16, 0) + (null,) * 3),
-        (L.myo_lstm_step_fwd, (null, 0, 0) + (null,) * 4 + (2, 16, 32, null, 0) + (null,) * 7),
-        (L.myo_lstm_step_bwd, (null, 0) + (null,) * 7 + (2, 16, 32) + (null,) * 3),
-        (L.myo_lstm_seq_fwd, (null, 0, 0, 0) + (null,) * 4 + (2, 16, 128, 4, 1, null, 0, 0) + (null,) * 4),
-        (L.myo_lstm_seq_bwd, (null, 0, 0) + (null,) * 5 + (2, 16, 128, 4, 1) + (null,) * 2),
     ]
+    if which == "hip":
+        checks += [
+            (L.myo_ppo_loss_grad, (null,) * 8 + (16, 39, f(0.2), f(0.5)) + (null,) * 6 + (0, f(0.0)) + (null,) * 4),
+            (L.myo_ppo_gather, (null,) * 6 + (16, 86, 39, null, 2) + (null,) * 7),
+            (L.myo_bias_relu_bf16, (null, null, 2, 16, 256, null)),
+            (L.myo_relu_bwd_colsum_bf16, (null, null, 64, 256, null, null)),
+            (L.myo_splitk_reduce, (null, 1, null, 2, 32, 256, null)),
+            (L.myo_splitk_reduce2, (null, 1, null, 2, 32, 256, null, 0, null, 2, 64, 256, null)),
+            (L.myo_adam_clip_step, (null,) * 4 + (10,) + (f(0.1),) * 6 + (null,) * 4),
+            (L.myo_gae, (null,) * 5 + (4, 4, f(0.99), f(0.95), null, null, null)),
+            (L.myo_rollout_policy_input, (null, 4, 86, null, null, 2, null, null)),
+            (L.myo_rollout_sample, (null, null, null, 4, 39, 1, null, null, null, null, null, null, 0, null)),
+            (L.myo_vecnorm_step, (null,) * 5 + (4, 86) + (null,) * 5 + (0.99, 1e-8, 10.0, 10.0, 1, 1, 1) + (null,) * 9),
+            (L.myo_rollout_advance, (null, 4, null, null)),
+            (L.myo_lstm_cell_fwd, (null,) * 4 + (8, 4, 16, 0) + (null,) * 6),
+            (L.myo_lstm_cell_bwd, (null,) * 7 + (8, 4, 16, 0) + (null,) * 3),
+            (L.myo_lstm_step_fwd, (null, 0, 0) + (null,) * 4 + (2, 16, 32, null, 0) + (null,) * 7),
+            (L.myo_lstm_step_bwd, (null, 0) + (null,) * 7 + (2, 16, 32) + (null,) * 3),
+            (L.myo_lstm_seq_fwd, (null, 0, 0, 0) + (null,) * 4 + (2, 16, 128, 4, 1, null, 0, 0) + (null,) * 4),
+            (L.myo_lstm_seq_bwd, (null, 0, 0) + (null,) * 5 + (2, 16, 128, 4, 1) + (null,) * 2),
+        ]
     for fn, args in checks:
         rc = fn(*args)
         assert rc == -1, (fn.__name__, rc)
-        assert len(emu_lib.L.myo_last_error()) > 0
+        assert len(L.myo_last_error()) > 0
     assert L.myo_batch_num_envs(null) <= 0 and L.myo_batch_obs_dim(null) <= 0
-    buf = (C.c_float * 64)()
-    assert L.myo_splitk_reduce(buf, 0, buf, 1, 2, 16, None) == -2          # valid arguments, but a GPU kernel
-    assert L.myo_splitk_reduce(buf, 0, buf, 1, 2, 15, None) == -1          # odd n
+    if which == "hip":
+        buf = (C.c_float * 64)()
+        assert L.myo_splitk_reduce(buf, 0, buf, 1, 2, 15, None) == -1          # odd n
 
 
 def test_build_identity_covers_every_included_file():

@@ -1,5 +1,5 @@
-"""CPU-side parity of the KERNEL SOURCE: tests/emu/libmyobatch_emu.so is myobatch.hip compiled
-with -DMYO_EMU (lanes of a phase run serially).  It is test tooling — the product library has no
+"""CPU-side parity of the KERNEL SOURCE: tests/emu/libmyobatch_emu.so is the kernel headers (wave.h, myo_physics.h, myo_task.h)
+compiled with -DMYO_EMU (lanes of a phase run serially) behind csrc/emu_host.h, the lane-serial backend.  It is test tooling — the product library has no
 CPU path — and lets the wave-parallel algorithm be checked against the oracle without a GPU.
 The same cases run on the real HIP kernels in test_gpu_parity.py (-m gpu)."""
 import numpy as np

@@ -47,6 +47,17 @@ typedef double HP;
 #else
 #define PROF(s, k)
 #endif
+// Stage instruction counts: the diagnostic build -DMYO_STAGECOUNT (tools/dev/stage_counts.sh) runs ONE stage of a substep twice — the
+// stage whose bit is set in c_dbg_repeat (MYO_DBG_REPEAT in the environment when the constants are bound) — and the difference of the
+// launch's SQ_INSTS_* counters to a run without a bit is that stage's instruction count.  Only stages that may be repeated (they read what
+// they do not write) carry a REP; the tool checks the state checksum of every pass against the plain run.  The product build contains
+// none of it.
+#if defined(MYO_STAGECOUNT) && !defined(MYO_EMU)
+__constant__ int c_dbg_repeat;
+#define REP(bit, ...) for (int _r = 0, _n = 1 + ((c_dbg_repeat >> (bit)) & 1); _r < _n; ++_r) { __VA_ARGS__; }
+#else
+#define REP(bit, ...) { __VA_ARGS__; }
+#endif
 // Storage of the dense system matrix H: lower triangle, row i padded to the next multiple of four columns
 // (rows 4q..4q+3 hold 4(q+1) entries each), so that a lane still fetches / stores its row with 16-byte
 // accesses: 720 entries for 36 dofs instead of 1296.  myo_hrow(i) = first entry of row i.
@@ -3216,10 +3227,9 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     SYNC();
   }
   // contacts: H += Jp' (R' A R) Jp with A = D sum_active w w'  (3x3 per contact, frame coordinates).
-  // Two-stage per contact, software-pipelined over contacts: while the pairs of contact ci are accumulated,
-  // the (<= 16) lanes of the support set of contact ci+1 already put its Jacobian columns, rotated into the
-  // contact frame and signed, into the other half of a staging buffer — each column is evaluated once per
-  // contact instead of once per pair.  bvec is free here (body vectors are rebuilt after the solve).
+  // Two stages per contact: (A) the (<= 16) lanes of its support set put its Jacobian columns, rotated into the contact frame and
+  // signed, into a staging buffer — each column is evaluated once per contact instead of once per pair; (B) the pair lanes add the
+  // block.  bvec is free here (body vectors are rebuilt after the solve).
   T* stage = s.bvec;                       // 2 x MYO_CS_MAX x 4: the column in frame coordinates and, in the fourth slot, its row of H
   static_assert(2 * MYO_CS_MAX * 4 <= MYO_NB_MAX * 6 && sizeof(T) >= sizeof(int), "staging fits in bvec");
   const int ncon = s.ncon, gen = M.any_gen;
@@ -3239,13 +3249,16 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     }
     LV(pa0) = pk3[0]; LV(pa1) = pk3[1]; LV(pa2) = pk3[2];
   }
-  for (int ci = -1; ci < ncon; ++ci) {
+  // Two contacts a trip: stage A for both at once (lanes 0-15 / 16-31: a support set has at most MYO_CS_MAX = 16 entries), then their
+  // stage B one after the other — H takes the contacts' blocks in index order, as before.
+  static_assert(MYO_CS_MAX <= 16, "two support sets side by side in stage A");
+  for (int c0 = 0; c0 < ncon; c0 += 2) {
     PHASE {
-      // ---- stage A for contact ci+1
-      const int cn = ci + 1;
-      if (cn < ncon && lane < con_nsup(CON(s, cn))) {
+      // ---- stage A for contacts c0, c0 + 1
+      const int half = lane >> 4, sl = lane & 15, cn = c0 + half;
+      if (lane < 32 && cn < ncon && sl < con_nsup(CON(s, cn))) {
         const auto& c = CON(s, cn);
-        const int sd = c.sup[lane];
+        const int sd = c.sup[sl];
         const int d = con_sup_dof(sd), on2 = con_sup_on2(sd), on1 = con_sup_on1(sd);
         T col[3];
         con_col(s, d, on2 ? c.r2 : c.r1, col);
@@ -3261,45 +3274,52 @@ DEV void build_hessian(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
         }
         if (!on2) { j[0] = -j[0]; j[1] = -j[1]; j[2] = -j[2]; }
         if (on1 == on2) { j[0] = 0; j[1] = 0; j[2] = 0; }   // moves both bodies or neither: no relative motion (its pairs add 0)
-        T* dst = stage + (cn & 1) * (MYO_CS_MAX * 4) + 4 * lane;
+        T* dst = stage + half * (MYO_CS_MAX * 4) + 4 * sl;
         dst[0] = j[0]; dst[1] = j[1]; dst[2] = j[2];
         *reinterpret_cast<int*>(dst + 3) = (int)s.hperm[d];   // the dof's row of H: stage B reads it with the column, not through sup -> hperm
       }
-      // ---- stage B for contact ci (its columns were staged in the previous trip)
-      if (ci >= 0) {
-        const auto& c = CON(s, ci);
-        const unsigned char* act = s.efc_active + nlim + 4 * ci;
-        T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
-        if (act[0]) { nn += 1; n1 += c.muA; a11 += c.muA * c.muA; }
-        if (act[1]) { nn += 1; n1 -= c.muA; a11 += c.muA * c.muA; }
-        if (act[2]) { nn += 1; n2 += c.muB; a22 += c.muB * c.muB; }
-        if (act[3]) { nn += 1; n2 -= c.muB; a22 += c.muB * c.muB; }
-        if (nn != 0) {
-          const T cD = CON_D(s, ci);
-          const T A0 = cD * nn, A1 = cD * n1, A2 = cD * n2, A3 = cD * a11, A4 = cD * a22;
-          const int ns = con_nsup(c);
-          const T* jc = stage + (ci & 1) * (MYO_CS_MAX * 4);
-          const int npair = ns * (ns + 1) / 2;
+    }
+    SYNC();
+    // ---- stage B for contacts c0, c0 + 1 (their columns were staged above), one after the other
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const int q = lane + 64 * k;
-            if (q < npair) {
-              const int pk = k == 0 ? LV(pa0) : (k == 1 ? LV(pa1) : LV(pa2));
-              const int a = pk & 255, b = pk >> 8;
-              const T ja[3] = {jc[4 * a], jc[4 * a + 1], jc[4 * a + 2]};
-              const T jb[3] = {jc[4 * b], jc[4 * b + 1], jc[4 * b + 2]};
-              const int pa = *reinterpret_cast<const int*>(jc + 4 * a + 3), pb = *reinterpret_cast<const int*>(jc + 4 * b + 3);
-              const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
-              const T Ajb1 = A1 * jb[0] + A3 * jb[1];
-              const T Ajb2 = A2 * jb[0] + A4 * jb[2];
-              // (an LDS add: the pairs of one contact are distinct entries, contacts follow each other in program order)
-              lds_add(&s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)], ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2);
+    for (int half = 0; half < 2; ++half) {
+      PHASE {
+        const int ci = c0 + half;
+        if (ci < ncon) {
+          const auto& c = CON(s, ci);
+          const unsigned char* act = s.efc_active + nlim + 4 * ci;
+          T nn = 0, n1 = 0, n2 = 0, a11 = 0, a22 = 0;
+          if (act[0]) { nn += 1; n1 += c.muA; a11 += c.muA * c.muA; }
+          if (act[1]) { nn += 1; n1 -= c.muA; a11 += c.muA * c.muA; }
+          if (act[2]) { nn += 1; n2 += c.muB; a22 += c.muB * c.muB; }
+          if (act[3]) { nn += 1; n2 -= c.muB; a22 += c.muB * c.muB; }
+          if (nn != 0) {
+            const T cD = CON_D(s, ci);
+            const T A0 = cD * nn, A1 = cD * n1, A2 = cD * n2, A3 = cD * a11, A4 = cD * a22;
+            const int ns = con_nsup(c);
+            const T* jc = stage + half * (MYO_CS_MAX * 4);
+            const int npair = ns * (ns + 1) / 2;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const int q = lane + 64 * k;
+              if (q < npair) {
+                const int pk = k == 0 ? LV(pa0) : (k == 1 ? LV(pa1) : LV(pa2));
+                const int a = pk & 255, b = pk >> 8;
+                const T ja[3] = {jc[4 * a], jc[4 * a + 1], jc[4 * a + 2]};
+                const T jb[3] = {jc[4 * b], jc[4 * b + 1], jc[4 * b + 2]};
+                const int pa = *reinterpret_cast<const int*>(jc + 4 * a + 3), pb = *reinterpret_cast<const int*>(jc + 4 * b + 3);
+                const T Ajb0 = A0 * jb[0] + A1 * jb[1] + A2 * jb[2];
+                const T Ajb1 = A1 * jb[0] + A3 * jb[1];
+                const T Ajb2 = A2 * jb[0] + A4 * jb[2];
+                // (an LDS add: the pairs of one contact are distinct entries, contacts follow each other in program order)
+                lds_add(&s.H[MYO_HIDX(pa > pb ? pa : pb, pa > pb ? pb : pa)], ja[0] * Ajb0 + ja[1] * Ajb1 + ja[2] * Ajb2);
+              }
             }
           }
         }
       }
+      SYNC();
     }
-    SYNC();
   }
 }
 
@@ -3341,9 +3361,12 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   int iter = 0;
   while (iter < M.iterations) {
     PROF(s, 11)
+    REP(12,      // (the Newton system: H = M + J'DJ, factor, solve; bit 13: load M + the Hessian alone)
+    REP(13,
     load_H_from_M(M, s, (const T*)0, (T)0, 1);
     PROF(s, 25)
     build_hessian(M, s);
+    )
     PROF(s, 9)
 #ifndef MYO_EMU
     if (M.arrow_nf > 0) {
@@ -3355,12 +3378,15 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     } else
 #endif
     chol_factor_solve(s, s.search, nv, (s.ncon == 0 && s.ntl == 0) ? M.nlead : nv);
+    )
     PROF(s, 10)
+    REP(14,      // (M search, body vectors, J search)
     mul_M(M, s, LOFF(s, s.Mv), LOFF(s, s.search));
     PROF(s, 28)
     body_vectors(M, s, LOFF(s, s.search), LOFF(s, s.bvec));
     PROF(s, 29)
     J_times(M, s, LOFF(s, s.search), LOFF(s, s.bvec), LOFF(s, s.efc_jv));
+    )
     PROF(s, 30)
     WAVE_SUM3_N(T, q1, q2, sn2, nv, c, { _e1 = s.search[c] * (s.Ma[c] - s.qfrc_smooth[c]); _e2 = (T)0.5 * s.search[c] * s.Mv[c]; _e3 = s.search[c] * s.search[c]; });
     const T snorm = sqrt(sn2);
@@ -3422,7 +3448,7 @@ DEV void newton_solve(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     }
     SYNC();
     const HP oldcost = cost;
-    cost = update_constraint(M, s);
+    REP(15, cost = update_constraint(M, s);)
     iter++;
     WAVE_SUM3_N(T, gn, qn2, fn, nv, c, { _e1 = s.search[c] * s.search[c]; _e2 = s.qacc[c] * s.qacc[c];
                                          _e3 = s.qfrc_smooth[c] * s.qfrc_smooth[c] + s.qfrc_constraint[c] * s.qfrc_constraint[c] + s.Ma[c] * s.Ma[c]; });
@@ -3449,9 +3475,11 @@ template <typename T, int NC>
 DEV void fwd_acceleration(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_S(T)
   WAVE_FN_K
+  REP(11,
   PHASE { const int c = lane; if (c < M.nv) s.qacc_smooth[c] = s.qfrc_smooth[c]; }
   SYNC();
   solve_M(M, s, s.qacc_smooth, 0);
+  )
   PROF(s, 8)
   if (s.nefc == 0) {
     PHASE {
@@ -3469,23 +3497,27 @@ template <typename T, int NC>
 DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s_in) {
   MYO_BIND_M(T) MYO_BIND_K MYO_BIND_S(T)
   PROF(s, 15)
-  kinematics(M, s);
+  REP(0, kinematics(M, s);)
   PROF(s, 1)
-  com_pos(M, K, s);
+  REP(1, com_pos(M, K, s);)
   PROF(s, 2)
+  REP(2,      // (the whole tendon stage; bit 3: its geom-wrap passes alone)
   tendon(M, K, s);
   PROF(s, 16)
-  for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);
+  REP(3, for (int base = 0; base < M.ngw; base += 64) tendon_wrap_pass(M, K, s, base);)
   PROF(s, 17)
   for (int base = 0; base < M.nte; base += 64) tendon_element_pass(M, K, s, base);
   tendon_length_sums(M, s);
+  )
   PROF(s, 3)
-  crb(M, s);
+  REP(4, crb(M, s);)
   PROF(s, 4)
+  REP(5,      // (limit rows, friction-loss rows, contacts: the constraint set is rebuilt from its counters)
   if (M.any_floss) friction_rows(M, K, s, 0);
   constraint_limits(M, K, s);
   if (M.any_floss) friction_rows(M, K, s, 1);
   PROF(s, 18)
+  REP(6,
   if (M.any_gen) {
     for (int base = 0; base < M.npair_std; base += 64) collision_pass<true>(M, K, s, base);
     for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<true>(M, K, s, base - M.npair_std);
@@ -3494,14 +3526,16 @@ DEV void forward(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
     for (int base = M.npair_std; base < M.npair; base += 64) collision_pass_ext<false>(M, K, s, base - M.npair_std);
   }
   contacts_clamp(K, s);
+  )
+  )
   PROF(s, 5)
-  body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));
+  REP(7, body_vectors(M, s, LOFF(s, S_QVELT(s)), LOFF(s, S_CVEL(s)));)
   PROF(s, 19)
-  fwd_velocity(M, K, s);
+  REP(8, fwd_velocity(M, K, s);)
   PROF(s, 20)
-  efc_reference(M, s);
+  REP(9, efc_reference(M, s);)
   PROF(s, 6)
-  fwd_actuation(M, s);
+  REP(10, fwd_actuation(M, s);)
   PROF(s, 7)
   fwd_acceleration(M, s);
 }
@@ -3655,9 +3689,11 @@ DEV void mj_step(const DevModel<T>& M_in, const TaskDev& K_in, Scratch<T, NC>& s
     advance(M, s, LOFF(s, S_RKDX(s) + 2 * nv), LOFF(s, S_RKDX(s) + nv), LOFF(s, S_RKDX(s)));
   } else if (M.any_damping) {
     // Euler, implicit in joint damping: (M + h diag(b)) qacc' = qfrc_smooth + qfrc_constraint
+    REP(16,
     PHASE { const int c = lane; if (c < M.nv) s.search[c] = s.qfrc_smooth[c] + s.qfrc_constraint[c]; }   // (search: dead after the solver)
     SYNC();
     solve_M(M, s, s.search, 1);
+    )
     PROF(s, 12)
     advance(M, s, LNULL(const T), LOFF(s, s.search), LNULL(const T));
     PROF(s, 13)

@@ -108,6 +108,9 @@ static int bind_constants(myo_batch* b, hipStream_t st) {
   if (b->dtype == MYO_F64) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_d), &b->Md, sizeof b->Md, 0, hipMemcpyHostToDevice, st);
   else e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_model_f), &b->Mf, sizeof b->Mf, 0, hipMemcpyHostToDevice, st);
   if (e == hipSuccess) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_task), &b->K, sizeof b->K, 0, hipMemcpyHostToDevice, st);
+#ifdef MYO_STAGECOUNT
+  { static int rep; const char* r = getenv("MYO_DBG_REPEAT"); rep = r ? atoi(r) : 0; if (e == hipSuccess) e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_dbg_repeat), &rep, sizeof rep, 0, hipMemcpyHostToDevice, st); }
+#endif
   if (e != hipSuccess) return fail(MYO_E_DEVICE, "binding model constants failed: %s", hipGetErrorString(e));
   g.b = b; g.last = st; g.have_last = true;
   return 0;

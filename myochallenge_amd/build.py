@@ -35,11 +35,22 @@ def reachable_includes(entry: str = "myobatch.hip") -> set:
     return seen
 
 
+# Code-generation flags of the product build (part of its identity: source_id() hashes them with the sources).
+# -fno-hip-fp32-correctly-rounded-divide-sqrt: 2.5-ulp fp32 div/sqrt (fewer VALU instructions; the fp64 stepper is unaffected).
+# -mllvm -amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism instead of for occupancy —
+#   occupancy is fixed here (256 VGPRs, 20 KB of LDS: two waves per SIMD whatever the scheduler does).  Same-box A/B, same state
+#   checksums: k_step<double> 2.003 -> 1.979 ms, RK4 6.87 -> 6.83, the fp32 stepper and the die's kernel unchanged
+#   (max-memory-clause +0.3 %, iterative-minreg +9 %, iterative-ilp crashes the compiler).
+HIP_CODEGEN_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
+                     "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+
+
 def source_id() -> str:
-    """Short hash of the native sources: compiled into the library (myo_version()) so that measured records
-    (profiles/*_pmc.json) can be matched to the build they were taken on."""
+    """Short hash of the native sources and the code-generation flags: compiled into the library (myo_version()) so that
+    measured records (profiles/*_pmc.json) can be matched to the build they were taken on."""
     import hashlib
     h = hashlib.sha1()
+    h.update(" ".join(HIP_CODEGEN_FLAGS).encode())
     for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
         h.update(open(f, "rb").read())
     return h.hexdigest()[:12]
@@ -48,6 +59,12 @@ def source_id() -> str:
 def _stale(target: str, extra=()) -> bool:
     if not os.path.exists(target):
         return True
+    if not extra:      # the product library: also stale when it was built from other sources / with other flags than these
+        try:
+            if (" build " + source_id()).encode() not in open(target, "rb").read():
+                return True
+        except OSError:
+            return True
     t = os.path.getmtime(target)
     deps = [os.path.join(CSRC, s) for s in list(SOURCES) + list(extra)] + HEADERS
     return any(os.path.getmtime(d) > t for d in deps)
@@ -59,11 +76,9 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         if not os.path.exists(hipcc):
             hipcc = "hipcc"
-        # -fno-hip-fp32-correctly-rounded-divide-sqrt: 2.5-ulp fp32 div/sqrt (fewer VALU instructions;
-        # the fp64 stepper is unaffected).  Parity tests run against this exact build.
-        cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-               "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-Wno-invalid-offsetof", '-DMYO_BUILD_ID="%s"' % source_id(),
-               os.path.join(CSRC, "myobatch.hip"), "-o", out]
+        # (the parity tests run against this exact build)
+        cmd = [hipcc] + HIP_CODEGEN_FLAGS + ["-fPIC", "-shared", "-Wno-invalid-offsetof", '-DMYO_BUILD_ID="%s"' % source_id(),
+                                             os.path.join(CSRC, "myobatch.hip"), "-o", out]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)

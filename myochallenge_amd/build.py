@@ -37,12 +37,11 @@ def reachable_includes(entry: str = "myobatch.hip") -> set:
 
 # Code-generation flags of the product build (part of its identity: source_id() hashes them with the sources).
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: 2.5-ulp fp32 div/sqrt (fewer VALU instructions; the fp64 stepper is unaffected).
-# -mllvm -amdgpu-sched-strategy=max-ilp: the machine scheduler orders for instruction-level parallelism instead of for occupancy —
-#   occupancy is fixed here (256 VGPRs, 20 KB of LDS: two waves per SIMD whatever the scheduler does).  Same-box A/B, same state
-#   checksums: k_step<double> 2.003 -> 1.979 ms, RK4 6.87 -> 6.83, the fp32 stepper and the die's kernel unchanged
-#   (max-memory-clause +0.3 %, iterative-minreg +9 %, iterative-ilp crashes the compiler).
-HIP_CODEGEN_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt",
-                     "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# (Measured and NOT used: -mllvm -amdgpu-sched-strategy=max-ilp makes k_step<double> 1.2 % faster on one box (2.003 -> 1.979 ms, same
+#  checksums) — and lets leaf functions grow to 248 VGPRs, where their callee-saved registers no longer fit into AGPRs and go to
+#  scratch memory: tendon_wrap_pass saves ten of them per call and the launch's write traffic goes from 48 to 119 MB.
+#  max-memory-clause +0.3 %, iterative-minreg +9 %, -O2 +0.3 %, no post-RA scheduling +0.9 %; iterative-ilp crashes the compiler.)
+HIP_CODEGEN_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 
 
 def source_id() -> str:

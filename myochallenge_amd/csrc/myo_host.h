@@ -1001,6 +1001,8 @@ extern "C" int myo_batch_create(const myo_model* m, const myo_task_cfg* cfg, int
   L.off_qpos = o; o += m->nq; L.off_qvel = o; o += m->nv; L.off_act = o; o += m->na; L.off_warm = o; o += m->nv;
   L.off_time = o; o += 1; L.off_taskd = o; o += MYO_TASKD_N; L.off_balld = o; o += MYO_BALLD_N; L.off_misc = o; o += MYO_MISC_N;
   L.off_objfric = o; o += 3 * MYO_OBJG_MAX;
+  // (store_env writes qpos | qvel | act | warm | time as one run: the order above is part of the kernels' contract)
+  if (L.off_qvel != L.off_qpos + m->nq || L.off_act != L.off_qvel + m->nv || L.off_warm != L.off_act + m->na || L.off_time != L.off_warm + m->nv) { delete b; return fail(MYO_E_STATE, "record layout"); }
   L.stride = (o + 15) / 16 * 16;      // whole 128-byte lines per env: no line is shared by two workgroups
   DumpLayout& D = b->D;
   o = 0;

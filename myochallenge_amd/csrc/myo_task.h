@@ -518,11 +518,21 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
       constexpr int NF = Scratch<T, NC>::OBJG_NF;
       for (int i = lane; i < NF * (K.objg_gidn - K.objg_gid0); i += 64) rec[L.off_objfric + 3 * (i / NF) + i % NF] = (double)S_OBJF(K, s)[i];
     }
-    for (int i = lane; i < M.nq; i += 64) st_pub(rec + L.off_qpos + i, (double)s.qpos[i], wt);
-    for (int i = lane; i < M.nv; i += 64) { st_pub(rec + L.off_qvel + i, (double)s.qvel[i], wt); st_pub(rec + L.off_warm + i, (double)warm_get(s, i), wt); }
-    if constexpr (!Scratch<T, NC>::SPILL) { for (int i = lane; i < M.na; i += 64) st_pub(rec + L.off_act + i, (double)s.act[i], wt); }
+    if constexpr (!Scratch<T, NC>::SPILL) {
+      // qpos | qvel | act | warm start | time are ONE contiguous run of the record (myo_batch_create lays them out so): stored as one,
+      // 64 consecutive doubles an instruction.  A part that hands its record on writes it through (sc1), and every store instruction
+      // of a partial line is a memory-side request of its own: four arrays + five scalars were ~34 requests a hand-off, this is 19.
+      const int n1 = M.nq, n2 = n1 + M.nv, n3 = n2 + M.na, n4 = n3 + M.nv;
+      for (int i = lane; i <= n4; i += 64) {
+        const double v = i < n1 ? (double)s.qpos[i] : (i < n2 ? (double)s.qvel[i - n1] : (i < n3 ? (double)s.act[i - n2] : (i < n4 ? (double)warm_get(s, i - n3) : (double)s.time)));
+        st_pub(rec + L.off_qpos + i, v, wt);
+      }
+    } else {
+      for (int i = lane; i < M.nq; i += 64) st_pub(rec + L.off_qpos + i, (double)s.qpos[i], wt);
+      for (int i = lane; i < M.nv; i += 64) { st_pub(rec + L.off_qvel + i, (double)s.qvel[i], wt); st_pub(rec + L.off_warm + i, (double)warm_get(s, i), wt); }
+      if (lane == 0) st_pub(rec + L.off_time, (double)s.time, wt);
+    }
     if (lane == 0) {
-      st_pub(rec + L.off_time, (double)s.time, wt);
       if (!mid_step) {
         double* bd = rec + L.off_balld;
         if (K.objg_gidn <= 0) {
@@ -531,12 +541,11 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
         }
         bd[8] = (double)s.ball_size[0]; bd[9] = (double)s.ball_size[1];
       }
-      double* mi = rec + L.off_misc;
-      if (!later) {
-        st_pub(mi, (double)s.which_task, wt); st_pub(mi + 1, (double)s.counter, wt); st_pub(mi + 2, (double)s.elapsed, wt); st_pub(mi + 3, (double)s.episode, wt);
-        st_pub(mi + 4, (double)s.ep_ret, wt); st_pub(mi + 5, (double)s.ep_len, wt);
-      }
-      st_pub(mi + 6, mid_step ? (double)s.bad : 0.0, wt);
+    }
+    if (lane < 7 && (lane == 6 || !later)) {      // the task counters, one lane each: one request instead of seven
+      const double v = lane == 0 ? (double)s.which_task : (lane == 1 ? (double)s.counter : (lane == 2 ? (double)s.elapsed : (lane == 3 ? (double)s.episode :
+                       (lane == 4 ? (double)s.ep_ret : (lane == 5 ? (double)s.ep_len : (mid_step ? (double)s.bad : 0.0))))));
+      st_pub(rec + L.off_misc + lane, v, wt);
     }
     if (lane < MYO_TASKD_N && !later) st_pub(rec + L.off_taskd + lane, (double)s.taskd[lane], wt);
   }

@@ -58,10 +58,9 @@ def source_id() -> str:
 def _stale(target: str, extra=()) -> bool:
     if not os.path.exists(target):
         return True
-    if not extra:      # the product library: also stale when it was built from other sources / with other flags than these
+    if not extra:      # the product library carries the hash of the sources and flags it was built from: that, not file times, decides
         try:
-            if (" build " + source_id()).encode() not in open(target, "rb").read():
-                return True
+            return (" build " + source_id()).encode() not in open(target, "rb").read()
         except OSError:
             return True
     t = os.path.getmtime(target)

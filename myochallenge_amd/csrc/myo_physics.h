@@ -198,7 +198,15 @@ template <typename T> struct ScratchPoses {
 // reads coalesce; read back by the tendon-velocity / actuator-moment phases and, for tendon-limit rows only, by the solver
 // big_g (Scratch::SPILL only): the wave slot's block of the BIG workspace (TaskDev::big_ws) — the contact records and the tendon
 // stage's wrap results of the 48-slot fp64 scratch live there (CON / S_TWRES below)
+#ifdef MYO_WARM_LDS      /* diagnostic build: the fp64 stepper's warm start in LDS (280 B: seven workgroups per CU) — is the warm start's trip through global memory what differs between two runs? */
+#ifdef MYO_TENJ_LDS     /* ... and the moment arms (2.5 KB more) */
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; double qacc_warm_[MYO_NV_MAX]; double ten_J_[MYO_NT_MAX * MYO_TJ_MAX]; };
+#else
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; double qacc_warm_[MYO_NV_MAX]; };
+#endif
+#else
 template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; };
+#endif
 /* bytes per wave slot of TaskDev::big_ws: MYO_NCON_BIG contact records, then 7 doubles per geom wrap (MYO_BIGWS_GW of them) */
 #define MYO_BIGWS_GW 96
 #define MYO_BIGWS_WRES (MYO_NCON_BIG * 136)
@@ -364,7 +372,11 @@ static_assert(2 * MYO_NJ_MAX * 3 * sizeof(HP) <= MYO_NCON_MAX * sizeof(ContactRe
 // reads entries it wrote itself (lane i <-> entry i, i + 64, ...), so the global copies need no fence inside a workgroup.
 // moment arm of tendon t with respect to the slot-th dof it moves
 template <typename T, int NC> DEV T tenj_get(const Scratch<T, NC>& s, int t, int slot) {
+#if defined(MYO_TENJ_LDS) && defined(MYO_WARM_LDS)
+  if constexpr (sizeof(T) == sizeof(HP)) return (T)s.ten_J_[slot * MYO_NT_MAX + t]; else return s.ten_J[t * MYO_TJ_MAX + slot];
+#else
   if constexpr (sizeof(T) == sizeof(HP)) return (T)((GPTR(const double))s.tenj_g)[slot * MYO_NT_MAX + t]; else return s.ten_J[t * MYO_TJ_MAX + slot];
+#endif
 }
 // all MYO_TJ_MAX of them (requested together: the fp64 stepper's come from global memory)
 template <typename T, int NC> DEV void tenj_row(const Scratch<T, NC>& s, int t, T* j) {
@@ -377,8 +389,13 @@ static_assert(MYO_NT_MAX * MYO_TJ_MAX <= 3 * (MYO_NLIM_MAX + 4 * MYO_NCON_F64), 
 template <typename T, int NC> DEV T ctrl_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)((GPTR(const double))s.ctrl_g)[i]; else return s.ctrl_[i]; }
 template <typename T, int NC> DEV void ctrl_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) ((GPTR(double))s.ctrl_g)[i] = (double)v; else s.ctrl_[i] = v; }
 // (fp64 stepper: in the wave slot's workspace between load_env and store_env, which copy it from / to the env's record — warm_g)
+#ifdef MYO_WARM_LDS
+template <typename T, int NC> DEV T warm_get(const Scratch<T, NC>& s, int i) { return (T)s.qacc_warm_[i]; }
+template <typename T, int NC> DEV void warm_set(Scratch<T, NC>& s, int i, T v) { s.qacc_warm_[i] = v; }
+#else
 template <typename T, int NC> DEV T warm_get(const Scratch<T, NC>& s, int i) { if constexpr (sizeof(T) == sizeof(HP)) return (T)((GPTR(const double))s.ctrl_g)[MYO_WS_WARM + i]; else return s.qacc_warm_[i]; }
 template <typename T, int NC> DEV void warm_set(Scratch<T, NC>& s, int i, T v) { if constexpr (sizeof(T) == sizeof(HP)) ((GPTR(double))s.ctrl_g)[MYO_WS_WARM + i] = (double)v; else s.qacc_warm_[i] = v; }
+#endif
 #define MYO_NEFC_MIN (MYO_NLIM_MAX + 4 * MYO_NCON_F64)   /* rows of the smallest scratch: every alias of an efc_* array must fit in this many */
 static_assert(2 * MYO_NLIM_MAX <= MYO_NEFC_MIN && 2 * MYO_NV_MAX + MYO_NU_MAX <= MYO_NEFC_MIN && MYO_NJ_MAX * 3 <= MYO_NEFC_MIN && MYO_NB_MAX * 3 <= MYO_NEFC_MIN && 64 <= MYO_NEFC_MIN,
               "efc aliases (S_RKDX, S_XANCHOR / S_XAXIS, S_XIPOS) in the smallest scratch");
@@ -1184,7 +1201,11 @@ DEVFN void tendon_length_sums(const DevModel<T>& M_in, Scratch<T, NC>& s_in) {
     if constexpr (sizeof(T) == sizeof(HP)) {      // the finished moment arms leave LDS: [slot][tendon]
       for (int o = lane; o < MYO_TJ_MAX * MYO_NT_MAX; o += 64) {
         const int slot = o / MYO_NT_MAX, tt = o - slot * MYO_NT_MAX;
+#if defined(MYO_TENJ_LDS) && defined(MYO_WARM_LDS)
+        if (tt < M.ntendon) s.ten_J_[o] = (double)S_TENJ_STAGE(s)[tt * MYO_TJ_MAX + slot];
+#else
         if (tt < M.ntendon) ((GPTR(double))s.tenj_g)[o] = (double)S_TENJ_STAGE(s)[tt * MYO_TJ_MAX + slot];
+#endif
       }
     }
   }
@@ -1410,7 +1431,12 @@ __device__ __noinline__ void chol_factor_solve_reg(int x_r, int n) {
   // and 1.7x SLOWER in fp32 (90 k instead of 54 k): there v_pk_fma_f32 already does two entries per instruction, the
   // column exchange is hidden by software pipelining, and what remains of the blocked version is its serial chain per
   // panel (stage round trip, 10 v_readlane, four dependent rsqrt, 40-cycle MFMA latency) nine times per factorisation.
-  if constexpr (sizeof(T) == 4) {
+#ifdef MYO_CHOL_NO_MFMA      /* diagnostic build: the fp64 factorisation without the matrix cores (the fp32 stepper's register algorithm) */
+  constexpr bool reg_alg = true;
+#else
+  constexpr bool reg_alg = sizeof(T) == 4;
+#endif
+  if constexpr (reg_alg) {
     {
       // row `row` of H (packed, MYO_HIDX): N/4 vectors from the row's first entry; what lies beyond the row's own
       // 4(row/4 + 1) entries belongs to later rows (always inside H) and lands above the diagonal

@@ -523,9 +523,21 @@ DEV void store_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecord
       // 64 consecutive doubles an instruction.  A part that hands its record on writes it through (sc1), and every store instruction
       // of a partial line is a memory-side request of its own: four arrays + five scalars were ~34 requests a hand-off, this is 19.
       const int n1 = M.nq, n2 = n1 + M.nv, n3 = n2 + M.na, n4 = n3 + M.nv;
-      for (int i = lane; i <= n4; i += 64) {
-        const double v = i < n1 ? (double)s.qpos[i] : (i < n2 ? (double)s.qvel[i - n1] : (i < n3 ? (double)s.act[i - n2] : (i < n4 ? (double)warm_get(s, i - n3) : (double)s.time)));
-        st_pub(rec + L.off_qpos + i, v, wt);
+      if constexpr (sizeof(T) == sizeof(HP)) {
+        // fp64 stepper: its warm start is in GLOBAL memory (the wave slot's workspace), written by lane = dof at the end of the substep
+        // just before: only THAT lane may read it back without a drain (wave.h, SYNC_G) — the run stops before it.  (Reading it from
+        // the run's lanes made one 4000-step run in six end in another state: found by tools/dev/soak_repeat.sh.)
+        for (int i = lane; i < n3; i += 64) {
+          const double v = i < n1 ? (double)s.qpos[i] : (i < n2 ? (double)s.qvel[i - n1] : (double)s.act[i - n2]);
+          st_pub(rec + L.off_qpos + i, v, wt);
+        }
+        for (int i = lane; i < M.nv; i += 64) st_pub(rec + L.off_warm + i, (double)warm_get(s, i), wt);
+        if (lane == 0) st_pub(rec + L.off_time, (double)s.time, wt);
+      } else {
+        for (int i = lane; i <= n4; i += 64) {
+          const double v = i < n1 ? (double)s.qpos[i] : (i < n2 ? (double)s.qvel[i - n1] : (i < n3 ? (double)s.act[i - n2] : (i < n4 ? (double)warm_get(s, i - n3) : (double)s.time)));
+          st_pub(rec + L.off_qpos + i, v, wt);
+        }
       }
     } else {
       for (int i = lane; i < M.nq; i += 64) st_pub(rec + L.off_qpos + i, (double)s.qpos[i], wt);

@@ -224,7 +224,17 @@ template <> __device__ __forceinline__ int myo_wave_sum<int>(int v) {
 // instruction that hit the same slot are served in a fixed order by the LDS unit, so the sum is reproducible.
 template <typename T> __device__ __forceinline__ void lds_add(T* p, T v) {
   typedef __attribute__((address_space(3))) T* lds_p;
+#ifdef MYO_LDS_ADD_SERIAL
+  // diagnostic build: the adds of a wave one lane after the other, in lane order (is the order of same-address ds_add_f64 of one instruction fixed?)
+  const unsigned long long act = __ballot(1);
+  for (unsigned long long m = act; m; m &= m - 1) {
+    const int l = __ffsll((long long)m) - 1;
+    if ((int)threadIdx.x == l) *(lds_p)p += v;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+#else
   (void)__hip_atomic_fetch_add((lds_p)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
 }
 __device__ __forceinline__ void myo_count(int* p) { atomicAdd(p, 1); }     // event counter in global memory
 __device__ __forceinline__ void myo_max(int* p, int v) { atomicMax(p, v); }

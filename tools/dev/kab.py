@@ -41,6 +41,9 @@ def child(args):
     rew = torch.zeros(N, dtype=torch.float32, device=dev)
     done = torch.zeros(N, dtype=torch.uint8, device=dev)
     b.reset(None, obs)
+    bad = torch.zeros(N, dtype=torch.uint8, device=dev)
+    bad_total = torch.zeros(N, dtype=torch.int32, device=dev)
+    b.set_bad_state_buffer(bad)
     g = torch.Generator(device="cuda"); g.manual_seed(0)
     acts = [torch.clamp(torch.randn((N, 39), device=dev, generator=g) * 0.135, -1, 1) for _ in range(16)]
     for t in range(args.warm):
@@ -51,13 +54,15 @@ def child(args):
     b.enable_timing(True)
     for t in range(args.steps):
         b.step(acts[t % 16], obs, rew, done)
+        bad_total += bad
     torch.cuda.synchronize()
     ms = b.kernel_ms()
     qp = torch.zeros((N, cm.size("nq")), dtype=torch.float64, device=dev)
     b.get_state(qp)
     torch.cuda.synchronize()
     h = hashlib.sha1(qp.cpu().numpy().tobytes()).hexdigest()[:12]
-    print(json.dumps({"ms": ms, "sum": h, "lds": b.lds_bytes}))
+    nb = int(bad_total.sum().item())
+    print(json.dumps({"ms": ms, "sum": h + ("" if nb == 0 else "+bad%d@%s" % (nb, ",".join(str(int(i)) for i in torch.nonzero(bad_total).flatten()[:4].tolist()))), "lds": b.lds_bytes}))
 
 
 def main():

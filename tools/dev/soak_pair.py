@@ -76,6 +76,8 @@ for t in range(steps):
                 print("   episode step of ALL envs (histogram of 20-step bins):", torch.bincount((cnt // 20).clamp(0, 10), minlength=11).tolist())
                 print("   which_task of differing envs:", sorted(collections.Counter(ti[:, 0].cpu()[es].tolist()).items()), "all:", sorted(collections.Counter(ti[:, 0].cpu().tolist()).items()))
                 print("   env %% 8 of differing envs:", sorted(collections.Counter((es % 8).tolist()).items()))
+                print("   differing envs per 256-env index range:", torch.bincount(es // 256, minlength=16).tolist())
+                print("   differing envs per (env // 8) % 32 (CU-ish):", torch.bincount((es // 8) % 32, minlength=32).tolist())
             found += 1
             if found >= 3:
                 break

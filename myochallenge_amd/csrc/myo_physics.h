@@ -102,7 +102,7 @@ struct TaskDev {  // device copy of myo_task_cfg (ids = -1 when there is no task
   int ro_n_rot_choice[3], ro_obj_bid;
   void* rk_ws;                // RkScratch<T>[n_envs] in global memory (RK4 models), else null
   int objf_off;               // env record: doubles from the warm start to the object group's friction triples (Scratch::SPILL reads them in place)
-  int* slot_map;              // int[MYO_WAVE_SLOTS + 1]: hardware wave-slot code -> dense workspace index, filled on first use (myo_ws_index, wave.h); emulation: null
+  int* slot_map;              // int[MYO_WS_SLOTS]: owner flags of the workspace blocks (myo_ws_acquire / myo_ws_release, wave.h); emulation: null
   char* big_ws;               // char[MYO_WS_SLOTS][MYO_BIGWS_BYTES]: the wave slots' blocks of the 48-slot fp64 scratch (Scratch::SPILL: contact records, wrap results); else null
   double* ctrl_ws;            // double[MYO_WS_SLOTS][MYO_ENVWS_N] in global memory, fp64 stepper: the wave slots' workspaces (one per device, shared by its batches; emulation: one per env)
   int* health;                // int[4] in global memory (myo_batch_health): [0] hand-off states of another generation met by k_step, [1] substeps that dropped contacts beyond the scratch's capacity, [2] substeps that dropped joint / tendon limit or friction-loss rows beyond MYO_NLIM_MAX
@@ -200,12 +200,12 @@ template <typename T> struct ScratchPoses {
 // stage's wrap results of the 48-slot fp64 scratch live there (CON / S_TWRES below)
 #ifdef MYO_WARM_LDS      /* diagnostic build: the fp64 stepper's warm start in LDS (280 B: seven workgroups per CU) — is the warm start's trip through global memory what differs between two runs? */
 #ifdef MYO_TENJ_LDS     /* ... and the moment arms (2.5 KB more) */
-template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; double qacc_warm_[MYO_NV_MAX]; double ten_J_[MYO_NT_MAX * MYO_TJ_MAX]; };
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; int ws_idx; double qacc_warm_[MYO_NV_MAX]; double ten_J_[MYO_NT_MAX * MYO_TJ_MAX]; };
 #else
-template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; double qacc_warm_[MYO_NV_MAX]; };
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; int ws_idx; double qacc_warm_[MYO_NV_MAX]; };
 #endif
 #else
-template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; };
+template <> struct ScratchPoses<double> { double* warm_g; double* ctrl_g; double* tenj_g; char* big_g; int pub; int ws_idx; };
 #endif
 /* bytes per wave slot of TaskDev::big_ws: MYO_NCON_BIG contact records, then 7 doubles per geom wrap (MYO_BIGWS_GW of them) */
 #define MYO_BIGWS_GW 96

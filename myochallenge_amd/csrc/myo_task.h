@@ -468,7 +468,8 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
     // (the workspace of the hardware wave slot this workgroup runs in: myo_wave_slot, wave.h; MYO_WS_* in myo_physics.h)
     PHASE {
       if (lane == 0) {
-        const size_t wsi = (size_t)myo_ws_index(K.slot_map, env, K.health);
+        const size_t wsi = (size_t)myo_ws_acquire(K.slot_map, env, K.health);      // (given back by ws_release when the workgroup leaves the env)
+        s.ws_idx = (int)wsi;
         s.warm_g = rec + L.off_warm; s.ctrl_g = K.ctrl_ws + wsi * MYO_ENVWS_N; s.tenj_g = s.ctrl_g + MYO_NU_MAX;
         if constexpr (Scratch<T, NC>::SPILL) s.big_g = K.big_ws + wsi * MYO_BIGWS_BYTES;      // (contact records, wrap results: CON / S_TWRES)
       }
@@ -503,6 +504,17 @@ DEV void load_env(const DevModel<T>& M_in, const TaskDev& K_in, const EnvRecordL
     }
   }
   SYNC();
+}
+
+// the workspace block load_env took goes back (fp64 stepper; every path that called load_env ends here)
+template <typename T, int NC>
+DEV void ws_release(const TaskDev& K_in, Scratch<T, NC>& s_in) {
+  MYO_BIND_K MYO_BIND_S(T)
+  WAVE_FN_K
+  if constexpr (sizeof(T) == sizeof(HP)) {
+    SYNC_G();      // (every lane's workspace stores are drained before lane 0 lets go)
+    PHASE { if (lane == 0) myo_ws_release(K.slot_map, s.ws_idx); }
+  }
 }
 
 template <typename T, int NC>
@@ -574,7 +586,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
   const int nobs = task_nobs(K, M.na);
   load_env(M, K, L, rec, s, env, pub);
   task_step_core<T, RKM>(M, K, s, act + (size_t)env * M.nu, k_lo, k_hi);
-  if (k_hi >= 0 && k_hi < K.frame_skip) { store_env(M, K, L, rec, s, (s.pub ? 3 : 1) | (k_lo > 0 ? 4 : 0)); return; }
+  if (k_hi >= 0 && k_hi < K.frame_skip) { store_env(M, K, L, rec, s, (s.pub ? 3 : 1) | (k_lo > 0 ? 4 : 0)); ws_release(K, s); return; }
   // A numerically blown-up env (mj_checkPos / mj_checkVel / mj_checkAcc: MuJoCo warns and resets the data) is not
   // an error of the batch: the env ends its episode with done = 1, reward 0, zero reward components except `done`,
   // is reset at once, and both the terminal and the returned observation are the (finite) reset observation, so that
@@ -612,6 +624,7 @@ DEV void env_step(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout&
   }
   SYNC();
   store_env(M, K, L, rec, s);
+  ws_release(K, s);
 }
 
 // env.step(a) of the UNWRAPPED gym env for the envs selected by mask: no TimeLimit / Monitor accounting and
@@ -639,6 +652,7 @@ DEV void env_step_inner(const DevModel<T>& M, const TaskDev& K, const EnvRecordL
   }
   SYNC();
   store_env(M, K, L, rec, s);
+  ws_release(K, s);
 }
 
 template <typename T, int NC>
@@ -653,6 +667,7 @@ DEV void env_reset(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayout
   task_reset(M, K, s, env);
   if (obs) { PHASE { for (int i = lane; i < nobs; i += 64) obs[(size_t)env * nobs + i] = (float)S_OBS(s)[i]; } SYNC(); }
   store_env(M, K, L, rec, s);
+  ws_release(K, s);
 }
 
 template <typename T, int RKM = -1, int NC>
@@ -664,6 +679,7 @@ DEV void env_physics(const DevModel<T>& M, const TaskDev& K, const EnvRecordLayo
   SYNC();
   for (int k = 0; k < nsub; ++k) mj_step<T, RKM>(M, K, s);
   store_env(M, K, L, rec, s);
+  ws_release(K, s);
 }
 
 // forward dynamics with intermediates exported (stage-wise parity tests)
@@ -685,6 +701,7 @@ DEV void env_wrap_census(const DevModel<T>& M, const TaskDev& K, const EnvRecord
       if (wres[7 * k] >= (HP)0) myo_count(cnt + k);
   }
   SYNC();
+  ws_release(K, s);
 }
 
 struct DumpLayout {
@@ -788,4 +805,5 @@ DEV void env_forward_dump(const DevModel<T>& M, const TaskDev& K, const EnvRecor
     }
   }
   SYNC();
+  ws_release(K, s);
 }

@@ -27,10 +27,10 @@ static const char* be_errstr(int e) { return hipGetErrorString((hipError_t)e); }
 struct BoundDev { const myo_batch* b = nullptr; hipStream_t last = nullptr; bool have_last = false; hipEvent_t ev = nullptr; };
 static BoundDev g_bound[MYO_MAX_DEVICES];
 static std::mutex g_bound_mu;
-// The wave slots' workspaces (TaskDev::ctrl_ws, myo_physics.h): MYO_WS_SLOTS x MYO_ENVWS_N doubles (~60 MB) and the map from the hardware
-// slot code to the dense workspace index (myo_ws_index, wave.h) per DEVICE, shared by every fp64 batch on it — a workspace belongs to a
-// hardware wave slot, so kernels of different batches, even on different streams, never meet in one.  Allocated with the first such
-// batch, freed with the last.
+// The workspace blocks (TaskDev::ctrl_ws, myo_physics.h): MYO_WS_SLOTS x MYO_ENVWS_N doubles (~60 MB) and their owner flags
+// (myo_ws_acquire / myo_ws_release, wave.h) per DEVICE, shared by every fp64 batch on it — a workgroup owns a block while it holds an
+// env, so kernels of different batches, even on different streams, never meet in one.  Allocated with the first such batch, freed
+// with the last.
 struct SlotWs { double* p = nullptr; int* map = nullptr; int users = 0; char* big = nullptr; int big_users = 0; };
 static SlotWs g_slot_ws[MYO_MAX_DEVICES];
 static bool slot_workspace_acquire(int device, double** ws, int** map) {
@@ -39,11 +39,10 @@ static bool slot_workspace_acquire(int device, double** ws, int** map) {
   SlotWs& w = g_slot_ws[device];
   if (!w.p) {
     void *q = nullptr, *mp = nullptr;
-    const size_t bytes = sizeof(double) * (size_t)MYO_WS_SLOTS * MYO_ENVWS_N, mbytes = sizeof(int) * ((size_t)MYO_WAVE_SLOTS + 1);
+    const size_t bytes = sizeof(double) * (size_t)MYO_WS_SLOTS * MYO_ENVWS_N, mbytes = sizeof(int) * (size_t)MYO_WS_SLOTS;      // (the blocks' owner flags: 0 = free)
     if (hipMalloc(&q, bytes) != hipSuccess) return false;
     if (hipMalloc(&mp, mbytes) != hipSuccess) { (void)hipFree(q); return false; }
-    if (hipMemset(q, 0, bytes) != hipSuccess || hipMemset(mp, 0xff, mbytes) != hipSuccess ||                       // (map: -1 = not assigned)
-        hipMemset((char*)mp + sizeof(int) * (size_t)MYO_WAVE_SLOTS, 0, sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    if (hipMemset(q, 0, bytes) != hipSuccess || hipMemset(mp, 0, mbytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
       (void)hipFree(q); (void)hipFree(mp);
       return false;
     }

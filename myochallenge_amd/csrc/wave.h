@@ -72,7 +72,8 @@ static inline void myo_max(int* p, int v) { if (v > *p) *p = v; }
 static inline void st_pub(double* p, double v, int wt) { (void)wt; *p = v; }
 #define MYO_WAVE_SLOTS_EMU 0
 static inline unsigned myo_wave_slot(int env) { return (unsigned)env; }      /* the emulation keeps one workspace per env */
-static inline int myo_ws_index(int* map, int env, int* health) { (void)map; (void)health; return env; }
+static inline int myo_ws_acquire(int* owner, int env, int* health) { (void)owner; (void)health; return env; }
+static inline void myo_ws_release(int* owner, int idx) { (void)owner; (void)idx; }
 static inline int myo_popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int myo_ffsll(unsigned long long x) { return __builtin_ctzll(x); }
 #else
@@ -241,28 +242,38 @@ __device__ __forceinline__ void myo_max(int* p, int v) { atomicMax(p, v); }
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
 // The hardware wave slot this wavefront occupies, as an index: (XCC, SE, SH, CU, SIMD, wave buffer) from HW_REG_XCC_ID [3:0] and
 // HW_REG_HW_ID (gfx9 / gfx94x / gfx950 layout: wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13]).
-// Two wavefronts that are resident at the same time never share it, and a slot belongs to one XCD — what k_step's per-slot workspace
-// is built on (TaskDev::ctrl_ws).  Checked on the device by myo_debug_wave_slots (tests/test_step_parts.py, -m gpu).
+// Two wavefronts that are resident at the same time never share it, and a slot belongs to one XCD (checked on the device by
+// myo_debug_wave_slots, tests/test_step_parts.py, -m gpu) — but a wavefront may be moved to another slot mid-kernel: see myo_ws_acquire.
 #define MYO_WAVE_SLOTS (8 * 16384)
 __device__ __forceinline__ unsigned myo_wave_slot(int) {
   const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
   return ((xcc & 7u) << 14) | (((hw >> 8) & 0xffu) << 6) | (hw & 0x3fu);
 }
-// The slot's WORKSPACE index: the 17-bit slot code is sparse (a chip has <= 256 CUs x 4 SIMDs x 10 wave buffers of it), so the device
-// keeps a map code -> dense index, filled on first use (map[MYO_WAVE_SLOTS] is the next free index; a code is only ever looked up by
-// the one wavefront that occupies the slot, so filling it needs no more than the counter's atomic), and the workspaces are sized for
-// MYO_WS_SLOTS dense indices (0.5 GB -> 60 MB a device).  A chip with more live slots than that would share workspaces: counted as a
-// protocol error (health[0]) — never silent.
+// A WORKSPACE block for this workgroup: the block the hardware slot it sits in prefers (a hash of the slot code inside the XCD's range
+// of MYO_WS_SLOTS / 8 blocks — so a slot keeps meeting the same, L2-resident block), taken with a compare-and-swap on its owner flag
+// and given back when the workgroup leaves (myo_ws_release); if the flag is taken, the next free block of the range.  Ownership, not
+// the slot, is what makes the block private: a wavefront does NOT keep its hardware slot for life — the scheduler saves and restores
+// waves mid-kernel (measured on MI355X: of 30 k one-substep launches x 4096 workgroups, 1,517 workgroups ended in another slot than
+// they started in, and 61 found the slot they arrived in still in use) — and round 6's first form, block = f(slot) without a flag, let a
+// restored wave and the slot's next tenant write one block: one k_step launch in ~5,000 left a quarter of its envs in other last
+// bits than the same launch of an identical run (tools/dev/soak_*.py).  An exhausted range (never: 2048 blocks for
+// the <= 512 workgroups an XCD holds) is counted as a protocol error (health[0]).
 #define MYO_WS_SLOTS 16384
-__device__ __forceinline__ int myo_ws_index(int* map, int, int* health) {
+#define MYO_WS_PER_XCD (MYO_WS_SLOTS / 8)
+__device__ __forceinline__ int myo_ws_acquire(int* owner, int, int* health) {
   const unsigned code = myo_wave_slot(0);
-  int id = __hip_atomic_load(map + code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (id < 0) {
-    id = atomicAdd(map + MYO_WAVE_SLOTS, 1);
-    __hip_atomic_store(map + code, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int base = (int)((code >> 14) & 7u) * MYO_WS_PER_XCD;
+  const unsigned pref = ((code & 0x3fffu) * 2654435761u) >> 21;          // 11 bits
+  for (int k = 0; k < MYO_WS_PER_XCD; ++k) {
+    const int idx = base + (int)((pref + (unsigned)k) & (MYO_WS_PER_XCD - 1));
+    if (atomicCAS(owner + idx, 0, 1) == 0) return idx;
   }
-  if (id >= MYO_WS_SLOTS) { if (health) atomicAdd(health, 1); id &= MYO_WS_SLOTS - 1; }
-  return id;
+  if (health) atomicAdd(health, 1);
+  return base + (int)pref;
+}
+__device__ __forceinline__ void myo_ws_release(int* owner, int idx) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this workgroup's stores into the block are in L2 before the next owner's
+  (void)atomicExch(owner + idx, 0);
 }
 __device__ __forceinline__ int myo_popcll(unsigned long long x) { return __popcll(x); }
 __device__ __forceinline__ int myo_ffsll(unsigned long long x) { return __ffsll((long long)x) - 1; }

@@ -31,8 +31,10 @@ offs = sorted((b.dump_offset(n), n) for n in names) + [(D, "end")]
 d1 = torch.zeros((N, D), dtype=torch.float64, device=dev); d2 = torch.zeros((N, D), dtype=torch.float64, device=dev)
 ctrl = torch.full((N, 39), 0.3, dtype=torch.float64, device=dev)
 found = 0
+every = int(os.environ.get("SOAK_STEP_EVERY", "1"))      # one env step every N dump pairs (N > 1: mostly dumps)
 for t in range(steps):
-    b.step(acts[t % 16], obs, rew, done)
+    if t % every == 0:
+        b.step(acts[(t // every) % 16], obs, rew, done)
     b.forward_dump(ctrl, d1)
     b.forward_dump(ctrl, d2)
     ne = (d1 != d2) & ~(torch.isnan(d1) & torch.isnan(d2))

@@ -14,7 +14,7 @@ from myochallenge_amd.synth_hand import synthetic_hand  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 nsub = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 every = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # compare every N launches
-lib = native.load()
+lib = native.load(os.path.abspath(os.environ['SOAK_LIB'])) if os.environ.get('SOAK_LIB') else native.load()
 dev = torch.device("cuda:0")
 N = 4096
 mj = synthetic_hand()
@@ -61,4 +61,5 @@ for t in range(steps):
         found += 1
         if found >= 2:
             break
+print("health (slot check build: [0] slot found occupied, [1] workgroup ended in another slot than it started in, [2] map changed) A", A.health(), "B", B.health())
 print("done: %d steps, %s; NaN envs %d" % (t + 1, "no difference" if not found else "differences above", int(torch.isnan(sa[0]).any(1).sum())))

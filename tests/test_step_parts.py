@@ -141,6 +141,40 @@ def test_wrap_order_changes_no_bit_on_gpu(hip_lib, models, dtype):
 
 
 @pytest.mark.gpu
+def test_workspace_blocks_are_returned_on_gpu(hip_lib, models):
+    """The fp64 stepper's workspace blocks are OWNED by a workgroup while it holds an env (csrc/wave.h: myo_ws_acquire / myo_ws_release)
+    — not implied by the hardware wave slot, which a wavefront does not keep for life.  Every entry point that loads an env must give
+    its block back: 4096 workgroups a launch against 2048 blocks per XCD would exhaust the pool within two launches of a leaking path,
+    and an exhausted pool is counted in health[0]."""
+    import torch
+    cm = compile_model(models["hand"], integrator=0)
+    tc = make_task_cfg("CustomMyoBaodingBallsP2", cm, drop_th=1.3, max_episode_steps=6)
+    n = 4096
+    b = native.Batch(native.Model(cm, hip_lib), tc, n, 0, 3, native.MYO_F64)
+    dev = torch.device("cuda:0")
+    obs = torch.zeros((n, b.obs_dim), dtype=torch.float32, device=dev)
+    rew, done = torch.zeros(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.uint8, device=dev)
+    act = torch.zeros((n, 39), dtype=torch.float32, device=dev)
+    ctrl = torch.full((n, 39), 0.2, dtype=torch.float64, device=dev)
+    dump = torch.zeros((n, b.dump_size), dtype=torch.float64, device=dev)
+    mask = torch.ones(n, dtype=torch.uint8, device=dev)
+    idx = torch.arange(n, dtype=torch.int32, device=dev)
+    b.reset(None, obs)
+    for _ in range(6):
+        b.step(act, obs, rew, done)                       # (the step plan: four workgroups an env)
+        b.step_inner(mask, act, obs, done)
+        b.step_inner_idx(idx, act, obs, done)
+        b.physics_step(ctrl, 2)
+        b.forward_dump(ctrl, dump)
+        b.tune_wrap_order()
+        b.reset(mask, obs)
+    torch.cuda.synchronize()
+    h = b.health()
+    assert h["protocol_errors"] == 0, h
+    b.close()
+
+
+@pytest.mark.gpu
 def test_step_plan_generation_counter_wraps(hip_lib, models):
     """The protocol's state is 16 x generation + part: the counter wraps after 2^28 steps (days of stepping); the arithmetic is
     modulo 2^32 and a rollout that crosses the wrap gives the same bits."""
